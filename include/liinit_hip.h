@@ -1,0 +1,205 @@
+/* liinit_hip.h — C-ABI of the MI355X-native LI-Init hot path (libliinit_hip.so).
+ *
+ * The reference (hku-mars/LiDAR_IMU_Init) has NO plugin / FFI seam: its hot path is inline C++ over
+ * globals in one ROS executable.  This header therefore DEFINES the boundary a
+ * maintainer would bind to; every entry point names the reference code it replaces (file:line relative
+ * to the reference root).  Conventions:
+ *   - plain C, opaque handle, `int` status (0 = LII_OK, negative = error; lii_strerror / lii_last_error);
+ *   - caller-owned host buffers, library-owned device buffers; no exceptions cross the boundary;
+ *   - one handle is used from one host thread; all device work of a handle runs on ONE HIP stream;
+ *   - the library FAILS (LII_ERR_NO_DEVICE) when no gfx950 device is usable — there is no CPU fallback.
+ */
+#ifndef LIINIT_HIP_H
+#define LIINIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LII_ABI_VERSION 1
+
+enum lii_status {
+  LII_OK = 0,
+  LII_ERR_INVALID = -1,   /* bad argument / NULL / size */
+  LII_ERR_NO_DEVICE = -2, /* no HIP device (the library never falls back to the CPU) */
+  LII_ERR_HIP = -3,       /* a HIP runtime call failed; see lii_last_error */
+  LII_ERR_CAPACITY = -4,  /* more points than the handle was created for */
+  LII_ERR_STATE = -5,     /* call order violated (e.g. registration without a map) */
+  LII_ERR_COMM = -6       /* RCCL failure */
+};
+
+typedef struct lii_context* lii_handle;
+
+/* Replaces the file-scope configuration of the reference: NUM_MATCH_POINTS 5 (include/common_lib.h:28),
+ * Nearest_Search max_dist 5 (src/laserMapping.cpp:980), esti_plane threshold 0.1 (:997),
+ * LASER_POINT_COV 0.001 (:59), the fixed 100000-point arrays (:108-109,117-119 — lifted to a capacity). */
+typedef struct lii_config {
+  int32_t struct_size;       /* = sizeof(lii_config) */
+  int32_t device;            /* HIP device ordinal */
+  int32_t max_scan_points;   /* capacity of one (sub-)scan, N */
+  int32_t max_map_points;    /* capacity of the local map, M */
+  float map_cell_size;       /* edge of the device k-NN grid cell [m]; <= 0: 2 x map_downsample_size */
+  float map_downsample_size; /* ikd-Tree downsample box = mapping/filter_size_map (set_downsample_param) */
+  float max_match_dist2;     /* accept neighbours with d^2 <= this (5.0) */
+  float reserved0;
+  double plane_threshold;     /* 0.1 */
+  double laser_point_cov_inv; /* 1000 */
+} lii_config;
+
+/* IMU pose-table record: msg/Pose6D.msg:1-7 as filled by set_pose6d (include/common_lib.h:183-199). */
+typedef struct lii_pose6d {
+  double offset_time; /* [s] from scan start */
+  double acc[3], gyr[3], vel[3], pos[3];
+  double rot[9]; /* row-major */
+} lii_pose6d;
+
+/* StatesGroup (include/common_lib.h:68-169) as POD; rotation matrices row-major; cov 24x24 row-major.
+ * State order: theta, p, theta_LI, T_LI, v, b_g, b_a, g (Appendix B of SURVEY.md). */
+typedef struct lii_state {
+  double rot_end[9];
+  double pos_end[3];
+  double offset_R_L_I[9];
+  double offset_T_L_I[3];
+  double vel_end[3];
+  double bias_g[3];
+  double bias_a[3];
+  double gravity[3];
+  double cov[24 * 24];
+} lii_state;
+
+/* Options of one scan registration — the loop constants of src/laserMapping.cpp:957-1134. */
+typedef struct lii_iekf_opts {
+  int32_t max_iterations; /* NUM_MAX_ITERATIONS (param max_iteration; launch files: 5) */
+  int32_t imu_en;         /* 0: LiDAR-only odometry (H cols 6..11 = 0), 1: LIO with extrinsic in state */
+} lii_iekf_opts;
+
+typedef struct lii_iekf_report {
+  int32_t iterations;    /* executed */
+  int32_t searches;      /* k-NN passes executed (S) */
+  int32_t effect_num;    /* effect_feat_num of the last iteration */
+  int32_t converged;     /* flg_EKF_converged of the last iteration */
+  double normal_eq[91];  /* last iteration: upper 78 of H^T R^-1 H, 12 of H^T R^-1 z, count */
+} lii_iekf_report;
+
+/* ---------------------------------------------------------------- lifecycle */
+int lii_abi_version(void);
+const char* lii_strerror(int status);
+const char* lii_last_error(lii_handle h);
+int lii_device_count(int* count);
+/* Replaces the global KD_TREE / buffers of src/laserMapping.cpp:102-150. */
+int lii_create(const lii_config* cfg, lii_handle* out);
+int lii_destroy(lii_handle h);
+int lii_synchronize(lii_handle h);
+
+/* ---------------------------------------------------------------- local map (device mirror of the ikd-Tree)
+ * lii_map_build      <- ikdtree.Build(feats_down_world->points)           src/laserMapping.cpp:921-931
+ * lii_map_add_points <- ikdtree.Add_Points(PointToAdd, true|false)        src/laserMapping.cpp:556-557,
+ *                       with the per-voxel keep-closest-to-centre semantics of include/ikd-Tree/ikd_Tree.cpp:381-456
+ * lii_map_size       <- ikdtree.validnum()                                src/laserMapping.cpp:933
+ * Points are float xyz with `stride_bytes` between records (12 for packed xyz, 48 for PointXYZINormal). */
+int lii_map_reset(lii_handle h);
+int lii_map_build(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes);
+int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes, int32_t downsample_on,
+                       int32_t* n_added);
+int lii_map_size(lii_handle h, int32_t* n_valid);
+int lii_map_download(lii_handle h, float* xyz_out, int32_t capacity, int32_t* n);
+/* Pushes pending host-side map edits to the device and rebuilds the k-NN grid (done lazily by the
+ * registration calls; exposed so that a caller can keep it out of a timed region). */
+int lii_map_commit(lii_handle h);
+
+/* ---------------------------------------------------------------- scan in / undistortion / down-sampling
+ * lii_scan_upload: host AoS -> device float4 (x,y,z,t_ms).  For pcl::PointXYZINormal use stride 48,
+ *                  time_offset_bytes 36 (`curvature`, include/common_lib.h:37).  Replaces the hand-over of
+ *                  Measures.lidar to ImuProcess::Process (src/laserMapping.cpp:909).
+ * lii_scan_set_device: same, from a device-resident float4 buffer (D2D on the handle's stream).
+ * lii_undistort_imu <- back-propagation loop of ImuProcess::propagation_and_undist, src/IMU_Processing.hpp:390-414
+ * lii_undistort_cv  <- CV de-skew of Forward_propagation_without_imu,            src/IMU_Processing.hpp:246-266
+ * lii_downsample    <- downSizeFilterSurf.filter(*feats_down_body),              src/laserMapping.cpp:917-919
+ * lii_downsample_skip: use the (undistorted) scan as feats_down_body unchanged (PCL's overflow-identity path).
+ * lii_scan_download: which = 0 undistorted scan, 1 down-sampled body points, 2 world points of the last iteration. */
+int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_bytes, int32_t time_offset_bytes);
+int lii_scan_set_device(lii_handle h, const void* dev_float4, int32_t n);
+int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, const double end_R[9],
+                      const double end_p[3], const double R_LI[9], const double T_LI[3]);
+int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], const double end_R[9]);
+int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered);
+int lii_downsample_skip(lii_handle h, int32_t* n_down);
+int lii_scan_download(lii_handle h, int32_t which, float* out_float4, int32_t capacity, int32_t* n);
+
+/* ---------------------------------------------------------------- scan-to-map registration
+ * lii_iekf_iterate: ONE pass of the per-point loop + Jacobian + normal-equation reduction at a fixed state —
+ *   pointBodyToWorld :209-220, Nearest_Search :980, esti_plane :997, residual/selection :987-1011,
+ *   Jacobian rows :1035-1071, H^T R^-1 H / H^T R^-1 z :1073-1080 (src/laserMapping.cpp).
+ *   out91 = upper triangle (78) of the 12x12, then 12, then effect_feat_num.  With a communicator attached
+ *   (lii_comm_init) out91 is the all-reduced sum over ranks.
+ * lii_iekf_update: the whole loop :957-1134 including the 24x24 solve (:1081-1087), convergence / rematch
+ *   logic (:1093-1106) and covariance update (:1109-1131), run on the host around lii_iekf_iterate.
+ * lii_neighbors_download: Nearest_Points of the last search (for map_incremental, :525-549);
+ *   pts = n_down x 5 x 3 floats, counts = n_down. */
+int lii_iekf_iterate(lii_handle h, const lii_state* state, int32_t search, int32_t imu_en, double out91[91]);
+int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_propagated, const lii_iekf_opts* opts,
+                    lii_iekf_report* report);
+int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* selected, int32_t capacity);
+/* map_incremental (src/laserMapping.cpp:516-559): decides PointToAdd / PointNoNeedDownsample from the last
+ * search's neighbour lists and applies both to the map. */
+int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, int32_t* n_no_downsample);
+
+/* ---------------------------------------------------------------- LI-Init batch calibration evaluators
+ * CalibState record (include/LI_init/LI_init.h:31-89). */
+typedef struct lii_calib_state {
+  double rot_end[9];
+  double ang_vel[3];
+  double linear_vel[3];
+  double ang_acc[3];
+  double linear_acc[3];
+  double timestamp;
+} lii_calib_state;
+
+/* Uploads the aligned IMU / LiDAR-odometry state sequences (IMU_state_group / Lidar_state_group). */
+int lii_calib_set_buffers(lii_handle h, const lii_calib_state* imu, const lii_calib_state* lidar, int32_t n);
+/* Residual + analytic Jacobian + J^T J / J^T r / cost for one stage at the given parameters:
+ *  stage 1: Angular_Vel_Cost_only_Rot (LI_init.h:91-117)   params = R_LI[9]                      -> 3 dof
+ *  stage 2: Angular_Vel_Cost          (LI_init.h:119-159)  params = R_LI[9], b_g[3], t_d         -> 7 dof
+ *  stage 3: Linear_acc_Cost           (LI_init.h:161-205)  params = R_GL0[9], b_a[3], T_IL[3], R_LI[9] -> 9 dof
+ * Tangent convention: R <- Exp(delta) R.  JtJ is dof x dof row-major, Jtr is dof, cost = 0.5 sum r^2. */
+int lii_calib_eval(lii_handle h, int32_t stage, const double* params, double* JtJ, double* Jtr, double* cost);
+
+typedef struct lii_calib_result {
+  double R_LI[9];
+  double T_LI[3];
+  double gyro_bias[3];
+  double acc_bias[3];
+  double grav_L0[3];
+  double time_lag_2;
+  int32_t iterations[3];
+  double final_cost[3];
+} lii_calib_result;
+/* solve_Rotation_only / solve_Rot_bias_gyro / solve_trans_biasacc_grav (LI_init.cpp:317-492): the three
+ * least-squares problems, host Levenberg-Marquardt around lii_calib_eval. stage 3 expects the buffers AFTER
+ * the second time compensation + acc_interpolate (caller re-uploads, as LI_Initialization does at :619-623). */
+int lii_calib_solve_stage(lii_handle h, int32_t stage, lii_calib_result* inout);
+
+/* ---------------------------------------------------------------- multi-GPU (points of one scan sharded across ranks)
+ * One process per GPU.  Rank 0 creates an id, the caller ships the 128 bytes to the other ranks (e.g.
+ * torch.distributed broadcast), every rank calls lii_comm_init; afterwards lii_iekf_iterate/update
+ * all-reduce the 91 normal-equation scalars (fp64 sum) over RCCL on the handle's stream. */
+int lii_comm_unique_id(uint8_t id_out[128]);
+int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id[128]);
+int lii_comm_destroy(lii_handle h);
+
+/* ---------------------------------------------------------------- utilities for harnesses */
+int lii_dev_alloc(lii_handle h, size_t bytes, void** dev_ptr);
+int lii_dev_free(lii_handle h, void* dev_ptr);
+int lii_dev_upload(lii_handle h, void* dev_dst, const void* host_src, size_t bytes);
+/* Per-stage device timings of the last lii_iekf_update [ms]: {knn+fit kernels, residual kernels, reduce kernels,
+ * host solve, total}.  Measured with HIP events on the handle's stream when profiling is enabled. */
+int lii_set_profiling(lii_handle h, int32_t enabled);
+int lii_last_timings(lii_handle h, double out_ms[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIINIT_HIP_H */

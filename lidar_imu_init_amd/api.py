@@ -1,0 +1,351 @@
+"""ctypes mirror of include/liinit_hip.h.
+
+`Registrar` wraps one `lii_handle`.  Method names follow the reference's vocabulary
+(src/laserMapping.cpp, src/IMU_Processing.hpp, include/LI_init/LI_init.h) so that tests read like the
+reference's call sites:  map_build ~ ikdtree.Build, map_add_points ~ ikdtree.Add_Points,
+undistort_imu/undistort_cv ~ ImuProcess::Process, downsample ~ downSizeFilterSurf.filter,
+iekf_update ~ the iterated-Kalman loop of main(), map_incremental ~ map_incremental().
+The shared library is mandatory: importing is cheap, but constructing a Registrar raises LIIError when
+libliinit_hip.so is missing or no gfx950 device is usable (there is no CPU fallback by design).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libliinit_hip.so")
+
+STATE_DOUBLES = 36 + 576
+
+
+class LIIError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libliinit_hip error {code}: {msg}")
+        self.code = code
+
+
+class lii_config(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("max_scan_points", C.c_int32),
+                ("max_map_points", C.c_int32), ("map_cell_size", C.c_float), ("map_downsample_size", C.c_float),
+                ("max_match_dist2", C.c_float), ("reserved0", C.c_float), ("plane_threshold", C.c_double),
+                ("laser_point_cov_inv", C.c_double)]
+
+
+class lii_iekf_opts(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("imu_en", C.c_int32)]
+
+
+class lii_iekf_report(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("searches", C.c_int32), ("effect_num", C.c_int32),
+                ("converged", C.c_int32), ("normal_eq", C.c_double * 91)]
+
+
+class lii_calib_result(C.Structure):
+    _fields_ = [("R_LI", C.c_double * 9), ("T_LI", C.c_double * 3), ("gyro_bias", C.c_double * 3),
+                ("acc_bias", C.c_double * 3), ("grav_L0", C.c_double * 3), ("time_lag_2", C.c_double),
+                ("iterations", C.c_int32 * 3), ("final_cost", C.c_double * 3)]
+
+
+_DECLS = {
+    # name: (restype, argtypes)
+    "lii_abi_version": (C.c_int, []),
+    "lii_strerror": (C.c_char_p, [C.c_int]),
+    "lii_last_error": (C.c_char_p, [C.c_void_p]),
+    "lii_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "lii_create": (C.c_int, [C.POINTER(lii_config), C.POINTER(C.c_void_p)]),
+    "lii_destroy": (C.c_int, [C.c_void_p]),
+    "lii_synchronize": (C.c_int, [C.c_void_p]),
+    "lii_map_reset": (C.c_int, [C.c_void_p]),
+    "lii_map_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "lii_map_add_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    "lii_map_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "lii_map_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "lii_map_commit": (C.c_int, [C.c_void_p]),
+    "lii_scan_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "lii_scan_set_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "lii_undistort_imu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 4),
+    "lii_undistort_cv": (C.c_int, [C.c_void_p] + [C.c_void_p] * 3),
+    "lii_downsample": (C.c_int, [C.c_void_p, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lii_downsample_skip": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "lii_scan_download": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "lii_iekf_iterate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "lii_iekf_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(lii_iekf_opts),
+                                  C.POINTER(lii_iekf_report)]),
+    "lii_neighbors_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "lii_map_incremental": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lii_calib_set_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "lii_calib_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "lii_calib_solve_stage": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(lii_calib_result)]),
+    "lii_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "lii_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "lii_comm_destroy": (C.c_int, [C.c_void_p]),
+    "lii_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "lii_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lii_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "lii_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lii_last_timings": (C.c_int, [C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_DECLS)
+_lib = None
+
+
+def library_path() -> str:
+    return _LIB
+
+
+def load_library():
+    """dlopen libliinit_hip.so and declare every C-ABI prototype.  Raises LIIError when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise LIIError(-2, f"{_LIB} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no Python/CPU fallback)")
+        L = C.CDLL(_LIB)
+        for name, (res, args) in _DECLS.items():
+            fn = getattr(L, name)  # AttributeError here = the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class State:
+    """StatesGroup (reference include/common_lib.h:68-169) as the 612-double `lii_state` POD."""
+
+    def __init__(self, pod=None):
+        if pod is None:
+            pod = np.zeros(STATE_DOUBLES)
+            pod[0:9] = np.eye(3).reshape(-1)
+            pod[12:21] = np.eye(3).reshape(-1)
+            cov = np.eye(24)
+            cov[15:, 15:] = np.eye(9) * 0.00001  # INIT_COV, common_lib.h:79-80
+            pod[36:] = cov.reshape(-1)
+        self.pod = np.ascontiguousarray(pod, dtype=np.float64).copy()
+        assert self.pod.shape == (STATE_DOUBLES,)
+
+    def copy(self):
+        return State(self.pod)
+
+    rot_end = property(lambda s: s.pod[0:9].reshape(3, 3))
+    pos_end = property(lambda s: s.pod[9:12])
+    offset_R_L_I = property(lambda s: s.pod[12:21].reshape(3, 3))
+    offset_T_L_I = property(lambda s: s.pod[21:24])
+    vel_end = property(lambda s: s.pod[24:27])
+    bias_g = property(lambda s: s.pod[27:30])
+    bias_a = property(lambda s: s.pod[30:33])
+    gravity = property(lambda s: s.pod[33:36])
+    cov = property(lambda s: s.pod[36:].reshape(24, 24))
+
+
+def pose6d_array(n):
+    """n x 22 doubles: offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9] (msg/Pose6D.msg)."""
+    return np.zeros((n, 22))
+
+
+def calib_state_array(n):
+    """n x 22 doubles: rot_end[9], ang_vel[3], linear_vel[3], ang_acc[3], linear_acc[3], timestamp."""
+    a = np.zeros((n, 22))
+    a[:, 0] = a[:, 4] = a[:, 8] = 1.0
+    return a
+
+
+class Registrar:
+    def __init__(self, max_scan_points=200_000, max_map_points=2_000_000, filter_size_map=0.15, map_cell_size=0.0,
+                 device=0):
+        self.L = load_library()
+        n = C.c_int(0)
+        rc = self.L.lii_device_count(C.byref(n))
+        if rc != 0 or n.value <= 0:
+            raise LIIError(-2, "no HIP device visible — libliinit_hip has no CPU fallback")
+        cfg = lii_config()
+        cfg.struct_size = C.sizeof(lii_config)
+        cfg.device = device
+        cfg.max_scan_points = int(max_scan_points)
+        cfg.max_map_points = int(max_map_points)
+        cfg.map_cell_size = float(map_cell_size)
+        cfg.map_downsample_size = float(filter_size_map)
+        cfg.max_match_dist2 = 5.0
+        cfg.plane_threshold = 0.1
+        cfg.laser_point_cov_inv = 1000.0
+        self.h = C.c_void_p()
+        self._check(self.L.lii_create(C.byref(cfg), C.byref(self.h)), None)
+        self.max_scan_points = int(max_scan_points)
+        self.max_map_points = int(max_map_points)
+        self._dev_bufs = []
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc, h=True):
+        if rc != 0:
+            msg = self.L.lii_last_error(self.h if h else None)
+            raise LIIError(rc, (msg or b"").decode() or self.L.lii_strerror(rc).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            for p in self._dev_bufs:
+                self.L.lii_dev_free(self.h, p)
+            self._dev_bufs = []
+            self.L.lii_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self.L.lii_synchronize(self.h))
+
+    # ------------------------------------------------------------------ local map
+    def map_reset(self):
+        self._check(self.L.lii_map_reset(self.h))
+
+    def map_build(self, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        self._check(self.L.lii_map_build(self.h, _ptr(xyz), len(xyz), xyz.strides[0]))
+
+    def map_add_points(self, xyz, downsample_on: bool) -> int:
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        n = C.c_int32(0)
+        self._check(self.L.lii_map_add_points(self.h, _ptr(xyz), len(xyz), xyz.strides[0] if len(xyz) else 12,
+                                              int(downsample_on), C.byref(n)))
+        return n.value
+
+    def map_size(self) -> int:
+        n = C.c_int32(0)
+        self._check(self.L.lii_map_size(self.h, C.byref(n)))
+        return n.value
+
+    def map_download(self):
+        n = C.c_int32(0)
+        self._check(self.L.lii_map_download(self.h, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), np.float32)
+        self._check(self.L.lii_map_download(self.h, _ptr(out), len(out), C.byref(n)))
+        return out[:n.value]
+
+    def map_commit(self):
+        self._check(self.L.lii_map_commit(self.h))
+
+    # ------------------------------------------------------------------ scan
+    def scan_upload(self, pts):
+        """pts: (n,4) float32 (x,y,z,t_ms) or a structured/2-D array with the 48-byte PointXYZINormal layout (n,12)."""
+        pts = np.ascontiguousarray(pts, np.float32)
+        assert pts.ndim == 2 and pts.shape[1] in (4, 12)
+        toff = 12 if pts.shape[1] == 4 else 36
+        self._check(self.L.lii_scan_upload(self.h, _ptr(pts), len(pts), pts.strides[0] if len(pts) else 16, toff))
+
+    def device_scan(self, pts4):
+        """Copies a float4 scan into a caller-owned device buffer; returns an opaque (ptr, n) for scan_set_device."""
+        pts4 = np.ascontiguousarray(pts4, np.float32)
+        assert pts4.ndim == 2 and pts4.shape[1] == 4
+        p = C.c_void_p()
+        self._check(self.L.lii_dev_alloc(self.h, max(pts4.nbytes, 16), C.byref(p)))
+        self._dev_bufs.append(p)
+        if len(pts4):
+            self._check(self.L.lii_dev_upload(self.h, p, _ptr(pts4), pts4.nbytes))
+        return (p, len(pts4))
+
+    def scan_set_device(self, dev):
+        self._check(self.L.lii_scan_set_device(self.h, dev[0], dev[1]))
+
+    def undistort_imu(self, poses22, end_R, end_p, R_LI, T_LI):
+        poses = np.ascontiguousarray(poses22, np.float64).reshape(-1, 22)
+        a = [np.ascontiguousarray(x, np.float64).reshape(-1) for x in (end_R, end_p, R_LI, T_LI)]
+        self._check(self.L.lii_undistort_imu(self.h, _ptr(poses), len(poses), *[_ptr(x) for x in a]))
+
+    def undistort_cv(self, omega, vel, end_R):
+        a = [np.ascontiguousarray(x, np.float64).reshape(-1) for x in (omega, vel, end_R)]
+        self._check(self.L.lii_undistort_cv(self.h, *[_ptr(x) for x in a]))
+
+    def downsample(self, leaf: float):
+        n, f = C.c_int32(0), C.c_int32(0)
+        self._check(self.L.lii_downsample(self.h, float(leaf), C.byref(n), C.byref(f)))
+        return n.value, bool(f.value)
+
+    def downsample_skip(self) -> int:
+        n = C.c_int32(0)
+        self._check(self.L.lii_downsample_skip(self.h, C.byref(n)))
+        return n.value
+
+    def scan_download(self, which=0):
+        n = C.c_int32(0)
+        self._check(self.L.lii_scan_download(self.h, which, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 4), np.float32)
+        self._check(self.L.lii_scan_download(self.h, which, _ptr(out), len(out), C.byref(n)))
+        return out[:n.value]
+
+    # ------------------------------------------------------------------ registration
+    def iekf_iterate(self, state: State, search: bool, imu_en: bool):
+        out = np.zeros(91)
+        self._check(self.L.lii_iekf_iterate(self.h, _ptr(state.pod), int(search), int(imu_en), _ptr(out)))
+        return out
+
+    def iekf_update(self, state: State, state_prop: State, max_iterations=4, imu_en=False):
+        """Runs the whole iterated update in place on `state`; returns the report dict."""
+        opts = lii_iekf_opts(int(max_iterations), int(imu_en))
+        rep = lii_iekf_report()
+        self._check(self.L.lii_iekf_update(self.h, _ptr(state.pod), _ptr(state_prop.pod), C.byref(opts), C.byref(rep)))
+        return dict(iterations=rep.iterations, searches=rep.searches, effect_num=rep.effect_num,
+                    converged=bool(rep.converged), normal_eq=np.array(rep.normal_eq[:]))
+
+    def neighbors(self, n):
+        pts = np.zeros((n, 5, 3), np.float32)
+        cnt = np.zeros(n, np.int32)
+        sel = np.zeros(n, np.uint8)
+        self._check(self.L.lii_neighbors_download(self.h, _ptr(pts), _ptr(cnt), _ptr(sel), n))
+        return pts, cnt, sel
+
+    def map_incremental(self, state: State):
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._check(self.L.lii_map_incremental(self.h, _ptr(state.pod), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # ------------------------------------------------------------------ calibration
+    def calib_set_buffers(self, imu22, lidar22):
+        imu = np.ascontiguousarray(imu22, np.float64).reshape(-1, 22)
+        lid = np.ascontiguousarray(lidar22, np.float64).reshape(-1, 22)
+        assert len(imu) == len(lid)
+        self._check(self.L.lii_calib_set_buffers(self.h, _ptr(imu), _ptr(lid), len(imu)))
+
+    def calib_eval(self, stage, params):
+        dof = {1: 3, 2: 7, 3: 9}[stage]
+        p = np.ascontiguousarray(params, np.float64).reshape(-1)
+        JtJ, Jtr, cost = np.zeros((dof, dof)), np.zeros(dof), C.c_double(0)
+        self._check(self.L.lii_calib_eval(self.h, stage, _ptr(p), _ptr(JtJ), _ptr(Jtr), C.byref(cost)))
+        return JtJ, Jtr, cost.value
+
+    def calib_solve_stage(self, stage, result=None):
+        res = result if result is not None else lii_calib_result()
+        if result is None:
+            res.R_LI[:] = list(np.eye(3).reshape(-1))
+        self._check(self.L.lii_calib_solve_stage(self.h, stage, C.byref(res)))
+        return res
+
+    # ------------------------------------------------------------------ multi-GPU
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        self._check(self.L.lii_comm_unique_id(buf), None)
+        return bytes(buf)
+
+    def comm_init(self, n_ranks, rank, uid: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._check(self.L.lii_comm_init(self.h, n_ranks, rank, buf))
+
+    def set_profiling(self, enabled: bool):
+        """Turns the HIP-event timing of the registration kernels on/off and zeroes the accumulators."""
+        self._check(self.L.lii_set_profiling(self.h, int(enabled)))
+
+    def timings(self):
+        """[0] sum ms search-pass kernel, [1] sum ms residual-pass kernel, [2] sum ms reduce kernel, [3] host solve ms of
+        the last update, [4] total ms of the last update, [5]/[6] launch counts behind [0]/[1]."""
+        out = np.zeros(8)
+        self._check(self.L.lii_last_timings(self.h, _ptr(out)))
+        return out

@@ -1,0 +1,809 @@
+// libliinit_hip — C-ABI implementation (host side).  Declarations and the reference code each entry point
+// replaces: include/liinit_hip.h.  Device work: lii_kernels.hip / lii_sort.hip on ONE stream per handle.
+// There is deliberately no CPU implementation of any stage here: without a usable gfx950 device
+// lii_create fails with LII_ERR_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/liinit_hip.h"
+#include "lii_hostmap.h"
+#include "lii_hostmath.h"
+#include "lii_launch.h"
+
+using namespace lii;
+
+struct lii_context {
+  lii_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // ---- local map
+  HostVoxelMap hmap;
+  uint64_t committed_version = ~0ull;
+  float4* d_map_unsorted = nullptr;
+  float4* d_map = nullptr;
+  unsigned long long *d_keys_a = nullptr, *d_keys_b = nullptr;
+  unsigned int *d_idx_a = nullptr, *d_idx_b = nullptr;
+  CellEntry* d_fine = nullptr;
+  unsigned long long* d_coarse = nullptr;
+  unsigned int fine_cap = 0, coarse_cap = 0;
+  unsigned int* d_counter = nullptr;
+  int n_map = 0;
+  float cell_size = 0.3f;
+  void* d_sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+
+  // ---- scan
+  float4* d_scan = nullptr;   // raw / undistorted (x,y,z,t_ms)
+  float4* d_body = nullptr;   // down-sampled body points
+  float4* d_world = nullptr;
+  float4* d_nbr = nullptr;    // 5 x cap
+  int* d_nbr_count = nullptr;
+  double* d_plane = nullptr;
+  unsigned char* d_selected = nullptr;
+  double* d_partials = nullptr;
+  double* d_out91 = nullptr;
+  unsigned long long* d_extent = nullptr;
+  unsigned int* d_mm = nullptr;
+  unsigned int *d_vkeys_a = nullptr, *d_vkeys_b = nullptr, *d_vidx_a = nullptr, *d_vidx_b = nullptr, *d_vflags = nullptr,
+               *d_vranks = nullptr;
+  double* d_poses = nullptr;
+  int n_scan = 0, n_body = 0;
+  bool body_is_scan = false;
+  bool have_search = false;
+
+  // ---- pinned staging
+  float4* h_stage = nullptr;     // max(max_scan, max_map) float4
+  size_t h_stage_elems = 0;
+  double* h_small = nullptr;     // 4096 doubles
+
+  // ---- calibration
+  double *d_cal_imu = nullptr, *d_cal_lidar = nullptr, *d_cal_params = nullptr, *d_cal_out = nullptr;
+  int n_cal = 0;
+
+  // ---- comm
+  ncclComm_t comm = nullptr;
+  int n_ranks = 1, rank = 0;
+
+  // ---- profiling
+  bool profiling = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(lii_handle h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(h, call)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = (call);                                                                               \
+    if (e_ != hipSuccess)                                                                                 \
+      return fail(h, LII_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                    \
+  } while (0)
+
+template <class T>
+hipError_t dmalloc(T** p, size_t n) {
+  return hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
+}
+unsigned int next_pow2(unsigned int v) {
+  unsigned int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+GridView grid_view(const lii_context* c) {
+  GridView g;
+  g.pts = c->d_map;
+  g.fine = c->d_fine;
+  g.coarse = c->d_coarse;
+  g.fine_mask = c->fine_cap - 1;
+  g.coarse_mask = c->coarse_cap - 1;
+  g.n_pts = c->n_map;
+  g.cs = c->cell_size;
+  g.inv_cs = 1.0f / c->cell_size;
+  g.max_d2 = c->cfg.max_match_dist2;
+  return g;
+}
+RegistrationBuffers reg_buffers(const lii_context* c) {
+  RegistrationBuffers rb;
+  rb.body = c->d_body;
+  rb.world = c->d_world;
+  rb.nbr = c->d_nbr;
+  rb.nbr_count = c->d_nbr_count;
+  rb.plane = c->d_plane;
+  rb.selected = c->d_selected;
+  rb.partials = c->d_partials;
+  rb.n = c->n_body;
+  rb.cap = c->cfg.max_scan_points;
+  return rb;
+}
+PoseArg pose_of(const lii_state& s) {
+  PoseArg p;
+  std::memcpy(p.R, s.rot_end, 72);
+  std::memcpy(p.p, s.pos_end, 24);
+  std::memcpy(p.RLI, s.offset_R_L_I, 72);
+  std::memcpy(p.TLI, s.offset_T_L_I, 24);
+  return p;
+}
+
+// Rebuilds the device k-NN index from n float4 points already in d_map_unsorted.
+int build_index(lii_handle h, int n) {
+  hipStream_t s = h->stream;
+  h->n_map = n;
+  if (n == 0) {
+    launch_table_clear(h->d_fine, h->fine_cap ? h->fine_cap : 0, h->d_coarse, h->coarse_cap ? h->coarse_cap : 0, s);
+    return LII_OK;
+  }
+  const float inv_cs = 1.0f / h->cell_size;
+  launch_map_keys(h->d_map_unsorted, n, inv_cs, h->d_keys_a, h->d_idx_a, s);
+  sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, n, s);
+  launch_map_gather(h->d_map_unsorted, h->d_idx_b, n, h->d_map, s);
+  HIPCHK(h, hipMemsetAsync(h->d_counter, 0, sizeof(unsigned int), s));
+  launch_cells_count(h->d_keys_b, n, h->d_counter, s);
+  unsigned int n_cells = 0;
+  HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_counter, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  std::memcpy(&n_cells, h->h_small, sizeof(unsigned int));
+  // tables sized to the occupancy (load factor <= 0.5) so that they stay cache-resident
+  unsigned int fcap = next_pow2(std::max(1024u, 2u * n_cells));
+  unsigned int ccap = next_pow2(std::max(1024u, 2u * n_cells));  // coarse cells <= fine cells
+  const unsigned int max_cap = next_pow2(2u * (unsigned)h->cfg.max_map_points);
+  if (fcap > max_cap) fcap = max_cap;
+  if (ccap > max_cap) ccap = max_cap;
+  h->fine_cap = fcap;
+  h->coarse_cap = ccap;
+  launch_table_clear(h->d_fine, fcap, h->d_coarse, ccap, s);
+  launch_cells_insert(h->d_keys_b, n, h->d_fine, fcap - 1, h->d_coarse, ccap - 1, s);
+  HIPCHK(h, hipGetLastError());
+  return LII_OK;
+}
+
+int commit_map(lii_handle h) {
+  if (h->committed_version == h->hmap.version()) return LII_OK;
+  int n = h->hmap.valid();
+  if (n > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "local map exceeds max_map_points");
+  int k = h->hmap.export_float4(reinterpret_cast<float*>(h->h_stage));
+  (void)k;
+  if (n > 0)
+    HIPCHK(h, hipMemcpyAsync(h->d_map_unsorted, h->h_stage, sizeof(float4) * size_t(n), hipMemcpyHostToDevice, h->stream));
+  int rc = build_index(h, n);
+  if (rc != LII_OK) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // h_stage is reused by other calls
+  h->committed_version = h->hmap.version();
+  return LII_OK;
+}
+
+int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double* out91) {
+  if (h->n_body <= 0) return fail(h, LII_ERR_STATE, "no down-sampled scan (call lii_downsample / lii_downsample_skip)");
+  int rc = commit_map(h);
+  if (rc != LII_OK) return rc;
+  if (!search && !h->have_search) return fail(h, LII_ERR_STATE, "non-search iteration before any search");
+  GridView g = grid_view(h);
+  RegistrationBuffers rb = reg_buffers(h);
+  const bool prof = h->profiling;
+  if (prof) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  launch_register(search, g, rb, pose_of(*st), imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, h->stream);
+  if (prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  launch_reduce91(rb.partials, rb.n, h->d_out91, h->stream);
+  if (prof) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+  if (search) h->have_search = true;
+  if (h->comm) {
+    ncclResult_t r = ncclAllReduce(h->d_out91, h->d_out91, kNormalEq, ncclDouble, ncclSum, h->comm, h->stream);
+    if (r != ncclSuccess) return fail(h, LII_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+  }
+  HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_out91, sizeof(double) * kNormalEq, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  std::memcpy(out91, h->h_small, sizeof(double) * kNormalEq);
+  if (prof) {
+    // timings: [0] sum ms search-pass kernel, [1] sum ms residual-pass kernel, [2] sum ms reduce kernel,
+    //          [3] host solve ms (last update), [4] total ms (last update), [5]/[6] launch counts of [0]/[1]
+    float a = 0, b = 0;
+    HIPCHK(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    if (search) { h->timings[0] += a; h->timings[5] += 1; } else { h->timings[1] += a; h->timings[6] += 1; }
+    h->timings[2] += b;
+  }
+  return LII_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lii_abi_version(void) { return LII_ABI_VERSION; }
+
+const char* lii_strerror(int status) {
+  switch (status) {
+    case LII_OK: return "ok";
+    case LII_ERR_INVALID: return "invalid argument";
+    case LII_ERR_NO_DEVICE: return "no usable HIP device (libliinit_hip has no CPU fallback)";
+    case LII_ERR_HIP: return "HIP runtime error";
+    case LII_ERR_CAPACITY: return "capacity exceeded";
+    case LII_ERR_STATE: return "call order violated";
+    case LII_ERR_COMM: return "RCCL error";
+    default: return "unknown status";
+  }
+}
+const char* lii_last_error(lii_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int lii_device_count(int* count) {
+  if (!count) return LII_ERR_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(nullptr, LII_ERR_NO_DEVICE, hipGetErrorString(e)); }
+  *count = n;
+  return LII_OK;
+}
+
+int lii_create(const lii_config* cfg, lii_handle* out) {
+  if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(lii_config)) return fail(nullptr, LII_ERR_INVALID, "bad lii_config");
+  if (cfg->max_scan_points <= 0 || cfg->max_map_points <= 0) return fail(nullptr, LII_ERR_INVALID, "capacities must be > 0");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, LII_ERR_NO_DEVICE, "no HIP device visible; libliinit_hip has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, LII_ERR_INVALID, "device ordinal out of range");
+  lii_handle h = new lii_context;
+  h->cfg = *cfg;
+  if (h->cfg.max_match_dist2 <= 0) h->cfg.max_match_dist2 = 5.0f;
+  if (h->cfg.plane_threshold <= 0) h->cfg.plane_threshold = 0.1;
+  if (h->cfg.laser_point_cov_inv <= 0) h->cfg.laser_point_cov_inv = 1000.0;
+  if (h->cfg.map_downsample_size <= 0) h->cfg.map_downsample_size = 0.2f;
+  h->cell_size = cfg->map_cell_size > 0 ? cfg->map_cell_size : 2.0f * h->cfg.map_downsample_size;
+  h->hmap.set_downsample(h->cfg.map_downsample_size);
+  h->hmap.clear();
+  h->device = cfg->device;
+#define CK(call)                                                                  \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      int rc_ = fail(nullptr, LII_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+      lii_destroy(h);                                                             \
+      return rc_;                                                                 \
+    }                                                                             \
+  } while (0)
+  CK(hipSetDevice(h->device));
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, h->device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+    int rc = fail(nullptr, LII_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    lii_destroy(h);
+    return rc;
+  }
+  CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const size_t N = size_t(cfg->max_scan_points), M = size_t(cfg->max_map_points);
+  const size_t NM = std::max(N, M);
+  CK(dmalloc(&h->d_map_unsorted, M));
+  CK(dmalloc(&h->d_map, M));
+  CK(dmalloc(&h->d_keys_a, M));
+  CK(dmalloc(&h->d_keys_b, M));
+  CK(dmalloc(&h->d_idx_a, M));
+  CK(dmalloc(&h->d_idx_b, M));
+  const unsigned int max_cap = next_pow2(2u * (unsigned)M);
+  CK(dmalloc(&h->d_fine, size_t(max_cap)));
+  CK(dmalloc(&h->d_coarse, size_t(max_cap)));
+  h->fine_cap = h->coarse_cap = 1024;
+  CK(dmalloc(&h->d_counter, 4));
+  h->sort_temp_bytes = sort_temp_bytes(int(NM));
+  CK(hipMalloc(&h->d_sort_temp, h->sort_temp_bytes));
+  CK(dmalloc(&h->d_scan, N));
+  CK(dmalloc(&h->d_body, N));
+  CK(dmalloc(&h->d_world, N));
+  CK(dmalloc(&h->d_nbr, N * kMatch));
+  CK(dmalloc(&h->d_nbr_count, N));
+  CK(dmalloc(&h->d_plane, N * 4));
+  CK(dmalloc(&h->d_selected, N));
+  CK(dmalloc(&h->d_partials, size_t(register_blocks(int(N)) + 1) * kNormalEq));
+  CK(dmalloc(&h->d_out91, 128));
+  CK(dmalloc(&h->d_extent, 2));
+  CK(dmalloc(&h->d_mm, 8));
+  CK(dmalloc(&h->d_vkeys_a, N));
+  CK(dmalloc(&h->d_vkeys_b, N));
+  CK(dmalloc(&h->d_vidx_a, N));
+  CK(dmalloc(&h->d_vidx_b, N));
+  CK(dmalloc(&h->d_vflags, N));
+  CK(dmalloc(&h->d_vranks, N));
+  CK(dmalloc(&h->d_poses, 22 * 1024));
+  CK(dmalloc(&h->d_cal_params, 64));
+  CK(dmalloc(&h->d_cal_out, 128));
+  h->h_stage_elems = NM * kMatch;  // large enough for the neighbour download too
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), sizeof(float4) * h->h_stage_elems, hipHostMallocDefault));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_small), sizeof(double) * 32768, hipHostMallocDefault));
+  for (int i = 0; i < 4; i++) CK(hipEventCreate(&h->ev[i]));
+  launch_table_clear(h->d_fine, h->fine_cap, h->d_coarse, h->coarse_cap, h->stream);
+  CK(hipStreamSynchronize(h->stream));
+#undef CK
+  *out = h;
+  return LII_OK;
+}
+
+int lii_destroy(lii_handle h) {
+  if (!h) return LII_OK;
+  (void)hipSetDevice(h->device);
+  if (h->comm) ncclCommDestroy(h->comm);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, h->d_fine, h->d_coarse,
+                 h->d_counter, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
+                 h->d_selected, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
+                 h->d_vidx_b, h->d_vflags, h->d_vranks, h->d_poses, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
+                 h->d_cal_out};
+  for (void* p : dev)
+    if (p) (void)hipFree(p);
+  if (h->h_stage) (void)hipHostFree(h->h_stage);
+  if (h->h_small) (void)hipHostFree(h->h_small);
+  for (int i = 0; i < 4; i++)
+    if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return LII_OK;
+}
+
+int lii_synchronize(lii_handle h) {
+  if (!h) return LII_ERR_INVALID;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return LII_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ map
+int lii_map_reset(lii_handle h) {
+  if (!h) return LII_ERR_INVALID;
+  h->hmap.clear();
+  h->have_search = false;
+  return LII_OK;
+}
+int lii_map_build(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes) {
+  if (!h || (!xyz && n > 0) || n < 0 || stride_bytes < 12 || stride_bytes % 4) return fail(h, LII_ERR_INVALID, "lii_map_build: bad arguments");
+  if (n > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "lii_map_build: n > max_map_points");
+  h->hmap.build(static_cast<const float*>(xyz), n, stride_bytes / 4);
+  h->have_search = false;
+  return LII_OK;
+}
+int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes, int32_t downsample_on, int32_t* n_added) {
+  if (!h || (!xyz && n > 0) || n < 0 || stride_bytes < 12 || stride_bytes % 4) return fail(h, LII_ERR_INVALID, "lii_map_add_points: bad arguments");
+  int c = h->hmap.add_points(static_cast<const float*>(xyz), n, stride_bytes / 4, downsample_on != 0);
+  if (n_added) *n_added = c;
+  if (h->hmap.valid() > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "local map exceeds max_map_points");
+  return LII_OK;
+}
+int lii_map_size(lii_handle h, int32_t* n_valid) {
+  if (!h || !n_valid) return LII_ERR_INVALID;
+  *n_valid = h->hmap.valid();
+  return LII_OK;
+}
+int lii_map_download(lii_handle h, float* xyz_out, int32_t capacity, int32_t* n) {
+  if (!h || !n) return LII_ERR_INVALID;
+  int cnt = h->hmap.valid();
+  *n = cnt;
+  if (!xyz_out) return LII_OK;
+  if (capacity < cnt) return fail(h, LII_ERR_CAPACITY, "lii_map_download: capacity too small");
+  std::vector<float> tmp(size_t(cnt) * 4);
+  h->hmap.export_float4(tmp.data());
+  for (int i = 0; i < cnt; i++) {
+    xyz_out[3 * size_t(i)] = tmp[4 * size_t(i)];
+    xyz_out[3 * size_t(i) + 1] = tmp[4 * size_t(i) + 1];
+    xyz_out[3 * size_t(i) + 2] = tmp[4 * size_t(i) + 2];
+  }
+  return LII_OK;
+}
+int lii_map_commit(lii_handle h) {
+  if (!h) return LII_ERR_INVALID;
+  return commit_map(h);
+}
+
+// ------------------------------------------------------------------------------------------------ scan
+int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_bytes, int32_t time_offset_bytes) {
+  if (!h || (!points && n > 0) || n < 0 || stride_bytes < 16 || time_offset_bytes < 12 || time_offset_bytes + 4 > stride_bytes)
+    return fail(h, LII_ERR_INVALID, "lii_scan_upload: bad arguments");
+  if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_upload: n > max_scan_points");
+  const char* src = static_cast<const char*>(points);
+  for (int i = 0; i < n; i++) {
+    const float* f = reinterpret_cast<const float*>(src + size_t(i) * stride_bytes);
+    float t;
+    std::memcpy(&t, src + size_t(i) * stride_bytes + time_offset_bytes, 4);
+    h->h_stage[i] = make_float4(f[0], f[1], f[2], t);
+  }
+  if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scan, h->h_stage, sizeof(float4) * size_t(n), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->n_scan = n;
+  h->n_body = 0;
+  h->have_search = false;
+  return LII_OK;
+}
+int lii_scan_set_device(lii_handle h, const void* dev_float4, int32_t n) {
+  if (!h || (!dev_float4 && n > 0) || n < 0) return fail(h, LII_ERR_INVALID, "lii_scan_set_device: bad arguments");
+  if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_set_device: n > max_scan_points");
+  if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scan, dev_float4, sizeof(float4) * size_t(n), hipMemcpyDeviceToDevice, h->stream));
+  h->n_scan = n;
+  h->n_body = 0;
+  h->have_search = false;
+  return LII_OK;
+}
+int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, const double end_R[9], const double end_p[3],
+                      const double R_LI[9], const double T_LI[3]) {
+  if (!h || !poses || n_poses < 1 || n_poses > 1024 || !end_R || !end_p || !R_LI || !T_LI)
+    return fail(h, LII_ERR_INVALID, "lii_undistort_imu: bad arguments");
+  static_assert(sizeof(lii_pose6d) == 22 * sizeof(double), "lii_pose6d layout");
+  if (h->n_scan <= 0 || n_poses < 2) return LII_OK;  // nothing to compensate (IMUpose needs a head and a tail)
+  std::memcpy(h->h_small, poses, sizeof(lii_pose6d) * size_t(n_poses));
+  HIPCHK(h, hipMemcpyAsync(h->d_poses, h->h_small, sizeof(lii_pose6d) * size_t(n_poses), hipMemcpyHostToDevice, h->stream));
+  UndistArgH u;
+  std::memcpy(u.endR, end_R, 72);
+  std::memcpy(u.endp, end_p, 24);
+  std::memcpy(u.RLI, R_LI, 72);
+  std::memcpy(u.TLI, T_LI, 24);
+  launch_time_extent(h->d_scan, h->n_scan, h->d_extent, h->stream);
+  launch_undistort_imu(h->d_scan, h->n_scan, h->d_poses, n_poses, u, h->d_extent, h->stream);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // h_small is reused
+  return LII_OK;
+}
+int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], const double end_R[9]) {
+  if (!h || !omega || !vel || !end_R) return fail(h, LII_ERR_INVALID, "lii_undistort_cv: bad arguments");
+  if (h->n_scan <= 0) return LII_OK;
+  CvArgH a;
+  std::memcpy(a.omega, omega, 24);
+  std::memcpy(a.vel, vel, 24);
+  std::memcpy(a.endR, end_R, 72);
+  launch_time_extent(h->d_scan, h->n_scan, h->d_extent, h->stream);
+  launch_undistort_cv(h->d_scan, h->n_scan, a, h->d_extent, h->stream);
+  HIPCHK(h, hipGetLastError());
+  return LII_OK;
+}
+int lii_downsample_skip(lii_handle h, int32_t* n_down) {
+  if (!h) return LII_ERR_INVALID;
+  if (h->n_scan > 0)
+    HIPCHK(h, hipMemcpyAsync(h->d_body, h->d_scan, sizeof(float4) * size_t(h->n_scan), hipMemcpyDeviceToDevice, h->stream));
+  h->n_body = h->n_scan;
+  h->have_search = false;
+  if (n_down) *n_down = h->n_body;
+  return LII_OK;
+}
+int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered) {
+  if (!h || !(leaf > 0)) return fail(h, LII_ERR_INVALID, "lii_downsample: bad arguments");
+  h->have_search = false;
+  const int n = h->n_scan;
+  if (n <= 0) {
+    h->n_body = 0;
+    if (n_down) *n_down = 0;
+    if (filtered) *filtered = 1;
+    return LII_OK;
+  }
+  hipStream_t s = h->stream;
+  launch_voxel_minmax(h->d_scan, n, h->d_mm, s);
+  HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_mm, 6 * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  unsigned int mm[6];
+  std::memcpy(mm, h->h_small, sizeof(mm));
+  if (mm[0] == 0xFFFFFFFFu) {  // no finite point at all
+    h->n_body = 0;
+    if (n_down) *n_down = 0;
+    if (filtered) *filtered = 1;
+    return LII_OK;
+  }
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; a++) { mn[a] = ord_to_float(mm[a]); mx[a] = ord_to_float(mm[3 + a]); }
+  const float inv = 1.0f / leaf;
+  // PCL's index-overflow guard: (dx*dy*dz) > INT32_MAX  ->  output = input
+  int64_t dx = int64_t((mx[0] - mn[0]) * inv) + 1, dy = int64_t((mx[1] - mn[1]) * inv) + 1, dz = int64_t((mx[2] - mn[2]) * inv) + 1;
+  if (dx * dy * dz > int64_t(2147483647)) {
+    int rc = lii_downsample_skip(h, n_down);
+    if (filtered) *filtered = 0;
+    return rc;
+  }
+  VoxelArgH v;
+  v.inv_leaf = inv;
+  int div_b[3];
+  for (int a = 0; a < 3; a++) {
+    v.min_b[a] = int(std::floor(mn[a] * inv));
+    int max_b = int(std::floor(mx[a] * inv));
+    div_b[a] = max_b - v.min_b[a] + 1;
+  }
+  v.mul[0] = 1; v.mul[1] = div_b[0]; v.mul[2] = div_b[0] * div_b[1];
+  launch_voxel_keys(h->d_scan, n, v, h->d_vkeys_a, h->d_vidx_a, s);
+  sort_pairs_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a, h->d_vidx_b, n, s);
+  launch_voxel_flags(h->d_vkeys_b, n, h->d_vflags, s);
+  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_vflags, h->d_vranks, n, s);
+  launch_voxel_centroid(h->d_scan, h->d_vkeys_b, h->d_vidx_b, h->d_vflags, h->d_vranks, n, h->d_body, s);
+  HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_vranks + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  unsigned int nd;
+  std::memcpy(&nd, h->h_small, 4);
+  h->n_body = int(nd);
+  if (n_down) *n_down = h->n_body;
+  if (filtered) *filtered = 1;
+  return LII_OK;
+}
+int lii_scan_download(lii_handle h, int32_t which, float* out_float4, int32_t capacity, int32_t* n) {
+  if (!h || !n) return LII_ERR_INVALID;
+  const float4* src = which == 0 ? h->d_scan : (which == 1 ? h->d_body : h->d_world);
+  int cnt = which == 0 ? h->n_scan : h->n_body;
+  *n = cnt;
+  if (!out_float4) return LII_OK;
+  if (capacity < cnt) return fail(h, LII_ERR_CAPACITY, "lii_scan_download: capacity too small");
+  if (cnt > 0) {
+    HIPCHK(h, hipMemcpyAsync(h->h_stage, src, sizeof(float4) * size_t(cnt), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::memcpy(out_float4, h->h_stage, sizeof(float4) * size_t(cnt));
+  }
+  return LII_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ registration
+int lii_iekf_iterate(lii_handle h, const lii_state* state, int32_t search, int32_t imu_en, double out91[91]) {
+  if (!h || !state || !out91) return fail(h, LII_ERR_INVALID, "lii_iekf_iterate: bad arguments");
+  return iterate(h, state, search != 0, imu_en != 0, out91);
+}
+
+int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_prop, const lii_iekf_opts* opts,
+                    lii_iekf_report* report) {
+  if (!h || !state || !state_prop || !opts || opts->max_iterations < 1) return fail(h, LII_ERR_INVALID, "lii_iekf_update: bad arguments");
+  const int max_it = opts->max_iterations;
+  auto t_begin = std::chrono::steady_clock::now();
+  double host_ms = 0;
+  // cov is constant inside the loop (it is only rewritten on exit, :1112-1114), so invert it once
+  std::vector<double> Pinv(kDim * kDim), A(kDim * kDim), K1(kDim * kDim), KH(kDim * 12), G(kDim * kDim);
+  if (!mat_inverse(state->cov, kDim, Pinv.data())) return fail(h, LII_ERR_INVALID, "state covariance is singular");
+  int rematch_num = 0;
+  bool search = true, stop = false, converged = false;
+  int it = 0, searches = 0;
+  double ne[kNormalEq];
+  for (it = 0; it < max_it; it++) {
+    int rc = iterate(h, state, search, opts->imu_en != 0, ne);
+    if (rc != LII_OK) return rc;
+    if (search) searches++;
+    auto t0 = std::chrono::steady_clock::now();
+    // H_T_H (+) P^-1  (:1080-1081)
+    A = Pinv;
+    double HTH[12][12];
+    int t = 0;
+    for (int i = 0; i < 12; i++)
+      for (int j = i; j < 12; j++) { HTH[i][j] = ne[t]; HTH[j][i] = ne[t]; t++; }
+    for (int i = 0; i < 12; i++)
+      for (int j = 0; j < 12; j++) A[size_t(i) * kDim + j] += HTH[i][j];
+    if (!mat_inverse(A.data(), kDim, K1.data())) return fail(h, LII_ERR_INVALID, "normal matrix is singular");
+    double vec[kDim], sol[kDim];
+    state_minus(*state_prop, *state, vec);
+    for (int r = 0; r < kDim; r++) {
+      double kz = 0;
+      for (int c = 0; c < 12; c++) kz += K1[size_t(r) * kDim + c] * ne[78 + c];
+      double khv = 0;
+      for (int c = 0; c < 12; c++) {
+        double s = 0;
+        for (int k = 0; k < 12; k++) s += K1[size_t(r) * kDim + k] * HTH[k][c];
+        KH[size_t(r) * 12 + c] = s;
+        khv += s * vec[c];
+      }
+      sol[r] = kz + vec[r] - khv;
+    }
+    state_plus(*state, sol);
+    double rn = std::sqrt(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
+    double tn = std::sqrt(sol[3] * sol[3] + sol[4] * sol[4] + sol[5] * sol[5]);
+    converged = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
+    search = false;
+    if (converged || ((rematch_num == 0) && (it == (max_it - 2)))) {
+      search = true;
+      rematch_num++;
+    }
+    if (!stop && (rematch_num >= 2 || (it == max_it - 1))) {
+      // state.cov = (I - G) cov, G[:, :12] = K H   (:1111-1114)
+      std::vector<double> newcov(kDim * kDim);
+      for (int r = 0; r < kDim; r++)
+        for (int c = 0; c < kDim; c++) {
+          double s = state->cov[size_t(r) * kDim + c];
+          for (int k = 0; k < 12; k++) s -= KH[size_t(r) * 12 + k] * state->cov[size_t(k) * kDim + c];
+          newcov[size_t(r) * kDim + c] = s;
+        }
+      std::memcpy(state->cov, newcov.data(), sizeof(double) * kDim * kDim);
+      stop = true;
+    }
+    host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (stop) { it++; break; }
+  }
+  if (report) {
+    report->iterations = it;
+    report->searches = searches;
+    report->effect_num = int(ne[90]);
+    report->converged = converged ? 1 : 0;
+    std::memcpy(report->normal_eq, ne, sizeof(ne));
+  }
+  h->timings[3] = host_ms;
+  h->timings[4] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  return LII_OK;
+}
+
+int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* selected, int32_t capacity) {
+  if (!h) return LII_ERR_INVALID;
+  const int n = h->n_body;
+  if (capacity < n) return fail(h, LII_ERR_CAPACITY, "lii_neighbors_download: capacity too small");
+  if (n == 0) return LII_OK;
+  const size_t cap = size_t(h->cfg.max_scan_points);
+  hipStream_t s = h->stream;
+  if (pts) {
+    for (int k = 0; k < kMatch; k++)
+      HIPCHK(h, hipMemcpyAsync(h->h_stage + size_t(k) * n, h->d_nbr + size_t(k) * cap, sizeof(float4) * size_t(n), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    for (int i = 0; i < n; i++)
+      for (int k = 0; k < kMatch; k++) {
+        const float4 v = h->h_stage[size_t(k) * n + i];
+        float* o = pts + (size_t(i) * kMatch + k) * 3;
+        o[0] = v.x; o[1] = v.y; o[2] = v.z;
+      }
+  }
+  if (counts) {
+    HIPCHK(h, hipMemcpyAsync(h->h_stage, h->d_nbr_count, sizeof(int) * size_t(n), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    std::memcpy(counts, h->h_stage, sizeof(int) * size_t(n));
+  }
+  if (selected) {
+    HIPCHK(h, hipMemcpyAsync(h->h_stage, h->d_selected, size_t(n), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    std::memcpy(selected, h->h_stage, size_t(n));
+  }
+  return LII_OK;
+}
+
+int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, int32_t* n_no_downsample) {
+  if (!h || !state) return fail(h, LII_ERR_INVALID, "lii_map_incremental: bad arguments");
+  const int n = h->n_body;
+  if (n <= 0) { if (n_add) *n_add = 0; if (n_no_downsample) *n_no_downsample = 0; return LII_OK; }
+  // body points + neighbour lists of the last search come back to the host (this row is "next" in the
+  // scope table: the decision below is host code exactly like the reference's)
+  std::vector<float> body(size_t(n) * 4), near(size_t(n) * kMatch * 3);
+  std::vector<int32_t> cnt(n, 0);
+  int32_t got = 0;
+  int rc = lii_scan_download(h, 1, body.data(), n, &got);
+  if (rc != LII_OK) return rc;
+  if (h->have_search) {
+    rc = lii_neighbors_download(h, near.data(), cnt.data(), nullptr, n);
+    if (rc != LII_OK) return rc;
+  }
+  const double fsd = double(h->cfg.map_downsample_size);
+  std::vector<float> to_add, no_down;
+  for (int i = 0; i < n; i++) {
+    const double b[3] = {body[4 * size_t(i)], body[4 * size_t(i) + 1], body[4 * size_t(i) + 2]};
+    double q[3], w[3];
+    m3_vec(state->offset_R_L_I, b, q);
+    for (int a = 0; a < 3; a++) q[a] += state->offset_T_L_I[a];
+    m3_vec(state->rot_end, q, w);
+    float pw[3];
+    for (int a = 0; a < 3; a++) pw[a] = float(w[a] + state->pos_end[a]);
+    if (cnt[i] > 0) {
+      const float* nb = &near[size_t(i) * kMatch * 3];
+      float mid[3];
+      for (int a = 0; a < 3; a++) mid[a] = float(std::floor(pw[a] / fsd) * fsd + 0.5 * fsd);
+      float dist = (pw[0] - mid[0]) * (pw[0] - mid[0]) + (pw[1] - mid[1]) * (pw[1] - mid[1]) + (pw[2] - mid[2]) * (pw[2] - mid[2]);
+      if (std::fabs(nb[0] - mid[0]) > 0.5 * fsd && std::fabs(nb[1] - mid[1]) > 0.5 * fsd && std::fabs(nb[2] - mid[2]) > 0.5 * fsd) {
+        no_down.insert(no_down.end(), pw, pw + 3);
+        continue;
+      }
+      bool need_add = true;
+      for (int k = 0; k < kMatch; k++) {
+        if (cnt[i] < kMatch) break;
+        float dk = (nb[3 * k] - mid[0]) * (nb[3 * k] - mid[0]) + (nb[3 * k + 1] - mid[1]) * (nb[3 * k + 1] - mid[1]) +
+                   (nb[3 * k + 2] - mid[2]) * (nb[3 * k + 2] - mid[2]);
+        if (dk < dist) { need_add = false; break; }
+      }
+      if (need_add) to_add.insert(to_add.end(), pw, pw + 3);
+    } else {
+      to_add.insert(to_add.end(), pw, pw + 3);
+    }
+  }
+  h->hmap.add_points(to_add.data(), int(to_add.size() / 3), 3, true);
+  h->hmap.add_points(no_down.data(), int(no_down.size() / 3), 3, false);
+  if (n_add) *n_add = int(to_add.size() / 3);
+  if (n_no_downsample) *n_no_downsample = int(no_down.size() / 3);
+  if (h->hmap.valid() > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "local map exceeds max_map_points");
+  return LII_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ calibration
+int lii_calib_set_buffers(lii_handle h, const lii_calib_state* imu, const lii_calib_state* lidar, int32_t n) {
+  if (!h || !imu || !lidar || n <= 0) return fail(h, LII_ERR_INVALID, "lii_calib_set_buffers: bad arguments");
+  static_assert(sizeof(lii_calib_state) == 22 * sizeof(double), "lii_calib_state layout");
+  if (n > h->n_cal || !h->d_cal_imu) {
+    if (h->d_cal_imu) (void)hipFree(h->d_cal_imu);
+    if (h->d_cal_lidar) (void)hipFree(h->d_cal_lidar);
+    h->d_cal_imu = h->d_cal_lidar = nullptr;
+    HIPCHK(h, dmalloc(&h->d_cal_imu, size_t(n) * 22));
+    HIPCHK(h, dmalloc(&h->d_cal_lidar, size_t(n) * 22));
+  }
+  HIPCHK(h, hipMemcpyAsync(h->d_cal_imu, imu, sizeof(lii_calib_state) * size_t(n), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_cal_lidar, lidar, sizeof(lii_calib_state) * size_t(n), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->n_cal = n;
+  return LII_OK;
+}
+
+int lii_calib_eval(lii_handle h, int32_t stage, const double* params, double* JtJ, double* Jtr, double* cost) {
+  if (!h || !params || stage < 1 || stage > 3) return fail(h, LII_ERR_INVALID, "lii_calib_eval: bad arguments");
+  if (h->n_cal <= 0) return fail(h, LII_ERR_STATE, "lii_calib_eval: no buffers uploaded");
+  const int np = stage == 1 ? 9 : (stage == 2 ? 13 : 24);
+  const int dof = stage == 1 ? 3 : (stage == 2 ? 7 : 9);
+  std::memcpy(h->h_small, params, sizeof(double) * np);
+  HIPCHK(h, hipMemcpyAsync(h->d_cal_params, h->h_small, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
+  launch_calib_eval(stage, h->d_cal_imu, h->d_cal_lidar, h->n_cal, h->d_cal_params, h->d_cal_out, h->stream);
+  const int n_out = dof * dof + dof + 1;
+  HIPCHK(h, hipMemcpyAsync(h->h_small + 64, h->d_cal_out, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const double* o = h->h_small + 64;
+  if (JtJ) std::memcpy(JtJ, o, sizeof(double) * dof * dof);
+  if (Jtr) std::memcpy(Jtr, o + dof * dof, sizeof(double) * dof);
+  if (cost) *cost = o[dof * dof + dof];
+  return LII_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ multi-GPU
+int lii_comm_unique_id(uint8_t id_out[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  if (!id_out) return LII_ERR_INVALID;
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return fail(nullptr, LII_ERR_COMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+  std::memcpy(id_out, &id, 128);
+  return LII_OK;
+}
+int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128]) {
+  if (!h || !id_in || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(h, LII_ERR_INVALID, "lii_comm_init: bad arguments");
+  if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
+  h->n_ranks = n_ranks;
+  h->rank = rank;
+  if (n_ranks == 1) return LII_OK;
+  ncclUniqueId id;
+  std::memcpy(&id, id_in, 128);
+  HIPCHK(h, hipSetDevice(h->device));
+  ncclResult_t r = ncclCommInitRank(&h->comm, n_ranks, id, rank);
+  if (r != ncclSuccess) { h->comm = nullptr; return fail(h, LII_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+  return LII_OK;
+}
+int lii_comm_destroy(lii_handle h) {
+  if (!h) return LII_ERR_INVALID;
+  if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
+  h->n_ranks = 1;
+  h->rank = 0;
+  return LII_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ utilities
+int lii_dev_alloc(lii_handle h, size_t bytes, void** dev_ptr) {
+  if (!h || !dev_ptr) return LII_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMalloc(dev_ptr, bytes));
+  return LII_OK;
+}
+int lii_dev_free(lii_handle h, void* dev_ptr) {
+  if (!h) return LII_ERR_INVALID;
+  HIPCHK(h, hipFree(dev_ptr));
+  return LII_OK;
+}
+int lii_dev_upload(lii_handle h, void* dev_dst, const void* host_src, size_t bytes) {
+  if (!h || !dev_dst || !host_src) return LII_ERR_INVALID;
+  HIPCHK(h, hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+  return LII_OK;
+}
+int lii_set_profiling(lii_handle h, int32_t enabled) {
+  if (!h) return LII_ERR_INVALID;
+  h->profiling = enabled != 0;
+  for (double& t : h->timings) t = 0;  // (re)starts the accumulation
+  return LII_OK;
+}
+int lii_last_timings(lii_handle h, double out_ms[8]) {
+  if (!h || !out_ms) return LII_ERR_INVALID;
+  std::memcpy(out_ms, h->timings, sizeof(h->timings));
+  return LII_OK;
+}
+
+}  // extern "C"

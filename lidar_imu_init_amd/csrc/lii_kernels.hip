@@ -1,0 +1,992 @@
+// HIP kernels of the LI-Init hot path for gfx950 (CDNA4, wave64).  Hand-written; no MFMA (the path is
+// gather + per-point small algebra + a low-rank reduction, HBM/L2-bound — DESIGN.md §3).
+//
+// Kernels and the reference code they replace (paths relative to the reference root):
+//   k_map_keys / k_map_gather / k_cells_* ... device mirror of the ikd-Tree point set as a cell-sorted
+//                                             array + hash grid (include/ikd-Tree/ikd_Tree.cpp:336-347)
+//   k_register<SEARCH> ...................... src/laserMapping.cpp:964-1012 (transform, Nearest_Search,
+//                                             esti_plane, residual/selection) fused with :1035-1071
+//                                             (Jacobian rows) and :1073-1080 (H^T R^-1 H, H^T R^-1 z)
+//   k_reduce91 .............................. deterministic final sum of the per-block partials
+//   k_time_extent / k_undistort_imu / _cv ... src/IMU_Processing.hpp:390-414 and :246-266
+//   k_voxel_* ............................... pcl::VoxelGrid::filter call site src/laserMapping.cpp:917-919
+//   k_calib_eval ............................ include/LI_init/LI_init.h:91-205 residuals + analytic Jacobians
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <cstring>
+#include <math.h>
+#include <stdint.h>
+
+#include "lii_device.h"
+
+namespace lii {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+__device__ __forceinline__ unsigned long long pack_cell(int cx, int cy, int cz) {
+  return ((unsigned long long)(unsigned)(cz + kCellBias) << 42) | ((unsigned long long)(unsigned)(cy + kCellBias) << 21) |
+         (unsigned long long)(unsigned)(cx + kCellBias);
+}
+__device__ __forceinline__ unsigned int hash_key(unsigned long long k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (unsigned int)k;
+}
+__device__ __forceinline__ int cell_of(float v, float inv_cs) { return (int)floorf(v * inv_cs); }
+
+// Squared distance with the reference's float32 evaluation order and NO fused multiply-add
+// (KD_TREE::calc_dist, include/ikd-Tree/ikd_Tree.cpp:1273-1277, compiled without FMA contraction).
+__device__ __forceinline__ float dist2_ref(float qx, float qy, float qz, float px, float py, float pz) {
+  float dx = __fsub_rn(qx, px), dy = __fsub_rn(qy, py), dz = __fsub_rn(qz, pz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ------------------------------------------------------------------------------------------------
+// map index construction
+__global__ void k_map_keys(const float4* __restrict__ pts, int n, float inv_cs, unsigned long long* __restrict__ keys,
+                           unsigned int* __restrict__ idx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  keys[i] = pack_cell(cell_of(p.x, inv_cs), cell_of(p.y, inv_cs), cell_of(p.z, inv_cs));
+  idx[i] = (unsigned)i;
+}
+
+__global__ void k_map_gather(const float4* __restrict__ src, const unsigned int* __restrict__ idx, int n,
+                             float4* __restrict__ dst) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  dst[i] = src[idx[i]];
+}
+
+// counts the distinct cells (one per run of equal keys)
+__global__ void k_cells_count(const unsigned long long* __restrict__ keys, int n, unsigned int* __restrict__ n_cells) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool start = (i < n) && (i == 0 || keys[i] != keys[i - 1]);
+  unsigned long long m = __ballot(start);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_cells, (unsigned)__popcll(m));
+}
+
+__global__ void k_table_clear(CellEntry* fine, unsigned int fine_cap, unsigned long long* coarse, unsigned int coarse_cap) {
+  unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < fine_cap) {
+    CellEntry e;
+    e.key = kEmptyKey;
+    e.start = 0;
+    e.end = 0;
+    fine[i] = e;
+  }
+  if (i < coarse_cap) coarse[i] = kEmptyKey;
+}
+
+__device__ __forceinline__ unsigned long long coarse_of_packed(unsigned long long key) {
+  // fields are biased by 2^20 (a multiple of 8), so a plain shift of each field is floor(c / 8) + bias/8
+  unsigned long long cx = (key & 0x1FFFFF) >> kCoarseShift;
+  unsigned long long cy = ((key >> 21) & 0x1FFFFF) >> kCoarseShift;
+  unsigned long long cz = ((key >> 42) & 0x1FFFFF) >> kCoarseShift;
+  return (cz << 42) | (cy << 21) | cx;
+}
+
+__global__ void k_cells_insert(const unsigned long long* __restrict__ keys, int n, CellEntry* fine, unsigned int fine_mask,
+                               unsigned long long* coarse, unsigned int coarse_mask) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long key = keys[i];
+  bool is_start = (i == 0) || (keys[i - 1] != key);
+  bool is_end = (i == n - 1) || (keys[i + 1] != key);
+  if (!is_start && !is_end) return;
+  // claim / find the slot of this cell; start and end are written by (possibly) different threads
+  unsigned int slot = hash_key(key) & fine_mask;
+  while (true) {
+    unsigned long long prev = atomicCAS(&fine[slot].key, kEmptyKey, key);
+    if (prev == kEmptyKey || prev == key) break;
+    slot = (slot + 1) & fine_mask;
+  }
+  if (is_start) fine[slot].start = (unsigned)i;
+  if (is_end) fine[slot].end = (unsigned)(i + 1);
+  if (is_start) {
+    unsigned long long ck = coarse_of_packed(key);
+    unsigned int cs = hash_key(ck) & coarse_mask;
+    while (true) {
+      unsigned long long prev = atomicCAS(&coarse[cs], kEmptyKey, ck);
+      if (prev == kEmptyKey || prev == ck) break;
+      cs = (cs + 1) & coarse_mask;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact 5-NN with d2 <= max_d2 (KD_TREE::Nearest_Search semantics, quirk A5)
+struct Knn5 {
+  float d0, d1, d2, d3, d4;
+  int i0, i1, i2, i3, i4;
+};
+
+__device__ __forceinline__ void knn_insert(Knn5& k, float d, int j) {
+  // strict '<' keeps the earlier-visited candidate on exact ties (ikd_Tree.cpp:842)
+  k.d4 = d; k.i4 = j;
+  if (k.d4 < k.d3) { float t = k.d3; k.d3 = k.d4; k.d4 = t; int u = k.i3; k.i3 = k.i4; k.i4 = u; } else return;
+  if (k.d3 < k.d2) { float t = k.d2; k.d2 = k.d3; k.d3 = t; int u = k.i2; k.i2 = k.i3; k.i3 = u; } else return;
+  if (k.d2 < k.d1) { float t = k.d1; k.d1 = k.d2; k.d2 = t; int u = k.i1; k.i1 = k.i2; k.i2 = u; } else return;
+  if (k.d1 < k.d0) { float t = k.d0; k.d0 = k.d1; k.d1 = t; int u = k.i0; k.i0 = k.i1; k.i1 = u; }
+}
+
+__device__ __forceinline__ float axis_gap(float q, int c, float cs, float eps) {
+  float lo = (float)c * cs - eps, hi = (float)(c + 1) * cs + eps;
+  float g = fmaxf(fmaxf(lo - q, q - hi), 0.f);
+  return g;
+}
+
+__device__ __forceinline__ void scan_cell(const GridView& g, int ix, int iy, int iz, float qx, float qy, float qz, Knn5& k) {
+  unsigned long long key = pack_cell(ix, iy, iz);
+  unsigned int slot = hash_key(key) & g.fine_mask;
+  while (true) {
+    CellEntry e = g.fine[slot];
+    if (e.key == key) {
+      for (unsigned int j = e.start; j < e.end; j++) {
+        float4 p = g.pts[j];
+        float d = dist2_ref(qx, qy, qz, p.x, p.y, p.z);
+        if (d <= g.max_d2 && d < k.d4) knn_insert(k, d, (int)j);
+      }
+      return;
+    }
+    if (e.key == kEmptyKey) return;
+    slot = (slot + 1) & g.fine_mask;
+  }
+}
+
+__device__ __forceinline__ bool coarse_present(const GridView& g, int X, int Y, int Z) {
+  // coarse coordinates are floor(c/8); rebuild the same packed form as coarse_of_packed
+  unsigned long long ck = ((unsigned long long)(unsigned)(Z + (kCellBias >> kCoarseShift)) << 42) |
+                          ((unsigned long long)(unsigned)(Y + (kCellBias >> kCoarseShift)) << 21) |
+                          (unsigned long long)(unsigned)(X + (kCellBias >> kCoarseShift));
+  unsigned int slot = hash_key(ck) & g.coarse_mask;
+  while (true) {
+    unsigned long long e = g.coarse[slot];
+    if (e == ck) return true;
+    if (e == kEmptyKey) return false;
+    slot = (slot + 1) & g.coarse_mask;
+  }
+}
+
+__device__ __forceinline__ void knn5_search(const GridView& g, float qx, float qy, float qz, Knn5& k) {
+  const float INF = __builtin_inff();
+  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = INF;
+  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
+  if (g.n_pts <= 0) return;
+  // slack for every geometric cell-bound test: float rounding of c*cs and of p*inv_cs grows with |coordinate|
+  const float cs = g.cs, eps = 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + 8.f);
+  const int cx = cell_of(qx, g.inv_cs), cy = cell_of(qy, g.inv_cs), cz = cell_of(qz, g.inv_cs);
+  // phase 1: the 3x3x3 block around the query's cell, own cell first; cells farther than the current
+  // 5th-best distance are skipped without a table probe (same pruning rule as the tree's calc_box_dist)
+  scan_cell(g, cx, cy, cz, qx, qy, qz, k);
+  for (int dz = -1; dz <= 1; dz++) {
+    float gz = axis_gap(qz, cz + dz, cs, eps);
+    for (int dy = -1; dy <= 1; dy++) {
+      float gy = axis_gap(qy, cy + dy, cs, eps);
+      for (int dx = -1; dx <= 1; dx++) {
+        if (dx == 0 && dy == 0 && dz == 0) continue;
+        float gx = axis_gap(qx, cx + dx, cs, eps);
+        float bd = gx * gx + gy * gy + gz * gz;
+        float bound = fminf(k.d4, g.max_d2);
+        if (bd > bound) continue;
+        scan_cell(g, cx + dx, cy + dy, cz + dz, qx, qy, qz, k);
+      }
+    }
+  }
+  // guaranteed radius of phase 1: distance from q to the faces of the 3x3x3 block
+  float fx = qx - (float)cx * cs, fy = qy - (float)cy * cs, fz = qz - (float)cz * cs;
+  float m1 = fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz));
+  m1 = cs + fmaxf(m1, 0.f) - 2.f * eps;
+  float bound = fminf(k.d4, g.max_d2);
+  if (bound <= m1 * m1) return;
+  // phase 2 (rare: sparse map / map frontier): every remaining cell that intersects the ball of radius
+  // sqrt(bound), found through the coarse occupancy table so that empty space costs no fine probes
+  float r = sqrtf(bound) + 2.f * eps;
+  int ix0 = cell_of(qx - r, g.inv_cs), ix1 = cell_of(qx + r, g.inv_cs);
+  int iy0 = cell_of(qy - r, g.inv_cs), iy1 = cell_of(qy + r, g.inv_cs);
+  int iz0 = cell_of(qz - r, g.inv_cs), iz1 = cell_of(qz + r, g.inv_cs);
+  const float ccs = cs * (float)(1 << kCoarseShift);
+  for (int Z = iz0 >> kCoarseShift; Z <= (iz1 >> kCoarseShift); Z++) {
+    float Gz = axis_gap(qz, Z, ccs, eps);
+    for (int Y = iy0 >> kCoarseShift; Y <= (iy1 >> kCoarseShift); Y++) {
+      float Gy = axis_gap(qy, Y, ccs, eps);
+      for (int X = ix0 >> kCoarseShift; X <= (ix1 >> kCoarseShift); X++) {
+        float Gx = axis_gap(qx, X, ccs, eps);
+        if (Gx * Gx + Gy * Gy + Gz * Gz > fminf(k.d4, g.max_d2)) continue;
+        if (!coarse_present(g, X, Y, Z)) continue;
+        int zl = max(iz0, Z * 8), zh = min(iz1, Z * 8 + 7);
+        int yl = max(iy0, Y * 8), yh = min(iy1, Y * 8 + 7);
+        int xl = max(ix0, X * 8), xh = min(ix1, X * 8 + 7);
+        for (int iz = zl; iz <= zh; iz++) {
+          float gz = axis_gap(qz, iz, cs, eps);
+          for (int iy = yl; iy <= yh; iy++) {
+            float gy = axis_gap(qy, iy, cs, eps);
+            for (int ix = xl; ix <= xh; ix++) {
+              if (abs(ix - cx) <= 1 && abs(iy - cy) <= 1 && abs(iz - cz) <= 1) continue;  // phase 1 did it
+              float gx = axis_gap(qx, ix, cs, eps);
+              if (gx * gx + gy * gy + gz * gz > fminf(k.d4, g.max_d2)) continue;
+              scan_cell(g, ix, iy, iz, qx, qy, qz, k);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// esti_plane<double> (include/common_lib.h:236-269): 5x3 least squares A n = -1 by column-pivoted
+// Householder QR — Eigen's ColPivHouseholderQR algorithm (Eigen >= 3.3.4, third-party, restated from
+// its published structure: max-norm column pivoting with LAPACK-WN-176 norm down-dating, reflectors,
+// solve over nonzeroPivots).  Double precision, contraction off (see Makefile) to track the CPU path.
+__device__ __forceinline__ void qr_solve_5x3(double (&a)[5][3], double (&x)[3]) {
+  const double eps = 2.220446049250313e-16;
+  double hc[3];
+  int tr[3];
+  double nu[3], nd[3];
+  double maxn = 0;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    double s = 0;
+#pragma unroll
+    for (int r = 0; r < 5; r++) s += a[r][c] * a[r][c];
+    nu[c] = nd[c] = sqrt(s);
+    maxn = fmax(maxn, nu[c]);
+  }
+  const double th = maxn * eps / 5.0;
+  const double thr_helper = th * th;
+  const double downdate_thr = 1.4901161193847656e-08;  // sqrt(eps)
+  int nzp = 3;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int big = k;
+    double bigv = nu[k];
+#pragma unroll
+    for (int j = k + 1; j < 3; j++)
+      if (nu[j] > bigv) { bigv = nu[j]; big = j; }
+    if (nzp == 3 && bigv * bigv < thr_helper * (double)(5 - k)) nzp = k;
+    tr[k] = big;
+    if (big != k) {
+#pragma unroll
+      for (int j = k + 1; j < 3; j++)
+        if (j == big) {
+#pragma unroll
+          for (int r = 0; r < 5; r++) { double t = a[r][k]; a[r][k] = a[r][j]; a[r][j] = t; }
+          double t = nu[k]; nu[k] = nu[j]; nu[j] = t;
+          t = nd[k]; nd[k] = nd[j]; nd[j] = t;
+        }
+    }
+    double tail = 0;
+#pragma unroll
+    for (int r = k + 1; r < 5; r++) tail += a[r][k] * a[r][k];
+    double c0 = a[k][k], beta, tau;
+    if (tail <= 2.2250738585072014e-308) {
+      tau = 0;
+      beta = c0;
+#pragma unroll
+      for (int r = k + 1; r < 5; r++) a[r][k] = 0;
+    } else {
+      beta = sqrt(c0 * c0 + tail);
+      if (c0 >= 0) beta = -beta;
+      double den = c0 - beta;
+#pragma unroll
+      for (int r = k + 1; r < 5; r++) a[r][k] /= den;
+      tau = (beta - c0) / beta;
+    }
+    hc[k] = tau;
+    a[k][k] = beta;
+    if (tau != 0) {
+#pragma unroll
+      for (int j = k + 1; j < 3; j++) {
+        double tmp = a[k][j];
+#pragma unroll
+        for (int r = k + 1; r < 5; r++) tmp += a[r][k] * a[r][j];
+        a[k][j] -= tau * tmp;
+#pragma unroll
+        for (int r = k + 1; r < 5; r++) a[r][j] -= tau * a[r][k] * tmp;
+      }
+    }
+#pragma unroll
+    for (int j = k + 1; j < 3; j++) {
+      if (nu[j] != 0) {
+        double t = fabs(a[k][j]) / nu[j];
+        t = (1.0 + t) * (1.0 - t);
+        t = t < 0 ? 0 : t;
+        double ratio = nu[j] / nd[j];
+        double t2 = t * ratio * ratio;
+        if (t2 <= downdate_thr) {
+          double s = 0;
+#pragma unroll
+          for (int r = k + 1; r < 5; r++) s += a[r][j] * a[r][j];
+          nd[j] = sqrt(s);
+          nu[j] = nd[j];
+        } else {
+          nu[j] *= sqrt(t);
+        }
+      }
+    }
+  }
+  double c[5] = {-1.0, -1.0, -1.0, -1.0, -1.0};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (k < nzp && hc[k] != 0) {
+      double tmp = c[k];
+#pragma unroll
+      for (int r = k + 1; r < 5; r++) tmp += a[r][k] * c[r];
+      c[k] -= hc[k] * tmp;
+#pragma unroll
+      for (int r = k + 1; r < 5; r++) c[r] -= hc[k] * a[r][k] * tmp;
+    }
+  }
+  double y[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 2; i >= 0; i--) {
+    if (i < nzp) {
+      double s = c[i];
+#pragma unroll
+      for (int j = i + 1; j < 3; j++)
+        if (j < nzp) s -= a[i][j] * y[j];
+      y[i] = s / a[i][i];
+    }
+  }
+  int perm[3] = {0, 1, 2};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    // swap(perm[k], perm[tr[k]]) with tr[k] >= k, written without dynamic register indexing
+#pragma unroll
+    for (int j = k + 1; j < 3; j++)
+      if (tr[k] == j) { int t = perm[k]; perm[k] = perm[j]; perm[j] = t; }
+  }
+  x[0] = x[1] = x[2] = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    if (i < nzp) {
+      double v = y[i];
+      if (perm[i] == 0) x[0] = v;
+      else if (perm[i] == 1) x[1] = v;
+      else x[2] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-block reduction of the 12-column Jacobian rows into 78 + 12 sums (+ count)
+constexpr int kCols = 13;         // 12 Jacobian columns + z
+constexpr int kColStride = 65;    // 64 lanes + 1 pad: column c of lane p at (c * 65 + p) — conflict-free b64 reads
+struct ReduceShared {
+  double col[4][kCols * kColStride];
+  double part[4][90];
+  int cnt[4];
+};
+
+// pair t (0..89) -> (a, b): t < 78 upper triangle of 12x12 row-major (a <= b), else (t - 78, 12)
+__device__ __forceinline__ void pair_of(int t, int& a, int& b) {
+  if (t >= 78) { a = t - 78; b = 12; return; }
+  int rem = t, row = 0;
+#pragma unroll
+  for (int r = 0; r < 12; r++) {
+    int len = 12 - r;
+    if (rem >= len && row == r) { rem -= len; row = r + 1; }
+  }
+  a = row;
+  b = row + rem;
+}
+
+__device__ __forceinline__ void block_reduce_rows(ReduceShared& sh, const double (&h)[12], double z, bool sel, double rinv,
+                                                  double* __restrict__ partial_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* col = sh.col[wave];
+#pragma unroll
+  for (int c = 0; c < 12; c++) col[c * kColStride + lane] = sel ? h[c] : 0.0;
+  col[12 * kColStride + lane] = sel ? z : 0.0;
+  unsigned long long m = __ballot(sel);
+  if (lane == 0) sh.cnt[wave] = __popcll(m);
+  __syncthreads();
+  // each lane owns pairs lane and lane + 64 (90 pairs per wave)
+  int a0, b0, a1, b1;
+  pair_of(lane, a0, b0);
+  const bool two = (lane + 64) < 90;
+  pair_of(two ? lane + 64 : 0, a1, b1);
+  double s0 = 0, s1 = 0;
+  const double* ca0 = col + a0 * kColStride;
+  const double* cb0 = col + b0 * kColStride;
+  const double* ca1 = col + a1 * kColStride;
+  const double* cb1 = col + b1 * kColStride;
+#pragma unroll 8
+  for (int p = 0; p < 64; p++) {
+    s0 += (ca0[p] * rinv) * cb0[p];
+    s1 += (ca1[p] * rinv) * cb1[p];
+  }
+  sh.part[wave][lane] = s0;
+  if (two) sh.part[wave][lane + 64] = s1;
+  __syncthreads();
+  if (threadIdx.x < 90) {
+    double s = sh.part[0][threadIdx.x];
+    s += sh.part[1][threadIdx.x];
+    s += sh.part[2][threadIdx.x];
+    s += sh.part[3][threadIdx.x];
+    partial_out[threadIdx.x] = s;
+  } else if (threadIdx.x == 90) {
+    partial_out[90] = (double)(sh.cnt[0] + sh.cnt[1] + sh.cnt[2] + sh.cnt[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fused registration pass.  SEARCH = true: transform, 5-NN, plane fit, residual, Jacobian, reduce.
+// SEARCH = false: transform, residual against the cached plane (the reference re-fits the plane from the
+// unchanged neighbours every iteration, which reproduces the same coefficients — caching is exact),
+// Jacobian, reduce.  `selected` is sticky between searches exactly as point_selected_surf (quirk A11).
+template <bool SEARCH>
+__global__ __launch_bounds__(kBlock) void k_register(GridView g, RegistrationBuffers rb, PoseArg ps, int imu_en,
+                                                      double plane_thr, double rinv) {
+  __shared__ ReduceShared sh;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool live = i < rb.n;
+  double h[12];
+#pragma unroll
+  for (int c = 0; c < 12; c++) h[c] = 0;
+  double z = 0;
+  bool sel = false;
+  if (live) {
+    float4 pb = rb.body[i];
+    // pointBodyToWorld (src/laserMapping.cpp:209-220): double math, float store
+    double bx = pb.x, by = pb.y, bz = pb.z;
+    double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
+    double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
+    double iz = ps.RLI[6] * bx + ps.RLI[7] * by + ps.RLI[8] * bz + ps.TLI[2];
+    float wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
+    float wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
+    float wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
+    rb.world[i] = make_float4(wx, wy, wz, 0.f);
+    double pa = 0, pbn = 0, pc = 0, pd = 0;
+    bool candidate;
+    if (SEARCH) {
+      Knn5 k;
+      knn5_search(g, wx, wy, wz, k);
+      int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
+      rb.nbr_count[i] = found;
+      float4 n0 = k.i0 >= 0 ? g.pts[k.i0] : make_float4(0, 0, 0, 0);
+      float4 n1 = k.i1 >= 0 ? g.pts[k.i1] : make_float4(0, 0, 0, 0);
+      float4 n2 = k.i2 >= 0 ? g.pts[k.i2] : make_float4(0, 0, 0, 0);
+      float4 n3 = k.i3 >= 0 ? g.pts[k.i3] : make_float4(0, 0, 0, 0);
+      float4 n4 = k.i4 >= 0 ? g.pts[k.i4] : make_float4(0, 0, 0, 0);
+      n0.w = k.d0; n1.w = k.d1; n2.w = k.d2; n3.w = k.d3; n4.w = k.d4;
+      rb.nbr[0 * (size_t)rb.cap + i] = n0;
+      rb.nbr[1 * (size_t)rb.cap + i] = n1;
+      rb.nbr[2 * (size_t)rb.cap + i] = n2;
+      rb.nbr[3 * (size_t)rb.cap + i] = n3;
+      rb.nbr[4 * (size_t)rb.cap + i] = n4;
+      // point_selected_surf[i] = found 5 && !(d2[4] > 5)   (:981-984)
+      candidate = (found == kMatch) && !(k.d4 > 5.0f);
+      bool plane_ok = false;
+      if (candidate) {
+        double a[5][3] = {{n0.x, n0.y, n0.z}, {n1.x, n1.y, n1.z}, {n2.x, n2.y, n2.z}, {n3.x, n3.y, n3.z}, {n4.x, n4.y, n4.z}};
+        double nv[3];
+        qr_solve_5x3(a, nv);
+        double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+        pa = nv[0] / nn; pbn = nv[1] / nn; pc = nv[2] / nn; pd = 1.0 / nn;
+        plane_ok = true;
+        const float4 nb[5] = {n0, n1, n2, n3, n4};
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+          if (fabs(pa * nb[j].x + pbn * nb[j].y + pc * nb[j].z + pd) > plane_thr) plane_ok = false;
+      }
+      double* pl = rb.plane + 4 * (size_t)i;
+      pl[0] = pa; pl[1] = pbn; pl[2] = pc; pl[3] = pd;
+      candidate = candidate && plane_ok;
+    } else {
+      // sticky: a point dropped in the previous pass stays dropped until the next search (:989-994)
+      candidate = rb.selected[i] != 0;
+      const double* pl = rb.plane + 4 * (size_t)i;
+      pa = pl[0]; pbn = pl[1]; pc = pl[2]; pd = pl[3];
+    }
+    if (candidate) {
+      float pd2 = (float)(pa * wx + pbn * wy + pc * wz + pd);
+      double pbnorm = sqrt(bx * bx + by * by + bz * bz);
+      float s = (float)(1 - 0.9 * fabsf(pd2) / sqrt(pbnorm));
+      if (s > 0.9) {
+        sel = true;
+        // normvec stores n̂ as float (:1004-1006); the Jacobian reads those floats back (:1046-1047)
+        double nx = (double)(float)pa, ny = (double)(float)pbn, nz = (double)(float)pc;
+        // A = [p_I]x R_end^T n̂ ; rows (:1054-1066)
+        double tx = ps.R[0] * nx + ps.R[3] * ny + ps.R[6] * nz;
+        double ty = ps.R[1] * nx + ps.R[4] * ny + ps.R[7] * nz;
+        double tz = ps.R[2] * nx + ps.R[5] * ny + ps.R[8] * nz;
+        h[0] = -iz * ty + iy * tz;
+        h[1] = iz * tx - ix * tz;
+        h[2] = -iy * tx + ix * ty;
+        h[3] = nx; h[4] = ny; h[5] = nz;
+        if (imu_en) {
+          // H_R_LI = [p_L]x R_LI^T R_end^T n̂ ; H_T_LI = R_end^T n̂
+          double ux = ps.RLI[0] * tx + ps.RLI[3] * ty + ps.RLI[6] * tz;
+          double uy = ps.RLI[1] * tx + ps.RLI[4] * ty + ps.RLI[7] * tz;
+          double uz = ps.RLI[2] * tx + ps.RLI[5] * ty + ps.RLI[8] * tz;
+          h[6] = -bz * uy + by * uz;
+          h[7] = bz * ux - bx * uz;
+          h[8] = -by * ux + bx * uy;
+          h[9] = tx; h[10] = ty; h[11] = tz;
+        }
+        z = -(double)pd2;
+      }
+    }
+    rb.selected[i] = sel ? 1 : 0;
+  }
+  block_reduce_rows(sh, h, z, sel, rinv, rb.partials + (size_t)blockIdx.x * kNormalEq);
+}
+
+template __global__ void k_register<true>(GridView, RegistrationBuffers, PoseArg, int, double, double);
+template __global__ void k_register<false>(GridView, RegistrationBuffers, PoseArg, int, double, double);
+
+// Deterministic final reduction: out[t] = sum over blocks (fixed order).  One block of 8 x 128 threads.
+__global__ __launch_bounds__(1024) void k_reduce91(const double* __restrict__ partials, int n_blocks, double* __restrict__ out) {
+  __shared__ double sh[8][kNormalEq];
+  const int t = threadIdx.x & 127, s = threadIdx.x >> 7;
+  if (t < kNormalEq) {
+    double acc = 0;
+    for (int b = s; b < n_blocks; b += 8) acc += partials[(size_t)b * kNormalEq + t];
+    sh[s][t] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNormalEq) {
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc += sh[k][threadIdx.x];
+    out[threadIdx.x] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// undistortion
+// order-preserving float -> uint map (so that integer atomics give float min / max)
+__device__ __forceinline__ unsigned int f2ord(float f) {
+  unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// extent[0] = (ord(t_min) << 32) | index of the first point with that time ; extent[1] = ord(t_max)
+__global__ void k_time_extent(const float4* __restrict__ pts, int n, unsigned long long* __restrict__ extent) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long mn = ~0ull, mx = 0;
+  if (i < n) {
+    unsigned int o = f2ord(pts[i].w);
+    mn = ((unsigned long long)o << 32) | (unsigned)i;
+    mx = o;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned long long a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&extent[0], mn);
+    atomicMax(&extent[1], mx);
+  }
+}
+__device__ __forceinline__ float ord2f(unsigned int o) {
+  unsigned int u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  return __uint_as_float(u);
+}
+
+// Exp(ang_vel, dt) — include/so3_math.h:37-59 — applied to a vector: R v with Rodrigues, R built explicitly
+__device__ __forceinline__ void exp_so3(const double w[3], double dt, double R[9]) {
+  double n = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  if (n > 0.0000001) {
+    double ax = w[0] / n, ay = w[1] / n, az = w[2] / n;
+    double ang = n * dt;
+    double s = sin(ang), c1 = 1.0 - cos(ang);
+    // K = skew(axis); K*K entries
+    double K[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
+    double KK[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) KK[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+#pragma unroll
+    for (int e = 0; e < 9; e++) R[e] = ((e % 4 == 0) ? 1.0 : 0.0) + s * K[e] + c1 * KK[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 9; e++) R[e] = (e % 4 == 0) ? 1.0 : 0.0;
+  }
+}
+__device__ __forceinline__ void mat3_mul(const double A[9], const double B[9], double C[9]) {
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+__device__ __forceinline__ void mat3_vec(const double A[9], const double v[3], double o[3]) {
+#pragma unroll
+  for (int r = 0; r < 3; r++) o[r] = A[3 * r] * v[0] + A[3 * r + 1] * v[1] + A[3 * r + 2] * v[2];
+}
+__device__ __forceinline__ void mat3t_vec(const double A[9], const double v[3], double o[3]) {
+#pragma unroll
+  for (int r = 0; r < 3; r++) o[r] = A[r] * v[0] + A[3 + r] * v[1] + A[6 + r] * v[2];
+}
+
+struct UndistArg {
+  double endR[9], endp[3], RLI[9], TLI[3];
+};
+
+// One back-propagation step of point p with pose-table head `h` (src/IMU_Processing.hpp:398-411)
+__device__ __forceinline__ void backprop_once(const double* __restrict__ head /*22 doubles*/, double t, const UndistArg& u,
+                                              double p[3]) {
+  double dt = t - head[0];
+  const double* acc = head + 1;
+  const double* gyr = head + 4;
+  const double* vel = head + 7;
+  const double* pos = head + 10;
+  const double* rot = head + 13;
+  double E[9], Ri[9];
+  exp_so3(gyr, dt, E);
+  mat3_mul(rot, E, Ri);
+  double Pi[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) Pi[a] = pos[a] + vel[a] * dt + 0.5 * acc[a] * dt * dt;
+  double q[3], w[3], e[3], o[3];
+  mat3_vec(u.RLI, p, q);
+#pragma unroll
+  for (int a = 0; a < 3; a++) q[a] += u.TLI[a];
+  mat3_vec(Ri, q, w);
+#pragma unroll
+  for (int a = 0; a < 3; a++) w[a] = w[a] + Pi[a] - u.endp[a];
+  mat3t_vec(u.endR, w, e);
+#pragma unroll
+  for (int a = 0; a < 3; a++) e[a] -= u.TLI[a];
+  mat3t_vec(u.RLI, e, o);
+  p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
+}
+
+// IMU-mode de-skew.  The reference walks the time-sorted cloud backwards over the pose table; per point this
+// is: head = the LAST pose index h <= K-2 with offset_time[h] < t (strict) — points with no such head stay
+// untouched.  Quirk A3: the time-earliest point (first of the sorted cloud) is re-tested against every earlier
+// head after being compensated, so it is compensated once per qualifying head, in descending order.
+__global__ void k_undistort_imu(float4* __restrict__ pts, int n, const double* __restrict__ poses, int K, UndistArg u,
+                                const unsigned long long* __restrict__ extent) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 P = pts[i];
+  double t = P.w / double(1000);
+  int h = -1;
+  for (int k = K - 2; k >= 0; k--)
+    if (t > poses[22 * k]) { h = k; break; }
+  if (h < 0) return;
+  double p[3] = {P.x, P.y, P.z};
+  backprop_once(poses + 22 * h, t, u, p);
+  const bool is_begin = ((unsigned)(extent[0] & 0xFFFFFFFFull) == (unsigned)i);
+  if (is_begin) {
+    for (int k = h - 1; k >= 0; k--) {
+      if (t > poses[22 * k]) {
+        // the reference reads the already-overwritten float coordinates back
+        p[0] = (double)(float)p[0]; p[1] = (double)(float)p[1]; p[2] = (double)(float)p[2];
+        backprop_once(poses + 22 * k, t, u, p);
+      }
+    }
+  }
+  pts[i] = make_float4((float)p[0], (float)p[1], (float)p[2], P.w);
+}
+
+struct CvArg {
+  double omega[3], vel[3], endR[9];
+};
+// CV-mode de-skew (src/IMU_Processing.hpp:246-266).  The time-earliest point is skipped (quirk A3).
+__global__ void k_undistort_cv(float4* __restrict__ pts, int n, CvArg a, const unsigned long long* __restrict__ extent) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if ((unsigned)(extent[0] & 0xFFFFFFFFull) == (unsigned)i) return;
+  float4 P = pts[i];
+  double end_off = ord2f((unsigned)extent[1]) / double(1000);
+  double dt_j = end_off - P.w / double(1000);
+  double R[9];
+  exp_so3(a.omega, -dt_j, R);
+  double rv[3];
+  mat3t_vec(a.endR, a.vel, rv);
+  double p[3] = {P.x, P.y, P.z}, o[3];
+  mat3_vec(R, p, o);
+#pragma unroll
+  for (int c = 0; c < 3; c++) o[c] = o[c] + (-rv[c]) * dt_j;
+  pts[i] = make_float4((float)o[0], (float)o[1], (float)o[2], P.w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// voxel-grid down-sampling (PCL VoxelGrid restatement)
+// mm[0..2] = ord(min xyz), mm[3..5] = ord(max xyz)
+__global__ void k_voxel_minmax(const float4* __restrict__ pts, int n, unsigned int* __restrict__ mm) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+  if (i < n) {
+    float4 p = pts[i];
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+      lo[0] = hi[0] = f2ord(p.x);
+      lo[1] = hi[1] = f2ord(p.y);
+      lo[2] = hi[2] = f2ord(p.z);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    for (int off = 32; off > 0; off >>= 1) {
+      unsigned int x = __shfl_xor(lo[a], off), y = __shfl_xor(hi[a], off);
+      lo[a] = min(lo[a], x);
+      hi[a] = max(hi[a], y);
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&mm[a], lo[a]);
+      atomicMax(&mm[3 + a], hi[a]);
+    }
+  }
+}
+
+struct VoxelArg {
+  float inv_leaf;
+  int min_b[3];
+  int mul[3];
+};
+__global__ void k_voxel_keys(const float4* __restrict__ pts, int n, VoxelArg v, unsigned int* __restrict__ keys,
+                             unsigned int* __restrict__ idx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  unsigned int key = 0x7FFFFFFFu;  // non-finite points sort last and are dropped
+  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+    int i0 = (int)(floorf(p.x * v.inv_leaf) - (float)v.min_b[0]);
+    int i1 = (int)(floorf(p.y * v.inv_leaf) - (float)v.min_b[1]);
+    int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)v.min_b[2]);
+    key = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);
+  }
+  keys[i] = key;
+  idx[i] = (unsigned)i;
+}
+__global__ void k_voxel_flags(const unsigned int* __restrict__ keys, int n, unsigned int* __restrict__ flags) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned int k = keys[i];
+  flags[i] = (k != 0x7FFFFFFFu && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+// ranks = inclusive scan of flags.  One thread per voxel start accumulates its run sequentially in input
+// order (the sort is stable), float32, then divides by the count — the same order the oracle uses.
+__global__ void k_voxel_centroid(const float4* __restrict__ pts, const unsigned int* __restrict__ keys,
+                                 const unsigned int* __restrict__ idx, const unsigned int* __restrict__ flags,
+                                 const unsigned int* __restrict__ ranks, int n, float4* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flags[i]) return;
+  unsigned int k = keys[i];
+  float sx = 0, sy = 0, sz = 0, st = 0;
+  int j = i;
+  for (; j < n && keys[j] == k; j++) {
+    float4 p = pts[idx[j]];
+    sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+  }
+  float c = (float)(j - i);
+  out[ranks[i] - 1] = make_float4(sx / c, sy / c, sz / c, st / c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LI-Init residual / Jacobian evaluators (include/LI_init/LI_init.h:91-205).  Records are 22 doubles:
+// rot_end[9], ang_vel[3], linear_vel[3], ang_acc[3], linear_acc[3], timestamp.
+// Tangent convention R <- Exp(delta) R  (Appendix B of SURVEY.md):
+//   stage 1/2: r = R w_L - w_I [- (dT + t_d) a_I + b_g];  dr/ddelta = -[R w_L]x, dr/db_g = I, dr/dt_d = -alpha_I
+//   stage 3:   r = R_LL0 R_LI^T a_I - R_LL0 b_a + R_GL0 g - a_L - R_LL0 ([w]x^2 + [alpha]x) T_IL
+//              dr/ddelta_G = -[R_GL0 g]x, dr/db_a = -R_LL0, dr/dT_IL = -R_LL0 ([w]x^2 + [alpha]x)
+// Output per block: dof*dof + dof + 1 doubles (J^T J row-major, J^T r, 0.5 sum r^2), reduced on one block.
+constexpr int kCalibMaxDof = 9;
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_calib_eval(const double* __restrict__ imu, const double* __restrict__ lidar, int n,
+                                                    const double* __restrict__ params, double* __restrict__ out) {
+  constexpr int DOF = STAGE == 1 ? 3 : (STAGE == 2 ? 7 : 9);
+  constexpr int NOUT = DOF * DOF + DOF + 1;
+  __shared__ double sh[256];
+  double acc[NOUT];
+#pragma unroll
+  for (int k = 0; k < NOUT; k++) acc[k] = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double* I = imu + 22 * (size_t)i;
+    const double* L = lidar + 22 * (size_t)i;
+    double r[3];
+    double J[3][DOF];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < DOF; b++) J[a][b] = 0;
+    if (STAGE == 1 || STAGE == 2) {
+      const double* R = params;
+      double Rw[3];
+      mat3_vec(R, L + 9, Rw);
+#pragma unroll
+      for (int a = 0; a < 3; a++) r[a] = Rw[a] - I[9 + a];
+      // -[Rw]x
+      J[0][1] = Rw[2]; J[0][2] = -Rw[1];
+      J[1][0] = -Rw[2]; J[1][2] = Rw[0];
+      J[2][0] = Rw[1]; J[2][1] = -Rw[0];
+      if (STAGE == 2) {
+        const double* bg = params + 9;
+        double td = params[12];
+        double dT = L[21] - I[21];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          r[a] = r[a] - (dT + td) * I[15 + a] + bg[a];
+          J[a][(3 + a) % DOF] = 1.0;
+          J[a][6 % DOF] = -I[15 + a];
+        }
+      }
+    } else {
+      const double* RG = params;        // R_GL0
+      const double* ba = params + 9;    // bias_aL
+      const double* Til = params + 12;  // T_IL
+      const double* RLI = params + 15;  // R_LI (fixed)
+      const double* RLL0 = L;           // rot_end
+      const double g[3] = {0, 0, -9.81};  // STD_GRAV (LI_init.h:27)
+      double aI_L[3], t1[3], Rg[3];
+      mat3t_vec(RLI, I + 18, aI_L);  // R_LI^T a_I
+      mat3_vec(RLL0, aI_L, t1);      // R_LL0 R_LI^T a_I
+      mat3_vec(RG, g, Rg);
+      const double* w = L + 9;
+      const double* al = L + 15;
+      double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+      double A[9] = {0, -al[2], al[1], al[2], 0, -al[0], -al[1], al[0], 0};
+      double M[9], RM[9];
+      mat3_mul(W, W, M);
+#pragma unroll
+      for (int e = 0; e < 9; e++) M[e] += A[e];
+      mat3_mul(RLL0, M, RM);
+      double Rb[3], RMt[3];
+      mat3_vec(RLL0, ba, Rb);
+      mat3_vec(RM, Til, RMt);
+#pragma unroll
+      for (int a = 0; a < 3; a++) r[a] = t1[a] - Rb[a] + Rg[a] - L[18 + a] - RMt[a];
+      J[0][1] = Rg[2]; J[0][2] = -Rg[1];
+      J[1][0] = -Rg[2]; J[1][2] = Rg[0];
+      J[2][0] = Rg[1]; J[2][1] = -Rg[0];
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          J[a][(3 + b) % DOF] = -RLL0[3 * a + b];
+          J[a][(6 + b) % DOF] = -RM[3 * a + b];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < DOF; a++) {
+#pragma unroll
+      for (int b = 0; b < DOF; b++) acc[a * DOF + b] += J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b];
+      acc[DOF * DOF + a] += J[0][a] * r[0] + J[1][a] * r[1] + J[2][a] * r[2];
+    }
+    acc[DOF * DOF + DOF] += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  }
+  // fixed-order block reduction (tree over 256 threads), one output at a time
+#pragma unroll
+  for (int k = 0; k < NOUT; k++) {
+    sh[threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] = sh[0];
+    __syncthreads();
+  }
+}
+template __global__ void k_calib_eval<1>(const double*, const double*, int, const double*, double*);
+template __global__ void k_calib_eval<2>(const double*, const double*, int, const double*, double*);
+template __global__ void k_calib_eval<3>(const double*, const double*, int, const double*, double*);
+
+}  // namespace lii
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+#include "lii_launch.h"
+namespace lii {
+static inline int nblk(int n, int b) { return (n + b - 1) / b; }
+
+void launch_map_keys(const float4* pts, int n, float inv_cs, unsigned long long* keys, unsigned int* idx, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_map_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, inv_cs, keys, idx);
+}
+void launch_map_gather(const float4* src, const unsigned int* idx, int n, float4* dst, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_map_gather, dim3(nblk(n, 256)), dim3(256), 0, s, src, idx, n, dst);
+}
+void launch_cells_count(const unsigned long long* keys, int n, unsigned int* n_cells, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_cells_count, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, n_cells);
+}
+void launch_table_clear(CellEntry* fine, unsigned int fine_cap, unsigned long long* coarse, unsigned int coarse_cap, hipStream_t s) {
+  unsigned int m = fine_cap > coarse_cap ? fine_cap : coarse_cap;
+  hipLaunchKernelGGL(k_table_clear, dim3(nblk((int)m, 256)), dim3(256), 0, s, fine, fine_cap, coarse, coarse_cap);
+}
+void launch_cells_insert(const unsigned long long* keys, int n, CellEntry* fine, unsigned int fine_mask,
+                         unsigned long long* coarse, unsigned int coarse_mask, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_cells_insert, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, fine, fine_mask, coarse, coarse_mask);
+}
+int register_blocks(int n) { return nblk(n, kBlock); }
+void launch_register(bool search, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en,
+                     double plane_thr, double rinv, hipStream_t s) {
+  int nb = nblk(rb.n, kBlock);
+  if (nb < 1) nb = 1;
+  if (search)
+    hipLaunchKernelGGL(k_register<true>, dim3(nb), dim3(kBlock), 0, s, g, rb, ps, imu_en, plane_thr, rinv);
+  else
+    hipLaunchKernelGGL(k_register<false>, dim3(nb), dim3(kBlock), 0, s, g, rb, ps, imu_en, plane_thr, rinv);
+}
+void launch_reduce91(const double* partials, int n_points, double* out91, hipStream_t s) {
+  int nb = nblk(n_points, kBlock);
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_reduce91, dim3(1), dim3(1024), 0, s, partials, nb, out91);
+}
+__global__ void k_extent_init(unsigned long long* e) {
+  e[0] = ~0ull;
+  e[1] = 0ull;
+}
+void launch_time_extent(const float4* pts, int n, unsigned long long* extent, hipStream_t s) {
+  hipLaunchKernelGGL(k_extent_init, dim3(1), dim3(1), 0, s, extent);
+  if (n > 0) hipLaunchKernelGGL(k_time_extent, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, extent);
+}
+void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& uh,
+                          const unsigned long long* extent, hipStream_t s) {
+  UndistArg u;
+  static_assert(sizeof(UndistArg) == sizeof(UndistArgH), "layout");
+  memcpy(&u, &uh, sizeof(u));
+  if (n > 0) hipLaunchKernelGGL(k_undistort_imu, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent);
+}
+void launch_undistort_cv(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, hipStream_t s) {
+  CvArg a;
+  static_assert(sizeof(CvArg) == sizeof(CvArgH), "layout");
+  memcpy(&a, &ah, sizeof(a));
+  if (n > 0) hipLaunchKernelGGL(k_undistort_cv, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent);
+}
+__global__ void k_minmax_init(unsigned int* mm) {
+  if (threadIdx.x < 3) mm[threadIdx.x] = 0xFFFFFFFFu;
+  else if (threadIdx.x < 6) mm[threadIdx.x] = 0u;
+}
+void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, hipStream_t s) {
+  hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, s, mm);
+  if (n > 0) hipLaunchKernelGGL(k_voxel_minmax, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm);
+}
+void launch_voxel_keys(const float4* pts, int n, const VoxelArgH& vh, unsigned int* keys, unsigned int* idx, hipStream_t s) {
+  VoxelArg v;
+  static_assert(sizeof(VoxelArg) == sizeof(VoxelArgH), "layout");
+  memcpy(&v, &vh, sizeof(v));
+  if (n > 0) hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, v, keys, idx);
+}
+void launch_voxel_flags(const unsigned int* keys, int n, unsigned int* flags, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_voxel_flags, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, flags);
+}
+void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const unsigned int* idx, const unsigned int* flags,
+                           const unsigned int* ranks, int n, float4* out, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_voxel_centroid, dim3(nblk(n, 256)), dim3(256), 0, s, pts, keys, idx, flags, ranks, n, out);
+}
+void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
+                       hipStream_t s) {
+  if (stage == 1) hipLaunchKernelGGL(k_calib_eval<1>, dim3(1), dim3(256), 0, s, imu, lidar, n, params, out);
+  else if (stage == 2) hipLaunchKernelGGL(k_calib_eval<2>, dim3(1), dim3(256), 0, s, imu, lidar, n, params, out);
+  else hipLaunchKernelGGL(k_calib_eval<3>, dim3(1), dim3(256), 0, s, imu, lidar, n, params, out);
+}
+float ord_to_float(unsigned int o) {
+  unsigned int u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+}  // namespace lii

@@ -1,0 +1,51 @@
+// Host-callable launchers of the kernels in lii_kernels.hip / lii_sort.hip (internal; not the C-ABI).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+
+#include "lii_device.h"
+
+namespace lii {
+
+struct UndistArgH { double endR[9], endp[3], RLI[9], TLI[3]; };
+struct CvArgH { double omega[3], vel[3], endR[9]; };
+struct VoxelArgH { float inv_leaf; int min_b[3]; int mul[3]; };
+
+// map index
+void launch_map_keys(const float4* pts, int n, float inv_cs, unsigned long long* keys, unsigned int* idx, hipStream_t s);
+void launch_map_gather(const float4* src, const unsigned int* idx, int n, float4* dst, hipStream_t s);
+void launch_cells_count(const unsigned long long* keys, int n, unsigned int* n_cells, hipStream_t s);
+void launch_table_clear(CellEntry* fine, unsigned int fine_cap, unsigned long long* coarse, unsigned int coarse_cap, hipStream_t s);
+void launch_cells_insert(const unsigned long long* keys, int n, CellEntry* fine, unsigned int fine_mask,
+                         unsigned long long* coarse, unsigned int coarse_mask, hipStream_t s);
+// registration
+void launch_register(bool search, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en,
+                     double plane_thr, double rinv, hipStream_t s);
+void launch_reduce91(const double* partials, int n_points, double* out91, hipStream_t s);
+int register_blocks(int n);
+// undistortion
+void launch_time_extent(const float4* pts, int n, unsigned long long* extent, hipStream_t s);
+void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& u,
+                          const unsigned long long* extent, hipStream_t s);
+void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned long long* extent, hipStream_t s);
+// voxel grid
+void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, hipStream_t s);
+void launch_voxel_keys(const float4* pts, int n, const VoxelArgH& v, unsigned int* keys, unsigned int* idx, hipStream_t s);
+void launch_voxel_flags(const unsigned int* keys, int n, unsigned int* flags, hipStream_t s);
+void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const unsigned int* idx, const unsigned int* flags,
+                           const unsigned int* ranks, int n, float4* out, hipStream_t s);
+// calibration
+void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
+                       hipStream_t s);
+
+// rocPRIM wrappers (lii_sort.hip)
+size_t sort_temp_bytes(int max_n);
+void sort_pairs_u64(void* temp, size_t temp_bytes, const unsigned long long* kin, unsigned long long* kout,
+                    const unsigned int* vin, unsigned int* vout, int n, hipStream_t s);
+void sort_pairs_u32(void* temp, size_t temp_bytes, const unsigned int* kin, unsigned int* kout, const unsigned int* vin,
+                    unsigned int* vout, int n, hipStream_t s);
+void inclusive_scan_u32(void* temp, size_t temp_bytes, const unsigned int* in, unsigned int* out, int n, hipStream_t s);
+
+float ord_to_float(unsigned int o);
+
+}  // namespace lii

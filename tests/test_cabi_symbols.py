@@ -1,0 +1,56 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol that
+include/liinit_hip.h declares, and refuses to run without a GPU (no silent CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import lidar_imu_init_amd as lii
+from lidar_imu_init_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "liinit_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(lii_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_all_exported():
+    assert os.path.exists(lii.library_path()), "build libliinit_hip.so first (__graft_entry__.build())"
+    L = ctypes.CDLL(lii.library_path())
+    names = _declared_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, f"declared in include/liinit_hip.h but not exported: {missing}"
+
+
+def test_python_mirror_covers_header():
+    assert sorted(api.EXPORTED_SYMBOLS) == _declared_symbols()
+    L = lii.load_library()
+    assert L.lii_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(api.lii_config) == 48
+    assert ctypes.sizeof(api.lii_iekf_report) == 16 + 91 * 8
+    assert api.STATE_DOUBLES == 612
+
+
+def test_fails_loudly_without_gpu():
+    L = lii.load_library()
+    n = ctypes.c_int(0)
+    rc = L.lii_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(lii.LIIError):
+        lii.Registrar(1000, 1000)
+    cfg = api.lii_config()
+    cfg.struct_size = ctypes.sizeof(api.lii_config)
+    cfg.max_scan_points = 10
+    cfg.max_map_points = 10
+    h = ctypes.c_void_p()
+    assert L.lii_create(ctypes.byref(cfg), ctypes.byref(h)) == -2  # LII_ERR_NO_DEVICE
+    assert not h.value

@@ -1,0 +1,127 @@
+"""GPU parity of the fused registration pass (k_register + k_reduce91) and of the full iterated update
+against the oracle, through the C-ABI.  Tolerances (stated per SURVEY.md Appendix B):
+  * neighbour lists: BIT-EXACT (same 5 points, same float32 squared distances, same order);
+  * selected set: identical except at 1-ulp threshold flips (Jaccard >= 0.999);
+  * H^T R^-1 H / H^T R^-1 z: relative 1e-9 when the selected sets are identical;
+  * final pose of the update: |dp| <= 1e-6 m, |dtheta| <= 1e-7 rad.
+"""
+import numpy as np
+import pytest
+
+from conftest import make_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def reg(small_world):
+    import lidar_imu_init_amd as lii
+    hall, map_pts = small_world
+    r = lii.Registrar(max_scan_points=150_000, max_map_points=400_000, filter_size_map=0.15)
+    yield r
+    r.close()
+
+
+def _scan(small_world, sensor="tiny", seed=3):
+    from lidar_imu_init_amd import synth
+    hall, _ = small_world
+    R = synth.rot_zyx(0.03, -0.02, 0.4)
+    p = np.array([0.8, -0.6, 0.1])
+    return synth.make_scan(hall, sensor, R, p, noise=0.02, seed=seed), R, p
+
+
+def _rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.mark.parametrize("sensor,imu_en", [("tiny", False), ("tiny", True), ("vlp16", True)])
+def test_iterate_matches_oracle(reg, oracle, small_world, sensor, imu_en):
+    import lidar_imu_init_amd as lii
+    hall, map_pts = small_world
+    scan, R, p = _scan(small_world, sensor)
+    # perturbed start pose + a non-trivial extrinsic
+    from lidar_imu_init_amd import synth
+    R_LI = synth.rot_zyx(0.01, 0.02, -0.015) if imu_en else np.eye(3)
+    T_LI = np.array([0.03, -0.02, 0.05]) if imu_en else np.zeros(3)
+    # body = LiDAR frame; world pose of the IMU frame chosen so that the LiDAR pose equals (R, p) + small error
+    Rw = R @ synth.rot_zyx(0.004, -0.003, 0.005) @ R_LI.T
+    pw = p + np.array([0.03, -0.02, 0.01]) - Rw @ T_LI
+    st = make_state(oracle, Rw, pw, R_LI, T_LI)
+    tree = oracle.Tree("oracle")
+    tree.build(map_pts)
+    ref = tree.iterate_once(scan, st, search=True, imu_en=imu_en, threads=4)
+    reg.map_build(map_pts)
+    reg.scan_upload(scan)
+    n = reg.downsample_skip()
+    assert n == len(scan)
+    out = reg.iekf_iterate(lii.State(st), True, imu_en)
+    nb, cnt, sel = reg.neighbors(n)
+    assert np.array_equal(cnt, ref["nearest_n"])
+    full = cnt == 5
+    assert full.mean() > 0.9
+    assert np.array_equal(nb[full], ref["nearest"][full]), "neighbour lists must be bit-exact"
+    inter = np.logical_and(sel, ref["selected"]).sum()
+    union = np.logical_or(sel, ref["selected"]).sum()
+    assert inter / union >= 0.999
+    if inter == union:
+        assert int(out[90]) == int(ref["out91"][90])
+        assert _rel(out[:90], ref["out91"][:90]) < 1e-9
+    # a second, non-search pass at a moved pose must reuse the cached planes and the sticky selection
+    st2 = oracle.state_boxplus(st, np.r_[0.001, -0.002, 0.0015, 0.01, -0.005, 0.004, np.zeros(18)])
+    ref2 = tree.iterate_once(scan, st2, search=False, imu_en=imu_en, threads=4, selected=ref["selected"])
+    out2 = reg.iekf_iterate(lii.State(st2), False, imu_en)
+    _, _, sel2 = reg.neighbors(n)
+    if inter == union and np.array_equal(sel2, ref2["selected"]):
+        assert _rel(out2[:90], ref2["out91"][:90]) < 1e-9
+    assert np.logical_xor(sel2, ref2["selected"]).sum() <= max(2, int(0.001 * n))
+
+
+@pytest.mark.parametrize("imu_en,max_it", [(False, 4), (True, 5)])
+def test_update_matches_oracle(reg, oracle, small_world, imu_en, max_it):
+    import lidar_imu_init_amd as lii
+    from lidar_imu_init_amd import synth
+    hall, map_pts = small_world
+    scan, R, p = _scan(small_world, "vlp16", seed=11)
+    st_true = make_state(oracle, R, p)
+    st0 = oracle.state_boxplus(st_true, np.r_[0.006, -0.004, 0.008, 0.04, -0.03, 0.02, np.zeros(18)])
+    tree = oracle.Tree("oracle")
+    tree.build(map_pts)
+    ref = tree.iekf_update(scan, st0, st0, max_iterations=max_it, imu_en=imu_en, threads=4)
+    reg.map_build(map_pts)
+    reg.scan_upload(scan)
+    reg.downsample_skip()
+    s = lii.State(st0)
+    rep = reg.iekf_update(s, lii.State(st0), max_iterations=max_it, imu_en=imu_en)
+    assert rep["iterations"] == ref["iters"]
+    v, w = oracle.StateView(ref["state"]), s
+    assert np.linalg.norm(v.pos_end - w.pos_end) <= 1e-6
+    dR = v.rot_end.T @ w.rot_end
+    assert np.linalg.norm(oracle.log_so3(dR)) <= 1e-7
+    assert np.max(np.abs(v.cov - w.cov)) <= 1e-9 * max(1.0, np.max(np.abs(v.cov)))
+    # and both recover the true pose to the noise level
+    assert np.linalg.norm(w.pos_end - p) < 0.01
+    assert np.linalg.norm(oracle.log_so3(R.T @ w.rot_end)) < 0.002
+
+
+def test_sparse_and_empty_neighbourhoods(reg, oracle):
+    """Frontier behaviour: queries with fewer than 5 neighbours within sqrt(5) m, phase-2 ring search."""
+    import lidar_imu_init_amd as lii
+    rng = np.random.default_rng(5)
+    # a sparse map: 4000 points scattered in a 60 m cube -> most 5-NN radii exceed the 3x3x3 cell block
+    map_pts = rng.uniform(-30, 30, (4000, 3)).astype(np.float32)
+    q = rng.uniform(-34, 34, (5000, 3)).astype(np.float32)
+    scan = np.c_[q, np.zeros(len(q), np.float32)]
+    tree = oracle.Tree("oracle")
+    tree.build(map_pts)
+    st = oracle.state_init()
+    ref = tree.iterate_once(scan, st, search=True, imu_en=False, threads=4)
+    reg.map_build(map_pts)
+    reg.scan_upload(scan)
+    n = reg.downsample_skip()
+    reg.iekf_iterate(lii.State(st), True, False)
+    nb, cnt, sel = reg.neighbors(n)
+    assert np.array_equal(cnt, ref["nearest_n"])
+    assert (cnt < 5).any() and (cnt == 5).any()
+    for k in range(5):
+        m = cnt > k
+        assert np.array_equal(nb[m, k], ref["nearest"][m, k])
