@@ -41,7 +41,7 @@ typedef struct lii_config {
   int32_t device;            /* HIP device ordinal */
   int32_t max_scan_points;   /* capacity of one (sub-)scan, N */
   int32_t max_map_points;    /* capacity of the local map, M */
-  float map_cell_size;       /* edge of the device k-NN grid cell [m]; <= 0: 2 x map_downsample_size */
+  float map_cell_size;       /* edge of the device k-NN grid cell [m]; <= 0: 3 x map_downsample_size */
   float map_downsample_size; /* ikd-Tree downsample box = mapping/filter_size_map (set_downsample_param) */
   float max_match_dist2;     /* accept neighbours with d^2 <= this (5.0) */
   float reserved0;

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,10 +34,14 @@ struct lii_context {
   float4* d_map = nullptr;
   unsigned long long *d_keys_a = nullptr, *d_keys_b = nullptr;
   unsigned int *d_idx_a = nullptr, *d_idx_b = nullptr;
-  CellEntry* d_fine = nullptr;
-  unsigned long long* d_coarse = nullptr;
-  unsigned int fine_cap = 0, coarse_cap = 0;
+  BlockEntry* d_blocks = nullptr;   // capacity-managed (grows on demand)
+  unsigned int blocks_cap = 0;      // allocated entries
+  unsigned int block_mask = 0;      // entries in use - 1
+  uint2* d_cells = nullptr;         // capacity-managed: 512 entries per occupied block
+  size_t cells_cap_blocks = 0;
+  int n_blocks = 0;
   unsigned int* d_counter = nullptr;
+  int partial_stride = 0;
   int n_map = 0;
   float cell_size = 0.3f;
   void* d_sort_temp = nullptr;
@@ -50,6 +55,7 @@ struct lii_context {
   int* d_nbr_count = nullptr;
   double* d_plane = nullptr;
   unsigned char* d_selected = nullptr;
+  int* d_needy = nullptr;
   double* d_partials = nullptr;
   double* d_out91 = nullptr;
   unsigned long long* d_extent = nullptr;
@@ -60,6 +66,7 @@ struct lii_context {
   int n_scan = 0, n_body = 0;
   bool body_is_scan = false;
   bool have_search = false;
+  int knn_variant = 1;  // 0: one lane per query (fused), 1: eight lanes per query + fit kernel
 
   // ---- pinned staging
   float4* h_stage = nullptr;     // max(max_scan, max_map) float4
@@ -109,10 +116,9 @@ unsigned int next_pow2(unsigned int v) {
 GridView grid_view(const lii_context* c) {
   GridView g;
   g.pts = c->d_map;
-  g.fine = c->d_fine;
-  g.coarse = c->d_coarse;
-  g.fine_mask = c->fine_cap - 1;
-  g.coarse_mask = c->coarse_cap - 1;
+  g.blocks = c->d_blocks;
+  g.cells = c->d_cells;
+  g.block_mask = c->block_mask;
   g.n_pts = c->n_map;
   g.cs = c->cell_size;
   g.inv_cs = 1.0f / c->cell_size;
@@ -128,6 +134,9 @@ RegistrationBuffers reg_buffers(const lii_context* c) {
   rb.plane = c->d_plane;
   rb.selected = c->d_selected;
   rb.partials = c->d_partials;
+  rb.needy = c->d_needy;
+  rb.needy_count = c->d_counter;
+  rb.partial_stride = c->partial_stride;
   rb.n = c->n_body;
   rb.cap = c->cfg.max_scan_points;
   return rb;
@@ -141,34 +150,44 @@ PoseArg pose_of(const lii_state& s) {
   return p;
 }
 
-// Rebuilds the device k-NN index from n float4 points already in d_map_unsorted.
+// Rebuilds the device k-NN index from n float4 points already in d_map_unsorted:
+// key (block | local cell) -> radix sort -> gather -> block ids by scan -> per-block cell tables + block table.
 int build_index(lii_handle h, int n) {
   hipStream_t s = h->stream;
   h->n_map = n;
-  if (n == 0) {
-    launch_table_clear(h->d_fine, h->fine_cap ? h->fine_cap : 0, h->d_coarse, h->coarse_cap ? h->coarse_cap : 0, s);
-    return LII_OK;
-  }
+  h->n_blocks = 0;
+  if (n == 0) return LII_OK;
   const float inv_cs = 1.0f / h->cell_size;
   launch_map_keys(h->d_map_unsorted, n, inv_cs, h->d_keys_a, h->d_idx_a, s);
   sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, n, s);
   launch_map_gather(h->d_map_unsorted, h->d_idx_b, n, h->d_map, s);
-  HIPCHK(h, hipMemsetAsync(h->d_counter, 0, sizeof(unsigned int), s));
-  launch_cells_count(h->d_keys_b, n, h->d_counter, s);
-  unsigned int n_cells = 0;
-  HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_counter, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  unsigned int* flags = h->d_idx_a;                                   // free after the sort
+  unsigned int* ranks = reinterpret_cast<unsigned int*>(h->d_keys_a);  // free after the sort
+  launch_block_flags(h->d_keys_b, n, flags, s);
+  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, flags, ranks, n, s);
+  HIPCHK(h, hipMemcpyAsync(h->h_small, ranks + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
-  std::memcpy(&n_cells, h->h_small, sizeof(unsigned int));
-  // tables sized to the occupancy (load factor <= 0.5) so that they stay cache-resident
-  unsigned int fcap = next_pow2(std::max(1024u, 2u * n_cells));
-  unsigned int ccap = next_pow2(std::max(1024u, 2u * n_cells));  // coarse cells <= fine cells
-  const unsigned int max_cap = next_pow2(2u * (unsigned)h->cfg.max_map_points);
-  if (fcap > max_cap) fcap = max_cap;
-  if (ccap > max_cap) ccap = max_cap;
-  h->fine_cap = fcap;
-  h->coarse_cap = ccap;
-  launch_table_clear(h->d_fine, fcap, h->d_coarse, ccap, s);
-  launch_cells_insert(h->d_keys_b, n, h->d_fine, fcap - 1, h->d_coarse, ccap - 1, s);
+  unsigned int n_blocks = 0;
+  std::memcpy(&n_blocks, h->h_small, sizeof(unsigned int));
+  if (size_t(n_blocks) > h->cells_cap_blocks) {
+    if (h->d_cells) HIPCHK(h, hipFree(h->d_cells));
+    h->d_cells = nullptr;
+    size_t want = std::max<size_t>(size_t(n_blocks) * 3 / 2, 4096);
+    HIPCHK(h, dmalloc(&h->d_cells, want * 512));
+    h->cells_cap_blocks = want;
+  }
+  unsigned int bcap = next_pow2(std::max(1024u, 2u * n_blocks));
+  if (bcap > h->blocks_cap) {
+    if (h->d_blocks) HIPCHK(h, hipFree(h->d_blocks));
+    h->d_blocks = nullptr;
+    HIPCHK(h, dmalloc(&h->d_blocks, size_t(bcap)));
+    h->blocks_cap = bcap;
+  }
+  h->block_mask = bcap - 1;
+  h->n_blocks = int(n_blocks);
+  HIPCHK(h, hipMemsetAsync(h->d_cells, 0, sizeof(uint2) * 512 * size_t(n_blocks), s));
+  launch_table_clear(h->d_blocks, bcap, s);
+  launch_cells_fill(h->d_keys_b, ranks, n, h->d_blocks, h->block_mask, h->d_cells, s);
   HIPCHK(h, hipGetLastError());
   return LII_OK;
 }
@@ -197,9 +216,17 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
   RegistrationBuffers rb = reg_buffers(h);
   const bool prof = h->profiling;
   if (prof) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  launch_register(search, g, rb, pose_of(*st), imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, h->stream);
+  const PoseArg ps = pose_of(*st);
+  if (h->knn_variant == 0) {
+    launch_register_fused(search, g, rb, ps, imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, h->stream);
+    if (prof) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+  } else {
+    if (search) launch_knn8(g, rb, ps, h->stream);
+    if (prof) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    launch_fit_reduce(search, rb, ps, imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, h->stream);
+  }
   if (prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-  launch_reduce91(rb.partials, rb.n, h->d_out91, h->stream);
+  launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->stream);
   if (prof) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
   if (search) h->have_search = true;
   if (h->comm) {
@@ -215,7 +242,11 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
     float a = 0, b = 0;
     HIPCHK(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
     HIPCHK(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
-    if (search) { h->timings[0] += a; h->timings[5] += 1; } else { h->timings[1] += a; h->timings[6] += 1; }
+    if (search) {
+      float k = 0;
+      HIPCHK(h, hipEventElapsedTime(&k, h->ev[0], h->ev[3]));
+      h->timings[0] += a; h->timings[5] += 1; h->timings[7] += k;  // [7]: the k-NN kernel alone
+    } else { h->timings[1] += a; h->timings[6] += 1; }
     h->timings[2] += b;
   }
   return LII_OK;
@@ -263,7 +294,10 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   if (h->cfg.plane_threshold <= 0) h->cfg.plane_threshold = 0.1;
   if (h->cfg.laser_point_cov_inv <= 0) h->cfg.laser_point_cov_inv = 1000.0;
   if (h->cfg.map_downsample_size <= 0) h->cfg.map_downsample_size = 0.2f;
-  h->cell_size = cfg->map_cell_size > 0 ? cfg->map_cell_size : 2.0f * h->cfg.map_downsample_size;
+  h->cell_size = cfg->map_cell_size > 0 ? cfg->map_cell_size : 3.0f * h->cfg.map_downsample_size;
+  // the 3x3x3 neighbourhood of 8x8x8-cell blocks must cover the acceptance radius sqrt(max_match_dist2)
+  h->cell_size = std::max(h->cell_size, std::sqrt(h->cfg.max_match_dist2) / 8.0f * 1.001f);
+  if (const char* v = std::getenv("LII_KNN_VARIANT")) h->knn_variant = std::atoi(v);  // A/B knob for profiling
   h->hmap.set_downsample(h->cfg.map_downsample_size);
   h->hmap.clear();
   h->device = cfg->device;
@@ -293,10 +327,11 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_keys_b, M));
   CK(dmalloc(&h->d_idx_a, M));
   CK(dmalloc(&h->d_idx_b, M));
-  const unsigned int max_cap = next_pow2(2u * (unsigned)M);
-  CK(dmalloc(&h->d_fine, size_t(max_cap)));
-  CK(dmalloc(&h->d_coarse, size_t(max_cap)));
-  h->fine_cap = h->coarse_cap = 1024;
+  h->blocks_cap = 4096;
+  h->block_mask = h->blocks_cap - 1;
+  CK(dmalloc(&h->d_blocks, size_t(h->blocks_cap)));
+  h->cells_cap_blocks = std::max<size_t>(4096, M / 64);
+  CK(dmalloc(&h->d_cells, h->cells_cap_blocks * 512));
   CK(dmalloc(&h->d_counter, 4));
   h->sort_temp_bytes = sort_temp_bytes(int(NM));
   CK(hipMalloc(&h->d_sort_temp, h->sort_temp_bytes));
@@ -307,7 +342,10 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_nbr_count, N));
   CK(dmalloc(&h->d_plane, N * 4));
   CK(dmalloc(&h->d_selected, N));
-  CK(dmalloc(&h->d_partials, size_t(register_blocks(int(N)) + 1) * kNormalEq));
+  CK(dmalloc(&h->d_needy, N));
+  CK(hipMemset(h->d_counter, 0, 16));
+  h->partial_stride = register_blocks(int(N)) + 8;
+  CK(dmalloc(&h->d_partials, size_t(h->partial_stride) * kNormalEq));
   CK(dmalloc(&h->d_out91, 128));
   CK(dmalloc(&h->d_extent, 2));
   CK(dmalloc(&h->d_mm, 8));
@@ -324,7 +362,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), sizeof(float4) * h->h_stage_elems, hipHostMallocDefault));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_small), sizeof(double) * 32768, hipHostMallocDefault));
   for (int i = 0; i < 4; i++) CK(hipEventCreate(&h->ev[i]));
-  launch_table_clear(h->d_fine, h->fine_cap, h->d_coarse, h->coarse_cap, h->stream);
+  launch_table_clear(h->d_blocks, h->blocks_cap, h->stream);
   CK(hipStreamSynchronize(h->stream));
 #undef CK
   *out = h;
@@ -336,9 +374,9 @@ int lii_destroy(lii_handle h) {
   (void)hipSetDevice(h->device);
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, h->d_fine, h->d_coarse,
+  void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
-                 h->d_selected, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
+                 h->d_selected, h->d_needy, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
                  h->d_vidx_b, h->d_vflags, h->d_vranks, h->d_poses, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)

@@ -20,19 +20,23 @@ struct PoseArg {
   double TLI[3];
 };
 
-struct __attribute__((aligned(16))) CellEntry {
-  unsigned long long key;  // packed (cz, cy, cx); kEmptyKey = free slot
-  unsigned int start;      // first index into the cell-sorted point array
-  unsigned int end;        // one past the last
+// One occupied 8x8x8 block of grid cells: open-addressing table entry  block key -> dense block id.
+struct __attribute__((aligned(16))) BlockEntry {
+  unsigned long long key;  // packed (Bz, By, Bx) = cell coordinate >> 3; kEmptyKey = free slot
+  unsigned int id;         // index of the block's 512-entry cell table
+  unsigned int pad;
 };
 
-// Device view of the local-map k-NN index: points sorted by fine-cell key + two open-addressing tables.
+// Device view of the local-map k-NN index.  Points are sorted by (block key, local cell index x-fastest), so
+// the cells of one block are contiguous and neighbouring cells sit next to each other in `cells`:
+//   cells[id * 512 + (lz*64 + ly*8 + lx)] = (first, one-past-last) index into pts of that cell (0,0 if empty).
+// The block table is tiny (a few thousand entries for a 1 M-point map) and stays cache resident; the cell
+// tables are spatially coherent, unlike a per-cell hash.
 struct GridView {
   const float4* pts;  // xyz + w = bit-cast insertion id
-  const CellEntry* fine;
-  const unsigned long long* coarse;
-  unsigned int fine_mask;
-  unsigned int coarse_mask;
+  const BlockEntry* blocks;
+  const uint2* cells;
+  unsigned int block_mask;
   int n_pts;
   float cs;
   float inv_cs;
@@ -46,7 +50,10 @@ struct RegistrationBuffers {
   int* nbr_count;       // neighbours found (0..5)
   double* plane;        // 4 doubles per point: n̂, d  (pabcd)
   unsigned char* selected;
-  double* partials;     // per-block 91 doubles
+  int* needy;                // queue of query indices that need the second search stage
+  unsigned int* needy_count;
+  double* partials;     // transposed per-block partial sums: partials[t * partial_stride + block], t < 91
+  int partial_stride;
   int n;
   int cap;
 };

@@ -1,16 +1,19 @@
 // HIP kernels of the LI-Init hot path for gfx950 (CDNA4, wave64).  Hand-written; no MFMA (the path is
-// gather + per-point small algebra + a low-rank reduction, HBM/L2-bound — DESIGN.md §3).
+// gather + per-point small algebra + a low-rank reduction — DESIGN.md §3).
 //
 // Kernels and the reference code they replace (paths relative to the reference root):
-//   k_map_keys / k_map_gather / k_cells_* ... device mirror of the ikd-Tree point set as a cell-sorted
-//                                             array + hash grid (include/ikd-Tree/ikd_Tree.cpp:336-347)
-//   k_register<SEARCH> ...................... src/laserMapping.cpp:964-1012 (transform, Nearest_Search,
-//                                             esti_plane, residual/selection) fused with :1035-1071
-//                                             (Jacobian rows) and :1073-1080 (H^T R^-1 H, H^T R^-1 z)
-//   k_reduce91 .............................. deterministic final sum of the per-block partials
+//   k_map_keys / k_map_gather / k_block_flags / k_cells_fill
+//                      device mirror of the ikd-Tree point set as a cell-sorted array + block-hierarchical grid
+//                      (include/ikd-Tree/ikd_Tree.cpp:336-347 Build)
+//   k_knn8             KD_TREE::Nearest_Search (ikd_Tree.cpp:349-379, Search :825-968) for every point of the
+//                      scan, after pointBodyToWorld (src/laserMapping.cpp:209-220, call :973-985)
+//   k_fit_reduce<FIT>  esti_plane + residual/selection (src/laserMapping.cpp:987-1011), Jacobian rows
+//                      (:1035-1071) and the H^T R^-1 H / H^T R^-1 z sums (:1073-1080)
+//   k_register<SEARCH> the same work with one lane per point, fused (A/B variant 0)
+//   k_reduce91         deterministic final sum of the per-block partials
 //   k_time_extent / k_undistort_imu / _cv ... src/IMU_Processing.hpp:390-414 and :246-266
-//   k_voxel_* ............................... pcl::VoxelGrid::filter call site src/laserMapping.cpp:917-919
-//   k_calib_eval ............................ include/LI_init/LI_init.h:91-205 residuals + analytic Jacobians
+//   k_voxel_*          pcl::VoxelGrid::filter call site src/laserMapping.cpp:917-919
+//   k_calib_eval       include/LI_init/LI_init.h:91-205 residuals + analytic Jacobians
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <cstring>
@@ -23,9 +26,17 @@ namespace lii {
 
 // ------------------------------------------------------------------------------------------------
 // helpers
-__device__ __forceinline__ unsigned long long pack_cell(int cx, int cy, int cz) {
-  return ((unsigned long long)(unsigned)(cz + kCellBias) << 42) | ((unsigned long long)(unsigned)(cy + kCellBias) << 21) |
-         (unsigned long long)(unsigned)(cx + kCellBias);
+constexpr int kBlockCells = 512;  // 8 x 8 x 8 cells per block
+
+// sort key of a map point: (Bz, By, Bx) block key in the high bits, local cell (lz, ly, lx) in the low 9
+__device__ __forceinline__ unsigned long long pack_block(int bx, int by, int bz) {  // biased block coordinates
+  return ((unsigned long long)(unsigned)bz << 36) | ((unsigned long long)(unsigned)by << 18) | (unsigned long long)(unsigned)bx;
+}
+__device__ __forceinline__ unsigned long long point_key(int cx, int cy, int cz) {
+  const unsigned ux = (unsigned)(cx + kCellBias), uy = (unsigned)(cy + kCellBias), uz = (unsigned)(cz + kCellBias);
+  const unsigned long long bk = pack_block((int)(ux >> kCoarseShift), (int)(uy >> kCoarseShift), (int)(uz >> kCoarseShift));
+  const unsigned local = ((uz & 7u) << 6) | ((uy & 7u) << 3) | (ux & 7u);
+  return (bk << 9) | local;
 }
 __device__ __forceinline__ unsigned int hash_key(unsigned long long k) {
   k ^= k >> 33;
@@ -51,7 +62,7 @@ __global__ void k_map_keys(const float4* __restrict__ pts, int n, float inv_cs, 
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
-  keys[i] = pack_cell(cell_of(p.x, inv_cs), cell_of(p.y, inv_cs), cell_of(p.z, inv_cs));
+  keys[i] = point_key(cell_of(p.x, inv_cs), cell_of(p.y, inv_cs), cell_of(p.z, inv_cs));
   idx[i] = (unsigned)i;
 }
 
@@ -62,58 +73,45 @@ __global__ void k_map_gather(const float4* __restrict__ src, const unsigned int*
   dst[i] = src[idx[i]];
 }
 
-// counts the distinct cells (one per run of equal keys)
-__global__ void k_cells_count(const unsigned long long* __restrict__ keys, int n, unsigned int* __restrict__ n_cells) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool start = (i < n) && (i == 0 || keys[i] != keys[i - 1]);
-  unsigned long long m = __ballot(start);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_cells, (unsigned)__popcll(m));
-}
-
-__global__ void k_table_clear(CellEntry* fine, unsigned int fine_cap, unsigned long long* coarse, unsigned int coarse_cap) {
-  unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < fine_cap) {
-    CellEntry e;
-    e.key = kEmptyKey;
-    e.start = 0;
-    e.end = 0;
-    fine[i] = e;
-  }
-  if (i < coarse_cap) coarse[i] = kEmptyKey;
-}
-
-__device__ __forceinline__ unsigned long long coarse_of_packed(unsigned long long key) {
-  // fields are biased by 2^20 (a multiple of 8), so a plain shift of each field is floor(c / 8) + bias/8
-  unsigned long long cx = (key & 0x1FFFFF) >> kCoarseShift;
-  unsigned long long cy = ((key >> 21) & 0x1FFFFF) >> kCoarseShift;
-  unsigned long long cz = ((key >> 42) & 0x1FFFFF) >> kCoarseShift;
-  return (cz << 42) | (cy << 21) | cx;
-}
-
-__global__ void k_cells_insert(const unsigned long long* __restrict__ keys, int n, CellEntry* fine, unsigned int fine_mask,
-                               unsigned long long* coarse, unsigned int coarse_mask) {
+// flags[i] = 1 where a new 8x8x8 block starts in the sorted key array (inclusive scan of it = block id + 1)
+__global__ void k_block_flags(const unsigned long long* __restrict__ keys, int n, unsigned int* __restrict__ flags) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  unsigned long long key = keys[i];
-  bool is_start = (i == 0) || (keys[i - 1] != key);
-  bool is_end = (i == n - 1) || (keys[i + 1] != key);
-  if (!is_start && !is_end) return;
-  // claim / find the slot of this cell; start and end are written by (possibly) different threads
-  unsigned int slot = hash_key(key) & fine_mask;
-  while (true) {
-    unsigned long long prev = atomicCAS(&fine[slot].key, kEmptyKey, key);
-    if (prev == kEmptyKey || prev == key) break;
-    slot = (slot + 1) & fine_mask;
+  flags[i] = (i == 0 || (keys[i] >> 9) != (keys[i - 1] >> 9)) ? 1u : 0u;
+}
+
+__global__ void k_table_clear(BlockEntry* blocks, unsigned int cap) {
+  unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) {
+    BlockEntry e;
+    e.key = kEmptyKey;
+    e.id = 0;
+    e.pad = 0;
+    blocks[i] = e;
   }
-  if (is_start) fine[slot].start = (unsigned)i;
-  if (is_end) fine[slot].end = (unsigned)(i + 1);
-  if (is_start) {
-    unsigned long long ck = coarse_of_packed(key);
-    unsigned int cs = hash_key(ck) & coarse_mask;
+}
+
+// cells must be zero-filled for the n_blocks * 512 entries in use
+__global__ void k_cells_fill(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ ranks, int n,
+                             BlockEntry* blocks, unsigned int block_mask, uint2* __restrict__ cells) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long key = keys[i];
+  const bool is_start = (i == 0) || (keys[i - 1] != key);
+  const bool is_end = (i == n - 1) || (keys[i + 1] != key);
+  if (!is_start && !is_end) return;
+  const unsigned int id = ranks[i] - 1;
+  const unsigned int local = (unsigned int)(key & 511u);
+  unsigned int* cell = reinterpret_cast<unsigned int*>(&cells[(size_t)id * kBlockCells + local]);
+  if (is_start) cell[0] = (unsigned)i;
+  if (is_end) cell[1] = (unsigned)(i + 1);
+  if (is_start && ((i == 0) || ((keys[i - 1] >> 9) != (key >> 9)))) {
+    const unsigned long long bk = key >> 9;
+    unsigned int slot = hash_key(bk) & block_mask;
     while (true) {
-      unsigned long long prev = atomicCAS(&coarse[cs], kEmptyKey, ck);
-      if (prev == kEmptyKey || prev == ck) break;
-      cs = (cs + 1) & coarse_mask;
+      unsigned long long prev = atomicCAS(&blocks[slot].key, kEmptyKey, bk);
+      if (prev == kEmptyKey) { blocks[slot].id = id; break; }
+      slot = (slot + 1) & block_mask;
     }
   }
 }
@@ -136,42 +134,48 @@ __device__ __forceinline__ void knn_insert(Knn5& k, float d, int j) {
 
 __device__ __forceinline__ float axis_gap(float q, int c, float cs, float eps) {
   float lo = (float)c * cs - eps, hi = (float)(c + 1) * cs + eps;
-  float g = fmaxf(fmaxf(lo - q, q - hi), 0.f);
-  return g;
+  return fmaxf(fmaxf(lo - q, q - hi), 0.f);
 }
 
-__device__ __forceinline__ void scan_cell(const GridView& g, int ix, int iy, int iz, float qx, float qy, float qz, Knn5& k) {
-  unsigned long long key = pack_cell(ix, iy, iz);
-  unsigned int slot = hash_key(key) & g.fine_mask;
+// block id of the 8x8x8 block with (unbiased) block coordinates (X, Y, Z), or -1
+__device__ __forceinline__ int find_block(const GridView& g, int X, int Y, int Z) {
+  const int bb = kCellBias >> kCoarseShift;
+  const unsigned long long bk = pack_block(X + bb, Y + bb, Z + bb);
+  unsigned int slot = hash_key(bk) & g.block_mask;
   while (true) {
-    CellEntry e = g.fine[slot];
-    if (e.key == key) {
-      for (unsigned int j = e.start; j < e.end; j++) {
-        float4 p = g.pts[j];
-        float d = dist2_ref(qx, qy, qz, p.x, p.y, p.z);
-        if (d <= g.max_d2 && d < k.d4) knn_insert(k, d, (int)j);
-      }
-      return;
-    }
-    if (e.key == kEmptyKey) return;
-    slot = (slot + 1) & g.fine_mask;
+    BlockEntry e = g.blocks[slot];
+    if (e.key == bk) return (int)e.id;
+    if (e.key == kEmptyKey) return -1;
+    slot = (slot + 1) & g.block_mask;
+  }
+}
+// [start, end) of cell (ix, iy, iz) in the sorted point array (empty -> start == end)
+__device__ __forceinline__ uint2 cell_range(const GridView& g, int ix, int iy, int iz) {
+  const int id = find_block(g, ix >> kCoarseShift, iy >> kCoarseShift, iz >> kCoarseShift);
+  if (id < 0) return make_uint2(0u, 0u);
+  const unsigned local = (((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u);
+  return g.cells[(size_t)id * kBlockCells + local];
+}
+
+__device__ __forceinline__ void scan_range(const GridView& g, unsigned int start, unsigned int end, float qx, float qy,
+                                           float qz, Knn5& k) {
+  unsigned int j = start;
+  // two candidates per trip: the loads are independent of the running top-5
+  for (; j + 1 < end; j += 2) {
+    float4 p0 = g.pts[j], p1 = g.pts[j + 1];
+    float d0 = dist2_ref(qx, qy, qz, p0.x, p0.y, p0.z);
+    float d1 = dist2_ref(qx, qy, qz, p1.x, p1.y, p1.z);
+    if (d0 <= g.max_d2 && d0 < k.d4) knn_insert(k, d0, (int)j);
+    if (d1 <= g.max_d2 && d1 < k.d4) knn_insert(k, d1, (int)(j + 1));
+  }
+  if (j < end) {
+    float4 p0 = g.pts[j];
+    float d0 = dist2_ref(qx, qy, qz, p0.x, p0.y, p0.z);
+    if (d0 <= g.max_d2 && d0 < k.d4) knn_insert(k, d0, (int)j);
   }
 }
 
-__device__ __forceinline__ bool coarse_present(const GridView& g, int X, int Y, int Z) {
-  // coarse coordinates are floor(c/8); rebuild the same packed form as coarse_of_packed
-  unsigned long long ck = ((unsigned long long)(unsigned)(Z + (kCellBias >> kCoarseShift)) << 42) |
-                          ((unsigned long long)(unsigned)(Y + (kCellBias >> kCoarseShift)) << 21) |
-                          (unsigned long long)(unsigned)(X + (kCellBias >> kCoarseShift));
-  unsigned int slot = hash_key(ck) & g.coarse_mask;
-  while (true) {
-    unsigned long long e = g.coarse[slot];
-    if (e == ck) return true;
-    if (e == kEmptyKey) return false;
-    slot = (slot + 1) & g.coarse_mask;
-  }
-}
-
+// one-lane-per-query search (variant 0): 3x3x3 block with box-distance pruning, then ring shells
 __device__ __forceinline__ void knn5_search(const GridView& g, float qx, float qy, float qz, Knn5& k) {
   const float INF = __builtin_inff();
   k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = INF;
@@ -180,9 +184,10 @@ __device__ __forceinline__ void knn5_search(const GridView& g, float qx, float q
   // slack for every geometric cell-bound test: float rounding of c*cs and of p*inv_cs grows with |coordinate|
   const float cs = g.cs, eps = 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + 8.f);
   const int cx = cell_of(qx, g.inv_cs), cy = cell_of(qy, g.inv_cs), cz = cell_of(qz, g.inv_cs);
-  // phase 1: the 3x3x3 block around the query's cell, own cell first; cells farther than the current
-  // 5th-best distance are skipped without a table probe (same pruning rule as the tree's calc_box_dist)
-  scan_cell(g, cx, cy, cz, qx, qy, qz, k);
+  {
+    uint2 r = cell_range(g, cx, cy, cz);
+    scan_range(g, r.x, r.y, qx, qy, qz, k);
+  }
   for (int dz = -1; dz <= 1; dz++) {
     float gz = axis_gap(qz, cz + dz, cs, eps);
     for (int dy = -1; dy <= 1; dy++) {
@@ -190,48 +195,28 @@ __device__ __forceinline__ void knn5_search(const GridView& g, float qx, float q
       for (int dx = -1; dx <= 1; dx++) {
         if (dx == 0 && dy == 0 && dz == 0) continue;
         float gx = axis_gap(qx, cx + dx, cs, eps);
-        float bd = gx * gx + gy * gy + gz * gz;
-        float bound = fminf(k.d4, g.max_d2);
-        if (bd > bound) continue;
-        scan_cell(g, cx + dx, cy + dy, cz + dz, qx, qy, qz, k);
+        if (gx * gx + gy * gy + gz * gz > fminf(k.d4, g.max_d2)) continue;
+        uint2 r = cell_range(g, cx + dx, cy + dy, cz + dz);
+        scan_range(g, r.x, r.y, qx, qy, qz, k);
       }
     }
   }
-  // guaranteed radius of phase 1: distance from q to the faces of the 3x3x3 block
   float fx = qx - (float)cx * cs, fy = qy - (float)cy * cs, fz = qz - (float)cz * cs;
-  float m1 = fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz));
-  m1 = cs + fmaxf(m1, 0.f) - 2.f * eps;
-  float bound = fminf(k.d4, g.max_d2);
-  if (bound <= m1 * m1) return;
-  // phase 2 (rare: sparse map / map frontier): every remaining cell that intersects the ball of radius
-  // sqrt(bound), found through the coarse occupancy table so that empty space costs no fine probes
-  float r = sqrtf(bound) + 2.f * eps;
-  int ix0 = cell_of(qx - r, g.inv_cs), ix1 = cell_of(qx + r, g.inv_cs);
-  int iy0 = cell_of(qy - r, g.inv_cs), iy1 = cell_of(qy + r, g.inv_cs);
-  int iz0 = cell_of(qz - r, g.inv_cs), iz1 = cell_of(qz + r, g.inv_cs);
-  const float ccs = cs * (float)(1 << kCoarseShift);
-  for (int Z = iz0 >> kCoarseShift; Z <= (iz1 >> kCoarseShift); Z++) {
-    float Gz = axis_gap(qz, Z, ccs, eps);
-    for (int Y = iy0 >> kCoarseShift; Y <= (iy1 >> kCoarseShift); Y++) {
-      float Gy = axis_gap(qy, Y, ccs, eps);
-      for (int X = ix0 >> kCoarseShift; X <= (ix1 >> kCoarseShift); X++) {
-        float Gx = axis_gap(qx, X, ccs, eps);
-        if (Gx * Gx + Gy * Gy + Gz * Gz > fminf(k.d4, g.max_d2)) continue;
-        if (!coarse_present(g, X, Y, Z)) continue;
-        int zl = max(iz0, Z * 8), zh = min(iz1, Z * 8 + 7);
-        int yl = max(iy0, Y * 8), yh = min(iy1, Y * 8 + 7);
-        int xl = max(ix0, X * 8), xh = min(ix1, X * 8 + 7);
-        for (int iz = zl; iz <= zh; iz++) {
-          float gz = axis_gap(qz, iz, cs, eps);
-          for (int iy = yl; iy <= yh; iy++) {
-            float gy = axis_gap(qy, iy, cs, eps);
-            for (int ix = xl; ix <= xh; ix++) {
-              if (abs(ix - cx) <= 1 && abs(iy - cy) <= 1 && abs(iz - cz) <= 1) continue;  // phase 1 did it
-              float gx = axis_gap(qx, ix, cs, eps);
-              if (gx * gx + gy * gy + gz * gz > fminf(k.d4, g.max_d2)) continue;
-              scan_cell(g, ix, iy, iz, qx, qy, qz, k);
-            }
-          }
+  float mfrac = fmaxf(fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz)), 0.f);
+  const int rmax = (int)ceilf(sqrtf(g.max_d2) * g.inv_cs) + 1;
+  for (int r = 2; r <= rmax; r++) {
+    float guard = (float)(r - 1) * cs + mfrac - 2.f * eps;
+    if (fminf(k.d4, g.max_d2) <= guard * guard) return;
+    for (int dz = -r; dz <= r; dz++) {
+      float gz = axis_gap(qz, cz + dz, cs, eps);
+      for (int dy = -r; dy <= r; dy++) {
+        float gy = axis_gap(qy, cy + dy, cs, eps);
+        const bool face = (abs(dz) == r) || (abs(dy) == r);
+        for (int dx = -r; dx <= r; dx += (face ? 1 : 2 * r)) {
+          float gx = axis_gap(qx, cx + dx, cs, eps);
+          if (gx * gx + gy * gy + gz * gz > fminf(k.d4, g.max_d2)) continue;
+          uint2 rr = cell_range(g, cx + dx, cy + dy, cz + dz);
+          scan_range(g, rr.x, rr.y, qx, qy, qz, k);
         }
       }
     }
@@ -396,8 +381,9 @@ __device__ __forceinline__ void pair_of(int t, int& a, int& b) {
   b = row + rem;
 }
 
+// partial_out[t * stride] (t < 91) receives this block's sums
 __device__ __forceinline__ void block_reduce_rows(ReduceShared& sh, const double (&h)[12], double z, bool sel, double rinv,
-                                                  double* __restrict__ partial_out) {
+                                                  double* __restrict__ partial_out, int stride) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* col = sh.col[wave];
 #pragma unroll
@@ -429,31 +415,90 @@ __device__ __forceinline__ void block_reduce_rows(ReduceShared& sh, const double
     s += sh.part[1][threadIdx.x];
     s += sh.part[2][threadIdx.x];
     s += sh.part[3][threadIdx.x];
-    partial_out[threadIdx.x] = s;
+    partial_out[(size_t)threadIdx.x * stride] = s;
   } else if (threadIdx.x == 90) {
-    partial_out[90] = (double)(sh.cnt[0] + sh.cnt[1] + sh.cnt[2] + sh.cnt[3]);
+    partial_out[(size_t)90 * stride] = (double)(sh.cnt[0] + sh.cnt[1] + sh.cnt[2] + sh.cnt[3]);
   }
 }
 
+// blocks are remapped so that each XCD (block b runs on XCD b % 8) works on a CONTIGUOUS eighth of the point
+// stream: neighbouring scan points touch the same map cells, which then stay in that XCD's private 4 MiB L2
+__device__ __forceinline__ int xcd_remap(int b, int nb_real) {
+  const int per = (nb_real + 7) >> 3;  // the grid is launched with 8 * per blocks
+  return (b & 7) * per + (b >> 3);
+}
+
+// residual gate + Jacobian row of one point (src/laserMapping.cpp:999-1010, :1035-1071)
+struct RowOut {
+  double h[12];
+  double z;
+  bool sel;
+};
+__device__ __forceinline__ void residual_row(const PoseArg& ps, int imu_en, double bx, double by, double bz, double ix,
+                                             double iy, double iz, float wx, float wy, float wz, double pa, double pbn,
+                                             double pc, double pd, RowOut& o) {
+  float pd2 = (float)(pa * wx + pbn * wy + pc * wz + pd);
+  double pbnorm = sqrt(bx * bx + by * by + bz * bz);
+  float s = (float)(1 - 0.9 * fabsf(pd2) / sqrt(pbnorm));
+  if (s > 0.9) {
+    o.sel = true;
+    // normvec stores n̂ as float (:1004-1006); the Jacobian reads those floats back (:1046-1047)
+    double nx = (double)(float)pa, ny = (double)(float)pbn, nz = (double)(float)pc;
+    double tx = ps.R[0] * nx + ps.R[3] * ny + ps.R[6] * nz;  // R_end^T n̂
+    double ty = ps.R[1] * nx + ps.R[4] * ny + ps.R[7] * nz;
+    double tz = ps.R[2] * nx + ps.R[5] * ny + ps.R[8] * nz;
+    o.h[0] = -iz * ty + iy * tz;  // [p_I]x R_end^T n̂
+    o.h[1] = iz * tx - ix * tz;
+    o.h[2] = -iy * tx + ix * ty;
+    o.h[3] = nx; o.h[4] = ny; o.h[5] = nz;
+    if (imu_en) {
+      double ux = ps.RLI[0] * tx + ps.RLI[3] * ty + ps.RLI[6] * tz;  // R_LI^T R_end^T n̂
+      double uy = ps.RLI[1] * tx + ps.RLI[4] * ty + ps.RLI[7] * tz;
+      double uz = ps.RLI[2] * tx + ps.RLI[5] * ty + ps.RLI[8] * tz;
+      o.h[6] = -bz * uy + by * uz;  // [p_L]x ...
+      o.h[7] = bz * ux - bx * uz;
+      o.h[8] = -by * ux + bx * uy;
+      o.h[9] = tx; o.h[10] = ty; o.h[11] = tz;
+    }
+    o.z = -(double)pd2;
+  }
+}
+// esti_plane on 5 neighbours; returns validity and (n̂, d)
+__device__ __forceinline__ bool fit_plane(const float4 (&nb)[5], double plane_thr, double& pa, double& pbn, double& pc,
+                                          double& pd) {
+  double a[5][3] = {{nb[0].x, nb[0].y, nb[0].z}, {nb[1].x, nb[1].y, nb[1].z}, {nb[2].x, nb[2].y, nb[2].z},
+                    {nb[3].x, nb[3].y, nb[3].z}, {nb[4].x, nb[4].y, nb[4].z}};
+  double nv[3];
+  qr_solve_5x3(a, nv);
+  double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+  pa = nv[0] / nn; pbn = nv[1] / nn; pc = nv[2] / nn; pd = 1.0 / nn;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 5; j++)
+    if (fabs(pa * nb[j].x + pbn * nb[j].y + pc * nb[j].z + pd) > plane_thr) ok = false;
+  return ok;
+}
+
+__device__ __forceinline__ bool canon_ties(float4 (&nb)[5]);
+
 // ------------------------------------------------------------------------------------------------
-// The fused registration pass.  SEARCH = true: transform, 5-NN, plane fit, residual, Jacobian, reduce.
-// SEARCH = false: transform, residual against the cached plane (the reference re-fits the plane from the
-// unchanged neighbours every iteration, which reproduces the same coefficients — caching is exact),
-// Jacobian, reduce.  `selected` is sticky between searches exactly as point_selected_surf (quirk A11).
+// Variant 0: the fused registration pass, one lane per point.  SEARCH = true: transform, 5-NN, plane fit,
+// residual, Jacobian, reduce.  SEARCH = false: residual against the cached plane (the reference re-fits the plane
+// from the unchanged neighbours every iteration, which reproduces the same coefficients — caching is exact).
+// `selected` is sticky between searches exactly as point_selected_surf (quirk A11).
 template <bool SEARCH>
 __global__ __launch_bounds__(kBlock) void k_register(GridView g, RegistrationBuffers rb, PoseArg ps, int imu_en,
                                                       double plane_thr, double rinv) {
   __shared__ ReduceShared sh;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool live = i < rb.n;
-  double h[12];
+  RowOut o;
 #pragma unroll
-  for (int c = 0; c < 12; c++) h[c] = 0;
-  double z = 0;
-  bool sel = false;
+  for (int c = 0; c < 12; c++) o.h[c] = 0;
+  o.z = 0;
+  o.sel = false;
   if (live) {
     float4 pb = rb.body[i];
-    // pointBodyToWorld (src/laserMapping.cpp:209-220): double math, float store
     double bx = pb.x, by = pb.y, bz = pb.z;
     double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
     double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
@@ -469,93 +514,305 @@ __global__ __launch_bounds__(kBlock) void k_register(GridView g, RegistrationBuf
       knn5_search(g, wx, wy, wz, k);
       int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
       rb.nbr_count[i] = found;
-      float4 n0 = k.i0 >= 0 ? g.pts[k.i0] : make_float4(0, 0, 0, 0);
-      float4 n1 = k.i1 >= 0 ? g.pts[k.i1] : make_float4(0, 0, 0, 0);
-      float4 n2 = k.i2 >= 0 ? g.pts[k.i2] : make_float4(0, 0, 0, 0);
-      float4 n3 = k.i3 >= 0 ? g.pts[k.i3] : make_float4(0, 0, 0, 0);
-      float4 n4 = k.i4 >= 0 ? g.pts[k.i4] : make_float4(0, 0, 0, 0);
-      n0.w = k.d0; n1.w = k.d1; n2.w = k.d2; n3.w = k.d3; n4.w = k.d4;
-      rb.nbr[0 * (size_t)rb.cap + i] = n0;
-      rb.nbr[1 * (size_t)rb.cap + i] = n1;
-      rb.nbr[2 * (size_t)rb.cap + i] = n2;
-      rb.nbr[3 * (size_t)rb.cap + i] = n3;
-      rb.nbr[4 * (size_t)rb.cap + i] = n4;
-      // point_selected_surf[i] = found 5 && !(d2[4] > 5)   (:981-984)
-      candidate = (found == kMatch) && !(k.d4 > 5.0f);
-      bool plane_ok = false;
-      if (candidate) {
-        double a[5][3] = {{n0.x, n0.y, n0.z}, {n1.x, n1.y, n1.z}, {n2.x, n2.y, n2.z}, {n3.x, n3.y, n3.z}, {n4.x, n4.y, n4.z}};
-        double nv[3];
-        qr_solve_5x3(a, nv);
-        double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
-        pa = nv[0] / nn; pbn = nv[1] / nn; pc = nv[2] / nn; pd = 1.0 / nn;
-        plane_ok = true;
-        const float4 nb[5] = {n0, n1, n2, n3, n4};
+      float4 nb[5];
+      nb[0] = k.i0 >= 0 ? g.pts[k.i0] : make_float4(0, 0, 0, 0);
+      nb[1] = k.i1 >= 0 ? g.pts[k.i1] : make_float4(0, 0, 0, 0);
+      nb[2] = k.i2 >= 0 ? g.pts[k.i2] : make_float4(0, 0, 0, 0);
+      nb[3] = k.i3 >= 0 ? g.pts[k.i3] : make_float4(0, 0, 0, 0);
+      nb[4] = k.i4 >= 0 ? g.pts[k.i4] : make_float4(0, 0, 0, 0);
+      nb[0].w = k.d0; nb[1].w = k.d1; nb[2].w = k.d2; nb[3].w = k.d3; nb[4].w = k.d4;
+      if (found == kMatch) canon_ties(nb);
 #pragma unroll
-        for (int j = 0; j < 5; j++)
-          if (fabs(pa * nb[j].x + pbn * nb[j].y + pc * nb[j].z + pd) > plane_thr) plane_ok = false;
-      }
+      for (int j = 0; j < 5; j++) rb.nbr[(size_t)j * rb.cap + i] = nb[j];
+      candidate = (found == kMatch) && !(k.d4 > 5.0f);  // (:981-984)
+      if (candidate) candidate = fit_plane(nb, plane_thr, pa, pbn, pc, pd);
       double* pl = rb.plane + 4 * (size_t)i;
       pl[0] = pa; pl[1] = pbn; pl[2] = pc; pl[3] = pd;
-      candidate = candidate && plane_ok;
     } else {
-      // sticky: a point dropped in the previous pass stays dropped until the next search (:989-994)
+      candidate = rb.selected[i] != 0;  // sticky (:989-994)
+      const double* pl = rb.plane + 4 * (size_t)i;
+      pa = pl[0]; pbn = pl[1]; pc = pl[2]; pd = pl[3];
+    }
+    if (candidate) residual_row(ps, imu_en, bx, by, bz, ix, iy, iz, wx, wy, wz, pa, pbn, pc, pd, o);
+    rb.selected[i] = o.sel ? 1 : 0;
+  }
+  block_reduce_rows(sh, o.h, o.z, o.sel, rinv, rb.partials + blockIdx.x, rb.partial_stride);
+}
+template __global__ void k_register<true>(GridView, RegistrationBuffers, PoseArg, int, double, double);
+template __global__ void k_register<false>(GridView, RegistrationBuffers, PoseArg, int, double, double);
+
+// ------------------------------------------------------------------------------------------------
+// Variant 1 of the search pass: the k-NN runs with EIGHT lanes per query (8 queries per wavefront) so that the
+// cell lookups and candidate loads of one query are spread over independent lanes (memory-level parallelism
+// instead of one long dependent chain per lane); the per-lane top-5 lists are merged with a 3-step
+// wavefront-shuffle butterfly.
+template <bool DEDUP>
+__device__ __forceinline__ void knn_merge_one(Knn5& k, float e, int j) {
+  if (DEDUP && (j == k.i0 || j == k.i1 || j == k.i2 || j == k.i3 || j == k.i4)) return;
+  if (e < k.d4) knn_insert(k, e, j);
+}
+// butterfly merge over the 8 lanes of a query group; afterwards every lane holds the group's top-5.
+// DEDUP: the lists may share entries (phase 2 starts every lane from the merged list).
+template <bool DEDUP>
+__device__ __forceinline__ void knn_group_merge(Knn5& k) {
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    float e0 = __shfl_xor(k.d0, off), e1 = __shfl_xor(k.d1, off), e2 = __shfl_xor(k.d2, off), e3 = __shfl_xor(k.d3, off),
+          e4 = __shfl_xor(k.d4, off);
+    int j0 = __shfl_xor(k.i0, off), j1 = __shfl_xor(k.i1, off), j2 = __shfl_xor(k.i2, off), j3 = __shfl_xor(k.i3, off),
+        j4 = __shfl_xor(k.i4, off);
+    if (j0 >= 0) knn_merge_one<DEDUP>(k, e0, j0);
+    if (j1 >= 0) knn_merge_one<DEDUP>(k, e1, j1);
+    if (j2 >= 0) knn_merge_one<DEDUP>(k, e2, j2);
+    if (j3 >= 0) knn_merge_one<DEDUP>(k, e3, j3);
+    if (j4 >= 0) knn_merge_one<DEDUP>(k, e4, j4);
+  }
+}
+
+constexpr int kLanesPerQuery = 8;
+constexpr int kQueriesPerBlock = kBlock / kLanesPerQuery;  // 32
+
+__global__ __launch_bounds__(kBlock) void k_knn8(GridView g, RegistrationBuffers rb, PoseArg ps, int nb_real) {
+  const int blk = xcd_remap(blockIdx.x, nb_real);
+  if (blk >= nb_real) return;
+  const int sub = threadIdx.x & (kLanesPerQuery - 1);
+  const int qi = blk * kQueriesPerBlock + (threadIdx.x >> 3);
+  const bool live = qi < rb.n;
+  // dead query slots still take part in the shuffles; they search nothing
+  float wx = 0, wy = 0, wz = 0;
+  if (live) {
+    float4 pb = rb.body[qi];
+    double bx = pb.x, by = pb.y, bz = pb.z;
+    double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
+    double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
+    double iz = ps.RLI[6] * bx + ps.RLI[7] * by + ps.RLI[8] * bz + ps.TLI[2];
+    wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
+    wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
+    wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
+  }
+  const float INF = __builtin_inff();
+  Knn5 k;
+  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = INF;
+  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
+  const float cs = g.cs;
+  const float eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
+  const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
+  const bool active = live && g.n_pts > 0;
+  if (active) {
+    // phase 1: the 27 cells of the 3x3x3 block, cell c -> lane c % 8; all lookups of a lane are issued first
+    uint2 r0, r1, r2, r3 = make_uint2(0u, 0u);
+    int c = sub;
+    r0 = cell_range(g, cx + (c % 3) - 1, cy + ((c / 3) % 3) - 1, cz + (c / 9) - 1);
+    c = sub + 8;
+    r1 = cell_range(g, cx + (c % 3) - 1, cy + ((c / 3) % 3) - 1, cz + (c / 9) - 1);
+    c = sub + 16;
+    r2 = cell_range(g, cx + (c % 3) - 1, cy + ((c / 3) % 3) - 1, cz + (c / 9) - 1);
+    c = sub + 24;
+    if (c < 27) r3 = cell_range(g, cx + (c % 3) - 1, cy + ((c / 3) % 3) - 1, cz + (c / 9) - 1);
+    scan_range(g, r0.x, r0.y, wx, wy, wz, k);
+    scan_range(g, r1.x, r1.y, wx, wy, wz, k);
+    scan_range(g, r2.x, r2.y, wx, wy, wz, k);
+    scan_range(g, r3.x, r3.y, wx, wy, wz, k);
+  }
+  knn_group_merge<false>(k);
+  // lanes of a group can hold differently ordered lists when two candidates tie: use lane 0's
+  const int src = (threadIdx.x & 63) & ~(kLanesPerQuery - 1);
+  k.d0 = __shfl(k.d0, src); k.d1 = __shfl(k.d1, src); k.d2 = __shfl(k.d2, src); k.d3 = __shfl(k.d3, src); k.d4 = __shfl(k.d4, src);
+  k.i0 = __shfl(k.i0, src); k.i1 = __shfl(k.i1, src); k.i2 = __shfl(k.i2, src); k.i3 = __shfl(k.i3, src); k.i4 = __shfl(k.i4, src);
+  // guaranteed radius of the 3x3x3 block: cs + distance from q to the nearest face of its own cell.  Queries whose
+  // 5th-best distance exceeds it (sparse map / map frontier) are queued for k_knn_fallback.
+  float fx = wx - (float)cx * cs, fy = wy - (float)cy * cs, fz = wz - (float)cz * cs;
+  float mfrac = fmaxf(fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz)), 0.f);
+  float guard = cs + mfrac - 2.f * eps;
+  const bool need = active && !(fminf(k.d4, g.max_d2) <= guard * guard);
+  if (live) {
+    int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
+    if (sub < 5) {
+      int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : (sub == 3 ? k.i3 : k.i4)));
+      float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : (sub == 3 ? k.d3 : k.d4)));
+      float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
+      v.w = dd;
+      rb.nbr[(size_t)sub * rb.cap + qi] = v;
+    } else if (sub == 5) {
+      rb.nbr_count[qi] = found;
+    } else if (sub == 6) {
+      rb.world[qi] = make_float4(wx, wy, wz, 0.f);
+    } else if (need) {  // sub == 7
+      unsigned int slot = atomicAdd(rb.needy_count, 1u);
+      rb.needy[slot] = qi;
+    }
+  }
+}
+
+// Second stage of the search for the queued queries: ONE 256-thread workgroup per query visits every cell that
+// intersects the ball of radius sqrt(min(d5 of stage 1, max_d2)) — looked up through the 3x3x3 neighbourhood of
+// 8x8x8-cell blocks, so empty space costs nothing — and merges the per-lane lists (wave butterfly, then LDS).
+__global__ __launch_bounds__(kBlock) void k_knn_fallback(GridView g, RegistrationBuffers rb) {
+  __shared__ int s_block[27];
+  __shared__ float s_d[4][5];
+  __shared__ int s_i[4][5];
+  const unsigned int n_needy = *rb.needy_count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (unsigned int e = blockIdx.x; e < n_needy; e += gridDim.x) {
+    const int qi = rb.needy[e];
+    const float4 w4 = rb.world[qi];
+    const float wx = w4.x, wy = w4.y, wz = w4.z;
+    const float d5 = rb.nbr_count[qi] == kMatch ? rb.nbr[(size_t)4 * rb.cap + qi].w : __builtin_inff();
+    const float bound0 = fminf(d5, g.max_d2);
+    const float cs = g.cs;
+    const float eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
+    const float r0 = sqrtf(bound0) + 2.f * eps;
+    const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
+    const int X0 = cx >> kCoarseShift, Y0 = cy >> kCoarseShift, Z0 = cz >> kCoarseShift;
+    __syncthreads();  // previous query's shared data fully consumed
+    if (threadIdx.x < 27) {
+      const int c = threadIdx.x;
+      s_block[c] = find_block(g, X0 + (c % 3) - 1, Y0 + ((c / 3) % 3) - 1, Z0 + (c / 9) - 1);
+    }
+    __syncthreads();
+    const int ix0 = cell_of(wx - r0, g.inv_cs), ix1 = cell_of(wx + r0, g.inv_cs);
+    const int iy0 = cell_of(wy - r0, g.inv_cs), iy1 = cell_of(wy + r0, g.inv_cs);
+    const int iz0 = cell_of(wz - r0, g.inv_cs), iz1 = cell_of(wz + r0, g.inv_cs);
+    const int nx = ix1 - ix0 + 1, ny = iy1 - iy0 + 1, nz = iz1 - iz0 + 1;
+    const int total = nx * ny * nz;
+    Knn5 k;
+    k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = __builtin_inff();
+    k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
+    for (int c = threadIdx.x; c < total; c += kBlock) {
+      const int ixx = ix0 + c % nx, iyy = iy0 + (c / nx) % ny, izz = iz0 + c / (nx * ny);
+      const int X = (ixx >> kCoarseShift) - X0 + 1, Y = (iyy >> kCoarseShift) - Y0 + 1, Z = (izz >> kCoarseShift) - Z0 + 1;
+      if ((unsigned)X > 2u || (unsigned)Y > 2u || (unsigned)Z > 2u) continue;  // farther than 8 cells >= sqrt(max_d2)
+      const int id = s_block[Z * 9 + Y * 3 + X];
+      if (id < 0) continue;
+      const float gx = axis_gap(wx, ixx, cs, eps), gy = axis_gap(wy, iyy, cs, eps), gz = axis_gap(wz, izz, cs, eps);
+      if (gx * gx + gy * gy + gz * gz > bound0) continue;
+      const unsigned local = (((unsigned)izz & 7u) << 6) | (((unsigned)iyy & 7u) << 3) | ((unsigned)ixx & 7u);
+      const uint2 rr = g.cells[(size_t)id * kBlockCells + local];
+      scan_range(g, rr.x, rr.y, wx, wy, wz, k);
+    }
+    // wave butterfly (disjoint cell sets -> no duplicates), then the 4 wave results through LDS
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      float e0 = __shfl_xor(k.d0, off), e1 = __shfl_xor(k.d1, off), e2 = __shfl_xor(k.d2, off), e3 = __shfl_xor(k.d3, off),
+            e4 = __shfl_xor(k.d4, off);
+      int j0 = __shfl_xor(k.i0, off), j1 = __shfl_xor(k.i1, off), j2 = __shfl_xor(k.i2, off), j3 = __shfl_xor(k.i3, off),
+          j4 = __shfl_xor(k.i4, off);
+      if (j0 >= 0) knn_merge_one<false>(k, e0, j0);
+      if (j1 >= 0) knn_merge_one<false>(k, e1, j1);
+      if (j2 >= 0) knn_merge_one<false>(k, e2, j2);
+      if (j3 >= 0) knn_merge_one<false>(k, e3, j3);
+      if (j4 >= 0) knn_merge_one<false>(k, e4, j4);
+    }
+    if (lane == 0) {
+      s_d[wave][0] = k.d0; s_d[wave][1] = k.d1; s_d[wave][2] = k.d2; s_d[wave][3] = k.d3; s_d[wave][4] = k.d4;
+      s_i[wave][0] = k.i0; s_i[wave][1] = k.i1; s_i[wave][2] = k.i2; s_i[wave][3] = k.i3; s_i[wave][4] = k.i4;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; w++)
+        for (int j = 0; j < 5; j++)
+          if (s_i[w][j] >= 0) knn_merge_one<false>(k, s_d[w][j], s_i[w][j]);
+      const int ids[5] = {k.i0, k.i1, k.i2, k.i3, k.i4};
+      const float ds[5] = {k.d0, k.d1, k.d2, k.d3, k.d4};
+      int found = 0;
+      for (int j = 0; j < 5; j++) {
+        float4 v = ids[j] >= 0 ? g.pts[ids[j]] : make_float4(0, 0, 0, 0);
+        v.w = ds[j];
+        rb.nbr[(size_t)j * rb.cap + qi] = v;
+        found += ids[j] >= 0;
+      }
+      rb.nbr_count[qi] = found;
+    }
+  }
+}
+
+// Equal squared distances inside the kept list are ordered by x, ascending — what the reference's heap comparator
+// (PointType_CMP, include/ikd-Tree/ikd_Tree.h:50-61: ties within 1e-10 fall back to point.x) produces after
+// Nearest_Search pops it.  (A tie across the 5th/6th place is resolved by visiting order in the tree and by
+// cell order here; that case cannot be reproduced and is documented in DESIGN.md.)
+__device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
+  bool changed = false;
+#pragma unroll
+  for (int pass = 0; pass < 4; pass++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (nb[j].w == nb[j + 1].w && nb[j].x > nb[j + 1].x) {
+        float4 t = nb[j]; nb[j] = nb[j + 1]; nb[j + 1] = t;
+        changed = true;
+      }
+  return changed;
+}
+
+// Plane fit + residual + Jacobian + block reduction, one lane per point.  FIT = true right after a k_knn8
+// pass (reads the 5 neighbours, caches the plane); FIT = false for the non-search iterations.
+template <bool FIT>
+__global__ __launch_bounds__(kBlock) void k_fit_reduce(RegistrationBuffers rb, PoseArg ps, int imu_en, double plane_thr,
+                                                        double rinv, int nb_real) {
+  __shared__ ReduceShared sh;
+  const int blk = xcd_remap(blockIdx.x, nb_real);
+  if (blk >= nb_real) return;  // uniform per block
+  const int i = blk * kBlock + threadIdx.x;
+  const bool live = i < rb.n;
+  RowOut o;
+#pragma unroll
+  for (int c = 0; c < 12; c++) o.h[c] = 0;
+  o.z = 0;
+  o.sel = false;
+  if (live) {
+    float4 pb = rb.body[i];
+    double bx = pb.x, by = pb.y, bz = pb.z;
+    double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
+    double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
+    double iz = ps.RLI[6] * bx + ps.RLI[7] * by + ps.RLI[8] * bz + ps.TLI[2];
+    float wx, wy, wz;
+    double pa = 0, pbn = 0, pc = 0, pd = 0;
+    bool candidate;
+    if (FIT) {
+      float4 w4 = rb.world[i];  // written by k_knn8 with the same arithmetic
+      wx = w4.x; wy = w4.y; wz = w4.z;
+      const int found = rb.nbr_count[i];
+      float4 nb[5];
+#pragma unroll
+      for (int j = 0; j < 5; j++) nb[j] = rb.nbr[(size_t)j * rb.cap + i];
+      if (found == kMatch && canon_ties(nb)) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) rb.nbr[(size_t)j * rb.cap + i] = nb[j];
+      }
+      candidate = (found == kMatch) && !(nb[4].w > 5.0f);
+      if (candidate) candidate = fit_plane(nb, plane_thr, pa, pbn, pc, pd);
+      double* pl = rb.plane + 4 * (size_t)i;
+      pl[0] = pa; pl[1] = pbn; pl[2] = pc; pl[3] = pd;
+    } else {
+      wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
+      wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
+      wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
+      rb.world[i] = make_float4(wx, wy, wz, 0.f);
       candidate = rb.selected[i] != 0;
       const double* pl = rb.plane + 4 * (size_t)i;
       pa = pl[0]; pbn = pl[1]; pc = pl[2]; pd = pl[3];
     }
-    if (candidate) {
-      float pd2 = (float)(pa * wx + pbn * wy + pc * wz + pd);
-      double pbnorm = sqrt(bx * bx + by * by + bz * bz);
-      float s = (float)(1 - 0.9 * fabsf(pd2) / sqrt(pbnorm));
-      if (s > 0.9) {
-        sel = true;
-        // normvec stores n̂ as float (:1004-1006); the Jacobian reads those floats back (:1046-1047)
-        double nx = (double)(float)pa, ny = (double)(float)pbn, nz = (double)(float)pc;
-        // A = [p_I]x R_end^T n̂ ; rows (:1054-1066)
-        double tx = ps.R[0] * nx + ps.R[3] * ny + ps.R[6] * nz;
-        double ty = ps.R[1] * nx + ps.R[4] * ny + ps.R[7] * nz;
-        double tz = ps.R[2] * nx + ps.R[5] * ny + ps.R[8] * nz;
-        h[0] = -iz * ty + iy * tz;
-        h[1] = iz * tx - ix * tz;
-        h[2] = -iy * tx + ix * ty;
-        h[3] = nx; h[4] = ny; h[5] = nz;
-        if (imu_en) {
-          // H_R_LI = [p_L]x R_LI^T R_end^T n̂ ; H_T_LI = R_end^T n̂
-          double ux = ps.RLI[0] * tx + ps.RLI[3] * ty + ps.RLI[6] * tz;
-          double uy = ps.RLI[1] * tx + ps.RLI[4] * ty + ps.RLI[7] * tz;
-          double uz = ps.RLI[2] * tx + ps.RLI[5] * ty + ps.RLI[8] * tz;
-          h[6] = -bz * uy + by * uz;
-          h[7] = bz * ux - bx * uz;
-          h[8] = -by * ux + bx * uy;
-          h[9] = tx; h[10] = ty; h[11] = tz;
-        }
-        z = -(double)pd2;
-      }
-    }
-    rb.selected[i] = sel ? 1 : 0;
+    if (candidate) residual_row(ps, imu_en, bx, by, bz, ix, iy, iz, wx, wy, wz, pa, pbn, pc, pd, o);
+    rb.selected[i] = o.sel ? 1 : 0;
   }
-  block_reduce_rows(sh, h, z, sel, rinv, rb.partials + (size_t)blockIdx.x * kNormalEq);
+  block_reduce_rows(sh, o.h, o.z, o.sel, rinv, rb.partials + blk, rb.partial_stride);
 }
+template __global__ void k_fit_reduce<true>(RegistrationBuffers, PoseArg, int, double, double, int);
+template __global__ void k_fit_reduce<false>(RegistrationBuffers, PoseArg, int, double, double, int);
 
-template __global__ void k_register<true>(GridView, RegistrationBuffers, PoseArg, int, double, double);
-template __global__ void k_register<false>(GridView, RegistrationBuffers, PoseArg, int, double, double);
-
-// Deterministic final reduction: out[t] = sum over blocks (fixed order).  One block of 8 x 128 threads.
-__global__ __launch_bounds__(1024) void k_reduce91(const double* __restrict__ partials, int n_blocks, double* __restrict__ out) {
-  __shared__ double sh[8][kNormalEq];
-  const int t = threadIdx.x & 127, s = threadIdx.x >> 7;
-  if (t < kNormalEq) {
-    double acc = 0;
-    for (int b = s; b < n_blocks; b += 8) acc += partials[(size_t)b * kNormalEq + t];
-    sh[s][t] = acc;
-  }
-  __syncthreads();
-  if (threadIdx.x < kNormalEq) {
-    double acc = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) acc += sh[k][threadIdx.x];
-    out[threadIdx.x] = acc;
+// Deterministic final reduction of the transposed partials: out[t] = sum_b partials[t * stride + b].
+// One 64-lane workgroup per output: coalesced loads, per-lane sums over b = lane + 64 k in a fixed order, then a
+// fixed shuffle tree.  (91 independent workgroups: the partials were written by other XCDs, so every load is an
+// L2 miss; one latency instead of a dependent chain of them.)  Workgroup 0 also re-arms the fallback queue.
+__global__ __launch_bounds__(64) void k_reduce91(const double* __restrict__ partials, int n_blocks, int stride,
+                                                  double* __restrict__ out, unsigned int* needy_count) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const double* row = partials + (size_t)t * stride;
+  double acc = 0;
+  for (int b = lane; b < n_blocks; b += 64) acc += row[b];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if (lane == 0) {
+    out[t] = acc;
+    if (t == 0) *needy_count = 0u;
   }
 }
 
@@ -567,20 +824,25 @@ __device__ __forceinline__ unsigned int f2ord(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 // extent[0] = (ord(t_min) << 32) | index of the first point with that time ; extent[1] = ord(t_max)
-__global__ void k_time_extent(const float4* __restrict__ pts, int n, unsigned long long* __restrict__ extent) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// grid-stride over a small grid, wave shuffle + LDS reduction, ONE pair of atomics per block
+__global__ __launch_bounds__(256) void k_time_extent(const float4* __restrict__ pts, int n, unsigned long long* __restrict__ extent) {
+  __shared__ unsigned long long smn[4], smx[4];
   unsigned long long mn = ~0ull, mx = 0;
-  if (i < n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     unsigned int o = f2ord(pts[i].w);
-    mn = ((unsigned long long)o << 32) | (unsigned)i;
-    mx = o;
+    unsigned long long a = ((unsigned long long)o << 32) | (unsigned)i;
+    mn = a < mn ? a : mn;
+    mx = (unsigned long long)o > mx ? (unsigned long long)o : mx;
   }
   for (int off = 32; off > 0; off >>= 1) {
     unsigned long long a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
     mn = a < mn ? a : mn;
     mx = b > mx ? b : mx;
   }
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) { mn = smn[w] < mn ? smn[w] : mn; mx = smx[w] > mx ? smx[w] : mx; }
     atomicMin(&extent[0], mn);
     atomicMax(&extent[1], mx);
   }
@@ -909,20 +1171,19 @@ void launch_map_keys(const float4* pts, int n, float inv_cs, unsigned long long*
 void launch_map_gather(const float4* src, const unsigned int* idx, int n, float4* dst, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_map_gather, dim3(nblk(n, 256)), dim3(256), 0, s, src, idx, n, dst);
 }
-void launch_cells_count(const unsigned long long* keys, int n, unsigned int* n_cells, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_cells_count, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, n_cells);
+void launch_block_flags(const unsigned long long* keys, int n, unsigned int* flags, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_block_flags, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, flags);
 }
-void launch_table_clear(CellEntry* fine, unsigned int fine_cap, unsigned long long* coarse, unsigned int coarse_cap, hipStream_t s) {
-  unsigned int m = fine_cap > coarse_cap ? fine_cap : coarse_cap;
-  hipLaunchKernelGGL(k_table_clear, dim3(nblk((int)m, 256)), dim3(256), 0, s, fine, fine_cap, coarse, coarse_cap);
+void launch_table_clear(BlockEntry* blocks, unsigned int cap, hipStream_t s) {
+  hipLaunchKernelGGL(k_table_clear, dim3(nblk((int)cap, 256)), dim3(256), 0, s, blocks, cap);
 }
-void launch_cells_insert(const unsigned long long* keys, int n, CellEntry* fine, unsigned int fine_mask,
-                         unsigned long long* coarse, unsigned int coarse_mask, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_cells_insert, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, fine, fine_mask, coarse, coarse_mask);
+void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks, int n, BlockEntry* blocks,
+                       unsigned int block_mask, uint2* cells, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_cells_fill, dim3(nblk(n, 256)), dim3(256), 0, s, keys, ranks, n, blocks, block_mask, cells);
 }
 int register_blocks(int n) { return nblk(n, kBlock); }
-void launch_register(bool search, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en,
-                     double plane_thr, double rinv, hipStream_t s) {
+void launch_register_fused(bool search, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en,
+                           double plane_thr, double rinv, hipStream_t s) {
   int nb = nblk(rb.n, kBlock);
   if (nb < 1) nb = 1;
   if (search)
@@ -930,10 +1191,27 @@ void launch_register(bool search, const GridView& g, const RegistrationBuffers& 
   else
     hipLaunchKernelGGL(k_register<false>, dim3(nb), dim3(kBlock), 0, s, g, rb, ps, imu_en, plane_thr, rinv);
 }
-void launch_reduce91(const double* partials, int n_points, double* out91, hipStream_t s) {
+void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, hipStream_t s) {
+  int nq = nblk(rb.n, kQueriesPerBlock);
+  if (nq < 1) nq = 1;
+  const int nq_pad = ((nq + 7) / 8) * 8;
+  hipLaunchKernelGGL(k_knn8, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, nq);
+  hipLaunchKernelGGL(k_knn_fallback, dim3(512), dim3(kBlock), 0, s, g, rb);
+}
+void launch_fit_reduce(bool fit, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en, double plane_thr, double rinv,
+                       hipStream_t s) {
+  int nb = nblk(rb.n, kBlock);
+  if (nb < 1) nb = 1;
+  const int nb_pad = ((nb + 7) / 8) * 8;
+  if (fit)
+    hipLaunchKernelGGL(k_fit_reduce<true>, dim3(nb_pad), dim3(kBlock), 0, s, rb, ps, imu_en, plane_thr, rinv, nb);
+  else
+    hipLaunchKernelGGL(k_fit_reduce<false>, dim3(nb_pad), dim3(kBlock), 0, s, rb, ps, imu_en, plane_thr, rinv, nb);
+}
+void launch_reduce91(const double* partials, int n_points, int stride, double* out91, unsigned int* needy_count, hipStream_t s) {
   int nb = nblk(n_points, kBlock);
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_reduce91, dim3(1), dim3(1024), 0, s, partials, nb, out91);
+  hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, needy_count);
 }
 __global__ void k_extent_init(unsigned long long* e) {
   e[0] = ~0ull;
@@ -941,7 +1219,11 @@ __global__ void k_extent_init(unsigned long long* e) {
 }
 void launch_time_extent(const float4* pts, int n, unsigned long long* extent, hipStream_t s) {
   hipLaunchKernelGGL(k_extent_init, dim3(1), dim3(1), 0, s, extent);
-  if (n > 0) hipLaunchKernelGGL(k_time_extent, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, extent);
+  if (n > 0) {
+    int nb = nblk(n, 256 * 8);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(k_time_extent, dim3(nb), dim3(256), 0, s, pts, n, extent);
+  }
 }
 void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& uh,
                           const unsigned long long* extent, hipStream_t s) {

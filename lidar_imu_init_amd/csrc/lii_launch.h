@@ -14,14 +14,17 @@ struct VoxelArgH { float inv_leaf; int min_b[3]; int mul[3]; };
 // map index
 void launch_map_keys(const float4* pts, int n, float inv_cs, unsigned long long* keys, unsigned int* idx, hipStream_t s);
 void launch_map_gather(const float4* src, const unsigned int* idx, int n, float4* dst, hipStream_t s);
-void launch_cells_count(const unsigned long long* keys, int n, unsigned int* n_cells, hipStream_t s);
-void launch_table_clear(CellEntry* fine, unsigned int fine_cap, unsigned long long* coarse, unsigned int coarse_cap, hipStream_t s);
-void launch_cells_insert(const unsigned long long* keys, int n, CellEntry* fine, unsigned int fine_mask,
-                         unsigned long long* coarse, unsigned int coarse_mask, hipStream_t s);
+void launch_block_flags(const unsigned long long* keys, int n, unsigned int* flags, hipStream_t s);
+void launch_table_clear(BlockEntry* blocks, unsigned int cap, hipStream_t s);
+void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks, int n, BlockEntry* blocks,
+                       unsigned int block_mask, uint2* cells, hipStream_t s);
 // registration
-void launch_register(bool search, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en,
-                     double plane_thr, double rinv, hipStream_t s);
-void launch_reduce91(const double* partials, int n_points, double* out91, hipStream_t s);
+void launch_register_fused(bool search, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en,
+                           double plane_thr, double rinv, hipStream_t s);
+void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, hipStream_t s);
+void launch_fit_reduce(bool fit, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en, double plane_thr, double rinv,
+                       hipStream_t s);
+void launch_reduce91(const double* partials, int n_points, int stride, double* out91, unsigned int* needy_count, hipStream_t s);
 int register_blocks(int n);
 // undistortion
 void launch_time_extent(const float4* pts, int n, unsigned long long* extent, hipStream_t s);
