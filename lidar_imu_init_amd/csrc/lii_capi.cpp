@@ -56,6 +56,10 @@ struct lii_context {
   double* d_plane = nullptr;
   unsigned char* d_selected = nullptr;
   int* d_needy = nullptr;
+  IekfCtrl* d_ctrl = nullptr;   // device-resident loop state of lii_iekf_update
+  PoseArg* d_pose = nullptr;    // pose slot of the host-driven lii_iekf_iterate
+  IekfCtrl* h_ctrl = nullptr;   // pinned mirror
+  bool host_solve = false;      // LII_HOST_SOLVE=1: drive the loop from the host (A/B, reference arrangement)
   double* d_partials = nullptr;
   double* d_out91 = nullptr;
   unsigned long long* d_extent = nullptr;
@@ -221,12 +225,14 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
     launch_register_fused(search, g, rb, ps, imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, h->stream);
     if (prof) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
   } else {
-    if (search) launch_knn8(g, rb, ps, h->stream);
+    if (search) launch_knn8(g, rb, ps, h->d_pose, h->d_ctrl, 1, h->stream);
     if (prof) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
-    launch_fit_reduce(search, rb, ps, imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, h->stream);
+    if (search) launch_knn_fallback(g, rb, h->d_ctrl, 1, h->stream);
+    launch_fit_reduce(rb, ps, h->d_pose, h->d_ctrl, search ? 1 : 0, imu_en ? 1 : 0, h->cfg.plane_threshold,
+                      h->cfg.laser_point_cov_inv, h->stream);
   }
   if (prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-  launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->stream);
+  launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, 1, h->stream);
   if (prof) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
   if (search) h->have_search = true;
   if (h->comm) {
@@ -248,6 +254,72 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
       h->timings[0] += a; h->timings[5] += 1; h->timings[7] += k;  // [7]: the k-NN kernel alone
     } else { h->timings[1] += a; h->timings[6] += 1; }
     h->timings[2] += b;
+  }
+  return LII_OK;
+}
+
+// The whole iterated update enqueued once: prologue (P^-1), then max_iterations x {k-NN, fallback, fit+reduce,
+// final reduce, 24-state solve}; every kernel consults the device-resident control block and returns at once when
+// its pass is not due (no search scheduled / loop already stopped).  One synchronisation at the end.
+int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop, const lii_iekf_opts* opts,
+                     lii_iekf_report* report) {
+  static_assert(sizeof(lii_state) == sizeof(double) * kStateDoubles, "lii_state layout");
+  if (h->n_body <= 0) return fail(h, LII_ERR_STATE, "no down-sampled scan (call lii_downsample / lii_downsample_skip)");
+  int rc = commit_map(h);
+  if (rc != LII_OK) return rc;
+  hipStream_t s = h->stream;
+  IekfCtrl* hc = h->h_ctrl;
+  std::memcpy(hc->st, state, sizeof(lii_state));
+  std::memcpy(hc->prop, state_prop, sizeof(lii_state));
+  hc->max_it = opts->max_iterations;
+  hc->imu_en = opts->imu_en;
+  hc->it = 0; hc->search_next = 1; hc->stop = 0; hc->rematch_num = 0; hc->converged = 0; hc->searches = 0;
+  hc->effect_num = 0; hc->singular = 0;
+  HIPCHK(h, hipMemcpyAsync(h->d_ctrl, hc, sizeof(IekfCtrl), hipMemcpyHostToDevice, s));
+  launch_iekf_begin(h->d_ctrl, s);
+  GridView g = grid_view(h);
+  RegistrationBuffers rb = reg_buffers(h);
+  const PoseArg* pose = reinterpret_cast<const PoseArg*>(h->d_ctrl);  // first 24 doubles of IekfCtrl::st
+  const PoseArg ps0 = pose_of(*state);  // unused by the device-driven kernels (they read `pose`)
+  const bool prof = h->profiling;
+  const double* ne = h->comm ? h->d_out91 + 128 : h->d_out91;
+  for (int it = 0; it < opts->max_iterations; it++) {
+    const bool timed = prof && it == 0;  // the first pass always searches
+    if (timed) HIPCHK(h, hipEventRecord(h->ev[0], s));
+    launch_knn8(g, rb, ps0, pose, h->d_ctrl, -1, s);
+    if (timed) HIPCHK(h, hipEventRecord(h->ev[3], s));
+    launch_knn_fallback(g, rb, h->d_ctrl, -1, s);
+    launch_fit_reduce(rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
+    if (timed) HIPCHK(h, hipEventRecord(h->ev[1], s));
+    launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, -1, s);
+    if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
+    if (h->comm) {
+      // every rank enqueues the same number of all-reduces; a pass that is skipped on the device re-sums the
+      // unchanged local buffer on all ranks alike, so the ranks stay in lock-step without a host decision
+      ncclResult_t r = ncclAllReduce(h->d_out91, h->d_out91 + 128, kNormalEq, ncclDouble, ncclSum, h->comm, s);
+      if (r != ncclSuccess) return fail(h, LII_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    }
+    launch_iekf_solve(h->d_ctrl, ne, s);
+  }
+  HIPCHK(h, hipMemcpyAsync(hc, h->d_ctrl, sizeof(IekfCtrl), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(h->h_small, ne, sizeof(double) * kNormalEq, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  h->have_search = true;
+  if (hc->singular) return fail(h, LII_ERR_INVALID, "singular covariance / normal matrix in the device solve");
+  std::memcpy(state, hc->st, sizeof(lii_state));
+  if (report) {
+    report->iterations = hc->it;
+    report->searches = hc->searches;
+    report->effect_num = hc->effect_num;
+    report->converged = hc->converged;
+    std::memcpy(report->normal_eq, h->h_small, sizeof(double) * kNormalEq);
+  }
+  if (prof) {
+    float a = 0, b = 0, k = 0;
+    HIPCHK(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    HIPCHK(h, hipEventElapsedTime(&k, h->ev[0], h->ev[3]));
+    h->timings[0] += a; h->timings[5] += 1; h->timings[7] += k; h->timings[2] += b;
   }
   return LII_OK;
 }
@@ -298,6 +370,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   // the 3x3x3 neighbourhood of 8x8x8-cell blocks must cover the acceptance radius sqrt(max_match_dist2)
   h->cell_size = std::max(h->cell_size, std::sqrt(h->cfg.max_match_dist2) / 8.0f * 1.001f);
   if (const char* v = std::getenv("LII_KNN_VARIANT")) h->knn_variant = std::atoi(v);  // A/B knob for profiling
+  if (const char* v = std::getenv("LII_HOST_SOLVE")) h->host_solve = std::atoi(v) != 0;
   h->hmap.set_downsample(h->cfg.map_downsample_size);
   h->hmap.clear();
   h->device = cfg->device;
@@ -343,10 +416,13 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_plane, N * 4));
   CK(dmalloc(&h->d_selected, N));
   CK(dmalloc(&h->d_needy, N));
+  CK(dmalloc(&h->d_ctrl, 1));
+  CK(dmalloc(&h->d_pose, 1));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_ctrl), sizeof(IekfCtrl), hipHostMallocDefault));
   CK(hipMemset(h->d_counter, 0, 16));
   h->partial_stride = register_blocks(int(N)) + 8;
   CK(dmalloc(&h->d_partials, size_t(h->partial_stride) * kNormalEq));
-  CK(dmalloc(&h->d_out91, 128));
+  CK(dmalloc(&h->d_out91, 256));  // [0,91): local sums, [128,219): all-reduced sums (sharded scans)
   CK(dmalloc(&h->d_extent, 2));
   CK(dmalloc(&h->d_mm, 8));
   CK(dmalloc(&h->d_vkeys_a, N));
@@ -376,13 +452,14 @@ int lii_destroy(lii_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
-                 h->d_selected, h->d_needy, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
+                 h->d_selected, h->d_needy, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
                  h->d_vidx_b, h->d_vflags, h->d_vranks, h->d_poses, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (h->h_stage) (void)hipHostFree(h->h_stage);
   if (h->h_small) (void)hipHostFree(h->h_small);
+  if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
   for (int i = 0; i < 4; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -591,6 +668,11 @@ int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_prop,
   if (!h || !state || !state_prop || !opts || opts->max_iterations < 1) return fail(h, LII_ERR_INVALID, "lii_iekf_update: bad arguments");
   const int max_it = opts->max_iterations;
   auto t_begin = std::chrono::steady_clock::now();
+  if (!h->host_solve && h->knn_variant != 0) {
+    int rc = update_on_device(h, state, state_prop, opts, report);
+    h->timings[4] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return rc;
+  }
   double host_ms = 0;
   // cov is constant inside the loop (it is only rewritten on exit, :1112-1114), so invert it once
   std::vector<double> Pinv(kDim * kDim), A(kDim * kDim), K1(kDim * kDim), KH(kDim * 12), G(kDim * kDim);

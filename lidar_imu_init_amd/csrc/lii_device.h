@@ -58,4 +58,28 @@ struct RegistrationBuffers {
   int cap;
 };
 
+// Device-resident control block of one scan registration (lii_iekf_update): the state, the propagated state and
+// the loop flags of src/laserMapping.cpp:957-1134 live in HBM so that the whole iterated update is enqueued once
+// and synchronised once.  The first 24 doubles of `st` are exactly a PoseArg (rot_end, pos_end, offset_R_L_I,
+// offset_T_L_I of lii_state), which the per-point kernels read through a pointer.
+constexpr int kStateDoubles = 36 + 24 * 24;
+struct IekfCtrl {
+  double st[kStateDoubles];    // lii_state: current estimate (in/out)
+  double prop[kStateDoubles];  // lii_state: state_propagat
+  double Pinv[24 * 24];        // inverse of the prior covariance (constant during the loop)
+  double KH[24 * 12];          // K * Hsub of the last iteration
+  double solution[24];
+  int max_it;
+  int imu_en;
+  int it;            // iterations executed so far
+  int search_next;   // nearest_search_en of the next pass
+  int stop;          // EKF_stop_flg
+  int rematch_num;
+  int converged;     // flg_EKF_converged of the last iteration
+  int searches;      // k-NN passes executed
+  int effect_num;    // effect_feat_num of the last iteration
+  int singular;      // a matrix inversion failed
+  int pad[2];
+};
+
 }  // namespace lii

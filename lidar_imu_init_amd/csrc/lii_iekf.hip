@@ -1,0 +1,267 @@
+// On-device 24-state solve of the iterated Kalman update — the host algebra of lii_iekf_update moved into one
+// single-wavefront kernel per iteration so that a scan registration needs ONE host synchronisation.
+// Reference code replaced (src/laserMapping.cpp): K_1 = (H^T R^-1 H (+) 0 + P^-1)^-1 and the state update :1080-1087,
+// convergence test :1093-1096, rematch schedule :1102-1106, covariance update :1109-1131;
+// StatesGroup boxplus/boxminus include/common_lib.h:126-154; Exp/Log include/so3_math.h:61-107.
+// The arithmetic mirrors lii_hostmath.h operation for operation (LU with partial pivoting, same loop orders), so the
+// device-driven and the host-driven update agree to rounding of sin/cos/acos.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <cstring>
+#include <math.h>
+
+#include "lii_device.h"
+#include "lii_launch.h"
+
+namespace lii {
+
+constexpr int N = 24;
+constexpr int H = 12;    // columns of the measurement Jacobian (pose + extrinsic)
+constexpr int LDH = 13;  // padded leading dimension of the 12-column LDS tiles
+
+// The gain needs only the first 12 columns of K_1 = (H^T R^-1 H (+) 0 + P^-1)^-1.  With G = H^T R^-1 H (12 x 12, PSD),
+// E = [I_12; 0] and P = [P11 P12; P21 P22]:
+//     K_1 = (P^-1 + E G E^T)^-1 = (I + P E G E^T)^-1 P,     I + P E G E^T = [ I + P11 G   0 ]
+//                                                                            [   P21 G     I ]
+//  => K_1[:, :12] = [ M P11 ; P21 - P21 G M P11 ],   M = (I + P11 G)^-1   (eigenvalues of P11 G are >= 0: always regular).
+// This is the reference's formula (src/laserMapping.cpp:1081) in exact arithmetic, with ONE 12 x 12 inversion instead of
+// two 24 x 24 ones (the reference's own route loses ~cond(P) eps); the host-driven path (LII_HOST_SOLVE=1) keeps the
+// literal two-inversion form, and tests/test_gpu_register.py holds both to the oracle.
+//
+// 12 x 12 Gauss-Jordan with partial pivoting, register resident: lane c < 24 owns column c of [A | I]; the multiplier
+// column is broadcast with constant-lane shuffles, all register indices are static (fully unrolled).
+__device__ bool gj12(double (&col)[H]) {
+#pragma unroll
+  for (int k = 0; k < H; k++) {
+    double m[H];
+#pragma unroll
+    for (int r = 0; r < H; r++) m[r] = __shfl(col[r], k);
+    int p = k;
+    double best = fabs(m[k]);
+#pragma unroll
+    for (int r = k + 1; r < H; r++) {
+      const double v = fabs(m[r]);
+      if (v > best) { best = v; p = r; }
+    }
+    if (best == 0.0) return false;
+    double colp = col[k], mp = m[k];
+#pragma unroll
+    for (int r = k + 1; r < H; r++)
+      if (r == p) { colp = col[r]; mp = m[r]; col[r] = col[k]; m[r] = m[k]; }
+    col[k] = colp;
+    m[k] = mp;
+    const double rowk = col[k] / m[k];
+#pragma unroll
+    for (int r = 0; r < H; r++)
+      if (r != k) col[r] -= m[r] * rowk;
+    col[k] = rowk;
+  }
+  return true;
+}
+
+__device__ void d_m3_mul(const double* A, const double* B, double* C) {
+  double t[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) t[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+  for (int e = 0; e < 9; e++) C[e] = t[e];
+}
+__device__ void d_m3t_mul(const double* A, const double* B, double* C) {
+  double t[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) t[3 * r + c] = A[r] * B[c] + A[3 + r] * B[3 + c] + A[6 + r] * B[6 + c];
+  for (int e = 0; e < 9; e++) C[e] = t[e];
+}
+// Exp(v1,v2,v3) — so3_math.h:61-79 (identity below 1e-5)
+__device__ void d_so3_exp(double v1, double v2, double v3, double* R) {
+  double n = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+  for (int e = 0; e < 9; e++) R[e] = (e % 4 == 0) ? 1.0 : 0.0;
+  if (n > 0.00001) {
+    double ax[3] = {v1 / n, v2 / n, v3 / n};
+    double K[9] = {0, -ax[2], ax[1], ax[2], 0, -ax[0], -ax[1], ax[0], 0};
+    double KK[9];
+    d_m3_mul(K, K, KK);
+    double s = sin(n), c1 = 1.0 - cos(n);
+    for (int e = 0; e < 9; e++) R[e] += s * K[e] + c1 * KK[e];
+  }
+}
+__device__ void d_so3_log(const double* R, double* out) {
+  double tr = R[0] + R[4] + R[8];
+  double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
+  double K[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+  double f = (fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / sin(theta));
+  out[0] = f * K[0]; out[1] = f * K[1]; out[2] = f * K[2];
+}
+
+// Per-scan prologue: the loop flags.
+__global__ __launch_bounds__(64) void k_iekf_begin(IekfCtrl* c) {
+  if (threadIdx.x == 0) {
+    c->it = 0;
+    c->search_next = 1;
+    c->stop = 0;
+    c->rematch_num = 0;
+    c->converged = 0;
+    c->searches = 0;
+    c->effect_num = 0;
+    c->singular = 0;
+  }
+}
+
+// One iteration's solve + state update + schedule.  ne = the 91 reduced normal-equation scalars of this pass.
+__global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __restrict__ ne) {
+  __shared__ double Pc[N * LDH];   // first 12 columns of the prior covariance: rows 0..11 = P11, rows 12..23 = P21
+  __shared__ double G[H * LDH];    // H^T R^-1 H
+  __shared__ double A[H * LDH];    // I + P11 G, later M
+  __shared__ double K1c[N * LDH];  // K_1[:, :12]
+  __shared__ double Y[H * LDH];    // P21 G
+  __shared__ double vec[N], sol[N];
+  __shared__ int s_flags[2];
+  if (c->stop) return;
+  const int lane = threadIdx.x;
+  const double* cov = c->st + 36;
+  if (lane == 0 && c->search_next) c->searches += 1;
+  if (lane == 0) {
+    int t = 0;
+    for (int i = 0; i < H; i++)
+      for (int j = i; j < H; j++) { G[i * LDH + j] = ne[t]; G[j * LDH + i] = ne[t]; t++; }
+  }
+  for (int e = lane; e < N * H; e += 64) Pc[(e / H) * LDH + e % H] = cov[(e / H) * N + e % H];
+  // vec = state_propagat (-) state   (lane 1, overlapping nothing critical: it is tiny)
+  if (lane == 1) {
+    const double* A_ = c->prop;
+    const double* B_ = c->st;
+    double R[9];
+    d_m3t_mul(B_, A_, R);
+    d_so3_log(R, vec);
+    d_m3t_mul(B_ + 12, A_ + 12, R);
+    d_so3_log(R, vec + 6);
+    for (int i = 0; i < 3; i++) {
+      vec[3 + i] = A_[9 + i] - B_[9 + i];
+      vec[9 + i] = A_[21 + i] - B_[21 + i];
+      vec[12 + i] = A_[24 + i] - B_[24 + i];
+      vec[15 + i] = A_[27 + i] - B_[27 + i];
+      vec[18 + i] = A_[30 + i] - B_[30 + i];
+      vec[21 + i] = A_[33 + i] - B_[33 + i];
+    }
+  }
+  __syncthreads();
+  // A = I + P11 G
+  for (int e = lane; e < H * H; e += 64) {
+    const int i = e / H, j = e % H;
+    double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < H; k++) s += Pc[i * LDH + k] * G[k * LDH + j];
+    A[i * LDH + j] = s;
+  }
+  __syncthreads();
+  // M = A^-1 : lanes 0..11 hold the columns of A, lanes 12..23 those of I
+  double col[H];
+#pragma unroll
+  for (int r = 0; r < H; r++) col[r] = lane < H ? A[r * LDH + lane] : ((lane < 2 * H && r == lane - H) ? 1.0 : 0.0);
+  const bool ok = gj12(col);
+  if (!ok) {
+    if (lane == 0) { c->stop = 1; c->singular = 1; }
+    return;
+  }
+  __syncthreads();
+  if (lane >= H && lane < 2 * H) {
+#pragma unroll
+    for (int r = 0; r < H; r++) A[r * LDH + (lane - H)] = col[r];  // A now holds M
+  }
+  __syncthreads();
+  // K1c[0:12] = M P11 ;  Y = P21 G
+  for (int e = lane; e < H * H; e += 64) {
+    const int i = e / H, j = e % H;
+    double s = 0, y = 0;
+#pragma unroll
+    for (int k = 0; k < H; k++) {
+      s += A[i * LDH + k] * Pc[k * LDH + j];
+      y += Pc[(H + i) * LDH + k] * G[k * LDH + j];
+    }
+    K1c[i * LDH + j] = s;
+    Y[i * LDH + j] = y;
+  }
+  __syncthreads();
+  // K1c[12:24] = P21 - Y (M P11)
+  for (int e = lane; e < H * H; e += 64) {
+    const int i = e / H, j = e % H;
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < H; k++) s += Y[i * LDH + k] * K1c[k * LDH + j];
+    K1c[(H + i) * LDH + j] = Pc[(H + i) * LDH + j] - s;
+  }
+  __syncthreads();
+  // K H = K1c G ;  solution = K1c (H^T R^-1 z) + vec - (K H) vec[:12]
+  if (lane < N) {
+    const int r = lane;
+    double kz = 0;
+    for (int cc = 0; cc < H; cc++) kz += K1c[r * LDH + cc] * ne[78 + cc];
+    double khv = 0;
+    for (int cc = 0; cc < H; cc++) {
+      double s = 0;
+      for (int k = 0; k < H; k++) s += K1c[r * LDH + k] * G[k * LDH + cc];
+      c->KH[r * H + cc] = s;
+      khv += s * vec[cc];
+    }
+    sol[r] = kz + vec[r] - khv;
+    c->solution[r] = sol[r];
+  }
+  __syncthreads();
+  if (lane == 0) {
+    // state += solution
+    double E[9];
+    d_so3_exp(sol[0], sol[1], sol[2], E);
+    d_m3_mul(c->st, E, c->st);
+    d_so3_exp(sol[6], sol[7], sol[8], E);
+    d_m3_mul(c->st + 12, E, c->st + 12);
+    for (int i = 0; i < 3; i++) {
+      c->st[9 + i] += sol[3 + i];
+      c->st[21 + i] += sol[9 + i];
+      c->st[24 + i] += sol[12 + i];
+      c->st[27 + i] += sol[15 + i];
+      c->st[30 + i] += sol[18 + i];
+      c->st[33 + i] += sol[21 + i];
+    }
+    const int it = c->it;
+    double rn = sqrt(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
+    double tn = sqrt(sol[3] * sol[3] + sol[4] * sol[4] + sol[5] * sol[5]);
+    int converged = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
+    int rematch = c->rematch_num;
+    int search = 0;
+    if (converged || ((rematch == 0) && (it == (c->max_it - 2)))) { search = 1; rematch++; }
+    int do_cov = (rematch >= 2 || (it == c->max_it - 1));
+    c->converged = converged;
+    c->rematch_num = rematch;
+    c->search_next = search;
+    c->effect_num = (int)ne[90];
+    c->it = it + 1;
+    s_flags[0] = do_cov;
+  }
+  __syncthreads();
+  if (s_flags[0]) {
+    // state.cov = (I - K H) cov = cov - (K H) cov[0:12, :]
+    __shared__ double Ptop[H * (N + 1)];  // rows 0..11 of the OLD covariance
+    double* covw = c->st + 36;
+    for (int e = lane; e < H * N; e += 64) Ptop[(e / N) * (N + 1) + e % N] = covw[e];
+    __syncthreads();
+    double out[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+      const int e = lane + 64 * q;
+      const int r = e / N, cc = e % N;
+      double s2 = covw[e];
+      for (int k = 0; k < H; k++) s2 -= c->KH[r * H + k] * Ptop[k * (N + 1) + cc];
+      out[q] = s2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 9; q++) covw[lane + 64 * q] = out[q];  // 576 = 9 x 64
+    if (lane == 0) c->stop = 1;
+  }
+}
+
+void launch_iekf_begin(IekfCtrl* c, hipStream_t s) { hipLaunchKernelGGL(k_iekf_begin, dim3(1), dim3(64), 0, s, c); }
+void launch_iekf_solve(IekfCtrl* c, const double* ne, hipStream_t s) {
+  hipLaunchKernelGGL(k_iekf_solve, dim3(1), dim3(64), 0, s, c, ne);
+}
+
+}  // namespace lii

@@ -572,7 +572,13 @@ __device__ __forceinline__ void knn_group_merge(Knn5& k) {
 constexpr int kLanesPerQuery = 8;
 constexpr int kQueriesPerBlock = kBlock / kLanesPerQuery;  // 32
 
-__global__ __launch_bounds__(kBlock) void k_knn8(GridView g, RegistrationBuffers rb, PoseArg ps, int nb_real) {
+// `forced` >= 0: host-driven pass (always runs).  forced < 0: device-driven loop — runs only when the control block
+// says the next pass searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).
+__global__ __launch_bounds__(kBlock) void k_knn8(GridView g, RegistrationBuffers rb, PoseArg ps_val,
+                                                  const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
+                                                  int forced, int nb_real) {
+  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
+  const PoseArg ps = forced < 0 ? *pose : ps_val;  // device-driven: the pose lives in the control block
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;
   const int sub = threadIdx.x & (kLanesPerQuery - 1);
@@ -647,7 +653,9 @@ __global__ __launch_bounds__(kBlock) void k_knn8(GridView g, RegistrationBuffers
 // Second stage of the search for the queued queries: ONE 256-thread workgroup per query visits every cell that
 // intersects the ball of radius sqrt(min(d5 of stage 1, max_d2)) — looked up through the 3x3x3 neighbourhood of
 // 8x8x8-cell blocks, so empty space costs nothing — and merges the per-lane lists (wave butterfly, then LDS).
-__global__ __launch_bounds__(kBlock) void k_knn_fallback(GridView g, RegistrationBuffers rb) {
+__global__ __launch_bounds__(kBlock) void k_knn_fallback(GridView g, RegistrationBuffers rb,
+                                                          const IekfCtrl* __restrict__ ctrl, int forced) {
+  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
   __shared__ int s_block[27];
   __shared__ float s_d[4][5];
   __shared__ int s_i[4][5];
@@ -743,12 +751,21 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
   return changed;
 }
 
-// Plane fit + residual + Jacobian + block reduction, one lane per point.  FIT = true right after a k_knn8
-// pass (reads the 5 neighbours, caches the plane); FIT = false for the non-search iterations.
-template <bool FIT>
-__global__ __launch_bounds__(kBlock) void k_fit_reduce(RegistrationBuffers rb, PoseArg ps, int imu_en, double plane_thr,
-                                                        double rinv, int nb_real) {
+// Plane fit + residual + Jacobian + block reduction, one lane per point.  fit = right after a k_knn8 pass (reads
+// the 5 neighbours, caches the plane); !fit for the non-search iterations.  `forced` as in k_knn8.
+__global__ __launch_bounds__(kBlock) void k_fit_reduce(RegistrationBuffers rb, PoseArg ps_val,
+                                                        const PoseArg* __restrict__ pose,
+                                                        const IekfCtrl* __restrict__ ctrl, int forced, int imu_en,
+                                                        double plane_thr, double rinv, int nb_real) {
   __shared__ ReduceShared sh;
+  bool FIT;
+  if (forced >= 0) {
+    FIT = forced != 0;
+  } else {
+    if (ctrl->stop) return;
+    FIT = ctrl->search_next != 0;
+  }
+  const PoseArg ps = forced < 0 ? *pose : ps_val;
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;  // uniform per block
   const int i = blk * kBlock + threadIdx.x;
@@ -796,15 +813,15 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(RegistrationBuffers rb, P
   }
   block_reduce_rows(sh, o.h, o.z, o.sel, rinv, rb.partials + blk, rb.partial_stride);
 }
-template __global__ void k_fit_reduce<true>(RegistrationBuffers, PoseArg, int, double, double, int);
-template __global__ void k_fit_reduce<false>(RegistrationBuffers, PoseArg, int, double, double, int);
 
 // Deterministic final reduction of the transposed partials: out[t] = sum_b partials[t * stride + b].
 // One 64-lane workgroup per output: coalesced loads, per-lane sums over b = lane + 64 k in a fixed order, then a
 // fixed shuffle tree.  (91 independent workgroups: the partials were written by other XCDs, so every load is an
 // L2 miss; one latency instead of a dependent chain of them.)  Workgroup 0 also re-arms the fallback queue.
 __global__ __launch_bounds__(64) void k_reduce91(const double* __restrict__ partials, int n_blocks, int stride,
-                                                  double* __restrict__ out, unsigned int* needy_count) {
+                                                  double* __restrict__ out, unsigned int* needy_count,
+                                                  const IekfCtrl* __restrict__ ctrl, int forced) {
+  if (forced < 0 && ctrl->stop) return;
   const int t = blockIdx.x, lane = threadIdx.x;
   const double* row = partials + (size_t)t * stride;
   double acc = 0;
@@ -1191,27 +1208,28 @@ void launch_register_fused(bool search, const GridView& g, const RegistrationBuf
   else
     hipLaunchKernelGGL(k_register<false>, dim3(nb), dim3(kBlock), 0, s, g, rb, ps, imu_en, plane_thr, rinv);
 }
-void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, hipStream_t s) {
+void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                 const IekfCtrl* ctrl, int forced, hipStream_t s) {
   int nq = nblk(rb.n, kQueriesPerBlock);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_knn8, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, nq);
-  hipLaunchKernelGGL(k_knn_fallback, dim3(512), dim3(kBlock), 0, s, g, rb);
+  hipLaunchKernelGGL(k_knn8, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
 }
-void launch_fit_reduce(bool fit, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en, double plane_thr, double rinv,
-                       hipStream_t s) {
+void launch_knn_fallback(const GridView& g, const RegistrationBuffers& rb, const IekfCtrl* ctrl, int forced, hipStream_t s) {
+  hipLaunchKernelGGL(k_knn_fallback, dim3(256), dim3(kBlock), 0, s, g, rb, ctrl, forced);
+}
+void launch_fit_reduce(const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, const IekfCtrl* ctrl,
+                       int forced, int imu_en, double plane_thr, double rinv, hipStream_t s) {
   int nb = nblk(rb.n, kBlock);
   if (nb < 1) nb = 1;
   const int nb_pad = ((nb + 7) / 8) * 8;
-  if (fit)
-    hipLaunchKernelGGL(k_fit_reduce<true>, dim3(nb_pad), dim3(kBlock), 0, s, rb, ps, imu_en, plane_thr, rinv, nb);
-  else
-    hipLaunchKernelGGL(k_fit_reduce<false>, dim3(nb_pad), dim3(kBlock), 0, s, rb, ps, imu_en, plane_thr, rinv, nb);
+  hipLaunchKernelGGL(k_fit_reduce, dim3(nb_pad), dim3(kBlock), 0, s, rb, ps, pose, ctrl, forced, imu_en, plane_thr, rinv, nb);
 }
-void launch_reduce91(const double* partials, int n_points, int stride, double* out91, unsigned int* needy_count, hipStream_t s) {
+void launch_reduce91(const double* partials, int n_points, int stride, double* out91, unsigned int* needy_count,
+                     const IekfCtrl* ctrl, int forced, hipStream_t s) {
   int nb = nblk(n_points, kBlock);
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, needy_count);
+  hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, needy_count, ctrl, forced);
 }
 __global__ void k_extent_init(unsigned long long* e) {
   e[0] = ~0ull;

@@ -21,10 +21,15 @@ void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks
 // registration
 void launch_register_fused(bool search, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en,
                            double plane_thr, double rinv, hipStream_t s);
-void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, hipStream_t s);
-void launch_fit_reduce(bool fit, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en, double plane_thr, double rinv,
-                       hipStream_t s);
-void launch_reduce91(const double* partials, int n_points, int stride, double* out91, unsigned int* needy_count, hipStream_t s);
+void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                 const IekfCtrl* ctrl, int forced, hipStream_t s);
+void launch_knn_fallback(const GridView& g, const RegistrationBuffers& rb, const IekfCtrl* ctrl, int forced, hipStream_t s);
+void launch_fit_reduce(const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, const IekfCtrl* ctrl,
+                       int forced, int imu_en, double plane_thr, double rinv, hipStream_t s);
+void launch_reduce91(const double* partials, int n_points, int stride, double* out91, unsigned int* needy_count,
+                     const IekfCtrl* ctrl, int forced, hipStream_t s);
+void launch_iekf_begin(IekfCtrl* c, hipStream_t s);
+void launch_iekf_solve(IekfCtrl* c, const double* ne, hipStream_t s);
 int register_blocks(int n);
 // undistortion
 void launch_time_extent(const float4* pts, int n, unsigned long long* extent, hipStream_t s);
