@@ -70,7 +70,7 @@ struct lii_context {
   int n_scan = 0, n_body = 0;
   bool body_is_scan = false;
   bool have_search = false;
-  int knn_variant = 1;  // 0: one lane per query (fused), 1: eight lanes per query + fit kernel
+  int knn_variant = 1;  // 0: one lane per query (fused), 1: eight lanes per query (default), 2: four lanes per query, row-based
 
   // ---- pinned staging
   float4* h_stage = nullptr;     // max(max_scan, max_map) float4
@@ -180,7 +180,7 @@ int build_index(lii_handle h, int n) {
     HIPCHK(h, dmalloc(&h->d_cells, want * 512));
     h->cells_cap_blocks = want;
   }
-  unsigned int bcap = next_pow2(std::max(1024u, 2u * n_blocks));
+  unsigned int bcap = next_pow2(std::max(1024u, 8u * n_blocks));  // load factor <= 1/8: first probe decides
   if (bcap > h->blocks_cap) {
     if (h->d_blocks) HIPCHK(h, hipFree(h->d_blocks));
     h->d_blocks = nullptr;
@@ -225,7 +225,7 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
     launch_register_fused(search, g, rb, ps, imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, h->stream);
     if (prof) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
   } else {
-    if (search) launch_knn8(g, rb, ps, h->d_pose, h->d_ctrl, 1, h->stream);
+    if (search) { if (h->knn_variant == 1) launch_knn8(g, rb, ps, h->d_pose, h->d_ctrl, 1, h->stream); else launch_knn4(g, rb, ps, h->d_pose, h->d_ctrl, 1, h->stream); }
     if (prof) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     if (search) launch_knn_fallback(g, rb, h->d_ctrl, 1, h->stream);
     launch_fit_reduce(rb, ps, h->d_pose, h->d_ctrl, search ? 1 : 0, imu_en ? 1 : 0, h->cfg.plane_threshold,
@@ -276,7 +276,6 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   hc->it = 0; hc->search_next = 1; hc->stop = 0; hc->rematch_num = 0; hc->converged = 0; hc->searches = 0;
   hc->effect_num = 0; hc->singular = 0;
   HIPCHK(h, hipMemcpyAsync(h->d_ctrl, hc, sizeof(IekfCtrl), hipMemcpyHostToDevice, s));
-  launch_iekf_begin(h->d_ctrl, s);
   GridView g = grid_view(h);
   RegistrationBuffers rb = reg_buffers(h);
   const PoseArg* pose = reinterpret_cast<const PoseArg*>(h->d_ctrl);  // first 24 doubles of IekfCtrl::st
@@ -286,7 +285,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   for (int it = 0; it < opts->max_iterations; it++) {
     const bool timed = prof && it == 0;  // the first pass always searches
     if (timed) HIPCHK(h, hipEventRecord(h->ev[0], s));
-    launch_knn8(g, rb, ps0, pose, h->d_ctrl, -1, s);
+    if (h->knn_variant == 1) launch_knn8(g, rb, ps0, pose, h->d_ctrl, -1, s); else launch_knn4(g, rb, ps0, pose, h->d_ctrl, -1, s);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[3], s));
     launch_knn_fallback(g, rb, h->d_ctrl, -1, s);
     launch_fit_reduce(rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);

@@ -107,28 +107,42 @@ __global__ __launch_bounds__(64) void k_iekf_begin(IekfCtrl* c) {
 }
 
 // One iteration's solve + state update + schedule.  ne = the 91 reduced normal-equation scalars of this pass.
+// Single wavefront.  Every global input is fetched in ONE parallel batch into LDS (the control block and `ne` were
+// just written by other kernels, so each dependent global read would cost a full memory round trip), the algebra runs
+// out of LDS / registers, and the results are written back once at the end.
 __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __restrict__ ne) {
-  __shared__ double Pc[N * LDH];   // first 12 columns of the prior covariance: rows 0..11 = P11, rows 12..23 = P21
+  __shared__ double s_cov[N * N];  // prior covariance (row-major, stride 24)
   __shared__ double G[H * LDH];    // H^T R^-1 H
   __shared__ double A[H * LDH];    // I + P11 G, later M
   __shared__ double K1c[N * LDH];  // K_1[:, :12]
   __shared__ double Y[H * LDH];    // P21 G
-  __shared__ double vec[N], sol[N];
-  __shared__ int s_flags[2];
-  if (c->stop) return;
+  __shared__ double vec[N], sol[N], s_KH[N * H];
+  __shared__ double s_ne[96], s_st[36], s_prop[36];
+  __shared__ int s_int[12];
   const int lane = threadIdx.x;
-  const double* cov = c->st + 36;
-  if (lane == 0 && c->search_next) c->searches += 1;
-  if (lane == 0) {
-    int t = 0;
-    for (int i = 0; i < H; i++)
-      for (int j = i; j < H; j++) { G[i * LDH + j] = ne[t]; G[j * LDH + i] = ne[t]; t++; }
+  {
+    const int* ci = &c->max_it;  // max_it, imu_en, it, search_next, stop, rematch_num, converged, searches, effect_num, singular
+    if (lane < 10) s_int[lane] = ci[lane];
+    for (int e = lane; e < 91; e += 64) s_ne[e] = ne[e];
+    if (lane < 36) { s_st[lane] = c->st[lane]; s_prop[lane] = c->prop[lane]; }
+    const double* cov = c->st + 36;
+#pragma unroll
+    for (int q = 0; q < 9; q++) s_cov[lane + 64 * q] = cov[lane + 64 * q];
   }
-  for (int e = lane; e < N * H; e += 64) Pc[(e / H) * LDH + e % H] = cov[(e / H) * N + e % H];
-  // vec = state_propagat (-) state   (lane 1, overlapping nothing critical: it is tiny)
+  __syncthreads();
+  const int max_it = s_int[0], it = s_int[2], search_now = s_int[3], stop = s_int[4], rematch0 = s_int[5], searches0 = s_int[7];
+  if (stop) return;
+  for (int t = lane; t < 78; t += 64) {
+    int rem = t, i = 0;
+    while (rem >= H - i) { rem -= H - i; i++; }
+    const int j = i + rem;
+    G[i * LDH + j] = s_ne[t];
+    G[j * LDH + i] = s_ne[t];
+  }
+  // vec = state_propagat (-) state
   if (lane == 1) {
-    const double* A_ = c->prop;
-    const double* B_ = c->st;
+    const double* A_ = s_prop;
+    const double* B_ = s_st;
     double R[9];
     d_m3t_mul(B_, A_, R);
     d_so3_log(R, vec);
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __
     const int i = e / H, j = e % H;
     double s = (i == j) ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < H; k++) s += Pc[i * LDH + k] * G[k * LDH + j];
+    for (int k = 0; k < H; k++) s += s_cov[i * N + k] * G[k * LDH + j];
     A[i * LDH + j] = s;
   }
   __syncthreads();
@@ -174,8 +188,8 @@ __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __
     double s = 0, y = 0;
 #pragma unroll
     for (int k = 0; k < H; k++) {
-      s += A[i * LDH + k] * Pc[k * LDH + j];
-      y += Pc[(H + i) * LDH + k] * G[k * LDH + j];
+      s += A[i * LDH + k] * s_cov[k * N + j];
+      y += s_cov[(H + i) * N + k] * G[k * LDH + j];
     }
     K1c[i * LDH + j] = s;
     Y[i * LDH + j] = y;
@@ -187,75 +201,68 @@ __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __
     double s = 0;
 #pragma unroll
     for (int k = 0; k < H; k++) s += Y[i * LDH + k] * K1c[k * LDH + j];
-    K1c[(H + i) * LDH + j] = Pc[(H + i) * LDH + j] - s;
+    K1c[(H + i) * LDH + j] = s_cov[(H + i) * N + j] - s;
   }
   __syncthreads();
   // K H = K1c G ;  solution = K1c (H^T R^-1 z) + vec - (K H) vec[:12]
   if (lane < N) {
     const int r = lane;
     double kz = 0;
-    for (int cc = 0; cc < H; cc++) kz += K1c[r * LDH + cc] * ne[78 + cc];
+    for (int cc = 0; cc < H; cc++) kz += K1c[r * LDH + cc] * s_ne[78 + cc];
     double khv = 0;
     for (int cc = 0; cc < H; cc++) {
       double s = 0;
       for (int k = 0; k < H; k++) s += K1c[r * LDH + k] * G[k * LDH + cc];
-      c->KH[r * H + cc] = s;
+      s_KH[r * H + cc] = s;
       khv += s * vec[cc];
     }
     sol[r] = kz + vec[r] - khv;
-    c->solution[r] = sol[r];
   }
   __syncthreads();
-  if (lane == 0) {
-    // state += solution
-    double E[9];
-    d_so3_exp(sol[0], sol[1], sol[2], E);
-    d_m3_mul(c->st, E, c->st);
-    d_so3_exp(sol[6], sol[7], sol[8], E);
-    d_m3_mul(c->st + 12, E, c->st + 12);
-    for (int i = 0; i < 3; i++) {
-      c->st[9 + i] += sol[3 + i];
-      c->st[21 + i] += sol[9 + i];
-      c->st[24 + i] += sol[12 + i];
-      c->st[27 + i] += sol[15 + i];
-      c->st[30 + i] += sol[18 + i];
-      c->st[33 + i] += sol[21 + i];
-    }
-    const int it = c->it;
-    double rn = sqrt(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
-    double tn = sqrt(sol[3] * sol[3] + sol[4] * sol[4] + sol[5] * sol[5]);
-    int converged = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
-    int rematch = c->rematch_num;
-    int search = 0;
-    if (converged || ((rematch == 0) && (it == (c->max_it - 2)))) { search = 1; rematch++; }
-    int do_cov = (rematch >= 2 || (it == c->max_it - 1));
+  // schedule (uniform: every lane evaluates it from LDS)
+  const double rn = sqrt(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
+  const double tn = sqrt(sol[3] * sol[3] + sol[4] * sol[4] + sol[5] * sol[5]);
+  const int converged = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
+  int rematch = rematch0, search = 0;
+  if (converged || ((rematch == 0) && (it == (max_it - 2)))) { search = 1; rematch++; }
+  const int do_cov = (rematch >= 2 || (it == max_it - 1));
+  // state += solution : the two rotations on two lanes, the vector blocks on 18 more
+  if (lane < 2) {
+    double E[9], Rn[9];
+    const int o = lane == 0 ? 0 : 12;  // rot_end / offset_R_L_I
+    const int so = lane == 0 ? 0 : 6;
+    d_so3_exp(sol[so], sol[so + 1], sol[so + 2], E);
+    d_m3_mul(s_st + o, E, Rn);
+    for (int e = 0; e < 9; e++) c->st[o + e] = Rn[e];
+  } else if (lane >= 8 && lane < 26) {
+    const int q = lane - 8;  // 0..17 : six 3-vectors
+    const int blk = q / 3, i = q % 3;
+    const int sto = blk == 0 ? 9 : (blk == 1 ? 21 : (blk == 2 ? 24 : (blk == 3 ? 27 : (blk == 4 ? 30 : 33))));
+    const int soo = blk == 0 ? 3 : (blk == 1 ? 9 : (blk == 2 ? 12 : (blk == 3 ? 15 : (blk == 4 ? 18 : 21))));
+    c->st[sto + i] = s_st[sto + i] + sol[soo + i];
+  } else if (lane >= 32 && lane < 32 + N) {
+    c->solution[lane - 32] = sol[lane - 32];
+  }
+  if (lane == 63) {
     c->converged = converged;
     c->rematch_num = rematch;
     c->search_next = search;
-    c->effect_num = (int)ne[90];
+    c->effect_num = (int)s_ne[90];
     c->it = it + 1;
-    s_flags[0] = do_cov;
+    c->searches = searches0 + (search_now ? 1 : 0);
+    if (do_cov) c->stop = 1;
   }
-  __syncthreads();
-  if (s_flags[0]) {
-    // state.cov = (I - K H) cov = cov - (K H) cov[0:12, :]
-    __shared__ double Ptop[H * (N + 1)];  // rows 0..11 of the OLD covariance
+  if (do_cov) {
+    // state.cov = (I - K H) cov = cov - (K H) cov[0:12, :]   (:1111-1114), all operands already in LDS
     double* covw = c->st + 36;
-    for (int e = lane; e < H * N; e += 64) Ptop[(e / N) * (N + 1) + e % N] = covw[e];
-    __syncthreads();
-    double out[9];
 #pragma unroll
     for (int q = 0; q < 9; q++) {
       const int e = lane + 64 * q;
       const int r = e / N, cc = e % N;
-      double s2 = covw[e];
-      for (int k = 0; k < H; k++) s2 -= c->KH[r * H + k] * Ptop[k * (N + 1) + cc];
-      out[q] = s2;
+      double s2 = s_cov[e];
+      for (int k = 0; k < H; k++) s2 -= s_KH[r * H + k] * s_cov[k * N + cc];
+      covw[e] = s2;
     }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 9; q++) covw[lane + 64 * q] = out[q];  // 576 = 9 x 64
-    if (lane == 0) c->stop = 1;
   }
 }
 

@@ -46,6 +46,11 @@ __device__ __forceinline__ unsigned int hash_key(unsigned long long k) {
   k ^= k >> 33;
   return (unsigned int)k;
 }
+__device__ __forceinline__ unsigned int hash_block(int bx, int by, int bz) {
+  // block coordinates are < 2^18 after biasing: 24-bit multiplies are full-rate VALU ops
+  return (__umul24((unsigned)bx, 7919u * 1021u) ^ __umul24((unsigned)by, 104729u * 13u) ^ __umul24((unsigned)bz, 1299709u)) * 2654435761u;
+}
+
 __device__ __forceinline__ int cell_of(float v, float inv_cs) { return (int)floorf(v * inv_cs); }
 
 // Squared distance with the reference's float32 evaluation order and NO fused multiply-add
@@ -107,7 +112,7 @@ __global__ void k_cells_fill(const unsigned long long* __restrict__ keys, const 
   if (is_end) cell[1] = (unsigned)(i + 1);
   if (is_start && ((i == 0) || ((keys[i - 1] >> 9) != (key >> 9)))) {
     const unsigned long long bk = key >> 9;
-    unsigned int slot = hash_key(bk) & block_mask;
+    unsigned int slot = hash_block((int)(bk & 0x3FFFF), (int)((bk >> 18) & 0x3FFFF), (int)((bk >> 36) & 0x3FFFF)) & block_mask;
     while (true) {
       unsigned long long prev = atomicCAS(&blocks[slot].key, kEmptyKey, bk);
       if (prev == kEmptyKey) { blocks[slot].id = id; break; }
@@ -141,7 +146,7 @@ __device__ __forceinline__ float axis_gap(float q, int c, float cs, float eps) {
 __device__ __forceinline__ int find_block(const GridView& g, int X, int Y, int Z) {
   const int bb = kCellBias >> kCoarseShift;
   const unsigned long long bk = pack_block(X + bb, Y + bb, Z + bb);
-  unsigned int slot = hash_key(bk) & g.block_mask;
+  unsigned int slot = hash_block(X + bb, Y + bb, Z + bb) & g.block_mask;
   while (true) {
     BlockEntry e = g.blocks[slot];
     if (e.key == bk) return (int)e.id;
@@ -159,19 +164,21 @@ __device__ __forceinline__ uint2 cell_range(const GridView& g, int ix, int iy, i
 
 __device__ __forceinline__ void scan_range(const GridView& g, unsigned int start, unsigned int end, float qx, float qy,
                                            float qz, Knn5& k) {
-  unsigned int j = start;
-  // two candidates per trip: the loads are independent of the running top-5
-  for (; j + 1 < end; j += 2) {
-    float4 p0 = g.pts[j], p1 = g.pts[j + 1];
+  // four candidates per trip: the loads do not depend on the running top-5, so they are issued together
+  for (unsigned int j = start; j < end; j += 4) {
+    const unsigned int last = end - 1;
+    float4 p0 = g.pts[j];
+    float4 p1 = g.pts[min(j + 1, last)];
+    float4 p2 = g.pts[min(j + 2, last)];
+    float4 p3 = g.pts[min(j + 3, last)];
     float d0 = dist2_ref(qx, qy, qz, p0.x, p0.y, p0.z);
     float d1 = dist2_ref(qx, qy, qz, p1.x, p1.y, p1.z);
+    float d2 = dist2_ref(qx, qy, qz, p2.x, p2.y, p2.z);
+    float d3 = dist2_ref(qx, qy, qz, p3.x, p3.y, p3.z);
     if (d0 <= g.max_d2 && d0 < k.d4) knn_insert(k, d0, (int)j);
-    if (d1 <= g.max_d2 && d1 < k.d4) knn_insert(k, d1, (int)(j + 1));
-  }
-  if (j < end) {
-    float4 p0 = g.pts[j];
-    float d0 = dist2_ref(qx, qy, qz, p0.x, p0.y, p0.z);
-    if (d0 <= g.max_d2 && d0 < k.d4) knn_insert(k, d0, (int)j);
+    if (j + 1 < end && d1 <= g.max_d2 && d1 < k.d4) knn_insert(k, d1, (int)(j + 1));
+    if (j + 2 < end && d2 <= g.max_d2 && d2 < k.d4) knn_insert(k, d2, (int)(j + 2));
+    if (j + 3 < end && d3 <= g.max_d2 && d3 < k.d4) knn_insert(k, d3, (int)(j + 3));
   }
 }
 
@@ -605,20 +612,49 @@ __global__ __launch_bounds__(kBlock) void k_knn8(GridView g, RegistrationBuffers
   const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
   const bool active = live && g.n_pts > 0;
   if (active) {
-    // phase 1: the 27 cells of the 3x3x3 block, cell c -> lane c % 8; all lookups of a lane are issued first
-    uint2 r0, r1, r2, r3 = make_uint2(0u, 0u);
-    int c = sub;
-    r0 = cell_range(g, cx + (c % 3) - 1, cy + ((c / 3) % 3) - 1, cz + (c / 9) - 1);
-    c = sub + 8;
-    r1 = cell_range(g, cx + (c % 3) - 1, cy + ((c / 3) % 3) - 1, cz + (c / 9) - 1);
-    c = sub + 16;
-    r2 = cell_range(g, cx + (c % 3) - 1, cy + ((c / 3) % 3) - 1, cz + (c / 9) - 1);
-    c = sub + 24;
-    if (c < 27) r3 = cell_range(g, cx + (c % 3) - 1, cy + ((c / 3) % 3) - 1, cz + (c / 9) - 1);
-    scan_range(g, r0.x, r0.y, wx, wy, wz, k);
-    scan_range(g, r1.x, r1.y, wx, wy, wz, k);
-    scan_range(g, r2.x, r2.y, wx, wy, wz, k);
-    scan_range(g, r3.x, r3.y, wx, wy, wz, k);
+    // phase 1: the 27 cells of the 3x3x3 block, cell c -> lane c % 8.  The loads of the four cells of a lane are
+    // issued as batches (block-table probes, then cell entries, then candidates) instead of one dependent chain each.
+    int ccx[4], ccy[4], ccz[4];
+    unsigned long long bk[4];
+    unsigned int slot[4];
+    uint4 be[4];  // raw BlockEntry words: key lo, key hi, id, pad
+    const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
+    const int bb = kCellBias >> kCoarseShift;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int c = sub + 8 * t;
+      const bool valid = c < 27;
+      ccx[t] = cx + (valid ? (c % 3) - 1 : 0);
+      ccy[t] = cy + (valid ? ((c / 3) % 3) - 1 : 0);
+      ccz[t] = cz + (valid ? (c / 9) - 1 : 0);
+      bk[t] = pack_block((ccx[t] >> kCoarseShift) + bb, (ccy[t] >> kCoarseShift) + bb, (ccz[t] >> kCoarseShift) + bb);
+      slot[t] = hash_block((ccx[t] >> kCoarseShift) + bb, (ccy[t] >> kCoarseShift) + bb, (ccz[t] >> kCoarseShift) + bb) & g.block_mask;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) be[t] = tab[slot[t]];
+    int id[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      // linear probing; the table is sized for a load factor <= 1/8, so the first probe almost always decides
+      unsigned int sl = slot[t];
+      uint4 e = be[t];
+      unsigned long long ek = ((unsigned long long)e.y << 32) | e.x;
+      while (ek != bk[t] && ek != kEmptyKey) {
+        sl = (sl + 1) & g.block_mask;
+        e = tab[sl];
+        ek = ((unsigned long long)e.y << 32) | e.x;
+      }
+      id[t] = (ek == bk[t]) ? (int)e.z : -1;
+      if (sub + 8 * t >= 27) id[t] = -1;
+    }
+    uint2 rg[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const unsigned local = (((unsigned)ccz[t] & 7u) << 6) | (((unsigned)ccy[t] & 7u) << 3) | ((unsigned)ccx[t] & 7u);
+      rg[t] = id[t] >= 0 ? g.cells[(size_t)id[t] * kBlockCells + local] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) scan_range(g, rg[t].x, rg[t].y, wx, wy, wz, k);
   }
   knn_group_merge<false>(k);
   // lanes of a group can hold differently ordered lists when two candidates tie: use lane 0's
@@ -644,6 +680,219 @@ __global__ __launch_bounds__(kBlock) void k_knn8(GridView g, RegistrationBuffers
     } else if (sub == 6) {
       rb.world[qi] = make_float4(wx, wy, wz, 0.f);
     } else if (need) {  // sub == 7
+      unsigned int slot = atomicAdd(rb.needy_count, 1u);
+      rb.needy[slot] = qi;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variant 2 of the search pass (default): FOUR lanes per query, 64 queries per workgroup, so that the whole scan
+// is resident in one round of waves and far less per-query work is replicated across lanes than with eight.
+// The 3x3x3 neighbourhood is split into its 9 (dy, dz) rows of three x-adjacent cells; row r belongs to lane r % 4.
+// All lookups of a lane are issued as batches (block-table probes -> cell entries -> candidates), the top-5
+// insertion is branch-free, and the per-lane lists are merged with a 2-step wavefront-shuffle butterfly.
+__device__ __forceinline__ void knn_insert_bl(Knn5& k, float d, int j) {
+  // branch-free sorted insertion (no-op when d >= d4); strict '<' keeps the earlier candidate on ties
+  const bool c0 = d < k.d0, c1 = d < k.d1, c2 = d < k.d2, c3 = d < k.d3, c4 = d < k.d4;
+  k.d4 = c3 ? k.d3 : (c4 ? d : k.d4);
+  k.i4 = c3 ? k.i3 : (c4 ? j : k.i4);
+  k.d3 = c2 ? k.d2 : (c3 ? d : k.d3);
+  k.i3 = c2 ? k.i2 : (c3 ? j : k.i3);
+  k.d2 = c1 ? k.d1 : (c2 ? d : k.d2);
+  k.i2 = c1 ? k.i1 : (c2 ? j : k.i2);
+  k.d1 = c0 ? k.d0 : (c1 ? d : k.d1);
+  k.i1 = c0 ? k.i0 : (c1 ? j : k.i1);
+  k.d0 = c0 ? d : k.d0;
+  k.i0 = c0 ? j : k.i0;
+}
+__device__ __forceinline__ void scan_range_bl(const GridView& g, unsigned int start, unsigned int end, float qx, float qy,
+                                              float qz, Knn5& k) {
+  const float INF = __builtin_inff();
+  for (unsigned int j = start; j < end; j += 4) {
+    const unsigned int last = end - 1;
+    float4 p0 = g.pts[j];
+    float4 p1 = g.pts[min(j + 1, last)];
+    float4 p2 = g.pts[min(j + 2, last)];
+    float4 p3 = g.pts[min(j + 3, last)];
+    float d0 = dist2_ref(qx, qy, qz, p0.x, p0.y, p0.z);
+    float d1 = dist2_ref(qx, qy, qz, p1.x, p1.y, p1.z);
+    float d2 = dist2_ref(qx, qy, qz, p2.x, p2.y, p2.z);
+    float d3 = dist2_ref(qx, qy, qz, p3.x, p3.y, p3.z);
+    // candidates beyond the range or the acceptance radius are turned into +inf (never inserted)
+    d0 = (d0 <= g.max_d2) ? d0 : INF;
+    d1 = (j + 1 < end && d1 <= g.max_d2) ? d1 : INF;
+    d2 = (j + 2 < end && d2 <= g.max_d2) ? d2 : INF;
+    d3 = (j + 3 < end && d3 <= g.max_d2) ? d3 : INF;
+    if (fminf(fminf(d0, d1), fminf(d2, d3)) < k.d4) {
+      knn_insert_bl(k, d0, (int)j);
+      knn_insert_bl(k, d1, (int)(j + 1));
+      knn_insert_bl(k, d2, (int)(j + 2));
+      knn_insert_bl(k, d3, (int)(j + 3));
+    }
+  }
+}
+
+constexpr int kLanesPerQuery4 = 4;
+constexpr int kQueriesPerBlock4 = kBlock / kLanesPerQuery4;  // 64
+
+__global__ __launch_bounds__(kBlock) void k_knn4(GridView g, RegistrationBuffers rb, PoseArg ps_val,
+                                                  const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
+                                                  int forced, int nb_real) {
+  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
+  const PoseArg ps = forced < 0 ? *pose : ps_val;
+  const int blk = xcd_remap(blockIdx.x, nb_real);
+  if (blk >= nb_real) return;
+  const int sub = threadIdx.x & 3;
+  const int qi = blk * kQueriesPerBlock4 + (threadIdx.x >> 2);
+  const bool live = qi < rb.n;
+  const int lane = threadIdx.x & 63, leader = lane & ~3;
+  // pointBodyToWorld on the group leader, broadcast to the other three lanes
+  float wx = 0, wy = 0, wz = 0;
+  if (live && sub == 0) {
+    float4 pb = rb.body[qi];
+    double bx = pb.x, by = pb.y, bz = pb.z;
+    double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
+    double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
+    double iz = ps.RLI[6] * bx + ps.RLI[7] * by + ps.RLI[8] * bz + ps.TLI[2];
+    wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
+    wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
+    wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
+  }
+  wx = __shfl(wx, leader); wy = __shfl(wy, leader); wz = __shfl(wz, leader);
+  const float INF = __builtin_inff();
+  Knn5 k;
+  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = INF;
+  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
+  const float cs = g.cs;
+  const float eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
+  const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
+  const bool active = live && g.n_pts > 0;
+  if (active) {
+    const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
+    const int bb = kCellBias >> kCoarseShift;
+    // biased x coordinates of the three cells and the (at most two) blocks they fall into
+    const int ux0 = cx - 1 + kCellBias;
+    const int bxA = ux0 >> kCoarseShift, bxB = (ux0 + 2) >> kCoarseShift;
+    // rows of this lane: r = sub, sub + 4, sub + 8 (< 9)
+    int by_[3], bz_[3], lyz[3];
+    bool rv[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const int r = sub + 4 * t;
+      rv[t] = r < 9;
+      const int rr = rv[t] ? r : 0;
+      const int uy = cy + (rr % 3) - 1 + kCellBias, uz = cz + (rr / 3) - 1 + kCellBias;
+      by_[t] = uy >> kCoarseShift;
+      bz_[t] = uz >> kCoarseShift;
+      lyz[t] = ((uz & 7) << 6) | ((uy & 7) << 3);
+    }
+    (void)bb;
+    // batch 1: first probe of every (row, block) pair
+    unsigned int slA[3], slB[3];
+    unsigned long long ekA[3], ekB[3];
+    unsigned int ezA[3], ezB[3];
+    const bool two = bxB != bxA;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      slA[t] = hash_block(bxA, by_[t], bz_[t]) & g.block_mask;
+      slB[t] = hash_block(bxB, by_[t], bz_[t]) & g.block_mask;
+      const uint4 a = tab[slA[t]];
+      const uint4 b = tab[two ? slB[t] : slA[t]];
+      ekA[t] = ((unsigned long long)a.y << 32) | a.x;
+      ezA[t] = a.z;
+      ekB[t] = ((unsigned long long)b.y << 32) | b.x;
+      ezB[t] = b.z;
+    }
+    int idA[3], idB[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      const unsigned long long kA = pack_block(bxA, by_[t], bz_[t]), kB = pack_block(bxB, by_[t], bz_[t]);
+      // linear probing; the table is sized for a load factor <= 1/8, so the first probe almost always decides
+      unsigned int sl = slA[t];
+      unsigned long long ek = ekA[t];
+      unsigned int ez = ezA[t];
+      while (ek != kA && ek != kEmptyKey) {
+        sl = (sl + 1) & g.block_mask;
+        const uint4 e = tab[sl];
+        ek = ((unsigned long long)e.y << 32) | e.x;
+        ez = e.z;
+      }
+      idA[t] = (rv[t] && ek == kA) ? (int)ez : -1;
+      sl = slB[t];
+      ek = ekB[t];
+      ez = ezB[t];
+      while (two && ek != kB && ek != kEmptyKey) {
+        sl = (sl + 1) & g.block_mask;
+        const uint4 e = tab[sl];
+        ek = ((unsigned long long)e.y << 32) | e.x;
+        ez = e.z;
+      }
+      idB[t] = two ? ((rv[t] && ek == kB) ? (int)ez : -1) : idA[t];
+    }
+    // batch 2: the three cell entries of every row
+    uint2 rg[3][3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+#pragma unroll
+      for (int x = 0; x < 3; x++) {
+        const int ux = ux0 + x;
+        const int id = ((ux >> kCoarseShift) == bxA) ? idA[t] : idB[t];
+        rg[t][x] = id >= 0 ? g.cells[(size_t)id * kBlockCells + (lyz[t] | (ux & 7))] : make_uint2(0u, 0u);
+      }
+    }
+    // batch 3: candidates.  x-adjacent cells of one block are adjacent in the sorted array: fuse touching ranges.
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      uint2 a = rg[t][0], b = rg[t][1], c = rg[t][2];
+      if (a.y == b.x && a.y > a.x && b.y > b.x) { b.x = a.x; a.y = a.x; }
+      if (b.y == c.x && b.y > b.x && c.y > c.x) { c.x = b.x; b.y = b.x; }
+      scan_range_bl(g, a.x, a.y, wx, wy, wz, k);
+      scan_range_bl(g, b.x, b.y, wx, wy, wz, k);
+      scan_range_bl(g, c.x, c.y, wx, wy, wz, k);
+    }
+  }
+  // 2-step butterfly over the 4 lanes (disjoint cell sets -> no duplicates)
+#pragma unroll
+  for (int off = 1; off < 4; off <<= 1) {
+    float e0 = __shfl_xor(k.d0, off), e1 = __shfl_xor(k.d1, off), e2 = __shfl_xor(k.d2, off), e3 = __shfl_xor(k.d3, off),
+          e4 = __shfl_xor(k.d4, off);
+    int j0 = __shfl_xor(k.i0, off), j1 = __shfl_xor(k.i1, off), j2 = __shfl_xor(k.i2, off), j3 = __shfl_xor(k.i3, off),
+        j4 = __shfl_xor(k.i4, off);
+    knn_insert_bl(k, e0, j0);
+    knn_insert_bl(k, e1, j1);
+    knn_insert_bl(k, e2, j2);
+    knn_insert_bl(k, e3, j3);
+    knn_insert_bl(k, e4, j4);
+  }
+  // lanes of a group can hold differently ordered lists when two candidates tie: use the leader's
+  k.d0 = __shfl(k.d0, leader); k.d1 = __shfl(k.d1, leader); k.d2 = __shfl(k.d2, leader); k.d3 = __shfl(k.d3, leader);
+  k.d4 = __shfl(k.d4, leader);
+  k.i0 = __shfl(k.i0, leader); k.i1 = __shfl(k.i1, leader); k.i2 = __shfl(k.i2, leader); k.i3 = __shfl(k.i3, leader);
+  k.i4 = __shfl(k.i4, leader);
+  float fx = wx - (float)cx * cs, fy = wy - (float)cy * cs, fz = wz - (float)cz * cs;
+  float mfrac = fmaxf(fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz)), 0.f);
+  float guard = cs + mfrac - 2.f * eps;
+  const bool need = active && !(fminf(k.d4, g.max_d2) <= guard * guard);
+  if (live) {
+    // lane s stores neighbours s and (for s == 0) 4; lane 1 the count, lane 2 world, lane 3 the fallback ticket
+    const int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
+    {
+      const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : k.i3));
+      const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : k.d3));
+      float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
+      v.w = dd;
+      rb.nbr[(size_t)sub * rb.cap + qi] = v;
+    }
+    if (sub == 0) {
+      float4 v = k.i4 >= 0 ? g.pts[k.i4] : make_float4(0, 0, 0, 0);
+      v.w = k.d4;
+      rb.nbr[(size_t)4 * rb.cap + qi] = v;
+    } else if (sub == 1) {
+      rb.nbr_count[qi] = found;
+    } else if (sub == 2) {
+      rb.world[qi] = make_float4(wx, wy, wz, 0.f);
+    } else if (need) {
       unsigned int slot = atomicAdd(rb.needy_count, 1u);
       rb.needy[slot] = qi;
     }
@@ -1214,6 +1463,13 @@ void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
   hipLaunchKernelGGL(k_knn8, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
+}
+void launch_knn4(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                 const IekfCtrl* ctrl, int forced, hipStream_t s) {
+  int nq = nblk(rb.n, kQueriesPerBlock4);
+  if (nq < 1) nq = 1;
+  const int nq_pad = ((nq + 7) / 8) * 8;
+  hipLaunchKernelGGL(k_knn4, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
 }
 void launch_knn_fallback(const GridView& g, const RegistrationBuffers& rb, const IekfCtrl* ctrl, int forced, hipStream_t s) {
   hipLaunchKernelGGL(k_knn_fallback, dim3(256), dim3(kBlock), 0, s, g, rb, ctrl, forced);

@@ -23,6 +23,8 @@ void launch_register_fused(bool search, const GridView& g, const RegistrationBuf
                            double plane_thr, double rinv, hipStream_t s);
 void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                  const IekfCtrl* ctrl, int forced, hipStream_t s);
+void launch_knn4(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                 const IekfCtrl* ctrl, int forced, hipStream_t s);
 void launch_knn_fallback(const GridView& g, const RegistrationBuffers& rb, const IekfCtrl* ctrl, int forced, hipStream_t s);
 void launch_fit_reduce(const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, const IekfCtrl* ctrl,
                        int forced, int imu_en, double plane_thr, double rinv, hipStream_t s);
