@@ -1,0 +1,77 @@
+"""GPU parity of the LI-Init evaluator (k_calib_eval through lii_calib_eval) and of the host LM around it
+(lii_calib_solve_stage) against the numpy oracle, on the sequences derived from the reference's committed run.
+Tolerances: J^T J / J^T r / cost relative 1e-10 (fp64, different summation order); solved parameters 1e-8."""
+import numpy as np
+import pytest
+
+import li_init_fixture as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def reg():
+    import lidar_imu_init_amd as lii
+    r = lii.Registrar(max_scan_points=1000, max_map_points=1000)
+    yield r
+    r.close()
+
+
+def _rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def test_calib_eval_matches_oracle(reg):
+    from oracle import li_init_np as LI
+    out = F.run(solve=True)
+    rng = np.random.default_rng(1)
+    q = np.array([0.72, 0.02, -0.01, 0.69]); q /= np.linalg.norm(q)
+    R = LI.quat_to_rot(q)
+    # stages 1 / 2 on the buffers before the second time compensation
+    imu, lid = out["imu_stage12"], out["lidar_stage12"]
+    reg.calib_set_buffers(imu.to_records(), lid.to_records())
+    for stage, v in ((1, np.zeros(0)), (2, np.r_[0.002, 0.0007, -0.0004, -0.0045])):
+        params = np.r_[R.reshape(-1), v]
+        JtJ, Jtr, cost = reg.calib_eval(stage, params)
+        rJ, rg, rc = LI.normal_equations(stage, R, v, imu, lid)
+        assert _rel(JtJ, rJ) < 1e-10 and _rel(Jtr, rg) < 1e-10 and abs(cost - rc) / rc < 1e-12
+    # stage 3 on the buffers after it + acc_interpolate
+    imu3, lid3 = out["imu_stage3"], out["lidar_stage3"]
+    reg.calib_set_buffers(imu3.to_records(), lid3.to_records())
+    R_LI = out["stage2"]["R_LI"]
+    RG = LI.quat_to_rot(LI.quat_plus(np.array([1.0, 0, 0, 0]), np.array([0.03, -0.02, 0.01])))
+    v = np.r_[0.004, -0.006, 0.009, 0.02, -0.02, -0.17]
+    JtJ, Jtr, cost = reg.calib_eval(3, np.r_[RG.reshape(-1), v, R_LI.reshape(-1)])
+    rJ, rg, rc = LI.normal_equations(3, RG, v, imu3, lid3, R_LI)
+    assert _rel(JtJ, rJ) < 1e-10 and _rel(Jtr, rg) < 1e-10 and abs(cost - rc) / rc < 1e-12
+
+
+def test_calib_solves_match_oracle_and_reference(reg):
+    from lidar_imu_init_amd.api import lii_calib_result
+    from oracle import oracle as O
+    d = F.load()
+    out = F.run(solve=True)
+    imu, lid = out["imu_stage12"], out["lidar_stage12"]
+    reg.calib_set_buffers(imu.to_records(), lid.to_records())
+    res = lii_calib_result()
+    res.R_LI[:] = list(np.eye(3).reshape(-1))
+    reg.calib_solve_stage(1, res)
+    assert np.allclose(np.array(res.R_LI[:]).reshape(3, 3), out["stage1"]["R_LI"], atol=1e-8)
+    assert res.iterations[0] == out["stage1"]["iterations"]
+    reg.calib_solve_stage(2, res)
+    R2 = np.array(res.R_LI[:]).reshape(3, 3)
+    assert np.allclose(R2, out["stage2"]["R_LI"], atol=1e-8)
+    assert np.allclose(res.gyro_bias[:], out["stage2"]["gyro_bias"], atol=1e-9)
+    assert abs(res.time_lag_2 - out["stage2"]["time_lag_2"]) < 1e-9
+    assert res.iterations[1] == out["stage2"]["iterations"]
+    # the HIP-evaluated solve lands on the reference's committed initialisation result too
+    assert np.abs(O.rot_to_euler(R2) * 57.3 - d["result_rot_euler_deg"]).max() < 0.01
+    assert np.abs(np.array(res.gyro_bias[:]) - d["result_gyro_bias"]).max() < 5e-5
+    # stage 3 on the re-aligned buffers (LI_Initialization re-uses the deques after IMU_time_compensate + acc_interpolate)
+    reg.calib_set_buffers(out["imu_stage3"].to_records(), out["lidar_stage3"].to_records())
+    reg.calib_solve_stage(3, res)
+    assert np.allclose(res.T_LI[:], out["stage3"]["T_LI"], atol=1e-8)
+    assert np.allclose(res.acc_bias[:], out["stage3"]["acc_bias"], atol=1e-9)
+    assert np.allclose(res.grav_L0[:], out["stage3"]["grav_L0"], atol=1e-8)
+    assert np.abs(np.array(res.T_LI[:]) - d["result_trans"]).max() < 1e-3
+    assert np.abs(np.array(res.grav_L0[:]) - d["result_gravity"]).max() < 2e-3

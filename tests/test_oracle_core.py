@@ -1,0 +1,163 @@
+"""CPU tests that pin the oracle itself (the reference ships no tests):
+  * SO(3) helpers against scipy;  * esti_plane against numpy.linalg.lstsq;
+  * the restated k-d tree against brute force and — where oracle/_ref is built — against the UNMODIFIED reference ikd-Tree;
+  * the iterated update against closed-form synthetic ground truth and its own literal (24 x m gain) form.
+"""
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+from scipy.spatial.transform import Rotation
+
+from conftest import make_state
+
+
+def test_exp_log_roundtrip(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        w = rng.normal(0, 1.0, 3)
+        R = oracle.exp_so3(w)
+        assert np.allclose(R, Rotation.from_rotvec(w).as_matrix(), atol=1e-13)
+        if np.linalg.norm(w) < 3.0:
+            assert np.allclose(oracle.log_so3(R), w, atol=1e-9)
+    assert np.array_equal(oracle.exp_so3(np.array([1e-8, 0, 0])), np.eye(3))       # identity below 1e-7 (so3_math.h:23)
+    assert np.array_equal(oracle.exp3(5e-6, 0, 0), np.eye(3))                      # 1e-5 for the 3-scalar overload (:66)
+    w = np.array([0.3, -0.2, 0.5])
+    assert np.allclose(oracle.exp_so3(w, 0.25), Rotation.from_rotvec(0.25 * w).as_matrix(), atol=1e-14)
+    e = oracle.rot_to_euler(Rotation.from_euler("ZYX", [0.7, -0.2, 0.1]).as_matrix())
+    assert np.allclose(e, [0.1, -0.2, 0.7], atol=1e-12)
+
+
+def test_state_boxplus_boxminus(oracle):
+    rng = np.random.default_rng(1)
+    s = oracle.state_init()
+    d = rng.normal(0, 0.1, 24)
+    s2 = oracle.state_boxplus(s, d)
+    assert np.allclose(oracle.state_boxminus(s2, s), d, atol=1e-9)
+    v = oracle.StateView(s)
+    assert np.allclose(np.diag(v.cov)[:15], 1.0) and np.allclose(np.diag(v.cov)[15:], 1e-5)
+
+
+def test_inverse_matches_numpy(oracle):
+    rng = np.random.default_rng(2)
+    A = rng.normal(size=(24, 24)) + 5 * np.eye(24)
+    assert np.allclose(oracle.inverse(A), np.linalg.inv(A), rtol=1e-10, atol=1e-12)
+
+
+def test_esti_plane_against_lstsq(oracle):
+    rng = np.random.default_rng(3)
+    n_valid = 0
+    for _ in range(500):
+        nrm = rng.normal(size=3)
+        nrm /= np.linalg.norm(nrm)
+        c = rng.uniform(-30, 30, 3)
+        u = np.cross(nrm, [1, 0, 0.3]); u /= np.linalg.norm(u)
+        v = np.cross(nrm, u)
+        pts = (c + rng.uniform(-0.3, 0.3, (5, 1)) * u + rng.uniform(-0.3, 0.3, (5, 1)) * v +
+               rng.normal(0, 0.01, (5, 1)) * nrm).astype(np.float32)
+        ok, pabcd = oracle.esti_plane(pts, 0.1)
+        x, *_ = np.linalg.lstsq(pts.astype(np.float64), -np.ones(5), rcond=None)
+        n = np.linalg.norm(x)
+        ref = np.r_[x / n, 1 / n]
+        assert np.allclose(pabcd, ref, rtol=1e-7, atol=1e-9)
+        assert ok == bool(np.all(np.abs(pts.astype(np.float64) @ ref[:3] + ref[3]) <= 0.1))
+        n_valid += ok
+    assert n_valid > 400
+    # a far-from-planar neighbourhood is rejected
+    ok, _ = oracle.esti_plane(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1]], np.float32) + 5, 0.1)
+    assert not ok
+
+
+def _world(seed=5, n=40_000):
+    rng = np.random.default_rng(seed)
+    pts = np.c_[rng.uniform(-15, 15, n), rng.uniform(-15, 15, n), rng.normal(0, 0.02, n)].astype(np.float32)
+    pts[n // 2:, 0] = 15 + rng.normal(0, 0.02, n - n // 2)
+    pts[n // 2:, 2] = rng.uniform(0, 6, n - n // 2)
+    return rng, pts
+
+
+def test_kdtree_against_bruteforce(oracle):
+    rng, pts = _world()
+    q = (pts[rng.choice(len(pts), 3000)] + rng.normal(0, 0.1, (3000, 3))).astype(np.float32)
+    q[:50] += 40  # no neighbour within sqrt(5)
+    t = oracle.Tree("oracle")
+    t.build(pts)
+    nb, d2, cnt = t.knn(q, threads=2)
+    d, i = cKDTree(pts.astype(np.float64)).query(q.astype(np.float64), k=5)
+    for j in range(len(q)):
+        exp = int((d[j] ** 2 <= 5.0).sum())
+        # float32 squared distances decide the <= 5.0 gate; allow the one-ulp band
+        assert cnt[j] == exp or np.any(np.abs(d[j] ** 2 - 5.0) < 1e-5)
+        assert np.array_equal(nb[j, :cnt[j]], pts[i[j, :cnt[j]]])
+    assert np.all(np.diff(d2[cnt == 5], axis=1) >= 0)
+    assert (cnt[:50] == 0).all()
+
+
+def test_kdtree_against_reference_ikdtree(oracle):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref/libref_ikdtree.so not built (needs /root/reference)")
+    rng, pts = _world(seed=9)
+    t, r = oracle.Tree("oracle", downsample=0.5), oracle.Tree("ref", downsample=0.5)
+    t.build(pts)
+    r.build(pts)
+    q = (pts[rng.choice(len(pts), 5000)] + rng.normal(0, 0.2, (5000, 3))).astype(np.float32)
+    a, b = t.knn(q), r.knn(q)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    for s in range(3):
+        add = (pts[rng.choice(len(pts), 3000)] + rng.normal(0, 0.3, (3000, 3))).astype(np.float32)
+        assert t.add_points(add, True) == r.add_points(add, True)
+        extra = rng.uniform(-20, 20, (500, 3)).astype(np.float32)
+        t.add_points(extra, False)
+        r.add_points(extra, False)
+        assert t.validnum() == r.validnum()
+    fa, fb = np.unique(t.flatten(), axis=0), np.unique(r.flatten(), axis=0)
+    assert fa.shape == fb.shape and np.array_equal(fa, fb)
+    a, b = t.knn(q), r.knn(q)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # quirk A5: acceptance is d2 <= 5.0 although the search prunes at 25
+    line = np.c_[np.arange(6) * 0.01, np.full(6, 2.2), np.zeros(6)].astype(np.float32)
+    t2, r2 = oracle.Tree("oracle"), oracle.Tree("ref")
+    t2.build(line)
+    r2.build(line)
+    q0 = np.zeros((1, 3), np.float32)
+    assert t2.knn(q0)[2][0] == r2.knn(q0)[2][0] == 5
+    far = line.copy(); far[:, 1] = 2.3
+    t2.build(far); r2.build(far)
+    assert t2.knn(q0)[2][0] == r2.knn(q0)[2][0] == 0
+
+
+def test_iekf_recovers_known_pose_and_literal_gain(oracle, small_world):
+    from lidar_imu_init_amd import synth
+    hall, map_pts = small_world
+    R = synth.rot_zyx(0.02, -0.03, 0.5)
+    p = np.array([1.0, -0.5, 0.2])
+    scan = synth.make_scan(hall, "tiny", R, p, noise=0.01, seed=2)
+    tree = oracle.Tree("oracle")
+    tree.build(map_pts)
+    st_true = make_state(oracle, R, p)
+    st0 = oracle.state_boxplus(st_true, np.r_[0.01, -0.008, 0.012, 0.05, -0.04, 0.03, np.zeros(18)])
+    a = tree.iekf_update(scan, st0, st0, max_iterations=5, imu_en=False, threads=2)
+    b = tree.iekf_update(scan, st0, st0, max_iterations=5, imu_en=False, threads=1, literal_gain=True)
+    va, vb = oracle.StateView(a["state"]), oracle.StateView(b["state"])
+    assert np.linalg.norm(va.pos_end - p) < 0.01
+    assert np.linalg.norm(oracle.log_so3(R.T @ va.rot_end)) < 0.002
+    # K z = K1[:, :12](H^T R^-1 z) and K H = K1[:, :12](H^T R^-1 H): the compact and the literal forms coincide
+    assert a["iters"] == b["iters"]
+    assert np.allclose(va.pos_end, vb.pos_end, atol=1e-10) and np.allclose(va.rot_end, vb.rot_end, atol=1e-10)
+    assert np.allclose(va.cov, vb.cov, atol=1e-9)
+    # rematch schedule (quirk A11): the first pass searches; a later one searches again
+    assert a["logs"][0, 0] == 1 and a["logs"][:, 0].sum() == 2
+    # LO mode leaves the extrinsic block of H at zero
+    assert np.all(a["logs"][0, 2:80].reshape(-1)[[11]] == a["logs"][0, 13])  # symmetric bookkeeping sanity
+
+
+def test_voxel_grid_and_undistort_shapes(oracle):
+    rng = np.random.default_rng(4)
+    pts = np.c_[rng.uniform(-5, 5, (5000, 3)), rng.uniform(0, 100, 5000)].astype(np.float32)
+    out, filtered = oracle.voxel_grid(pts, 0.5)
+    assert filtered and 0 < len(out) < len(pts)
+    # centroid property: every output lies in the voxel of its members
+    key = np.floor(out[:, :3] / 0.5)
+    assert len(np.unique(key, axis=0)) == len(out)
+    und = oracle.undistort_cv(pts, np.zeros(3), np.zeros(3), np.eye(3))
+    srt = pts[np.argsort(pts[:, 3], kind="stable")]
+    assert np.array_equal(und, srt)  # zero motion: only the time sort remains

@@ -1,0 +1,97 @@
+"""Pins the LI-Init oracle (oracle/li_init_np.py) against the reference's own committed run — the only known-answer data
+the reference holds (Log/*.txt, result/Initialization_result.txt).
+
+  * conditioning chain (discard 10, zero-phase Butterworth incl. the 0.0011 coefficient, normalisation, tail cut, |omega|
+    cross-correlation, time compensation, central differences): rows of Log/IMU_meas.txt / Log/LiDAR_meas.txt reproduced to
+    the files' print precision.  The fixture lacks the last input sample (fout_before_filter omits it), which perturbs the
+    reflection padding: the comparison is tight on the first 1000 rows and documented-loose on the tail.
+  * the three solves, with a Levenberg-Marquardt loop that follows Ceres' documented trajectory: the committed answers are an
+    early-terminated Ceres iterate (0.03 deg from the minimiser); this restatement lands 10x closer than that.
+"""
+import numpy as np
+
+import li_init_fixture as F
+
+
+def _rows(seq, lidar=False):
+    from oracle import li_init_np as LI
+    acc = seq.linear_acc - LI.STD_GRAV if lidar else seq.linear_acc
+    a = np.c_[seq.ang_vel, np.linalg.norm(seq.ang_vel, axis=1), acc, seq.ang_acc, seq.t]
+    return a[1:len(a) - 2]  # central_diff prints indices 1 .. n-3
+
+
+def test_conditioning_chain_reproduces_reference_logs():
+    d = F.load()
+    out = F.run(solve=False)
+    assert out["lag_frames"] == -4 and abs(out["time_lag_1"] + 0.08) < 1e-12   # "IMU lag wtr Lidar : 4" at 50 Hz
+    mine_i, mine_l = _rows(out["imu_meas"]), _rows(out["lidar_meas"], lidar=True)
+    gi, gl = d["imu_meas"], d["lidar_meas"]
+    assert len(mine_i) == len(gi) - 1  # one row short: the input lacks its last sample
+    k = 1000
+    assert np.abs(mine_i[:k, 10] - gi[:k, 10]).max() < 1e-8          # stamps (12 significant digits printed)
+    assert np.abs(mine_i[:k, 0:4] - gi[:k, 0:4]).max() < 1e-10       # IMU omega, |omega|
+    assert np.abs(mine_i[:k, 4:7] - gi[:k, 4:7]).max() < 1e-9        # IMU acceleration (filtered + normalised)
+    assert np.abs(mine_i[:k, 7:10] - gi[:k, 7:10]).max() < 5e-9      # IMU angular acceleration
+    assert np.abs(mine_l[:k, 0:4] - gl[:k, 0:4]).max() < 1e-10       # LiDAR omega
+    assert np.abs(mine_l[:k, 7:10] - gl[:k, 7:10]).max() < 1e-8      # LiDAR angular acceleration
+    assert np.abs(mine_l[:k, 4:7] - gl[:k, 4:7]).max() < 1e-4        # LiDAR linear acc: input velocities have 6 digits
+    # tail: bounded influence of the missing last sample
+    assert np.abs(mine_i[1000:1200, :10] - gi[1000:1200, :10]).max() < 1e-7
+    assert np.abs(mine_i[1200:, :10] - gi[1200:len(mine_i), :10]).max() < 0.05
+
+
+def test_solves_land_on_the_committed_result():
+    from oracle import oracle as O
+    d = F.load()
+    out = F.run(solve=True)
+    s2, s3 = out["stage2"], out["stage3"]
+    euler = O.rot_to_euler(s2["R_LI"]) * 57.3
+    assert np.abs(euler - d["result_rot_euler_deg"]).max() < 0.01          # deg (committed: -0.937632 -0.323818 88.130258)
+    assert np.abs(s2["gyro_bias"] - d["result_gyro_bias"]).max() < 5e-5    # rad/s
+    # stage-2 soft lag: Log/acc_cost.txt row 0 IMU stamp 3106.963272 vs Log/IMU_meas.txt 3106.95848 + ... -> about -0.0048 s
+    lag2_ref = d["acc_cost"][0, 6] - (d["imu_meas"][0, 10] - (d["acc_cost"][0, 7] - d["lidar_meas"][0, 10]))
+    assert abs(s2["time_lag_2"] - (-0.00479)) < 5e-4
+    assert abs(out["time_delay"] - (out["time_lag_1"] + s2["time_lag_2"])) < 1e-15
+    assert np.abs(s3["T_LI"] - d["result_trans"]).max() < 1e-3             # m   (inputs: 6-digit velocities / attitudes)
+    assert np.abs(s3["acc_bias"] - d["result_acc_bias"]).max() < 1e-5      # m/s^2 (on the +-0.01 bound in the LiDAR frame)
+    assert np.abs(s3["grav_L0"] - d["result_gravity"]).max() < 2e-3        # m/s^2
+    assert abs(np.linalg.norm(s3["grav_L0"]) - 9.81) < 1e-9
+    # R_LI w_L + b_g after the stage-2 solve = Log/Lidar_omg_after_rot.txt
+    mine, t = out["lidar_after_rot"]
+    ar = d["after_rot"]
+    assert np.abs(t[:1000] - ar[:1000, 3]).max() < 1e-8
+    assert np.abs(mine[:1000] - ar[:1000, :3]).max() < 2e-4
+    assert np.isfinite(lag2_ref)
+
+
+def test_quaternion_helpers_and_jacobians():
+    """Analytic Jacobians of the three cost functors against central finite differences of the residuals."""
+    from oracle import li_init_np as LI
+    out = F.run(solve=False)
+    imu, lid = out["imu_stage12"].slice(slice(0, 200)), out["lidar_stage12"].slice(slice(0, 200))
+    rng = np.random.default_rng(0)
+    q = LI.rot_to_quat(LI.quat_to_rot(np.array([0.8, 0.1, -0.2, 0.55]) / np.linalg.norm([0.8, 0.1, -0.2, 0.55])))
+    assert np.allclose(LI.quat_to_rot(LI.quat_plus(q, np.zeros(3))), LI.quat_to_rot(q))
+
+    def cost(stage, R, v, R_LI=None):
+        return LI.normal_equations(stage, R, v, imu, lid, R_LI)[2]
+
+    def expm(d):
+        from oracle import oracle as O
+        return O.exp_so3(d)
+
+    for stage, nv in ((1, 0), (2, 4), (3, 6)):
+        R = LI.quat_to_rot(q)
+        v = rng.normal(0, 0.01, nv)
+        R_LI = LI.quat_to_rot(q) if stage == 3 else None
+        JtJ, Jtr, c0 = LI.normal_equations(stage, R, v, imu, lid, R_LI)
+        dof = 3 + nv
+        g = np.zeros(dof)
+        h = 1e-6
+        for k in range(dof):
+            d = np.zeros(dof); d[k] = h
+            cp = cost(stage, expm(d[:3]) @ R, v + d[3:], R_LI)
+            cm = cost(stage, expm(-d[:3]) @ R, v - d[3:], R_LI)
+            g[k] = (cp - cm) / (2 * h)
+        assert np.allclose(g, Jtr, rtol=1e-5, atol=1e-6 * max(1.0, np.abs(Jtr).max()))
+        assert np.allclose(JtJ, JtJ.T) and np.all(np.linalg.eigvalsh(JtJ) > -1e-9)
