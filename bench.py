@@ -126,7 +126,7 @@ def main():
         reg.scan_set_device(dev_scans[j])
         reg.undistort_imu(T, eye, np.zeros(3), eye, np.zeros(3))
         if not args.no_downsample:
-            reg.downsample(wl["fs_surf"])
+            reg.downsample(wl["fs_surf"], want_count=False)
         else:
             reg.downsample_skip()
         st = states0[j].copy()

@@ -118,6 +118,7 @@ int lii_map_commit(lii_handle h);
  * lii_undistort_imu <- back-propagation loop of ImuProcess::propagation_and_undist, src/IMU_Processing.hpp:390-414
  * lii_undistort_cv  <- CV de-skew of Forward_propagation_without_imu,            src/IMU_Processing.hpp:246-266
  * lii_downsample    <- downSizeFilterSurf.filter(*feats_down_body),              src/laserMapping.cpp:917-919
+ *                      (n_down == NULL && filtered == NULL: fully asynchronous — the result size stays on the device)
  * lii_downsample_skip: use the (undistorted) scan as feats_down_body unchanged (PCL's overflow-identity path).
  * lii_scan_download: which = 0 undistorted scan, 1 down-sampled body points, 2 world points of the last iteration. */
 int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_bytes, int32_t time_offset_bytes);

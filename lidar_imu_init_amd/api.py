@@ -265,7 +265,12 @@ class Registrar:
         a = [np.ascontiguousarray(x, np.float64).reshape(-1) for x in (omega, vel, end_R)]
         self._check(self.L.lii_undistort_cv(self.h, *[_ptr(x) for x in a]))
 
-    def downsample(self, leaf: float):
+    def downsample(self, leaf: float, want_count: bool = True):
+        """Voxel-grid filter.  want_count=False keeps it asynchronous: the size of the result stays on the device
+        (the registration kernels read it there) and no host synchronisation happens."""
+        if not want_count:
+            self._check(self.L.lii_downsample(self.h, float(leaf), None, None))
+            return None
         n, f = C.c_int32(0), C.c_int32(0)
         self._check(self.L.lii_downsample(self.h, float(leaf), C.byref(n), C.byref(f)))
         return n.value, bool(f.value)

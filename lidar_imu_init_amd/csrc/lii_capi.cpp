@@ -67,10 +67,14 @@ struct lii_context {
   unsigned int *d_vkeys_a = nullptr, *d_vkeys_b = nullptr, *d_vidx_a = nullptr, *d_vidx_b = nullptr, *d_vflags = nullptr,
                *d_vranks = nullptr;
   double* d_poses = nullptr;
-  int n_scan = 0, n_body = 0;
+  int n_scan = 0, n_body = 0;   // n_body is an upper bound while n_body_pending (the exact count lives in d_nbody)
+  bool n_body_pending = false;
+  int last_filtered = 1;
+  int* d_nbody = nullptr;       // [0] size of the down-sampled cloud, [1] `filtered` flag of the last voxel filter
+  void* d_voxel_arg = nullptr;
   bool body_is_scan = false;
   bool have_search = false;
-  int knn_variant = 1;  // 0: one lane per query (fused), 1: eight lanes per query (default), 2: four lanes per query, row-based
+  int knn_variant = 3;  // 0: one lane/query fused; 1: eight lanes/query, all 27 cells; 2: four lanes/query, rows; 3: eight lanes/query, pruned (default)
 
   // ---- pinned staging
   float4* h_stage = nullptr;     // max(max_scan, max_map) float4
@@ -142,6 +146,7 @@ RegistrationBuffers reg_buffers(const lii_context* c) {
   rb.needy_count = c->d_counter;
   rb.partial_stride = c->partial_stride;
   rb.n = c->n_body;
+  rb.n_dev = c->n_body_pending ? c->d_nbody : nullptr;
   rb.cap = c->cfg.max_scan_points;
   return rb;
 }
@@ -211,6 +216,27 @@ int commit_map(lii_handle h) {
   return LII_OK;
 }
 
+void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, int forced) {
+  switch (h->knn_variant) {
+    case 1: launch_knn8(g, rb, ps, pose, h->d_ctrl, forced, h->stream); break;
+    case 2: launch_knn4(g, rb, ps, pose, h->d_ctrl, forced, h->stream); break;
+    default: launch_knn8p(g, rb, ps, pose, h->d_ctrl, forced, h->stream); break;
+  }
+}
+
+// Fetches the exact size of the down-sampled cloud from the device (one small synchronising copy).
+int resolve_n_body(lii_handle h) {
+  if (!h->n_body_pending) return LII_OK;
+  HIPCHK(h, hipMemcpyAsync(h->h_small + 2048, h->d_nbody, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int v[2];
+  std::memcpy(v, h->h_small + 2048, sizeof(v));
+  h->n_body = v[0];
+  h->last_filtered = v[1];
+  h->n_body_pending = false;
+  return LII_OK;
+}
+
 int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double* out91) {
   if (h->n_body <= 0) return fail(h, LII_ERR_STATE, "no down-sampled scan (call lii_downsample / lii_downsample_skip)");
   int rc = commit_map(h);
@@ -225,14 +251,14 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
     launch_register_fused(search, g, rb, ps, imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, h->stream);
     if (prof) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
   } else {
-    if (search) { if (h->knn_variant == 1) launch_knn8(g, rb, ps, h->d_pose, h->d_ctrl, 1, h->stream); else launch_knn4(g, rb, ps, h->d_pose, h->d_ctrl, 1, h->stream); }
+    if (search) launch_knn(h, g, rb, ps, h->d_pose, 1);
     if (prof) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     if (search) launch_knn_fallback(g, rb, h->d_ctrl, 1, h->stream);
     launch_fit_reduce(rb, ps, h->d_pose, h->d_ctrl, search ? 1 : 0, imu_en ? 1 : 0, h->cfg.plane_threshold,
                       h->cfg.laser_point_cov_inv, h->stream);
   }
   if (prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-  launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, 1, h->stream);
+  launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, 1, rb.n_dev, h->stream);
   if (prof) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
   if (search) h->have_search = true;
   if (h->comm) {
@@ -285,12 +311,12 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   for (int it = 0; it < opts->max_iterations; it++) {
     const bool timed = prof && it == 0;  // the first pass always searches
     if (timed) HIPCHK(h, hipEventRecord(h->ev[0], s));
-    if (h->knn_variant == 1) launch_knn8(g, rb, ps0, pose, h->d_ctrl, -1, s); else launch_knn4(g, rb, ps0, pose, h->d_ctrl, -1, s);
+    launch_knn(h, g, rb, ps0, pose, -1);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[3], s));
     launch_knn_fallback(g, rb, h->d_ctrl, -1, s);
     launch_fit_reduce(rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[1], s));
-    launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, -1, s);
+    launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, -1, rb.n_dev, s);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
     if (h->comm) {
       // every rank enqueues the same number of all-reduces; a pass that is skipped on the device re-sums the
@@ -415,6 +441,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_plane, N * 4));
   CK(dmalloc(&h->d_selected, N));
   CK(dmalloc(&h->d_needy, N));
+  CK(dmalloc(&h->d_nbody, 4));
+  CK(hipMalloc(&h->d_voxel_arg, 64));
   CK(dmalloc(&h->d_ctrl, 1));
   CK(dmalloc(&h->d_pose, 1));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_ctrl), sizeof(IekfCtrl), hipHostMallocDefault));
@@ -451,7 +479,7 @@ int lii_destroy(lii_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
-                 h->d_selected, h->d_needy, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
+                 h->d_selected, h->d_needy, h->d_nbody, h->d_voxel_arg, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
                  h->d_vidx_b, h->d_vflags, h->d_vranks, h->d_poses, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)
@@ -534,6 +562,7 @@ int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->n_scan = n;
   h->n_body = 0;
+  h->n_body_pending = false;
   h->have_search = false;
   return LII_OK;
 }
@@ -543,6 +572,7 @@ int lii_scan_set_device(lii_handle h, const void* dev_float4, int32_t n) {
   if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scan, dev_float4, sizeof(float4) * size_t(n), hipMemcpyDeviceToDevice, h->stream));
   h->n_scan = n;
   h->n_body = 0;
+  h->n_body_pending = false;
   h->have_search = false;
   return LII_OK;
 }
@@ -582,6 +612,7 @@ int lii_downsample_skip(lii_handle h, int32_t* n_down) {
   if (h->n_scan > 0)
     HIPCHK(h, hipMemcpyAsync(h->d_body, h->d_scan, sizeof(float4) * size_t(h->n_scan), hipMemcpyDeviceToDevice, h->stream));
   h->n_body = h->n_scan;
+  h->n_body_pending = false;
   h->have_search = false;
   if (n_down) *n_down = h->n_body;
   return LII_OK;
@@ -589,6 +620,7 @@ int lii_downsample_skip(lii_handle h, int32_t* n_down) {
 int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered) {
   if (!h || !(leaf > 0)) return fail(h, LII_ERR_INVALID, "lii_downsample: bad arguments");
   h->have_search = false;
+  h->n_body_pending = false;
   const int n = h->n_scan;
   if (n <= 0) {
     h->n_body = 0;
@@ -596,54 +628,32 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
     if (filtered) *filtered = 1;
     return LII_OK;
   }
+  // Entirely on the stream: bounding box -> (device) overflow guard + grid parameters -> keys -> stable radix sort ->
+  // voxel-start flags -> scan -> centroids + count.  The size of the result stays in HBM (d_nbody); the registration
+  // kernels read it there, so the host learns it only if the caller asks (n_down / filtered != NULL, or a download).
   hipStream_t s = h->stream;
   launch_voxel_minmax(h->d_scan, n, h->d_mm, s);
-  HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_mm, 6 * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipStreamSynchronize(s));
-  unsigned int mm[6];
-  std::memcpy(mm, h->h_small, sizeof(mm));
-  if (mm[0] == 0xFFFFFFFFu) {  // no finite point at all
-    h->n_body = 0;
-    if (n_down) *n_down = 0;
-    if (filtered) *filtered = 1;
-    return LII_OK;
-  }
-  float mn[3], mx[3];
-  for (int a = 0; a < 3; a++) { mn[a] = ord_to_float(mm[a]); mx[a] = ord_to_float(mm[3 + a]); }
-  const float inv = 1.0f / leaf;
-  // PCL's index-overflow guard: (dx*dy*dz) > INT32_MAX  ->  output = input
-  int64_t dx = int64_t((mx[0] - mn[0]) * inv) + 1, dy = int64_t((mx[1] - mn[1]) * inv) + 1, dz = int64_t((mx[2] - mn[2]) * inv) + 1;
-  if (dx * dy * dz > int64_t(2147483647)) {
-    int rc = lii_downsample_skip(h, n_down);
-    if (filtered) *filtered = 0;
-    return rc;
-  }
-  VoxelArgH v;
-  v.inv_leaf = inv;
-  int div_b[3];
-  for (int a = 0; a < 3; a++) {
-    v.min_b[a] = int(std::floor(mn[a] * inv));
-    int max_b = int(std::floor(mx[a] * inv));
-    div_b[a] = max_b - v.min_b[a] + 1;
-  }
-  v.mul[0] = 1; v.mul[1] = div_b[0]; v.mul[2] = div_b[0] * div_b[1];
-  launch_voxel_keys(h->d_scan, n, v, h->d_vkeys_a, h->d_vidx_a, s);
+  launch_voxel_prepare(h->d_mm, leaf, h->d_voxel_arg, h->d_nbody + 1, s);
+  launch_voxel_keys(h->d_scan, n, h->d_voxel_arg, h->d_vkeys_a, h->d_vidx_a, s);
   sort_pairs_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a, h->d_vidx_b, n, s);
   launch_voxel_flags(h->d_vkeys_b, n, h->d_vflags, s);
   inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_vflags, h->d_vranks, n, s);
-  launch_voxel_centroid(h->d_scan, h->d_vkeys_b, h->d_vidx_b, h->d_vflags, h->d_vranks, n, h->d_body, s);
-  HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_vranks + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipStreamSynchronize(s));
-  unsigned int nd;
-  std::memcpy(&nd, h->h_small, 4);
-  h->n_body = int(nd);
-  if (n_down) *n_down = h->n_body;
-  if (filtered) *filtered = 1;
+  launch_voxel_centroid(h->d_scan, h->d_vkeys_b, h->d_vidx_b, h->d_vflags, h->d_vranks, n, h->d_body, h->d_nbody, s);
+  HIPCHK(h, hipGetLastError());
+  h->n_body = n;  // upper bound until resolved
+  h->n_body_pending = true;
+  if (n_down || filtered) {
+    int rc = resolve_n_body(h);
+    if (rc != LII_OK) return rc;
+    if (n_down) *n_down = h->n_body;
+    if (filtered) *filtered = h->last_filtered;
+  }
   return LII_OK;
 }
 int lii_scan_download(lii_handle h, int32_t which, float* out_float4, int32_t capacity, int32_t* n) {
   if (!h || !n) return LII_ERR_INVALID;
   const float4* src = which == 0 ? h->d_scan : (which == 1 ? h->d_body : h->d_world);
+  if (which != 0) { int rc0 = resolve_n_body(h); if (rc0 != LII_OK) return rc0; }
   int cnt = which == 0 ? h->n_scan : h->n_body;
   *n = cnt;
   if (!out_float4) return LII_OK;
@@ -746,6 +756,7 @@ int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_prop,
 
 int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* selected, int32_t capacity) {
   if (!h) return LII_ERR_INVALID;
+  { int rc0 = resolve_n_body(h); if (rc0 != LII_OK) return rc0; }
   const int n = h->n_body;
   if (capacity < n) return fail(h, LII_ERR_CAPACITY, "lii_neighbors_download: capacity too small");
   if (n == 0) return LII_OK;
@@ -777,6 +788,7 @@ int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* s
 
 int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, int32_t* n_no_downsample) {
   if (!h || !state) return fail(h, LII_ERR_INVALID, "lii_map_incremental: bad arguments");
+  { int rc0 = resolve_n_body(h); if (rc0 != LII_OK) return rc0; }
   const int n = h->n_body;
   if (n <= 0) { if (n_add) *n_add = 0; if (n_no_downsample) *n_no_downsample = 0; return LII_OK; }
   // body points + neighbour lists of the last search come back to the host (this row is "next" in the

@@ -54,8 +54,9 @@ struct RegistrationBuffers {
   unsigned int* needy_count;
   double* partials;     // transposed per-block partial sums: partials[t * partial_stride + block], t < 91
   int partial_stride;
-  int n;
+  int n;              // number of points, or an upper bound of it when n_dev != nullptr
   int cap;
+  const int* n_dev;   // device-resident point count (set by the sync-free voxel filter), or nullptr
 };
 
 // Device-resident control block of one scan registration (lii_iekf_update): the state, the propagated state and

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void k_register(GridView g, RegistrationBuf
                                                       double plane_thr, double rinv) {
   __shared__ ReduceShared sh;
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  const bool live = i < rb.n;
+  const bool live = i < (rb.n_dev ? *rb.n_dev : rb.n);
   RowOut o;
 #pragma unroll
   for (int c = 0; c < 12; c++) o.h[c] = 0;
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(kBlock) void k_knn8(GridView g, RegistrationBuffers
   if (blk >= nb_real) return;
   const int sub = threadIdx.x & (kLanesPerQuery - 1);
   const int qi = blk * kQueriesPerBlock + (threadIdx.x >> 3);
-  const bool live = qi < rb.n;
+  const bool live = qi < (rb.n_dev ? *rb.n_dev : rb.n);
   // dead query slots still take part in the shuffles; they search nothing
   float wx = 0, wy = 0, wz = 0;
   if (live) {
@@ -687,6 +687,117 @@ __global__ __launch_bounds__(kBlock) void k_knn8(GridView g, RegistrationBuffers
 }
 
 // ------------------------------------------------------------------------------------------------
+// Variant 3 of the search pass: eight lanes per query with box-distance pruning in two rounds.
+// Round 1: the 2x2x2 block of cells nearest to the query (own cell + the neighbour on the nearer side of every axis) —
+// exactly one cell per lane — which covers the ball of radius g0 = min_axis max(f, cs - f) >= cs / 2 around the query.
+// If the merged 5th distance is within g0 the search is complete (the usual case for a converged map).
+// Round 2: the other 19 cells of the 3x3x3 block, each tested against the current 5th distance first (the tree's
+// calc_box_dist rule), so most of them cost neither a table lookup nor a candidate.
+__device__ __forceinline__ uint2 lookup_cell(const GridView& g, const uint4* __restrict__ tab, int ix, int iy, int iz) {
+  const int bb = kCellBias >> kCoarseShift;
+  const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
+  const unsigned long long bk = pack_block(bx, by, bz);
+  unsigned int sl = hash_block(bx, by, bz) & g.block_mask;
+  uint4 e = tab[sl];
+  unsigned long long ek = ((unsigned long long)e.y << 32) | e.x;
+  while (ek != bk && ek != kEmptyKey) {
+    sl = (sl + 1) & g.block_mask;
+    e = tab[sl];
+    ek = ((unsigned long long)e.y << 32) | e.x;
+  }
+  if (ek != bk) return make_uint2(0u, 0u);
+  const unsigned local = (((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u);
+  return g.cells[(size_t)e.z * kBlockCells + local];
+}
+
+__global__ __launch_bounds__(kBlock) void k_knn8p(GridView g, RegistrationBuffers rb, PoseArg ps_val,
+                                                   const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
+                                                   int forced, int nb_real) {
+  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
+  const PoseArg ps = forced < 0 ? *pose : ps_val;
+  const int blk = xcd_remap(blockIdx.x, nb_real);
+  if (blk >= nb_real) return;
+  const int sub = threadIdx.x & (kLanesPerQuery - 1);
+  const int qi = blk * kQueriesPerBlock + (threadIdx.x >> 3);
+  const bool live = qi < (rb.n_dev ? *rb.n_dev : rb.n);
+  const int leader = (threadIdx.x & 63) & ~(kLanesPerQuery - 1);
+  float wx = 0, wy = 0, wz = 0;
+  if (live && sub == 0) {
+    float4 pb = rb.body[qi];
+    double bx = pb.x, by = pb.y, bz = pb.z;
+    double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
+    double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
+    double iz = ps.RLI[6] * bx + ps.RLI[7] * by + ps.RLI[8] * bz + ps.TLI[2];
+    wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
+    wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
+    wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
+  }
+  wx = __shfl(wx, leader); wy = __shfl(wy, leader); wz = __shfl(wz, leader);
+  const float INF = __builtin_inff();
+  Knn5 k;
+  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = INF;
+  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
+  const float cs = g.cs;
+  const float eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
+  const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
+  const bool active = live && g.n_pts > 0;
+  const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
+  // position of the query inside its cell and the nearer-side neighbour on every axis
+  const float fx = fminf(fmaxf(wx - (float)cx * cs, 0.f), cs), fy = fminf(fmaxf(wy - (float)cy * cs, 0.f), cs),
+              fz = fminf(fmaxf(wz - (float)cz * cs, 0.f), cs);
+  const int ox = fx < 0.5f * cs ? -1 : 1, oy = fy < 0.5f * cs ? -1 : 1, oz = fz < 0.5f * cs ? -1 : 1;
+  if (active) {
+    const uint2 r = lookup_cell(g, tab, cx + ((sub & 1) ? ox : 0), cy + ((sub & 2) ? oy : 0), cz + ((sub & 4) ? oz : 0));
+    scan_range(g, r.x, r.y, wx, wy, wz, k);
+  }
+  knn_group_merge<false>(k);
+  const float g0 = fminf(fminf(fmaxf(fx, cs - fx), fmaxf(fy, cs - fy)), fmaxf(fz, cs - fz)) - 2.f * eps;
+  bool more = active && !(fminf(k.d4, g.max_d2) <= g0 * g0);
+  if (__any(more)) {
+    // every lane of the group now holds the same 5th distance (ties aside, which only makes the bound equal)
+    const float bound = fminf(__shfl(k.d4, leader), g.max_d2);
+    if (more) {
+      // the 19 remaining cells of the 3x3x3 block: enumerate all 27, skip the 8 of round 1
+      for (int c = sub; c < 27; c += 8) {
+        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+        const bool in_r1 = (dx == 0 || dx == ox) && (dy == 0 || dy == oy) && (dz == 0 || dz == oz);
+        if (in_r1) continue;
+        const float gx = axis_gap(wx, cx + dx, cs, eps), gy = axis_gap(wy, cy + dy, cs, eps), gz = axis_gap(wz, cz + dz, cs, eps);
+        if (gx * gx + gy * gy + gz * gz > bound) continue;
+        const uint2 r = lookup_cell(g, tab, cx + dx, cy + dy, cz + dz);
+        scan_range(g, r.x, r.y, wx, wy, wz, k);
+      }
+    }
+    // round-2 lists start from the shared round-1 list: merge with duplicate suppression
+    knn_group_merge<true>(k);
+  }
+  k.d0 = __shfl(k.d0, leader); k.d1 = __shfl(k.d1, leader); k.d2 = __shfl(k.d2, leader); k.d3 = __shfl(k.d3, leader);
+  k.d4 = __shfl(k.d4, leader);
+  k.i0 = __shfl(k.i0, leader); k.i1 = __shfl(k.i1, leader); k.i2 = __shfl(k.i2, leader); k.i3 = __shfl(k.i3, leader);
+  k.i4 = __shfl(k.i4, leader);
+  const float mfrac = fmaxf(fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz)), 0.f);
+  const float guard = cs + mfrac - 2.f * eps;
+  const bool need = active && !(fminf(k.d4, g.max_d2) <= guard * guard);
+  if (live) {
+    const int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
+    if (sub < 5) {
+      const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : (sub == 3 ? k.i3 : k.i4)));
+      const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : (sub == 3 ? k.d3 : k.d4)));
+      float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
+      v.w = dd;
+      rb.nbr[(size_t)sub * rb.cap + qi] = v;
+    } else if (sub == 5) {
+      rb.nbr_count[qi] = found;
+    } else if (sub == 6) {
+      rb.world[qi] = make_float4(wx, wy, wz, 0.f);
+    } else if (need) {
+      unsigned int slot = atomicAdd(rb.needy_count, 1u);
+      rb.needy[slot] = qi;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Variant 2 of the search pass (default): FOUR lanes per query, 64 queries per workgroup, so that the whole scan
 // is resident in one round of waves and far less per-query work is replicated across lanes than with eight.
 // The 3x3x3 neighbourhood is split into its 9 (dy, dz) rows of three x-adjacent cells; row r belongs to lane r % 4.
@@ -745,7 +856,7 @@ __global__ __launch_bounds__(kBlock) void k_knn4(GridView g, RegistrationBuffers
   if (blk >= nb_real) return;
   const int sub = threadIdx.x & 3;
   const int qi = blk * kQueriesPerBlock4 + (threadIdx.x >> 2);
-  const bool live = qi < rb.n;
+  const bool live = qi < (rb.n_dev ? *rb.n_dev : rb.n);
   const int lane = threadIdx.x & 63, leader = lane & ~3;
   // pointBodyToWorld on the group leader, broadcast to the other three lanes
   float wx = 0, wy = 0, wz = 0;
@@ -1018,7 +1129,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(RegistrationBuffers rb, P
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;  // uniform per block
   const int i = blk * kBlock + threadIdx.x;
-  const bool live = i < rb.n;
+  const bool live = i < (rb.n_dev ? *rb.n_dev : rb.n);
   RowOut o;
 #pragma unroll
   for (int c = 0; c < 12; c++) o.h[c] = 0;
@@ -1069,8 +1180,9 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(RegistrationBuffers rb, P
 // L2 miss; one latency instead of a dependent chain of them.)  Workgroup 0 also re-arms the fallback queue.
 __global__ __launch_bounds__(64) void k_reduce91(const double* __restrict__ partials, int n_blocks, int stride,
                                                   double* __restrict__ out, unsigned int* needy_count,
-                                                  const IekfCtrl* __restrict__ ctrl, int forced) {
+                                                  const IekfCtrl* __restrict__ ctrl, int forced, const int* __restrict__ n_dev) {
   if (forced < 0 && ctrl->stop) return;
+  if (n_dev) n_blocks = max(1, (*n_dev + kBlock - 1) / kBlock);
   const int t = blockIdx.x, lane = threadIdx.x;
   const double* row = partials + (size_t)t * stride;
   double acc = 0;
@@ -1241,15 +1353,17 @@ __global__ void k_undistort_cv(float4* __restrict__ pts, int n, CvArg a, const u
 // ------------------------------------------------------------------------------------------------
 // voxel-grid down-sampling (PCL VoxelGrid restatement)
 // mm[0..2] = ord(min xyz), mm[3..5] = ord(max xyz)
-__global__ void k_voxel_minmax(const float4* __restrict__ pts, int n, unsigned int* __restrict__ mm) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_voxel_minmax(const float4* __restrict__ pts, int n, unsigned int* __restrict__ mm) {
+  // grid-stride over a small grid, wave shuffle + LDS reduction, ONE set of atomics per workgroup
+  __shared__ unsigned int s_lo[4][3], s_hi[4][3];
   unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
-  if (i < n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float4 p = pts[i];
     if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-      lo[0] = hi[0] = f2ord(p.x);
-      lo[1] = hi[1] = f2ord(p.y);
-      lo[2] = hi[2] = f2ord(p.z);
+      unsigned int ox = f2ord(p.x), oy = f2ord(p.y), oz = f2ord(p.z);
+      lo[0] = min(lo[0], ox); hi[0] = max(hi[0], ox);
+      lo[1] = min(lo[1], oy); hi[1] = max(hi[1], oy);
+      lo[2] = min(lo[2], oz); hi[2] = max(hi[2], oz);
     }
   }
 #pragma unroll
@@ -1260,12 +1374,18 @@ __global__ void k_voxel_minmax(const float4* __restrict__ pts, int n, unsigned i
       hi[a] = max(hi[a], y);
     }
   }
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      atomicMin(&mm[a], lo[a]);
-      atomicMax(&mm[3 + a], hi[a]);
-    }
+    for (int a = 0; a < 3; a++) { s_lo[wave][a] = lo[a]; s_hi[wave][a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    unsigned int l = min(min(s_lo[0][a], s_lo[1][a]), min(s_lo[2][a], s_lo[3][a]));
+    unsigned int h = max(max(s_hi[0][a], s_hi[1][a]), max(s_hi[2][a], s_hi[3][a]));
+    atomicMin(&mm[a], l);
+    atomicMax(&mm[3 + a], h);
   }
 }
 
@@ -1273,14 +1393,50 @@ struct VoxelArg {
   float inv_leaf;
   int min_b[3];
   int mul[3];
+  int identity;  // PCL's int32 index-overflow guard tripped: output = input
 };
-__global__ void k_voxel_keys(const float4* __restrict__ pts, int n, VoxelArg v, unsigned int* __restrict__ keys,
+// Derives the voxel-grid parameters from the min/max reduction ON THE DEVICE (no host round trip):
+// PCL VoxelGrid::applyFilter — bounding box, (dx*dy*dz) > INT32_MAX -> "Leaf size is too small" -> identity copy.
+__global__ void k_voxel_prepare(const unsigned int* __restrict__ mm, float leaf, VoxelArg* __restrict__ out, int* __restrict__ filtered) {
+  if (threadIdx.x != 0) return;
+  VoxelArg v;
+  v.inv_leaf = 1.0f / leaf;
+  v.identity = 0;
+  for (int a = 0; a < 3; a++) { v.min_b[a] = 0; v.mul[a] = 0; }
+  if (mm[0] != 0xFFFFFFFFu) {  // at least one finite point
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; a++) {
+      unsigned int lo = mm[a], hi = mm[3 + a];
+      unsigned int ul = (lo & 0x80000000u) ? (lo & 0x7FFFFFFFu) : ~lo, uh = (hi & 0x80000000u) ? (hi & 0x7FFFFFFFu) : ~hi;
+      mn[a] = __uint_as_float(ul);
+      mx[a] = __uint_as_float(uh);
+    }
+    long long dx = (long long)((mx[0] - mn[0]) * v.inv_leaf) + 1, dy = (long long)((mx[1] - mn[1]) * v.inv_leaf) + 1,
+              dz = (long long)((mx[2] - mn[2]) * v.inv_leaf) + 1;
+    if (dx * dy * dz > 2147483647LL) {
+      v.identity = 1;
+    } else {
+      int div_b[3];
+      for (int a = 0; a < 3; a++) {
+        v.min_b[a] = (int)floorf(mn[a] * v.inv_leaf);
+        div_b[a] = (int)floorf(mx[a] * v.inv_leaf) - v.min_b[a] + 1;
+      }
+      v.mul[0] = 1; v.mul[1] = div_b[0]; v.mul[2] = div_b[0] * div_b[1];
+    }
+  }
+  *out = v;
+  *filtered = v.identity ? 0 : 1;
+}
+__global__ void k_voxel_keys(const float4* __restrict__ pts, int n, const VoxelArg* __restrict__ vp, unsigned int* __restrict__ keys,
                              unsigned int* __restrict__ idx) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const VoxelArg v = *vp;
   float4 p = pts[i];
   unsigned int key = 0x7FFFFFFFu;  // non-finite points sort last and are dropped
-  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+  if (v.identity) {
+    key = (unsigned)i;  // every point is its own voxel, in input order
+  } else if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
     int i0 = (int)(floorf(p.x * v.inv_leaf) - (float)v.min_b[0]);
     int i1 = (int)(floorf(p.y * v.inv_leaf) - (float)v.min_b[1]);
     int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)v.min_b[2]);
@@ -1299,8 +1455,10 @@ __global__ void k_voxel_flags(const unsigned int* __restrict__ keys, int n, unsi
 // order (the sort is stable), float32, then divides by the count — the same order the oracle uses.
 __global__ void k_voxel_centroid(const float4* __restrict__ pts, const unsigned int* __restrict__ keys,
                                  const unsigned int* __restrict__ idx, const unsigned int* __restrict__ flags,
-                                 const unsigned int* __restrict__ ranks, int n, float4* __restrict__ out) {
+                                 const unsigned int* __restrict__ ranks, int n, float4* __restrict__ out,
+                                 int* __restrict__ n_out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == n - 1) *n_out = (int)ranks[n - 1];  // number of occupied voxels = size of the down-sampled cloud
   if (i >= n || !flags[i]) return;
   unsigned int k = keys[i];
   float sx = 0, sy = 0, sz = 0, st = 0;
@@ -1310,6 +1468,7 @@ __global__ void k_voxel_centroid(const float4* __restrict__ pts, const unsigned 
     sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
   }
   float c = (float)(j - i);
+  // a single-point voxel reproduces the point exactly (x / 1.0f == x), which is also what the identity path needs
   out[ranks[i] - 1] = make_float4(sx / c, sy / c, sz / c, st / c);
 }
 
@@ -1464,6 +1623,13 @@ void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg
   const int nq_pad = ((nq + 7) / 8) * 8;
   hipLaunchKernelGGL(k_knn8, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
 }
+void launch_knn8p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                  const IekfCtrl* ctrl, int forced, hipStream_t s) {
+  int nq = nblk(rb.n, kQueriesPerBlock);
+  if (nq < 1) nq = 1;
+  const int nq_pad = ((nq + 7) / 8) * 8;
+  hipLaunchKernelGGL(k_knn8p, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
+}
 void launch_knn4(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                  const IekfCtrl* ctrl, int forced, hipStream_t s) {
   int nq = nblk(rb.n, kQueriesPerBlock4);
@@ -1482,10 +1648,10 @@ void launch_fit_reduce(const RegistrationBuffers& rb, const PoseArg& ps, const P
   hipLaunchKernelGGL(k_fit_reduce, dim3(nb_pad), dim3(kBlock), 0, s, rb, ps, pose, ctrl, forced, imu_en, plane_thr, rinv, nb);
 }
 void launch_reduce91(const double* partials, int n_points, int stride, double* out91, unsigned int* needy_count,
-                     const IekfCtrl* ctrl, int forced, hipStream_t s) {
+                     const IekfCtrl* ctrl, int forced, const int* n_dev, hipStream_t s) {
   int nb = nblk(n_points, kBlock);
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, needy_count, ctrl, forced);
+  hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, needy_count, ctrl, forced, n_dev);
 }
 __global__ void k_extent_init(unsigned long long* e) {
   e[0] = ~0ull;
@@ -1518,20 +1684,25 @@ __global__ void k_minmax_init(unsigned int* mm) {
 }
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, hipStream_t s) {
   hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, s, mm);
-  if (n > 0) hipLaunchKernelGGL(k_voxel_minmax, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm);
+  if (n > 0) {
+    int nb = nblk(n, 256 * 4);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(k_voxel_minmax, dim3(nb), dim3(256), 0, s, pts, n, mm);
+  }
 }
-void launch_voxel_keys(const float4* pts, int n, const VoxelArgH& vh, unsigned int* keys, unsigned int* idx, hipStream_t s) {
-  VoxelArg v;
-  static_assert(sizeof(VoxelArg) == sizeof(VoxelArgH), "layout");
-  memcpy(&v, &vh, sizeof(v));
-  if (n > 0) hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, v, keys, idx);
+void launch_voxel_prepare(const unsigned int* mm, float leaf, void* voxel_arg_dev, int* filtered_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_voxel_prepare, dim3(1), dim3(64), 0, s, mm, leaf, reinterpret_cast<VoxelArg*>(voxel_arg_dev), filtered_dev);
+}
+void launch_voxel_keys(const float4* pts, int n, const void* voxel_arg_dev, unsigned int* keys, unsigned int* idx, hipStream_t s) {
+  if (n > 0)
+    hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, reinterpret_cast<const VoxelArg*>(voxel_arg_dev), keys, idx);
 }
 void launch_voxel_flags(const unsigned int* keys, int n, unsigned int* flags, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_voxel_flags, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, flags);
 }
 void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const unsigned int* idx, const unsigned int* flags,
-                           const unsigned int* ranks, int n, float4* out, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_voxel_centroid, dim3(nblk(n, 256)), dim3(256), 0, s, pts, keys, idx, flags, ranks, n, out);
+                           const unsigned int* ranks, int n, float4* out, int* n_out, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_voxel_centroid, dim3(nblk(n, 256)), dim3(256), 0, s, pts, keys, idx, flags, ranks, n, out, n_out);
 }
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s) {

@@ -23,13 +23,15 @@ void launch_register_fused(bool search, const GridView& g, const RegistrationBuf
                            double plane_thr, double rinv, hipStream_t s);
 void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                  const IekfCtrl* ctrl, int forced, hipStream_t s);
+void launch_knn8p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                  const IekfCtrl* ctrl, int forced, hipStream_t s);
 void launch_knn4(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                  const IekfCtrl* ctrl, int forced, hipStream_t s);
 void launch_knn_fallback(const GridView& g, const RegistrationBuffers& rb, const IekfCtrl* ctrl, int forced, hipStream_t s);
 void launch_fit_reduce(const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, const IekfCtrl* ctrl,
                        int forced, int imu_en, double plane_thr, double rinv, hipStream_t s);
 void launch_reduce91(const double* partials, int n_points, int stride, double* out91, unsigned int* needy_count,
-                     const IekfCtrl* ctrl, int forced, hipStream_t s);
+                     const IekfCtrl* ctrl, int forced, const int* n_dev, hipStream_t s);
 void launch_iekf_begin(IekfCtrl* c, hipStream_t s);
 void launch_iekf_solve(IekfCtrl* c, const double* ne, hipStream_t s);
 int register_blocks(int n);
@@ -40,10 +42,11 @@ void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const 
 void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned long long* extent, hipStream_t s);
 // voxel grid
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, hipStream_t s);
-void launch_voxel_keys(const float4* pts, int n, const VoxelArgH& v, unsigned int* keys, unsigned int* idx, hipStream_t s);
+void launch_voxel_prepare(const unsigned int* mm, float leaf, void* voxel_arg_dev, int* filtered_dev, hipStream_t s);
+void launch_voxel_keys(const float4* pts, int n, const void* voxel_arg_dev, unsigned int* keys, unsigned int* idx, hipStream_t s);
 void launch_voxel_flags(const unsigned int* keys, int n, unsigned int* flags, hipStream_t s);
 void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const unsigned int* idx, const unsigned int* flags,
-                           const unsigned int* ranks, int n, float4* out, hipStream_t s);
+                           const unsigned int* ranks, int n, float4* out, int* n_out, hipStream_t s);
 // calibration
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s);
