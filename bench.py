@@ -195,7 +195,7 @@ def main():
                                    f"LIO mode (12-col H), static map, {'voxel-grid leaf %.2f' % wl['fs_surf'] if not args.no_downsample else 'no voxel-grid'}",
                        "points_per_scan": n_full, "map_points": M, "avg_iterations": iters_total[0] / args.steps,
                        "avg_knn_passes": search_total[0] / args.steps, "parallelism": f"points sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_knn8 (exact 5-NN into the hash-grid local map, 8 lanes/query)",
+            "roofline": {"bound": "hbm", "kernel": "k_knn_pruned<4> (exact 5-NN into the block-grid local map, 4 lanes/query, box-distance pruning)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": avg_search_ms, "alg_bytes_per_launch": alg_bytes,
                          "launches": int(tm[5]), "avg_search_pass_ms": avg_pass_ms,

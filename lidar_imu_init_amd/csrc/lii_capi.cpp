@@ -74,7 +74,7 @@ struct lii_context {
   void* d_voxel_arg = nullptr;
   bool body_is_scan = false;
   bool have_search = false;
-  int knn_variant = 3;  // 0: one lane/query fused; 1: eight lanes/query, all 27 cells; 2: four lanes/query, rows; 3: eight lanes/query, pruned (default)
+  int knn_variant = 4;  // 0: 1 lane/query fused; 1: 8 lanes, all 27 cells; 2: 4 lanes, rows; 3: 8 lanes, pruned; 4: 4 lanes, pruned (default)
 
   // ---- pinned staging
   float4* h_stage = nullptr;     // max(max_scan, max_map) float4
@@ -220,6 +220,7 @@ void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, 
   switch (h->knn_variant) {
     case 1: launch_knn8(g, rb, ps, pose, h->d_ctrl, forced, h->stream); break;
     case 2: launch_knn4(g, rb, ps, pose, h->d_ctrl, forced, h->stream); break;
+    case 4: launch_knn4p(g, rb, ps, pose, h->d_ctrl, forced, h->stream); break;
     default: launch_knn8p(g, rb, ps, pose, h->d_ctrl, forced, h->stream); break;
   }
 }

@@ -710,17 +710,35 @@ __device__ __forceinline__ uint2 lookup_cell(const GridView& g, const uint4* __r
   return g.cells[(size_t)e.z * kBlockCells + local];
 }
 
-__global__ __launch_bounds__(kBlock) void k_knn8p(GridView g, RegistrationBuffers rb, PoseArg ps_val,
+template <int LPQ, bool DEDUP>
+__device__ __forceinline__ void knn_group_merge_n(Knn5& k) {
+#pragma unroll
+  for (int off = 1; off < LPQ; off <<= 1) {
+    float e0 = __shfl_xor(k.d0, off), e1 = __shfl_xor(k.d1, off), e2 = __shfl_xor(k.d2, off), e3 = __shfl_xor(k.d3, off),
+          e4 = __shfl_xor(k.d4, off);
+    int j0 = __shfl_xor(k.i0, off), j1 = __shfl_xor(k.i1, off), j2 = __shfl_xor(k.i2, off), j3 = __shfl_xor(k.i3, off),
+        j4 = __shfl_xor(k.i4, off);
+    if (j0 >= 0) knn_merge_one<DEDUP>(k, e0, j0);
+    if (j1 >= 0) knn_merge_one<DEDUP>(k, e1, j1);
+    if (j2 >= 0) knn_merge_one<DEDUP>(k, e2, j2);
+    if (j3 >= 0) knn_merge_one<DEDUP>(k, e3, j3);
+    if (j4 >= 0) knn_merge_one<DEDUP>(k, e4, j4);
+  }
+}
+
+template <int LPQ>
+__global__ __launch_bounds__(kBlock) void k_knn_pruned(GridView g, RegistrationBuffers rb, PoseArg ps_val,
                                                    const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
                                                    int forced, int nb_real) {
   if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
   const PoseArg ps = forced < 0 ? *pose : ps_val;
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;
-  const int sub = threadIdx.x & (kLanesPerQuery - 1);
-  const int qi = blk * kQueriesPerBlock + (threadIdx.x >> 3);
+  constexpr int QPB = kBlock / LPQ;
+  const int sub = threadIdx.x & (LPQ - 1);
+  const int qi = blk * QPB + threadIdx.x / LPQ;
   const bool live = qi < (rb.n_dev ? *rb.n_dev : rb.n);
-  const int leader = (threadIdx.x & 63) & ~(kLanesPerQuery - 1);
+  const int leader = (threadIdx.x & 63) & ~(LPQ - 1);
   float wx = 0, wy = 0, wz = 0;
   if (live && sub == 0) {
     float4 pb = rb.body[qi];
@@ -747,10 +765,17 @@ __global__ __launch_bounds__(kBlock) void k_knn8p(GridView g, RegistrationBuffer
               fz = fminf(fmaxf(wz - (float)cz * cs, 0.f), cs);
   const int ox = fx < 0.5f * cs ? -1 : 1, oy = fy < 0.5f * cs ? -1 : 1, oz = fz < 0.5f * cs ? -1 : 1;
   if (active) {
-    const uint2 r = lookup_cell(g, tab, cx + ((sub & 1) ? ox : 0), cy + ((sub & 2) ? oy : 0), cz + ((sub & 4) ? oz : 0));
-    scan_range(g, r.x, r.y, wx, wy, wz, k);
+    // the 8 cells of round 1 are dealt to the LPQ lanes; lookups first, then the candidate loops
+    uint2 r[8 / LPQ];
+#pragma unroll
+    for (int t = 0; t < 8 / LPQ; t++) {
+      const int c = sub + LPQ * t;
+      r[t] = lookup_cell(g, tab, cx + ((c & 1) ? ox : 0), cy + ((c & 2) ? oy : 0), cz + ((c & 4) ? oz : 0));
+    }
+#pragma unroll
+    for (int t = 0; t < 8 / LPQ; t++) scan_range(g, r[t].x, r[t].y, wx, wy, wz, k);
   }
-  knn_group_merge<false>(k);
+  knn_group_merge_n<LPQ, false>(k);
   const float g0 = fminf(fminf(fmaxf(fx, cs - fx), fmaxf(fy, cs - fy)), fmaxf(fz, cs - fz)) - 2.f * eps;
   bool more = active && !(fminf(k.d4, g.max_d2) <= g0 * g0);
   if (__any(more)) {
@@ -758,7 +783,7 @@ __global__ __launch_bounds__(kBlock) void k_knn8p(GridView g, RegistrationBuffer
     const float bound = fminf(__shfl(k.d4, leader), g.max_d2);
     if (more) {
       // the 19 remaining cells of the 3x3x3 block: enumerate all 27, skip the 8 of round 1
-      for (int c = sub; c < 27; c += 8) {
+      for (int c = sub; c < 27; c += LPQ) {
         const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
         const bool in_r1 = (dx == 0 || dx == ox) && (dy == 0 || dy == oy) && (dz == 0 || dz == oz);
         if (in_r1) continue;
@@ -769,7 +794,7 @@ __global__ __launch_bounds__(kBlock) void k_knn8p(GridView g, RegistrationBuffer
       }
     }
     // round-2 lists start from the shared round-1 list: merge with duplicate suppression
-    knn_group_merge<true>(k);
+    knn_group_merge_n<LPQ, true>(k);
   }
   k.d0 = __shfl(k.d0, leader); k.d1 = __shfl(k.d1, leader); k.d2 = __shfl(k.d2, leader); k.d3 = __shfl(k.d3, leader);
   k.d4 = __shfl(k.d4, leader);
@@ -780,22 +805,47 @@ __global__ __launch_bounds__(kBlock) void k_knn8p(GridView g, RegistrationBuffer
   const bool need = active && !(fminf(k.d4, g.max_d2) <= guard * guard);
   if (live) {
     const int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
-    if (sub < 5) {
-      const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : (sub == 3 ? k.i3 : k.i4)));
-      const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : (sub == 3 ? k.d3 : k.d4)));
-      float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
-      v.w = dd;
-      rb.nbr[(size_t)sub * rb.cap + qi] = v;
-    } else if (sub == 5) {
-      rb.nbr_count[qi] = found;
-    } else if (sub == 6) {
-      rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-    } else if (need) {
-      unsigned int slot = atomicAdd(rb.needy_count, 1u);
-      rb.needy[slot] = qi;
+    if (LPQ == 8) {
+      if (sub < 5) {
+        const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : (sub == 3 ? k.i3 : k.i4)));
+        const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : (sub == 3 ? k.d3 : k.d4)));
+        float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
+        v.w = dd;
+        rb.nbr[(size_t)sub * rb.cap + qi] = v;
+      } else if (sub == 5) {
+        rb.nbr_count[qi] = found;
+      } else if (sub == 6) {
+        rb.world[qi] = make_float4(wx, wy, wz, 0.f);
+      } else if (need) {
+        unsigned int slot = atomicAdd(rb.needy_count, 1u);
+        rb.needy[slot] = qi;
+      }
+    } else {
+      {
+        const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : k.i3));
+        const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : k.d3));
+        float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
+        v.w = dd;
+        rb.nbr[(size_t)sub * rb.cap + qi] = v;
+      }
+      if (sub == 0) {
+        float4 v = k.i4 >= 0 ? g.pts[k.i4] : make_float4(0, 0, 0, 0);
+        v.w = k.d4;
+        rb.nbr[(size_t)4 * rb.cap + qi] = v;
+      } else if (sub == 1) {
+        rb.nbr_count[qi] = found;
+      } else if (sub == 2) {
+        rb.world[qi] = make_float4(wx, wy, wz, 0.f);
+      } else if (need) {
+        unsigned int slot = atomicAdd(rb.needy_count, 1u);
+        rb.needy[slot] = qi;
+      }
     }
   }
 }
+
+template __global__ void k_knn_pruned<8>(GridView, RegistrationBuffers, PoseArg, const PoseArg*, const IekfCtrl*, int, int);
+template __global__ void k_knn_pruned<4>(GridView, RegistrationBuffers, PoseArg, const PoseArg*, const IekfCtrl*, int, int);
 
 // ------------------------------------------------------------------------------------------------
 // Variant 2 of the search pass (default): FOUR lanes per query, 64 queries per workgroup, so that the whole scan
@@ -1628,7 +1678,14 @@ void launch_knn8p(const GridView& g, const RegistrationBuffers& rb, const PoseAr
   int nq = nblk(rb.n, kQueriesPerBlock);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_knn8p, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
+  hipLaunchKernelGGL(k_knn_pruned<8>, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
+}
+void launch_knn4p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                  const IekfCtrl* ctrl, int forced, hipStream_t s) {
+  int nq = nblk(rb.n, kBlock / 4);
+  if (nq < 1) nq = 1;
+  const int nq_pad = ((nq + 7) / 8) * 8;
+  hipLaunchKernelGGL(k_knn_pruned<4>, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
 }
 void launch_knn4(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                  const IekfCtrl* ctrl, int forced, hipStream_t s) {

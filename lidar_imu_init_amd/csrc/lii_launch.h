@@ -25,6 +25,8 @@ void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg
                  const IekfCtrl* ctrl, int forced, hipStream_t s);
 void launch_knn8p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                   const IekfCtrl* ctrl, int forced, hipStream_t s);
+void launch_knn4p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                  const IekfCtrl* ctrl, int forced, hipStream_t s);
 void launch_knn4(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                  const IekfCtrl* ctrl, int forced, hipStream_t s);
 void launch_knn_fallback(const GridView& g, const RegistrationBuffers& rb, const IekfCtrl* ctrl, int forced, hipStream_t s);
