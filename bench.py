@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-downsample", action="store_true",
                     help="skip the GPU voxel-grid filter (mapping/filter_size_surf) that the step includes by default")
+    ap.add_argument("--map-update", action="store_true",
+                    help="also run map_incremental (device-side ikd-Tree Add_Points semantics + index rebuild) every step")
     ap.add_argument("--prime", type=int, default=150, help="untimed runtime-priming steps before the warm-up")
     ap.add_argument("--scans", type=int, default=8, help="distinct resident scans cycled through")
     ap.add_argument("--cell-size", type=float, default=0.0, help="k-NN grid cell edge [m]; 0 = 2 x filter_size_map")
@@ -133,6 +135,8 @@ def main():
         rep = reg.iekf_update(st, states0[j], max_iterations=wl["max_it"], imu_en=True)
         iters_total[0] += rep["iterations"]
         search_total[0] += rep["searches"]
+        if args.map_update:
+            reg.map_incremental(st)
         return st
 
     # The ROCm runtime grows internal pools (signals / staging) once, ~100 steps into a process: a single 30-50 ms
@@ -192,7 +196,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n_full} pts/scan vs {M}-pt local map, max_iteration {wl['max_it']}, "
-                                   f"LIO mode (12-col H), static map, {'voxel-grid leaf %.2f' % wl['fs_surf'] if not args.no_downsample else 'no voxel-grid'}",
+                                   f"LIO mode (12-col H), {'map_incremental every step' if args.map_update else 'static map'}, {'voxel-grid leaf %.2f' % wl['fs_surf'] if not args.no_downsample else 'no voxel-grid'}",
                        "points_per_scan": n_full, "map_points": M, "avg_iterations": iters_total[0] / args.steps,
                        "avg_knn_passes": search_total[0] / args.steps, "parallelism": f"points sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_knn_pruned<4> (exact 5-NN into the block-grid local map, 4 lanes/query, box-distance pruning)",

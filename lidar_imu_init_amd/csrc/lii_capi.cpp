@@ -15,7 +15,6 @@
 #include <vector>
 
 #include "../../include/liinit_hip.h"
-#include "lii_hostmap.h"
 #include "lii_hostmath.h"
 #include "lii_launch.h"
 
@@ -27,9 +26,14 @@ struct lii_context {
   hipStream_t stream = nullptr;
   std::string err;
 
-  // ---- local map
-  HostVoxelMap hmap;
-  uint64_t committed_version = ~0ull;
+  // ---- local map (device resident; the sorted point array d_map[0, n_map) is the source of truth)
+  float ds = 0.2f;              // ikd-Tree downsample box (set_downsample_param)
+  unsigned char* d_tomb = nullptr;
+  float4* d_batch = nullptr;    // a host-provided Add_Points batch (M)
+  float4 *d_ins = nullptr, *d_ins_c = nullptr;         // fold output / compacted inserts or host batches (M each)
+  unsigned int *d_u32_a = nullptr, *d_u32_b = nullptr, *d_u32_c = nullptr;  // flags / ranks (max(N, M) each)
+  float4 *d_list_add = nullptr, *d_list_nodown = nullptr;  // map_incremental lists (N each)
+  int* d_counts = nullptr;      // [0] add list, [1] no-downsample list, [2] alive, [3] inserted, [4] total, [5] events
   float4* d_map_unsorted = nullptr;
   float4* d_map = nullptr;
   unsigned long long *d_keys_a = nullptr, *d_keys_b = nullptr;
@@ -43,6 +47,7 @@ struct lii_context {
   unsigned int* d_counter = nullptr;
   int partial_stride = 0;
   int n_map = 0;
+  int* n_map_pinned = nullptr;  // small pinned scratch for H2D of counters
   float cell_size = 0.3f;
   void* d_sort_temp = nullptr;
   size_t sort_temp_bytes = 0;
@@ -165,6 +170,7 @@ int build_index(lii_handle h, int n) {
   hipStream_t s = h->stream;
   h->n_map = n;
   h->n_blocks = 0;
+  if (h->n_map_pinned) h->n_map_pinned[0] = n;
   if (n == 0) return LII_OK;
   const float inv_cs = 1.0f / h->cell_size;
   launch_map_keys(h->d_map_unsorted, n, inv_cs, h->d_keys_a, h->d_idx_a, s);
@@ -198,22 +204,58 @@ int build_index(lii_handle h, int n) {
   launch_table_clear(h->d_blocks, bcap, s);
   launch_cells_fill(h->d_keys_b, ranks, n, h->d_blocks, h->block_mask, h->d_cells, s);
   HIPCHK(h, hipGetLastError());
+  if (h->n_map_pinned) h->n_map_pinned[0] = n;
   return LII_OK;
 }
 
-int commit_map(lii_handle h) {
-  if (h->committed_version == h->hmap.version()) return LII_OK;
-  int n = h->hmap.valid();
-  if (n > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "local map exceeds max_map_points");
-  int k = h->hmap.export_float4(reinterpret_cast<float*>(h->h_stage));
-  (void)k;
-  if (n > 0)
-    HIPCHK(h, hipMemcpyAsync(h->d_map_unsorted, h->h_stage, sizeof(float4) * size_t(n), hipMemcpyHostToDevice, h->stream));
-  int rc = build_index(h, n);
-  if (rc != LII_OK) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));  // h_stage is reused by other calls
-  h->committed_version = h->hmap.version();
-  return LII_OK;
+int commit_map(lii_handle) { return LII_OK; }  // the device map is always current
+
+// Applies one Add_Points batch to the device map.  `list` holds the batch (device float4, `n_bound` entries of which
+// *n_dev are valid when n_dev != nullptr).  When `extra` != nullptr its *extra_n points are appended without
+// down-sampling afterwards (map_incremental's PointNoNeedDownsample).  Ends with ONE synchronising read of the counters
+// and an index rebuild.
+int map_apply(lii_handle h, const float4* list, int n_bound, const int* n_dev, bool downsample, const float4* extra,
+              const int* extra_n, int extra_bound, int* events_out) {
+  hipStream_t s = h->stream;
+  const int n_old = h->n_map;
+  HIPCHK(h, hipMemsetAsync(h->d_counts + 2, 0, 4 * sizeof(int), s));
+  if (downsample && n_bound > 0) {
+    launch_add_keys(list, n_bound, n_dev, h->ds, h->d_keys_a, h->d_idx_a, s);
+    sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, n_bound, s);
+    if (n_old > 0) HIPCHK(h, hipMemsetAsync(h->d_tomb, 0, size_t(n_old), s));
+    launch_add_fold(list, h->d_keys_b, h->d_idx_b, n_bound, h->ds, grid_view(h), h->d_tomb, h->d_ins, h->d_u32_a,
+                    reinterpret_cast<unsigned int*>(h->d_counts + 5), s);
+    // surviving old points -> d_map_unsorted[0, alive)
+    if (n_old > 0) {
+      launch_alive_flags(h->d_tomb, n_old, h->d_u32_b, s);
+      inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_b, h->d_u32_c, n_old, s);
+      launch_compact_f4(h->d_map, h->d_u32_b, h->d_u32_c, n_old, h->d_map_unsorted, 0, h->d_counts + 2, s);
+    }
+    // inserted points -> behind them
+    inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_a, h->d_u32_c, n_bound, s);
+    launch_compact_f4(h->d_ins, h->d_u32_a, h->d_u32_c, n_bound, h->d_ins_c, 0, h->d_counts + 3, s);
+    launch_append_f4(h->d_ins_c, h->d_counts + 3, n_bound, h->d_map_unsorted, h->d_counts + 2, nullptr, s);
+  } else {
+    if (n_old > 0) HIPCHK(h, hipMemcpyAsync(h->d_map_unsorted, h->d_map, sizeof(float4) * size_t(n_old), hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_counts + 2, &h->n_map_pinned[0], sizeof(int), hipMemcpyHostToDevice, s));
+    if (n_bound > 0) {
+      // plain Add_Points(points, false): append the whole batch
+      launch_append_f4(list, n_dev, n_bound, h->d_map_unsorted, h->d_counts + 2, nullptr, s);
+      if (n_dev) HIPCHK(h, hipMemcpyAsync(h->d_counts + 3, n_dev, sizeof(int), hipMemcpyDeviceToDevice, s));
+      else { h->n_map_pinned[1] = n_bound; HIPCHK(h, hipMemcpyAsync(h->d_counts + 3, &h->n_map_pinned[1], sizeof(int), hipMemcpyHostToDevice, s)); }
+    }
+  }
+  if (extra && extra_bound > 0) launch_append_f4(extra, extra_n, extra_bound, h->d_map_unsorted, h->d_counts + 2, h->d_counts + 3, s);
+  launch_sum3(h->d_counts + 2, h->d_counts + 3, extra ? extra_n : nullptr, h->d_counts + 4, s);
+  HIPCHK(h, hipMemcpyAsync(h->h_small + 3072, h->d_counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  int cnt[8];
+  std::memcpy(cnt, h->h_small + 3072, sizeof(cnt));
+  if (events_out) *events_out = cnt[5];
+  const int total = cnt[4];
+  if (total > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "local map exceeds max_map_points");
+  h->n_map_pinned[0] = total;
+  return build_index(h, total);
 }
 
 void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, int forced) {
@@ -397,8 +439,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   h->cell_size = std::max(h->cell_size, std::sqrt(h->cfg.max_match_dist2) / 8.0f * 1.001f);
   if (const char* v = std::getenv("LII_KNN_VARIANT")) h->knn_variant = std::atoi(v);  // A/B knob for profiling
   if (const char* v = std::getenv("LII_HOST_SOLVE")) h->host_solve = std::atoi(v) != 0;
-  h->hmap.set_downsample(h->cfg.map_downsample_size);
-  h->hmap.clear();
+  h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;
 #define CK(call)                                                                  \
   do {                                                                            \
@@ -432,6 +473,19 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   h->cells_cap_blocks = std::max<size_t>(4096, M / 64);
   CK(dmalloc(&h->d_cells, h->cells_cap_blocks * 512));
   CK(dmalloc(&h->d_counter, 4));
+  CK(dmalloc(&h->d_tomb, M));
+  CK(dmalloc(&h->d_ins, M));
+  CK(dmalloc(&h->d_batch, M));
+  CK(dmalloc(&h->d_ins_c, M));
+  CK(dmalloc(&h->d_u32_a, NM));
+  CK(dmalloc(&h->d_u32_b, NM));
+  CK(dmalloc(&h->d_u32_c, NM));
+  CK(dmalloc(&h->d_list_add, N));
+  CK(dmalloc(&h->d_list_nodown, N));
+  CK(dmalloc(&h->d_counts, 8));
+  CK(hipMemset(h->d_counts, 0, 32));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->n_map_pinned), 64, hipHostMallocDefault));
+  h->n_map_pinned[0] = 0;
   h->sort_temp_bytes = sort_temp_bytes(int(NM));
   CK(hipMalloc(&h->d_sort_temp, h->sort_temp_bytes));
   CK(dmalloc(&h->d_scan, N));
@@ -479,7 +533,7 @@ int lii_destroy(lii_handle h) {
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
-                 h->d_counter, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
+                 h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_needy, h->d_nbody, h->d_voxel_arg, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
                  h->d_vidx_b, h->d_vflags, h->d_vranks, h->d_poses, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
@@ -488,6 +542,7 @@ int lii_destroy(lii_handle h) {
   if (h->h_stage) (void)hipHostFree(h->h_stage);
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
+  if (h->n_map_pinned) (void)hipHostFree(h->n_map_pinned);
   for (int i = 0; i < 4; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -504,47 +559,74 @@ int lii_synchronize(lii_handle h) {
 // ------------------------------------------------------------------------------------------------ map
 int lii_map_reset(lii_handle h) {
   if (!h) return LII_ERR_INVALID;
-  h->hmap.clear();
   h->have_search = false;
+  return build_index(h, 0);
+}
+namespace {
+// host xyz (stride in bytes) -> pinned float4 staging -> device buffer
+int upload_xyz(lii_handle h, const void* xyz, int n, int stride_bytes, float4* dst) {
+  const char* src = static_cast<const char*>(xyz);
+  for (int i = 0; i < n; i++) {
+    const float* f = reinterpret_cast<const float*>(src + size_t(i) * stride_bytes);
+    h->h_stage[i] = make_float4(f[0], f[1], f[2], 0.f);
+  }
+  if (n > 0) {
+    HIPCHK(h, hipMemcpyAsync(dst, h->h_stage, sizeof(float4) * size_t(n), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // h_stage is reused
+  }
   return LII_OK;
 }
+}  // namespace
 int lii_map_build(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes) {
   if (!h || (!xyz && n > 0) || n < 0 || stride_bytes < 12 || stride_bytes % 4) return fail(h, LII_ERR_INVALID, "lii_map_build: bad arguments");
   if (n > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "lii_map_build: n > max_map_points");
-  h->hmap.build(static_cast<const float*>(xyz), n, stride_bytes / 4);
   h->have_search = false;
+  int rc = upload_xyz(h, xyz, n, stride_bytes, h->d_map_unsorted);
+  if (rc != LII_OK) return rc;
+  rc = build_index(h, n);
+  if (rc != LII_OK) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return LII_OK;
 }
 int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes, int32_t downsample_on, int32_t* n_added) {
   if (!h || (!xyz && n > 0) || n < 0 || stride_bytes < 12 || stride_bytes % 4) return fail(h, LII_ERR_INVALID, "lii_map_add_points: bad arguments");
-  int c = h->hmap.add_points(static_cast<const float*>(xyz), n, stride_bytes / 4, downsample_on != 0);
-  if (n_added) *n_added = c;
-  if (h->hmap.valid() > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "local map exceeds max_map_points");
+  if (n > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "lii_map_add_points: batch larger than max_map_points");
+  if (n_added) *n_added = 0;
+  if (n == 0) return LII_OK;
+  int rc = upload_xyz(h, xyz, n, stride_bytes, h->d_batch);
+  if (rc != LII_OK) return rc;
+  int ev = 0;
+  rc = map_apply(h, h->d_batch, n, nullptr, downsample_on != 0, nullptr, nullptr, 0, &ev);
+  if (rc != LII_OK) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (n_added) *n_added = downsample_on ? ev : 0;
   return LII_OK;
 }
 int lii_map_size(lii_handle h, int32_t* n_valid) {
   if (!h || !n_valid) return LII_ERR_INVALID;
-  *n_valid = h->hmap.valid();
+  *n_valid = h->n_map;
   return LII_OK;
 }
 int lii_map_download(lii_handle h, float* xyz_out, int32_t capacity, int32_t* n) {
   if (!h || !n) return LII_ERR_INVALID;
-  int cnt = h->hmap.valid();
+  const int cnt = h->n_map;
   *n = cnt;
   if (!xyz_out) return LII_OK;
   if (capacity < cnt) return fail(h, LII_ERR_CAPACITY, "lii_map_download: capacity too small");
-  std::vector<float> tmp(size_t(cnt) * 4);
-  h->hmap.export_float4(tmp.data());
+  if (cnt == 0) return LII_OK;
+  HIPCHK(h, hipMemcpyAsync(h->h_stage, h->d_map, sizeof(float4) * size_t(cnt), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < cnt; i++) {
-    xyz_out[3 * size_t(i)] = tmp[4 * size_t(i)];
-    xyz_out[3 * size_t(i) + 1] = tmp[4 * size_t(i) + 1];
-    xyz_out[3 * size_t(i) + 2] = tmp[4 * size_t(i) + 2];
+    xyz_out[3 * size_t(i)] = h->h_stage[i].x;
+    xyz_out[3 * size_t(i) + 1] = h->h_stage[i].y;
+    xyz_out[3 * size_t(i) + 2] = h->h_stage[i].z;
   }
   return LII_OK;
 }
 int lii_map_commit(lii_handle h) {
   if (!h) return LII_ERR_INVALID;
-  return commit_map(h);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return LII_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ scan
@@ -789,56 +871,26 @@ int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* s
 
 int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, int32_t* n_no_downsample) {
   if (!h || !state) return fail(h, LII_ERR_INVALID, "lii_map_incremental: bad arguments");
-  { int rc0 = resolve_n_body(h); if (rc0 != LII_OK) return rc0; }
-  const int n = h->n_body;
-  if (n <= 0) { if (n_add) *n_add = 0; if (n_no_downsample) *n_no_downsample = 0; return LII_OK; }
-  // body points + neighbour lists of the last search come back to the host (this row is "next" in the
-  // scope table: the decision below is host code exactly like the reference's)
-  std::vector<float> body(size_t(n) * 4), near(size_t(n) * kMatch * 3);
-  std::vector<int32_t> cnt(n, 0);
-  int32_t got = 0;
-  int rc = lii_scan_download(h, 1, body.data(), n, &got);
+  if (n_add) *n_add = 0;
+  if (n_no_downsample) *n_no_downsample = 0;
+  const int nb = h->n_body;  // upper bound while the exact count is still on the device
+  if (nb <= 0) return LII_OK;
+  if (nb > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "lii_map_incremental: scan larger than max_map_points");
+  hipStream_t s = h->stream;
+  RegistrationBuffers rb = reg_buffers(h);
+  // decision per point on the device (world point, neighbour list of the last search), then two order-preserving compactions
+  launch_map_decide(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, h->d_u32_a, h->d_u32_b, h->d_world, s);
+  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_a, h->d_u32_c, nb, s);
+  launch_compact_f4(h->d_world, h->d_u32_a, h->d_u32_c, nb, h->d_list_add, 0, h->d_counts + 0, s);
+  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_b, h->d_u32_c, nb, s);
+  launch_compact_f4(h->d_world, h->d_u32_b, h->d_u32_c, nb, h->d_list_nodown, 0, h->d_counts + 1, s);
+  // Add_Points(PointToAdd, true) then Add_Points(PointNoNeedDownsample, false)  (:556-557)
+  int rc = map_apply(h, h->d_list_add, nb, h->d_counts + 0, true, h->d_list_nodown, h->d_counts + 1, nb, nullptr);
   if (rc != LII_OK) return rc;
-  if (h->have_search) {
-    rc = lii_neighbors_download(h, near.data(), cnt.data(), nullptr, n);
-    if (rc != LII_OK) return rc;
-  }
-  const double fsd = double(h->cfg.map_downsample_size);
-  std::vector<float> to_add, no_down;
-  for (int i = 0; i < n; i++) {
-    const double b[3] = {body[4 * size_t(i)], body[4 * size_t(i) + 1], body[4 * size_t(i) + 2]};
-    double q[3], w[3];
-    m3_vec(state->offset_R_L_I, b, q);
-    for (int a = 0; a < 3; a++) q[a] += state->offset_T_L_I[a];
-    m3_vec(state->rot_end, q, w);
-    float pw[3];
-    for (int a = 0; a < 3; a++) pw[a] = float(w[a] + state->pos_end[a]);
-    if (cnt[i] > 0) {
-      const float* nb = &near[size_t(i) * kMatch * 3];
-      float mid[3];
-      for (int a = 0; a < 3; a++) mid[a] = float(std::floor(pw[a] / fsd) * fsd + 0.5 * fsd);
-      float dist = (pw[0] - mid[0]) * (pw[0] - mid[0]) + (pw[1] - mid[1]) * (pw[1] - mid[1]) + (pw[2] - mid[2]) * (pw[2] - mid[2]);
-      if (std::fabs(nb[0] - mid[0]) > 0.5 * fsd && std::fabs(nb[1] - mid[1]) > 0.5 * fsd && std::fabs(nb[2] - mid[2]) > 0.5 * fsd) {
-        no_down.insert(no_down.end(), pw, pw + 3);
-        continue;
-      }
-      bool need_add = true;
-      for (int k = 0; k < kMatch; k++) {
-        if (cnt[i] < kMatch) break;
-        float dk = (nb[3 * k] - mid[0]) * (nb[3 * k] - mid[0]) + (nb[3 * k + 1] - mid[1]) * (nb[3 * k + 1] - mid[1]) +
-                   (nb[3 * k + 2] - mid[2]) * (nb[3 * k + 2] - mid[2]);
-        if (dk < dist) { need_add = false; break; }
-      }
-      if (need_add) to_add.insert(to_add.end(), pw, pw + 3);
-    } else {
-      to_add.insert(to_add.end(), pw, pw + 3);
-    }
-  }
-  h->hmap.add_points(to_add.data(), int(to_add.size() / 3), 3, true);
-  h->hmap.add_points(no_down.data(), int(no_down.size() / 3), 3, false);
-  if (n_add) *n_add = int(to_add.size() / 3);
-  if (n_no_downsample) *n_no_downsample = int(no_down.size() / 3);
-  if (h->hmap.valid() > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "local map exceeds max_map_points");
+  int cnt[8];
+  std::memcpy(cnt, h->h_small + 3072, sizeof(cnt));  // read back by map_apply
+  if (n_add) *n_add = cnt[0];
+  if (n_no_downsample) *n_no_downsample = cnt[1];
   return LII_OK;
 }
 

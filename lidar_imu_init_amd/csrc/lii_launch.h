@@ -53,6 +53,18 @@ void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const un
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s);
 
+// device-side map maintenance (lii_map.hip)
+void launch_map_decide(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* flag_add,
+                       unsigned int* flag_nodown, float4* world_out, hipStream_t s);
+void launch_compact_f4(const float4* src, const unsigned int* flag, const unsigned int* ranks, int n, float4* dst, int dst_offset,
+                       int* count, hipStream_t s);
+void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, hipStream_t s);
+void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
+                     unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, hipStream_t s);
+void launch_alive_flags(const unsigned char* tomb, int n, unsigned int* alive, hipStream_t s);
+void launch_append_f4(const float4* src, const int* count, int n_bound, float4* dst, const int* off_a, const int* off_b, hipStream_t s);
+void launch_sum3(const int* a, const int* b, const int* c, int* out, hipStream_t s);
+
 // rocPRIM wrappers (lii_sort.hip)
 size_t sort_temp_bytes(int max_n);
 void sort_pairs_u64(void* temp, size_t temp_bytes, const unsigned long long* kin, unsigned long long* kout,

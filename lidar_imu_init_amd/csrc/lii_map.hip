@@ -1,0 +1,277 @@
+// Device-side maintenance of the local map with the reference's incremental k-d tree SET semantics.
+//   k_map_decide ........ map_incremental's per-point decision            src/laserMapping.cpp:516-553
+//   k_add_keys / k_add_fold  KD_TREE::Add_Points(points, downsample_on = true)   include/ikd-Tree/ikd_Tree.cpp:381-426:
+//                         per down-sample voxel "keep the point closest to the voxel centre": the points of one batch that
+//                         fall into the same voxel interact sequentially, different voxels are independent — one GPU thread
+//                         folds one voxel group in the batch order (stable sort by voxel), querying the current map grid with
+//                         the reference's exact float box predicate (Search_by_range / Delete_by_range, :616-629, :970-985).
+//   k_compact_* ......... apply deletions (tombstones) and insertions, then the index is rebuilt (lii_capi.cpp: build_index)
+// Set equivalence with the tree is tested against the oracle's restated tree and against the unmodified reference tree
+// (tests/test_gpu_map.py).  Ties between equal squared distances to the voxel centre are broken by map order here and by
+// tree traversal order in the reference (measure zero).
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <cstring>
+#include <math.h>
+
+#include "lii_device.h"
+#include "lii_launch.h"
+
+namespace lii {
+
+namespace {
+constexpr int kBias = 1 << 20;
+constexpr int kCells = 512;
+constexpr unsigned long long kInvalidKey = ~0ull;
+
+__device__ __forceinline__ unsigned int d_hash_block(int bx, int by, int bz) {
+  return (__umul24((unsigned)bx, 7919u * 1021u) ^ __umul24((unsigned)by, 104729u * 13u) ^ __umul24((unsigned)bz, 1299709u)) * 2654435761u;
+}
+__device__ __forceinline__ unsigned long long d_pack_block(int bx, int by, int bz) {
+  return ((unsigned long long)(unsigned)bz << 36) | ((unsigned long long)(unsigned)by << 18) | (unsigned long long)(unsigned)bx;
+}
+__device__ __forceinline__ uint2 d_cell_range(const GridView& g, int ix, int iy, int iz) {
+  const int bb = kBias >> kCoarseShift;
+  const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
+  const unsigned long long bk = d_pack_block(bx, by, bz);
+  unsigned int sl = d_hash_block(bx, by, bz) & g.block_mask;
+  while (true) {
+    BlockEntry e = g.blocks[sl];
+    if (e.key == bk) {
+      const unsigned local = (((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u);
+      return g.cells[(size_t)e.id * kCells + local];
+    }
+    if (e.key == kEmptyKey) return make_uint2(0u, 0u);
+    sl = (sl + 1) & g.block_mask;
+  }
+}
+// calc_dist — float32, the reference's evaluation order, no FMA (ikd_Tree.cpp:1273-1277, laserMapping.cpp:152-155)
+__device__ __forceinline__ float d_dist2(float ax, float ay, float az, float bx, float by, float bz) {
+  float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+__device__ __forceinline__ bool d_same_point(float ax, float ay, float az, float bx, float by, float bz) {
+  // same_point (ikd_Tree.cpp:1269-1271): fabs(float - float) < EPSS (1e-6, double)
+  return (double)fabsf(ax - bx) < 1e-6 && (double)fabsf(ay - by) < 1e-6 && (double)fabsf(az - bz) < 1e-6;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ map_incremental
+// cls[i]: 0 = not added, 1 = PointToAdd (with down-sampling), 2 = PointNoNeedDownsample.  world[i] = the world point.
+__global__ void k_map_decide(RegistrationBuffers rb, PoseArg ps, double fsd, int have_search, unsigned int* __restrict__ flag_add,
+                             unsigned int* __restrict__ flag_nodown, float4* __restrict__ world_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = rb.n_dev ? *rb.n_dev : rb.n;
+  if (i >= rb.n) return;  // rb.n is the launch bound
+  unsigned int fa = 0, fn = 0;
+  if (i < n) {
+    float4 pb = rb.body[i];
+    double bx = pb.x, by = pb.y, bz = pb.z;
+    double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
+    double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
+    double iz = ps.RLI[6] * bx + ps.RLI[7] * by + ps.RLI[8] * bz + ps.TLI[2];
+    const float wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
+    const float wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
+    const float wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
+    world_out[i] = make_float4(wx, wy, wz, 0.f);
+    const int cnt = have_search ? rb.nbr_count[i] : 0;
+    if (cnt > 0) {
+      // mid_point = floor(p / filter_size_map) * filter_size_map + 0.5 * filter_size_map, double math stored to float (:529-534)
+      const float mx = (float)(floor(wx / fsd) * fsd + 0.5 * fsd);
+      const float my = (float)(floor(wy / fsd) * fsd + 0.5 * fsd);
+      const float mz = (float)(floor(wz / fsd) * fsd + 0.5 * fsd);
+      const float dist = d_dist2(wx, wy, wz, mx, my, mz);
+      const float4 n0 = rb.nbr[i];
+      if ((double)fabsf(n0.x - mx) > 0.5 * fsd && (double)fabsf(n0.y - my) > 0.5 * fsd && (double)fabsf(n0.z - mz) > 0.5 * fsd) {
+        fn = 1;  // PointNoNeedDownsample (:536-541)
+      } else {
+        bool need_add = true;
+        if (cnt >= kMatch) {
+#pragma unroll
+          for (int k = 0; k < kMatch; k++) {
+            const float4 q = rb.nbr[(size_t)k * rb.cap + i];
+            if (need_add && d_dist2(q.x, q.y, q.z, mx, my, mz) < dist) need_add = false;
+          }
+        }
+        fa = need_add ? 1u : 0u;
+      }
+    } else {
+      fa = 1;  // no neighbour list: always added (:551-553)
+    }
+  }
+  flag_add[i] = fa;
+  flag_nodown[i] = fn;
+}
+
+// dst[rank - 1] = src[i] where flag[i] (rank = inclusive scan of flag); *count = ranks[n - 1]
+__global__ void k_compact_f4(const float4* __restrict__ src, const unsigned int* __restrict__ flag,
+                             const unsigned int* __restrict__ ranks, int n, float4* __restrict__ dst, int dst_offset,
+                             int* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == n - 1 && count) *count = (int)ranks[n - 1];
+  if (flag[i]) dst[dst_offset + ranks[i] - 1] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------ Add_Points (down-sampling)
+// n may be an upper bound: entries i >= *n_dev get the invalid key and sort to the end.
+__global__ void k_add_keys(const float4* __restrict__ pts, int n, const int* __restrict__ n_dev, float ds,
+                           unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long key = kInvalidKey;
+  if (!n_dev || i < *n_dev) {
+    const float4 p = pts[i];
+    // floor(PointToAdd[i].x / downsample_size): float arithmetic (:390-395)
+    const int vx = (int)floorf(p.x / ds), vy = (int)floorf(p.y / ds), vz = (int)floorf(p.z / ds);
+    key = ((unsigned long long)(unsigned)(vz + kBias) << 42) | ((unsigned long long)(unsigned)(vy + kBias) << 21) |
+          (unsigned long long)(unsigned)(vx + kBias);
+  }
+  keys[i] = key;
+  idx[i] = (unsigned)i;
+}
+
+// One thread per voxel group.  tomb[j] = 1 marks existing map point j as deleted; ins_flag[i] = 1 / ins_pts[i] = the point
+// to insert, for the group starting at sorted position i; *events accumulates the reference's tmp_counter.
+__global__ void k_add_fold(const float4* __restrict__ add_pts, const unsigned long long* __restrict__ keys,
+                           const unsigned int* __restrict__ idx, int n, float ds, GridView g, unsigned char* __restrict__ tomb,
+                           float4* __restrict__ ins_pts, unsigned int* __restrict__ ins_flag, unsigned int* __restrict__ events) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ins_flag[i] = 0;
+  const unsigned long long key = keys[i];
+  if (key == kInvalidKey) return;
+  if (i > 0 && keys[i - 1] == key) return;  // not a group leader
+  const float4 p0 = add_pts[idx[i]];
+  // Box_of_Point / mid_point (:390-399), float arithmetic; (max - min) / 2.0 is evaluated in double
+  float bmin[3], bmax[3], mid[3];
+  {
+    const float c[3] = {p0.x, p0.y, p0.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      bmin[a] = floorf(c[a] / ds) * ds;
+      bmax[a] = bmin[a] + ds;
+      mid[a] = (float)((double)bmin[a] + (double)(bmax[a] - bmin[a]) / 2.0);
+    }
+  }
+  // existing points inside the box: every grid cell that can intersect it (with slack for float rounding of cell bounds)
+  int c0[3], c1[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float slack = 1e-6f * (fabsf(bmin[a]) + fabsf(bmax[a]) + 8.f);
+    c0[a] = (int)floorf((bmin[a] - slack) * g.inv_cs);
+    c1[a] = (int)floorf((bmax[a] + slack) * g.inv_cs);
+  }
+  int n0 = 0, best = -1;
+  float bestd = __builtin_inff();
+  if (g.n_pts > 0) {
+    for (int cz = c0[2]; cz <= c1[2]; cz++)
+      for (int cy = c0[1]; cy <= c1[1]; cy++)
+        for (int cx = c0[0]; cx <= c1[0]; cx++) {
+          const uint2 r = d_cell_range(g, cx, cy, cz);
+          for (unsigned int j = r.x; j < r.y; j++) {
+            const float4 q = g.pts[j];
+            if (bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) {
+              n0++;
+              const float d = d_dist2(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
+              if (d < bestd) { bestd = d; best = (int)j; }
+            }
+          }
+        }
+  }
+  // sequential fold over the points of this voxel, in batch order (see header)
+  bool ev = false;
+  bool cur_new = false;
+  int cur_old = -1;
+  float cx_ = 0, cy_ = 0, cz_ = 0, cd = 0;
+  unsigned int n_events = 0;
+  for (int t = i; t < n && keys[t] == key; t++) {
+    const float4 p = add_pts[idx[t]];
+    const float dp = d_dist2(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
+    if (!ev) {
+      const bool old_wins = (n0 > 0) && (bestd < dp);
+      float rx = p.x, ry = p.y, rz = p.z;
+      if (old_wins) { const float4 q = g.pts[best]; rx = q.x; ry = q.y; rz = q.z; }
+      if (n0 > 1 || d_same_point(p.x, p.y, p.z, rx, ry, rz)) {
+        ev = true;
+        n_events++;
+        cur_new = !old_wins;
+        cur_old = old_wins ? best : -1;
+        cx_ = rx; cy_ = ry; cz_ = rz;
+        cd = old_wins ? bestd : dp;
+      }
+    } else {
+      const bool cur_wins = cd < dp;
+      const float rx = cur_wins ? cx_ : p.x, ry = cur_wins ? cy_ : p.y, rz = cur_wins ? cz_ : p.z;
+      if (d_same_point(p.x, p.y, p.z, rx, ry, rz)) {
+        n_events++;
+        if (!cur_wins) { cur_new = true; cur_old = -1; cx_ = p.x; cy_ = p.y; cz_ = p.z; cd = dp; }
+      }
+    }
+  }
+  if (!ev) return;
+  atomicAdd(events, n_events);
+  // delete every existing in-box point except a surviving one; insert the survivor if it is a new point
+  if (n0 > 0) {
+    for (int cz = c0[2]; cz <= c1[2]; cz++)
+      for (int cy = c0[1]; cy <= c1[1]; cy++)
+        for (int cx = c0[0]; cx <= c1[0]; cx++) {
+          const uint2 r = d_cell_range(g, cx, cy, cz);
+          for (unsigned int j = r.x; j < r.y; j++) {
+            const float4 q = g.pts[j];
+            if ((int)j != cur_old && bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z)
+              tomb[j] = 1;
+          }
+        }
+  }
+  if (cur_new) {
+    ins_pts[i] = make_float4(cx_, cy_, cz_, 0.f);
+    ins_flag[i] = 1;
+  }
+}
+
+__global__ void k_alive_flags(const unsigned char* __restrict__ tomb, int n, unsigned int* __restrict__ alive) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) alive[i] = tomb[i] ? 0u : 1u;
+}
+// appends src[0 .. *count) behind dst[*offset ...); counts live on the device (upper bound n for the launch)
+__global__ void k_append_f4(const float4* __restrict__ src, const int* __restrict__ count, int n_bound, float4* __restrict__ dst,
+                            const int* __restrict__ off_a, const int* __restrict__ off_b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = count ? *count : n_bound;
+  if (i >= n_bound || i >= n) return;
+  const int off = (off_a ? *off_a : 0) + (off_b ? *off_b : 0);
+  dst[off + i] = src[i];
+}
+__global__ void k_sum3(const int* a, const int* b, const int* c, int* out) {
+  if (threadIdx.x == 0) *out = (a ? *a : 0) + (b ? *b : 0) + (c ? *c : 0);
+}
+
+static inline int nblk(int n, int b) { return (n + b - 1) / b; }
+
+void launch_map_decide(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* flag_add,
+                       unsigned int* flag_nodown, float4* world_out, hipStream_t s) {
+  if (rb.n > 0) hipLaunchKernelGGL(k_map_decide, dim3(nblk(rb.n, 256)), dim3(256), 0, s, rb, ps, fsd, have_search, flag_add, flag_nodown, world_out);
+}
+void launch_compact_f4(const float4* src, const unsigned int* flag, const unsigned int* ranks, int n, float4* dst, int dst_offset,
+                       int* count, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_compact_f4, dim3(nblk(n, 256)), dim3(256), 0, s, src, flag, ranks, n, dst, dst_offset, count);
+}
+void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_add_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, n_dev, ds, keys, idx);
+}
+void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
+                     unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_add_fold, dim3(nblk(n, 128)), dim3(128), 0, s, add_pts, keys, idx, n, ds, g, tomb, ins_pts, ins_flag, events);
+}
+void launch_alive_flags(const unsigned char* tomb, int n, unsigned int* alive, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_alive_flags, dim3(nblk(n, 256)), dim3(256), 0, s, tomb, n, alive);
+}
+void launch_append_f4(const float4* src, const int* count, int n_bound, float4* dst, const int* off_a, const int* off_b, hipStream_t s) {
+  if (n_bound > 0) hipLaunchKernelGGL(k_append_f4, dim3(nblk(n_bound, 256)), dim3(256), 0, s, src, count, n_bound, dst, off_a, off_b);
+}
+void launch_sum3(const int* a, const int* b, const int* c, int* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum3, dim3(1), dim3(64), 0, s, a, b, c, out);
+}
+
+}  // namespace lii
