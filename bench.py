@@ -94,7 +94,7 @@ def main():
 
     wl = build_workload(args.workload, args.scans)
     n_full = max(len(s) for s in wl["scans"])
-    reg = lii.Registrar(max_scan_points=n_full + 1024, max_map_points=len(wl["map"]) + 1024,
+    reg = lii.Registrar(max_scan_points=n_full + 1024, max_map_points=int(len(wl["map"]) * 1.5) + 1024,
                         filter_size_map=wl["fs_map"], map_cell_size=args.cell_size, device=local_rank)
     if world > 1:
         uid = [reg.comm_unique_id() if rank == 0 else None]
