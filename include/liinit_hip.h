@@ -183,6 +183,15 @@ typedef struct lii_calib_result {
  * the second time compensation + acc_interpolate (caller re-uploads, as LI_Initialization does at :619-623). */
 int lii_calib_solve_stage(lii_handle h, int32_t stage, lii_calib_result* inout);
 
+/* LI_Init::LI_Initialization as a whole (include/LI_init/LI_init.cpp:586-632): the signal-conditioning chain on the host
+ * (mean filter + interpolation :82-125, zero-phase Butterworth :260-315, cross-correlation :160-193, time compensation
+ * :195-238, central differences :127-158, acc interpolation :240-258) around the three GPU-evaluated solves.
+ * lii_li_init_interpolate = downsample_interpolate_IMU; lii_li_init_run = everything after it. */
+int lii_li_init_interpolate(const lii_calib_state* imu_all, int32_t n_imu, const lii_calib_state* lidar, int32_t n_lidar,
+                            double move_start_time, lii_calib_state* imu_out, lii_calib_state* lidar_out, int32_t* n_out);
+int lii_li_init_run(lii_handle h, const lii_calib_state* imu, const lii_calib_state* lidar, int32_t n, int32_t orig_odom_freq,
+                    int32_t cut_frame_num, lii_calib_result* out, double* time_lag_1, double* total_time_lag);
+
 /* ---------------------------------------------------------------- multi-GPU (points of one scan sharded across ranks)
  * One process per GPU.  Rank 0 creates an id, the caller ships the 128 bytes to the other ranks (e.g.
  * torch.distributed broadcast), every rank calls lii_comm_init; afterwards lii_iekf_iterate/update

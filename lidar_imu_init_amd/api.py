@@ -79,6 +79,10 @@ _DECLS = {
     "lii_calib_set_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "lii_calib_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "lii_calib_solve_stage": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(lii_calib_result)]),
+    "lii_li_init_interpolate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_int32)]),
+    "lii_li_init_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.POINTER(lii_calib_result), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lii_comm_unique_id": (C.c_int, [C.c_void_p]),
     "lii_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lii_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -333,6 +337,16 @@ class Registrar:
             res.R_LI[:] = list(np.eye(3).reshape(-1))
         self._check(self.L.lii_calib_solve_stage(self.h, stage, C.byref(res)))
         return res
+
+    def li_init_run(self, imu22, lidar22, orig_odom_freq, cut_frame_num):
+        """LI_Init::LI_Initialization after downsample_interpolate_IMU; returns (lii_calib_result, time_lag_1, total_lag)."""
+        imu = np.ascontiguousarray(imu22, np.float64).reshape(-1, 22)
+        lid = np.ascontiguousarray(lidar22, np.float64).reshape(-1, 22)
+        res = lii_calib_result()
+        l1, tot = C.c_double(0), C.c_double(0)
+        self._check(self.L.lii_li_init_run(self.h, _ptr(imu), _ptr(lid), len(imu), int(orig_odom_freq), int(cut_frame_num),
+                                           C.byref(res), C.byref(l1), C.byref(tot)))
+        return res, l1.value, tot.value
 
     # ------------------------------------------------------------------ multi-GPU
     def comm_unique_id(self) -> bytes:

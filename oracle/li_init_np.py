@@ -193,6 +193,33 @@ def acc_interpolate(imu: CalibSeq, lidar: CalibSeq) -> CalibSeq:
     return imu
 
 
+def downsample_interpolate_imu(imu_all: CalibSeq, lidar: CalibSeq, move_start_time: float):
+    """LI_Init::downsample_interpolate_IMU (:82-125): drop everything older than move_start - 3 s, 5-tap running-mean filter
+    of the accelerations, linear interpolation of omega / acc at the LiDAR stamps.  The reference's filter reads one element
+    past the end of its copy in its last iteration (UB, quirk A10); that read is the last raw sample here."""
+    ka = int(np.argmax(imu_all.t >= move_start_time - 3.0)) if np.any(imu_all.t >= move_start_time - 3.0) else len(imu_all)
+    kl = int(np.argmax(lidar.t >= move_start_time - 3.0)) if np.any(lidar.t >= move_start_time - 3.0) else len(lidar)
+    a, l = imu_all.slice(slice(ka, None)), lidar.slice(slice(kl, None))
+    origin = a.linear_acc.copy()
+    for i in range(2, len(a) - 2):
+        acc = np.zeros(3)
+        for d in range(-2, 3):
+            acc += (origin[i + d] - acc) / (d + 3)
+        a.linear_acc[i] = acc
+    out_i, keep = [], []
+    for i in range(len(l)):
+        j = np.searchsorted(a.t, l.t[i], side="right")  # first j with a.t[j] > t ; need a.t[j-1] <= t
+        if j < 1 or j >= len(a):
+            continue
+        s_ = (a.t[j] - l.t[i]) / (a.t[j] - a.t[j - 1])
+        out_i.append((s_ * a.ang_vel[j - 1] + (1 - s_) * a.ang_vel[j], s_ * a.linear_acc[j - 1] + (1 - s_) * a.linear_acc[j], l.t[i]))
+        keep.append(i)
+    imu = CalibSeq(len(out_i))
+    for k, (w, acc, t) in enumerate(out_i):
+        imu.ang_vel[k], imu.linear_acc[k], imu.t[k] = w, acc, t
+    return imu, l.slice(np.array(keep, dtype=int))
+
+
 # ---------------------------------------------------------------------------------------------- residuals + Jacobians
 def skew(v):
     return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])

@@ -75,3 +75,25 @@ def test_calib_solves_match_oracle_and_reference(reg):
     assert np.allclose(res.grav_L0[:], out["stage3"]["grav_L0"], atol=1e-8)
     assert np.abs(np.array(res.T_LI[:]) - d["result_trans"]).max() < 1e-3
     assert np.abs(np.array(res.grav_L0[:]) - d["result_gravity"]).max() < 2e-3
+
+
+def test_li_initialization_end_to_end_on_reference_run(reg):
+    """lii_li_init_run (C++ conditioning chain + HIP-evaluated solves) against the numpy oracle and the reference's result."""
+    from oracle import oracle as O
+    d = F.load()
+    out = F.run(solve=True)
+    imu, lid = F.sequences()
+    res, lag1, total = reg.li_init_run(imu.to_records(), lid.to_records(), 10, 5)
+    assert abs(lag1 - out["time_lag_1"]) < 1e-15 and abs(lag1 + 0.08) < 1e-12
+    R = np.array(res.R_LI[:]).reshape(3, 3)
+    assert np.allclose(R, out["stage2"]["R_LI"], atol=1e-8)
+    assert np.allclose(res.gyro_bias[:], out["stage2"]["gyro_bias"], atol=1e-9)
+    assert abs(res.time_lag_2 - out["stage2"]["time_lag_2"]) < 1e-9
+    assert abs(total - out["time_delay"]) < 1e-9
+    assert np.allclose(res.T_LI[:], out["stage3"]["T_LI"], atol=1e-7)
+    assert np.allclose(res.acc_bias[:], out["stage3"]["acc_bias"], atol=1e-8)
+    assert np.allclose(res.grav_L0[:], out["stage3"]["grav_L0"], atol=1e-7)
+    # and the committed result of the reference program
+    assert np.abs(O.rot_to_euler(R) * 57.3 - d["result_rot_euler_deg"]).max() < 0.01
+    assert np.abs(np.array(res.T_LI[:]) - d["result_trans"]).max() < 1e-3
+    assert np.abs(np.array(res.acc_bias[:]) - d["result_acc_bias"]).max() < 1e-5

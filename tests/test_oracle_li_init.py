@@ -95,3 +95,43 @@ def test_quaternion_helpers_and_jacobians():
             g[k] = (cp - cm) / (2 * h)
         assert np.allclose(g, Jtr, rtol=1e-5, atol=1e-6 * max(1.0, np.abs(Jtr).max()))
         assert np.allclose(JtJ, JtJ.T) and np.all(np.linalg.eigvalsh(JtJ) > -1e-9)
+
+
+def test_host_interpolation_matches_oracle():
+    """lii_li_init_interpolate (downsample_interpolate_IMU, host code of the library: no GPU needed) vs the numpy oracle."""
+    import ctypes as C
+
+    import lidar_imu_init_amd as lii
+    from oracle import li_init_np as LI
+    L = lii.load_library()
+    rng = np.random.default_rng(3)
+    n_imu, n_lid = 4000, 700
+    a = LI.CalibSeq(n_imu)
+    a.t = 100.0 + np.cumsum(rng.uniform(0.004, 0.006, n_imu))
+    a.ang_vel = rng.normal(0, 0.5, (n_imu, 3))
+    a.linear_acc = rng.normal(0, 1.0, (n_imu, 3)) + [0, 0, 9.8]
+    l = LI.CalibSeq(n_lid)
+    l.t = 100.5 + np.cumsum(rng.uniform(0.019, 0.021, n_lid))
+    l.t = l.t[l.t < a.t[-1] + 0.05]
+    l = l.slice(slice(0, len(l.t))) if len(l.t) == n_lid else _resize(l, len(l.t))
+    l.ang_vel = rng.normal(0, 0.5, (len(l), 3))
+    l.linear_vel = rng.normal(0, 0.5, (len(l), 3))
+    move_start = 104.0
+    ri, rl = LI.downsample_interpolate_imu(a, l, move_start)
+    ai, li = a.to_records(), l.to_records()
+    oi, ol = np.zeros((len(l), 22)), np.zeros((len(l), 22))
+    n = C.c_int32(0)
+    rc = L.lii_li_init_interpolate(ai.ctypes.data_as(C.c_void_p), len(ai), li.ctypes.data_as(C.c_void_p), len(li), move_start,
+                                   oi.ctypes.data_as(C.c_void_p), ol.ctypes.data_as(C.c_void_p), C.byref(n))
+    assert rc == 0 and n.value == len(ri) == len(rl) > 100
+    assert np.allclose(oi[:n.value, 9:12], ri.ang_vel, atol=1e-14)
+    assert np.allclose(oi[:n.value, 18:21], ri.linear_acc, atol=1e-13)
+    assert np.array_equal(oi[:n.value, 21], ri.t) and np.array_equal(ol[:n.value, 21], rl.t)
+    assert np.array_equal(ol[:n.value, 9:12], rl.ang_vel)
+
+
+def _resize(seq, n):
+    from oracle import li_init_np as LI
+    o = LI.CalibSeq(n)
+    o.t = seq.t[:n].copy()
+    return o
