@@ -113,6 +113,7 @@ SENSORS = {
     "stream100k": (100, 1000, -25.0, 25.0),  # 100 000 (north-star stream)
     "dense500k": (128, 3906, -25.0, 15.0),   # ~500 k (configs[4])
     "tiny": (16, 128, -15.0, 15.0),        # 2 048 — unit tests
+    "mid16k": (32, 512, -25.0, 25.0),      # 16 384 — end-to-end plumbing test
 }
 
 
@@ -142,3 +143,87 @@ def bench_world(n_map_points=1_000_000, spacing=0.15, seed=SEED):
     if len(pts) > n_map_points:
         pts = pts[rng.choice(len(pts), n_map_points, replace=False)]
     return hall, pts
+
+
+# ------------------------------------------------------------------------------------------------ moving platform
+def rot_zyx_batch(roll, pitch, yaw):
+    cr, sr, cp, sp, cy, sy = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+    R = np.empty(roll.shape + (3, 3))
+    R[..., 0, 0] = cy * cp; R[..., 0, 1] = cy * sp * sr - sy * cr; R[..., 0, 2] = cy * sp * cr + sy * sr
+    R[..., 1, 0] = sy * cp; R[..., 1, 1] = sy * sp * sr + cy * cr; R[..., 1, 2] = sy * sp * cr - cy * sr
+    R[..., 2, 0] = -sp;     R[..., 2, 1] = cp * sr;                R[..., 2, 2] = cp * cr
+    return R
+
+
+class Trajectory:
+    """Smooth 6-DoF motion of the LiDAR frame with >= 0.5 rad/s excitation about all three axes after a soft start
+    (LI_Init::data_sufficiency_assess needs rotation about every axis, LI_init.cpp:531-556; README.md:97 asks for a standstill)."""
+
+    def __init__(self, ramp_s=2.0, amp=(0.32, 0.30, 0.45), freq=(0.37, 0.29, 0.23), pamp=(1.2, 0.9, 0.25), pfreq=(0.21, 0.17, 0.31)):
+        self.ramp, self.amp, self.freq, self.pamp, self.pfreq = ramp_s, np.array(amp), np.array(freq), np.array(pamp), np.array(pfreq)
+
+    def _gain(self, t):
+        x = np.clip(np.asarray(t, float) / self.ramp, 0.0, 1.0)
+        return x * x * x * (x * (6 * x - 15) + 10)  # smootherstep: zero velocity and acceleration at both ends
+
+    def euler(self, t):
+        t = np.asarray(t, float)
+        g = self._gain(t)
+        return [g * self.amp[k] * np.sin(2 * np.pi * self.freq[k] * t + 0.4 * k) for k in range(3)]
+
+    def R(self, t):
+        r, p, y = self.euler(t)
+        return rot_zyx_batch(np.asarray(r), np.asarray(p), np.asarray(y))
+
+    def p(self, t):
+        t = np.asarray(t, float)
+        g = self._gain(t)
+        return np.stack([g * self.pamp[k] * np.sin(2 * np.pi * self.pfreq[k] * t + 0.9 * k) for k in range(3)], -1)
+
+    def omega_body(self, t, h=1e-4):
+        """vee(R^T dR/dt) by a symmetric difference of the rotation."""
+        Rm, Rp = self.R(np.asarray(t) - h), self.R(np.asarray(t) + h)
+        D = np.einsum("...ji,...jk->...ik", Rm, Rp)  # R(t-h)^T R(t+h) ~ Exp(2 h w)
+        w = np.stack([D[..., 2, 1] - D[..., 1, 2], D[..., 0, 2] - D[..., 2, 0], D[..., 1, 0] - D[..., 0, 1]], -1) / 2.0
+        return w / (2 * h)
+
+    def vel(self, t, h=1e-4):
+        return (self.p(np.asarray(t) + h) - self.p(np.asarray(t) - h)) / (2 * h)
+
+
+def make_distorted_scan(hall: Hall, sensor: str, traj: Trajectory, t_beg: float, sweep_s: float, noise=0.01, seed=SEED,
+                        blind=0.5, max_range=100.0):
+    """One sub-frame taken WHILE the platform moves: ray j is cast at time t_beg + frac_j * sweep_s from the pose the
+    platform has at that instant; the returned float4 cloud holds the raw (skewed) body-frame points and their time
+    offsets in ms — what the de-skew kernels have to undo."""
+    rings, cols, fd, fu = SENSORS[sensor]
+    rng = np.random.default_rng(seed)
+    dirs_b, t_ms = spinning_lidar(rings, cols, fd, fu, sweep_ms=1000.0 * sweep_s)
+    tj = t_beg + t_ms.astype(np.float64) / 1000.0
+    R = traj.R(tj)
+    o = traj.p(tj)
+    dirs_w = np.einsum("nij,nj->ni", R, dirs_b)
+    rngs = hall.raycast(o, dirs_w) + rng.normal(0, noise, len(dirs_b))
+    ok = np.isfinite(rngs) & (rngs > blind) & (rngs < max_range)
+    pts = dirs_b[ok] * rngs[ok, None]
+    return np.concatenate([pts, t_ms[ok, None]], 1).astype(np.float32)
+
+
+def simulate_imu(traj: Trajectory, t0, t1, rate_hz, R_LI, T_LI, b_g, b_a, t_offset, noise_g=1e-3, noise_a=1e-2, seed=SEED):
+    """IMU rigidly mounted on the LiDAR with p_I = R_LI p_L + T_LI.  Returns stamps (true time + t_offset), gyro, accel."""
+    rng = np.random.default_rng(seed + 11)
+    t = np.arange(t0, t1, 1.0 / rate_hz)
+    R_WL = traj.R(t)
+    w_L = traj.omega_body(t)
+    gyro = w_L @ np.asarray(R_LI).T + b_g + rng.normal(0, noise_g, (len(t), 3))
+    T_IL = -np.asarray(R_LI).T @ np.asarray(T_LI)  # IMU origin in the LiDAR frame
+    h = 2e-3
+
+    def p_I(tt):
+        return traj.p(tt) + np.einsum("nij,j->ni", traj.R(tt), T_IL)
+
+    acc_w = (p_I(t + h) - 2 * p_I(t) + p_I(t - h)) / (h * h)
+    g_w = np.array([0.0, 0.0, -9.81])
+    f_L = np.einsum("nji,nj->ni", R_WL, acc_w - g_w)  # specific force in the LiDAR frame
+    accel = f_L @ np.asarray(R_LI).T + b_a + rng.normal(0, noise_a, (len(t), 3))
+    return t + t_offset, gyro, accel

@@ -1,0 +1,74 @@
+"""End-to-end plumbing on a synthetic stream (BASELINE.json configs[0] in spirit, through the GPU path):
+LiDAR-only odometry (CV propagation on the host, de-skew + voxel filter + iterated update + map_incremental on the GPU)
+accumulates LiDAR states while a simulated IMU with a known extrinsic / time offset / biases runs alongside; then
+LI_Initialization (host conditioning chain + GPU-evaluated solves) must recover the ground truth.
+Tolerances are those of the method on a 16 k-point/sub-frame sensor, not of the arithmetic: rotation 1 deg, translation 10 cm,
+time offset 5 ms (against the offset the odometry can observe) (translation 10 cm: it is the weakest observable of the method — the committed reference run moves it by 3 cm during its own refinement), gyro bias 5e-3 rad/s, gravity direction 1.5 deg."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lo_then_li_init_recovers_extrinsic(oracle):
+    import lidar_imu_init_amd as lii
+    from lidar_imu_init_amd import calib_state_array, synth
+    from lidar_imu_init_amd.lo_harness import LoOdometry
+
+    hall = synth.Hall(size=(24.0, 18.0, 6.0), n_boxes=8, seed=7)
+    traj = synth.Trajectory()
+    sweep = 0.05                         # 20 Hz sub-frames (cut frames)
+    n_scans = 480                        # 24 s
+    R_LI = synth.rot_zyx(np.deg2rad(-1.0), np.deg2rad(-0.3), np.deg2rad(88.0))
+    T_LI = np.array([-0.02, 0.02, 0.17])
+    b_g = np.array([0.002, 0.0007, -0.0004])
+    b_a = np.array([0.006, -0.007, 0.008])
+    t_off = 0.015
+
+    reg = lii.Registrar(max_scan_points=20_000, max_map_points=600_000, filter_size_map=0.15)
+    lo = LoOdometry(reg, filter_size_surf=0.1, max_iteration=5)
+    pos_err = []
+    for k in range(n_scans):
+        t_beg = k * sweep
+        scan = synth.make_distorted_scan(hall, "mid16k", traj, t_beg, sweep, noise=0.01, seed=1000 + k)
+        rep = lo.process(scan, t_beg)
+        if rep is not None:
+            t_end = lo.lidar_states[-1][3]
+            pos_err.append(np.linalg.norm(lo.state.pos_end - traj.p(t_end)))
+    pos_err = np.array(pos_err)
+    assert np.median(pos_err) < 0.06 and pos_err.max() < 0.15, (np.median(pos_err), pos_err.max())  # LO drift while the map is young
+    # odometry velocities follow the truth (they feed the calibration)
+    ts = np.array([s[3] for s in lo.lidar_states])
+    w_est = np.array([s[1] for s in lo.lidar_states])
+    w_true = traj.omega_body(ts - sweep / 2)  # the CV model holds the mean rate of the last sub-frame
+    assert np.median(np.linalg.norm(w_est - w_true, axis=1)) < 0.08
+
+    # IMU stream + LI_Initialization
+    t_imu, gyro, accel = synth.simulate_imu(traj, -0.5, n_scans * sweep + 0.5, 200.0, R_LI, T_LI, b_g, b_a, t_off)
+    imu_all = calib_state_array(len(t_imu))
+    imu_all[:, 9:12], imu_all[:, 18:21], imu_all[:, 21] = gyro, accel, t_imu
+    lid = lo.lidar_calib_states()
+    import ctypes as C
+    L = lii.load_library()
+    oi, ol = calib_state_array(len(lid)), calib_state_array(len(lid))
+    n = C.c_int32(0)
+    move_start = 2.5
+    rc = L.lii_li_init_interpolate(imu_all.ctypes.data_as(C.c_void_p), len(imu_all), lid.ctypes.data_as(C.c_void_p), len(lid),
+                                   move_start, oi.ctypes.data_as(C.c_void_p), ol.ctypes.data_as(C.c_void_p), C.byref(n))
+    assert rc == 0 and n.value > 300
+    res, lag1, total = reg.li_init_run(oi[:n.value], ol[:n.value], 20, 1)
+    R_est = np.array(res.R_LI[:]).reshape(3, 3)
+    rot_err = np.rad2deg(np.linalg.norm(oracle.log_so3(R_LI.T @ R_est)))
+    T_est = np.array(res.T_LI[:])
+    g_est = np.array(res.grav_L0[:])
+    g_ang = np.rad2deg(np.arccos(np.clip(g_est @ np.array([0, 0, -9.81]) / (np.linalg.norm(g_est) * 9.81), -1, 1)))
+    print(f"rot err {rot_err:.3f} deg  T err {np.linalg.norm(T_est - T_LI) * 100:.2f} cm  lag {total * 1e3:.2f} ms (truth {t_off * 1e3:.1f})  "
+          f"b_g err {np.linalg.norm(np.array(res.gyro_bias[:]) - b_g):.2e}  gravity {g_est} ({g_ang:.2f} deg)")
+    assert rot_err < 1.0, rot_err
+    assert np.linalg.norm(T_est - T_LI) < 0.10, T_est
+    # the CV odometry reports the MEAN rate of the last sub-frame at its end stamp, i.e. a signal delayed by sweep / 2: the
+    # lag the method can see is the IMU clock offset minus that delay (the reference's LO has the same property)
+    assert abs(total - (t_off - sweep / 2)) < 0.005, total
+    assert np.linalg.norm(np.array(res.gyro_bias[:]) - b_g) < 5e-3
+    assert g_ang < 1.5 and abs(np.linalg.norm(g_est) - 9.81) < 1e-6, g_ang
+    reg.close()
