@@ -206,7 +206,7 @@ int lii_dev_free(lii_handle h, void* dev_ptr);
 int lii_dev_upload(lii_handle h, void* dev_dst, const void* host_src, size_t bytes);
 /* Per-stage device timings of the last lii_iekf_update [ms]: {knn+fit kernels, residual kernels, reduce kernels,
  * host solve, total}.  Measured with HIP events on the handle's stream when profiling is enabled. */
-int lii_set_profiling(lii_handle h, int32_t enabled);
+int lii_set_profiling(lii_handle h, int32_t enabled); /* 1: start (zero the accumulators), 2: resume, 0: pause */
 int lii_last_timings(lii_handle h, double out_ms[8]);
 
 #ifdef __cplusplus

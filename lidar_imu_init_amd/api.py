@@ -360,7 +360,7 @@ class Registrar:
 
     def set_profiling(self, enabled: bool):
         """Turns the HIP-event timing of the registration kernels on/off and zeroes the accumulators."""
-        self._check(self.L.lii_set_profiling(self.h, int(enabled)))
+        self._check(self.L.lii_set_profiling(self.h, int(enabled)))  # 1 = start (zero), 2 = resume, 0 = pause
 
     def timings(self):
         """[0] sum ms search-pass kernel, [1] sum ms residual-pass kernel, [2] sum ms reduce kernel, [3] host solve ms of

@@ -97,6 +97,7 @@ struct lii_context {
   // ---- profiling
   bool profiling = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_it[32] = {};  // per-iteration brackets of the k-NN kernel in the device-driven loop
   double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -354,7 +355,9 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   for (int it = 0; it < opts->max_iterations; it++) {
     const bool timed = prof && it == 0;  // the first pass always searches
     if (timed) HIPCHK(h, hipEventRecord(h->ev[0], s));
+    if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it], s));
     launch_knn(h, g, rb, ps0, pose, -1);
+    if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it + 1], s));
     if (timed) HIPCHK(h, hipEventRecord(h->ev[3], s));
     launch_knn_fallback(g, rb, h->d_ctrl, -1, s);
     launch_fit_reduce(rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
@@ -387,7 +390,16 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     HIPCHK(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
     HIPCHK(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
     HIPCHK(h, hipEventElapsedTime(&k, h->ev[0], h->ev[3]));
-    h->timings[0] += a; h->timings[5] += 1; h->timings[7] += k; h->timings[2] += b;
+    h->timings[0] += a; h->timings[2] += b;
+    // the k-NN kernel alone, over EVERY pass that actually searched (the device logs which iterations did)
+    for (int it = 0; it < opts->max_iterations && it < 16; it++) {
+      if (it >= hc->it || !hc->search_log[it]) continue;
+      float kk = 0;
+      HIPCHK(h, hipEventElapsedTime(&kk, h->ev_it[2 * it], h->ev_it[2 * it + 1]));
+      h->timings[7] += kk;
+      h->timings[5] += 1;
+    }
+    (void)k;
   }
   return LII_OK;
 }
@@ -520,6 +532,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), sizeof(float4) * h->h_stage_elems, hipHostMallocDefault));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_small), sizeof(double) * 32768, hipHostMallocDefault));
   for (int i = 0; i < 4; i++) CK(hipEventCreate(&h->ev[i]));
+  for (int i = 0; i < 32; i++) CK(hipEventCreate(&h->ev_it[i]));
   launch_table_clear(h->d_blocks, h->blocks_cap, h->stream);
   CK(hipStreamSynchronize(h->stream));
 #undef CK
@@ -545,6 +558,8 @@ int lii_destroy(lii_handle h) {
   if (h->n_map_pinned) (void)hipHostFree(h->n_map_pinned);
   for (int i = 0; i < 4; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  for (int i = 0; i < 32; i++)
+    if (h->ev_it[i]) (void)hipEventDestroy(h->ev_it[i]);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return LII_OK;
@@ -981,7 +996,8 @@ int lii_dev_upload(lii_handle h, void* dev_dst, const void* host_src, size_t byt
 int lii_set_profiling(lii_handle h, int32_t enabled) {
   if (!h) return LII_ERR_INVALID;
   h->profiling = enabled != 0;
-  for (double& t : h->timings) t = 0;  // (re)starts the accumulation
+  if (enabled == 1)
+    for (double& t : h->timings) t = 0;  // 1: (re)start the accumulation; 2: resume; 0: pause (accumulators kept)
   return LII_OK;
 }
 int lii_last_timings(lii_handle h, double out_ms[8]) {

@@ -81,6 +81,7 @@ struct IekfCtrl {
   int effect_num;    // effect_feat_num of the last iteration
   int singular;      // a matrix inversion failed
   int pad[2];
+  int search_log[16];  // search_log[it] = 1 when iteration `it` ran the k-NN pass (for profiling)
 };
 
 }  // namespace lii

@@ -30,12 +30,19 @@ constexpr int LDH = 13;  // padded leading dimension of the 12-column LDS tiles
 //
 // 12 x 12 Gauss-Jordan with partial pivoting, register resident: lane c < 24 owns column c of [A | I]; the multiplier
 // column is broadcast with constant-lane shuffles, all register indices are static (fully unrolled).
+__device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane is wave-uniform (a constant after unrolling)
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+  return u.d;
+}
 __device__ bool gj12(double (&col)[H]) {
 #pragma unroll
   for (int k = 0; k < H; k++) {
     double m[H];
 #pragma unroll
-    for (int r = 0; r < H; r++) m[r] = __shfl(col[r], k);
+    for (int r = 0; r < H; r++) m[r] = readlane_f64(col[r], k);  // v_readlane: the multiplier column lands in SGPRs
     int p = k;
     double best = fabs(m[k]);
 #pragma unroll
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __
     c->effect_num = (int)s_ne[90];
     c->it = it + 1;
     c->searches = searches0 + (search_now ? 1 : 0);
+    if (it < 16) c->search_log[it] = search_now;
     if (do_cov) c->stop = 1;
   }
   if (do_cov) {
