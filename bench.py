@@ -49,22 +49,25 @@ def build_workload(name, n_scans, seed=20220613):
     return dict(map=map_pts, scans=scans, poses=poses, fs_map=fs_map, fs_surf=fs_surf, max_it=max_it, rng=rng)
 
 
-def pose_table(n_poses=12, sweep_s=0.1):
-    """A pose table of a body that barely moves during the sweep (the scans are generated undistorted); every
-    point still goes through the full back-propagation arithmetic (sin/cos, 3 rotations)."""
+def pose_table(R_end=np.eye(3), p_end=np.zeros(3), n_poses=12, sweep_s=0.1):
+    """A pose table of a body that barely moves during the sweep and ends at (R_end, p_end) (the scans are generated
+    undistorted); every point still goes through the full back-propagation arithmetic (sin/cos, 3 rotations)."""
     from lidar_imu_init_amd import pose6d_array
     T = pose6d_array(n_poses)
     for k in range(n_poses):
         T[k, 0] = sweep_s * k / (n_poses - 1) if k else 0.0
         T[k, 4:7] = [1e-5, -2e-5, 1.5e-5]      # gyr
         T[k, 7:10] = [1e-5, 1e-5, 0.0]          # vel
-        T[k, 13:22] = np.eye(3).reshape(-1)
+        T[k, 10:13] = p_end
+        T[k, 13:22] = np.asarray(R_end).reshape(-1)
     return T
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--profile-every", type=int, default=8, help="HIP-event kernel timing on every Nth timed step (0: never)")
+    ap.add_argument("--separate-calls", action="store_true", help="undistort / downsample / update as three library calls")
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="stream100k", choices=sorted(WORKLOADS))
@@ -119,6 +122,7 @@ def main():
         st.pos_end[:] = p
         pert = np.r_[0.004, -0.003, 0.005, 0.03, -0.02, 0.015, np.zeros(18)]
         states0.append(lii.State(O.state_boxplus(st.pod, pert)))
+    tables = [pose_table(s0.rot_end, s0.pos_end) for s0 in states0]  # consistent with the propagated state
 
     iters_total = [0]
     search_total = [0]
@@ -126,13 +130,18 @@ def main():
     def step(k):
         j = k % len(dev_scans)
         reg.scan_set_device(dev_scans[j])
-        reg.undistort_imu(T, eye, np.zeros(3), eye, np.zeros(3))
-        if not args.no_downsample:
-            reg.downsample(wl["fs_surf"], want_count=False)
-        else:
-            reg.downsample_skip()
         st = states0[j].copy()
-        rep = reg.iekf_update(st, states0[j], max_iterations=wl["max_it"], imu_en=True)
+        if args.separate_calls:
+            s0 = states0[j]
+            reg.undistort_imu(tables[j], s0.rot_end, s0.pos_end, s0.offset_R_L_I, s0.offset_T_L_I)
+            if not args.no_downsample:
+                reg.downsample(wl["fs_surf"], want_count=False)
+            else:
+                reg.downsample_skip()
+            rep = reg.iekf_update(st, states0[j], max_iterations=wl["max_it"], imu_en=True)
+        else:  # the same three stages through the one-call entry point (one host round trip per scan)
+            rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=0.0 if args.no_downsample else wl["fs_surf"],
+                                    max_iterations=wl["max_it"], imu_en=True)
         iters_total[0] += rep["iterations"]
         search_total[0] += rep["searches"]
         if args.map_update:
@@ -159,7 +168,7 @@ def main():
     for k in range(args.steps):
         # HIP-event brackets of the kernels are recorded on every 8th step of the timed region only: each event is a
         # barrier packet on the stream, and ten of them per scan would cost ~5 % of the throughput being measured
-        reg.set_profiling(2 if k % 8 == 0 else 0)
+        reg.set_profiling(2 if (args.profile_every and k % args.profile_every == 0) else 0)
         last = step(k)
         if trace:
             stamps.append(time.perf_counter())

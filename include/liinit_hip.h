@@ -144,6 +144,24 @@ int lii_iekf_iterate(lii_handle h, const lii_state* state, int32_t search, int32
 int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_propagated, const lii_iekf_opts* opts,
                     lii_iekf_report* report);
 int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* selected, int32_t capacity);
+
+/* The per-scan sequence of main() (src/laserMapping.cpp:909-1134) in ONE call, enqueued back to back on the handle's
+ * stream with a single synchronisation at the end: p_imu->Process' undistortion (:909; the scan must have been handed
+ * over by lii_scan_upload / lii_scan_set_device), downSizeFilterSurf.filter (:917-919) and the iterated update
+ * (:957-1134).  The undistortion takes its end pose and extrinsic from `state` (the propagated state, as the reference
+ * does: IMU_Processing.hpp:404-407 reads state_inout).  Equivalent to lii_undistort_* + lii_downsample(_skip) +
+ * lii_iekf_update; it exists because every separate call costs the caller a host round trip. */
+typedef struct lii_scan_job {
+  uint32_t struct_size;            /* sizeof(lii_scan_job) */
+  int32_t undistort;               /* 0 none, 1 IMU back-propagation, 2 constant-velocity model (LO mode) */
+  const lii_pose6d* imu_poses;     /* undistort == 1: IMUpose table */
+  int32_t n_imu_poses;
+  float leaf;                      /* voxel-grid leaf size; <= 0: use the scan unfiltered */
+  lii_iekf_opts opts;
+} lii_scan_job;
+int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, const lii_state* state_propagated,
+                      lii_iekf_report* report);
+
 /* map_incremental (src/laserMapping.cpp:516-559): decides PointToAdd / PointNoNeedDownsample from the last
  * search's neighbour lists and applies both to the map. */
 int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, int32_t* n_no_downsample);

@@ -60,10 +60,12 @@ struct lii_context {
   int* d_nbr_count = nullptr;
   double* d_plane = nullptr;
   unsigned char* d_selected = nullptr;
-  int* d_needy = nullptr;
   IekfCtrl* d_ctrl = nullptr;   // device-resident loop state of lii_iekf_update
   PoseArg* d_pose = nullptr;    // pose slot of the host-driven lii_iekf_iterate
-  IekfCtrl* h_ctrl = nullptr;   // pinned mirror
+  IekfCtrl* h_ctrl = nullptr;   // pinned upload image
+  IekfResult* h_res = nullptr;  // pinned, device-mapped: written by the solve kernel of the stopping iteration
+  lii_pose6d* h_poses = nullptr;  // pinned staging of the IMU pose table
+  hipEvent_t ev_poses = nullptr;  // the last pose-table upload
   bool host_solve = false;      // LII_HOST_SOLVE=1: drive the loop from the host (A/B, reference arrangement)
   double* d_partials = nullptr;
   double* d_out91 = nullptr;
@@ -79,7 +81,7 @@ struct lii_context {
   void* d_voxel_arg = nullptr;
   bool body_is_scan = false;
   bool have_search = false;
-  int knn_variant = 4;  // 0: 1 lane/query fused; 1: 8 lanes, all 27 cells; 2: 4 lanes, rows; 3: 8 lanes, pruned; 4: 4 lanes, pruned (default)
+  int knn_variant = 4;  // lanes per query of the search pass: 4 (default) or 8 (LII_KNN_VARIANT, an A/B knob)
 
   // ---- pinned staging
   float4* h_stage = nullptr;     // max(max_scan, max_map) float4
@@ -148,8 +150,6 @@ RegistrationBuffers reg_buffers(const lii_context* c) {
   rb.plane = c->d_plane;
   rb.selected = c->d_selected;
   rb.partials = c->d_partials;
-  rb.needy = c->d_needy;
-  rb.needy_count = c->d_counter;
   rb.partial_stride = c->partial_stride;
   rb.n = c->n_body;
   rb.n_dev = c->n_body_pending ? c->d_nbody : nullptr;
@@ -260,12 +260,8 @@ int map_apply(lii_handle h, const float4* list, int n_bound, const int* n_dev, b
 }
 
 void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, int forced) {
-  switch (h->knn_variant) {
-    case 1: launch_knn8(g, rb, ps, pose, h->d_ctrl, forced, h->stream); break;
-    case 2: launch_knn4(g, rb, ps, pose, h->d_ctrl, forced, h->stream); break;
-    case 4: launch_knn4p(g, rb, ps, pose, h->d_ctrl, forced, h->stream); break;
-    default: launch_knn8p(g, rb, ps, pose, h->d_ctrl, forced, h->stream); break;
-  }
+  if (h->knn_variant == 8) launch_knn8p(g, rb, ps, pose, h->d_ctrl, forced, h->stream);
+  else launch_knn4p(g, rb, ps, pose, h->d_ctrl, forced, h->stream);
 }
 
 // Fetches the exact size of the down-sampled cloud from the device (one small synchronising copy).
@@ -291,18 +287,12 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
   const bool prof = h->profiling;
   if (prof) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   const PoseArg ps = pose_of(*st);
-  if (h->knn_variant == 0) {
-    launch_register_fused(search, g, rb, ps, imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, h->stream);
-    if (prof) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
-  } else {
-    if (search) launch_knn(h, g, rb, ps, h->d_pose, 1);
-    if (prof) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
-    if (search) launch_knn_fallback(g, rb, h->d_ctrl, 1, h->stream);
-    launch_fit_reduce(rb, ps, h->d_pose, h->d_ctrl, search ? 1 : 0, imu_en ? 1 : 0, h->cfg.plane_threshold,
-                      h->cfg.laser_point_cov_inv, h->stream);
-  }
+  if (search) launch_knn(h, g, rb, ps, h->d_pose, 1);
+  if (prof) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+  launch_fit_reduce(g, rb, ps, h->d_pose, h->d_ctrl, search ? 1 : 0, imu_en ? 1 : 0, h->cfg.plane_threshold,
+                    h->cfg.laser_point_cov_inv, h->stream);
   if (prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-  launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, 1, rb.n_dev, h->stream);
+  launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_ctrl, 1, rb.n_dev, h->stream);
   if (prof) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
   if (search) h->have_search = true;
   if (h->comm) {
@@ -340,11 +330,13 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   hipStream_t s = h->stream;
   IekfCtrl* hc = h->h_ctrl;
   std::memcpy(hc->st, state, sizeof(lii_state));
-  std::memcpy(hc->prop, state_prop, sizeof(lii_state));
+  std::memcpy(hc->prop, state_prop, sizeof(hc->prop));
   hc->max_it = opts->max_iterations;
   hc->imu_en = opts->imu_en;
   hc->it = 0; hc->search_next = 1; hc->stop = 0; hc->rematch_num = 0; hc->converged = 0; hc->searches = 0;
   hc->effect_num = 0; hc->singular = 0;
+  h->h_res->singular = 0;
+  h->h_res->it = -1;  // overwritten by the stopping iteration
   HIPCHK(h, hipMemcpyAsync(h->d_ctrl, hc, sizeof(IekfCtrl), hipMemcpyHostToDevice, s));
   GridView g = grid_view(h);
   RegistrationBuffers rb = reg_buffers(h);
@@ -359,31 +351,35 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     launch_knn(h, g, rb, ps0, pose, -1);
     if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it + 1], s));
     if (timed) HIPCHK(h, hipEventRecord(h->ev[3], s));
-    launch_knn_fallback(g, rb, h->d_ctrl, -1, s);
-    launch_fit_reduce(rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
+    launch_fit_reduce(g, rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[1], s));
-    launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, -1, rb.n_dev, s);
+    if (!h->comm) {  // single GPU: final reduction and solve in one launch ([2] then times both)
+      launch_reduce_solve(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, h->h_res, rb.n_dev, s);
+      if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
+      continue;
+    }
+    launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_ctrl, -1, rb.n_dev, s);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
-    if (h->comm) {
+    {
       // every rank enqueues the same number of all-reduces; a pass that is skipped on the device re-sums the
       // unchanged local buffer on all ranks alike, so the ranks stay in lock-step without a host decision
       ncclResult_t r = ncclAllReduce(h->d_out91, h->d_out91 + 128, kNormalEq, ncclDouble, ncclSum, h->comm, s);
       if (r != ncclSuccess) return fail(h, LII_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
     }
-    launch_iekf_solve(h->d_ctrl, ne, s);
+    launch_iekf_solve(h->d_ctrl, ne, h->h_res, s);
   }
-  HIPCHK(h, hipMemcpyAsync(hc, h->d_ctrl, sizeof(IekfCtrl), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipMemcpyAsync(h->h_small, ne, sizeof(double) * kNormalEq, hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipStreamSynchronize(s));  // the stopping iteration's solve has written h_res (mapped host memory)
+  const IekfResult* hr = h->h_res;
   h->have_search = true;
-  if (hc->singular) return fail(h, LII_ERR_INVALID, "singular covariance / normal matrix in the device solve");
-  std::memcpy(state, hc->st, sizeof(lii_state));
+  if (hr->singular) return fail(h, LII_ERR_INVALID, "singular covariance / normal matrix in the device solve");
+  if (hr->it < 0) return fail(h, LII_ERR_HIP, "device loop ended without a result");
+  std::memcpy(state, hr->st, sizeof(lii_state));
   if (report) {
-    report->iterations = hc->it;
-    report->searches = hc->searches;
-    report->effect_num = hc->effect_num;
-    report->converged = hc->converged;
-    std::memcpy(report->normal_eq, h->h_small, sizeof(double) * kNormalEq);
+    report->iterations = hr->it;
+    report->searches = hr->searches;
+    report->effect_num = hr->effect_num;
+    report->converged = hr->converged;
+    std::memcpy(report->normal_eq, hr->ne, sizeof(double) * kNormalEq);
   }
   if (prof) {
     float a = 0, b = 0, k = 0;
@@ -393,7 +389,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     h->timings[0] += a; h->timings[2] += b;
     // the k-NN kernel alone, over EVERY pass that actually searched (the device logs which iterations did)
     for (int it = 0; it < opts->max_iterations && it < 16; it++) {
-      if (it >= hc->it || !hc->search_log[it]) continue;
+      if (it >= hr->it || !hr->search_log[it]) continue;
       float kk = 0;
       HIPCHK(h, hipEventElapsedTime(&kk, h->ev_it[2 * it], h->ev_it[2 * it + 1]));
       h->timings[7] += kk;
@@ -507,12 +503,15 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_nbr_count, N));
   CK(dmalloc(&h->d_plane, N * 4));
   CK(dmalloc(&h->d_selected, N));
-  CK(dmalloc(&h->d_needy, N));
   CK(dmalloc(&h->d_nbody, 4));
   CK(hipMalloc(&h->d_voxel_arg, 64));
   CK(dmalloc(&h->d_ctrl, 1));
   CK(dmalloc(&h->d_pose, 1));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_ctrl), sizeof(IekfCtrl), hipHostMallocDefault));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_res), sizeof(IekfResult), hipHostMallocMapped));
+  std::memset(h->h_res, 0, sizeof(IekfResult));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_poses), sizeof(lii_pose6d) * 1024, hipHostMallocDefault));
+  CK(hipEventCreateWithFlags(&h->ev_poses, hipEventDisableTiming));
   CK(hipMemset(h->d_counter, 0, 16));
   h->partial_stride = register_blocks(int(N)) + 8;
   CK(dmalloc(&h->d_partials, size_t(h->partial_stride) * kNormalEq));
@@ -547,7 +546,7 @@ int lii_destroy(lii_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
-                 h->d_selected, h->d_needy, h->d_nbody, h->d_voxel_arg, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
+                 h->d_selected, h->d_nbody, h->d_voxel_arg, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
                  h->d_vidx_b, h->d_vflags, h->d_vranks, h->d_poses, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)
@@ -555,6 +554,9 @@ int lii_destroy(lii_handle h) {
   if (h->h_stage) (void)hipHostFree(h->h_stage);
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
+  if (h->h_res) (void)hipHostFree(h->h_res);
+  if (h->h_poses) (void)hipHostFree(h->h_poses);
+  if (h->ev_poses) (void)hipEventDestroy(h->ev_poses);
   if (h->n_map_pinned) (void)hipHostFree(h->n_map_pinned);
   for (int i = 0; i < 4; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -680,8 +682,10 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
     return fail(h, LII_ERR_INVALID, "lii_undistort_imu: bad arguments");
   static_assert(sizeof(lii_pose6d) == 22 * sizeof(double), "lii_pose6d layout");
   if (h->n_scan <= 0 || n_poses < 2) return LII_OK;  // nothing to compensate (IMUpose needs a head and a tail)
-  std::memcpy(h->h_small, poses, sizeof(lii_pose6d) * size_t(n_poses));
-  HIPCHK(h, hipMemcpyAsync(h->d_poses, h->h_small, sizeof(lii_pose6d) * size_t(n_poses), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipEventSynchronize(h->ev_poses));  // the previous table has left the staging buffer (normally long ago)
+  std::memcpy(h->h_poses, poses, sizeof(lii_pose6d) * size_t(n_poses));
+  HIPCHK(h, hipMemcpyAsync(h->d_poses, h->h_poses, sizeof(lii_pose6d) * size_t(n_poses), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_poses, h->stream));
   UndistArgH u;
   std::memcpy(u.endR, end_R, 72);
   std::memcpy(u.endp, end_p, 24);
@@ -690,7 +694,6 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
   launch_time_extent(h->d_scan, h->n_scan, h->d_extent, h->stream);
   launch_undistort_imu(h->d_scan, h->n_scan, h->d_poses, n_poses, u, h->d_extent, h->stream);
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));  // h_small is reused
   return LII_OK;
 }
 int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], const double end_R[9]) {
@@ -775,7 +778,7 @@ int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_prop,
   if (!h || !state || !state_prop || !opts || opts->max_iterations < 1) return fail(h, LII_ERR_INVALID, "lii_iekf_update: bad arguments");
   const int max_it = opts->max_iterations;
   auto t_begin = std::chrono::steady_clock::now();
-  if (!h->host_solve && h->knn_variant != 0) {
+  if (!h->host_solve) {
     int rc = update_on_device(h, state, state_prop, opts, report);
     h->timings[4] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return rc;
@@ -850,6 +853,25 @@ int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_prop,
   h->timings[3] = host_ms;
   h->timings[4] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return LII_OK;
+}
+
+int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, const lii_state* state_prop,
+                      lii_iekf_report* report) {
+  if (!h || !job || job->struct_size != sizeof(lii_scan_job) || !state || !state_prop || job->opts.max_iterations < 1)
+    return fail(h, LII_ERR_INVALID, "lii_scan_register: bad arguments");
+  int rc = LII_OK;
+  if (job->undistort == 1) {
+    rc = lii_undistort_imu(h, job->imu_poses, job->n_imu_poses, state->rot_end, state->pos_end, state->offset_R_L_I,
+                           state->offset_T_L_I);
+  } else if (job->undistort == 2) {
+    rc = lii_undistort_cv(h, state->bias_g, state->vel_end, state->rot_end);  // CV model: bias_g = omega, vel_end = v
+  } else if (job->undistort != 0) {
+    return fail(h, LII_ERR_INVALID, "lii_scan_register: undistort must be 0, 1 or 2");
+  }
+  if (rc != LII_OK) return rc;
+  rc = job->leaf > 0 ? lii_downsample(h, job->leaf, nullptr, nullptr) : lii_downsample_skip(h, nullptr);
+  if (rc != LII_OK) return rc;
+  return lii_iekf_update(h, state, state_prop, &job->opts, report);
 }
 
 int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* selected, int32_t capacity) {

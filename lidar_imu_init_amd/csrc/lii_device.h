@@ -6,6 +6,7 @@
 namespace lii {
 
 constexpr int kMatch = 5;          // NUM_MATCH_POINTS — reference include/common_lib.h:28
+constexpr int kNeedy = 0x100;      // nbr_count flag: the 3x3x3 search pass could not prove this list exact yet
 constexpr int kBlock = 256;        // 4 wavefronts of 64
 constexpr int kNormalEq = 91;      // 78 + 12 + 1
 constexpr int kCoarseShift = 3;    // coarse occupancy cell = 8 x 8 x 8 fine cells
@@ -50,8 +51,6 @@ struct RegistrationBuffers {
   int* nbr_count;       // neighbours found (0..5)
   double* plane;        // 4 doubles per point: n̂, d  (pabcd)
   unsigned char* selected;
-  int* needy;                // queue of query indices that need the second search stage
-  unsigned int* needy_count;
   double* partials;     // transposed per-block partial sums: partials[t * partial_stride + block], t < 91
   int partial_stride;
   int n;              // number of points, or an upper bound of it when n_dev != nullptr
@@ -65,10 +64,8 @@ struct RegistrationBuffers {
 // offset_T_L_I of lii_state), which the per-point kernels read through a pointer.
 constexpr int kStateDoubles = 36 + 24 * 24;
 struct IekfCtrl {
-  double st[kStateDoubles];    // lii_state: current estimate (in/out)
-  double prop[kStateDoubles];  // lii_state: state_propagat
-  double Pinv[24 * 24];        // inverse of the prior covariance (constant during the loop)
-  double KH[24 * 12];          // K * Hsub of the last iteration
+  double st[kStateDoubles];    // lii_state: current estimate (in/out); its first 24 doubles are the PoseArg the kernels read
+  double prop[36];             // state_propagat without its covariance (only used through boxminus)
   double solution[24];
   int max_it;
   int imu_en;
@@ -82,6 +79,15 @@ struct IekfCtrl {
   int singular;      // a matrix inversion failed
   int pad[2];
   int search_log[16];  // search_log[it] = 1 when iteration `it` ran the k-NN pass (for profiling)
+};
+
+// What the host needs back from one iterated update.  Lives in pinned, device-mapped HOST memory: the solve kernel of the
+// stopping iteration writes it there directly, so the update ends with one stream synchronisation and no D2H copy.
+struct IekfResult {
+  double st[kStateDoubles];
+  double ne[96];  // the 91 normal-equation scalars of the last executed pass
+  int it, searches, effect_num, converged, singular, pad[3];
+  int search_log[16];
 };
 
 }  // namespace lii

@@ -99,25 +99,11 @@ __device__ void d_so3_log(const double* R, double* out) {
   out[0] = f * K[0]; out[1] = f * K[1]; out[2] = f * K[2];
 }
 
-// Per-scan prologue: the loop flags.
-__global__ __launch_bounds__(64) void k_iekf_begin(IekfCtrl* c) {
-  if (threadIdx.x == 0) {
-    c->it = 0;
-    c->search_next = 1;
-    c->stop = 0;
-    c->rematch_num = 0;
-    c->converged = 0;
-    c->searches = 0;
-    c->effect_num = 0;
-    c->singular = 0;
-  }
-}
-
 // One iteration's solve + state update + schedule.  ne = the 91 reduced normal-equation scalars of this pass.
 // Single wavefront.  Every global input is fetched in ONE parallel batch into LDS (the control block and `ne` were
 // just written by other kernels, so each dependent global read would cost a full memory round trip), the algebra runs
 // out of LDS / registers, and the results are written back once at the end.
-__global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __restrict__ ne) {
+__device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, IekfResult* res) {
   __shared__ double s_cov[N * N];  // prior covariance (row-major, stride 24)
   __shared__ double G[H * LDH];    // H^T R^-1 H
   __shared__ double A[H * LDH];    // I + P11 G, later M
@@ -130,7 +116,8 @@ __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __
   {
     const int* ci = &c->max_it;  // max_it, imu_en, it, search_next, stop, rematch_num, converged, searches, effect_num, singular
     if (lane < 10) s_int[lane] = ci[lane];
-    for (int e = lane; e < 91; e += 64) s_ne[e] = ne[e];
+    // agent-scope loads: in the fused kernel these sums were written by other workgroups of the SAME launch
+    for (int e = lane; e < 91; e += 64) s_ne[e] = __hip_atomic_load(ne + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane < 36) { s_st[lane] = c->st[lane]; s_prop[lane] = c->prop[lane]; }
     const double* cov = c->st + 36;
 #pragma unroll
@@ -180,7 +167,7 @@ __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __
   for (int r = 0; r < H; r++) col[r] = lane < H ? A[r * LDH + lane] : ((lane < 2 * H && r == lane - H) ? 1.0 : 0.0);
   const bool ok = gj12(col);
   if (!ok) {
-    if (lane == 0) { c->stop = 1; c->singular = 1; }
+    if (lane == 0) { c->stop = 1; c->singular = 1; res->singular = 1; }
     return;
   }
   __syncthreads();
@@ -241,12 +228,16 @@ __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __
     d_so3_exp(sol[so], sol[so + 1], sol[so + 2], E);
     d_m3_mul(s_st + o, E, Rn);
     for (int e = 0; e < 9; e++) c->st[o + e] = Rn[e];
+    if (do_cov)
+      for (int e = 0; e < 9; e++) res->st[o + e] = Rn[e];
   } else if (lane >= 8 && lane < 26) {
     const int q = lane - 8;  // 0..17 : six 3-vectors
     const int blk = q / 3, i = q % 3;
     const int sto = blk == 0 ? 9 : (blk == 1 ? 21 : (blk == 2 ? 24 : (blk == 3 ? 27 : (blk == 4 ? 30 : 33))));
     const int soo = blk == 0 ? 3 : (blk == 1 ? 9 : (blk == 2 ? 12 : (blk == 3 ? 15 : (blk == 4 ? 18 : 21))));
-    c->st[sto + i] = s_st[sto + i] + sol[soo + i];
+    const double v = s_st[sto + i] + sol[soo + i];
+    c->st[sto + i] = v;
+    if (do_cov) res->st[sto + i] = v;
   } else if (lane >= 32 && lane < 32 + N) {
     c->solution[lane - 32] = sol[lane - 32];
   }
@@ -258,7 +249,14 @@ __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __
     c->it = it + 1;
     c->searches = searches0 + (search_now ? 1 : 0);
     if (it < 16) c->search_log[it] = search_now;
-    if (do_cov) c->stop = 1;
+    if (do_cov) {
+      c->stop = 1;
+      res->it = it + 1;
+      res->searches = searches0 + (search_now ? 1 : 0);
+      res->effect_num = (int)s_ne[90];
+      res->converged = converged;
+      res->singular = 0;
+    }
   }
   if (do_cov) {
     // state.cov = (I - K H) cov = cov - (K H) cov[0:12, :]   (:1111-1114), all operands already in LDS
@@ -270,13 +268,52 @@ __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __
       double s2 = s_cov[e];
       for (int k = 0; k < H; k++) s2 -= s_KH[r * H + k] * s_cov[k * N + cc];
       covw[e] = s2;
+      res->st[36 + e] = s2;
     }
+    for (int e = lane; e < 91; e += 64) res->ne[e] = s_ne[e];
+    if (lane < 16) res->search_log[lane] = (lane < it) ? c->search_log[lane] : (lane == it ? search_now : 0);
   }
 }
 
-void launch_iekf_begin(IekfCtrl* c, hipStream_t s) { hipLaunchKernelGGL(k_iekf_begin, dim3(1), dim3(64), 0, s, c); }
-void launch_iekf_solve(IekfCtrl* c, const double* ne, hipStream_t s) {
-  hipLaunchKernelGGL(k_iekf_solve, dim3(1), dim3(64), 0, s, c, ne);
+__global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __restrict__ ne, IekfResult* res) {
+  iekf_solve_body(c, ne, res);
+}
+
+// Final reduction of the per-workgroup partials (91 workgroups, one output each, fixed summation order — the same
+// order as k_reduce91) FUSED with the solve: the workgroup that finishes last (ticket counter) runs the 24-state
+// update.  Used when no all-reduce sits between the two (single GPU); one launch less per iteration.
+__global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ partials, int n_blocks, int stride,
+                                                      double* out, unsigned int* ticket, IekfCtrl* c, IekfResult* res,
+                                                      const int* __restrict__ n_dev) {
+  __shared__ int s_last;
+  if (c->stop) return;  // read by every workgroup before its ticket; the solve (which may set it) runs after all tickets
+  if (n_dev) n_blocks = max(1, (*n_dev + kBlock - 1) / kBlock);
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const double* row = partials + (size_t)t * stride;
+  double acc = 0;
+  for (int b = lane; b < n_blocks; b += 64) acc += row[b];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if (lane == 0) {
+    __hip_atomic_store(out + t, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    const unsigned int tk = atomicAdd(ticket, 1u);
+    s_last = tk == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (lane == 0) *ticket = 0u;  // re-armed for the next launch (kernel boundary orders it)
+  __threadfence();
+  iekf_solve_body(c, out, res);
+}
+
+void launch_reduce_solve(const double* partials, int n_points, int stride, double* out91, unsigned int* ticket, IekfCtrl* c,
+                         IekfResult* res, const int* n_dev, hipStream_t s) {
+  int nb = (n_points + kBlock - 1) / kBlock;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, ticket, c, res, n_dev);
+}
+void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s) {
+  hipLaunchKernelGGL(k_iekf_solve, dim3(1), dim3(64), 0, s, c, ne, res);
 }
 
 }  // namespace lii

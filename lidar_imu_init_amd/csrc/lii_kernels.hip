@@ -5,12 +5,12 @@
 //   k_map_keys / k_map_gather / k_block_flags / k_cells_fill
 //                      device mirror of the ikd-Tree point set as a cell-sorted array + block-hierarchical grid
 //                      (include/ikd-Tree/ikd_Tree.cpp:336-347 Build)
-//   k_knn8             KD_TREE::Nearest_Search (ikd_Tree.cpp:349-379, Search :825-968) for every point of the
+//   k_knn_pruned<LPQ>  KD_TREE::Nearest_Search (ikd_Tree.cpp:349-379, Search :825-968) for every point of the
 //                      scan, after pointBodyToWorld (src/laserMapping.cpp:209-220, call :973-985)
-//   k_fit_reduce<FIT>  esti_plane + residual/selection (src/laserMapping.cpp:987-1011), Jacobian rows
-//                      (:1035-1071) and the H^T R^-1 H / H^T R^-1 z sums (:1073-1080)
-//   k_register<SEARCH> the same work with one lane per point, fused (A/B variant 0)
-//   k_reduce91         deterministic final sum of the per-block partials
+//   k_fit_reduce       completes the few searches the 3x3x3 pass could not prove exact, then esti_plane +
+//                      residual/selection (src/laserMapping.cpp:987-1011), Jacobian rows (:1035-1071) and the
+//                      H^T R^-1 H / H^T R^-1 z sums (:1073-1080)
+//   k_reduce91         deterministic final sum of the per-block partials (lii_iekf.hip fuses it with the solve)
 //   k_time_extent / k_undistort_imu / _cv ... src/IMU_Processing.hpp:390-414 and :246-266
 //   k_voxel_*          pcl::VoxelGrid::filter call site src/laserMapping.cpp:917-919
 //   k_calib_eval       include/LI_init/LI_init.h:91-205 residuals + analytic Jacobians
@@ -179,54 +179,6 @@ __device__ __forceinline__ void scan_range(const GridView& g, unsigned int start
     if (j + 1 < end && d1 <= g.max_d2 && d1 < k.d4) knn_insert(k, d1, (int)(j + 1));
     if (j + 2 < end && d2 <= g.max_d2 && d2 < k.d4) knn_insert(k, d2, (int)(j + 2));
     if (j + 3 < end && d3 <= g.max_d2 && d3 < k.d4) knn_insert(k, d3, (int)(j + 3));
-  }
-}
-
-// one-lane-per-query search (variant 0): 3x3x3 block with box-distance pruning, then ring shells
-__device__ __forceinline__ void knn5_search(const GridView& g, float qx, float qy, float qz, Knn5& k) {
-  const float INF = __builtin_inff();
-  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = INF;
-  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
-  if (g.n_pts <= 0) return;
-  // slack for every geometric cell-bound test: float rounding of c*cs and of p*inv_cs grows with |coordinate|
-  const float cs = g.cs, eps = 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + 8.f);
-  const int cx = cell_of(qx, g.inv_cs), cy = cell_of(qy, g.inv_cs), cz = cell_of(qz, g.inv_cs);
-  {
-    uint2 r = cell_range(g, cx, cy, cz);
-    scan_range(g, r.x, r.y, qx, qy, qz, k);
-  }
-  for (int dz = -1; dz <= 1; dz++) {
-    float gz = axis_gap(qz, cz + dz, cs, eps);
-    for (int dy = -1; dy <= 1; dy++) {
-      float gy = axis_gap(qy, cy + dy, cs, eps);
-      for (int dx = -1; dx <= 1; dx++) {
-        if (dx == 0 && dy == 0 && dz == 0) continue;
-        float gx = axis_gap(qx, cx + dx, cs, eps);
-        if (gx * gx + gy * gy + gz * gz > fminf(k.d4, g.max_d2)) continue;
-        uint2 r = cell_range(g, cx + dx, cy + dy, cz + dz);
-        scan_range(g, r.x, r.y, qx, qy, qz, k);
-      }
-    }
-  }
-  float fx = qx - (float)cx * cs, fy = qy - (float)cy * cs, fz = qz - (float)cz * cs;
-  float mfrac = fmaxf(fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz)), 0.f);
-  const int rmax = (int)ceilf(sqrtf(g.max_d2) * g.inv_cs) + 1;
-  for (int r = 2; r <= rmax; r++) {
-    float guard = (float)(r - 1) * cs + mfrac - 2.f * eps;
-    if (fminf(k.d4, g.max_d2) <= guard * guard) return;
-    for (int dz = -r; dz <= r; dz++) {
-      float gz = axis_gap(qz, cz + dz, cs, eps);
-      for (int dy = -r; dy <= r; dy++) {
-        float gy = axis_gap(qy, cy + dy, cs, eps);
-        const bool face = (abs(dz) == r) || (abs(dy) == r);
-        for (int dx = -r; dx <= r; dx += (face ? 1 : 2 * r)) {
-          float gx = axis_gap(qx, cx + dx, cs, eps);
-          if (gx * gx + gy * gy + gz * gz > fminf(k.d4, g.max_d2)) continue;
-          uint2 rr = cell_range(g, cx + dx, cy + dy, cz + dz);
-          scan_range(g, rr.x, rr.y, qx, qy, qz, k);
-        }
-      }
-    }
   }
 }
 
@@ -489,205 +441,13 @@ __device__ __forceinline__ bool fit_plane(const float4 (&nb)[5], double plane_th
 __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]);
 
 // ------------------------------------------------------------------------------------------------
-// Variant 0: the fused registration pass, one lane per point.  SEARCH = true: transform, 5-NN, plane fit,
-// residual, Jacobian, reduce.  SEARCH = false: residual against the cached plane (the reference re-fits the plane
-// from the unchanged neighbours every iteration, which reproduces the same coefficients — caching is exact).
-// `selected` is sticky between searches exactly as point_selected_surf (quirk A11).
-template <bool SEARCH>
-__global__ __launch_bounds__(kBlock) void k_register(GridView g, RegistrationBuffers rb, PoseArg ps, int imu_en,
-                                                      double plane_thr, double rinv) {
-  __shared__ ReduceShared sh;
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  const bool live = i < (rb.n_dev ? *rb.n_dev : rb.n);
-  RowOut o;
-#pragma unroll
-  for (int c = 0; c < 12; c++) o.h[c] = 0;
-  o.z = 0;
-  o.sel = false;
-  if (live) {
-    float4 pb = rb.body[i];
-    double bx = pb.x, by = pb.y, bz = pb.z;
-    double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
-    double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
-    double iz = ps.RLI[6] * bx + ps.RLI[7] * by + ps.RLI[8] * bz + ps.TLI[2];
-    float wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
-    float wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
-    float wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
-    rb.world[i] = make_float4(wx, wy, wz, 0.f);
-    double pa = 0, pbn = 0, pc = 0, pd = 0;
-    bool candidate;
-    if (SEARCH) {
-      Knn5 k;
-      knn5_search(g, wx, wy, wz, k);
-      int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
-      rb.nbr_count[i] = found;
-      float4 nb[5];
-      nb[0] = k.i0 >= 0 ? g.pts[k.i0] : make_float4(0, 0, 0, 0);
-      nb[1] = k.i1 >= 0 ? g.pts[k.i1] : make_float4(0, 0, 0, 0);
-      nb[2] = k.i2 >= 0 ? g.pts[k.i2] : make_float4(0, 0, 0, 0);
-      nb[3] = k.i3 >= 0 ? g.pts[k.i3] : make_float4(0, 0, 0, 0);
-      nb[4] = k.i4 >= 0 ? g.pts[k.i4] : make_float4(0, 0, 0, 0);
-      nb[0].w = k.d0; nb[1].w = k.d1; nb[2].w = k.d2; nb[3].w = k.d3; nb[4].w = k.d4;
-      if (found == kMatch) canon_ties(nb);
-#pragma unroll
-      for (int j = 0; j < 5; j++) rb.nbr[(size_t)j * rb.cap + i] = nb[j];
-      candidate = (found == kMatch) && !(k.d4 > 5.0f);  // (:981-984)
-      if (candidate) candidate = fit_plane(nb, plane_thr, pa, pbn, pc, pd);
-      double* pl = rb.plane + 4 * (size_t)i;
-      pl[0] = pa; pl[1] = pbn; pl[2] = pc; pl[3] = pd;
-    } else {
-      candidate = rb.selected[i] != 0;  // sticky (:989-994)
-      const double* pl = rb.plane + 4 * (size_t)i;
-      pa = pl[0]; pbn = pl[1]; pc = pl[2]; pd = pl[3];
-    }
-    if (candidate) residual_row(ps, imu_en, bx, by, bz, ix, iy, iz, wx, wy, wz, pa, pbn, pc, pd, o);
-    rb.selected[i] = o.sel ? 1 : 0;
-  }
-  block_reduce_rows(sh, o.h, o.z, o.sel, rinv, rb.partials + blockIdx.x, rb.partial_stride);
-}
-template __global__ void k_register<true>(GridView, RegistrationBuffers, PoseArg, int, double, double);
-template __global__ void k_register<false>(GridView, RegistrationBuffers, PoseArg, int, double, double);
-
-// ------------------------------------------------------------------------------------------------
-// Variant 1 of the search pass: the k-NN runs with EIGHT lanes per query (8 queries per wavefront) so that the
-// cell lookups and candidate loads of one query are spread over independent lanes (memory-level parallelism
-// instead of one long dependent chain per lane); the per-lane top-5 lists are merged with a 3-step
-// wavefront-shuffle butterfly.
 template <bool DEDUP>
 __device__ __forceinline__ void knn_merge_one(Knn5& k, float e, int j) {
   if (DEDUP && (j == k.i0 || j == k.i1 || j == k.i2 || j == k.i3 || j == k.i4)) return;
   if (e < k.d4) knn_insert(k, e, j);
 }
-// butterfly merge over the 8 lanes of a query group; afterwards every lane holds the group's top-5.
-// DEDUP: the lists may share entries (phase 2 starts every lane from the merged list).
-template <bool DEDUP>
-__device__ __forceinline__ void knn_group_merge(Knn5& k) {
-#pragma unroll
-  for (int off = 1; off < 8; off <<= 1) {
-    float e0 = __shfl_xor(k.d0, off), e1 = __shfl_xor(k.d1, off), e2 = __shfl_xor(k.d2, off), e3 = __shfl_xor(k.d3, off),
-          e4 = __shfl_xor(k.d4, off);
-    int j0 = __shfl_xor(k.i0, off), j1 = __shfl_xor(k.i1, off), j2 = __shfl_xor(k.i2, off), j3 = __shfl_xor(k.i3, off),
-        j4 = __shfl_xor(k.i4, off);
-    if (j0 >= 0) knn_merge_one<DEDUP>(k, e0, j0);
-    if (j1 >= 0) knn_merge_one<DEDUP>(k, e1, j1);
-    if (j2 >= 0) knn_merge_one<DEDUP>(k, e2, j2);
-    if (j3 >= 0) knn_merge_one<DEDUP>(k, e3, j3);
-    if (j4 >= 0) knn_merge_one<DEDUP>(k, e4, j4);
-  }
-}
-
-constexpr int kLanesPerQuery = 8;
-constexpr int kQueriesPerBlock = kBlock / kLanesPerQuery;  // 32
-
-// `forced` >= 0: host-driven pass (always runs).  forced < 0: device-driven loop — runs only when the control block
-// says the next pass searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).
-__global__ __launch_bounds__(kBlock) void k_knn8(GridView g, RegistrationBuffers rb, PoseArg ps_val,
-                                                  const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
-                                                  int forced, int nb_real) {
-  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
-  const PoseArg ps = forced < 0 ? *pose : ps_val;  // device-driven: the pose lives in the control block
-  const int blk = xcd_remap(blockIdx.x, nb_real);
-  if (blk >= nb_real) return;
-  const int sub = threadIdx.x & (kLanesPerQuery - 1);
-  const int qi = blk * kQueriesPerBlock + (threadIdx.x >> 3);
-  const bool live = qi < (rb.n_dev ? *rb.n_dev : rb.n);
-  // dead query slots still take part in the shuffles; they search nothing
-  float wx = 0, wy = 0, wz = 0;
-  if (live) {
-    float4 pb = rb.body[qi];
-    double bx = pb.x, by = pb.y, bz = pb.z;
-    double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
-    double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
-    double iz = ps.RLI[6] * bx + ps.RLI[7] * by + ps.RLI[8] * bz + ps.TLI[2];
-    wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
-    wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
-    wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
-  }
-  const float INF = __builtin_inff();
-  Knn5 k;
-  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = INF;
-  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
-  const float cs = g.cs;
-  const float eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
-  const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
-  const bool active = live && g.n_pts > 0;
-  if (active) {
-    // phase 1: the 27 cells of the 3x3x3 block, cell c -> lane c % 8.  The loads of the four cells of a lane are
-    // issued as batches (block-table probes, then cell entries, then candidates) instead of one dependent chain each.
-    int ccx[4], ccy[4], ccz[4];
-    unsigned long long bk[4];
-    unsigned int slot[4];
-    uint4 be[4];  // raw BlockEntry words: key lo, key hi, id, pad
-    const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
-    const int bb = kCellBias >> kCoarseShift;
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const int c = sub + 8 * t;
-      const bool valid = c < 27;
-      ccx[t] = cx + (valid ? (c % 3) - 1 : 0);
-      ccy[t] = cy + (valid ? ((c / 3) % 3) - 1 : 0);
-      ccz[t] = cz + (valid ? (c / 9) - 1 : 0);
-      bk[t] = pack_block((ccx[t] >> kCoarseShift) + bb, (ccy[t] >> kCoarseShift) + bb, (ccz[t] >> kCoarseShift) + bb);
-      slot[t] = hash_block((ccx[t] >> kCoarseShift) + bb, (ccy[t] >> kCoarseShift) + bb, (ccz[t] >> kCoarseShift) + bb) & g.block_mask;
-    }
-#pragma unroll
-    for (int t = 0; t < 4; t++) be[t] = tab[slot[t]];
-    int id[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      // linear probing; the table is sized for a load factor <= 1/8, so the first probe almost always decides
-      unsigned int sl = slot[t];
-      uint4 e = be[t];
-      unsigned long long ek = ((unsigned long long)e.y << 32) | e.x;
-      while (ek != bk[t] && ek != kEmptyKey) {
-        sl = (sl + 1) & g.block_mask;
-        e = tab[sl];
-        ek = ((unsigned long long)e.y << 32) | e.x;
-      }
-      id[t] = (ek == bk[t]) ? (int)e.z : -1;
-      if (sub + 8 * t >= 27) id[t] = -1;
-    }
-    uint2 rg[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const unsigned local = (((unsigned)ccz[t] & 7u) << 6) | (((unsigned)ccy[t] & 7u) << 3) | ((unsigned)ccx[t] & 7u);
-      rg[t] = id[t] >= 0 ? g.cells[(size_t)id[t] * kBlockCells + local] : make_uint2(0u, 0u);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; t++) scan_range(g, rg[t].x, rg[t].y, wx, wy, wz, k);
-  }
-  knn_group_merge<false>(k);
-  // lanes of a group can hold differently ordered lists when two candidates tie: use lane 0's
-  const int src = (threadIdx.x & 63) & ~(kLanesPerQuery - 1);
-  k.d0 = __shfl(k.d0, src); k.d1 = __shfl(k.d1, src); k.d2 = __shfl(k.d2, src); k.d3 = __shfl(k.d3, src); k.d4 = __shfl(k.d4, src);
-  k.i0 = __shfl(k.i0, src); k.i1 = __shfl(k.i1, src); k.i2 = __shfl(k.i2, src); k.i3 = __shfl(k.i3, src); k.i4 = __shfl(k.i4, src);
-  // guaranteed radius of the 3x3x3 block: cs + distance from q to the nearest face of its own cell.  Queries whose
-  // 5th-best distance exceeds it (sparse map / map frontier) are queued for k_knn_fallback.
-  float fx = wx - (float)cx * cs, fy = wy - (float)cy * cs, fz = wz - (float)cz * cs;
-  float mfrac = fmaxf(fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz)), 0.f);
-  float guard = cs + mfrac - 2.f * eps;
-  const bool need = active && !(fminf(k.d4, g.max_d2) <= guard * guard);
-  if (live) {
-    int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
-    if (sub < 5) {
-      int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : (sub == 3 ? k.i3 : k.i4)));
-      float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : (sub == 3 ? k.d3 : k.d4)));
-      float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
-      v.w = dd;
-      rb.nbr[(size_t)sub * rb.cap + qi] = v;
-    } else if (sub == 5) {
-      rb.nbr_count[qi] = found;
-    } else if (sub == 6) {
-      rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-    } else if (need) {  // sub == 7
-      unsigned int slot = atomicAdd(rb.needy_count, 1u);
-      rb.needy[slot] = qi;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Variant 3 of the search pass: eight lanes per query with box-distance pruning in two rounds.
+// The search pass: LPQ (4 by default, 8 optional) lanes per query with box-distance pruning in two rounds.
 // Round 1: the 2x2x2 block of cells nearest to the query (own cell + the neighbour on the nearer side of every axis) —
 // exactly one cell per lane — which covers the ball of radius g0 = min_axis max(f, cs - f) >= cs / 2 around the query.
 // If the merged 5th distance is within g0 the search is complete (the usual case for a converged map).
@@ -726,6 +486,9 @@ __device__ __forceinline__ void knn_group_merge_n(Knn5& k) {
   }
 }
 
+// `forced` >= 0: host-driven pass (always runs).  forced < 0: device-driven loop — runs only when the control block
+// says the next pass searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).
+// A query whose 3x3x3 block cannot prove its list complete is flagged in nbr_count (kNeedy); k_fit_reduce finishes it.
 template <int LPQ>
 __global__ __launch_bounds__(kBlock) void k_knn_pruned(GridView g, RegistrationBuffers rb, PoseArg ps_val,
                                                    const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
@@ -813,12 +576,9 @@ __global__ __launch_bounds__(kBlock) void k_knn_pruned(GridView g, RegistrationB
         v.w = dd;
         rb.nbr[(size_t)sub * rb.cap + qi] = v;
       } else if (sub == 5) {
-        rb.nbr_count[qi] = found;
+        rb.nbr_count[qi] = found | (need ? kNeedy : 0);
       } else if (sub == 6) {
         rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-      } else if (need) {
-        unsigned int slot = atomicAdd(rb.needy_count, 1u);
-        rb.needy[slot] = qi;
       }
     } else {
       {
@@ -833,12 +593,9 @@ __global__ __launch_bounds__(kBlock) void k_knn_pruned(GridView g, RegistrationB
         v.w = k.d4;
         rb.nbr[(size_t)4 * rb.cap + qi] = v;
       } else if (sub == 1) {
-        rb.nbr_count[qi] = found;
+        rb.nbr_count[qi] = found | (need ? kNeedy : 0);
       } else if (sub == 2) {
         rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-      } else if (need) {
-        unsigned int slot = atomicAdd(rb.needy_count, 1u);
-        rb.needy[slot] = qi;
       }
     }
   }
@@ -847,300 +604,71 @@ __global__ __launch_bounds__(kBlock) void k_knn_pruned(GridView g, RegistrationB
 template __global__ void k_knn_pruned<8>(GridView, RegistrationBuffers, PoseArg, const PoseArg*, const IekfCtrl*, int, int);
 template __global__ void k_knn_pruned<4>(GridView, RegistrationBuffers, PoseArg, const PoseArg*, const IekfCtrl*, int, int);
 
-// ------------------------------------------------------------------------------------------------
-// Variant 2 of the search pass (default): FOUR lanes per query, 64 queries per workgroup, so that the whole scan
-// is resident in one round of waves and far less per-query work is replicated across lanes than with eight.
-// The 3x3x3 neighbourhood is split into its 9 (dy, dz) rows of three x-adjacent cells; row r belongs to lane r % 4.
-// All lookups of a lane are issued as batches (block-table probes -> cell entries -> candidates), the top-5
-// insertion is branch-free, and the per-lane lists are merged with a 2-step wavefront-shuffle butterfly.
-__device__ __forceinline__ void knn_insert_bl(Knn5& k, float d, int j) {
-  // branch-free sorted insertion (no-op when d >= d4); strict '<' keeps the earlier candidate on ties
-  const bool c0 = d < k.d0, c1 = d < k.d1, c2 = d < k.d2, c3 = d < k.d3, c4 = d < k.d4;
-  k.d4 = c3 ? k.d3 : (c4 ? d : k.d4);
-  k.i4 = c3 ? k.i3 : (c4 ? j : k.i4);
-  k.d3 = c2 ? k.d2 : (c3 ? d : k.d3);
-  k.i3 = c2 ? k.i2 : (c3 ? j : k.i3);
-  k.d2 = c1 ? k.d1 : (c2 ? d : k.d2);
-  k.i2 = c1 ? k.i1 : (c2 ? j : k.i2);
-  k.d1 = c0 ? k.d0 : (c1 ? d : k.d1);
-  k.i1 = c0 ? k.i0 : (c1 ? j : k.i1);
-  k.d0 = c0 ? d : k.d0;
-  k.i0 = c0 ? j : k.i0;
-}
-__device__ __forceinline__ void scan_range_bl(const GridView& g, unsigned int start, unsigned int end, float qx, float qy,
-                                              float qz, Knn5& k) {
-  const float INF = __builtin_inff();
-  for (unsigned int j = start; j < end; j += 4) {
-    const unsigned int last = end - 1;
-    float4 p0 = g.pts[j];
-    float4 p1 = g.pts[min(j + 1, last)];
-    float4 p2 = g.pts[min(j + 2, last)];
-    float4 p3 = g.pts[min(j + 3, last)];
-    float d0 = dist2_ref(qx, qy, qz, p0.x, p0.y, p0.z);
-    float d1 = dist2_ref(qx, qy, qz, p1.x, p1.y, p1.z);
-    float d2 = dist2_ref(qx, qy, qz, p2.x, p2.y, p2.z);
-    float d3 = dist2_ref(qx, qy, qz, p3.x, p3.y, p3.z);
-    // candidates beyond the range or the acceptance radius are turned into +inf (never inserted)
-    d0 = (d0 <= g.max_d2) ? d0 : INF;
-    d1 = (j + 1 < end && d1 <= g.max_d2) ? d1 : INF;
-    d2 = (j + 2 < end && d2 <= g.max_d2) ? d2 : INF;
-    d3 = (j + 3 < end && d3 <= g.max_d2) ? d3 : INF;
-    if (fminf(fminf(d0, d1), fminf(d2, d3)) < k.d4) {
-      knn_insert_bl(k, d0, (int)j);
-      knn_insert_bl(k, d1, (int)(j + 1));
-      knn_insert_bl(k, d2, (int)(j + 2));
-      knn_insert_bl(k, d3, (int)(j + 3));
-    }
-  }
-}
-
-constexpr int kLanesPerQuery4 = 4;
-constexpr int kQueriesPerBlock4 = kBlock / kLanesPerQuery4;  // 64
-
-__global__ __launch_bounds__(kBlock) void k_knn4(GridView g, RegistrationBuffers rb, PoseArg ps_val,
-                                                  const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
-                                                  int forced, int nb_real) {
-  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
-  const PoseArg ps = forced < 0 ? *pose : ps_val;
-  const int blk = xcd_remap(blockIdx.x, nb_real);
-  if (blk >= nb_real) return;
-  const int sub = threadIdx.x & 3;
-  const int qi = blk * kQueriesPerBlock4 + (threadIdx.x >> 2);
-  const bool live = qi < (rb.n_dev ? *rb.n_dev : rb.n);
-  const int lane = threadIdx.x & 63, leader = lane & ~3;
-  // pointBodyToWorld on the group leader, broadcast to the other three lanes
-  float wx = 0, wy = 0, wz = 0;
-  if (live && sub == 0) {
-    float4 pb = rb.body[qi];
-    double bx = pb.x, by = pb.y, bz = pb.z;
-    double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
-    double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
-    double iz = ps.RLI[6] * bx + ps.RLI[7] * by + ps.RLI[8] * bz + ps.TLI[2];
-    wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
-    wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
-    wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
-  }
-  wx = __shfl(wx, leader); wy = __shfl(wy, leader); wz = __shfl(wz, leader);
-  const float INF = __builtin_inff();
-  Knn5 k;
-  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = INF;
-  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
+// Second stage of the search for a flagged query, run by the WHOLE 256-thread workgroup that owns the point: visits
+// every cell that intersects the ball of radius sqrt(min(d5 of stage 1, max_d2)) — looked up through the 3x3x3
+// neighbourhood of 8x8x8-cell blocks, so empty space costs nothing — and merges the per-lane lists (wave butterfly,
+// then LDS).  Thread 0 returns the final list in `k`; the call contains workgroup barriers (uniform call sites only).
+struct FallbackShared {
+  int block[27];
+  float d[4][5];
+  int i[4][5];
+};
+__device__ __forceinline__ void knn_fallback_block(const GridView& g, FallbackShared& fs, float wx, float wy, float wz,
+                                                   float d5, Knn5& k) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float bound0 = fminf(d5, g.max_d2);
   const float cs = g.cs;
   const float eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
+  const float r0 = sqrtf(bound0) + 2.f * eps;
   const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
-  const bool active = live && g.n_pts > 0;
-  if (active) {
-    const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
-    const int bb = kCellBias >> kCoarseShift;
-    // biased x coordinates of the three cells and the (at most two) blocks they fall into
-    const int ux0 = cx - 1 + kCellBias;
-    const int bxA = ux0 >> kCoarseShift, bxB = (ux0 + 2) >> kCoarseShift;
-    // rows of this lane: r = sub, sub + 4, sub + 8 (< 9)
-    int by_[3], bz_[3], lyz[3];
-    bool rv[3];
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-      const int r = sub + 4 * t;
-      rv[t] = r < 9;
-      const int rr = rv[t] ? r : 0;
-      const int uy = cy + (rr % 3) - 1 + kCellBias, uz = cz + (rr / 3) - 1 + kCellBias;
-      by_[t] = uy >> kCoarseShift;
-      bz_[t] = uz >> kCoarseShift;
-      lyz[t] = ((uz & 7) << 6) | ((uy & 7) << 3);
-    }
-    (void)bb;
-    // batch 1: first probe of every (row, block) pair
-    unsigned int slA[3], slB[3];
-    unsigned long long ekA[3], ekB[3];
-    unsigned int ezA[3], ezB[3];
-    const bool two = bxB != bxA;
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-      slA[t] = hash_block(bxA, by_[t], bz_[t]) & g.block_mask;
-      slB[t] = hash_block(bxB, by_[t], bz_[t]) & g.block_mask;
-      const uint4 a = tab[slA[t]];
-      const uint4 b = tab[two ? slB[t] : slA[t]];
-      ekA[t] = ((unsigned long long)a.y << 32) | a.x;
-      ezA[t] = a.z;
-      ekB[t] = ((unsigned long long)b.y << 32) | b.x;
-      ezB[t] = b.z;
-    }
-    int idA[3], idB[3];
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-      const unsigned long long kA = pack_block(bxA, by_[t], bz_[t]), kB = pack_block(bxB, by_[t], bz_[t]);
-      // linear probing; the table is sized for a load factor <= 1/8, so the first probe almost always decides
-      unsigned int sl = slA[t];
-      unsigned long long ek = ekA[t];
-      unsigned int ez = ezA[t];
-      while (ek != kA && ek != kEmptyKey) {
-        sl = (sl + 1) & g.block_mask;
-        const uint4 e = tab[sl];
-        ek = ((unsigned long long)e.y << 32) | e.x;
-        ez = e.z;
-      }
-      idA[t] = (rv[t] && ek == kA) ? (int)ez : -1;
-      sl = slB[t];
-      ek = ekB[t];
-      ez = ezB[t];
-      while (two && ek != kB && ek != kEmptyKey) {
-        sl = (sl + 1) & g.block_mask;
-        const uint4 e = tab[sl];
-        ek = ((unsigned long long)e.y << 32) | e.x;
-        ez = e.z;
-      }
-      idB[t] = two ? ((rv[t] && ek == kB) ? (int)ez : -1) : idA[t];
-    }
-    // batch 2: the three cell entries of every row
-    uint2 rg[3][3];
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-#pragma unroll
-      for (int x = 0; x < 3; x++) {
-        const int ux = ux0 + x;
-        const int id = ((ux >> kCoarseShift) == bxA) ? idA[t] : idB[t];
-        rg[t][x] = id >= 0 ? g.cells[(size_t)id * kBlockCells + (lyz[t] | (ux & 7))] : make_uint2(0u, 0u);
-      }
-    }
-    // batch 3: candidates.  x-adjacent cells of one block are adjacent in the sorted array: fuse touching ranges.
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-      uint2 a = rg[t][0], b = rg[t][1], c = rg[t][2];
-      if (a.y == b.x && a.y > a.x && b.y > b.x) { b.x = a.x; a.y = a.x; }
-      if (b.y == c.x && b.y > b.x && c.y > c.x) { c.x = b.x; b.y = b.x; }
-      scan_range_bl(g, a.x, a.y, wx, wy, wz, k);
-      scan_range_bl(g, b.x, b.y, wx, wy, wz, k);
-      scan_range_bl(g, c.x, c.y, wx, wy, wz, k);
-    }
+  const int X0 = cx >> kCoarseShift, Y0 = cy >> kCoarseShift, Z0 = cz >> kCoarseShift;
+  __syncthreads();  // previous query's shared data fully consumed
+  if (threadIdx.x < 27) {
+    const int c = threadIdx.x;
+    fs.block[c] = find_block(g, X0 + (c % 3) - 1, Y0 + ((c / 3) % 3) - 1, Z0 + (c / 9) - 1);
   }
-  // 2-step butterfly over the 4 lanes (disjoint cell sets -> no duplicates)
+  __syncthreads();
+  const int ix0 = cell_of(wx - r0, g.inv_cs), ix1 = cell_of(wx + r0, g.inv_cs);
+  const int iy0 = cell_of(wy - r0, g.inv_cs), iy1 = cell_of(wy + r0, g.inv_cs);
+  const int iz0 = cell_of(wz - r0, g.inv_cs), iz1 = cell_of(wz + r0, g.inv_cs);
+  const int nx = ix1 - ix0 + 1, ny = iy1 - iy0 + 1, nz = iz1 - iz0 + 1;
+  const int total = nx * ny * nz;
+  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = __builtin_inff();
+  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
+  for (int c = threadIdx.x; c < total; c += kBlock) {
+    const int ixx = ix0 + c % nx, iyy = iy0 + (c / nx) % ny, izz = iz0 + c / (nx * ny);
+    const int X = (ixx >> kCoarseShift) - X0 + 1, Y = (iyy >> kCoarseShift) - Y0 + 1, Z = (izz >> kCoarseShift) - Z0 + 1;
+    if ((unsigned)X > 2u || (unsigned)Y > 2u || (unsigned)Z > 2u) continue;  // farther than 8 cells >= sqrt(max_d2)
+    const int id = fs.block[Z * 9 + Y * 3 + X];
+    if (id < 0) continue;
+    const float gx = axis_gap(wx, ixx, cs, eps), gy = axis_gap(wy, iyy, cs, eps), gz = axis_gap(wz, izz, cs, eps);
+    if (gx * gx + gy * gy + gz * gz > bound0) continue;
+    const unsigned local = (((unsigned)izz & 7u) << 6) | (((unsigned)iyy & 7u) << 3) | ((unsigned)ixx & 7u);
+    const uint2 rr = g.cells[(size_t)id * kBlockCells + local];
+    scan_range(g, rr.x, rr.y, wx, wy, wz, k);
+  }
+  // wave butterfly (disjoint cell sets -> no duplicates), then the 4 wave results through LDS
 #pragma unroll
-  for (int off = 1; off < 4; off <<= 1) {
+  for (int off = 1; off < 64; off <<= 1) {
     float e0 = __shfl_xor(k.d0, off), e1 = __shfl_xor(k.d1, off), e2 = __shfl_xor(k.d2, off), e3 = __shfl_xor(k.d3, off),
           e4 = __shfl_xor(k.d4, off);
     int j0 = __shfl_xor(k.i0, off), j1 = __shfl_xor(k.i1, off), j2 = __shfl_xor(k.i2, off), j3 = __shfl_xor(k.i3, off),
         j4 = __shfl_xor(k.i4, off);
-    knn_insert_bl(k, e0, j0);
-    knn_insert_bl(k, e1, j1);
-    knn_insert_bl(k, e2, j2);
-    knn_insert_bl(k, e3, j3);
-    knn_insert_bl(k, e4, j4);
+    if (j0 >= 0) knn_merge_one<false>(k, e0, j0);
+    if (j1 >= 0) knn_merge_one<false>(k, e1, j1);
+    if (j2 >= 0) knn_merge_one<false>(k, e2, j2);
+    if (j3 >= 0) knn_merge_one<false>(k, e3, j3);
+    if (j4 >= 0) knn_merge_one<false>(k, e4, j4);
   }
-  // lanes of a group can hold differently ordered lists when two candidates tie: use the leader's
-  k.d0 = __shfl(k.d0, leader); k.d1 = __shfl(k.d1, leader); k.d2 = __shfl(k.d2, leader); k.d3 = __shfl(k.d3, leader);
-  k.d4 = __shfl(k.d4, leader);
-  k.i0 = __shfl(k.i0, leader); k.i1 = __shfl(k.i1, leader); k.i2 = __shfl(k.i2, leader); k.i3 = __shfl(k.i3, leader);
-  k.i4 = __shfl(k.i4, leader);
-  float fx = wx - (float)cx * cs, fy = wy - (float)cy * cs, fz = wz - (float)cz * cs;
-  float mfrac = fmaxf(fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz)), 0.f);
-  float guard = cs + mfrac - 2.f * eps;
-  const bool need = active && !(fminf(k.d4, g.max_d2) <= guard * guard);
-  if (live) {
-    // lane s stores neighbours s and (for s == 0) 4; lane 1 the count, lane 2 world, lane 3 the fallback ticket
-    const int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
-    {
-      const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : k.i3));
-      const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : k.d3));
-      float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
-      v.w = dd;
-      rb.nbr[(size_t)sub * rb.cap + qi] = v;
-    }
-    if (sub == 0) {
-      float4 v = k.i4 >= 0 ? g.pts[k.i4] : make_float4(0, 0, 0, 0);
-      v.w = k.d4;
-      rb.nbr[(size_t)4 * rb.cap + qi] = v;
-    } else if (sub == 1) {
-      rb.nbr_count[qi] = found;
-    } else if (sub == 2) {
-      rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-    } else if (need) {
-      unsigned int slot = atomicAdd(rb.needy_count, 1u);
-      rb.needy[slot] = qi;
-    }
+  if (lane == 0) {
+    fs.d[wave][0] = k.d0; fs.d[wave][1] = k.d1; fs.d[wave][2] = k.d2; fs.d[wave][3] = k.d3; fs.d[wave][4] = k.d4;
+    fs.i[wave][0] = k.i0; fs.i[wave][1] = k.i1; fs.i[wave][2] = k.i2; fs.i[wave][3] = k.i3; fs.i[wave][4] = k.i4;
   }
-}
-
-// Second stage of the search for the queued queries: ONE 256-thread workgroup per query visits every cell that
-// intersects the ball of radius sqrt(min(d5 of stage 1, max_d2)) — looked up through the 3x3x3 neighbourhood of
-// 8x8x8-cell blocks, so empty space costs nothing — and merges the per-lane lists (wave butterfly, then LDS).
-__global__ __launch_bounds__(kBlock) void k_knn_fallback(GridView g, RegistrationBuffers rb,
-                                                          const IekfCtrl* __restrict__ ctrl, int forced) {
-  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
-  __shared__ int s_block[27];
-  __shared__ float s_d[4][5];
-  __shared__ int s_i[4][5];
-  const unsigned int n_needy = *rb.needy_count;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (unsigned int e = blockIdx.x; e < n_needy; e += gridDim.x) {
-    const int qi = rb.needy[e];
-    const float4 w4 = rb.world[qi];
-    const float wx = w4.x, wy = w4.y, wz = w4.z;
-    const float d5 = rb.nbr_count[qi] == kMatch ? rb.nbr[(size_t)4 * rb.cap + qi].w : __builtin_inff();
-    const float bound0 = fminf(d5, g.max_d2);
-    const float cs = g.cs;
-    const float eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
-    const float r0 = sqrtf(bound0) + 2.f * eps;
-    const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
-    const int X0 = cx >> kCoarseShift, Y0 = cy >> kCoarseShift, Z0 = cz >> kCoarseShift;
-    __syncthreads();  // previous query's shared data fully consumed
-    if (threadIdx.x < 27) {
-      const int c = threadIdx.x;
-      s_block[c] = find_block(g, X0 + (c % 3) - 1, Y0 + ((c / 3) % 3) - 1, Z0 + (c / 9) - 1);
-    }
-    __syncthreads();
-    const int ix0 = cell_of(wx - r0, g.inv_cs), ix1 = cell_of(wx + r0, g.inv_cs);
-    const int iy0 = cell_of(wy - r0, g.inv_cs), iy1 = cell_of(wy + r0, g.inv_cs);
-    const int iz0 = cell_of(wz - r0, g.inv_cs), iz1 = cell_of(wz + r0, g.inv_cs);
-    const int nx = ix1 - ix0 + 1, ny = iy1 - iy0 + 1, nz = iz1 - iz0 + 1;
-    const int total = nx * ny * nz;
-    Knn5 k;
-    k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = __builtin_inff();
-    k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
-    for (int c = threadIdx.x; c < total; c += kBlock) {
-      const int ixx = ix0 + c % nx, iyy = iy0 + (c / nx) % ny, izz = iz0 + c / (nx * ny);
-      const int X = (ixx >> kCoarseShift) - X0 + 1, Y = (iyy >> kCoarseShift) - Y0 + 1, Z = (izz >> kCoarseShift) - Z0 + 1;
-      if ((unsigned)X > 2u || (unsigned)Y > 2u || (unsigned)Z > 2u) continue;  // farther than 8 cells >= sqrt(max_d2)
-      const int id = s_block[Z * 9 + Y * 3 + X];
-      if (id < 0) continue;
-      const float gx = axis_gap(wx, ixx, cs, eps), gy = axis_gap(wy, iyy, cs, eps), gz = axis_gap(wz, izz, cs, eps);
-      if (gx * gx + gy * gy + gz * gz > bound0) continue;
-      const unsigned local = (((unsigned)izz & 7u) << 6) | (((unsigned)iyy & 7u) << 3) | ((unsigned)ixx & 7u);
-      const uint2 rr = g.cells[(size_t)id * kBlockCells + local];
-      scan_range(g, rr.x, rr.y, wx, wy, wz, k);
-    }
-    // wave butterfly (disjoint cell sets -> no duplicates), then the 4 wave results through LDS
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      float e0 = __shfl_xor(k.d0, off), e1 = __shfl_xor(k.d1, off), e2 = __shfl_xor(k.d2, off), e3 = __shfl_xor(k.d3, off),
-            e4 = __shfl_xor(k.d4, off);
-      int j0 = __shfl_xor(k.i0, off), j1 = __shfl_xor(k.i1, off), j2 = __shfl_xor(k.i2, off), j3 = __shfl_xor(k.i3, off),
-          j4 = __shfl_xor(k.i4, off);
-      if (j0 >= 0) knn_merge_one<false>(k, e0, j0);
-      if (j1 >= 0) knn_merge_one<false>(k, e1, j1);
-      if (j2 >= 0) knn_merge_one<false>(k, e2, j2);
-      if (j3 >= 0) knn_merge_one<false>(k, e3, j3);
-      if (j4 >= 0) knn_merge_one<false>(k, e4, j4);
-    }
-    if (lane == 0) {
-      s_d[wave][0] = k.d0; s_d[wave][1] = k.d1; s_d[wave][2] = k.d2; s_d[wave][3] = k.d3; s_d[wave][4] = k.d4;
-      s_i[wave][0] = k.i0; s_i[wave][1] = k.i1; s_i[wave][2] = k.i2; s_i[wave][3] = k.i3; s_i[wave][4] = k.i4;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int w = 1; w < 4; w++)
-        for (int j = 0; j < 5; j++)
-          if (s_i[w][j] >= 0) knn_merge_one<false>(k, s_d[w][j], s_i[w][j]);
-      const int ids[5] = {k.i0, k.i1, k.i2, k.i3, k.i4};
-      const float ds[5] = {k.d0, k.d1, k.d2, k.d3, k.d4};
-      int found = 0;
-      for (int j = 0; j < 5; j++) {
-        float4 v = ids[j] >= 0 ? g.pts[ids[j]] : make_float4(0, 0, 0, 0);
-        v.w = ds[j];
-        rb.nbr[(size_t)j * rb.cap + qi] = v;
-        found += ids[j] >= 0;
-      }
-      rb.nbr_count[qi] = found;
-    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++)
+      for (int j = 0; j < 5; j++)
+        if (fs.i[w][j] >= 0) knn_merge_one<false>(k, fs.d[w][j], fs.i[w][j]);
   }
 }
 
@@ -1161,13 +689,17 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
   return changed;
 }
 
-// Plane fit + residual + Jacobian + block reduction, one lane per point.  fit = right after a k_knn8 pass (reads
-// the 5 neighbours, caches the plane); !fit for the non-search iterations.  `forced` as in k_knn8.
-__global__ __launch_bounds__(kBlock) void k_fit_reduce(RegistrationBuffers rb, PoseArg ps_val,
+// Plane fit + residual + Jacobian + block reduction, one lane per point.  FIT = right after a search pass (finishes
+// the flagged searches of this workgroup's points, reads the 5 neighbours, caches the plane); !FIT for the
+// non-search iterations.  `forced` as in k_knn_pruned.
+__global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationBuffers rb, PoseArg ps_val,
                                                         const PoseArg* __restrict__ pose,
                                                         const IekfCtrl* __restrict__ ctrl, int forced, int imu_en,
                                                         double plane_thr, double rinv, int nb_real) {
   __shared__ ReduceShared sh;
+  __shared__ FallbackShared fs;
+  __shared__ int s_needy[kBlock];
+  __shared__ int s_nneedy;
   bool FIT;
   if (forced >= 0) {
     FIT = forced != 0;
@@ -1180,6 +712,34 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(RegistrationBuffers rb, P
   if (blk >= nb_real) return;  // uniform per block
   const int i = blk * kBlock + threadIdx.x;
   const bool live = i < (rb.n_dev ? *rb.n_dev : rb.n);
+  if (FIT) {  // uniform per workgroup
+    if (threadIdx.x == 0) s_nneedy = 0;
+    __syncthreads();
+    if (live && (rb.nbr_count[i] & kNeedy)) s_needy[atomicAdd(&s_nneedy, 1)] = threadIdx.x;
+    __syncthreads();
+    const int nn = s_nneedy;
+    for (int e = 0; e < nn; e++) {  // rare (a handful of queries per scan); any processing order gives the same lists
+      const int qi = blk * kBlock + s_needy[e];
+      const float4 w4 = rb.world[qi];
+      const int c0 = rb.nbr_count[qi] & 0xFF;
+      const float d5 = c0 == kMatch ? rb.nbr[(size_t)4 * rb.cap + qi].w : __builtin_inff();
+      Knn5 k;
+      knn_fallback_block(g, fs, w4.x, w4.y, w4.z, d5, k);
+      if (threadIdx.x == 0) {
+        const int ids[5] = {k.i0, k.i1, k.i2, k.i3, k.i4};
+        const float ds[5] = {k.d0, k.d1, k.d2, k.d3, k.d4};
+        int found = 0;
+        for (int j = 0; j < 5; j++) {
+          float4 v = ids[j] >= 0 ? g.pts[ids[j]] : make_float4(0, 0, 0, 0);
+          v.w = ds[j];
+          rb.nbr[(size_t)j * rb.cap + qi] = v;
+          found += ids[j] >= 0;
+        }
+        rb.nbr_count[qi] = found;
+      }
+    }
+    if (nn) __syncthreads();  // thread 0's lists are visible to their owners (workgroup-scope release/acquire)
+  }
   RowOut o;
 #pragma unroll
   for (int c = 0; c < 12; c++) o.h[c] = 0;
@@ -1195,7 +755,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(RegistrationBuffers rb, P
     double pa = 0, pbn = 0, pc = 0, pd = 0;
     bool candidate;
     if (FIT) {
-      float4 w4 = rb.world[i];  // written by k_knn8 with the same arithmetic
+      float4 w4 = rb.world[i];  // written by the search pass with the same arithmetic
       wx = w4.x; wy = w4.y; wz = w4.z;
       const int found = rb.nbr_count[i];
       float4 nb[5];
@@ -1227,10 +787,10 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(RegistrationBuffers rb, P
 // Deterministic final reduction of the transposed partials: out[t] = sum_b partials[t * stride + b].
 // One 64-lane workgroup per output: coalesced loads, per-lane sums over b = lane + 64 k in a fixed order, then a
 // fixed shuffle tree.  (91 independent workgroups: the partials were written by other XCDs, so every load is an
-// L2 miss; one latency instead of a dependent chain of them.)  Workgroup 0 also re-arms the fallback queue.
+// L2 miss; one latency instead of a dependent chain of them.)
 __global__ __launch_bounds__(64) void k_reduce91(const double* __restrict__ partials, int n_blocks, int stride,
-                                                  double* __restrict__ out, unsigned int* needy_count,
-                                                  const IekfCtrl* __restrict__ ctrl, int forced, const int* __restrict__ n_dev) {
+                                                  double* __restrict__ out, const IekfCtrl* __restrict__ ctrl, int forced,
+                                                  const int* __restrict__ n_dev) {
   if (forced < 0 && ctrl->stop) return;
   if (n_dev) n_blocks = max(1, (*n_dev + kBlock - 1) / kBlock);
   const int t = blockIdx.x, lane = threadIdx.x;
@@ -1238,10 +798,7 @@ __global__ __launch_bounds__(64) void k_reduce91(const double* __restrict__ part
   double acc = 0;
   for (int b = lane; b < n_blocks; b += 64) acc += row[b];
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-  if (lane == 0) {
-    out[t] = acc;
-    if (t == 0) *needy_count = 0u;
-  }
+  if (lane == 0) out[t] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1657,25 +1214,9 @@ void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks
   if (n > 0) hipLaunchKernelGGL(k_cells_fill, dim3(nblk(n, 256)), dim3(256), 0, s, keys, ranks, n, blocks, block_mask, cells);
 }
 int register_blocks(int n) { return nblk(n, kBlock); }
-void launch_register_fused(bool search, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en,
-                           double plane_thr, double rinv, hipStream_t s) {
-  int nb = nblk(rb.n, kBlock);
-  if (nb < 1) nb = 1;
-  if (search)
-    hipLaunchKernelGGL(k_register<true>, dim3(nb), dim3(kBlock), 0, s, g, rb, ps, imu_en, plane_thr, rinv);
-  else
-    hipLaunchKernelGGL(k_register<false>, dim3(nb), dim3(kBlock), 0, s, g, rb, ps, imu_en, plane_thr, rinv);
-}
-void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                 const IekfCtrl* ctrl, int forced, hipStream_t s) {
-  int nq = nblk(rb.n, kQueriesPerBlock);
-  if (nq < 1) nq = 1;
-  const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_knn8, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
-}
 void launch_knn8p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                   const IekfCtrl* ctrl, int forced, hipStream_t s) {
-  int nq = nblk(rb.n, kQueriesPerBlock);
+  int nq = nblk(rb.n, kBlock / 8);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
   hipLaunchKernelGGL(k_knn_pruned<8>, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
@@ -1687,28 +1228,18 @@ void launch_knn4p(const GridView& g, const RegistrationBuffers& rb, const PoseAr
   const int nq_pad = ((nq + 7) / 8) * 8;
   hipLaunchKernelGGL(k_knn_pruned<4>, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
 }
-void launch_knn4(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                 const IekfCtrl* ctrl, int forced, hipStream_t s) {
-  int nq = nblk(rb.n, kQueriesPerBlock4);
-  if (nq < 1) nq = 1;
-  const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_knn4, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
-}
-void launch_knn_fallback(const GridView& g, const RegistrationBuffers& rb, const IekfCtrl* ctrl, int forced, hipStream_t s) {
-  hipLaunchKernelGGL(k_knn_fallback, dim3(256), dim3(kBlock), 0, s, g, rb, ctrl, forced);
-}
-void launch_fit_reduce(const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, const IekfCtrl* ctrl,
-                       int forced, int imu_en, double plane_thr, double rinv, hipStream_t s) {
+void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                       const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s) {
   int nb = nblk(rb.n, kBlock);
   if (nb < 1) nb = 1;
   const int nb_pad = ((nb + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_fit_reduce, dim3(nb_pad), dim3(kBlock), 0, s, rb, ps, pose, ctrl, forced, imu_en, plane_thr, rinv, nb);
+  hipLaunchKernelGGL(k_fit_reduce, dim3(nb_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, imu_en, plane_thr, rinv, nb);
 }
-void launch_reduce91(const double* partials, int n_points, int stride, double* out91, unsigned int* needy_count,
-                     const IekfCtrl* ctrl, int forced, const int* n_dev, hipStream_t s) {
+void launch_reduce91(const double* partials, int n_points, int stride, double* out91, const IekfCtrl* ctrl, int forced,
+                     const int* n_dev, hipStream_t s) {
   int nb = nblk(n_points, kBlock);
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, needy_count, ctrl, forced, n_dev);
+  hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, ctrl, forced, n_dev);
 }
 __global__ void k_extent_init(unsigned long long* e) {
   e[0] = ~0ull;

@@ -19,23 +19,17 @@ void launch_table_clear(BlockEntry* blocks, unsigned int cap, hipStream_t s);
 void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks, int n, BlockEntry* blocks,
                        unsigned int block_mask, uint2* cells, hipStream_t s);
 // registration
-void launch_register_fused(bool search, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, int imu_en,
-                           double plane_thr, double rinv, hipStream_t s);
-void launch_knn8(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                 const IekfCtrl* ctrl, int forced, hipStream_t s);
 void launch_knn8p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                   const IekfCtrl* ctrl, int forced, hipStream_t s);
 void launch_knn4p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                   const IekfCtrl* ctrl, int forced, hipStream_t s);
-void launch_knn4(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                 const IekfCtrl* ctrl, int forced, hipStream_t s);
-void launch_knn_fallback(const GridView& g, const RegistrationBuffers& rb, const IekfCtrl* ctrl, int forced, hipStream_t s);
-void launch_fit_reduce(const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, const IekfCtrl* ctrl,
-                       int forced, int imu_en, double plane_thr, double rinv, hipStream_t s);
-void launch_reduce91(const double* partials, int n_points, int stride, double* out91, unsigned int* needy_count,
-                     const IekfCtrl* ctrl, int forced, const int* n_dev, hipStream_t s);
-void launch_iekf_begin(IekfCtrl* c, hipStream_t s);
-void launch_iekf_solve(IekfCtrl* c, const double* ne, hipStream_t s);
+void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                       const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s);
+void launch_reduce91(const double* partials, int n_points, int stride, double* out91, const IekfCtrl* ctrl, int forced,
+                     const int* n_dev, hipStream_t s);
+void launch_reduce_solve(const double* partials, int n_points, int stride, double* out91, unsigned int* ticket, IekfCtrl* c,
+                         IekfResult* res, const int* n_dev, hipStream_t s);
+void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s);
 int register_blocks(int n);
 // undistortion
 void launch_time_extent(const float4* pts, int n, unsigned long long* extent, hipStream_t s);

@@ -72,3 +72,52 @@ def test_lo_then_li_init_recovers_extrinsic(oracle):
     assert np.linalg.norm(np.array(res.gyro_bias[:]) - b_g) < 5e-3
     assert g_ang < 1.5 and abs(np.linalg.norm(g_est) - 9.81) < 1e-6, g_ang
     reg.close()
+
+
+def test_scan_register_equals_separate_calls(oracle):
+    """lii_scan_register (one call, one synchronisation) == undistort + voxel grid + iterated update called one by one."""
+    import lidar_imu_init_amd as lii
+    from lidar_imu_init_amd import synth
+    from conftest import make_state
+    hall, map_pts = synth.bench_world(200_000, 0.15)
+    reg = lii.Registrar(max_scan_points=40_000, max_map_points=250_000, filter_size_map=0.15)
+    reg.map_build(map_pts)
+    R = synth.rot_zyx(0.02, 0.01, -0.4)
+    p = np.array([2.0, 1.0, 0.2])
+    scan = synth.make_scan(hall, "vlp16", R, p, noise=0.02, seed=5)
+    scan[:, 3] = np.linspace(0, 100, len(scan), dtype=np.float32)
+    st_true = make_state(oracle, R, p)
+    st0 = oracle.state_boxplus(st_true, np.r_[0.002, -0.001, 0.003, 0.02, -0.01, 0.01, np.zeros(18)])
+    T = lii.pose6d_array(6)
+    s0 = lii.State(st0)
+    for k in range(6):
+        T[k, 0] = 0.02 * k
+        T[k, 4:7] = [1e-3, -2e-3, 1e-3]
+        T[k, 7:10] = [1e-2, 0, 0]
+        T[k, 10:13] = s0.pos_end
+        T[k, 13:22] = s0.rot_end.reshape(-1)
+    for imu_en in (False, True):
+        reg.scan_upload(scan)
+        reg.undistort_imu(T, s0.rot_end, s0.pos_end, s0.offset_R_L_I, s0.offset_T_L_I)
+        reg.downsample(0.1, want_count=False)
+        a = lii.State(st0)
+        rep_a = reg.iekf_update(a, lii.State(st0), max_iterations=5, imu_en=imu_en)
+        reg.scan_upload(scan)
+        b = lii.State(st0)
+        rep_b = reg.scan_register(b, lii.State(st0), imu_poses=T, leaf=0.1, max_iterations=5, imu_en=imu_en)
+        assert np.array_equal(a.pod, b.pod)
+        assert rep_a["iterations"] == rep_b["iterations"] and np.array_equal(rep_a["normal_eq"], rep_b["normal_eq"])
+        assert rep_b["effect_num"] > 1000
+    # LO mode: constant-velocity de-skew taken from the state's bias_g / vel_end slots
+    s0.bias_g[:] = [1e-3, 0, 2e-3]
+    s0.vel_end[:] = [0.05, 0, 0]
+    reg.scan_upload(scan)
+    reg.undistort_cv(s0.bias_g, s0.vel_end, s0.rot_end)
+    reg.downsample_skip()
+    a = s0.copy()
+    reg.iekf_update(a, s0, max_iterations=4, imu_en=False)
+    reg.scan_upload(scan)
+    b = s0.copy()
+    reg.scan_register(b, s0, cv=True, leaf=0.0, max_iterations=4, imu_en=False)
+    assert np.array_equal(a.pod, b.pod)
+    reg.close()
