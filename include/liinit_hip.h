@@ -130,6 +130,48 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
 int lii_downsample_skip(lii_handle h, int32_t* n_down);
 int lii_scan_download(lii_handle h, int32_t which, float* out_float4, int32_t capacity, int32_t* n);
 
+/* ---------------------------------------------------------------- ingest: driver message -> device-resident scan frames
+ * lii_ingest_pcl2  <- Preprocess::process_cut_frame_pcl2  (src/preprocess.cpp:115-335; callers laserMapping.cpp:363-372)
+ * lii_ingest_livox <- Preprocess::process_cut_frame_livox (src/preprocess.cpp:50-113;  callers laserMapping.cpp:326-336)
+ * `data` is sensor_msgs/PointCloud2::data (or the CustomPoint array) as received; the field offsets are what
+ * pcl::fromROSMsg derives from msg->fields for the point structs of src/preprocess.h:35-116 (types per lidar_type:
+ * VELO time f32 [s] / ring u16; OUSTER t u32 [ns] / ring u8; PANDAR timestamp f64 / ring u16; ROBOSENSE timestamp f64 /
+ * ring u16 / intensity u8; intensity is not carried — nothing on the path reads it).  Decode, blind / NaN / ring /
+ * point_filter_num filters, azimuth time synthesis for clouds without per-point time (:163-185), time sort and the
+ * sub-frame cut (:296-334) run on the device; the frames stay there.  frames[k].begin_time_s is the value the caller
+ * pushes to time_buffer (time_lidar / 1000), offset/count index the handle's frame buffer.
+ * Equal time stamps keep their input order (the reference's std::sort leaves that order unspecified).
+ * lii_frame_select: frame k becomes the current scan (what lidar_buffer.front() -> meas.lidar -> lii_scan_upload did). */
+enum { LII_LIDAR_AVIA = 1, LII_LIDAR_VELO = 2, LII_LIDAR_OUSTER = 3, LII_LIDAR_L515 = 4, LII_LIDAR_PANDAR = 5,
+       LII_LIDAR_ROBOSENSE = 6 }; /* LID_TYPE, include/common_lib.h:55 */
+typedef struct lii_pc2_fields {
+  int32_t point_step; /* bytes per point record */
+  int32_t x, y, z, intensity, time, ring; /* byte offsets */
+} lii_pc2_fields;
+typedef struct lii_livox_fields {
+  int32_t point_step;
+  int32_t offset_time, x, y, z, reflectivity, tag, line; /* byte offsets (livox_ros_driver/CustomPoint.msg) */
+} lii_livox_fields;
+typedef struct lii_ingest_opts {
+  uint32_t struct_size;     /* sizeof(lii_ingest_opts) */
+  int32_t lidar_type;       /* LII_LIDAR_* (preprocess/lidar_type) */
+  int32_t n_scans;          /* N_SCANS (preprocess/scan_line) */
+  int32_t point_filter_num; /* point_filter_num */
+  double blind;             /* preprocess/blind [m] */
+  double stamp_s;           /* msg->header.stamp.toSec() */
+  int32_t cut_frame_num;    /* required_frame_num (initialization/cut_frame_num), <= 64 */
+  int32_t scan_count;       /* the caller's scan_count: the first 20 (PointCloud2) / 5 (Livox) messages are not cut */
+} lii_ingest_opts;
+typedef struct lii_frame_info {
+  double begin_time_s;
+  int32_t offset, count;
+} lii_frame_info;
+int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_pc2_fields* fields, const lii_ingest_opts* opts,
+                    lii_frame_info* frames, int32_t max_frames, int32_t* n_frames);
+int lii_ingest_livox(lii_handle h, const void* points, int32_t n_points, const lii_livox_fields* fields,
+                     const lii_ingest_opts* opts, lii_frame_info* frames, int32_t max_frames, int32_t* n_frames);
+int lii_frame_select(lii_handle h, int32_t frame);
+
 /* ---------------------------------------------------------------- scan-to-map registration
  * lii_iekf_iterate: ONE pass of the per-point loop + Jacobian + normal-equation reduction at a fixed state —
  *   pointBodyToWorld :209-220, Nearest_Search :980, esti_plane :997, residual/selection :987-1011,

@@ -48,6 +48,24 @@ class lii_scan_job(C.Structure):
                 ("n_imu_poses", C.c_int32), ("leaf", C.c_float), ("opts", lii_iekf_opts)]
 
 
+class lii_pc2_fields(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("point_step", "x", "y", "z", "intensity", "time", "ring")]
+
+
+class lii_livox_fields(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("point_step", "offset_time", "x", "y", "z", "reflectivity", "tag", "line")]
+
+
+class lii_ingest_opts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("lidar_type", C.c_int32), ("n_scans", C.c_int32),
+                ("point_filter_num", C.c_int32), ("blind", C.c_double), ("stamp_s", C.c_double),
+                ("cut_frame_num", C.c_int32), ("scan_count", C.c_int32)]
+
+
+class lii_frame_info(C.Structure):
+    _fields_ = [("begin_time_s", C.c_double), ("offset", C.c_int32), ("count", C.c_int32)]
+
+
 class lii_calib_result(C.Structure):
     _fields_ = [("R_LI", C.c_double * 9), ("T_LI", C.c_double * 3), ("gyro_bias", C.c_double * 3),
                 ("acc_bias", C.c_double * 3), ("grav_L0", C.c_double * 3), ("time_lag_2", C.c_double),
@@ -76,6 +94,11 @@ _DECLS = {
     "lii_downsample": (C.c_int, [C.c_void_p, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lii_downsample_skip": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "lii_scan_download": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "lii_ingest_pcl2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(lii_pc2_fields), C.POINTER(lii_ingest_opts),
+                                  C.POINTER(lii_frame_info), C.c_int32, C.POINTER(C.c_int32)]),
+    "lii_ingest_livox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(lii_livox_fields), C.POINTER(lii_ingest_opts),
+                                   C.POINTER(lii_frame_info), C.c_int32, C.POINTER(C.c_int32)]),
+    "lii_frame_select": (C.c_int, [C.c_void_p, C.c_int32]),
     "lii_iekf_iterate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lii_iekf_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(lii_iekf_opts),
                                   C.POINTER(lii_iekf_report)]),
@@ -298,6 +321,31 @@ class Registrar:
         out = np.zeros((max(n.value, 1), 4), np.float32)
         self._check(self.L.lii_scan_download(self.h, which, _ptr(out), len(out), C.byref(n)))
         return out[:n.value]
+
+    # ------------------------------------------------------------------ ingest
+    def _ingest(self, fn, data, n_points, fields, lidar_type, n_scans, point_filter_num, blind, stamp_s, cut_frame_num,
+                scan_count):
+        raw = np.frombuffer(data, np.uint8)
+        opts = lii_ingest_opts(C.sizeof(lii_ingest_opts), lidar_type, n_scans, point_filter_num, blind, stamp_s,
+                               cut_frame_num, scan_count)
+        frames = (lii_frame_info * 64)()
+        nf = C.c_int32(0)
+        self._check(fn(self.h, _ptr(raw) if len(raw) else None, n_points, C.byref(fields), C.byref(opts), frames, 64, C.byref(nf)))
+        return [(frames[k].begin_time_s, frames[k].offset, frames[k].count) for k in range(nf.value)]
+
+    def ingest_pcl2(self, data, n_points, fields, lidar_type, n_scans, point_filter_num, blind, stamp_s, cut_frame_num=1,
+                    scan_count=1000):
+        """process_cut_frame_pcl2 on the device.  Returns [(begin_time_s, offset, count)] per sub-frame."""
+        return self._ingest(self.L.lii_ingest_pcl2, data, n_points, lii_pc2_fields(*fields), lidar_type, n_scans,
+                            point_filter_num, blind, stamp_s, cut_frame_num, scan_count)
+
+    def ingest_livox(self, data, n_points, fields, n_scans, point_filter_num, blind, stamp_s, cut_frame_num=1, scan_count=1000):
+        """process_cut_frame_livox on the device."""
+        return self._ingest(self.L.lii_ingest_livox, data, n_points, lii_livox_fields(*fields), 1, n_scans, point_filter_num,
+                            blind, stamp_s, cut_frame_num, scan_count)
+
+    def frame_select(self, k: int):
+        self._check(self.L.lii_frame_select(self.h, k))
 
     # ------------------------------------------------------------------ registration
     def iekf_iterate(self, state: State, search: bool, imu_en: bool):

@@ -92,6 +92,8 @@ struct lii_context {
   double *d_cal_imu = nullptr, *d_cal_lidar = nullptr, *d_cal_params = nullptr, *d_cal_out = nullptr;
   int n_cal = 0;
 
+  void* ingest = nullptr;  // lii_ingest.hip state (frames of the last driver message)
+
   // ---- comm
   ncclComm_t comm = nullptr;
   int n_ranks = 1, rank = 0;
@@ -402,6 +404,10 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
 
 }  // namespace
 
+int lii_internal_fail(lii_context* h, int code, const std::string& msg) { return fail(h, code, msg); }
+hipStream_t lii_internal_stream(lii_context* h) { return h->stream; }
+void** lii_internal_ingest_slot(lii_context* h) { return &h->ingest; }
+
 extern "C" {
 
 int lii_abi_version(void) { return LII_ABI_VERSION; }
@@ -551,6 +557,7 @@ int lii_destroy(lii_handle h) {
                  h->d_cal_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
+  if (h->ingest) ingest_destroy(h->ingest);
   if (h->h_stage) (void)hipHostFree(h->h_stage);
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);

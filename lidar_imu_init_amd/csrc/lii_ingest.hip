@@ -1,0 +1,426 @@
+// Ingest on the device: wire-format decode, blind / NaN / ring / decimation filters, per-point time synthesis, time sort and
+// sub-frame cutting, straight into device-resident scan frames (gfx950).  Replaces
+//   Preprocess::process_cut_frame_livox   reference src/preprocess.cpp:50-113
+//   Preprocess::process_cut_frame_pcl2    reference src/preprocess.cpp:115-335
+// for the point layouts of src/preprocess.h:35-116.  HBM-bound byte work: one pass over the raw records, one scan, one
+// stable radix sort of the kept points by time, one pass that writes the frames.  One host synchronisation per message
+// (the frame table lands in mapped host memory).
+//
+// The order of points with equal time stamps is the input order (stable sort); the reference's std::sort leaves it
+// implementation-defined (oracle/orc_ingest.hpp).
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <cstring>
+#include <math.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/liinit_hip.h"
+#include "lii_device.h"
+#include "lii_launch.h"
+
+namespace lii {
+
+namespace {
+
+constexpr int kMaxLines = 128;   // MAX_LINE_NUM, src/preprocess.cpp:114
+constexpr int kMaxFrames = 64;
+
+struct IngestTable {  // written by k_cut_plan into mapped host memory
+  int n_frames;
+  int n_kept;        // pl_surf.size()
+  int n_emitted;     // points inside frames
+  int pad;
+  int first[kMaxFrames];   // sorted index of the first point of frame c
+  int last[kMaxFrames];    // sorted index of the boundary point of frame c
+  double begin_ms[kMaxFrames];
+  double delta[kMaxFrames];  // stamp_ms - last_frame_end_time while frame c is filled
+};
+
+struct IngestCtx {
+  int cap = 0;  // raw points the buffers hold
+  size_t raw_bytes = 0;
+  uint8_t* d_raw = nullptr;
+  float4* d_pts = nullptr;       // decoded (x, y, z, curvature) per raw point
+  double* d_yaw = nullptr;       // azimuth [deg] per raw point (time synthesis)
+  uint8_t* d_ring = nullptr;
+  unsigned int *d_flag = nullptr, *d_rank = nullptr, *d_aux = nullptr, *d_aux_rank = nullptr;
+  unsigned int *d_key_a = nullptr, *d_key_b = nullptr, *d_idx_a = nullptr, *d_idx_b = nullptr;
+  float4* d_frames = nullptr;    // the emitted frames, contiguous
+  void* d_temp = nullptr;
+  size_t temp_bytes = 0;
+  IngestTable* h_table = nullptr;  // pinned + mapped
+  IngestTable table;               // host copy of the last message
+  bool have = false;
+};
+
+template <class T>
+__device__ __forceinline__ T rd(const uint8_t* p) {  // unaligned-safe field read
+  T v;
+  memcpy(&v, p, sizeof(T));
+  return v;
+}
+__device__ __forceinline__ unsigned int ford(float f) {  // order-preserving float -> uint
+  unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct Pc2Arg {
+  lii_pc2_fields f;
+  int lidar_type, n_scans, pfn;
+  double blind2, stamp_s;
+};
+
+// given_offset_time (src/preprocess.cpp:132-139, :246-253): the LAST point carries a positive time
+__device__ __forceinline__ bool pc2_given_time(const uint8_t* raw, int n, const Pc2Arg& a) {
+  if (a.lidar_type != LII_LIDAR_VELO && a.lidar_type != LII_LIDAR_ROBOSENSE) return true;
+  const uint8_t* last = raw + (size_t)(n - 1) * a.f.point_step;
+  const double tl = a.lidar_type == LII_LIDAR_VELO ? (double)rd<float>(last + a.f.time) : rd<double>(last + a.f.time);
+  return tl > 0;
+}
+
+// one thread per raw point: decode, blind / NaN test, decimation and ring filter (the per-type loops :141-294)
+__global__ void k_pc2_decode(const uint8_t* __restrict__ raw, int n, Pc2Arg a, float4* __restrict__ pts, double* __restrict__ yaw,
+                             uint8_t* __restrict__ ring_out, unsigned int* __restrict__ pass0, unsigned int* __restrict__ keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* p = raw + (size_t)i * a.f.point_step;
+  const float x = rd<float>(p + a.f.x), y = rd<float>(p + a.f.y), z = rd<float>(p + a.f.z);
+  float t;
+  int ring;
+  if (a.lidar_type == LII_LIDAR_VELO) {
+    t = (float)((double)rd<float>(p + a.f.time) * 1000.0);
+    ring = rd<uint16_t>(p + a.f.ring);
+  } else if (a.lidar_type == LII_LIDAR_OUSTER) {
+    t = (float)((double)rd<uint32_t>(p + a.f.time) / 1e6);
+    ring = rd<uint8_t>(p + a.f.ring);
+  } else if (a.lidar_type == LII_LIDAR_PANDAR) {
+    const double ts0 = rd<double>(raw + a.f.time);
+    t = (float)((rd<double>(p + a.f.time) - ts0) * 1000);
+    ring = rd<uint16_t>(p + a.f.ring);
+  } else {
+    t = (float)((rd<double>(p + a.f.time) - a.stamp_s + 0.1) * 1000.0);
+    ring = rd<uint16_t>(p + a.f.ring);
+  }
+  const float d = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));  // float arithmetic, then widened
+  const bool ok = !((double)d < a.blind2 || isnan(x) || isnan(y) || isnan(z));
+  pts[i] = make_float4(x, y, z, t);
+  ring_out[i] = (uint8_t)min(ring, 255);
+  yaw[i] = atan2((double)y, (double)x) * 57.2957;
+  pass0[i] = ok ? 1u : 0u;
+  keep[i] = (ok && (i % a.pfn == 0) && ring < a.n_scans) ? 1u : 0u;
+}
+
+// Time synthesis from the azimuth when the driver gives none (:163-185, :272-294): a sequential recurrence per ring —
+// one lane per ring walks the cloud in input order.  The ring's first surviving point only seeds the recurrence and is
+// dropped (`continue`).  Returns at once when the message carries per-point time.
+__global__ __launch_bounds__(kMaxLines) void k_pc2_ring_times(const uint8_t* __restrict__ raw, int n, Pc2Arg a,
+                                                              float4* __restrict__ pts, const double* __restrict__ yaw,
+                                                              const uint8_t* __restrict__ ring,
+                                                              const unsigned int* __restrict__ pass0,
+                                                              unsigned int* __restrict__ keep) {
+  if (n <= 0 || pc2_given_time(raw, n, a)) return;
+  const int layer = threadIdx.x;
+  const double omega_l = 3.61;
+  bool first = true;
+  double yaw_fp = 0;
+  float time_last = 0.f;
+  for (int i = 0; i < n; i++) {
+    if (ring[i] != layer || !pass0[i]) continue;
+    const double yaw_angle = yaw[i];
+    if (first) {
+      yaw_fp = yaw_angle;
+      first = false;
+      time_last = 0.f;
+      keep[i] = 0u;
+      continue;
+    }
+    float t;
+    if (yaw_angle <= yaw_fp) t = (float)((yaw_fp - yaw_angle) / omega_l);
+    else t = (float)((yaw_fp - yaw_angle + 360.0) / omega_l);
+    if (t < time_last) t = (float)((double)t + 360.0 / omega_l);
+    time_last = t;
+    pts[i].w = t;
+  }
+}
+// rings >= 128 index out of bounds in the reference's time synthesis; such points are dropped here
+__global__ void k_pc2_drop_wide_rings(const uint8_t* __restrict__ raw, int n, Pc2Arg a, const uint8_t* __restrict__ ring,
+                                      unsigned int* __restrict__ keep) {
+  if (n <= 0 || pc2_given_time(raw, n, a)) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && ring[i] >= kMaxLines) keep[i] = 0u;
+}
+
+struct LivoxArg {
+  lii_livox_fields f;
+  int n_scans, pfn;
+  double blind2;
+};
+// v_i = the tag / line test of point i >= 1 (:60-62)
+__global__ void k_livox_valid(const uint8_t* __restrict__ raw, int n, LivoxArg a, unsigned int* __restrict__ valid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* p = raw + (size_t)i * a.f.point_step;
+  const int line = rd<uint8_t>(p + a.f.line), tag = rd<uint8_t>(p + a.f.tag);
+  valid[i] = (i >= 1 && line < a.n_scans && ((tag & 0x30) == 0x10 || (tag & 0x30) == 0x00)) ? 1u : 0u;
+}
+// cnt = inclusive scan of v (valid_point_num).  A point is decoded ("populated" in pl_full) when v_i and cnt_i % pfn == 0;
+// it is kept when it is outside the blind zone and differs from pl_full[i-1], which is the previous RAW point if that one
+// was populated and the zero point otherwise (:64-81).
+__global__ void k_livox_decode(const uint8_t* __restrict__ raw, int n, LivoxArg a, const unsigned int* __restrict__ valid,
+                               const unsigned int* __restrict__ cnt, float4* __restrict__ pts, unsigned int* __restrict__ keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool k = false;
+  float4 out = make_float4(0, 0, 0, 0);
+  if (valid[i] && (cnt[i] % (unsigned)a.pfn) == 0u) {
+    const uint8_t* p = raw + (size_t)i * a.f.point_step;
+    const float x = rd<float>(p + a.f.x), y = rd<float>(p + a.f.y), z = rd<float>(p + a.f.z);
+    const float t = __fdiv_rn((float)rd<uint32_t>(p + a.f.offset_time), 1000000.f);
+    out = make_float4(x, y, z, t);
+    const float d = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+    if (!((double)d < a.blind2)) {
+      float px = 0.f, py = 0.f, pz = 0.f;
+      if (valid[i - 1] && (cnt[i - 1] % (unsigned)a.pfn) == 0u) {
+        const uint8_t* q = raw + (size_t)(i - 1) * a.f.point_step;
+        px = rd<float>(q + a.f.x); py = rd<float>(q + a.f.y); pz = rd<float>(q + a.f.z);
+      }
+      k = ((double)fabsf(__fsub_rn(x, px)) > 1e-7) || ((double)fabsf(__fsub_rn(y, py)) > 1e-7) ||
+          ((double)fabsf(__fsub_rn(z, pz)) > 1e-7);
+    }
+  }
+  pts[i] = out;
+  keep[i] = k ? 1u : 0u;
+}
+
+// kept points -> (time key, raw index) in input order
+__global__ void k_ingest_compact(const float4* __restrict__ pts, const unsigned int* __restrict__ keep,
+                                 const unsigned int* __restrict__ rank, int n, unsigned int* __restrict__ key,
+                                 unsigned int* __restrict__ idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned int kkey = 0xFFFFFFFFu, kidx = 0u;  // padding beyond the kept count sorts last
+  if (keep[i]) {
+    const unsigned int r = rank[i] - 1u;
+    key[r] = ford(pts[i].w);
+    idx[r] = (unsigned)i;
+  }
+  // slots [kept, n) are filled by the tail threads so that the sort can run over the fixed length n
+  const unsigned int kept = rank[n - 1];
+  if ((unsigned)i >= kept) { key[i] = kkey; idx[i] = kidx; }
+}
+
+// The cutting loop (:88-112 == :298-334) as a plan: boundary indices from the unsigned-arithmetic test, the
+// last_frame_end_time chain in double from the boundary points' float times.  One thread.
+__global__ void k_cut_plan(const float4* __restrict__ pts, const unsigned int* __restrict__ sorted_idx,
+                           const unsigned int* __restrict__ rank, int n, double stamp_ms, int required_cut_num,
+                           IngestTable* __restrict__ dev, IngestTable* __restrict__ host) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  IngestTable t;
+  const unsigned int size = n > 0 ? rank[n - 1] : 0u;
+  t.n_kept = (int)size;
+  t.n_frames = 0;
+  t.n_emitted = 0;
+  t.pad = 0;
+  double lfe = stamp_ms;
+  unsigned int cut_num = 0;
+  int start = 1;
+  while (t.n_frames < kMaxFrames) {
+    const int b = (int)((cut_num + 1u) * size / (unsigned)required_cut_num) - 1;
+    if (b < start || b > (int)size - 1) break;  // a boundary the running counter can never equal: cutting stops
+    const int c = t.n_frames;
+    const double delta = stamp_ms - lfe;
+    t.first[c] = start;
+    t.last[c] = b;
+    t.begin_ms[c] = lfe;
+    t.delta[c] = delta;
+    const float tb = (float)((double)pts[sorted_idx[b]].w + delta);  // the boundary point's adjusted curvature
+    lfe += (double)tb;
+    t.n_frames = c + 1;
+    t.n_emitted = b;  // points 1..b
+    cut_num++;
+    start = b + 1;
+  }
+  *dev = t;
+  *host = t;
+}
+// frame point (sorted position s in [1, n_emitted]) -> frames[s - 1] with curvature += stamp_ms - last_frame_end_time
+__global__ void k_cut_apply(const float4* __restrict__ pts, const unsigned int* __restrict__ sorted_idx,
+                            const IngestTable* __restrict__ tab, int n, float4* __restrict__ frames) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  if (s > tab->n_emitted || s >= n + 1) return;
+  int c = 0;
+  while (c + 1 < tab->n_frames && s > tab->last[c]) c++;
+  float4 p = pts[sorted_idx[s]];
+  p.w = (float)((double)p.w + tab->delta[c]);
+  frames[s - 1] = p;
+}
+
+template <class T>
+hipError_t dm(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (n ? n : 1)); }
+
+void ingest_free(IngestCtx* c) {
+  if (!c) return;
+  void* ptrs[] = {c->d_raw, c->d_pts, c->d_yaw, c->d_ring, c->d_flag, c->d_rank, c->d_aux, c->d_aux_rank, c->d_key_a, c->d_key_b,
+                  c->d_idx_a, c->d_idx_b, c->d_frames, c->d_temp};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (c->h_table) (void)hipHostFree(c->h_table);
+  delete c;
+}
+
+#define ICHK(h, expr)                                                                                         \
+  do {                                                                                                        \
+    hipError_t e_ = (expr);                                                                                   \
+    if (e_ != hipSuccess) return lii_internal_fail(h, LII_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+int ingest_reserve(lii_handle h, IngestCtx* c, int n, size_t raw_bytes) {
+  if (!c->h_table) ICHK(h, hipHostMalloc(reinterpret_cast<void**>(&c->h_table), sizeof(IngestTable), hipHostMallocMapped));
+  if (raw_bytes > c->raw_bytes) {
+    if (c->d_raw) (void)hipFree(c->d_raw);
+    c->d_raw = nullptr;
+    ICHK(h, dm(&c->d_raw, raw_bytes + 64));
+    c->raw_bytes = raw_bytes;
+  }
+  if (n > c->cap) {
+    void** ptrs[] = {(void**)&c->d_pts, (void**)&c->d_yaw, (void**)&c->d_ring, (void**)&c->d_flag, (void**)&c->d_rank, (void**)&c->d_aux,
+                     (void**)&c->d_aux_rank, (void**)&c->d_key_a, (void**)&c->d_key_b, (void**)&c->d_idx_a, (void**)&c->d_idx_b,
+                     (void**)&c->d_frames, (void**)&c->d_temp};
+    for (void** p : ptrs) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    const int cap = n + n / 4 + 1024;
+    ICHK(h, dm(&c->d_pts, cap));
+    ICHK(h, dm(&c->d_yaw, cap));
+    ICHK(h, dm(&c->d_ring, cap));
+    ICHK(h, dm(&c->d_flag, cap));
+    ICHK(h, dm(&c->d_rank, cap));
+    ICHK(h, dm(&c->d_aux, cap));
+    ICHK(h, dm(&c->d_aux_rank, cap));
+    ICHK(h, dm(&c->d_key_a, cap));
+    ICHK(h, dm(&c->d_key_b, cap));
+    ICHK(h, dm(&c->d_idx_a, cap));
+    ICHK(h, dm(&c->d_idx_b, cap));
+    ICHK(h, dm(&c->d_frames, cap));
+    c->temp_bytes = sort_temp_bytes(cap);
+    ICHK(h, hipMalloc(&c->d_temp, c->temp_bytes));
+    c->cap = cap;
+  }
+  return LII_OK;
+}
+
+IngestCtx* ctx_of(lii_handle h) {
+  void** slot = lii_internal_ingest_slot(h);
+  if (!*slot) *slot = new IngestCtx();
+  return static_cast<IngestCtx*>(*slot);
+}
+
+// shared tail: scan of the keep flags, compaction, stable sort by time, plan, apply, one synchronisation, frame table out
+int ingest_finish(lii_handle h, IngestCtx* c, int n, const lii_ingest_opts* o, int uncut_below, lii_frame_info* frames,
+                  int32_t max_frames, int32_t* n_frames) {
+  hipStream_t s = lii_internal_stream(h);
+  const int nb = (n + 255) / 256;
+  inclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_flag, c->d_rank, n, s);
+  hipLaunchKernelGGL(k_ingest_compact, dim3(nb), dim3(256), 0, s, c->d_pts, c->d_flag, c->d_rank, n, c->d_key_a, c->d_idx_a);
+  sort_pairs_u32(c->d_temp, c->temp_bytes, c->d_key_a, c->d_key_b, c->d_idx_a, c->d_idx_b, n, s);
+  int required = o->cut_frame_num;
+  if (o->scan_count < uncut_below) required = 1;
+  IngestTable* d_table = reinterpret_cast<IngestTable*>(c->d_aux);  // d_aux is free again after the Livox scan
+  hipLaunchKernelGGL(k_cut_plan, dim3(1), dim3(64), 0, s, c->d_pts, c->d_idx_b, c->d_rank, n, o->stamp_s * 1000, required, d_table,
+                     c->h_table);
+  hipLaunchKernelGGL(k_cut_apply, dim3(nb), dim3(256), 0, s, c->d_pts, c->d_idx_b, d_table, n, c->d_frames);
+  ICHK(h, hipGetLastError());
+  ICHK(h, hipStreamSynchronize(s));
+  c->table = *c->h_table;
+  c->have = true;
+  *n_frames = c->table.n_frames;
+  if (c->table.n_frames > max_frames) return lii_internal_fail(h, LII_ERR_CAPACITY, "lii_ingest: more frames than max_frames");
+  for (int k = 0; k < c->table.n_frames; k++) {
+    frames[k].begin_time_s = c->table.begin_ms[k] / double(1000);  // laserMapping.cpp:334,370
+    frames[k].offset = c->table.first[k] - 1;
+    frames[k].count = c->table.last[k] - c->table.first[k] + 1;
+  }
+  return LII_OK;
+}
+
+}  // namespace
+
+void ingest_destroy(void* slot) { ingest_free(static_cast<IngestCtx*>(slot)); }
+
+}  // namespace lii
+
+using namespace lii;
+
+extern "C" {
+
+int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_pc2_fields* f, const lii_ingest_opts* o,
+                    lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
+  if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || !frames || !n_frames || n_points < 0 || (!data && n_points > 0) ||
+      f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 1 || o->cut_frame_num > kMaxFrames)
+    return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: bad arguments");
+  if (o->lidar_type != LII_LIDAR_VELO && o->lidar_type != LII_LIDAR_OUSTER && o->lidar_type != LII_LIDAR_PANDAR &&
+      o->lidar_type != LII_LIDAR_ROBOSENSE)
+    return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: Wrong LiDAR Type (src/preprocess.cpp:290-292)");
+  *n_frames = 0;
+  IngestCtx* c = ctx_of(h);
+  c->have = false;
+  if (n_points == 0) return LII_OK;
+  const size_t bytes = (size_t)n_points * f->point_step;
+  int rc = ingest_reserve(h, c, n_points, bytes);
+  if (rc != LII_OK) return rc;
+  hipStream_t s = lii_internal_stream(h);
+  ICHK(h, hipMemcpyAsync(c->d_raw, data, bytes, hipMemcpyHostToDevice, s));
+  Pc2Arg a;
+  a.f = *f;
+  a.lidar_type = o->lidar_type;
+  a.n_scans = o->n_scans;
+  a.pfn = o->point_filter_num;
+  a.blind2 = o->blind * o->blind;
+  a.stamp_s = o->stamp_s;
+  const int nb = (n_points + 255) / 256;
+  hipLaunchKernelGGL(k_pc2_decode, dim3(nb), dim3(256), 0, s, c->d_raw, n_points, a, c->d_pts, c->d_yaw, c->d_ring, c->d_aux, c->d_flag);
+  if (o->lidar_type == LII_LIDAR_VELO || o->lidar_type == LII_LIDAR_ROBOSENSE) {
+    hipLaunchKernelGGL(k_pc2_ring_times, dim3(1), dim3(kMaxLines), 0, s, c->d_raw, n_points, a, c->d_pts, c->d_yaw, c->d_ring, c->d_aux,
+                       c->d_flag);
+    hipLaunchKernelGGL(k_pc2_drop_wide_rings, dim3(nb), dim3(256), 0, s, c->d_raw, n_points, a, c->d_ring, c->d_flag);
+  }
+  return ingest_finish(h, c, n_points, o, 20, frames, max_frames, n_frames);
+}
+
+int lii_ingest_livox(lii_handle h, const void* points, int32_t n_points, const lii_livox_fields* f, const lii_ingest_opts* o,
+                     lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
+  if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || !frames || !n_frames || n_points < 0 || (!points && n_points > 0) ||
+      f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 1 || o->cut_frame_num > kMaxFrames)
+    return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_livox: bad arguments");
+  *n_frames = 0;
+  IngestCtx* c = ctx_of(h);
+  c->have = false;
+  if (n_points == 0) return LII_OK;
+  const size_t bytes = (size_t)n_points * f->point_step;
+  int rc = ingest_reserve(h, c, n_points, bytes);
+  if (rc != LII_OK) return rc;
+  hipStream_t s = lii_internal_stream(h);
+  ICHK(h, hipMemcpyAsync(c->d_raw, points, bytes, hipMemcpyHostToDevice, s));
+  LivoxArg a;
+  a.f = *f;
+  a.n_scans = o->n_scans;
+  a.pfn = o->point_filter_num;
+  a.blind2 = o->blind * o->blind;
+  const int nb = (n_points + 255) / 256;
+  hipLaunchKernelGGL(k_livox_valid, dim3(nb), dim3(256), 0, s, c->d_raw, n_points, a, c->d_aux);
+  inclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_aux, c->d_aux_rank, n_points, s);
+  hipLaunchKernelGGL(k_livox_decode, dim3(nb), dim3(256), 0, s, c->d_raw, n_points, a, c->d_aux, c->d_aux_rank, c->d_pts, c->d_flag);
+  return ingest_finish(h, c, n_points, o, 5, frames, max_frames, n_frames);
+}
+
+int lii_frame_select(lii_handle h, int32_t frame) {
+  if (!h) return LII_ERR_INVALID;
+  IngestCtx* c = ctx_of(h);
+  if (!c->have || frame < 0 || frame >= c->table.n_frames) return lii_internal_fail(h, LII_ERR_STATE, "lii_frame_select: no such frame");
+  const int first = c->table.first[frame], cnt = c->table.last[frame] - first + 1;
+  return lii_scan_set_device(h, c->d_frames + (first - 1), cnt);
+}
+
+}  // extern "C"

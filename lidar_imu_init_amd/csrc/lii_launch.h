@@ -3,9 +3,18 @@
 #include <hip/hip_runtime_api.h>
 #include <stddef.h>
 
+#include <string>
+
 #include "lii_device.h"
 
+struct lii_context;
+// internal hooks of the handle for the translation units that live beside lii_capi.cpp (not exported in the C-ABI header)
+int lii_internal_fail(lii_context* h, int code, const std::string& msg);
+hipStream_t lii_internal_stream(lii_context* h);
+void** lii_internal_ingest_slot(lii_context* h);
+
 namespace lii {
+void ingest_destroy(void* slot);  // lii_ingest.hip
 
 struct UndistArgH { double endR[9], endp[3], RLI[9], TLI[3]; };
 struct CvArgH { double omega[3], vel[3], endR[9]; };

@@ -89,6 +89,10 @@ def lib():
         L.orc_esti_plane_batch.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_double, C.POINTER(C.c_double),
                                            C.POINTER(C.c_ubyte)]
         L.orc_sort_by_time.argtypes = [C.POINTER(C.c_float), C.c_int]
+        L.orc_ingest_pcl2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                      C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_ingest_livox.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                       C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_undistort_imu.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_double), C.c_int] + \
                                        [C.POINTER(C.c_double)] * 4
         L.orc_undistort_cv.argtypes = [C.POINTER(C.c_float), C.c_int] + [C.POINTER(C.c_double)] * 3
@@ -379,6 +383,45 @@ def voxel_grid(pts4, leaf):
     n = C.c_int(0)
     filtered = lib().orc_voxel_grid(_fp(p), len(p), C.c_float(leaf), _fp(out), C.byref(n))
     return out[:n.value].copy(), bool(filtered)
+
+
+# LID_TYPE, reference include/common_lib.h:55
+AVIA, VELO, OUSTER, L515, PANDAR, ROBOSENSE = 1, 2, 3, 4, 5, 6
+
+
+def _unflatten(nf, out, begin, offs, cnts):
+    if nf < 0:
+        raise RuntimeError(f"oracle ingest failed ({nf})")
+    return [(begin[k], out[offs[k]:offs[k] + cnts[k]].copy()) for k in range(nf)]
+
+
+def ingest_pcl2(data, n_points, fields, lidar_type, n_scans, point_filter_num, blind, stamp_s, cut_frame_num, scan_count):
+    """process_cut_frame_pcl2 (reference src/preprocess.cpp:115-335).  data: the raw bytes of PointCloud2::data;
+    fields = (point_step, off_x, off_y, off_z, off_intensity, off_time, off_ring).
+    Returns [(begin_time_ms, float32 (m,4) array of x,y,z,curvature_ms), ...] — one entry per sub-frame."""
+    raw = np.ascontiguousarray(np.frombuffer(data, np.uint8))
+    f = np.asarray(fields, np.int32)
+    out = np.zeros((max(n_points, 1), 4), np.float32)
+    cap_f = max(int(cut_frame_num), 1) + 1
+    begin, offs, cnts = np.zeros(cap_f), np.zeros(cap_f, np.int32), np.zeros(cap_f, np.int32)
+    nf = lib().orc_ingest_pcl2(raw.ctypes.data, n_points, f.ctypes.data, lidar_type, n_scans, point_filter_num, blind,
+                               stamp_s, cut_frame_num, scan_count, out.ctypes.data, len(out), begin.ctypes.data,
+                               offs.ctypes.data, cnts.ctypes.data, cap_f)
+    return _unflatten(nf, out, begin, offs, cnts)
+
+
+def ingest_livox(data, n_points, fields, n_scans, point_filter_num, blind, stamp_s, cut_frame_num, scan_count):
+    """process_cut_frame_livox (reference src/preprocess.cpp:50-113).
+    fields = (point_step, off_offset_time, off_x, off_y, off_z, off_reflectivity, off_tag, off_line)."""
+    raw = np.ascontiguousarray(np.frombuffer(data, np.uint8))
+    f = np.asarray(fields, np.int32)
+    out = np.zeros((max(n_points, 1), 4), np.float32)
+    cap_f = max(int(cut_frame_num), 1) + 1
+    begin, offs, cnts = np.zeros(cap_f), np.zeros(cap_f, np.int32), np.zeros(cap_f, np.int32)
+    nf = lib().orc_ingest_livox(raw.ctypes.data, n_points, f.ctypes.data, n_scans, point_filter_num, blind, stamp_s,
+                                cut_frame_num, scan_count, out.ctypes.data, len(out), begin.ctypes.data,
+                                offs.ctypes.data, cnts.ctypes.data, cap_f)
+    return _unflatten(nf, out, begin, offs, cnts)
 
 
 def num_procs() -> int:

@@ -9,6 +9,7 @@
 #include "orc_math.hpp"
 #include "orc_plane.hpp"
 #include "orc_scan.hpp"
+#include "orc_ingest.hpp"
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -259,6 +260,40 @@ void orc_map_incremental(void* h, const float* body4, int n, const double* state
   *n_nodown = int(b.size());
   for (size_t i = 0; i < a.size(); i++) { out_add[3 * i] = a[i].x; out_add[3 * i + 1] = a[i].y; out_add[3 * i + 2] = a[i].z; }
   for (size_t i = 0; i < b.size(); i++) { out_nodown[3 * i] = b[i].x; out_nodown[3 * i + 1] = b[i].y; out_nodown[3 * i + 2] = b[i].z; }
+}
+
+// ---- ingest (orc_ingest.hpp): frames are returned flattened; returns the number of frames or -1
+static int flatten_frames(const std::vector<orc::Frame>& fr, float* out4, int cap_pts, double* begin_ms, int* offsets, int* counts,
+                          int cap_frames) {
+  int off = 0;
+  if ((int)fr.size() > cap_frames) return -2;
+  for (size_t k = 0; k < fr.size(); k++) {
+    if (off + (int)fr[k].pts.size() > cap_pts) return -2;
+    begin_ms[k] = fr[k].begin_time_ms;
+    offsets[k] = off;
+    counts[k] = (int)fr[k].pts.size();
+    if (!fr[k].pts.empty()) std::memcpy(out4 + 4 * (size_t)off, fr[k].pts.data(), sizeof(orc::P4) * fr[k].pts.size());
+    off += (int)fr[k].pts.size();
+  }
+  return (int)fr.size();
+}
+int orc_ingest_pcl2(const unsigned char* data, int n, const int* fields7, int lidar_type, int n_scans, int point_filter_num,
+                    double blind, double stamp_s, int cut_frame_num, int scan_count, float* out4, int cap_pts,
+                    double* begin_ms, int* offsets, int* counts, int cap_frames) {
+  orc::Pc2Fields f{fields7[0], fields7[1], fields7[2], fields7[3], fields7[4], fields7[5], fields7[6]};
+  orc::IngestOpts o{lidar_type, n_scans, point_filter_num, blind, stamp_s, cut_frame_num, scan_count};
+  std::vector<orc::Frame> fr;
+  if (orc::ingest_pcl2(data, n, f, o, fr) != 0) return -1;
+  return flatten_frames(fr, out4, cap_pts, begin_ms, offsets, counts, cap_frames);
+}
+int orc_ingest_livox(const unsigned char* data, int n, const int* fields8, int n_scans, int point_filter_num, double blind,
+                     double stamp_s, int cut_frame_num, int scan_count, float* out4, int cap_pts, double* begin_ms,
+                     int* offsets, int* counts, int cap_frames) {
+  orc::LivoxFields f{fields8[0], fields8[1], fields8[2], fields8[3], fields8[4], fields8[5], fields8[6], fields8[7]};
+  orc::IngestOpts o{orc::AVIA, n_scans, point_filter_num, blind, stamp_s, cut_frame_num, scan_count};
+  std::vector<orc::Frame> fr;
+  if (orc::ingest_livox(data, n, f, o, fr) != 0) return -1;
+  return flatten_frames(fr, out4, cap_pts, begin_ms, offsets, counts, cap_frames);
 }
 
 }  // extern "C"
