@@ -424,5 +424,47 @@ def ingest_livox(data, n_points, fields, n_scans, point_filter_num, blind, stamp
     return _unflatten(nf, out, begin, offs, cnts)
 
 
+_ref_pre = None
+
+
+def ref_preprocess_lib():
+    """The UNMODIFIED reference src/preprocess.cpp built by `make -C oracle ref` (None when it was never built)."""
+    global _ref_pre
+    if _ref_pre is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libref_preprocess.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        L.ref_ingest_pcl2.argtypes = lib().orc_ingest_pcl2.argtypes
+        L.ref_ingest_livox.argtypes = lib().orc_ingest_livox.argtypes
+        _ref_pre = L
+    return _ref_pre
+
+
+def ref_ingest_pcl2(data, n_points, fields, lidar_type, n_scans, point_filter_num, blind, stamp_s, cut_frame_num, scan_count):
+    """Preprocess::process_cut_frame_pcl2 of the reference itself (same signature as ingest_pcl2)."""
+    raw = np.ascontiguousarray(np.frombuffer(data, np.uint8))
+    f = np.asarray(fields, np.int32)
+    out = np.zeros((max(n_points, 1), 4), np.float32)
+    cap_f = max(int(cut_frame_num), 1) + 1
+    begin, offs, cnts = np.zeros(cap_f), np.zeros(cap_f, np.int32), np.zeros(cap_f, np.int32)
+    nf = ref_preprocess_lib().ref_ingest_pcl2(raw.ctypes.data, n_points, f.ctypes.data, lidar_type, n_scans, point_filter_num,
+                                              blind, stamp_s, cut_frame_num, scan_count, out.ctypes.data, len(out),
+                                              begin.ctypes.data, offs.ctypes.data, cnts.ctypes.data, cap_f)
+    return _unflatten(nf, out, begin, offs, cnts)
+
+
+def ref_ingest_livox(data, n_points, fields, n_scans, point_filter_num, blind, stamp_s, cut_frame_num, scan_count):
+    raw = np.ascontiguousarray(np.frombuffer(data, np.uint8))
+    f = np.asarray(fields, np.int32)
+    out = np.zeros((max(n_points, 1), 4), np.float32)
+    cap_f = max(int(cut_frame_num), 1) + 1
+    begin, offs, cnts = np.zeros(cap_f), np.zeros(cap_f, np.int32), np.zeros(cap_f, np.int32)
+    nf = ref_preprocess_lib().ref_ingest_livox(raw.ctypes.data, n_points, f.ctypes.data, n_scans, point_filter_num, blind,
+                                               stamp_s, cut_frame_num, scan_count, out.ctypes.data, len(out),
+                                               begin.ctypes.data, offs.ctypes.data, cnts.ctypes.data, cap_f)
+    return _unflatten(nf, out, begin, offs, cnts)
+
+
 def num_procs() -> int:
     return lib().orc_num_procs()

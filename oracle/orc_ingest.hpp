@@ -16,8 +16,10 @@
 // Deviation (documented, unavoidable): the reference orders the kept points with std::sort on `curvature`
 // (src/preprocess.cpp:86,296), which is not stable — the order of points with EQUAL time stamps (e.g. the 128 returns of
 // one Ouster column) is implementation-defined there.  Here ties keep their input order (std::stable_sort).
-// PARITY UNPINNED at the level of tie order; every count, boundary and time value is independent of it except which
-// of several equal-time points sits at a sub-frame boundary.
+// PINNED: tests/test_oracle_ingest.py runs this restatement against the UNMODIFIED reference src/preprocess.cpp (built
+// out-of-tree by oracle/Makefile into oracle/_ref/libref_preprocess.so) and against tests/golden/ingest/reference_frames.npz
+// (outputs of that library, committed).  Only the tie order is unpinned; every count, boundary and time value is
+// independent of it except which of several equal-time points sits at a sub-frame boundary.
 //
 // Quirks reproduced: the cut loop and the Livox decode loop start at index 1; the boundary test is
 // `valid_num == int((cut_num + 1) * size / required) - 1` in unsigned arithmetic; the first 5 (Livox) / 20
