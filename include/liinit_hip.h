@@ -247,6 +247,12 @@ int lii_calib_solve_stage(lii_handle h, int32_t stage, lii_calib_result* inout);
  * (mean filter + interpolation :82-125, zero-phase Butterworth :260-315, cross-correlation :160-193, time compensation
  * :195-238, central differences :127-158, acc interpolation :240-258) around the three GPU-evaluated solves.
  * lii_li_init_interpolate = downsample_interpolate_IMU; lii_li_init_run = everything after it. */
+/* LI_Init::data_sufficiency_assess (include/LI_init/LI_init.cpp:506-556; caller src/laserMapping.cpp:1169-1177) without the
+ * progress bars: omg = the LiDAR angular velocity of every LO frame so far (n_frames x 3, frame order),
+ * data_accum_length = initialization/data_accum_length.  eigenvalues: of sum [w]x^T [w]x, ascending; rot_percent: the
+ * pairwise products of the scaled eigenvalues (the reference's Rot_percent up to its axis order); sufficient: all > 0.99. */
+int lii_data_sufficiency(const double* omg, int32_t n_frames, double data_accum_length, double eigenvalues[3],
+                         double rot_percent[3], int32_t* sufficient);
 int lii_li_init_interpolate(const lii_calib_state* imu_all, int32_t n_imu, const lii_calib_state* lidar, int32_t n_lidar,
                             double move_start_time, lii_calib_state* imu_out, lii_calib_state* lidar_out, int32_t* n_out);
 int lii_li_init_run(lii_handle h, const lii_calib_state* imu, const lii_calib_state* lidar, int32_t n, int32_t orig_odom_freq,

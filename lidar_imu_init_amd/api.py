@@ -108,6 +108,7 @@ _DECLS = {
     "lii_calib_set_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "lii_calib_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "lii_calib_solve_stage": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(lii_calib_result)]),
+    "lii_data_sufficiency": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "lii_li_init_interpolate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p,
                                           C.POINTER(C.c_int32)]),
     "lii_li_init_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -150,6 +151,16 @@ def _ptr(a):
     # the raw address (ctypes converts an int for a c_void_p parameter); ndarray.ctypes.data_as() is two orders of
     # magnitude slower once a large framework is loaded in the process (measured: 60 us per call next to torch)
     return a.__array_interface__["data"][0]
+
+
+def data_sufficiency(omg, data_accum_length):
+    """LI_Init::data_sufficiency_assess (host function of the library): returns (eigenvalues, rot_percent, sufficient)."""
+    w = np.ascontiguousarray(omg, np.float64).reshape(-1, 3)
+    ev, rp, ok = np.zeros(3), np.zeros(3), C.c_int32(0)
+    rc = load_library().lii_data_sufficiency(_ptr(w) if len(w) else None, len(w), float(data_accum_length), _ptr(ev), _ptr(rp), C.byref(ok))
+    if rc != 0:
+        raise LIIError(rc, "lii_data_sufficiency")
+    return ev, rp, bool(ok.value)
 
 
 class State:

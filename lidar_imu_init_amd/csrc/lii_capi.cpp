@@ -373,6 +373,16 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   HIPCHK(h, hipStreamSynchronize(s));  // the stopping iteration's solve has written h_res (mapped host memory)
   const IekfResult* hr = h->h_res;
   h->have_search = true;
+#ifdef LII_SOLVE_TRACE
+  {
+    static int cnt = 0;
+    if (++cnt % 100 == 0) {
+      fprintf(stderr, "[solve trace, 10 ns ticks]");
+      for (int k = 1; k <= 10; k++) fprintf(stderr, " %lld", hr->ts[k] - hr->ts[k - 1]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   if (hr->singular) return fail(h, LII_ERR_INVALID, "singular covariance / normal matrix in the device solve");
   if (hr->it < 0) return fail(h, LII_ERR_HIP, "device loop ended without a result");
   std::memcpy(state, hr->st, sizeof(lii_state));

@@ -88,6 +88,7 @@ struct IekfResult {
   double ne[96];  // the 91 normal-equation scalars of the last executed pass
   int it, searches, effect_num, converged, singular, pad[3];
   int search_log[16];
+  long long ts[16];  // LII_SOLVE_TRACE builds: wall_clock64 stamps of the solve phases
 };
 
 }  // namespace lii

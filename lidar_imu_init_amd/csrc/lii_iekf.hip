@@ -57,7 +57,11 @@ __device__ bool gj12(double (&col)[H]) {
       if (r == p) { colp = col[r]; mp = m[r]; col[r] = col[k]; m[r] = m[k]; }
     col[k] = colp;
     m[k] = mp;
-    const double rowk = col[k] / m[k];
+    // 1 / pivot: hardware reciprocal seed + two Newton steps (full double precision, a third of the divide's latency)
+    double inv = __builtin_amdgcn_rcp(m[k]);
+    inv = fma(fma(-m[k], inv, 1.0), inv, inv);
+    inv = fma(fma(-m[k], inv, 1.0), inv, inv);
+    const double rowk = col[k] * inv;
 #pragma unroll
     for (int r = 0; r < H; r++)
       if (r != k) col[r] -= m[r] * rowk;
@@ -103,7 +107,14 @@ __device__ void d_so3_log(const double* R, double* out) {
 // Single wavefront.  Every global input is fetched in ONE parallel batch into LDS (the control block and `ne` were
 // just written by other kernels, so each dependent global read would cost a full memory round trip), the algebra runs
 // out of LDS / registers, and the results are written back once at the end.
+#ifdef LII_SOLVE_TRACE
+#define LII_TS(k) do { if (threadIdx.x == 0) s_ts[k] = wall_clock64(); } while (0)
+#else
+#define LII_TS(k)
+#endif
 __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, IekfResult* res) {
+  __shared__ long long s_ts[16];
+  LII_TS(0);
   __shared__ double s_cov[N * N];  // prior covariance (row-major, stride 24)
   __shared__ double G[H * LDH];    // H^T R^-1 H
   __shared__ double A[H * LDH];    // I + P11 G, later M
@@ -124,6 +135,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
     for (int q = 0; q < 9; q++) s_cov[lane + 64 * q] = cov[lane + 64 * q];
   }
   __syncthreads();
+  LII_TS(1);
   const int max_it = s_int[0], it = s_int[2], search_now = s_int[3], stop = s_int[4], rematch0 = s_int[5], searches0 = s_int[7];
   if (stop) return;
   for (int t = lane; t < 78; t += 64) {
@@ -133,25 +145,20 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
     G[i * LDH + j] = s_ne[t];
     G[j * LDH + i] = s_ne[t];
   }
-  // vec = state_propagat (-) state
-  if (lane == 1) {
-    const double* A_ = s_prop;
-    const double* B_ = s_st;
+  // vec = state_propagat (-) state : the two rotation logs on two lanes (same instruction stream), the vector blocks on 18 more
+  if (lane < 2) {
+    const int o = lane * 12, so = lane * 6;  // rot_end / offset_R_L_I
     double R[9];
-    d_m3t_mul(B_, A_, R);
-    d_so3_log(R, vec);
-    d_m3t_mul(B_ + 12, A_ + 12, R);
-    d_so3_log(R, vec + 6);
-    for (int i = 0; i < 3; i++) {
-      vec[3 + i] = A_[9 + i] - B_[9 + i];
-      vec[9 + i] = A_[21 + i] - B_[21 + i];
-      vec[12 + i] = A_[24 + i] - B_[24 + i];
-      vec[15 + i] = A_[27 + i] - B_[27 + i];
-      vec[18 + i] = A_[30 + i] - B_[30 + i];
-      vec[21 + i] = A_[33 + i] - B_[33 + i];
-    }
+    d_m3t_mul(s_st + o, s_prop + o, R);
+    d_so3_log(R, vec + so);
+  } else if (lane >= 8 && lane < 26) {
+    const int q = lane - 8, blk = q / 3, i = q % 3;
+    const int sto = blk == 0 ? 9 : (blk == 1 ? 21 : (blk == 2 ? 24 : (blk == 3 ? 27 : (blk == 4 ? 30 : 33))));
+    const int vo = blk == 0 ? 3 : (blk == 1 ? 9 : (blk == 2 ? 12 : (blk == 3 ? 15 : (blk == 4 ? 18 : 21))));
+    vec[vo + i] = s_prop[sto + i] - s_st[sto + i];
   }
   __syncthreads();
+  LII_TS(2);
   // A = I + P11 G
   for (int e = lane; e < H * H; e += 64) {
     const int i = e / H, j = e % H;
@@ -161,6 +168,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
     A[i * LDH + j] = s;
   }
   __syncthreads();
+  LII_TS(3);
   // M = A^-1 : lanes 0..11 hold the columns of A, lanes 12..23 those of I
   double col[H];
 #pragma unroll
@@ -171,11 +179,13 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
     return;
   }
   __syncthreads();
+  LII_TS(4);
   if (lane >= H && lane < 2 * H) {
 #pragma unroll
     for (int r = 0; r < H; r++) A[r * LDH + (lane - H)] = col[r];  // A now holds M
   }
   __syncthreads();
+  LII_TS(5);
   // K1c[0:12] = M P11 ;  Y = P21 G
   for (int e = lane; e < H * H; e += 64) {
     const int i = e / H, j = e % H;
@@ -189,6 +199,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
     Y[i * LDH + j] = y;
   }
   __syncthreads();
+  LII_TS(6);
   // K1c[12:24] = P21 - Y (M P11)
   for (int e = lane; e < H * H; e += 64) {
     const int i = e / H, j = e % H;
@@ -198,21 +209,26 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
     K1c[(H + i) * LDH + j] = s_cov[(H + i) * N + j] - s;
   }
   __syncthreads();
+  LII_TS(7);
   // K H = K1c G ;  solution = K1c (H^T R^-1 z) + vec - (K H) vec[:12]
+  for (int e = lane; e < N * H; e += 64) {
+    const int r = e / H, cc = e % H;
+    double s2 = 0;
+#pragma unroll
+    for (int k = 0; k < H; k++) s2 += K1c[r * LDH + k] * G[k * LDH + cc];
+    s_KH[e] = s2;
+  }
+  __syncthreads();
   if (lane < N) {
     const int r = lane;
     double kz = 0;
     for (int cc = 0; cc < H; cc++) kz += K1c[r * LDH + cc] * s_ne[78 + cc];
     double khv = 0;
-    for (int cc = 0; cc < H; cc++) {
-      double s = 0;
-      for (int k = 0; k < H; k++) s += K1c[r * LDH + k] * G[k * LDH + cc];
-      s_KH[r * H + cc] = s;
-      khv += s * vec[cc];
-    }
+    for (int cc = 0; cc < H; cc++) khv += s_KH[r * H + cc] * vec[cc];
     sol[r] = kz + vec[r] - khv;
   }
   __syncthreads();
+  LII_TS(8);
   // schedule (uniform: every lane evaluates it from LDS)
   const double rn = sqrt(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
   const double tn = sqrt(sol[3] * sol[3] + sol[4] * sol[4] + sol[5] * sol[5]);
@@ -258,6 +274,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
       res->singular = 0;
     }
   }
+  LII_TS(9);
   if (do_cov) {
     // state.cov = (I - K H) cov = cov - (K H) cov[0:12, :]   (:1111-1114), all operands already in LDS
     double* covw = c->st + 36;
@@ -273,6 +290,11 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
     for (int e = lane; e < 91; e += 64) res->ne[e] = s_ne[e];
     if (lane < 16) res->search_log[lane] = (lane < it) ? c->search_log[lane] : (lane == it ? search_now : 0);
   }
+#ifdef LII_SOLVE_TRACE
+  __syncthreads();
+  LII_TS(10);
+  if (threadIdx.x < 11) res->ts[threadIdx.x] = s_ts[threadIdx.x];
+#endif
 }
 
 __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __restrict__ ne, IekfResult* res) {

@@ -151,6 +151,57 @@ void acc_interpolate(Seq& imu, const Seq& lidar) {
 
 extern "C" {
 
+// LI_Init::data_sufficiency_assess (:506-556) without its terminal UI: Hessian_rot = Jacobian_rot^T Jacobian_rot with one
+// 3x3 block [w]x per LO frame = sum (|w|^2 I - w w^T); its eigenvalues (cyclic Jacobi, symmetric 3x3) scaled by
+// data_accum_length; Rot_percent = pairwise products; sufficient iff all three exceed 0.99.  The reference's EigenSolver
+// returns the eigenvalues in no particular order and maps them to axes only for the progress bars; here they come ascending.
+int lii_data_sufficiency(const double* omg, int32_t n_frames, double data_accum_length, double eigenvalues[3],
+                         double rot_percent[3], int32_t* sufficient) {
+  if ((!omg && n_frames > 0) || n_frames < 0 || !(data_accum_length > 0) || !eigenvalues || !rot_percent || !sufficient) return LII_ERR_INVALID;
+  double Hm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int f = 0; f < n_frames; f++) {
+    const double* w = omg + 3 * (size_t)f;
+    // [w]x^T [w]x, entry by entry as the matrix product forms it
+    const double K[3][3] = {{0, -w[2], w[1]}, {w[2], 0, -w[0]}, {-w[1], w[0], 0}};
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += K[k][i] * K[k][j];
+        Hm[i][j] += s;
+      }
+  }
+  for (int sweep = 0; sweep < 60; sweep++) {
+    const double off = std::fabs(Hm[0][1]) + std::fabs(Hm[0][2]) + std::fabs(Hm[1][2]);
+    if (off < 1e-300 || off < 1e-18 * (std::fabs(Hm[0][0]) + std::fabs(Hm[1][1]) + std::fabs(Hm[2][2]))) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        if (Hm[p][q] == 0.0) continue;
+        const double theta = (Hm[q][q] - Hm[p][p]) / (2.0 * Hm[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 3; k++) {  // A <- A J
+          const double akp = Hm[k][p], akq = Hm[k][q];
+          Hm[k][p] = c * akp - sn * akq;
+          Hm[k][q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < 3; k++) {  // A <- J^T A
+          const double apk = Hm[p][k], aqk = Hm[q][k];
+          Hm[p][k] = c * apk - sn * aqk;
+          Hm[q][k] = sn * apk + c * aqk;
+        }
+      }
+  }
+  double ev[3] = {Hm[0][0], Hm[1][1], Hm[2][2]};
+  std::sort(ev, ev + 3);
+  for (int a = 0; a < 3; a++) eigenvalues[a] = ev[a];
+  const double s0 = ev[0] / data_accum_length, s1 = ev[1] / data_accum_length, s2 = ev[2] / data_accum_length;
+  rot_percent[0] = s1 * s2;
+  rot_percent[1] = s0 * s2;
+  rot_percent[2] = s0 * s1;
+  *sufficient = (rot_percent[0] > 0.99 && rot_percent[1] > 0.99 && rot_percent[2] > 0.99) ? 1 : 0;
+  return LII_OK;
+}
+
 // downsample_interpolate_IMU (:82-125).  imu_all: raw IMU states (ang_vel, linear_acc already scaled to m/s^2, timestamp);
 // lidar: LiDAR-odometry states.  Writes the interpolated IMU sequence (one per retained LiDAR state) and the retained
 // LiDAR states; returns their count through n_out (capacity = n_lidar).

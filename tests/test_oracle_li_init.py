@@ -135,3 +135,36 @@ def _resize(seq, n):
     o = LI.CalibSeq(n)
     o.t = seq.t[:n].copy()
     return o
+
+
+def test_data_sufficiency_host_function():
+    """lii_data_sufficiency (LI_Init::data_sufficiency_assess, LI_init.cpp:506-556 — host code of the library, no GPU) against
+    numpy: Hessian = sum [w]x^T [w]x, eigenvalues / data_accum_length, pairwise products > 0.99."""
+    import lidar_imu_init_amd as lii
+    from lidar_imu_init_amd.api import data_sufficiency
+    rng = np.random.default_rng(3)
+
+    def np_assess(w, L):
+        Hm = np.zeros((3, 3))
+        for v in w:
+            K = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+            Hm += K.T @ K
+        ev = np.linalg.eigvalsh(Hm)
+        s = ev / L
+        rp = np.array([s[1] * s[2], s[0] * s[2], s[0] * s[1]])
+        return ev, rp, bool(np.all(rp > 0.99))
+
+    # rotation about all three axes: sufficient once enough frames have accumulated; about two axes only: never
+    w_full = rng.normal(0, 0.5, (400, 3))
+    w_planar = w_full * np.array([1.0, 1.0, 0.0])
+    for w, L in [(w_full[:20], 10.0), (w_full, 10.0), (w_full, 300.0), (w_planar, 10.0), (np.zeros((5, 3)), 10.0), (w_full[:0], 5.0)]:
+        ev, rp, ok = data_sufficiency(w, L)
+        ev_n, rp_n, ok_n = np_assess(w, L)
+        assert np.allclose(ev, ev_n, rtol=1e-12, atol=1e-12 * max(1.0, ev_n.max()))
+        assert np.allclose(rp, rp_n, rtol=1e-11, atol=1e-12)
+        assert ok == ok_n
+    assert data_sufficiency(w_full, 10.0)[2] and not data_sufficiency(w_full[:20], 10.0)[2]
+    # one rotation axis leaves a zero eigenvalue (|w|^2 I - w w^T): never sufficient
+    assert not data_sufficiency(w_full * np.array([1.0, 0.0, 0.0]), 1.0)[2]
+    with pytest.raises(lii.LIIError):
+        data_sufficiency(w_full, 0.0)
