@@ -166,5 +166,8 @@ def test_data_sufficiency_host_function():
     assert data_sufficiency(w_full, 10.0)[2] and not data_sufficiency(w_full[:20], 10.0)[2]
     # one rotation axis leaves a zero eigenvalue (|w|^2 I - w w^T): never sufficient
     assert not data_sufficiency(w_full * np.array([1.0, 0.0, 0.0]), 1.0)[2]
-    with pytest.raises(lii.LIIError):
+    try:
         data_sufficiency(w_full, 0.0)
+        raise AssertionError("data_accum_length = 0 must be rejected")
+    except lii.LIIError as e:
+        assert e.code == -1
