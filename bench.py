@@ -191,7 +191,6 @@ def main():
         M = len(wl["map"])
         n_search = max(tm[5], 1.0)
         avg_search_ms = tm[7] / n_search      # the k-NN kernel alone (dominant kernel)
-        avg_pass_ms = tm[0] / max((args.steps + 7) // 8, 1)   # first pass of a scan: k-NN + fallback + plane-fit/reduce kernels
         # algorithmic bytes of one k-NN launch: read query 16 B + write 5 neighbours 80 B per point,
         # the map once (16 B per map point)
         alg_bytes = 96.0 * n_d + 16.0 * M
@@ -215,7 +214,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_knn_pruned<4> (exact 5-NN into the block-grid local map, 4 lanes/query, box-distance pruning)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": avg_search_ms, "alg_bytes_per_launch": alg_bytes,
-                         "launches": int(tm[5]), "avg_search_pass_ms": avg_pass_ms,
+                         "launches": int(tm[5]),
                          "peak_measured_copy": 6290.0, "frac_of_measured_copy": achieved / 6290.0},
         }
         if not args.no_cpu_baseline and args.gpus == 1:
