@@ -163,7 +163,8 @@ typedef struct lii_ingest_opts {
   int32_t scan_count;       /* the caller's scan_count: the first 20 (PointCloud2) / 5 (Livox) messages are not cut */
 } lii_ingest_opts;
 typedef struct lii_frame_info {
-  double begin_time_s;
+  double begin_time_s;   /* time_lidar / 1000 */
+  double last_offset_ms; /* curvature of the frame's last point: lidar_end_time = begin + this / 1000 (laserMapping.cpp:452-456) */
   int32_t offset, count;
 } lii_frame_info;
 int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_pc2_fields* fields, const lii_ingest_opts* opts,

@@ -63,7 +63,7 @@ class lii_ingest_opts(C.Structure):
 
 
 class lii_frame_info(C.Structure):
-    _fields_ = [("begin_time_s", C.c_double), ("offset", C.c_int32), ("count", C.c_int32)]
+    _fields_ = [("begin_time_s", C.c_double), ("last_offset_ms", C.c_double), ("offset", C.c_int32), ("count", C.c_int32)]
 
 
 class lii_calib_result(C.Structure):
@@ -342,6 +342,7 @@ class Registrar:
         frames = (lii_frame_info * 64)()
         nf = C.c_int32(0)
         self._check(fn(self.h, _ptr(raw) if len(raw) else None, n_points, C.byref(fields), C.byref(opts), frames, 64, C.byref(nf)))
+        self.frame_tail_ms = [frames[k].last_offset_ms for k in range(nf.value)]  # curvature of each frame's last point
         return [(frames[k].begin_time_s, frames[k].offset, frames[k].count) for k in range(nf.value)]
 
     def ingest_pcl2(self, data, n_points, fields, lidar_type, n_scans, point_filter_num, blind, stamp_s, cut_frame_num=1,

@@ -35,6 +35,7 @@ struct IngestTable {  // written by k_cut_plan into mapped host memory
   int last[kMaxFrames];    // sorted index of the boundary point of frame c
   double begin_ms[kMaxFrames];
   double delta[kMaxFrames];  // stamp_ms - last_frame_end_time while frame c is filled
+  double tail_ms[kMaxFrames];  // adjusted curvature of the frame's last (boundary) point
 };
 
 struct IngestCtx {
@@ -235,6 +236,7 @@ __global__ void k_cut_plan(const float4* __restrict__ pts, const unsigned int* _
     t.begin_ms[c] = lfe;
     t.delta[c] = delta;
     const float tb = (float)((double)pts[sorted_idx[b]].w + delta);  // the boundary point's adjusted curvature
+    t.tail_ms[c] = (double)tb;
     lfe += (double)tb;
     t.n_frames = c + 1;
     t.n_emitted = b;  // points 1..b
@@ -341,6 +343,7 @@ int ingest_finish(lii_handle h, IngestCtx* c, int n, const lii_ingest_opts* o, i
     frames[k].begin_time_s = c->table.begin_ms[k] / double(1000);  // laserMapping.cpp:334,370
     frames[k].offset = c->table.first[k] - 1;
     frames[k].count = c->table.last[k] - c->table.first[k] + 1;
+    frames[k].last_offset_ms = c->table.tail_ms[k];
   }
   return LII_OK;
 }

@@ -51,16 +51,20 @@ class LoOdometry:
         self.first = True
         self.t_last_beg = None
         self.lidar_states = []  # (rot_end, ang_vel, linear_vel, lidar_end_time)
+        self.positions = []     # pos_end after every update (diagnostics)
         self.reports = []
 
     def process(self, scan4: np.ndarray, t_beg: float):
         """scan4: (n,4) float32 body-frame points with per-point time offsets [ms] from t_beg."""
+        self.reg.scan_upload(scan4)
+        return self.process_current(t_beg, t_beg + float(scan4[:, 3].max()) / 1000.0)
+
+    def process_current(self, t_beg: float, t_end: float):
+        """The scan is already the handle's current scan (lii_scan_upload or lii_frame_select after a device ingest)."""
         st = self.state
         dt = 0.1 if self.t_last_beg is None else (t_beg - self.t_last_beg)  # b_first_frame_ -> 0.1 (:215-221)
         self.t_last_beg = t_beg
         cv_propagate(st, dt, self.gyr_cov, self.acc_cov)
-        t_end = t_beg + float(scan4[:, 3].max()) / 1000.0
-        self.reg.scan_upload(scan4)
         self.reg.undistort_cv(st.bias_g, st.vel_end, st.rot_end)
         self.reg.downsample(self.leaf, want_count=False)
         if self.first:
@@ -74,6 +78,7 @@ class LoOdometry:
         self.reg.map_incremental(st)
         self.reports.append(rep)
         self.lidar_states.append((st.rot_end.copy(), st.bias_g.copy(), st.vel_end.copy(), t_end))
+        self.positions.append(st.pos_end.copy())
         return rep
 
     def lidar_calib_states(self):

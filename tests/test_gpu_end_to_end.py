@@ -74,6 +74,71 @@ def test_lo_then_li_init_recovers_extrinsic(oracle):
     reg.close()
 
 
+def test_wire_messages_to_calibration(oracle):
+    """The same chain fed by DRIVER MESSAGES: 10 Hz Ouster-layout PointCloud2 messages are ingested on the device
+    (decode, blind filter, time sort, cut into 2 sub-frames), every frame goes frame_select -> CV de-skew -> voxel grid ->
+    iterated update -> map_incremental without leaving the GPU; the excitation appraisal (lii_data_sufficiency) gates
+    LI_Initialization as data_sufficiency_assess does in the reference (src/laserMapping.cpp:1169-1198)."""
+    import lidar_imu_init_amd as lii
+    from lidar_imu_init_amd import calib_state_array, synth, wire
+    from lidar_imu_init_amd.api import data_sufficiency
+    from lidar_imu_init_amd.lo_harness import LoOdometry
+
+    hall = synth.Hall(size=(24.0, 18.0, 6.0), n_boxes=8, seed=7)
+    traj = synth.Trajectory()
+    msg_period, cut = 0.1, 2
+    n_msgs = 200  # 20 s
+    R_LI = synth.rot_zyx(np.deg2rad(2.0), np.deg2rad(-1.0), np.deg2rad(-45.0))
+    T_LI = np.array([0.05, -0.03, 0.10])
+    b_g = np.array([-0.001, 0.0015, 0.0005])
+    b_a = np.array([0.004, 0.005, -0.006])
+    t_off = 0.02
+    reg = lii.Registrar(max_scan_points=40_000, max_map_points=600_000, filter_size_map=0.15)
+    lo = LoOdometry(reg, filter_size_surf=0.1, max_iteration=5)
+    f = wire.pc2_fields(wire.OUSTER)
+    sufficient_at = None
+    for k in range(n_msgs):
+        stamp = k * msg_period
+        scan = synth.make_distorted_scan(hall, "mid16k", traj, stamp, msg_period, noise=0.01, seed=3000 + k, blind=0.0)
+        raw = wire.pack_pcl2(wire.OUSTER, scan[:, :3], np.zeros(len(scan), np.int32), scan[:, 3].astype(np.float64), stamp)
+        # scan_count as the node counts it: the first 20 messages are NOT cut (src/preprocess.cpp:307-308) — a half sweep of a
+        # spinning LiDAR sees half the room, and a map seeded from one half cannot register the other
+        frames = reg.ingest_pcl2(raw, len(scan), f, wire.OUSTER, 32, 1, 0.5, stamp, cut, scan_count=k + 1)
+        assert len(frames) == (1 if k + 1 < 20 else cut)
+        for j, (t_beg, off, cnt) in enumerate(frames):
+            reg.frame_select(j)
+            lo.process_current(t_beg, t_beg + reg.frame_tail_ms[j] / 1000.0)
+        if sufficient_at is None and len(lo.lidar_states) > 0 and k % 10 == 0:
+            if data_sufficiency(np.array([s[1] for s in lo.lidar_states]), 10.0)[2]:
+                sufficient_at = k
+    assert sufficient_at is not None and sufficient_at < 150, sufficient_at  # >= 0.5 rad/s about all axes: enough data
+    ts = np.array([s[3] for s in lo.lidar_states])
+    pos_err = np.array([np.linalg.norm(s_p - traj.p(t)) for s_p, t in zip(lo.positions, ts)])
+    assert np.median(pos_err) < 0.06 and pos_err.max() < 0.2, (np.median(pos_err), pos_err.max())
+    t_imu, gyro, accel = synth.simulate_imu(traj, -0.5, n_msgs * msg_period + 0.5, 200.0, R_LI, T_LI, b_g, b_a, t_off)
+    imu_all = calib_state_array(len(t_imu))
+    imu_all[:, 9:12], imu_all[:, 18:21], imu_all[:, 21] = gyro, accel, t_imu
+    lid = lo.lidar_calib_states()
+    import ctypes as C
+    L = lii.load_library()
+    oi, ol = calib_state_array(len(lid)), calib_state_array(len(lid))
+    n = C.c_int32(0)
+    rc = L.lii_li_init_interpolate(imu_all.ctypes.data_as(C.c_void_p), len(imu_all), lid.ctypes.data_as(C.c_void_p), len(lid), 2.5,
+                                   oi.ctypes.data_as(C.c_void_p), ol.ctypes.data_as(C.c_void_p), C.byref(n))
+    assert rc == 0 and n.value > 250
+    res, lag1, total = reg.li_init_run(oi[:n.value], ol[:n.value], 10, cut)
+    R_est = np.array(res.R_LI[:]).reshape(3, 3)
+    rot_err = np.rad2deg(np.linalg.norm(oracle.log_so3(R_LI.T @ R_est)))
+    T_est = np.array(res.T_LI[:])
+    print(f"wire->calibration: rot err {rot_err:.3f} deg  T err {np.linalg.norm(T_est - T_LI) * 100:.2f} cm  lag {total * 1e3:.2f} ms "
+          f"(truth {t_off * 1e3:.1f})  sufficient after {sufficient_at} messages")
+    assert rot_err < 1.0, rot_err
+    assert np.linalg.norm(T_est - T_LI) < 0.10, T_est
+    assert abs(total - (t_off - msg_period / cut / 2)) < 0.005, total
+    assert np.linalg.norm(np.array(res.gyro_bias[:]) - b_g) < 5e-3
+    reg.close()
+
+
 def test_scan_register_equals_separate_calls(oracle):
     """lii_scan_register (one call, one synchronisation) == undistort + voxel grid + iterated update called one by one."""
     import lidar_imu_init_amd as lii
