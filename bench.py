@@ -67,6 +67,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--profile-every", type=int, default=8, help="HIP-event kernel timing on every Nth timed step (0: never)")
+    ap.add_argument("--upload", action="store_true",
+                    help="hand every scan over from HOST memory (lii_scan_upload, PCIe inside the timed region) instead of HBM")
     ap.add_argument("--separate-calls", action="store_true", help="undistort / downsample / update as three library calls")
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
@@ -106,10 +108,11 @@ def main():
     reg.map_build(wl["map"])
     reg.map_commit()
     # shard the points of each scan over the ranks (contiguous blocks of the voxel-ordered cloud)
-    dev_scans, shard_sizes = [], []
+    dev_scans, shard_sizes, host_scans = [], [], []
     for s in wl["scans"]:
         lo, hi = (len(s) * rank) // world, (len(s) * (rank + 1)) // world
         dev_scans.append(reg.device_scan(s[lo:hi]))
+        host_scans.append(np.ascontiguousarray(s[lo:hi]))
         shard_sizes.append(hi - lo)
     T = pose_table()
     eye = np.eye(3)
@@ -129,7 +132,10 @@ def main():
 
     def step(k):
         j = k % len(dev_scans)
-        reg.scan_set_device(dev_scans[j])
+        if args.upload:
+            reg.scan_upload(host_scans[j])
+        else:
+            reg.scan_set_device(dev_scans[j])
         st = states0[j].copy()
         if args.separate_calls:
             s0 = states0[j]

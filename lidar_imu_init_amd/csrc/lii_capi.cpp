@@ -66,6 +66,7 @@ struct lii_context {
   IekfResult* h_res = nullptr;  // pinned, device-mapped: written by the solve kernel of the stopping iteration
   lii_pose6d* h_poses = nullptr;  // pinned staging of the IMU pose table
   hipEvent_t ev_poses = nullptr;  // the last pose-table upload
+  hipEvent_t ev_stage = nullptr;  // the last scan upload through h_stage
   bool host_solve = false;      // LII_HOST_SOLVE=1: drive the loop from the host (A/B, reference arrangement)
   double* d_partials = nullptr;
   double* d_out91 = nullptr;
@@ -528,6 +529,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   std::memset(h->h_res, 0, sizeof(IekfResult));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_poses), sizeof(lii_pose6d) * 1024, hipHostMallocDefault));
   CK(hipEventCreateWithFlags(&h->ev_poses, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
   CK(hipMemset(h->d_counter, 0, 16));
   h->partial_stride = register_blocks(int(N)) + 8;
   CK(dmalloc(&h->d_partials, size_t(h->partial_stride) * kNormalEq));
@@ -574,6 +576,7 @@ int lii_destroy(lii_handle h) {
   if (h->h_res) (void)hipHostFree(h->h_res);
   if (h->h_poses) (void)hipHostFree(h->h_poses);
   if (h->ev_poses) (void)hipEventDestroy(h->ev_poses);
+  if (h->ev_stage) (void)hipEventDestroy(h->ev_stage);
   if (h->n_map_pinned) (void)hipHostFree(h->n_map_pinned);
   for (int i = 0; i < 4; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -600,6 +603,7 @@ namespace {
 // host xyz (stride in bytes) -> pinned float4 staging -> device buffer
 int upload_xyz(lii_handle h, const void* xyz, int n, int stride_bytes, float4* dst) {
   const char* src = static_cast<const char*>(xyz);
+  HIPCHK(h, hipEventSynchronize(h->ev_stage));  // an asynchronous scan upload may still be reading the staging buffer
   for (int i = 0; i < n; i++) {
     const float* f = reinterpret_cast<const float*>(src + size_t(i) * stride_bytes);
     h->h_stage[i] = make_float4(f[0], f[1], f[2], 0.f);
@@ -669,14 +673,19 @@ int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_
     return fail(h, LII_ERR_INVALID, "lii_scan_upload: bad arguments");
   if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_upload: n > max_scan_points");
   const char* src = static_cast<const char*>(points);
-  for (int i = 0; i < n; i++) {
-    const float* f = reinterpret_cast<const float*>(src + size_t(i) * stride_bytes);
-    float t;
-    std::memcpy(&t, src + size_t(i) * stride_bytes + time_offset_bytes, 4);
-    h->h_stage[i] = make_float4(f[0], f[1], f[2], t);
+  HIPCHK(h, hipEventSynchronize(h->ev_stage));  // the previous upload has left the staging buffer
+  if (stride_bytes == 16 && time_offset_bytes == 12) {
+    if (n > 0) std::memcpy(h->h_stage, src, sizeof(float4) * size_t(n));  // already (x, y, z, t) records
+  } else {
+    for (int i = 0; i < n; i++) {
+      const float* f = reinterpret_cast<const float*>(src + size_t(i) * stride_bytes);
+      float t;
+      std::memcpy(&t, src + size_t(i) * stride_bytes + time_offset_bytes, 4);
+      h->h_stage[i] = make_float4(f[0], f[1], f[2], t);
+    }
   }
   if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scan, h->h_stage, sizeof(float4) * size_t(n), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_stage, h->stream));
   h->n_scan = n;
   h->n_body = 0;
   h->n_body_pending = false;
