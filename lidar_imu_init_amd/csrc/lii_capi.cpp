@@ -36,7 +36,7 @@ struct lii_context {
   int* d_counts = nullptr;      // [0] add list, [1] no-downsample list, [2] alive, [3] inserted, [4] total, [5] events
   float4* d_map_unsorted = nullptr;
   float4* d_map = nullptr;
-  unsigned long long *d_keys_a = nullptr, *d_keys_b = nullptr;
+  unsigned long long *d_keys_a = nullptr, *d_keys_b = nullptr, *d_keys_c = nullptr;
   unsigned int *d_idx_a = nullptr, *d_idx_b = nullptr;
   BlockEntry* d_blocks = nullptr;   // capacity-managed (grows on demand)
   unsigned int blocks_cap = 0;      // allocated entries
@@ -170,7 +170,10 @@ PoseArg pose_of(const lii_state& s) {
 
 // Rebuilds the device k-NN index from n float4 points already in d_map_unsorted:
 // key (block | local cell) -> radix sort -> gather -> block ids by scan -> per-block cell tables + block table.
-int build_index(lii_handle h, int n) {
+// The first n_sorted points are known to be in key order already (the survivors of the previous index, compacted in
+// place): only the tail is sorted and the two runs are merged — a map update then costs a merge pass over the map
+// instead of an 8-pass radix sort of it.  The resulting order is the one a stable sort of the whole array gives.
+int build_index(lii_handle h, int n, int n_sorted = 0) {
   hipStream_t s = h->stream;
   h->n_map = n;
   h->n_blocks = 0;
@@ -178,11 +181,26 @@ int build_index(lii_handle h, int n) {
   if (n == 0) return LII_OK;
   const float inv_cs = 1.0f / h->cell_size;
   launch_map_keys(h->d_map_unsorted, n, inv_cs, h->d_keys_a, h->d_idx_a, s);
-  sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, n, s);
-  launch_map_gather(h->d_map_unsorted, h->d_idx_b, n, h->d_map, s);
+  unsigned long long* sorted_keys = h->d_keys_b;
+  const int n_new = n - n_sorted;
+  if (n_sorted <= 0) {
+    sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, n, s);
+    launch_map_gather(h->d_map_unsorted, h->d_idx_b, n, h->d_map, s);
+  } else if (n_new == 0) {
+    HIPCHK(h, hipMemcpyAsync(h->d_map, h->d_map_unsorted, sizeof(float4) * size_t(n), hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_keys_c, h->d_keys_a, sizeof(unsigned long long) * size_t(n), hipMemcpyDeviceToDevice, s));
+    sorted_keys = h->d_keys_c;
+  } else {
+    sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a + n_sorted, h->d_keys_b + n_sorted, h->d_idx_a + n_sorted,
+                   h->d_idx_b + n_sorted, n_new, s);
+    launch_map_gather(h->d_map_unsorted, h->d_idx_b + n_sorted, n_new, h->d_ins, s);  // the tail, in key order
+    merge_pairs_u64_f4(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b + n_sorted, h->d_keys_c, h->d_map_unsorted,
+                       h->d_ins, h->d_map, n_sorted, n_new, s);
+    sorted_keys = h->d_keys_c;
+  }
   unsigned int* flags = h->d_idx_a;                                   // free after the sort
   unsigned int* ranks = reinterpret_cast<unsigned int*>(h->d_keys_a);  // free after the sort
-  launch_block_flags(h->d_keys_b, n, flags, s);
+  launch_block_flags(sorted_keys, n, flags, s);
   inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, flags, ranks, n, s);
   HIPCHK(h, hipMemcpyAsync(h->h_small, ranks + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
@@ -206,7 +224,7 @@ int build_index(lii_handle h, int n) {
   h->n_blocks = int(n_blocks);
   HIPCHK(h, hipMemsetAsync(h->d_cells, 0, sizeof(uint2) * 512 * size_t(n_blocks), s));
   launch_table_clear(h->d_blocks, bcap, s);
-  launch_cells_fill(h->d_keys_b, ranks, n, h->d_blocks, h->block_mask, h->d_cells, s);
+  launch_cells_fill(sorted_keys, ranks, n, h->d_blocks, h->block_mask, h->d_cells, s);
   HIPCHK(h, hipGetLastError());
   if (h->n_map_pinned) h->n_map_pinned[0] = n;
   return LII_OK;
@@ -259,7 +277,7 @@ int map_apply(lii_handle h, const float4* list, int n_bound, const int* n_dev, b
   const int total = cnt[4];
   if (total > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "local map exceeds max_map_points");
   h->n_map_pinned[0] = total;
-  return build_index(h, total);
+  return build_index(h, total, cnt[2]);  // the cnt[2] survivors lead the array in key order
 }
 
 void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, int forced) {
@@ -490,6 +508,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_map, M));
   CK(dmalloc(&h->d_keys_a, M));
   CK(dmalloc(&h->d_keys_b, M));
+  CK(dmalloc(&h->d_keys_c, M));
   CK(dmalloc(&h->d_idx_a, M));
   CK(dmalloc(&h->d_idx_b, M));
   h->blocks_cap = 4096;
@@ -562,7 +581,7 @@ int lii_destroy(lii_handle h) {
   (void)hipSetDevice(h->device);
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
+  void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_voxel_arg, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
                  h->d_vidx_b, h->d_vflags, h->d_vranks, h->d_poses, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,

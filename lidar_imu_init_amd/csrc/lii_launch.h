@@ -74,6 +74,9 @@ void sort_pairs_u64(void* temp, size_t temp_bytes, const unsigned long long* kin
                     const unsigned int* vin, unsigned int* vout, int n, hipStream_t s);
 void sort_pairs_u32(void* temp, size_t temp_bytes, const unsigned int* kin, unsigned int* kout, const unsigned int* vin,
                     unsigned int* vout, int n, hipStream_t s);
+void merge_pairs_u64_f4(void* temp, size_t temp_bytes, const unsigned long long* k1, const unsigned long long* k2,
+                        unsigned long long* kout, const float4* v1, const float4* v2, float4* vout, int n1, int n2,
+                        hipStream_t s);
 void inclusive_scan_u32(void* temp, size_t temp_bytes, const unsigned int* in, unsigned int* out, int n, hipStream_t s);
 
 float ord_to_float(unsigned int o);
