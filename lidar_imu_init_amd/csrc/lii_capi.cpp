@@ -70,8 +70,9 @@ struct lii_context {
   bool host_solve = false;      // LII_HOST_SOLVE=1: drive the loop from the host (A/B, reference arrangement)
   double* d_partials = nullptr;
   double* d_out91 = nullptr;
-  unsigned long long* d_extent = nullptr;
-  unsigned int* d_mm = nullptr;
+  unsigned long long* d_extent = nullptr;  // 2 x {min (time|index), max time}: ping-pong accumulators
+  unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
+  int extent_sel = 0, mm_sel = 0;
   unsigned int *d_vkeys_a = nullptr, *d_vkeys_b = nullptr, *d_vidx_a = nullptr, *d_vidx_b = nullptr, *d_vflags = nullptr,
                *d_vranks = nullptr;
   double* d_poses = nullptr;
@@ -553,8 +554,14 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   h->partial_stride = register_blocks(int(N)) + 8;
   CK(dmalloc(&h->d_partials, size_t(h->partial_stride) * kNormalEq));
   CK(dmalloc(&h->d_out91, 256));  // [0,91): local sums, [128,219): all-reduced sums (sharded scans)
-  CK(dmalloc(&h->d_extent, 2));
-  CK(dmalloc(&h->d_mm, 8));
+  CK(dmalloc(&h->d_extent, 4));
+  CK(dmalloc(&h->d_mm, 16));
+  {
+    const unsigned long long e0[4] = {~0ull, 0ull, ~0ull, 0ull};
+    const unsigned int m0[16] = {~0u, ~0u, ~0u, 0, 0, 0, 0, 0, ~0u, ~0u, ~0u, 0, 0, 0, 0, 0};
+    CK(hipMemcpy(h->d_extent, e0, sizeof(e0), hipMemcpyHostToDevice));
+    CK(hipMemcpy(h->d_mm, m0, sizeof(m0), hipMemcpyHostToDevice));
+  }
   CK(dmalloc(&h->d_vkeys_a, N));
   CK(dmalloc(&h->d_vkeys_b, N));
   CK(dmalloc(&h->d_vidx_a, N));
@@ -736,8 +743,10 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
   std::memcpy(u.endp, end_p, 24);
   std::memcpy(u.RLI, R_LI, 72);
   std::memcpy(u.TLI, T_LI, 24);
-  launch_time_extent(h->d_scan, h->n_scan, h->d_extent, h->stream);
-  launch_undistort_imu(h->d_scan, h->n_scan, h->d_poses, n_poses, u, h->d_extent, h->stream);
+  unsigned long long* ext = h->d_extent + 2 * h->extent_sel;
+  h->extent_sel ^= 1;
+  launch_time_extent(h->d_scan, h->n_scan, ext, h->d_extent + 2 * h->extent_sel, h->stream);
+  launch_undistort_imu(h->d_scan, h->n_scan, h->d_poses, n_poses, u, ext, h->stream);
   HIPCHK(h, hipGetLastError());
   return LII_OK;
 }
@@ -748,8 +757,10 @@ int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], c
   std::memcpy(a.omega, omega, 24);
   std::memcpy(a.vel, vel, 24);
   std::memcpy(a.endR, end_R, 72);
-  launch_time_extent(h->d_scan, h->n_scan, h->d_extent, h->stream);
-  launch_undistort_cv(h->d_scan, h->n_scan, a, h->d_extent, h->stream);
+  unsigned long long* ext = h->d_extent + 2 * h->extent_sel;
+  h->extent_sel ^= 1;
+  launch_time_extent(h->d_scan, h->n_scan, ext, h->d_extent + 2 * h->extent_sel, h->stream);
+  launch_undistort_cv(h->d_scan, h->n_scan, a, ext, h->stream);
   HIPCHK(h, hipGetLastError());
   return LII_OK;
 }
@@ -778,13 +789,13 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
   // voxel-start flags -> scan -> centroids + count.  The size of the result stays in HBM (d_nbody); the registration
   // kernels read it there, so the host learns it only if the caller asks (n_down / filtered != NULL, or a download).
   hipStream_t s = h->stream;
-  launch_voxel_minmax(h->d_scan, n, h->d_mm, s);
-  launch_voxel_prepare(h->d_mm, leaf, h->d_voxel_arg, h->d_nbody + 1, s);
-  launch_voxel_keys(h->d_scan, n, h->d_voxel_arg, h->d_vkeys_a, h->d_vidx_a, s);
+  unsigned int* mm = h->d_mm + 8 * h->mm_sel;
+  h->mm_sel ^= 1;
+  launch_voxel_minmax(h->d_scan, n, mm, h->d_mm + 8 * h->mm_sel, s);
+  launch_voxel_keys(h->d_scan, n, mm, leaf, h->d_vkeys_a, h->d_vidx_a, h->d_nbody + 1, s);
   sort_pairs_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a, h->d_vidx_b, n, s);
-  launch_voxel_flags(h->d_vkeys_b, n, h->d_vflags, s);
-  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_vflags, h->d_vranks, n, s);
-  launch_voxel_centroid(h->d_scan, h->d_vkeys_b, h->d_vidx_b, h->d_vflags, h->d_vranks, n, h->d_body, h->d_nbody, s);
+  voxel_rank_scan(h->d_sort_temp, h->sort_temp_bytes, h->d_vkeys_b, h->d_vranks, n, s);
+  launch_voxel_centroid(h->d_scan, h->d_vkeys_b, h->d_vidx_b, h->d_vranks, n, h->d_body, h->d_nbody, s);
   HIPCHK(h, hipGetLastError());
   h->n_body = n;  // upper bound until resolved
   h->n_body_pending = true;

@@ -91,4 +91,11 @@ struct IekfResult {
   long long ts[16];  // LII_SOLVE_TRACE builds: wall_clock64 stamps of the solve phases
 };
 
+// 1 at the first point of every voxel run of the sorted voxel-grid keys (non-finite points carry the sentinel key and start
+// nothing).  Shared by the scan's input iterator (lii_sort.hip) and k_voxel_centroid.
+__device__ __forceinline__ unsigned int voxel_start_flag(const unsigned int* __restrict__ keys, int i) {
+  const unsigned int k = keys[i];
+  return (k != 0x7FFFFFFFu && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+
 }  // namespace lii

@@ -113,7 +113,9 @@ __device__ void d_so3_log(const double* R, double* out) {
 #define LII_TS(k)
 #endif
 __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, IekfResult* res) {
+#ifdef LII_SOLVE_TRACE
   __shared__ long long s_ts[16];
+#endif
   LII_TS(0);
   __shared__ double s_cov[N * N];  // prior covariance (row-major, stride 24)
   __shared__ double G[H * LDH];    // H^T R^-1 H

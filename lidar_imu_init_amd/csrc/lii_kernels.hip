@@ -810,8 +810,12 @@ __device__ __forceinline__ unsigned int f2ord(float f) {
 }
 // extent[0] = (ord(t_min) << 32) | index of the first point with that time ; extent[1] = ord(t_max)
 // grid-stride over a small grid, wave shuffle + LDS reduction, ONE pair of atomics per block
-__global__ __launch_bounds__(256) void k_time_extent(const float4* __restrict__ pts, int n, unsigned long long* __restrict__ extent) {
+__global__ __launch_bounds__(256) void k_time_extent(const float4* __restrict__ pts, int n, unsigned long long* __restrict__ extent,
+                                                     unsigned long long* __restrict__ extent_next) {
   __shared__ unsigned long long smn[4], smx[4];
+  // the accumulators ping-pong between two buffers: this launch re-arms the one the NEXT scan will reduce into (nobody reads
+  // it any more: its consumers belonged to the previous scan), which saves a separate initialisation launch per scan
+  if (blockIdx.x == 0 && threadIdx.x == 0) { extent_next[0] = ~0ull; extent_next[1] = 0ull; }
   unsigned long long mn = ~0ull, mx = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     unsigned int o = f2ord(pts[i].w);
@@ -960,8 +964,11 @@ __global__ void k_undistort_cv(float4* __restrict__ pts, int n, CvArg a, const u
 // ------------------------------------------------------------------------------------------------
 // voxel-grid down-sampling (PCL VoxelGrid restatement)
 // mm[0..2] = ord(min xyz), mm[3..5] = ord(max xyz)
-__global__ __launch_bounds__(256) void k_voxel_minmax(const float4* __restrict__ pts, int n, unsigned int* __restrict__ mm) {
-  // grid-stride over a small grid, wave shuffle + LDS reduction, ONE set of atomics per workgroup
+__global__ __launch_bounds__(256) void k_voxel_minmax(const float4* __restrict__ pts, int n, unsigned int* __restrict__ mm,
+                                                      unsigned int* __restrict__ mm_next) {
+  // grid-stride over a small grid, wave shuffle + LDS reduction, ONE set of atomics per workgroup; re-arms the ping-pong
+  // partner buffer for the next scan (see k_time_extent)
+  if (blockIdx.x == 0 && threadIdx.x < 6) mm_next[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
   __shared__ unsigned int s_lo[4][3], s_hi[4][3];
   unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -1002,10 +1009,10 @@ struct VoxelArg {
   int mul[3];
   int identity;  // PCL's int32 index-overflow guard tripped: output = input
 };
-// Derives the voxel-grid parameters from the min/max reduction ON THE DEVICE (no host round trip):
+// Derives the voxel-grid parameters from the min/max reduction ON THE DEVICE (no host round trip), in every thread of the
+// key kernel (six loads + a few flops — cheaper than a launch of its own):
 // PCL VoxelGrid::applyFilter — bounding box, (dx*dy*dz) > INT32_MAX -> "Leaf size is too small" -> identity copy.
-__global__ void k_voxel_prepare(const unsigned int* __restrict__ mm, float leaf, VoxelArg* __restrict__ out, int* __restrict__ filtered) {
-  if (threadIdx.x != 0) return;
+__device__ __forceinline__ VoxelArg voxel_prepare(const unsigned int* __restrict__ mm, float leaf) {
   VoxelArg v;
   v.inv_leaf = 1.0f / leaf;
   v.identity = 0;
@@ -1031,14 +1038,14 @@ __global__ void k_voxel_prepare(const unsigned int* __restrict__ mm, float leaf,
       v.mul[0] = 1; v.mul[1] = div_b[0]; v.mul[2] = div_b[0] * div_b[1];
     }
   }
-  *out = v;
-  *filtered = v.identity ? 0 : 1;
+  return v;
 }
-__global__ void k_voxel_keys(const float4* __restrict__ pts, int n, const VoxelArg* __restrict__ vp, unsigned int* __restrict__ keys,
-                             unsigned int* __restrict__ idx) {
+__global__ void k_voxel_keys(const float4* __restrict__ pts, int n, const unsigned int* __restrict__ mm, float leaf,
+                             unsigned int* __restrict__ keys, unsigned int* __restrict__ idx, int* __restrict__ filtered) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const VoxelArg v = *vp;
+  const VoxelArg v = voxel_prepare(mm, leaf);
+  if (i == 0) *filtered = v.identity ? 0 : 1;
   float4 p = pts[i];
   unsigned int key = 0x7FFFFFFFu;  // non-finite points sort last and are dropped
   if (v.identity) {
@@ -1052,21 +1059,14 @@ __global__ void k_voxel_keys(const float4* __restrict__ pts, int n, const VoxelA
   keys[i] = key;
   idx[i] = (unsigned)i;
 }
-__global__ void k_voxel_flags(const unsigned int* __restrict__ keys, int n, unsigned int* __restrict__ flags) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  unsigned int k = keys[i];
-  flags[i] = (k != 0x7FFFFFFFu && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
-}
 // ranks = inclusive scan of flags.  One thread per voxel start accumulates its run sequentially in input
 // order (the sort is stable), float32, then divides by the count — the same order the oracle uses.
 __global__ void k_voxel_centroid(const float4* __restrict__ pts, const unsigned int* __restrict__ keys,
-                                 const unsigned int* __restrict__ idx, const unsigned int* __restrict__ flags,
-                                 const unsigned int* __restrict__ ranks, int n, float4* __restrict__ out,
-                                 int* __restrict__ n_out) {
+                                 const unsigned int* __restrict__ idx, const unsigned int* __restrict__ ranks, int n,
+                                 float4* __restrict__ out, int* __restrict__ n_out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == n - 1) *n_out = (int)ranks[n - 1];  // number of occupied voxels = size of the down-sampled cloud
-  if (i >= n || !flags[i]) return;
+  if (i >= n || !voxel_start_flag(keys, i)) return;
   unsigned int k = keys[i];
   float sx = 0, sy = 0, sz = 0, st = 0;
   int j = i;
@@ -1087,7 +1087,6 @@ __global__ void k_voxel_centroid(const float4* __restrict__ pts, const unsigned 
 //   stage 3:   r = R_LL0 R_LI^T a_I - R_LL0 b_a + R_GL0 g - a_L - R_LL0 ([w]x^2 + [alpha]x) T_IL
 //              dr/ddelta_G = -[R_GL0 g]x, dr/db_a = -R_LL0, dr/dT_IL = -R_LL0 ([w]x^2 + [alpha]x)
 // Output per block: dof*dof + dof + 1 doubles (J^T J row-major, J^T r, 0.5 sum r^2), reduced on one block.
-constexpr int kCalibMaxDof = 9;
 
 template <int STAGE>
 __global__ __launch_bounds__(256) void k_calib_eval(const double* __restrict__ imu, const double* __restrict__ lidar, int n,
@@ -1241,17 +1240,11 @@ void launch_reduce91(const double* partials, int n_points, int stride, double* o
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, ctrl, forced, n_dev);
 }
-__global__ void k_extent_init(unsigned long long* e) {
-  e[0] = ~0ull;
-  e[1] = 0ull;
-}
-void launch_time_extent(const float4* pts, int n, unsigned long long* extent, hipStream_t s) {
-  hipLaunchKernelGGL(k_extent_init, dim3(1), dim3(1), 0, s, extent);
-  if (n > 0) {
-    int nb = nblk(n, 256 * 8);
-    if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(k_time_extent, dim3(nb), dim3(256), 0, s, pts, n, extent);
-  }
+void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, hipStream_t s) {
+  int nb = nblk(n, 256 * 8);
+  if (nb > 256) nb = 256;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_time_extent, dim3(nb), dim3(256), 0, s, pts, n, extent, extent_next);
 }
 void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& uh,
                           const unsigned long long* extent, hipStream_t s) {
@@ -1266,31 +1259,19 @@ void launch_undistort_cv(float4* pts, int n, const CvArgH& ah, const unsigned lo
   memcpy(&a, &ah, sizeof(a));
   if (n > 0) hipLaunchKernelGGL(k_undistort_cv, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent);
 }
-__global__ void k_minmax_init(unsigned int* mm) {
-  if (threadIdx.x < 3) mm[threadIdx.x] = 0xFFFFFFFFu;
-  else if (threadIdx.x < 6) mm[threadIdx.x] = 0u;
+void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s) {
+  int nb = nblk(n, 256 * 4);
+  if (nb > 256) nb = 256;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_voxel_minmax, dim3(nb), dim3(256), 0, s, pts, n, mm, mm_next);
 }
-void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, hipStream_t s) {
-  hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, s, mm);
-  if (n > 0) {
-    int nb = nblk(n, 256 * 4);
-    if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(k_voxel_minmax, dim3(nb), dim3(256), 0, s, pts, n, mm);
-  }
+void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, float leaf, unsigned int* keys, unsigned int* idx,
+                       int* filtered_dev, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, leaf, keys, idx, filtered_dev);
 }
-void launch_voxel_prepare(const unsigned int* mm, float leaf, void* voxel_arg_dev, int* filtered_dev, hipStream_t s) {
-  hipLaunchKernelGGL(k_voxel_prepare, dim3(1), dim3(64), 0, s, mm, leaf, reinterpret_cast<VoxelArg*>(voxel_arg_dev), filtered_dev);
-}
-void launch_voxel_keys(const float4* pts, int n, const void* voxel_arg_dev, unsigned int* keys, unsigned int* idx, hipStream_t s) {
-  if (n > 0)
-    hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, reinterpret_cast<const VoxelArg*>(voxel_arg_dev), keys, idx);
-}
-void launch_voxel_flags(const unsigned int* keys, int n, unsigned int* flags, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_voxel_flags, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, flags);
-}
-void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const unsigned int* idx, const unsigned int* flags,
-                           const unsigned int* ranks, int n, float4* out, int* n_out, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_voxel_centroid, dim3(nblk(n, 256)), dim3(256), 0, s, pts, keys, idx, flags, ranks, n, out, n_out);
+void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const unsigned int* idx, const unsigned int* ranks, int n,
+                           float4* out, int* n_out, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_voxel_centroid, dim3(nblk(n, 256)), dim3(256), 0, s, pts, keys, idx, ranks, n, out, n_out);
 }
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s) {

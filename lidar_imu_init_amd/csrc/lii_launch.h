@@ -41,17 +41,16 @@ void launch_reduce_solve(const double* partials, int n_points, int stride, doubl
 void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s);
 int register_blocks(int n);
 // undistortion
-void launch_time_extent(const float4* pts, int n, unsigned long long* extent, hipStream_t s);
+void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, hipStream_t s);
 void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& u,
                           const unsigned long long* extent, hipStream_t s);
 void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned long long* extent, hipStream_t s);
 // voxel grid
-void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, hipStream_t s);
-void launch_voxel_prepare(const unsigned int* mm, float leaf, void* voxel_arg_dev, int* filtered_dev, hipStream_t s);
-void launch_voxel_keys(const float4* pts, int n, const void* voxel_arg_dev, unsigned int* keys, unsigned int* idx, hipStream_t s);
-void launch_voxel_flags(const unsigned int* keys, int n, unsigned int* flags, hipStream_t s);
-void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const unsigned int* idx, const unsigned int* flags,
-                           const unsigned int* ranks, int n, float4* out, int* n_out, hipStream_t s);
+void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s);
+void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, float leaf, unsigned int* keys, unsigned int* idx,
+                       int* filtered_dev, hipStream_t s);
+void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const unsigned int* idx, const unsigned int* ranks, int n,
+                           float4* out, int* n_out, hipStream_t s);
 // calibration
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s);
@@ -77,6 +76,7 @@ void sort_pairs_u32(void* temp, size_t temp_bytes, const unsigned int* kin, unsi
 void merge_pairs_u64_f4(void* temp, size_t temp_bytes, const unsigned long long* k1, const unsigned long long* k2,
                         unsigned long long* kout, const float4* v1, const float4* v2, float4* vout, int n1, int n2,
                         hipStream_t s);
+void voxel_rank_scan(void* temp, size_t temp_bytes, const unsigned int* sorted_keys, unsigned int* ranks, int n, hipStream_t s);
 void inclusive_scan_u32(void* temp, size_t temp_bytes, const unsigned int* in, unsigned int* out, int n, hipStream_t s);
 
 float ord_to_float(unsigned int o);
