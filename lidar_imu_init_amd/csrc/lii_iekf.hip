@@ -23,7 +23,8 @@ constexpr int LDH = 13;  // padded leading dimension of the 12-column LDS tiles
 // E = [I_12; 0] and P = [P11 P12; P21 P22]:
 //     K_1 = (P^-1 + E G E^T)^-1 = (I + P E G E^T)^-1 P,     I + P E G E^T = [ I + P11 G   0 ]
 //                                                                            [   P21 G     I ]
-//  => K_1[:, :12] = [ M P11 ; P21 - P21 G M P11 ],   M = (I + P11 G)^-1   (eigenvalues of P11 G are >= 0: always regular).
+//  => K_1[:, :12] = [ M P11 ; P21 - P21 G M P11 ] = P[:, :12] (I + G P11)^-1 = P[:, :12] M^T,   M = (I + P11 G)^-1
+//     (eigenvalues of P11 G are >= 0: always regular; the last form is the one evaluated — see the kernel).
 // This is the reference's formula (src/laserMapping.cpp:1081) in exact arithmetic, with ONE 12 x 12 inversion instead of
 // two 24 x 24 ones (the reference's own route loses ~cond(P) eps); the host-driven path (LII_HOST_SOLVE=1) keeps the
 // literal two-inversion form, and tests/test_gpu_register.py holds both to the oracle.
@@ -121,7 +122,6 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   __shared__ double G[H * LDH];    // H^T R^-1 H
   __shared__ double A[H * LDH];    // I + P11 G, later M
   __shared__ double K1c[N * LDH];  // K_1[:, :12]
-  __shared__ double Y[H * LDH];    // P21 G
   __shared__ double vec[N], sol[N], s_KH[N * H];
   __shared__ double s_ne[96], s_st[36], s_prop[36];
   __shared__ int s_int[12];
@@ -133,8 +133,14 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
     for (int e = lane; e < 91; e += 64) s_ne[e] = __hip_atomic_load(ne + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane < 36) { s_st[lane] = c->st[lane]; s_prop[lane] = c->prop[lane]; }
     const double* cov = c->st + 36;
+    // the prior enters as its symmetric part: K_1[:, :12] = P[:, :12] M^T below relies on P11 = P11^T, and whatever
+    // asymmetry (I - K H) P picks up from rounding must not feed back into the next scan's gain (it compounds otherwise:
+    // the pose block of P grew to 0.4 within 200 scans of a LIO run, the literal two-inversion algebra stays at 4e-5)
 #pragma unroll
-    for (int q = 0; q < 9; q++) s_cov[lane + 64 * q] = cov[lane + 64 * q];
+    for (int q = 0; q < 9; q++) {
+      const int e = lane + 64 * q, r = e / N, cc = e % N;
+      s_cov[e] = 0.5 * (cov[e] + cov[cc * N + r]);
+    }
   }
   __syncthreads();
   LII_TS(1);
@@ -188,29 +194,18 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   }
   __syncthreads();
   LII_TS(5);
-  // K1c[0:12] = M P11 ;  Y = P21 G
-  for (int e = lane; e < H * H; e += 64) {
-    const int i = e / H, j = e % H;
-    double s = 0, y = 0;
+  // K_1[:, :12] = P[:, :12] (I + G P11)^-1 = P[:, :12] M^T   (G and P11 symmetric).  One product, and no subtraction of
+  // nearly equal terms: the algebraically equal form P21 - P21 G M P11 cancels catastrophically once the pose block of P has
+  // collapsed (1e-8) next to velocity / bias blocks of order 1 — the regime of the LIO phase.
+  for (int e = lane; e < N * H; e += 64) {
+    const int r = e / H, j = e % H;
+    double s = 0;
 #pragma unroll
-    for (int k = 0; k < H; k++) {
-      s += A[i * LDH + k] * s_cov[k * N + j];
-      y += s_cov[(H + i) * N + k] * G[k * LDH + j];
-    }
-    K1c[i * LDH + j] = s;
-    Y[i * LDH + j] = y;
+    for (int k = 0; k < H; k++) s += s_cov[r * N + k] * A[j * LDH + k];
+    K1c[r * LDH + j] = s;
   }
   __syncthreads();
   LII_TS(6);
-  // K1c[12:24] = P21 - Y (M P11)
-  for (int e = lane; e < H * H; e += 64) {
-    const int i = e / H, j = e % H;
-    double s = 0;
-#pragma unroll
-    for (int k = 0; k < H; k++) s += Y[i * LDH + k] * K1c[k * LDH + j];
-    K1c[(H + i) * LDH + j] = s_cov[(H + i) * N + j] - s;
-  }
-  __syncthreads();
   LII_TS(7);
   // K H = K1c G ;  solution = K1c (H^T R^-1 z) + vec - (K H) vec[:12]
   for (int e = lane; e < N * H; e += 64) {
