@@ -107,6 +107,41 @@ def test_update_matches_oracle(reg, oracle, small_world, imu_en, max_it):
     assert np.linalg.norm(oracle.log_so3(R.T @ R_lidar)) < 0.002
 
 
+def test_update_with_lio_regime_covariance(reg, oracle, small_world):
+    """The covariance of a running LIO filter: pose block collapsed (1e-8) next to velocity / bias blocks of order 1 with
+    strong cross-correlations, and a propagated state that differs from the current one in all 24 dimensions.  This is the
+    regime where a gain evaluated as P21 - P21 G M P11 cancels catastrophically; all 24 states must follow the oracle's
+    literal two-inversion algebra."""
+    import lidar_imu_init_amd as lii
+    hall, map_pts = small_world
+    scan, R, p = _scan(small_world, "vlp16", seed=21)
+    st_true = make_state(oracle, R, p)
+    rng = np.random.default_rng(5)
+    scale = np.sqrt(np.r_[np.full(6, 1e-8), np.full(6, 1e-4), np.full(3, 1.0), np.full(3, 1e-3), np.full(3, 1e-2), np.full(3, 1e-5)])
+    A = rng.normal(0, 1, (24, 24))
+    C = A @ A.T / 24 + np.eye(24)
+    C = C / np.sqrt(np.outer(np.diag(C), np.diag(C)))          # a correlation matrix with off-diagonals up to ~0.4
+    P = C * np.outer(scale, scale)
+    for imu_en in (True, False):
+        prop = lii.State(oracle.state_boxplus(st_true, np.r_[2e-4, -1e-4, 2e-4, 2e-3, -1e-3, 1e-3, np.zeros(18)]))
+        prop.cov[:] = P
+        cur = lii.State(oracle.state_boxplus(prop.pod, np.r_[rng.normal(0, 1e-4, 6), rng.normal(0, 1e-3, 6), rng.normal(0, 1e-2, 12)]))
+        tree = oracle.Tree("oracle")
+        tree.build(map_pts)
+        ref = tree.iekf_update(scan, cur.pod, prop.pod, max_iterations=5, imu_en=imu_en, threads=4)
+        reg.map_build(map_pts)
+        reg.scan_upload(scan)
+        reg.downsample_skip()
+        s = cur.copy()
+        rep = reg.iekf_update(s, prop, max_iterations=5, imu_en=imu_en)
+        assert rep["iterations"] == ref["iters"]
+        v = oracle.StateView(ref["state"])
+        d = oracle.state_boxminus(s.pod, ref["state"])
+        assert np.max(np.abs(d[:12])) < 1e-7, d[:12]          # pose + extrinsic
+        assert np.max(np.abs(d[12:])) < 1e-5, d[12:]          # velocity, biases, gravity (prior std 1 .. 3e-3)
+        assert np.max(np.abs(v.cov - s.cov)) <= 1e-6 * np.max(np.abs(v.cov))
+
+
 def test_sparse_and_empty_neighbourhoods(reg, oracle):
     """Frontier behaviour: queries with fewer than 5 neighbours within sqrt(5) m, phase-2 ring search."""
     import lidar_imu_init_amd as lii
