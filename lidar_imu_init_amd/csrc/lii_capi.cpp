@@ -73,14 +73,13 @@ struct lii_context {
   unsigned long long* d_extent = nullptr;  // 2 x {min (time|index), max time}: ping-pong accumulators
   unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
   int extent_sel = 0, mm_sel = 0;
-  unsigned int *d_vkeys_a = nullptr, *d_vkeys_b = nullptr, *d_vidx_a = nullptr, *d_vidx_b = nullptr, *d_vflags = nullptr,
+  unsigned int *d_vkeys_a = nullptr, *d_vkeys_b = nullptr, *d_vidx_a = nullptr, *d_vidx_b = nullptr,
                *d_vranks = nullptr;
   double* d_poses = nullptr;
   int n_scan = 0, n_body = 0;   // n_body is an upper bound while n_body_pending (the exact count lives in d_nbody)
   bool n_body_pending = false;
   int last_filtered = 1;
   int* d_nbody = nullptr;       // [0] size of the down-sampled cloud, [1] `filtered` flag of the last voxel filter
-  void* d_voxel_arg = nullptr;
   bool body_is_scan = false;
   bool have_search = false;
   int knn_variant = 4;  // lanes per query of the search pass: 4 (default) or 8 (LII_KNN_VARIANT, an A/B knob)
@@ -541,7 +540,6 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_plane, N * 4));
   CK(dmalloc(&h->d_selected, N));
   CK(dmalloc(&h->d_nbody, 4));
-  CK(hipMalloc(&h->d_voxel_arg, 64));
   CK(dmalloc(&h->d_ctrl, 1));
   CK(dmalloc(&h->d_pose, 1));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_ctrl), sizeof(IekfCtrl), hipHostMallocDefault));
@@ -566,7 +564,6 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_vkeys_b, N));
   CK(dmalloc(&h->d_vidx_a, N));
   CK(dmalloc(&h->d_vidx_b, N));
-  CK(dmalloc(&h->d_vflags, N));
   CK(dmalloc(&h->d_vranks, N));
   CK(dmalloc(&h->d_poses, 22 * 1024));
   CK(dmalloc(&h->d_cal_params, 64));
@@ -590,8 +587,8 @@ int lii_destroy(lii_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
-                 h->d_selected, h->d_nbody, h->d_voxel_arg, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
-                 h->d_vidx_b, h->d_vflags, h->d_vranks, h->d_poses, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
+                 h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
+                 h->d_vidx_b, h->d_vranks, h->d_poses, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);

@@ -18,7 +18,6 @@ void ingest_destroy(void* slot);  // lii_ingest.hip
 
 struct UndistArgH { double endR[9], endp[3], RLI[9], TLI[3]; };
 struct CvArgH { double omega[3], vel[3], endR[9]; };
-struct VoxelArgH { float inv_leaf; int min_b[3]; int mul[3]; };
 
 // map index
 void launch_map_keys(const float4* pts, int n, float inv_cs, unsigned long long* keys, unsigned int* idx, hipStream_t s);
