@@ -35,7 +35,7 @@ WORKLOADS = {
 
 
 def build_workload(name, n_scans, seed=20220613):
-    from lidar_imu_init_amd import synth
+    from harness import synth
     sensor, n_map, fs_map, fs_surf, max_it = WORKLOADS[name]
     hall, map_pts = synth.bench_world(n_map, fs_map, seed=seed)
     rng = np.random.default_rng(seed)
@@ -117,7 +117,7 @@ def main():
     T = pose_table()
     eye = np.eye(3)
 
-    from lidar_imu_init_amd.lo_harness import so3_exp  # numpy helper of the test harness (the oracle is only used by cpu_baseline)
+    from harness.lo_harness import so3_exp  # numpy helper of the test harness (the oracle is only used by cpu_baseline)
     states0 = []
     for (R, p) in wl["poses"]:
         st = lii.State()

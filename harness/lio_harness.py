@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .api import Registrar, State, pose6d_array
+from lidar_imu_init_amd.api import Registrar, State, pose6d_array
 from .lo_harness import so3_exp
 
 G_m_s2 = 9.81

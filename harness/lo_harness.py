@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .api import Registrar, State, calib_state_array
+from lidar_imu_init_amd.api import Registrar, State, calib_state_array
 
 
 def so3_exp(w):

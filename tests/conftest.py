@@ -23,7 +23,7 @@ def oracle():
 @pytest.fixture(scope="session")
 def small_world():
     """A 24 x 18 x 6 m hall, its 0.15 m-lattice map (~70 k points) and a 2 k-point scan."""
-    from lidar_imu_init_amd import synth
+    from harness import synth
     hall = synth.Hall(size=(24.0, 18.0, 6.0), n_boxes=8, seed=7)
     map_pts = hall.surface_points(0.15, noise=0.01, seed=7)
     return hall, map_pts

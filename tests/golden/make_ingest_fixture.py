@@ -11,7 +11,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
-from lidar_imu_init_amd import synth, wire  # noqa: E402
+from harness import wire  # noqa: E402
+from harness import synth
 from oracle import oracle as O  # noqa: E402
 
 

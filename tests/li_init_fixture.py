@@ -16,7 +16,7 @@ def load():
 def sequences():
     """IMU / LiDAR CalibSeq as dumped by fout_before_filter (the last element it omits is unavailable), with the
     LiDAR linear velocity and attitude taken from Log/mat_out.txt (6 significant digits)."""
-    from lidar_imu_init_amd import synth
+    from harness import synth
     from oracle import li_init_np as LI
     d = load()
     ib, lb, mo = d["imu_before"], d["lidar_before"], d["mat_out"]

@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 
 def test_lo_then_li_init_recovers_extrinsic(oracle):
     import lidar_imu_init_amd as lii
-    from lidar_imu_init_amd import calib_state_array, synth
-    from lidar_imu_init_amd.lo_harness import LoOdometry
+    from lidar_imu_init_amd import calib_state_array
+    from harness import synth
+    from harness.lo_harness import LoOdometry
 
     hall = synth.Hall(size=(24.0, 18.0, 6.0), n_boxes=8, seed=7)
     traj = synth.Trajectory()
@@ -80,9 +81,10 @@ def test_wire_messages_to_calibration(oracle):
     iterated update -> map_incremental without leaving the GPU; the excitation appraisal (lii_data_sufficiency) gates
     LI_Initialization as data_sufficiency_assess does in the reference (src/laserMapping.cpp:1169-1198)."""
     import lidar_imu_init_amd as lii
-    from lidar_imu_init_amd import calib_state_array, synth, wire
+    from lidar_imu_init_amd import calib_state_array
+    from harness import synth, wire
     from lidar_imu_init_amd.api import data_sufficiency
-    from lidar_imu_init_amd.lo_harness import LoOdometry
+    from harness.lo_harness import LoOdometry
 
     hall = synth.Hall(size=(24.0, 18.0, 6.0), n_boxes=8, seed=7)
     traj = synth.Trajectory()
@@ -145,8 +147,8 @@ def test_lio_phase_tracks_and_refines_extrinsic(oracle):
     IMU_Processing.hpp:296-382), IMU back-propagation de-skew, voxel grid, iterated update (12-column H) and map_incremental on
     the GPU.  Starts from a slightly wrong extrinsic / zero biases, as LI_Initialization would leave them."""
     import lidar_imu_init_amd as lii
-    from lidar_imu_init_amd import synth
-    from lidar_imu_init_amd.lio_harness import LioOdometry
+    from harness import synth
+    from harness.lio_harness import LioOdometry
 
     hall = synth.Hall(size=(24.0, 18.0, 6.0), n_boxes=8, seed=7)
     traj = synth.Trajectory()
@@ -209,7 +211,7 @@ def test_lio_phase_tracks_and_refines_extrinsic(oracle):
 def test_scan_register_equals_separate_calls(oracle):
     """lii_scan_register (one call, one synchronisation) == undistort + voxel grid + iterated update called one by one."""
     import lidar_imu_init_amd as lii
-    from lidar_imu_init_amd import synth
+    from harness import synth
     from conftest import make_state
     hall, map_pts = synth.bench_world(200_000, 0.15)
     reg = lii.Registrar(max_scan_points=40_000, max_map_points=250_000, filter_size_map=0.15)

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def big():
     import lidar_imu_init_amd as lii
-    from lidar_imu_init_amd import synth
+    from harness import synth
     hall, map_pts = synth.bench_world(1_000_000, 0.15)
     reg = lii.Registrar(max_scan_points=520_000, max_map_points=1_100_000, filter_size_map=0.15)
     reg.map_build(map_pts)
@@ -23,7 +23,8 @@ def big():
 @pytest.mark.parametrize("sensor", ["os1_128", "dense500k"])
 def test_full_size_properties(big, oracle, sensor):
     import lidar_imu_init_amd as lii
-    from lidar_imu_init_amd import sharding, synth
+    from lidar_imu_init_amd import sharding
+    from harness import synth
     hall, map_pts, reg = big
     R = synth.rot_zyx(0.01, -0.02, 0.8)
     p = np.array([4.0, -3.0, 0.3])

@@ -3,7 +3,7 @@ Preprocess::process_cut_frame_* (reference src/preprocess.cpp:50-335): bit-exact
 import numpy as np
 import pytest
 
-from lidar_imu_init_amd import synth, wire
+from harness import synth, wire
 
 pytestmark = pytest.mark.gpu
 

@@ -83,7 +83,7 @@ def test_reference_tree_agrees_when_available(oracle):
 def test_stream_with_map_incremental(oracle):
     """8 scans along a path: undistort (CV) -> voxel grid -> IEKF -> map_incremental, GPU pipeline vs oracle pipeline."""
     import lidar_imu_init_amd as lii
-    from lidar_imu_init_amd import synth
+    from harness import synth
     hall = synth.Hall(size=(24.0, 18.0, 6.0), n_boxes=8, seed=7)
     fs_map, leaf = 0.3, 0.2
     reg = lii.Registrar(max_scan_points=40_000, max_map_points=400_000, filter_size_map=fs_map)

@@ -23,7 +23,7 @@ def reg(small_world):
 
 
 def _scan(small_world, sensor="tiny", seed=3):
-    from lidar_imu_init_amd import synth
+    from harness import synth
     hall, _ = small_world
     R = synth.rot_zyx(0.03, -0.02, 0.4)
     p = np.array([0.8, -0.6, 0.1])
@@ -40,7 +40,7 @@ def test_iterate_matches_oracle(reg, oracle, small_world, sensor, imu_en):
     hall, map_pts = small_world
     scan, R, p = _scan(small_world, sensor)
     # perturbed start pose + a non-trivial extrinsic
-    from lidar_imu_init_amd import synth
+    from harness import synth
     R_LI = synth.rot_zyx(0.01, 0.02, -0.015) if imu_en else np.eye(3)
     T_LI = np.array([0.03, -0.02, 0.05]) if imu_en else np.zeros(3)
     # body = LiDAR frame; world pose of the IMU frame chosen so that the LiDAR pose equals (R, p) + small error
@@ -79,7 +79,7 @@ def test_iterate_matches_oracle(reg, oracle, small_world, sensor, imu_en):
 @pytest.mark.parametrize("imu_en,max_it", [(False, 4), (True, 5)])
 def test_update_matches_oracle(reg, oracle, small_world, imu_en, max_it):
     import lidar_imu_init_amd as lii
-    from lidar_imu_init_amd import synth
+    from harness import synth
     hall, map_pts = small_world
     scan, R, p = _scan(small_world, "vlp16", seed=11)
     st_true = make_state(oracle, R, p)

@@ -27,7 +27,8 @@ def _ulp_diff(a, b):
 
 
 def _pose_table(rng, K, sweep_s=0.1, t0=0.0):
-    from lidar_imu_init_amd import pose6d_array, synth
+    from lidar_imu_init_amd import pose6d_array
+    from harness import synth
     T = pose6d_array(K)
     times = np.sort(np.r_[t0, rng.uniform(0.002, sweep_s, K - 1)])
     R = np.eye(3)
@@ -45,7 +46,7 @@ def _pose_table(rng, K, sweep_s=0.1, t0=0.0):
 
 @pytest.mark.parametrize("n,K,tmin", [(50_000, 12, 0.0), (4097, 3, 0.7), (1, 5, 3.0), (257, 2, 0.0)])
 def test_undistort_imu_matches_oracle(reg, oracle, n, K, tmin):
-    from lidar_imu_init_amd import synth
+    from harness import synth
     rng = np.random.default_rng(100 + n)
     pts = np.c_[rng.uniform(-40, 40, (n, 3)), rng.uniform(tmin, 100.0, n)].astype(np.float32)
     if n > 10:
@@ -70,7 +71,7 @@ def test_undistort_imu_matches_oracle(reg, oracle, n, K, tmin):
 
 @pytest.mark.parametrize("n", [30_000, 1, 2, 1000])
 def test_undistort_cv_matches_oracle(reg, oracle, n):
-    from lidar_imu_init_amd import synth
+    from harness import synth
     rng = np.random.default_rng(7 + n)
     pts = np.c_[rng.uniform(-30, 30, (n, 3)), rng.uniform(0.0, 100.0, n)].astype(np.float32)
     if n > 10:

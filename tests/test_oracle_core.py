@@ -126,7 +126,7 @@ def test_kdtree_against_reference_ikdtree(oracle):
 
 
 def test_iekf_recovers_known_pose_and_literal_gain(oracle, small_world):
-    from lidar_imu_init_amd import synth
+    from harness import synth
     hall, map_pts = small_world
     R = synth.rot_zyx(0.02, -0.03, 0.5)
     p = np.array([1.0, -0.5, 0.2])

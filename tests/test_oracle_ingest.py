@@ -3,7 +3,7 @@ vectorised numpy formulation of the same rules and against small hand-worked cas
 import numpy as np
 import pytest
 
-from lidar_imu_init_amd import synth, wire
+from harness import synth, wire
 
 
 def np_cut(pts, stamp_s, required, scan_count, uncut_below):

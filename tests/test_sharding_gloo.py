@@ -26,7 +26,8 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     from conftest import make_state
-    from lidar_imu_init_amd import sharding, synth
+    from lidar_imu_init_amd import sharding
+    from harness import synth
     from oracle import oracle as O
     dist.init_process_group("gloo", rank=rank, world_size=world)
     hall = synth.Hall(size=(20.0, 16.0, 6.0), n_boxes=6, seed=3)

@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import lidar_imu_init_amd as lii
-from lidar_imu_init_amd import synth
+from harness import synth
 from oracle import oracle as O
 from conftest import make_state
 
