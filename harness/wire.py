@@ -114,3 +114,30 @@ def avia_sweep(hall: synth.Hall, R_wb, p_wb, n_points=24000, n_lines=6, noise=0.
     tag |= rng.integers(0, 16, n_points).astype(np.uint8)  # low bits are unrelated flags
     a["tag"] = tag
     return a.tobytes(), n_points
+
+
+def avia_message(hall: synth.Hall, traj, t_beg: float, sweep_s=0.1, n_points=24000, n_lines=6, noise=0.01, seed=11, max_range=100.0):
+    """One Livox-Avia CustomMsg taken WHILE the platform moves along `traj` (ray k fired at t_beg + k / n * sweep_s from the pose
+    of that instant): the rosette of avia_sweep, phase-continuous across messages so that the scan pattern does not repeat."""
+    rng = np.random.default_rng(seed)
+    k = np.arange(n_points)
+    frac = k / n_points
+    tj = t_beg + frac * sweep_s
+    ph = tj / sweep_s  # pattern phase keeps running between messages (non-repetitive scanning)
+    az = np.deg2rad(35.2) * np.sin(2 * np.pi * 17.0 * ph) * np.cos(2 * np.pi * 3.137 * ph)
+    el = np.deg2rad(38.6) * np.sin(2 * np.pi * 23.0 * ph + 0.3) + np.deg2rad(1.0) * ((k % n_lines) - 2.5)
+    dirs = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], -1)
+    R = traj.R(tj)
+    o = traj.p(tj)
+    rngs = hall.raycast(o, np.einsum("nij,nj->ni", R, dirs)) + rng.normal(0, noise, n_points)
+    ok = np.isfinite(rngs) & (rngs < max_range) & (rngs > 0.1)
+    xyz = np.where(ok[:, None], dirs * np.where(ok, rngs, 0.0)[:, None], 0.0).astype(np.float32)
+    a = np.zeros(n_points, LIVOX_DTYPE)
+    a["x"], a["y"], a["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    a["offset_time"] = np.round(frac * sweep_s * 1e9).astype(np.uint32)
+    a["reflectivity"] = rng.integers(0, 255, n_points)
+    a["line"] = k % n_lines
+    tag = np.where(rng.random(n_points) < 0.95, 0x10, 0x00).astype(np.uint8)
+    tag[rng.random(n_points) < 0.02] = 0x20
+    a["tag"] = tag
+    return a.tobytes(), n_points
