@@ -212,7 +212,10 @@ __global__ void k_add_fold(const float4* __restrict__ add_pts, const unsigned lo
   if (!ev) return;
   atomicAdd(events, n_events);
   // delete every existing in-box point except a surviving one; insert the survivor if it is a new point
-  if (n0 > 0) {
+  if (n0 == 1) {
+    // the usual case once the map is down-sampled (at most one point per box): the only in-box point is `best`
+    if (best != cur_old) tomb[best] = 1;
+  } else if (n0 > 1) {
     for (int cz = c0[2]; cz <= c1[2]; cz++)
       for (int cy = c0[1]; cy <= c1[1]; cy++)
         for (int cx = c0[0]; cx <= c1[0]; cx++) {
