@@ -179,8 +179,11 @@ int lii_frame_select(lii_handle h, int32_t frame);
  *   Jacobian rows :1035-1071, H^T R^-1 H / H^T R^-1 z :1073-1080 (src/laserMapping.cpp).
  *   out91 = upper triangle (78) of the 12x12, then 12, then effect_feat_num.  With a communicator attached
  *   (lii_comm_init) out91 is the all-reduced sum over ranks.
- * lii_iekf_update: the whole loop :957-1134 including the 24x24 solve (:1081-1087), convergence / rematch
- *   logic (:1093-1106) and covariance update (:1109-1131), run on the host around lii_iekf_iterate.
+ * lii_iekf_update: the whole loop :957-1134 including the 24-state solve (:1081-1087), convergence / rematch
+ *   logic (:1093-1106) and covariance update (:1109-1131).  The loop is device resident: every pass is enqueued up
+ *   front, the kernels consult a control block in HBM and skip the passes the reference's schedule does not run, the
+ *   final state lands in mapped host memory — one synchronisation per call.  (LII_HOST_SOLVE=1 in the environment
+ *   drives the loop from the host around lii_iekf_iterate with the literal two-inversion algebra instead.)
  * lii_neighbors_download: Nearest_Points of the last search (for map_incremental, :525-549);
  *   pts = n_down x 5 x 3 floats, counts = n_down. */
 int lii_iekf_iterate(lii_handle h, const lii_state* state, int32_t search, int32_t imu_en, double out91[91]);
@@ -271,8 +274,9 @@ int lii_comm_destroy(lii_handle h);
 int lii_dev_alloc(lii_handle h, size_t bytes, void** dev_ptr);
 int lii_dev_free(lii_handle h, void* dev_ptr);
 int lii_dev_upload(lii_handle h, void* dev_dst, const void* host_src, size_t bytes);
-/* Per-stage device timings of the last lii_iekf_update [ms]: {knn+fit kernels, residual kernels, reduce kernels,
- * host solve, total}.  Measured with HIP events on the handle's stream when profiling is enabled. */
+/* Accumulated device timings [ms] since lii_set_profiling(h, 1), measured with HIP events on the handle's stream:
+ * [0] first pass of every update (k-NN + plane fit / residual / block reduce), [2] its final sum + solve, [3] host solve
+ * (host-driven loop only), [4] wall time of the last update, [5] number of executed k-NN passes, [7] their total time. */
 int lii_set_profiling(lii_handle h, int32_t enabled); /* 1: start (zero the accumulators), 2: resume, 0: pause */
 int lii_last_timings(lii_handle h, double out_ms[8]);
 
