@@ -42,8 +42,6 @@ struct lii_context {
   unsigned int blocks_cap = 0;      // allocated entries
   unsigned int block_mask = 0;      // entries in use - 1
   uint2* d_cells = nullptr;         // capacity-managed: 512 entries per occupied block
-  unsigned long long* d_cmask = nullptr;  // same shape: sub-voxel occupancy of every cell (voxel-aligned grids)
-  bool aligned = false;             // cell = 4 x 4 x 4 down-sample voxels
   size_t cells_cap_blocks = 0;
   int n_blocks = 0;
   unsigned int* d_counter = nullptr;
@@ -139,9 +137,6 @@ GridView grid_view(const lii_context* c) {
   g.pts = c->d_map;
   g.blocks = c->d_blocks;
   g.cells = c->d_cells;
-  g.cmask = c->d_cmask;
-  g.ds = c->ds;
-  g.aligned = c->aligned ? 1 : 0;
   g.block_mask = c->block_mask;
   g.n_pts = c->n_map;
   g.cs = c->cell_size;
@@ -185,7 +180,7 @@ int build_index(lii_handle h, int n, int n_sorted = 0) {
   if (h->n_map_pinned) h->n_map_pinned[0] = n;
   if (n == 0) return LII_OK;
   const float inv_cs = 1.0f / h->cell_size;
-  launch_map_keys(h->d_map_unsorted, n, inv_cs, h->ds, h->aligned ? 1 : 0, h->d_keys_a, h->d_idx_a, s);
+  launch_map_keys(h->d_map_unsorted, n, inv_cs, h->d_keys_a, h->d_idx_a, s);
   unsigned long long* sorted_keys = h->d_keys_b;
   const int n_new = n - n_sorted;
   if (n_sorted <= 0) {
@@ -213,12 +208,9 @@ int build_index(lii_handle h, int n, int n_sorted = 0) {
   std::memcpy(&n_blocks, h->h_small, sizeof(unsigned int));
   if (size_t(n_blocks) > h->cells_cap_blocks) {
     if (h->d_cells) HIPCHK(h, hipFree(h->d_cells));
-    if (h->d_cmask) HIPCHK(h, hipFree(h->d_cmask));
     h->d_cells = nullptr;
-    h->d_cmask = nullptr;
     size_t want = std::max<size_t>(size_t(n_blocks) * 3 / 2, 4096);
     HIPCHK(h, dmalloc(&h->d_cells, want * 512));
-    HIPCHK(h, dmalloc(&h->d_cmask, want * 512));
     h->cells_cap_blocks = want;
   }
   unsigned int bcap = next_pow2(std::max(1024u, 8u * n_blocks));  // load factor <= 1/8: first probe decides
@@ -231,9 +223,8 @@ int build_index(lii_handle h, int n, int n_sorted = 0) {
   h->block_mask = bcap - 1;
   h->n_blocks = int(n_blocks);
   HIPCHK(h, hipMemsetAsync(h->d_cells, 0, sizeof(uint2) * 512 * size_t(n_blocks), s));
-  HIPCHK(h, hipMemsetAsync(h->d_cmask, 0, sizeof(unsigned long long) * 512 * size_t(n_blocks), s));
   launch_table_clear(h->d_blocks, bcap, s);
-  launch_cells_fill(sorted_keys, ranks, n, h->d_blocks, h->block_mask, h->d_cells, h->d_cmask, s);
+  launch_cells_fill(sorted_keys, ranks, n, h->d_blocks, h->block_mask, h->d_cells, s);
   HIPCHK(h, hipGetLastError());
   if (h->n_map_pinned) h->n_map_pinned[0] = n;
   return LII_OK;
@@ -486,12 +477,9 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   if (h->cfg.plane_threshold <= 0) h->cfg.plane_threshold = 0.1;
   if (h->cfg.laser_point_cov_inv <= 0) h->cfg.laser_point_cov_inv = 1000.0;
   if (h->cfg.map_downsample_size <= 0) h->cfg.map_downsample_size = 0.2f;
+  h->cell_size = cfg->map_cell_size > 0 ? cfg->map_cell_size : 3.0f * h->cfg.map_downsample_size;
   // the 3x3x3 neighbourhood of 8x8x8-cell blocks must cover the acceptance radius sqrt(max_match_dist2)
-  const float min_cs = std::sqrt(h->cfg.max_match_dist2) / 8.0f * 1.001f;
-  const float aligned_cs = 4.0f * h->cfg.map_downsample_size;  // a cell = 4 x 4 x 4 down-sample voxels
-  if (cfg->map_cell_size > 0) h->cell_size = std::max(cfg->map_cell_size, min_cs);
-  else h->cell_size = aligned_cs >= min_cs ? aligned_cs : std::max(3.0f * h->cfg.map_downsample_size, min_cs);
-  h->aligned = (h->cell_size == aligned_cs);
+  h->cell_size = std::max(h->cell_size, std::sqrt(h->cfg.max_match_dist2) / 8.0f * 1.001f);
   if (const char* v = std::getenv("LII_KNN_VARIANT")) h->knn_variant = std::atoi(v);  // A/B knob for profiling
   if (const char* v = std::getenv("LII_HOST_SOLVE")) h->host_solve = std::atoi(v) != 0;
   h->ds = h->cfg.map_downsample_size;
@@ -528,7 +516,6 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_blocks, size_t(h->blocks_cap)));
   h->cells_cap_blocks = std::max<size_t>(4096, M / 64);
   CK(dmalloc(&h->d_cells, h->cells_cap_blocks * 512));
-  CK(dmalloc(&h->d_cmask, h->cells_cap_blocks * 512));
   CK(dmalloc(&h->d_counter, 4));
   CK(dmalloc(&h->d_tomb, M));
   CK(dmalloc(&h->d_ins, M));
@@ -598,7 +585,7 @@ int lii_destroy(lii_handle h) {
   (void)hipSetDevice(h->device);
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells, h->d_cmask,
+  void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
                  h->d_vidx_b, h->d_vranks, h->d_poses, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,

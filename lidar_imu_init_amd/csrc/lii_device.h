@@ -11,8 +11,7 @@ constexpr int kBlock = 256;        // 4 wavefronts of 64
 constexpr int kNormalEq = 91;      // 78 + 12 + 1
 constexpr int kCoarseShift = 3;    // coarse occupancy cell = 8 x 8 x 8 fine cells
 constexpr unsigned long long kEmptyKey = ~0ull;
-constexpr int kCellBias = 1 << 18;  // cell coordinates are biased to 19 bits: 16-bit block coordinates
-constexpr int kSubBits = 6;         // sub-voxel (4 x 4 x 4 down-sample voxels per cell) inside the sort key
+constexpr int kCellBias = 1 << 20;
 
 // Pose the per-point kernels need: state.rot_end, pos_end, offset_R_L_I, offset_T_L_I (row-major).
 struct PoseArg {
@@ -37,39 +36,13 @@ struct __attribute__((aligned(16))) BlockEntry {
 struct GridView {
   const float4* pts;  // xyz + w = bit-cast insertion id
   const BlockEntry* blocks;
-  const uint2* cells;                 // (first, one-past-last | kCellMulti)
-  const unsigned long long* cmask;    // voxel-aligned grids: bit (sz*16 + sy*4 + sx) = sub-voxel occupied
+  const uint2* cells;
   unsigned int block_mask;
   int n_pts;
   float cs;
   float inv_cs;
   float max_d2;
-  float ds;       // down-sample voxel edge (ikd-Tree downsample_size)
-  int aligned;    // 1: cs == 4 * ds and cells are unions of 4 x 4 x 4 down-sample voxels (cell = floor(x / ds) >> 2); the
-                  //    points of a cell are sorted by sub-voxel, so with one point per sub-voxel its index is first + popcount
 };
-constexpr unsigned int kCellMulti = 0x80000000u;  // set in cells[].y when some sub-voxel of the cell holds more than one point
-
-// ---- shared index arithmetic (lii_kernels.hip builds and searches the index, lii_map.hip folds batches into it)
-__device__ __forceinline__ unsigned long long pack_block(int bx, int by, int bz) {  // biased block coordinates, 16 bits each
-  return ((unsigned long long)(unsigned)bz << 32) | ((unsigned long long)(unsigned)by << 16) | (unsigned long long)(unsigned)bx;
-}
-__device__ __forceinline__ unsigned int hash_block(int bx, int by, int bz) {
-  // 24-bit multiplies are full-rate VALU ops
-  return (__umul24((unsigned)bx, 7919u * 1021u) ^ __umul24((unsigned)by, 104729u * 13u) ^ __umul24((unsigned)bz, 1299709u)) * 2654435761u;
-}
-// sort key of a map point: block (Bz, By, Bx) | local cell (lz, ly, lx) | sub-voxel (sz, sy, sx)  = 48 + 9 + 6 bits
-__device__ __forceinline__ unsigned long long point_key(int cx, int cy, int cz, unsigned int sub) {
-  const unsigned ux = (unsigned)(cx + kCellBias), uy = (unsigned)(cy + kCellBias), uz = (unsigned)(cz + kCellBias);
-  const unsigned long long bk = pack_block((int)(ux >> kCoarseShift), (int)(uy >> kCoarseShift), (int)(uz >> kCoarseShift));
-  const unsigned local = ((uz & 7u) << 6) | ((uy & 7u) << 3) | (ux & 7u);
-  return (bk << (9 + kSubBits)) | ((unsigned long long)local << kSubBits) | sub;
-}
-__device__ __forceinline__ int voxel_of(float x, float ds) { return (int)floorf(x / ds); }  // ikd_Tree.cpp:390-395
-// cell coordinate of a coordinate value (voxel-aligned grids: through the down-sample voxel, exactly as Add_Points boxes points)
-__device__ __forceinline__ int grid_cell(const GridView& g, float x) {
-  return g.aligned ? (voxel_of(x, g.ds) >> 2) : (int)floorf(x * g.inv_cs);
-}
 
 struct RegistrationBuffers {
   const float4* body;   // down-sampled LiDAR-frame points (x,y,z,t)

@@ -28,6 +28,29 @@ namespace lii {
 // helpers
 constexpr int kBlockCells = 512;  // 8 x 8 x 8 cells per block
 
+// sort key of a map point: (Bz, By, Bx) block key in the high bits, local cell (lz, ly, lx) in the low 9
+__device__ __forceinline__ unsigned long long pack_block(int bx, int by, int bz) {  // biased block coordinates
+  return ((unsigned long long)(unsigned)bz << 36) | ((unsigned long long)(unsigned)by << 18) | (unsigned long long)(unsigned)bx;
+}
+__device__ __forceinline__ unsigned long long point_key(int cx, int cy, int cz) {
+  const unsigned ux = (unsigned)(cx + kCellBias), uy = (unsigned)(cy + kCellBias), uz = (unsigned)(cz + kCellBias);
+  const unsigned long long bk = pack_block((int)(ux >> kCoarseShift), (int)(uy >> kCoarseShift), (int)(uz >> kCoarseShift));
+  const unsigned local = ((uz & 7u) << 6) | ((uy & 7u) << 3) | (ux & 7u);
+  return (bk << 9) | local;
+}
+__device__ __forceinline__ unsigned int hash_key(unsigned long long k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (unsigned int)k;
+}
+__device__ __forceinline__ unsigned int hash_block(int bx, int by, int bz) {
+  // block coordinates are < 2^18 after biasing: 24-bit multiplies are full-rate VALU ops
+  return (__umul24((unsigned)bx, 7919u * 1021u) ^ __umul24((unsigned)by, 104729u * 13u) ^ __umul24((unsigned)bz, 1299709u)) * 2654435761u;
+}
+
 __device__ __forceinline__ int cell_of(float v, float inv_cs) { return (int)floorf(v * inv_cs); }
 
 // Squared distance with the reference's float32 evaluation order and NO fused multiply-add
@@ -39,17 +62,12 @@ __device__ __forceinline__ float dist2_ref(float qx, float qy, float qz, float p
 
 // ------------------------------------------------------------------------------------------------
 // map index construction
-__global__ void k_map_keys(const float4* __restrict__ pts, int n, float inv_cs, float ds, int aligned,
-                           unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx) {
+__global__ void k_map_keys(const float4* __restrict__ pts, int n, float inv_cs, unsigned long long* __restrict__ keys,
+                           unsigned int* __restrict__ idx) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 p = pts[i];
-  if (aligned) {
-    const int vx = voxel_of(p.x, ds), vy = voxel_of(p.y, ds), vz = voxel_of(p.z, ds);
-    keys[i] = point_key(vx >> 2, vy >> 2, vz >> 2, ((unsigned)(vz & 3) << 4) | ((unsigned)(vy & 3) << 2) | (unsigned)(vx & 3));
-  } else {
-    keys[i] = point_key(cell_of(p.x, inv_cs), cell_of(p.y, inv_cs), cell_of(p.z, inv_cs), 0u);
-  }
+  keys[i] = point_key(cell_of(p.x, inv_cs), cell_of(p.y, inv_cs), cell_of(p.z, inv_cs));
   idx[i] = (unsigned)i;
 }
 
@@ -64,7 +82,7 @@ __global__ void k_map_gather(const float4* __restrict__ src, const unsigned int*
 __global__ void k_block_flags(const unsigned long long* __restrict__ keys, int n, unsigned int* __restrict__ flags) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  flags[i] = (i == 0 || (keys[i] >> (9 + kSubBits)) != (keys[i - 1] >> (9 + kSubBits))) ? 1u : 0u;
+  flags[i] = (i == 0 || (keys[i] >> 9) != (keys[i - 1] >> 9)) ? 1u : 0u;
 }
 
 __global__ void k_table_clear(BlockEntry* blocks, unsigned int cap) {
@@ -78,27 +96,23 @@ __global__ void k_table_clear(BlockEntry* blocks, unsigned int cap) {
   }
 }
 
-// cells and cmask must be zero-filled for the n_blocks * 512 entries in use (every field is OR-ed in: the writers of one
-// cell are different threads)
+// cells must be zero-filled for the n_blocks * 512 entries in use
 __global__ void k_cells_fill(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ ranks, int n,
-                             BlockEntry* blocks, unsigned int block_mask, uint2* __restrict__ cells,
-                             unsigned long long* __restrict__ cmask) {
+                             BlockEntry* blocks, unsigned int block_mask, uint2* __restrict__ cells) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned long long key = keys[i];
-  const unsigned long long ckey = key >> kSubBits;  // block | local cell
-  const bool is_start = (i == 0) || ((keys[i - 1] >> kSubBits) != ckey);
-  const bool is_end = (i == n - 1) || ((keys[i + 1] >> kSubBits) != ckey);
+  const bool is_start = (i == 0) || (keys[i - 1] != key);
+  const bool is_end = (i == n - 1) || (keys[i + 1] != key);
+  if (!is_start && !is_end) return;
   const unsigned int id = ranks[i] - 1;
-  const unsigned int local = (unsigned int)(ckey & 511u);
+  const unsigned int local = (unsigned int)(key & 511u);
   unsigned int* cell = reinterpret_cast<unsigned int*>(&cells[(size_t)id * kBlockCells + local]);
-  if (is_start) atomicOr(&cell[0], (unsigned)i);
-  if (is_end) atomicOr(&cell[1], (unsigned)(i + 1));
-  if (i > 0 && keys[i - 1] == key) atomicOr(&cell[1], kCellMulti);  // two points in one sub-voxel
-  else atomicOr(&cmask[(size_t)id * kBlockCells + local], 1ull << (unsigned)(key & 63u));
-  if (is_start && ((i == 0) || ((keys[i - 1] >> (9 + kSubBits)) != (key >> (9 + kSubBits))))) {
-    const unsigned long long bk = key >> (9 + kSubBits);
-    unsigned int slot = hash_block((int)(bk & 0xFFFF), (int)((bk >> 16) & 0xFFFF), (int)((bk >> 32) & 0xFFFF)) & block_mask;
+  if (is_start) cell[0] = (unsigned)i;
+  if (is_end) cell[1] = (unsigned)(i + 1);
+  if (is_start && ((i == 0) || ((keys[i - 1] >> 9) != (key >> 9)))) {
+    const unsigned long long bk = key >> 9;
+    unsigned int slot = hash_block((int)(bk & 0x3FFFF), (int)((bk >> 18) & 0x3FFFF), (int)((bk >> 36) & 0x3FFFF)) & block_mask;
     while (true) {
       unsigned long long prev = atomicCAS(&blocks[slot].key, kEmptyKey, bk);
       if (prev == kEmptyKey) { blocks[slot].id = id; break; }
@@ -145,9 +159,7 @@ __device__ __forceinline__ uint2 cell_range(const GridView& g, int ix, int iy, i
   const int id = find_block(g, ix >> kCoarseShift, iy >> kCoarseShift, iz >> kCoarseShift);
   if (id < 0) return make_uint2(0u, 0u);
   const unsigned local = (((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u);
-  uint2 r = g.cells[(size_t)id * kBlockCells + local];
-  r.y &= ~kCellMulti;
-  return r;
+  return g.cells[(size_t)id * kBlockCells + local];
 }
 
 __device__ __forceinline__ void scan_range(const GridView& g, unsigned int start, unsigned int end, float qx, float qy,
@@ -455,9 +467,7 @@ __device__ __forceinline__ uint2 lookup_cell(const GridView& g, const uint4* __r
   }
   if (ek != bk) return make_uint2(0u, 0u);
   const unsigned local = (((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u);
-  uint2 r = g.cells[(size_t)e.z * kBlockCells + local];
-  r.y &= ~kCellMulti;
-  return r;
+  return g.cells[(size_t)e.z * kBlockCells + local];
 }
 
 template <int LPQ, bool DEDUP>
@@ -635,7 +645,7 @@ __device__ __forceinline__ void knn_fallback_block(const GridView& g, FallbackSh
     if (gx * gx + gy * gy + gz * gz > bound0) continue;
     const unsigned local = (((unsigned)izz & 7u) << 6) | (((unsigned)iyy & 7u) << 3) | ((unsigned)ixx & 7u);
     const uint2 rr = g.cells[(size_t)id * kBlockCells + local];
-    scan_range(g, rr.x, rr.y & ~kCellMulti, wx, wy, wz, k);
+    scan_range(g, rr.x, rr.y, wx, wy, wz, k);
   }
   // wave butterfly (disjoint cell sets -> no duplicates), then the 4 wave results through LDS
 #pragma unroll
@@ -1186,9 +1196,8 @@ template __global__ void k_calib_eval<3>(const double*, const double*, int, cons
 namespace lii {
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 
-void launch_map_keys(const float4* pts, int n, float inv_cs, float ds, int aligned, unsigned long long* keys, unsigned int* idx,
-                     hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_map_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, inv_cs, ds, aligned, keys, idx);
+void launch_map_keys(const float4* pts, int n, float inv_cs, unsigned long long* keys, unsigned int* idx, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_map_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, inv_cs, keys, idx);
 }
 void launch_map_gather(const float4* src, const unsigned int* idx, int n, float4* dst, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_map_gather, dim3(nblk(n, 256)), dim3(256), 0, s, src, idx, n, dst);
@@ -1200,8 +1209,8 @@ void launch_table_clear(BlockEntry* blocks, unsigned int cap, hipStream_t s) {
   hipLaunchKernelGGL(k_table_clear, dim3(nblk((int)cap, 256)), dim3(256), 0, s, blocks, cap);
 }
 void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks, int n, BlockEntry* blocks,
-                       unsigned int block_mask, uint2* cells, unsigned long long* cmask, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_cells_fill, dim3(nblk(n, 256)), dim3(256), 0, s, keys, ranks, n, blocks, block_mask, cells, cmask);
+                       unsigned int block_mask, uint2* cells, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_cells_fill, dim3(nblk(n, 256)), dim3(256), 0, s, keys, ranks, n, blocks, block_mask, cells);
 }
 int register_blocks(int n) { return nblk(n, kBlock); }
 void launch_knn8p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,

@@ -20,13 +20,12 @@ struct UndistArgH { double endR[9], endp[3], RLI[9], TLI[3]; };
 struct CvArgH { double omega[3], vel[3], endR[9]; };
 
 // map index
-void launch_map_keys(const float4* pts, int n, float inv_cs, float ds, int aligned, unsigned long long* keys, unsigned int* idx,
-                     hipStream_t s);
+void launch_map_keys(const float4* pts, int n, float inv_cs, unsigned long long* keys, unsigned int* idx, hipStream_t s);
 void launch_map_gather(const float4* src, const unsigned int* idx, int n, float4* dst, hipStream_t s);
 void launch_block_flags(const unsigned long long* keys, int n, unsigned int* flags, hipStream_t s);
 void launch_table_clear(BlockEntry* blocks, unsigned int cap, hipStream_t s);
 void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks, int n, BlockEntry* blocks,
-                       unsigned int block_mask, uint2* cells, unsigned long long* cmask, hipStream_t s);
+                       unsigned int block_mask, uint2* cells, hipStream_t s);
 // registration
 void launch_knn8p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                   const IekfCtrl* ctrl, int forced, hipStream_t s);

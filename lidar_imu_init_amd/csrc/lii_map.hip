@@ -20,22 +20,26 @@
 namespace lii {
 
 namespace {
+constexpr int kBias = 1 << 20;
 constexpr int kCells = 512;
-constexpr int kBias = 1 << 20;  // bias of the DOWN-SAMPLE voxel coordinates inside the Add_Points sort key (k_add_keys)
 constexpr unsigned long long kInvalidKey = ~0ull;
 
+__device__ __forceinline__ unsigned int d_hash_block(int bx, int by, int bz) {
+  return (__umul24((unsigned)bx, 7919u * 1021u) ^ __umul24((unsigned)by, 104729u * 13u) ^ __umul24((unsigned)bz, 1299709u)) * 2654435761u;
+}
+__device__ __forceinline__ unsigned long long d_pack_block(int bx, int by, int bz) {
+  return ((unsigned long long)(unsigned)bz << 36) | ((unsigned long long)(unsigned)by << 18) | (unsigned long long)(unsigned)bx;
+}
 __device__ __forceinline__ uint2 d_cell_range(const GridView& g, int ix, int iy, int iz) {
-  const int bb = kCellBias >> kCoarseShift;
+  const int bb = kBias >> kCoarseShift;
   const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
-  const unsigned long long bk = pack_block(bx, by, bz);
-  unsigned int sl = hash_block(bx, by, bz) & g.block_mask;
+  const unsigned long long bk = d_pack_block(bx, by, bz);
+  unsigned int sl = d_hash_block(bx, by, bz) & g.block_mask;
   while (true) {
     BlockEntry e = g.blocks[sl];
     if (e.key == bk) {
       const unsigned local = (((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u);
-      uint2 r = g.cells[(size_t)e.id * kCells + local];
-      r.y &= ~kCellMulti;
-      return r;
+      return g.cells[(size_t)e.id * kCells + local];
     }
     if (e.key == kEmptyKey) return make_uint2(0u, 0u);
     sl = (sl + 1) & g.block_mask;
