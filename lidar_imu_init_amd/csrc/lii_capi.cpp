@@ -398,6 +398,8 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     if (++cnt % 100 == 0) {
       fprintf(stderr, "[solve trace, 10 ns ticks]");
       for (int k = 1; k <= 10; k++) fprintf(stderr, " %lld", hr->ts[k] - hr->ts[k - 1]);
+      fprintf(stderr, "  | it0:");
+      for (int k = 1; k <= 10; k++) fprintf(stderr, " %lld", hr->ts0[k] - hr->ts0[k - 1]);
       fprintf(stderr, "\n");
     }
   }
@@ -791,7 +793,10 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
   launch_voxel_minmax(h->d_scan, n, mm, h->d_mm + 8 * h->mm_sel, s);
   launch_voxel_keys(h->d_scan, n, mm, leaf, h->d_vkeys_a, h->d_vidx_a, h->d_nbody + 1, s);
   sort_pairs_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a, h->d_vidx_b, n, s);
-  voxel_rank_scan(h->d_sort_temp, h->sort_temp_bytes, h->d_vkeys_b, h->d_vranks, n, s);
+  // (feeding the scan through a transform iterator that evaluates the flag on the fly saves this launch but makes the scan
+  // itself 8 us slower: measured)
+  launch_voxel_flags(h->d_vkeys_b, n, h->d_vidx_a, s);  // d_vidx_a is free after the sort
+  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_vidx_a, h->d_vranks, n, s);
   launch_voxel_centroid(h->d_scan, h->d_vkeys_b, h->d_vidx_b, h->d_vranks, n, h->d_body, h->d_nbody, s);
   HIPCHK(h, hipGetLastError());
   h->n_body = n;  // upper bound until resolved

@@ -88,7 +88,8 @@ struct IekfResult {
   double ne[96];  // the 91 normal-equation scalars of the last executed pass
   int it, searches, effect_num, converged, singular, pad[3];
   int search_log[16];
-  long long ts[16];  // LII_SOLVE_TRACE builds: wall_clock64 stamps of the solve phases
+  long long ts[16];  // LII_SOLVE_TRACE builds: wall_clock64 stamps of the solve phases (stopping iteration)
+  long long ts0[16]; // ... of iteration 0
 };
 
 // 1 at the first point of every voxel run of the sorted voxel-grid keys (non-finite points carry the sentinel key and start

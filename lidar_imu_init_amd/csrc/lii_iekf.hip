@@ -133,13 +133,21 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
     for (int e = lane; e < 91; e += 64) s_ne[e] = __hip_atomic_load(ne + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane < 36) { s_st[lane] = c->st[lane]; s_prop[lane] = c->prop[lane]; }
     const double* cov = c->st + 36;
-    // the prior enters as its symmetric part: K_1[:, :12] = P[:, :12] M^T below relies on P11 = P11^T, and whatever
-    // asymmetry (I - K H) P picks up from rounding must not feed back into the next scan's gain (it compounds otherwise:
-    // the pose block of P grew to 0.4 within 200 scans of a LIO run, the literal two-inversion algebra stays at 4e-5)
 #pragma unroll
-    for (int q = 0; q < 9; q++) {
-      const int e = lane + 64 * q, r = e / N, cc = e % N;
-      s_cov[e] = 0.5 * (cov[e] + cov[cc * N + r]);
+    for (int q = 0; q < 9; q++) s_cov[lane + 64 * q] = cov[lane + 64 * q];
+  }
+  __syncthreads();
+  if (s_int[4]) return;  // EKF_stop_flg already set: this pass is not due
+  // the prior enters as its symmetric part: K_1[:, :12] = P[:, :12] M^T below relies on P11 = P11^T, and whatever asymmetry
+  // (I - K H) P picks up from rounding must not feed back into the next scan's gain (it compounds otherwise: the pose block
+  // of P grew to 0.4 within 200 scans of a LIO run, the literal two-inversion algebra stays at 4e-5).  Done in LDS: the
+  // transposed global reads would not coalesce.
+  for (int e = lane; e < N * N; e += 64) {
+    const int r = e / N, cc = e % N;
+    if (r < cc) {
+      const double a = 0.5 * (s_cov[e] + s_cov[cc * N + r]);
+      s_cov[e] = a;
+      s_cov[cc * N + r] = a;
     }
   }
   __syncthreads();
@@ -290,7 +298,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
 #ifdef LII_SOLVE_TRACE
   __syncthreads();
   LII_TS(10);
-  if (threadIdx.x < 11) res->ts[threadIdx.x] = s_ts[threadIdx.x];
+  if (threadIdx.x < 11) { if (it == 0) res->ts0[threadIdx.x] = s_ts[threadIdx.x]; else res->ts[threadIdx.x] = s_ts[threadIdx.x]; }
 #endif
 }
 

@@ -1059,6 +1059,10 @@ __global__ void k_voxel_keys(const float4* __restrict__ pts, int n, const unsign
   keys[i] = key;
   idx[i] = (unsigned)i;
 }
+__global__ void k_voxel_flags(const unsigned int* __restrict__ keys, int n, unsigned int* __restrict__ flags) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = voxel_start_flag(keys, i);
+}
 // ranks = inclusive scan of flags.  One thread per voxel start accumulates its run sequentially in input
 // order (the sort is stable), float32, then divides by the count — the same order the oracle uses.
 __global__ void k_voxel_centroid(const float4* __restrict__ pts, const unsigned int* __restrict__ keys,
@@ -1268,6 +1272,9 @@ void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned in
 void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, float leaf, unsigned int* keys, unsigned int* idx,
                        int* filtered_dev, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, leaf, keys, idx, filtered_dev);
+}
+void launch_voxel_flags(const unsigned int* keys, int n, unsigned int* flags, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_voxel_flags, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, flags);
 }
 void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const unsigned int* idx, const unsigned int* ranks, int n,
                            float4* out, int* n_out, hipStream_t s) {

@@ -48,6 +48,7 @@ void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned lon
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s);
 void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, float leaf, unsigned int* keys, unsigned int* idx,
                        int* filtered_dev, hipStream_t s);
+void launch_voxel_flags(const unsigned int* keys, int n, unsigned int* flags, hipStream_t s);
 void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const unsigned int* idx, const unsigned int* ranks, int n,
                            float4* out, int* n_out, hipStream_t s);
 // calibration
@@ -75,7 +76,6 @@ void sort_pairs_u32(void* temp, size_t temp_bytes, const unsigned int* kin, unsi
 void merge_pairs_u64_f4(void* temp, size_t temp_bytes, const unsigned long long* k1, const unsigned long long* k2,
                         unsigned long long* kout, const float4* v1, const float4* v2, float4* vout, int n1, int n2,
                         hipStream_t s);
-void voxel_rank_scan(void* temp, size_t temp_bytes, const unsigned int* sorted_keys, unsigned int* ranks, int n, hipStream_t s);
 void inclusive_scan_u32(void* temp, size_t temp_bytes, const unsigned int* in, unsigned int* out, int n, hipStream_t s);
 
 float ord_to_float(unsigned int o);

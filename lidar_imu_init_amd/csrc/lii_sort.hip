@@ -44,16 +44,6 @@ void sort_pairs_u32(void* temp, size_t temp_bytes, const unsigned int* kin, unsi
   if (n <= 0) return;
   (void)rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0, 32, s);
 }
-// ranks of the voxel runs: inclusive scan of voxel_start_flag(keys, i) evaluated on the fly (no flag array, no flag kernel)
-struct VoxelFlagOp {
-  const unsigned int* keys;
-  __device__ unsigned int operator()(int i) const { return voxel_start_flag(keys, i); }
-};
-void voxel_rank_scan(void* temp, size_t temp_bytes, const unsigned int* sorted_keys, unsigned int* ranks, int n, hipStream_t s) {
-  if (n <= 0) return;
-  auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), VoxelFlagOp{sorted_keys});
-  (void)rocprim::inclusive_scan(temp, temp_bytes, in, ranks, (size_t)n, rocprim::plus<unsigned int>(), s);
-}
 void inclusive_scan_u32(void* temp, size_t temp_bytes, const unsigned int* in, unsigned int* out, int n, hipStream_t s) {
   if (n <= 0) return;
   (void)rocprim::inclusive_scan(temp, temp_bytes, in, out, (size_t)n, rocprim::plus<unsigned int>(), s);
