@@ -226,33 +226,41 @@ def main():
                          "peak_measured_copy": 6290.0, "frac_of_measured_copy": achieved / 6290.0},
         }
         if not args.no_cpu_baseline and args.gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(wl, states0)
+            out["cpu_baseline"] = cpu_baseline(wl, states0, tables, args.no_downsample)
         print(json.dumps(out), flush=True)
     reg.close()
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(wl, states0, threads=3, budget_s=20.0):
-    """The oracle restatement of the same per-scan path (ikd-Tree-semantics k-NN, per-point QR plane fit, Jacobian,
-    24-state update) on this box's host cores with the reference's 3 OpenMP threads (CMakeLists.txt:24-27)."""
+def cpu_baseline(wl, states0, tables, no_downsample, threads=3, budget_s=15.0):
+    """The oracle restatement of the same step — time sort + IMU back-propagation de-skew, voxel grid, iterated update
+    (ikd-Tree-semantics k-NN, per-point QR plane fit, Jacobian, 24-state solve) — on this box's host cores with the
+    reference's 3 OpenMP threads for the registration loop (CMakeLists.txt:24-27; the de-skew and the voxel filter are
+    single-threaded in the reference, as here)."""
     from oracle import oracle as O
     tree = O.Tree("oracle")
     tree.build(wl["map"])
-    secs, n = 0.0, 0
+    secs, n, reg_secs = 0.0, 0, 0.0
     k = 0
     best = None
-    while secs < budget_s and n < 64:
+    while secs < budget_s and n < 160:
         j = k % len(wl["scans"])
-        r = tree.iekf_update(wl["scans"][j], states0[j].pod, states0[j].pod, max_iterations=wl["max_it"], imu_en=True,
-                             threads=threads)
-        secs += r["seconds"]
-        best = r["seconds"] if best is None else min(best, r["seconds"])
+        s0 = states0[j]
+        t0 = time.perf_counter()
+        und = O.undistort_imu(wl["scans"][j], tables[j], s0.rot_end, s0.pos_end, s0.offset_R_L_I, s0.offset_T_L_I)
+        body = und if no_downsample else O.voxel_grid(und, wl["fs_surf"])[0]
+        r = tree.iekf_update(body, s0.pod, s0.pod, max_iterations=wl["max_it"], imu_en=True, threads=threads)
+        dt = time.perf_counter() - t0
+        secs += dt
+        reg_secs += r["seconds"]
+        best = dt if best is None else min(best, dt)
         n += 1
         k += 1
     return {"value": n / secs, "unit": "scans/s", "cores": threads, "kind": "port",
-            "sample": f"{n} scans of the same workload, registration only (no undistortion), {secs:.1f} s CPU wall, "
-                      f"best scan {best * 1e3:.0f} ms; host has {O.num_procs()} logical cores"}
+            "sample": f"{n} scans of the same workload and the same step (de-skew + voxel grid + iterated update), {secs:.1f} s CPU "
+                      f"wall of which {reg_secs:.1f} s in the registration loop, best scan {best * 1e3:.0f} ms; host has "
+                      f"{O.num_procs()} logical cores"}
 
 
 if __name__ == "__main__":
