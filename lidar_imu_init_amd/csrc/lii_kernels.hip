@@ -604,30 +604,64 @@ __global__ __launch_bounds__(kBlock) void k_knn_pruned(GridView g, RegistrationB
 template __global__ void k_knn_pruned<8>(GridView, RegistrationBuffers, PoseArg, const PoseArg*, const IekfCtrl*, int, int);
 template __global__ void k_knn_pruned<4>(GridView, RegistrationBuffers, PoseArg, const PoseArg*, const IekfCtrl*, int, int);
 
-// Second stage of the search for a flagged query, run by the WHOLE 256-thread workgroup that owns the point: visits
-// every cell that intersects the ball of radius sqrt(min(d5 of stage 1, max_d2)) — looked up through the 3x3x3
-// neighbourhood of 8x8x8-cell blocks, so empty space costs nothing — and merges the per-lane lists (wave butterfly,
-// then LDS).  Thread 0 returns the final list in `k`; the call contains workgroup barriers (uniform call sites only).
-struct FallbackShared {
-  int block[27];
-  float d[4][5];
-  int i[4][5];
-};
-__device__ __forceinline__ void knn_fallback_block(const GridView& g, FallbackShared& fs, float wx, float wy, float wz,
-                                                   float d5, Knn5& k) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Second stage of the search for a flagged query, run by ONE WAVEFRONT (four flagged queries of a workgroup proceed
+// concurrently): every cell that intersects the ball of radius sqrt(min(d5 of stage 1, max_d2)) is visited — looked up through
+// the 3x3x3 neighbourhood of 8x8x8-cell blocks (27 block ids held one per lane and fetched by shuffle), so empty space costs
+// nothing.  Two passes: the 3x3x3 cells around the query first; their exact top-5 gives the bound that prunes the (up to
+// ~1300) outer cells.  The per-lane sorted lists are merged by five rounds of "wave-wide minimum of the list heads, owner
+// pops" — ~25 instructions per round instead of a 6-step butterfly of 5-element insertions.  The result is wave-uniform.
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+  return v;
+}
+// pops the 5 smallest (d, idx) over the lists of all lanes into uniform arrays; lists must be sorted ascending (Knn5 is)
+__device__ __forceinline__ void wave_select5(Knn5 k, float (&od)[5], int (&oi)[5]) {
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    const float m = wave_min_f32(k.d0);
+    const unsigned long long owners = __ballot(k.d0 == m && k.i0 >= 0);
+    if (owners == 0ull) { od[r] = __builtin_inff(); oi[r] = -1; continue; }  // fewer than r + 1 candidates in total
+    const int owner = __ffsll((long long)owners) - 1;
+    od[r] = m;
+    oi[r] = __shfl(k.i0, owner);
+    if ((int)(threadIdx.x & 63) == owner) {
+      k.d0 = k.d1; k.d1 = k.d2; k.d2 = k.d3; k.d3 = k.d4; k.d4 = __builtin_inff();
+      k.i0 = k.i1; k.i1 = k.i2; k.i2 = k.i3; k.i3 = k.i4; k.i4 = -1;
+    }
+  }
+}
+__device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, float wy, float wz, float d5, float (&od)[5],
+                                                  int (&oi)[5]) {
+  const int lane = threadIdx.x & 63;
   const float bound0 = fminf(d5, g.max_d2);
   const float cs = g.cs;
   const float eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
   const float r0 = sqrtf(bound0) + 2.f * eps;
   const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
   const int X0 = cx >> kCoarseShift, Y0 = cy >> kCoarseShift, Z0 = cz >> kCoarseShift;
-  __syncthreads();  // previous query's shared data fully consumed
-  if (threadIdx.x < 27) {
-    const int c = threadIdx.x;
-    fs.block[c] = find_block(g, X0 + (c % 3) - 1, Y0 + ((c / 3) % 3) - 1, Z0 + (c / 9) - 1);
+  const int my_block = lane < 27 ? find_block(g, X0 + (lane % 3) - 1, Y0 + ((lane / 3) % 3) - 1, Z0 + (lane / 9) - 1) : -1;
+  Knn5 k;
+  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = __builtin_inff();
+  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
+  // pass 1: the 3 x 3 x 3 cells around the query, one per lane
+  {
+    const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = (lane / 9) % 3 - 1;
+    const int ixx = cx + dx, iyy = cy + dy, izz = cz + dz;
+    const int X = (ixx >> kCoarseShift) - X0 + 1, Y = (iyy >> kCoarseShift) - Y0 + 1, Z = (izz >> kCoarseShift) - Z0 + 1;
+    const int id = __shfl(my_block, Z * 9 + Y * 3 + X);  // X, Y, Z in 0..2: the neighbour cells stay inside the 3x3x3 blocks
+    if (lane < 27 && id >= 0) {
+      const float gx = axis_gap(wx, ixx, cs, eps), gy = axis_gap(wy, iyy, cs, eps), gz = axis_gap(wz, izz, cs, eps);
+      if (!(gx * gx + gy * gy + gz * gz > bound0)) {
+        const unsigned local = (((unsigned)izz & 7u) << 6) | (((unsigned)iyy & 7u) << 3) | ((unsigned)ixx & 7u);
+        const uint2 rr = g.cells[(size_t)id * kBlockCells + local];
+        scan_range(g, rr.x, rr.y, wx, wy, wz, k);
+      }
+    }
   }
-  __syncthreads();
+  wave_select5(k, od, oi);
+  const float bound1 = fminf(od[4], bound0);  // exact 5th distance over the inner cells (inf if they hold fewer than 5)
+  // pass 2: the rest of the cube around the ball of radius sqrt(bound0), pruned with bound1
   const int ix0 = cell_of(wx - r0, g.inv_cs), ix1 = cell_of(wx + r0, g.inv_cs);
   const int iy0 = cell_of(wy - r0, g.inv_cs), iy1 = cell_of(wy + r0, g.inv_cs);
   const int iz0 = cell_of(wz - r0, g.inv_cs), iz1 = cell_of(wz + r0, g.inv_cs);
@@ -635,41 +669,32 @@ __device__ __forceinline__ void knn_fallback_block(const GridView& g, FallbackSh
   const int total = nx * ny * nz;
   k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = __builtin_inff();
   k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
-  for (int c = threadIdx.x; c < total; c += kBlock) {
-    const int ixx = ix0 + c % nx, iyy = iy0 + (c / nx) % ny, izz = iz0 + c / (nx * ny);
+  {  // the inner result re-enters as five one-element lists (lanes 0..4)
+    const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
+    const int ii = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
+    if (lane < 5 && ii >= 0) { k.d0 = dd; k.i0 = ii; }
+  }
+  for (int c0 = 0; c0 < total; c0 += 64) {  // uniform trip count: the shuffle below needs every lane
+    const int c = c0 + lane;
+    const bool in = c < total;
+    const int ixx = ix0 + (in ? c % nx : 0), iyy = iy0 + (in ? (c / nx) % ny : 0), izz = iz0 + (in ? c / (nx * ny) : 0);
     const int X = (ixx >> kCoarseShift) - X0 + 1, Y = (iyy >> kCoarseShift) - Y0 + 1, Z = (izz >> kCoarseShift) - Z0 + 1;
-    if ((unsigned)X > 2u || (unsigned)Y > 2u || (unsigned)Z > 2u) continue;  // farther than 8 cells >= sqrt(max_d2)
-    const int id = fs.block[Z * 9 + Y * 3 + X];
-    if (id < 0) continue;
+    const bool in_blocks = (unsigned)X <= 2u && (unsigned)Y <= 2u && (unsigned)Z <= 2u;  // else farther than 8 cells >= sqrt(max_d2)
+    const int id = __shfl(my_block, in_blocks ? Z * 9 + Y * 3 + X : 0);
+    const bool inner = abs(ixx - cx) <= 1 && abs(iyy - cy) <= 1 && abs(izz - cz) <= 1;  // done in pass 1
+    if (!in || !in_blocks || inner || id < 0) continue;
     const float gx = axis_gap(wx, ixx, cs, eps), gy = axis_gap(wy, iyy, cs, eps), gz = axis_gap(wz, izz, cs, eps);
-    if (gx * gx + gy * gy + gz * gz > bound0) continue;
+    if (gx * gx + gy * gy + gz * gz > bound1) continue;
     const unsigned local = (((unsigned)izz & 7u) << 6) | (((unsigned)iyy & 7u) << 3) | ((unsigned)ixx & 7u);
     const uint2 rr = g.cells[(size_t)id * kBlockCells + local];
-    scan_range(g, rr.x, rr.y, wx, wy, wz, k);
+    // candidates must beat the inner 5th distance as well as the lane's own list
+    for (unsigned int j = rr.x; j < rr.y; j++) {
+      const float4 p = g.pts[j];
+      const float d = dist2_ref(wx, wy, wz, p.x, p.y, p.z);
+      if (d <= g.max_d2 && d < fminf(k.d4, bound1)) knn_insert(k, d, (int)j);
+    }
   }
-  // wave butterfly (disjoint cell sets -> no duplicates), then the 4 wave results through LDS
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    float e0 = __shfl_xor(k.d0, off), e1 = __shfl_xor(k.d1, off), e2 = __shfl_xor(k.d2, off), e3 = __shfl_xor(k.d3, off),
-          e4 = __shfl_xor(k.d4, off);
-    int j0 = __shfl_xor(k.i0, off), j1 = __shfl_xor(k.i1, off), j2 = __shfl_xor(k.i2, off), j3 = __shfl_xor(k.i3, off),
-        j4 = __shfl_xor(k.i4, off);
-    if (j0 >= 0) knn_merge_one<false>(k, e0, j0);
-    if (j1 >= 0) knn_merge_one<false>(k, e1, j1);
-    if (j2 >= 0) knn_merge_one<false>(k, e2, j2);
-    if (j3 >= 0) knn_merge_one<false>(k, e3, j3);
-    if (j4 >= 0) knn_merge_one<false>(k, e4, j4);
-  }
-  if (lane == 0) {
-    fs.d[wave][0] = k.d0; fs.d[wave][1] = k.d1; fs.d[wave][2] = k.d2; fs.d[wave][3] = k.d3; fs.d[wave][4] = k.d4;
-    fs.i[wave][0] = k.i0; fs.i[wave][1] = k.i1; fs.i[wave][2] = k.i2; fs.i[wave][3] = k.i3; fs.i[wave][4] = k.i4;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; w++)
-      for (int j = 0; j < 5; j++)
-        if (fs.i[w][j] >= 0) knn_merge_one<false>(k, fs.d[w][j], fs.i[w][j]);
-  }
+  wave_select5(k, od, oi);
 }
 
 // Equal squared distances inside the kept list are ordered by x, ascending — what the reference's heap comparator
@@ -697,7 +722,6 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
                                                         const IekfCtrl* __restrict__ ctrl, int forced, int imu_en,
                                                         double plane_thr, double rinv, int nb_real) {
   __shared__ ReduceShared sh;
-  __shared__ FallbackShared fs;
   __shared__ int s_needy[kBlock];
   __shared__ int s_nneedy;
   bool FIT;
@@ -718,27 +742,26 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
     if (live && (rb.nbr_count[i] & kNeedy)) s_needy[atomicAdd(&s_nneedy, 1)] = threadIdx.x;
     __syncthreads();
     const int nn = s_nneedy;
-    for (int e = 0; e < nn; e++) {  // rare (a handful of queries per scan); any processing order gives the same lists
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int e = wave; e < nn; e += kBlock / 64) {  // rare (~0.07 % of the queries) but clustered: four at a time, one per wavefront
       const int qi = blk * kBlock + s_needy[e];
       const float4 w4 = rb.world[qi];
       const int c0 = rb.nbr_count[qi] & 0xFF;
       const float d5 = c0 == kMatch ? rb.nbr[(size_t)4 * rb.cap + qi].w : __builtin_inff();
-      Knn5 k;
-      knn_fallback_block(g, fs, w4.x, w4.y, w4.z, d5, k);
-      if (threadIdx.x == 0) {
-        const int ids[5] = {k.i0, k.i1, k.i2, k.i3, k.i4};
-        const float ds[5] = {k.d0, k.d1, k.d2, k.d3, k.d4};
-        int found = 0;
-        for (int j = 0; j < 5; j++) {
-          float4 v = ids[j] >= 0 ? g.pts[ids[j]] : make_float4(0, 0, 0, 0);
-          v.w = ds[j];
-          rb.nbr[(size_t)j * rb.cap + qi] = v;
-          found += ids[j] >= 0;
-        }
-        rb.nbr_count[qi] = found;
+      float od[5];
+      int oi[5];
+      knn_fallback_wave(g, w4.x, w4.y, w4.z, d5, od, oi);
+      const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
+      const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
+      if (lane < 5) {
+        float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
+        v.w = dd;
+        rb.nbr[(size_t)lane * rb.cap + qi] = v;
+      } else if (lane == 5) {
+        rb.nbr_count[qi] = (oi[0] >= 0) + (oi[1] >= 0) + (oi[2] >= 0) + (oi[3] >= 0) + (oi[4] >= 0);
       }
     }
-    if (nn) __syncthreads();  // thread 0's lists are visible to their owners (workgroup-scope release/acquire)
+    if (nn) __syncthreads();  // the completed lists are visible to their owners (workgroup-scope release/acquire)
   }
   RowOut o;
 #pragma unroll
