@@ -20,6 +20,10 @@
 
 using namespace lii;
 
+namespace {
+constexpr size_t kCtrlBytes = (sizeof(IekfCtrl) + 255) / 256 * 256;
+}
+
 struct lii_context {
   lii_config cfg{};
   int device = 0;
@@ -64,7 +68,8 @@ struct lii_context {
   PoseArg* d_pose = nullptr;    // pose slot of the host-driven lii_iekf_iterate
   IekfCtrl* h_ctrl = nullptr;   // pinned upload image
   IekfResult* h_res = nullptr;  // pinned, device-mapped: written by the solve kernel of the stopping iteration
-  lii_pose6d* h_poses = nullptr;  // pinned staging of the IMU pose table
+  lii_pose6d* h_poses = nullptr;  // pinned staging of the IMU pose table (lives behind h_ctrl: one upload can carry both)
+  bool poses_preloaded = false, ctrl_preloaded = false;  // lii_scan_register uploaded them already
   hipEvent_t ev_poses = nullptr;  // the last pose-table upload
   hipEvent_t ev_stage = nullptr;  // the last scan upload through h_stage
   bool host_solve = false;      // LII_HOST_SOLVE=1: drive the loop from the host (A/B, reference arrangement)
@@ -342,13 +347,7 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
 // The whole iterated update enqueued once: prologue (P^-1), then max_iterations x {k-NN, fallback, fit+reduce,
 // final reduce, 24-state solve}; every kernel consults the device-resident control block and returns at once when
 // its pass is not due (no search scheduled / loop already stopped).  One synchronisation at the end.
-int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop, const lii_iekf_opts* opts,
-                     lii_iekf_report* report) {
-  static_assert(sizeof(lii_state) == sizeof(double) * kStateDoubles, "lii_state layout");
-  if (h->n_body <= 0) return fail(h, LII_ERR_STATE, "no down-sampled scan (call lii_downsample / lii_downsample_skip)");
-  int rc = commit_map(h);
-  if (rc != LII_OK) return rc;
-  hipStream_t s = h->stream;
+void fill_ctrl(lii_handle h, const lii_state* state, const lii_state* state_prop, const lii_iekf_opts* opts) {
   IekfCtrl* hc = h->h_ctrl;
   std::memcpy(hc->st, state, sizeof(lii_state));
   std::memcpy(hc->prop, state_prop, sizeof(hc->prop));
@@ -356,9 +355,22 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   hc->imu_en = opts->imu_en;
   hc->it = 0; hc->search_next = 1; hc->stop = 0; hc->rematch_num = 0; hc->converged = 0; hc->searches = 0;
   hc->effect_num = 0; hc->singular = 0;
+}
+
+int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop, const lii_iekf_opts* opts,
+                     lii_iekf_report* report) {
+  static_assert(sizeof(lii_state) == sizeof(double) * kStateDoubles, "lii_state layout");
+  if (h->n_body <= 0) return fail(h, LII_ERR_STATE, "no down-sampled scan (call lii_downsample / lii_downsample_skip)");
+  int rc = commit_map(h);
+  if (rc != LII_OK) return rc;
+  hipStream_t s = h->stream;
+  if (!h->ctrl_preloaded) {
+    fill_ctrl(h, state, state_prop, opts);
+    HIPCHK(h, hipMemcpyAsync(h->d_ctrl, h->h_ctrl, sizeof(IekfCtrl), hipMemcpyHostToDevice, s));
+  }
+  h->ctrl_preloaded = false;
   h->h_res->singular = 0;
   h->h_res->it = -1;  // overwritten by the stopping iteration
-  HIPCHK(h, hipMemcpyAsync(h->d_ctrl, hc, sizeof(IekfCtrl), hipMemcpyHostToDevice, s));
   GridView g = grid_view(h);
   RegistrationBuffers rb = reg_buffers(h);
   const PoseArg* pose = reinterpret_cast<const PoseArg*>(h->d_ctrl);  // first 24 doubles of IekfCtrl::st
@@ -542,12 +554,18 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_plane, N * 4));
   CK(dmalloc(&h->d_selected, N));
   CK(dmalloc(&h->d_nbody, 4));
-  CK(dmalloc(&h->d_ctrl, 1));
+  {
+    // control block and pose table share one allocation so that lii_scan_register uploads both with one copy
+    void* p = nullptr;
+    CK(hipMalloc(&p, kCtrlBytes + sizeof(lii_pose6d) * 1024));
+    h->d_ctrl = static_cast<IekfCtrl*>(p);
+    h->d_poses = reinterpret_cast<double*>(static_cast<char*>(p) + kCtrlBytes);
+  }
   CK(dmalloc(&h->d_pose, 1));
-  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_ctrl), sizeof(IekfCtrl), hipHostMallocDefault));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_ctrl), kCtrlBytes + sizeof(lii_pose6d) * 1024, hipHostMallocDefault));
+  h->h_poses = reinterpret_cast<lii_pose6d*>(reinterpret_cast<char*>(h->h_ctrl) + kCtrlBytes);
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_res), sizeof(IekfResult), hipHostMallocMapped));
   std::memset(h->h_res, 0, sizeof(IekfResult));
-  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_poses), sizeof(lii_pose6d) * 1024, hipHostMallocDefault));
   CK(hipEventCreateWithFlags(&h->ev_poses, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
   CK(hipMemset(h->d_counter, 0, 16));
@@ -567,7 +585,6 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_vidx_a, N));
   CK(dmalloc(&h->d_vidx_b, N));
   CK(dmalloc(&h->d_vranks, N));
-  CK(dmalloc(&h->d_poses, 22 * 1024));
   CK(dmalloc(&h->d_cal_params, 64));
   CK(dmalloc(&h->d_cal_out, 128));
   h->h_stage_elems = NM * kMatch;  // large enough for the neighbour download too
@@ -590,7 +607,7 @@ int lii_destroy(lii_handle h) {
   void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
-                 h->d_vidx_b, h->d_vranks, h->d_poses, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
+                 h->d_vidx_b, h->d_vranks, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -599,7 +616,6 @@ int lii_destroy(lii_handle h) {
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
   if (h->h_res) (void)hipHostFree(h->h_res);
-  if (h->h_poses) (void)hipHostFree(h->h_poses);
   if (h->ev_poses) (void)hipEventDestroy(h->ev_poses);
   if (h->ev_stage) (void)hipEventDestroy(h->ev_stage);
   if (h->n_map_pinned) (void)hipHostFree(h->n_map_pinned);
@@ -733,10 +749,13 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
     return fail(h, LII_ERR_INVALID, "lii_undistort_imu: bad arguments");
   static_assert(sizeof(lii_pose6d) == 22 * sizeof(double), "lii_pose6d layout");
   if (h->n_scan <= 0 || n_poses < 2) return LII_OK;  // nothing to compensate (IMUpose needs a head and a tail)
-  HIPCHK(h, hipEventSynchronize(h->ev_poses));  // the previous table has left the staging buffer (normally long ago)
-  std::memcpy(h->h_poses, poses, sizeof(lii_pose6d) * size_t(n_poses));
-  HIPCHK(h, hipMemcpyAsync(h->d_poses, h->h_poses, sizeof(lii_pose6d) * size_t(n_poses), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipEventRecord(h->ev_poses, h->stream));
+  if (!h->poses_preloaded) {
+    HIPCHK(h, hipEventSynchronize(h->ev_poses));  // the previous table has left the staging buffer (normally long ago)
+    std::memcpy(h->h_poses, poses, sizeof(lii_pose6d) * size_t(n_poses));
+    HIPCHK(h, hipMemcpyAsync(h->d_poses, h->h_poses, sizeof(lii_pose6d) * size_t(n_poses), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_poses, h->stream));
+  }
+  h->poses_preloaded = false;
   UndistArgH u;
   std::memcpy(u.endR, end_R, 72);
   std::memcpy(u.endp, end_p, 24);
@@ -918,6 +937,16 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   if (!h || !job || job->struct_size != sizeof(lii_scan_job) || !state || !state_prop || job->opts.max_iterations < 1)
     return fail(h, LII_ERR_INVALID, "lii_scan_register: bad arguments");
   int rc = LII_OK;
+  if (job->undistort == 1 && !h->host_solve && job->imu_poses && job->n_imu_poses >= 2 && job->n_imu_poses <= 1024 && h->n_scan > 0) {
+    // one H2D copy for the control block of the update AND the pose table of the de-skew (they sit behind each other)
+    HIPCHK(h, hipEventSynchronize(h->ev_poses));
+    fill_ctrl(h, state, state_prop, &job->opts);
+    std::memcpy(h->h_poses, job->imu_poses, sizeof(lii_pose6d) * size_t(job->n_imu_poses));
+    HIPCHK(h, hipMemcpyAsync(h->d_ctrl, h->h_ctrl, kCtrlBytes + sizeof(lii_pose6d) * size_t(job->n_imu_poses), hipMemcpyHostToDevice,
+                             h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_poses, h->stream));
+    h->poses_preloaded = h->ctrl_preloaded = true;
+  }
   if (job->undistort == 1) {
     rc = lii_undistort_imu(h, job->imu_poses, job->n_imu_poses, state->rot_end, state->pos_end, state->offset_R_L_I,
                            state->offset_T_L_I);
@@ -926,10 +955,10 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   } else if (job->undistort != 0) {
     return fail(h, LII_ERR_INVALID, "lii_scan_register: undistort must be 0, 1 or 2");
   }
-  if (rc != LII_OK) return rc;
-  rc = job->leaf > 0 ? lii_downsample(h, job->leaf, nullptr, nullptr) : lii_downsample_skip(h, nullptr);
-  if (rc != LII_OK) return rc;
-  return lii_iekf_update(h, state, state_prop, &job->opts, report);
+  if (rc == LII_OK) rc = job->leaf > 0 ? lii_downsample(h, job->leaf, nullptr, nullptr) : lii_downsample_skip(h, nullptr);
+  if (rc == LII_OK) rc = lii_iekf_update(h, state, state_prop, &job->opts, report);
+  h->poses_preloaded = h->ctrl_preloaded = false;  // also on the error paths
+  return rc;
 }
 
 int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* selected, int32_t capacity) {
