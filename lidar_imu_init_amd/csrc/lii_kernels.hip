@@ -129,12 +129,14 @@ struct Knn5 {
 };
 
 __device__ __forceinline__ void knn_insert(Knn5& k, float d, int j) {
-  // strict '<' keeps the earlier-visited candidate on exact ties (ikd_Tree.cpp:842)
-  k.d4 = d; k.i4 = j;
-  if (k.d4 < k.d3) { float t = k.d3; k.d3 = k.d4; k.d4 = t; int u = k.i3; k.i3 = k.i4; k.i4 = u; } else return;
-  if (k.d3 < k.d2) { float t = k.d2; k.d2 = k.d3; k.d3 = t; int u = k.i2; k.i2 = k.i3; k.i3 = u; } else return;
-  if (k.d2 < k.d1) { float t = k.d1; k.d1 = k.d2; k.d2 = t; int u = k.i1; k.i1 = k.i2; k.i2 = u; } else return;
-  if (k.d1 < k.d0) { float t = k.d0; k.d0 = k.d1; k.d1 = t; int u = k.i0; k.i0 = k.i1; k.i1 = u; }
+  // precondition d < k.d4.  Strict '<' keeps the earlier-visited candidate on exact ties (ikd_Tree.cpp:842).  Branch-free:
+  // in a wavefront some lane almost always takes the longest path of a compare-and-return chain anyway.
+  const bool c3 = d < k.d3, c2 = d < k.d2, c1 = d < k.d1, c0 = d < k.d0;
+  k.d4 = c3 ? k.d3 : d;                 k.i4 = c3 ? k.i3 : j;
+  k.d3 = c2 ? k.d2 : (c3 ? d : k.d3);   k.i3 = c2 ? k.i2 : (c3 ? j : k.i3);
+  k.d2 = c1 ? k.d1 : (c2 ? d : k.d2);   k.i2 = c1 ? k.i1 : (c2 ? j : k.i2);
+  k.d1 = c0 ? k.d0 : (c1 ? d : k.d1);   k.i1 = c0 ? k.i0 : (c1 ? j : k.i1);
+  k.d0 = c0 ? d : k.d0;                 k.i0 = c0 ? j : k.i0;
 }
 
 __device__ __forceinline__ float axis_gap(float q, int c, float cs, float eps) {
