@@ -704,6 +704,7 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
 // Nearest_Search pops it.  (A tie across the 5th/6th place is resolved by visiting order in the tree and by
 // cell order here; that case cannot be reproduced and is documented in DESIGN.md.)
 __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
+  if (!(nb[0].w == nb[1].w || nb[1].w == nb[2].w || nb[2].w == nb[3].w || nb[3].w == nb[4].w)) return false;  // the usual case
   bool changed = false;
 #pragma unroll
   for (int pass = 0; pass < 4; pass++)
