@@ -122,7 +122,8 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   __shared__ double G[H * LDH];    // H^T R^-1 H
   __shared__ double A[H * LDH];    // I + P11 G, later M
   __shared__ double K1c[N * LDH];  // K_1[:, :12]
-  __shared__ double vec[N], sol[N], s_KH[N * H];
+  __shared__ double vec[N], sol[N], s_u[H], s_KH[N * H];
+  __shared__ double s_x[N * N];    // (I - K H) P before it is symmetrised (stopping iteration only)
   __shared__ double s_ne[96], s_st[36], s_prop[36];
   __shared__ int s_int[12];
   const int lane = threadIdx.x;
@@ -138,19 +139,6 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   }
   __syncthreads();
   if (s_int[4]) return;  // EKF_stop_flg already set: this pass is not due
-  // the prior enters as its symmetric part: K_1[:, :12] = P[:, :12] M^T below relies on P11 = P11^T, and whatever asymmetry
-  // (I - K H) P picks up from rounding must not feed back into the next scan's gain (it compounds otherwise: the pose block
-  // of P grew to 0.4 within 200 scans of a LIO run, the literal two-inversion algebra stays at 4e-5).  Done in LDS: the
-  // transposed global reads would not coalesce.
-  for (int e = lane; e < N * N; e += 64) {
-    const int r = e / N, cc = e % N;
-    if (r < cc) {
-      const double a = 0.5 * (s_cov[e] + s_cov[cc * N + r]);
-      s_cov[e] = a;
-      s_cov[cc * N + r] = a;
-    }
-  }
-  __syncthreads();
   LII_TS(1);
   const int max_it = s_int[0], it = s_int[2], search_now = s_int[3], stop = s_int[4], rematch0 = s_int[5], searches0 = s_int[7];
   if (stop) return;
@@ -185,52 +173,40 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   }
   __syncthreads();
   LII_TS(3);
-  // M = A^-1 : lanes 0..11 hold the columns of A, lanes 12..23 those of I
+  // K_1[:, :12]^T = A^-1 P[:12, :]  (A = I + P11 G;  K_1[:, :12] = P[:, :12] (I + G P11)^-1 and G, P symmetric).  Gauss-Jordan
+  // on [A | P[:12, :]]: lanes 0..11 hold the columns of A, lanes 12..35 the 24 columns of P[:12, :]; afterwards lane 12 + j
+  // holds row j of K_1[:, :12].  One elimination gives the gain directly — no inverse to store, no product — and no
+  // subtraction of nearly equal terms: the algebraically equal form [M P11 ; P21 - P21 G M P11] cancels catastrophically once
+  // the pose block of P has collapsed (1e-8) next to velocity / bias blocks of order 1, the regime of the LIO phase.
   double col[H];
 #pragma unroll
-  for (int r = 0; r < H; r++) col[r] = lane < H ? A[r * LDH + lane] : ((lane < 2 * H && r == lane - H) ? 1.0 : 0.0);
+  for (int r = 0; r < H; r++) col[r] = lane < H ? A[r * LDH + lane] : (lane < H + N ? s_cov[r * N + (lane - H)] : 0.0);
   const bool ok = gj12(col);
   if (!ok) {
     if (lane == 0) { c->stop = 1; c->singular = 1; res->singular = 1; }
     return;
   }
-  __syncthreads();
   LII_TS(4);
-  if (lane >= H && lane < 2 * H) {
+  if (lane >= H && lane < H + N) {
 #pragma unroll
-    for (int r = 0; r < H; r++) A[r * LDH + (lane - H)] = col[r];  // A now holds M
+    for (int r = 0; r < H; r++) K1c[(lane - H) * LDH + r] = col[r];
+  }
+  // u = H^T R^-1 z - G vec[:12]  (then solution = K_1[:, :12] u + vec, the reference's K z + vec - K H vec[:12] regrouped)
+  if (lane < H) {
+    double s2 = s_ne[78 + lane];
+#pragma unroll
+    for (int k = 0; k < H; k++) s2 -= G[lane * LDH + k] * vec[k];
+    s_u[lane] = s2;
   }
   __syncthreads();
   LII_TS(5);
-  // K_1[:, :12] = P[:, :12] (I + G P11)^-1 = P[:, :12] M^T   (G and P11 symmetric).  One product, and no subtraction of
-  // nearly equal terms: the algebraically equal form P21 - P21 G M P11 cancels catastrophically once the pose block of P has
-  // collapsed (1e-8) next to velocity / bias blocks of order 1 — the regime of the LIO phase.
-  for (int e = lane; e < N * H; e += 64) {
-    const int r = e / H, j = e % H;
-    double s = 0;
-#pragma unroll
-    for (int k = 0; k < H; k++) s += s_cov[r * N + k] * A[j * LDH + k];
-    K1c[r * LDH + j] = s;
-  }
-  __syncthreads();
   LII_TS(6);
   LII_TS(7);
-  // K H = K1c G ;  solution = K1c (H^T R^-1 z) + vec - (K H) vec[:12]
-  for (int e = lane; e < N * H; e += 64) {
-    const int r = e / H, cc = e % H;
-    double s2 = 0;
-#pragma unroll
-    for (int k = 0; k < H; k++) s2 += K1c[r * LDH + k] * G[k * LDH + cc];
-    s_KH[e] = s2;
-  }
-  __syncthreads();
   if (lane < N) {
-    const int r = lane;
-    double kz = 0;
-    for (int cc = 0; cc < H; cc++) kz += K1c[r * LDH + cc] * s_ne[78 + cc];
-    double khv = 0;
-    for (int cc = 0; cc < H; cc++) khv += s_KH[r * H + cc] * vec[cc];
-    sol[r] = kz + vec[r] - khv;
+    double s2 = vec[lane];
+#pragma unroll
+    for (int k = 0; k < H; k++) s2 += K1c[lane * LDH + k] * s_u[k];
+    sol[lane] = s2;
   }
   __syncthreads();
   LII_TS(8);
@@ -281,16 +257,36 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   }
   LII_TS(9);
   if (do_cov) {
+    // K H = K_1[:, :12] G, needed for the covariance only
+    for (int e = lane; e < N * H; e += 64) {
+      const int r = e / H, cc = e % H;
+      double s2 = 0;
+#pragma unroll
+      for (int k = 0; k < H; k++) s2 += K1c[r * LDH + k] * G[k * LDH + cc];
+      s_KH[e] = s2;
+    }
+    __syncthreads();
     // state.cov = (I - K H) cov = cov - (K H) cov[0:12, :]   (:1111-1114), all operands already in LDS
-    double* covw = c->st + 36;
 #pragma unroll
     for (int q = 0; q < 9; q++) {
       const int e = lane + 64 * q;
       const int r = e / N, cc = e % N;
       double s2 = s_cov[e];
       for (int k = 0; k < H; k++) s2 -= s_KH[r * H + k] * s_cov[k * N + cc];
-      covw[e] = s2;
-      res->st[36 + e] = s2;
+      s_x[e] = s2;
+    }
+    __syncthreads();
+    // the posterior leaves as its symmetric part: the gain above relies on P = P^T, and whatever asymmetry rounding puts into
+    // (I - K H) P must not feed back into the next scan's gain (it compounds otherwise: the pose block of P grew to 0.4 within
+    // 200 scans of a LIO run; the literal two-inversion algebra stays at 4e-5)
+    double* covw = c->st + 36;
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+      const int e = lane + 64 * q;
+      const int r = e / N, cc = e % N;
+      const double v = 0.5 * (s_x[e] + s_x[cc * N + r]);
+      covw[e] = v;
+      res->st[36 + e] = v;
     }
     for (int e = lane; e < 91; e += 64) res->ne[e] = s_ne[e];
     if (lane < 16) res->search_log[lane] = (lane < it) ? c->search_log[lane] : (lane == it ? search_now : 0);
