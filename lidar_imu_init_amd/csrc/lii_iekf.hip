@@ -3,8 +3,8 @@
 // Reference code replaced (src/laserMapping.cpp): K_1 = (H^T R^-1 H (+) 0 + P^-1)^-1 and the state update :1080-1087,
 // convergence test :1093-1096, rematch schedule :1102-1106, covariance update :1109-1131;
 // StatesGroup boxplus/boxminus include/common_lib.h:126-154; Exp/Log include/so3_math.h:61-107.
-// The arithmetic mirrors lii_hostmath.h operation for operation (LU with partial pivoting, same loop orders), so the
-// device-driven and the host-driven update agree to rounding of sin/cos/acos.
+// The gain is evaluated in an algebraically equal but better-conditioned form than the reference's (see below); the
+// host-driven update (lii_hostmath.h, LII_HOST_SOLVE=1) keeps the literal form, and both are held to the oracle in the tests.
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <cstring>
@@ -23,14 +23,14 @@ constexpr int LDH = 13;  // padded leading dimension of the 12-column LDS tiles
 // E = [I_12; 0] and P = [P11 P12; P21 P22]:
 //     K_1 = (P^-1 + E G E^T)^-1 = (I + P E G E^T)^-1 P,     I + P E G E^T = [ I + P11 G   0 ]
 //                                                                            [   P21 G     I ]
-//  => K_1[:, :12] = [ M P11 ; P21 - P21 G M P11 ] = P[:, :12] (I + G P11)^-1 = P[:, :12] M^T,   M = (I + P11 G)^-1
-//     (eigenvalues of P11 G are >= 0: always regular; the last form is the one evaluated — see the kernel).
-// This is the reference's formula (src/laserMapping.cpp:1081) in exact arithmetic, with ONE 12 x 12 inversion instead of
-// two 24 x 24 ones (the reference's own route loses ~cond(P) eps); the host-driven path (LII_HOST_SOLVE=1) keeps the
-// literal two-inversion form, and tests/test_gpu_register.py holds both to the oracle.
+//  => K_1[:, :12] = [ M P11 ; P21 - P21 G M P11 ] = P[:, :12] (I + G P11)^-1,   M = (I + P11 G)^-1
+//     (eigenvalues of P11 G are >= 0: always regular), i.e.  K_1[:, :12]^T = (I + P11 G)^-1 P[:12, :]  for symmetric P, G.
+// This is the reference's formula (src/laserMapping.cpp:1081) in exact arithmetic, with ONE 12-step elimination instead of
+// two 24 x 24 inversions (the reference's own route loses ~cond(P) eps).
 //
-// 12 x 12 Gauss-Jordan with partial pivoting, register resident: lane c < 24 owns column c of [A | I]; the multiplier
-// column is broadcast with constant-lane shuffles, all register indices are static (fully unrolled).
+// Gauss-Jordan with partial pivoting on a 12-row system, register resident: every lane owns one column of the augmented
+// matrix (12 of A + the right-hand sides); the multiplier column is broadcast with v_readlane, all register indices are
+// static (fully unrolled).
 __device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane is wave-uniform (a constant after unrolling)
   union { double d; int i[2]; } u;
   u.d = v;
