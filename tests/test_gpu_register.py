@@ -164,3 +164,29 @@ def test_sparse_and_empty_neighbourhoods(reg, oracle):
     for k in range(5):
         m = cnt > k
         assert np.array_equal(nb[m, k], ref["nearest"][m, k])
+
+
+def test_communicator_path_world_size_one(oracle, small_world):
+    """With a communicator attached the loop runs as separate final-sum / RCCL all-reduce / solve launches; at world size 1
+    the all-reduce is the identity, so the result must be BIT-identical to the fused single-GPU loop."""
+    import lidar_imu_init_amd as lii
+    hall, map_pts = small_world
+    scan, R, p = _scan(small_world, "vlp16", seed=31)
+    st_true = make_state(oracle, R, p)
+    st0 = oracle.state_boxplus(st_true, np.r_[0.003, -0.002, 0.004, 0.03, -0.02, 0.01, np.zeros(18)])
+    out = []
+    for comm in (False, True):
+        r = lii.Registrar(max_scan_points=40_000, max_map_points=400_000, filter_size_map=0.15)
+        r.map_build(map_pts)
+        if comm:
+            r.comm_init(1, 0, r.comm_unique_id())
+        r.scan_upload(scan)
+        r.downsample_skip()
+        s = lii.State(st0)
+        rep = r.iekf_update(s, lii.State(st0), max_iterations=5, imu_en=True)
+        sums = r.iekf_iterate(s, True, True)  # the host-driven single pass goes through the all-reduce as well
+        out.append((s.pod.copy(), rep, sums))
+        r.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert out[0][1]["iterations"] == out[1][1]["iterations"] and np.array_equal(out[0][1]["normal_eq"], out[1][1]["normal_eq"])
+    assert np.array_equal(out[0][2], out[1][2])
