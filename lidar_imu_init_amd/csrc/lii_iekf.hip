@@ -142,10 +142,10 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   LII_TS(1);
   const int max_it = s_int[0], it = s_int[2], search_now = s_int[3], stop = s_int[4], rematch0 = s_int[5], searches0 = s_int[7];
   if (stop) return;
+  // upper-triangle index t -> (i, j), packed i * 16 + j
+  static const unsigned char kTri[78] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58, 59, 68, 69, 70, 71, 72, 73, 74, 75, 85, 86, 87, 88, 89, 90, 91, 102, 103, 104, 105, 106, 107, 119, 120, 121, 122, 123, 136, 137, 138, 139, 153, 154, 155, 170, 171, 187};
   for (int t = lane; t < 78; t += 64) {
-    int rem = t, i = 0;
-    while (rem >= H - i) { rem -= H - i; i++; }
-    const int j = i + rem;
+    const int i = kTri[t] >> 4, j = kTri[t] & 15;
     G[i * LDH + j] = s_ne[t];
     G[j * LDH + i] = s_ne[t];
   }
