@@ -472,6 +472,41 @@ __device__ __forceinline__ uint2 lookup_cell(const GridView& g, const uint4* __r
   return g.cells[(size_t)e.z * kBlockCells + local];
 }
 
+// NC cell lookups with their loads issued as two batches (first probes of all block-table slots, then all cell entries)
+// instead of NC dependent probe -> entry chains; a probe that hits a foreign key walks on alone (load factor <= 1/8: rare).
+template <int NC>
+__device__ __forceinline__ void lookup_cells_batched(const GridView& g, const uint4* __restrict__ tab, const int (&ix)[NC],
+                                                     const int (&iy)[NC], const int (&iz)[NC], const bool (&want)[NC],
+                                                     uint2 (&out)[NC]) {
+  const int bb = kCellBias >> kCoarseShift;
+  unsigned long long bk[NC];
+  unsigned int sl[NC];
+  uint4 e[NC];
+#pragma unroll
+  for (int t = 0; t < NC; t++) {
+    const int bx = (ix[t] >> kCoarseShift) + bb, by = (iy[t] >> kCoarseShift) + bb, bz = (iz[t] >> kCoarseShift) + bb;
+    bk[t] = pack_block(bx, by, bz);
+    sl[t] = hash_block(bx, by, bz) & g.block_mask;
+  }
+#pragma unroll
+  for (int t = 0; t < NC; t++) e[t] = want[t] ? tab[sl[t]] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+  unsigned int ci[NC];
+  bool hit[NC];
+#pragma unroll
+  for (int t = 0; t < NC; t++) {
+    unsigned long long ek = ((unsigned long long)e[t].y << 32) | e[t].x;
+    while (want[t] && ek != bk[t] && ek != kEmptyKey) {
+      sl[t] = (sl[t] + 1) & g.block_mask;
+      e[t] = tab[sl[t]];
+      ek = ((unsigned long long)e[t].y << 32) | e[t].x;
+    }
+    hit[t] = want[t] && ek == bk[t];
+    ci[t] = e[t].z * (unsigned)kBlockCells + ((((unsigned)iz[t] & 7u) << 6) | (((unsigned)iy[t] & 7u) << 3) | ((unsigned)ix[t] & 7u));
+  }
+#pragma unroll
+  for (int t = 0; t < NC; t++) out[t] = hit[t] ? g.cells[ci[t]] : make_uint2(0u, 0u);
+}
+
 template <int LPQ, bool DEDUP>
 __device__ __forceinline__ void knn_group_merge_n(Knn5& k) {
 #pragma unroll
@@ -532,10 +567,16 @@ __global__ __launch_bounds__(kBlock) void k_knn_pruned(GridView g, RegistrationB
   if (active) {
     // the 8 cells of round 1 are dealt to the LPQ lanes; lookups first, then the candidate loops
     uint2 r[8 / LPQ];
+    {
+      int jx[8 / LPQ], jy[8 / LPQ], jz[8 / LPQ];
+      bool want[8 / LPQ];
 #pragma unroll
-    for (int t = 0; t < 8 / LPQ; t++) {
-      const int c = sub + LPQ * t;
-      r[t] = lookup_cell(g, tab, cx + ((c & 1) ? ox : 0), cy + ((c & 2) ? oy : 0), cz + ((c & 4) ? oz : 0));
+      for (int t = 0; t < 8 / LPQ; t++) {
+        const int c = sub + LPQ * t;
+        jx[t] = cx + ((c & 1) ? ox : 0); jy[t] = cy + ((c & 2) ? oy : 0); jz[t] = cz + ((c & 4) ? oz : 0);
+        want[t] = true;
+      }
+      lookup_cells_batched<8 / LPQ>(g, tab, jx, jy, jz, want, r);
     }
 #pragma unroll
     for (int t = 0; t < 8 / LPQ; t++) scan_range(g, r[t].x, r[t].y, wx, wy, wz, k);
