@@ -18,6 +18,7 @@
 #include <string.h>
 #include <cstring>
 #include <math.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "lii_device.h"
@@ -526,15 +527,15 @@ __device__ __forceinline__ void knn_group_merge_n(Knn5& k) {
 // `forced` >= 0: host-driven pass (always runs).  forced < 0: device-driven loop — runs only when the control block
 // says the next pass searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).
 // A query whose 3x3x3 block cannot prove its list complete is flagged in nbr_count (kNeedy); k_fit_reduce finishes it.
-template <int LPQ>
-__global__ __launch_bounds__(kBlock) void k_knn_pruned(GridView g, RegistrationBuffers rb, PoseArg ps_val,
+template <int LPQ, int BS>
+__global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffers rb, PoseArg ps_val,
                                                    const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
                                                    int forced, int nb_real) {
   if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
   const PoseArg ps = forced < 0 ? *pose : ps_val;
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;
-  constexpr int QPB = kBlock / LPQ;
+  constexpr int QPB = BS / LPQ;
   const int sub = threadIdx.x & (LPQ - 1);
   const int qi = blk * QPB + threadIdx.x / LPQ;
   const bool live = qi < (rb.n_dev ? *rb.n_dev : rb.n);
@@ -644,8 +645,6 @@ __global__ __launch_bounds__(kBlock) void k_knn_pruned(GridView g, RegistrationB
   }
 }
 
-template __global__ void k_knn_pruned<8>(GridView, RegistrationBuffers, PoseArg, const PoseArg*, const IekfCtrl*, int, int);
-template __global__ void k_knn_pruned<4>(GridView, RegistrationBuffers, PoseArg, const PoseArg*, const IekfCtrl*, int, int);
 
 // Second stage of the search for a flagged query, run by ONE WAVEFRONT (four flagged queries of a workgroup proceed
 // concurrently): every cell that intersects the ball of radius sqrt(min(d5 of stage 1, max_d2)) is visited — looked up through
@@ -1284,19 +1283,22 @@ void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks
   if (n > 0) hipLaunchKernelGGL(k_cells_fill, dim3(nblk(n, 256)), dim3(256), 0, s, keys, ranks, n, blocks, block_mask, cells);
 }
 int register_blocks(int n) { return nblk(n, kBlock); }
-void launch_knn8p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                  const IekfCtrl* ctrl, int forced, hipStream_t s) {
-  int nq = nblk(rb.n, kBlock / 8);
+template <int LPQ, int BS>
+static void launch_knn_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                         const IekfCtrl* ctrl, int forced, hipStream_t s) {
+  int nq = nblk(rb.n, BS / LPQ);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_knn_pruned<8>, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
+  hipLaunchKernelGGL((k_knn_pruned<LPQ, BS>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq);
+}
+void launch_knn8p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                  const IekfCtrl* ctrl, int forced, hipStream_t s) {
+  launch_knn_t<8, 256>(g, rb, ps, pose, ctrl, forced, s);
 }
 void launch_knn4p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                   const IekfCtrl* ctrl, int forced, hipStream_t s) {
-  int nq = nblk(rb.n, kBlock / 4);
-  if (nq < 1) nq = 1;
-  const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_knn_pruned<4>, dim3(nq_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, nq);
+  // 128-thread workgroups: measured 29.3 us per pass against 30.3 us at 256 (shorter tail), 64 is no better.
+  launch_knn_t<4, 128>(g, rb, ps, pose, ctrl, forced, s);
 }
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s) {
