@@ -92,10 +92,19 @@ def main():
     import torch  # device sync + torch.distributed rendezvous only (plumbing)
     import lidar_imu_init_amd as lii
     dist = None
+    # LII_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank path on a single-GPU box (every rank drives device 0, rendezvous
+    # over gloo; RCCL refuses two ranks on one device, the library's node-local mailbox transport does not).  The ranks
+    # then time-share one GPU: the line it prints proves the path, it is not a scaling number.
+    one_device = world > 1 and os.environ.get("LII_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = build_workload(args.workload, args.scans)
     n_full = max(len(s) for s in wl["scans"])
@@ -186,7 +195,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_device else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     tm = reg.timings()
@@ -218,7 +227,7 @@ def main():
             "config": {"workload": f"{args.workload}: {n_full} pts/scan vs {M}-pt local map, max_iteration {wl['max_it']}, "
                                    f"LIO mode (12-col H), {'map_incremental every step' if args.map_update else 'static map'}, {'voxel-grid leaf %.2f' % wl['fs_surf'] if not args.no_downsample else 'no voxel-grid'}",
                        "points_per_scan": n_full, "map_points": M, "avg_iterations": iters_total[0] / args.steps,
-                       "avg_knn_passes": search_total[0] / args.steps, "parallelism": f"points sharded x{world}"},
+                       "avg_knn_passes": search_total[0] / args.steps, "parallelism": f"points sharded x{world}" + (f", 91-scalar exchange over {reg.comm_transport()}" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_knn_pruned<4> (exact 5-NN into the block-grid local map, 4 lanes/query, box-distance pruning)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": avg_search_ms, "alg_bytes_per_launch": alg_bytes,

@@ -264,10 +264,20 @@ int lii_li_init_run(lii_handle h, const lii_calib_state* imu, const lii_calib_st
 
 /* ---------------------------------------------------------------- multi-GPU (points of one scan sharded across ranks)
  * One process per GPU.  Rank 0 creates an id, the caller ships the 128 bytes to the other ranks (e.g.
- * torch.distributed broadcast), every rank calls lii_comm_init; afterwards lii_iekf_iterate/update
- * all-reduce the 91 normal-equation scalars (fp64 sum) over RCCL on the handle's stream. */
+ * torch.distributed broadcast), every rank calls lii_comm_init with the SAME state / options per scan; afterwards
+ * lii_iekf_iterate / lii_iekf_update / lii_scan_register sum the 91 normal-equation scalars (fp64, in rank order, so every
+ * rank forms the bit-identical sum and takes the same decisions) over the ranks.  Two transports:
+ *   LII_COMM_MAILBOX  ranks of ONE node meet in a shared-memory segment that each registers with its device; the exchange
+ *                     runs inside the reduce+solve kernel (no extra launch, no collective-library call; ~5 us).
+ *   LII_COMM_RCCL     ncclAllReduce on the handle's stream between a separate final-sum and solve launch (any topology).
+ *   LII_COMM_AUTO     mailbox when all ranks meet in the segment within LII_MAILBOX_WAIT_S (default 20 s), else RCCL.
+ * A rank that stops calling (error on one rank only) makes the others' next update fail with LII_ERR_COMM after
+ * LII_MAILBOX_TIMEOUT_S (default 30 s; RCCL: its own watchdog); the communicator must then be re-created.  lii_comm_init == lii_comm_init_ex(..., LII_COMM_AUTO). */
+enum { LII_COMM_AUTO = 0, LII_COMM_RCCL = 1, LII_COMM_MAILBOX = 2 };
 int lii_comm_unique_id(uint8_t id_out[128]);
 int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id[128]);
+int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id[128], int32_t transport);
+int lii_comm_transport(lii_handle h, int32_t* transport); /* the transport in use; LII_COMM_AUTO = none (single rank) */
 int lii_comm_destroy(lii_handle h);
 
 /* ---------------------------------------------------------------- utilities for harnesses */

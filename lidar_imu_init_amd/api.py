@@ -115,6 +115,8 @@ _DECLS = {
                                   C.POINTER(lii_calib_result), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lii_comm_unique_id": (C.c_int, [C.c_void_p]),
     "lii_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "lii_comm_init_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "lii_comm_transport": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lii_comm_destroy": (C.c_int, [C.c_void_p]),
     "lii_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "lii_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -440,9 +442,18 @@ class Registrar:
         self._check(self.L.lii_comm_unique_id(buf), None)
         return bytes(buf)
 
-    def comm_init(self, n_ranks, rank, uid: bytes):
+    def comm_init(self, n_ranks, rank, uid: bytes, transport="auto"):
+        """transport: "auto" (node-local mailbox when all ranks share the node, else RCCL), "rccl", "mailbox"."""
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
-        self._check(self.L.lii_comm_init(self.h, n_ranks, rank, buf))
+        self._check(self.L.lii_comm_init_ex(self.h, n_ranks, rank, buf, {"auto": 0, "rccl": 1, "mailbox": 2}[transport]))
+
+    def comm_transport(self) -> str:
+        t = C.c_int32(0)
+        self._check(self.L.lii_comm_transport(self.h, C.byref(t)))
+        return {0: "none", 1: "rccl", 2: "mailbox"}[t.value]
+
+    def comm_destroy(self):
+        self._check(self.L.lii_comm_destroy(self.h))
 
     def set_profiling(self, enabled: bool):
         """Turns the HIP-event timing of the registration kernels on/off and zeroes the accumulators."""

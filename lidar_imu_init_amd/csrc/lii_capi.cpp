@@ -101,7 +101,10 @@ struct lii_context {
   void* ingest = nullptr;  // lii_ingest.hip state (frames of the last driver message)
 
   // ---- comm
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;   // RCCL transport (ranks on several nodes, or forced)
+  MailboxHost mailbox;         // node-local transport: the exchange happens inside k_reduce_solve
+  unsigned long long* d_mb_seq = nullptr;
+  long long mailbox_timeout_ticks = 3000000000ll;  // 30 s (LII_MAILBOX_TIMEOUT_S): ranks may start a scan seconds apart
   int n_ranks = 1, rank = 0;
 
   // ---- profiling
@@ -303,6 +306,16 @@ int resolve_n_body(lii_handle h) {
   return LII_OK;
 }
 
+MailboxView mailbox_view(lii_handle h) {
+  MailboxView v;
+  v.slots = h->mailbox.dev_slots;
+  v.seq = h->d_mb_seq;
+  v.n_ranks = h->n_ranks;
+  v.rank = h->rank;
+  v.timeout_ticks = h->mailbox_timeout_ticks;
+  return v;
+}
+
 int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double* out91) {
   if (h->n_body <= 0) return fail(h, LII_ERR_STATE, "no down-sampled scan (call lii_downsample / lii_downsample_skip)");
   int rc = commit_map(h);
@@ -324,10 +337,14 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
   if (h->comm) {
     ncclResult_t r = ncclAllReduce(h->d_out91, h->d_out91, kNormalEq, ncclDouble, ncclSum, h->comm, h->stream);
     if (r != ncclSuccess) return fail(h, LII_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+  } else if (h->mailbox.dev_slots) {
+    launch_mailbox_allreduce(h->d_out91, mailbox_view(h), h->stream);
   }
   HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_out91, sizeof(double) * kNormalEq, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   std::memcpy(out91, h->h_small, sizeof(double) * kNormalEq);
+  if (h->mailbox.dev_slots && out91[kNormalEq - 1] != out91[kNormalEq - 1])
+    return fail(h, LII_ERR_COMM, "mailbox exchange timed out (a rank of the job did not reach this pass)");
   if (prof) {
     // timings: [0] sum ms search-pass kernel, [1] sum ms residual-pass kernel, [2] sum ms reduce kernel,
     //          [3] host solve ms (last update), [4] total ms (last update), [5]/[6] launch counts of [0]/[1]
@@ -386,8 +403,9 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     if (timed) HIPCHK(h, hipEventRecord(h->ev[3], s));
     launch_fit_reduce(g, rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[1], s));
-    if (!h->comm) {  // single GPU: final reduction and solve in one launch ([2] then times both)
-      launch_reduce_solve(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, h->h_res, rb.n_dev, s);
+    if (!h->comm) {  // single GPU or node-local mailbox: final sum (+ exchange) and solve in one launch ([2] times both)
+      launch_reduce_solve(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, h->h_res, rb.n_dev,
+                          mailbox_view(h), s);
       if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
       continue;
     }
@@ -416,6 +434,8 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     }
   }
 #endif
+  if (hr->singular == 3)
+    return fail(h, LII_ERR_COMM, "mailbox exchange timed out (a rank of the job did not reach this pass); re-create the communicator");
   if (hr->singular) return fail(h, LII_ERR_INVALID, "singular covariance / normal matrix in the device solve");
   if (hr->it < 0) return fail(h, LII_ERR_HIP, "device loop ended without a result");
   std::memcpy(state, hr->st, sizeof(lii_state));
@@ -604,6 +624,8 @@ int lii_destroy(lii_handle h) {
   (void)hipSetDevice(h->device);
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  mailbox_close(&h->mailbox);
+  if (h->d_mb_seq) (void)hipFree(h->d_mb_seq);
   void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
@@ -1064,24 +1086,57 @@ int lii_comm_unique_id(uint8_t id_out[128]) {
   std::memcpy(id_out, &id, 128);
   return LII_OK;
 }
-int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128]) {
-  if (!h || !id_in || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(h, LII_ERR_INVALID, "lii_comm_init: bad arguments");
+namespace {
+void comm_drop(lii_handle h) {
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
+  mailbox_close(&h->mailbox);
+  h->n_ranks = 1;
+  h->rank = 0;
+}
+}  // namespace
+int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128], int32_t transport) {
+  if (!h || !id_in || n_ranks < 1 || rank < 0 || rank >= n_ranks || transport < LII_COMM_AUTO || transport > LII_COMM_MAILBOX)
+    return fail(h, LII_ERR_INVALID, "lii_comm_init: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  comm_drop(h);
   h->n_ranks = n_ranks;
   h->rank = rank;
   if (n_ranks == 1) return LII_OK;
+  if (transport != LII_COMM_RCCL) {
+    if (!h->d_mb_seq) HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->d_mb_seq), sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->d_mb_seq, 0, sizeof(unsigned long long)));
+    if (const char* t = std::getenv("LII_MAILBOX_TIMEOUT_S")) h->mailbox_timeout_ticks = (long long)(std::atof(t) * 1e8);
+    const char* w = std::getenv("LII_MAILBOX_WAIT_S");
+    const double wait_s = w ? std::atof(w) : 20.0;
+    std::string why;
+    if (mailbox_open(id_in, n_ranks, rank, wait_s, &h->mailbox, &why) == 0) return LII_OK;
+    if (transport == LII_COMM_MAILBOX) {
+      h->n_ranks = 1; h->rank = 0;
+      return fail(h, LII_ERR_COMM, "node-local mailbox unavailable: " + why);
+    }
+  }
   ncclUniqueId id;
   std::memcpy(&id, id_in, 128);
-  HIPCHK(h, hipSetDevice(h->device));
   ncclResult_t r = ncclCommInitRank(&h->comm, n_ranks, id, rank);
-  if (r != ncclSuccess) { h->comm = nullptr; return fail(h, LII_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+  if (r != ncclSuccess) {
+    h->comm = nullptr; h->n_ranks = 1; h->rank = 0;
+    return fail(h, LII_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  }
+  return LII_OK;
+}
+int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128]) {
+  return lii_comm_init_ex(h, n_ranks, rank, id_in, LII_COMM_AUTO);
+}
+int lii_comm_transport(lii_handle h, int32_t* transport) {
+  if (!h || !transport) return LII_ERR_INVALID;
+  *transport = h->comm ? LII_COMM_RCCL : (h->mailbox.dev_slots ? LII_COMM_MAILBOX : LII_COMM_AUTO);
   return LII_OK;
 }
 int lii_comm_destroy(lii_handle h) {
   if (!h) return LII_ERR_INVALID;
-  if (h->comm) { ncclCommDestroy(h->comm); h->comm = nullptr; }
-  h->n_ranks = 1;
-  h->rank = 0;
+  (void)hipSetDevice(h->device);
+  comm_drop(h);
   return LII_OK;
 }
 

@@ -81,6 +81,59 @@ struct IekfCtrl {
   int search_log[16];  // search_log[it] = 1 when iteration `it` ran the k-NN pass (for profiling)
 };
 
+// Node-local exchange of the 91 normal-equation scalars between the ranks of one job.  The slots live in
+// a POSIX shared-memory segment that every rank has registered with its own device (fine-grained host memory): rank r owns
+// two slots (parity of the exchange number) of 96 doubles + a sequence flag.  An exchange = write own slot, fence, publish the
+// flag, wait for every rank's flag, sum the slots in rank order (every rank forms the bit-identical sum).  Two parities
+// suffice: a rank can be at most one exchange ahead of the slowest reader.
+constexpr int kMailboxSlotDoubles = 128;               // 1 KiB: [0..90] data, [96] sequence flag (as u64)
+constexpr int kMailboxFlagAt = 96;
+constexpr int kMailboxMaxRanks = 64;                   // one polling lane per rank
+struct MailboxView {
+  double* slots;            // device address of the registered segment's slot area; nullptr = no exchange
+  unsigned long long* seq;  // device memory: exchanges completed so far (identical on all ranks)
+  int n_ranks, rank;
+  long long timeout_ticks;  // of the 100 MHz wall clock: how long to wait for a peer that may never arrive
+};
+
+// Called by ONE wavefront (64 lanes).  `in` holds this rank's 91 partial sums, `out` receives the sum over ranks (may alias
+// `in`).  Returns false when a peer did not publish within the time limit (the communicator is unusable afterwards).
+__device__ inline bool mailbox_allreduce(const MailboxView& mb, const double* in, double* out) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long q = *mb.seq + 1ull;
+  const int par = (int)(q & 1ull);
+  double* mine = mb.slots + (size_t)(mb.rank * 2 + par) * kMailboxSlotDoubles;
+  for (int i = lane; i < kNormalEq; i += 64)
+    __hip_atomic_store(mine + i, __hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();  // the wavefront's data stores are complete before the flag leaves
+  if (lane == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine + kMailboxFlagAt), q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const long long t0 = wall_clock64();
+  bool ok = true;
+  for (;;) {
+    unsigned long long v = q;
+    if (lane < mb.n_ranks)
+      v = __hip_atomic_load(reinterpret_cast<unsigned long long*>(mb.slots + (size_t)(lane * 2 + par) * kMailboxSlotDoubles + kMailboxFlagAt),
+                            __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (__all(v >= q)) break;
+    if (wall_clock64() - t0 > mb.timeout_ticks) { ok = false; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (ok) {
+    for (int i = lane; i < kNormalEq; i += 64) {
+      double acc = 0;
+#pragma unroll 8
+      for (int r = 0; r < mb.n_ranks; r++)
+        acc += __hip_atomic_load(mb.slots + (size_t)(r * 2 + par) * kMailboxSlotDoubles + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      out[i] = acc;
+    }
+  }
+  __threadfence();
+  if (lane == 0) *mb.seq = q;
+  return ok;
+}
+
 // What the host needs back from one iterated update.  Lives in pinned, device-mapped HOST memory: the solve kernel of the
 // stopping iteration writes it there directly, so the update ends with one stream synchronisation and no D2H copy.
 struct IekfResult {

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __
 // update.  Used when no all-reduce sits between the two (single GPU); one launch less per iteration.
 __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ partials, int n_blocks, int stride,
                                                       double* out, unsigned int* ticket, IekfCtrl* c, IekfResult* res,
-                                                      const int* __restrict__ n_dev) {
+                                                      const int* __restrict__ n_dev, MailboxView mb) {
   __shared__ int s_last;
   if (c->stop) return;  // read by every workgroup before its ticket; the solve (which may set it) runs after all tickets
   if (n_dev) n_blocks = max(1, (*n_dev + kBlock - 1) / kBlock);
@@ -326,14 +326,33 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
   if (!s_last) return;
   if (lane == 0) *ticket = 0u;  // re-armed for the next launch (kernel boundary orders it)
   __threadfence();
-  iekf_solve_body(c, out, res);
+  const double* ne = out;
+  if (mb.slots) {  // several ranks: this rank's sums meet the others' in the node-local mailbox, still inside this launch
+    if (!mailbox_allreduce(mb, out, out + 128)) {
+      if (threadIdx.x == 0) { c->stop = 1; c->singular = 3; res->singular = 3; res->it = 0; }
+      __threadfence_system();
+      return;
+    }
+    ne = out + 128;
+  }
+  iekf_solve_body(c, ne, res);
 }
 
+// The same exchange for the host-driven single pass (lii_iekf_iterate): in place on the 91 sums; a timeout poisons them.
+__global__ __launch_bounds__(64) void k_mailbox_allreduce(double* out, MailboxView mb) {
+  if (!mailbox_allreduce(mb, out, out)) {
+    for (int i = threadIdx.x; i < kNormalEq; i += 64) out[i] = __builtin_nan("");
+  }
+}
+
+void launch_mailbox_allreduce(double* out91, const MailboxView& mb, hipStream_t s) {
+  hipLaunchKernelGGL(k_mailbox_allreduce, dim3(1), dim3(64), 0, s, out91, mb);
+}
 void launch_reduce_solve(const double* partials, int n_points, int stride, double* out91, unsigned int* ticket, IekfCtrl* c,
-                         IekfResult* res, const int* n_dev, hipStream_t s) {
+                         IekfResult* res, const int* n_dev, const MailboxView& mb, hipStream_t s) {
   int nb = (n_points + kBlock - 1) / kBlock;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, ticket, c, res, n_dev);
+  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, ticket, c, res, n_dev, mb);
 }
 void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s) {
   hipLaunchKernelGGL(k_iekf_solve, dim3(1), dim3(64), 0, s, c, ne, res);

@@ -36,7 +36,19 @@ void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const P
 void launch_reduce91(const double* partials, int n_points, int stride, double* out91, const IekfCtrl* ctrl, int forced,
                      const int* n_dev, hipStream_t s);
 void launch_reduce_solve(const double* partials, int n_points, int stride, double* out91, unsigned int* ticket, IekfCtrl* c,
-                         IekfResult* res, const int* n_dev, hipStream_t s);
+                         IekfResult* res, const int* n_dev, const MailboxView& mb, hipStream_t s);
+void launch_mailbox_allreduce(double* out91, const MailboxView& mb, hipStream_t s);
+// node-local mailbox (lii_mailbox.cpp)
+struct MailboxHost {
+  void* map = nullptr;        // the shared segment in this process
+  size_t bytes = 0;
+  double* dev_slots = nullptr;  // device address of its slot area
+  bool registered = false;
+  char name[64] = {0};        // non-empty while the segment still has a name to unlink
+};
+size_t mailbox_segment_bytes(int n_ranks);
+int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, MailboxHost* m, std::string* why);
+void mailbox_close(MailboxHost* m);
 void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s);
 int register_blocks(int n);
 // undistortion
