@@ -78,8 +78,10 @@ struct lii_context {
   unsigned long long* d_extent = nullptr;  // 2 x {min (time|index), max time}: ping-pong accumulators
   unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
   int extent_sel = 0, mm_sel = 0;
-  unsigned int *d_vkeys_a = nullptr, *d_vkeys_b = nullptr, *d_vidx_a = nullptr, *d_vidx_b = nullptr,
-               *d_vranks = nullptr;
+  unsigned int *d_vkeys_a = nullptr, *d_vkeys_b = nullptr, *d_vidx_b = nullptr;
+  unsigned long long *d_vcomp = nullptr, *d_vsplit = nullptr;  // sample sort of the voxel filter (lii_vsort.hip)
+  unsigned int* d_vhist = nullptr;
+  unsigned short* d_vbucket = nullptr;
   double* d_poses = nullptr;
   int n_scan = 0, n_body = 0;   // n_body is an upper bound while n_body_pending (the exact count lives in d_nbody)
   bool n_body_pending = false;
@@ -602,9 +604,12 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   }
   CK(dmalloc(&h->d_vkeys_a, N));
   CK(dmalloc(&h->d_vkeys_b, N));
-  CK(dmalloc(&h->d_vidx_a, N));
   CK(dmalloc(&h->d_vidx_b, N));
-  CK(dmalloc(&h->d_vranks, N));
+  CK(dmalloc(&h->d_vcomp, N));
+  CK(dmalloc(&h->d_vsplit, 2048 + 4096));  // splitters | samples
+  CK(dmalloc(&h->d_vhist, voxel_sort_hist_elems((int)N)));
+  CK(hipMemset(h->d_vhist, 0, sizeof(unsigned int) * voxel_sort_hist_elems((int)N)));
+  CK(dmalloc(&h->d_vbucket, N));
   CK(dmalloc(&h->d_cal_params, 64));
   CK(dmalloc(&h->d_cal_out, 128));
   h->h_stage_elems = NM * kMatch;  // large enough for the neighbour download too
@@ -628,8 +633,8 @@ int lii_destroy(lii_handle h) {
   if (h->d_mb_seq) (void)hipFree(h->d_mb_seq);
   void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
-                 h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a,
-                 h->d_vidx_b, h->d_vranks, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
+                 h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b,
+                 h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -825,20 +830,22 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
     if (filtered) *filtered = 1;
     return LII_OK;
   }
-  // Entirely on the stream: bounding box -> (device) overflow guard + grid parameters -> keys -> stable radix sort ->
-  // voxel-start flags -> scan -> centroids + count.  The size of the result stays in HBM (d_nbody); the registration
+  // Entirely on the stream: bounding box -> (device) overflow guard + grid parameters -> keys (+ splitter samples) ->
+  // sample sort -> centroids + count (lii_vsort.hip).  The size of the result stays in HBM (d_nbody); the registration
   // kernels read it there, so the host learns it only if the caller asks (n_down / filtered != NULL, or a download).
   hipStream_t s = h->stream;
   unsigned int* mm = h->d_mm + 8 * h->mm_sel;
   h->mm_sel ^= 1;
   launch_voxel_minmax(h->d_scan, n, mm, h->d_mm + 8 * h->mm_sel, s);
-  launch_voxel_keys(h->d_scan, n, mm, leaf, h->d_vkeys_a, h->d_vidx_a, h->d_nbody + 1, s);
-  sort_pairs_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_vkeys_a, h->d_vkeys_b, h->d_vidx_a, h->d_vidx_b, n, s);
-  // (feeding the scan through a transform iterator that evaluates the flag on the fly saves this launch but makes the scan
-  // itself 8 us slower: measured)
-  launch_voxel_flags(h->d_vkeys_b, n, h->d_vidx_a, s);  // d_vidx_a is free after the sort
-  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_vidx_a, h->d_vranks, n, s);
-  launch_voxel_centroid(h->d_scan, h->d_vkeys_b, h->d_vidx_b, h->d_vranks, n, h->d_body, h->d_nbody, s);
+  {
+    const VoxelSortPlan plan = voxel_sort_plan(n);
+    launch_voxel_keys(h->d_scan, n, mm, leaf, h->d_vkeys_a, h->d_nbody + 1, plan.samples ? h->d_vsplit + 2048 : nullptr, plan.width, s);
+    VoxelSortBuffers vb;
+    vb.samples = h->d_vsplit + 2048;
+    vb.keys_in = h->d_vkeys_a; vb.keys_out = h->d_vkeys_b; vb.idx_out = h->d_vidx_b;
+    vb.comp = h->d_vcomp; vb.splitters = h->d_vsplit; vb.hist = h->d_vhist; vb.bucket_of = h->d_vbucket;
+    launch_voxel_sort_centroids(vb, h->d_scan, n, h->d_body, h->d_nbody, s);
+  }
   HIPCHK(h, hipGetLastError());
   h->n_body = n;  // upper bound until resolved
   h->n_body_pending = true;

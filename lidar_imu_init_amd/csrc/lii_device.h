@@ -81,6 +81,15 @@ struct IekfCtrl {
   int search_log[16];  // search_log[it] = 1 when iteration `it` ran the k-NN pass (for profiling)
 };
 
+// "Last workgroup finishes the job" kernels publish their partial results with device-scope ATOMIC stores / adds (performed
+// at the coherent level, read back with device-scope atomic loads) and then draw a ticket.  All the ticket needs is that
+// those atomics have completed: s_waitcnt vmcnt(0).  __threadfence() would also write the L2 back (buffer_wbl2) and
+// invalidate it - measured at ~5 us per launch when every workgroup does it.
+__device__ __forceinline__ void wait_published_atomics() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // compiler ordering (+ LDS) ...
+  __builtin_amdgcn_s_waitcnt(0x0F70);                     // ... and vmcnt(0): the global atomics have been acknowledged
+}
+
 // Node-local exchange of the 91 normal-equation scalars between the ranks of one job.  The slots live in
 // a POSIX shared-memory segment that every rank has registered with its own device (fine-grained host memory): rank r owns
 // two slots (parity of the exchange number) of 96 doubles + a sequence flag.  An exchange = write own slot, fence, publish the
@@ -144,12 +153,5 @@ struct IekfResult {
   long long ts[16];  // LII_SOLVE_TRACE builds: wall_clock64 stamps of the solve phases (stopping iteration)
   long long ts0[16]; // ... of iteration 0
 };
-
-// 1 at the first point of every voxel run of the sorted voxel-grid keys (non-finite points carry the sentinel key and start
-// nothing).  Shared by the scan's input iterator (lii_sort.hip) and k_voxel_centroid.
-__device__ __forceinline__ unsigned int voxel_start_flag(const unsigned int* __restrict__ keys, int i) {
-  const unsigned int k = keys[i];
-  return (k != 0x7FFFFFFFu && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
-}
 
 }  // namespace lii

@@ -318,14 +318,13 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
   if (lane == 0) {
     __hip_atomic_store(out + t, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
+    wait_published_atomics();  // not __threadfence(): see lii_device.h
     const unsigned int tk = atomicAdd(ticket, 1u);
     s_last = tk == gridDim.x - 1;
   }
   __syncthreads();
   if (!s_last) return;
   if (lane == 0) *ticket = 0u;  // re-armed for the next launch (kernel boundary orders it)
-  __threadfence();
   const double* ne = out;
   if (mb.slots) {  // several ranks: this rank's sums meet the others' in the node-local mailbox, still inside this launch
     if (!mailbox_allreduce(mb, out, out + 128)) {

@@ -1107,7 +1107,8 @@ __device__ __forceinline__ VoxelArg voxel_prepare(const unsigned int* __restrict
   return v;
 }
 __global__ void k_voxel_keys(const float4* __restrict__ pts, int n, const unsigned int* __restrict__ mm, float leaf,
-                             unsigned int* __restrict__ keys, unsigned int* __restrict__ idx, int* __restrict__ filtered) {
+                             unsigned int* __restrict__ keys, int* __restrict__ filtered,
+                             unsigned long long* __restrict__ samples, int sample_width) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const VoxelArg v = voxel_prepare(mm, leaf);
@@ -1123,32 +1124,14 @@ __global__ void k_voxel_keys(const float4* __restrict__ pts, int n, const unsign
     key = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);
   }
   keys[i] = key;
-  idx[i] = (unsigned)i;
-}
-__global__ void k_voxel_flags(const unsigned int* __restrict__ keys, int n, unsigned int* __restrict__ flags) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flags[i] = voxel_start_flag(keys, i);
-}
-// ranks = inclusive scan of flags.  One thread per voxel start accumulates its run sequentially in input
-// order (the sort is stable), float32, then divides by the count — the same order the oracle uses.
-__global__ void k_voxel_centroid(const float4* __restrict__ pts, const unsigned int* __restrict__ keys,
-                                 const unsigned int* __restrict__ idx, const unsigned int* __restrict__ ranks, int n,
-                                 float4* __restrict__ out, int* __restrict__ n_out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == n - 1) *n_out = (int)ranks[n - 1];  // number of occupied voxels = size of the down-sampled cloud
-  if (i >= n || !voxel_start_flag(keys, i)) return;
-  unsigned int k = keys[i];
-  float sx = 0, sy = 0, sz = 0, st = 0;
-  int j = i;
-  for (; j < n && keys[j] == k; j++) {
-    float4 p = pts[idx[j]];
-    sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+  if (samples) {  // the sort's splitter samples (lii_vsort.hip): one jittered position per stratum of `sample_width` points
+    const unsigned int j = (unsigned int)i / (unsigned int)sample_width, lo = j * (unsigned int)sample_width;
+    unsigned int hsh = j * 2654435761u;
+    hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+    const unsigned int w = min((unsigned int)sample_width, (unsigned int)n - lo);
+    if (lo + hsh % w == (unsigned int)i) samples[j] = ((unsigned long long)key << 32) | (unsigned int)i;
   }
-  float c = (float)(j - i);
-  // a single-point voxel reproduces the point exactly (x / 1.0f == x), which is also what the identity path needs
-  out[ranks[i] - 1] = make_float4(sx / c, sy / c, sz / c, st / c);
 }
-
 // ------------------------------------------------------------------------------------------------
 // LI-Init residual / Jacobian evaluators (include/LI_init/LI_init.h:91-205).  Records are 22 doubles:
 // rot_end[9], ang_vel[3], linear_vel[3], ang_acc[3], linear_acc[3], timestamp.
@@ -1338,16 +1321,11 @@ void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned in
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(k_voxel_minmax, dim3(nb), dim3(256), 0, s, pts, n, mm, mm_next);
 }
-void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, float leaf, unsigned int* keys, unsigned int* idx,
-                       int* filtered_dev, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, leaf, keys, idx, filtered_dev);
-}
-void launch_voxel_flags(const unsigned int* keys, int n, unsigned int* flags, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_voxel_flags, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, flags);
-}
-void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const unsigned int* idx, const unsigned int* ranks, int n,
-                           float4* out, int* n_out, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_voxel_centroid, dim3(nblk(n, 256)), dim3(256), 0, s, pts, keys, idx, ranks, n, out, n_out);
+void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, float leaf, unsigned int* keys, int* filtered_dev,
+                       unsigned long long* samples, int sample_width, hipStream_t s) {
+  if (n > 0)
+    hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, leaf, keys, filtered_dev, samples,
+                       sample_width);
 }
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s) {

@@ -58,11 +58,8 @@ void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const 
 void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned long long* extent, hipStream_t s);
 // voxel grid
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s);
-void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, float leaf, unsigned int* keys, unsigned int* idx,
-                       int* filtered_dev, hipStream_t s);
-void launch_voxel_flags(const unsigned int* keys, int n, unsigned int* flags, hipStream_t s);
-void launch_voxel_centroid(const float4* pts, const unsigned int* keys, const unsigned int* idx, const unsigned int* ranks, int n,
-                           float4* out, int* n_out, hipStream_t s);
+void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, float leaf, unsigned int* keys,
+                       int* filtered_dev, unsigned long long* samples, int sample_width, hipStream_t s);
 // calibration
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s);
@@ -83,6 +80,21 @@ void launch_sum3(const int* a, const int* b, const int* c, int* out, hipStream_t
 size_t sort_temp_bytes(int max_n);
 void sort_pairs_u64(void* temp, size_t temp_bytes, const unsigned long long* kin, unsigned long long* kout,
                     const unsigned int* vin, unsigned int* vout, int n, hipStream_t s);
+// back half of the voxel-grid filter (lii_vsort.hip): sample sort of the (key, index) pairs + centroids
+struct VoxelSortBuffers {
+  const unsigned int* keys_in;
+  unsigned int *keys_out, *idx_out;
+  unsigned long long* comp;       // n composites, bucket order
+  unsigned long long* splitters;  // 2048
+  const unsigned long long* samples;  // 4096, written by k_voxel_keys (voxel_sort_plan)
+  unsigned int* hist;             // voxel_sort_hist_elems(max n), zero-initialised once
+  unsigned short* bucket_of;      // n
+};
+size_t voxel_sort_hist_elems(int max_n);
+struct VoxelSortPlan { int buckets, samples, width, strata; };
+VoxelSortPlan voxel_sort_plan(int n);
+// sort + one centroid per voxel: out[0 .. *n_out) in key order, *n_out (device) = number of occupied voxels
+void launch_voxel_sort_centroids(const VoxelSortBuffers& vb, const float4* pts, int n, float4* out, int* n_out, hipStream_t s);
 void sort_pairs_u32(void* temp, size_t temp_bytes, const unsigned int* kin, unsigned int* kout, const unsigned int* vin,
                     unsigned int* vout, int n, hipStream_t s);
 void merge_pairs_u64_f4(void* temp, size_t temp_bytes, const unsigned long long* k1, const unsigned long long* k2,

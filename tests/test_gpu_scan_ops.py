@@ -88,7 +88,11 @@ def test_undistort_cv_matches_oracle(reg, oracle, n):
     assert np.array_equal(got[order[0], :3], pts[order[0], :3])  # the time-earliest point is never compensated
 
 
-@pytest.mark.parametrize("n,leaf,spread", [(120_000, 0.05, 30.0), (50_000, 0.5, 20.0), (5000, 5.0, 1.0), (1, 0.05, 1.0)])
+@pytest.mark.parametrize("n,leaf,spread", [(120_000, 0.05, 30.0), (50_000, 0.5, 20.0), (5000, 5.0, 1.0), (1, 0.05, 1.0),
+                                           # the sample sort's regimes: one-workgroup path, smallest bucket count, every
+                                           # point in ONE voxel (equal keys must not overload a bucket), a large scan
+                                           (512, 0.5, 5.0), (513, 0.5, 5.0), (2049, 0.2, 3.0), (20_000, 50.0, 1.0),
+                                           (149_000, 0.1, 40.0)])
 def test_voxel_grid_matches_oracle(reg, oracle, n, leaf, spread):
     rng = np.random.default_rng(n)
     pts = np.c_[rng.uniform(-spread, spread, (n, 2)), rng.uniform(-2, 4, n), rng.uniform(0, 100, n)].astype(np.float32)
