@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -69,6 +70,8 @@ struct lii_context {
   IekfCtrl* h_ctrl = nullptr;   // pinned upload image
   IekfResult* h_res = nullptr;  // pinned, device-mapped: written by the solve kernel of the stopping iteration
   lii_pose6d* h_poses = nullptr;  // pinned staging of the IMU pose table (lives behind h_ctrl: one upload can carry both)
+  int update_seq = 0;           // IekfCtrl::seq of the last update (never 0)
+  bool poll_result = true;      // LII_SYNC_RESULT=1: end an update with hipStreamSynchronize instead of polling IekfResult::done
   bool poses_preloaded = false, ctrl_preloaded = false;  // lii_scan_register uploaded them already
   hipEvent_t ev_poses = nullptr;  // the last pose-table upload
   hipEvent_t ev_stage = nullptr;  // the last scan upload through h_stage
@@ -374,6 +377,8 @@ void fill_ctrl(lii_handle h, const lii_state* state, const lii_state* state_prop
   hc->imu_en = opts->imu_en;
   hc->it = 0; hc->search_next = 1; hc->stop = 0; hc->rematch_num = 0; hc->converged = 0; hc->searches = 0;
   hc->effect_num = 0; hc->singular = 0;
+  h->update_seq = h->update_seq == 0x7FFFFFFF ? 1 : h->update_seq + 1;
+  hc->seq = h->update_seq;
 }
 
 int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop, const lii_iekf_opts* opts,
@@ -421,7 +426,25 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     }
     launch_iekf_solve(h->d_ctrl, ne, h->h_res, s);
   }
-  HIPCHK(h, hipStreamSynchronize(s));  // the stopping iteration's solve has written h_res (mapped host memory)
+  // The iteration that stops the loop writes the result block (mapped host memory) and then its sequence number.  Polling
+  // that word instead of synchronising the stream returns as soon as the result exists: the launches enqueued behind the
+  // stopping iteration (they only read `stop` and return) drain while the caller already prepares the next scan.
+  if (h->poll_result && !prof && !h->comm) {
+    volatile int* done = &h->h_res->done;
+    unsigned int spins = 0;
+    while (*done != h->update_seq) {
+      if ((++spins & 0x3FFF) == 0) {  // every ~50 us: is the stream still alive?
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) break;  // everything ran; `done` is final (a loop that never stopped is reported below)
+        if (q != hipErrorNotReady) return fail(h, LII_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+      }
+      __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (*done != h->update_seq) HIPCHK(h, hipStreamSynchronize(s));
+  } else {
+    HIPCHK(h, hipStreamSynchronize(s));  // the stopping iteration's solve has written h_res (mapped host memory)
+  }
   const IekfResult* hr = h->h_res;
   h->have_search = true;
 #ifdef LII_SOLVE_TRACE
@@ -518,6 +541,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   h->cell_size = std::max(h->cell_size, std::sqrt(h->cfg.max_match_dist2) / 8.0f * 1.001f);
   if (const char* v = std::getenv("LII_KNN_VARIANT")) h->knn_variant = std::atoi(v);  // A/B knob for profiling
   if (const char* v = std::getenv("LII_HOST_SOLVE")) h->host_solve = std::atoi(v) != 0;
+  if (const char* v = std::getenv("LII_SYNC_RESULT")) h->poll_result = std::atoi(v) == 0;
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;
 #define CK(call)                                                                  \
@@ -579,12 +603,12 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   {
     // control block and pose table share one allocation so that lii_scan_register uploads both with one copy
     void* p = nullptr;
-    CK(hipMalloc(&p, kCtrlBytes + sizeof(lii_pose6d) * 1024));
+    CK(hipMalloc(&p, kCtrlBytes + sizeof(lii_pose6d) * 1024 + 1024));
     h->d_ctrl = static_cast<IekfCtrl*>(p);
     h->d_poses = reinterpret_cast<double*>(static_cast<char*>(p) + kCtrlBytes);
   }
   CK(dmalloc(&h->d_pose, 1));
-  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_ctrl), kCtrlBytes + sizeof(lii_pose6d) * 1024, hipHostMallocDefault));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_ctrl), kCtrlBytes + sizeof(lii_pose6d) * 1024 + 1024, hipHostMallocDefault));
   h->h_poses = reinterpret_cast<lii_pose6d*>(reinterpret_cast<char*>(h->h_ctrl) + kCtrlBytes);
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_res), sizeof(IekfResult), hipHostMallocMapped));
   std::memset(h->h_res, 0, sizeof(IekfResult));
@@ -971,7 +995,8 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     HIPCHK(h, hipEventSynchronize(h->ev_poses));
     fill_ctrl(h, state, state_prop, &job->opts);
     std::memcpy(h->h_poses, job->imu_poses, sizeof(lii_pose6d) * size_t(job->n_imu_poses));
-    HIPCHK(h, hipMemcpyAsync(h->d_ctrl, h->h_ctrl, kCtrlBytes + sizeof(lii_pose6d) * size_t(job->n_imu_poses), hipMemcpyHostToDevice,
+    // (size rounded to 1 KiB: the runtime splits an H2D copy with an unaligned tail into two blit kernels)
+    HIPCHK(h, hipMemcpyAsync(h->d_ctrl, h->h_ctrl, (kCtrlBytes + sizeof(lii_pose6d) * size_t(job->n_imu_poses) + 1023) / 1024 * 1024, hipMemcpyHostToDevice,
                              h->stream));
     HIPCHK(h, hipEventRecord(h->ev_poses, h->stream));
     h->poses_preloaded = h->ctrl_preloaded = true;

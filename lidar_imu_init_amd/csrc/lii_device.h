@@ -77,7 +77,8 @@ struct IekfCtrl {
   int searches;      // k-NN passes executed
   int effect_num;    // effect_feat_num of the last iteration
   int singular;      // a matrix inversion failed
-  int pad[2];
+  int seq;           // number of this update (host); echoed into IekfResult::done by the iteration that ends the loop
+  int pad[1];
   int search_log[16];  // search_log[it] = 1 when iteration `it` ran the k-NN pass (for profiling)
 };
 
@@ -148,7 +149,9 @@ __device__ inline bool mailbox_allreduce(const MailboxView& mb, const double* in
 struct IekfResult {
   double st[kStateDoubles];
   double ne[96];  // the 91 normal-equation scalars of the last executed pass
-  int it, searches, effect_num, converged, singular, pad[3];
+  int it, searches, effect_num, converged, singular;
+  int done;  // == IekfCtrl::seq once everything above has landed (written last, after a system-scope fence): the host polls it
+  int pad[2];
   int search_log[16];
   long long ts[16];  // LII_SOLVE_TRACE builds: wall_clock64 stamps of the solve phases (stopping iteration)
   long long ts0[16]; // ... of iteration 0

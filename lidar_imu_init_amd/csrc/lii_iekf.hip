@@ -113,6 +113,13 @@ __device__ void d_so3_log(const double* R, double* out) {
 #else
 #define LII_TS(k)
 #endif
+// The iteration that ends the loop tells the host so through the mapped result block: every store of this (single)
+// wavefront to `res` has been acknowledged before the flag goes out, so a host that sees done == seq sees the result.
+__device__ __forceinline__ void publish_done(IekfResult* res, int seq) {
+  __threadfence_system();
+  if (threadIdx.x == 0) __hip_atomic_store(&res->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, IekfResult* res) {
 #ifdef LII_SOLVE_TRACE
   __shared__ long long s_ts[16];
@@ -128,8 +135,8 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   __shared__ int s_int[12];
   const int lane = threadIdx.x;
   {
-    const int* ci = &c->max_it;  // max_it, imu_en, it, search_next, stop, rematch_num, converged, searches, effect_num, singular
-    if (lane < 10) s_int[lane] = ci[lane];
+    const int* ci = &c->max_it;  // max_it, imu_en, it, search_next, stop, rematch_num, converged, searches, effect_num, singular, seq
+    if (lane < 11) s_int[lane] = ci[lane];
     // agent-scope loads: in the fused kernel these sums were written by other workgroups of the SAME launch
     for (int e = lane; e < 91; e += 64) s_ne[e] = __hip_atomic_load(ne + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane < 36) { s_st[lane] = c->st[lane]; s_prop[lane] = c->prop[lane]; }
@@ -184,6 +191,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   const bool ok = gj12(col);
   if (!ok) {
     if (lane == 0) { c->stop = 1; c->singular = 1; res->singular = 1; }
+    publish_done(res, c->seq);
     return;
   }
   LII_TS(4);
@@ -290,6 +298,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
     }
     for (int e = lane; e < 91; e += 64) res->ne[e] = s_ne[e];
     if (lane < 16) res->search_log[lane] = (lane < it) ? c->search_log[lane] : (lane == it ? search_now : 0);
+    publish_done(res, s_int[10]);
   }
 #ifdef LII_SOLVE_TRACE
   __syncthreads();
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
   if (mb.slots) {  // several ranks: this rank's sums meet the others' in the node-local mailbox, still inside this launch
     if (!mailbox_allreduce(mb, out, out + 128)) {
       if (threadIdx.x == 0) { c->stop = 1; c->singular = 3; res->singular = 3; res->it = 0; }
-      __threadfence_system();
+      publish_done(res, c->seq);
       return;
     }
     ne = out + 128;
