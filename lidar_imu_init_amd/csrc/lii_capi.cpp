@@ -81,6 +81,7 @@ struct lii_context {
   unsigned long long* d_extent = nullptr;  // 2 x {min (time|index), max time}: ping-pong accumulators
   unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
   int extent_sel = 0, mm_sel = 0;
+  bool mm_valid = false;  // d_mm[mm_sel] holds the bounding box of d_scan (left behind by a de-skew kernel); else it is armed
   unsigned int *d_vkeys_a = nullptr, *d_vkeys_b = nullptr, *d_vidx_b = nullptr;
   unsigned long long *d_vcomp = nullptr, *d_vsplit = nullptr;  // sample sort of the voxel filter (lii_vsort.hip)
   unsigned int* d_vhist = nullptr;
@@ -311,6 +312,18 @@ int resolve_n_body(lii_handle h) {
   return LII_OK;
 }
 
+// Bounding-box accumulators of the voxel filter ping-pong: whoever fills one re-arms the other for the next scan.
+void mm_discard(lii_handle h) {  // a new scan arrived: a box nobody consumed is stale, its partner is armed
+  if (h->mm_valid) h->mm_sel ^= 1;
+  h->mm_valid = false;
+}
+void mm_for_deskew(lii_handle h, unsigned int** mm, unsigned int** mm_next) {
+  mm_discard(h);
+  *mm = h->d_mm + 8 * h->mm_sel;
+  *mm_next = h->d_mm + 8 * (h->mm_sel ^ 1);
+  h->mm_valid = true;
+}
+
 MailboxView mailbox_view(lii_handle h) {
   MailboxView v;
   v.slots = h->mailbox.dev_slots;
@@ -401,7 +414,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   const PoseArg ps0 = pose_of(*state);  // unused by the device-driven kernels (they read `pose`)
   const bool prof = h->profiling;
   const double* ne = h->comm ? h->d_out91 + 128 : h->d_out91;
-  for (int it = 0; it < opts->max_iterations; it++) {
+  auto enqueue_pass = [&](int it) -> int {
     const bool timed = prof && it == 0;  // the first pass always searches
     if (timed) HIPCHK(h, hipEventRecord(h->ev[0], s));
     if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it], s));
@@ -414,21 +427,26 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
       launch_reduce_solve(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, h->h_res, rb.n_dev,
                           mailbox_view(h), s);
       if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
-      continue;
+      return LII_OK;
     }
     launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_ctrl, -1, rb.n_dev, s);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
-    {
-      // every rank enqueues the same number of all-reduces; a pass that is skipped on the device re-sums the
-      // unchanged local buffer on all ranks alike, so the ranks stay in lock-step without a host decision
-      ncclResult_t r = ncclAllReduce(h->d_out91, h->d_out91 + 128, kNormalEq, ncclDouble, ncclSum, h->comm, s);
-      if (r != ncclSuccess) return fail(h, LII_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
-    }
+    // every rank enqueues the same number of all-reduces; a pass that is skipped on the device re-sums the
+    // unchanged local buffer on all ranks alike, so the ranks stay in lock-step without a host decision
+    ncclResult_t r = ncclAllReduce(h->d_out91, h->d_out91 + 128, kNormalEq, ncclDouble, ncclSum, h->comm, s);
+    if (r != ncclSuccess) return fail(h, LII_ERR_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
     launch_iekf_solve(h->d_ctrl, ne, h->h_res, s);
+    return LII_OK;
+  };
+  for (int it = 0; it < opts->max_iterations; it++) {
+    rc = enqueue_pass(it);
+    if (rc != LII_OK) return rc;
   }
   // The iteration that stops the loop writes the result block (mapped host memory) and then its sequence number.  Polling
-  // that word instead of synchronising the stream returns as soon as the result exists: the launches enqueued behind the
-  // stopping iteration (they only read `stop` and return) drain while the caller already prepares the next scan.
+  // that word instead of synchronising the stream returns as soon as the result exists: the passes enqueued behind the
+  // stopping one (they only read `stop` and return) drain while the caller already prepares the next scan.
+  // (Enqueueing only as many passes as the previous scan needed, and further ones on demand, was measured: no gain - the
+  // drained passes fit into the host's turn-around between two scans - and a scan that needs more pays a round trip.)
   if (h->poll_result && !prof && !h->comm) {
     volatile int* done = &h->h_res->done;
     unsigned int spins = 0;
@@ -779,6 +797,7 @@ int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_
   if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scan, h->h_stage, sizeof(float4) * size_t(n), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipEventRecord(h->ev_stage, h->stream));
   h->n_scan = n;
+  mm_discard(h);
   h->n_body = 0;
   h->n_body_pending = false;
   h->have_search = false;
@@ -789,6 +808,7 @@ int lii_scan_set_device(lii_handle h, const void* dev_float4, int32_t n) {
   if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_set_device: n > max_scan_points");
   if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scan, dev_float4, sizeof(float4) * size_t(n), hipMemcpyDeviceToDevice, h->stream));
   h->n_scan = n;
+  mm_discard(h);
   h->n_body = 0;
   h->n_body_pending = false;
   h->have_search = false;
@@ -815,7 +835,9 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
   unsigned long long* ext = h->d_extent + 2 * h->extent_sel;
   h->extent_sel ^= 1;
   launch_time_extent(h->d_scan, h->n_scan, ext, h->d_extent + 2 * h->extent_sel, h->stream);
-  launch_undistort_imu(h->d_scan, h->n_scan, h->d_poses, n_poses, u, ext, h->stream);
+  unsigned int *mm, *mm_next;
+  mm_for_deskew(h, &mm, &mm_next);
+  launch_undistort_imu(h->d_scan, h->n_scan, h->d_poses, n_poses, u, ext, mm, mm_next, h->stream);
   HIPCHK(h, hipGetLastError());
   return LII_OK;
 }
@@ -829,7 +851,9 @@ int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], c
   unsigned long long* ext = h->d_extent + 2 * h->extent_sel;
   h->extent_sel ^= 1;
   launch_time_extent(h->d_scan, h->n_scan, ext, h->d_extent + 2 * h->extent_sel, h->stream);
-  launch_undistort_cv(h->d_scan, h->n_scan, a, ext, h->stream);
+  unsigned int *mm, *mm_next;
+  mm_for_deskew(h, &mm, &mm_next);
+  launch_undistort_cv(h->d_scan, h->n_scan, a, ext, mm, mm_next, h->stream);
   HIPCHK(h, hipGetLastError());
   return LII_OK;
 }
@@ -858,9 +882,10 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
   // sample sort -> centroids + count (lii_vsort.hip).  The size of the result stays in HBM (d_nbody); the registration
   // kernels read it there, so the host learns it only if the caller asks (n_down / filtered != NULL, or a download).
   hipStream_t s = h->stream;
-  unsigned int* mm = h->d_mm + 8 * h->mm_sel;
+  unsigned int* mm = h->d_mm + 8 * h->mm_sel;  // the box a de-skew kernel left behind, or a pass of its own over the scan
+  if (!h->mm_valid) launch_voxel_minmax(h->d_scan, n, mm, h->d_mm + 8 * (h->mm_sel ^ 1), s);
   h->mm_sel ^= 1;
-  launch_voxel_minmax(h->d_scan, n, mm, h->d_mm + 8 * h->mm_sel, s);
+  h->mm_valid = false;
   {
     const VoxelSortPlan plan = voxel_sort_plan(n);
     launch_voxel_keys(h->d_scan, n, mm, leaf, h->d_vkeys_a, h->d_nbody + 1, plan.samples ? h->d_vsplit + 2048 : nullptr, plan.width, s);

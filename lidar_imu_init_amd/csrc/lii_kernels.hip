@@ -976,76 +976,10 @@ __device__ __forceinline__ void backprop_once(const double* __restrict__ head /*
   p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
 }
 
-// IMU-mode de-skew.  The reference walks the time-sorted cloud backwards over the pose table; per point this
-// is: head = the LAST pose index h <= K-2 with offset_time[h] < t (strict) — points with no such head stay
-// untouched.  Quirk A3: the time-earliest point (first of the sorted cloud) is re-tested against every earlier
-// head after being compensated, so it is compensated once per qualifying head, in descending order.
-__global__ void k_undistort_imu(float4* __restrict__ pts, int n, const double* __restrict__ poses, int K, UndistArg u,
-                                const unsigned long long* __restrict__ extent) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 P = pts[i];
-  double t = P.w / double(1000);
-  int h = -1;
-  for (int k = K - 2; k >= 0; k--)
-    if (t > poses[22 * k]) { h = k; break; }
-  if (h < 0) return;
-  double p[3] = {P.x, P.y, P.z};
-  backprop_once(poses + 22 * h, t, u, p);
-  const bool is_begin = ((unsigned)(extent[0] & 0xFFFFFFFFull) == (unsigned)i);
-  if (is_begin) {
-    for (int k = h - 1; k >= 0; k--) {
-      if (t > poses[22 * k]) {
-        // the reference reads the already-overwritten float coordinates back
-        p[0] = (double)(float)p[0]; p[1] = (double)(float)p[1]; p[2] = (double)(float)p[2];
-        backprop_once(poses + 22 * k, t, u, p);
-      }
-    }
-  }
-  pts[i] = make_float4((float)p[0], (float)p[1], (float)p[2], P.w);
-}
-
-struct CvArg {
-  double omega[3], vel[3], endR[9];
-};
-// CV-mode de-skew (src/IMU_Processing.hpp:246-266).  The time-earliest point is skipped (quirk A3).
-__global__ void k_undistort_cv(float4* __restrict__ pts, int n, CvArg a, const unsigned long long* __restrict__ extent) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if ((unsigned)(extent[0] & 0xFFFFFFFFull) == (unsigned)i) return;
-  float4 P = pts[i];
-  double end_off = ord2f((unsigned)extent[1]) / double(1000);
-  double dt_j = end_off - P.w / double(1000);
-  double R[9];
-  exp_so3(a.omega, -dt_j, R);
-  double rv[3];
-  mat3t_vec(a.endR, a.vel, rv);
-  double p[3] = {P.x, P.y, P.z}, o[3];
-  mat3_vec(R, p, o);
-#pragma unroll
-  for (int c = 0; c < 3; c++) o[c] = o[c] + (-rv[c]) * dt_j;
-  pts[i] = make_float4((float)o[0], (float)o[1], (float)o[2], P.w);
-}
-
-// ------------------------------------------------------------------------------------------------
-// voxel-grid down-sampling (PCL VoxelGrid restatement, see DESIGN.md §3.5)
-// mm[0..2] = ord(min xyz), mm[3..5] = ord(max xyz)
-__global__ __launch_bounds__(256) void k_voxel_minmax(const float4* __restrict__ pts, int n, unsigned int* __restrict__ mm,
-                                                      unsigned int* __restrict__ mm_next) {
-  // grid-stride over a small grid, wave shuffle + LDS reduction, ONE set of atomics per workgroup; re-arms the ping-pong
-  // partner buffer for the next scan (see k_time_extent)
-  if (blockIdx.x == 0 && threadIdx.x < 6) mm_next[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+// Bounding box of the points a 256-lane workgroup holds (non-finite points excluded), folded into mm[0..2] = ord(min xyz),
+// mm[3..5] = ord(max xyz): wave shuffle + LDS reduction, ONE set of atomics per workgroup.  Every lane must call it.
+__device__ __forceinline__ void block_bbox_accumulate(unsigned int (&lo)[3], unsigned int (&hi)[3], unsigned int* __restrict__ mm) {
   __shared__ unsigned int s_lo[4][3], s_hi[4][3];
-  unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float4 p = pts[i];
-    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-      unsigned int ox = f2ord(p.x), oy = f2ord(p.y), oz = f2ord(p.z);
-      lo[0] = min(lo[0], ox); hi[0] = max(hi[0], ox);
-      lo[1] = min(lo[1], oy); hi[1] = max(hi[1], oy);
-      lo[2] = min(lo[2], oz); hi[2] = max(hi[2], oz);
-    }
-  }
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -1067,6 +1001,99 @@ __global__ __launch_bounds__(256) void k_voxel_minmax(const float4* __restrict__
     atomicMin(&mm[a], l);
     atomicMax(&mm[3 + a], h);
   }
+}
+__device__ __forceinline__ void bbox_point(float x, float y, float z, unsigned int (&lo)[3], unsigned int (&hi)[3]) {
+  if (isfinite(x) && isfinite(y) && isfinite(z)) {
+    const unsigned int ox = f2ord(x), oy = f2ord(y), oz = f2ord(z);
+    lo[0] = min(lo[0], ox); hi[0] = max(hi[0], ox);
+    lo[1] = min(lo[1], oy); hi[1] = max(hi[1], oy);
+    lo[2] = min(lo[2], oz); hi[2] = max(hi[2], oz);
+  }
+}
+// The de-skew kernels leave the bounding box of their output behind (mm != nullptr): the voxel filter that follows needs it
+// and a pass of its own over the scan costs a launch.  Like k_voxel_minmax they re-arm the ping-pong partner for the next scan.
+__device__ __forceinline__ void deskew_bbox(float4 q, bool in_range, unsigned int* __restrict__ mm, unsigned int* __restrict__ mm_next) {
+  if (!mm) return;  // uniform
+  if (blockIdx.x == 0 && threadIdx.x < 6) mm_next[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+  unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+  if (in_range) bbox_point(q.x, q.y, q.z, lo, hi);
+  block_bbox_accumulate(lo, hi, mm);
+}
+
+// IMU-mode de-skew.  The reference walks the time-sorted cloud backwards over the pose table; per point this
+// is: head = the LAST pose index h <= K-2 with offset_time[h] < t (strict) — points with no such head stay
+// untouched.  Quirk A3: the time-earliest point (first of the sorted cloud) is re-tested against every earlier
+// head after being compensated, so it is compensated once per qualifying head, in descending order.
+__global__ __launch_bounds__(256) void k_undistort_imu(float4* __restrict__ pts, int n, const double* __restrict__ poses, int K,
+                                                       UndistArg u, const unsigned long long* __restrict__ extent,
+                                                       unsigned int* __restrict__ mm, unsigned int* __restrict__ mm_next) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in_range = i < n;
+  float4 P = in_range ? pts[i] : make_float4(0, 0, 0, 0);
+  if (in_range) {
+    double t = P.w / double(1000);
+    int h = -1;
+    for (int k = K - 2; k >= 0; k--)
+      if (t > poses[22 * k]) { h = k; break; }
+    if (h >= 0) {
+      double p[3] = {P.x, P.y, P.z};
+      backprop_once(poses + 22 * h, t, u, p);
+      const bool is_begin = ((unsigned)(extent[0] & 0xFFFFFFFFull) == (unsigned)i);
+      if (is_begin) {
+        for (int k = h - 1; k >= 0; k--) {
+          if (t > poses[22 * k]) {
+            // the reference reads the already-overwritten float coordinates back
+            p[0] = (double)(float)p[0]; p[1] = (double)(float)p[1]; p[2] = (double)(float)p[2];
+            backprop_once(poses + 22 * k, t, u, p);
+          }
+        }
+      }
+      P = make_float4((float)p[0], (float)p[1], (float)p[2], P.w);
+      pts[i] = P;
+    }
+  }
+  deskew_bbox(P, in_range, mm, mm_next);
+}
+
+struct CvArg {
+  double omega[3], vel[3], endR[9];
+};
+// CV-mode de-skew (src/IMU_Processing.hpp:246-266).  The time-earliest point is skipped (quirk A3).
+__global__ __launch_bounds__(256) void k_undistort_cv(float4* __restrict__ pts, int n, CvArg a, const unsigned long long* __restrict__ extent,
+                                                      unsigned int* __restrict__ mm, unsigned int* __restrict__ mm_next) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in_range = i < n;
+  float4 P = in_range ? pts[i] : make_float4(0, 0, 0, 0);
+  if (in_range && (unsigned)(extent[0] & 0xFFFFFFFFull) != (unsigned)i) {
+    double end_off = ord2f((unsigned)extent[1]) / double(1000);
+    double dt_j = end_off - P.w / double(1000);
+    double R[9];
+    exp_so3(a.omega, -dt_j, R);
+    double rv[3];
+    mat3t_vec(a.endR, a.vel, rv);
+    double p[3] = {P.x, P.y, P.z}, o[3];
+    mat3_vec(R, p, o);
+#pragma unroll
+    for (int c = 0; c < 3; c++) o[c] = o[c] + (-rv[c]) * dt_j;
+    P = make_float4((float)o[0], (float)o[1], (float)o[2], P.w);
+    pts[i] = P;
+  }
+  deskew_bbox(P, in_range, mm, mm_next);
+}
+
+// ------------------------------------------------------------------------------------------------
+// voxel-grid down-sampling (PCL VoxelGrid restatement, see DESIGN.md §3.5)
+// mm[0..2] = ord(min xyz), mm[3..5] = ord(max xyz)
+__global__ __launch_bounds__(256) void k_voxel_minmax(const float4* __restrict__ pts, int n, unsigned int* __restrict__ mm,
+                                                      unsigned int* __restrict__ mm_next) {
+  // grid-stride over a small grid; re-arms the ping-pong partner buffer for the next scan (see k_time_extent)
+  if (blockIdx.x == 0 && threadIdx.x < 6) mm_next[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+  unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p = pts[i];
+    bbox_point(p.x, p.y, p.z, lo, hi);
+  }
+  block_bbox_accumulate(lo, hi, mm);
 }
 
 struct VoxelArg {
@@ -1303,17 +1330,18 @@ void launch_time_extent(const float4* pts, int n, unsigned long long* extent, un
   hipLaunchKernelGGL(k_time_extent, dim3(nb), dim3(256), 0, s, pts, n, extent, extent_next);
 }
 void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& uh,
-                          const unsigned long long* extent, hipStream_t s) {
+                          const unsigned long long* extent, unsigned int* mm, unsigned int* mm_next, hipStream_t s) {
   UndistArg u;
   static_assert(sizeof(UndistArg) == sizeof(UndistArgH), "layout");
   memcpy(&u, &uh, sizeof(u));
-  if (n > 0) hipLaunchKernelGGL(k_undistort_imu, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent);
+  if (n > 0) hipLaunchKernelGGL(k_undistort_imu, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent, mm, mm_next);
 }
-void launch_undistort_cv(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, hipStream_t s) {
+void launch_undistort_cv(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, unsigned int* mm,
+                         unsigned int* mm_next, hipStream_t s) {
   CvArg a;
   static_assert(sizeof(CvArg) == sizeof(CvArgH), "layout");
   memcpy(&a, &ah, sizeof(a));
-  if (n > 0) hipLaunchKernelGGL(k_undistort_cv, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent);
+  if (n > 0) hipLaunchKernelGGL(k_undistort_cv, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent, mm, mm_next);
 }
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s) {
   int nb = nblk(n, 256 * 4);

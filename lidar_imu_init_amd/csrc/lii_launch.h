@@ -54,8 +54,9 @@ int register_blocks(int n);
 // undistortion
 void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, hipStream_t s);
 void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& u,
-                          const unsigned long long* extent, hipStream_t s);
-void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned long long* extent, hipStream_t s);
+                          const unsigned long long* extent, unsigned int* mm, unsigned int* mm_next, hipStream_t s);
+void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned long long* extent, unsigned int* mm,
+                         unsigned int* mm_next, hipStream_t s);
 // voxel grid
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s);
 void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, float leaf, unsigned int* keys,

@@ -190,3 +190,4 @@ def test_communicator_path_world_size_one(oracle, small_world):
     assert np.array_equal(out[0][0], out[1][0])
     assert out[0][1]["iterations"] == out[1][1]["iterations"] and np.array_equal(out[0][1]["normal_eq"], out[1][1]["normal_eq"])
     assert np.array_equal(out[0][2], out[1][2])
+
