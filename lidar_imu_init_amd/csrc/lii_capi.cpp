@@ -81,6 +81,7 @@ struct lii_context {
   unsigned long long* d_extent = nullptr;  // 2 x {min (time|index), max time}: ping-pong accumulators
   unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
   int extent_sel = 0, mm_sel = 0;
+  bool extent_valid = false;  // d_extent[extent_sel] holds the time extent of d_scan (lii_scan_set_device computed it on the way)
   bool mm_valid = false;  // d_mm[mm_sel] holds the bounding box of d_scan (left behind by a de-skew kernel); else it is armed
   unsigned int *d_vkeys_a = nullptr, *d_vkeys_b = nullptr, *d_vidx_b = nullptr;
   unsigned long long *d_vcomp = nullptr, *d_vsplit = nullptr;  // sample sort of the voxel filter (lii_vsort.hip)
@@ -316,6 +317,19 @@ int resolve_n_body(lii_handle h) {
 void mm_discard(lii_handle h) {  // a new scan arrived: a box nobody consumed is stale, its partner is armed
   if (h->mm_valid) h->mm_sel ^= 1;
   h->mm_valid = false;
+}
+// Same protocol for the time extent of the scan: returns the accumulator that holds it, launching the reduction unless the
+// scan's arrival already produced it.
+void extent_discard(lii_handle h) {
+  if (h->extent_valid) h->extent_sel ^= 1;
+  h->extent_valid = false;
+}
+unsigned long long* extent_of_scan(lii_handle h) {
+  unsigned long long* ext = h->d_extent + 2 * h->extent_sel;
+  if (!h->extent_valid) launch_time_extent(h->d_scan, h->n_scan, ext, h->d_extent + 2 * (h->extent_sel ^ 1), nullptr, h->stream);
+  h->extent_sel ^= 1;  // consumed: the partner (re-armed by whoever filled `ext`) serves the next scan
+  h->extent_valid = false;
+  return ext;
 }
 void mm_for_deskew(lii_handle h, unsigned int** mm, unsigned int** mm_next) {
   mm_discard(h);
@@ -797,6 +811,7 @@ int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_
   if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scan, h->h_stage, sizeof(float4) * size_t(n), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipEventRecord(h->ev_stage, h->stream));
   h->n_scan = n;
+  extent_discard(h);
   mm_discard(h);
   h->n_body = 0;
   h->n_body_pending = false;
@@ -806,9 +821,14 @@ int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_
 int lii_scan_set_device(lii_handle h, const void* dev_float4, int32_t n) {
   if (!h || (!dev_float4 && n > 0) || n < 0) return fail(h, LII_ERR_INVALID, "lii_scan_set_device: bad arguments");
   if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_set_device: n > max_scan_points");
-  if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scan, dev_float4, sizeof(float4) * size_t(n), hipMemcpyDeviceToDevice, h->stream));
-  h->n_scan = n;
+  extent_discard(h);
   mm_discard(h);
+  if (n > 0) {  // copy + time extent of the scan in one pass (the de-skew that usually follows needs the extent)
+    launch_time_extent(static_cast<const float4*>(dev_float4), n, h->d_extent + 2 * h->extent_sel,
+                       h->d_extent + 2 * (h->extent_sel ^ 1), h->d_scan, h->stream);
+    h->extent_valid = true;
+  }
+  h->n_scan = n;
   h->n_body = 0;
   h->n_body_pending = false;
   h->have_search = false;
@@ -832,9 +852,7 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
   std::memcpy(u.endp, end_p, 24);
   std::memcpy(u.RLI, R_LI, 72);
   std::memcpy(u.TLI, T_LI, 24);
-  unsigned long long* ext = h->d_extent + 2 * h->extent_sel;
-  h->extent_sel ^= 1;
-  launch_time_extent(h->d_scan, h->n_scan, ext, h->d_extent + 2 * h->extent_sel, h->stream);
+  unsigned long long* ext = extent_of_scan(h);
   unsigned int *mm, *mm_next;
   mm_for_deskew(h, &mm, &mm_next);
   launch_undistort_imu(h->d_scan, h->n_scan, h->d_poses, n_poses, u, ext, mm, mm_next, h->stream);
@@ -848,9 +866,7 @@ int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], c
   std::memcpy(a.omega, omega, 24);
   std::memcpy(a.vel, vel, 24);
   std::memcpy(a.endR, end_R, 72);
-  unsigned long long* ext = h->d_extent + 2 * h->extent_sel;
-  h->extent_sel ^= 1;
-  launch_time_extent(h->d_scan, h->n_scan, ext, h->d_extent + 2 * h->extent_sel, h->stream);
+  unsigned long long* ext = extent_of_scan(h);
   unsigned int *mm, *mm_next;
   mm_for_deskew(h, &mm, &mm_next);
   launch_undistort_cv(h->d_scan, h->n_scan, a, ext, mm, mm_next, h->stream);

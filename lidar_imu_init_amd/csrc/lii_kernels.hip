@@ -876,15 +876,19 @@ __device__ __forceinline__ unsigned int f2ord(float f) {
 }
 // extent[0] = (ord(t_min) << 32) | index of the first point with that time ; extent[1] = ord(t_max)
 // grid-stride over a small grid, wave shuffle + LDS reduction, ONE pair of atomics per block
+// COPY != nullptr: the scan is adopted from a caller-owned device buffer on the way (lii_scan_set_device) - one pass
+// and one launch instead of a copy followed by the reduction.
 __global__ __launch_bounds__(256) void k_time_extent(const float4* __restrict__ pts, int n, unsigned long long* __restrict__ extent,
-                                                     unsigned long long* __restrict__ extent_next) {
+                                                     unsigned long long* __restrict__ extent_next, float4* __restrict__ copy_to) {
   __shared__ unsigned long long smn[4], smx[4];
   // the accumulators ping-pong between two buffers: this launch re-arms the one the NEXT scan will reduce into (nobody reads
   // it any more: its consumers belonged to the previous scan), which saves a separate initialisation launch per scan
   if (blockIdx.x == 0 && threadIdx.x == 0) { extent_next[0] = ~0ull; extent_next[1] = 0ull; }
   unsigned long long mn = ~0ull, mx = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    unsigned int o = f2ord(pts[i].w);
+    const float4 p = pts[i];
+    if (copy_to) copy_to[i] = p;
+    unsigned int o = f2ord(p.w);
     unsigned long long a = ((unsigned long long)o << 32) | (unsigned)i;
     mn = a < mn ? a : mn;
     mx = (unsigned long long)o > mx ? (unsigned long long)o : mx;
@@ -1323,11 +1327,12 @@ void launch_reduce91(const double* partials, int n_points, int stride, double* o
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, ctrl, forced, n_dev);
 }
-void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, hipStream_t s) {
-  int nb = nblk(n, 256 * 8);
-  if (nb > 256) nb = 256;
+void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, float4* copy_to,
+                        hipStream_t s) {
+  int nb = nblk(n, 256 * (copy_to ? 2 : 8));  // a copy wants the whole chip, the bare reduction few atomics
+  if (nb > (copy_to ? 1024 : 256)) nb = copy_to ? 1024 : 256;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_time_extent, dim3(nb), dim3(256), 0, s, pts, n, extent, extent_next);
+  hipLaunchKernelGGL(k_time_extent, dim3(nb), dim3(256), 0, s, pts, n, extent, extent_next, copy_to);
 }
 void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& uh,
                           const unsigned long long* extent, unsigned int* mm, unsigned int* mm_next, hipStream_t s) {
