@@ -143,10 +143,13 @@ def main():
 
     def step(k):
         j = k % len(dev_scans)
+        hand_over = None
         if args.upload:
             reg.scan_upload(host_scans[j])
-        else:
+        elif args.separate_calls:
             reg.scan_set_device(dev_scans[j])
+        else:
+            hand_over = dev_scans[j]  # lii_scan_job::scan_dev: the scan is adopted inside the one call
         st = states0[j].copy()
         if args.separate_calls:
             s0 = states0[j]
@@ -158,7 +161,7 @@ def main():
             rep = reg.iekf_update(st, states0[j], max_iterations=wl["max_it"], imu_en=True)
         else:  # the same three stages through the one-call entry point (one host round trip per scan)
             rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=0.0 if args.no_downsample else wl["fs_surf"],
-                                    max_iterations=wl["max_it"], imu_en=True)
+                                    max_iterations=wl["max_it"], imu_en=True, scan_dev=hand_over)
         iters_total[0] += rep["iterations"]
         search_total[0] += rep["searches"]
         if args.map_update:

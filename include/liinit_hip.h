@@ -204,6 +204,9 @@ typedef struct lii_scan_job {
   int32_t n_imu_poses;
   float leaf;                      /* voxel-grid leaf size; <= 0: use the scan unfiltered */
   lii_iekf_opts opts;
+  const void* scan_dev;            /* optional: adopt this device-resident scan first (as lii_scan_set_device would: float4
+                                      x, y, z, t_ms; caller-owned, only read) - saves the separate call and a launch */
+  int32_t n_scan_dev;
 } lii_scan_job;
 int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, const lii_state* state_propagated,
                       lii_iekf_report* report);

@@ -45,7 +45,8 @@ class lii_iekf_report(C.Structure):
 
 class lii_scan_job(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("undistort", C.c_int32), ("imu_poses", C.c_void_p),
-                ("n_imu_poses", C.c_int32), ("leaf", C.c_float), ("opts", lii_iekf_opts)]
+                ("n_imu_poses", C.c_int32), ("leaf", C.c_float), ("opts", lii_iekf_opts), ("scan_dev", C.c_void_p),
+                ("n_scan_dev", C.c_int32)]
 
 
 class lii_pc2_fields(C.Structure):
@@ -376,10 +377,13 @@ class Registrar:
                     converged=bool(rep.converged), normal_eq=np.array(rep.normal_eq[:]))
 
     def scan_register(self, state: State, state_prop: State, *, imu_poses=None, cv=False, leaf=0.0, max_iterations=4,
-                      imu_en=False):
-        """Undistortion + voxel grid + iterated update in one library call (one host synchronisation)."""
+                      imu_en=False, scan_dev=None):
+        """Undistortion + voxel grid + iterated update in one library call (one host synchronisation).  scan_dev: a
+        device_scan() handle to adopt first (what scan_set_device would do, without the separate call)."""
         job = lii_scan_job()
         job.struct_size = C.sizeof(lii_scan_job)
+        if scan_dev is not None:
+            job.scan_dev, job.n_scan_dev = scan_dev[0], scan_dev[1]
         poses = None
         if imu_poses is not None:
             poses = np.ascontiguousarray(imu_poses, np.float64).reshape(-1, 22)

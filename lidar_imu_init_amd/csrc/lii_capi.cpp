@@ -81,6 +81,7 @@ struct lii_context {
   unsigned long long* d_extent = nullptr;  // 2 x {min (time|index), max time}: ping-pong accumulators
   unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
   int extent_sel = 0, mm_sel = 0;
+  size_t ctrl_pending = 0;    // bytes of h_ctrl (+ poses) the next k_time_extent launch carries to d_ctrl; 0 = nothing pending
   bool extent_valid = false;  // d_extent[extent_sel] holds the time extent of d_scan (lii_scan_set_device computed it on the way)
   bool mm_valid = false;  // d_mm[mm_sel] holds the bounding box of d_scan (left behind by a de-skew kernel); else it is armed
   unsigned int *d_vkeys_a = nullptr, *d_vkeys_b = nullptr, *d_vidx_b = nullptr;
@@ -326,7 +327,11 @@ void extent_discard(lii_handle h) {
 }
 unsigned long long* extent_of_scan(lii_handle h) {
   unsigned long long* ext = h->d_extent + 2 * h->extent_sel;
-  if (!h->extent_valid) launch_time_extent(h->d_scan, h->n_scan, ext, h->d_extent + 2 * (h->extent_sel ^ 1), nullptr, h->stream);
+  if (!h->extent_valid) {
+    launch_time_extent(h->d_scan, h->n_scan, ext, h->d_extent + 2 * (h->extent_sel ^ 1), nullptr, h->h_ctrl, h->d_ctrl, h->ctrl_pending,
+                       h->stream);
+    h->ctrl_pending = 0;
+  }
   h->extent_sel ^= 1;  // consumed: the partner (re-armed by whoever filled `ext`) serves the next scan
   h->extent_valid = false;
   return ext;
@@ -825,7 +830,8 @@ int lii_scan_set_device(lii_handle h, const void* dev_float4, int32_t n) {
   mm_discard(h);
   if (n > 0) {  // copy + time extent of the scan in one pass (the de-skew that usually follows needs the extent)
     launch_time_extent(static_cast<const float4*>(dev_float4), n, h->d_extent + 2 * h->extent_sel,
-                       h->d_extent + 2 * (h->extent_sel ^ 1), h->d_scan, h->stream);
+                       h->d_extent + 2 * (h->extent_sel ^ 1), h->d_scan, h->h_ctrl, h->d_ctrl, h->ctrl_pending, h->stream);
+    h->ctrl_pending = 0;
     h->extent_valid = true;
   }
   h->n_scan = n;
@@ -1031,16 +1037,26 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   if (!h || !job || job->struct_size != sizeof(lii_scan_job) || !state || !state_prop || job->opts.max_iterations < 1)
     return fail(h, LII_ERR_INVALID, "lii_scan_register: bad arguments");
   int rc = LII_OK;
-  if (job->undistort == 1 && !h->host_solve && job->imu_poses && job->n_imu_poses >= 2 && job->n_imu_poses <= 1024 && h->n_scan > 0) {
-    // one H2D copy for the control block of the update AND the pose table of the de-skew (they sit behind each other)
-    HIPCHK(h, hipEventSynchronize(h->ev_poses));
+  const bool adopt = job->scan_dev != nullptr && job->n_scan_dev > 0;
+  if (adopt && job->n_scan_dev > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_register: n_scan_dev > max_scan_points");
+  const int n_next = adopt ? job->n_scan_dev : h->n_scan;
+  if (job->undistort == 1 && !h->host_solve && job->imu_poses && job->n_imu_poses >= 2 && job->n_imu_poses <= 1024 && n_next > 0) {
+    // the control block of the update AND the pose table of the de-skew (they sit behind each other) reach the device once
+    HIPCHK(h, hipEventSynchronize(h->ev_poses));  // the previous scan's copy of them has left the staging buffer
     fill_ctrl(h, state, state_prop, &job->opts);
     std::memcpy(h->h_poses, job->imu_poses, sizeof(lii_pose6d) * size_t(job->n_imu_poses));
-    // (size rounded to 1 KiB: the runtime splits an H2D copy with an unaligned tail into two blit kernels)
-    HIPCHK(h, hipMemcpyAsync(h->d_ctrl, h->h_ctrl, (kCtrlBytes + sizeof(lii_pose6d) * size_t(job->n_imu_poses) + 1023) / 1024 * 1024, hipMemcpyHostToDevice,
-                             h->stream));
-    HIPCHK(h, hipEventRecord(h->ev_poses, h->stream));
+    const size_t bytes = kCtrlBytes + sizeof(lii_pose6d) * size_t(job->n_imu_poses);
+    if (adopt || !h->extent_valid) {
+      h->ctrl_pending = (bytes + 15) / 16 * 16;  // rides in the scan's first kernel (k_time_extent), which is launched below
+    } else {
+      // (size rounded to 1 KiB: the runtime splits an H2D copy with an unaligned tail into two blit kernels)
+      HIPCHK(h, hipMemcpyAsync(h->d_ctrl, h->h_ctrl, (bytes + 1023) / 1024 * 1024, hipMemcpyHostToDevice, h->stream));
+    }
     h->poses_preloaded = h->ctrl_preloaded = true;
+  }
+  if (adopt) {
+    rc = lii_scan_set_device(h, job->scan_dev, job->n_scan_dev);
+    if (rc != LII_OK) { h->ctrl_pending = 0; h->poses_preloaded = h->ctrl_preloaded = false; return rc; }
   }
   if (job->undistort == 1) {
     rc = lii_undistort_imu(h, job->imu_poses, job->n_imu_poses, state->rot_end, state->pos_end, state->offset_R_L_I,
@@ -1049,6 +1065,13 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     rc = lii_undistort_cv(h, state->bias_g, state->vel_end, state->rot_end);  // CV model: bias_g = omega, vel_end = v
   } else if (job->undistort != 0) {
     return fail(h, LII_ERR_INVALID, "lii_scan_register: undistort must be 0, 1 or 2");
+  }
+  if (h->ctrl_preloaded) {
+    if (h->ctrl_pending) {  // no kernel picked the block up (cannot happen with the conditions above; kept as a guard)
+      HIPCHK(h, hipMemcpyAsync(h->d_ctrl, h->h_ctrl, h->ctrl_pending, hipMemcpyHostToDevice, h->stream));
+      h->ctrl_pending = 0;
+    }
+    HIPCHK(h, hipEventRecord(h->ev_poses, h->stream));  // whoever read the staging buffer is behind this point of the stream
   }
   if (rc == LII_OK) rc = job->leaf > 0 ? lii_downsample(h, job->leaf, nullptr, nullptr) : lii_downsample_skip(h, nullptr);
   if (rc == LII_OK) rc = lii_iekf_update(h, state, state_prop, &job->opts, report);

@@ -876,11 +876,16 @@ __device__ __forceinline__ unsigned int f2ord(float f) {
 }
 // extent[0] = (ord(t_min) << 32) | index of the first point with that time ; extent[1] = ord(t_max)
 // grid-stride over a small grid, wave shuffle + LDS reduction, ONE pair of atomics per block
-// COPY != nullptr: the scan is adopted from a caller-owned device buffer on the way (lii_scan_set_device) - one pass
+// copy_to != nullptr: the scan is adopted from a caller-owned device buffer on the way (lii_scan_set_device) - one pass
 // and one launch instead of a copy followed by the reduction.
 __global__ __launch_bounds__(256) void k_time_extent(const float4* __restrict__ pts, int n, unsigned long long* __restrict__ extent,
-                                                     unsigned long long* __restrict__ extent_next, float4* __restrict__ copy_to) {
+                                                     unsigned long long* __restrict__ extent_next, float4* __restrict__ copy_to,
+                                                     const uint4* __restrict__ ctrl_src, uint4* __restrict__ ctrl_dst, int ctrl_vec) {
   __shared__ unsigned long long smn[4], smx[4];
+  // first kernel of a scan: workgroup 0 also pulls the update's control block + IMU pose table out of the caller-side pinned
+  // buffer (ctrl_vec 16-byte words over PCIe, ~3 us inside this launch instead of an H2D copy submission of ~10 us before it)
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < ctrl_vec; i += 256) ctrl_dst[i] = ctrl_src[i];
   // the accumulators ping-pong between two buffers: this launch re-arms the one the NEXT scan will reduce into (nobody reads
   // it any more: its consumers belonged to the previous scan), which saves a separate initialisation launch per scan
   if (blockIdx.x == 0 && threadIdx.x == 0) { extent_next[0] = ~0ull; extent_next[1] = 0ull; }
@@ -1328,11 +1333,12 @@ void launch_reduce91(const double* partials, int n_points, int stride, double* o
   hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, ctrl, forced, n_dev);
 }
 void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, float4* copy_to,
-                        hipStream_t s) {
+                        const void* ctrl_src, void* ctrl_dst, size_t ctrl_bytes, hipStream_t s) {
   int nb = nblk(n, 256 * (copy_to ? 2 : 8));  // a copy wants the whole chip, the bare reduction few atomics
   if (nb > (copy_to ? 1024 : 256)) nb = copy_to ? 1024 : 256;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_time_extent, dim3(nb), dim3(256), 0, s, pts, n, extent, extent_next, copy_to);
+  hipLaunchKernelGGL(k_time_extent, dim3(nb), dim3(256), 0, s, pts, n, extent, extent_next, copy_to,
+                     static_cast<const uint4*>(ctrl_src), static_cast<uint4*>(ctrl_dst), (int)(ctrl_bytes / 16));
 }
 void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& uh,
                           const unsigned long long* extent, unsigned int* mm, unsigned int* mm_next, hipStream_t s) {

@@ -53,7 +53,7 @@ void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream
 int register_blocks(int n);
 // undistortion
 void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, float4* copy_to,
-                        hipStream_t s);
+                        const void* ctrl_src, void* ctrl_dst, size_t ctrl_bytes, hipStream_t s);
 void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& u,
                           const unsigned long long* extent, unsigned int* mm, unsigned int* mm_next, hipStream_t s);
 void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned long long* extent, unsigned int* mm,

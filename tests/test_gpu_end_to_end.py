@@ -242,6 +242,17 @@ def test_scan_register_equals_separate_calls(oracle):
         assert np.array_equal(a.pod, b.pod)
         assert rep_a["iterations"] == rep_b["iterations"] and np.array_equal(rep_a["normal_eq"], rep_b["normal_eq"])
         assert rep_b["effect_num"] > 1000
+        # the same scan handed over inside the job (lii_scan_job::scan_dev): adoption, time extent and the upload of the
+        # control block share the first kernel; and once more after a separate lii_scan_set_device (extent already there)
+        dev = reg.device_scan(scan)
+        for separate in (False, True):
+            if separate:
+                reg.scan_set_device(dev)
+            c = lii.State(st0)
+            rep_c = reg.scan_register(c, lii.State(st0), imu_poses=T, leaf=0.1, max_iterations=5, imu_en=imu_en,
+                                      scan_dev=None if separate else dev)
+            assert np.array_equal(a.pod, c.pod)
+            assert rep_a["iterations"] == rep_c["iterations"] and np.array_equal(rep_a["normal_eq"], rep_c["normal_eq"])
     # LO mode: constant-velocity de-skew taken from the state's bias_g / vel_end slots
     s0.bias_g[:] = [1e-3, 0, 2e-3]
     s0.vel_end[:] = [0.05, 0, 0]
