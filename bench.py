@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--upload", action="store_true",
                     help="hand every scan over from HOST memory (lii_scan_upload, PCIe inside the timed region) instead of HBM")
     ap.add_argument("--separate-calls", action="store_true", help="undistort / downsample / update as three library calls")
+    ap.add_argument("--python-loop", action="store_true", help="drive the per-scan loop from Python (ctypes) instead of the C++ host loop")
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="stream100k", choices=sorted(WORKLOADS))
@@ -168,12 +169,48 @@ def main():
             reg.map_incremental(st)
         return st
 
+    # The timed loop is the C++ host loop of harness/stream_driver.cpp (one lii_scan_register per scan, the scan handed over
+    # in HBM): the reference's host is C++, and a ctypes round trip per scan is ~25 us of interpreter time no deployment
+    # pays.  --python-loop / --separate-calls / --upload / LII_BENCH_TRACE keep the loop in Python (same calls).
+    native = None
+    if not (args.python_loop or args.separate_calls or args.upload or os.environ.get("LII_BENCH_TRACE")):
+        import ctypes as C
+
+        class StreamScan(C.Structure):
+            _fields_ = [("scan_dev", C.c_void_p), ("n_points", C.c_int32), ("n_poses", C.c_int32), ("poses", C.c_void_p),
+                        ("state0", C.c_void_p)]
+        drv_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "harness", "libliinit_stream.so")
+        if not os.path.exists(drv_path):
+            raise SystemExit(f"{drv_path} missing - run `python -c 'import __graft_entry__ as g; g.build()'`")
+        drv = C.CDLL(drv_path)
+        drv.lii_stream_run.restype = C.c_int
+        drv.lii_stream_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        tables_c = [np.ascontiguousarray(t, np.float64) for t in tables]
+        stream = (StreamScan * len(dev_scans))()
+        for j, d in enumerate(dev_scans):
+            stream[j].scan_dev, stream[j].n_points = d[0], d[1]
+            stream[j].poses, stream[j].n_poses = tables_c[j].ctypes.data, len(tables_c[j])
+            stream[j].state0 = states0[j].pod.ctypes.data
+        totals = np.zeros(2, np.int64)
+        last_pod = lii.State()
+
+        def native(first, steps, profile_every):
+            rc = drv.lii_stream_run(reg.h, C.byref(stream), len(dev_scans), first, steps,
+                                    0.0 if args.no_downsample else float(wl["fs_surf"]), int(wl["max_it"]), 1,
+                                    int(bool(args.map_update)), int(profile_every), totals.ctypes.data, last_pod.pod.ctypes.data)
+            if rc != 0:
+                raise SystemExit(f"lii_stream_run: status {rc}: {reg.L.lii_last_error(reg.h).decode()}")
+
     # The ROCm runtime grows internal pools (signals / staging) once, ~100 steps into a process: a single 30-50 ms
     # stall at a fixed step index.  Prime it out before the W warm-up steps so that it cannot land in the timed region.
-    for k in range(args.prime):
-        step(k)
-    for k in range(args.warmup):
-        step(k)
+    if native:
+        native(0, args.prime + args.warmup, 0)
+    else:
+        for k in range(args.prime):
+            step(k)
+        for k in range(args.warmup):
+            step(k)
     reg.synchronize()
     reg.set_profiling(1)
     reg.set_profiling(0)
@@ -185,13 +222,19 @@ def main():
     last = None
     trace = os.environ.get("LII_BENCH_TRACE")
     stamps = []
-    for k in range(args.steps):
-        # HIP-event brackets of the kernels are recorded on every 8th step of the timed region only: each event is a
-        # barrier packet on the stream, and ten of them per scan would cost ~5 % of the throughput being measured
-        reg.set_profiling(2 if (args.profile_every and k % args.profile_every == 0) else 0)
-        last = step(k)
-        if trace:
-            stamps.append(time.perf_counter())
+    # HIP-event brackets of the kernels are recorded on every 8th step of the timed region only: each event is a
+    # barrier packet on the stream, and ten of them per scan would cost ~5 % of the throughput being measured
+    if native:
+        totals[:] = 0
+        native(0, args.steps, args.profile_every)
+        iters_total[0], search_total[0] = int(totals[0]), int(totals[1])
+        last = last_pod
+    else:
+        for k in range(args.steps):
+            reg.set_profiling(2 if (args.profile_every and k % args.profile_every == 0) else 0)
+            last = step(k)
+            if trace:
+                stamps.append(time.perf_counter())
     reg.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
@@ -230,7 +273,8 @@ def main():
             "config": {"workload": f"{args.workload}: {n_full} pts/scan vs {M}-pt local map, max_iteration {wl['max_it']}, "
                                    f"LIO mode (12-col H), {'map_incremental every step' if args.map_update else 'static map'}, {'voxel-grid leaf %.2f' % wl['fs_surf'] if not args.no_downsample else 'no voxel-grid'}",
                        "points_per_scan": n_full, "map_points": M, "avg_iterations": iters_total[0] / args.steps,
-                       "avg_knn_passes": search_total[0] / args.steps, "parallelism": f"points sharded x{world}" + (f", 91-scalar exchange over {reg.comm_transport()}" if world > 1 else "")},
+                       "avg_knn_passes": search_total[0] / args.steps,
+                       "host_loop": "C++ (harness/stream_driver.cpp)" if native else "Python (ctypes)", "parallelism": f"points sharded x{world}" + (f", 91-scalar exchange over {reg.comm_transport()}" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_knn_pruned<4> (exact 5-NN into the block-grid local map, 4 lanes/query, box-distance pruning)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": avg_search_ms, "alg_bytes_per_launch": alg_bytes,

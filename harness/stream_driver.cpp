@@ -1,0 +1,58 @@
+// A laserMapping-shaped host loop over the C-ABI, in the reference's host language: per scan the propagated state and the
+// IMU pose table go in, lii_scan_register (de-skew -> voxel grid -> iterated update) runs, the map takes the scan
+// (map_incremental) when asked.  bench.py times THIS loop: a ROS node calling the library is C++, and a ctypes round trip
+// per scan costs ~25 us of interpreter time that no deployment would pay.  Harness code, not product: it only calls
+// include/liinit_hip.h.   (the call sites it stands for: src/laserMapping.cpp:905-919 + :960-1120 + :1130 map_incremental)
+#include <cstdint>
+#include <cstring>
+
+#include "liinit_hip.h"
+
+extern "C" {
+
+typedef struct lii_stream_scan {
+  const void* scan_dev;      // device-resident float4 (x, y, z, t_ms), caller-owned
+  int32_t n_points;
+  int32_t n_poses;
+  const lii_pose6d* poses;   // IMUpose table of this scan
+  const lii_state* state0;   // the state IMU propagation hands to the update (state_propagat == start of the iteration)
+} lii_stream_scan;
+
+// Runs steps [first, first + steps) of the cyclic stream.  profile_every > 0: HIP-event kernel timing on every Nth step.
+// Returns the first non-zero library status; totals[0] += iterations, totals[1] += k-NN passes.
+int lii_stream_run(lii_handle h, const lii_stream_scan* scans, int32_t n_scans, int32_t first, int32_t steps, float leaf,
+                   int32_t max_iterations, int32_t imu_en, int32_t map_update, int32_t profile_every, int64_t totals[2],
+                   lii_state* last_state) {
+  if (!h || !scans || n_scans < 1 || steps < 0 || !totals) return LII_ERR_INVALID;
+  lii_state st;
+  lii_iekf_report rep;
+  for (int32_t k = first; k < first + steps; k++) {
+    const lii_stream_scan& sc = scans[k % n_scans];
+    int rc = lii_set_profiling(h, (profile_every > 0 && k % profile_every == 0) ? 2 : 0);
+    if (rc != LII_OK) return rc;
+    std::memcpy(&st, sc.state0, sizeof(st));
+    lii_scan_job job;
+    std::memset(&job, 0, sizeof(job));
+    job.struct_size = sizeof(job);
+    job.undistort = 1;
+    job.imu_poses = sc.poses;
+    job.n_imu_poses = sc.n_poses;
+    job.leaf = leaf;
+    job.opts.max_iterations = max_iterations;
+    job.opts.imu_en = imu_en;
+    job.scan_dev = sc.scan_dev;
+    job.n_scan_dev = sc.n_points;
+    rc = lii_scan_register(h, &job, &st, sc.state0, &rep);
+    if (rc != LII_OK) return rc;
+    totals[0] += rep.iterations;
+    totals[1] += rep.searches;
+    if (map_update) {
+      rc = lii_map_incremental(h, &st, nullptr, nullptr);
+      if (rc != LII_OK) return rc;
+    }
+  }
+  if (last_state && steps > 0) std::memcpy(last_state, &st, sizeof(st));
+  return LII_OK;
+}
+
+}  // extern "C"
