@@ -83,7 +83,8 @@ struct lii_context {
   int extent_sel = 0, mm_sel = 0;
   size_t ctrl_pending = 0;    // bytes of h_ctrl (+ poses) the next k_time_extent launch carries to d_ctrl; 0 = nothing pending
   bool extent_valid = false;  // d_extent[extent_sel] holds the time extent of d_scan (lii_scan_set_device computed it on the way)
-  bool mm_valid = false;  // d_mm[mm_sel] holds the bounding box of d_scan (left behind by a de-skew kernel); else it is armed
+  unsigned int* d_bbox_rows = nullptr;  // one row per de-skew workgroup: bounding box of its output points
+  int bbox_rows = 0;                    // rows valid for the current d_scan (0: the voxel filter makes its own pass)
   unsigned int *d_vkeys_a = nullptr, *d_vkeys_b = nullptr, *d_vidx_b = nullptr;
   unsigned long long *d_vcomp = nullptr, *d_vsplit = nullptr;  // sample sort of the voxel filter (lii_vsort.hip)
   unsigned int* d_vhist = nullptr;
@@ -314,13 +315,8 @@ int resolve_n_body(lii_handle h) {
   return LII_OK;
 }
 
-// Bounding-box accumulators of the voxel filter ping-pong: whoever fills one re-arms the other for the next scan.
-void mm_discard(lii_handle h) {  // a new scan arrived: a box nobody consumed is stale, its partner is armed
-  if (h->mm_valid) h->mm_sel ^= 1;
-  h->mm_valid = false;
-}
-// Same protocol for the time extent of the scan: returns the accumulator that holds it, launching the reduction unless the
-// scan's arrival already produced it.
+// The time extent of a scan ping-pongs between two accumulators (whoever fills one re-arms the other for the next scan).
+// Returns the accumulator that holds it, launching the reduction unless the scan's arrival already produced it.
 void extent_discard(lii_handle h) {
   if (h->extent_valid) h->extent_sel ^= 1;
   h->extent_valid = false;
@@ -336,13 +332,6 @@ unsigned long long* extent_of_scan(lii_handle h) {
   h->extent_valid = false;
   return ext;
 }
-void mm_for_deskew(lii_handle h, unsigned int** mm, unsigned int** mm_next) {
-  mm_discard(h);
-  *mm = h->d_mm + 8 * h->mm_sel;
-  *mm_next = h->d_mm + 8 * (h->mm_sel ^ 1);
-  h->mm_valid = true;
-}
-
 MailboxView mailbox_view(lii_handle h) {
   MailboxView v;
   v.slots = h->mailbox.dev_slots;
@@ -657,6 +646,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_out91, 256));  // [0,91): local sums, [128,219): all-reduced sums (sharded scans)
   CK(dmalloc(&h->d_extent, 4));
   CK(dmalloc(&h->d_mm, 16));
+  CK(dmalloc(&h->d_bbox_rows, (N / 256 + 2) * 8));
   {
     const unsigned long long e0[4] = {~0ull, 0ull, ~0ull, 0ull};
     const unsigned int m0[16] = {~0u, ~0u, ~0u, 0, 0, 0, 0, 0, ~0u, ~0u, ~0u, 0, 0, 0, 0, 0};
@@ -694,7 +684,7 @@ int lii_destroy(lii_handle h) {
   if (h->d_mb_seq) (void)hipFree(h->d_mb_seq);
   void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
-                 h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_vkeys_a, h->d_vkeys_b,
+                 h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
                  h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)
@@ -817,7 +807,7 @@ int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_
   HIPCHK(h, hipEventRecord(h->ev_stage, h->stream));
   h->n_scan = n;
   extent_discard(h);
-  mm_discard(h);
+  h->bbox_rows = 0;
   h->n_body = 0;
   h->n_body_pending = false;
   h->have_search = false;
@@ -827,7 +817,7 @@ int lii_scan_set_device(lii_handle h, const void* dev_float4, int32_t n) {
   if (!h || (!dev_float4 && n > 0) || n < 0) return fail(h, LII_ERR_INVALID, "lii_scan_set_device: bad arguments");
   if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_set_device: n > max_scan_points");
   extent_discard(h);
-  mm_discard(h);
+  h->bbox_rows = 0;
   if (n > 0) {  // copy + time extent of the scan in one pass (the de-skew that usually follows needs the extent)
     launch_time_extent(static_cast<const float4*>(dev_float4), n, h->d_extent + 2 * h->extent_sel,
                        h->d_extent + 2 * (h->extent_sel ^ 1), h->d_scan, h->h_ctrl, h->d_ctrl, h->ctrl_pending, h->stream);
@@ -859,9 +849,8 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
   std::memcpy(u.RLI, R_LI, 72);
   std::memcpy(u.TLI, T_LI, 24);
   unsigned long long* ext = extent_of_scan(h);
-  unsigned int *mm, *mm_next;
-  mm_for_deskew(h, &mm, &mm_next);
-  launch_undistort_imu(h->d_scan, h->n_scan, h->d_poses, n_poses, u, ext, mm, mm_next, h->stream);
+  launch_undistort_imu(h->d_scan, h->n_scan, h->d_poses, n_poses, u, ext, h->d_bbox_rows, h->stream);
+  h->bbox_rows = (h->n_scan + 255) / 256;
   HIPCHK(h, hipGetLastError());
   return LII_OK;
 }
@@ -873,9 +862,8 @@ int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], c
   std::memcpy(a.vel, vel, 24);
   std::memcpy(a.endR, end_R, 72);
   unsigned long long* ext = extent_of_scan(h);
-  unsigned int *mm, *mm_next;
-  mm_for_deskew(h, &mm, &mm_next);
-  launch_undistort_cv(h->d_scan, h->n_scan, a, ext, mm, mm_next, h->stream);
+  launch_undistort_cv(h->d_scan, h->n_scan, a, ext, h->d_bbox_rows, h->stream);
+  h->bbox_rows = (h->n_scan + 255) / 256;
   HIPCHK(h, hipGetLastError());
   return LII_OK;
 }
@@ -904,13 +892,14 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
   // sample sort -> centroids + count (lii_vsort.hip).  The size of the result stays in HBM (d_nbody); the registration
   // kernels read it there, so the host learns it only if the caller asks (n_down / filtered != NULL, or a download).
   hipStream_t s = h->stream;
-  unsigned int* mm = h->d_mm + 8 * h->mm_sel;  // the box a de-skew kernel left behind, or a pass of its own over the scan
-  if (!h->mm_valid) launch_voxel_minmax(h->d_scan, n, mm, h->d_mm + 8 * (h->mm_sel ^ 1), s);
-  h->mm_sel ^= 1;
-  h->mm_valid = false;
+  unsigned int* mm = h->d_mm + 8 * h->mm_sel;  // the box: rows a de-skew kernel left behind, or a pass of its own over the scan
+  if (h->bbox_rows == 0) {
+    h->mm_sel ^= 1;
+    launch_voxel_minmax(h->d_scan, n, mm, h->d_mm + 8 * h->mm_sel, s);
+  }
   {
     const VoxelSortPlan plan = voxel_sort_plan(n);
-    launch_voxel_keys(h->d_scan, n, mm, leaf, h->d_vkeys_a, h->d_nbody + 1, plan.samples ? h->d_vsplit + 2048 : nullptr, plan.width, s);
+    launch_voxel_keys(h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_vkeys_a, h->d_nbody + 1, plan.samples ? h->d_vsplit + 2048 : nullptr, plan.width, s);
     VoxelSortBuffers vb;
     vb.samples = h->d_vsplit + 2048;
     vb.keys_in = h->d_vkeys_a; vb.keys_out = h->d_vkeys_b; vb.idx_out = h->d_vidx_b;

@@ -882,15 +882,19 @@ __global__ __launch_bounds__(256) void k_time_extent(const float4* __restrict__ 
                                                      unsigned long long* __restrict__ extent_next, float4* __restrict__ copy_to,
                                                      const uint4* __restrict__ ctrl_src, uint4* __restrict__ ctrl_dst, int ctrl_vec) {
   __shared__ unsigned long long smn[4], smx[4];
-  // first kernel of a scan: workgroup 0 also pulls the update's control block + IMU pose table out of the caller-side pinned
-  // buffer (ctrl_vec 16-byte words over PCIe, ~3 us inside this launch instead of an H2D copy submission of ~10 us before it)
-  if (blockIdx.x == 0)
+  // first kernel of a scan: one extra workgroup pulls the update's control block + IMU pose table out of the caller-side
+  // pinned buffer (ctrl_vec 16-byte words over PCIe, ~3 us beside the others' work instead of an H2D copy submission of
+  // ~10 us before the launch)
+  const int n_scan_blocks = gridDim.x - (ctrl_vec > 0 ? 1 : 0);
+  if ((int)blockIdx.x == n_scan_blocks) {
     for (int i = threadIdx.x; i < ctrl_vec; i += 256) ctrl_dst[i] = ctrl_src[i];
+    return;
+  }
   // the accumulators ping-pong between two buffers: this launch re-arms the one the NEXT scan will reduce into (nobody reads
   // it any more: its consumers belonged to the previous scan), which saves a separate initialisation launch per scan
   if (blockIdx.x == 0 && threadIdx.x == 0) { extent_next[0] = ~0ull; extent_next[1] = 0ull; }
   unsigned long long mn = ~0ull, mx = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += n_scan_blocks * blockDim.x) {
     const float4 p = pts[i];
     if (copy_to) copy_to[i] = p;
     unsigned int o = f2ord(p.w);
@@ -985,9 +989,9 @@ __device__ __forceinline__ void backprop_once(const double* __restrict__ head /*
   p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
 }
 
-// Bounding box of the points a 256-lane workgroup holds (non-finite points excluded), folded into mm[0..2] = ord(min xyz),
-// mm[3..5] = ord(max xyz): wave shuffle + LDS reduction, ONE set of atomics per workgroup.  Every lane must call it.
-__device__ __forceinline__ void block_bbox_accumulate(unsigned int (&lo)[3], unsigned int (&hi)[3], unsigned int* __restrict__ mm) {
+// Bounding box of the points a 256-lane workgroup holds (non-finite points excluded; order-preserving uints): wave shuffle +
+// LDS reduction; afterwards lanes 0..2 hold the min / max of axis threadIdx.x in lo[0] / hi[0].  Every lane must call it.
+__device__ __forceinline__ void block_bbox_reduce(unsigned int (&lo)[3], unsigned int (&hi)[3]) {
   __shared__ unsigned int s_lo[4][3], s_hi[4][3];
 #pragma unroll
   for (int a = 0; a < 3; a++) {
@@ -1005,10 +1009,8 @@ __device__ __forceinline__ void block_bbox_accumulate(unsigned int (&lo)[3], uns
   __syncthreads();
   if (threadIdx.x < 3) {
     const int a = threadIdx.x;
-    unsigned int l = min(min(s_lo[0][a], s_lo[1][a]), min(s_lo[2][a], s_lo[3][a]));
-    unsigned int h = max(max(s_hi[0][a], s_hi[1][a]), max(s_hi[2][a], s_hi[3][a]));
-    atomicMin(&mm[a], l);
-    atomicMax(&mm[3 + a], h);
+    lo[0] = min(min(s_lo[0][a], s_lo[1][a]), min(s_lo[2][a], s_lo[3][a]));
+    hi[0] = max(max(s_hi[0][a], s_hi[1][a]), max(s_hi[2][a], s_hi[3][a]));
   }
 }
 __device__ __forceinline__ void bbox_point(float x, float y, float z, unsigned int (&lo)[3], unsigned int (&hi)[3]) {
@@ -1019,14 +1021,18 @@ __device__ __forceinline__ void bbox_point(float x, float y, float z, unsigned i
     lo[2] = min(lo[2], oz); hi[2] = max(hi[2], oz);
   }
 }
-// The de-skew kernels leave the bounding box of their output behind (mm != nullptr): the voxel filter that follows needs it
-// and a pass of its own over the scan costs a launch.  Like k_voxel_minmax they re-arm the ping-pong partner for the next scan.
-__device__ __forceinline__ void deskew_bbox(float4 q, bool in_range, unsigned int* __restrict__ mm, unsigned int* __restrict__ mm_next) {
-  if (!mm) return;  // uniform
-  if (blockIdx.x == 0 && threadIdx.x < 6) mm_next[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+// The de-skew kernels leave the bounding box of their output behind for the voxel filter that follows (a pass of its own
+// over the scan costs a launch): one row of 8 uints per workgroup (min xyz, -, max xyz, -), reduced by k_voxel_keys.
+// (Folding the rows with atomics instead costs the kernel ~5 us: 400 workgroups x 6 atomics on one cache line.)
+__device__ __forceinline__ void deskew_bbox(float4 q, bool in_range, unsigned int* __restrict__ rows) {
+  if (!rows) return;  // uniform
   unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
   if (in_range) bbox_point(q.x, q.y, q.z, lo, hi);
-  block_bbox_accumulate(lo, hi, mm);
+  block_bbox_reduce(lo, hi);
+  if (threadIdx.x < 3) {
+    rows[blockIdx.x * 8 + threadIdx.x] = lo[0];
+    rows[blockIdx.x * 8 + 4 + threadIdx.x] = hi[0];
+  }
 }
 
 // IMU-mode de-skew.  The reference walks the time-sorted cloud backwards over the pose table; per point this
@@ -1035,7 +1041,7 @@ __device__ __forceinline__ void deskew_bbox(float4 q, bool in_range, unsigned in
 // head after being compensated, so it is compensated once per qualifying head, in descending order.
 __global__ __launch_bounds__(256) void k_undistort_imu(float4* __restrict__ pts, int n, const double* __restrict__ poses, int K,
                                                        UndistArg u, const unsigned long long* __restrict__ extent,
-                                                       unsigned int* __restrict__ mm, unsigned int* __restrict__ mm_next) {
+                                                       unsigned int* __restrict__ bbox_rows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = i < n;
   float4 P = in_range ? pts[i] : make_float4(0, 0, 0, 0);
@@ -1061,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_undistort_imu(float4* __restrict__ pts,
       pts[i] = P;
     }
   }
-  deskew_bbox(P, in_range, mm, mm_next);
+  deskew_bbox(P, in_range, bbox_rows);
 }
 
 struct CvArg {
@@ -1069,7 +1075,7 @@ struct CvArg {
 };
 // CV-mode de-skew (src/IMU_Processing.hpp:246-266).  The time-earliest point is skipped (quirk A3).
 __global__ __launch_bounds__(256) void k_undistort_cv(float4* __restrict__ pts, int n, CvArg a, const unsigned long long* __restrict__ extent,
-                                                      unsigned int* __restrict__ mm, unsigned int* __restrict__ mm_next) {
+                                                      unsigned int* __restrict__ bbox_rows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = i < n;
   float4 P = in_range ? pts[i] : make_float4(0, 0, 0, 0);
@@ -1087,7 +1093,7 @@ __global__ __launch_bounds__(256) void k_undistort_cv(float4* __restrict__ pts, 
     P = make_float4((float)o[0], (float)o[1], (float)o[2], P.w);
     pts[i] = P;
   }
-  deskew_bbox(P, in_range, mm, mm_next);
+  deskew_bbox(P, in_range, bbox_rows);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1102,7 +1108,11 @@ __global__ __launch_bounds__(256) void k_voxel_minmax(const float4* __restrict__
     const float4 p = pts[i];
     bbox_point(p.x, p.y, p.z, lo, hi);
   }
-  block_bbox_accumulate(lo, hi, mm);
+  block_bbox_reduce(lo, hi);
+  if (threadIdx.x < 3) {  // ONE set of atomics per workgroup (<= 256 of them)
+    atomicMin(&mm[threadIdx.x], lo[0]);
+    atomicMax(&mm[3 + threadIdx.x], hi[0]);
+  }
 }
 
 struct VoxelArg {
@@ -1142,9 +1152,23 @@ __device__ __forceinline__ VoxelArg voxel_prepare(const unsigned int* __restrict
   }
   return v;
 }
-__global__ void k_voxel_keys(const float4* __restrict__ pts, int n, const unsigned int* __restrict__ mm, float leaf,
-                             unsigned int* __restrict__ keys, int* __restrict__ filtered,
-                             unsigned long long* __restrict__ samples, int sample_width) {
+__global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ pts, int n, const unsigned int* __restrict__ mm,
+                                                    const unsigned int* __restrict__ bbox_rows, int n_rows, float leaf,
+                                                    unsigned int* __restrict__ keys, int* __restrict__ filtered,
+                                                    unsigned long long* __restrict__ samples, int sample_width) {
+  __shared__ unsigned int s_mm[8];
+  if (n_rows > 0) {  // the box arrives as one row per de-skew workgroup: every workgroup folds them for itself (a few KB from L2)
+    unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+    for (int r = threadIdx.x; r < n_rows; r += 256) {
+      const uint4 a = *reinterpret_cast<const uint4*>(bbox_rows + r * 8), b = *reinterpret_cast<const uint4*>(bbox_rows + r * 8 + 4);
+      lo[0] = min(lo[0], a.x); lo[1] = min(lo[1], a.y); lo[2] = min(lo[2], a.z);
+      hi[0] = max(hi[0], b.x); hi[1] = max(hi[1], b.y); hi[2] = max(hi[2], b.z);
+    }
+    block_bbox_reduce(lo, hi);
+    if (threadIdx.x < 3) { s_mm[threadIdx.x] = lo[0]; s_mm[3 + threadIdx.x] = hi[0]; }
+    __syncthreads();
+    mm = s_mm;
+  }
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const VoxelArg v = voxel_prepare(mm, leaf);
@@ -1334,25 +1358,25 @@ void launch_reduce91(const double* partials, int n_points, int stride, double* o
 }
 void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, float4* copy_to,
                         const void* ctrl_src, void* ctrl_dst, size_t ctrl_bytes, hipStream_t s) {
-  int nb = nblk(n, 256 * (copy_to ? 2 : 8));  // a copy wants the whole chip, the bare reduction few atomics
-  if (nb > (copy_to ? 1024 : 256)) nb = copy_to ? 1024 : 256;
+  int nb = nblk(n, 256 * 2);  // every workgroup ends with a pair of atomics on one cache line: keep them few
+  if (nb > 256) nb = 256;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_time_extent, dim3(nb), dim3(256), 0, s, pts, n, extent, extent_next, copy_to,
+  hipLaunchKernelGGL(k_time_extent, dim3(nb + (ctrl_bytes ? 1 : 0)), dim3(256), 0, s, pts, n, extent, extent_next, copy_to,
                      static_cast<const uint4*>(ctrl_src), static_cast<uint4*>(ctrl_dst), (int)(ctrl_bytes / 16));
 }
 void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& uh,
-                          const unsigned long long* extent, unsigned int* mm, unsigned int* mm_next, hipStream_t s) {
+                          const unsigned long long* extent, unsigned int* bbox_rows, hipStream_t s) {
   UndistArg u;
   static_assert(sizeof(UndistArg) == sizeof(UndistArgH), "layout");
   memcpy(&u, &uh, sizeof(u));
-  if (n > 0) hipLaunchKernelGGL(k_undistort_imu, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent, mm, mm_next);
+  if (n > 0) hipLaunchKernelGGL(k_undistort_imu, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent, bbox_rows);
 }
-void launch_undistort_cv(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, unsigned int* mm,
-                         unsigned int* mm_next, hipStream_t s) {
+void launch_undistort_cv(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, unsigned int* bbox_rows,
+                         hipStream_t s) {
   CvArg a;
   static_assert(sizeof(CvArg) == sizeof(CvArgH), "layout");
   memcpy(&a, &ah, sizeof(a));
-  if (n > 0) hipLaunchKernelGGL(k_undistort_cv, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent, mm, mm_next);
+  if (n > 0) hipLaunchKernelGGL(k_undistort_cv, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent, bbox_rows);
 }
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s) {
   int nb = nblk(n, 256 * 4);
@@ -1360,11 +1384,11 @@ void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned in
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(k_voxel_minmax, dim3(nb), dim3(256), 0, s, pts, n, mm, mm_next);
 }
-void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, float leaf, unsigned int* keys, int* filtered_dev,
-                       unsigned long long* samples, int sample_width, hipStream_t s) {
+void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows, int n_rows, float leaf,
+                       unsigned int* keys, int* filtered_dev, unsigned long long* samples, int sample_width, hipStream_t s) {
   if (n > 0)
-    hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, leaf, keys, filtered_dev, samples,
-                       sample_width);
+    hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, keys, filtered_dev,
+                       samples, sample_width);
 }
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s) {

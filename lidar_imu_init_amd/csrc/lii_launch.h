@@ -55,13 +55,13 @@ int register_blocks(int n);
 void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, float4* copy_to,
                         const void* ctrl_src, void* ctrl_dst, size_t ctrl_bytes, hipStream_t s);
 void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& u,
-                          const unsigned long long* extent, unsigned int* mm, unsigned int* mm_next, hipStream_t s);
-void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned long long* extent, unsigned int* mm,
-                         unsigned int* mm_next, hipStream_t s);
+                          const unsigned long long* extent, unsigned int* bbox_rows, hipStream_t s);
+void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned long long* extent, unsigned int* bbox_rows,
+                         hipStream_t s);
 // voxel grid
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s);
-void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, float leaf, unsigned int* keys,
-                       int* filtered_dev, unsigned long long* samples, int sample_width, hipStream_t s);
+void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows, int n_rows, float leaf,
+                       unsigned int* keys, int* filtered_dev, unsigned long long* samples, int sample_width, hipStream_t s);
 // calibration
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s);

@@ -128,3 +128,35 @@ def test_voxel_grid_edge_cases(reg, oracle):
     nd, f = reg.downsample(0.05)
     assert (not f) and nd == 1000
     assert np.array_equal(reg.scan_download(1), big)
+
+
+def test_voxel_grid_sort_survives_adversarial_sampling(reg, oracle):
+    """The voxel filter's sample sort draws one jittered sample per stratum of the input (k_voxel_keys).  Here every sampled
+    position holds a point of the lowest voxels and everything else lies above them: all splitters collapse to the bottom, one
+    bucket receives ~the whole scan, and the oversized-group path (ranking out of global memory) has to produce the same
+    bit-exact result."""
+    n, leaf = 20_000, 0.1
+    rng = np.random.default_rng(5)
+    pts = np.c_[rng.uniform(5, 25, (n, 2)), rng.uniform(1, 4, n), rng.uniform(0, 100, n)].astype(np.float32)
+    # the library's sampling plan (lii_vsort.hip: voxel_sort_plan / k_voxel_keys), restated
+    want, B = (n + 63) // 64, 8
+    while B < want and B < 2048:
+        B *= 2
+    S = 2 * B
+    W = (n + S - 1) // S
+    strata = (n + W - 1) // W
+    M32 = 0xFFFFFFFF
+    for j in range(strata):
+        h = (j * 2654435761) & M32
+        h ^= h >> 15
+        h = (h * 2246822519) & M32
+        h ^= h >> 13
+        lo = j * W
+        pos = lo + h % min(W, n - lo)
+        pts[pos, :3] = np.float32([0.01 + 1e-4 * (j % 7), 0.01, 0.01])  # the lowest corner of the grid
+    ref, filtered = oracle.voxel_grid(pts, leaf)
+    assert filtered
+    reg.scan_upload(pts)
+    nd, f = reg.downsample(leaf)
+    assert f and nd == len(ref)
+    assert np.array_equal(reg.scan_download(1), ref)

@@ -19,7 +19,7 @@ def main():
     trace = glob.glob(d + "/*kernel_trace.csv")[0]
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
-        name = r["Kernel_Name"].split("(")[0]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         if "rocprim" in name or "ROCPRIM" in name:
             name = "rocprim::" + name.split("detail::")[-1][:60]
         per[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
