@@ -160,3 +160,17 @@ def test_voxel_grid_sort_survives_adversarial_sampling(reg, oracle):
     nd, f = reg.downsample(leaf)
     assert f and nd == len(ref)
     assert np.array_equal(reg.scan_download(1), ref)
+
+
+@pytest.mark.parametrize("n", [700, 1000, 4095, 4096, 8191, 8192, 8193, 16385, 65536, 131072, 131073, 200000])
+def test_voxel_grid_sizes_around_the_sort_thresholds(reg, oracle, n):
+    """Bucket counts, sample counts and the group size of the voxel filter's sort change at these sizes (lii_vsort.hip:
+    voxel_sort_plan, the 131 k switch to one bucket per workgroup); half of the points share voxels with others."""
+    rng = np.random.default_rng(n)
+    pts = np.c_[rng.uniform(-20, 20, (n, 2)), rng.uniform(-1, 3, n), rng.uniform(0, 100, n)].astype(np.float32)
+    pts[n // 2:, :3] = pts[rng.integers(0, n // 2, n - n // 2), :3] + rng.uniform(0, 0.02, (n - n // 2, 3)).astype(np.float32)
+    ref, filtered = oracle.voxel_grid(pts, 0.1)
+    reg.scan_upload(pts)
+    nd, f = reg.downsample(0.1)
+    assert f == filtered and nd == len(ref)
+    assert np.array_equal(reg.scan_download(1), ref)
