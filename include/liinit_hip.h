@@ -114,7 +114,9 @@ int lii_map_commit(lii_handle h);
  * lii_scan_upload: host AoS -> device float4 (x,y,z,t_ms).  For pcl::PointXYZINormal use stride 48,
  *                  time_offset_bytes 36 (`curvature`, include/common_lib.h:37).  Replaces the hand-over of
  *                  Measures.lidar to ImuProcess::Process (src/laserMapping.cpp:909).
- * lii_scan_set_device: same, from a device-resident float4 buffer (D2D on the handle's stream).
+ * lii_scan_set_device: same, from a device-resident float4 buffer (copied on the handle's stream by the kernel that also
+ *                  reduces the scan's time extent; the caller's buffer is only read and free again once a later call on
+ *                  the handle has returned).
  * lii_undistort_imu <- back-propagation loop of ImuProcess::propagation_and_undist, src/IMU_Processing.hpp:390-414
  * lii_undistort_cv  <- CV de-skew of Forward_propagation_without_imu,            src/IMU_Processing.hpp:246-266
  * lii_downsample    <- downSizeFilterSurf.filter(*feats_down_body),              src/laserMapping.cpp:917-919
@@ -182,8 +184,11 @@ int lii_frame_select(lii_handle h, int32_t frame);
  * lii_iekf_update: the whole loop :957-1134 including the 24-state solve (:1081-1087), convergence / rematch
  *   logic (:1093-1106) and covariance update (:1109-1131).  The loop is device resident: every pass is enqueued up
  *   front, the kernels consult a control block in HBM and skip the passes the reference's schedule does not run, the
- *   final state lands in mapped host memory — one synchronisation per call.  (LII_HOST_SOLVE=1 in the environment
- *   drives the loop from the host around lii_iekf_iterate with the literal two-inversion algebra instead.)
+ *   final state lands in mapped host memory followed by a sequence word the call waits for — one host round trip per
+ *   call, and the call returns as soon as the result exists: passes still queued behind the stopping one (they read a flag
+ *   and return) drain in stream order while the caller goes on; every later call on the handle is ordered behind them.
+ *   (LII_SYNC_RESULT=1 waits for the whole stream instead.  LII_HOST_SOLVE=1 drives the loop from the host around
+ *   lii_iekf_iterate with the literal two-inversion algebra.)
  * lii_neighbors_download: Nearest_Points of the last search (for map_incremental, :525-549);
  *   pts = n_down x 5 x 3 floats, counts = n_down. */
 int lii_iekf_iterate(lii_handle h, const lii_state* state, int32_t search, int32_t imu_en, double out91[91]);
@@ -192,8 +197,8 @@ int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_propa
 int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* selected, int32_t capacity);
 
 /* The per-scan sequence of main() (src/laserMapping.cpp:909-1134) in ONE call, enqueued back to back on the handle's
- * stream with a single synchronisation at the end: p_imu->Process' undistortion (:909; the scan must have been handed
- * over by lii_scan_upload / lii_scan_set_device), downSizeFilterSurf.filter (:917-919) and the iterated update
+ * stream with a single host round trip at the end: p_imu->Process' undistortion (:909; the scan is the one handed over by
+ * lii_scan_upload / lii_scan_set_device, or job->scan_dev), downSizeFilterSurf.filter (:917-919) and the iterated update
  * (:957-1134).  The undistortion takes its end pose and extrinsic from `state` (the propagated state, as the reference
  * does: IMU_Processing.hpp:404-407 reads state_inout).  Equivalent to lii_undistort_* + lii_downsample(_skip) +
  * lii_iekf_update; it exists because every separate call costs the caller a host round trip. */
