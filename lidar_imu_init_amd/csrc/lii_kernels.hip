@@ -784,7 +784,11 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
     __syncthreads();
     if (live && (rb.nbr_count[i] & kNeedy)) s_needy[atomicAdd(&s_nneedy, 1)] = threadIdx.x;
     __syncthreads();
+#ifdef LII_DIAG_SKIP_NEEDY  // diagnostic build only: how much of the search-pass fit kernel is the completion of flagged searches
+    const int nn = 0;
+#else
     const int nn = s_nneedy;
+#endif
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int e = wave; e < nn; e += kBlock / 64) {  // rare (~0.07 % of the queries) but clustered: four at a time, one per wavefront
       const int qi = blk * kBlock + s_needy[e];
