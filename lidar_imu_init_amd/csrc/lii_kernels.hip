@@ -716,24 +716,48 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
     const int ii = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
     if (lane < 5 && ii >= 0) { k.d0 = dd; k.i0 = ii; }
   }
-  for (int c0 = 0; c0 < total; c0 += 64) {  // uniform trip count: the shuffle below needs every lane
-    const int c = c0 + lane;
-    const bool in = c < total;
-    const int ixx = ix0 + (in ? c % nx : 0), iyy = iy0 + (in ? (c / nx) % ny : 0), izz = iz0 + (in ? c / (nx * ny) : 0);
-    const int X = (ixx >> kCoarseShift) - X0 + 1, Y = (iyy >> kCoarseShift) - Y0 + 1, Z = (izz >> kCoarseShift) - Z0 + 1;
-    const bool in_blocks = (unsigned)X <= 2u && (unsigned)Y <= 2u && (unsigned)Z <= 2u;  // else farther than 8 cells >= sqrt(max_d2)
-    const int id = __shfl(my_block, in_blocks ? Z * 9 + Y * 3 + X : 0);
-    const bool inner = abs(ixx - cx) <= 1 && abs(iyy - cy) <= 1 && abs(izz - cz) <= 1;  // done in pass 1
-    if (!in || !in_blocks || inner || id < 0) continue;
-    const float gx = axis_gap(wx, ixx, cs, eps), gy = axis_gap(wy, iyy, cs, eps), gz = axis_gap(wz, izz, cs, eps);
-    if (gx * gx + gy * gy + gz * gz > bound1) continue;
-    const unsigned local = (((unsigned)izz & 7u) << 6) | (((unsigned)iyy & 7u) << 3) | ((unsigned)ixx & 7u);
-    const uint2 rr = g.cells[(size_t)id * kBlockCells + local];
-    // candidates must beat the inner 5th distance as well as the lane's own list
-    for (unsigned int j = rr.x; j < rr.y; j++) {
-      const float4 p = g.pts[j];
-      const float d = dist2_ref(wx, wy, wz, p.x, p.y, p.z);
-      if (d <= g.max_d2 && d < fminf(k.d4, bound1)) knn_insert(k, d, (int)j);
+  // Four rounds of 64 cells at a time: which cells survive (inside the ball, outside the inner cube, closer than bound1) does
+  // not depend on the candidates found on the way, so the four cell entries of a lane are fetched together and their
+  // candidates four per trip - the loop is a chain of dependent loads, not of arithmetic.
+  constexpr int NB = 4;
+  const int nxy = nx * ny;
+  for (int c0 = 0; c0 < total; c0 += 64 * NB) {  // uniform trip count: the shuffle below needs every lane
+    uint2 rr[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const int c = c0 + b * 64 + lane;
+      const bool in = c < total;
+      const int cc = in ? c : 0;
+      const int q2 = cc / nxy, r2 = cc - q2 * nxy, q1 = r2 / nx;
+      const int ixx = ix0 + (r2 - q1 * nx), iyy = iy0 + q1, izz = iz0 + q2;
+      const int X = (ixx >> kCoarseShift) - X0 + 1, Y = (iyy >> kCoarseShift) - Y0 + 1, Z = (izz >> kCoarseShift) - Z0 + 1;
+      const bool in_blocks = (unsigned)X <= 2u && (unsigned)Y <= 2u && (unsigned)Z <= 2u;  // else farther than 8 cells >= sqrt(max_d2)
+      const int id = __shfl(my_block, in_blocks ? Z * 9 + Y * 3 + X : 0);
+      const bool inner = abs(ixx - cx) <= 1 && abs(iyy - cy) <= 1 && abs(izz - cz) <= 1;  // done in pass 1
+      bool act = in && in_blocks && !inner && id >= 0;
+      if (act) {
+        const float gx = axis_gap(wx, ixx, cs, eps), gy = axis_gap(wy, iyy, cs, eps), gz = axis_gap(wz, izz, cs, eps);
+        act = !(gx * gx + gy * gy + gz * gz > bound1);
+      }
+      rr[b] = make_uint2(0u, 0u);
+      if (act) {
+        const unsigned local = (((unsigned)izz & 7u) << 6) | (((unsigned)iyy & 7u) << 3) | ((unsigned)ixx & 7u);
+        rr[b] = g.cells[(size_t)id * kBlockCells + local];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      // candidates must beat the inner 5th distance as well as the lane's own list
+      for (unsigned int j = rr[b].x; j < rr[b].y; j += 4) {
+        const unsigned int last = rr[b].y - 1;
+        const float4 p0 = g.pts[j], p1 = g.pts[min(j + 1, last)], p2 = g.pts[min(j + 2, last)], p3 = g.pts[min(j + 3, last)];
+        const float d0 = dist2_ref(wx, wy, wz, p0.x, p0.y, p0.z), d1 = dist2_ref(wx, wy, wz, p1.x, p1.y, p1.z);
+        const float d2 = dist2_ref(wx, wy, wz, p2.x, p2.y, p2.z), d3 = dist2_ref(wx, wy, wz, p3.x, p3.y, p3.z);
+        if (d0 <= g.max_d2 && d0 < fminf(k.d4, bound1)) knn_insert(k, d0, (int)j);
+        if (j + 1 <= last && d1 <= g.max_d2 && d1 < fminf(k.d4, bound1)) knn_insert(k, d1, (int)(j + 1));
+        if (j + 2 <= last && d2 <= g.max_d2 && d2 < fminf(k.d4, bound1)) knn_insert(k, d2, (int)(j + 2));
+        if (j + 3 <= last && d3 <= g.max_d2 && d3 < fminf(k.d4, bound1)) knn_insert(k, d3, (int)(j + 3));
+      }
     }
   }
   wave_select5(k, od, oi);
