@@ -703,10 +703,11 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
   }
   wave_select5(k, od, oi);
   const float bound1 = fminf(od[4], bound0);  // exact 5th distance over the inner cells (inf if they hold fewer than 5)
-  // pass 2: the rest of the cube around the ball of radius sqrt(bound0), pruned with bound1
-  const int ix0 = cell_of(wx - r0, g.inv_cs), ix1 = cell_of(wx + r0, g.inv_cs);
-  const int iy0 = cell_of(wy - r0, g.inv_cs), iy1 = cell_of(wy + r0, g.inv_cs);
-  const int iz0 = cell_of(wz - r0, g.inv_cs), iz1 = cell_of(wz + r0, g.inv_cs);
+  // pass 2: the rest of the cube around the ball of radius sqrt(bound1) (nothing farther can enter the list), pruned with bound1
+  const float r1 = fminf(r0, sqrtf(bound1) + 2.f * eps);
+  const int ix0 = cell_of(wx - r1, g.inv_cs), ix1 = cell_of(wx + r1, g.inv_cs);
+  const int iy0 = cell_of(wy - r1, g.inv_cs), iy1 = cell_of(wy + r1, g.inv_cs);
+  const int iz0 = cell_of(wz - r1, g.inv_cs), iz1 = cell_of(wz + r1, g.inv_cs);
   const int nx = ix1 - ix0 + 1, ny = iy1 - iy0 + 1, nz = iz1 - iz0 + 1;
   const int total = nx * ny * nz;
   k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = __builtin_inff();
