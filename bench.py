@@ -181,7 +181,7 @@ def main():
                         ("state0", C.c_void_p)]
         drv_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "harness", "libliinit_stream.so")
         if not os.path.exists(drv_path):
-            raise SystemExit(f"{drv_path} missing - run `python -c 'import __graft_entry__ as g; g.build()'`")
+            raise SystemExit(f"{drv_path} missing - run `python -c 'import __graft_entry__ as g; g.build()'` (or --python-loop)")
         drv = C.CDLL(drv_path)
         drv.lii_stream_run.restype = C.c_int
         drv.lii_stream_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32,

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define LII_ABI_VERSION 1
+#define LII_ABI_VERSION 2 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport */
 
 enum lii_status {
   LII_OK = 0,
