@@ -28,9 +28,6 @@ const double kA[7] = {1.0000, -4.182389, 7.491611, -7.313596, 4.089349, -1.23852
 inline double* vec4(lii_calib_state& s, int f) {  // the four fields CalibState arithmetic touches
   return f == 0 ? s.ang_vel : (f == 1 ? s.linear_vel : (f == 2 ? s.ang_acc : s.linear_acc));
 }
-inline const double* vec4(const lii_calib_state& s, int f) {
-  return f == 0 ? s.ang_vel : (f == 1 ? s.linear_vel : (f == 2 ? s.ang_acc : s.linear_acc));
-}
 inline double norm3(const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
 void align(Seq& imu, Seq& lidar) {
