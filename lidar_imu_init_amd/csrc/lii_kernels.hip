@@ -925,7 +925,14 @@ __global__ __launch_bounds__(256) void k_time_extent(const float4* __restrict__ 
   // ~10 us before the launch)
   const int n_scan_blocks = gridDim.x - (ctrl_vec > 0 ? 1 : 0);
   if ((int)blockIdx.x == n_scan_blocks) {
-    for (int i = threadIdx.x; i < ctrl_vec; i += 256) ctrl_dst[i] = ctrl_src[i];
+    for (int i0 = threadIdx.x; i0 < ctrl_vec; i0 += 256 * 4) {  // four PCIe reads in flight per lane
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = i0 + 256 * u < ctrl_vec ? ctrl_src[i0 + 256 * u] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (i0 + 256 * u < ctrl_vec) ctrl_dst[i0 + 256 * u] = v[u];
+    }
     return;
   }
   // the accumulators ping-pong between two buffers: this launch re-arms the one the NEXT scan will reduce into (nobody reads
@@ -1083,11 +1090,24 @@ __global__ __launch_bounds__(256) void k_undistort_imu(float4* __restrict__ pts,
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = i < n;
   float4 P = in_range ? pts[i] : make_float4(0, 0, 0, 0);
+  // the head search walks the table's time column backwards: staged in LDS once per workgroup (tables of up to 256 poses;
+  // longer ones are walked in global memory), a walk of up to K dependent global loads per point otherwise
+  __shared__ double s_time[256];
+  const bool staged = K <= 256;
+  if (staged) {
+    if ((int)threadIdx.x < K) s_time[threadIdx.x] = poses[22 * threadIdx.x];
+    __syncthreads();
+  }
   if (in_range) {
     double t = P.w / double(1000);
     int h = -1;
-    for (int k = K - 2; k >= 0; k--)
-      if (t > poses[22 * k]) { h = k; break; }
+    if (staged) {
+      for (int k = K - 2; k >= 0; k--)
+        if (t > s_time[k]) { h = k; break; }
+    } else {
+      for (int k = K - 2; k >= 0; k--)
+        if (t > poses[22 * k]) { h = k; break; }
+    }
     if (h >= 0) {
       double p[3] = {P.x, P.y, P.z};
       backprop_once(poses + 22 * h, t, u, p);
