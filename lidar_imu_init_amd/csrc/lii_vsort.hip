@@ -194,10 +194,12 @@ __global__ __launch_bounds__(256) void k_vsort_scatter(const unsigned int* __res
   constexpr int E = kTile / 256;
   const int base = blockIdx.x * kTile;
   unsigned short mine[E];
+  unsigned int key[E];
 #pragma unroll
-  for (int k = 0; k < E; k++) {
+  for (int k = 0; k < E; k++) {  // everything this workgroup reads from global memory goes out in one round
     const int i = base + k * 256 + tid;
     mine[k] = i < n ? bucket_of[i] : (unsigned short)0xFFFF;
+    key[k] = i < n ? keys[i] : 0u;
   }
   const int per = B >= 256 ? B >> 8 : 1;  // consecutive buckets per lane in the scan
   unsigned int v[kPerLane], loc = 0;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void k_vsort_scatter(const unsigned int* __res
 #pragma unroll
   for (int k = 0; k < E; k++) {
     const int i = base + k * 256 + tid;
-    if (i < n) comp[atomicAdd(&off[mine[k]], 1u)] = composite(keys[i], (unsigned int)i);
+    if (i < n) comp[atomicAdd(&off[mine[k]], 1u)] = composite(key[k], (unsigned int)i);
   }
 }
 
@@ -398,20 +400,26 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restric
   if (g == (int)gridDim.x - 1 && tid == 0) *n_out = (int)(slot0 + group_count[g]);  // size of the down-sampled cloud
   for (unsigned int base = s0; base < s1; base += 256) {
     const unsigned int i = base + tid;
-    unsigned int k = 0, flag = 0;
-    if (i < s1) {
+    unsigned int k = 0, flag = 0, k_next = kDropKey, id0 = 0;
+    if (i < s1) {  // everything the common case (a voxel of one point) needs, in one round of loads
       k = keys[i];
-      flag = (k != kDropKey && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+      const unsigned int k_prev = i > 0 ? keys[i - 1] : kDropKey;
+      if (i + 1 < (unsigned int)n) k_next = keys[i + 1];
+      id0 = idx[i];
+      flag = (k != kDropKey && (i == 0 || k_prev != k)) ? 1u : 0u;
     }
     unsigned int total;
     const unsigned int slot = slot0 + block_exclusive_scan(flag, wtot, &total);
     slot0 += total;
     if (flag) {
-      float sx = 0, sy = 0, sz = 0, st = 0;
-      unsigned int j = i;
-      for (; j < (unsigned int)n && keys[j] == k; j++) {
-        const float4 p = pts[idx[j]];
-        sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+      const float4 p0 = pts[id0];
+      float sx = __fadd_rn(0.f, p0.x), sy = __fadd_rn(0.f, p0.y), sz = __fadd_rn(0.f, p0.z), st = __fadd_rn(0.f, p0.w);
+      unsigned int j = i + 1;
+      if (k_next == k) {  // the run goes on (a second point of the voxel follows): the general walk
+        for (; j < (unsigned int)n && keys[j] == k; j++) {
+          const float4 p = pts[idx[j]];
+          sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+        }
       }
       const float c = (float)(j - i);
       // a single-point voxel reproduces the point exactly (x / 1.0f == x), which is also what the identity path needs
