@@ -318,8 +318,9 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
                                                       double* out, unsigned int* ticket, IekfCtrl* c, IekfResult* res,
                                                       const int* __restrict__ n_dev, MailboxView mb) {
   __shared__ int s_last;
+  const int n_dev_now = n_dev ? *n_dev : -1;  // issued with the flag below, not after the branch on it
   if (c->stop) return;  // read by every workgroup before its ticket; the solve (which may set it) runs after all tickets
-  if (n_dev) n_blocks = max(1, (*n_dev + kBlock - 1) / kBlock);
+  if (n_dev) n_blocks = max(1, (n_dev_now + kBlock - 1) / kBlock);
   const int t = blockIdx.x, lane = threadIdx.x;
   const double* row = partials + (size_t)t * stride;
   // the partials were written by other XCDs: every load is an L2 miss.  Eight are in flight before the first add (same

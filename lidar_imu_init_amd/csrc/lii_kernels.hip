@@ -531,14 +531,17 @@ template <int LPQ, int BS>
 __global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffers rb, PoseArg ps_val,
                                                    const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
                                                    int forced, int nb_real) {
-  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
+  // the pose sits in the control block: its load goes out together with the flags instead of after the branch on them
+  // (one dependent round trip less at the head of every launch, executed or not)
   const PoseArg ps = forced < 0 ? *pose : ps_val;
+  const int n_live = rb.n_dev ? *rb.n_dev : rb.n;
+  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;
   constexpr int QPB = BS / LPQ;
   const int sub = threadIdx.x & (LPQ - 1);
   const int qi = blk * QPB + threadIdx.x / LPQ;
-  const bool live = qi < (rb.n_dev ? *rb.n_dev : rb.n);
+  const bool live = qi < n_live;
   const int leader = (threadIdx.x & 63) & ~(LPQ - 1);
   float wx = 0, wy = 0, wz = 0;
   if (live && sub == 0) {
@@ -792,6 +795,9 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   __shared__ ReduceShared sh;
   __shared__ int s_needy[kBlock];
   __shared__ int s_nneedy;
+  // (pose and point count are loaded together with the flags, not after the branch on them: see k_knn_pruned)
+  const PoseArg ps = forced < 0 ? *pose : ps_val;
+  const int n_live = rb.n_dev ? *rb.n_dev : rb.n;
   bool FIT;
   if (forced >= 0) {
     FIT = forced != 0;
@@ -799,11 +805,10 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
     if (ctrl->stop) return;
     FIT = ctrl->search_next != 0;
   }
-  const PoseArg ps = forced < 0 ? *pose : ps_val;
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;  // uniform per block
   const int i = blk * kBlock + threadIdx.x;
-  const bool live = i < (rb.n_dev ? *rb.n_dev : rb.n);
+  const bool live = i < n_live;
   if (FIT) {  // uniform per workgroup
     if (threadIdx.x == 0) s_nneedy = 0;
     __syncthreads();
