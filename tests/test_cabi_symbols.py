@@ -54,3 +54,19 @@ def test_fails_loudly_without_gpu():
     h = ctypes.c_void_p()
     assert L.lii_create(ctypes.byref(cfg), ctypes.byref(h)) == -2  # LII_ERR_NO_DEVICE
     assert not h.value
+
+
+def test_cxx_host_loop_links_against_the_boundary():
+    """harness/libliinit_stream.so (the C++ per-scan loop bench.py times) is built from include/liinit_hip.h alone, resolves
+    the product library by name and rejects a null handle without touching a device."""
+    path = os.path.join(ROOT, "harness", "libliinit_stream.so")
+    assert os.path.exists(path), "build it with __graft_entry__.build() (make -C harness)"
+    lii.load_library()  # the same libliinit_hip.so the driver library resolves through its rpath
+    drv = ctypes.CDLL(path)
+    drv.lii_stream_run.restype = ctypes.c_int
+    drv.lii_stream_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                   ctypes.c_float, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                   ctypes.c_void_p, ctypes.c_void_p]
+    totals = (ctypes.c_int64 * 2)()
+    assert drv.lii_stream_run(None, None, 0, 0, 0, 0.0, 5, 1, 0, 0, totals, None) == -1  # LII_ERR_INVALID
+    assert ctypes.sizeof(api.lii_scan_job) == 48  # struct_size the C++ loop fills in (two 8-byte members after the options)
