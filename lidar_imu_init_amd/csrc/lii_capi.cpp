@@ -81,6 +81,7 @@ struct lii_context {
   unsigned long long* d_extent = nullptr;  // 2 x {min (time|index), max time}: ping-pong accumulators
   unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
   int extent_sel = 0, mm_sel = 0;
+  bool staging_busy = false;  // h_ctrl / h_poses were handed to the device by lii_scan_register and no wait has covered the read yet
   size_t ctrl_pending = 0;    // bytes of h_ctrl (+ poses) the next k_time_extent launch carries to d_ctrl; 0 = nothing pending
   bool extent_valid = false;  // d_extent[extent_sel] holds the time extent of d_scan (lii_scan_set_device computed it on the way)
   unsigned int* d_bbox_rows = nullptr;  // one row per de-skew workgroup: bounding box of its output points
@@ -410,6 +411,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   if (rc != LII_OK) return rc;
   hipStream_t s = h->stream;
   if (!h->ctrl_preloaded) {
+    if (h->staging_busy) HIPCHK(h, hipStreamSynchronize(s));  // a lii_scan_register that failed half way left the buffer in use
     fill_ctrl(h, state, state_prop, opts);
     HIPCHK(h, hipMemcpyAsync(h->d_ctrl, h->h_ctrl, sizeof(IekfCtrl), hipMemcpyHostToDevice, s));
   }
@@ -471,6 +473,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   } else {
     HIPCHK(h, hipStreamSynchronize(s));  // the stopping iteration's solve has written h_res (mapped host memory)
   }
+  h->staging_busy = false;  // the wait above covers everything enqueued before the stopping pass
   const IekfResult* hr = h->h_res;
   h->have_search = true;
 #ifdef LII_SOLVE_TRACE
@@ -837,6 +840,7 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
   static_assert(sizeof(lii_pose6d) == 22 * sizeof(double), "lii_pose6d layout");
   if (h->n_scan <= 0 || n_poses < 2) return LII_OK;  // nothing to compensate (IMUpose needs a head and a tail)
   if (!h->poses_preloaded) {
+    if (h->staging_busy) { HIPCHK(h, hipStreamSynchronize(h->stream)); h->staging_busy = false; }
     HIPCHK(h, hipEventSynchronize(h->ev_poses));  // the previous table has left the staging buffer (normally long ago)
     std::memcpy(h->h_poses, poses, sizeof(lii_pose6d) * size_t(n_poses));
     HIPCHK(h, hipMemcpyAsync(h->d_poses, h->h_poses, sizeof(lii_pose6d) * size_t(n_poses), hipMemcpyHostToDevice, h->stream));
@@ -1030,8 +1034,13 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   if (adopt && job->n_scan_dev > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_register: n_scan_dev > max_scan_points");
   const int n_next = adopt ? job->n_scan_dev : h->n_scan;
   if (job->undistort == 1 && !h->host_solve && job->imu_poses && job->n_imu_poses >= 2 && job->n_imu_poses <= 1024 && n_next > 0) {
-    // the control block of the update AND the pose table of the de-skew (they sit behind each other) reach the device once
-    HIPCHK(h, hipEventSynchronize(h->ev_poses));  // the previous scan's copy of them has left the staging buffer
+    // the control block of the update AND the pose table of the de-skew (they sit behind each other) reach the device once.
+    // The staging buffer is free again: the previous call returned after its stopping pass, which runs behind the kernel
+    // that read the buffer - unless that call failed half way (then wait).  No event: recording one between the de-skew and
+    // the voxel filter cost a ~5 us bubble on the device per scan.
+    if (h->staging_busy) HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev_poses));  // a pose table uploaded by a stand-alone lii_undistort_imu (long done)
+    h->staging_busy = true;
     fill_ctrl(h, state, state_prop, &job->opts);
     std::memcpy(h->h_poses, job->imu_poses, sizeof(lii_pose6d) * size_t(job->n_imu_poses));
     const size_t bytes = kCtrlBytes + sizeof(lii_pose6d) * size_t(job->n_imu_poses);
@@ -1055,12 +1064,9 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   } else if (job->undistort != 0) {
     return fail(h, LII_ERR_INVALID, "lii_scan_register: undistort must be 0, 1 or 2");
   }
-  if (h->ctrl_preloaded) {
-    if (h->ctrl_pending) {  // no kernel picked the block up (cannot happen with the conditions above; kept as a guard)
-      HIPCHK(h, hipMemcpyAsync(h->d_ctrl, h->h_ctrl, h->ctrl_pending, hipMemcpyHostToDevice, h->stream));
-      h->ctrl_pending = 0;
-    }
-    HIPCHK(h, hipEventRecord(h->ev_poses, h->stream));  // whoever read the staging buffer is behind this point of the stream
+  if (h->ctrl_preloaded && h->ctrl_pending) {  // no kernel picked the block up (cannot happen with the conditions above; a guard)
+    HIPCHK(h, hipMemcpyAsync(h->d_ctrl, h->h_ctrl, h->ctrl_pending, hipMemcpyHostToDevice, h->stream));
+    h->ctrl_pending = 0;
   }
   if (rc == LII_OK) rc = job->leaf > 0 ? lii_downsample(h, job->leaf, nullptr, nullptr) : lii_downsample_skip(h, nullptr);
   if (rc == LII_OK) rc = lii_iekf_update(h, state, state_prop, &job->opts, report);
