@@ -19,7 +19,8 @@
 extern "C" {
 #endif
 
-#define LII_ABI_VERSION 2 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport */
+#define LII_ABI_VERSION 3 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
+                             3: lii_params_*, lii_comm_set_partition (library-side split of the down-sampled cloud) */
 
 enum lii_status {
   LII_OK = 0,
@@ -274,7 +275,14 @@ int lii_li_init_run(lii_handle h, const lii_calib_state* imu, const lii_calib_st
  * One process per GPU.  Rank 0 creates an id, the caller ships the 128 bytes to the other ranks (e.g.
  * torch.distributed broadcast), every rank calls lii_comm_init with the SAME state / options per scan; afterwards
  * lii_iekf_iterate / lii_iekf_update / lii_scan_register sum the 91 normal-equation scalars (fp64, in rank order, so every
- * rank forms the bit-identical sum and takes the same decisions) over the ranks.  Two transports:
+ * rank forms the bit-identical sum and takes the same decisions) over the ranks.
+ * Partition (lii_comm_set_partition; default 1): every rank hands over the WHOLE scan and holds the whole map; the de-skew and
+ *   the voxel filter run replicated (their output is bit-identical on every rank, so a voxel is never split between ranks)
+ *   and rank r registers the contiguous block [n r / N, n (r + 1) / N) of the down-sampled cloud, which the filter emits in
+ *   brick order - a compact region of the map per rank.  The sharded result equals the single-GPU result up to the
+ *   re-association of the 91 sums.  lii_map_incremental of a sharded job repeats the last search for the whole cloud (no
+ *   exchange) so that every rank applies the identical insert lists.  Partition 0: the caller hands every rank its own points.
+ * Two transports:
  *   LII_COMM_MAILBOX  ranks of ONE node meet in a shared-memory segment that each registers with its device; the exchange
  *                     runs inside the reduce+solve kernel (no extra launch, no collective-library call; ~5 us).
  *   LII_COMM_RCCL     ncclAllReduce on the handle's stream between a separate final-sum and solve launch (any topology).
@@ -286,7 +294,44 @@ int lii_comm_unique_id(uint8_t id_out[128]);
 int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id[128]);
 int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id[128], int32_t transport);
 int lii_comm_transport(lii_handle h, int32_t* transport); /* the transport in use; LII_COMM_AUTO = none (single rank) */
+int lii_comm_set_partition(lii_handle h, int32_t library_partition);
 int lii_comm_destroy(lii_handle h);
+
+/* ---------------------------------------------------------------- parameter surface (config/*.yaml + launch/*.launch)
+ * The nh.param<> block of main() (src/laserMapping.cpp:767-799) as a POD: same names (`section/key` -> field), same defaults.
+ * roslaunch fills the parameter server from `<rosparam command="load" file="$(find lidar_imu_init)/config/X.yaml"/>` and
+ * `<param name=".." value=".."/>` (launch/*.launch:6-12); a host without ROS calls
+ *   lii_params_defaults    the third argument of every nh.param<> call
+ *   lii_params_load_yaml   one config/*.yaml on top (block maps, scalars, quoted strings, flow lists, '#' comments)
+ *   lii_params_load_launch a launch file: its rosparam yaml (looked up in `config_dir`, else <launch dir>/../config) first,
+ *                          then its <param> tags (names a node never reads are ignored, as on the parameter server)
+ *   lii_params_set         one override by name ("max_iteration", "mapping/filter_size_surf", ...)
+ *   lii_params_apply       -> lii_config (map down-sample box = mapping/filter_size_map), lii_ingest_opts (lidar_type, scan_line,
+ *                          point_filter_num, blind, cut_frame_num; stamp / scan_count stay per message), lii_iekf_opts
+ *                          (max_iteration; imu_en = 0 as at start-up, laserMapping.cpp:87), voxel leaf = mapping/filter_size_surf.
+ * Host functions (no device work, no handle). */
+typedef struct lii_params {
+  uint32_t struct_size; /* sizeof(lii_params); set by lii_params_defaults */
+  int32_t max_iteration, point_filter_num;
+  double filter_size_surf, filter_size_map, cube_side_length, det_range;
+  double gyr_cov, acc_cov, grav_cov, b_gyr_cov, b_acc_cov;
+  double blind;
+  int32_t lidar_type, scan_line, feature_extract_en;
+  int32_t cut_frame, cut_frame_num, orig_odom_freq;
+  double online_refine_time, mean_acc_norm, data_accum_length;
+  double Rot_LI_cov[3], Trans_LI_cov[3];
+  int32_t n_Rot_LI_cov, n_Trans_LI_cov; /* entries present in the file (the reference reads vector<double>) */
+  int32_t path_en, scan_publish_en, dense_publish_en, scan_bodyframe_pub_en, runtime_pos_log_enable, pcd_save_en, pcd_save_interval;
+  int32_t reserved0;
+  char lid_topic[128], imu_topic[128], map_file_path[256];
+} lii_params;
+int lii_params_defaults(lii_params* p);
+int lii_params_load_yaml(const char* yaml_path, lii_params* inout);
+int lii_params_load_launch(const char* launch_path, const char* config_dir /* may be NULL */, lii_params* inout);
+int lii_params_set(lii_params* inout, const char* name, const char* value);
+int lii_params_apply(const lii_params* p, int32_t device, int32_t max_scan_points, int32_t max_map_points, lii_config* cfg /* may be NULL */,
+                     lii_ingest_opts* ingest /* may be NULL */, lii_iekf_opts* opts /* may be NULL */, float* leaf /* may be NULL */);
+const char* lii_params_last_error(void);
 
 /* ---------------------------------------------------------------- utilities for harnesses */
 int lii_dev_alloc(lii_handle h, size_t bytes, void** dev_ptr);

@@ -118,10 +118,17 @@ _DECLS = {
     "lii_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lii_comm_init_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "lii_comm_transport": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lii_comm_set_partition": (C.c_int, [C.c_void_p, C.c_int32]),
     "lii_comm_destroy": (C.c_int, [C.c_void_p]),
     "lii_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "lii_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lii_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "lii_params_defaults": (C.c_int, [C.c_void_p]),
+    "lii_params_load_yaml": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "lii_params_load_launch": (C.c_int, [C.c_char_p, C.c_char_p, C.c_void_p]),
+    "lii_params_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    "lii_params_apply": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lii_params_last_error": (C.c_char_p, []),
     "lii_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "lii_last_timings": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
@@ -450,6 +457,11 @@ class Registrar:
         """transport: "auto" (node-local mailbox when all ranks share the node, else RCCL), "rccl", "mailbox"."""
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._check(self.L.lii_comm_init_ex(self.h, n_ranks, rank, buf, {"auto": 0, "rccl": 1, "mailbox": 2}[transport]))
+
+    def comm_set_partition(self, library_partition: bool):
+        """True (default): every rank hands over the whole scan, the library splits the down-sampled cloud; False: the
+        caller hands every rank its own points."""
+        self._check(self.L.lii_comm_set_partition(self.h, int(library_partition)))
 
     def comm_transport(self) -> str:
         t = C.c_int32(0)

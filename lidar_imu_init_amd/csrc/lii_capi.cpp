@@ -90,6 +90,11 @@ struct lii_context {
   unsigned long long *d_vcomp = nullptr, *d_vsplit = nullptr;  // sample sort of the voxel filter (lii_vsort.hip)
   unsigned int* d_vhist = nullptr;
   unsigned short* d_vbucket = nullptr;
+  unsigned int *d_vpcl_in = nullptr, *d_vpcl_out = nullptr;  // PCL voxel index per input point / per output voxel
+  bool coherent_order = true;    // the voxel filter emits brick-major (Morton) order; LII_VOXEL_ORDER=pcl: the PCL index order
+  bool body_reordered = false;   // d_body is in brick order: the download entry points restore the PCL order (pcl_perm)
+  std::vector<int> pcl_perm;     // pcl_perm[r] = position in d_body of the r-th point in PCL order (valid while pcl_perm_valid)
+  bool pcl_perm_valid = false;
   double* d_poses = nullptr;
   int n_scan = 0, n_body = 0;   // n_body is an upper bound while n_body_pending (the exact count lives in d_nbody)
   bool n_body_pending = false;
@@ -97,7 +102,10 @@ struct lii_context {
   int* d_nbody = nullptr;       // [0] size of the down-sampled cloud, [1] `filtered` flag of the last voxel filter
   bool body_is_scan = false;
   bool have_search = false;
-  int knn_variant = 4;  // lanes per query of the search pass: 4 (default) or 8 (LII_KNN_VARIANT, an A/B knob)
+  int knn_variant = 64;  // search pass: 64 = LDS-tiled (k_knn_tile, default); 4 / 8 = lanes per query of the global-memory
+                         // search (k_knn_pruned); 65 / 32 / 128 = other tile geometries (LII_KNN_VARIANT, an A/B knob)
+  unsigned int* d_knn_stats = nullptr;  // [0] workgroups of k_knn_tile that searched out of LDS, [1] that took the global path
+  bool knn_stats = false;               // LII_KNN_STATS=1: count them (adds one atomic per workgroup)
 
   // ---- pinned staging
   float4* h_stage = nullptr;     // max(max_scan, max_map) float4
@@ -116,6 +124,8 @@ struct lii_context {
   unsigned long long* d_mb_seq = nullptr;
   long long mailbox_timeout_ticks = 3000000000ll;  // 30 s (LII_MAILBOX_TIMEOUT_S): ranks may start a scan seconds apart
   int n_ranks = 1, rank = 0;
+  bool library_partition = true;  // lii_comm_set_partition: the library splits the down-sampled cloud over the ranks (every rank
+                                  // hands over the whole scan); false: the caller hands every rank its own points
 
   // ---- profiling
   bool profiling = false;
@@ -175,6 +185,8 @@ RegistrationBuffers reg_buffers(const lii_context* c) {
   rb.n = c->n_body;
   rb.n_dev = c->n_body_pending ? c->d_nbody : nullptr;
   rb.cap = c->cfg.max_scan_points;
+  rb.shard_rank = c->rank;
+  rb.shard_world = (c->n_ranks > 1 && c->library_partition) ? c->n_ranks : 1;
   return rb;
 }
 PoseArg pose_of(const lii_state& s) {
@@ -274,18 +286,19 @@ int map_apply(lii_handle h, const float4* list, int n_bound, const int* n_dev, b
     // inserted points -> behind them
     inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_a, h->d_u32_c, n_bound, s);
     launch_compact_f4(h->d_ins, h->d_u32_a, h->d_u32_c, n_bound, h->d_ins_c, 0, h->d_counts + 3, s);
-    launch_append_f4(h->d_ins_c, h->d_counts + 3, n_bound, h->d_map_unsorted, h->d_counts + 2, nullptr, s);
+    launch_append_f4(h->d_ins_c, h->d_counts + 3, n_bound, h->d_map_unsorted, h->cfg.max_map_points, h->d_counts + 2, nullptr, s);
   } else {
     if (n_old > 0) HIPCHK(h, hipMemcpyAsync(h->d_map_unsorted, h->d_map, sizeof(float4) * size_t(n_old), hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipMemcpyAsync(h->d_counts + 2, &h->n_map_pinned[0], sizeof(int), hipMemcpyHostToDevice, s));
     if (n_bound > 0) {
       // plain Add_Points(points, false): append the whole batch
-      launch_append_f4(list, n_dev, n_bound, h->d_map_unsorted, h->d_counts + 2, nullptr, s);
+      launch_append_f4(list, n_dev, n_bound, h->d_map_unsorted, h->cfg.max_map_points, h->d_counts + 2, nullptr, s);
       if (n_dev) HIPCHK(h, hipMemcpyAsync(h->d_counts + 3, n_dev, sizeof(int), hipMemcpyDeviceToDevice, s));
       else { h->n_map_pinned[1] = n_bound; HIPCHK(h, hipMemcpyAsync(h->d_counts + 3, &h->n_map_pinned[1], sizeof(int), hipMemcpyHostToDevice, s)); }
     }
   }
-  if (extra && extra_bound > 0) launch_append_f4(extra, extra_n, extra_bound, h->d_map_unsorted, h->d_counts + 2, h->d_counts + 3, s);
+  if (extra && extra_bound > 0)
+    launch_append_f4(extra, extra_n, extra_bound, h->d_map_unsorted, h->cfg.max_map_points, h->d_counts + 2, h->d_counts + 3, s);
   launch_sum3(h->d_counts + 2, h->d_counts + 3, extra ? extra_n : nullptr, h->d_counts + 4, s);
   HIPCHK(h, hipMemcpyAsync(h->h_small + 3072, h->d_counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
@@ -293,14 +306,16 @@ int map_apply(lii_handle h, const float4* list, int n_bound, const int* n_dev, b
   std::memcpy(cnt, h->h_small + 3072, sizeof(cnt));
   if (events_out) *events_out = cnt[5];
   const int total = cnt[4];
+  // (the appends above dropped every write at or beyond max_map_points: nothing outside d_map_unsorted was touched, and the
+  // live map - d_map and its index - is only replaced by build_index below, so it is unchanged when this error returns)
   if (total > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "local map exceeds max_map_points");
   h->n_map_pinned[0] = total;
   return build_index(h, total, cnt[2]);  // the cnt[2] survivors lead the array in key order
 }
 
 void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, int forced) {
-  if (h->knn_variant == 8) launch_knn8p(g, rb, ps, pose, h->d_ctrl, forced, h->stream);
-  else launch_knn4p(g, rb, ps, pose, h->d_ctrl, forced, h->stream);
+  lii::launch_knn(h->knn_variant, g, rb, ps, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->knn_stats ? h->d_knn_stats : nullptr,
+                  h->stream);
 }
 
 // Fetches the exact size of the down-sampled cloud from the device (one small synchronising copy).
@@ -313,6 +328,32 @@ int resolve_n_body(lii_handle h) {
   h->n_body = v[0];
   h->last_filtered = v[1];
   h->n_body_pending = false;
+  return LII_OK;
+}
+
+// The down-sampled cloud lives on the device in brick order (k_voxel_keys: coherent_key); the reference's filter emits it
+// ascending in the PCL voxel index.  Every entry point that hands per-point data of the down-sampled cloud to the host
+// (lii_scan_download 1 / 2, lii_neighbors_download) restores that order: perm[r] = device position of the r-th point in PCL
+// order, from the PCL index kept per output voxel (distinct per voxel).  Host work, off the per-scan path.
+int pcl_order(lii_handle h, const int** perm) {
+  *perm = nullptr;
+  if (!h->body_reordered) return LII_OK;
+  int rc = resolve_n_body(h);
+  if (rc != LII_OK) return rc;
+  if (!h->pcl_perm_valid) {
+    const int n = h->n_body;
+    std::vector<unsigned int> keys(size_t(std::max(n, 1)));
+    if (n > 0) {
+      HIPCHK(h, hipMemcpyAsync(h->h_stage, h->d_vpcl_out, sizeof(unsigned int) * size_t(n), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      std::memcpy(keys.data(), h->h_stage, sizeof(unsigned int) * size_t(n));
+    }
+    h->pcl_perm.resize(size_t(n));
+    for (int i = 0; i < n; i++) h->pcl_perm[size_t(i)] = i;
+    std::sort(h->pcl_perm.begin(), h->pcl_perm.end(), [&](int a, int b) { return keys[size_t(a)] < keys[size_t(b)]; });
+    h->pcl_perm_valid = true;
+  }
+  *perm = h->pcl_perm.data();
   return LII_OK;
 }
 
@@ -358,7 +399,7 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
   launch_fit_reduce(g, rb, ps, h->d_pose, h->d_ctrl, search ? 1 : 0, imu_en ? 1 : 0, h->cfg.plane_threshold,
                     h->cfg.laser_point_cov_inv, h->stream);
   if (prof) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-  launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_ctrl, 1, rb.n_dev, h->stream);
+  launch_reduce91(rb, h->d_out91, h->d_ctrl, 1, h->stream);
   if (prof) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
   if (search) h->have_search = true;
   if (h->comm) {
@@ -434,12 +475,11 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     launch_fit_reduce(g, rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[1], s));
     if (!h->comm) {  // single GPU or node-local mailbox: final sum (+ exchange) and solve in one launch ([2] times both)
-      launch_reduce_solve(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_counter, h->d_ctrl, h->h_res, rb.n_dev,
-                          mailbox_view(h), s);
+      launch_reduce_solve(rb, h->d_out91, h->d_counter, h->d_ctrl, h->h_res, mailbox_view(h), s);
       if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
       return LII_OK;
     }
-    launch_reduce91(rb.partials, rb.n, rb.partial_stride, h->d_out91, h->d_ctrl, -1, rb.n_dev, s);
+    launch_reduce91(rb, h->d_out91, h->d_ctrl, -1, s);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
     // every rank enqueues the same number of all-reduces; a pass that is skipped on the device re-sums the
     // unchanged local buffer on all ranks alike, so the ranks stay in lock-step without a host decision
@@ -569,6 +609,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   // the 3x3x3 neighbourhood of 8x8x8-cell blocks must cover the acceptance radius sqrt(max_match_dist2)
   h->cell_size = std::max(h->cell_size, std::sqrt(h->cfg.max_match_dist2) / 8.0f * 1.001f);
   if (const char* v = std::getenv("LII_KNN_VARIANT")) h->knn_variant = std::atoi(v);  // A/B knob for profiling
+  if (const char* v = std::getenv("LII_KNN_STATS")) h->knn_stats = std::atoi(v) != 0;
+  if (const char* v = std::getenv("LII_VOXEL_ORDER")) h->coherent_order = std::string(v) != "pcl";
   if (const char* v = std::getenv("LII_HOST_SOLVE")) h->host_solve = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_SYNC_RESULT")) h->poll_result = std::atoi(v) == 0;
   h->ds = h->cfg.map_downsample_size;
@@ -606,6 +648,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   h->cells_cap_blocks = std::max<size_t>(4096, M / 64);
   CK(dmalloc(&h->d_cells, h->cells_cap_blocks * 512));
   CK(dmalloc(&h->d_counter, 4));
+  CK(dmalloc(&h->d_knn_stats, 4));
+  CK(hipMemset(h->d_knn_stats, 0, 16));
   CK(dmalloc(&h->d_tomb, M));
   CK(dmalloc(&h->d_ins, M));
   CK(dmalloc(&h->d_batch, M));
@@ -664,6 +708,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_vhist, voxel_sort_hist_elems((int)N)));
   CK(hipMemset(h->d_vhist, 0, sizeof(unsigned int) * voxel_sort_hist_elems((int)N)));
   CK(dmalloc(&h->d_vbucket, N));
+  CK(dmalloc(&h->d_vpcl_in, N));
+  CK(dmalloc(&h->d_vpcl_out, N));
   CK(dmalloc(&h->d_cal_params, 64));
   CK(dmalloc(&h->d_cal_out, 128));
   h->h_stage_elems = NM * kMatch;  // large enough for the neighbour download too
@@ -686,9 +732,9 @@ int lii_destroy(lii_handle h) {
   mailbox_close(&h->mailbox);
   if (h->d_mb_seq) (void)hipFree(h->d_mb_seq);
   void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
-                 h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
+                 h->d_counter, h->d_knn_stats, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
-                 h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
+                 h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -878,6 +924,7 @@ int lii_downsample_skip(lii_handle h, int32_t* n_down) {
   h->n_body = h->n_scan;
   h->n_body_pending = false;
   h->have_search = false;
+  h->body_reordered = false;
   if (n_down) *n_down = h->n_body;
   return LII_OK;
 }
@@ -903,8 +950,10 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
   }
   {
     const VoxelSortPlan plan = voxel_sort_plan(n);
-    launch_voxel_keys(h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_vkeys_a, h->d_nbody + 1, plan.samples ? h->d_vsplit + 2048 : nullptr, plan.width, s);
+    launch_voxel_keys(h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_vkeys_a, h->d_vpcl_in, h->coherent_order ? 1 : 0,
+                      h->d_nbody + 1, plan.samples ? h->d_vsplit + 2048 : nullptr, plan.width, s);
     VoxelSortBuffers vb;
+    vb.pcl_in = h->d_vpcl_in; vb.pcl_out = h->d_vpcl_out;
     vb.samples = h->d_vsplit + 2048;
     vb.keys_in = h->d_vkeys_a; vb.keys_out = h->d_vkeys_b; vb.idx_out = h->d_vidx_b;
     vb.comp = h->d_vcomp; vb.splitters = h->d_vsplit; vb.hist = h->d_vhist; vb.bucket_of = h->d_vbucket;
@@ -913,6 +962,8 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
   HIPCHK(h, hipGetLastError());
   h->n_body = n;  // upper bound until resolved
   h->n_body_pending = true;
+  h->body_reordered = h->coherent_order;
+  h->pcl_perm_valid = false;
   if (n_down || filtered) {
     int rc = resolve_n_body(h);
     if (rc != LII_OK) return rc;
@@ -930,9 +981,13 @@ int lii_scan_download(lii_handle h, int32_t which, float* out_float4, int32_t ca
   if (!out_float4) return LII_OK;
   if (capacity < cnt) return fail(h, LII_ERR_CAPACITY, "lii_scan_download: capacity too small");
   if (cnt > 0) {
+    const int* perm = nullptr;
+    if (which != 0) { int rc1 = pcl_order(h, &perm); if (rc1 != LII_OK) return rc1; }
     HIPCHK(h, hipMemcpyAsync(h->h_stage, src, sizeof(float4) * size_t(cnt), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    std::memcpy(out_float4, h->h_stage, sizeof(float4) * size_t(cnt));
+    if (!perm) std::memcpy(out_float4, h->h_stage, sizeof(float4) * size_t(cnt));
+    else
+      for (int r = 0; r < cnt; r++) std::memcpy(out_float4 + 4 * size_t(r), &h->h_stage[perm[r]], sizeof(float4));
   }
   return LII_OK;
 }
@@ -1082,13 +1137,15 @@ int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* s
   if (n == 0) return LII_OK;
   const size_t cap = size_t(h->cfg.max_scan_points);
   hipStream_t s = h->stream;
+  const int* perm = nullptr;  // rows come out in the order lii_scan_download(1) uses (the reference's feats_down_body order)
+  { int rc1 = pcl_order(h, &perm); if (rc1 != LII_OK) return rc1; }
   if (pts) {
     for (int k = 0; k < kMatch; k++)
       HIPCHK(h, hipMemcpyAsync(h->h_stage + size_t(k) * n, h->d_nbr + size_t(k) * cap, sizeof(float4) * size_t(n), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     for (int i = 0; i < n; i++)
       for (int k = 0; k < kMatch; k++) {
-        const float4 v = h->h_stage[size_t(k) * n + i];
+        const float4 v = h->h_stage[size_t(k) * n + (perm ? perm[i] : i)];
         float* o = pts + (size_t(i) * kMatch + k) * 3;
         o[0] = v.x; o[1] = v.y; o[2] = v.z;
       }
@@ -1096,12 +1153,14 @@ int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* s
   if (counts) {
     HIPCHK(h, hipMemcpyAsync(h->h_stage, h->d_nbr_count, sizeof(int) * size_t(n), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
-    std::memcpy(counts, h->h_stage, sizeof(int) * size_t(n));
+    const int* src = reinterpret_cast<const int*>(h->h_stage);
+    for (int i = 0; i < n; i++) counts[i] = src[perm ? perm[i] : i];
   }
   if (selected) {
     HIPCHK(h, hipMemcpyAsync(h->h_stage, h->d_selected, size_t(n), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
-    std::memcpy(selected, h->h_stage, size_t(n));
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(h->h_stage);
+    for (int i = 0; i < n; i++) selected[i] = src[perm ? perm[i] : i];
   }
   return LII_OK;
 }
@@ -1115,6 +1174,19 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
   if (nb > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "lii_map_incremental: scan larger than max_map_points");
   hipStream_t s = h->stream;
   RegistrationBuffers rb = reg_buffers(h);
+  if (rb.shard_world > 1) {
+    // A sharded job: this rank holds neighbour lists for its own block only, but every rank must take the SAME decisions for
+    // the whole cloud or the replicated maps drift apart.  No exchange: the search is repeated here for the whole cloud at the
+    // pose of the last executed search pass (IekfCtrl::search_pose, identical on every rank) - one more k-NN pass, a few
+    // percent of what the map update itself costs - and the lists come out bit-identical on every rank.
+    rb.shard_world = 1;
+    if (h->have_search) {
+      const GridView g = grid_view(h);
+      lii::launch_knn(h->knn_variant, g, rb, pose_of(*state), reinterpret_cast<const PoseArg*>(h->d_ctrl->search_pose), h->d_ctrl, 2, nullptr,
+                      nullptr, s);
+      launch_knn_complete(g, rb, s);
+    }
+  }
   // decision per point on the device (world point, neighbour list of the last search), then two order-preserving compactions
   launch_map_decide(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, h->d_u32_a, h->d_u32_b, h->d_world, s);
   inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_a, h->d_u32_c, nb, s);
@@ -1193,7 +1265,9 @@ int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t 
   comm_drop(h);
   h->n_ranks = n_ranks;
   h->rank = rank;
-  if (n_ranks == 1) return LII_OK;
+  // a single rank needs no exchange; asked for by name, the RCCL transport is still set up (a one-rank communicator), so that
+  // the three-launch form of the loop - final sum, ncclAllReduce, solve - can be exercised on one device
+  if (n_ranks == 1 && transport != LII_COMM_RCCL) return LII_OK;
   if (transport != LII_COMM_RCCL) {
     if (!h->d_mb_seq) HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->d_mb_seq), sizeof(unsigned long long)));
     HIPCHK(h, hipMemset(h->d_mb_seq, 0, sizeof(unsigned long long)));
@@ -1214,6 +1288,11 @@ int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t 
     h->comm = nullptr; h->n_ranks = 1; h->rank = 0;
     return fail(h, LII_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
   }
+  return LII_OK;
+}
+int lii_comm_set_partition(lii_handle h, int32_t library_partition) {
+  if (!h) return LII_ERR_INVALID;
+  h->library_partition = library_partition != 0;
   return LII_OK;
 }
 int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128]) {

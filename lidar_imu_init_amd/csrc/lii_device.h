@@ -56,7 +56,21 @@ struct RegistrationBuffers {
   int n;              // number of points, or an upper bound of it when n_dev != nullptr
   int cap;
   const int* n_dev;   // device-resident point count (set by the sync-free voxel filter), or nullptr
+  int shard_rank;     // points of one scan sharded across ranks: this rank registers the contiguous
+  int shard_world;    // block [n * rank / world, n * (rank + 1) / world) of the down-sampled cloud; world <= 1: all of it
 };
+
+// The block of the down-sampled cloud this rank registers: first index and size.  Every rank holds the WHOLE cloud (the
+// de-skew and the voxel filter run replicated, so the cloud is bit-identical everywhere) and the split needs no exchange.
+__device__ __forceinline__ void shard_range(const RegistrationBuffers& rb, int& lo, int& n_live) {
+  const int n_all = rb.n_dev ? *rb.n_dev : rb.n;
+  lo = 0;
+  n_live = n_all;
+  if (rb.shard_world > 1) {
+    lo = (int)(((long long)n_all * rb.shard_rank) / rb.shard_world);
+    n_live = (int)(((long long)n_all * (rb.shard_rank + 1)) / rb.shard_world) - lo;
+  }
+}
 
 // Device-resident control block of one scan registration (lii_iekf_update): the state, the propagated state and
 // the loop flags of src/laserMapping.cpp:957-1134 live in HBM so that the whole iterated update is enqueued once
@@ -80,6 +94,8 @@ struct IekfCtrl {
   int seq;           // number of this update (host); echoed into IekfResult::done by the iteration that ends the loop
   int pad[1];
   int search_log[16];  // search_log[it] = 1 when iteration `it` ran the k-NN pass (for profiling)
+  double search_pose[24];  // the PoseArg of the last executed k-NN pass (written by that pass): a sharded job re-runs the search
+                           // for the blocks of the other ranks at exactly this pose before map_incremental (lii_capi.cpp)
 };
 
 // "Last workgroup finishes the job" kernels publish their partial results with device-scope ATOMIC stores / adds (performed

@@ -316,11 +316,12 @@ __global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __
 // update.  Used when no all-reduce sits between the two (single GPU); one launch less per iteration.
 __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ partials, int n_blocks, int stride,
                                                       double* out, unsigned int* ticket, IekfCtrl* c, IekfResult* res,
-                                                      const int* __restrict__ n_dev, MailboxView mb) {
+                                                      RegistrationBuffers rb, MailboxView mb) {
   __shared__ int s_last;
-  const int n_dev_now = n_dev ? *n_dev : -1;  // issued with the flag below, not after the branch on it
+  int lo, n_live;
+  shard_range(rb, lo, n_live);  // (the device-resident cloud size is loaded together with the flag below, not after the branch on it)
   if (c->stop) return;  // read by every workgroup before its ticket; the solve (which may set it) runs after all tickets
-  if (n_dev) n_blocks = max(1, (n_dev_now + kBlock - 1) / kBlock);
+  if (rb.n_dev || rb.shard_world > 1) n_blocks = max(1, (n_live + kBlock - 1) / kBlock);
   const int t = blockIdx.x, lane = threadIdx.x;
   const double* row = partials + (size_t)t * stride;
   // the partials were written by other XCDs: every load is an L2 miss.  Eight are in flight before the first add (same
@@ -366,11 +367,11 @@ __global__ __launch_bounds__(64) void k_mailbox_allreduce(double* out, MailboxVi
 void launch_mailbox_allreduce(double* out91, const MailboxView& mb, hipStream_t s) {
   hipLaunchKernelGGL(k_mailbox_allreduce, dim3(1), dim3(64), 0, s, out91, mb);
 }
-void launch_reduce_solve(const double* partials, int n_points, int stride, double* out91, unsigned int* ticket, IekfCtrl* c,
-                         IekfResult* res, const int* n_dev, const MailboxView& mb, hipStream_t s) {
-  int nb = (n_points + kBlock - 1) / kBlock;
+void launch_reduce_solve(const RegistrationBuffers& rb, double* out91, unsigned int* ticket, IekfCtrl* c, IekfResult* res,
+                         const MailboxView& mb, hipStream_t s) {
+  int nb = (rb.n + kBlock - 1) / kBlock;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, ticket, c, res, n_dev, mb);
+  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq), dim3(64), 0, s, rb.partials, nb, rb.partial_stride, out91, ticket, c, res, rb, mb);
 }
 void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s) {
   hipLaunchKernelGGL(k_iekf_solve, dim3(1), dim3(64), 0, s, c, ne, res);

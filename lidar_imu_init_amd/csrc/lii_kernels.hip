@@ -165,23 +165,23 @@ __device__ __forceinline__ uint2 cell_range(const GridView& g, int ix, int iy, i
   return g.cells[(size_t)id * kBlockCells + local];
 }
 
-__device__ __forceinline__ void scan_range(const GridView& g, unsigned int start, unsigned int end, float qx, float qy,
-                                           float qz, Knn5& k) {
+__device__ __forceinline__ void scan_range(const float4* __restrict__ pts, const float max_d2, unsigned int start, unsigned int end,
+                                           float qx, float qy, float qz, Knn5& k) {
   // four candidates per trip: the loads do not depend on the running top-5, so they are issued together
   for (unsigned int j = start; j < end; j += 4) {
     const unsigned int last = end - 1;
-    float4 p0 = g.pts[j];
-    float4 p1 = g.pts[min(j + 1, last)];
-    float4 p2 = g.pts[min(j + 2, last)];
-    float4 p3 = g.pts[min(j + 3, last)];
+    float4 p0 = pts[j];
+    float4 p1 = pts[min(j + 1, last)];
+    float4 p2 = pts[min(j + 2, last)];
+    float4 p3 = pts[min(j + 3, last)];
     float d0 = dist2_ref(qx, qy, qz, p0.x, p0.y, p0.z);
     float d1 = dist2_ref(qx, qy, qz, p1.x, p1.y, p1.z);
     float d2 = dist2_ref(qx, qy, qz, p2.x, p2.y, p2.z);
     float d3 = dist2_ref(qx, qy, qz, p3.x, p3.y, p3.z);
-    if (d0 <= g.max_d2 && d0 < k.d4) knn_insert(k, d0, (int)j);
-    if (j + 1 < end && d1 <= g.max_d2 && d1 < k.d4) knn_insert(k, d1, (int)(j + 1));
-    if (j + 2 < end && d2 <= g.max_d2 && d2 < k.d4) knn_insert(k, d2, (int)(j + 2));
-    if (j + 3 < end && d3 <= g.max_d2 && d3 < k.d4) knn_insert(k, d3, (int)(j + 3));
+    if (d0 <= max_d2 && d0 < k.d4) knn_insert(k, d0, (int)j);
+    if (j + 1 < end && d1 <= max_d2 && d1 < k.d4) knn_insert(k, d1, (int)(j + 1));
+    if (j + 2 < end && d2 <= max_d2 && d2 < k.d4) knn_insert(k, d2, (int)(j + 2));
+    if (j + 3 < end && d3 <= max_d2 && d3 < k.d4) knn_insert(k, d3, (int)(j + 3));
   }
 }
 
@@ -508,6 +508,54 @@ __device__ __forceinline__ void lookup_cells_batched(const GridView& g, const ui
   for (int t = 0; t < NC; t++) out[t] = hit[t] ? g.cells[ci[t]] : make_uint2(0u, 0u);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Where the candidates of a query come from.  GlobalCells: block-table probe -> cell entry -> map points in HBM / L2 (one
+// dependent load chain per query).  TileCells: the cells a workgroup's queries can touch were de-duplicated and staged in LDS
+// by the workgroup (k_knn_tile); lookups and candidates are LDS reads.  Both enumerate a cell's points in map order, so the
+// two produce bit-identical neighbour lists (same visiting order, same strict '<' on ties).
+struct GlobalCells {
+  const GridView& g;
+  const uint4* __restrict__ tab;
+  __device__ __forceinline__ const float4* points() const { return g.pts; }
+  __device__ __forceinline__ uint2 lookup1(int ix, int iy, int iz) const { return lookup_cell(g, tab, ix, iy, iz); }
+  template <int NC>
+  __device__ __forceinline__ void lookup(const int (&ix)[NC], const int (&iy)[NC], const int (&iz)[NC], uint2 (&out)[NC]) const {
+    bool want[NC];
+#pragma unroll
+    for (int t = 0; t < NC; t++) want[t] = true;
+    lookup_cells_batched<NC>(g, tab, ix, iy, iz, want, out);
+  }
+};
+
+constexpr unsigned int kTileEmpty = 0xFFFFFFFFu;
+__device__ __forceinline__ unsigned int tile_key(int rx, int ry, int rz) { return (unsigned)rx | ((unsigned)ry << 10) | ((unsigned)rz << 20); }
+__device__ __forceinline__ unsigned int tile_slot(unsigned int key, unsigned int mask) { return ((key * 2654435761u) >> 11) & mask; }
+struct TileCells {
+  const unsigned int* hkey;  // LDS: packed cell coordinates relative to (bx, by, bz), kTileEmpty = free
+  const unsigned int* hval;  // LDS: tile offset | count << 16
+  const float4* tile;        // LDS: the staged map points, cell by cell
+  unsigned int mask;
+  int bx, by, bz;
+  __device__ __forceinline__ const float4* points() const { return tile; }
+  __device__ __forceinline__ uint2 lookup1(int ix, int iy, int iz) const {
+    const unsigned int key = tile_key(ix - bx, iy - by, iz - bz);
+    unsigned int sl = tile_slot(key, mask);
+    unsigned int kk = hkey[sl];
+    while (kk != key && kk != kTileEmpty) {
+      sl = (sl + 1) & mask;
+      kk = hkey[sl];
+    }
+    if (kk != key) return make_uint2(0u, 0u);
+    const unsigned int v = hval[sl];
+    return make_uint2(v & 0xFFFFu, (v & 0xFFFFu) + (v >> 16));
+  }
+  template <int NC>
+  __device__ __forceinline__ void lookup(const int (&ix)[NC], const int (&iy)[NC], const int (&iz)[NC], uint2 (&out)[NC]) const {
+#pragma unroll
+    for (int t = 0; t < NC; t++) out[t] = lookup1(ix[t], iy[t], iz[t]);
+  }
+};
+
 template <int LPQ, bool DEDUP>
 __device__ __forceinline__ void knn_group_merge_n(Knn5& k) {
 #pragma unroll
@@ -524,66 +572,56 @@ __device__ __forceinline__ void knn_group_merge_n(Knn5& k) {
   }
 }
 
-// `forced` >= 0: host-driven pass (always runs).  forced < 0: device-driven loop — runs only when the control block
-// says the next pass searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).
-// A query whose 3x3x3 block cannot prove its list complete is flagged in nbr_count (kNeedy); k_fit_reduce finishes it.
-template <int LPQ, int BS>
-__global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffers rb, PoseArg ps_val,
-                                                   const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
-                                                   int forced, int nb_real) {
-  // the pose sits in the control block: its load goes out together with the flags instead of after the branch on them
-  // (one dependent round trip less at the head of every launch, executed or not)
-  const PoseArg ps = forced < 0 ? *pose : ps_val;
-  const int n_live = rb.n_dev ? *rb.n_dev : rb.n;
-  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
-  const int blk = xcd_remap(blockIdx.x, nb_real);
-  if (blk >= nb_real) return;
-  constexpr int QPB = BS / LPQ;
-  const int sub = threadIdx.x & (LPQ - 1);
-  const int qi = blk * QPB + threadIdx.x / LPQ;
-  const bool live = qi < n_live;
-  const int leader = (threadIdx.x & 63) & ~(LPQ - 1);
-  float wx = 0, wy = 0, wz = 0;
-  if (live && sub == 0) {
-    float4 pb = rb.body[qi];
-    double bx = pb.x, by = pb.y, bz = pb.z;
-    double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
-    double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
-    double iz = ps.RLI[6] * bx + ps.RLI[7] * by + ps.RLI[8] * bz + ps.TLI[2];
-    wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
-    wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
-    wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
-  }
-  wx = __shfl(wx, leader); wy = __shfl(wy, leader); wz = __shfl(wz, leader);
+// element t of a PoseArg seen as 24 doubles, without dynamic indexing (which would push the struct into scratch memory)
+__device__ __forceinline__ double pose_element(const PoseArg& ps, int t) {
+  double v = 0;
+#pragma unroll
+  for (int e = 0; e < 9; e++) { v = t == e ? ps.R[e] : v; v = t == 12 + e ? ps.RLI[e] : v; }
+#pragma unroll
+  for (int e = 0; e < 3; e++) { v = t == 9 + e ? ps.p[e] : v; v = t == 21 + e ? ps.TLI[e] : v; }
+  return v;
+}
+// pointBodyToWorld (src/laserMapping.cpp:209-220): fp64 arithmetic, float result
+__device__ __forceinline__ void body_to_world(const PoseArg& ps, const float4 pb, float& wx, float& wy, float& wz) {
+  double bx = pb.x, by = pb.y, bz = pb.z;
+  double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
+  double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
+  double iz = ps.RLI[6] * bx + ps.RLI[7] * by + ps.RLI[8] * bz + ps.TLI[2];
+  wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
+  wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
+  wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
+}
+
+// The two search rounds of one query on its LPQ lanes (all lanes of the group hold the query's world point).  On return the
+// leader's list has been broadcast to the group; `need` = the 3x3x3 block cannot prove the list complete (kNeedy).
+template <int LPQ, class Cells>
+__device__ __forceinline__ void knn_search_query(const Cells& src, const GridView& g, bool active, float wx, float wy, float wz,
+                                                 int sub, int leader, Knn5& k, bool& need) {
   const float INF = __builtin_inff();
-  Knn5 k;
   k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = INF;
   k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
   const float cs = g.cs;
   const float eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
   const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
-  const bool active = live && g.n_pts > 0;
-  const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
   // position of the query inside its cell and the nearer-side neighbour on every axis
   const float fx = fminf(fmaxf(wx - (float)cx * cs, 0.f), cs), fy = fminf(fmaxf(wy - (float)cy * cs, 0.f), cs),
               fz = fminf(fmaxf(wz - (float)cz * cs, 0.f), cs);
   const int ox = fx < 0.5f * cs ? -1 : 1, oy = fy < 0.5f * cs ? -1 : 1, oz = fz < 0.5f * cs ? -1 : 1;
+  const float4* __restrict__ pts = src.points();
   if (active) {
     // the 8 cells of round 1 are dealt to the LPQ lanes; lookups first, then the candidate loops
     uint2 r[8 / LPQ];
     {
       int jx[8 / LPQ], jy[8 / LPQ], jz[8 / LPQ];
-      bool want[8 / LPQ];
 #pragma unroll
       for (int t = 0; t < 8 / LPQ; t++) {
         const int c = sub + LPQ * t;
         jx[t] = cx + ((c & 1) ? ox : 0); jy[t] = cy + ((c & 2) ? oy : 0); jz[t] = cz + ((c & 4) ? oz : 0);
-        want[t] = true;
       }
-      lookup_cells_batched<8 / LPQ>(g, tab, jx, jy, jz, want, r);
+      src.template lookup<8 / LPQ>(jx, jy, jz, r);
     }
 #pragma unroll
-    for (int t = 0; t < 8 / LPQ; t++) scan_range(g, r[t].x, r[t].y, wx, wy, wz, k);
+    for (int t = 0; t < 8 / LPQ; t++) scan_range(pts, g.max_d2, r[t].x, r[t].y, wx, wy, wz, k);
   }
   knn_group_merge_n<LPQ, false>(k);
   const float g0 = fminf(fminf(fmaxf(fx, cs - fx), fmaxf(fy, cs - fy)), fmaxf(fz, cs - fz)) - 2.f * eps;
@@ -599,8 +637,8 @@ __global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffe
         if (in_r1) continue;
         const float gx = axis_gap(wx, cx + dx, cs, eps), gy = axis_gap(wy, cy + dy, cs, eps), gz = axis_gap(wz, cz + dz, cs, eps);
         if (gx * gx + gy * gy + gz * gz > bound) continue;
-        const uint2 r = lookup_cell(g, tab, cx + dx, cy + dy, cz + dz);
-        scan_range(g, r.x, r.y, wx, wy, wz, k);
+        const uint2 r = src.lookup1(cx + dx, cy + dy, cz + dz);
+        scan_range(pts, g.max_d2, r.x, r.y, wx, wy, wz, k);
       }
     }
     // round-2 lists start from the shared round-1 list: merge with duplicate suppression
@@ -612,42 +650,233 @@ __global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffe
   k.i4 = __shfl(k.i4, leader);
   const float mfrac = fmaxf(fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz)), 0.f);
   const float guard = cs + mfrac - 2.f * eps;
-  const bool need = active && !(fminf(k.d4, g.max_d2) <= guard * guard);
-  if (live) {
-    const int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
-    if (LPQ == 8) {
-      if (sub < 5) {
-        const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : (sub == 3 ? k.i3 : k.i4)));
-        const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : (sub == 3 ? k.d3 : k.d4)));
-        float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
-        v.w = dd;
-        rb.nbr[(size_t)sub * rb.cap + qi] = v;
-      } else if (sub == 5) {
-        rb.nbr_count[qi] = found | (need ? kNeedy : 0);
-      } else if (sub == 6) {
-        rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-      }
-    } else {
-      {
-        const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : k.i3));
-        const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : k.d3));
-        float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
-        v.w = dd;
-        rb.nbr[(size_t)sub * rb.cap + qi] = v;
-      }
-      if (sub == 0) {
-        float4 v = k.i4 >= 0 ? g.pts[k.i4] : make_float4(0, 0, 0, 0);
-        v.w = k.d4;
-        rb.nbr[(size_t)4 * rb.cap + qi] = v;
-      } else if (sub == 1) {
-        rb.nbr_count[qi] = found | (need ? kNeedy : 0);
-      } else if (sub == 2) {
-        rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-      }
+  need = active && !(fminf(k.d4, g.max_d2) <= guard * guard);
+}
+
+// The group's lanes store the five neighbours (coordinates from `pts`, w = d2), the count (+ kNeedy) and the world point.
+template <int LPQ>
+__device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const float4* __restrict__ pts, int qi, int sub, const Knn5& k,
+                                          bool need, float wx, float wy, float wz) {
+  const int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
+  if (LPQ == 8) {
+    if (sub < 5) {
+      const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : (sub == 3 ? k.i3 : k.i4)));
+      const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : (sub == 3 ? k.d3 : k.d4)));
+      float4 v = idx >= 0 ? pts[idx] : make_float4(0, 0, 0, 0);
+      v.w = dd;
+      rb.nbr[(size_t)sub * rb.cap + qi] = v;
+    } else if (sub == 5) {
+      rb.nbr_count[qi] = found | (need ? kNeedy : 0);
+    } else if (sub == 6) {
+      rb.world[qi] = make_float4(wx, wy, wz, 0.f);
+    }
+  } else {
+    {
+      const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : k.i3));
+      const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : k.d3));
+      float4 v = idx >= 0 ? pts[idx] : make_float4(0, 0, 0, 0);
+      v.w = dd;
+      rb.nbr[(size_t)sub * rb.cap + qi] = v;
+    }
+    if (sub == 0) {
+      float4 v = k.i4 >= 0 ? pts[k.i4] : make_float4(0, 0, 0, 0);
+      v.w = k.d4;
+      rb.nbr[(size_t)4 * rb.cap + qi] = v;
+    } else if (sub == 1) {
+      rb.nbr_count[qi] = found | (need ? kNeedy : 0);
+    } else if (sub == 2) {
+      rb.world[qi] = make_float4(wx, wy, wz, 0.f);
     }
   }
 }
 
+// `forced` 1: host-driven pass at the pose `ps_val` (always runs).  forced 2: always runs, pose read from `pose` (device).
+// forced < 0: device-driven loop — pose from `pose` (the control block), runs only when the control block says the next pass
+// searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).  An executed pass leaves its pose in
+// `search_pose_out` (may be null).  A query whose 3x3x3 block cannot prove its list complete is flagged in nbr_count
+// (kNeedy); k_fit_reduce / k_knn_complete finishes it.
+template <int LPQ, int BS>
+__global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffers rb, PoseArg ps_val,
+                                                   const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
+                                                   int forced, int nb_real, double* __restrict__ search_pose_out) {
+  // the pose sits in the control block: its load goes out together with the flags instead of after the branch on them
+  // (one dependent round trip less at the head of every launch, executed or not)
+  const PoseArg ps = forced != 1 ? *pose : ps_val;
+  int lo, n_live;
+  shard_range(rb, lo, n_live);
+  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
+  if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
+  const int blk = xcd_remap(blockIdx.x, nb_real);
+  if (blk >= nb_real) return;
+  constexpr int QPB = BS / LPQ;
+  const int sub = threadIdx.x & (LPQ - 1);
+  const int ql = blk * QPB + threadIdx.x / LPQ;
+  const int qi = lo + ql;
+  const bool live = ql < n_live;
+  const int leader = (threadIdx.x & 63) & ~(LPQ - 1);
+  float wx = 0, wy = 0, wz = 0;
+  if (live && sub == 0) body_to_world(ps, rb.body[qi], wx, wy, wz);
+  wx = __shfl(wx, leader); wy = __shfl(wy, leader); wz = __shfl(wz, leader);
+  Knn5 k;
+  bool need;
+  const GlobalCells src{g, reinterpret_cast<const uint4*>(g.blocks)};
+  knn_search_query<LPQ>(src, g, live && g.n_pts > 0, wx, wy, wz, sub, leader, k, need);
+  if (live) knn_store<LPQ>(rb, g.pts, qi, sub, k, need, wx, wy, wz);
+}
+
+// The search pass with LDS-staged map tiles.  A workgroup takes QPB = BS / 4 consecutive queries of the down-sampled cloud,
+// which the voxel filter emits in a spatially coherent order (k_voxel_keys: Morton order of 8x8x8-voxel bricks), so their
+// 3x3x3 cell neighbourhoods overlap heavily:
+//   1. world points (pointBodyToWorld), cell coordinates, workgroup minimum (the tile's origin);
+//   2. every (query, cell) pair of the neighbourhoods goes into an LDS hash set: the distinct cells (~230 for 64 queries);
+//   3. one lane per distinct cell: block-table probe + cell entry (two dependent loads, all cells in parallel);
+//   4. block scan of the cell sizes -> tile offsets; the cells' points are copied into LDS (~660 points, coalesced per cell);
+//   5. the two search rounds of every query run entirely out of LDS (knn_search_query<TileCells>), the winners' coordinates
+//      come from LDS as well - no gather at the end.
+// A workgroup whose queries are too scattered (hash set or tile full: a chunk that straddles a depth discontinuity) searches
+// through global memory like k_knn_pruned.  Results are bit-identical to k_knn_pruned.
+template <int BS, int TCAP, int HCAP>
+__global__ __launch_bounds__(BS) void k_knn_tile(GridView g, RegistrationBuffers rb, PoseArg ps_val, const PoseArg* __restrict__ pose,
+                                                 const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
+                                                 double* __restrict__ search_pose_out, unsigned int* __restrict__ stats) {
+  constexpr int LPQ = 4, QPB = BS / LPQ;
+  constexpr int CCAP = HCAP * 3 / 4;          // distinct cells a workgroup may stage (hash load factor <= 3/4)
+  constexpr int NCT = (CCAP + BS - 1) / BS;   // cells per lane in steps 3-4
+  static_assert((HCAP & (HCAP - 1)) == 0 && TCAP <= 65535 && CCAP * 4 <= TCAP * 16, "tile geometry");
+  __shared__ unsigned int s_hkey[HCAP];
+  __shared__ unsigned int s_hval[HCAP];
+  __shared__ __align__(16) float4 s_tile[TCAP];  // steps 2-3: its head doubles as the list of distinct cells (hash slots)
+  __shared__ int s_cmin[3], s_cmax[3];
+  __shared__ unsigned int s_ncell, s_over, s_big, s_wtot[BS / 64];
+  const PoseArg ps = forced != 1 ? *pose : ps_val;
+  int lo, n_live;
+  shard_range(rb, lo, n_live);
+  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
+  if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
+  const int blk = xcd_remap(blockIdx.x, nb_real);
+  if (blk >= nb_real) return;
+  const int tid = threadIdx.x, sub = tid & (LPQ - 1);
+  const int ql = blk * QPB + tid / LPQ;
+  const int qi = lo + ql;
+  const bool live = ql < n_live;
+  const int leader = (tid & 63) & ~(LPQ - 1);
+  float wx = 0, wy = 0, wz = 0;
+  if (live && sub == 0) body_to_world(ps, rb.body[qi], wx, wy, wz);
+  wx = __shfl(wx, leader); wy = __shfl(wy, leader); wz = __shfl(wz, leader);
+  const bool active = live && g.n_pts > 0;
+  const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
+  unsigned int* s_clist = reinterpret_cast<unsigned int*>(s_tile);
+  // ---- 1. tile origin; hash set cleared
+  for (int s = tid; s < HCAP; s += BS) s_hkey[s] = kTileEmpty;
+  if (tid < 3) { s_cmin[tid] = 0x7FFFFFFF; s_cmax[tid] = -0x7FFFFFFF; }
+  if (tid == 0) { s_ncell = 0u; s_over = 0u; s_big = 0u; }
+  __syncthreads();
+  {
+    int mn[3] = {active ? cx : 0x7FFFFFFF, active ? cy : 0x7FFFFFFF, active ? cz : 0x7FFFFFFF};
+    int mx[3] = {active ? cx : -0x7FFFFFFF, active ? cy : -0x7FFFFFFF, active ? cz : -0x7FFFFFFF};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      for (int off = 32; off > 0; off >>= 1) { mn[a] = min(mn[a], __shfl_xor(mn[a], off)); mx[a] = max(mx[a], __shfl_xor(mx[a], off)); }
+      if ((tid & 63) == 0) { atomicMin(&s_cmin[a], mn[a]); atomicMax(&s_cmax[a], mx[a]); }
+    }
+  }
+  __syncthreads();
+  const int bx = s_cmin[0] - 1, by = s_cmin[1] - 1, bz = s_cmin[2] - 1;
+  // cells relative to the origin must fit 10 bits per axis (a workgroup spanning > 1000 cells is not coherent anyway)
+  bool tiled = s_cmax[0] - bx + 1 < 1024 && s_cmax[1] - by + 1 < 1024 && s_cmax[2] - bz + 1 < 1024 && s_cmin[0] != 0x7FFFFFFF;
+  if (tiled) {
+    // ---- 2. the distinct cells of the workgroup's 3x3x3 neighbourhoods
+    if (active) {
+      for (int c = sub; c < 27; c += LPQ) {
+        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+        const unsigned int key = tile_key(cx + dx - bx, cy + dy - by, cz + dz - bz);
+        unsigned int sl = tile_slot(key, HCAP - 1);
+        for (int probes = 0; probes < HCAP; probes++) {
+          const unsigned int prev = atomicCAS(&s_hkey[sl], kTileEmpty, key);
+          if (prev == kTileEmpty) {
+            const unsigned int at = atomicAdd(&s_ncell, 1u);
+            if (at < (unsigned)CCAP) s_clist[at] = sl; else s_over = 1u;
+            break;
+          }
+          if (prev == key) break;
+          if (*reinterpret_cast<volatile unsigned int*>(&s_over)) break;  // the set is full: the workgroup takes the global path
+          sl = (sl + 1) & (HCAP - 1);
+        }
+      }
+    }
+    __syncthreads();
+    tiled = s_over == 0u;
+  }
+  unsigned int c_start[NCT], c_cnt[NCT], c_slot[NCT];
+  unsigned int mine = 0;
+  if (tiled) {
+    // ---- 3. one lane per distinct cell: where its points are
+    const int ncell = (int)s_ncell;
+    const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
+    int jx[NCT], jy[NCT], jz[NCT];
+    bool want[NCT];
+    uint2 r[NCT];
+#pragma unroll
+    for (int t = 0; t < NCT; t++) {
+      const int i = tid + BS * t;
+      want[t] = i < ncell;
+      c_slot[t] = want[t] ? s_clist[i] : 0u;
+      const unsigned int key = want[t] ? s_hkey[c_slot[t]] : 0u;
+      jx[t] = bx + (int)(key & 1023u); jy[t] = by + (int)((key >> 10) & 1023u); jz[t] = bz + (int)(key >> 20);
+    }
+    lookup_cells_batched<NCT>(g, tab, jx, jy, jz, want, r);
+#pragma unroll
+    for (int t = 0; t < NCT; t++) {
+      c_start[t] = r[t].x;
+      c_cnt[t] = want[t] ? r[t].y - r[t].x : 0u;
+      if (c_cnt[t] > 0xFFFFu) s_big = 1u;
+      mine += c_cnt[t];
+    }
+    // ---- 4. tile offsets (block scan), then the copy
+    unsigned int inc = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned int o = __shfl_up(inc, off);
+      if ((tid & 63) >= off) inc += o;
+    }
+    __syncthreads();  // every lane has read its s_clist entries: the tile may be overwritten
+    if ((tid & 63) == 63) s_wtot[tid >> 6] = inc;
+    __syncthreads();
+    unsigned int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < BS / 64; w++) { if (w < (tid >> 6)) before += s_wtot[w]; total += s_wtot[w]; }
+    tiled = total <= (unsigned)TCAP && s_big == 0u;
+    if (tiled) {
+      unsigned int off = before + inc - mine;
+#pragma unroll
+      for (int t = 0; t < NCT; t++) {
+        if (tid + BS * t < ncell) s_hval[c_slot[t]] = off | (c_cnt[t] << 16);
+        for (unsigned int j = 0; j < c_cnt[t]; j += 4) {
+          const unsigned int last = c_cnt[t] - 1;
+          const float4 p0 = g.pts[c_start[t] + j], p1 = g.pts[c_start[t] + min(j + 1, last)],
+                       p2 = g.pts[c_start[t] + min(j + 2, last)], p3 = g.pts[c_start[t] + min(j + 3, last)];
+          s_tile[off + j] = p0;
+          if (j + 1 <= last) s_tile[off + j + 1] = p1;
+          if (j + 2 <= last) s_tile[off + j + 2] = p2;
+          if (j + 3 <= last) s_tile[off + j + 3] = p3;
+        }
+        off += c_cnt[t];
+      }
+    }
+    __syncthreads();
+  }
+  if (stats && tid == 0) atomicAdd(&stats[tiled ? 0 : 1], 1u);
+  Knn5 k;
+  bool need;
+  if (tiled) {  // uniform per workgroup
+    const TileCells src{s_hkey, s_hval, s_tile, (unsigned)(HCAP - 1), bx, by, bz};
+    knn_search_query<LPQ>(src, g, active, wx, wy, wz, sub, leader, k, need);
+    if (live) knn_store<LPQ>(rb, s_tile, qi, sub, k, need, wx, wy, wz);
+  } else {
+    const GlobalCells src{g, reinterpret_cast<const uint4*>(g.blocks)};
+    knn_search_query<LPQ>(src, g, active, wx, wy, wz, sub, leader, k, need);
+    if (live) knn_store<LPQ>(rb, g.pts, qi, sub, k, need, wx, wy, wz);
+  }
+}
 
 // Second stage of the search for a flagged query, run by ONE WAVEFRONT (four flagged queries of a workgroup proceed
 // concurrently): every cell that intersects the ball of radius sqrt(min(d5 of stage 1, max_d2)) is visited — looked up through
@@ -700,7 +929,7 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
       if (!(gx * gx + gy * gy + gz * gz > bound0)) {
         const unsigned local = (((unsigned)izz & 7u) << 6) | (((unsigned)iyy & 7u) << 3) | ((unsigned)ixx & 7u);
         const uint2 rr = g.cells[(size_t)id * kBlockCells + local];
-        scan_range(g, rr.x, rr.y, wx, wy, wz, k);
+        scan_range(g.pts, g.max_d2, rr.x, rr.y, wx, wy, wz, k);
       }
     }
   }
@@ -788,6 +1017,53 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
 // Plane fit + residual + Jacobian + block reduction, one lane per point.  FIT = right after a search pass (finishes
 // the flagged searches of this workgroup's points, reads the 5 neighbours, caches the plane); !FIT for the
 // non-search iterations.  `forced` as in k_knn_pruned.
+// Completion of the flagged searches among the kBlock points [first, first + kBlock) of one workgroup: one wavefront per
+// flagged query, four at a time (they are rare, ~0.07 % of the queries, but clustered at the map frontier).  Every lane of
+// the workgroup must call it; on return the completed lists are visible to the whole workgroup.
+__device__ __forceinline__ void complete_flagged(const GridView& g, const RegistrationBuffers& rb, int first, bool live, int* s_needy,
+                                                 int* s_nneedy) {
+  if (threadIdx.x == 0) *s_nneedy = 0;
+  __syncthreads();
+  if (live && (rb.nbr_count[first + threadIdx.x] & kNeedy)) s_needy[atomicAdd(s_nneedy, 1)] = threadIdx.x;
+  __syncthreads();
+#ifdef LII_DIAG_SKIP_NEEDY  // diagnostic build only: how much of the search-pass fit kernel is the completion of flagged searches
+  const int nn = 0;
+#else
+  const int nn = *s_nneedy;
+#endif
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int e = wave; e < nn; e += kBlock / 64) {
+    const int qi = first + s_needy[e];
+    const float4 w4 = rb.world[qi];
+    const int c0 = rb.nbr_count[qi] & 0xFF;
+    const float d5 = c0 == kMatch ? rb.nbr[(size_t)4 * rb.cap + qi].w : __builtin_inff();
+    float od[5];
+    int oi[5];
+    knn_fallback_wave(g, w4.x, w4.y, w4.z, d5, od, oi);
+    const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
+    const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
+    if (lane < 5) {
+      float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
+      v.w = dd;
+      rb.nbr[(size_t)lane * rb.cap + qi] = v;
+    } else if (lane == 5) {
+      rb.nbr_count[qi] = (oi[0] >= 0) + (oi[1] >= 0) + (oi[2] >= 0) + (oi[3] >= 0) + (oi[4] >= 0);
+    }
+  }
+  if (nn) __syncthreads();  // the completed lists are visible to their owners (workgroup-scope release/acquire)
+}
+
+// The completion alone, over the whole cloud (lii_map_incremental of a sharded job: the blocks of the other ranks were searched
+// by a stand-alone k-NN pass, not by a fit pass).
+__global__ __launch_bounds__(kBlock) void k_knn_complete(GridView g, RegistrationBuffers rb) {
+  __shared__ int s_needy[kBlock];
+  __shared__ int s_nneedy;
+  int lo, n_live;
+  shard_range(rb, lo, n_live);
+  const int first = lo + blockIdx.x * kBlock;
+  complete_flagged(g, rb, first, (int)(blockIdx.x * kBlock + threadIdx.x) < n_live, s_needy, &s_nneedy);
+}
+
 __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationBuffers rb, PoseArg ps_val,
                                                         const PoseArg* __restrict__ pose,
                                                         const IekfCtrl* __restrict__ ctrl, int forced, int imu_en,
@@ -797,7 +1073,8 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   __shared__ int s_nneedy;
   // (pose and point count are loaded together with the flags, not after the branch on them: see k_knn_pruned)
   const PoseArg ps = forced < 0 ? *pose : ps_val;
-  const int n_live = rb.n_dev ? *rb.n_dev : rb.n;
+  int lo, n_live;
+  shard_range(rb, lo, n_live);
   bool FIT;
   if (forced >= 0) {
     FIT = forced != 0;
@@ -807,39 +1084,9 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   }
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;  // uniform per block
-  const int i = blk * kBlock + threadIdx.x;
-  const bool live = i < n_live;
-  if (FIT) {  // uniform per workgroup
-    if (threadIdx.x == 0) s_nneedy = 0;
-    __syncthreads();
-    if (live && (rb.nbr_count[i] & kNeedy)) s_needy[atomicAdd(&s_nneedy, 1)] = threadIdx.x;
-    __syncthreads();
-#ifdef LII_DIAG_SKIP_NEEDY  // diagnostic build only: how much of the search-pass fit kernel is the completion of flagged searches
-    const int nn = 0;
-#else
-    const int nn = s_nneedy;
-#endif
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int e = wave; e < nn; e += kBlock / 64) {  // rare (~0.07 % of the queries) but clustered: four at a time, one per wavefront
-      const int qi = blk * kBlock + s_needy[e];
-      const float4 w4 = rb.world[qi];
-      const int c0 = rb.nbr_count[qi] & 0xFF;
-      const float d5 = c0 == kMatch ? rb.nbr[(size_t)4 * rb.cap + qi].w : __builtin_inff();
-      float od[5];
-      int oi[5];
-      knn_fallback_wave(g, w4.x, w4.y, w4.z, d5, od, oi);
-      const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
-      const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
-      if (lane < 5) {
-        float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
-        v.w = dd;
-        rb.nbr[(size_t)lane * rb.cap + qi] = v;
-      } else if (lane == 5) {
-        rb.nbr_count[qi] = (oi[0] >= 0) + (oi[1] >= 0) + (oi[2] >= 0) + (oi[3] >= 0) + (oi[4] >= 0);
-      }
-    }
-    if (nn) __syncthreads();  // the completed lists are visible to their owners (workgroup-scope release/acquire)
-  }
+  const int i = lo + blk * kBlock + threadIdx.x;
+  const bool live = blk * kBlock + (int)threadIdx.x < n_live;
+  if (FIT) complete_flagged(g, rb, lo + blk * kBlock, live, s_needy, &s_nneedy);  // uniform per workgroup
   RowOut o;
 #pragma unroll
   for (int c = 0; c < 12; c++) o.h[c] = 0;
@@ -890,9 +1137,13 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
 // L2 miss; one latency instead of a dependent chain of them.)
 __global__ __launch_bounds__(64) void k_reduce91(const double* __restrict__ partials, int n_blocks, int stride,
                                                   double* __restrict__ out, const IekfCtrl* __restrict__ ctrl, int forced,
-                                                  const int* __restrict__ n_dev) {
+                                                  RegistrationBuffers rb) {
   if (forced < 0 && ctrl->stop) return;
-  if (n_dev) n_blocks = max(1, (*n_dev + kBlock - 1) / kBlock);
+  if (rb.n_dev || rb.shard_world > 1) {
+    int lo, n_live;
+    shard_range(rb, lo, n_live);
+    n_blocks = max(1, (n_live + kBlock - 1) / kBlock);
+  }
   const int t = blockIdx.x, lane = threadIdx.x;
   const double* row = partials + (size_t)t * stride;
   // the partials were written by other XCDs: every load is an L2 miss.  Eight are in flight before the first add (same
@@ -1183,6 +1434,8 @@ struct VoxelArg {
   int min_b[3];
   int mul[3];
   int identity;  // PCL's int32 index-overflow guard tripped: output = input
+  int w[3];      // coherent sort key: bits of the 8-voxel brick coordinate per axis; coherent = 0: sort by the PCL index itself
+  int coherent;
 };
 // Derives the voxel-grid parameters from the min/max reduction ON THE DEVICE (no host round trip), in every thread of the
 // key kernel (six loads + a few flops — cheaper than a launch of its own):
@@ -1211,13 +1464,40 @@ __device__ __forceinline__ VoxelArg voxel_prepare(const unsigned int* __restrict
         div_b[a] = (int)floorf(mx[a] * v.inv_leaf) - v.min_b[a] + 1;
       }
       v.mul[0] = 1; v.mul[1] = div_b[0]; v.mul[2] = div_b[0] * div_b[1];
+      int bits = 9;
+      for (int a = 0; a < 3; a++) {
+        const int nb = div_b[a] > 1 ? 32 - __clz(div_b[a] - 1) : 0;  // bits of the largest voxel coordinate
+        v.w[a] = nb > 3 ? nb - 3 : 0;
+        bits += v.w[a];
+      }
+      // 31 bits hold every voxel of a grid PCL accepts unless the axis widths round up badly (sum of ceil(log2) > 31 while
+      // the product stays below 2^31): then the PCL index is the sort key and the cloud simply is not brick-ordered
+      v.coherent = bits <= 31 ? 1 : 0;
     }
   }
   return v;
 }
+// Sort key of a voxel that keeps space together: Morton order over 8x8x8-voxel bricks (bits interleaved z, y, x from the top,
+// an axis joining in once its width is reached), the voxel's 9 bits inside the brick below.  Injective on the voxels of the
+// grid, so the groups - and with them the centroids, bit for bit - are those of the PCL index; only the ORDER in which the
+// down-sampled cloud comes out differs: consecutive points are neighbours in space, which is what lets the search pass stage
+// map tiles in LDS for a block of queries (k_knn_tile).  The PCL order is restored by the download entry points
+// (lii_capi.cpp: pcl_order) from the PCL index kept per output point.
+__device__ __forceinline__ unsigned int coherent_key(const VoxelArg& v, int i0, int i1, int i2) {
+  const int h[3] = {i0 >> 3, i1 >> 3, i2 >> 3};
+  const int maxw = max(v.w[0], max(v.w[1], v.w[2]));
+  unsigned int m = 0;
+  for (int b = maxw - 1; b >= 0; b--) {
+#pragma unroll
+    for (int a = 2; a >= 0; a--)
+      if (b < v.w[a]) m = (m << 1) | (unsigned)((h[a] >> b) & 1);
+  }
+  return (m << 9) | (unsigned)(((i2 & 7) << 6) | ((i1 & 7) << 3) | (i0 & 7));
+}
 __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ pts, int n, const unsigned int* __restrict__ mm,
                                                     const unsigned int* __restrict__ bbox_rows, int n_rows, float leaf,
-                                                    unsigned int* __restrict__ keys, int* __restrict__ filtered,
+                                                    unsigned int* __restrict__ keys, unsigned int* __restrict__ pcl_keys,
+                                                    int coherent_order, int* __restrict__ filtered,
                                                     unsigned long long* __restrict__ samples, int sample_width) {
   __shared__ unsigned int s_mm[8];
   if (n_rows > 0) {  // the box arrives as one row per de-skew workgroup: every workgroup folds them for itself (a few KB from L2)
@@ -1237,16 +1517,18 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ p
   const VoxelArg v = voxel_prepare(mm, leaf);
   if (i == 0) *filtered = v.identity ? 0 : 1;
   float4 p = pts[i];
-  unsigned int key = 0x7FFFFFFFu;  // non-finite points sort last and are dropped
+  unsigned int key = 0x7FFFFFFFu, pcl = 0x7FFFFFFFu;  // non-finite points sort last and are dropped
   if (v.identity) {
-    key = (unsigned)i;  // every point is its own voxel, in input order
+    key = pcl = (unsigned)i;  // every point is its own voxel, in input order
   } else if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
     int i0 = (int)(floorf(p.x * v.inv_leaf) - (float)v.min_b[0]);
     int i1 = (int)(floorf(p.y * v.inv_leaf) - (float)v.min_b[1]);
     int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)v.min_b[2]);
-    key = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);
+    pcl = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);
+    key = (coherent_order && v.coherent) ? coherent_key(v, i0, i1, i2) : pcl;
   }
   keys[i] = key;
+  pcl_keys[i] = pcl;
   if (samples) {  // the sort's splitter samples (lii_vsort.hip): one jittered position per stratum of `sample_width` points
     const unsigned int j = (unsigned int)i / (unsigned int)sample_width, lo = j * (unsigned int)sample_width;
     unsigned int hsh = j * 2654435761u;
@@ -1389,35 +1671,56 @@ void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks
   if (n > 0) hipLaunchKernelGGL(k_cells_fill, dim3(nblk(n, 256)), dim3(256), 0, s, keys, ranks, n, blocks, block_mask, cells);
 }
 int register_blocks(int n) { return nblk(n, kBlock); }
+// upper bound of the points one rank registers (the exact split is taken on the device from the exact cloud size)
+static inline int shard_bound(const RegistrationBuffers& rb) {
+  return rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;
+}
 template <int LPQ, int BS>
 static void launch_knn_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                         const IekfCtrl* ctrl, int forced, hipStream_t s) {
-  int nq = nblk(rb.n, BS / LPQ);
+                         const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
+  int nq = nblk(shard_bound(rb), BS / LPQ);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_knn_pruned<LPQ, BS>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq);
+  hipLaunchKernelGGL((k_knn_pruned<LPQ, BS>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
 }
-void launch_knn8p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                  const IekfCtrl* ctrl, int forced, hipStream_t s) {
-  launch_knn_t<8, 256>(g, rb, ps, pose, ctrl, forced, s);
+template <int BS, int TCAP, int HCAP>
+static void launch_knn_tile_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                              const IekfCtrl* ctrl, int forced, double* search_pose_out, unsigned int* stats, hipStream_t s) {
+  int nq = nblk(shard_bound(rb), BS / 4);
+  if (nq < 1) nq = 1;
+  const int nq_pad = ((nq + 7) / 8) * 8;
+  hipLaunchKernelGGL((k_knn_tile<BS, TCAP, HCAP>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out, stats);
 }
-void launch_knn4p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                  const IekfCtrl* ctrl, int forced, hipStream_t s) {
-  // 128-thread workgroups: measured 29.3 us per pass against 30.3 us at 256 (shorter tail), 64 is no better.
-  launch_knn_t<4, 128>(g, rb, ps, pose, ctrl, forced, s);
+// variant: 4 / 8 = lanes per query of the global-memory search (k_knn_pruned); 64 / 65 / 32 / 128 = LDS-tiled search
+// (k_knn_tile) with 64 queries per workgroup and a 1536- / 1024-point tile, 32 queries (768 points), 128 queries (3072 points)
+void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                const IekfCtrl* ctrl, int forced, double* search_pose_out, unsigned int* stats, hipStream_t s) {
+  switch (variant) {
+    case 8: launch_knn_t<8, 256>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    // 128-thread workgroups: measured 29.3 us per pass against 30.3 us at 256 (shorter tail), 64 is no better.
+    case 4: launch_knn_t<4, 128>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 65: launch_knn_tile_t<256, 1024, 1024>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
+    case 32: launch_knn_tile_t<128, 768, 512>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
+    case 128: launch_knn_tile_t<512, 3072, 2048>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
+    default: launch_knn_tile_t<256, 1536, 1024>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
+  }
+}
+void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {
+  int nb = nblk(shard_bound(rb), kBlock);
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_knn_complete, dim3(nb), dim3(kBlock), 0, s, g, rb);
 }
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s) {
-  int nb = nblk(rb.n, kBlock);
+  int nb = nblk(shard_bound(rb), kBlock);
   if (nb < 1) nb = 1;
   const int nb_pad = ((nb + 7) / 8) * 8;
   hipLaunchKernelGGL(k_fit_reduce, dim3(nb_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, imu_en, plane_thr, rinv, nb);
 }
-void launch_reduce91(const double* partials, int n_points, int stride, double* out91, const IekfCtrl* ctrl, int forced,
-                     const int* n_dev, hipStream_t s) {
-  int nb = nblk(n_points, kBlock);
+void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s) {
+  int nb = nblk(shard_bound(rb), kBlock);
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, partials, nb, stride, out91, ctrl, forced, n_dev);
+  hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, rb.partials, nb, rb.partial_stride, out91, ctrl, forced, rb);
 }
 void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, float4* copy_to,
                         const void* ctrl_src, void* ctrl_dst, size_t ctrl_bytes, hipStream_t s) {
@@ -1448,10 +1751,11 @@ void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned in
   hipLaunchKernelGGL(k_voxel_minmax, dim3(nb), dim3(256), 0, s, pts, n, mm, mm_next);
 }
 void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows, int n_rows, float leaf,
-                       unsigned int* keys, int* filtered_dev, unsigned long long* samples, int sample_width, hipStream_t s) {
+                       unsigned int* keys, unsigned int* pcl_keys, int coherent_order, int* filtered_dev, unsigned long long* samples,
+                       int sample_width, hipStream_t s) {
   if (n > 0)
-    hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, keys, filtered_dev,
-                       samples, sample_width);
+    hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, keys, pcl_keys,
+                       coherent_order, filtered_dev, samples, sample_width);
 }
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s) {

@@ -27,16 +27,14 @@ void launch_table_clear(BlockEntry* blocks, unsigned int cap, hipStream_t s);
 void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks, int n, BlockEntry* blocks,
                        unsigned int block_mask, uint2* cells, hipStream_t s);
 // registration
-void launch_knn8p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                  const IekfCtrl* ctrl, int forced, hipStream_t s);
-void launch_knn4p(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                  const IekfCtrl* ctrl, int forced, hipStream_t s);
+void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                const IekfCtrl* ctrl, int forced, double* search_pose_out, unsigned int* stats, hipStream_t s);
+void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s);
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s);
-void launch_reduce91(const double* partials, int n_points, int stride, double* out91, const IekfCtrl* ctrl, int forced,
-                     const int* n_dev, hipStream_t s);
-void launch_reduce_solve(const double* partials, int n_points, int stride, double* out91, unsigned int* ticket, IekfCtrl* c,
-                         IekfResult* res, const int* n_dev, const MailboxView& mb, hipStream_t s);
+void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s);
+void launch_reduce_solve(const RegistrationBuffers& rb, double* out91, unsigned int* ticket, IekfCtrl* c, IekfResult* res,
+                         const MailboxView& mb, hipStream_t s);
 void launch_mailbox_allreduce(double* out91, const MailboxView& mb, hipStream_t s);
 // node-local mailbox (lii_mailbox.cpp)
 struct MailboxHost {
@@ -61,7 +59,8 @@ void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned lon
 // voxel grid
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s);
 void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows, int n_rows, float leaf,
-                       unsigned int* keys, int* filtered_dev, unsigned long long* samples, int sample_width, hipStream_t s);
+                       unsigned int* keys, unsigned int* pcl_keys, int coherent_order, int* filtered_dev, unsigned long long* samples,
+                       int sample_width, hipStream_t s);
 // calibration
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s);
@@ -75,7 +74,8 @@ void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsig
 void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
                      unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, hipStream_t s);
 void launch_alive_flags(const unsigned char* tomb, int n, unsigned int* alive, hipStream_t s);
-void launch_append_f4(const float4* src, const int* count, int n_bound, float4* dst, const int* off_a, const int* off_b, hipStream_t s);
+void launch_append_f4(const float4* src, const int* count, int n_bound, float4* dst, int dst_cap, const int* off_a, const int* off_b,
+                      hipStream_t s);
 void launch_sum3(const int* a, const int* b, const int* c, int* out, hipStream_t s);
 
 // rocPRIM wrappers (lii_sort.hip)
@@ -91,6 +91,8 @@ struct VoxelSortBuffers {
   const unsigned long long* samples;  // 4096, written by k_voxel_keys (voxel_sort_plan)
   unsigned int* hist;             // voxel_sort_hist_elems(max n), zero-initialised once
   unsigned short* bucket_of;      // n
+  const unsigned int* pcl_in;     // PCL voxel index of every input point ...
+  unsigned int* pcl_out;          // ... and of every output voxel (the order the reference's filter would emit them in)
 };
 size_t voxel_sort_hist_elems(int max_n);
 struct VoxelSortPlan { int buckets, samples, width, strata; };

@@ -237,14 +237,15 @@ __global__ void k_alive_flags(const unsigned char* __restrict__ tomb, int n, uns
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) alive[i] = tomb[i] ? 0u : 1u;
 }
-// appends src[0 .. *count) behind dst[*offset ...); counts live on the device (upper bound n for the launch)
+// appends src[0 .. *count) behind dst[*offset ...); counts live on the device (upper bound n for the launch).  Writes at or
+// beyond dst_cap are dropped: the caller learns about the overflow from the counters and reports LII_ERR_CAPACITY.
 __global__ void k_append_f4(const float4* __restrict__ src, const int* __restrict__ count, int n_bound, float4* __restrict__ dst,
-                            const int* __restrict__ off_a, const int* __restrict__ off_b) {
+                            int dst_cap, const int* __restrict__ off_a, const int* __restrict__ off_b) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = count ? *count : n_bound;
   if (i >= n_bound || i >= n) return;
-  const int off = (off_a ? *off_a : 0) + (off_b ? *off_b : 0);
-  dst[off + i] = src[i];
+  const long long at = (long long)(off_a ? *off_a : 0) + (off_b ? *off_b : 0) + i;
+  if (at < dst_cap) dst[at] = src[i];
 }
 __global__ void k_sum3(const int* a, const int* b, const int* c, int* out) {
   if (threadIdx.x == 0) *out = (a ? *a : 0) + (b ? *b : 0) + (c ? *c : 0);
@@ -270,8 +271,9 @@ void launch_add_fold(const float4* add_pts, const unsigned long long* keys, cons
 void launch_alive_flags(const unsigned char* tomb, int n, unsigned int* alive, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_alive_flags, dim3(nblk(n, 256)), dim3(256), 0, s, tomb, n, alive);
 }
-void launch_append_f4(const float4* src, const int* count, int n_bound, float4* dst, const int* off_a, const int* off_b, hipStream_t s) {
-  if (n_bound > 0) hipLaunchKernelGGL(k_append_f4, dim3(nblk(n_bound, 256)), dim3(256), 0, s, src, count, n_bound, dst, off_a, off_b);
+void launch_append_f4(const float4* src, const int* count, int n_bound, float4* dst, int dst_cap, const int* off_a, const int* off_b,
+                      hipStream_t s) {
+  if (n_bound > 0) hipLaunchKernelGGL(k_append_f4, dim3(nblk(n_bound, 256)), dim3(256), 0, s, src, count, n_bound, dst, dst_cap, off_a, off_b);
 }
 void launch_sum3(const int* a, const int* b, const int* c, int* out, hipStream_t s) {
   hipLaunchKernelGGL(k_sum3, dim3(1), dim3(64), 0, s, a, b, c, out);

@@ -1,8 +1,9 @@
-"""Point sharding of one scan across ranks: the down-sampled points of a scan are split into contiguous
-blocks, the local map is replicated, every rank evaluates its block, and ONE all-reduce (sum, fp64) of the 91
-normal-equation scalars per IEKF iteration joins them.  On GPUs the all-reduce runs inside libliinit_hip over RCCL
-(lii_comm_init); this module holds the rank-independent bookkeeping and a torch.distributed form of the same reduction
-that the CPU (gloo) tests exercise."""
+"""Point sharding of one scan across ranks: every rank voxel-filters the WHOLE scan (replicated), the
+down-sampled cloud is split into contiguous blocks, the local map is replicated, every rank evaluates its block, and ONE sum
+(fp64) of the 91 normal-equation scalars per IEKF iteration joins them.  On GPUs both the split (shard_range in
+csrc/lii_device.h - the same arithmetic as shard_bounds below) and the exchange (node-local mailbox or RCCL, lii_comm_init)
+happen inside libliinit_hip; this module is the host-side statement of the bookkeeping and a torch.distributed form of the
+reduction, exercised by the CPU (gloo) tests with the oracle standing in for the kernels."""
 from __future__ import annotations
 
 import numpy as np

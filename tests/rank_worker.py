@@ -1,8 +1,11 @@
 """One rank of a multi-rank registration job (run as a subprocess by tests/test_gpu_multirank.py).
 
 argv: rank world uid_hex transport out.npz [device]
-Every rank builds the same map, takes its contiguous block of the same scan, attaches the communicator and runs the
-iterated update through lii_iekf_update and lii_iekf_iterate; the final state, the report and the 91 sums are saved.
+Every rank builds the same map and receives the WHOLE scan (LII_WORKER_PARTITION=library, the default: the library splits the
+down-sampled cloud) or its contiguous block of it (=caller: the round-1 arrangement, no voxel filter), attaches the communicator
+and runs (a) one host-driven pass at the common start state (lii_iekf_iterate: only the summation order differs between
+worlds), (b) the whole per-scan call - de-skew, voxel filter ON, device-driven iterated update - through lii_scan_register,
+(c) map_incremental.  The final state, the report, the 91 sums and the map size after every scan are saved.
 """
 import os
 import sys
@@ -18,6 +21,9 @@ def main():
     uid, transport, out = bytes.fromhex(sys.argv[3]), sys.argv[4], sys.argv[5]
     device = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     n_scans = int(os.environ.get("LII_WORKER_SCANS", "3"))
+    caller_partition = os.environ.get("LII_WORKER_PARTITION", "library") == "caller"
+    leaf = float(os.environ.get("LII_WORKER_LEAF", "0.1"))
+    import bench
     import lidar_imu_init_amd as lii
     from harness import synth
     from harness.lo_harness import so3_exp
@@ -26,26 +32,41 @@ def main():
     map_pts = hall.surface_points(0.15, noise=0.01, seed=7)
     reg = lii.Registrar(max_scan_points=40_000, max_map_points=400_000, filter_size_map=0.15, device=device)
     reg.map_build(map_pts)
-    if world > 1:
+    if world > 1 or transport == "rccl":
         reg.comm_init(world, rank, uid, transport)
-    states, reports, sums = [], [], []
+        reg.comm_set_partition(not caller_partition)
+    states, reports, sums, map_sizes, n_down = [], [], [], [], []
     for k in range(n_scans):
         R = synth.rot_zyx(0.03, -0.02, 0.4 + 0.05 * k)
         p = np.array([0.8 + 0.1 * k, -0.6, 0.1])
         scan = synth.make_scan(hall, "vlp16", R, p, noise=0.02, seed=31 + k)
-        lo, hi = (len(scan) * rank) // world, (len(scan) * (rank + 1)) // world
+        scan = scan[np.argsort(scan[:, 3], kind="stable")]
         st = lii.State()
         st.rot_end[:] = R @ so3_exp(np.array([0.003, -0.002, 0.004]))
         st.pos_end[:] = p + np.array([0.03, -0.02, 0.01])
         prop = st.copy()
-        reg.scan_upload(scan[lo:hi])
-        reg.downsample_skip()
-        s91 = reg.iekf_iterate(st, True, True)  # at the common start state: only the summation order differs between worlds
-        rep = reg.iekf_update(st, prop, max_iterations=5, imu_en=True)
+        if caller_partition:
+            lo, hi = (len(scan) * rank) // world, (len(scan) * (rank + 1)) // world
+            reg.scan_upload(scan[lo:hi])
+            reg.downsample_skip()
+            s91 = reg.iekf_iterate(st, True, True)
+            rep = reg.iekf_update(st, prop, max_iterations=5, imu_en=True)
+            n_down.append(hi - lo)
+        else:
+            table = bench.pose_table(prop.rot_end, prop.pos_end)
+            reg.scan_upload(scan)
+            reg.undistort_imu(table, prop.rot_end, prop.pos_end, prop.offset_R_L_I, prop.offset_T_L_I)
+            nd, _ = reg.downsample(leaf)
+            n_down.append(nd)
+            s91 = reg.iekf_iterate(st, True, True)  # at the common start state
+            rep = reg.scan_register(st, prop, imu_poses=table, leaf=leaf, max_iterations=5, imu_en=True, scan_dev=reg.device_scan(scan))
+            reg.map_incremental(st)
+            map_sizes.append(reg.map_size())
         states.append(st.pod.copy())
         reports.append([rep["iterations"], rep["searches"], rep["effect_num"], int(rep["converged"])])
         sums.append(np.asarray(s91).copy())
-    np.savez(out, states=np.array(states), reports=np.array(reports), sums=np.array(sums),
+    np.savez(out, states=np.array(states), reports=np.array(reports), sums=np.array(sums), map_sizes=np.array(map_sizes),
+             n_down=np.array(n_down), map_final=reg.map_download() if not caller_partition else np.zeros((0, 3), np.float32),
              transport=reg.comm_transport())
     reg.close()
 

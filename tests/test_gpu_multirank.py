@@ -5,8 +5,13 @@ path - rendezvous in the shared segment, the exchange inside k_reduce_solve, the
 lock-step - runs here exactly as it does with one GPU per rank.  Checked:
   * both ranks end every scan with the BIT-identical state, report and sums (the sum is formed in rank order on each);
   * they agree with the single-rank run within the re-association of an fp64 sum (1e-11 relative on the sums of the
-    first pass, 1e-6 m / rad on the final pose as everywhere in this suite);
-  * a rank that never shows up turns into LII_ERR_COMM on the other (no hang).
+    first pass, 1e-6 m / rad on the final pose as everywhere in this suite) - WITH the voxel filter on: every rank hands over
+    the whole scan, the de-skew and the filter run replicated and the library splits the down-sampled cloud (SURVEY.md
+    section 8e: a voxel is never split between ranks), and map_incremental keeps the replicated maps bit-identical;
+  * the caller-partitioned arrangement (every rank hands over its own points) still works;
+  * a rank that never shows up turns into LII_ERR_COMM on the other (no hang);
+  * the RCCL transport (final sum / ncclAllReduce / solve as three launches) on a one-rank communicator - the only RCCL
+    configuration a single-GPU box can execute - reproduces the fused single-GPU loop bit for bit.
 """
 import os
 import subprocess
@@ -20,7 +25,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run_ranks(tmp_path, world, transport="auto", timeout=300):
+def _run_ranks(tmp_path, world, transport="auto", timeout=300, env=None):
     import lidar_imu_init_amd as lii
     r = lii.Registrar(max_scan_points=1024, max_map_points=1024)
     uid = r.comm_unique_id().hex()
@@ -30,7 +35,8 @@ def _run_ranks(tmp_path, world, transport="auto", timeout=300):
         out = str(tmp_path / f"w{world}_r{rank}.npz")
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "rank_worker.py"), str(rank), str(world), uid,
-                                       transport, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+                                       transport, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      env=dict(os.environ, **(env or {}))))
     logs = []
     for p in procs:
         try:
@@ -58,13 +64,40 @@ def test_two_ranks_meet_in_the_mailbox(tmp_path):
     # (a re-associated sum moves the iterate by ~1e-12, which can flip a point sitting on the plane / residual threshold in
     # a later pass: the suite-wide pose tolerance of tests/test_gpu_register.py applies, not the sum's)
     assert np.max(np.abs(one["states"][:, :12] - two[0]["states"][:, :12])) <= 1e-6
+    # the voxel filter ran on the WHOLE scan on every rank: same down-sampled cloud as the single-rank job, and after
+    # map_incremental the replicated maps are bit-identical to each other and equal to the single-rank map as a set
+    assert np.array_equal(one["n_down"], two[0]["n_down"]) and np.array_equal(two[0]["n_down"], two[1]["n_down"])
+    assert np.array_equal(two[0]["map_sizes"], two[1]["map_sizes"]) and np.array_equal(two[0]["map_final"], two[1]["map_final"])
+    assert np.all(np.abs(one["map_sizes"] - two[0]["map_sizes"]) <= 3)  # (a pose that differs by 1e-12 can flip a keep-closest tie)
 
 
 def test_three_ranks(tmp_path):
     three = _run_ranks(tmp_path, 3)
     for r in (1, 2):
-        for key in ("states", "reports", "sums"):
+        for key in ("states", "reports", "sums", "map_sizes", "map_final"):
             assert np.array_equal(three[0][key], three[r][key]), key
+
+
+def test_caller_partitioned_ranks(tmp_path):
+    """lii_comm_set_partition(0): every rank hands over its own block of an unfiltered scan (the round-1 arrangement)."""
+    env = {"LII_WORKER_PARTITION": "caller"}
+    one = _run_ranks(tmp_path, 1, env=env)[0]
+    two = _run_ranks(tmp_path, 2, env=env)
+    for key in ("states", "reports", "sums"):
+        assert np.array_equal(two[0][key], two[1][key]), key
+    assert np.max(np.abs(one["sums"] - two[0]["sums"])) <= 1e-11 * np.max(np.abs(one["sums"]))
+    assert np.max(np.abs(one["states"][:, :12] - two[0]["states"][:, :12])) <= 1e-6
+
+
+def test_rccl_transport_on_a_one_rank_communicator(tmp_path):
+    """ncclCommInitRank(1 rank) + ncclAllReduce inside the loop: the three-launch form of the update must give the fused
+    loop's result bit for bit (the all-reduce over one rank is the identity).  RCCL with N > 1 needs N devices and has not
+    been executed anywhere yet (this box has one GPU) - stated in DESIGN.md section 6."""
+    fused = _run_ranks(tmp_path, 1)[0]
+    rccl = _run_ranks(tmp_path, 1, transport="rccl")[0]
+    assert str(rccl["transport"]) == "rccl" and str(fused["transport"]) == "none"
+    for key in ("states", "reports", "sums", "map_sizes"):
+        assert np.array_equal(fused[key], rccl[key]), key
 
 
 def test_missing_rank_is_an_error_not_a_hang(tmp_path):

@@ -38,10 +38,13 @@ def _worker(rank, world, port, q):
     st = O.state_boxplus(make_state(O, R, p), np.r_[0.004, -0.003, 0.005, 0.03, -0.02, 0.015, np.zeros(18)])
     tree = O.Tree("oracle")
     tree.build(map_pts)  # the map is replicated on every rank
-    lo, hi = sharding.shard_bounds(len(scan), world, rank)
-    local = tree.iterate_once(scan[lo:hi], st, search=True, imu_en=True)
+    # every rank voxel-filters the WHOLE scan (replicated, so no voxel is ever split between ranks - SURVEY.md section 8e)
+    # and registers its contiguous block of the down-sampled cloud: what libliinit_hip does with a communicator attached
+    body = O.voxel_grid(scan, 0.1)[0]
+    lo, hi = sharding.shard_bounds(len(body), world, rank)
+    local = tree.iterate_once(body[lo:hi], st, search=True, imu_en=True)
     total = sharding.all_reduce_normal_equations(local["out91"])
-    full = tree.iterate_once(scan, st, search=True, imu_en=True)
+    full = tree.iterate_once(body, st, search=True, imu_en=True)
     q.put((rank, lo, hi, total, full["out91"], local["selected"].sum()))
     dist.barrier()
     dist.destroy_process_group()
