@@ -86,7 +86,8 @@ struct lii_context {
   bool extent_valid = false;  // d_extent[extent_sel] holds the time extent of d_scan (lii_scan_set_device computed it on the way)
   unsigned int* d_bbox_rows = nullptr;  // one row per de-skew workgroup: bounding box of its output points
   int bbox_rows = 0;                    // rows valid for the current d_scan (0: the voxel filter makes its own pass)
-  unsigned int *d_vkeys_a = nullptr, *d_vkeys_b = nullptr, *d_vidx_b = nullptr;
+  unsigned long long *d_vkeys_a = nullptr, *d_vkeys_b = nullptr;  // sort keys of the voxel filter (kVoxKeyBits wide)
+  unsigned int* d_vidx_b = nullptr;
   unsigned long long *d_vcomp = nullptr, *d_vsplit = nullptr;  // sample sort of the voxel filter (lii_vsort.hip)
   unsigned int* d_vhist = nullptr;
   unsigned short* d_vbucket = nullptr;
@@ -104,6 +105,9 @@ struct lii_context {
   bool have_search = false;
   int knn_variant = 64;  // search pass: 64 = LDS-tiled (k_knn_tile, default); 4 / 8 = lanes per query of the global-memory
                          // search (k_knn_pruned); 65 / 32 / 128 = other tile geometries (LII_KNN_VARIANT, an A/B knob)
+  unsigned int* d_nq_ctr = nullptr;   // queue of the flagged searches of a k-NN launch (RegistrationBuffers::nq_*)
+  float4* d_nq_entry = nullptr;
+  int* d_nq_id = nullptr;
   unsigned int* d_knn_stats = nullptr;  // [0] workgroups of k_knn_tile that searched out of LDS, [1] that took the global path
   bool knn_stats = false;               // LII_KNN_STATS=1: count them (adds one atomic per workgroup)
 
@@ -185,6 +189,9 @@ RegistrationBuffers reg_buffers(const lii_context* c) {
   rb.n = c->n_body;
   rb.n_dev = c->n_body_pending ? c->d_nbody : nullptr;
   rb.cap = c->cfg.max_scan_points;
+  rb.nq_ctr = c->d_nq_ctr;
+  rb.nq_entry = c->d_nq_entry;
+  rb.nq_id = c->d_nq_id;
   rb.shard_rank = c->rank;
   rb.shard_world = (c->n_ranks > 1 && c->library_partition) ? c->n_ranks : 1;
   return rb;
@@ -648,8 +655,12 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   h->cells_cap_blocks = std::max<size_t>(4096, M / 64);
   CK(dmalloc(&h->d_cells, h->cells_cap_blocks * 512));
   CK(dmalloc(&h->d_counter, 4));
-  CK(dmalloc(&h->d_knn_stats, 4));
-  CK(hipMemset(h->d_knn_stats, 0, 16));
+  CK(dmalloc(&h->d_nq_ctr, kNqWords));
+  CK(hipMemset(h->d_nq_ctr, 0, sizeof(unsigned int) * kNqWords));
+  CK(dmalloc(&h->d_nq_entry, N));
+  CK(dmalloc(&h->d_nq_id, N));
+  CK(dmalloc(&h->d_knn_stats, 8));
+  CK(hipMemset(h->d_knn_stats, 0, 32));
   CK(dmalloc(&h->d_tomb, M));
   CK(dmalloc(&h->d_ins, M));
   CK(dmalloc(&h->d_batch, M));
@@ -729,10 +740,19 @@ int lii_destroy(lii_handle h) {
   (void)hipSetDevice(h->device);
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->knn_stats && h->d_knn_stats) {  // LII_KNN_STATS=1: how the search workgroups of this handle split (diagnostic)
+    unsigned int st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpy(st, h->d_knn_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess) {
+      std::fprintf(stderr, "[libliinit_hip] k_knn_tile workgroups: %u searched out of LDS, %u through global memory\n", st[0], st[1]);
+      const double wg = double(st[0]) + double(st[1]) > 0 ? double(st[0]) + double(st[1]) : 1.0;
+      std::fprintf(stderr, "[libliinit_hip] k_knn_tile us per workgroup: origin %.2f, cell set %.2f, cell lookups %.2f, scan + copy %.2f, search %.2f, store %.2f\n",
+                   st[2] / wg / 100.0, st[3] / wg / 100.0, st[4] / wg / 100.0, st[5] / wg / 100.0, st[6] / wg / 100.0, st[7] / wg / 100.0);
+    }
+  }
   mailbox_close(&h->mailbox);
   if (h->d_mb_seq) (void)hipFree(h->d_mb_seq);
   void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
-                 h->d_counter, h->d_knn_stats, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
+                 h->d_counter, h->d_knn_stats, h->d_nq_ctr, h->d_nq_entry, h->d_nq_id, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
                  h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
@@ -1184,7 +1204,6 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
       const GridView g = grid_view(h);
       lii::launch_knn(h->knn_variant, g, rb, pose_of(*state), reinterpret_cast<const PoseArg*>(h->d_ctrl->search_pose), h->d_ctrl, 2, nullptr,
                       nullptr, s);
-      launch_knn_complete(g, rb, s);
     }
   }
   // decision per point on the device (world point, neighbour list of the last search), then two order-preserving compactions

@@ -6,12 +6,20 @@
 namespace lii {
 
 constexpr int kMatch = 5;          // NUM_MATCH_POINTS — reference include/common_lib.h:28
-constexpr int kNeedy = 0x100;      // nbr_count flag: the 3x3x3 search pass could not prove this list exact yet
+constexpr int kDrainWGs = 32;      // drainer workgroups appended to every search launch (finish the flagged searches)
+// RegistrationBuffers::nq_ctr, one 128-byte cache line per word: [0] queue entries, kNqDone search workgroups finished,
+// kNqDrained drainers finished, kNqGo "all search workgroups are done" (set by drainer 0); all zero between launches
+constexpr int kNqDone = 32, kNqDrained = 64, kNqGo = 96, kNqWords = 128;
 constexpr int kBlock = 256;        // 4 wavefronts of 64
 constexpr int kNormalEq = 91;      // 78 + 12 + 1
 constexpr int kCoarseShift = 3;    // coarse occupancy cell = 8 x 8 x 8 fine cells
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr int kCellBias = 1 << 20;
+// voxel-filter sort: 64-bit composites = (sort key << kVoxIdxBits) | point index.  The brick-order key of a grid PCL accepts
+// (dx dy dz < 2^31) needs at most 31 + 3 bits (every axis width rounded up to a power of two); 28 bits index 268 M points.
+constexpr int kVoxIdxBits = 28;
+constexpr int kVoxKeyBits = 36;
+constexpr unsigned long long kVoxDropKey = (1ull << kVoxKeyBits) - 1ull;
 
 // Pose the per-point kernels need: state.rot_end, pos_end, offset_R_L_I, offset_T_L_I (row-major).
 struct PoseArg {
@@ -56,6 +64,11 @@ struct RegistrationBuffers {
   int n;              // number of points, or an upper bound of it when n_dev != nullptr
   int cap;
   const int* n_dev;   // device-resident point count (set by the sync-free voxel filter), or nullptr
+  // queue of the searches the 3x3x3 pass could not prove exact (flagged): filled by the search workgroups, drained by the
+  // drainer workgroups at the end of the SAME launch (lii_kernels.hip: knn_finish_block / knn_drain)
+  unsigned int* nq_ctr;   // kNqWords counters (see above)
+  float4* nq_entry;       // (world x, y, z, 5th squared distance found so far or +inf)
+  int* nq_id;             // index of the query in the down-sampled cloud
   int shard_rank;     // points of one scan sharded across ranks: this rank registers the contiguous
   int shard_world;    // block [n * rank / world, n * (rank + 1) / world) of the down-sampled cloud; world <= 1: all of it
 };

@@ -42,10 +42,11 @@ inline void so3_exp(double v1, double v2, double v3, double thr, double* R) {
   if (n > thr) {
     double a[3] = {v1 / n, v2 / n, v3 / n};
     double K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
-    double KK[9];
-    m3_mul(K, K, KK);
+    double cK[9], KK[9];
     double s = std::sin(n), c1 = 1.0 - std::cos(n);
-    for (int e = 0; e < 9; e++) R[e] += s * K[e] + c1 * KK[e];
+    for (int e = 0; e < 9; e++) cK[e] = c1 * K[e];  // `(1.0 - cos) * K * K` = ((1 - cos) K) K (so3_math.h:73)
+    m3_mul(cK, K, KK);
+    for (int e = 0; e < 9; e++) R[e] = (R[e] + s * K[e]) + KK[e];
   }
 }
 inline void so3_log(const double* R, double* out) {

@@ -90,10 +90,11 @@ __device__ void d_so3_exp(double v1, double v2, double v3, double* R) {
   if (n > 0.00001) {
     double ax[3] = {v1 / n, v2 / n, v3 / n};
     double K[9] = {0, -ax[2], ax[1], ax[2], 0, -ax[0], -ax[1], ax[0], 0};
-    double KK[9];
-    d_m3_mul(K, K, KK);
+    double cK[9], KK[9];
     double s = sin(n), c1 = 1.0 - cos(n);
-    for (int e = 0; e < 9; e++) R[e] += s * K[e] + c1 * KK[e];
+    for (int e = 0; e < 9; e++) cK[e] = c1 * K[e];  // `(1.0 - cos) * K * K` = ((1 - cos) K) K, so3_math.h:73
+    d_m3_mul(cK, K, KK);
+    for (int e = 0; e < 9; e++) R[e] = (R[e] + s * K[e]) + KK[e];
   }
 }
 __device__ void d_so3_log(const double* R, double* out) {

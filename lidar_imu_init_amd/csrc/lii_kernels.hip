@@ -204,8 +204,8 @@ __device__ __forceinline__ void qr_solve_5x3(double (&a)[5][3], double (&x)[3]) 
     nu[c] = nd[c] = sqrt(s);
     maxn = fmax(maxn, nu[c]);
   }
-  const double th = maxn * eps / 5.0;
-  const double thr_helper = th * th;
+  const double th = maxn * eps;  // Eigen 3.3: threshold_helper = abs2(maxCoeff * epsilon) / rows
+  const double thr_helper = th * th / 5.0;
   const double downdate_thr = 1.4901161193847656e-08;  // sqrt(eps)
   int nzp = 3;
 #pragma unroll
@@ -653,11 +653,17 @@ __device__ __forceinline__ void knn_search_query(const Cells& src, const GridVie
   need = active && !(fminf(k.d4, g.max_d2) <= guard * guard);
 }
 
-// The group's lanes store the five neighbours (coordinates from `pts`, w = d2), the count (+ kNeedy) and the world point.
+// The group's lanes store the five neighbours (coordinates from `pts`, w = d2), the count and the world point.  A flagged
+// query (`need`) stores the world point only: its list and count are written by the drainer that finishes the search
+// (two writers of one address in different XCDs would race in their L2s).
 template <int LPQ>
 __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const float4* __restrict__ pts, int qi, int sub, const Knn5& k,
                                           bool need, float wx, float wy, float wz) {
   const int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
+  if (need) {
+    if (sub == 2) rb.world[qi] = make_float4(wx, wy, wz, 0.f);
+    return;
+  }
   if (LPQ == 8) {
     if (sub < 5) {
       const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : (sub == 3 ? k.i3 : k.i4)));
@@ -666,7 +672,7 @@ __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const f
       v.w = dd;
       rb.nbr[(size_t)sub * rb.cap + qi] = v;
     } else if (sub == 5) {
-      rb.nbr_count[qi] = found | (need ? kNeedy : 0);
+      rb.nbr_count[qi] = found;
     } else if (sub == 6) {
       rb.world[qi] = make_float4(wx, wy, wz, 0.f);
     }
@@ -683,9 +689,85 @@ __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const f
       v.w = k.d4;
       rb.nbr[(size_t)4 * rb.cap + qi] = v;
     } else if (sub == 1) {
-      rb.nbr_count[qi] = found | (need ? kNeedy : 0);
+      rb.nbr_count[qi] = found;
     } else if (sub == 2) {
       rb.world[qi] = make_float4(wx, wy, wz, 0.f);
+    }
+  }
+}
+
+// ---- flagged searches: queue + drainers
+// A query whose 3x3x3 block cannot prove its list complete (sparse map / map frontier: ~0.07 % of the queries, but CLUSTERED in
+// space, so in the brick-ordered cloud they sit in a handful of workgroups) is handed to the drainer workgroups that ride at
+// the end of the same launch: kDrainWGs extra workgroups with the highest block indices wait until every search workgroup has
+// finished, then finish the queued searches one wavefront per query, spread over the chip (knn_fallback_wave).  Finishing
+// them inside the plane-fit kernel, by the workgroup that owns them, cost that kernel 10 us per search pass once the cloud was
+// brick-ordered (27.8 against 17.9 us).  The queue travels through agent-scope atomic stores / loads (the writers and the
+// drainers sit in different XCDs, whose L2s are not coherent for plain accesses within a launch); the finished lists are
+// plain stores, visible to the next kernel.  The drainers are dispatched last, so they can only wait on workgroups that are
+// already resident or done, and they take 32 of the device's thousands of workgroup slots.
+__device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, float wy, float wz, float d5, float (&od)[5], int (&oi)[5]);
+
+// Every lane of a search workgroup calls this after its stores; `flag` on the leader lane of a flagged live query.
+__device__ __forceinline__ void knn_finish_block(const RegistrationBuffers& rb, bool flag, int qi, float wx, float wy, float wz, float d5) {
+  if (flag) {
+    const unsigned int at = atomicAdd(&rb.nq_ctr[0], 1u);
+    unsigned int* e = reinterpret_cast<unsigned int*>(rb.nq_entry + at);
+    __hip_atomic_store(e + 0, __float_as_uint(wx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(e + 1, __float_as_uint(wy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(e + 2, __float_as_uint(wz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(e + 3, __float_as_uint(d5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rb.nq_id + at, qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  wait_published_atomics();
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&rb.nq_ctr[kNqDone], 1u);
+}
+// Body of drainer workgroup `d` of `n_drain`; n_search = the search workgroups that will report.
+template <int BS>
+__device__ __forceinline__ void knn_drain(const GridView& g, const RegistrationBuffers& rb, unsigned int n_search, int d, int n_drain) {
+  // ONE lane of ONE drainer watches the counter the search workgroups bump, and rarely: 32 spinning readers on that cache
+  // line slowed every one of the ~3000 atomic increments down (the search pass went from 28 to 93 us).  The other drainers
+  // watch a flag on a line of its own.
+  if (threadIdx.x == 0) {
+    if (d == 0) {
+      while (__hip_atomic_load(&rb.nq_ctr[kNqDone], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_search) __builtin_amdgcn_s_sleep(48);
+      __hip_atomic_store(&rb.nq_ctr[kNqGo], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(&rb.nq_ctr[kNqGo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  __syncthreads();
+  const int n = (int)__hip_atomic_load(&rb.nq_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int e = d * (BS / 64) + wave; e < n; e += n_drain * (BS / 64)) {
+    const unsigned int* en = reinterpret_cast<const unsigned int*>(rb.nq_entry + e);
+    const float wx = __uint_as_float(__hip_atomic_load(en + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const float wy = __uint_as_float(__hip_atomic_load(en + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const float wz = __uint_as_float(__hip_atomic_load(en + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const float d5 = __uint_as_float(__hip_atomic_load(en + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const int qi = __hip_atomic_load(rb.nq_id + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float od[5];
+    int oi[5];
+    knn_fallback_wave(g, wx, wy, wz, d5, od, oi);
+    const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
+    const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
+    if (lane < 5) {
+      float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
+      v.w = dd;
+      rb.nbr[(size_t)lane * rb.cap + qi] = v;
+    } else if (lane == 5) {
+      rb.nbr_count[qi] = (oi[0] >= 0) + (oi[1] >= 0) + (oi[2] >= 0) + (oi[3] >= 0) + (oi[4] >= 0);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(&rb.nq_ctr[kNqDrained], 1u);
+    if (t == (unsigned)n_drain - 1u) {  // every drainer has read the queue: re-arm the counters for the next launch
+      __hip_atomic_store(&rb.nq_ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&rb.nq_ctr[kNqDone], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&rb.nq_ctr[kNqDrained], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&rb.nq_ctr[kNqGo], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -693,8 +775,7 @@ __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const f
 // `forced` 1: host-driven pass at the pose `ps_val` (always runs).  forced 2: always runs, pose read from `pose` (device).
 // forced < 0: device-driven loop — pose from `pose` (the control block), runs only when the control block says the next pass
 // searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).  An executed pass leaves its pose in
-// `search_pose_out` (may be null).  A query whose 3x3x3 block cannot prove its list complete is flagged in nbr_count
-// (kNeedy); k_fit_reduce / k_knn_complete finishes it.
+// `search_pose_out` (may be null).  The grid is n_pad search workgroups (of which nb_real have queries) + kDrainWGs drainers.
 template <int LPQ, int BS>
 __global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffers rb, PoseArg ps_val,
                                                    const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
@@ -706,6 +787,8 @@ __global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffe
   shard_range(rb, lo, n_live);
   if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
   if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
+  const int n_pad = (int)gridDim.x - kDrainWGs;
+  if ((int)blockIdx.x >= n_pad) { knn_drain<BS>(g, rb, (unsigned)nb_real, (int)blockIdx.x - n_pad, kDrainWGs); return; }
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;
   constexpr int QPB = BS / LPQ;
@@ -722,6 +805,7 @@ __global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffe
   const GlobalCells src{g, reinterpret_cast<const uint4*>(g.blocks)};
   knn_search_query<LPQ>(src, g, live && g.n_pts > 0, wx, wy, wz, sub, leader, k, need);
   if (live) knn_store<LPQ>(rb, g.pts, qi, sub, k, need, wx, wy, wz);
+  knn_finish_block(rb, live && need && sub == 0, qi, wx, wy, wz, k.i4 >= 0 ? k.d4 : __builtin_inff());
 }
 
 // The search pass with LDS-staged map tiles.  A workgroup takes QPB = BS / 4 consecutive queries of the down-sampled cloud,
@@ -753,6 +837,8 @@ __global__ __launch_bounds__(BS) void k_knn_tile(GridView g, RegistrationBuffers
   shard_range(rb, lo, n_live);
   if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
   if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
+  const int n_pad = (int)gridDim.x - kDrainWGs;
+  if ((int)blockIdx.x >= n_pad) { knn_drain<BS>(g, rb, (unsigned)nb_real, (int)blockIdx.x - n_pad, kDrainWGs); return; }
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;
   const int tid = threadIdx.x, sub = tid & (LPQ - 1);
@@ -766,6 +852,16 @@ __global__ __launch_bounds__(BS) void k_knn_tile(GridView g, RegistrationBuffers
   const bool active = live && g.n_pts > 0;
   const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
   unsigned int* s_clist = reinterpret_cast<unsigned int*>(s_tile);
+  // LII_KNN_STATS=1: stats[2 + k] accumulates the 10 ns ticks workgroups spent in phase k (thread 0's wall clock)
+  long long t_phase = stats ? wall_clock64() : 0;
+#define LII_TILE_PHASE(k)                                                              \
+  do {                                                                                 \
+    if (stats && tid == 0) {                                                           \
+      const long long now_ = wall_clock64();                                           \
+      atomicAdd(&stats[2 + (k)], (unsigned int)(now_ - t_phase));                      \
+      t_phase = now_;                                                                  \
+    }                                                                                  \
+  } while (0)
   // ---- 1. tile origin; hash set cleared
   for (int s = tid; s < HCAP; s += BS) s_hkey[s] = kTileEmpty;
   if (tid < 3) { s_cmin[tid] = 0x7FFFFFFF; s_cmax[tid] = -0x7FFFFFFF; }
@@ -781,6 +877,7 @@ __global__ __launch_bounds__(BS) void k_knn_tile(GridView g, RegistrationBuffers
     }
   }
   __syncthreads();
+  LII_TILE_PHASE(0);
   const int bx = s_cmin[0] - 1, by = s_cmin[1] - 1, bz = s_cmin[2] - 1;
   // cells relative to the origin must fit 10 bits per axis (a workgroup spanning > 1000 cells is not coherent anyway)
   bool tiled = s_cmax[0] - bx + 1 < 1024 && s_cmax[1] - by + 1 < 1024 && s_cmax[2] - bz + 1 < 1024 && s_cmin[0] != 0x7FFFFFFF;
@@ -807,6 +904,7 @@ __global__ __launch_bounds__(BS) void k_knn_tile(GridView g, RegistrationBuffers
     __syncthreads();
     tiled = s_over == 0u;
   }
+  LII_TILE_PHASE(1);
   unsigned int c_start[NCT], c_cnt[NCT], c_slot[NCT];
   unsigned int mine = 0;
   if (tiled) {
@@ -832,6 +930,7 @@ __global__ __launch_bounds__(BS) void k_knn_tile(GridView g, RegistrationBuffers
       if (c_cnt[t] > 0xFFFFu) s_big = 1u;
       mine += c_cnt[t];
     }
+    LII_TILE_PHASE(2);
     // ---- 4. tile offsets (block scan), then the copy
     unsigned int inc = mine;
     for (int off = 1; off < 64; off <<= 1) {
@@ -846,18 +945,43 @@ __global__ __launch_bounds__(BS) void k_knn_tile(GridView g, RegistrationBuffers
     for (int w = 0; w < BS / 64; w++) { if (w < (tid >> 6)) before += s_wtot[w]; total += s_wtot[w]; }
     tiled = total <= (unsigned)TCAP && s_big == 0u;
     if (tiled) {
-      unsigned int off = before + inc - mine;
+      // The copy is cooperative per wavefront: in round t the 64 lanes own up to 64 cells (~a third of them occupied, ~9 points
+      // each); point q of the round's W points belongs to the lane whose inclusive prefix first exceeds q (a 6-step search by
+      // shuffle), so every lane moves W / 64 points and all of its loads are in flight together - instead of one lane walking
+      // its cell alone, a dependent global round trip per four points.
+      unsigned int off = before + inc - mine;  // tile offset of this lane's first cell
+      const int lane = tid & 63;
 #pragma unroll
       for (int t = 0; t < NCT; t++) {
         if (tid + BS * t < ncell) s_hval[c_slot[t]] = off | (c_cnt[t] << 16);
-        for (unsigned int j = 0; j < c_cnt[t]; j += 4) {
-          const unsigned int last = c_cnt[t] - 1;
-          const float4 p0 = g.pts[c_start[t] + j], p1 = g.pts[c_start[t] + min(j + 1, last)],
-                       p2 = g.pts[c_start[t] + min(j + 2, last)], p3 = g.pts[c_start[t] + min(j + 3, last)];
-          s_tile[off + j] = p0;
-          if (j + 1 <= last) s_tile[off + j + 1] = p1;
-          if (j + 2 <= last) s_tile[off + j + 2] = p2;
-          if (j + 3 <= last) s_tile[off + j + 3] = p3;
+        unsigned int pre = c_cnt[t];  // inclusive prefix of the round's cell sizes over the wavefront
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned int v = __shfl_up(pre, o);
+          if (lane >= o) pre += v;
+        }
+        const unsigned int W = __shfl(pre, 63);
+        for (unsigned int q0 = 0; q0 < W; q0 += 256) {  // uniform trip count
+          float4 p[4];
+          unsigned int dst[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const unsigned int q = q0 + 64 * u + lane;
+            int pos = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+              const unsigned int v = __shfl(pre, pos + step - 1);
+              if (v <= q) pos += step;
+            }
+            pos = min(pos, 63);
+            const unsigned int o_pre = __shfl(pre, pos), o_cnt = __shfl(c_cnt[t], pos), o_start = __shfl(c_start[t], pos),
+                               o_off = __shfl(off, pos);
+            const unsigned int j = q - (o_pre - o_cnt);
+            dst[u] = q < W ? o_off + j : 0xFFFFFFFFu;
+            p[u] = q < W ? g.pts[o_start + j] : make_float4(0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (dst[u] != 0xFFFFFFFFu) s_tile[dst[u]] = p[u];
         }
         off += c_cnt[t];
       }
@@ -865,17 +989,21 @@ __global__ __launch_bounds__(BS) void k_knn_tile(GridView g, RegistrationBuffers
     __syncthreads();
   }
   if (stats && tid == 0) atomicAdd(&stats[tiled ? 0 : 1], 1u);
+  LII_TILE_PHASE(3);
   Knn5 k;
   bool need;
   if (tiled) {  // uniform per workgroup
     const TileCells src{s_hkey, s_hval, s_tile, (unsigned)(HCAP - 1), bx, by, bz};
     knn_search_query<LPQ>(src, g, active, wx, wy, wz, sub, leader, k, need);
+    LII_TILE_PHASE(4);
     if (live) knn_store<LPQ>(rb, s_tile, qi, sub, k, need, wx, wy, wz);
+    LII_TILE_PHASE(5);
   } else {
     const GlobalCells src{g, reinterpret_cast<const uint4*>(g.blocks)};
     knn_search_query<LPQ>(src, g, active, wx, wy, wz, sub, leader, k, need);
     if (live) knn_store<LPQ>(rb, g.pts, qi, sub, k, need, wx, wy, wz);
   }
+  knn_finish_block(rb, live && need && sub == 0, qi, wx, wy, wz, k.i4 >= 0 ? k.d4 : __builtin_inff());
 }
 
 // Second stage of the search for a flagged query, run by ONE WAVEFRONT (four flagged queries of a workgroup proceed
@@ -1017,60 +1145,11 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
 // Plane fit + residual + Jacobian + block reduction, one lane per point.  FIT = right after a search pass (finishes
 // the flagged searches of this workgroup's points, reads the 5 neighbours, caches the plane); !FIT for the
 // non-search iterations.  `forced` as in k_knn_pruned.
-// Completion of the flagged searches among the kBlock points [first, first + kBlock) of one workgroup: one wavefront per
-// flagged query, four at a time (they are rare, ~0.07 % of the queries, but clustered at the map frontier).  Every lane of
-// the workgroup must call it; on return the completed lists are visible to the whole workgroup.
-__device__ __forceinline__ void complete_flagged(const GridView& g, const RegistrationBuffers& rb, int first, bool live, int* s_needy,
-                                                 int* s_nneedy) {
-  if (threadIdx.x == 0) *s_nneedy = 0;
-  __syncthreads();
-  if (live && (rb.nbr_count[first + threadIdx.x] & kNeedy)) s_needy[atomicAdd(s_nneedy, 1)] = threadIdx.x;
-  __syncthreads();
-#ifdef LII_DIAG_SKIP_NEEDY  // diagnostic build only: how much of the search-pass fit kernel is the completion of flagged searches
-  const int nn = 0;
-#else
-  const int nn = *s_nneedy;
-#endif
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int e = wave; e < nn; e += kBlock / 64) {
-    const int qi = first + s_needy[e];
-    const float4 w4 = rb.world[qi];
-    const int c0 = rb.nbr_count[qi] & 0xFF;
-    const float d5 = c0 == kMatch ? rb.nbr[(size_t)4 * rb.cap + qi].w : __builtin_inff();
-    float od[5];
-    int oi[5];
-    knn_fallback_wave(g, w4.x, w4.y, w4.z, d5, od, oi);
-    const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
-    const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
-    if (lane < 5) {
-      float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
-      v.w = dd;
-      rb.nbr[(size_t)lane * rb.cap + qi] = v;
-    } else if (lane == 5) {
-      rb.nbr_count[qi] = (oi[0] >= 0) + (oi[1] >= 0) + (oi[2] >= 0) + (oi[3] >= 0) + (oi[4] >= 0);
-    }
-  }
-  if (nn) __syncthreads();  // the completed lists are visible to their owners (workgroup-scope release/acquire)
-}
-
-// The completion alone, over the whole cloud (lii_map_incremental of a sharded job: the blocks of the other ranks were searched
-// by a stand-alone k-NN pass, not by a fit pass).
-__global__ __launch_bounds__(kBlock) void k_knn_complete(GridView g, RegistrationBuffers rb) {
-  __shared__ int s_needy[kBlock];
-  __shared__ int s_nneedy;
-  int lo, n_live;
-  shard_range(rb, lo, n_live);
-  const int first = lo + blockIdx.x * kBlock;
-  complete_flagged(g, rb, first, (int)(blockIdx.x * kBlock + threadIdx.x) < n_live, s_needy, &s_nneedy);
-}
-
 __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationBuffers rb, PoseArg ps_val,
                                                         const PoseArg* __restrict__ pose,
                                                         const IekfCtrl* __restrict__ ctrl, int forced, int imu_en,
                                                         double plane_thr, double rinv, int nb_real) {
   __shared__ ReduceShared sh;
-  __shared__ int s_needy[kBlock];
-  __shared__ int s_nneedy;
   // (pose and point count are loaded together with the flags, not after the branch on them: see k_knn_pruned)
   const PoseArg ps = forced < 0 ? *pose : ps_val;
   int lo, n_live;
@@ -1086,7 +1165,6 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   if (blk >= nb_real) return;  // uniform per block
   const int i = lo + blk * kBlock + threadIdx.x;
   const bool live = blk * kBlock + (int)threadIdx.x < n_live;
-  if (FIT) complete_flagged(g, rb, lo + blk * kBlock, live, s_needy, &s_nneedy);  // uniform per workgroup
   RowOut o;
 #pragma unroll
   for (int c = 0; c < 12; c++) o.h[c] = 0;
@@ -1228,15 +1306,18 @@ __device__ __forceinline__ void exp_so3(const double w[3], double dt, double R[9
     double ax = w[0] / n, ay = w[1] / n, az = w[2] / n;
     double ang = n * dt;
     double s = sin(ang), c1 = 1.0 - cos(ang);
-    // K = skew(axis); K*K entries
+    // K = skew(axis).  The reference writes `(1.0 - cos) * K * K`, which C++ evaluates as ((1 - cos) K) K: the scalar is
+    // rounded into K before the product (so3_math.h:48-53; pinned by tests/test_oracle_math_pinned.py)
     double K[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
-    double KK[9];
+    double cK[9], KK[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) cK[e] = c1 * K[e];
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
-      for (int c = 0; c < 3; c++) KK[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+      for (int c = 0; c < 3; c++) KK[3 * r + c] = cK[3 * r] * K[c] + cK[3 * r + 1] * K[3 + c] + cK[3 * r + 2] * K[6 + c];
 #pragma unroll
-    for (int e = 0; e < 9; e++) R[e] = ((e % 4 == 0) ? 1.0 : 0.0) + s * K[e] + c1 * KK[e];
+    for (int e = 0; e < 9; e++) R[e] = ((e % 4 == 0) ? 1.0 : 0.0) + s * K[e] + KK[e];
   } else {
 #pragma unroll
     for (int e = 0; e < 9; e++) R[e] = (e % 4 == 0) ? 1.0 : 0.0;
@@ -1470,9 +1551,8 @@ __device__ __forceinline__ VoxelArg voxel_prepare(const unsigned int* __restrict
         v.w[a] = nb > 3 ? nb - 3 : 0;
         bits += v.w[a];
       }
-      // 31 bits hold every voxel of a grid PCL accepts unless the axis widths round up badly (sum of ceil(log2) > 31 while
-      // the product stays below 2^31): then the PCL index is the sort key and the cloud simply is not brick-ordered
-      v.coherent = bits <= 31 ? 1 : 0;
+      // dx dy dz < 2^31 bounds the sum of the rounded-up axis widths by 34 bits: always below the kVoxKeyBits of the sort key
+      v.coherent = bits < kVoxKeyBits ? 1 : 0;
     }
   }
   return v;
@@ -1483,20 +1563,20 @@ __device__ __forceinline__ VoxelArg voxel_prepare(const unsigned int* __restrict
 // down-sampled cloud comes out differs: consecutive points are neighbours in space, which is what lets the search pass stage
 // map tiles in LDS for a block of queries (k_knn_tile).  The PCL order is restored by the download entry points
 // (lii_capi.cpp: pcl_order) from the PCL index kept per output point.
-__device__ __forceinline__ unsigned int coherent_key(const VoxelArg& v, int i0, int i1, int i2) {
+__device__ __forceinline__ unsigned long long coherent_key(const VoxelArg& v, int i0, int i1, int i2) {
   const int h[3] = {i0 >> 3, i1 >> 3, i2 >> 3};
   const int maxw = max(v.w[0], max(v.w[1], v.w[2]));
-  unsigned int m = 0;
+  unsigned long long m = 0;
   for (int b = maxw - 1; b >= 0; b--) {
 #pragma unroll
     for (int a = 2; a >= 0; a--)
-      if (b < v.w[a]) m = (m << 1) | (unsigned)((h[a] >> b) & 1);
+      if (b < v.w[a]) m = (m << 1) | (unsigned long long)((h[a] >> b) & 1);
   }
-  return (m << 9) | (unsigned)(((i2 & 7) << 6) | ((i1 & 7) << 3) | (i0 & 7));
+  return (m << 9) | (unsigned long long)(((i2 & 7) << 6) | ((i1 & 7) << 3) | (i0 & 7));
 }
 __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ pts, int n, const unsigned int* __restrict__ mm,
                                                     const unsigned int* __restrict__ bbox_rows, int n_rows, float leaf,
-                                                    unsigned int* __restrict__ keys, unsigned int* __restrict__ pcl_keys,
+                                                    unsigned long long* __restrict__ keys, unsigned int* __restrict__ pcl_keys,
                                                     int coherent_order, int* __restrict__ filtered,
                                                     unsigned long long* __restrict__ samples, int sample_width) {
   __shared__ unsigned int s_mm[8];
@@ -1517,7 +1597,8 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ p
   const VoxelArg v = voxel_prepare(mm, leaf);
   if (i == 0) *filtered = v.identity ? 0 : 1;
   float4 p = pts[i];
-  unsigned int key = 0x7FFFFFFFu, pcl = 0x7FFFFFFFu;  // non-finite points sort last and are dropped
+  unsigned long long key = kVoxDropKey;  // non-finite points sort last and are dropped
+  unsigned int pcl = 0x7FFFFFFFu;
   if (v.identity) {
     key = pcl = (unsigned)i;  // every point is its own voxel, in input order
   } else if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
@@ -1534,7 +1615,7 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ p
     unsigned int hsh = j * 2654435761u;
     hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
     const unsigned int w = min((unsigned int)sample_width, (unsigned int)n - lo);
-    if (lo + hsh % w == (unsigned int)i) samples[j] = ((unsigned long long)key << 32) | (unsigned int)i;
+    if (lo + hsh % w == (unsigned int)i) samples[j] = (key << kVoxIdxBits) | (unsigned long long)(unsigned int)i;
   }
 }
 // ------------------------------------------------------------------------------------------------
@@ -1681,7 +1762,7 @@ static void launch_knn_t(const GridView& g, const RegistrationBuffers& rb, const
   int nq = nblk(shard_bound(rb), BS / LPQ);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_knn_pruned<LPQ, BS>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
+  hipLaunchKernelGGL((k_knn_pruned<LPQ, BS>), dim3(nq_pad + kDrainWGs), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
 }
 template <int BS, int TCAP, int HCAP>
 static void launch_knn_tile_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
@@ -1689,7 +1770,8 @@ static void launch_knn_tile_t(const GridView& g, const RegistrationBuffers& rb, 
   int nq = nblk(shard_bound(rb), BS / 4);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_knn_tile<BS, TCAP, HCAP>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out, stats);
+  hipLaunchKernelGGL((k_knn_tile<BS, TCAP, HCAP>), dim3(nq_pad + kDrainWGs), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out,
+                     stats);
 }
 // variant: 4 / 8 = lanes per query of the global-memory search (k_knn_pruned); 64 / 65 / 32 / 128 = LDS-tiled search
 // (k_knn_tile) with 64 queries per workgroup and a 1536- / 1024-point tile, 32 queries (768 points), 128 queries (3072 points)
@@ -1704,11 +1786,6 @@ void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, c
     case 128: launch_knn_tile_t<512, 3072, 2048>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
     default: launch_knn_tile_t<256, 1536, 1024>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
   }
-}
-void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {
-  int nb = nblk(shard_bound(rb), kBlock);
-  if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_knn_complete, dim3(nb), dim3(kBlock), 0, s, g, rb);
 }
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s) {
@@ -1751,8 +1828,8 @@ void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned in
   hipLaunchKernelGGL(k_voxel_minmax, dim3(nb), dim3(256), 0, s, pts, n, mm, mm_next);
 }
 void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows, int n_rows, float leaf,
-                       unsigned int* keys, unsigned int* pcl_keys, int coherent_order, int* filtered_dev, unsigned long long* samples,
-                       int sample_width, hipStream_t s) {
+                       unsigned long long* keys, unsigned int* pcl_keys, int coherent_order, int* filtered_dev,
+                       unsigned long long* samples, int sample_width, hipStream_t s) {
   if (n > 0)
     hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, keys, pcl_keys,
                        coherent_order, filtered_dev, samples, sample_width);

@@ -29,7 +29,6 @@ void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks
 // registration
 void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                 const IekfCtrl* ctrl, int forced, double* search_pose_out, unsigned int* stats, hipStream_t s);
-void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s);
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s);
 void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s);
@@ -59,8 +58,8 @@ void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned lon
 // voxel grid
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s);
 void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows, int n_rows, float leaf,
-                       unsigned int* keys, unsigned int* pcl_keys, int coherent_order, int* filtered_dev, unsigned long long* samples,
-                       int sample_width, hipStream_t s);
+                       unsigned long long* keys, unsigned int* pcl_keys, int coherent_order, int* filtered_dev,
+                       unsigned long long* samples, int sample_width, hipStream_t s);
 // calibration
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s);
@@ -84,8 +83,9 @@ void sort_pairs_u64(void* temp, size_t temp_bytes, const unsigned long long* kin
                     const unsigned int* vin, unsigned int* vout, int n, hipStream_t s);
 // back half of the voxel-grid filter (lii_vsort.hip): sample sort of the (key, index) pairs + centroids
 struct VoxelSortBuffers {
-  const unsigned int* keys_in;
-  unsigned int *keys_out, *idx_out;
+  const unsigned long long* keys_in;   // kVoxKeyBits-wide sort keys (lii_device.h)
+  unsigned long long* keys_out;
+  unsigned int* idx_out;
   unsigned long long* comp;       // n composites, bucket order
   unsigned long long* splitters;  // 2048
   const unsigned long long* samples;  // 4096, written by k_voxel_keys (voxel_sort_plan)

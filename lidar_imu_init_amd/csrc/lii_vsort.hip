@@ -35,9 +35,13 @@ constexpr int kMaxBuckets = 2048;
 constexpr int kPerLane = kMaxBuckets / 256;
 constexpr int kGroup = 4;          // consecutive buckets per local / centroid workgroup (1 once the buckets are large)
 constexpr int kLocalCap = 2048;    // composites a group keeps in LDS
-constexpr unsigned int kDropKey = 0x7FFFFFFFu;  // non-finite points (k_voxel_keys): sorted last, start no voxel
+// Sort keys are kVoxKeyBits wide (the brick-order key of k_voxel_keys needs up to 34 bits), the point index takes the low
+// kVoxIdxBits of the 64-bit composite.  kVoxDropKey = non-finite points: sorted last, start no voxel.
+constexpr u64 kDropKey = kVoxDropKey;
 
-__device__ __forceinline__ u64 composite(unsigned int key, unsigned int i) { return ((u64)key << 32) | (u64)i; }
+__device__ __forceinline__ u64 composite(u64 key, unsigned int i) { return (key << kVoxIdxBits) | (u64)i; }
+__device__ __forceinline__ u64 comp_key(u64 c) { return c >> kVoxIdxBits; }
+__device__ __forceinline__ unsigned int comp_idx(u64 c) { return (unsigned int)(c & ((1ull << kVoxIdxBits) - 1ull)); }
 
 // #{k in [k0, k1) : e[k] < x}; k0, k1 multiples of 8 (arrays are padded with ~0, which is never smaller).  Eight broadcast
 // reads are issued before the compares so the LDS latency is paid once per eight composites, not per composite.
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void k_vsort_splitters_small(const u64* __rest
 
 // ---------------------------------------------------------------------------------------------------- 2. classify
 // tot[b] is zero on entry (k_vsort_local of the previous sort clears it) and holds the bucket sizes on exit.
-__global__ __launch_bounds__(256) void k_vsort_classify(const unsigned int* __restrict__ keys, int n, int B,
+__global__ __launch_bounds__(256) void k_vsort_classify(const u64* __restrict__ keys, int n, int B,
                                                          const u64* __restrict__ splitters, int n_splitters,
                                                          unsigned short* __restrict__ bucket_of, unsigned int* tot) {
   __shared__ u64 spl[kMaxBuckets];
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256) void k_vsort_classify(const unsigned int* __re
 // ---------------------------------------------------------------------------------------------------- 3. scatter
 // Every workgroup turns the B totals into offsets itself (8 KB of loads and a block scan: cheaper than a kernel or a ticketed
 // tail doing it once); workgroup 0 leaves them in bucket_start for the kernels that follow.  cursor[b] is zero on entry.
-__global__ __launch_bounds__(256) void k_vsort_scatter(const unsigned int* __restrict__ keys, int n, int B,
+__global__ __launch_bounds__(256) void k_vsort_scatter(const u64* __restrict__ keys, int n, int B,
                                                         const unsigned short* __restrict__ bucket_of,
                                                         const unsigned int* __restrict__ tot, unsigned int* cursor,
                                                         unsigned int* __restrict__ bucket_start, u64* __restrict__ comp) {
@@ -194,12 +198,12 @@ __global__ __launch_bounds__(256) void k_vsort_scatter(const unsigned int* __res
   constexpr int E = kTile / 256;
   const int base = blockIdx.x * kTile;
   unsigned short mine[E];
-  unsigned int key[E];
+  u64 key[E];
 #pragma unroll
   for (int k = 0; k < E; k++) {  // everything this workgroup reads from global memory goes out in one round
     const int i = base + k * 256 + tid;
     mine[k] = i < n ? bucket_of[i] : (unsigned short)0xFFFF;
-    key[k] = i < n ? keys[i] : 0u;
+    key[k] = i < n ? keys[i] : 0ull;
   }
   const int per = B >= 256 ? B >> 8 : 1;  // consecutive buckets per lane in the scan
   unsigned int v[kPerLane], loc = 0;
@@ -263,12 +267,13 @@ __global__ __launch_bounds__(256) void k_vsort_scatter(const unsigned int* __res
 template <int kGroup>
 __global__ __launch_bounds__(256) void k_vsort_local(const u64* __restrict__ comp, const unsigned int* __restrict__ bucket_start,
                                                       int B, unsigned int* tot, unsigned int* cursor,
-                                                      unsigned int* __restrict__ keys_out, unsigned int* __restrict__ idx_out,
+                                                      u64* __restrict__ keys_out, unsigned int* __restrict__ idx_out,
                                                       unsigned int* __restrict__ group_count) {
   __shared__ __align__(16) u64 e[kLocalCap + 8];
   __shared__ __align__(16) u64 srt[kLocalCap];
   __shared__ unsigned int bs[kGroup + 2];  // [0] start of the bucket below the group, [1..kGroup+1] the group's boundaries
-  __shared__ unsigned int s_prev, s_count;
+  __shared__ u64 s_prev;
+  __shared__ unsigned int s_count;
   const int tid = threadIdx.x;
   const int b0 = blockIdx.x * kGroup;
   if (tid <= kGroup + 1) {
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256) void k_vsort_local(const u64* __restrict__ com
     tot[b0 + tid] = 0u;
     cursor[b0 + tid] = 0u;
   }
-  if (tid == 0) { s_prev = 0u; s_count = 0u; }
+  if (tid == 0) { s_prev = 0ull; s_count = 0u; }
   __syncthreads();
   const unsigned int s0 = bs[1];
   const int M = (int)(bs[kGroup + 1] - s0);
@@ -300,8 +305,8 @@ __global__ __launch_bounds__(256) void k_vsort_local(const u64* __restrict__ com
       __syncthreads();
       p0 = bs[0];
     }
-    unsigned int mx = 0;
-    for (unsigned int k = p0 + tid; k < s0; k += 256) mx = max(mx, (unsigned int)(comp[k] >> 32));
+    u64 mx = 0;
+    for (unsigned int k = p0 + tid; k < s0; k += 256) mx = max(mx, comp_key(comp[k]));
     if (mx) atomicMax(&s_prev, mx);
   }
   const bool in_lds = M <= kLocalCap;
@@ -323,21 +328,21 @@ __global__ __launch_bounds__(256) void k_vsort_local(const u64* __restrict__ com
       const u64 x = comp[s0 + t];
       int cnt = 0;
       for (int k = lo; k < hi; k++) cnt += comp[s0 + k] < x ? 1 : 0;
-      keys_out[s0 + lo + cnt] = (unsigned int)(x >> 32);
-      idx_out[s0 + lo + cnt] = (unsigned int)x;
+      keys_out[s0 + lo + cnt] = comp_key(x);
+      idx_out[s0 + lo + cnt] = comp_idx(x);
     }
   }
   __threadfence_block();
   __syncthreads();
   unsigned int starts = 0;
   for (int k = tid; k < M; k += 256) {
-    unsigned int key, before;
+    u64 key, before;
     if (in_lds) {
       const u64 x = srt[k];
-      key = (unsigned int)(x >> 32);
+      key = comp_key(x);
       keys_out[s0 + k] = key;
-      idx_out[s0 + k] = (unsigned int)x;
-      before = k > 0 ? (unsigned int)(srt[k - 1] >> 32) : s_prev;
+      idx_out[s0 + k] = comp_idx(x);
+      before = k > 0 ? comp_key(srt[k - 1]) : s_prev;
     } else {
       key = keys_out[s0 + k];
       before = k > 0 ? keys_out[s0 + k - 1] : s_prev;
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(256) void k_vsort_local(const u64* __restrict__ com
 }
 
 // n <= 512: one workgroup ranks the pairs straight from the keys and plays a single group
-__global__ __launch_bounds__(512) void k_vsort_small(const unsigned int* __restrict__ keys, int n, unsigned int* __restrict__ keys_out,
+__global__ __launch_bounds__(512) void k_vsort_small(const u64* __restrict__ keys, int n, u64* __restrict__ keys_out,
                                                       unsigned int* __restrict__ idx_out, unsigned int* __restrict__ bucket_start,
                                                       unsigned int* __restrict__ group_count) {
   __shared__ __align__(16) u64 e[512];
@@ -366,10 +371,10 @@ __global__ __launch_bounds__(512) void k_vsort_small(const unsigned int* __restr
   __syncthreads();
   unsigned int st = 0;
   if (tid < n) {
-    const unsigned int key = (unsigned int)(srt[tid] >> 32);
+    const u64 key = comp_key(srt[tid]);
     keys_out[tid] = key;
-    idx_out[tid] = (unsigned int)srt[tid];
-    st = (key != kDropKey && (tid == 0 || key != (unsigned int)(srt[tid - 1] >> 32))) ? 1u : 0u;
+    idx_out[tid] = comp_idx(srt[tid]);
+    st = (key != kDropKey && (tid == 0 || key != comp_key(srt[tid - 1]))) ? 1u : 0u;
   }
   for (int off = 32; off > 0; off >>= 1) st += __shfl_down(st, off);
   if ((tid & 63) == 0 && st) atomicAdd(&s_count, st);
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(512) void k_vsort_small(const unsigned int* __restr
 // order the oracle uses.  A run may continue past the end of the group (a voxel split by a splitter): the lane just keeps
 // reading the sorted arrays.
 template <int kGroup>
-__global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restrict__ pts, const unsigned int* __restrict__ keys,
+__global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restrict__ pts, const u64* __restrict__ keys,
                                                           const unsigned int* __restrict__ idx,
                                                           const unsigned int* __restrict__ bucket_start, int B, int n,
                                                           const unsigned int* __restrict__ group_count, float4* __restrict__ out,
@@ -401,10 +406,11 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restric
   if (g == (int)gridDim.x - 1 && tid == 0) *n_out = (int)(slot0 + group_count[g]);  // size of the down-sampled cloud
   for (unsigned int base = s0; base < s1; base += 256) {
     const unsigned int i = base + tid;
-    unsigned int k = 0, flag = 0, k_next = kDropKey, id0 = 0;
+    u64 k = 0, k_next = kDropKey;
+    unsigned int flag = 0, id0 = 0;
     if (i < s1) {  // everything the common case (a voxel of one point) needs, in one round of loads
       k = keys[i];
-      const unsigned int k_prev = i > 0 ? keys[i - 1] : kDropKey;
+      const u64 k_prev = i > 0 ? keys[i - 1] : kDropKey;
       if (i + 1 < (unsigned int)n) k_next = keys[i + 1];
       id0 = idx[i];
       flag = (k != kDropKey && (i == 0 || k_prev != k)) ? 1u : 0u;

@@ -466,5 +466,91 @@ def ref_ingest_livox(data, n_points, fields, n_scans, point_filter_num, blind, s
     return _unflatten(nf, out, begin, offs, cnts)
 
 
+_ref_math = None
+
+
+def ref_math_lib():
+    """The UNMODIFIED reference include/so3_math.h + include/common_lib.h (StatesGroup) built by `make -C oracle ref` against
+    oracle/ref_shim_math (None when it was never built)."""
+    global _ref_math
+    if _ref_math is None:
+        path = os.path.join(_HERE, "_ref", "libref_math.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        D = C.POINTER(C.c_double)
+        L.ref_exp1.argtypes = [D, D]
+        L.ref_exp_dt.argtypes = [D, C.c_double, D]
+        L.ref_exp3.argtypes = [C.c_double, C.c_double, C.c_double, D]
+        L.ref_log.argtypes = [D, D]
+        L.ref_rot_to_euler.argtypes = [D, D]
+        L.ref_skew.argtypes = [D, D]
+        L.ref_state_init.argtypes = [D]
+        L.ref_state_boxplus.argtypes = [D, D]
+        L.ref_state_plus.argtypes = [D, D, D]
+        L.ref_state_boxminus.argtypes = [D, D, D]
+        L.ref_set_pose6d.argtypes = [C.c_double, D, D, D, D, D, D]
+        _ref_math = L
+    return _ref_math
+
+
+class RefMath:
+    """numpy front-end of ref_math_lib(): same call shapes as the oracle's exp_so3 / exp3 / log_so3 / rot_to_euler /
+    state_init / state_boxplus / state_boxminus."""
+
+    def __init__(self):
+        self.L = ref_math_lib()
+        if self.L is None:
+            raise RuntimeError("oracle/_ref/libref_math.so is not built")
+
+    def exp_so3(self, w, dt=None):
+        R, w = np.zeros(9), _f64(w)
+        if dt is None:
+            self.L.ref_exp1(_dp(w), _dp(R))
+        else:
+            self.L.ref_exp_dt(_dp(w), C.c_double(dt), _dp(R))
+        return R.reshape(3, 3)
+
+    def exp3(self, a, b, c):
+        R = np.zeros(9)
+        self.L.ref_exp3(a, b, c, _dp(R))
+        return R.reshape(3, 3)
+
+    def log_so3(self, R):
+        out = np.zeros(3)
+        self.L.ref_log(_dp(_f64(R).reshape(-1)), _dp(out))
+        return out
+
+    def rot_to_euler(self, R):
+        out = np.zeros(3)
+        self.L.ref_rot_to_euler(_dp(_f64(R).reshape(-1)), _dp(out))
+        return out
+
+    def state_init(self):
+        s = np.zeros(STATE_DOUBLES)
+        self.L.ref_state_init(_dp(s))
+        return s
+
+    def state_boxplus(self, state, d24):
+        s = _f64(state).copy()
+        self.L.ref_state_boxplus(_dp(s), _dp(_f64(d24)))
+        return s
+
+    def state_plus(self, state, d24):
+        out = np.zeros(STATE_DOUBLES)
+        self.L.ref_state_plus(_dp(_f64(state)), _dp(_f64(d24)), _dp(out))
+        return out
+
+    def state_boxminus(self, a, b):
+        out = np.zeros(24)
+        self.L.ref_state_boxminus(_dp(_f64(a)), _dp(_f64(b)), _dp(out))
+        return out
+
+    def set_pose6d(self, t, acc, gyr, vel, pos, R):
+        out = np.zeros(22)
+        self.L.ref_set_pose6d(t, _dp(_f64(acc)), _dp(_f64(gyr)), _dp(_f64(vel)), _dp(_f64(pos)), _dp(_f64(R).reshape(-1)), _dp(out))
+        return out
+
+
 def num_procs() -> int:
     return lib().orc_num_procs()

@@ -5,8 +5,10 @@
 // of the small SO(3) / dense-matrix helpers of hku-mars/LiDAR_IMU_Init.
 //   Exp / Log / RotMtoEuler ...... reference include/so3_math.h:18-129
 //   24-state boxplus / boxminus .. reference include/common_lib.h:68-169
-// Parity status: the reference has no tests or golden vectors for these — they are
-// cross-checked against scipy.spatial.transform in tests/test_oracle_math.py.
+// Parity status: PINNED - held bit for bit to the reference's own so3_math.h / common_lib.h compiled unmodified against a
+// minimal matrix shim (oracle/ref_shim_math -> oracle/_ref/libref_math.so, tests/test_oracle_math_pinned.py), and cross-checked
+// against scipy.spatial.transform (tests/test_oracle_core.py).  Note the Rodrigues term: the reference writes
+// `(1.0 - cos) * K * K`, which C++ evaluates as ((1 - cos) K) K - the scalar is rounded into K before the product.
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -94,7 +96,7 @@ inline M3 Exp(const V3& ang) {
   double n = norm(ang);
   if (n > 0.0000001) {
     M3 K = skew(ang / n);
-    return M3::identity() + std::sin(n) * K + (1.0 - std::cos(n)) * (K * K);
+    return M3::identity() + std::sin(n) * K + ((1.0 - std::cos(n)) * K) * K;
   }
   return M3::identity();
 }
@@ -104,7 +106,7 @@ inline M3 Exp(const V3& w, double dt) {
   if (n > 0.0000001) {
     M3 K = skew(w / n);
     double r = n * dt;
-    return M3::identity() + std::sin(r) * K + (1.0 - std::cos(r)) * (K * K);
+    return M3::identity() + std::sin(r) * K + ((1.0 - std::cos(r)) * K) * K;
   }
   return M3::identity();
 }
@@ -113,7 +115,7 @@ inline M3 Exp3(double v1, double v2, double v3) {
   double n = std::sqrt(v1 * v1 + v2 * v2 + v3 * v3);
   if (n > 0.00001) {
     M3 K = skew(V3(v1 / n, v2 / n, v3 / n));
-    return M3::identity() + std::sin(n) * K + (1.0 - std::cos(n)) * (K * K);
+    return M3::identity() + std::sin(n) * K + ((1.0 - std::cos(n)) * K) * K;
   }
   return M3::identity();
 }

@@ -6,8 +6,12 @@
 // Eigen >= 3.3.4); its published algorithm (Eigen/src/QR/ColPivHouseholderQR.h, 3.3.x:
 // LAPACK-working-note-176 column-norm down-dating, Householder reflectors, solve() over
 // nonzeroPivots()) is restated here from the Eigen documentation/source structure.
-// Parity status: UNPINNED by the reference (no golden vectors); cross-checked against
-// numpy.linalg.lstsq in tests/test_oracle_plane.py to 1e-9.
+// Parity status: UNPINNED by the reference (no golden vectors, Eigen not installed here).  Cross-checked against
+// numpy.linalg.lstsq (tests/test_oracle_core.py) and against an independently written numpy implementation of the same
+// published algorithm on well-conditioned AND rank-deficient neighbourhoods - coplanar through the origin, collinear,
+// duplicated points (tests/test_oracle_plane_degenerate.py).  What cannot be derived without the library is the summation
+// order inside Eigen's dynamic-size applyHouseholderOnTheLeft (a gemv kernel): the plane coefficients agree with Eigen's to
+// rounding (~1e-15 relative), not bit for bit.
 #pragma once
 #include <cmath>
 #include <limits>
@@ -31,8 +35,10 @@ inline void colpiv_qr_solve_5x3(const double Ain[15], const double bin[5], doubl
     normsDirect[k] = normsUpdated[k] = std::sqrt(s);
     maxnorm = std::max(maxnorm, normsUpdated[k]);
   }
-  const double th = maxnorm * eps / double(R);
-  const double threshold_helper = th * th;
+  // Eigen 3.3 ColPivHouseholderQR::computeInPlace: threshold_helper = abs2(m_colNormsUpdated.maxCoeff() * epsilon) / rows
+  // (round 1 had (maxnorm eps / rows)^2 - a factor `rows` smaller; it only matters for exactly rank-deficient neighbourhoods)
+  const double th = maxnorm * eps;
+  const double threshold_helper = th * th / double(R);
   const double norm_downdate_threshold = std::sqrt(eps);
   int nonzero_pivots = C;
   double maxpivot = 0;

@@ -31,8 +31,9 @@ def _run_ranks(tmp_path, world, transport="auto", timeout=300, env=None):
     uid = r.comm_unique_id().hex()
     r.close()
     procs, outs = [], []
+    _run_ranks.calls = getattr(_run_ranks, "calls", 0) + 1
     for rank in range(world):
-        out = str(tmp_path / f"w{world}_r{rank}.npz")
+        out = str(tmp_path / f"job{_run_ranks.calls}_w{world}_r{rank}.npz")
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "rank_worker.py"), str(rank), str(world), uid,
                                        transport, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
@@ -47,7 +48,7 @@ def _run_ranks(tmp_path, world, transport="auto", timeout=300, env=None):
         logs.append(o.decode(errors="replace"))
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-3000:]
-    return [np.load(o) for o in outs]
+    return [dict(np.load(o)) for o in outs]  # (read now: the archive is opened lazily)
 
 
 def test_two_ranks_meet_in_the_mailbox(tmp_path):
@@ -58,8 +59,12 @@ def test_two_ranks_meet_in_the_mailbox(tmp_path):
         assert np.array_equal(two[0][key], two[1][key]), key
     assert np.array_equal(one["reports"][:, [0, 1, 3]], two[0]["reports"][:, [0, 1, 3]])  # iterations, searches, converged
     assert np.all(np.abs(one["reports"][:, 2] - two[0]["reports"][:, 2]) <= 2)          # effect_num (1-ulp threshold flips)
+    # sums at the common start state of the FIRST scan: same map, same cloud - only the summation order differs.  (From the
+    # second scan on the maps of the two jobs may differ in a few points: a pose that differs by 1e-12 moves a float32 world
+    # point by an ulp now and then, and map_incremental inserts it.)
     ref, got = one["sums"], two[0]["sums"]
-    assert np.max(np.abs(ref - got)) <= 1e-11 * np.max(np.abs(ref))  # sums at the common start state
+    assert np.max(np.abs(ref[0] - got[0])) <= 1e-11 * np.max(np.abs(ref[0]))
+    assert np.max(np.abs(ref - got)) <= 1e-6 * np.max(np.abs(ref))
     # lii_state: rot_end (9), pos_end (3) lead the POD
     # (a re-associated sum moves the iterate by ~1e-12, which can flip a point sitting on the plane / residual threshold in
     # a later pass: the suite-wide pose tolerance of tests/test_gpu_register.py applies, not the sum's)
