@@ -361,7 +361,7 @@ def main():
 
 
 def knn_kernel_name():
-    v = int(os.environ.get("LII_KNN_VARIANT", "64"))
+    v = int(os.environ.get("LII_KNN_VARIANT", "4"))
     if v in (4, 8):
         return f"k_knn_pruned<{v}> (exact 5-NN into the block-grid local map, {v} lanes/query, candidates from global memory)"
     return "k_knn_tile (exact 5-NN, the distinct cells of 64 brick-ordered queries staged in LDS, 4 lanes/query)"

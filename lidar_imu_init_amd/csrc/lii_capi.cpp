@@ -92,7 +92,9 @@ struct lii_context {
   unsigned int* d_vhist = nullptr;
   unsigned short* d_vbucket = nullptr;
   unsigned int *d_vpcl_in = nullptr, *d_vpcl_out = nullptr;  // PCL voxel index per input point / per output voxel
-  bool coherent_order = true;    // the voxel filter emits brick-major (Morton) order; LII_VOXEL_ORDER=pcl: the PCL index order
+  bool coherent_order = false;   // LII_VOXEL_ORDER=brick: the voxel filter emits brick-major (Morton) order instead of the PCL
+                                 // index order (what the LDS-tiled search needs; the default search gains 10 % from it, the
+                                 // completion of the flagged searches inside the fit kernel loses more: they cluster)
   bool body_reordered = false;   // d_body is in brick order: the download entry points restore the PCL order (pcl_perm)
   std::vector<int> pcl_perm;     // pcl_perm[r] = position in d_body of the r-th point in PCL order (valid while pcl_perm_valid)
   bool pcl_perm_valid = false;
@@ -103,11 +105,9 @@ struct lii_context {
   int* d_nbody = nullptr;       // [0] size of the down-sampled cloud, [1] `filtered` flag of the last voxel filter
   bool body_is_scan = false;
   bool have_search = false;
-  int knn_variant = 64;  // search pass: 64 = LDS-tiled (k_knn_tile, default); 4 / 8 = lanes per query of the global-memory
-                         // search (k_knn_pruned); 65 / 32 / 128 = other tile geometries (LII_KNN_VARIANT, an A/B knob)
-  unsigned int* d_nq_ctr = nullptr;   // queue of the flagged searches of a k-NN launch (RegistrationBuffers::nq_*)
-  float4* d_nq_entry = nullptr;
-  int* d_nq_id = nullptr;
+  int knn_variant = 4;   // search pass: 4 (default) / 8 = lanes per query of the global-memory search (k_knn_pruned);
+                         // 64 / 65 / 32 / 128 = the LDS-tiled search (k_knn_tile) in four geometries - built, measured, 2.5x
+                         // slower (profiles/r02_knn_tile_ab.md); LII_KNN_VARIANT selects, for A/B
   unsigned int* d_knn_stats = nullptr;  // [0] workgroups of k_knn_tile that searched out of LDS, [1] that took the global path
   bool knn_stats = false;               // LII_KNN_STATS=1: count them (adds one atomic per workgroup)
 
@@ -189,9 +189,6 @@ RegistrationBuffers reg_buffers(const lii_context* c) {
   rb.n = c->n_body;
   rb.n_dev = c->n_body_pending ? c->d_nbody : nullptr;
   rb.cap = c->cfg.max_scan_points;
-  rb.nq_ctr = c->d_nq_ctr;
-  rb.nq_entry = c->d_nq_entry;
-  rb.nq_id = c->d_nq_id;
   rb.shard_rank = c->rank;
   rb.shard_world = (c->n_ranks > 1 && c->library_partition) ? c->n_ranks : 1;
   return rb;
@@ -617,7 +614,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   h->cell_size = std::max(h->cell_size, std::sqrt(h->cfg.max_match_dist2) / 8.0f * 1.001f);
   if (const char* v = std::getenv("LII_KNN_VARIANT")) h->knn_variant = std::atoi(v);  // A/B knob for profiling
   if (const char* v = std::getenv("LII_KNN_STATS")) h->knn_stats = std::atoi(v) != 0;
-  if (const char* v = std::getenv("LII_VOXEL_ORDER")) h->coherent_order = std::string(v) != "pcl";
+  if (const char* v = std::getenv("LII_VOXEL_ORDER")) h->coherent_order = std::string(v) == "brick";
   if (const char* v = std::getenv("LII_HOST_SOLVE")) h->host_solve = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_SYNC_RESULT")) h->poll_result = std::atoi(v) == 0;
   h->ds = h->cfg.map_downsample_size;
@@ -655,10 +652,6 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   h->cells_cap_blocks = std::max<size_t>(4096, M / 64);
   CK(dmalloc(&h->d_cells, h->cells_cap_blocks * 512));
   CK(dmalloc(&h->d_counter, 4));
-  CK(dmalloc(&h->d_nq_ctr, kNqWords));
-  CK(hipMemset(h->d_nq_ctr, 0, sizeof(unsigned int) * kNqWords));
-  CK(dmalloc(&h->d_nq_entry, N));
-  CK(dmalloc(&h->d_nq_id, N));
   CK(dmalloc(&h->d_knn_stats, 8));
   CK(hipMemset(h->d_knn_stats, 0, 32));
   CK(dmalloc(&h->d_tomb, M));
@@ -752,7 +745,7 @@ int lii_destroy(lii_handle h) {
   mailbox_close(&h->mailbox);
   if (h->d_mb_seq) (void)hipFree(h->d_mb_seq);
   void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
-                 h->d_counter, h->d_knn_stats, h->d_nq_ctr, h->d_nq_entry, h->d_nq_id, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
+                 h->d_counter, h->d_knn_stats, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
                  h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
@@ -1204,6 +1197,7 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
       const GridView g = grid_view(h);
       lii::launch_knn(h->knn_variant, g, rb, pose_of(*state), reinterpret_cast<const PoseArg*>(h->d_ctrl->search_pose), h->d_ctrl, 2, nullptr,
                       nullptr, s);
+      launch_knn_complete(g, rb, s);
     }
   }
   // decision per point on the device (world point, neighbour list of the last search), then two order-preserving compactions

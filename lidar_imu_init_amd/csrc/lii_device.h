@@ -6,10 +6,7 @@
 namespace lii {
 
 constexpr int kMatch = 5;          // NUM_MATCH_POINTS — reference include/common_lib.h:28
-constexpr int kDrainWGs = 32;      // drainer workgroups appended to every search launch (finish the flagged searches)
-// RegistrationBuffers::nq_ctr, one 128-byte cache line per word: [0] queue entries, kNqDone search workgroups finished,
-// kNqDrained drainers finished, kNqGo "all search workgroups are done" (set by drainer 0); all zero between launches
-constexpr int kNqDone = 32, kNqDrained = 64, kNqGo = 96, kNqWords = 128;
+constexpr int kNeedy = 0x100;      // nbr_count flag: the 3x3x3 search pass could not prove this list exact yet
 constexpr int kBlock = 256;        // 4 wavefronts of 64
 constexpr int kNormalEq = 91;      // 78 + 12 + 1
 constexpr int kCoarseShift = 3;    // coarse occupancy cell = 8 x 8 x 8 fine cells
@@ -64,11 +61,6 @@ struct RegistrationBuffers {
   int n;              // number of points, or an upper bound of it when n_dev != nullptr
   int cap;
   const int* n_dev;   // device-resident point count (set by the sync-free voxel filter), or nullptr
-  // queue of the searches the 3x3x3 pass could not prove exact (flagged): filled by the search workgroups, drained by the
-  // drainer workgroups at the end of the SAME launch (lii_kernels.hip: knn_finish_block / knn_drain)
-  unsigned int* nq_ctr;   // kNqWords counters (see above)
-  float4* nq_entry;       // (world x, y, z, 5th squared distance found so far or +inf)
-  int* nq_id;             // index of the query in the down-sampled cloud
   int shard_rank;     // points of one scan sharded across ranks: this rank registers the contiguous
   int shard_world;    // block [n * rank / world, n * (rank + 1) / world) of the down-sampled cloud; world <= 1: all of it
 };
@@ -118,6 +110,32 @@ struct IekfCtrl {
 __device__ __forceinline__ void wait_published_atomics() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // compiler ordering (+ LDS) ...
   __builtin_amdgcn_s_waitcnt(0x0F70);                     // ... and vmcnt(0): the global atomics have been acknowledged
+}
+
+// Deterministic final sum of one row of the transposed partials (one value per fit workgroup) by a workgroup of BS lanes:
+// lane l adds the values l, l + BS, l + 2 BS, ... in that order (four loads in flight: the partials were written by other
+// XCDs, every load is an L2 miss), a fixed shuffle tree joins the lanes of a wavefront, the wavefront sums are added in
+// order.  k_reduce91 and k_reduce_solve share it so that the fused and the three-launch (RCCL) forms of the loop produce
+// bit-identical sums.  Returns the sum in every lane of the calling workgroup's thread 0 (other lanes: unspecified).
+template <int BS>
+__device__ __forceinline__ double final_sum_row(const double* __restrict__ row, int n_blocks, double* s_w /* [BS / 64] LDS */) {
+  const int tid = threadIdx.x;
+  double acc = 0;
+  for (int b0 = tid; b0 < n_blocks; b0 += BS * 4) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = b0 + BS * u < n_blocks ? row[b0 + BS * u] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (b0 + BS * u < n_blocks) acc += v[u];
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((tid & 63) == 0) s_w[tid >> 6] = acc;
+  __syncthreads();
+  double total = s_w[0];
+#pragma unroll
+  for (int w = 1; w < BS / 64; w++) total += s_w[w];
+  return total;
 }
 
 // Node-local exchange of the 91 normal-equation scalars between the ranks of one job.  The slots live in

@@ -106,18 +106,26 @@ __device__ void d_so3_log(const double* R, double* out) {
 }
 
 // One iteration's solve + state update + schedule.  ne = the 91 reduced normal-equation scalars of this pass.
-// Single wavefront.  Every global input is fetched in ONE parallel batch into LDS (the control block and `ne` were
-// just written by other kernels, so each dependent global read would cost a full memory round trip), the algebra runs
-// out of LDS / registers, and the results are written back once at the end.
+// ONE workgroup of kSolveThreads = 256 lanes (round 1: a single wavefront, ~11 us of serial algebra per iteration).  Every
+// global input is fetched in ONE parallel batch into LDS (the control block and `ne` were just written by other kernels, so
+// each dependent global read would cost a full memory round trip); then
+//   phase A  G (78 lanes) | boxminus: the two rotation logarithms + the vector blocks (second wavefront) - side by side
+//   phase A2 A = I + P11 G (144 lanes)
+//   phase B  the 12-step register-resident Gauss-Jordan (first wavefront - inherently serial) | u = H^T z - G vec (second)
+//   phase C  solution (24 lanes), schedule, boxplus, and on the stopping iteration K H (288 entries) and the covariance
+//            (576 entries, 12 MACs each) over all 256 lanes.
 #ifdef LII_SOLVE_TRACE
 #define LII_TS(k) do { if (threadIdx.x == 0) s_ts[k] = wall_clock64(); } while (0)
 #else
 #define LII_TS(k)
 #endif
-// The iteration that ends the loop tells the host so through the mapped result block: every store of this (single)
-// wavefront to `res` has been acknowledged before the flag goes out, so a host that sees done == seq sees the result.
+constexpr int kSolveThreads = 256;
+// The iteration that ends the loop tells the host so through the mapped result block: every lane's stores to `res` have been
+// acknowledged (system-scope fence by every lane, then the barrier) before the flag goes out, so a host that sees
+// done == seq sees the result.
 __device__ __forceinline__ void publish_done(IekfResult* res, int seq) {
   __threadfence_system();
+  __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(&res->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -128,52 +136,55 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   LII_TS(0);
   __shared__ double s_cov[N * N];  // prior covariance (row-major, stride 24)
   __shared__ double G[H * LDH];    // H^T R^-1 H
-  __shared__ double A[H * LDH];    // I + P11 G, later M
+  __shared__ double A[H * LDH];    // I + P11 G
   __shared__ double K1c[N * LDH];  // K_1[:, :12]
   __shared__ double vec[N], sol[N], s_u[H], s_KH[N * H];
   __shared__ double s_x[N * N];    // (I - K H) P before it is symmetrised (stopping iteration only)
   __shared__ double s_ne[96], s_st[36], s_prop[36];
   __shared__ int s_int[12];
-  const int lane = threadIdx.x;
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   {
     const int* ci = &c->max_it;  // max_it, imu_en, it, search_next, stop, rematch_num, converged, searches, effect_num, singular, seq
-    if (lane < 11) s_int[lane] = ci[lane];
+    if (tid < 11) s_int[tid] = ci[tid];
     // agent-scope loads: in the fused kernel these sums were written by other workgroups of the SAME launch
-    for (int e = lane; e < 91; e += 64) s_ne[e] = __hip_atomic_load(ne + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (lane < 36) { s_st[lane] = c->st[lane]; s_prop[lane] = c->prop[lane]; }
+    if (tid >= 64 && tid < 64 + 91) s_ne[tid - 64] = __hip_atomic_load(ne + (tid - 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid >= 160 && tid < 196) { s_st[tid - 160] = c->st[tid - 160]; s_prop[tid - 160] = c->prop[tid - 160]; }
     const double* cov = c->st + 36;
-#pragma unroll
-    for (int q = 0; q < 9; q++) s_cov[lane + 64 * q] = cov[lane + 64 * q];
+    for (int e = tid; e < N * N; e += kSolveThreads) s_cov[e] = cov[e];
   }
   __syncthreads();
-  if (s_int[4]) return;  // EKF_stop_flg already set: this pass is not due
+  if (s_int[4]) return;  // EKF_stop_flg already set: this pass is not due (uniform)
   LII_TS(1);
-  const int max_it = s_int[0], it = s_int[2], search_now = s_int[3], stop = s_int[4], rematch0 = s_int[5], searches0 = s_int[7];
-  if (stop) return;
+  const int max_it = s_int[0], it = s_int[2], search_now = s_int[3], rematch0 = s_int[5], searches0 = s_int[7];
   // upper-triangle index t -> (i, j), packed i * 16 + j
   static const unsigned char kTri[78] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58, 59, 68, 69, 70, 71, 72, 73, 74, 75, 85, 86, 87, 88, 89, 90, 91, 102, 103, 104, 105, 106, 107, 119, 120, 121, 122, 123, 136, 137, 138, 139, 153, 154, 155, 170, 171, 187};
-  for (int t = lane; t < 78; t += 64) {
-    const int i = kTri[t] >> 4, j = kTri[t] & 15;
-    G[i * LDH + j] = s_ne[t];
-    G[j * LDH + i] = s_ne[t];
+  // ---- phase A: G on the first 78 lanes; vec = state_propagat (-) state on the second wavefront (the two rotation logs on two
+  // lanes - same instruction stream - and the vector blocks on 18 more)
+  if (tid < 78) {
+    const int i = kTri[tid] >> 4, j = kTri[tid] & 15;
+    G[i * LDH + j] = s_ne[tid];
+    G[j * LDH + i] = s_ne[tid];
   }
-  // vec = state_propagat (-) state : the two rotation logs on two lanes (same instruction stream), the vector blocks on 18 more
-  if (lane < 2) {
-    const int o = lane * 12, so = lane * 6;  // rot_end / offset_R_L_I
-    double R[9];
-    d_m3t_mul(s_st + o, s_prop + o, R);
-    d_so3_log(R, vec + so);
-  } else if (lane >= 8 && lane < 26) {
-    const int q = lane - 8, blk = q / 3, i = q % 3;
-    const int sto = blk == 0 ? 9 : (blk == 1 ? 21 : (blk == 2 ? 24 : (blk == 3 ? 27 : (blk == 4 ? 30 : 33))));
-    const int vo = blk == 0 ? 3 : (blk == 1 ? 9 : (blk == 2 ? 12 : (blk == 3 ? 15 : (blk == 4 ? 18 : 21))));
-    vec[vo + i] = s_prop[sto + i] - s_st[sto + i];
+  if (wave == 1) {
+    if (lane < 2) {
+      const int o = lane * 12, so = lane * 6;  // rot_end / offset_R_L_I
+      double R[9];
+      d_m3t_mul(s_st + o, s_prop + o, R);
+      d_so3_log(R, vec + so);
+    } else if (lane >= 8 && lane < 26) {
+      const int q = lane - 8, blk = q / 3, i = q % 3;
+      const int sto = blk == 0 ? 9 : (blk == 1 ? 21 : (blk == 2 ? 24 : (blk == 3 ? 27 : (blk == 4 ? 30 : 33))));
+      const int vo = blk == 0 ? 3 : (blk == 1 ? 9 : (blk == 2 ? 12 : (blk == 3 ? 15 : (blk == 4 ? 18 : 21))));
+      vec[vo + i] = s_prop[sto + i] - s_st[sto + i];
+    }
   }
+  if (tid == 0) s_ok = 1;
   __syncthreads();
   LII_TS(2);
-  // A = I + P11 G
-  for (int e = lane; e < H * H; e += 64) {
-    const int i = e / H, j = e % H;
+  // ---- phase A2: A = I + P11 G
+  if (tid < H * H) {
+    const int i = tid / H, j = tid % H;
     double s = (i == j) ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 0; k < H; k++) s += s_cov[i * N + k] * G[k * LDH + j];
@@ -181,41 +192,42 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   }
   __syncthreads();
   LII_TS(3);
-  // K_1[:, :12]^T = A^-1 P[:12, :]  (A = I + P11 G;  K_1[:, :12] = P[:, :12] (I + G P11)^-1 and G, P symmetric).  Gauss-Jordan
-  // on [A | P[:12, :]]: lanes 0..11 hold the columns of A, lanes 12..35 the 24 columns of P[:12, :]; afterwards lane 12 + j
-  // holds row j of K_1[:, :12].  One elimination gives the gain directly — no inverse to store, no product — and no
-  // subtraction of nearly equal terms: the algebraically equal form [M P11 ; P21 - P21 G M P11] cancels catastrophically once
-  // the pose block of P has collapsed (1e-8) next to velocity / bias blocks of order 1, the regime of the LIO phase.
-  double col[H];
+  // ---- phase B: K_1[:, :12]^T = A^-1 P[:12, :]  (A = I + P11 G;  K_1[:, :12] = P[:, :12] (I + G P11)^-1 and G, P symmetric).
+  // Gauss-Jordan on [A | P[:12, :]]: lanes 0..11 of the first wavefront hold the columns of A, lanes 12..35 the 24 columns of
+  // P[:12, :]; afterwards lane 12 + j holds row j of K_1[:, :12].  One elimination gives the gain directly - no inverse to
+  // store, no product - and no subtraction of nearly equal terms: the algebraically equal form [M P11 ; P21 - P21 G M P11]
+  // cancels catastrophically once the pose block of P has collapsed (1e-8) next to velocity / bias blocks of order 1, the
+  // regime of the LIO phase.  Meanwhile the second wavefront forms u = H^T R^-1 z - G vec[:12] (then solution = K_1[:, :12] u
+  // + vec, the reference's K z + vec - K H vec[:12] regrouped).
+  if (wave == 0) {
+    double col[H];
 #pragma unroll
-  for (int r = 0; r < H; r++) col[r] = lane < H ? A[r * LDH + lane] : (lane < H + N ? s_cov[r * N + (lane - H)] : 0.0);
-  const bool ok = gj12(col);
-  if (!ok) {
-    if (lane == 0) { c->stop = 1; c->singular = 1; res->singular = 1; }
-    publish_done(res, c->seq);
-    return;
-  }
-  LII_TS(4);
-  if (lane >= H && lane < H + N) {
+    for (int r = 0; r < H; r++) col[r] = lane < H ? A[r * LDH + lane] : (lane < H + N ? s_cov[r * N + (lane - H)] : 0.0);
+    const bool ok = gj12(col);
+    if (!ok && lane == 0) s_ok = 0;
+    if (lane >= H && lane < H + N) {
 #pragma unroll
-    for (int r = 0; r < H; r++) K1c[(lane - H) * LDH + r] = col[r];
-  }
-  // u = H^T R^-1 z - G vec[:12]  (then solution = K_1[:, :12] u + vec, the reference's K z + vec - K H vec[:12] regrouped)
-  if (lane < H) {
+      for (int r = 0; r < H; r++) K1c[(lane - H) * LDH + r] = col[r];
+    }
+  } else if (wave == 1 && lane < H) {
     double s2 = s_ne[78 + lane];
 #pragma unroll
     for (int k = 0; k < H; k++) s2 -= G[lane * LDH + k] * vec[k];
     s_u[lane] = s2;
   }
   __syncthreads();
-  LII_TS(5);
-  LII_TS(6);
-  LII_TS(7);
-  if (lane < N) {
-    double s2 = vec[lane];
+  if (!s_ok) {  // uniform
+    if (tid == 0) { c->stop = 1; c->singular = 1; res->singular = 1; }
+    publish_done(res, s_int[10]);
+    return;
+  }
+  LII_TS(4);
+  // ---- phase C
+  if (tid < N) {
+    double s2 = vec[tid];
 #pragma unroll
-    for (int k = 0; k < H; k++) s2 += K1c[lane * LDH + k] * s_u[k];
-    sol[lane] = s2;
+    for (int k = 0; k < H; k++) s2 += K1c[tid * LDH + k] * s_u[k];
+    sol[tid] = s2;
   }
   __syncthreads();
   LII_TS(8);
@@ -226,59 +238,60 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   int rematch = rematch0, search = 0;
   if (converged || ((rematch == 0) && (it == (max_it - 2)))) { search = 1; rematch++; }
   const int do_cov = (rematch >= 2 || (it == max_it - 1));
-  // state += solution : the two rotations on two lanes, the vector blocks on 18 more
-  if (lane < 2) {
-    double E[9], Rn[9];
-    const int o = lane == 0 ? 0 : 12;  // rot_end / offset_R_L_I
-    const int so = lane == 0 ? 0 : 6;
-    d_so3_exp(sol[so], sol[so + 1], sol[so + 2], E);
-    d_m3_mul(s_st + o, E, Rn);
-    for (int e = 0; e < 9; e++) c->st[o + e] = Rn[e];
-    if (do_cov)
-      for (int e = 0; e < 9; e++) res->st[o + e] = Rn[e];
-  } else if (lane >= 8 && lane < 26) {
-    const int q = lane - 8;  // 0..17 : six 3-vectors
-    const int blk = q / 3, i = q % 3;
-    const int sto = blk == 0 ? 9 : (blk == 1 ? 21 : (blk == 2 ? 24 : (blk == 3 ? 27 : (blk == 4 ? 30 : 33))));
-    const int soo = blk == 0 ? 3 : (blk == 1 ? 9 : (blk == 2 ? 12 : (blk == 3 ? 15 : (blk == 4 ? 18 : 21))));
-    const double v = s_st[sto + i] + sol[soo + i];
-    c->st[sto + i] = v;
-    if (do_cov) res->st[sto + i] = v;
-  } else if (lane >= 32 && lane < 32 + N) {
-    c->solution[lane - 32] = sol[lane - 32];
-  }
-  if (lane == 63) {
-    c->converged = converged;
-    c->rematch_num = rematch;
-    c->search_next = search;
-    c->effect_num = (int)s_ne[90];
-    c->it = it + 1;
-    c->searches = searches0 + (search_now ? 1 : 0);
-    if (it < 16) c->search_log[it] = search_now;
-    if (do_cov) {
-      c->stop = 1;
-      res->it = it + 1;
-      res->searches = searches0 + (search_now ? 1 : 0);
-      res->effect_num = (int)s_ne[90];
-      res->converged = converged;
-      res->singular = 0;
+  // state += solution : the two rotations on two lanes of the first wavefront, the vector blocks on 18 more; on the stopping
+  // iteration the other three wavefronts start on K H = K_1[:, :12] G (needed for the covariance only) right away
+  if (wave == 0) {
+    if (lane < 2) {
+      double E[9], Rn[9];
+      const int o = lane == 0 ? 0 : 12;  // rot_end / offset_R_L_I
+      const int so = lane == 0 ? 0 : 6;
+      d_so3_exp(sol[so], sol[so + 1], sol[so + 2], E);
+      d_m3_mul(s_st + o, E, Rn);
+      for (int e = 0; e < 9; e++) c->st[o + e] = Rn[e];
+      if (do_cov)
+        for (int e = 0; e < 9; e++) res->st[o + e] = Rn[e];
+    } else if (lane >= 8 && lane < 26) {
+      const int q = lane - 8;  // 0..17 : six 3-vectors
+      const int blk = q / 3, i = q % 3;
+      const int sto = blk == 0 ? 9 : (blk == 1 ? 21 : (blk == 2 ? 24 : (blk == 3 ? 27 : (blk == 4 ? 30 : 33))));
+      const int soo = blk == 0 ? 3 : (blk == 1 ? 9 : (blk == 2 ? 12 : (blk == 3 ? 15 : (blk == 4 ? 18 : 21))));
+      const double v = s_st[sto + i] + sol[soo + i];
+      c->st[sto + i] = v;
+      if (do_cov) res->st[sto + i] = v;
+    } else if (lane >= 32 && lane < 32 + N) {
+      c->solution[lane - 32] = sol[lane - 32];
     }
-  }
-  LII_TS(9);
-  if (do_cov) {
-    // K H = K_1[:, :12] G, needed for the covariance only
-    for (int e = lane; e < N * H; e += 64) {
+    if (lane == 63) {
+      c->converged = converged;
+      c->rematch_num = rematch;
+      c->search_next = search;
+      c->effect_num = (int)s_ne[90];
+      c->it = it + 1;
+      c->searches = searches0 + (search_now ? 1 : 0);
+      if (it < 16) c->search_log[it] = search_now;
+      if (do_cov) {
+        c->stop = 1;
+        res->it = it + 1;
+        res->searches = searches0 + (search_now ? 1 : 0);
+        res->effect_num = (int)s_ne[90];
+        res->converged = converged;
+        res->singular = 0;
+      }
+    }
+  } else if (do_cov) {
+    for (int e = tid - 64; e < N * H; e += kSolveThreads - 64) {
       const int r = e / H, cc = e % H;
       double s2 = 0;
 #pragma unroll
       for (int k = 0; k < H; k++) s2 += K1c[r * LDH + k] * G[k * LDH + cc];
       s_KH[e] = s2;
     }
+  }
+  LII_TS(9);
+  if (do_cov) {  // uniform
     __syncthreads();
     // state.cov = (I - K H) cov = cov - (K H) cov[0:12, :]   (:1111-1114), all operands already in LDS
-#pragma unroll
-    for (int q = 0; q < 9; q++) {
-      const int e = lane + 64 * q;
+    for (int e = tid; e < N * N; e += kSolveThreads) {
       const int r = e / N, cc = e % N;
       double s2 = s_cov[e];
       for (int k = 0; k < H; k++) s2 -= s_KH[r * H + k] * s_cov[k * N + cc];
@@ -289,16 +302,17 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
     // (I - K H) P must not feed back into the next scan's gain (it compounds otherwise: the pose block of P grew to 0.4 within
     // 200 scans of a LIO run; the literal two-inversion algebra stays at 4e-5)
     double* covw = c->st + 36;
-#pragma unroll
-    for (int q = 0; q < 9; q++) {
-      const int e = lane + 64 * q;
+    for (int e = tid; e < N * N; e += kSolveThreads) {
       const int r = e / N, cc = e % N;
       const double v = 0.5 * (s_x[e] + s_x[cc * N + r]);
       covw[e] = v;
       res->st[36 + e] = v;
     }
-    for (int e = lane; e < 91; e += 64) res->ne[e] = s_ne[e];
-    if (lane < 16) res->search_log[lane] = (lane < it) ? c->search_log[lane] : (lane == it ? search_now : 0);
+    if (tid < 91) res->ne[tid] = s_ne[tid];
+    if (tid >= 96 && tid < 112) {
+      const int q = tid - 96;
+      res->search_log[q] = (q < it) ? c->search_log[q] : (q == it ? search_now : 0);
+    }
     publish_done(res, s_int[10]);
   }
 #ifdef LII_SOLVE_TRACE
@@ -308,36 +322,26 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
 #endif
 }
 
-__global__ __launch_bounds__(64) void k_iekf_solve(IekfCtrl* c, const double* __restrict__ ne, IekfResult* res) {
+__global__ __launch_bounds__(kSolveThreads) void k_iekf_solve(IekfCtrl* c, const double* __restrict__ ne, IekfResult* res) {
   iekf_solve_body(c, ne, res);
 }
 
-// Final reduction of the per-workgroup partials (91 workgroups, one output each, fixed summation order — the same
-// order as k_reduce91) FUSED with the solve: the workgroup that finishes last (ticket counter) runs the 24-state
-// update.  Used when no all-reduce sits between the two (single GPU); one launch less per iteration.
-__global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ partials, int n_blocks, int stride,
-                                                      double* out, unsigned int* ticket, IekfCtrl* c, IekfResult* res,
-                                                      RegistrationBuffers rb, MailboxView mb) {
+// Final reduction of the per-workgroup partials (91 workgroups, one output each, fixed summation order - the same order as
+// k_reduce91: final_sum_row in lii_device.h) FUSED with the solve: the workgroup that finishes last (ticket counter) runs the
+// 24-state update.  Used when no all-reduce sits between the two (single GPU, or the node-local mailbox); one launch less per
+// iteration.
+__global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __restrict__ partials, int n_blocks, int stride,
+                                                                 double* out, unsigned int* ticket, IekfCtrl* c, IekfResult* res,
+                                                                 RegistrationBuffers rb, MailboxView mb) {
   __shared__ int s_last;
+  __shared__ double s_w[kSolveThreads / 64];
   int lo, n_live;
   shard_range(rb, lo, n_live);  // (the device-resident cloud size is loaded together with the flag below, not after the branch on it)
   if (c->stop) return;  // read by every workgroup before its ticket; the solve (which may set it) runs after all tickets
   if (rb.n_dev || rb.shard_world > 1) n_blocks = max(1, (n_live + kBlock - 1) / kBlock);
-  const int t = blockIdx.x, lane = threadIdx.x;
-  const double* row = partials + (size_t)t * stride;
-  // the partials were written by other XCDs: every load is an L2 miss.  Eight are in flight before the first add (same
-  // order of additions as the plain loop, so the sum is bit-identical) - one latency per eight rows instead of one per row.
-  double acc = 0;
-  for (int b0 = lane; b0 < n_blocks; b0 += 64 * 8) {
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = b0 + 64 * u < n_blocks ? row[b0 + 64 * u] : 0.0;
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (b0 + 64 * u < n_blocks) acc += v[u];
-  }
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-  if (lane == 0) {
+  const int t = blockIdx.x;
+  const double acc = final_sum_row<kSolveThreads>(partials + (size_t)t * stride, n_blocks, s_w);
+  if (threadIdx.x == 0) {
     __hip_atomic_store(out + t, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wait_published_atomics();  // not __threadfence(): see lii_device.h
     const unsigned int tk = atomicAdd(ticket, 1u);
@@ -345,10 +349,16 @@ __global__ __launch_bounds__(64) void k_reduce_solve(const double* __restrict__ 
   }
   __syncthreads();
   if (!s_last) return;
-  if (lane == 0) *ticket = 0u;  // re-armed for the next launch (kernel boundary orders it)
+  if (threadIdx.x == 0) *ticket = 0u;  // re-armed for the next launch (kernel boundary orders it)
   const double* ne = out;
   if (mb.slots) {  // several ranks: this rank's sums meet the others' in the node-local mailbox, still inside this launch
-    if (!mailbox_allreduce(mb, out, out + 128)) {
+    __shared__ int s_mb_ok;
+    if (threadIdx.x < 64) {  // one wavefront runs the exchange
+      const bool ok = mailbox_allreduce(mb, out, out + 128);
+      if (threadIdx.x == 0) s_mb_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_mb_ok) {
       if (threadIdx.x == 0) { c->stop = 1; c->singular = 3; res->singular = 3; res->it = 0; }
       publish_done(res, c->seq);
       return;
@@ -372,10 +382,11 @@ void launch_reduce_solve(const RegistrationBuffers& rb, double* out91, unsigned 
                          const MailboxView& mb, hipStream_t s) {
   int nb = (rb.n + kBlock - 1) / kBlock;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq), dim3(64), 0, s, rb.partials, nb, rb.partial_stride, out91, ticket, c, res, rb, mb);
+  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq), dim3(kSolveThreads), 0, s, rb.partials, nb, rb.partial_stride, out91, ticket, c, res, rb,
+                     mb);
 }
 void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s) {
-  hipLaunchKernelGGL(k_iekf_solve, dim3(1), dim3(64), 0, s, c, ne, res);
+  hipLaunchKernelGGL(k_iekf_solve, dim3(1), dim3(kSolveThreads), 0, s, c, ne, res);
 }
 
 }  // namespace lii

@@ -653,17 +653,11 @@ __device__ __forceinline__ void knn_search_query(const Cells& src, const GridVie
   need = active && !(fminf(k.d4, g.max_d2) <= guard * guard);
 }
 
-// The group's lanes store the five neighbours (coordinates from `pts`, w = d2), the count and the world point.  A flagged
-// query (`need`) stores the world point only: its list and count are written by the drainer that finishes the search
-// (two writers of one address in different XCDs would race in their L2s).
+// The group's lanes store the five neighbours (coordinates from `pts`, w = d2), the count (+ kNeedy) and the world point.
 template <int LPQ>
 __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const float4* __restrict__ pts, int qi, int sub, const Knn5& k,
                                           bool need, float wx, float wy, float wz) {
   const int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
-  if (need) {
-    if (sub == 2) rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-    return;
-  }
   if (LPQ == 8) {
     if (sub < 5) {
       const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : (sub == 3 ? k.i3 : k.i4)));
@@ -672,7 +666,7 @@ __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const f
       v.w = dd;
       rb.nbr[(size_t)sub * rb.cap + qi] = v;
     } else if (sub == 5) {
-      rb.nbr_count[qi] = found;
+      rb.nbr_count[qi] = found | (need ? kNeedy : 0);
     } else if (sub == 6) {
       rb.world[qi] = make_float4(wx, wy, wz, 0.f);
     }
@@ -689,85 +683,9 @@ __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const f
       v.w = k.d4;
       rb.nbr[(size_t)4 * rb.cap + qi] = v;
     } else if (sub == 1) {
-      rb.nbr_count[qi] = found;
+      rb.nbr_count[qi] = found | (need ? kNeedy : 0);
     } else if (sub == 2) {
       rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-    }
-  }
-}
-
-// ---- flagged searches: queue + drainers
-// A query whose 3x3x3 block cannot prove its list complete (sparse map / map frontier: ~0.07 % of the queries, but CLUSTERED in
-// space, so in the brick-ordered cloud they sit in a handful of workgroups) is handed to the drainer workgroups that ride at
-// the end of the same launch: kDrainWGs extra workgroups with the highest block indices wait until every search workgroup has
-// finished, then finish the queued searches one wavefront per query, spread over the chip (knn_fallback_wave).  Finishing
-// them inside the plane-fit kernel, by the workgroup that owns them, cost that kernel 10 us per search pass once the cloud was
-// brick-ordered (27.8 against 17.9 us).  The queue travels through agent-scope atomic stores / loads (the writers and the
-// drainers sit in different XCDs, whose L2s are not coherent for plain accesses within a launch); the finished lists are
-// plain stores, visible to the next kernel.  The drainers are dispatched last, so they can only wait on workgroups that are
-// already resident or done, and they take 32 of the device's thousands of workgroup slots.
-__device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, float wy, float wz, float d5, float (&od)[5], int (&oi)[5]);
-
-// Every lane of a search workgroup calls this after its stores; `flag` on the leader lane of a flagged live query.
-__device__ __forceinline__ void knn_finish_block(const RegistrationBuffers& rb, bool flag, int qi, float wx, float wy, float wz, float d5) {
-  if (flag) {
-    const unsigned int at = atomicAdd(&rb.nq_ctr[0], 1u);
-    unsigned int* e = reinterpret_cast<unsigned int*>(rb.nq_entry + at);
-    __hip_atomic_store(e + 0, __float_as_uint(wx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(e + 1, __float_as_uint(wy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(e + 2, __float_as_uint(wz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(e + 3, __float_as_uint(d5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(rb.nq_id + at, qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  wait_published_atomics();
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&rb.nq_ctr[kNqDone], 1u);
-}
-// Body of drainer workgroup `d` of `n_drain`; n_search = the search workgroups that will report.
-template <int BS>
-__device__ __forceinline__ void knn_drain(const GridView& g, const RegistrationBuffers& rb, unsigned int n_search, int d, int n_drain) {
-  // ONE lane of ONE drainer watches the counter the search workgroups bump, and rarely: 32 spinning readers on that cache
-  // line slowed every one of the ~3000 atomic increments down (the search pass went from 28 to 93 us).  The other drainers
-  // watch a flag on a line of its own.
-  if (threadIdx.x == 0) {
-    if (d == 0) {
-      while (__hip_atomic_load(&rb.nq_ctr[kNqDone], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_search) __builtin_amdgcn_s_sleep(48);
-      __hip_atomic_store(&rb.nq_ctr[kNqGo], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      while (__hip_atomic_load(&rb.nq_ctr[kNqGo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(16);
-    }
-  }
-  __syncthreads();
-  const int n = (int)__hip_atomic_load(&rb.nq_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int e = d * (BS / 64) + wave; e < n; e += n_drain * (BS / 64)) {
-    const unsigned int* en = reinterpret_cast<const unsigned int*>(rb.nq_entry + e);
-    const float wx = __uint_as_float(__hip_atomic_load(en + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const float wy = __uint_as_float(__hip_atomic_load(en + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const float wz = __uint_as_float(__hip_atomic_load(en + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const float d5 = __uint_as_float(__hip_atomic_load(en + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const int qi = __hip_atomic_load(rb.nq_id + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float od[5];
-    int oi[5];
-    knn_fallback_wave(g, wx, wy, wz, d5, od, oi);
-    const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
-    const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
-    if (lane < 5) {
-      float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
-      v.w = dd;
-      rb.nbr[(size_t)lane * rb.cap + qi] = v;
-    } else if (lane == 5) {
-      rb.nbr_count[qi] = (oi[0] >= 0) + (oi[1] >= 0) + (oi[2] >= 0) + (oi[3] >= 0) + (oi[4] >= 0);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned int t = atomicAdd(&rb.nq_ctr[kNqDrained], 1u);
-    if (t == (unsigned)n_drain - 1u) {  // every drainer has read the queue: re-arm the counters for the next launch
-      __hip_atomic_store(&rb.nq_ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&rb.nq_ctr[kNqDone], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&rb.nq_ctr[kNqDrained], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&rb.nq_ctr[kNqGo], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -775,7 +693,8 @@ __device__ __forceinline__ void knn_drain(const GridView& g, const RegistrationB
 // `forced` 1: host-driven pass at the pose `ps_val` (always runs).  forced 2: always runs, pose read from `pose` (device).
 // forced < 0: device-driven loop — pose from `pose` (the control block), runs only when the control block says the next pass
 // searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).  An executed pass leaves its pose in
-// `search_pose_out` (may be null).  The grid is n_pad search workgroups (of which nb_real have queries) + kDrainWGs drainers.
+// `search_pose_out` (may be null).  A query whose 3x3x3 block cannot prove its list complete is flagged in nbr_count
+// (kNeedy); k_fit_reduce (or k_knn_complete after a stand-alone search) finishes it.
 template <int LPQ, int BS>
 __global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffers rb, PoseArg ps_val,
                                                    const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
@@ -787,8 +706,6 @@ __global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffe
   shard_range(rb, lo, n_live);
   if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
   if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
-  const int n_pad = (int)gridDim.x - kDrainWGs;
-  if ((int)blockIdx.x >= n_pad) { knn_drain<BS>(g, rb, (unsigned)nb_real, (int)blockIdx.x - n_pad, kDrainWGs); return; }
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;
   constexpr int QPB = BS / LPQ;
@@ -805,7 +722,6 @@ __global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffe
   const GlobalCells src{g, reinterpret_cast<const uint4*>(g.blocks)};
   knn_search_query<LPQ>(src, g, live && g.n_pts > 0, wx, wy, wz, sub, leader, k, need);
   if (live) knn_store<LPQ>(rb, g.pts, qi, sub, k, need, wx, wy, wz);
-  knn_finish_block(rb, live && need && sub == 0, qi, wx, wy, wz, k.i4 >= 0 ? k.d4 : __builtin_inff());
 }
 
 // The search pass with LDS-staged map tiles.  A workgroup takes QPB = BS / 4 consecutive queries of the down-sampled cloud,
@@ -837,8 +753,6 @@ __global__ __launch_bounds__(BS) void k_knn_tile(GridView g, RegistrationBuffers
   shard_range(rb, lo, n_live);
   if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
   if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
-  const int n_pad = (int)gridDim.x - kDrainWGs;
-  if ((int)blockIdx.x >= n_pad) { knn_drain<BS>(g, rb, (unsigned)nb_real, (int)blockIdx.x - n_pad, kDrainWGs); return; }
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;
   const int tid = threadIdx.x, sub = tid & (LPQ - 1);
@@ -1003,7 +917,6 @@ __global__ __launch_bounds__(BS) void k_knn_tile(GridView g, RegistrationBuffers
     knn_search_query<LPQ>(src, g, active, wx, wy, wz, sub, leader, k, need);
     if (live) knn_store<LPQ>(rb, g.pts, qi, sub, k, need, wx, wy, wz);
   }
-  knn_finish_block(rb, live && need && sub == 0, qi, wx, wy, wz, k.i4 >= 0 ? k.d4 : __builtin_inff());
 }
 
 // Second stage of the search for a flagged query, run by ONE WAVEFRONT (four flagged queries of a workgroup proceed
@@ -1145,11 +1058,60 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
 // Plane fit + residual + Jacobian + block reduction, one lane per point.  FIT = right after a search pass (finishes
 // the flagged searches of this workgroup's points, reads the 5 neighbours, caches the plane); !FIT for the
 // non-search iterations.  `forced` as in k_knn_pruned.
+// Completion of the flagged searches among the kBlock points [first, first + kBlock) of one workgroup: one wavefront per
+// flagged query, four at a time (they are rare, ~0.07 % of the queries, but clustered at the map frontier).  Every lane of
+// the workgroup must call it; on return the completed lists are visible to the whole workgroup.
+__device__ __forceinline__ void complete_flagged(const GridView& g, const RegistrationBuffers& rb, int first, bool live, int* s_needy,
+                                                 int* s_nneedy) {
+  if (threadIdx.x == 0) *s_nneedy = 0;
+  __syncthreads();
+  if (live && (rb.nbr_count[first + threadIdx.x] & kNeedy)) s_needy[atomicAdd(s_nneedy, 1)] = threadIdx.x;
+  __syncthreads();
+#ifdef LII_DIAG_SKIP_NEEDY  // diagnostic build only: how much of the search-pass fit kernel is the completion of flagged searches
+  const int nn = 0;
+#else
+  const int nn = *s_nneedy;
+#endif
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int e = wave; e < nn; e += kBlock / 64) {
+    const int qi = first + s_needy[e];
+    const float4 w4 = rb.world[qi];
+    const int c0 = rb.nbr_count[qi] & 0xFF;
+    const float d5 = c0 == kMatch ? rb.nbr[(size_t)4 * rb.cap + qi].w : __builtin_inff();
+    float od[5];
+    int oi[5];
+    knn_fallback_wave(g, w4.x, w4.y, w4.z, d5, od, oi);
+    const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
+    const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
+    if (lane < 5) {
+      float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
+      v.w = dd;
+      rb.nbr[(size_t)lane * rb.cap + qi] = v;
+    } else if (lane == 5) {
+      rb.nbr_count[qi] = (oi[0] >= 0) + (oi[1] >= 0) + (oi[2] >= 0) + (oi[3] >= 0) + (oi[4] >= 0);
+    }
+  }
+  if (nn) __syncthreads();  // the completed lists are visible to their owners (workgroup-scope release/acquire)
+}
+
+// The completion alone, over the whole cloud (lii_map_incremental of a sharded job: the blocks of the other ranks were searched
+// by a stand-alone k-NN pass, not by a fit pass).
+__global__ __launch_bounds__(kBlock) void k_knn_complete(GridView g, RegistrationBuffers rb) {
+  __shared__ int s_needy[kBlock];
+  __shared__ int s_nneedy;
+  int lo, n_live;
+  shard_range(rb, lo, n_live);
+  const int first = lo + blockIdx.x * kBlock;
+  complete_flagged(g, rb, first, (int)(blockIdx.x * kBlock + threadIdx.x) < n_live, s_needy, &s_nneedy);
+}
+
 __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationBuffers rb, PoseArg ps_val,
                                                         const PoseArg* __restrict__ pose,
                                                         const IekfCtrl* __restrict__ ctrl, int forced, int imu_en,
                                                         double plane_thr, double rinv, int nb_real) {
   __shared__ ReduceShared sh;
+  __shared__ int s_needy[kBlock];
+  __shared__ int s_nneedy;
   // (pose and point count are loaded together with the flags, not after the branch on them: see k_knn_pruned)
   const PoseArg ps = forced < 0 ? *pose : ps_val;
   int lo, n_live;
@@ -1165,6 +1127,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   if (blk >= nb_real) return;  // uniform per block
   const int i = lo + blk * kBlock + threadIdx.x;
   const bool live = blk * kBlock + (int)threadIdx.x < n_live;
+  if (FIT) complete_flagged(g, rb, lo + blk * kBlock, live, s_needy, &s_nneedy);  // uniform per workgroup
   RowOut o;
 #pragma unroll
   for (int c = 0; c < 12; c++) o.h[c] = 0;
@@ -1213,30 +1176,19 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
 // One 64-lane workgroup per output: coalesced loads, per-lane sums over b = lane + 64 k in a fixed order, then a
 // fixed shuffle tree.  (91 independent workgroups: the partials were written by other XCDs, so every load is an
 // L2 miss; one latency instead of a dependent chain of them.)
-__global__ __launch_bounds__(64) void k_reduce91(const double* __restrict__ partials, int n_blocks, int stride,
-                                                  double* __restrict__ out, const IekfCtrl* __restrict__ ctrl, int forced,
-                                                  RegistrationBuffers rb) {
+__global__ __launch_bounds__(256) void k_reduce91(const double* __restrict__ partials, int n_blocks, int stride,
+                                                   double* __restrict__ out, const IekfCtrl* __restrict__ ctrl, int forced,
+                                                   RegistrationBuffers rb) {
+  __shared__ double s_w[4];
   if (forced < 0 && ctrl->stop) return;
   if (rb.n_dev || rb.shard_world > 1) {
     int lo, n_live;
     shard_range(rb, lo, n_live);
     n_blocks = max(1, (n_live + kBlock - 1) / kBlock);
   }
-  const int t = blockIdx.x, lane = threadIdx.x;
-  const double* row = partials + (size_t)t * stride;
-  // the partials were written by other XCDs: every load is an L2 miss.  Eight are in flight before the first add (same
-  // order of additions as the plain loop, so the sum is bit-identical) - one latency per eight rows instead of one per row.
-  double acc = 0;
-  for (int b0 = lane; b0 < n_blocks; b0 += 64 * 8) {
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = b0 + 64 * u < n_blocks ? row[b0 + 64 * u] : 0.0;
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (b0 + 64 * u < n_blocks) acc += v[u];
-  }
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-  if (lane == 0) out[t] = acc;
+  const int t = blockIdx.x;
+  const double acc = final_sum_row<256>(partials + (size_t)t * stride, n_blocks, s_w);  // same order as k_reduce_solve
+  if (threadIdx.x == 0) out[t] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1762,7 +1714,7 @@ static void launch_knn_t(const GridView& g, const RegistrationBuffers& rb, const
   int nq = nblk(shard_bound(rb), BS / LPQ);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_knn_pruned<LPQ, BS>), dim3(nq_pad + kDrainWGs), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
+  hipLaunchKernelGGL((k_knn_pruned<LPQ, BS>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
 }
 template <int BS, int TCAP, int HCAP>
 static void launch_knn_tile_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
@@ -1770,8 +1722,7 @@ static void launch_knn_tile_t(const GridView& g, const RegistrationBuffers& rb, 
   int nq = nblk(shard_bound(rb), BS / 4);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_knn_tile<BS, TCAP, HCAP>), dim3(nq_pad + kDrainWGs), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out,
-                     stats);
+  hipLaunchKernelGGL((k_knn_tile<BS, TCAP, HCAP>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out, stats);
 }
 // variant: 4 / 8 = lanes per query of the global-memory search (k_knn_pruned); 64 / 65 / 32 / 128 = LDS-tiled search
 // (k_knn_tile) with 64 queries per workgroup and a 1536- / 1024-point tile, 32 queries (768 points), 128 queries (3072 points)
@@ -1787,6 +1738,11 @@ void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, c
     default: launch_knn_tile_t<256, 1536, 1024>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
   }
 }
+void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {
+  int nb = nblk(shard_bound(rb), kBlock);
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_knn_complete, dim3(nb), dim3(kBlock), 0, s, g, rb);
+}
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);
@@ -1797,7 +1753,7 @@ void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const P
 void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(64), 0, s, rb.partials, nb, rb.partial_stride, out91, ctrl, forced, rb);
+  hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(256), 0, s, rb.partials, nb, rb.partial_stride, out91, ctrl, forced, rb);
 }
 void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, float4* copy_to,
                         const void* ctrl_src, void* ctrl_dst, size_t ctrl_bytes, hipStream_t s) {

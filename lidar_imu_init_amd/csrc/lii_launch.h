@@ -29,6 +29,7 @@ void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks
 // registration
 void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                 const IekfCtrl* ctrl, int forced, double* search_pose_out, unsigned int* stats, hipStream_t s);
+void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s);
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s);
 void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s);

@@ -1,7 +1,8 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r2e; mkdir -p $O
+O=gpurun_out/r2f; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.log
+LII_VOXEL_ORDER=brick LII_KNN_VARIANT=64 timeout 600 python -m pytest tests/test_gpu_register.py tests/test_gpu_scan_ops.py tests/test_gpu_headline_parity.py tests/test_gpu_end_to_end.py -m gpu -q -x --timeout 900 > $O/pytest_brick_tile.log 2>&1; echo "pytest brick+tile rc=$?"; tail -3 $O/pytest_brick_tile.log
 run() { local name=$1; shift
   env "$@" timeout 300 python bench.py --steps 200 --no-cpu-baseline > $O/bench_$name.json 2> $O/bench_$name.err
   echo "$name rc=$?"; python - $O/bench_$name.json <<'PY'
@@ -12,9 +13,8 @@ try:
 except Exception as e: print("  parse failed",e)
 PY
 }
-run v4 LII_KNN_VARIANT=4
-run v4pcl LII_KNN_VARIANT=4 LII_VOXEL_ORDER=pcl
-run v8 LII_KNN_VARIANT=8
+run default
+run brick LII_VOXEL_ORDER=brick
 prof() { local name=$1; shift
   env "$@" timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o t -- python bench.py --steps 100 --warmup 10 --prime 20 --no-cpu-baseline > $O/prof_$name.log 2>&1
   echo "prof $name rc=$?"
@@ -22,4 +22,4 @@ prof() { local name=$1; shift
   rm -rf $O/prof_$name
   sed -n 5,40p $O/timeline_$name.md
 }
-prof v4 LII_KNN_VARIANT=4
+prof default
