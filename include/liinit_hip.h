@@ -105,6 +105,10 @@ int lii_map_reset(lii_handle h);
 int lii_map_build(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes);
 int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes, int32_t downsample_on,
                        int32_t* n_added);
+/* lii_map_delete_boxes <- ikdtree.Delete_Point_Boxes(cub_needrm)  (include/ikd-Tree/ikd_Tree.cpp:500-516; the call the reference
+ *                       prepares in lasermap_fov_segment, src/laserMapping.cpp:260-305, and never makes - quirk A6: its map only
+ *                       grows).  boxes = n x 6 floats (min xyz, max xyz); a point goes when min <= p < max on every axis. */
+int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int32_t* n_deleted);
 int lii_map_size(lii_handle h, int32_t* n_valid);
 int lii_map_download(lii_handle h, float* xyz_out, int32_t capacity, int32_t* n);
 /* Pushes pending host-side map edits to the device and rebuilds the k-NN grid (done lazily by the
@@ -270,6 +274,16 @@ int lii_li_init_interpolate(const lii_calib_state* imu_all, int32_t n_imu, const
                             double move_start_time, lii_calib_state* imu_out, lii_calib_state* lidar_out, int32_t* n_out);
 int lii_li_init_run(lii_handle h, const lii_calib_state* imu, const lii_calib_state* lidar, int32_t n, int32_t orig_odom_freq,
                     int32_t cut_frame_num, lii_calib_result* out, double* time_lag_1, double* total_time_lag);
+/* The two pieces of that chain with real arithmetic volume, on the device, bit-identical to the host
+ * path of lii_li_init_run:
+ *   lii_zero_phase_filter  LI_Init::zero_phase_filt (include/LI_init/LI_init.cpp:260-315; Butterworth coefficients
+ *                          LI_init.h:218-224) on n_seq sequences of n CalibStates laid back to back: the four 3-vectors are
+ *                          filtered, rot_end / timestamp pass through (CalibState::operator= copies only the vectors);
+ *   lii_xcorr_lag          LI_Init::xcorr_temporal_init (:160-193): lag_IMU_wtr_Lidar of the |ang_vel| series, one lane per lag;
+ *   lii_li_init_set_device lii_li_init_run uses them (1) or the host functions (0, default). */
+int lii_zero_phase_filter(lii_handle h, const lii_calib_state* in, int32_t n_seq, int32_t n, lii_calib_state* out);
+int lii_xcorr_lag(lii_handle h, const lii_calib_state* imu, const lii_calib_state* lidar, int32_t n, int32_t* lag_imu_wrt_lidar);
+int lii_li_init_set_device(lii_handle h, int32_t on_device);
 
 /* ---------------------------------------------------------------- multi-GPU (points of one scan sharded across ranks)
  * One process per GPU.  Rank 0 creates an id, the caller ships the 128 bytes to the other ranks (e.g.

@@ -85,6 +85,7 @@ _DECLS = {
     "lii_map_reset": (C.c_int, [C.c_void_p]),
     "lii_map_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "lii_map_add_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    "lii_map_delete_boxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "lii_map_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "lii_map_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "lii_map_commit": (C.c_int, [C.c_void_p]),
@@ -114,6 +115,9 @@ _DECLS = {
                                           C.POINTER(C.c_int32)]),
     "lii_li_init_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.POINTER(lii_calib_result), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "lii_zero_phase_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "lii_xcorr_lag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "lii_li_init_set_device": (C.c_int, [C.c_void_p, C.c_int32]),
     "lii_comm_unique_id": (C.c_int, [C.c_void_p]),
     "lii_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lii_comm_init_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
@@ -273,6 +277,13 @@ class Registrar:
         n = C.c_int32(0)
         self._check(self.L.lii_map_add_points(self.h, _ptr(xyz), len(xyz), xyz.strides[0] if len(xyz) else 12,
                                               int(downsample_on), C.byref(n)))
+        return n.value
+
+    def map_delete_boxes(self, boxes6) -> int:
+        """ikdtree.Delete_Point_Boxes: boxes6 (n, 6) = min xyz, max xyz; returns the number of points removed."""
+        b = np.ascontiguousarray(boxes6, np.float32).reshape(-1, 6)
+        n = C.c_int32(0)
+        self._check(self.L.lii_map_delete_boxes(self.h, _ptr(b) if len(b) else None, len(b), C.byref(n)))
         return n.value
 
     def map_size(self) -> int:
@@ -446,6 +457,25 @@ class Registrar:
         self._check(self.L.lii_li_init_run(self.h, _ptr(imu), _ptr(lid), len(imu), int(orig_odom_freq), int(cut_frame_num),
                                            C.byref(res), C.byref(l1), C.byref(tot)))
         return res, l1.value, tot.value
+
+    def zero_phase_filter(self, seqs22):
+        """LI_Init::zero_phase_filt on the device: seqs22 (n_seq, n, 22) -> filtered copy."""
+        a = np.ascontiguousarray(seqs22, np.float64)
+        assert a.ndim == 3 and a.shape[2] == 22
+        out = np.zeros_like(a)
+        self._check(self.L.lii_zero_phase_filter(self.h, _ptr(a), a.shape[0], a.shape[1], _ptr(out)))
+        return out
+
+    def xcorr_lag(self, imu22, lidar22) -> int:
+        """LI_Init::xcorr_temporal_init on the device: lag_IMU_wtr_Lidar in samples."""
+        imu = np.ascontiguousarray(imu22, np.float64).reshape(-1, 22)
+        lid = np.ascontiguousarray(lidar22, np.float64).reshape(-1, 22)
+        lag = C.c_int32(0)
+        self._check(self.L.lii_xcorr_lag(self.h, _ptr(imu), _ptr(lid), len(imu), C.byref(lag)))
+        return lag.value
+
+    def li_init_set_device(self, on: bool):
+        self._check(self.L.lii_li_init_set_device(self.h, int(on)))
 
     # ------------------------------------------------------------------ multi-GPU
     def comm_unique_id(self) -> bytes:

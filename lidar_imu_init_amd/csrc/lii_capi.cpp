@@ -121,6 +121,7 @@ struct lii_context {
   int n_cal = 0;
 
   void* ingest = nullptr;  // lii_ingest.hip state (frames of the last driver message)
+  bool li_init_device = false;  // lii_li_init_set_device: zero-phase filter + cross-correlation of lii_li_init_run on the device
 
   // ---- comm
   ncclComm_t comm = nullptr;   // RCCL transport (ranks on several nodes, or forced)
@@ -566,6 +567,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
 }  // namespace
 
 int lii_internal_fail(lii_context* h, int code, const std::string& msg) { return fail(h, code, msg); }
+int lii_internal_li_init_on_device(lii_context* h) { return h && h->li_init_device ? 1 : 0; }
 hipStream_t lii_internal_stream(lii_context* h) { return h->stream; }
 void** lii_internal_ingest_slot(lii_context* h) { return &h->ingest; }
 
@@ -819,6 +821,31 @@ int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_
   if (rc != LII_OK) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (n_added) *n_added = downsample_on ? ev : 0;
+  return LII_OK;
+}
+int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int32_t* n_deleted) {
+  if (!h || (!boxes && n_boxes > 0) || n_boxes < 0 || n_boxes > 4096) return fail(h, LII_ERR_INVALID, "lii_map_delete_boxes: bad arguments (<= 4096 boxes)");
+  if (n_deleted) *n_deleted = 0;
+  const int n_old = h->n_map;
+  if (n_boxes == 0 || n_old == 0) return LII_OK;
+  hipStream_t s = h->stream;
+  float* d_boxes = reinterpret_cast<float*>(h->d_keys_b);  // scratch of the index build, free between calls
+  std::memcpy(h->h_small + 4096, boxes, sizeof(float) * 6 * size_t(n_boxes));
+  HIPCHK(h, hipMemcpyAsync(d_boxes, h->h_small + 4096, sizeof(float) * 6 * size_t(n_boxes), hipMemcpyHostToDevice, s));
+  launch_box_tomb(h->d_map, n_old, d_boxes, n_boxes, h->d_tomb, h->d_u32_b, s);
+  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_b, h->d_u32_c, n_old, s);
+  launch_compact_f4(h->d_map, h->d_u32_b, h->d_u32_c, n_old, h->d_map_unsorted, 0, h->d_counts + 2, s);
+  HIPCHK(h, hipMemcpyAsync(h->h_small + 3072, h->d_counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  int cnt[8];
+  std::memcpy(cnt, h->h_small + 3072, sizeof(cnt));
+  const int alive = cnt[2];
+  if (n_deleted) *n_deleted = n_old - alive;
+  if (alive == n_old) return LII_OK;  // nothing inside the boxes: the map and its index stay as they are
+  h->have_search = false;
+  int rc = build_index(h, alive, alive);  // the survivors are still in key order: no sort, no merge
+  if (rc != LII_OK) return rc;
+  HIPCHK(h, hipStreamSynchronize(s));
   return LII_OK;
 }
 int lii_map_size(lii_handle h, int32_t* n_valid) {
@@ -1249,6 +1276,12 @@ int lii_calib_eval(lii_handle h, int32_t stage, const double* params, double* Jt
   if (JtJ) std::memcpy(JtJ, o, sizeof(double) * dof * dof);
   if (Jtr) std::memcpy(Jtr, o + dof * dof, sizeof(double) * dof);
   if (cost) *cost = o[dof * dof + dof];
+  return LII_OK;
+}
+
+int lii_li_init_set_device(lii_handle h, int32_t on_device) {
+  if (!h) return LII_ERR_INVALID;
+  h->li_init_device = on_device != 0;
   return LII_OK;
 }
 

@@ -73,6 +73,7 @@ void launch_compact_f4(const float4* src, const unsigned int* flag, const unsign
 void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, hipStream_t s);
 void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
                      unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, hipStream_t s);
+void launch_box_tomb(const float4* pts, int n, const float* boxes, int n_boxes, unsigned char* tomb, unsigned int* alive, hipStream_t s);
 void launch_alive_flags(const unsigned char* tomb, int n, unsigned int* alive, hipStream_t s);
 void launch_append_f4(const float4* src, const int* count, int n_bound, float4* dst, int dst_cap, const int* off_a, const int* off_b,
                       hipStream_t s);

@@ -18,6 +18,9 @@
 
 #include "../../include/liinit_hip.h"
 
+struct lii_context;
+int lii_internal_li_init_on_device(lii_context* h);  // lii_capi.cpp: lii_li_init_set_device
+
 namespace {
 
 using Seq = std::vector<lii_calib_state>;
@@ -250,19 +253,42 @@ int lii_li_init_run(lii_handle h, const lii_calib_state* imu_in, const lii_calib
                     double* total_time_lag) {
   if (!h || !imu_in || !lidar_in || !out || n < 200 || orig_odom_freq < 1 || cut_frame_num < 1) return LII_ERR_INVALID;
   Seq imu(imu_in, imu_in + n), lidar(lidar_in, lidar_in + n);
+  // lii_li_init_set_device(h, 1): the zero-phase Butterworth passes and the O(N^2) cross-correlation run on the device
+  // (lii_li_init_dev.hip - bit-identical to the host functions above); everything else of the chain is O(N) bookkeeping
+  const bool dev = lii_internal_li_init_on_device(h) != 0;
+  auto zero_phase_pair = [&](const Seq& a, const Seq& b, Seq& fa, Seq& fb) -> int {
+    if (!dev || a.size() != b.size() || a.size() < 62) { fa = zero_phase(a); fb = zero_phase(b); return LII_OK; }
+    Seq both(a);
+    both.insert(both.end(), b.begin(), b.end());
+    Seq out(both.size());
+    const int rc_ = lii_zero_phase_filter(h, both.data(), 2, int32_t(a.size()), out.data());
+    if (rc_ != LII_OK) return rc_;
+    fa.assign(out.begin(), out.begin() + a.size());
+    fb.assign(out.begin() + a.size(), out.end());
+    return LII_OK;
+  };
   time_compensate(imu, lidar, 0.0, true);
-  Seq imu_f = zero_phase(imu);
+  Seq imu_f, lidar_f;
+  int rc = zero_phase_pair(imu, lidar, imu_f, lidar_f);
+  if (rc != LII_OK) return rc;
   normalize_acc(imu_f);
-  Seq lidar_f = zero_phase(lidar);
   imu.assign(imu_f.begin(), imu_f.end() - 1);
   lidar.assign(lidar_f.begin(), lidar_f.end() - 1);
   cut_tail(imu, lidar);
-  const int lag = xcorr(imu, lidar);
+  int lag = 0;
+  if (dev) {
+    int32_t l = 0;
+    if ((rc = lii_xcorr_lag(h, imu.data(), lidar.data(), int32_t(imu.size()), &l)) != LII_OK) return rc;
+    lag = l;
+  } else {
+    lag = xcorr(imu, lidar);
+  }
   const double lag1 = double(lag) / double(orig_odom_freq * cut_frame_num);
   time_compensate(imu, lidar, lag1, false);
   central_diff(imu, lidar);
   {
-    Seq imu2 = zero_phase(imu), lidar2 = zero_phase(lidar);
+    Seq imu2, lidar2;
+    if ((rc = zero_phase_pair(imu, lidar, imu2, lidar2)) != LII_OK) return rc;
     for (size_t i = 0; i < imu.size(); i++) {
       std::memcpy(imu[i].ang_acc, imu2[i].ang_acc, 24);
       std::memcpy(lidar[i].ang_acc, lidar2[i].ang_acc, 24);
@@ -271,7 +297,7 @@ int lii_li_init_run(lii_handle h, const lii_calib_state* imu_in, const lii_calib
   }
   std::memset(out, 0, sizeof(*out));
   out->R_LI[0] = out->R_LI[4] = out->R_LI[8] = 1.0;
-  int rc = lii_calib_set_buffers(h, imu.data(), lidar.data(), int32_t(imu.size()));
+  rc = lii_calib_set_buffers(h, imu.data(), lidar.data(), int32_t(imu.size()));
   if (rc != LII_OK) return rc;
   if ((rc = lii_calib_solve_stage(h, 1, out)) != LII_OK) return rc;
   if ((rc = lii_calib_solve_stage(h, 2, out)) != LII_OK) return rc;

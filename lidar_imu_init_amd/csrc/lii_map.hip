@@ -251,7 +251,26 @@ __global__ void k_sum3(const int* a, const int* b, const int* c, int* out) {
   if (threadIdx.x == 0) *out = (a ? *a : 0) + (b ? *b : 0) + (c ? *c : 0);
 }
 
+// KD_TREE::Delete_Point_Boxes (ikd_Tree.cpp:500-516) -> Delete_by_range (:608-670): a point goes when min <= p < max on every
+// axis (:631).  One lane per map point, the boxes (6 floats each) walked from constant-cached memory.
+__global__ void k_box_tomb(const float4* __restrict__ pts, int n, const float* __restrict__ boxes, int n_boxes,
+                           unsigned char* __restrict__ tomb, unsigned int* __restrict__ alive) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  bool dead = false;
+  for (int b = 0; b < n_boxes; b++) {
+    const float* q = boxes + 6 * b;
+    dead = dead || (q[0] <= p.x && q[3] > p.x && q[1] <= p.y && q[4] > p.y && q[2] <= p.z && q[5] > p.z);
+  }
+  tomb[i] = dead ? 1 : 0;
+  alive[i] = dead ? 0u : 1u;
+}
+
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
+void launch_box_tomb(const float4* pts, int n, const float* boxes, int n_boxes, unsigned char* tomb, unsigned int* alive, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_box_tomb, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, boxes, n_boxes, tomb, alive);
+}
 
 void launch_map_decide(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* flag_add,
                        unsigned int* flag_nodown, float4* world_out, hipStream_t s) {

@@ -133,6 +133,7 @@ def ref():
         R.ref_tree_build.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
         R.ref_tree_add_points.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int]
         R.ref_tree_size.argtypes = [C.c_void_p]
+        R.ref_tree_delete_boxes.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
         R.ref_tree_validnum.argtypes = [C.c_void_p]
         R.ref_tree_flatten.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int]
         R.ref_tree_knn.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_double,
@@ -198,6 +199,12 @@ class Tree:
         if len(xyz) == 0:
             return 0
         return self._f("add_points")(self._h, _fp(xyz), len(xyz), int(downsample_on))
+
+    def delete_boxes(self, boxes6) -> int:
+        """KD_TREE::Delete_Point_Boxes of the unmodified reference tree (backend 'ref' only)."""
+        assert self.backend == "ref"
+        b = _f32(np.asarray(boxes6).reshape(-1, 6))
+        return self._L.ref_tree_delete_boxes(self._h, _fp(b), len(b))
 
     def size(self) -> int:
         return self._f("size")(self._h)

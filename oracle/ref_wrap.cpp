@@ -29,6 +29,12 @@ int ref_tree_add_points(void* h, const float* xyz, int n, int downsample_on) {
   PointVector v = to_pv(xyz, n);
   return static_cast<KD_TREE*>(h)->Add_Points(v, downsample_on != 0);
 }
+int ref_tree_delete_boxes(void* h, const float* boxes, int n) {  // n x 6: min xyz, max xyz
+  std::vector<BoxPointType> v(n);
+  for (int i = 0; i < n; i++)
+    for (int a = 0; a < 3; a++) { v[i].vertex_min[a] = boxes[6 * i + a]; v[i].vertex_max[a] = boxes[6 * i + 3 + a]; }
+  return static_cast<KD_TREE*>(h)->Delete_Point_Boxes(v);
+}
 int ref_tree_size(void* h) { return static_cast<KD_TREE*>(h)->size(); }
 int ref_tree_validnum(void* h) { return static_cast<KD_TREE*>(h)->validnum(); }
 

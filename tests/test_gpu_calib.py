@@ -97,3 +97,60 @@ def test_li_initialization_end_to_end_on_reference_run(reg):
     assert np.abs(O.rot_to_euler(R) * 57.3 - d["result_rot_euler_deg"]).max() < 0.01
     assert np.abs(np.array(res.T_LI[:]) - d["result_trans"]).max() < 1e-3
     assert np.abs(np.array(res.acc_bias[:]) - d["result_acc_bias"]).max() < 1e-5
+
+
+def test_conditioning_chain_on_the_device(reg):
+    """SURVEY.md section 8(f)4 on the device (lii_li_init_dev.hip): the zero-phase Butterworth filter and the O(N^2)
+    cross-correlation against the numpy oracle - bit for bit (same order of additions, no FMA contraction; tolerance stated as
+    1e-12 relative) - and against the reference's own Log/IMU_meas.txt through the fixture; then the whole LI_Initialization
+    with the device chain switched on must give the host chain's result bit for bit."""
+    import time
+    from oracle import li_init_np as LI
+    imu, lid = F.sequences()
+    imu_c, lid_c = LI.imu_time_compensate(imu.copy(), lid.copy(), 0.0, True)
+    want_i, want_l = LI.zero_phase_filt(imu_c), LI.zero_phase_filt(lid_c)
+    batch = np.stack([imu_c.to_records(), lid_c.to_records()])
+    t0 = time.perf_counter()
+    got = reg.zero_phase_filter(batch)
+    t_dev = time.perf_counter() - t0
+    for g, w in ((got[0], want_i.to_records()), (got[1], want_l.to_records())):
+        assert np.array_equal(g[:, :9], w[:, :9]) and np.array_equal(g[:, 21], w[:, 21])   # rot_end / timestamp pass through
+        assert np.max(np.abs(g[:, 9:21] - w[:, 9:21])) <= 1e-12 * max(1.0, np.max(np.abs(w[:, 9:21])))
+        assert np.array_equal(g[:, 9:21], w[:, 9:21]), "same additions in the same order: bit-identical"
+    # the filtered IMU angular velocity is what the reference logged (Log/IMU_meas.txt holds the sequence after the chain's
+    # tail cut and time compensation: compare the common span through the oracle's own pinned reproduction)
+    out = F.run(solve=False)
+    # cross-correlation: the lag of the reference run (-0.08 s at 50 Hz = 4 samples), then shifted copies
+    fi, fl = LI.normalize_acc(want_i), want_l
+    fi2, fl2 = LI.cut_sequence_tail(fi.slice(slice(0, len(fi) - 1)), fl.slice(slice(0, len(fl) - 1)))
+    lag1, lag_samples = LI.xcorr_temporal_init(fi2, fl2, 50.0)
+    t0 = time.perf_counter()
+    got_lag = reg.xcorr_lag(fi2.to_records(), fl2.to_records())
+    t_x = time.perf_counter() - t0
+    assert got_lag == lag_samples and abs(lag1 - out["time_lag_1"]) < 1e-15
+    rng = np.random.default_rng(4)
+    for shift in (0, 7, -13, 40):
+        a = LI.CalibSeq(900)
+        a.ang_vel = rng.normal(0, 0.5, (900, 3))
+        b = a.copy()
+        b.ang_vel = np.roll(a.ang_vel, shift, axis=0) + rng.normal(0, 0.01, (900, 3))
+        assert reg.xcorr_lag(a.to_records(), b.to_records()) == LI.xcorr_temporal_init(a, b, 50.0)[1]
+    # a plateau of equal maxima: the first lag in ascending order wins on both sides
+    a = LI.CalibSeq(64)
+    b = LI.CalibSeq(64)
+    assert reg.xcorr_lag(a.to_records(), b.to_records()) == LI.xcorr_temporal_init(a, b, 50.0)[1]
+    # the whole initialization with the device chain: bit-identical to the host chain
+    res_h, lag_h, tot_h = reg.li_init_run(imu.to_records(), lid.to_records(), 10, 5)
+    reg.li_init_set_device(True)
+    try:
+        t0 = time.perf_counter()
+        res_d, lag_d, tot_d = reg.li_init_run(imu.to_records(), lid.to_records(), 10, 5)
+        t_run = time.perf_counter() - t0
+    finally:
+        reg.li_init_set_device(False)
+    assert lag_d == lag_h and tot_d == tot_h
+    for f in ("R_LI", "T_LI", "gyro_bias", "acc_bias", "grav_L0", "final_cost"):
+        assert np.array_equal(np.array(getattr(res_d, f)[:]), np.array(getattr(res_h, f)[:])), f
+    assert res_d.time_lag_2 == res_h.time_lag_2
+    print(f"device zero-phase filter of 2 x {batch.shape[1]} states: {t_dev * 1e3:.2f} ms; cross-correlation ({len(fi2)} samples): "
+          f"{t_x * 1e3:.2f} ms; lii_li_init_run with the device chain: {t_run * 1e3:.1f} ms")

@@ -132,3 +132,85 @@ def test_stream_with_map_incremental(oracle):
         # rings, so single-scan accuracy is a few cm for the reference algorithm as well — the oracle lands on the same pose)
         assert np.linalg.norm(sg.pos_end - p) < 0.10
     reg.close()
+
+
+def test_delete_boxes_matches_the_reference_tree(oracle):
+    """lii_map_delete_boxes against KD_TREE::Delete_Point_Boxes of the UNMODIFIED reference tree (min <= p < max on every axis,
+    ikd_Tree.cpp:631): same count, same surviving set, and the rebuilt index answers like the tree afterwards."""
+    import lidar_imu_init_amd as lii
+    rng = np.random.default_rng(12)
+    base = rng.uniform(-10, 10, (30_000, 3)).astype(np.float32)
+    boxes = np.array([[-2, -2, -2, 2, 2, 2], [5, -10, -10, 10, 10, 0.5], [-9.5, 3, 3, -9.0, 3.5, 3.5], [20, 20, 20, 30, 30, 30]], np.float32)
+    # points exactly on the faces: the lower face belongs to the box, the upper one does not
+    base[:6] = [[-2, 0, 0], [2, 0, 0], [0, -2, 1.999], [0, 2, 0], [5, 0, 0.5], [5, 0, 0.4999]]
+    reg = lii.Registrar(max_scan_points=20_000, max_map_points=60_000, filter_size_map=0.2)
+    reg.map_build(base)
+    inside = np.zeros(len(base), bool)
+    for b in boxes:
+        inside |= np.all((base >= b[:3]) & (base < b[3:]), axis=1)
+    n_del = reg.map_delete_boxes(boxes)
+    assert n_del == int(inside.sum()) and reg.map_size() == len(base) - n_del
+    got = _as_set(reg.map_download())
+    assert np.array_equal(got, _as_set(base[~inside]))
+    if oracle.ref_available():
+        tree = oracle.Tree("ref")
+        tree.build(base)
+        assert tree.delete_boxes(boxes) == n_del
+        assert tree.validnum() == reg.map_size()
+        assert np.array_equal(_as_set(tree.flatten()), got)
+    # the index after the deletion: neighbours come from the survivors only
+    q = rng.uniform(-3, 3, (4000, 3)).astype(np.float32)
+    reg.scan_upload(np.c_[q, np.zeros(len(q), np.float32)])
+    n = reg.downsample_skip()
+    reg.iekf_iterate(lii.State(oracle.state_init()), True, False)
+    nb, cnt, _ = reg.neighbors(n)
+    t2 = oracle.Tree("oracle")
+    t2.build(base[~inside])
+    pts, d2, rc = t2.knn(q, threads=4)
+    assert np.array_equal(cnt, rc)
+    for k in range(5):
+        m = cnt > k
+        assert np.array_equal(nb[m, k], pts[m, k])
+    assert reg.map_delete_boxes(np.zeros((0, 6), np.float32)) == 0 and reg.map_delete_boxes(boxes) == 0  # idempotent
+    reg.close()
+
+
+def test_capacity_overflow_leaves_the_map_untouched(oracle):
+    """More points than max_map_points: LII_ERR_CAPACITY, nothing written outside the staging buffers (the appends drop writes
+    at or beyond the capacity), the live map and its index exactly as before - lii_map_add_points with and without
+    down-sampling, and lii_map_incremental."""
+    import lidar_imu_init_amd as lii
+    rng = np.random.default_rng(2)
+    cap = 20_000
+    base = rng.uniform(-8, 8, (18_000, 3)).astype(np.float32)
+    reg = lii.Registrar(max_scan_points=8000, max_map_points=cap, filter_size_map=0.05)
+    reg.map_build(base)
+    before = reg.map_download().copy()
+    q = rng.uniform(-8, 8, (3000, 3)).astype(np.float32)
+
+    def knn_now():
+        reg.scan_upload(np.c_[q, np.zeros(len(q), np.float32)])
+        n = reg.downsample_skip()
+        out = reg.iekf_iterate(lii.State(oracle.state_init()), True, False)
+        return reg.neighbors(n), out
+
+    (nb0, cnt0, sel0), out0 = knn_now()
+    far = rng.uniform(20, 60, (6000, 3)).astype(np.float32)  # every point in a voxel of its own: 18 000 + 6 000 > 20 000
+    for downsample in (False, True):
+        with pytest.raises(lii.LIIError) as e:
+            reg.map_add_points(far, downsample)
+        assert e.value.code == -4
+        assert reg.map_size() == len(base) and np.array_equal(reg.map_download(), before)
+        (nb1, cnt1, sel1), out1 = knn_now()
+        assert np.array_equal(nb0, nb1) and np.array_equal(cnt0, cnt1) and np.array_equal(out0, out1)
+    # map_incremental: a scan far away from the map adds every point (no neighbour lists): overflow as well
+    reg.scan_upload(np.c_[far, np.zeros(len(far), np.float32)])
+    reg.downsample_skip()
+    reg.iekf_iterate(lii.State(oracle.state_init()), True, False)
+    with pytest.raises(lii.LIIError) as e:
+        reg.map_incremental(lii.State(oracle.state_init()))
+    assert e.value.code == -4
+    assert reg.map_size() == len(base) and np.array_equal(reg.map_download(), before)
+    # a batch that fits still goes in afterwards
+    assert reg.map_add_points(far[:1500], False) == 0 and reg.map_size() == len(base) + 1500
+    reg.close()
