@@ -2,7 +2,7 @@
 """Per-launch PMC figures of k_knn_pruned from the passes written by tools/collect_pmc.sh -> profiles/r01_pmc_knn.json.
 Only launches that executed count (the device-driven loop enqueues the kernel for every iteration; the ones that return at
 once move no data): a launch is 'executed' when its WRITE_SIZE / wave count is non-trivial.
-usage: summarize_pmc.py <dir of collect_pmc.sh> <out.json>"""
+usage: summarize_pmc.py <dir of collect_pmc.sh> <out.json> [algorithmic bytes per launch]"""
 import collections
 import csv
 import glob
@@ -12,6 +12,7 @@ import sys
 
 def main():
     d, out = sys.argv[1], sys.argv[2]
+    alg = float(sys.argv[3]) if len(sys.argv) > 3 else 25600000.0
     per = collections.defaultdict(lambda: collections.defaultdict(list))  # counter -> dispatch id -> values
     for f in glob.glob(d + "/p*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
@@ -36,7 +37,7 @@ def main():
                 "actually fetched, so the read side is doubled for `traffic`; the raw figure is kept beside it.",
         "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
         "hbm_bytes_per_launch_raw": (fetch_kb + write_kb) * 1024.0,
-        "algorithmic_bytes_per_launch": 25600000.0,
+        "algorithmic_bytes_per_launch": alg,
         "l2_hit_rate": hits / (hits + miss) if hits + miss > 0 else None,
     }
     json.dump(j, open(out, "w"), indent=1)
