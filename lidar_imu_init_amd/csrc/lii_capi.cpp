@@ -105,7 +105,8 @@ struct lii_context {
   int* d_nbody = nullptr;       // [0] size of the down-sampled cloud, [1] `filtered` flag of the last voxel filter
   bool body_is_scan = false;
   bool have_search = false;
-  int knn_variant = 4;   // search pass: 4 (default) / 8 = lanes per query of the global-memory search (k_knn_pruned);
+  int knn_variant = 5;   // search pass: 5 (default) = 4 lanes per query, round-1 candidates balanced over the lanes; 4 / 8 = plain
+                         // 4 / 8 lanes per query of the global-memory search (k_knn_pruned); 6 / 7 = variants of 5;
                          // 64 / 65 / 32 / 128 = the LDS-tiled search (k_knn_tile) in four geometries - built, measured, 2.5x
                          // slower (profiles/r02_knn_tile_ab.md); LII_KNN_VARIANT selects, for A/B
   unsigned int* d_knn_stats = nullptr;  // [0] workgroups of k_knn_tile that searched out of LDS, [1] that took the global path
@@ -1233,8 +1234,15 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
   launch_compact_f4(h->d_world, h->d_u32_a, h->d_u32_c, nb, h->d_list_add, 0, h->d_counts + 0, s);
   inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_b, h->d_u32_c, nb, s);
   launch_compact_f4(h->d_world, h->d_u32_b, h->d_u32_c, nb, h->d_list_nodown, 0, h->d_counts + 1, s);
+  // The sizes of the two lists, now: a converged map takes a few thousand of the ~100 k points, and everything downstream
+  // (voxel keys, the batch sort, the per-voxel fold, the insert compaction) is launched for the exact count instead of the
+  // scan-sized bound - one small host round trip (~15 us) against ~80 us of kernels working on padding.
+  HIPCHK(h, hipMemcpyAsync(h->h_small + 3080, h->d_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  int n_lists[2];
+  std::memcpy(n_lists, h->h_small + 3080, sizeof(n_lists));
   // Add_Points(PointToAdd, true) then Add_Points(PointNoNeedDownsample, false)  (:556-557)
-  int rc = map_apply(h, h->d_list_add, nb, h->d_counts + 0, true, h->d_list_nodown, h->d_counts + 1, nb, nullptr);
+  int rc = map_apply(h, h->d_list_add, n_lists[0], h->d_counts + 0, true, h->d_list_nodown, h->d_counts + 1, n_lists[1], nullptr);
   if (rc != LII_OK) return rc;
   int cnt[8];
   std::memcpy(cnt, h->h_small + 3072, sizeof(cnt));  // read back by map_apply

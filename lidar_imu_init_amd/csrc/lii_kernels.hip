@@ -594,7 +594,7 @@ __device__ __forceinline__ void body_to_world(const PoseArg& ps, const float4 pb
 
 // The two search rounds of one query on its LPQ lanes (all lanes of the group hold the query's world point).  On return the
 // leader's list has been broadcast to the group; `need` = the 3x3x3 block cannot prove the list complete (kNeedy).
-template <int LPQ, class Cells>
+template <int LPQ, class Cells, bool BAL = false>
 __device__ __forceinline__ void knn_search_query(const Cells& src, const GridView& g, bool active, float wx, float wy, float wz,
                                                  int sub, int leader, Knn5& k, bool& need) {
   const float INF = __builtin_inff();
@@ -620,8 +620,53 @@ __device__ __forceinline__ void knn_search_query(const Cells& src, const GridVie
       }
       src.template lookup<8 / LPQ>(jx, jy, jz, r);
     }
+    if (BAL && LPQ == 4) {
+      // Balanced round 1: the eight ranges go to every lane of the group (shuffles), the candidates of the concatenated list are
+      // dealt out four consecutive ones per lane and trip - ceil(total / 16) load trips for the group instead of the trips of its
+      // busiest lane (two occupied cells on one lane, none on another).  Ends of the ranges relative to the list start travel
+      // as bytes (cells hold ~9 points; a group with a cell of more than 255 takes the plain path).
+      unsigned int off[8];  // map index = list position + off[c] inside range c
+      unsigned int pk0 = 0, pk1 = 0, run = 0, big = 0;
 #pragma unroll
-    for (int t = 0; t < 8 / LPQ; t++) scan_range(pts, g.max_d2, r[t].x, r[t].y, wx, wy, wz, k);
+      for (int c = 0; c < 8; c++) {
+        const int owner = leader + (c & 3);
+        const unsigned int a = __shfl(r[c >> 2].x, owner), e = __shfl(r[c >> 2].y, owner);
+        off[c] = a - run;
+        run += e - a;
+        big |= run;
+        if (c < 4) pk0 |= (run & 255u) << (8 * c); else pk1 |= (run & 255u) << (8 * (c - 4));
+      }
+      if (big < 256u) {
+        const unsigned int T = run;
+        for (unsigned int base = 4u * (unsigned)sub; base < T; base += 16u) {
+          unsigned int idx[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const unsigned int f = min(base + u, T - 1u);
+            unsigned int o = off[0];
+#pragma unroll
+            for (int c = 1; c < 8; c++) {
+              const unsigned int endprev = c <= 4 ? ((pk0 >> (8 * (c - 1))) & 255u) : ((pk1 >> (8 * (c - 5))) & 255u);
+              o = f >= endprev ? off[c] : o;
+            }
+            idx[u] = f + o;
+          }
+          const float4 p0 = pts[idx[0]], p1 = pts[idx[1]], p2 = pts[idx[2]], p3 = pts[idx[3]];
+          const float d0 = dist2_ref(wx, wy, wz, p0.x, p0.y, p0.z), d1 = dist2_ref(wx, wy, wz, p1.x, p1.y, p1.z);
+          const float d2 = dist2_ref(wx, wy, wz, p2.x, p2.y, p2.z), d3 = dist2_ref(wx, wy, wz, p3.x, p3.y, p3.z);
+          if (d0 <= g.max_d2 && d0 < k.d4) knn_insert(k, d0, (int)idx[0]);
+          if (base + 1 < T && d1 <= g.max_d2 && d1 < k.d4) knn_insert(k, d1, (int)idx[1]);
+          if (base + 2 < T && d2 <= g.max_d2 && d2 < k.d4) knn_insert(k, d2, (int)idx[2]);
+          if (base + 3 < T && d3 <= g.max_d2 && d3 < k.d4) knn_insert(k, d3, (int)idx[3]);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8 / LPQ; t++) scan_range(pts, g.max_d2, r[t].x, r[t].y, wx, wy, wz, k);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8 / LPQ; t++) scan_range(pts, g.max_d2, r[t].x, r[t].y, wx, wy, wz, k);
+    }
   }
   knn_group_merge_n<LPQ, false>(k);
   const float g0 = fminf(fminf(fmaxf(fx, cs - fx), fmaxf(fy, cs - fy)), fmaxf(fz, cs - fz)) - 2.f * eps;
@@ -695,8 +740,8 @@ __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const f
 // searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).  An executed pass leaves its pose in
 // `search_pose_out` (may be null).  A query whose 3x3x3 block cannot prove its list complete is flagged in nbr_count
 // (kNeedy); k_fit_reduce (or k_knn_complete after a stand-alone search) finishes it.
-template <int LPQ, int BS>
-__global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffers rb, PoseArg ps_val,
+template <int LPQ, int BS, bool BAL = false, int WPE = 1>
+__global__ __launch_bounds__(BS, WPE) void k_knn_pruned(GridView g, RegistrationBuffers rb, PoseArg ps_val,
                                                    const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
                                                    int forced, int nb_real, double* __restrict__ search_pose_out) {
   // the pose sits in the control block: its load goes out together with the flags instead of after the branch on them
@@ -720,7 +765,7 @@ __global__ __launch_bounds__(BS) void k_knn_pruned(GridView g, RegistrationBuffe
   Knn5 k;
   bool need;
   const GlobalCells src{g, reinterpret_cast<const uint4*>(g.blocks)};
-  knn_search_query<LPQ>(src, g, live && g.n_pts > 0, wx, wy, wz, sub, leader, k, need);
+  knn_search_query<LPQ, GlobalCells, BAL>(src, g, live && g.n_pts > 0, wx, wy, wz, sub, leader, k, need);
   if (live) knn_store<LPQ>(rb, g.pts, qi, sub, k, need, wx, wy, wz);
 }
 
@@ -1708,13 +1753,13 @@ int register_blocks(int n) { return nblk(n, kBlock); }
 static inline int shard_bound(const RegistrationBuffers& rb) {
   return rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;
 }
-template <int LPQ, int BS>
+template <int LPQ, int BS, bool BAL = false, int WPE = 1>
 static void launch_knn_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                          const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
   int nq = nblk(shard_bound(rb), BS / LPQ);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_knn_pruned<LPQ, BS>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
+  hipLaunchKernelGGL((k_knn_pruned<LPQ, BS, BAL, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
 }
 template <int BS, int TCAP, int HCAP>
 static void launch_knn_tile_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
@@ -1732,6 +1777,9 @@ void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, c
     case 8: launch_knn_t<8, 256>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
     // 128-thread workgroups: measured 29.3 us per pass against 30.3 us at 256 (shorter tail), 64 is no better.
     case 4: launch_knn_t<4, 128>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 5: launch_knn_t<4, 128, true>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;  // 4 lanes, balanced round 1
+    case 6: launch_knn_t<4, 128, true, 8>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;  // ... capped at 64 VGPRs
+    case 7: launch_knn_t<4, 256, true>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
     case 65: launch_knn_tile_t<256, 1024, 1024>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
     case 32: launch_knn_tile_t<128, 768, 512>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
     case 128: launch_knn_tile_t<512, 3072, 2048>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;

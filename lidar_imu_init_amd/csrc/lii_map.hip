@@ -233,6 +233,151 @@ __global__ void k_add_fold(const float4* __restrict__ add_pts, const unsigned lo
   }
 }
 
+// The same fold with EIGHT lanes per voxel group: the down-sample box (edge ds) spans at most 2 x 2 x 2 grid cells (cell edge >= ds:
+// the usual 3 ds), one per lane, so the existing in-box points are found with ONE dependent lookup chain per group instead of
+// eight in sequence; lane 0 then replays the batch points of the voxel and the lanes mark the tombstones of their own cells.
+// Groups whose box spans more cells (a caller-chosen cell edge below ds) take k_add_fold's sequential walk.  Same results: the
+// lanes are numbered in the walk's order (z outer, x inner), ties of the squared distance go to the lower lane / lower index.
+__global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ add_pts, const unsigned long long* __restrict__ keys,
+                                                   const unsigned int* __restrict__ idx, int n, float ds, GridView g,
+                                                   unsigned char* __restrict__ tomb, float4* __restrict__ ins_pts,
+                                                   unsigned int* __restrict__ ins_flag, unsigned int* __restrict__ events) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const int c = threadIdx.x & 7;
+  const bool in_range = i < n;
+  if (in_range && c == 0) ins_flag[i] = 0;
+  const unsigned long long key = in_range ? keys[i] : kInvalidKey;
+  const bool leader_pos = in_range && key != kInvalidKey && !(i > 0 && keys[i - 1] == key);  // uniform over the 8 lanes
+  if (!leader_pos) return;
+  const float4 p0 = add_pts[idx[i]];
+  float bmin[3], bmax[3], mid[3];
+  {
+    const float cc[3] = {p0.x, p0.y, p0.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      bmin[a] = floorf(cc[a] / ds) * ds;
+      bmax[a] = bmin[a] + ds;
+      mid[a] = (float)((double)bmin[a] + (double)(bmax[a] - bmin[a]) / 2.0);
+    }
+  }
+  int c0[3], c1[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float slack = 1e-6f * (fabsf(bmin[a]) + fabsf(bmax[a]) + 8.f);
+    c0[a] = (int)floorf((bmin[a] - slack) * g.inv_cs);
+    c1[a] = (int)floorf((bmax[a] + slack) * g.inv_cs);
+  }
+  const bool wide = (c1[0] - c0[0] > 1) || (c1[1] - c0[1] > 1) || (c1[2] - c0[2] > 1);  // uniform over the 8 lanes
+  const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+  const bool mine = !wide && c0[0] + dx <= c1[0] && c0[1] + dy <= c1[1] && c0[2] + dz <= c1[2];
+  int n0 = 0, best = -1;
+  float bestd = __builtin_inff();
+  uint2 r = make_uint2(0u, 0u);
+  if (g.n_pts > 0) {
+    if (mine) {
+      r = d_cell_range(g, c0[0] + dx, c0[1] + dy, c0[2] + dz);
+      for (unsigned int j = r.x; j < r.y; j++) {
+        const float4 q = g.pts[j];
+        if (bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) {
+          n0++;
+          const float d = d_dist2(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
+          if (d < bestd) { bestd = d; best = (int)j; }
+        }
+      }
+    } else if (wide && c == 0) {  // the sequential walk of k_add_fold
+      for (int cz = c0[2]; cz <= c1[2]; cz++)
+        for (int cy = c0[1]; cy <= c1[1]; cy++)
+          for (int cx = c0[0]; cx <= c1[0]; cx++) {
+            const uint2 rr = d_cell_range(g, cx, cy, cz);
+            for (unsigned int j = rr.x; j < rr.y; j++) {
+              const float4 q = g.pts[j];
+              if (bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) {
+                n0++;
+                const float d = d_dist2(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
+                if (d < bestd) { bestd = d; best = (int)j; }
+              }
+            }
+          }
+    }
+  }
+  // the group's count and its first minimum in walk order (lower lane wins a tie: the lanes are the walk's cell order)
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    const int on = __shfl_xor(n0, off), ob = __shfl_xor(best, off);
+    const float od = __shfl_xor(bestd, off);
+    const int other_lane = c ^ off;
+    n0 += on;
+    const bool take = ob >= 0 && (best < 0 || od < bestd || (od == bestd && other_lane < c));
+    // (after a step both partners hold the same winner; "other_lane < c" orders the ORIGINAL owners only in the first step,
+    // later steps compare sub-group winners whose owner order is the order of the sub-groups: the lower sub-group holds lower lanes)
+    if (take) { best = ob; bestd = od; }
+  }
+  bool ev = false, cur_new = false;
+  int cur_old = -1;
+  if (c == 0) {
+    // sequential fold over the points of this voxel, in batch order (k_add_fold)
+    float cx_ = 0, cy_ = 0, cz_ = 0, cd = 0;
+    unsigned int n_events = 0;
+    for (int t = i; t < n && keys[t] == key; t++) {
+      const float4 p = add_pts[idx[t]];
+      const float dp = d_dist2(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
+      if (!ev) {
+        const bool old_wins = (n0 > 0) && (bestd < dp);
+        float rx = p.x, ry = p.y, rz = p.z;
+        if (old_wins) { const float4 q = g.pts[best]; rx = q.x; ry = q.y; rz = q.z; }
+        if (n0 > 1 || d_same_point(p.x, p.y, p.z, rx, ry, rz)) {
+          ev = true;
+          n_events++;
+          cur_new = !old_wins;
+          cur_old = old_wins ? best : -1;
+          cx_ = rx; cy_ = ry; cz_ = rz;
+          cd = old_wins ? bestd : dp;
+        }
+      } else {
+        const bool cur_wins = cd < dp;
+        const float rx = cur_wins ? cx_ : p.x, ry = cur_wins ? cy_ : p.y, rz = cur_wins ? cz_ : p.z;
+        if (d_same_point(p.x, p.y, p.z, rx, ry, rz)) {
+          n_events++;
+          if (!cur_wins) { cur_new = true; cur_old = -1; cx_ = p.x; cy_ = p.y; cz_ = p.z; cd = dp; }
+        }
+      }
+    }
+    if (ev) {
+      atomicAdd(events, n_events);
+      if (cur_new) {
+        ins_pts[i] = make_float4(cx_, cy_, cz_, 0.f);
+        ins_flag[i] = 1;
+      }
+    }
+  }
+  const int lead = (threadIdx.x & 63) & ~7;
+  ev = __shfl((int)ev, lead) != 0;
+  cur_old = __shfl(cur_old, lead);
+  if (!ev) return;
+  // delete every existing in-box point except a surviving one
+  if (n0 == 1) {
+    if (c == 0 && best != cur_old) tomb[best] = 1;
+  } else if (n0 > 1) {
+    if (mine) {
+      for (unsigned int j = r.x; j < r.y; j++) {
+        const float4 q = g.pts[j];
+        if ((int)j != cur_old && bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) tomb[j] = 1;
+      }
+    } else if (wide && c == 0) {
+      for (int cz = c0[2]; cz <= c1[2]; cz++)
+        for (int cy = c0[1]; cy <= c1[1]; cy++)
+          for (int cx = c0[0]; cx <= c1[0]; cx++) {
+            const uint2 rr = d_cell_range(g, cx, cy, cz);
+            for (unsigned int j = rr.x; j < rr.y; j++) {
+              const float4 q = g.pts[j];
+              if ((int)j != cur_old && bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z)
+                tomb[j] = 1;
+            }
+          }
+    }
+  }
+}
+
 __global__ void k_alive_flags(const unsigned char* __restrict__ tomb, int n, unsigned int* __restrict__ alive) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) alive[i] = tomb[i] ? 0u : 1u;
@@ -285,7 +430,8 @@ void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsig
 }
 void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
                      unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_add_fold, dim3(nblk(n, 128)), dim3(128), 0, s, add_pts, keys, idx, n, ds, g, tomb, ins_pts, ins_flag, events);
+  (void)&k_add_fold;  // kept as the reference form of the walk (k_add_fold8 falls back to it lane by lane for wide boxes)
+  if (n > 0) hipLaunchKernelGGL(k_add_fold8, dim3(nblk(n * 8, 256)), dim3(256), 0, s, add_pts, keys, idx, n, ds, g, tomb, ins_pts, ins_flag, events);
 }
 void launch_alive_flags(const unsigned char* tomb, int n, unsigned int* alive, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_alive_flags, dim3(nblk(n, 256)), dim3(256), 0, s, tomb, n, alive);
