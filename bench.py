@@ -428,6 +428,11 @@ def cpu_baseline(wl, states0, tables, no_downsample, gpu_results, budget_s=14.0)
     va, na, sa, _, _ = run(ncores, 4.0, 64)
     extra = ""
     if O.ref_available():  # the k-NN stage through the reference's own tree (3 threads), beside the port's tree
+        # (the reference tree prints from its rebuild thread - "Multi thread started" / "Rebuild thread terminated normally": its
+        # stdout goes to stderr for as long as it lives, the bench's stdout carries the ONE JSON line only)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
         try:
             rt = O.Tree("ref")
             rt.build(wl["map"])
@@ -440,8 +445,15 @@ def cpu_baseline(wl, states0, tables, no_downsample, gpu_results, budget_s=14.0)
             t0 = time.perf_counter(); tree.knn(q, threads=3); t_port = time.perf_counter() - t0
             extra = (f"; k-NN stage alone on {len(q)} queries, 3 threads: unmodified reference ikd-Tree {t_ref * 1e3:.0f} ms, "
                      f"the port's tree {t_port * 1e3:.0f} ms")
+            rt.close()
         except Exception as e:  # the reference tree is a checker: never let it break the bench line
             extra = f"; reference-tree timing failed: {e}"
+        finally:
+            time.sleep(0.3)  # its thread prints on the way out
+            import ctypes
+            ctypes.CDLL(None).fflush(None)  # ... into the C library's stdio buffer: flush it while fd 1 still points at stderr
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     base = {"value": v3, "unit": "scans/s", "cores": 3, "kind": "port",
             "threads_1": v1, "threads_all": va, "host_cores": ncores,
             "sample": f"{n3} scans of the same workload and the same step (de-skew + voxel grid + iterated update) on 3 OpenMP threads "
