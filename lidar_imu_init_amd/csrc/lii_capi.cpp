@@ -31,7 +31,8 @@ struct lii_context {
   hipStream_t stream = nullptr;
   std::string err;
 
-  // ---- local map (device resident; the sorted point array d_map[0, n_map) is the source of truth)
+  // ---- local map (device resident).  d_pts is the live point array: cell by cell with slack behind every cell (in-place
+  // updates, lii_map.hip); d_map_unsorted / d_map are staging for (re)builds (input, then cell-sorted and compact).
   float ds = 0.2f;              // ikd-Tree downsample box (set_downsample_param)
   unsigned char* d_tomb = nullptr;
   float4* d_batch = nullptr;    // a host-provided Add_Points batch (M)
@@ -41,6 +42,17 @@ struct lii_context {
   int* d_counts = nullptr;      // [0] add list, [1] no-downsample list, [2] alive, [3] inserted, [4] total, [5] events
   float4* d_map_unsorted = nullptr;
   float4* d_map = nullptr;
+  float4* d_pts = nullptr;            // pts_cap slots
+  unsigned int pts_cap = 0;
+  unsigned int* d_cell_cap = nullptr; // capacity end of every cell entry (same indexing as d_cells)
+  unsigned int* d_tp = nullptr;       // per cell entry: on-work-list bit | pending inserts
+  unsigned int *d_cs_a = nullptr, *d_cs_b = nullptr;  // per cell entry scratch (capacities / counts and their scans)
+  unsigned int* d_work = nullptr;     // work list of the update in flight (cell entries)
+  unsigned int work_cap = 0;
+  unsigned int *d_ins_e = nullptr, *d_ins_e2 = nullptr;  // cell entry of every insert (fold output / plain list)
+  int* d_mapctr = nullptr;            // kMapCtr* counters
+  int n_used = 0;                     // host copy of kMapCtrUsed as of the last map_counters()
+  bool map_dirty = false;             // an update has been enqueued since the last map_counters(): n_map / n_used / n_blocks are stale
   unsigned long long *d_keys_a = nullptr, *d_keys_b = nullptr, *d_keys_c = nullptr;
   unsigned int *d_idx_a = nullptr, *d_idx_b = nullptr;
   BlockEntry* d_blocks = nullptr;   // capacity-managed (grows on demand)
@@ -168,11 +180,11 @@ unsigned int next_pow2(unsigned int v) {
 
 GridView grid_view(const lii_context* c) {
   GridView g;
-  g.pts = c->d_map;
+  g.pts = c->d_pts;
   g.blocks = c->d_blocks;
   g.cells = c->d_cells;
   g.block_mask = c->block_mask;
-  g.n_pts = c->n_map;
+  g.n_pts = c->map_dirty ? std::max(c->n_map, 1) : c->n_map;  // (an update in flight may have put the first points in)
   g.cs = c->cell_size;
   g.inv_cs = 1.0f / c->cell_size;
   g.max_d2 = c->cfg.max_match_dist2;
@@ -204,119 +216,189 @@ PoseArg pose_of(const lii_state& s) {
   return p;
 }
 
-// Rebuilds the device k-NN index from n float4 points already in d_map_unsorted:
-// key (block | local cell) -> radix sort -> gather -> block ids by scan -> per-block cell tables + block table.
-// The first n_sorted points are known to be in key order already (the survivors of the previous index, compacted in
-// place): only the tail is sorted and the two runs are merged — a map update then costs a merge pass over the map
-// instead of an 8-pass radix sort of it.  The resulting order is the one a stable sort of the whole array gives.
-int build_index(lii_handle h, int n, int n_sorted = 0) {
+// Builds the device map from n float4 points in d_map_unsorted:
+// key (block | local cell) -> radix sort -> gather (d_map: cell-sorted, compact) -> block ids by scan -> per-block cell tables +
+// block table -> capacities with slack -> scan -> spread into d_pts (the live array) + cell_cap.  Room for `extra_blocks` more
+// 8x8x8 blocks is provisioned in the tables (in-place updates create blocks without a rebuild).
+int build_index(lii_handle h, int n, int extra_blocks = 0) {
   hipStream_t s = h->stream;
   h->n_map = n;
   h->n_blocks = 0;
-  if (h->n_map_pinned) h->n_map_pinned[0] = n;
-  if (n == 0) return LII_OK;
-  const float inv_cs = 1.0f / h->cell_size;
-  launch_map_keys(h->d_map_unsorted, n, inv_cs, h->d_keys_a, h->d_idx_a, s);
-  unsigned long long* sorted_keys = h->d_keys_b;
-  const int n_new = n - n_sorted;
-  if (n_sorted <= 0) {
+  h->n_used = 0;
+  h->map_dirty = false;
+  unsigned int n_blocks = 0;
+  unsigned int* ranks = reinterpret_cast<unsigned int*>(h->d_keys_a);  // free after the sort
+  if (n > 0) {
+    const float inv_cs = 1.0f / h->cell_size;
+    launch_map_keys(h->d_map_unsorted, n, inv_cs, h->d_keys_a, h->d_idx_a, s);
     sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, n, s);
     launch_map_gather(h->d_map_unsorted, h->d_idx_b, n, h->d_map, s);
-  } else if (n_new == 0) {
-    HIPCHK(h, hipMemcpyAsync(h->d_map, h->d_map_unsorted, sizeof(float4) * size_t(n), hipMemcpyDeviceToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->d_keys_c, h->d_keys_a, sizeof(unsigned long long) * size_t(n), hipMemcpyDeviceToDevice, s));
-    sorted_keys = h->d_keys_c;
-  } else {
-    sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a + n_sorted, h->d_keys_b + n_sorted, h->d_idx_a + n_sorted,
-                   h->d_idx_b + n_sorted, n_new, s);
-    launch_map_gather(h->d_map_unsorted, h->d_idx_b + n_sorted, n_new, h->d_ins, s);  // the tail, in key order
-    merge_pairs_u64_f4(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b + n_sorted, h->d_keys_c, h->d_map_unsorted,
-                       h->d_ins, h->d_map, n_sorted, n_new, s);
-    sorted_keys = h->d_keys_c;
+    unsigned int* flags = h->d_idx_a;  // free after the sort
+    launch_block_flags(h->d_keys_b, n, flags, s);
+    inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, flags, ranks, n, s);
+    HIPCHK(h, hipMemcpyAsync(h->h_small, ranks + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    std::memcpy(&n_blocks, h->h_small, sizeof(unsigned int));
   }
-  unsigned int* flags = h->d_idx_a;                                   // free after the sort
-  unsigned int* ranks = reinterpret_cast<unsigned int*>(h->d_keys_a);  // free after the sort
-  launch_block_flags(sorted_keys, n, flags, s);
-  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, flags, ranks, n, s);
-  HIPCHK(h, hipMemcpyAsync(h->h_small, ranks + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipStreamSynchronize(s));
-  unsigned int n_blocks = 0;
-  std::memcpy(&n_blocks, h->h_small, sizeof(unsigned int));
-  if (size_t(n_blocks) > h->cells_cap_blocks) {
-    if (h->d_cells) HIPCHK(h, hipFree(h->d_cells));
-    h->d_cells = nullptr;
-    size_t want = std::max<size_t>(size_t(n_blocks) * 3 / 2, 4096);
+  const size_t want_blocks = size_t(n_blocks) + size_t(std::max(extra_blocks, 0));
+  if (want_blocks > h->cells_cap_blocks || !h->d_cell_cap) {
+    for (void* q : {static_cast<void*>(h->d_cells), static_cast<void*>(h->d_cell_cap), static_cast<void*>(h->d_tp), static_cast<void*>(h->d_cs_a),
+                    static_cast<void*>(h->d_cs_b)})
+      if (q) HIPCHK(h, hipFree(q));
+    h->d_cells = nullptr; h->d_cell_cap = nullptr; h->d_tp = nullptr; h->d_cs_a = nullptr; h->d_cs_b = nullptr;
+    const size_t want = std::max<size_t>(std::max<size_t>(want_blocks * 2, h->cells_cap_blocks), 4096);
     HIPCHK(h, dmalloc(&h->d_cells, want * 512));
+    HIPCHK(h, dmalloc(&h->d_cell_cap, want * 512));
+    HIPCHK(h, dmalloc(&h->d_tp, want * 512));
+    HIPCHK(h, dmalloc(&h->d_cs_a, want * 512));
+    HIPCHK(h, dmalloc(&h->d_cs_b, want * 512));
     h->cells_cap_blocks = want;
+    if (want * 512 * sizeof(unsigned int) + 4096 > h->sort_temp_bytes) {  // the scans over the cell entries need their temporary storage
+      if (h->d_sort_temp) HIPCHK(h, hipFree(h->d_sort_temp));
+      h->d_sort_temp = nullptr;
+      h->sort_temp_bytes = std::max(h->sort_temp_bytes, sort_temp_bytes(int(std::min<size_t>(want * 512, 0x7FFFFFFF))));
+      HIPCHK(h, hipMalloc(&h->d_sort_temp, h->sort_temp_bytes));
+    }
   }
-  unsigned int bcap = next_pow2(std::max(1024u, 8u * n_blocks));  // load factor <= 1/8: first probe decides
+  unsigned int bcap = next_pow2(std::max(1024u, 8u * (unsigned int)want_blocks));  // load factor <= 1/8 now, <= 1/2 before the next rebuild
   if (bcap > h->blocks_cap) {
     if (h->d_blocks) HIPCHK(h, hipFree(h->d_blocks));
     h->d_blocks = nullptr;
     HIPCHK(h, dmalloc(&h->d_blocks, size_t(bcap)));
     h->blocks_cap = bcap;
   }
+  bcap = h->blocks_cap;
   h->block_mask = bcap - 1;
   h->n_blocks = int(n_blocks);
-  HIPCHK(h, hipMemsetAsync(h->d_cells, 0, sizeof(uint2) * 512 * size_t(n_blocks), s));
+  // every table entry of the pool starts out zero: blocks created later by k_ins_cells find an empty cell table
+  const size_t entries = h->cells_cap_blocks * 512;
+  HIPCHK(h, hipMemsetAsync(h->d_cells, 0, sizeof(uint2) * entries, s));
+  HIPCHK(h, hipMemsetAsync(h->d_cell_cap, 0, sizeof(unsigned int) * entries, s));
+  HIPCHK(h, hipMemsetAsync(h->d_tp, 0, sizeof(unsigned int) * entries, s));
+  HIPCHK(h, hipMemsetAsync(h->d_tomb, 0, size_t(h->pts_cap), s));
+  HIPCHK(h, hipMemsetAsync(h->d_mapctr, 0, sizeof(int) * kMapCtrWords, s));
   launch_table_clear(h->d_blocks, bcap, s);
-  launch_cells_fill(sorted_keys, ranks, n, h->d_blocks, h->block_mask, h->d_cells, s);
+  if (n > 0) {
+    launch_cells_fill(h->d_keys_b, ranks, n, h->d_blocks, h->block_mask, h->d_cells, s);
+    const int ne = int(n_blocks) * 512;
+    unsigned int* caps = h->d_cs_a;
+    unsigned int* capsum = h->d_cs_b;
+    launch_cell_caps(h->d_cells, ne, caps, s);
+    inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, caps, capsum, ne, s);
+    launch_spread(h->d_map, h->d_cells, h->d_cell_cap, caps, capsum, ne, h->d_pts, h->d_mapctr, n, int(n_blocks), s);
+  }
   HIPCHK(h, hipGetLastError());
-  if (h->n_map_pinned) h->n_map_pinned[0] = n;
-  return LII_OK;
+  int rc = LII_OK;
+  {  // the slots in use (sum of the capacities) - and a first capacity check
+    HIPCHK(h, hipMemcpyAsync(h->h_small + 3072, h->d_mapctr, sizeof(int) * kMapCtrWords, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    int c[kMapCtrWords];
+    std::memcpy(c, h->h_small + 3072, sizeof(c));
+    h->n_used = c[kMapCtrUsed];
+    if ((unsigned int)h->n_used > h->pts_cap) rc = fail(h, LII_ERR_CAPACITY, "local map with its per-cell slack exceeds the point array");
+  }
+  return rc;
 }
 
 int commit_map(lii_handle) { return LII_OK; }  // the device map is always current
 
-// Applies one Add_Points batch to the device map.  `list` holds the batch (device float4, `n_bound` entries of which
-// *n_dev are valid when n_dev != nullptr).  When `extra` != nullptr its *extra_n points are appended without
-// down-sampling afterwards (map_incremental's PointNoNeedDownsample).  Ends with ONE synchronising read of the counters
-// and an index rebuild.
-int map_apply(lii_handle h, const float4* list, int n_bound, const int* n_dev, bool downsample, const float4* extra,
-              const int* extra_n, int extra_bound, int* events_out) {
-  hipStream_t s = h->stream;
-  const int n_old = h->n_map;
-  HIPCHK(h, hipMemsetAsync(h->d_counts + 2, 0, 4 * sizeof(int), s));
-  if (downsample && n_bound > 0) {
-    launch_add_keys(list, n_bound, n_dev, h->ds, h->d_keys_a, h->d_idx_a, s);
-    sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, n_bound, s);
-    if (n_old > 0) HIPCHK(h, hipMemsetAsync(h->d_tomb, 0, size_t(n_old), s));
-    launch_add_fold(list, h->d_keys_b, h->d_idx_b, n_bound, h->ds, grid_view(h), h->d_tomb, h->d_ins, h->d_u32_a,
-                    reinterpret_cast<unsigned int*>(h->d_counts + 5), s);
-    // surviving old points -> d_map_unsorted[0, alive)
-    if (n_old > 0) {
-      launch_alive_flags(h->d_tomb, n_old, h->d_u32_b, s);
-      inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_b, h->d_u32_c, n_old, s);
-      launch_compact_f4(h->d_map, h->d_u32_b, h->d_u32_c, n_old, h->d_map_unsorted, 0, h->d_counts + 2, s);
-    }
-    // inserted points -> behind them
-    inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_a, h->d_u32_c, n_bound, s);
-    launch_compact_f4(h->d_ins, h->d_u32_a, h->d_u32_c, n_bound, h->d_ins_c, 0, h->d_counts + 3, s);
-    launch_append_f4(h->d_ins_c, h->d_counts + 3, n_bound, h->d_map_unsorted, h->cfg.max_map_points, h->d_counts + 2, nullptr, s);
-  } else {
-    if (n_old > 0) HIPCHK(h, hipMemcpyAsync(h->d_map_unsorted, h->d_map, sizeof(float4) * size_t(n_old), hipMemcpyDeviceToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->d_counts + 2, &h->n_map_pinned[0], sizeof(int), hipMemcpyHostToDevice, s));
-    if (n_bound > 0) {
-      // plain Add_Points(points, false): append the whole batch
-      launch_append_f4(list, n_dev, n_bound, h->d_map_unsorted, h->cfg.max_map_points, h->d_counts + 2, nullptr, s);
-      if (n_dev) HIPCHK(h, hipMemcpyAsync(h->d_counts + 3, n_dev, sizeof(int), hipMemcpyDeviceToDevice, s));
-      else { h->n_map_pinned[1] = n_bound; HIPCHK(h, hipMemcpyAsync(h->d_counts + 3, &h->n_map_pinned[1], sizeof(int), hipMemcpyHostToDevice, s)); }
-    }
+// Host copies of the device counters (one small synchronising read).  A capacity flag raised by an update in flight turns into
+// LII_ERR_CAPACITY here - the map has then lost inserts and is rebuilt from what it holds.
+int map_rebuild(lii_handle h, int extra_blocks);
+int map_counters(lii_handle h, bool already_synced = false) {
+  if (!h->map_dirty) return LII_OK;
+  if (!already_synced) {
+    HIPCHK(h, hipMemcpyAsync(h->h_small + 3072, h->d_mapctr, sizeof(int) * kMapCtrWords, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
   }
-  if (extra && extra_bound > 0)
-    launch_append_f4(extra, extra_n, extra_bound, h->d_map_unsorted, h->cfg.max_map_points, h->d_counts + 2, h->d_counts + 3, s);
-  launch_sum3(h->d_counts + 2, h->d_counts + 3, extra ? extra_n : nullptr, h->d_counts + 4, s);
-  HIPCHK(h, hipMemcpyAsync(h->h_small + 3072, h->d_counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
+  int c[kMapCtrWords];
+  std::memcpy(c, h->h_small + 3072, sizeof(c));
+  h->n_used = c[kMapCtrUsed];
+  h->n_map = c[kMapCtrValid];
+  h->n_blocks = c[kMapCtrBlocks];
+  h->map_dirty = false;
+  if (c[kMapCtrOverflow]) {
+    (void)map_rebuild(h, 0);
+    return fail(h, LII_ERR_CAPACITY, "local map update ran out of room (point-array tail, block tables or work list); the map was rebuilt from the points it holds");
+  }
+  return LII_OK;
+}
+// Gathers the live points into d_map_unsorted (entry order) and returns their number.
+int map_gather(lii_handle h, int* n_out) {
+  hipStream_t s = h->stream;
+  const int ne = h->n_blocks * 512;
+  *n_out = 0;
+  if (ne <= 0) return LII_OK;
+  launch_cell_counts(h->d_cells, ne, h->d_cs_a, s);
+  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_cs_a, h->d_cs_b, ne, s);
+  launch_gather_live(h->d_pts, h->d_cells, h->d_cs_b, ne, h->d_map_unsorted, h->cfg.max_map_points, s);
+  HIPCHK(h, hipMemcpyAsync(h->h_small + 3000, h->d_cs_b + (ne - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
-  int cnt[8];
-  std::memcpy(cnt, h->h_small + 3072, sizeof(cnt));
-  if (events_out) *events_out = cnt[5];
-  const int total = cnt[4];
-  // (the appends above dropped every write at or beyond max_map_points: nothing outside d_map_unsorted was touched, and the
-  // live map - d_map and its index - is only replaced by build_index below, so it is unchanged when this error returns)
-  if (total > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "local map exceeds max_map_points");
-  h->n_map_pinned[0] = total;
-  return build_index(h, total, cnt[2]);  // the cnt[2] survivors lead the array in key order
+  unsigned int n = 0;
+  std::memcpy(&n, h->h_small + 3000, sizeof(n));
+  *n_out = int(std::min<unsigned int>(n, (unsigned int)h->cfg.max_map_points));
+  return LII_OK;
+}
+// Garbage collection: the live points, re-sorted and laid out with fresh slack (restores the cell-sorted order of the array).
+int map_rebuild(lii_handle h, int extra_blocks) {
+  int n = 0;
+  int rc = map_gather(h, &n);
+  if (rc != LII_OK) return rc;
+  return build_index(h, n, extra_blocks);
+}
+
+// Applies one Add_Points batch IN PLACE (lii_map.hip): `list` holds n_list points (device float4) added with or without the
+// per-voxel down-sampling; `extra` (n_extra points) is added without it afterwards (map_incremental's PointNoNeedDownsample).
+// Nothing is synchronised: the counters move on the device (map_counters reads them when somebody asks).  The capacity check is
+// made BEFORE anything is touched and is conservative: n_valid + n_list + n_extra <= max_map_points (a down-sampled batch may
+// replace points instead of adding them; the check still counts every point of it) - a refused batch leaves the map untouched.
+int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra) {
+  hipStream_t s = h->stream;
+  int rc = map_counters(h);
+  if (rc != LII_OK) return rc;
+  const int n_ins = n_list + n_extra;
+  if (n_ins <= 0) return LII_OK;
+  if ((long long)h->n_map + n_ins > (long long)h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "local map exceeds max_map_points");
+  // room for the update: tail of the point array (a touched cell may move there with its slack), block tables, work list
+  // (an insert moves at most one cell to the tail, with its points and fresh slack: ~14 slots for the usual 9-point cell; should a
+  // batch of unusually crowded cells still run out, the update raises the overflow flag and the next map_counters reports it)
+  const long long tail_need = 24ll * n_ins + 4096;
+  const unsigned int work_need = 9u * (unsigned int)n_list + (unsigned int)n_ins + 64u;
+  if (work_need > h->work_cap) return fail(h, LII_ERR_CAPACITY, "Add_Points batch larger than the work list of the in-place update");
+  if ((long long)h->pts_cap - h->n_used < tail_need || size_t(h->n_blocks) + size_t(n_ins) > h->cells_cap_blocks ||
+      2ull * (size_t(h->n_blocks) + size_t(n_ins)) > size_t(h->blocks_cap)) {
+    rc = map_rebuild(h, n_ins);
+    if (rc != LII_OK) return rc;
+    if ((long long)h->pts_cap - h->n_used < tail_need) return fail(h, LII_ERR_CAPACITY, "local map: no room left behind the cells for an in-place update");
+  }
+  const GridView g = grid_view(h);
+  h->map_dirty = true;
+  const unsigned int tables_cap = (unsigned int)h->cells_cap_blocks;
+  HIPCHK(h, hipMemsetAsync(h->d_mapctr + kMapCtrEvents, 0, sizeof(int), s));
+  bool have_a = false;
+  if (downsample && n_list > 0) {
+    launch_add_keys(list, n_list, nullptr, h->ds, h->d_keys_a, h->d_idx_a, s);
+    sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, n_list, s);
+    launch_add_fold(list, h->d_keys_b, h->d_idx_b, n_list, h->ds, g, h->d_tomb, h->d_ins, h->d_u32_a,
+                    reinterpret_cast<unsigned int*>(h->d_mapctr + kMapCtrEvents), h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s);
+    launch_ins_cells(h->d_ins, h->d_u32_a, n_list, nullptr, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp, h->d_work,
+                     h->d_mapctr, h->work_cap, s);
+    have_a = true;
+  } else if (n_list > 0) {
+    launch_ins_cells(list, nullptr, n_list, nullptr, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp, h->d_work, h->d_mapctr,
+                     h->work_cap, s);
+    have_a = true;
+  }
+  if (n_extra > 0)
+    launch_ins_cells(extra, nullptr, n_extra, nullptr, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e2, h->d_tp, h->d_work, h->d_mapctr,
+                     h->work_cap, s);
+  launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap, (int)work_need, s);
+  if (have_a) launch_ins_write(downsample ? h->d_ins : list, h->d_ins_e, n_list, nullptr, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, s);
+  if (n_extra > 0) launch_ins_write(extra, h->d_ins_e2, n_extra, nullptr, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, s);
+  if (!have_a && n_extra <= 0) launch_ins_write(list, h->d_ins_e, 0, nullptr, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, s);
+  HIPCHK(h, hipGetLastError());
+  // the block table may have grown: kernels launched from now on must see it (grid_view reads the host copy of the mask only)
+  return LII_OK;
 }
 
 void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, int forced) {
@@ -644,6 +726,14 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   const size_t NM = std::max(N, M);
   CK(dmalloc(&h->d_map_unsorted, M));
   CK(dmalloc(&h->d_map, M));
+  h->pts_cap = (unsigned int)std::min<size_t>(3 * M + 65536, 0x7FFFFFF0u);
+  CK(dmalloc(&h->d_pts, size_t(h->pts_cap)));
+  h->work_cap = (unsigned int)std::min<size_t>(10 * NM + 4096, 0x7FFFFFF0u);
+  CK(dmalloc(&h->d_work, size_t(h->work_cap)));
+  CK(dmalloc(&h->d_ins_e, NM));
+  CK(dmalloc(&h->d_ins_e2, NM));
+  CK(dmalloc(&h->d_mapctr, kMapCtrWords));
+  CK(hipMemset(h->d_mapctr, 0, sizeof(int) * kMapCtrWords));
   CK(dmalloc(&h->d_keys_a, M));
   CK(dmalloc(&h->d_keys_b, M));
   CK(dmalloc(&h->d_keys_c, M));
@@ -654,10 +744,18 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_blocks, size_t(h->blocks_cap)));
   h->cells_cap_blocks = std::max<size_t>(4096, M / 64);
   CK(dmalloc(&h->d_cells, h->cells_cap_blocks * 512));
+  CK(dmalloc(&h->d_cell_cap, h->cells_cap_blocks * 512));
+  CK(dmalloc(&h->d_tp, h->cells_cap_blocks * 512));
+  CK(dmalloc(&h->d_cs_a, h->cells_cap_blocks * 512));
+  CK(dmalloc(&h->d_cs_b, h->cells_cap_blocks * 512));
+  CK(hipMemset(h->d_cells, 0, sizeof(uint2) * h->cells_cap_blocks * 512));
+  CK(hipMemset(h->d_cell_cap, 0, sizeof(unsigned int) * h->cells_cap_blocks * 512));
+  CK(hipMemset(h->d_tp, 0, sizeof(unsigned int) * h->cells_cap_blocks * 512));
   CK(dmalloc(&h->d_counter, 4));
   CK(dmalloc(&h->d_knn_stats, 8));
   CK(hipMemset(h->d_knn_stats, 0, 32));
-  CK(dmalloc(&h->d_tomb, M));
+  CK(dmalloc(&h->d_tomb, size_t(h->pts_cap)));
+  CK(hipMemset(h->d_tomb, 0, size_t(h->pts_cap)));
   CK(dmalloc(&h->d_ins, M));
   CK(dmalloc(&h->d_batch, M));
   CK(dmalloc(&h->d_ins_c, M));
@@ -670,7 +768,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(hipMemset(h->d_counts, 0, 32));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->n_map_pinned), 64, hipHostMallocDefault));
   h->n_map_pinned[0] = 0;
-  h->sort_temp_bytes = sort_temp_bytes(int(NM));
+  h->sort_temp_bytes = sort_temp_bytes(int(std::max<size_t>(NM, h->cells_cap_blocks * 512)));
   CK(hipMalloc(&h->d_sort_temp, h->sort_temp_bytes));
   CK(dmalloc(&h->d_scan, N));
   CK(dmalloc(&h->d_body, N));
@@ -747,7 +845,7 @@ int lii_destroy(lii_handle h) {
   }
   mailbox_close(&h->mailbox);
   if (h->d_mb_seq) (void)hipFree(h->d_mb_seq);
-  void* dev[] = {h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
+  void* dev[] = {h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_knn_stats, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
                  h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
@@ -817,51 +915,65 @@ int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_
   if (n == 0) return LII_OK;
   int rc = upload_xyz(h, xyz, n, stride_bytes, h->d_batch);
   if (rc != LII_OK) return rc;
-  int ev = 0;
-  rc = map_apply(h, h->d_batch, n, nullptr, downsample_on != 0, nullptr, nullptr, 0, &ev);
+  h->have_search = false;
+  rc = map_apply(h, h->d_batch, n, downsample_on != 0, nullptr, 0);
   if (rc != LII_OK) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int ev = 0;  // this entry point reports Add_Points' counter: one synchronising read (lii_map_incremental does not)
+  HIPCHK(h, hipMemcpyAsync(h->h_small + 3090, h->d_mapctr + kMapCtrEvents, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  rc = map_counters(h);  // synchronises; reports a capacity problem of this very update
+  if (rc != LII_OK) return rc;
+  std::memcpy(&ev, h->h_small + 3090, sizeof(int));
   if (n_added) *n_added = downsample_on ? ev : 0;
   return LII_OK;
 }
 int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int32_t* n_deleted) {
   if (!h || (!boxes && n_boxes > 0) || n_boxes < 0 || n_boxes > 4096) return fail(h, LII_ERR_INVALID, "lii_map_delete_boxes: bad arguments (<= 4096 boxes)");
   if (n_deleted) *n_deleted = 0;
+  int rc = map_counters(h);
+  if (rc != LII_OK) return rc;
   const int n_old = h->n_map;
   if (n_boxes == 0 || n_old == 0) return LII_OK;
   hipStream_t s = h->stream;
   float* d_boxes = reinterpret_cast<float*>(h->d_keys_b);  // scratch of the index build, free between calls
   std::memcpy(h->h_small + 4096, boxes, sizeof(float) * 6 * size_t(n_boxes));
   HIPCHK(h, hipMemcpyAsync(d_boxes, h->h_small + 4096, sizeof(float) * 6 * size_t(n_boxes), hipMemcpyHostToDevice, s));
-  launch_box_tomb(h->d_map, n_old, d_boxes, n_boxes, h->d_tomb, h->d_u32_b, s);
-  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_b, h->d_u32_c, n_old, s);
-  launch_compact_f4(h->d_map, h->d_u32_b, h->d_u32_c, n_old, h->d_map_unsorted, 0, h->d_counts + 2, s);
-  HIPCHK(h, hipMemcpyAsync(h->h_small + 3072, h->d_counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipStreamSynchronize(s));
-  int cnt[8];
-  std::memcpy(cnt, h->h_small + 3072, sizeof(cnt));
-  const int alive = cnt[2];
-  if (n_deleted) *n_deleted = n_old - alive;
-  if (alive == n_old) return LII_OK;  // nothing inside the boxes: the map and its index stay as they are
-  h->have_search = false;
-  int rc = build_index(h, alive, alive);  // the survivors are still in key order: no sort, no merge
+  // in place: every cell walks its live points, the cells that lose points squeeze them out (k_cell_apply)
+  const int ne = h->n_blocks * 512;
+  if ((unsigned int)ne > h->work_cap) {  // more cells than the work list holds: rebuild-free fallback is not worth it - grow the list
+    if (h->d_work) HIPCHK(h, hipFree(h->d_work));
+    h->d_work = nullptr;
+    h->work_cap = (unsigned int)ne + 4096u;
+    HIPCHK(h, dmalloc(&h->d_work, size_t(h->work_cap)));
+  }
+  h->map_dirty = true;
+  launch_box_tomb_cells(h->d_pts, h->d_cells, ne, d_boxes, n_boxes, h->d_tomb, h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s);
+  launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap, ne, s);
+  launch_ins_write(h->d_pts, h->d_ins_e, 0, nullptr, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, s);  // (re-arms the work list)
+  rc = map_counters(h);
   if (rc != LII_OK) return rc;
-  HIPCHK(h, hipStreamSynchronize(s));
+  if (n_deleted) *n_deleted = n_old - h->n_map;
+  if (h->n_map != n_old) h->have_search = false;
   return LII_OK;
 }
 int lii_map_size(lii_handle h, int32_t* n_valid) {
   if (!h || !n_valid) return LII_ERR_INVALID;
+  int rc = map_counters(h);  // (a pending in-place update: one small synchronising read)
   *n_valid = h->n_map;
-  return LII_OK;
+  return rc;
 }
 int lii_map_download(lii_handle h, float* xyz_out, int32_t capacity, int32_t* n) {
   if (!h || !n) return LII_ERR_INVALID;
-  const int cnt = h->n_map;
+  int rc = map_counters(h);
+  if (rc != LII_OK) return rc;
+  int cnt = h->n_map;
   *n = cnt;
   if (!xyz_out) return LII_OK;
   if (capacity < cnt) return fail(h, LII_ERR_CAPACITY, "lii_map_download: capacity too small");
   if (cnt == 0) return LII_OK;
-  HIPCHK(h, hipMemcpyAsync(h->h_stage, h->d_map, sizeof(float4) * size_t(cnt), hipMemcpyDeviceToHost, h->stream));
+  rc = map_gather(h, &cnt);  // the live points, cell by cell (the array itself has slack between the cells)
+  if (rc != LII_OK) return rc;
+  *n = cnt;
+  HIPCHK(h, hipMemcpyAsync(h->h_stage, h->d_map_unsorted, sizeof(float4) * size_t(cnt), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < cnt; i++) {
     xyz_out[3 * size_t(i)] = h->h_stage[i].x;
@@ -1237,17 +1349,21 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
   // The sizes of the two lists, now: a converged map takes a few thousand of the ~100 k points, and everything downstream
   // (voxel keys, the batch sort, the per-voxel fold, the insert compaction) is launched for the exact count instead of the
   // scan-sized bound - one small host round trip (~15 us) against ~80 us of kernels working on padding.
-  HIPCHK(h, hipMemcpyAsync(h->h_small + 3080, h->d_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  // (the same round trip brings the map's counters up to date: the previous update ran without a synchronisation)
+  HIPCHK(h, hipMemcpyAsync(h->h_small + 3090, h->d_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(h->h_small + 3072, h->d_mapctr, sizeof(int) * kMapCtrWords, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   int n_lists[2];
-  std::memcpy(n_lists, h->h_small + 3080, sizeof(n_lists));
+  std::memcpy(n_lists, h->h_small + 3090, sizeof(n_lists));
+  {
+    const int rc0 = map_counters(h, true);
+    if (rc0 != LII_OK) return rc0;
+  }
   // Add_Points(PointToAdd, true) then Add_Points(PointNoNeedDownsample, false)  (:556-557)
-  int rc = map_apply(h, h->d_list_add, n_lists[0], h->d_counts + 0, true, h->d_list_nodown, h->d_counts + 1, n_lists[1], nullptr);
+  int rc = map_apply(h, h->d_list_add, n_lists[0], true, h->d_list_nodown, n_lists[1]);
   if (rc != LII_OK) return rc;
-  int cnt[8];
-  std::memcpy(cnt, h->h_small + 3072, sizeof(cnt));  // read back by map_apply
-  if (n_add) *n_add = cnt[0];
-  if (n_no_downsample) *n_no_downsample = cnt[1];
+  if (n_add) *n_add = n_lists[0];
+  if (n_no_downsample) *n_no_downsample = n_lists[1];
   return LII_OK;
 }
 

@@ -116,7 +116,7 @@ __global__ void k_cells_fill(const unsigned long long* __restrict__ keys, const 
     unsigned int slot = hash_block((int)(bk & 0x3FFFF), (int)((bk >> 18) & 0x3FFFF), (int)((bk >> 36) & 0x3FFFF)) & block_mask;
     while (true) {
       unsigned long long prev = atomicCAS(&blocks[slot].key, kEmptyKey, bk);
-      if (prev == kEmptyKey) { blocks[slot].id = id; break; }
+      if (prev == kEmptyKey) { blocks[slot].id = id; blocks[slot].pad = 1u; break; }  // pad = "id is valid" (k_ins_cells waits on it)
       slot = (slot + 1) & block_mask;
     }
   }

@@ -72,7 +72,24 @@ void launch_compact_f4(const float4* src, const unsigned int* flag, const unsign
                        int* count, hipStream_t s);
 void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, hipStream_t s);
 void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
-                     unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, hipStream_t s);
+                     unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, unsigned int* tp, unsigned int* work,
+                     int* ctr, unsigned int work_cap, hipStream_t s);
+// in-place map update (lii_map.hip)
+void launch_touch_tombs(const unsigned char* tomb, const float4* pts, int n_slots, const BlockEntry* blocks, unsigned int mask, float inv_cs,
+                        unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s);
+void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, BlockEntry* blocks, unsigned int mask, float inv_cs,
+                      unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s);
+void launch_cell_apply(const unsigned int* work, uint2* cells, unsigned int* cell_cap, float4* pts, unsigned char* tomb, unsigned int* tp, int* ctr,
+                       unsigned int pts_cap, int launch_bound, hipStream_t s);
+void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, uint2* cells, const unsigned int* cell_cap, float4* pts,
+                      int* ctr, hipStream_t s);
+void launch_cell_caps(const uint2* cells, int n_entries, unsigned int* caps, hipStream_t s);
+void launch_spread(const float4* src, uint2* cells, unsigned int* cell_cap, const unsigned int* caps, const unsigned int* capsum, int n_entries,
+                   float4* dst, int* ctr, int n_valid, int n_blocks, hipStream_t s);
+void launch_cell_counts(const uint2* cells, int n_entries, unsigned int* cnt, hipStream_t s);
+void launch_gather_live(const float4* pts, const uint2* cells, const unsigned int* cntsum, int n_entries, float4* dst, int dst_cap, hipStream_t s);
+void launch_box_tomb_cells(const float4* pts, const uint2* cells, int n_entries, const float* boxes, int n_boxes, unsigned char* tomb, unsigned int* tp,
+                           unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s);
 void launch_box_tomb(const float4* pts, int n, const float* boxes, int n_boxes, unsigned char* tomb, unsigned int* alive, hipStream_t s);
 void launch_alive_flags(const unsigned char* tomb, int n, unsigned int* alive, hipStream_t s);
 void launch_append_f4(const float4* src, const int* count, int n_bound, float4* dst, int dst_cap, const int* off_a, const int* off_b,

@@ -45,6 +45,39 @@ __device__ __forceinline__ uint2 d_cell_range(const GridView& g, int ix, int iy,
     sl = (sl + 1) & g.block_mask;
   }
 }
+// the same lookup, also returning the cell's entry index (block id * 512 + local cell; -1: the block is not in the table)
+__device__ __forceinline__ uint2 d_cell_range_e(const GridView& g, int ix, int iy, int iz, long long& entry) {
+  const int bb = kBias >> kCoarseShift;
+  const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
+  const unsigned long long bk = d_pack_block(bx, by, bz);
+  unsigned int sl = d_hash_block(bx, by, bz) & g.block_mask;
+  while (true) {
+    BlockEntry e = g.blocks[sl];
+    if (e.key == bk) {
+      const unsigned local = (((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u);
+      entry = (long long)e.id * kCells + local;
+      return g.cells[(size_t)entry];
+    }
+    if (e.key == kEmptyKey) { entry = -1; return make_uint2(0u, 0u); }
+    sl = (sl + 1) & g.block_mask;
+  }
+}
+// A cell that loses or gains points goes on the work list of the in-place update (see "in-place map update" below): top bit of
+// tp[e] = listed, low bits = inserts pending for it.
+__device__ __forceinline__ void touch_cell(unsigned int* __restrict__ tp, unsigned int* __restrict__ work, int* __restrict__ ctr, unsigned int work_cap,
+                                           unsigned int e) {
+  const unsigned int old = atomicOr(&tp[e], 0x80000000u);
+  if (!(old & 0x80000000u)) {
+    // one atomic on the list counter per wavefront, not per lane (thousands of cells are listed per update)
+    const unsigned long long m = __ballot(1);  // the lanes that are here together
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = (unsigned int)atomicAdd(&ctr[kMapCtrWork], __popcll(m));
+    base = __shfl(base, leader);
+    const unsigned int at = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+    if (at < work_cap) work[at] = e; else ctr[kMapCtrOverflow] = 1;
+  }
+}
 // calc_dist — float32, the reference's evaluation order, no FMA (ikd_Tree.cpp:1273-1277, laserMapping.cpp:152-155)
 __device__ __forceinline__ float d_dist2(float ax, float ay, float az, float bx, float by, float bz) {
   float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
@@ -241,7 +274,9 @@ __global__ void k_add_fold(const float4* __restrict__ add_pts, const unsigned lo
 __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ add_pts, const unsigned long long* __restrict__ keys,
                                                    const unsigned int* __restrict__ idx, int n, float ds, GridView g,
                                                    unsigned char* __restrict__ tomb, float4* __restrict__ ins_pts,
-                                                   unsigned int* __restrict__ ins_flag, unsigned int* __restrict__ events) {
+                                                   unsigned int* __restrict__ ins_flag, unsigned int* __restrict__ events,
+                                                   unsigned int* __restrict__ tp, unsigned int* __restrict__ work, int* __restrict__ ctr,
+                                                   unsigned int work_cap) {
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
   const int c = threadIdx.x & 7;
   const bool in_range = i < n;
@@ -273,9 +308,10 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
   int n0 = 0, best = -1;
   float bestd = __builtin_inff();
   uint2 r = make_uint2(0u, 0u);
+  long long my_entry = -1;
   if (g.n_pts > 0) {
     if (mine) {
-      r = d_cell_range(g, c0[0] + dx, c0[1] + dy, c0[2] + dz);
+      r = d_cell_range_e(g, c0[0] + dx, c0[1] + dy, c0[2] + dz, my_entry);
       for (unsigned int j = r.x; j < r.y; j++) {
         const float4 q = g.pts[j];
         if (bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) {
@@ -355,24 +391,43 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
   cur_old = __shfl(cur_old, lead);
   if (!ev) return;
   // delete every existing in-box point except a surviving one
+  // (the lane whose cell holds a tombstoned point also puts that cell on the work list of the in-place update)
   if (n0 == 1) {
-    if (c == 0 && best != cur_old) tomb[best] = 1;
+    if (!wide) {
+      if (mine && best != cur_old && (unsigned)best >= r.x && (unsigned)best < r.y) {
+        tomb[best] = 1;
+        touch_cell(tp, work, ctr, work_cap, (unsigned int)my_entry);
+      }
+    } else if (c == 0 && best != cur_old) {
+      tomb[best] = 1;
+      const float4 q = g.pts[best];
+      long long e;
+      (void)d_cell_range_e(g, (int)floorf(q.x * g.inv_cs), (int)floorf(q.y * g.inv_cs), (int)floorf(q.z * g.inv_cs), e);
+      if (e >= 0) touch_cell(tp, work, ctr, work_cap, (unsigned int)e);
+    }
   } else if (n0 > 1) {
     if (mine) {
+      bool any = false;
       for (unsigned int j = r.x; j < r.y; j++) {
         const float4 q = g.pts[j];
-        if ((int)j != cur_old && bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) tomb[j] = 1;
+        if ((int)j != cur_old && bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) { tomb[j] = 1; any = true; }
       }
+      if (any) touch_cell(tp, work, ctr, work_cap, (unsigned int)my_entry);
     } else if (wide && c == 0) {
       for (int cz = c0[2]; cz <= c1[2]; cz++)
         for (int cy = c0[1]; cy <= c1[1]; cy++)
           for (int cx = c0[0]; cx <= c1[0]; cx++) {
-            const uint2 rr = d_cell_range(g, cx, cy, cz);
-            for (unsigned int j = rr.x; j < rr.y; j++) {
+            long long e;
+            const uint2 rr2 = d_cell_range_e(g, cx, cy, cz, e);
+            bool any = false;
+            for (unsigned int j = rr2.x; j < rr2.y; j++) {
               const float4 q = g.pts[j];
-              if ((int)j != cur_old && bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z)
+              if ((int)j != cur_old && bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) {
                 tomb[j] = 1;
+                any = true;
+              }
             }
+            if (any && e >= 0) touch_cell(tp, work, ctr, work_cap, (unsigned int)e);
           }
     }
   }
@@ -412,7 +467,236 @@ __global__ void k_box_tomb(const float4* __restrict__ pts, int n, const float* _
   alive[i] = dead ? 0u : 1u;
 }
 
+// ================================================================================================ in-place map update
+// Round 2: the map is no longer re-sorted / re-indexed on every update.  The point array keeps SLACK behind every cell
+// (capacity end in cell_cap[]); an update touches only the cells it changes:
+//   k_touch_tombs   the cells that own a tombstoned slot (set by the fold or by a box deletion) go on the work list
+//   k_ins_cells     every insert finds its cell entry - creating the 8x8x8 block (hash insert + a zeroed cell table from the
+//                   pool) when the map has never seen it - bumps the cell's pending count and puts the cell on the work list
+//   k_cell_apply    one lane per listed cell: tombstoned points are squeezed out in place, and when the survivors + the pending
+//                   inserts exceed the capacity the cell moves to the tail of the array with fresh slack
+//   k_ins_write     every insert claims a slot behind its cell's end
+// O(batch) per update instead of six passes over the whole map.  The order of the points inside a cell (and of relocated cells
+// in the array) depends on the order the atomics resolve: the map is the same SET on every run and every rank, its array
+// order is not.  A rebuild (gather -> sort -> index -> spread, lii_capi.cpp) restores the cell-sorted order when the tail
+// fills up or the block table gets crowded.
+namespace {
+__device__ __forceinline__ unsigned int m_hash_block(int bx, int by, int bz) { return d_hash_block(bx, by, bz); }
+// cell entry index (block id * 512 + local cell) of the cell holding p, or -1 when its block is not in the table
+__device__ __forceinline__ long long entry_of(const BlockEntry* __restrict__ blocks, unsigned int mask, float inv_cs, float x, float y, float z) {
+  const int ix = (int)floorf(x * inv_cs), iy = (int)floorf(y * inv_cs), iz = (int)floorf(z * inv_cs);
+  const int bb = kBias >> kCoarseShift;
+  const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
+  const unsigned long long bk = d_pack_block(bx, by, bz);
+  unsigned int sl = m_hash_block(bx, by, bz) & mask;
+  while (true) {
+    const BlockEntry e = blocks[sl];
+    if (e.key == bk) return (long long)e.id * kCells + ((((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u));
+    if (e.key == kEmptyKey) return -1;
+    sl = (sl + 1) & mask;
+  }
+}
+}  // namespace
+
+__global__ void k_touch_tombs(const unsigned char* __restrict__ tomb, const float4* __restrict__ pts, int n_slots,
+                              const BlockEntry* __restrict__ blocks, unsigned int mask, float inv_cs, unsigned int* __restrict__ tp,
+                              unsigned int* __restrict__ work, int* __restrict__ ctr, unsigned int work_cap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots || !tomb[i]) return;
+  const float4 p = pts[i];
+  const long long e = entry_of(blocks, mask, inv_cs, p.x, p.y, p.z);
+  if (e >= 0) touch_cell(tp, work, ctr, work_cap, (unsigned int)e);
+}
+
+// flags == nullptr: every point of the list is an insert.  n_dev != nullptr: the list holds *n_dev points (n is the launch bound).
+__global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int* __restrict__ flags, int n, const int* __restrict__ n_dev,
+                            BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* __restrict__ ins_e,
+                            unsigned int* __restrict__ tp, unsigned int* __restrict__ work, int* __restrict__ ctr, unsigned int work_cap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || (n_dev && i >= *n_dev)) return;
+  if (flags && !flags[i]) { ins_e[i] = 0xFFFFFFFFu; return; }
+  const float4 p = list[i];
+  const int ix = (int)floorf(p.x * inv_cs), iy = (int)floorf(p.y * inv_cs), iz = (int)floorf(p.z * inv_cs);
+  const int bb = kBias >> kCoarseShift;
+  const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
+  const unsigned long long bk = d_pack_block(bx, by, bz);
+  unsigned int sl = m_hash_block(bx, by, bz) & mask;
+  long long id = -1;
+  for (unsigned int probes = 0; probes <= mask; probes++) {
+    unsigned long long k = __hip_atomic_load(&blocks[sl].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == kEmptyKey) {
+      const unsigned long long prev = atomicCAS(&blocks[sl].key, kEmptyKey, bk);
+      if (prev == kEmptyKey) {  // this lane creates the block: a cell table from the (zeroed) pool
+        const int nid = atomicAdd(&ctr[kMapCtrBlocks], 1);
+        if ((unsigned int)nid >= tables_cap) { ctr[kMapCtrOverflow] = 1; break; }
+        __hip_atomic_store(&blocks[sl].id, (unsigned int)nid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&blocks[sl].pad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        id = nid;
+        break;
+      }
+      k = prev;
+    }
+    if (k == bk) {  // somebody else may be creating it right now: wait for the id
+      while (__hip_atomic_load(&blocks[sl].pad, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+      id = (long long)__hip_atomic_load(&blocks[sl].id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    sl = (sl + 1) & mask;
+  }
+  if (id < 0) { ins_e[i] = 0xFFFFFFFFu; ctr[kMapCtrOverflow] = 1; return; }
+  const unsigned int e = (unsigned int)id * kCells + ((((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u));
+  ins_e[i] = e;
+  touch_cell(tp, work, ctr, work_cap, e);
+  atomicAdd(&tp[e], 1u);
+}
+
+__global__ void k_cell_apply(const unsigned int* __restrict__ work, uint2* __restrict__ cells, unsigned int* __restrict__ cell_cap,
+                             float4* __restrict__ pts, unsigned char* __restrict__ tomb, unsigned int* __restrict__ tp, int* __restrict__ ctr,
+                             unsigned int pts_cap, int launch_bound) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_work = ctr[kMapCtrWork];
+  if (w >= n_work || w >= launch_bound) return;
+  const unsigned int e = work[w];
+  const uint2 c = cells[e];
+  unsigned int first = c.x, end = c.y, wpos = c.x;
+  for (unsigned int j = first; j < end; j++) {
+    if (!tomb[j]) {
+      if (wpos != j) pts[wpos] = pts[j];
+      wpos++;
+    } else {
+      tomb[j] = 0;
+    }
+  }
+  const unsigned int deleted = end - wpos, alive = wpos - first;
+  const unsigned int pending = tp[e] & 0x7FFFFFFFu;
+  tp[e] = 0u;
+  if (first + alive + pending > cell_cap[e]) {  // (an empty, never used cell has first = end = cap = 0)
+    const unsigned int need = alive + pending, newcap = need + max(2u, need >> 2);
+    const unsigned int nf = (unsigned int)atomicAdd(&ctr[kMapCtrUsed], (int)newcap);
+    if (nf + newcap > pts_cap) {
+      ctr[kMapCtrOverflow] = 1;  // the inserts of this cell are dropped by k_ins_write (cap stays): the host rebuilds and reports
+    } else {
+      for (unsigned int j = 0; j < alive; j++) pts[nf + j] = pts[first + j];
+      first = nf;
+      cell_cap[e] = nf + newcap;
+    }
+  }
+  cells[e] = make_uint2(first, first + alive);
+  if (deleted) atomicAdd(&ctr[kMapCtrValid], -(int)deleted);
+}
+
+__global__ void k_ins_write(const float4* __restrict__ list, const unsigned int* __restrict__ ins_e, int n, const int* __restrict__ n_dev,
+                            uint2* __restrict__ cells, const unsigned int* __restrict__ cell_cap, float4* __restrict__ pts, int* __restrict__ ctr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) ctr[kMapCtrWork] = 0;  // the work list has been consumed (k_cell_apply ran before this launch)
+  if (i >= n || (n_dev && i >= *n_dev)) return;
+  const unsigned int e = ins_e[i];
+  if (e == 0xFFFFFFFFu) return;
+  const unsigned int slot = atomicAdd(reinterpret_cast<unsigned int*>(&cells[e]) + 1, 1u);
+  if (slot < cell_cap[e]) {
+    const float4 p = list[i];
+    pts[slot] = make_float4(p.x, p.y, p.z, 0.f);
+    atomicAdd(&ctr[kMapCtrValid], 1);
+  } else {
+    atomicSub(reinterpret_cast<unsigned int*>(&cells[e]) + 1, 1u);
+    ctr[kMapCtrOverflow] = 1;
+  }
+}
+
+// ---- (re)build: slack layout from the compact, cell-sorted array
+__global__ void k_cell_caps(const uint2* __restrict__ cells, int n_entries, unsigned int* __restrict__ caps) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_entries) return;
+  const unsigned int cnt = cells[e].y - cells[e].x;
+  caps[e] = cnt ? cnt + max(2u, cnt >> 2) : 0u;
+}
+// capsum = inclusive scan of caps.  Points are copied cell by cell (one lane per cell: ~9 points), then the tables are rewritten.
+__global__ void k_spread(const float4* __restrict__ src, uint2* __restrict__ cells, unsigned int* __restrict__ cell_cap,
+                         const unsigned int* __restrict__ caps, const unsigned int* __restrict__ capsum, int n_entries, float4* __restrict__ dst,
+                         int* __restrict__ ctr, int n_valid, int n_blocks) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_entries) return;
+  if (e == n_entries - 1) {
+    ctr[kMapCtrUsed] = (int)capsum[e];
+    ctr[kMapCtrValid] = n_valid;
+    ctr[kMapCtrBlocks] = n_blocks;
+    ctr[kMapCtrWork] = 0;
+    ctr[kMapCtrOverflow] = 0;
+  }
+  const uint2 c = cells[e];
+  const unsigned int cnt = c.y - c.x, nf = capsum[e] - caps[e];
+  for (unsigned int j = 0; j < cnt; j++) dst[nf + j] = src[c.x + j];
+  cells[e] = cnt ? make_uint2(nf, nf + cnt) : make_uint2(0u, 0u);
+  cell_cap[e] = cnt ? nf + caps[e] : 0u;
+}
+// ---- gather the live points (download, rebuild): cnt -> inclusive scan -> copy
+__global__ void k_cell_counts(const uint2* __restrict__ cells, int n_entries, unsigned int* __restrict__ cnt) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_entries) cnt[e] = cells[e].y - cells[e].x;
+}
+__global__ void k_gather_live(const float4* __restrict__ pts, const uint2* __restrict__ cells, const unsigned int* __restrict__ cntsum, int n_entries,
+                              float4* __restrict__ dst, int dst_cap) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_entries) return;
+  const uint2 c = cells[e];
+  const unsigned int cnt = c.y - c.x, at = cntsum[e] - cnt;
+  for (unsigned int j = 0; j < cnt; j++)
+    if ((int)(at + j) < dst_cap) dst[at + j] = pts[c.x + j];
+}
+// KD_TREE::Delete_Point_Boxes on the slack layout: one lane per cell entry walks its live points
+__global__ void k_box_tomb_cells(const float4* __restrict__ pts, const uint2* __restrict__ cells, int n_entries, const float* __restrict__ boxes,
+                                 int n_boxes, unsigned char* __restrict__ tomb, unsigned int* __restrict__ tp, unsigned int* __restrict__ work,
+                                 int* __restrict__ ctr, unsigned int work_cap) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_entries) return;
+  const uint2 c = cells[e];
+  bool any = false;
+  for (unsigned int j = c.x; j < c.y; j++) {
+    const float4 p = pts[j];
+    bool dead = false;
+    for (int b = 0; b < n_boxes; b++) {
+      const float* q = boxes + 6 * b;
+      dead = dead || (q[0] <= p.x && q[3] > p.x && q[1] <= p.y && q[4] > p.y && q[2] <= p.z && q[5] > p.z);
+    }
+    if (dead) { tomb[j] = 1; any = true; }
+  }
+  if (any) touch_cell(tp, work, ctr, work_cap, (unsigned int)e);
+}
+
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
+void launch_touch_tombs(const unsigned char* tomb, const float4* pts, int n_slots, const BlockEntry* blocks, unsigned int mask, float inv_cs,
+                        unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s) {
+  if (n_slots > 0) hipLaunchKernelGGL(k_touch_tombs, dim3(nblk(n_slots, 256)), dim3(256), 0, s, tomb, pts, n_slots, blocks, mask, inv_cs, tp, work, ctr, work_cap);
+}
+void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, BlockEntry* blocks, unsigned int mask, float inv_cs,
+                      unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_ins_cells, dim3(nblk(n, 256)), dim3(256), 0, s, list, flags, n, n_dev, blocks, mask, inv_cs, tables_cap, ins_e, tp, work, ctr, work_cap);
+}
+void launch_cell_apply(const unsigned int* work, uint2* cells, unsigned int* cell_cap, float4* pts, unsigned char* tomb, unsigned int* tp, int* ctr,
+                       unsigned int pts_cap, int launch_bound, hipStream_t s) {
+  if (launch_bound > 0) hipLaunchKernelGGL(k_cell_apply, dim3(nblk(launch_bound, 128)), dim3(128), 0, s, work, cells, cell_cap, pts, tomb, tp, ctr, pts_cap, launch_bound);
+}
+void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, uint2* cells, const unsigned int* cell_cap, float4* pts,
+                      int* ctr, hipStream_t s) {
+  hipLaunchKernelGGL(k_ins_write, dim3(nblk(n > 0 ? n : 1, 256)), dim3(256), 0, s, list, ins_e, n, n_dev, cells, cell_cap, pts, ctr);
+}
+void launch_cell_caps(const uint2* cells, int n_entries, unsigned int* caps, hipStream_t s) {
+  if (n_entries > 0) hipLaunchKernelGGL(k_cell_caps, dim3(nblk(n_entries, 256)), dim3(256), 0, s, cells, n_entries, caps);
+}
+void launch_spread(const float4* src, uint2* cells, unsigned int* cell_cap, const unsigned int* caps, const unsigned int* capsum, int n_entries,
+                   float4* dst, int* ctr, int n_valid, int n_blocks, hipStream_t s) {
+  if (n_entries > 0) hipLaunchKernelGGL(k_spread, dim3(nblk(n_entries, 256)), dim3(256), 0, s, src, cells, cell_cap, caps, capsum, n_entries, dst, ctr, n_valid, n_blocks);
+}
+void launch_cell_counts(const uint2* cells, int n_entries, unsigned int* cnt, hipStream_t s) {
+  if (n_entries > 0) hipLaunchKernelGGL(k_cell_counts, dim3(nblk(n_entries, 256)), dim3(256), 0, s, cells, n_entries, cnt);
+}
+void launch_gather_live(const float4* pts, const uint2* cells, const unsigned int* cntsum, int n_entries, float4* dst, int dst_cap, hipStream_t s) {
+  if (n_entries > 0) hipLaunchKernelGGL(k_gather_live, dim3(nblk(n_entries, 256)), dim3(256), 0, s, pts, cells, cntsum, n_entries, dst, dst_cap);
+}
+void launch_box_tomb_cells(const float4* pts, const uint2* cells, int n_entries, const float* boxes, int n_boxes, unsigned char* tomb, unsigned int* tp,
+                           unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s) {
+  if (n_entries > 0) hipLaunchKernelGGL(k_box_tomb_cells, dim3(nblk(n_entries, 256)), dim3(256), 0, s, pts, cells, n_entries, boxes, n_boxes, tomb, tp, work, ctr, work_cap);
+}
 void launch_box_tomb(const float4* pts, int n, const float* boxes, int n_boxes, unsigned char* tomb, unsigned int* alive, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_box_tomb, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, boxes, n_boxes, tomb, alive);
 }
@@ -429,9 +713,11 @@ void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsig
   if (n > 0) hipLaunchKernelGGL(k_add_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, n_dev, ds, keys, idx);
 }
 void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
-                     unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, hipStream_t s) {
+                     unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, unsigned int* tp, unsigned int* work,
+                     int* ctr, unsigned int work_cap, hipStream_t s) {
   (void)&k_add_fold;  // kept as the reference form of the walk (k_add_fold8 falls back to it lane by lane for wide boxes)
-  if (n > 0) hipLaunchKernelGGL(k_add_fold8, dim3(nblk(n * 8, 256)), dim3(256), 0, s, add_pts, keys, idx, n, ds, g, tomb, ins_pts, ins_flag, events);
+  if (n > 0) hipLaunchKernelGGL(k_add_fold8, dim3(nblk(n * 8, 256)), dim3(256), 0, s, add_pts, keys, idx, n, ds, g, tomb, ins_pts, ins_flag, events, tp,
+                            work, ctr, work_cap);
 }
 void launch_alive_flags(const unsigned char* tomb, int n, unsigned int* alive, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_alive_flags, dim3(nblk(n, 256)), dim3(256), 0, s, tomb, n, alive);
