@@ -311,12 +311,12 @@ int lii_comm_transport(lii_handle h, int32_t* transport); /* the transport in us
 int lii_comm_set_partition(lii_handle h, int32_t library_partition);
 int lii_comm_destroy(lii_handle h);
 
-/* ---------------------------------------------------------------- parameter surface (config/*.yaml + launch/*.launch)
+/* ---------------------------------------------------------------- parameter surface (config/<sensor>.yaml + launch/<sensor>.launch)
  * The nh.param<> block of main() (src/laserMapping.cpp:767-799) as a POD: same names (`section/key` -> field), same defaults.
  * roslaunch fills the parameter server from `<rosparam command="load" file="$(find lidar_imu_init)/config/X.yaml"/>` and
- * `<param name=".." value=".."/>` (launch/*.launch:6-12); a host without ROS calls
+ * `<param name=".." value=".."/>` (launch/<sensor>.launch:6-12); a host without ROS calls
  *   lii_params_defaults    the third argument of every nh.param<> call
- *   lii_params_load_yaml   one config/*.yaml on top (block maps, scalars, quoted strings, flow lists, '#' comments)
+ *   lii_params_load_yaml   one config/<sensor>.yaml on top (block maps, scalars, quoted strings, flow lists, '#' comments)
  *   lii_params_load_launch a launch file: its rosparam yaml (looked up in `config_dir`, else <launch dir>/../config) first,
  *                          then its <param> tags (names a node never reads are ignored, as on the parameter server)
  *   lii_params_set         one override by name ("max_iteration", "mapping/filter_size_surf", ...)

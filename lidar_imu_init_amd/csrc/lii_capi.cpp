@@ -375,27 +375,21 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
   h->map_dirty = true;
   const unsigned int tables_cap = (unsigned int)h->cells_cap_blocks;
   HIPCHK(h, hipMemsetAsync(h->d_mapctr + kMapCtrEvents, 0, sizeof(int), s));
-  bool have_a = false;
+  // one launch each for the cells of both insert lists and for writing both (the second list rides behind the first)
+  const float4* list_a = list;
+  const unsigned int* flags_a = nullptr;
   if (downsample && n_list > 0) {
     launch_add_keys(list, n_list, nullptr, h->ds, h->d_keys_a, h->d_idx_a, s);
     sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, n_list, s);
     launch_add_fold(list, h->d_keys_b, h->d_idx_b, n_list, h->ds, g, h->d_tomb, h->d_ins, h->d_u32_a,
                     reinterpret_cast<unsigned int*>(h->d_mapctr + kMapCtrEvents), h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s);
-    launch_ins_cells(h->d_ins, h->d_u32_a, n_list, nullptr, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp, h->d_work,
-                     h->d_mapctr, h->work_cap, s);
-    have_a = true;
-  } else if (n_list > 0) {
-    launch_ins_cells(list, nullptr, n_list, nullptr, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp, h->d_work, h->d_mapctr,
-                     h->work_cap, s);
-    have_a = true;
+    list_a = h->d_ins;
+    flags_a = h->d_u32_a;
   }
-  if (n_extra > 0)
-    launch_ins_cells(extra, nullptr, n_extra, nullptr, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e2, h->d_tp, h->d_work, h->d_mapctr,
-                     h->work_cap, s);
+  launch_ins_cells(list_a, flags_a, n_list, nullptr, extra, n_extra, h->d_ins_e2, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp,
+                   h->d_work, h->d_mapctr, h->work_cap, s);
   launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap, (int)work_need, s);
-  if (have_a) launch_ins_write(downsample ? h->d_ins : list, h->d_ins_e, n_list, nullptr, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, s);
-  if (n_extra > 0) launch_ins_write(extra, h->d_ins_e2, n_extra, nullptr, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, s);
-  if (!have_a && n_extra <= 0) launch_ins_write(list, h->d_ins_e, 0, nullptr, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, s);
+  launch_ins_write(list_a, h->d_ins_e, n_list, nullptr, extra, h->d_ins_e2, n_extra, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, s);
   HIPCHK(h, hipGetLastError());
   // the block table may have grown: kernels launched from now on must see it (grid_view reads the host copy of the mask only)
   return LII_OK;
@@ -948,7 +942,7 @@ int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int3
   h->map_dirty = true;
   launch_box_tomb_cells(h->d_pts, h->d_cells, ne, d_boxes, n_boxes, h->d_tomb, h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s);
   launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap, ne, s);
-  launch_ins_write(h->d_pts, h->d_ins_e, 0, nullptr, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, s);  // (re-arms the work list)
+  launch_ins_write(h->d_pts, h->d_ins_e, 0, nullptr, nullptr, nullptr, 0, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, s);  // (re-arms the work list)
   rc = map_counters(h);
   if (rc != LII_OK) return rc;
   if (n_deleted) *n_deleted = n_old - h->n_map;
@@ -1340,12 +1334,9 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
       launch_knn_complete(g, rb, s);
     }
   }
-  // decision per point on the device (world point, neighbour list of the last search), then two order-preserving compactions
-  launch_map_decide(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, h->d_u32_a, h->d_u32_b, h->d_world, s);
-  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_a, h->d_u32_c, nb, s);
-  launch_compact_f4(h->d_world, h->d_u32_a, h->d_u32_c, nb, h->d_list_add, 0, h->d_counts + 0, s);
-  inclusive_scan_u32(h->d_sort_temp, h->sort_temp_bytes, h->d_u32_b, h->d_u32_c, nb, s);
-  launch_compact_f4(h->d_world, h->d_u32_b, h->d_u32_c, nb, h->d_list_nodown, 0, h->d_counts + 1, s);
+  // decision per point on the device (world point, neighbour list of the last search) and both order-preserving compactions
+  launch_map_decide_compact(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, h->d_u32_a,
+                            reinterpret_cast<uint2*>(h->d_u32_b), h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, s);
   // The sizes of the two lists, now: a converged map takes a few thousand of the ~100 k points, and everything downstream
   // (voxel keys, the batch sort, the per-voxel fold, the insert compaction) is launched for the exact count instead of the
   // scan-sized bound - one small host round trip (~15 us) against ~80 us of kernels working on padding.

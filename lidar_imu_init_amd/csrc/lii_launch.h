@@ -66,8 +66,8 @@ void launch_calib_eval(int stage, const double* imu, const double* lidar, int n,
                        hipStream_t s);
 
 // device-side map maintenance (lii_map.hip)
-void launch_map_decide(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* flag_add,
-                       unsigned int* flag_nodown, float4* world_out, hipStream_t s);
+void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* cls, uint2* blk_counts,
+                               float4* world, float4* dst_add, float4* dst_nodown, int* counts, hipStream_t s);
 void launch_compact_f4(const float4* src, const unsigned int* flag, const unsigned int* ranks, int n, float4* dst, int dst_offset,
                        int* count, hipStream_t s);
 void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, hipStream_t s);
@@ -77,12 +77,13 @@ void launch_add_fold(const float4* add_pts, const unsigned long long* keys, cons
 // in-place map update (lii_map.hip)
 void launch_touch_tombs(const unsigned char* tomb, const float4* pts, int n_slots, const BlockEntry* blocks, unsigned int mask, float inv_cs,
                         unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s);
-void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, BlockEntry* blocks, unsigned int mask, float inv_cs,
-                      unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s);
+void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, const float4* list2, int n2, unsigned int* ins_e2,
+                      BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp,
+                      unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s);
 void launch_cell_apply(const unsigned int* work, uint2* cells, unsigned int* cell_cap, float4* pts, unsigned char* tomb, unsigned int* tp, int* ctr,
                        unsigned int pts_cap, int launch_bound, hipStream_t s);
-void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, uint2* cells, const unsigned int* cell_cap, float4* pts,
-                      int* ctr, hipStream_t s);
+void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, const float4* list2, const unsigned int* ins_e2, int n2,
+                      uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, hipStream_t s);
 void launch_cell_caps(const uint2* cells, int n_entries, unsigned int* caps, hipStream_t s);
 void launch_spread(const float4* src, uint2* cells, unsigned int* cell_cap, const unsigned int* caps, const unsigned int* capsum, int n_entries,
                    float4* dst, int* ctr, int n_valid, int n_blocks, hipStream_t s);

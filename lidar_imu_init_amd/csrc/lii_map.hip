@@ -91,13 +91,13 @@ __device__ __forceinline__ bool d_same_point(float ax, float ay, float az, float
 
 // ------------------------------------------------------------------------------------------------ map_incremental
 // cls[i]: 0 = not added, 1 = PointToAdd (with down-sampling), 2 = PointNoNeedDownsample.  world[i] = the world point.
-__global__ void k_map_decide(RegistrationBuffers rb, PoseArg ps, double fsd, int have_search, unsigned int* __restrict__ flag_add,
-                             unsigned int* __restrict__ flag_nodown, float4* __restrict__ world_out) {
+// cls[i] = fa | fn << 1; blk_counts[block] = (#fa, #fn) of the block's 256 points, for the single-pass compaction below.
+__global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, PoseArg ps, double fsd, int have_search, unsigned int* __restrict__ cls,
+                                                    uint2* __restrict__ blk_counts, float4* __restrict__ world_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = rb.n_dev ? *rb.n_dev : rb.n;
-  if (i >= rb.n) return;  // rb.n is the launch bound
   unsigned int fa = 0, fn = 0;
-  if (i < n) {
+  if (i < rb.n && i < n) {  // rb.n is the launch bound
     float4 pb = rb.body[i];
     double bx = pb.x, by = pb.y, bz = pb.z;
     double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
@@ -132,8 +132,41 @@ __global__ void k_map_decide(RegistrationBuffers rb, PoseArg ps, double fsd, int
       fa = 1;  // no neighbour list: always added (:551-553)
     }
   }
-  flag_add[i] = fa;
-  flag_nodown[i] = fn;
+  if (i < rb.n) cls[i] = fa | (fn << 1);
+  __shared__ unsigned int s_a[4], s_n[4];
+  const int w = threadIdx.x >> 6;
+  const unsigned int ca = (unsigned int)__popcll(__ballot(fa != 0)), cn = (unsigned int)__popcll(__ballot(fn != 0));
+  if ((threadIdx.x & 63) == 0) { s_a[w] = ca; s_n[w] = cn; }
+  __syncthreads();
+  if (threadIdx.x == 0) blk_counts[blockIdx.x] = make_uint2(s_a[0] + s_a[1] + s_a[2] + s_a[3], s_n[0] + s_n[1] + s_n[2] + s_n[3]);
+}
+
+// Both order-preserving compactions of map_incremental in ONE launch: a block adds up the counts of the blocks before it (a few
+// hundred values at most), ranks its own 256 points with wavefront ballots, and writes the two lists; the last block leaves the
+// list sizes in counts[0..1].  (Replaces two library scans and two scatter kernels.)
+__global__ __launch_bounds__(256) void k_compact_lists(const float4* __restrict__ src, const unsigned int* __restrict__ cls,
+                                                       const uint2* __restrict__ blk_counts, int n, float4* __restrict__ dst_add,
+                                                       float4* __restrict__ dst_nodown, int* __restrict__ counts) {
+  __shared__ unsigned int s_a[4], s_n[4], s_wa[4], s_wn[4];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  unsigned int pa = 0, pn = 0;
+  for (int j = t; j < (int)blockIdx.x; j += 256) { const uint2 c = blk_counts[j]; pa += c.x; pn += c.y; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { pa += __shfl_xor(pa, off); pn += __shfl_xor(pn, off); }
+  const int i = blockIdx.x * 256 + t;
+  const unsigned int c = i < n ? cls[i] : 0u;
+  const unsigned long long ma = __ballot(c & 1u), mn = __ballot(c & 2u);
+  if (lane == 0) { s_a[w] = pa; s_n[w] = pn; s_wa[w] = (unsigned int)__popcll(ma); s_wn[w] = (unsigned int)__popcll(mn); }
+  __syncthreads();
+  unsigned int base_a = s_a[0] + s_a[1] + s_a[2] + s_a[3], base_n = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+  for (int k = 0; k < w; k++) { base_a += s_wa[k]; base_n += s_wn[k]; }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (c & 1u) dst_add[base_a + (unsigned int)__popcll(ma & below)] = src[i];
+  if (c & 2u) dst_nodown[base_n + (unsigned int)__popcll(mn & below)] = src[i];
+  if (blockIdx.x == gridDim.x - 1 && t == 255) {
+    counts[0] = (int)(base_a + (unsigned int)__popcll(ma));
+    counts[1] = (int)(base_n + (unsigned int)__popcll(mn));
+  }
 }
 
 // dst[rank - 1] = src[i] where flag[i] (rank = inclusive scan of flag); *count = ranks[n - 1]
@@ -509,11 +542,19 @@ __global__ void k_touch_tombs(const unsigned char* __restrict__ tomb, const floa
 }
 
 // flags == nullptr: every point of the list is an insert.  n_dev != nullptr: the list holds *n_dev points (n is the launch bound).
+// A second list (list2, n2 points, all of them inserts, entries to ins_e2) rides in the same launch: lanes [n, n + n2).
 __global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int* __restrict__ flags, int n, const int* __restrict__ n_dev,
+                            const float4* __restrict__ list2, int n2, unsigned int* __restrict__ ins_e2,
                             BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* __restrict__ ins_e,
                             unsigned int* __restrict__ tp, unsigned int* __restrict__ work, int* __restrict__ ctr, unsigned int work_cap) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || (n_dev && i >= *n_dev)) return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) {
+    i -= n;
+    if (i >= n2) return;
+    list = list2; flags = nullptr; ins_e = ins_e2;
+  } else if (n_dev && i >= *n_dev) {
+    return;
+  }
   if (flags && !flags[i]) { ins_e[i] = 0xFFFFFFFFu; return; }
   const float4 p = list[i];
   const int ix = (int)floorf(p.x * inv_cs), iy = (int)floorf(p.y * inv_cs), iz = (int)floorf(p.z * inv_cs);
@@ -586,10 +627,17 @@ __global__ void k_cell_apply(const unsigned int* __restrict__ work, uint2* __res
 }
 
 __global__ void k_ins_write(const float4* __restrict__ list, const unsigned int* __restrict__ ins_e, int n, const int* __restrict__ n_dev,
+                            const float4* __restrict__ list2, const unsigned int* __restrict__ ins_e2, int n2,
                             uint2* __restrict__ cells, const unsigned int* __restrict__ cell_cap, float4* __restrict__ pts, int* __restrict__ ctr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) ctr[kMapCtrWork] = 0;  // the work list has been consumed (k_cell_apply ran before this launch)
-  if (i >= n || (n_dev && i >= *n_dev)) return;
+  if (i >= n) {
+    i -= n;
+    if (i >= n2) return;
+    list = list2; ins_e = ins_e2;
+  } else if (n_dev && i >= *n_dev) {
+    return;
+  }
   const unsigned int e = ins_e[i];
   if (e == 0xFFFFFFFFu) return;
   const unsigned int slot = atomicAdd(reinterpret_cast<unsigned int*>(&cells[e]) + 1, 1u);
@@ -668,17 +716,25 @@ void launch_touch_tombs(const unsigned char* tomb, const float4* pts, int n_slot
                         unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s) {
   if (n_slots > 0) hipLaunchKernelGGL(k_touch_tombs, dim3(nblk(n_slots, 256)), dim3(256), 0, s, tomb, pts, n_slots, blocks, mask, inv_cs, tp, work, ctr, work_cap);
 }
-void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, BlockEntry* blocks, unsigned int mask, float inv_cs,
-                      unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_ins_cells, dim3(nblk(n, 256)), dim3(256), 0, s, list, flags, n, n_dev, blocks, mask, inv_cs, tables_cap, ins_e, tp, work, ctr, work_cap);
+void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, const float4* list2, int n2, unsigned int* ins_e2,
+                      BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp,
+                      unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s) {
+  if (n < 0) n = 0;
+  if (n2 < 0) n2 = 0;
+  if (n + n2 > 0)
+    hipLaunchKernelGGL(k_ins_cells, dim3(nblk(n + n2, 256)), dim3(256), 0, s, list, flags, n, n_dev, list2, n2, ins_e2, blocks, mask, inv_cs, tables_cap,
+                       ins_e, tp, work, ctr, work_cap);
 }
 void launch_cell_apply(const unsigned int* work, uint2* cells, unsigned int* cell_cap, float4* pts, unsigned char* tomb, unsigned int* tp, int* ctr,
                        unsigned int pts_cap, int launch_bound, hipStream_t s) {
   if (launch_bound > 0) hipLaunchKernelGGL(k_cell_apply, dim3(nblk(launch_bound, 128)), dim3(128), 0, s, work, cells, cell_cap, pts, tomb, tp, ctr, pts_cap, launch_bound);
 }
-void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, uint2* cells, const unsigned int* cell_cap, float4* pts,
-                      int* ctr, hipStream_t s) {
-  hipLaunchKernelGGL(k_ins_write, dim3(nblk(n > 0 ? n : 1, 256)), dim3(256), 0, s, list, ins_e, n, n_dev, cells, cell_cap, pts, ctr);
+void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, const float4* list2, const unsigned int* ins_e2, int n2,
+                      uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, hipStream_t s) {
+  if (n < 0) n = 0;
+  if (n2 < 0) n2 = 0;
+  hipLaunchKernelGGL(k_ins_write, dim3(nblk(n + n2 > 0 ? n + n2 : 1, 256)), dim3(256), 0, s, list, ins_e, n, n_dev, list2, ins_e2, n2, cells, cell_cap, pts,
+                     ctr);
 }
 void launch_cell_caps(const uint2* cells, int n_entries, unsigned int* caps, hipStream_t s) {
   if (n_entries > 0) hipLaunchKernelGGL(k_cell_caps, dim3(nblk(n_entries, 256)), dim3(256), 0, s, cells, n_entries, caps);
@@ -701,9 +757,12 @@ void launch_box_tomb(const float4* pts, int n, const float* boxes, int n_boxes, 
   if (n > 0) hipLaunchKernelGGL(k_box_tomb, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, boxes, n_boxes, tomb, alive);
 }
 
-void launch_map_decide(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* flag_add,
-                       unsigned int* flag_nodown, float4* world_out, hipStream_t s) {
-  if (rb.n > 0) hipLaunchKernelGGL(k_map_decide, dim3(nblk(rb.n, 256)), dim3(256), 0, s, rb, ps, fsd, have_search, flag_add, flag_nodown, world_out);
+void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* cls, uint2* blk_counts,
+                               float4* world, float4* dst_add, float4* dst_nodown, int* counts, hipStream_t s) {
+  if (rb.n <= 0) return;
+  const int nb = nblk(rb.n, 256);
+  hipLaunchKernelGGL(k_map_decide, dim3(nb), dim3(256), 0, s, rb, ps, fsd, have_search, cls, blk_counts, world);
+  hipLaunchKernelGGL(k_compact_lists, dim3(nb), dim3(256), 0, s, world, cls, blk_counts, rb.n, dst_add, dst_nodown, counts);
 }
 void launch_compact_f4(const float4* src, const unsigned int* flag, const unsigned int* ranks, int n, float4* dst, int dst_offset,
                        int* count, hipStream_t s) {
