@@ -93,6 +93,10 @@ struct lii_context {
   unsigned long long* d_extent = nullptr;  // 2 x {min (time|index), max time}: ping-pong accumulators
   unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
   int extent_sel = 0, mm_sel = 0;
+  bool knn_plan = true;        // LII_KNN_PLAN=0: every k-NN launch is enqueued (IekfCtrl::plan_mask)
+  int knn_plan_force = -1;     // LII_KNN_PLAN_FORCE=<mask>: use this plan for every update (tests: forces the parked path)
+  unsigned int plan_next = 0xFFFFFFFFu, plan_cur = 0xFFFFFFFFu;
+  long long plan_parked = 0;   // updates that had to be continued by the host
   bool staging_busy = false;  // h_ctrl / h_poses were handed to the device by lii_scan_register and no wait has covered the read yet
   size_t ctrl_pending = 0;    // bytes of h_ctrl (+ poses) the next k_time_extent launch carries to d_ctrl; 0 = nothing pending
   bool extent_valid = false;  // d_extent[extent_sel] holds the time extent of d_scan (lii_scan_set_device computed it on the way)
@@ -524,6 +528,11 @@ void fill_ctrl(lii_handle h, const lii_state* state, const lii_state* state_prop
   hc->effect_num = 0; hc->singular = 0;
   h->update_seq = h->update_seq == 0x7FFFFFFF ? 1 : h->update_seq + 1;
   hc->seq = h->update_seq;
+  // which k-NN launches ride along (IekfCtrl::plan_mask): the first pass always; the others as the previous update needed them
+  unsigned int plan = 0xFFFFFFFFu;
+  if (h->knn_plan && !h->profiling && !h->comm && h->n_ranks == 1) plan = (h->knn_plan_force >= 0 ? (unsigned int)h->knn_plan_force : h->plan_next) | 1u;
+  hc->plan_mask = plan;
+  h->plan_cur = plan;
 }
 
 int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop, const lii_iekf_opts* opts,
@@ -547,11 +556,12 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   const PoseArg ps0 = pose_of(*state);  // unused by the device-driven kernels (they read `pose`)
   const bool prof = h->profiling;
   const double* ne = h->comm ? h->d_out91 + 128 : h->d_out91;
+  unsigned int plan = h->plan_cur;  // fill_ctrl chose it (the control block on the device carries the same mask)
   auto enqueue_pass = [&](int it) -> int {
     const bool timed = prof && it == 0;  // the first pass always searches
     if (timed) HIPCHK(h, hipEventRecord(h->ev[0], s));
     if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it], s));
-    launch_knn(h, g, rb, ps0, pose, -1);
+    if (it >= 32 || ((plan >> it) & 1u)) launch_knn(h, g, rb, ps0, pose, -1);
     if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it + 1], s));
     if (timed) HIPCHK(h, hipEventRecord(h->ev[3], s));
     launch_fit_reduce(g, rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
@@ -579,21 +589,41 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   // stopping one (they only read `stop` and return) drain while the caller already prepares the next scan.
   // (Enqueueing only as many passes as the previous scan needed, and further ones on demand, was measured: no gain - the
   // drained passes fit into the host's turn-around between two scans - and a scan that needs more pays a round trip.)
-  if (h->poll_result && !prof && !h->comm) {
-    volatile int* done = &h->h_res->done;
-    unsigned int spins = 0;
-    while (*done != h->update_seq) {
-      if ((++spins & 0x3FFF) == 0) {  // every ~50 us: is the stream still alive?
-        const hipError_t q = hipStreamQuery(s);
-        if (q == hipSuccess) break;  // everything ran; `done` is final (a loop that never stopped is reported below)
-        if (q != hipErrorNotReady) return fail(h, LII_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+  // A loop that parked itself (the next pass needs a search the plan did not hold - the pattern changed against the previous
+  // scan) is continued from here with every launch: one host round trip, on the scans whose pattern changes.
+  auto wait_result = [&](bool first) -> int {
+    const int parked_word = first ? (h->update_seq | kLoopParked) : h->update_seq;
+    if (h->poll_result && !prof && !h->comm) {
+      volatile int* done = &h->h_res->done;
+      unsigned int spins = 0;
+      while (*done != h->update_seq && *done != parked_word) {
+        if ((++spins & 0x3FFF) == 0) {  // every ~50 us: is the stream still alive?
+          const hipError_t q = hipStreamQuery(s);
+          if (q == hipSuccess) break;  // everything ran; `done` is final (a loop that never stopped is reported below)
+          if (q != hipErrorNotReady) return fail(h, LII_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        }
+        __builtin_ia32_pause();
       }
-      __builtin_ia32_pause();
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (*done != h->update_seq && *done != parked_word) HIPCHK(h, hipStreamSynchronize(s));
+    } else {
+      HIPCHK(h, hipStreamSynchronize(s));  // the stopping iteration's solve has written h_res (mapped host memory)
     }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    if (*done != h->update_seq) HIPCHK(h, hipStreamSynchronize(s));
-  } else {
-    HIPCHK(h, hipStreamSynchronize(s));  // the stopping iteration's solve has written h_res (mapped host memory)
+    return LII_OK;
+  };
+  rc = wait_result(true);
+  if (rc != LII_OK) return rc;
+  if (h->h_res->done == (h->update_seq | kLoopParked)) {
+    const int from = h->h_res->parked_it;
+    h->plan_parked++;
+    plan = 0xFFFFFFFFu;
+    launch_loop_resume(h->d_ctrl, s);
+    for (int it = from; it < opts->max_iterations; it++) {
+      rc = enqueue_pass(it);
+      if (rc != LII_OK) return rc;
+    }
+    rc = wait_result(false);
+    if (rc != LII_OK) return rc;
   }
   h->staging_busy = false;  // the wait above covers everything enqueued before the stopping pass
   const IekfResult* hr = h->h_res;
@@ -615,6 +645,12 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   if (hr->singular) return fail(h, LII_ERR_INVALID, "singular covariance / normal matrix in the device solve");
   if (hr->it < 0) return fail(h, LII_ERR_HIP, "device loop ended without a result");
   std::memcpy(state, hr->st, sizeof(lii_state));
+  {  // the next update's plan: this one's pattern; passes it did not reach keep their launch
+    unsigned int next = 0xFFFFFFFFu;
+    for (int q = 0; q < 16 && q < hr->it; q++)
+      if (!hr->search_log[q]) next &= ~(1u << q);
+    h->plan_next = next;
+  }
   if (report) {
     report->iterations = hr->it;
     report->searches = hr->searches;
@@ -696,6 +732,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   if (const char* v = std::getenv("LII_VOXEL_ORDER")) h->coherent_order = std::string(v) == "brick";
   if (const char* v = std::getenv("LII_HOST_SOLVE")) h->host_solve = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_SYNC_RESULT")) h->poll_result = std::atoi(v) == 0;
+  if (const char* v = std::getenv("LII_KNN_PLAN")) h->knn_plan = std::atoi(v) != 0;
+  if (const char* v = std::getenv("LII_KNN_PLAN_FORCE")) h->knn_plan_force = int(std::strtol(v, nullptr, 0) & 0x7FFFFFFF);
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;
 #define CK(call)                                                                  \
@@ -828,6 +866,7 @@ int lii_destroy(lii_handle h) {
   (void)hipSetDevice(h->device);
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->knn_stats) std::fprintf(stderr, "[libliinit_hip] updates continued by the host after a parked loop: %lld\n", h->plan_parked);
   if (h->knn_stats && h->d_knn_stats) {  // LII_KNN_STATS=1: how the search workgroups of this handle split (diagnostic)
     unsigned int st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpy(st, h->d_knn_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess) {

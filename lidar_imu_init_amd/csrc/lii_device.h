@@ -101,7 +101,10 @@ struct IekfCtrl {
   int effect_num;    // effect_feat_num of the last iteration
   int singular;      // a matrix inversion failed
   int seq;           // number of this update (host); echoed into IekfResult::done by the iteration that ends the loop
-  int pad[1];
+  unsigned int plan_mask;  // bit k: the host enqueued a k-NN launch ahead of iteration k (iterations >= 32: always).  The host
+                           // predicts the search pattern from the previous scan and leaves out the launches that would only read
+                           // the flags and return (~4.5 us each on the device); a solve that asks for a search the plan does not
+                           // hold parks the loop (stop = 2) and tells the host, which enqueues the rest with every launch.
   int search_log[16];  // search_log[it] = 1 when iteration `it` ran the k-NN pass (for profiling)
   double search_pose[24];  // the PoseArg of the last executed k-NN pass (written by that pass): a sharded job re-runs the search
                            // for the blocks of the other ranks at exactly this pose before map_incremental (lii_capi.cpp)
@@ -197,12 +200,15 @@ __device__ inline bool mailbox_allreduce(const MailboxView& mb, const double* in
 
 // What the host needs back from one iterated update.  Lives in pinned, device-mapped HOST memory: the solve kernel of the
 // stopping iteration writes it there directly, so the update ends with one stream synchronisation and no D2H copy.
+constexpr int kLoopParked = 0x40000000;
 struct IekfResult {
   double st[kStateDoubles];
   double ne[96];  // the 91 normal-equation scalars of the last executed pass
   int it, searches, effect_num, converged, singular;
   int done;  // == IekfCtrl::seq once everything above has landed (written last, after a system-scope fence): the host polls it
-  int pad[2];
+             // (== seq | kLoopParked: the loop is parked ahead of iteration `parked_it`, see IekfCtrl::plan_mask)
+  int parked_it;
+  int pad[1];
   int search_log[16];
   long long ts[16];  // LII_SOLVE_TRACE builds: wall_clock64 stamps of the solve phases (stopping iteration)
   long long ts0[16]; // ... of iteration 0

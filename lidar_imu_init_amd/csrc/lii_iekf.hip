@@ -145,8 +145,8 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   __shared__ int s_ok;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   {
-    const int* ci = &c->max_it;  // max_it, imu_en, it, search_next, stop, rematch_num, converged, searches, effect_num, singular, seq
-    if (tid < 11) s_int[tid] = ci[tid];
+    const int* ci = &c->max_it;  // max_it, imu_en, it, search_next, stop, rematch_num, converged, searches, effect_num, singular, seq, plan_mask
+    if (tid < 12) s_int[tid] = ci[tid];
     // agent-scope loads: in the fused kernel these sums were written by other workgroups of the SAME launch
     if (tid >= 64 && tid < 64 + 91) s_ne[tid - 64] = __hip_atomic_load(ne + (tid - 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid >= 160 && tid < 196) { s_st[tid - 160] = c->st[tid - 160]; s_prop[tid - 160] = c->prop[tid - 160]; }
@@ -238,6 +238,8 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   int rematch = rematch0, search = 0;
   if (converged || ((rematch == 0) && (it == (max_it - 2)))) { search = 1; rematch++; }
   const int do_cov = (rematch >= 2 || (it == max_it - 1));
+  // the next pass searches but the host did not enqueue a k-NN launch for it: park the loop and say so (IekfCtrl::plan_mask)
+  const int parked = !do_cov && search && (it + 1 < 32) && !(((unsigned int)s_int[11] >> (it + 1)) & 1u);
   // state += solution : the two rotations on two lanes of the first wavefront, the vector blocks on 18 more; on the stopping
   // iteration the other three wavefronts start on K H = K_1[:, :12] G (needed for the covariance only) right away
   if (wave == 0) {
@@ -269,6 +271,10 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
       c->it = it + 1;
       c->searches = searches0 + (search_now ? 1 : 0);
       if (it < 16) c->search_log[it] = search_now;
+      if (parked) {
+        c->stop = 2;
+        res->parked_it = it + 1;
+      }
       if (do_cov) {
         c->stop = 1;
         res->it = it + 1;
@@ -314,6 +320,8 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
       res->search_log[q] = (q < it) ? c->search_log[q] : (q == it ? search_now : 0);
     }
     publish_done(res, s_int[10]);
+  } else if (parked) {  // uniform
+    publish_done(res, s_int[10] | kLoopParked);
   }
 #ifdef LII_SOLVE_TRACE
   __syncthreads();
@@ -385,6 +393,12 @@ void launch_reduce_solve(const RegistrationBuffers& rb, double* out91, unsigned 
   hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq), dim3(kSolveThreads), 0, s, rb.partials, nb, rb.partial_stride, out91, ticket, c, res, rb,
                      mb);
 }
+// A parked loop goes on: every launch is enqueued from here on.
+__global__ void k_loop_resume(IekfCtrl* c) {
+  c->stop = 0;
+  c->plan_mask = 0xFFFFFFFFu;
+}
+void launch_loop_resume(IekfCtrl* c, hipStream_t s) { hipLaunchKernelGGL(k_loop_resume, dim3(1), dim3(1), 0, s, c); }
 void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s) {
   hipLaunchKernelGGL(k_iekf_solve, dim3(1), dim3(kSolveThreads), 0, s, c, ne, res);
 }

@@ -47,6 +47,7 @@ struct MailboxHost {
 size_t mailbox_segment_bytes(int n_ranks);
 int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, MailboxHost* m, std::string* why);
 void mailbox_close(MailboxHost* m);
+void launch_loop_resume(IekfCtrl* c, hipStream_t s);
 void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s);
 int register_blocks(int n);
 // undistortion

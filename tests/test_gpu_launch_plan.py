@@ -1,0 +1,54 @@
+"""The k-NN launch plan of the device-driven update (IekfCtrl::plan_mask, lii_capi.cpp update_on_device): the host leaves out the
+search launches the previous scan did not need; a scan whose pattern differs parks the loop and is continued by the host.
+Whatever the plan, the result must be THE SAME BITS as with every launch enqueued (src/laserMapping.cpp:957-1134: the schedule
+of nearest_search_en is decided by the solve, never by the plan)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(env, wl, states0, tables, n_rounds=2):
+    import lidar_imu_init_amd as lii
+    old = {k: os.environ.get(k) for k in ("LII_KNN_PLAN", "LII_KNN_PLAN_FORCE")}
+    for k in old:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    try:
+        reg = lii.Registrar(max_scan_points=140_000, max_map_points=1_100_000, filter_size_map=wl["fs_map"])
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    out = []
+    try:
+        reg.map_build(wl["map"])
+        for _ in range(n_rounds):  # the second round runs with the plan learnt from the first
+            for j, scan in enumerate(wl["scans"]):
+                st = states0[j].copy()
+                rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=wl["fs_surf"], max_iterations=wl["max_it"],
+                                        imu_en=True, scan_dev=reg.device_scan(scan))
+                out.append((st.pod.copy(), rep["iterations"], rep["searches"], rep["effect_num"], np.array(rep["normal_eq"])))
+    finally:
+        reg.close()
+    return out
+
+
+def test_results_do_not_depend_on_the_launch_plan():
+    import bench
+    wl = bench.build_workload("os1_128_cut3", 3)
+    states0, tables = bench.start_states(wl)
+    # a far-off start for the last scan: more iterations / another search pattern than its predecessor
+    states0[2] = states0[2].copy()
+    states0[2].pos_end[:] += np.array([0.08, -0.05, 0.03])
+    full = _run({"LII_KNN_PLAN": "0"}, wl, states0, tables)
+    assert len({(r[1], r[2]) for r in full}) >= 1
+    for env in ({}, {"LII_KNN_PLAN_FORCE": "1"}, {"LII_KNN_PLAN_FORCE": "0x2B"}, {"LII_KNN_PLAN_FORCE": "0x7FFFFFFF"}):
+        got = _run(env, wl, states0, tables)
+        for a, b in zip(full, got):
+            assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3], (env, a[1:4], b[1:4])
+            assert np.array_equal(a[0], b[0]), env
+            assert np.array_equal(a[4], b[4]), env
