@@ -321,20 +321,60 @@ def main():
     pipeline = None
     if world == 1 and not args.no_pipeline:
         n_pipe = max(10, min(args.steps, 120))
-        reg.synchronize()
-        tp0 = time.perf_counter()
-        for k in range(n_pipe):
-            j = k % len(host_scans)
-            reg.scan_upload(host_scans[j])
-            st = states0[j].copy()
-            reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=0.0 if args.no_downsample else wl["fs_surf"],
-                              max_iterations=wl["max_it"], imu_en=True)
-            reg.map_incremental(st)
-        reg.synchronize()
-        tp = time.perf_counter() - tp0
-        pipeline = {"value": n_pipe / tp, "unit": "scans/s", "ms_per_scan": 1e3 * tp / n_pipe, "steps": n_pipe,
-                    "what": "H2D upload of the scan + lii_scan_register + lii_map_incremental per step (Python host loop), separately timed",
-                    "map_points_after": reg.map_size()}
+        leaf = 0.0 if args.no_downsample else float(wl["fs_surf"])
+
+        def python_pipeline():
+            reg.synchronize()
+            tp0 = time.perf_counter()
+            for k in range(n_pipe):
+                j = k % len(host_scans)
+                reg.scan_upload(host_scans[j])
+                st = states0[j].copy()
+                reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=leaf, max_iterations=wl["max_it"], imu_en=True)
+                reg.map_incremental(st)
+            reg.synchronize()
+            return time.perf_counter() - tp0
+
+        if native is not None:
+            # the C++ host loop again (harness/stream_driver.cpp: lii_stream_run_pipeline).  Three forms of the hand-over:
+            # overlapped out of pinned host memory (the copy engine reads the caller's buffer while the previous scan registers),
+            # overlapped out of pageable memory (the library stages the scan first), and the serial lii_scan_upload.
+            drv.lii_stream_run_pipeline.restype = C.c_int
+            drv.lii_stream_run_pipeline.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                                    C.c_int32, C.c_int32, C.c_void_p]
+            pinned = [torch.from_numpy(h).pin_memory() for h in host_scans]
+
+            def run_pipe(ptrs, overlap, steps=n_pipe):
+                arr = (C.c_void_p * len(ptrs))(*ptrs)
+                tot = np.zeros(2, np.int64)
+                reg.synchronize()
+                tp0 = time.perf_counter()
+                rc = drv.lii_stream_run_pipeline(reg.h, C.byref(stream), arr, len(ptrs), steps, leaf, int(wl["max_it"]), 1,
+                                                 int(overlap), tot.ctypes.data)
+                if rc != 0:
+                    raise SystemExit(f"lii_stream_run_pipeline: status {rc}: {reg.L.lii_last_error(reg.h).decode()}")
+                return time.perf_counter() - tp0
+
+            # the first pass over the stream is the one that GROWS the map (afterwards the cyclic stream only replaces points):
+            # it is timed on its own, the three forms of the hand-over are then compared on the same (settled) map
+            tp_first = run_pipe([p.data_ptr() for p in pinned], 1, len(host_scans))
+            tp_serial = run_pipe([h.ctypes.data for h in host_scans], 0)
+            tp_pageable = run_pipe([h.ctypes.data for h in host_scans], 1)
+            tp = run_pipe([p.data_ptr() for p in pinned], 1)
+            pipeline = {"value": n_pipe / tp, "unit": "scans/s", "ms_per_scan": 1e3 * tp / n_pipe, "steps": n_pipe,
+                        "first_pass_growing_map": {"value": len(host_scans) / tp_first, "ms_per_scan": 1e3 * tp_first / len(host_scans),
+                                                   "steps": len(host_scans)},
+                        "what": "every scan out of HOST memory: lii_scan_upload_next (pinned source, copy stream, overlapping the "
+                                "previous scan) + lii_scan_register + lii_map_incremental + lii_scan_advance per step, C++ host loop, "
+                                "separately timed",
+                        "pageable_source": {"value": n_pipe / tp_pageable, "ms_per_scan": 1e3 * tp_pageable / n_pipe},
+                        "serial_upload": {"value": n_pipe / tp_serial, "ms_per_scan": 1e3 * tp_serial / n_pipe},
+                        "map_points_after": reg.map_size()}
+        else:
+            tp = python_pipeline()
+            pipeline = {"value": n_pipe / tp, "unit": "scans/s", "ms_per_scan": 1e3 * tp / n_pipe, "steps": n_pipe,
+                        "what": "H2D upload of the scan + lii_scan_register + lii_map_incremental per step (Python host loop), separately timed",
+                        "map_points_after": reg.map_size()}
 
     if rank == 0:
         scans_per_s = args.steps / dt

@@ -55,4 +55,52 @@ int lii_stream_run(lii_handle h, const lii_stream_scan* scans, int32_t n_scans, 
   return LII_OK;
 }
 
+// The COMPLETE per-scan pipeline out of host memory: the next scan travels (lii_scan_upload_next, copy stream) while the current
+// one is registered and inserted into the map; lii_scan_advance swaps.  host_scans[k]: (x, y, z, t_ms) float records of scan k
+// (pinned memory is read by the copy engine directly, pageable memory is staged by the library).
+// (the reference: the driver callback queues the scan - src/laserMapping.cpp:331-366 - while the main loop works on its predecessor)
+int lii_stream_run_pipeline(lii_handle h, const lii_stream_scan* scans, const void* const* host_scans, int32_t n_scans, int32_t steps,
+                            float leaf, int32_t max_iterations, int32_t imu_en, int32_t overlap, int64_t totals[2]) {
+  if (!h || !scans || !host_scans || n_scans < 1 || steps < 0 || !totals) return LII_ERR_INVALID;
+  lii_state st;
+  lii_iekf_report rep;
+  int rc = lii_set_profiling(h, 0);
+  if (rc != LII_OK) return rc;
+  if (overlap && steps > 0) {
+    rc = lii_scan_upload_next(h, host_scans[0], scans[0].n_points, 16, 12);
+    if (rc == LII_OK) rc = lii_scan_advance(h);
+    if (rc != LII_OK) return rc;
+  }
+  for (int32_t k = 0; k < steps; k++) {
+    const lii_stream_scan& sc = scans[k % n_scans];
+    if (overlap) {
+      if (k + 1 < steps) rc = lii_scan_upload_next(h, host_scans[(k + 1) % n_scans], scans[(k + 1) % n_scans].n_points, 16, 12);
+    } else {
+      rc = lii_scan_upload(h, host_scans[k % n_scans], sc.n_points, 16, 12);
+    }
+    if (rc != LII_OK) return rc;
+    std::memcpy(&st, sc.state0, sizeof(st));
+    lii_scan_job job;
+    std::memset(&job, 0, sizeof(job));
+    job.struct_size = sizeof(job);
+    job.undistort = 1;
+    job.imu_poses = sc.poses;
+    job.n_imu_poses = sc.n_poses;
+    job.leaf = leaf;
+    job.opts.max_iterations = max_iterations;
+    job.opts.imu_en = imu_en;
+    rc = lii_scan_register(h, &job, &st, sc.state0, &rep);
+    if (rc != LII_OK) return rc;
+    totals[0] += rep.iterations;
+    totals[1] += rep.searches;
+    rc = lii_map_incremental(h, &st, nullptr, nullptr);
+    if (rc != LII_OK) return rc;
+    if (overlap && k + 1 < steps) {
+      rc = lii_scan_advance(h);
+      if (rc != LII_OK) return rc;
+    }
+  }
+  return lii_synchronize(h);
+}
+
 }  // extern "C"

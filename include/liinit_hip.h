@@ -19,8 +19,9 @@
 extern "C" {
 #endif
 
-#define LII_ABI_VERSION 3 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
-                             3: lii_params_*, lii_comm_set_partition (library-side split of the down-sampled cloud) */
+#define LII_ABI_VERSION 4 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
+                             3: lii_params_*, lii_comm_set_partition (library-side split of the down-sampled cloud)
+                             4: lii_scan_upload_next / lii_scan_advance (the next scan travels while the current one registers) */
 
 enum lii_status {
   LII_OK = 0,
@@ -127,8 +128,18 @@ int lii_map_commit(lii_handle h);
  * lii_downsample    <- downSizeFilterSurf.filter(*feats_down_body),              src/laserMapping.cpp:917-919
  *                      (n_down == NULL && filtered == NULL: fully asynchronous — the result size stays on the device)
  * lii_downsample_skip: use the (undistorted) scan as feats_down_body unchanged (PCL's overflow-identity path).
- * lii_scan_download: which = 0 undistorted scan, 1 down-sampled body points, 2 world points of the last iteration. */
+ * lii_scan_download: which = 0 undistorted scan, 1 down-sampled body points, 2 world points of the last iteration.
+ * lii_scan_upload_next / lii_scan_advance: the scan queue of the reference (lidar_buffer, src/laserMapping.cpp:331-366 ->
+ *                  sync_packages :432-480) one element deep, on the device.  lii_scan_upload_next starts the NEXT scan on its
+ *                  way (same arguments as lii_scan_upload) into a second device buffer on the library's copy stream and returns
+ *                  at once: the transfer overlaps the registration / map update of the current scan.  A source in pinned host
+ *                  memory with stride 16 / time offset 12 is read by the copy engine directly and must stay untouched until
+ *                  lii_scan_advance has returned; any other source is staged (copied before the call returns).
+ *                  lii_scan_advance makes that scan the current one (as lii_scan_upload would have): waits for its transfer,
+ *                  swaps the buffers.  LII_ERR_STATE without a pending lii_scan_upload_next. */
 int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_bytes, int32_t time_offset_bytes);
+int lii_scan_upload_next(lii_handle h, const void* points, int32_t n, int32_t stride_bytes, int32_t time_offset_bytes);
+int lii_scan_advance(lii_handle h);
 int lii_scan_set_device(lii_handle h, const void* dev_float4, int32_t n);
 int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, const double end_R[9],
                       const double end_p[3], const double R_LI[9], const double T_LI[3]);

@@ -90,6 +90,8 @@ _DECLS = {
     "lii_map_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "lii_map_commit": (C.c_int, [C.c_void_p]),
     "lii_scan_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "lii_scan_upload_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "lii_scan_advance": (C.c_int, [C.c_void_p]),
     "lii_scan_set_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "lii_undistort_imu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 4),
     "lii_undistort_cv": (C.c_int, [C.c_void_p] + [C.c_void_p] * 3),
@@ -308,6 +310,17 @@ class Registrar:
         assert pts.ndim == 2 and pts.shape[1] in (4, 12)
         toff = 12 if pts.shape[1] == 4 else 36
         self._check(self.L.lii_scan_upload(self.h, _ptr(pts), len(pts), pts.strides[0] if len(pts) else 16, toff))
+
+    def scan_upload_next(self, pts):
+        """Starts the NEXT scan on its way (copy stream, second device buffer); `pts` must stay alive and untouched until
+        scan_advance() has returned (a pinned (n,4) source is read by the copy engine directly)."""
+        assert pts.dtype == np.float32 and pts.flags.c_contiguous and pts.ndim == 2 and pts.shape[1] in (4, 12)
+        toff = 12 if pts.shape[1] == 4 else 36
+        self._check(self.L.lii_scan_upload_next(self.h, _ptr(pts), len(pts), pts.strides[0] if len(pts) else 16, toff))
+
+    def scan_advance(self):
+        """The scan handed to scan_upload_next becomes the current one (as scan_upload would have made it)."""
+        self._check(self.L.lii_scan_advance(self.h))
 
     def device_scan(self, pts4):
         """Copies a float4 scan into a caller-owned device buffer; returns an opaque (ptr, n) for scan_set_device."""

@@ -36,6 +36,10 @@ struct lii_context {
   float ds = 0.2f;              // ikd-Tree downsample box (set_downsample_param)
   unsigned char* d_tomb = nullptr;
   float4* d_batch = nullptr;    // a host-provided Add_Points batch (M)
+  float4* d_dropped = nullptr;  // inserts an in-place update found no room for (kMapCtrDropped of them): re-inserted after a rebuild
+  unsigned int drop_cap = 0;
+  bool map_tight = false;       // LII_MAP_TEST_TIGHT=1: no spare room is provisioned (tests: forces the recovery path)
+  long long map_recoveries = 0;
   float4 *d_ins = nullptr, *d_ins_c = nullptr;         // fold output / compacted inserts or host batches (M each)
   unsigned int *d_u32_a = nullptr, *d_u32_b = nullptr, *d_u32_c = nullptr;  // flags / ranks (max(N, M) each)
   float4 *d_list_add = nullptr, *d_list_nodown = nullptr;  // map_incremental lists (N each)
@@ -44,6 +48,7 @@ struct lii_context {
   float4* d_map = nullptr;
   float4* d_pts = nullptr;            // pts_cap slots
   unsigned int pts_cap = 0;
+  unsigned int pts_cap_eff = 0;  // = pts_cap (LII_MAP_TEST_TIGHT: a few slots behind the cells, so that updates run out of room)
   unsigned int* d_cell_cap = nullptr; // capacity end of every cell entry (same indexing as d_cells)
   unsigned int* d_tp = nullptr;       // per cell entry: on-work-list bit | pending inserts
   unsigned int *d_cs_a = nullptr, *d_cs_b = nullptr;  // per cell entry scratch (capacities / counts and their scans)
@@ -71,6 +76,13 @@ struct lii_context {
 
   // ---- scan
   float4* d_scan = nullptr;   // raw / undistorted (x,y,z,t_ms)
+  // lii_scan_upload_next / lii_scan_advance: the next scan travels on a copy stream into a second buffer
+  float4* d_scan_next = nullptr;
+  float4* h_stage_next = nullptr;   // pinned staging for sources that are not (pinned, stride 16)
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_next = nullptr;      // the transfer of the next scan
+  hipEvent_t ev_scan_free = nullptr; // the compute stream has finished with the buffer the next transfer writes to
+  int n_scan_next = -1;              // >= 0: a scan is waiting in d_scan_next
   float4* d_body = nullptr;   // down-sampled body points
   float4* d_world = nullptr;
   float4* d_nbr = nullptr;    // 5 x cap
@@ -250,7 +262,7 @@ int build_index(lii_handle h, int n, int extra_blocks = 0) {
                     static_cast<void*>(h->d_cs_b)})
       if (q) HIPCHK(h, hipFree(q));
     h->d_cells = nullptr; h->d_cell_cap = nullptr; h->d_tp = nullptr; h->d_cs_a = nullptr; h->d_cs_b = nullptr;
-    const size_t want = std::max<size_t>(std::max<size_t>(want_blocks * 2, h->cells_cap_blocks), 4096);
+    const size_t want = h->map_tight ? std::max<size_t>(want_blocks, 1) : std::max<size_t>(std::max<size_t>(want_blocks * 2, h->cells_cap_blocks), 4096);
     HIPCHK(h, dmalloc(&h->d_cells, want * 512));
     HIPCHK(h, dmalloc(&h->d_cell_cap, want * 512));
     HIPCHK(h, dmalloc(&h->d_tp, want * 512));
@@ -300,15 +312,19 @@ int build_index(lii_handle h, int n, int extra_blocks = 0) {
     std::memcpy(c, h->h_small + 3072, sizeof(c));
     h->n_used = c[kMapCtrUsed];
     if ((unsigned int)h->n_used > h->pts_cap) rc = fail(h, LII_ERR_CAPACITY, "local map with its per-cell slack exceeds the point array");
+    h->pts_cap_eff = h->map_tight ? std::min<unsigned int>(h->pts_cap, (unsigned int)h->n_used + 256u) : h->pts_cap;
   }
   return rc;
 }
 
 int commit_map(lii_handle) { return LII_OK; }  // the device map is always current
 
-// Host copies of the device counters (one small synchronising read).  A capacity flag raised by an update in flight turns into
-// LII_ERR_CAPACITY here - the map has then lost inserts and is rebuilt from what it holds.
+// Host copies of the device counters (one small synchronising read).  An update in flight that ran out of room (block tables,
+// slack + tail of the point array) has parked the inserts it could not place in d_dropped: the index is rebuilt with more room
+// and those points are inserted again - nothing is lost, the caller sees no error.  Only a dropped list that itself overflowed
+// (cannot happen: it holds a whole batch) or a work-list overflow turns into LII_ERR_CAPACITY.
 int map_rebuild(lii_handle h, int extra_blocks);
+int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra);
 int map_counters(lii_handle h, bool already_synced = false) {
   if (!h->map_dirty) return LII_OK;
   if (!already_synced) {
@@ -322,8 +338,32 @@ int map_counters(lii_handle h, bool already_synced = false) {
   h->n_blocks = c[kMapCtrBlocks];
   h->map_dirty = false;
   if (c[kMapCtrOverflow]) {
-    (void)map_rebuild(h, 0);
-    return fail(h, LII_ERR_CAPACITY, "local map update ran out of room (point-array tail, block tables or work list); the map was rebuilt from the points it holds");
+    const int n_drop = c[kMapCtrDropped];
+    if (n_drop < 0 || (unsigned int)n_drop > h->drop_cap || (size_t)n_drop > size_t(h->cfg.max_map_points)) {
+      (void)map_rebuild(h, 0);
+      return fail(h, LII_ERR_CAPACITY, "local map update ran out of room and could not keep the inserts; the map was rebuilt from the points it holds");
+    }
+    h->map_recoveries++;
+    if (n_drop > 0)  // (the rebuild leaves d_dropped alone; the batch buffer is free: its Add_Points call has returned)
+      HIPCHK(h, hipMemcpyAsync(h->d_batch, h->d_dropped, sizeof(float4) * size_t(n_drop), hipMemcpyDeviceToDevice, h->stream));
+    int rc = map_rebuild(h, std::max(4096, 2 * n_drop));
+    if (rc != LII_OK) return rc;
+    if (n_drop > 0) {
+      const bool tight = h->map_tight;
+      h->map_tight = false;  // the second attempt gets its room
+      rc = map_apply(h, h->d_batch, n_drop, false, nullptr, 0);
+      h->map_tight = tight;
+      if (rc != LII_OK) return rc;
+      // settle it now: the caller of map_counters goes on with counters that include the re-inserted points
+      HIPCHK(h, hipMemcpyAsync(h->h_small + 3072, h->d_mapctr, sizeof(int) * kMapCtrWords, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      std::memcpy(c, h->h_small + 3072, sizeof(c));
+      h->n_used = c[kMapCtrUsed];
+      h->n_map = c[kMapCtrValid];
+      h->n_blocks = c[kMapCtrBlocks];
+      h->map_dirty = false;
+      if (c[kMapCtrOverflow]) return fail(h, LII_ERR_CAPACITY, "local map: the re-insertion after a rebuild ran out of room again");
+    }
   }
   return LII_OK;
 }
@@ -363,17 +403,19 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
   const int n_ins = n_list + n_extra;
   if (n_ins <= 0) return LII_OK;
   if ((long long)h->n_map + n_ins > (long long)h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "local map exceeds max_map_points");
-  // room for the update: tail of the point array (a touched cell may move there with its slack), block tables, work list
-  // (an insert moves at most one cell to the tail, with its points and fresh slack: ~14 slots for the usual 9-point cell; should a
-  // batch of unusually crowded cells still run out, the update raises the overflow flag and the next map_counters reports it)
-  const long long tail_need = 24ll * n_ins + 4096;
+  // Room is provisioned for the usual batch, not for the worst one: a handful of new 8x8x8-cell blocks, and a tail slot budget
+  // of 8 per insert (an insert that does not fit its cell's slack moves the cell - ~9 points + fresh slack - to the tail; most
+  // fit).  A batch that needs more parks the inserts it cannot place in d_dropped and the next map_counters() rebuilds and
+  // re-inserts them (lossless, slow: a full rebuild).
+  const long long tail_need = h->map_tight ? 0 : 8ll * n_ins + 4096;
+  const size_t spare_blocks = h->map_tight ? 0 : std::min<size_t>(size_t(n_ins), 1024);
   const unsigned int work_need = 9u * (unsigned int)n_list + (unsigned int)n_ins + 64u;
   if (work_need > h->work_cap) return fail(h, LII_ERR_CAPACITY, "Add_Points batch larger than the work list of the in-place update");
-  if ((long long)h->pts_cap - h->n_used < tail_need || size_t(h->n_blocks) + size_t(n_ins) > h->cells_cap_blocks ||
-      2ull * (size_t(h->n_blocks) + size_t(n_ins)) > size_t(h->blocks_cap)) {
-    rc = map_rebuild(h, n_ins);
+  if ((long long)h->pts_cap_eff - h->n_used < tail_need || size_t(h->n_blocks) + spare_blocks > h->cells_cap_blocks ||
+      2ull * (size_t(h->n_blocks) + spare_blocks) > size_t(h->blocks_cap)) {
+    rc = map_rebuild(h, h->map_tight ? 0 : std::max(4096, h->n_blocks / 2));
     if (rc != LII_OK) return rc;
-    if ((long long)h->pts_cap - h->n_used < tail_need) return fail(h, LII_ERR_CAPACITY, "local map: no room left behind the cells for an in-place update");
+    if ((long long)h->pts_cap_eff - h->n_used < tail_need) return fail(h, LII_ERR_CAPACITY, "local map: no room left behind the cells for an in-place update");
   }
   const GridView g = grid_view(h);
   h->map_dirty = true;
@@ -391,9 +433,10 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
     flags_a = h->d_u32_a;
   }
   launch_ins_cells(list_a, flags_a, n_list, nullptr, extra, n_extra, h->d_ins_e2, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp,
-                   h->d_work, h->d_mapctr, h->work_cap, s);
-  launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap, (int)work_need, s);
-  launch_ins_write(list_a, h->d_ins_e, n_list, nullptr, extra, h->d_ins_e2, n_extra, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, s);
+                   h->d_work, h->d_mapctr, h->work_cap, h->d_dropped, h->drop_cap, s);
+  launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap_eff, (int)work_need, s);
+  launch_ins_write(list_a, h->d_ins_e, n_list, nullptr, extra, h->d_ins_e2, n_extra, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, h->d_dropped,
+                   h->drop_cap, s);
   HIPCHK(h, hipGetLastError());
   // the block table may have grown: kernels launched from now on must see it (grid_view reads the host copy of the mask only)
   return LII_OK;
@@ -732,6 +775,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   if (const char* v = std::getenv("LII_VOXEL_ORDER")) h->coherent_order = std::string(v) == "brick";
   if (const char* v = std::getenv("LII_HOST_SOLVE")) h->host_solve = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_SYNC_RESULT")) h->poll_result = std::atoi(v) == 0;
+  if (const char* v = std::getenv("LII_MAP_TEST_TIGHT")) h->map_tight = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_KNN_PLAN")) h->knn_plan = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_KNN_PLAN_FORCE")) h->knn_plan_force = int(std::strtol(v, nullptr, 0) & 0x7FFFFFFF);
   h->ds = h->cfg.map_downsample_size;
@@ -790,6 +834,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(hipMemset(h->d_tomb, 0, size_t(h->pts_cap)));
   CK(dmalloc(&h->d_ins, M));
   CK(dmalloc(&h->d_batch, M));
+  h->drop_cap = (unsigned int)NM;
+  CK(dmalloc(&h->d_dropped, NM));
   CK(dmalloc(&h->d_ins_c, M));
   CK(dmalloc(&h->d_u32_a, NM));
   CK(dmalloc(&h->d_u32_b, NM));
@@ -866,6 +912,7 @@ int lii_destroy(lii_handle h) {
   (void)hipSetDevice(h->device);
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->knn_stats) std::fprintf(stderr, "[libliinit_hip] map updates completed by a rebuild + re-insertion: %lld\n", h->map_recoveries);
   if (h->knn_stats) std::fprintf(stderr, "[libliinit_hip] updates continued by the host after a parked loop: %lld\n", h->plan_parked);
   if (h->knn_stats && h->d_knn_stats) {  // LII_KNN_STATS=1: how the search workgroups of this handle split (diagnostic)
     unsigned int st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -878,7 +925,12 @@ int lii_destroy(lii_handle h) {
   }
   mailbox_close(&h->mailbox);
   if (h->d_mb_seq) (void)hipFree(h->d_mb_seq);
-  void* dev[] = {h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
+  if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+  if (h->ev_next) (void)hipEventDestroy(h->ev_next);
+  if (h->ev_scan_free) (void)hipEventDestroy(h->ev_scan_free);
+  if (h->h_stage_next) (void)hipHostFree(h->h_stage_next);
+  if (h->d_scan_next) (void)hipFree(h->d_scan_next);
+  void* dev[] = {h->d_dropped, h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_knn_stats, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
                  h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
@@ -980,8 +1032,9 @@ int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int3
   }
   h->map_dirty = true;
   launch_box_tomb_cells(h->d_pts, h->d_cells, ne, d_boxes, n_boxes, h->d_tomb, h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s);
-  launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap, ne, s);
-  launch_ins_write(h->d_pts, h->d_ins_e, 0, nullptr, nullptr, nullptr, 0, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, s);  // (re-arms the work list)
+  launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap_eff, ne, s);
+  launch_ins_write(h->d_pts, h->d_ins_e, 0, nullptr, nullptr, nullptr, 0, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, h->d_dropped, h->drop_cap,
+                   s);  // (re-arms the work list)
   rc = map_counters(h);
   if (rc != LII_OK) return rc;
   if (n_deleted) *n_deleted = n_old - h->n_map;
@@ -1041,6 +1094,64 @@ int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_
   if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scan, h->h_stage, sizeof(float4) * size_t(n), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipEventRecord(h->ev_stage, h->stream));
   h->n_scan = n;
+  extent_discard(h);
+  h->bbox_rows = 0;
+  h->n_body = 0;
+  h->n_body_pending = false;
+  h->have_search = false;
+  return LII_OK;
+}
+int lii_scan_upload_next(lii_handle h, const void* points, int32_t n, int32_t stride_bytes, int32_t time_offset_bytes) {
+  if (!h || (!points && n > 0) || n < 0 || stride_bytes < 16 || time_offset_bytes < 12 || time_offset_bytes + 4 > stride_bytes)
+    return fail(h, LII_ERR_INVALID, "lii_scan_upload_next: bad arguments");
+  if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_upload_next: n > max_scan_points");
+  if (!h->copy_stream) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_next, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_scan_free, hipEventDisableTiming));
+    HIPCHK(h, dmalloc(&h->d_scan_next, size_t(h->cfg.max_scan_points)));
+  }
+  if (h->n_scan_next >= 0) HIPCHK(h, hipEventSynchronize(h->ev_next));  // a scan that was never advanced to is replaced
+  h->n_scan_next = -1;
+  const void* src = points;
+  bool direct = false;
+  if (n > 0 && stride_bytes == 16 && time_offset_bytes == 12) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, points) == hipSuccess) direct = attr.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();  // pageable memory: not an error
+  }
+  if (n > 0 && !direct) {
+    if (!h->h_stage_next)
+      HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_stage_next), sizeof(float4) * size_t(h->cfg.max_scan_points), hipHostMallocDefault));
+    const char* p = static_cast<const char*>(points);
+    if (stride_bytes == 16 && time_offset_bytes == 12) {
+      std::memcpy(h->h_stage_next, p, sizeof(float4) * size_t(n));
+    } else {
+      for (int i = 0; i < n; i++) {
+        const float* f = reinterpret_cast<const float*>(p + size_t(i) * stride_bytes);
+        float t;
+        std::memcpy(&t, p + size_t(i) * stride_bytes + time_offset_bytes, 4);
+        h->h_stage_next[i] = make_float4(f[0], f[1], f[2], t);
+      }
+    }
+    src = h->h_stage_next;
+  }
+  // the buffer being written was the current scan of an earlier call: whatever the compute stream still has to do with it
+  // (kernels enqueued up to now) comes first
+  HIPCHK(h, hipEventRecord(h->ev_scan_free, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_scan_free, 0));
+  if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scan_next, src, sizeof(float4) * size_t(n), hipMemcpyHostToDevice, h->copy_stream));
+  HIPCHK(h, hipEventRecord(h->ev_next, h->copy_stream));
+  h->n_scan_next = n;
+  return LII_OK;
+}
+int lii_scan_advance(lii_handle h) {
+  if (!h) return LII_ERR_INVALID;
+  if (h->n_scan_next < 0) return fail(h, LII_ERR_STATE, "lii_scan_advance: no scan under way (call lii_scan_upload_next)");
+  HIPCHK(h, hipEventSynchronize(h->ev_next));  // long done when the transfer overlapped a registration; frees the caller's buffer
+  std::swap(h->d_scan, h->d_scan_next);
+  h->n_scan = h->n_scan_next;
+  h->n_scan_next = -1;
   extent_discard(h);
   h->bbox_rows = 0;
   h->n_body = 0;

@@ -80,11 +80,11 @@ void launch_touch_tombs(const unsigned char* tomb, const float4* pts, int n_slot
                         unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s);
 void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, const float4* list2, int n2, unsigned int* ins_e2,
                       BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp,
-                      unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s);
+                      unsigned int* work, int* ctr, unsigned int work_cap, float4* dropped, unsigned int drop_cap, hipStream_t s);
 void launch_cell_apply(const unsigned int* work, uint2* cells, unsigned int* cell_cap, float4* pts, unsigned char* tomb, unsigned int* tp, int* ctr,
                        unsigned int pts_cap, int launch_bound, hipStream_t s);
 void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, const float4* list2, const unsigned int* ins_e2, int n2,
-                      uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, hipStream_t s);
+                      uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, float4* dropped, unsigned int drop_cap, hipStream_t s);
 void launch_cell_caps(const uint2* cells, int n_entries, unsigned int* caps, hipStream_t s);
 void launch_spread(const float4* src, uint2* cells, unsigned int* cell_cap, const unsigned int* caps, const unsigned int* capsum, int n_entries,
                    float4* dst, int* ctr, int n_valid, int n_blocks, hipStream_t s);

@@ -541,12 +541,20 @@ __global__ void k_touch_tombs(const unsigned char* __restrict__ tomb, const floa
   if (e >= 0) touch_cell(tp, work, ctr, work_cap, (unsigned int)e);
 }
 
+// An insert that found no room (block tables full, no slack left and no tail to move the cell to) is kept for the host: the
+// next read of the counters rebuilds the index with more room and inserts these points again.
+__device__ __forceinline__ void drop_point(float4* __restrict__ dropped, unsigned int drop_cap, int* __restrict__ ctr, const float4 p) {
+  const unsigned int at = (unsigned int)atomicAdd(&ctr[kMapCtrDropped], 1);
+  if (at < drop_cap) dropped[at] = make_float4(p.x, p.y, p.z, 0.f);
+}
+
 // flags == nullptr: every point of the list is an insert.  n_dev != nullptr: the list holds *n_dev points (n is the launch bound).
 // A second list (list2, n2 points, all of them inserts, entries to ins_e2) rides in the same launch: lanes [n, n + n2).
 __global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int* __restrict__ flags, int n, const int* __restrict__ n_dev,
                             const float4* __restrict__ list2, int n2, unsigned int* __restrict__ ins_e2,
                             BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* __restrict__ ins_e,
-                            unsigned int* __restrict__ tp, unsigned int* __restrict__ work, int* __restrict__ ctr, unsigned int work_cap) {
+                            unsigned int* __restrict__ tp, unsigned int* __restrict__ work, int* __restrict__ ctr, unsigned int work_cap,
+                            float4* __restrict__ dropped, unsigned int drop_cap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) {
     i -= n;
@@ -584,7 +592,12 @@ __global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int*
     }
     sl = (sl + 1) & mask;
   }
-  if (id < 0) { ins_e[i] = 0xFFFFFFFFu; ctr[kMapCtrOverflow] = 1; return; }
+  if (id < 0) {  // no table left for a new block: the point waits in the dropped list for the host's rebuild (nothing is lost)
+    ins_e[i] = 0xFFFFFFFFu;
+    ctr[kMapCtrOverflow] = 1;
+    drop_point(dropped, drop_cap, ctr, p);
+    return;
+  }
   const unsigned int e = (unsigned int)id * kCells + ((((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u));
   ins_e[i] = e;
   touch_cell(tp, work, ctr, work_cap, e);
@@ -628,7 +641,8 @@ __global__ void k_cell_apply(const unsigned int* __restrict__ work, uint2* __res
 
 __global__ void k_ins_write(const float4* __restrict__ list, const unsigned int* __restrict__ ins_e, int n, const int* __restrict__ n_dev,
                             const float4* __restrict__ list2, const unsigned int* __restrict__ ins_e2, int n2,
-                            uint2* __restrict__ cells, const unsigned int* __restrict__ cell_cap, float4* __restrict__ pts, int* __restrict__ ctr) {
+                            uint2* __restrict__ cells, const unsigned int* __restrict__ cell_cap, float4* __restrict__ pts, int* __restrict__ ctr,
+                            float4* __restrict__ dropped, unsigned int drop_cap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) ctr[kMapCtrWork] = 0;  // the work list has been consumed (k_cell_apply ran before this launch)
   if (i >= n) {
@@ -641,13 +655,14 @@ __global__ void k_ins_write(const float4* __restrict__ list, const unsigned int*
   const unsigned int e = ins_e[i];
   if (e == 0xFFFFFFFFu) return;
   const unsigned int slot = atomicAdd(reinterpret_cast<unsigned int*>(&cells[e]) + 1, 1u);
+  const float4 p = list[i];
   if (slot < cell_cap[e]) {
-    const float4 p = list[i];
     pts[slot] = make_float4(p.x, p.y, p.z, 0.f);
     atomicAdd(&ctr[kMapCtrValid], 1);
   } else {
     atomicSub(reinterpret_cast<unsigned int*>(&cells[e]) + 1, 1u);
     ctr[kMapCtrOverflow] = 1;
+    drop_point(dropped, drop_cap, ctr, p);
   }
 }
 
@@ -718,23 +733,23 @@ void launch_touch_tombs(const unsigned char* tomb, const float4* pts, int n_slot
 }
 void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, const float4* list2, int n2, unsigned int* ins_e2,
                       BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp,
-                      unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s) {
+                      unsigned int* work, int* ctr, unsigned int work_cap, float4* dropped, unsigned int drop_cap, hipStream_t s) {
   if (n < 0) n = 0;
   if (n2 < 0) n2 = 0;
   if (n + n2 > 0)
     hipLaunchKernelGGL(k_ins_cells, dim3(nblk(n + n2, 256)), dim3(256), 0, s, list, flags, n, n_dev, list2, n2, ins_e2, blocks, mask, inv_cs, tables_cap,
-                       ins_e, tp, work, ctr, work_cap);
+                       ins_e, tp, work, ctr, work_cap, dropped, drop_cap);
 }
 void launch_cell_apply(const unsigned int* work, uint2* cells, unsigned int* cell_cap, float4* pts, unsigned char* tomb, unsigned int* tp, int* ctr,
                        unsigned int pts_cap, int launch_bound, hipStream_t s) {
   if (launch_bound > 0) hipLaunchKernelGGL(k_cell_apply, dim3(nblk(launch_bound, 128)), dim3(128), 0, s, work, cells, cell_cap, pts, tomb, tp, ctr, pts_cap, launch_bound);
 }
 void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, const float4* list2, const unsigned int* ins_e2, int n2,
-                      uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, hipStream_t s) {
+                      uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, float4* dropped, unsigned int drop_cap, hipStream_t s) {
   if (n < 0) n = 0;
   if (n2 < 0) n2 = 0;
   hipLaunchKernelGGL(k_ins_write, dim3(nblk(n + n2 > 0 ? n + n2 : 1, 256)), dim3(256), 0, s, list, ins_e, n, n_dev, list2, ins_e2, n2, cells, cell_cap, pts,
-                     ctr);
+                     ctr, dropped, drop_cap);
 }
 void launch_cell_caps(const uint2* cells, int n_entries, unsigned int* caps, hipStream_t s) {
   if (n_entries > 0) hipLaunchKernelGGL(k_cell_caps, dim3(nblk(n_entries, 256)), dim3(256), 0, s, cells, n_entries, caps);

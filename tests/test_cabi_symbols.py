@@ -30,7 +30,7 @@ def test_header_symbols_all_exported():
 def test_python_mirror_covers_header():
     assert sorted(api.EXPORTED_SYMBOLS) == _declared_symbols()
     L = lii.load_library()
-    assert L.lii_abi_version() == 3
+    assert L.lii_abi_version() == 4
 
 
 def test_struct_layouts_match_header():

@@ -214,3 +214,47 @@ def test_capacity_overflow_leaves_the_map_untouched(oracle):
     # a batch that fits still goes in afterwards
     assert reg.map_add_points(far[:1500], False) == 0 and reg.map_size() == len(base) + 1500
     reg.close()
+
+
+def test_update_that_runs_out_of_room_loses_nothing(oracle):
+    """An in-place update provisions room for the usual batch only (a few new 8x8x8-cell blocks, some tail slots).  A batch that
+    needs more - here forced with LII_MAP_TEST_TIGHT=1: no spare block tables, a 256-slot tail - parks the inserts it cannot
+    place; the next read of the counters rebuilds the index and inserts them again.  The caller sees no error and the map is
+    the reference tree's point set (ikd_Tree.cpp:381-456) all the same - including batches far outside the mapped region
+    (every point a new block) and searches right after."""
+    import os
+    import lidar_imu_init_amd as lii
+    rng = np.random.default_rng(23)
+    ds = 0.5
+    base = np.c_[rng.uniform(-15, 15, (20_000, 2)), rng.normal(0, 0.05, 20_000)].astype(np.float32)
+    os.environ["LII_MAP_TEST_TIGHT"] = "1"
+    try:
+        reg = lii.Registrar(max_scan_points=30_000, max_map_points=120_000, filter_size_map=ds)
+    finally:
+        del os.environ["LII_MAP_TEST_TIGHT"]
+    tree = oracle.Tree("oracle", downsample=ds)
+    reg.map_build(base)
+    tree.build(base)
+    for s in range(5):
+        # dense re-observation of the mapped area (slack runs out -> cells must move to the tail -> the tail runs out) ...
+        add = (base[rng.choice(len(base), 5000)] + rng.normal(0, 0.4, (5000, 3))).astype(np.float32)
+        assert reg.map_add_points(add, True) == tree.add_points(add, True)
+        assert reg.map_size() == tree.validnum()
+        # ... and a far-away patch: every point opens a new block
+        far = (rng.uniform(-1, 1, (800, 3)) * 400 + np.array([3000.0 * (s + 1), 0, 0])).astype(np.float32)
+        reg.map_add_points(far, False)
+        tree.add_points(far, False)
+        assert reg.map_size() == tree.validnum()
+    got, ref = _as_set(reg.map_download()), _as_set(tree.flatten())
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    q = np.r_[base[rng.choice(len(base), 4000)] + rng.normal(0, 0.2, (4000, 3)), far[:500] + rng.normal(0, 0.2, (500, 3))].astype(np.float32)
+    reg.scan_upload(np.c_[q, np.zeros(len(q), np.float32)])
+    n = reg.downsample_skip()
+    reg.iekf_iterate(lii.State(oracle.state_init()), True, False)
+    nb, cnt, _ = reg.neighbors(n)
+    pts, d2, rc = tree.knn(q, threads=4)
+    assert np.array_equal(cnt, rc)
+    for k in range(5):
+        m = cnt > k
+        assert np.array_equal(nb[m, k], pts[m, k])
+    reg.close()

@@ -174,3 +174,43 @@ def test_voxel_grid_sizes_around_the_sort_thresholds(reg, oracle, n):
     nd, f = reg.downsample(0.1)
     assert f == filtered and nd == len(ref)
     assert np.array_equal(reg.scan_download(1), ref)
+
+
+def test_next_scan_travels_while_the_current_one_is_in_use(reg):
+    """lii_scan_upload_next / lii_scan_advance (the reference's one-deep scan queue, src/laserMapping.cpp:331-366): the scan that
+    arrives through the second buffer is the scan lii_scan_upload would have delivered - from pageable memory (staged), from
+    pinned memory (read by the copy engine), and from 48-byte PointXYZINormal records - and the current scan is untouched
+    until the swap."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")  # the runtime the library itself uses: pinned host memory for the direct path
+    rng = np.random.default_rng(11)
+    a = rng.normal(size=(30_000, 4)).astype(np.float32)
+    b = rng.normal(size=(41_000, 4)).astype(np.float32)
+    c12 = rng.normal(size=(5_000, 12)).astype(np.float32)
+    reg.scan_upload(a)
+    reg.scan_upload_next(b)                      # pageable
+    assert np.array_equal(reg.scan_download(0), a)
+    reg.scan_advance()
+    assert np.array_equal(reg.scan_download(0), b)
+    ptr = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(ptr), C.c_size_t(a.nbytes), C.c_uint(0)) == 0
+    pinned = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(a.size,)).reshape(a.shape)
+    pinned[:] = a
+    reg.scan_upload_next(pinned)                 # pinned: direct
+    assert np.array_equal(reg.scan_download(0), b)
+    reg.scan_advance()
+    assert np.array_equal(reg.scan_download(0), a)
+    reg.scan_upload_next(c12)                    # strided records
+    reg.scan_upload_next(b)                      # replaces a scan that was never advanced to
+    reg.scan_advance()
+    assert np.array_equal(reg.scan_download(0), b)
+    reg.scan_upload_next(c12)
+    reg.scan_advance()
+    got = reg.scan_download(0)
+    assert np.array_equal(got[:, :3], c12[:, :3]) and np.array_equal(got[:, 3], c12[:, 9])
+    with pytest.raises(Exception):
+        reg.scan_advance()                       # nothing under way
+    reg.scan_upload_next(np.zeros((0, 4), np.float32))
+    reg.scan_advance()
+    assert len(reg.scan_download(0)) == 0
+    assert hip.hipHostFree(ptr) == 0
