@@ -69,15 +69,11 @@ void launch_calib_eval(int stage, const double* imu, const double* lidar, int n,
 // device-side map maintenance (lii_map.hip)
 void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* cls, uint2* blk_counts,
                                float4* world, float4* dst_add, float4* dst_nodown, int* counts, hipStream_t s);
-void launch_compact_f4(const float4* src, const unsigned int* flag, const unsigned int* ranks, int n, float4* dst, int dst_offset,
-                       int* count, hipStream_t s);
 void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, hipStream_t s);
 void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
                      unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, unsigned int* tp, unsigned int* work,
                      int* ctr, unsigned int work_cap, hipStream_t s);
 // in-place map update (lii_map.hip)
-void launch_touch_tombs(const unsigned char* tomb, const float4* pts, int n_slots, const BlockEntry* blocks, unsigned int mask, float inv_cs,
-                        unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s);
 void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, const float4* list2, int n2, unsigned int* ins_e2,
                       BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp,
                       unsigned int* work, int* ctr, unsigned int work_cap, float4* dropped, unsigned int drop_cap, hipStream_t s);
@@ -92,11 +88,6 @@ void launch_cell_counts(const uint2* cells, int n_entries, unsigned int* cnt, hi
 void launch_gather_live(const float4* pts, const uint2* cells, const unsigned int* cntsum, int n_entries, float4* dst, int dst_cap, hipStream_t s);
 void launch_box_tomb_cells(const float4* pts, const uint2* cells, int n_entries, const float* boxes, int n_boxes, unsigned char* tomb, unsigned int* tp,
                            unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s);
-void launch_box_tomb(const float4* pts, int n, const float* boxes, int n_boxes, unsigned char* tomb, unsigned int* alive, hipStream_t s);
-void launch_alive_flags(const unsigned char* tomb, int n, unsigned int* alive, hipStream_t s);
-void launch_append_f4(const float4* src, const int* count, int n_bound, float4* dst, int dst_cap, const int* off_a, const int* off_b,
-                      hipStream_t s);
-void launch_sum3(const int* a, const int* b, const int* c, int* out, hipStream_t s);
 
 // rocPRIM wrappers (lii_sort.hip)
 size_t sort_temp_bytes(int max_n);
@@ -122,9 +113,6 @@ VoxelSortPlan voxel_sort_plan(int n);
 void launch_voxel_sort_centroids(const VoxelSortBuffers& vb, const float4* pts, int n, float4* out, int* n_out, hipStream_t s);
 void sort_pairs_u32(void* temp, size_t temp_bytes, const unsigned int* kin, unsigned int* kout, const unsigned int* vin,
                     unsigned int* vout, int n, hipStream_t s);
-void merge_pairs_u64_f4(void* temp, size_t temp_bytes, const unsigned long long* k1, const unsigned long long* k2,
-                        unsigned long long* kout, const float4* v1, const float4* v2, float4* vout, int n1, int n2,
-                        hipStream_t s);
 void inclusive_scan_u32(void* temp, size_t temp_bytes, const unsigned int* in, unsigned int* out, int n, hipStream_t s);
 
 float ord_to_float(unsigned int o);

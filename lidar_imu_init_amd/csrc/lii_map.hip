@@ -1,11 +1,16 @@
-// Device-side maintenance of the local map with the reference's incremental k-d tree SET semantics.
-//   k_map_decide ........ map_incremental's per-point decision            src/laserMapping.cpp:516-553
-//   k_add_keys / k_add_fold  KD_TREE::Add_Points(points, downsample_on = true)   include/ikd-Tree/ikd_Tree.cpp:381-426:
+// Device-side maintenance of the local map with the reference's incremental k-d tree SET semantics, IN PLACE (DESIGN.md
+// section 2): the point array keeps slack behind every cell, an update touches the cells of its batch only.
+//   k_map_decide + k_compact_lists  map_incremental's per-point decision and its two lists     src/laserMapping.cpp:516-553
+//   k_add_keys / k_add_fold8        KD_TREE::Add_Points(points, downsample_on = true)  include/ikd-Tree/ikd_Tree.cpp:381-426:
 //                         per down-sample voxel "keep the point closest to the voxel centre": the points of one batch that
-//                         fall into the same voxel interact sequentially, different voxels are independent — one GPU thread
-//                         folds one voxel group in the batch order (stable sort by voxel), querying the current map grid with
+//                         fall into the same voxel interact sequentially, different voxels are independent - eight lanes
+//                         fold one voxel group in the batch order (stable sort by voxel), querying the current map grid with
 //                         the reference's exact float box predicate (Search_by_range / Delete_by_range, :616-629, :970-985).
-//   k_compact_* ......... apply deletions (tombstones) and insertions, then the index is rebuilt (lii_capi.cpp: build_index)
+//   k_ins_cells -> k_cell_apply -> k_ins_write   apply the tombstones and the inserts cell by cell: find / create the cell of
+//                         every insert, squeeze the touched cells (moving one to the tail of the array when its slack is used
+//                         up), claim a slot per insert.  Inserts that find no room wait in a list for the host's rebuild.
+//   k_box_tomb_cells      KD_TREE::Delete_Point_Boxes                                  include/ikd-Tree/ikd_Tree.cpp:500-516
+//   k_cell_caps / k_spread / k_cell_counts / k_gather_live   (re)build: compact cell-sorted array <-> slack layout
 // Set equivalence with the tree is tested against the oracle's restated tree and against the unmodified reference tree
 // (tests/test_gpu_map.py).  Ties between equal squared distances to the voxel centre are broken by map order here and by
 // tree traversal order in the reference (measure zero).
@@ -169,15 +174,6 @@ __global__ __launch_bounds__(256) void k_compact_lists(const float4* __restrict_
   }
 }
 
-// dst[rank - 1] = src[i] where flag[i] (rank = inclusive scan of flag); *count = ranks[n - 1]
-__global__ void k_compact_f4(const float4* __restrict__ src, const unsigned int* __restrict__ flag,
-                             const unsigned int* __restrict__ ranks, int n, float4* __restrict__ dst, int dst_offset,
-                             int* __restrict__ count) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (i == n - 1 && count) *count = (int)ranks[n - 1];
-  if (flag[i]) dst[dst_offset + ranks[i] - 1] = src[i];
-}
 
 // ------------------------------------------------------------------------------------------------ Add_Points (down-sampling)
 // n may be an upper bound: entries i >= *n_dev get the invalid key and sort to the end.
@@ -197,113 +193,17 @@ __global__ void k_add_keys(const float4* __restrict__ pts, int n, const int* __r
   idx[i] = (unsigned)i;
 }
 
-// One thread per voxel group.  tomb[j] = 1 marks existing map point j as deleted; ins_flag[i] = 1 / ins_pts[i] = the point
-// to insert, for the group starting at sorted position i; *events accumulates the reference's tmp_counter.
-__global__ void k_add_fold(const float4* __restrict__ add_pts, const unsigned long long* __restrict__ keys,
-                           const unsigned int* __restrict__ idx, int n, float ds, GridView g, unsigned char* __restrict__ tomb,
-                           float4* __restrict__ ins_pts, unsigned int* __restrict__ ins_flag, unsigned int* __restrict__ events) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  ins_flag[i] = 0;
-  const unsigned long long key = keys[i];
-  if (key == kInvalidKey) return;
-  if (i > 0 && keys[i - 1] == key) return;  // not a group leader
-  const float4 p0 = add_pts[idx[i]];
-  // Box_of_Point / mid_point (:390-399), float arithmetic; (max - min) / 2.0 is evaluated in double
-  float bmin[3], bmax[3], mid[3];
-  {
-    const float c[3] = {p0.x, p0.y, p0.z};
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      bmin[a] = floorf(c[a] / ds) * ds;
-      bmax[a] = bmin[a] + ds;
-      mid[a] = (float)((double)bmin[a] + (double)(bmax[a] - bmin[a]) / 2.0);
-    }
-  }
-  // existing points inside the box: every grid cell that can intersect it (with slack for float rounding of cell bounds)
-  int c0[3], c1[3];
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    const float slack = 1e-6f * (fabsf(bmin[a]) + fabsf(bmax[a]) + 8.f);
-    c0[a] = (int)floorf((bmin[a] - slack) * g.inv_cs);
-    c1[a] = (int)floorf((bmax[a] + slack) * g.inv_cs);
-  }
-  int n0 = 0, best = -1;
-  float bestd = __builtin_inff();
-  if (g.n_pts > 0) {
-    for (int cz = c0[2]; cz <= c1[2]; cz++)
-      for (int cy = c0[1]; cy <= c1[1]; cy++)
-        for (int cx = c0[0]; cx <= c1[0]; cx++) {
-          const uint2 r = d_cell_range(g, cx, cy, cz);
-          for (unsigned int j = r.x; j < r.y; j++) {
-            const float4 q = g.pts[j];
-            if (bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) {
-              n0++;
-              const float d = d_dist2(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
-              if (d < bestd) { bestd = d; best = (int)j; }
-            }
-          }
-        }
-  }
-  // sequential fold over the points of this voxel, in batch order (see header)
-  bool ev = false;
-  bool cur_new = false;
-  int cur_old = -1;
-  float cx_ = 0, cy_ = 0, cz_ = 0, cd = 0;
-  unsigned int n_events = 0;
-  for (int t = i; t < n && keys[t] == key; t++) {
-    const float4 p = add_pts[idx[t]];
-    const float dp = d_dist2(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
-    if (!ev) {
-      const bool old_wins = (n0 > 0) && (bestd < dp);
-      float rx = p.x, ry = p.y, rz = p.z;
-      if (old_wins) { const float4 q = g.pts[best]; rx = q.x; ry = q.y; rz = q.z; }
-      if (n0 > 1 || d_same_point(p.x, p.y, p.z, rx, ry, rz)) {
-        ev = true;
-        n_events++;
-        cur_new = !old_wins;
-        cur_old = old_wins ? best : -1;
-        cx_ = rx; cy_ = ry; cz_ = rz;
-        cd = old_wins ? bestd : dp;
-      }
-    } else {
-      const bool cur_wins = cd < dp;
-      const float rx = cur_wins ? cx_ : p.x, ry = cur_wins ? cy_ : p.y, rz = cur_wins ? cz_ : p.z;
-      if (d_same_point(p.x, p.y, p.z, rx, ry, rz)) {
-        n_events++;
-        if (!cur_wins) { cur_new = true; cur_old = -1; cx_ = p.x; cy_ = p.y; cz_ = p.z; cd = dp; }
-      }
-    }
-  }
-  if (!ev) return;
-  atomicAdd(events, n_events);
-  // delete every existing in-box point except a surviving one; insert the survivor if it is a new point
-  if (n0 == 1) {
-    // the usual case once the map is down-sampled (at most one point per box): the only in-box point is `best`
-    if (best != cur_old) tomb[best] = 1;
-  } else if (n0 > 1) {
-    for (int cz = c0[2]; cz <= c1[2]; cz++)
-      for (int cy = c0[1]; cy <= c1[1]; cy++)
-        for (int cx = c0[0]; cx <= c1[0]; cx++) {
-          const uint2 r = d_cell_range(g, cx, cy, cz);
-          for (unsigned int j = r.x; j < r.y; j++) {
-            const float4 q = g.pts[j];
-            if ((int)j != cur_old && bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z)
-              tomb[j] = 1;
-          }
-        }
-  }
-  if (cur_new) {
-    ins_pts[i] = make_float4(cx_, cy_, cz_, 0.f);
-    ins_flag[i] = 1;
-  }
-}
 
-// The same fold with EIGHT lanes per voxel group: the down-sample box (edge ds) spans at most 2 x 2 x 2 grid cells (cell edge >= ds:
-// the usual 3 ds), one per lane, so the existing in-box points are found with ONE dependent lookup chain per group instead of
-// eight in sequence; lane 0 then replays the batch points of the voxel and the lanes mark the tombstones of their own cells.
-// Groups whose box spans more cells (a caller-chosen cell edge below ds) take k_add_fold's sequential walk.  Same results: the
-// lanes are numbered in the walk's order (z outer, x inner), ties of the squared distance go to the lower lane / lower index.
+// Add_Points with down-sampling, one voxel group (the batch points of one down-sample box, adjacent after the sort) per EIGHT
+// lanes.  tomb[j] = 1 marks existing map point j as deleted; ins_flag[i] = 1 / ins_pts[i] = the point to insert, for the group
+// starting at sorted position i; *events accumulates the reference's tmp_counter (ikd_Tree.cpp:381-426).
+// The down-sample box (edge ds) spans at most 2 x 2 x 2 grid cells (cell edge >= ds: the usual 3 ds), one per lane, so the
+// existing in-box points are found with ONE dependent lookup chain per group instead of eight in sequence; lane 0 then replays the
+// batch points of the voxel in batch order - the reference's sequential "keep the point closest to the centre" rule: existing
+// count, strict '<', same_point 1e-6 - and the lanes mark the tombstones of their own cells (putting the cell on the work list
+// of the in-place update).  Groups whose box spans more cells (a caller-chosen cell edge below ds) are walked by lane 0 alone,
+// cells in z-outer / x-inner order.  The lanes are numbered in that order too, ties of the squared distance go to the lower
+// lane / lower index: both forms visit the existing points in the same order.
 __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ add_pts, const unsigned long long* __restrict__ keys,
                                                    const unsigned int* __restrict__ idx, int n, float ds, GridView g,
                                                    unsigned char* __restrict__ tomb, float4* __restrict__ ins_pts,
@@ -353,7 +253,7 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
           if (d < bestd) { bestd = d; best = (int)j; }
         }
       }
-    } else if (wide && c == 0) {  // the sequential walk of k_add_fold
+    } else if (wide && c == 0) {  // the sequential walk (box wider than 2 x 2 x 2 cells)
       for (int cz = c0[2]; cz <= c1[2]; cz++)
         for (int cy = c0[1]; cy <= c1[1]; cy++)
           for (int cx = c0[0]; cx <= c1[0]; cx++) {
@@ -384,7 +284,7 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
   bool ev = false, cur_new = false;
   int cur_old = -1;
   if (c == 0) {
-    // sequential fold over the points of this voxel, in batch order (k_add_fold)
+    // sequential fold over the points of this voxel, in batch order
     float cx_ = 0, cy_ = 0, cz_ = 0, cd = 0;
     unsigned int n_events = 0;
     for (int t = i; t < n && keys[t] == key; t++) {
@@ -466,39 +366,7 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
   }
 }
 
-__global__ void k_alive_flags(const unsigned char* __restrict__ tomb, int n, unsigned int* __restrict__ alive) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) alive[i] = tomb[i] ? 0u : 1u;
-}
-// appends src[0 .. *count) behind dst[*offset ...); counts live on the device (upper bound n for the launch).  Writes at or
-// beyond dst_cap are dropped: the caller learns about the overflow from the counters and reports LII_ERR_CAPACITY.
-__global__ void k_append_f4(const float4* __restrict__ src, const int* __restrict__ count, int n_bound, float4* __restrict__ dst,
-                            int dst_cap, const int* __restrict__ off_a, const int* __restrict__ off_b) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = count ? *count : n_bound;
-  if (i >= n_bound || i >= n) return;
-  const long long at = (long long)(off_a ? *off_a : 0) + (off_b ? *off_b : 0) + i;
-  if (at < dst_cap) dst[at] = src[i];
-}
-__global__ void k_sum3(const int* a, const int* b, const int* c, int* out) {
-  if (threadIdx.x == 0) *out = (a ? *a : 0) + (b ? *b : 0) + (c ? *c : 0);
-}
 
-// KD_TREE::Delete_Point_Boxes (ikd_Tree.cpp:500-516) -> Delete_by_range (:608-670): a point goes when min <= p < max on every
-// axis (:631).  One lane per map point, the boxes (6 floats each) walked from constant-cached memory.
-__global__ void k_box_tomb(const float4* __restrict__ pts, int n, const float* __restrict__ boxes, int n_boxes,
-                           unsigned char* __restrict__ tomb, unsigned int* __restrict__ alive) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
-  bool dead = false;
-  for (int b = 0; b < n_boxes; b++) {
-    const float* q = boxes + 6 * b;
-    dead = dead || (q[0] <= p.x && q[3] > p.x && q[1] <= p.y && q[4] > p.y && q[2] <= p.z && q[5] > p.z);
-  }
-  tomb[i] = dead ? 1 : 0;
-  alive[i] = dead ? 0u : 1u;
-}
 
 // ================================================================================================ in-place map update
 // Round 2: the map is no longer re-sorted / re-indexed on every update.  The point array keeps SLACK behind every cell
@@ -515,31 +383,8 @@ __global__ void k_box_tomb(const float4* __restrict__ pts, int n, const float* _
 // fills up or the block table gets crowded.
 namespace {
 __device__ __forceinline__ unsigned int m_hash_block(int bx, int by, int bz) { return d_hash_block(bx, by, bz); }
-// cell entry index (block id * 512 + local cell) of the cell holding p, or -1 when its block is not in the table
-__device__ __forceinline__ long long entry_of(const BlockEntry* __restrict__ blocks, unsigned int mask, float inv_cs, float x, float y, float z) {
-  const int ix = (int)floorf(x * inv_cs), iy = (int)floorf(y * inv_cs), iz = (int)floorf(z * inv_cs);
-  const int bb = kBias >> kCoarseShift;
-  const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
-  const unsigned long long bk = d_pack_block(bx, by, bz);
-  unsigned int sl = m_hash_block(bx, by, bz) & mask;
-  while (true) {
-    const BlockEntry e = blocks[sl];
-    if (e.key == bk) return (long long)e.id * kCells + ((((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u));
-    if (e.key == kEmptyKey) return -1;
-    sl = (sl + 1) & mask;
-  }
-}
 }  // namespace
 
-__global__ void k_touch_tombs(const unsigned char* __restrict__ tomb, const float4* __restrict__ pts, int n_slots,
-                              const BlockEntry* __restrict__ blocks, unsigned int mask, float inv_cs, unsigned int* __restrict__ tp,
-                              unsigned int* __restrict__ work, int* __restrict__ ctr, unsigned int work_cap) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_slots || !tomb[i]) return;
-  const float4 p = pts[i];
-  const long long e = entry_of(blocks, mask, inv_cs, p.x, p.y, p.z);
-  if (e >= 0) touch_cell(tp, work, ctr, work_cap, (unsigned int)e);
-}
 
 // An insert that found no room (block tables full, no slack left and no tail to move the cell to) is kept for the host: the
 // next read of the counters rebuilds the index with more room and inserts these points again.
@@ -727,10 +572,6 @@ __global__ void k_box_tomb_cells(const float4* __restrict__ pts, const uint2* __
 }
 
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
-void launch_touch_tombs(const unsigned char* tomb, const float4* pts, int n_slots, const BlockEntry* blocks, unsigned int mask, float inv_cs,
-                        unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s) {
-  if (n_slots > 0) hipLaunchKernelGGL(k_touch_tombs, dim3(nblk(n_slots, 256)), dim3(256), 0, s, tomb, pts, n_slots, blocks, mask, inv_cs, tp, work, ctr, work_cap);
-}
 void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, const float4* list2, int n2, unsigned int* ins_e2,
                       BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp,
                       unsigned int* work, int* ctr, unsigned int work_cap, float4* dropped, unsigned int drop_cap, hipStream_t s) {
@@ -768,9 +609,6 @@ void launch_box_tomb_cells(const float4* pts, const uint2* cells, int n_entries,
                            unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s) {
   if (n_entries > 0) hipLaunchKernelGGL(k_box_tomb_cells, dim3(nblk(n_entries, 256)), dim3(256), 0, s, pts, cells, n_entries, boxes, n_boxes, tomb, tp, work, ctr, work_cap);
 }
-void launch_box_tomb(const float4* pts, int n, const float* boxes, int n_boxes, unsigned char* tomb, unsigned int* alive, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_box_tomb, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, boxes, n_boxes, tomb, alive);
-}
 
 void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* cls, uint2* blk_counts,
                                float4* world, float4* dst_add, float4* dst_nodown, int* counts, hipStream_t s) {
@@ -779,29 +617,14 @@ void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps,
   hipLaunchKernelGGL(k_map_decide, dim3(nb), dim3(256), 0, s, rb, ps, fsd, have_search, cls, blk_counts, world);
   hipLaunchKernelGGL(k_compact_lists, dim3(nb), dim3(256), 0, s, world, cls, blk_counts, rb.n, dst_add, dst_nodown, counts);
 }
-void launch_compact_f4(const float4* src, const unsigned int* flag, const unsigned int* ranks, int n, float4* dst, int dst_offset,
-                       int* count, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_compact_f4, dim3(nblk(n, 256)), dim3(256), 0, s, src, flag, ranks, n, dst, dst_offset, count);
-}
 void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_add_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, n_dev, ds, keys, idx);
 }
 void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
                      unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, unsigned int* tp, unsigned int* work,
                      int* ctr, unsigned int work_cap, hipStream_t s) {
-  (void)&k_add_fold;  // kept as the reference form of the walk (k_add_fold8 falls back to it lane by lane for wide boxes)
   if (n > 0) hipLaunchKernelGGL(k_add_fold8, dim3(nblk(n * 8, 256)), dim3(256), 0, s, add_pts, keys, idx, n, ds, g, tomb, ins_pts, ins_flag, events, tp,
                             work, ctr, work_cap);
-}
-void launch_alive_flags(const unsigned char* tomb, int n, unsigned int* alive, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_alive_flags, dim3(nblk(n, 256)), dim3(256), 0, s, tomb, n, alive);
-}
-void launch_append_f4(const float4* src, const int* count, int n_bound, float4* dst, int dst_cap, const int* off_a, const int* off_b,
-                      hipStream_t s) {
-  if (n_bound > 0) hipLaunchKernelGGL(k_append_f4, dim3(nblk(n_bound, 256)), dim3(256), 0, s, src, count, n_bound, dst, dst_cap, off_a, off_b);
-}
-void launch_sum3(const int* a, const int* b, const int* c, int* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_sum3, dim3(1), dim3(64), 0, s, a, b, c, out);
 }
 
 }  // namespace lii

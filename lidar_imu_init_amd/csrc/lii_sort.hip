@@ -27,13 +27,6 @@ size_t sort_temp_bytes(int max_n) {
   m = m > d ? m : d;
   return m + 256;
 }
-// Two sorted (key, point) runs -> one; equal keys keep run 1 before run 2 (merge path with `less`), so a cell's old points
-// stay ahead of its new ones exactly as a stable sort of the concatenation would leave them.
-void merge_pairs_u64_f4(void* temp, size_t temp_bytes, const unsigned long long* k1, const unsigned long long* k2,
-                        unsigned long long* kout, const float4* v1, const float4* v2, float4* vout, int n1, int n2,
-                        hipStream_t s) {
-  (void)rocprim::merge(temp, temp_bytes, k1, k2, kout, v1, v2, vout, (size_t)n1, (size_t)n2, rocprim::less<unsigned long long>(), s);
-}
 void sort_pairs_u64(void* temp, size_t temp_bytes, const unsigned long long* kin, unsigned long long* kout,
                     const unsigned int* vin, unsigned int* vout, int n, hipStream_t s) {
   if (n <= 0) return;

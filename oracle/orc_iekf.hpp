@@ -14,8 +14,10 @@
 //   * K(24 x m) is never materialised by default: K z = K1[:, :12](H^T R^-1 z) and
 //     K H = K1[:, :12](H^T R^-1 H) exactly; `literal_gain` forms K as the reference
 //     does, for the equivalence test.
-// Parity status: UNPINNED by the reference (no point clouds or tests are committed);
-// validated by closed-form synthetic ground truth in tests/test_oracle_iekf.py.
+// Parity status: UNPINNED by the reference (no point clouds or tests are committed); validated by closed-form
+// synthetic ground truth (tests/test_oracle_core.py::test_iekf_recovers_known_pose_and_literal_gain) and by an independent numpy
+// iteration with the literal 24 x m gain (tests/test_oracle_iekf_independent.py); its so3 / StatesGroup algebra (orc_math.hpp) is
+// pinned bit for bit to the reference's headers (tests/test_oracle_math_pinned.py).
 #pragma once
 #include <cstdint>
 #include <vector>

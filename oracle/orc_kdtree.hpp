@@ -14,8 +14,8 @@
 //   * no background rebuild pthread / operation logger: every rebuild is synchronous;
 //   * box deletions mark nodes eagerly instead of lazily pushing `tree_deleted` flags down.
 // Pinned against the UNMODIFIED reference tree compiled out-of-tree (oracle/_ref, see Makefile)
-// in tests/test_oracle_kdtree.py: identical neighbour sets and distances, identical tree contents
-// after Add_Points streams.
+// in tests/test_oracle_core.py::test_kdtree_against_reference_ikdtree (and, through the device map, in tests/test_gpu_map.py):
+// identical neighbour sets and distances, identical tree contents after Add_Points / Delete_Point_Boxes streams.
 #pragma once
 #include <algorithm>
 #include <cmath>

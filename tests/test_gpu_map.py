@@ -258,3 +258,48 @@ def test_update_that_runs_out_of_room_loses_nothing(oracle):
         m = cnt > k
         assert np.array_equal(nb[m, k], pts[m, k])
     reg.close()
+
+
+def test_long_update_sequence_keeps_the_tree_set(oracle):
+    """Thirty rounds of what a moving sensor does to the map - down-sampled re-observations of the mapped area, plain inserts,
+    a patch of new ground ahead (new 8x8x8-cell blocks created inside the update), box deletions behind - applied IN PLACE:
+    after every fifth round and at the end the device map is the tree's point set, `Add_Points` / `Delete_Point_Boxes` return the
+    tree's counters every time, and the index answers like the tree (ikd_Tree.cpp:381-456, :500-516)."""
+    import lidar_imu_init_amd as lii
+    rng = np.random.default_rng(41)
+    ds = 0.4
+    base = np.c_[rng.uniform(-12, 12, (25_000, 2)), rng.normal(0, 0.05, 25_000)].astype(np.float32)
+    reg = lii.Registrar(max_scan_points=30_000, max_map_points=400_000, filter_size_map=ds)
+    tree = oracle.Tree("ref" if oracle.ref_available() else "oracle", downsample=ds)
+    reg.map_build(base)
+    tree.build(base)
+    live = base
+    for s in range(30):
+        x0 = 12.0 + 4.0 * s  # the frontier moves along +x
+        again = (live[rng.choice(len(live), 4000)] + rng.normal(0, 0.3, (4000, 3))).astype(np.float32)
+        assert reg.map_add_points(again, True) == tree.add_points(again, True)
+        ahead = np.c_[rng.uniform(x0, x0 + 4.0, 1500), rng.uniform(-12, 12, 1500), rng.normal(0, 0.05, 1500)].astype(np.float32)
+        assert reg.map_add_points(ahead, True) == tree.add_points(ahead, True)
+        plain = np.c_[rng.uniform(x0 - 8, x0 + 4, 300), rng.uniform(-12, 12, 300), rng.uniform(0.5, 3.0, 300)].astype(np.float32)
+        reg.map_add_points(plain, False)
+        tree.add_points(plain, False)
+        if s % 3 == 2:  # drop a slab behind the sensor (lasermap_fov_segment's cub_needrm, src/laserMapping.cpp:260-305)
+            xb = -12.0 + 4.0 * (s // 3)
+            boxes = np.array([[xb, -13, -1, xb + 4.0, 13, 4]], np.float32)
+            assert reg.map_delete_boxes(boxes) == tree.delete_boxes(boxes)
+        assert reg.map_size() == tree.validnum()
+        if s % 5 == 4 or s == 29:
+            got, ref = _as_set(reg.map_download()), _as_set(tree.flatten())
+            assert got.shape == ref.shape and np.array_equal(got, ref), s
+            live = got
+    q = (live[rng.choice(len(live), 6000)] + rng.normal(0, 0.2, (6000, 3))).astype(np.float32)
+    reg.scan_upload(np.c_[q, np.zeros(len(q), np.float32)])
+    n = reg.downsample_skip()
+    reg.iekf_iterate(lii.State(oracle.state_init()), True, False)
+    nb, cnt, _ = reg.neighbors(n)
+    pts, d2, rc = tree.knn(q, threads=4)
+    assert np.array_equal(cnt, rc)
+    for k in range(5):
+        m = cnt > k
+        assert np.array_equal(nb[m, k], pts[m, k])
+    reg.close()
