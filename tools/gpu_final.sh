@@ -17,6 +17,10 @@ for w in vlp16 os1_128 os1_128_cut3 dense500k; do
   timeout 300 python bench.py --workload $w --no-cpu-baseline --no-pipeline --steps 200 > $O/bench_$w.json 2> $O/bench_$w.err; echo "$w rc=$?"; cut -c1-130 $O/bench_$w.json
 done
 timeout 300 python bench.py --map-update --no-cpu-baseline --no-pipeline --steps 200 > $O/bench_mapupdate.json 2> $O/bench_mapupdate.err; echo "map-update rc=$?"; cut -c1-130 $O/bench_mapupdate.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_map -o r02 -- python bench.py --steps 100 --warmup 10 --prime 20 --map-update --no-cpu-baseline --no-pipeline > $O/prof_map.log 2>&1; echo "prof map rc=$?"
+python tools/summarize_profile.py $O/prof_map $O/r02_mapupdate_kernel_summary.md "Round 2 - python bench.py --steps 100 --warmup 10 --prime 20 --map-update --no-cpu-baseline --no-pipeline (stream100k; lii_scan_register + lii_map_incremental per scan: in-place map update)" > /dev/null 2>&1
+rm -rf $O/prof_map
+LII_KNN_PLAN=0 timeout 300 python bench.py --no-cpu-baseline --no-pipeline --steps 200 > $O/bench_noplan.json 2> $O/bench_noplan.err; echo "no launch plan rc=$?"; cut -c1-130 $O/bench_noplan.json
 timeout 300 python bench.py --upload --no-cpu-baseline --no-pipeline --steps 200 > $O/bench_upload.json 2> $O/bench_upload.err; echo "upload rc=$?"; cut -c1-130 $O/bench_upload.json
 timeout 300 python bench.py --no-downsample --no-cpu-baseline --no-pipeline --steps 200 > $O/bench_nodown.json 2> $O/bench_nodown.err; echo "no-downsample rc=$?"; cut -c1-130 $O/bench_nodown.json
 for n in 2 4; do
