@@ -88,6 +88,28 @@ __device__ __forceinline__ float d_dist2(float ax, float ay, float az, float bx,
   float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
   return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
+// Thousands of lanes adding to the same counter serialise at ~2.4 ns each (12 us per update for the live-point counter alone):
+// the lanes of a wavefront add up first and issue ONE atomic.
+// wave_atomic_add_all: every lane of the wavefront is active at the call (butterfly sum).
+__device__ __forceinline__ void wave_atomic_add_all(int* ctr, int v) {
+  int sum = v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  if ((threadIdx.x & 63) == 0 && sum != 0) atomicAdd(ctr, sum);
+}
+// wave_atomic_add_few: any set of active lanes, few contributors (`has`): the active lanes walk the contributors' bits together.
+__device__ __forceinline__ void wave_atomic_add_few(unsigned int* ctr, bool has, unsigned int v) {
+  const unsigned long long act = __ballot(1);
+  unsigned long long m = __ballot(has);
+  unsigned int sum = 0;
+  while (m) {
+    const int l = __ffsll((long long)m) - 1;
+    sum += (unsigned int)__shfl((int)v, l);
+    m &= m - 1ull;
+  }
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1 && sum != 0u) atomicAdd(ctr, sum);
+}
+
 __device__ __forceinline__ bool d_same_point(float ax, float ay, float az, float bx, float by, float bz) {
   // same_point (ikd_Tree.cpp:1269-1271): fabs(float - float) < EPSS (1e-6, double)
   return (double)fabsf(ax - bx) < 1e-6 && (double)fabsf(ay - by) < 1e-6 && (double)fabsf(az - bz) < 1e-6;
@@ -238,6 +260,11 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
   const bool wide = (c1[0] - c0[0] > 1) || (c1[1] - c0[1] > 1) || (c1[2] - c0[2] > 1);  // uniform over the 8 lanes
   const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
   const bool mine = !wide && c0[0] + dx <= c1[0] && c0[1] + dy <= c1[1] && c0[2] + dz <= c1[2];
+  // the first eight batch points of the group, one per lane (the replay below reads them by shuffle instead of walking
+  // keys[t] -> idx[t] -> add_pts[...] one dependent pair of loads per point); the loads overlap the grid lookups
+  const int tt = i + c;
+  const bool mv = tt < n && keys[tt] == key;
+  const float4 mp = mv ? add_pts[idx[tt]] : make_float4(0.f, 0.f, 0.f, 0.f);
   int n0 = 0, best = -1;
   float bestd = __builtin_inff();
   uint2 r = make_uint2(0u, 0u);
@@ -245,12 +272,18 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
   if (g.n_pts > 0) {
     if (mine) {
       r = d_cell_range_e(g, c0[0] + dx, c0[1] + dy, c0[2] + dz, my_entry);
-      for (unsigned int j = r.x; j < r.y; j++) {
-        const float4 q = g.pts[j];
-        if (bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) {
-          n0++;
-          const float d = d_dist2(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
-          if (d < bestd) { bestd = d; best = (int)j; }
+      for (unsigned int j0 = r.x; j0 < r.y; j0 += 4u) {  // four candidates per trip, loaded together; visited in index order
+        float4 q4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) q4[u] = g.pts[min(j0 + (unsigned)u, r.y - 1u)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const float4 q = q4[u];
+          if (j0 + (unsigned)u < r.y && bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) {
+            n0++;
+            const float d = d_dist2(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
+            if (d < bestd) { bestd = d; best = (int)(j0 + (unsigned)u); }
+          }
         }
       }
     } else if (wide && c == 0) {  // the sequential walk (box wider than 2 x 2 x 2 cells)
@@ -281,19 +314,24 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
     // later steps compare sub-group winners whose owner order is the order of the sub-groups: the lower sub-group holds lower lanes)
     if (take) { best = ob; bestd = od; }
   }
+  // Sequential fold over the points of this voxel, in batch order - run by all eight lanes alike (same inputs, same result in
+  // every lane): the first eight points come out of the lanes' registers by shuffle, a longer group goes on from memory.
   bool ev = false, cur_new = false;
   int cur_old = -1;
-  if (c == 0) {
-    // sequential fold over the points of this voxel, in batch order
+  {
+    const int lead = (threadIdx.x & 63) & ~7;
+    const unsigned int gm = (unsigned int)((__ballot(mv) >> lead) & 0xFFull);  // the group is contiguous: a prefix of the 8 lanes
+    const int m8 = __popc(gm);
+    float4 qb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n0 > 0 && best >= 0) qb = g.pts[best];  // the existing point a batch point may lose against
     float cx_ = 0, cy_ = 0, cz_ = 0, cd = 0;
     unsigned int n_events = 0;
-    for (int t = i; t < n && keys[t] == key; t++) {
-      const float4 p = add_pts[idx[t]];
+    auto replay = [&](const float4 p) {
       const float dp = d_dist2(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
       if (!ev) {
         const bool old_wins = (n0 > 0) && (bestd < dp);
         float rx = p.x, ry = p.y, rz = p.z;
-        if (old_wins) { const float4 q = g.pts[best]; rx = q.x; ry = q.y; rz = q.z; }
+        if (old_wins) { rx = qb.x; ry = qb.y; rz = qb.z; }
         if (n0 > 1 || d_same_point(p.x, p.y, p.z, rx, ry, rz)) {
           ev = true;
           n_events++;
@@ -310,18 +348,22 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
           if (!cur_wins) { cur_new = true; cur_old = -1; cx_ = p.x; cy_ = p.y; cz_ = p.z; cd = dp; }
         }
       }
+    };
+    for (int t = 0; t < m8; t++) {
+      float4 p;
+      p.x = __shfl(mp.x, lead + t); p.y = __shfl(mp.y, lead + t); p.z = __shfl(mp.z, lead + t); p.w = 0.f;
+      replay(p);
     }
-    if (ev) {
-      atomicAdd(events, n_events);
+    if (m8 == 8)
+      for (int t = i + 8; t < n && keys[t] == key; t++) replay(add_pts[idx[t]]);
+    wave_atomic_add_few(events, c == 0 && ev, n_events);  // (the groups of this wavefront that are still here: all leaders)
+    if (c == 0 && ev) {
       if (cur_new) {
         ins_pts[i] = make_float4(cx_, cy_, cz_, 0.f);
         ins_flag[i] = 1;
       }
     }
   }
-  const int lead = (threadIdx.x & 63) & ~7;
-  ev = __shfl((int)ev, lead) != 0;
-  cur_old = __shfl(cur_old, lead);
   if (!ev) return;
   // delete every existing in-box point except a surviving one
   // (the lane whose cell holds a tombstoned point also puts that cell on the work list of the in-place update)
@@ -454,34 +496,63 @@ __global__ void k_cell_apply(const unsigned int* __restrict__ work, uint2* __res
                              unsigned int pts_cap, int launch_bound) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   const int n_work = ctr[kMapCtrWork];
-  if (w >= n_work || w >= launch_bound) return;
+  const bool valid = w < n_work && w < launch_bound;
+  if (!__any(valid)) return;  // (uniform per wavefront)
+  int gone = 0;
+  if (valid) {
   const unsigned int e = work[w];
   const uint2 c = cells[e];
+  const unsigned int tpv = tp[e], capv = cell_cap[e];  // (loaded beside the cell entry, not behind the squeeze)
   unsigned int first = c.x, end = c.y, wpos = c.x;
-  for (unsigned int j = first; j < end; j++) {
-    if (!tomb[j]) {
-      if (wpos != j) pts[wpos] = pts[j];
-      wpos++;
-    } else {
-      tomb[j] = 0;
+  // squeeze the tombstones out, eight slots at a time: the flags and the points of a chunk are loaded together (the loop was a
+  // chain of ~20 dependent loads per cell: 15 us per update)
+  for (unsigned int j0 = first; j0 < end; j0 += 8u) {
+    unsigned char t[8];
+    float4 p[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const unsigned int jj = min(j0 + (unsigned)u, end - 1u);
+      t[u] = tomb[jj];
+      p[u] = pts[jj];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const unsigned int j = j0 + (unsigned)u;
+      if (j < end) {
+        if (!t[u]) {
+          if (wpos != j) pts[wpos] = p[u];  // wpos <= j: a slot of this chunk already read, or of an earlier one
+          wpos++;
+        } else {
+          tomb[j] = 0;
+        }
+      }
     }
   }
   const unsigned int deleted = end - wpos, alive = wpos - first;
-  const unsigned int pending = tp[e] & 0x7FFFFFFFu;
+  const unsigned int pending = tpv & 0x7FFFFFFFu;
   tp[e] = 0u;
-  if (first + alive + pending > cell_cap[e]) {  // (an empty, never used cell has first = end = cap = 0)
+  if (first + alive + pending > capv) {  // (an empty, never used cell has first = end = cap = 0)
     const unsigned int need = alive + pending, newcap = need + max(2u, need >> 2);
     const unsigned int nf = (unsigned int)atomicAdd(&ctr[kMapCtrUsed], (int)newcap);
     if (nf + newcap > pts_cap) {
-      ctr[kMapCtrOverflow] = 1;  // the inserts of this cell are dropped by k_ins_write (cap stays): the host rebuilds and reports
+      ctr[kMapCtrOverflow] = 1;  // the inserts of this cell are parked by k_ins_write (cap stays): the host rebuilds and re-inserts
     } else {
-      for (unsigned int j = 0; j < alive; j++) pts[nf + j] = pts[first + j];
+      for (unsigned int j0 = 0; j0 < alive; j0 += 8u) {
+        float4 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) p[u] = pts[first + min(j0 + (unsigned)u, alive - 1u)];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (j0 + (unsigned)u < alive) pts[nf + j0 + (unsigned)u] = p[u];
+      }
       first = nf;
       cell_cap[e] = nf + newcap;
     }
   }
   cells[e] = make_uint2(first, first + alive);
-  if (deleted) atomicAdd(&ctr[kMapCtrValid], -(int)deleted);
+  gone = (int)deleted;
+  }
+  wave_atomic_add_all(&ctr[kMapCtrValid], -gone);
 }
 
 __global__ void k_ins_write(const float4* __restrict__ list, const unsigned int* __restrict__ ins_e, int n, const int* __restrict__ n_dev,
@@ -490,25 +561,31 @@ __global__ void k_ins_write(const float4* __restrict__ list, const unsigned int*
                             float4* __restrict__ dropped, unsigned int drop_cap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) ctr[kMapCtrWork] = 0;  // the work list has been consumed (k_cell_apply ran before this launch)
+  bool valid = true;
   if (i >= n) {
     i -= n;
-    if (i >= n2) return;
+    valid = i < n2;
     list = list2; ins_e = ins_e2;
   } else if (n_dev && i >= *n_dev) {
-    return;
+    valid = false;
   }
-  const unsigned int e = ins_e[i];
-  if (e == 0xFFFFFFFFu) return;
-  const unsigned int slot = atomicAdd(reinterpret_cast<unsigned int*>(&cells[e]) + 1, 1u);
-  const float4 p = list[i];
-  if (slot < cell_cap[e]) {
-    pts[slot] = make_float4(p.x, p.y, p.z, 0.f);
-    atomicAdd(&ctr[kMapCtrValid], 1);
-  } else {
-    atomicSub(reinterpret_cast<unsigned int*>(&cells[e]) + 1, 1u);
-    ctr[kMapCtrOverflow] = 1;
-    drop_point(dropped, drop_cap, ctr, p);
+  int added = 0;
+  if (valid) {
+    const unsigned int e = ins_e[i];
+    if (e != 0xFFFFFFFFu) {
+      const unsigned int slot = atomicAdd(reinterpret_cast<unsigned int*>(&cells[e]) + 1, 1u);
+      const float4 p = list[i];
+      if (slot < cell_cap[e]) {
+        pts[slot] = make_float4(p.x, p.y, p.z, 0.f);
+        added = 1;
+      } else {
+        atomicSub(reinterpret_cast<unsigned int*>(&cells[e]) + 1, 1u);
+        ctr[kMapCtrOverflow] = 1;
+        drop_point(dropped, drop_cap, ctr, p);
+      }
+    }
   }
+  wave_atomic_add_all(&ctr[kMapCtrValid], added);  // every lane of the wavefront arrives here
 }
 
 // ---- (re)build: slack layout from the compact, cell-sorted array
