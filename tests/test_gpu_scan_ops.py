@@ -214,3 +214,43 @@ def test_next_scan_travels_while_the_current_one_is_in_use(reg):
     reg.scan_advance()
     assert len(reg.scan_download(0)) == 0
     assert hip.hipHostFree(ptr) == 0
+
+
+def test_pipelined_hand_over_gives_the_same_stream(oracle):
+    """A short stream processed twice - serial lii_scan_upload per scan, and with every next scan travelling through
+    lii_scan_upload_next while its predecessor is registered and inserted into the map - ends in the same states (bit for bit) and
+    the same map (as a set)."""
+    import bench
+    import lidar_imu_init_amd as lii
+    wl = bench.build_workload("vlp16", 4)
+    states0, tables = bench.start_states(wl)
+    scans = [np.ascontiguousarray(s, np.float32) for s in wl["scans"]]
+
+    def run(pipelined):
+        reg = lii.Registrar(max_scan_points=40_000, max_map_points=400_000, filter_size_map=wl["fs_map"])
+        reg.map_build(wl["map"])
+        out = []
+        if pipelined:
+            reg.scan_upload_next(scans[0])
+            reg.scan_advance()
+        for k in range(len(scans)):
+            if pipelined:
+                if k + 1 < len(scans):
+                    reg.scan_upload_next(scans[k + 1])
+            else:
+                reg.scan_upload(scans[k])
+            st = states0[k].copy()
+            rep = reg.scan_register(st, states0[k], imu_poses=tables[k], leaf=wl["fs_surf"], max_iterations=wl["max_it"], imu_en=True)
+            reg.map_incremental(st)
+            out.append((st.pod.copy(), rep["iterations"], rep["searches"]))
+            if pipelined and k + 1 < len(scans):
+                reg.scan_advance()
+        m = np.unique(reg.map_download(), axis=0)
+        reg.close()
+        return out, m
+
+    a, ma = run(False)
+    b, mb = run(True)
+    for x, y in zip(a, b):
+        assert x[1:] == y[1:] and np.array_equal(x[0], y[0])
+    assert ma.shape == mb.shape and np.array_equal(ma, mb)
