@@ -257,12 +257,13 @@ int build_index(lii_handle h, int n, int extra_blocks = 0) {
     std::memcpy(&n_blocks, h->h_small, sizeof(unsigned int));
   }
   const size_t want_blocks = size_t(n_blocks) + size_t(std::max(extra_blocks, 0));
-  if (want_blocks > h->cells_cap_blocks || !h->d_cell_cap) {
+  if (want_blocks + 1 > h->cells_cap_blocks || !h->d_cell_cap) {
     for (void* q : {static_cast<void*>(h->d_cells), static_cast<void*>(h->d_cell_cap), static_cast<void*>(h->d_tp), static_cast<void*>(h->d_cs_a),
                     static_cast<void*>(h->d_cs_b)})
       if (q) HIPCHK(h, hipFree(q));
     h->d_cells = nullptr; h->d_cell_cap = nullptr; h->d_tp = nullptr; h->d_cs_a = nullptr; h->d_cs_b = nullptr;
-    const size_t want = h->map_tight ? std::max<size_t>(want_blocks, 1) : std::max<size_t>(std::max<size_t>(want_blocks * 2, h->cells_cap_blocks), 4096);
+    // (+ 1: the last table of the pool is the shared all-empty one, k_ins_cells)
+    const size_t want = h->map_tight ? want_blocks + 1 : std::max<size_t>(std::max<size_t>(want_blocks * 2, h->cells_cap_blocks), 4096);
     HIPCHK(h, dmalloc(&h->d_cells, want * 512));
     HIPCHK(h, dmalloc(&h->d_cell_cap, want * 512));
     HIPCHK(h, dmalloc(&h->d_tp, want * 512));
@@ -335,7 +336,7 @@ int map_counters(lii_handle h, bool already_synced = false) {
   std::memcpy(c, h->h_small + 3072, sizeof(c));
   h->n_used = c[kMapCtrUsed];
   h->n_map = c[kMapCtrValid];
-  h->n_blocks = c[kMapCtrBlocks];
+  h->n_blocks = int(std::min<size_t>(size_t(std::max(c[kMapCtrBlocks], 0)), h->cells_cap_blocks));  // (the counter runs past the pool when it is exhausted)
   h->map_dirty = false;
   if (c[kMapCtrOverflow]) {
     const int n_drop = c[kMapCtrDropped];
@@ -360,7 +361,7 @@ int map_counters(lii_handle h, bool already_synced = false) {
       std::memcpy(c, h->h_small + 3072, sizeof(c));
       h->n_used = c[kMapCtrUsed];
       h->n_map = c[kMapCtrValid];
-      h->n_blocks = c[kMapCtrBlocks];
+      h->n_blocks = int(std::min<size_t>(size_t(std::max(c[kMapCtrBlocks], 0)), h->cells_cap_blocks));
       h->map_dirty = false;
       if (c[kMapCtrOverflow]) return fail(h, LII_ERR_CAPACITY, "local map: the re-insertion after a rebuild ran out of room again");
     }
@@ -411,7 +412,7 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
   const size_t spare_blocks = h->map_tight ? 0 : std::min<size_t>(size_t(n_ins), 1024);
   const unsigned int work_need = 9u * (unsigned int)n_list + (unsigned int)n_ins + 64u;
   if (work_need > h->work_cap) return fail(h, LII_ERR_CAPACITY, "Add_Points batch larger than the work list of the in-place update");
-  if ((long long)h->pts_cap_eff - h->n_used < tail_need || size_t(h->n_blocks) + spare_blocks > h->cells_cap_blocks ||
+  if ((long long)h->pts_cap_eff - h->n_used < tail_need || size_t(h->n_blocks) + spare_blocks + 1 > h->cells_cap_blocks ||
       2ull * (size_t(h->n_blocks) + spare_blocks) > size_t(h->blocks_cap)) {
     rc = map_rebuild(h, h->map_tight ? 0 : std::max(4096, h->n_blocks / 2));
     if (rc != LII_OK) return rc;
@@ -998,7 +999,10 @@ int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_
   if (n > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "lii_map_add_points: batch larger than max_map_points");
   if (n_added) *n_added = 0;
   if (n == 0) return LII_OK;
-  int rc = upload_xyz(h, xyz, n, stride_bytes, h->d_batch);
+  // settle an earlier update first: should it have to be completed by a rebuild, the re-insertion uses the batch buffer
+  int rc = map_counters(h);
+  if (rc != LII_OK) return rc;
+  rc = upload_xyz(h, xyz, n, stride_bytes, h->d_batch);
   if (rc != LII_OK) return rc;
   h->have_search = false;
   rc = map_apply(h, h->d_batch, n, downsample_on != 0, nullptr, 0);

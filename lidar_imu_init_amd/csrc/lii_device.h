@@ -20,7 +20,7 @@ constexpr unsigned long long kVoxDropKey = (1ull << kVoxKeyBits) - 1ull;
 
 // device-resident counters of the in-place map (lii_map.hip): slots used at the tail of the point array, live points, occupied
 // 8x8x8 blocks, entries of the work list of the update in flight, "a capacity was exceeded" flag, events of the last fold
-constexpr int kMapCtrUsed = 0, kMapCtrValid = 1, kMapCtrBlocks = 2, kMapCtrWork = 3, kMapCtrOverflow = 4, kMapCtrEvents = 5, kMapCtrDropped = 6, kMapCtrWords = 16;
+constexpr int kMapCtrUsed = 0, kMapCtrValid = 1, kMapCtrBlocks = 2, kMapCtrWork = 3, kMapCtrOverflow = 4, kMapCtrEvents = 5, kMapCtrDropped = 6, kMapCtrSlots = 7, kMapCtrWords = 16;
 
 // Pose the per-point kernels need: state.rot_end, pos_end, offset_R_L_I, offset_T_L_I (row-major).
 struct PoseArg {

@@ -461,20 +461,34 @@ __global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int*
   for (unsigned int probes = 0; probes <= mask; probes++) {
     unsigned long long k = __hip_atomic_load(&blocks[sl].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k == kEmptyKey) {
+      // A slot of the block table is reserved before it is claimed: the table must keep a free slot, or probes for blocks that
+      // are not there (every search does them) would never end.
+      const int s_used = atomicAdd(&ctr[kMapCtrSlots], 1);
+      if ((unsigned int)s_used >= mask) {
+        atomicSub(&ctr[kMapCtrSlots], 1);
+        ctr[kMapCtrOverflow] = 1;
+        break;  // (id < 0: the point is parked for the host's rebuild)
+      }
       const unsigned long long prev = atomicCAS(&blocks[sl].key, kEmptyKey, bk);
       if (prev == kEmptyKey) {  // this lane creates the block: a cell table from the (zeroed) pool
         const int nid = atomicAdd(&ctr[kMapCtrBlocks], 1);
-        if ((unsigned int)nid >= tables_cap) { ctr[kMapCtrOverflow] = 1; break; }
-        __hip_atomic_store(&blocks[sl].id, (unsigned int)nid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The LAST table of the pool is never handed out: it stays all-empty, and a block that finds the pool exhausted points
+        // at it - searches see an empty block, lanes waiting for this block's id are released and park their points like this
+        // one does (leaving `pad` at 0 would have them wait forever; the host rebuilds with more room).
+        const bool got_table = (unsigned int)nid + 1u < tables_cap;
+        if (!got_table) ctr[kMapCtrOverflow] = 1;
+        __hip_atomic_store(&blocks[sl].id, got_table ? (unsigned int)nid : tables_cap - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&blocks[sl].pad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        id = nid;
+        id = got_table ? nid : -1;
         break;
       }
+      atomicSub(&ctr[kMapCtrSlots], 1);  // somebody else took the slot
       k = prev;
     }
     if (k == bk) {  // somebody else may be creating it right now: wait for the id
       while (__hip_atomic_load(&blocks[sl].pad, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
-      id = (long long)__hip_atomic_load(&blocks[sl].id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int got = __hip_atomic_load(&blocks[sl].id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      id = got + 1u == tables_cap ? -1 : (long long)got;  // (the shared empty table: its creator found the pool exhausted)
       break;
     }
     sl = (sl + 1) & mask;
@@ -605,6 +619,7 @@ __global__ void k_spread(const float4* __restrict__ src, uint2* __restrict__ cel
     ctr[kMapCtrUsed] = (int)capsum[e];
     ctr[kMapCtrValid] = n_valid;
     ctr[kMapCtrBlocks] = n_blocks;
+    ctr[kMapCtrSlots] = n_blocks;  // occupied slots of the block table
     ctr[kMapCtrWork] = 0;
     ctr[kMapCtrOverflow] = 0;
   }

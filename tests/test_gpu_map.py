@@ -247,7 +247,23 @@ def test_update_that_runs_out_of_room_loses_nothing(oracle):
         assert reg.map_size() == tree.validnum()
     got, ref = _as_set(reg.map_download()), _as_set(tree.flatten())
     assert got.shape == ref.shape and np.array_equal(got, ref)
-    q = np.r_[base[rng.choice(len(base), 4000)] + rng.normal(0, 0.2, (4000, 3)), far[:500] + rng.normal(0, 0.2, (500, 3))].astype(np.float32)
+    # an update that is NOT followed by a read of the counters (lii_map_incremental) and runs out of room, then a batch from the
+    # host right behind it: the rebuild that completes the first must not eat the second
+    scan = (base[rng.choice(len(base), 6000)] + rng.normal(0, 0.35, (6000, 3))).astype(np.float32)
+    reg.scan_upload(np.c_[scan, np.zeros(len(scan), np.float32)])
+    reg.downsample_skip()
+    st = lii.State(oracle.state_init())
+    reg.iekf_iterate(st, True, False)
+    n_before = reg.map_size()
+    na, nn = reg.map_incremental(st)
+    batch = (rng.uniform(-1, 1, (700, 3)) * 50 + np.array([-5000.0, 0, 0])).astype(np.float32)
+    reg.map_add_points(batch, False)
+    got2 = _as_set(reg.map_download())
+    assert len(_as_set(np.r_[got2, batch])) == len(got2)          # every point of the batch is in the map
+    assert reg.map_size() == len(got2) and len(got2) >= n_before + len(batch)
+    tree.add_points(batch, False)                                   # (the k-NN check below runs against base + far + batch)
+    # (queries around the two far patches only: the tree did not take part in the map_incremental around `base`)
+    q = np.r_[batch[rng.choice(len(batch), 500)] + rng.normal(0, 0.2, (500, 3)), far[:500] + rng.normal(0, 0.2, (500, 3))].astype(np.float32)
     reg.scan_upload(np.c_[q, np.zeros(len(q), np.float32)])
     n = reg.downsample_skip()
     reg.iekf_iterate(lii.State(oracle.state_init()), True, False)
