@@ -4,7 +4,7 @@
 # one-device multi-rank rehearsals.  Everything lands under gpurun_out/$1; the summaries to keep are copied to profiles/ by hand.
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$1; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
+timeout 600 python -m pytest tests -m gpu -q --timeout 180 > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench default rc=$?"; cat $O/bench_default.json
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_form.json 2> $O/bench_driver_form.err; echo "bench driver-form rc=$?"; cut -c1-220 $O/bench_driver_form.json
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o r02 -- python bench.py --steps 100 --warmup 10 --prime 20 --no-cpu-baseline --no-pipeline > $O/prof.log 2>&1; echo "prof rc=$?"
