@@ -10,7 +10,9 @@
 //                      (README.md:57 pins PCL >= 1.8); its documented algorithm (voxel_grid.hpp,
 //                      PCL 1.8: getMinMax3D, int64 overflow guard -> identity copy, linear voxel index,
 //                      sort by index, per-voxel centroid of all fields, ascending-index output) is
-//                      restated here.  PARITY UNPINNED for this function (no PCL source, no vectors).
+//                      restated here.  PARITY UNPINNED for this function (no PCL source, no vectors); held bit for
+//                      bit to an independently written numpy version in tests/test_oracle_scan_independent.py
+//                      (which also checks the two de-skew loops against per-point numpy / scipy formulations).
 // Points are carried as float4 records (x, y, z, t) where t is the reference's `curvature` field:
 // the per-point time offset from the scan start in MILLISECONDS (src/preprocess.cpp).
 #pragma once
