@@ -101,7 +101,11 @@ int lii_synchronize(lii_handle h);
  * lii_map_add_points <- ikdtree.Add_Points(PointToAdd, true|false)        src/laserMapping.cpp:556-557,
  *                       with the per-voxel keep-closest-to-centre semantics of include/ikd-Tree/ikd_Tree.cpp:381-456
  * lii_map_size       <- ikdtree.validnum()                                src/laserMapping.cpp:933
- * Points are float xyz with `stride_bytes` between records (12 for packed xyz, 48 for PointXYZINormal). */
+ * Points are float xyz with `stride_bytes` between records (12 for packed xyz, 48 for PointXYZINormal).
+ * The map is a point SET kept on the device and updated in place: lii_map_download returns it in no particular order;
+ * an update is enqueued, not waited for (lii_map_size / lii_map_download / lii_map_add_points' counter read the device).
+ * LII_ERR_CAPACITY: n_valid + batch would exceed lii_config::max_map_points - tested BEFORE the batch is applied, counting
+ * every point of it; the map is left as it was. */
 int lii_map_reset(lii_handle h);
 int lii_map_build(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes);
 int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes, int32_t downsample_on,
@@ -112,8 +116,7 @@ int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_
 int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int32_t* n_deleted);
 int lii_map_size(lii_handle h, int32_t* n_valid);
 int lii_map_download(lii_handle h, float* xyz_out, int32_t capacity, int32_t* n);
-/* Pushes pending host-side map edits to the device and rebuilds the k-NN grid (done lazily by the
- * registration calls; exposed so that a caller can keep it out of a timed region). */
+/* Kept for callers of ABI 1: the device map is always current (updates are applied in place), this returns LII_OK. */
 int lii_map_commit(lii_handle h);
 
 /* ---------------------------------------------------------------- scan in / undistortion / down-sampling
