@@ -116,7 +116,7 @@ int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_
 int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int32_t* n_deleted);
 int lii_map_size(lii_handle h, int32_t* n_valid);
 int lii_map_download(lii_handle h, float* xyz_out, int32_t capacity, int32_t* n);
-/* Kept for callers of ABI 1: the device map is always current (updates are applied in place), this returns LII_OK. */
+/* Kept for callers of ABI 1: the device map is always current (updates are applied in place); waits for the stream. */
 int lii_map_commit(lii_handle h);
 
 /* ---------------------------------------------------------------- scan in / undistortion / down-sampling
