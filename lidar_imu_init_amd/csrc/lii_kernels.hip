@@ -324,10 +324,11 @@ __device__ __forceinline__ void qr_solve_5x3(double (&a)[5][3], double (&x)[3]) 
 // per-block reduction of the 12-column Jacobian rows into 78 + 12 sums (+ count)
 constexpr int kCols = 13;         // 12 Jacobian columns + z
 constexpr int kColStride = 65;    // 64 lanes + 1 pad: column c of lane p at (c * 65 + p) — conflict-free b64 reads
+constexpr int kFitWaves = kBlock / 64;
 struct ReduceShared {
-  double col[4][kCols * kColStride];
-  double part[4][90];
-  int cnt[4];
+  double col[kFitWaves][kCols * kColStride];
+  double part[kFitWaves][90];
+  int cnt[kFitWaves];
 };
 
 // pair t (0..89) -> (a, b): t < 78 upper triangle of 12x12 row-major (a <= b), else (t - 78, 12)
@@ -372,14 +373,19 @@ __device__ __forceinline__ void block_reduce_rows(ReduceShared& sh, const double
   sh.part[wave][lane] = s0;
   if (two) sh.part[wave][lane + 64] = s1;
   __syncthreads();
-  if (threadIdx.x < 90) {
-    double s = sh.part[0][threadIdx.x];
-    s += sh.part[1][threadIdx.x];
-    s += sh.part[2][threadIdx.x];
-    s += sh.part[3][threadIdx.x];
-    partial_out[(size_t)threadIdx.x * stride] = s;
-  } else if (threadIdx.x == 90) {
-    partial_out[(size_t)90 * stride] = (double)(sh.cnt[0] + sh.cnt[1] + sh.cnt[2] + sh.cnt[3]);
+  // (kBlock = 64: one wavefront, lanes 0..63 write pairs t and t + 64)
+  for (int t = threadIdx.x; t < 91; t += kBlock) {
+    if (t < 90) {
+      double s = sh.part[0][t];
+#pragma unroll
+      for (int w = 1; w < kFitWaves; w++) s += sh.part[w][t];
+      partial_out[(size_t)t * stride] = s;
+    } else {
+      int cn = sh.cnt[0];
+#pragma unroll
+      for (int w = 1; w < kFitWaves; w++) cn += sh.cnt[w];
+      partial_out[(size_t)90 * stride] = (double)cn;
+    }
   }
 }
 
