@@ -427,12 +427,11 @@ def main():
 
 
 def knn_kernel_name():
-    v = int(os.environ.get("LII_KNN_VARIANT", "5"))
-    if v in (4, 5, 6, 7, 8):
-        lanes = 8 if v == 8 else 4
-        return (f"k_knn_pruned<{lanes}> (exact 5-NN into the block-grid local map, {lanes} lanes/query, candidates from global memory"
-                + (", round-1 candidates balanced over the lanes)" if v in (5, 6, 7) else ")"))
-    return "k_knn_tile (exact 5-NN, the distinct cells of 64 brick-ordered queries staged in LDS, 4 lanes/query)"
+    v = int(os.environ.get("LII_KNN_VARIANT", "0"))
+    if v == 5:
+        return "k_knn_exact (exact 5-NN into the block-grid local map, 4 lanes/query, exact (distance, index) lists throughout)"
+    return ("k_knn_pk (exact 5-NN into the block-grid local map, 4 lanes/query, packed 32-bit keys in round 1, winners re-measured "
+            "exactly)")
 
 
 def cpu_baseline(wl, states0, tables, no_downsample, gpu_results, budget_s=14.0):

@@ -133,12 +133,9 @@ struct lii_context {
   int* d_nbody = nullptr;       // [0] size of the down-sampled cloud, [1] `filtered` flag of the last voxel filter
   bool body_is_scan = false;
   bool have_search = false;
-  int knn_variant = 5;   // search pass: 5 (default) = 4 lanes per query, round-1 candidates balanced over the lanes; 4 / 8 = plain
-                         // 4 / 8 lanes per query of the global-memory search (k_knn_pruned); 6 / 7 = variants of 5;
-                         // 64 / 65 / 32 / 128 = the LDS-tiled search (k_knn_tile) in four geometries - built, measured, 2.5x
-                         // slower (profiles/r02_knn_tile_ab.md); LII_KNN_VARIANT selects, for A/B
-  unsigned int* d_knn_stats = nullptr;  // [0] workgroups of k_knn_tile that searched out of LDS, [1] that took the global path
-  bool knn_stats = false;               // LII_KNN_STATS=1: count them (adds one atomic per workgroup)
+  int knn_variant = 0;   // search pass: 0 = packed keys (k_knn_pk); 5 = exact lists throughout (k_knn_exact, its reference form) -
+                         // LII_KNN_VARIANT selects
+  bool diag = false;     // LII_DIAG=1: counters of the rare paths on stderr when the handle is destroyed
 
   // ---- pinned staging
   float4* h_stage = nullptr;     // max(max_scan, max_map) float4
@@ -444,8 +441,7 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
 }
 
 void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, int forced) {
-  lii::launch_knn(h->knn_variant, g, rb, ps, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->knn_stats ? h->d_knn_stats : nullptr,
-                  h->stream);
+  lii::launch_knn(h->knn_variant, g, rb, ps, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->stream);
 }
 
 // Fetches the exact size of the down-sampled cloud from the device (one small synchronising copy).
@@ -772,7 +768,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   // the 3x3x3 neighbourhood of 8x8x8-cell blocks must cover the acceptance radius sqrt(max_match_dist2)
   h->cell_size = std::max(h->cell_size, std::sqrt(h->cfg.max_match_dist2) / 8.0f * 1.001f);
   if (const char* v = std::getenv("LII_KNN_VARIANT")) h->knn_variant = std::atoi(v);  // A/B knob for profiling
-  if (const char* v = std::getenv("LII_KNN_STATS")) h->knn_stats = std::atoi(v) != 0;
+  if (const char* v = std::getenv("LII_DIAG")) h->diag = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_VOXEL_ORDER")) h->coherent_order = std::string(v) == "brick";
   if (const char* v = std::getenv("LII_HOST_SOLVE")) h->host_solve = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_SYNC_RESULT")) h->poll_result = std::atoi(v) == 0;
@@ -829,8 +825,6 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(hipMemset(h->d_cell_cap, 0, sizeof(unsigned int) * h->cells_cap_blocks * 512));
   CK(hipMemset(h->d_tp, 0, sizeof(unsigned int) * h->cells_cap_blocks * 512));
   CK(dmalloc(&h->d_counter, 4));
-  CK(dmalloc(&h->d_knn_stats, 8));
-  CK(hipMemset(h->d_knn_stats, 0, 32));
   CK(dmalloc(&h->d_tomb, size_t(h->pts_cap)));
   CK(hipMemset(h->d_tomb, 0, size_t(h->pts_cap)));
   CK(dmalloc(&h->d_ins, M));
@@ -913,17 +907,8 @@ int lii_destroy(lii_handle h) {
   (void)hipSetDevice(h->device);
   if (h->comm) ncclCommDestroy(h->comm);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  if (h->knn_stats) std::fprintf(stderr, "[libliinit_hip] map updates completed by a rebuild + re-insertion: %lld\n", h->map_recoveries);
-  if (h->knn_stats) std::fprintf(stderr, "[libliinit_hip] updates continued by the host after a parked loop: %lld\n", h->plan_parked);
-  if (h->knn_stats && h->d_knn_stats) {  // LII_KNN_STATS=1: how the search workgroups of this handle split (diagnostic)
-    unsigned int st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpy(st, h->d_knn_stats, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess) {
-      std::fprintf(stderr, "[libliinit_hip] k_knn_tile workgroups: %u searched out of LDS, %u through global memory\n", st[0], st[1]);
-      const double wg = double(st[0]) + double(st[1]) > 0 ? double(st[0]) + double(st[1]) : 1.0;
-      std::fprintf(stderr, "[libliinit_hip] k_knn_tile us per workgroup: origin %.2f, cell set %.2f, cell lookups %.2f, scan + copy %.2f, search %.2f, store %.2f\n",
-                   st[2] / wg / 100.0, st[3] / wg / 100.0, st[4] / wg / 100.0, st[5] / wg / 100.0, st[6] / wg / 100.0, st[7] / wg / 100.0);
-    }
-  }
+  if (h->diag) std::fprintf(stderr, "[libliinit_hip] map updates completed by a rebuild + re-insertion: %lld\n", h->map_recoveries);
+  if (h->diag) std::fprintf(stderr, "[libliinit_hip] updates continued by the host after a parked loop: %lld\n", h->plan_parked);
   mailbox_close(&h->mailbox);
   if (h->d_mb_seq) (void)hipFree(h->d_mb_seq);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
@@ -932,7 +917,7 @@ int lii_destroy(lii_handle h) {
   if (h->h_stage_next) (void)hipHostFree(h->h_stage_next);
   if (h->d_scan_next) (void)hipFree(h->d_scan_next);
   void* dev[] = {h->d_dropped, h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
-                 h->d_counter, h->d_knn_stats, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
+                 h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
                  h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
@@ -1483,8 +1468,7 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
     rb.shard_world = 1;
     if (h->have_search) {
       const GridView g = grid_view(h);
-      lii::launch_knn(h->knn_variant, g, rb, pose_of(*state), reinterpret_cast<const PoseArg*>(h->d_ctrl->search_pose), h->d_ctrl, 2, nullptr,
-                      nullptr, s);
+      lii::launch_knn(h->knn_variant, g, rb, pose_of(*state), reinterpret_cast<const PoseArg*>(h->d_ctrl->search_pose), h->d_ctrl, 2, nullptr, s);
       launch_knn_complete(g, rb, s);
     }
   }

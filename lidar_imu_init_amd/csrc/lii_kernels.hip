@@ -5,7 +5,7 @@
 //   k_map_keys / k_map_gather / k_block_flags / k_cells_fill
 //                      device mirror of the ikd-Tree point set as a cell-sorted array + block-hierarchical grid
 //                      (include/ikd-Tree/ikd_Tree.cpp:336-347 Build)
-//   k_knn_pruned<LPQ>  KD_TREE::Nearest_Search (ikd_Tree.cpp:349-379, Search :825-968) for every point of the
+//   k_knn_pk / _exact  KD_TREE::Nearest_Search (ikd_Tree.cpp:349-379, Search :825-968) for every point of the
 //                      scan, after pointBodyToWorld (src/laserMapping.cpp:209-220, call :973-985)
 //   k_fit_reduce       completes the few searches the 3x3x3 pass could not prove exact, then esti_plane +
 //                      residual/selection (src/laserMapping.cpp:987-1011), Jacobian rows (:1035-1071) and the
@@ -515,57 +515,18 @@ __device__ __forceinline__ void lookup_cells_batched(const GridView& g, const ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// Where the candidates of a query come from.  GlobalCells: block-table probe -> cell entry -> map points in HBM / L2 (one
-// dependent load chain per query).  TileCells: the cells a workgroup's queries can touch were de-duplicated and staged in LDS
-// by the workgroup (k_knn_tile); lookups and candidates are LDS reads.  Both enumerate a cell's points in map order, so the
-// two produce bit-identical neighbour lists (same visiting order, same strict '<' on ties).
-struct GlobalCells {
-  const GridView& g;
-  const uint4* __restrict__ tab;
-  __device__ __forceinline__ const float4* points() const { return g.pts; }
-  __device__ __forceinline__ uint2 lookup1(int ix, int iy, int iz) const { return lookup_cell(g, tab, ix, iy, iz); }
-  template <int NC>
-  __device__ __forceinline__ void lookup(const int (&ix)[NC], const int (&iy)[NC], const int (&iz)[NC], uint2 (&out)[NC]) const {
-    bool want[NC];
-#pragma unroll
-    for (int t = 0; t < NC; t++) want[t] = true;
-    lookup_cells_batched<NC>(g, tab, ix, iy, iz, want, out);
-  }
-};
+// The search pass.  Four lanes per query (16 queries per wavefront).  Geometry of both kernels below:
+// Round 1: the 2x2x2 block of cells nearest to the query (own cell + the neighbour on the nearer side of every axis), two
+// cells per lane, which covers the ball of radius g0 = min_axis max(f, cs - f) >= cs / 2 around the query.  If the 5th
+// distance is within g0 the search is complete.
+// Round 2 (only the queries that need it): the other 19 cells of the 3x3x3 block, each tested against the current 5th
+// distance first (the tree's calc_box_dist rule, ikd_Tree.cpp:1279-1289).
+// A query whose 3x3x3 block cannot prove its list complete is flagged (kNeedy) and finished by k_fit_reduce / k_knn_complete.
 
-constexpr unsigned int kTileEmpty = 0xFFFFFFFFu;
-__device__ __forceinline__ unsigned int tile_key(int rx, int ry, int rz) { return (unsigned)rx | ((unsigned)ry << 10) | ((unsigned)rz << 20); }
-__device__ __forceinline__ unsigned int tile_slot(unsigned int key, unsigned int mask) { return ((key * 2654435761u) >> 11) & mask; }
-struct TileCells {
-  const unsigned int* hkey;  // LDS: packed cell coordinates relative to (bx, by, bz), kTileEmpty = free
-  const unsigned int* hval;  // LDS: tile offset | count << 16
-  const float4* tile;        // LDS: the staged map points, cell by cell
-  unsigned int mask;
-  int bx, by, bz;
-  __device__ __forceinline__ const float4* points() const { return tile; }
-  __device__ __forceinline__ uint2 lookup1(int ix, int iy, int iz) const {
-    const unsigned int key = tile_key(ix - bx, iy - by, iz - bz);
-    unsigned int sl = tile_slot(key, mask);
-    unsigned int kk = hkey[sl];
-    while (kk != key && kk != kTileEmpty) {
-      sl = (sl + 1) & mask;
-      kk = hkey[sl];
-    }
-    if (kk != key) return make_uint2(0u, 0u);
-    const unsigned int v = hval[sl];
-    return make_uint2(v & 0xFFFFu, (v & 0xFFFFu) + (v >> 16));
-  }
-  template <int NC>
-  __device__ __forceinline__ void lookup(const int (&ix)[NC], const int (&iy)[NC], const int (&iz)[NC], uint2 (&out)[NC]) const {
+template <bool DEDUP>
+__device__ __forceinline__ void knn_group_merge4(Knn5& k) {
 #pragma unroll
-    for (int t = 0; t < NC; t++) out[t] = lookup1(ix[t], iy[t], iz[t]);
-  }
-};
-
-template <int LPQ, bool DEDUP>
-__device__ __forceinline__ void knn_group_merge_n(Knn5& k) {
-#pragma unroll
-  for (int off = 1; off < LPQ; off <<= 1) {
+  for (int off = 1; off < 4; off <<= 1) {
     float e0 = __shfl_xor(k.d0, off), e1 = __shfl_xor(k.d1, off), e2 = __shfl_xor(k.d2, off), e3 = __shfl_xor(k.d3, off),
           e4 = __shfl_xor(k.d4, off);
     int j0 = __shfl_xor(k.i0, off), j1 = __shfl_xor(k.i1, off), j2 = __shfl_xor(k.i2, off), j3 = __shfl_xor(k.i3, off),
@@ -576,6 +537,12 @@ __device__ __forceinline__ void knn_group_merge_n(Knn5& k) {
     if (j3 >= 0) knn_merge_one<DEDUP>(k, e3, j3);
     if (j4 >= 0) knn_merge_one<DEDUP>(k, e4, j4);
   }
+}
+__device__ __forceinline__ void knn_group_bcast(Knn5& k, int leader) {
+  k.d0 = __shfl(k.d0, leader); k.d1 = __shfl(k.d1, leader); k.d2 = __shfl(k.d2, leader); k.d3 = __shfl(k.d3, leader);
+  k.d4 = __shfl(k.d4, leader);
+  k.i0 = __shfl(k.i0, leader); k.i1 = __shfl(k.i1, leader); k.i2 = __shfl(k.i2, leader); k.i3 = __shfl(k.i3, leader);
+  k.i4 = __shfl(k.i4, leader);
 }
 
 // element t of a PoseArg seen as 24 doubles, without dynamic indexing (which would push the struct into scratch memory)
@@ -598,160 +565,150 @@ __device__ __forceinline__ void body_to_world(const PoseArg& ps, const float4 pb
   wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
 }
 
-// The two search rounds of one query on its LPQ lanes (all lanes of the group hold the query's world point).  On return the
-// leader's list has been broadcast to the group; `need` = the 3x3x3 block cannot prove the list complete (kNeedy).
-template <int LPQ, class Cells, bool BAL = false>
-__device__ __forceinline__ void knn_search_query(const Cells& src, const GridView& g, bool active, float wx, float wy, float wz,
-                                                 int sub, int leader, Knn5& k, bool& need) {
-  const float INF = __builtin_inff();
-  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = INF;
-  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
+// Where a query sits in the grid: its cell, the nearer-side neighbour on every axis, the radius round 1 covers (g0) and the
+// radius the whole 3x3x3 block covers (guard).
+struct QueryCell {
+  int cx, cy, cz, ox, oy, oz;
+  float eps, g0, guard;
+};
+__device__ __forceinline__ QueryCell query_cell(const GridView& g, float wx, float wy, float wz) {
+  QueryCell q;
   const float cs = g.cs;
-  const float eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
-  const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
-  // position of the query inside its cell and the nearer-side neighbour on every axis
-  const float fx = fminf(fmaxf(wx - (float)cx * cs, 0.f), cs), fy = fminf(fmaxf(wy - (float)cy * cs, 0.f), cs),
-              fz = fminf(fmaxf(wz - (float)cz * cs, 0.f), cs);
-  const int ox = fx < 0.5f * cs ? -1 : 1, oy = fy < 0.5f * cs ? -1 : 1, oz = fz < 0.5f * cs ? -1 : 1;
-  const float4* __restrict__ pts = src.points();
-  if (active) {
-    // the 8 cells of round 1 are dealt to the LPQ lanes; lookups first, then the candidate loops
-    uint2 r[8 / LPQ];
-    {
-      int jx[8 / LPQ], jy[8 / LPQ], jz[8 / LPQ];
-#pragma unroll
-      for (int t = 0; t < 8 / LPQ; t++) {
-        const int c = sub + LPQ * t;
-        jx[t] = cx + ((c & 1) ? ox : 0); jy[t] = cy + ((c & 2) ? oy : 0); jz[t] = cz + ((c & 4) ? oz : 0);
-      }
-      src.template lookup<8 / LPQ>(jx, jy, jz, r);
-    }
-    if (BAL && LPQ == 4) {
-      // Balanced round 1: the eight ranges go to every lane of the group (shuffles), the candidates of the concatenated list are
-      // dealt out four consecutive ones per lane and trip - ceil(total / 16) load trips for the group instead of the trips of its
-      // busiest lane (two occupied cells on one lane, none on another).  Ends of the ranges relative to the list start travel
-      // as bytes (cells hold ~9 points; a group with a cell of more than 255 takes the plain path).
-      unsigned int off[8];  // map index = list position + off[c] inside range c
-      unsigned int pk0 = 0, pk1 = 0, run = 0, big = 0;
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const int owner = leader + (c & 3);
-        const unsigned int a = __shfl(r[c >> 2].x, owner), e = __shfl(r[c >> 2].y, owner);
-        off[c] = a - run;
-        run += e - a;
-        big |= run;
-        if (c < 4) pk0 |= (run & 255u) << (8 * c); else pk1 |= (run & 255u) << (8 * (c - 4));
-      }
-      if (big < 256u) {
-        const unsigned int T = run;
-        for (unsigned int base = 4u * (unsigned)sub; base < T; base += 16u) {
-          unsigned int idx[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const unsigned int f = min(base + u, T - 1u);
-            unsigned int o = off[0];
-#pragma unroll
-            for (int c = 1; c < 8; c++) {
-              const unsigned int endprev = c <= 4 ? ((pk0 >> (8 * (c - 1))) & 255u) : ((pk1 >> (8 * (c - 5))) & 255u);
-              o = f >= endprev ? off[c] : o;
-            }
-            idx[u] = f + o;
-          }
-          const float4 p0 = pts[idx[0]], p1 = pts[idx[1]], p2 = pts[idx[2]], p3 = pts[idx[3]];
-          const float d0 = dist2_ref(wx, wy, wz, p0.x, p0.y, p0.z), d1 = dist2_ref(wx, wy, wz, p1.x, p1.y, p1.z);
-          const float d2 = dist2_ref(wx, wy, wz, p2.x, p2.y, p2.z), d3 = dist2_ref(wx, wy, wz, p3.x, p3.y, p3.z);
-          if (d0 <= g.max_d2 && d0 < k.d4) knn_insert(k, d0, (int)idx[0]);
-          if (base + 1 < T && d1 <= g.max_d2 && d1 < k.d4) knn_insert(k, d1, (int)idx[1]);
-          if (base + 2 < T && d2 <= g.max_d2 && d2 < k.d4) knn_insert(k, d2, (int)idx[2]);
-          if (base + 3 < T && d3 <= g.max_d2 && d3 < k.d4) knn_insert(k, d3, (int)idx[3]);
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 8 / LPQ; t++) scan_range(pts, g.max_d2, r[t].x, r[t].y, wx, wy, wz, k);
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 8 / LPQ; t++) scan_range(pts, g.max_d2, r[t].x, r[t].y, wx, wy, wz, k);
-    }
-  }
-  knn_group_merge_n<LPQ, false>(k);
-  const float g0 = fminf(fminf(fmaxf(fx, cs - fx), fmaxf(fy, cs - fy)), fmaxf(fz, cs - fz)) - 2.f * eps;
-  bool more = active && !(fminf(k.d4, g.max_d2) <= g0 * g0);
-  if (__any(more)) {
-    // every lane of the group now holds the same 5th distance (ties aside, which only makes the bound equal)
-    const float bound = fminf(__shfl(k.d4, leader), g.max_d2);
-    if (more) {
-      // the 19 remaining cells of the 3x3x3 block: enumerate all 27, skip the 8 of round 1
-      for (int c = sub; c < 27; c += LPQ) {
-        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
-        const bool in_r1 = (dx == 0 || dx == ox) && (dy == 0 || dy == oy) && (dz == 0 || dz == oz);
-        if (in_r1) continue;
-        const float gx = axis_gap(wx, cx + dx, cs, eps), gy = axis_gap(wy, cy + dy, cs, eps), gz = axis_gap(wz, cz + dz, cs, eps);
-        if (gx * gx + gy * gy + gz * gz > bound) continue;
-        const uint2 r = src.lookup1(cx + dx, cy + dy, cz + dz);
-        scan_range(pts, g.max_d2, r.x, r.y, wx, wy, wz, k);
-      }
-    }
-    // round-2 lists start from the shared round-1 list: merge with duplicate suppression
-    knn_group_merge_n<LPQ, true>(k);
-  }
-  k.d0 = __shfl(k.d0, leader); k.d1 = __shfl(k.d1, leader); k.d2 = __shfl(k.d2, leader); k.d3 = __shfl(k.d3, leader);
-  k.d4 = __shfl(k.d4, leader);
-  k.i0 = __shfl(k.i0, leader); k.i1 = __shfl(k.i1, leader); k.i2 = __shfl(k.i2, leader); k.i3 = __shfl(k.i3, leader);
-  k.i4 = __shfl(k.i4, leader);
+  q.eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
+  q.cx = cell_of(wx, g.inv_cs); q.cy = cell_of(wy, g.inv_cs); q.cz = cell_of(wz, g.inv_cs);
+  const float fx = fminf(fmaxf(wx - (float)q.cx * cs, 0.f), cs), fy = fminf(fmaxf(wy - (float)q.cy * cs, 0.f), cs),
+              fz = fminf(fmaxf(wz - (float)q.cz * cs, 0.f), cs);
+  q.ox = fx < 0.5f * cs ? -1 : 1; q.oy = fy < 0.5f * cs ? -1 : 1; q.oz = fz < 0.5f * cs ? -1 : 1;
+  q.g0 = fminf(fminf(fmaxf(fx, cs - fx), fmaxf(fy, cs - fy)), fmaxf(fz, cs - fz)) - 2.f * q.eps;
   const float mfrac = fmaxf(fminf(fminf(fminf(fx, cs - fx), fminf(fy, cs - fy)), fminf(fz, cs - fz)), 0.f);
-  const float guard = cs + mfrac - 2.f * eps;
-  need = active && !(fminf(k.d4, g.max_d2) <= guard * guard);
+  q.guard = cs + mfrac - 2.f * q.eps;
+  return q;
 }
 
-// The group's lanes store the five neighbours (coordinates from `pts`, w = d2), the count (+ kNeedy) and the world point.
-template <int LPQ>
+// Round 2 on exact (distance, index) lists: every lane of the group enters with the group's round-1 list; the lanes of a
+// query that needs it (`more`) visit the 19 outer cells that can still hold a closer point, the lists are merged with
+// duplicate suppression.  Must be called by every lane of the wavefront.
+__device__ __forceinline__ void knn_round2(const GridView& g, const uint4* __restrict__ tab, const QueryCell& q, bool more, float wx,
+                                           float wy, float wz, int sub, int leader, Knn5& k) {
+  const float bound = fminf(__shfl(k.d4, leader), g.max_d2);
+  if (more) {
+    for (int c = sub; c < 27; c += 4) {
+      const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+      const bool in_r1 = (dx == 0 || dx == q.ox) && (dy == 0 || dy == q.oy) && (dz == 0 || dz == q.oz);
+      if (in_r1) continue;
+      const float gx = axis_gap(wx, q.cx + dx, g.cs, q.eps), gy = axis_gap(wy, q.cy + dy, g.cs, q.eps),
+                  gz = axis_gap(wz, q.cz + dz, g.cs, q.eps);
+      if (gx * gx + gy * gy + gz * gz > bound) continue;
+      const uint2 r = lookup_cell(g, tab, q.cx + dx, q.cy + dy, q.cz + dz);
+      scan_range(g.pts, g.max_d2, r.x, r.y, wx, wy, wz, k);
+    }
+  }
+  knn_group_merge4<true>(k);
+}
+
+// The group's lanes store the five neighbours (coordinates from the map, w = d2), the count (+ kNeedy) and the world point.
 __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const float4* __restrict__ pts, int qi, int sub, const Knn5& k,
                                           bool need, float wx, float wy, float wz) {
   const int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
-  if (LPQ == 8) {
-    if (sub < 5) {
-      const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : (sub == 3 ? k.i3 : k.i4)));
-      const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : (sub == 3 ? k.d3 : k.d4)));
-      float4 v = idx >= 0 ? pts[idx] : make_float4(0, 0, 0, 0);
-      v.w = dd;
-      rb.nbr[(size_t)sub * rb.cap + qi] = v;
-    } else if (sub == 5) {
-      rb.nbr_count[qi] = found | (need ? kNeedy : 0);
-    } else if (sub == 6) {
-      rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-    }
-  } else {
-    {
-      const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : k.i3));
-      const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : k.d3));
-      float4 v = idx >= 0 ? pts[idx] : make_float4(0, 0, 0, 0);
-      v.w = dd;
-      rb.nbr[(size_t)sub * rb.cap + qi] = v;
-    }
-    if (sub == 0) {
-      float4 v = k.i4 >= 0 ? pts[k.i4] : make_float4(0, 0, 0, 0);
-      v.w = k.d4;
-      rb.nbr[(size_t)4 * rb.cap + qi] = v;
-    } else if (sub == 1) {
-      rb.nbr_count[qi] = found | (need ? kNeedy : 0);
-    } else if (sub == 2) {
-      rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-    }
+  {
+    const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : k.i3));
+    const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : k.d3));
+    float4 v = idx >= 0 ? pts[idx] : make_float4(0, 0, 0, 0);
+    v.w = dd;
+    rb.nbr[(size_t)sub * rb.cap + qi] = v;
   }
+  if (sub == 0) {
+    float4 v = k.i4 >= 0 ? pts[k.i4] : make_float4(0, 0, 0, 0);
+    v.w = k.d4;
+    rb.nbr[(size_t)4 * rb.cap + qi] = v;
+  } else if (sub == 1) {
+    rb.nbr_count[qi] = found | (need ? kNeedy : 0);
+  } else if (sub == 2) {
+    rb.world[qi] = make_float4(wx, wy, wz, 0.f);
+  }
+}
+
+// ---- packed keys ---------------------------------------------------------------------------------
+// Round 1 ranks its candidates as 32-bit keys: the float bits of d2 with the low kPkPosBits mantissa bits replaced by the
+// candidate's position in the group's candidate list (2 bits: the lane that scanned it, 8 bits: its place in that lane's
+// two cells).  d2 >= 0, so the keys order like the distances (to 13 mantissa bits) and are unique; a sorted list of the SEVEN
+// smallest keys is maintained with one v_min_u32 and six v_med3_u32 per candidate - no compares, no selects, no index
+// registers.  The four lists of a group are joined by two bitonic merges over DPP quad permutes.  Then the seven winners are
+// re-measured exactly by the lanes that scanned them and ranked exactly (distance, then position - the visiting order): the
+// five nearest are the exact answer unless the exact 5th distance reaches the truncated distance of the 7th key - every
+// candidate that was dropped is at least that far - in which case the query is flagged for the completion pass (5th, 6th and
+// 7th distances equal to 13 bits: ~1e-7 of the queries).
+constexpr unsigned int kPkInf = 0xFFFFFFFFu;
+constexpr int kPkPosBits = 10;
+constexpr unsigned int kPkPosMask = (1u << kPkPosBits) - 1u;
+constexpr unsigned int kPkLaneCap = 256;  // candidates a lane can number
+
+struct Pk7 {
+  unsigned int k0, k1, k2, k3, k4, k5, k6;
+};
+__device__ __forceinline__ unsigned int umed3(unsigned int a, unsigned int b, unsigned int c) {
+  unsigned int r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ void pk_insert(Pk7& L, unsigned int x) {
+  L.k6 = umed3(L.k5, L.k6, x);
+  L.k5 = umed3(L.k4, L.k5, x);
+  L.k4 = umed3(L.k3, L.k4, x);
+  L.k3 = umed3(L.k2, L.k3, x);
+  L.k2 = umed3(L.k1, L.k2, x);
+  L.k1 = umed3(L.k0, L.k1, x);
+  L.k0 = min(L.k0, x);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned int quad_perm(unsigned int v) {
+  return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float quad_perm_f(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+#define LII_CE(a, b) { const unsigned int lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; }
+// L <- the seven smallest keys of L and of the partner lane's list (quad permute CTRL), sorted.  C_i = min(L_i, M_{7-i}) with an
+// eighth "infinite" key on both sides is a bitonic sequence holding the eight smallest of the sixteen; three half-cleaner stages
+// sort it.  Both partners compute the same list.
+template <int CTRL>
+__device__ __forceinline__ void pk_merge(Pk7& L) {
+  const unsigned int m0 = quad_perm<CTRL>(L.k0), m1 = quad_perm<CTRL>(L.k1), m2 = quad_perm<CTRL>(L.k2), m3 = quad_perm<CTRL>(L.k3),
+                     m4 = quad_perm<CTRL>(L.k4), m5 = quad_perm<CTRL>(L.k5), m6 = quad_perm<CTRL>(L.k6);
+  unsigned int c0 = L.k0, c1 = min(L.k1, m6), c2 = min(L.k2, m5), c3 = min(L.k3, m4), c4 = min(L.k4, m3), c5 = min(L.k5, m2),
+               c6 = min(L.k6, m1), c7 = m0;
+  LII_CE(c0, c4) LII_CE(c1, c5) LII_CE(c2, c6) LII_CE(c3, c7)
+  LII_CE(c0, c2) LII_CE(c1, c3) LII_CE(c4, c6) LII_CE(c5, c7)
+  LII_CE(c0, c1) LII_CE(c2, c3) LII_CE(c4, c5)
+  c6 = min(c6, c7);
+  L.k0 = c0; L.k1 = c1; L.k2 = c2; L.k3 = c3; L.k4 = c4; L.k5 = c5; L.k6 = c6;
+}
+#undef LII_CE
+
+struct F3 {
+  float x, y, z;
+};
+// xyz of map slot `idx`: 12 of the 16 bytes (w is the insertion id).  The byte offset is formed in 32 bits (the point array holds
+// fewer than 2^28 slots), so the load takes the uniform base from scalar registers and ONE address register.
+__device__ __forceinline__ F3 load_xyz(const float4* __restrict__ pts, unsigned int idx) {
+  typedef float f3v __attribute__((ext_vector_type(3)));
+  const f3v v = *reinterpret_cast<const f3v*>(reinterpret_cast<const char*>(pts) + (size_t)(idx << 4));
+  F3 r;
+  r.x = v.x; r.y = v.y; r.z = v.z;
+  return r;
 }
 
 // `forced` 1: host-driven pass at the pose `ps_val` (always runs).  forced 2: always runs, pose read from `pose` (device).
 // forced < 0: device-driven loop — pose from `pose` (the control block), runs only when the control block says the next pass
 // searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).  An executed pass leaves its pose in
-// `search_pose_out` (may be null).  A query whose 3x3x3 block cannot prove its list complete is flagged in nbr_count
-// (kNeedy); k_fit_reduce (or k_knn_complete after a stand-alone search) finishes it.
-template <int LPQ, int BS, bool BAL = false, int WPE = 1>
-__global__ __launch_bounds__(BS, WPE) void k_knn_pruned(GridView g, RegistrationBuffers rb, PoseArg ps_val,
-                                                   const PoseArg* __restrict__ pose, const IekfCtrl* __restrict__ ctrl,
-                                                   int forced, int nb_real, double* __restrict__ search_pose_out) {
+// `search_pose_out` (may be null).
+// NB = candidate loads a lane keeps in flight (one batch).
+template <int BS, int NB, int WPE>
+__global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuffers rb, PoseArg ps_val, const PoseArg* __restrict__ pose,
+                                               const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
+                                               double* __restrict__ search_pose_out) {
   // the pose sits in the control block: its load goes out together with the flags instead of after the branch on them
-  // (one dependent round trip less at the head of every launch, executed or not)
   const PoseArg ps = forced != 1 ? *pose : ps_val;
   int lo, n_live;
   shard_range(rb, lo, n_live);
@@ -759,46 +716,196 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pruned(GridView g, Registration
   if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;
-  constexpr int QPB = BS / LPQ;
-  const int sub = threadIdx.x & (LPQ - 1);
-  const int ql = blk * QPB + threadIdx.x / LPQ;
+  constexpr int QPB = BS / 4;
+  const int sub = threadIdx.x & 3;
+  const int ql = blk * QPB + (threadIdx.x >> 2);
   const int qi = lo + ql;
   const bool live = ql < n_live;
-  const int leader = (threadIdx.x & 63) & ~(LPQ - 1);
+  const int leader = (threadIdx.x & 63) & ~3;
   float wx = 0, wy = 0, wz = 0;
   if (live && sub == 0) body_to_world(ps, rb.body[qi], wx, wy, wz);
-  wx = __shfl(wx, leader); wy = __shfl(wy, leader); wz = __shfl(wz, leader);
+  wx = quad_perm_f<0x00>(wx); wy = quad_perm_f<0x00>(wy); wz = quad_perm_f<0x00>(wz);
+  const bool active = live && g.n_pts > 0;
+  const float INF = __builtin_inff();
+  const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
+  const float4* __restrict__ pts = g.pts;
+
+  // The lane's two cells: opposite corners of the 2x2x2 block (c and 7 - c differ on every axis, so a surface that runs along
+  // the axes puts one occupied cell on every lane).  Idle lanes look their cells up as well (a lookup behind a branch is
+  // waited for on its own).
+  float g0sq, guardsq;
+  unsigned int A0, Bm, lenA, n_lane;  // map index of position p in the lane's candidate list: (p < lenA ? A0 : Bm) + p
+  {
+    const QueryCell q = query_cell(g, wx, wy, wz);
+    g0sq = q.g0 * q.g0;
+    guardsq = q.guard * q.guard;
+    uint2 r[2];
+    int jx[2], jy[2], jz[2];
+    const bool want[2] = {true, true};
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int c = t == 0 ? sub : 7 - sub;
+      jx[t] = q.cx + ((c & 1) ? q.ox : 0); jy[t] = q.cy + ((c & 2) ? q.oy : 0); jz[t] = q.cz + ((c & 4) ? q.oz : 0);
+    }
+    lookup_cells_batched<2>(g, tab, jx, jy, jz, want, r);
+    lenA = r[0].y - r[0].x;
+    n_lane = lenA + (r[1].y - r[1].x);
+    A0 = r[0].x;
+    Bm = r[1].x - lenA;
+  }
+  // a group with a lane that cannot number its candidates takes the exact path below
+  bool big = n_lane > kPkLaneCap;
+  big = big || quad_perm<0xB1>((unsigned)big) != 0u;
+  big = big || quad_perm<0x4E>((unsigned)big) != 0u;
+  const bool fast = active && !big;
+  const bool slow = active && big;
+
+  Pk7 L;
+  L.k0 = L.k1 = L.k2 = L.k3 = L.k4 = L.k5 = L.k6 = kPkInf;
+  {
+    const unsigned int n = fast ? n_lane : 0u;
+    const unsigned int posbase = (unsigned)sub << 8;
+    for (unsigned int base = 0; base < n; base += NB) {
+      // one batch: NB loads in flight (positions behind the end re-read the last candidate and are discarded - a load behind
+      // a branch would be waited for on its own)
+      F3 P[NB];
+#pragma unroll
+      for (int u = 0; u < NB; u++) {
+        const unsigned int p = min(base + u, n - 1u);
+        P[u] = load_xyz(pts, (p < lenA ? A0 : Bm) + p);
+      }
+#pragma unroll
+      for (int u = 0; u < NB; u++) {
+        const unsigned int p = base + u;
+        const float d = dist2_ref(wx, wy, wz, P[u].x, P[u].y, P[u].z);
+        const unsigned int key = (__float_as_uint(d) & ~kPkPosMask) | (posbase + p);
+        pk_insert(L, (p < n && d <= g.max_d2) ? key : kPkInf);
+      }
+    }
+  }
+  pk_merge<0xB1>(L);  // lanes 0<->1, 2<->3
+  pk_merge<0x4E>(L);  // lanes 0<->2, 1<->3: every lane of the group now holds the group's seven smallest keys
+
+  // Exact re-measurement of the seven winners.  The lane that scanned a winner knows its map index; the index travels to the
+  // other three lanes of the group (an OR over the quad: the other lanes contribute 0).  Lane `sub` then loads and measures
+  // winners `sub` and `sub + 4`, and the seven exact distances are shared by quad broadcasts.
+  unsigned int widx[7];
+  float e[7];
+  F3 Wa, Wb;  // this lane's two winners
+  float d7t;  // the truncated distance of the 7th key: no dropped candidate is nearer (inf: nothing was dropped)
+  {
+    const unsigned int K[7] = {L.k0, L.k1, L.k2, L.k3, L.k4, L.k5, L.k6};
+#pragma unroll
+    for (int w = 0; w < 7; w++) {
+      const unsigned int pos = K[w] & kPkPosMask, p = pos & 255u;
+      const bool mine = K[w] != kPkInf && (pos >> 8) == (unsigned)sub;
+      unsigned int v = mine ? (p < lenA ? A0 : Bm) + p : 0u;
+      v |= quad_perm<0xB1>(v);
+      v |= quad_perm<0x4E>(v);
+      widx[w] = v;  // (an empty slot reads map slot 0 and is discarded)
+    }
+    const unsigned int ia = sub == 0 ? widx[0] + 0u : (sub == 1 ? widx[1] + 0u : (sub == 2 ? widx[2] + 0u : widx[3] + 0u));
+    const unsigned int ib = sub == 0 ? widx[4] + 0u : (sub == 1 ? widx[5] + 0u : widx[6] + 0u);
+    Wa = load_xyz(pts, ia);
+    Wb = load_xyz(pts, ib);
+    const float ea = dist2_ref(wx, wy, wz, Wa.x, Wa.y, Wa.z), eb = dist2_ref(wx, wy, wz, Wb.x, Wb.y, Wb.z);
+    e[0] = quad_perm_f<0x00>(ea); e[1] = quad_perm_f<0x55>(ea); e[2] = quad_perm_f<0xAA>(ea); e[3] = quad_perm_f<0xFF>(ea);
+    e[4] = quad_perm_f<0x00>(eb); e[5] = quad_perm_f<0x55>(eb); e[6] = quad_perm_f<0xAA>(eb);
+#pragma unroll
+    for (int w = 0; w < 7; w++) e[w] = K[w] != kPkInf ? e[w] : INF;
+    d7t = K[6] != kPkInf ? __uint_as_float(K[6] & ~kPkPosMask) : INF;
+  }
+  // Exact ranks.  The keys are in ascending order, so for v < w the exact order can differ from the key order only where the
+  // truncated distances agree, and there an equal exact distance keeps the key order (position = visiting order):
+  // v stays ahead of w unless e[v] > e[w].  Empty slots (inf) keep their places at the end.
+  int rank[7];
+#pragma unroll
+  for (int w = 0; w < 7; w++) rank[w] = 0;
+#pragma unroll
+  for (int v = 0; v < 7; v++)
+#pragma unroll
+    for (int w = v + 1; w < 7; w++) {
+      const bool swapped = e[v] > e[w];
+      rank[w] += swapped ? 0 : 1;
+      rank[v] += swapped ? 1 : 0;
+    }
+  float d5 = INF;  // exact 5th distance among the kept candidates (inf: fewer than five)
+#pragma unroll
+  for (int w = 0; w < 7; w++) d5 = rank[w] == 4 ? e[w] : d5;
+  int found = 0;
+#pragma unroll
+  for (int w = 0; w < 7; w++) found += e[w] < INF ? 1 : 0;
+  found = min(found, 5);
+  // the five nearest are exact unless a dropped candidate could tie with or beat the 5th
+  const bool amb = fast && d7t < INF && !(d5 < d7t);
+  const bool more_fast = fast && !(fminf(d5, g.max_d2) <= g0sq);
+
+  // Queries that need round 2 continue on exact (distance, index) lists: the packed result, on every lane of the group
   Knn5 k;
-  bool need;
-  const GlobalCells src{g, reinterpret_cast<const uint4*>(g.blocks)};
-  knn_search_query<LPQ, GlobalCells, BAL>(src, g, live && g.n_pts > 0, wx, wy, wz, sub, leader, k, need);
-  if (live) knn_store<LPQ>(rb, g.pts, qi, sub, k, need, wx, wy, wz);
+  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = INF;
+  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
+  if (__any(more_fast)) {
+    if (more_fast) {
+#pragma unroll
+      for (int w = 0; w < 7; w++) {
+        const bool valid = e[w] < INF;
+        const int gi = (int)widx[w];
+        if (valid && rank[w] == 0) { k.d0 = e[w]; k.i0 = gi; }
+        if (valid && rank[w] == 1) { k.d1 = e[w]; k.i1 = gi; }
+        if (valid && rank[w] == 2) { k.d2 = e[w]; k.i2 = gi; }
+        if (valid && rank[w] == 3) { k.d3 = e[w]; k.i3 = gi; }
+        if (valid && rank[w] == 4) { k.d4 = e[w]; k.i4 = gi; }
+      }
+    }
+  }
+  // The usual case ends here: every lane stores its two winners at their ranks.
+  if (live && !slow && !more_fast) {
+    const bool need = active && (amb || !(fminf(d5, g.max_d2) <= guardsq));
+    {
+      const float ea = sub == 0 ? e[0] + 0.f : (sub == 1 ? e[1] + 0.f : (sub == 2 ? e[2] + 0.f : e[3] + 0.f));
+      const int ra = sub == 0 ? rank[0] + 0 : (sub == 1 ? rank[1] + 0 : (sub == 2 ? rank[2] + 0 : rank[3] + 0));
+      const float eb = sub == 0 ? e[4] + 0.f : (sub == 1 ? e[5] + 0.f : e[6] + 0.f);
+      const int rbk = sub == 0 ? rank[4] + 0 : (sub == 1 ? rank[5] + 0 : rank[6] + 0);
+      if (ea < INF && ra < 5) rb.nbr[(size_t)ra * rb.cap + qi] = make_float4(Wa.x, Wa.y, Wa.z, ea);
+      if (sub < 3 && eb < INF && rbk < 5) rb.nbr[(size_t)rbk * rb.cap + qi] = make_float4(Wb.x, Wb.y, Wb.z, eb);
+    }
+    if (found < 5) {  // the missing neighbours read (0, 0, 0, inf)
+      if (sub >= found) rb.nbr[(size_t)sub * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
+      if (sub == 0) rb.nbr[(size_t)4 * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
+    }
+    if (sub == 1) {
+      rb.nbr_count[qi] = found | (need ? kNeedy : 0);
+    } else if (sub == 2) {
+      rb.world[qi] = make_float4(wx, wy, wz, 0.f);
+    }
+  }
+  const bool exact_list = slow || more_fast;
+  if (!__any(exact_list)) return;
+  // The rest: groups that could not number their candidates (their round 1 on exact lists) and round 2.  (The query's place in
+  // the grid is derived again rather than kept in registers across the common path.)
+  const QueryCell q = query_cell(g, wx, wy, wz);
+  if (slow) {
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int c = t == 0 ? sub : 7 - sub;
+      const uint2 r = lookup_cell(g, tab, q.cx + ((c & 1) ? q.ox : 0), q.cy + ((c & 2) ? q.oy : 0), q.cz + ((c & 4) ? q.oz : 0));
+      scan_range(pts, g.max_d2, r.x, r.y, wx, wy, wz, k);
+    }
+  }
+  knn_group_merge4<true>(k);  // (the lanes of a packed group hold one and the same list: duplicates are suppressed)
+  const bool more = slow ? !(fminf(k.d4, g.max_d2) <= q.g0 * q.g0) : more_fast;
+  if (__any(more)) knn_round2(g, tab, q, more, wx, wy, wz, sub, leader, k);
+  knn_group_bcast(k, leader);
+  const bool need = active && (amb || !(fminf(k.d4, g.max_d2) <= q.guard * q.guard));
+  if (live && exact_list) knn_store(rb, pts, qi, sub, k, need, wx, wy, wz);
 }
 
-// The search pass with LDS-staged map tiles.  A workgroup takes QPB = BS / 4 consecutive queries of the down-sampled cloud,
-// which the voxel filter emits in a spatially coherent order (k_voxel_keys: Morton order of 8x8x8-voxel bricks), so their
-// 3x3x3 cell neighbourhoods overlap heavily:
-//   1. world points (pointBodyToWorld), cell coordinates, workgroup minimum (the tile's origin);
-//   2. every (query, cell) pair of the neighbourhoods goes into an LDS hash set: the distinct cells (~230 for 64 queries);
-//   3. one lane per distinct cell: block-table probe + cell entry (two dependent loads, all cells in parallel);
-//   4. block scan of the cell sizes -> tile offsets; the cells' points are copied into LDS (~660 points, coalesced per cell);
-//   5. the two search rounds of every query run entirely out of LDS (knn_search_query<TileCells>), the winners' coordinates
-//      come from LDS as well - no gather at the end.
-// A workgroup whose queries are too scattered (hash set or tile full: a chunk that straddles a depth discontinuity) searches
-// through global memory like k_knn_pruned.  Results are bit-identical to k_knn_pruned.
-template <int BS, int TCAP, int HCAP>
-__global__ __launch_bounds__(BS) void k_knn_tile(GridView g, RegistrationBuffers rb, PoseArg ps_val, const PoseArg* __restrict__ pose,
-                                                 const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
-                                                 double* __restrict__ search_pose_out, unsigned int* __restrict__ stats) {
-  constexpr int LPQ = 4, QPB = BS / LPQ;
-  constexpr int CCAP = HCAP * 3 / 4;          // distinct cells a workgroup may stage (hash load factor <= 3/4)
-  constexpr int NCT = (CCAP + BS - 1) / BS;   // cells per lane in steps 3-4
-  static_assert((HCAP & (HCAP - 1)) == 0 && TCAP <= 65535 && CCAP * 4 <= TCAP * 16, "tile geometry");
-  __shared__ unsigned int s_hkey[HCAP];
-  __shared__ unsigned int s_hval[HCAP];
-  __shared__ __align__(16) float4 s_tile[TCAP];  // steps 2-3: its head doubles as the list of distinct cells (hash slots)
-  __shared__ int s_cmin[3], s_cmax[3];
-  __shared__ unsigned int s_ncell, s_over, s_big, s_wtot[BS / 64];
+// The search pass on exact (distance, index) lists throughout (round 2's form in round 1 too).  Kept as the reference form of
+// k_knn_pk: same cells, same candidates; LII_KNN_VARIANT=5 selects it.
+template <int BS>
+__global__ __launch_bounds__(BS) void k_knn_exact(GridView g, RegistrationBuffers rb, PoseArg ps_val, const PoseArg* __restrict__ pose,
+                                                  const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
+                                                  double* __restrict__ search_pose_out) {
   const PoseArg ps = forced != 1 ? *pose : ps_val;
   int lo, n_live;
   shard_range(rb, lo, n_live);
@@ -806,169 +913,42 @@ __global__ __launch_bounds__(BS) void k_knn_tile(GridView g, RegistrationBuffers
   if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;
-  const int tid = threadIdx.x, sub = tid & (LPQ - 1);
-  const int ql = blk * QPB + tid / LPQ;
+  constexpr int QPB = BS / 4;
+  const int sub = threadIdx.x & 3;
+  const int ql = blk * QPB + (threadIdx.x >> 2);
   const int qi = lo + ql;
   const bool live = ql < n_live;
-  const int leader = (tid & 63) & ~(LPQ - 1);
+  const int leader = (threadIdx.x & 63) & ~3;
   float wx = 0, wy = 0, wz = 0;
   if (live && sub == 0) body_to_world(ps, rb.body[qi], wx, wy, wz);
   wx = __shfl(wx, leader); wy = __shfl(wy, leader); wz = __shfl(wz, leader);
   const bool active = live && g.n_pts > 0;
-  const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
-  unsigned int* s_clist = reinterpret_cast<unsigned int*>(s_tile);
-  // LII_KNN_STATS=1: stats[2 + k] accumulates the 10 ns ticks workgroups spent in phase k (thread 0's wall clock)
-  long long t_phase = stats ? wall_clock64() : 0;
-#define LII_TILE_PHASE(k)                                                              \
-  do {                                                                                 \
-    if (stats && tid == 0) {                                                           \
-      const long long now_ = wall_clock64();                                           \
-      atomicAdd(&stats[2 + (k)], (unsigned int)(now_ - t_phase));                      \
-      t_phase = now_;                                                                  \
-    }                                                                                  \
-  } while (0)
-  // ---- 1. tile origin; hash set cleared
-  for (int s = tid; s < HCAP; s += BS) s_hkey[s] = kTileEmpty;
-  if (tid < 3) { s_cmin[tid] = 0x7FFFFFFF; s_cmax[tid] = -0x7FFFFFFF; }
-  if (tid == 0) { s_ncell = 0u; s_over = 0u; s_big = 0u; }
-  __syncthreads();
-  {
-    int mn[3] = {active ? cx : 0x7FFFFFFF, active ? cy : 0x7FFFFFFF, active ? cz : 0x7FFFFFFF};
-    int mx[3] = {active ? cx : -0x7FFFFFFF, active ? cy : -0x7FFFFFFF, active ? cz : -0x7FFFFFFF};
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      for (int off = 32; off > 0; off >>= 1) { mn[a] = min(mn[a], __shfl_xor(mn[a], off)); mx[a] = max(mx[a], __shfl_xor(mx[a], off)); }
-      if ((tid & 63) == 0) { atomicMin(&s_cmin[a], mn[a]); atomicMax(&s_cmax[a], mx[a]); }
-    }
-  }
-  __syncthreads();
-  LII_TILE_PHASE(0);
-  const int bx = s_cmin[0] - 1, by = s_cmin[1] - 1, bz = s_cmin[2] - 1;
-  // cells relative to the origin must fit 10 bits per axis (a workgroup spanning > 1000 cells is not coherent anyway)
-  bool tiled = s_cmax[0] - bx + 1 < 1024 && s_cmax[1] - by + 1 < 1024 && s_cmax[2] - bz + 1 < 1024 && s_cmin[0] != 0x7FFFFFFF;
-  if (tiled) {
-    // ---- 2. the distinct cells of the workgroup's 3x3x3 neighbourhoods
-    if (active) {
-      for (int c = sub; c < 27; c += LPQ) {
-        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
-        const unsigned int key = tile_key(cx + dx - bx, cy + dy - by, cz + dz - bz);
-        unsigned int sl = tile_slot(key, HCAP - 1);
-        for (int probes = 0; probes < HCAP; probes++) {
-          const unsigned int prev = atomicCAS(&s_hkey[sl], kTileEmpty, key);
-          if (prev == kTileEmpty) {
-            const unsigned int at = atomicAdd(&s_ncell, 1u);
-            if (at < (unsigned)CCAP) s_clist[at] = sl; else s_over = 1u;
-            break;
-          }
-          if (prev == key) break;
-          if (*reinterpret_cast<volatile unsigned int*>(&s_over)) break;  // the set is full: the workgroup takes the global path
-          sl = (sl + 1) & (HCAP - 1);
-        }
-      }
-    }
-    __syncthreads();
-    tiled = s_over == 0u;
-  }
-  LII_TILE_PHASE(1);
-  unsigned int c_start[NCT], c_cnt[NCT], c_slot[NCT];
-  unsigned int mine = 0;
-  if (tiled) {
-    // ---- 3. one lane per distinct cell: where its points are
-    const int ncell = (int)s_ncell;
-    const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
-    int jx[NCT], jy[NCT], jz[NCT];
-    bool want[NCT];
-    uint2 r[NCT];
-#pragma unroll
-    for (int t = 0; t < NCT; t++) {
-      const int i = tid + BS * t;
-      want[t] = i < ncell;
-      c_slot[t] = want[t] ? s_clist[i] : 0u;
-      const unsigned int key = want[t] ? s_hkey[c_slot[t]] : 0u;
-      jx[t] = bx + (int)(key & 1023u); jy[t] = by + (int)((key >> 10) & 1023u); jz[t] = bz + (int)(key >> 20);
-    }
-    lookup_cells_batched<NCT>(g, tab, jx, jy, jz, want, r);
-#pragma unroll
-    for (int t = 0; t < NCT; t++) {
-      c_start[t] = r[t].x;
-      c_cnt[t] = want[t] ? r[t].y - r[t].x : 0u;
-      if (c_cnt[t] > 0xFFFFu) s_big = 1u;
-      mine += c_cnt[t];
-    }
-    LII_TILE_PHASE(2);
-    // ---- 4. tile offsets (block scan), then the copy
-    unsigned int inc = mine;
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned int o = __shfl_up(inc, off);
-      if ((tid & 63) >= off) inc += o;
-    }
-    __syncthreads();  // every lane has read its s_clist entries: the tile may be overwritten
-    if ((tid & 63) == 63) s_wtot[tid >> 6] = inc;
-    __syncthreads();
-    unsigned int before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < BS / 64; w++) { if (w < (tid >> 6)) before += s_wtot[w]; total += s_wtot[w]; }
-    tiled = total <= (unsigned)TCAP && s_big == 0u;
-    if (tiled) {
-      // The copy is cooperative per wavefront: in round t the 64 lanes own up to 64 cells (~a third of them occupied, ~9 points
-      // each); point q of the round's W points belongs to the lane whose inclusive prefix first exceeds q (a 6-step search by
-      // shuffle), so every lane moves W / 64 points and all of its loads are in flight together - instead of one lane walking
-      // its cell alone, a dependent global round trip per four points.
-      unsigned int off = before + inc - mine;  // tile offset of this lane's first cell
-      const int lane = tid & 63;
-#pragma unroll
-      for (int t = 0; t < NCT; t++) {
-        if (tid + BS * t < ncell) s_hval[c_slot[t]] = off | (c_cnt[t] << 16);
-        unsigned int pre = c_cnt[t];  // inclusive prefix of the round's cell sizes over the wavefront
-        for (int o = 1; o < 64; o <<= 1) {
-          const unsigned int v = __shfl_up(pre, o);
-          if (lane >= o) pre += v;
-        }
-        const unsigned int W = __shfl(pre, 63);
-        for (unsigned int q0 = 0; q0 < W; q0 += 256) {  // uniform trip count
-          float4 p[4];
-          unsigned int dst[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const unsigned int q = q0 + 64 * u + lane;
-            int pos = 0;
-#pragma unroll
-            for (int step = 32; step > 0; step >>= 1) {
-              const unsigned int v = __shfl(pre, pos + step - 1);
-              if (v <= q) pos += step;
-            }
-            pos = min(pos, 63);
-            const unsigned int o_pre = __shfl(pre, pos), o_cnt = __shfl(c_cnt[t], pos), o_start = __shfl(c_start[t], pos),
-                               o_off = __shfl(off, pos);
-            const unsigned int j = q - (o_pre - o_cnt);
-            dst[u] = q < W ? o_off + j : 0xFFFFFFFFu;
-            p[u] = q < W ? g.pts[o_start + j] : make_float4(0, 0, 0, 0);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            if (dst[u] != 0xFFFFFFFFu) s_tile[dst[u]] = p[u];
-        }
-        off += c_cnt[t];
-      }
-    }
-    __syncthreads();
-  }
-  if (stats && tid == 0) atomicAdd(&stats[tiled ? 0 : 1], 1u);
-  LII_TILE_PHASE(3);
+  const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
+  const QueryCell q = query_cell(g, wx, wy, wz);
   Knn5 k;
-  bool need;
-  if (tiled) {  // uniform per workgroup
-    const TileCells src{s_hkey, s_hval, s_tile, (unsigned)(HCAP - 1), bx, by, bz};
-    knn_search_query<LPQ>(src, g, active, wx, wy, wz, sub, leader, k, need);
-    LII_TILE_PHASE(4);
-    if (live) knn_store<LPQ>(rb, s_tile, qi, sub, k, need, wx, wy, wz);
-    LII_TILE_PHASE(5);
-  } else {
-    const GlobalCells src{g, reinterpret_cast<const uint4*>(g.blocks)};
-    knn_search_query<LPQ>(src, g, active, wx, wy, wz, sub, leader, k, need);
-    if (live) knn_store<LPQ>(rb, g.pts, qi, sub, k, need, wx, wy, wz);
+  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = __builtin_inff();
+  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
+  if (active) {
+    uint2 r[2];
+    int jx[2], jy[2], jz[2];
+    const bool want[2] = {true, true};
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int c = t == 0 ? sub : 7 - sub;
+      jx[t] = q.cx + ((c & 1) ? q.ox : 0); jy[t] = q.cy + ((c & 2) ? q.oy : 0); jz[t] = q.cz + ((c & 4) ? q.oz : 0);
+    }
+    lookup_cells_batched<2>(g, tab, jx, jy, jz, want, r);
+    scan_range(g.pts, g.max_d2, r[0].x, r[0].y, wx, wy, wz, k);
+    scan_range(g.pts, g.max_d2, r[1].x, r[1].y, wx, wy, wz, k);
   }
+  knn_group_merge4<false>(k);
+  const bool more = active && !(fminf(k.d4, g.max_d2) <= q.g0 * q.g0);
+  if (__any(more)) knn_round2(g, tab, q, more, wx, wy, wz, sub, leader, k);
+  knn_group_bcast(k, leader);
+  const bool need = active && !(fminf(k.d4, g.max_d2) <= q.guard * q.guard);
+  if (live) knn_store(rb, g.pts, qi, sub, k, need, wx, wy, wz);
 }
+
 
 // Second stage of the search for a flagged query, run by ONE WAVEFRONT (four flagged queries of a workgroup proceed
 // concurrently): every cell that intersects the ball of radius sqrt(min(d5 of stage 1, max_d2)) is visited — looked up through
@@ -1759,37 +1739,34 @@ int register_blocks(int n) { return nblk(n, kBlock); }
 static inline int shard_bound(const RegistrationBuffers& rb) {
   return rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;
 }
-template <int LPQ, int BS, bool BAL = false, int WPE = 1>
-static void launch_knn_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                         const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
-  int nq = nblk(shard_bound(rb), BS / LPQ);
-  if (nq < 1) nq = 1;
-  const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_knn_pruned<LPQ, BS, BAL, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
-}
-template <int BS, int TCAP, int HCAP>
-static void launch_knn_tile_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                              const IekfCtrl* ctrl, int forced, double* search_pose_out, unsigned int* stats, hipStream_t s) {
+template <int BS, int NB, int WPE>
+static void launch_knn_pk_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+                            const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
   int nq = nblk(shard_bound(rb), BS / 4);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_knn_tile<BS, TCAP, HCAP>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out, stats);
+  hipLaunchKernelGGL((k_knn_pk<BS, NB, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
 }
-// variant: 4 / 8 = lanes per query of the global-memory search (k_knn_pruned); 64 / 65 / 32 / 128 = LDS-tiled search
-// (k_knn_tile) with 64 queries per workgroup and a 1536- / 1024-point tile, 32 queries (768 points), 128 queries (3072 points)
+// variant 0: packed keys (k_knn_pk, the product path); 5: exact lists throughout (k_knn_exact, its reference form);
+// other values: diagnostic geometries of k_knn_pk
 void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                const IekfCtrl* ctrl, int forced, double* search_pose_out, unsigned int* stats, hipStream_t s) {
+                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
   switch (variant) {
-    case 8: launch_knn_t<8, 256>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    // 128-thread workgroups: measured 29.3 us per pass against 30.3 us at 256 (shorter tail), 64 is no better.
-    case 4: launch_knn_t<4, 128>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 5: launch_knn_t<4, 128, true>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;  // 4 lanes, balanced round 1
-    case 6: launch_knn_t<4, 128, true, 8>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;  // ... capped at 64 VGPRs
-    case 7: launch_knn_t<4, 256, true>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 65: launch_knn_tile_t<256, 1024, 1024>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
-    case 32: launch_knn_tile_t<128, 768, 512>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
-    case 128: launch_knn_tile_t<512, 3072, 2048>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
-    default: launch_knn_tile_t<256, 1536, 1024>(g, rb, ps, pose, ctrl, forced, search_pose_out, stats, s); break;
+    case 5: {
+      int nq = nblk(shard_bound(rb), 128 / 4);
+      if (nq < 1) nq = 1;
+      const int nq_pad = ((nq + 7) / 8) * 8;
+      hipLaunchKernelGGL((k_knn_exact<128>), dim3(nq_pad), dim3(128), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
+      break;
+    }
+    case 21: launch_knn_pk_t<128, 6, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 22: launch_knn_pk_t<128, 4, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 23: launch_knn_pk_t<256, 8, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 24: launch_knn_pk_t<64, 8, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 25: launch_knn_pk_t<128, 8, 8>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 26: launch_knn_pk_t<128, 4, 8>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 27: launch_knn_pk_t<128, 8, 1>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    default: launch_knn_pk_t<128, 8, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
   }
 }
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {

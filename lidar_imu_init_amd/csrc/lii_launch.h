@@ -28,7 +28,7 @@ void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks
                        unsigned int block_mask, uint2* cells, hipStream_t s);
 // registration
 void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                const IekfCtrl* ctrl, int forced, double* search_pose_out, unsigned int* stats, hipStream_t s);
+                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s);
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s);
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s);
