@@ -20,6 +20,9 @@
 #include <math.h>
 #include <cstdlib>
 #include <stdint.h>
+#include <algorithm>
+#include <cstdio>
+#include <vector>
 
 #include "lii_device.h"
 
@@ -629,19 +632,20 @@ __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const f
 }
 
 // ---- packed keys ---------------------------------------------------------------------------------
-// Round 1 ranks its candidates as 32-bit keys: the float bits of d2 with the low kPkPosBits mantissa bits replaced by the
-// candidate's position in the group's candidate list (2 bits: the lane that scanned it, 8 bits: its place in that lane's
-// two cells).  d2 >= 0, so the keys order like the distances (to 13 mantissa bits) and are unique; a sorted list of the SEVEN
+// k_knn_pk ranks its candidates as 32-bit keys: the float bits of d2 with the low kPkPosBits mantissa bits replaced by the
+// candidate's position in the group's candidate list (2 bits: the lane that scanned it, 10 bits: its place in that lane's
+// cells).  d2 >= 0, so the keys order like the distances (to 11 mantissa bits) and are unique; a sorted list of the SEVEN
 // smallest keys is maintained with one v_min_u32 and six v_med3_u32 per candidate - no compares, no selects, no index
-// registers.  The four lists of a group are joined by two bitonic merges over DPP quad permutes.  Then the seven winners are
-// re-measured exactly by the lanes that scanned them and ranked exactly (distance, then position - the visiting order): the
-// five nearest are the exact answer unless the exact 5th distance reaches the truncated distance of the 7th key - every
-// candidate that was dropped is at least that far - in which case the query is flagged for the completion pass (5th, 6th and
-// 7th distances equal to 13 bits: ~1e-7 of the queries).
+// registers.  The four lists of a group are joined by two bitonic merges over DPP quad permutes.  At the end the seven winners
+// are re-measured exactly and ranked exactly (distance, then position - the visiting order): the five nearest are the exact
+// answer unless the exact 5th distance reaches the truncated distance of the 7th key - every candidate that was dropped is at
+// least that far - in which case the query is flagged for the completion pass (5th, 6th and 7th distances equal to 11 bits:
+// ~1e-5 of the queries).
 constexpr unsigned int kPkInf = 0xFFFFFFFFu;
-constexpr int kPkPosBits = 10;
+constexpr int kPkPosBits = 12, kPkLaneBits = 10;
 constexpr unsigned int kPkPosMask = (1u << kPkPosBits) - 1u;
-constexpr unsigned int kPkLaneCap = 256;  // candidates a lane can number
+constexpr unsigned int kPkLaneMask = (1u << kPkLaneBits) - 1u;
+constexpr unsigned int kPkLaneCap = 1u << kPkLaneBits;  // candidates a lane can number
 
 struct Pk7 {
   unsigned int k0, k1, k2, k3, k4, k5, k6;
@@ -699,15 +703,43 @@ __device__ __forceinline__ F3 load_xyz(const float4* __restrict__ pts, unsigned 
   return r;
 }
 
+// Scans positions [first, first + count) of the lane's candidate list - two cell ranges: map index = p + (p < split ? off_lo :
+// off_hi) - in batches of NB loads (positions behind the end re-read the last candidate and are discarded: a load behind a
+// branch would be waited for on its own), keys into L.
+template <int NB>
+__device__ __forceinline__ void pk_scan(const float4* __restrict__ pts, unsigned int split, unsigned int off_lo, unsigned int off_hi,
+                                        unsigned int first, unsigned int count, unsigned int posbase, float max_d2, float wx, float wy,
+                                        float wz, Pk7& L) {
+  const unsigned int end = first + count;
+  for (unsigned int base = first; base < end; base += NB) {
+    F3 P[NB];
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+      const unsigned int p = min(base + u, end - 1u);
+      P[u] = load_xyz(pts, p + (p < split ? off_lo : off_hi));
+    }
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+      const unsigned int p = base + u;
+      const float d = dist2_ref(wx, wy, wz, P[u].x, P[u].y, P[u].z);
+      const unsigned int key = (__float_as_uint(d) & ~kPkPosMask) | (posbase + p);
+      pk_insert(L, (p < end && d <= max_d2) ? key : kPkInf);
+    }
+  }
+}
+
 // `forced` 1: host-driven pass at the pose `ps_val` (always runs).  forced 2: always runs, pose read from `pose` (device).
 // forced < 0: device-driven loop — pose from `pose` (the control block), runs only when the control block says the next pass
 // searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).  An executed pass leaves its pose in
 // `search_pose_out` (may be null).
-// NB = candidate loads a lane keeps in flight (one batch).
+// NB = candidate loads a lane keeps in flight (one batch).  diag / wlog: timing experiments (LII_KNN_DIAG).
 template <int BS, int NB, int WPE>
 __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuffers rb, PoseArg ps_val, const PoseArg* __restrict__ pose,
                                                const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
-                                               double* __restrict__ search_pose_out) {
+                                               double* __restrict__ search_pose_out, int diag,
+                                               unsigned long long* __restrict__ wlog) {
+  __shared__ uint2 s_rng[6 * BS];
+  const long long t_start = wlog ? wall_clock64() : 0;
   // the pose sits in the control block: its load goes out together with the flags instead of after the branch on them
   const PoseArg ps = forced != 1 ? *pose : ps_val;
   int lo, n_live;
@@ -719,9 +751,11 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
   constexpr int QPB = BS / 4;
   const int sub = threadIdx.x & 3;
   const int ql = blk * QPB + (threadIdx.x >> 2);
+  // the grid is sized for an upper bound of the cloud (the voxel filter leaves the exact size on the device): wavefronts
+  // beyond the cloud leave at once
+  if (blk * QPB + (int)((threadIdx.x & ~63u) >> 2) >= n_live) return;
   const int qi = lo + ql;
   const bool live = ql < n_live;
-  const int leader = (threadIdx.x & 63) & ~3;
   float wx = 0, wy = 0, wz = 0;
   if (live && sub == 0) body_to_world(ps, rb.body[qi], wx, wy, wz);
   wx = quad_perm_f<0x00>(wx); wy = quad_perm_f<0x00>(wy); wz = quad_perm_f<0x00>(wz);
@@ -729,12 +763,12 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
   const float INF = __builtin_inff();
   const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
   const float4* __restrict__ pts = g.pts;
-
-  // The lane's two cells: opposite corners of the 2x2x2 block (c and 7 - c differ on every axis, so a surface that runs along
-  // the axes puts one occupied cell on every lane).  Idle lanes look their cells up as well (a lookup behind a branch is
-  // waited for on its own).
+  const unsigned int posbase = (unsigned)sub << kPkLaneBits;
+  // Round 1.  The lane's two cells: opposite corners of the 2x2x2 block (c and 7 - c differ on every axis, so a surface that runs
+  // along the axes puts one occupied cell on every lane).  Idle lanes look their cells up as well (a lookup behind a branch is
+  // waited for on its own).  Map index of position p < nAB of the lane's candidate list: p + (p < nA ? A0 : Bm).
   float g0sq, guardsq;
-  unsigned int A0, Bm, lenA, n_lane;  // map index of position p in the lane's candidate list: (p < lenA ? A0 : Bm) + p
+  unsigned int A0, Bm, nA, nAB;
   {
     const QueryCell q = query_cell(g, wx, wy, wz);
     g0sq = q.g0 * q.g0;
@@ -748,58 +782,118 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
       jx[t] = q.cx + ((c & 1) ? q.ox : 0); jy[t] = q.cy + ((c & 2) ? q.oy : 0); jz[t] = q.cz + ((c & 4) ? q.oz : 0);
     }
     lookup_cells_batched<2>(g, tab, jx, jy, jz, want, r);
-    lenA = r[0].y - r[0].x;
-    n_lane = lenA + (r[1].y - r[1].x);
+    nA = r[0].y - r[0].x;
+    nAB = nA + (r[1].y - r[1].x);
     A0 = r[0].x;
-    Bm = r[1].x - lenA;
+    Bm = r[1].x - nA;
   }
-  // a group with a lane that cannot number its candidates takes the exact path below
-  bool big = n_lane > kPkLaneCap;
-  big = big || quad_perm<0xB1>((unsigned)big) != 0u;
-  big = big || quad_perm<0x4E>((unsigned)big) != 0u;
-  const bool fast = active && !big;
-  const bool slow = active && big;
+  // a group with a lane that cannot number its candidates is left to the completion pass (cells of more than 500 points)
+  bool ovf = nAB > kPkLaneCap;
+  ovf = ovf || quad_perm<0xB1>((unsigned)ovf) != 0u;
+  ovf = ovf || quad_perm<0x4E>((unsigned)ovf) != 0u;
+  const bool fast = active && !ovf;
 
   Pk7 L;
   L.k0 = L.k1 = L.k2 = L.k3 = L.k4 = L.k5 = L.k6 = kPkInf;
-  {
-    const unsigned int n = fast ? n_lane : 0u;
-    const unsigned int posbase = (unsigned)sub << 8;
-    for (unsigned int base = 0; base < n; base += NB) {
-      // one batch: NB loads in flight (positions behind the end re-read the last candidate and are discarded - a load behind
-      // a branch would be waited for on its own)
-      F3 P[NB];
-#pragma unroll
-      for (int u = 0; u < NB; u++) {
-        const unsigned int p = min(base + u, n - 1u);
-        P[u] = load_xyz(pts, (p < lenA ? A0 : Bm) + p);
-      }
-#pragma unroll
-      for (int u = 0; u < NB; u++) {
-        const unsigned int p = base + u;
-        const float d = dist2_ref(wx, wy, wz, P[u].x, P[u].y, P[u].z);
-        const unsigned int key = (__float_as_uint(d) & ~kPkPosMask) | (posbase + p);
-        pk_insert(L, (p < n && d <= g.max_d2) ? key : kPkInf);
-      }
-    }
-  }
+  pk_scan<NB>(pts, nA, A0, Bm, 0u, fast ? nAB : 0u, posbase, g.max_d2, wx, wy, wz, L);
   pk_merge<0xB1>(L);  // lanes 0<->1, 2<->3
   pk_merge<0x4E>(L);  // lanes 0<->2, 1<->3: every lane of the group now holds the group's seven smallest keys
+
+  // Round 2 (the tree's calc_box_dist rule, ikd_Tree.cpp:1279-1289): is the 5th distance - here its upper bound, the 5th key
+  // with the position bits set - within the radius round 1 covers?  If not, the outer cells of the 3x3x3 block that can hold a
+  // closer point are dealt out to the four lanes, two per lane and pass (one pass for all but ~0.2 % of the queries; three at
+  // most); their candidates continue the lane's position count, and the ranges they come from are noted in LDS for the
+  // re-measurement below: s_rng[j][lane] = (end position, map index - position) of the lane's j-th range of round 2.
+  bool used2 = false;
+  {
+    const float ub5 = L.k4 != kPkInf ? __uint_as_float(L.k4 | kPkPosMask) : INF;
+    const float bound = fminf(ub5, g.max_d2);
+    const bool need2 = fast && !(bound <= g0sq) && !(diag & 128);
+    if (__any(need2)) {
+      // per axis the squared gaps to the three cell slabs, then 27 sums against the bound (every lane of the group computes the
+      // same mask; the 8 cells of round 1 are masked out)
+      const QueryCell q = query_cell(g, wx, wy, wz);
+      float gx[3], gy[3], gz[3];
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const float ax = axis_gap(wx, q.cx + j - 1, g.cs, q.eps), ay = axis_gap(wy, q.cy + j - 1, g.cs, q.eps),
+                    az = axis_gap(wz, q.cz + j - 1, g.cs, q.eps);
+        gx[j] = ax * ax; gy[j] = ay * ay; gz[j] = az * az;
+      }
+      unsigned int m = 0u;
+#pragma unroll
+      for (int c = 0; c < 27; c++) {
+        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+        const bool in_r1 = (dx == 0 || dx == q.ox) && (dy == 0 || dy == q.oy) && (dz == 0 || dz == q.oz);
+        if (!in_r1 && !(gx[dx + 1] + gy[dy + 1] + gz[dz + 1] > bound)) m |= 1u << c;
+      }
+      m = need2 ? m : 0u;
+      used2 = m != 0u;
+#pragma unroll
+      for (int j = 0; j < 6; j++) s_rng[j * BS + threadIdx.x] = make_uint2(0u, 0u);
+      // the group's list continues on lane 0 alone (four copies would come back as duplicates), the other lanes start empty
+      if (sub != 0) L.k0 = L.k1 = L.k2 = L.k3 = L.k4 = L.k5 = L.k6 = kPkInf;
+      unsigned int t = m, n_pos = nAB;
+#pragma unroll
+      for (int j = 0; j < 3; j++) t = j < sub ? (t & (t - 1u)) : t;  // the lane's first survivor: number `sub` of the set bits
+      for (int pass = 0; pass < 3; pass++) {
+        if (!__any(t != 0u)) break;
+        const int c1 = t ? __ffs((int)t) - 1 : -1;
+        t = t & (t - 1u); t = t & (t - 1u); t = t & (t - 1u); t = t & (t - 1u);
+        const int c2 = t ? __ffs((int)t) - 1 : -1;
+        t = t & (t - 1u); t = t & (t - 1u); t = t & (t - 1u); t = t & (t - 1u);
+        uint2 r[2];
+        {
+          int jx[2], jy[2], jz[2];
+          const bool want[2] = {true, true};
+          const int ca = c1 < 0 ? 13 : c1, cb = c2 < 0 ? 13 : c2;  // (13 = the query's own cell: looked up for nothing, not branched around)
+          jx[0] = q.cx + ca % 3 - 1; jy[0] = q.cy + (ca / 3) % 3 - 1; jz[0] = q.cz + ca / 9 - 1;
+          jx[1] = q.cx + cb % 3 - 1; jy[1] = q.cy + (cb / 3) % 3 - 1; jz[1] = q.cz + cb / 9 - 1;
+          lookup_cells_batched<2>(g, tab, jx, jy, jz, want, r);
+        }
+        const unsigned int nC = c1 < 0 ? 0u : r[0].y - r[0].x, nD = c2 < 0 ? 0u : r[1].y - r[1].x;
+        const unsigned int eC = n_pos + nC, eD = eC + nD;
+        const unsigned int Cm = r[0].x - n_pos, Dm = r[1].x - eC;
+        bool o2 = eD > kPkLaneCap;  // out of positions: the group stops here and is left to the completion pass
+        o2 = o2 || quad_perm<0xB1>((unsigned)o2) != 0u;
+        o2 = o2 || quad_perm<0x4E>((unsigned)o2) != 0u;
+        if (o2) { ovf = true; t = 0u; }
+        const unsigned int cnt = o2 ? 0u : eD - n_pos;
+        s_rng[(2 * pass) * BS + threadIdx.x] = make_uint2(n_pos + (o2 ? 0u : nC), Cm);
+        s_rng[(2 * pass + 1) * BS + threadIdx.x] = make_uint2(n_pos + cnt, Dm);
+        pk_scan<NB>(pts, eC, Cm, Dm, n_pos, cnt, posbase, g.max_d2, wx, wy, wz, L);
+        n_pos += cnt;
+      }
+      pk_merge<0xB1>(L);
+      pk_merge<0x4E>(L);
+    }
+  }
 
   // Exact re-measurement of the seven winners.  The lane that scanned a winner knows its map index; the index travels to the
   // other three lanes of the group (an OR over the quad: the other lanes contribute 0).  Lane `sub` then loads and measures
   // winners `sub` and `sub + 4`, and the seven exact distances are shared by quad broadcasts.
-  unsigned int widx[7];
   float e[7];
   F3 Wa, Wb;  // this lane's two winners
   float d7t;  // the truncated distance of the 7th key: no dropped candidate is nearer (inf: nothing was dropped)
+  bool tie = false;  // two neighbouring keys agree in their distance bits: the exact order may differ from the key order
   {
     const unsigned int K[7] = {L.k0, L.k1, L.k2, L.k3, L.k4, L.k5, L.k6};
+    unsigned int widx[7];
+    const bool used2w = __any(used2);  // some winner of this wavefront may sit in a round-2 range: their table comes out of LDS
+    uint2 rg[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) rg[j] = make_uint2(0u, 0u);
+    if (used2w) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) rg[j] = s_rng[j * BS + threadIdx.x];
+    }
 #pragma unroll
     for (int w = 0; w < 7; w++) {
-      const unsigned int pos = K[w] & kPkPosMask, p = pos & 255u;
-      const bool mine = K[w] != kPkInf && (pos >> 8) == (unsigned)sub;
-      unsigned int v = mine ? (p < lenA ? A0 : Bm) + p : 0u;
+      const unsigned int pos = K[w] & kPkPosMask, p = pos & kPkLaneMask;
+      const bool mine = K[w] != kPkInf && (pos >> kPkLaneBits) == (unsigned)sub;
+      unsigned int v = p + (p < nA ? A0 : Bm);
+      if (used2w) v = p < nAB ? v : p + (p < rg[0].x ? rg[0].y : (p < rg[1].x ? rg[1].y : (p < rg[2].x ? rg[2].y : (p < rg[3].x ? rg[3].y : (p < rg[4].x ? rg[4].y : rg[5].y)))));
+      v = mine ? v : 0u;
       v |= quad_perm<0xB1>(v);
       v |= quad_perm<0x4E>(v);
       widx[w] = v;  // (an empty slot reads map slot 0 and is discarded)
@@ -808,67 +902,49 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
     const unsigned int ib = sub == 0 ? widx[4] + 0u : (sub == 1 ? widx[5] + 0u : widx[6] + 0u);
     Wa = load_xyz(pts, ia);
     Wb = load_xyz(pts, ib);
+#pragma unroll
+    for (int w = 0; w < 6; w++) tie = tie || ((K[w] ^ K[w + 1]) <= kPkPosMask && K[w + 1] != kPkInf);
+    d7t = K[6] != kPkInf ? __uint_as_float(K[6] & ~kPkPosMask) : INF;
     const float ea = dist2_ref(wx, wy, wz, Wa.x, Wa.y, Wa.z), eb = dist2_ref(wx, wy, wz, Wb.x, Wb.y, Wb.z);
     e[0] = quad_perm_f<0x00>(ea); e[1] = quad_perm_f<0x55>(ea); e[2] = quad_perm_f<0xAA>(ea); e[3] = quad_perm_f<0xFF>(ea);
     e[4] = quad_perm_f<0x00>(eb); e[5] = quad_perm_f<0x55>(eb); e[6] = quad_perm_f<0xAA>(eb);
 #pragma unroll
     for (int w = 0; w < 7; w++) e[w] = K[w] != kPkInf ? e[w] : INF;
-    d7t = K[6] != kPkInf ? __uint_as_float(K[6] & ~kPkPosMask) : INF;
   }
-  // Exact ranks.  The keys are in ascending order, so for v < w the exact order can differ from the key order only where the
-  // truncated distances agree, and there an equal exact distance keeps the key order (position = visiting order):
-  // v stays ahead of w unless e[v] > e[w].  Empty slots (inf) keep their places at the end.
-  int rank[7];
+  // Exact ranks of this lane's two winners (a = sub, b = sub + 4) and the exact 5th distance.  The keys are in ascending order,
+  // so the exact order can differ from the key order only where the distance bits of neighbouring keys agree (a wavefront
+  // without such a pair skips the ranking), and there an equal exact distance keeps the key order (position = visiting order):
+  // for v < w, v stays ahead of w unless e[v] > e[w].  Empty slots (inf) keep their places at the end.
+  int ra = sub, rbk = sub + 4;
+  float d5 = e[4];  // (inf: fewer than five candidates)
+  if (__any(tie)) {
+    int rank[7];
 #pragma unroll
-  for (int w = 0; w < 7; w++) rank[w] = 0;
+    for (int w = 0; w < 7; w++) rank[w] = 0;
 #pragma unroll
-  for (int v = 0; v < 7; v++)
+    for (int v = 0; v < 7; v++)
 #pragma unroll
-    for (int w = v + 1; w < 7; w++) {
-      const bool swapped = e[v] > e[w];
-      rank[w] += swapped ? 0 : 1;
-      rank[v] += swapped ? 1 : 0;
-    }
-  float d5 = INF;  // exact 5th distance among the kept candidates (inf: fewer than five)
-#pragma unroll
-  for (int w = 0; w < 7; w++) d5 = rank[w] == 4 ? e[w] : d5;
-  int found = 0;
-#pragma unroll
-  for (int w = 0; w < 7; w++) found += e[w] < INF ? 1 : 0;
-  found = min(found, 5);
-  // the five nearest are exact unless a dropped candidate could tie with or beat the 5th
-  const bool amb = fast && d7t < INF && !(d5 < d7t);
-  const bool more_fast = fast && !(fminf(d5, g.max_d2) <= g0sq);
-
-  // Queries that need round 2 continue on exact (distance, index) lists: the packed result, on every lane of the group
-  Knn5 k;
-  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = INF;
-  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
-  if (__any(more_fast)) {
-    if (more_fast) {
-#pragma unroll
-      for (int w = 0; w < 7; w++) {
-        const bool valid = e[w] < INF;
-        const int gi = (int)widx[w];
-        if (valid && rank[w] == 0) { k.d0 = e[w]; k.i0 = gi; }
-        if (valid && rank[w] == 1) { k.d1 = e[w]; k.i1 = gi; }
-        if (valid && rank[w] == 2) { k.d2 = e[w]; k.i2 = gi; }
-        if (valid && rank[w] == 3) { k.d3 = e[w]; k.i3 = gi; }
-        if (valid && rank[w] == 4) { k.d4 = e[w]; k.i4 = gi; }
+      for (int w = v + 1; w < 7; w++) {
+        const bool swapped = e[v] > e[w];
+        rank[w] += swapped ? 0 : 1;
+        rank[v] += swapped ? 1 : 0;
       }
-    }
+    d5 = INF;
+#pragma unroll
+    for (int w = 0; w < 7; w++) d5 = rank[w] == 4 ? e[w] : d5;
+    ra = sub == 0 ? rank[0] + 0 : (sub == 1 ? rank[1] + 0 : (sub == 2 ? rank[2] + 0 : rank[3] + 0));
+    rbk = sub == 0 ? rank[4] + 0 : (sub == 1 ? rank[5] + 0 : rank[6] + 0);
   }
-  // The usual case ends here: every lane stores its two winners at their ranks.
-  if (live && !slow && !more_fast) {
-    const bool need = active && (amb || !(fminf(d5, g.max_d2) <= guardsq));
-    {
-      const float ea = sub == 0 ? e[0] + 0.f : (sub == 1 ? e[1] + 0.f : (sub == 2 ? e[2] + 0.f : e[3] + 0.f));
-      const int ra = sub == 0 ? rank[0] + 0 : (sub == 1 ? rank[1] + 0 : (sub == 2 ? rank[2] + 0 : rank[3] + 0));
-      const float eb = sub == 0 ? e[4] + 0.f : (sub == 1 ? e[5] + 0.f : e[6] + 0.f);
-      const int rbk = sub == 0 ? rank[4] + 0 : (sub == 1 ? rank[5] + 0 : rank[6] + 0);
-      if (ea < INF && ra < 5) rb.nbr[(size_t)ra * rb.cap + qi] = make_float4(Wa.x, Wa.y, Wa.z, ea);
-      if (sub < 3 && eb < INF && rbk < 5) rb.nbr[(size_t)rbk * rb.cap + qi] = make_float4(Wb.x, Wb.y, Wb.z, eb);
-    }
+  const float ea = sub == 0 ? e[0] + 0.f : (sub == 1 ? e[1] + 0.f : (sub == 2 ? e[2] + 0.f : e[3] + 0.f));
+  const float eb = sub == 0 ? e[4] + 0.f : (sub == 1 ? e[5] + 0.f : e[6] + 0.f);
+  const int found = e[4] < INF ? 5 : (e[3] < INF ? 4 : (e[2] < INF ? 3 : (e[1] < INF ? 2 : (e[0] < INF ? 1 : 0))));
+  // the five nearest are exact unless a dropped candidate could tie with or beat the 5th; a query whose 3x3x3 block cannot prove
+  // its list complete (or that ran out of positions) is flagged: k_fit_reduce / k_knn_complete finishes it
+  const bool amb = d7t < INF && !(d5 < d7t);
+  const bool need = active && (ovf || amb || !(fminf(d5, g.max_d2) <= guardsq));
+  if (live) {
+    if (ea < INF && ra < 5) rb.nbr[(size_t)ra * rb.cap + qi] = make_float4(Wa.x, Wa.y, Wa.z, ea);
+    if (sub < 3 && eb < INF && rbk < 5) rb.nbr[(size_t)rbk * rb.cap + qi] = make_float4(Wb.x, Wb.y, Wb.z, eb);
     if (found < 5) {  // the missing neighbours read (0, 0, 0, inf)
       if (sub >= found) rb.nbr[(size_t)sub * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
       if (sub == 0) rb.nbr[(size_t)4 * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
@@ -879,25 +955,15 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
       rb.world[qi] = make_float4(wx, wy, wz, 0.f);
     }
   }
-  const bool exact_list = slow || more_fast;
-  if (!__any(exact_list)) return;
-  // The rest: groups that could not number their candidates (their round 1 on exact lists) and round 2.  (The query's place in
-  // the grid is derived again rather than kept in registers across the common path.)
-  const QueryCell q = query_cell(g, wx, wy, wz);
-  if (slow) {
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-      const int c = t == 0 ? sub : 7 - sub;
-      const uint2 r = lookup_cell(g, tab, q.cx + ((c & 1) ? q.ox : 0), q.cy + ((c & 2) ? q.oy : 0), q.cz + ((c & 4) ? q.oz : 0));
-      scan_range(pts, g.max_d2, r.x, r.y, wx, wy, wz, k);
-    }
+  unsigned int wmax = 0;
+  if (wlog) {
+    wmax = fast ? nAB : 0u;
+    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, off));
   }
-  knn_group_merge4<true>(k);  // (the lanes of a packed group hold one and the same list: duplicates are suppressed)
-  const bool more = slow ? !(fminf(k.d4, g.max_d2) <= q.g0 * q.g0) : more_fast;
-  if (__any(more)) knn_round2(g, tab, q, more, wx, wy, wz, sub, leader, k);
-  knn_group_bcast(k, leader);
-  const bool need = active && (amb || !(fminf(k.d4, g.max_d2) <= q.guard * q.guard));
-  if (live && exact_list) knn_store(rb, pts, qi, sub, k, need, wx, wy, wz);
+  if (wlog && (threadIdx.x & 63) == 0) {
+    const int wid = blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
+    wlog[3 * wid] = (unsigned long long)t_start; wlog[3 * wid + 1] = (unsigned long long)wall_clock64(); wlog[3 * wid + 2] = (__any(used2) ? 1ull : 0ull) | ((unsigned long long)wmax << 8);
+  }
 }
 
 // The search pass on exact (distance, index) lists throughout (round 2's form in round 1 too).  Kept as the reference form of
@@ -1739,13 +1805,46 @@ int register_blocks(int n) { return nblk(n, kBlock); }
 static inline int shard_bound(const RegistrationBuffers& rb) {
   return rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;
 }
+// LII_KNN_DIAG & 256 (timing experiments): start / end stamps of every wavefront of the last search launch, summarised at exit
+static unsigned long long* g_wlog = nullptr;
+static int g_wlog_waves = 0;
+static void wlog_dump() {
+  if (!g_wlog || g_wlog_waves <= 0) return;
+  std::vector<unsigned long long> h(size_t(3) * g_wlog_waves);
+  if (hipMemcpy(h.data(), g_wlog, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+  std::vector<double> st, life, life_r, en;
+  unsigned long long t0 = ~0ull;
+  for (int w = 0; w < g_wlog_waves; w++) if (h[3 * w + 1]) t0 = std::min(t0, h[3 * w]);
+  for (int w = 0; w < g_wlog_waves; w++) {
+    if (!h[3 * w + 1]) continue;
+    st.push_back((h[3 * w] - t0) * 0.01); en.push_back((h[3 * w + 1] - t0) * 0.01);
+    ((h[3 * w + 2] & 1) ? life_r : life).push_back((h[3 * w + 1] - h[3 * w]) * 0.01);
+  }
+  auto pct = [](std::vector<double>& v, double p) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[std::min(v.size() - 1, size_t(p * v.size()))]; };
+  std::fprintf(stderr, "[wlog] waves %zu  start us p50 %.2f p90 %.2f p99 %.2f max %.2f | end us p50 %.2f p90 %.2f p99 %.2f max %.2f\n", st.size(), pct(st, .5), pct(st, .9), pct(st, .99), pct(st, 1.0),
+               pct(en, .5), pct(en, .9), pct(en, .99), pct(en, 1.0));
+  std::fprintf(stderr, "[wlog] lifetime us, common path (%zu waves): p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f\n", life.size(), pct(life, .1), pct(life, .5), pct(life, .9), pct(life, .99), pct(life, 1.0));
+  for (int lo = 0; lo < 48; lo += 6) {
+    std::vector<double> b;
+    for (int w = 0; w < g_wlog_waves; w++) if (h[3 * w + 1] && !(h[3 * w + 2] & 1) && int(h[3 * w + 2] >> 8) > lo && int(h[3 * w + 2] >> 8) <= lo + 6) b.push_back((h[3 * w + 1] - h[3 * w]) * 0.01);
+    if (!b.empty()) std::fprintf(stderr, "[wlog]   wave max n in (%d, %d]: %zu waves, lifetime p50 %.2f p90 %.2f max %.2f\n", lo, lo + 6, b.size(), pct(b, .5), pct(b, .9), pct(b, 1.0));
+  }
+  std::fprintf(stderr, "[wlog] lifetime us, rare path (%zu waves): p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f\n", life_r.size(), pct(life_r, .1), pct(life_r, .5), pct(life_r, .9), pct(life_r, .99), pct(life_r, 1.0));
+}
 template <int BS, int NB, int WPE>
 static void launch_knn_pk_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                             const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
   int nq = nblk(shard_bound(rb), BS / 4);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_knn_pk<BS, NB, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
+  static const int diag = std::getenv("LII_KNN_DIAG") ? std::atoi(std::getenv("LII_KNN_DIAG")) : 0;  // timing experiments only
+  unsigned long long* wlog = nullptr;
+  if (diag & 256) {
+    if (!g_wlog) { (void)hipMalloc(&g_wlog, sizeof(unsigned long long) * 3 * 65536); (void)hipMemset(g_wlog, 0, sizeof(unsigned long long) * 3 * 65536); std::atexit(wlog_dump); }
+    g_wlog_waves = nq_pad * (BS / 64);
+    wlog = g_wlog;
+  }
+  hipLaunchKernelGGL((k_knn_pk<BS, NB, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out, diag, wlog);
 }
 // variant 0: packed keys (k_knn_pk, the product path); 5: exact lists throughout (k_knn_exact, its reference form);
 // other values: diagnostic geometries of k_knn_pk
@@ -1760,12 +1859,12 @@ void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, c
       break;
     }
     case 21: launch_knn_pk_t<128, 6, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 22: launch_knn_pk_t<128, 4, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 22: launch_knn_pk_t<128, 4, 8>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
     case 23: launch_knn_pk_t<256, 8, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
     case 24: launch_knn_pk_t<64, 8, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 25: launch_knn_pk_t<128, 8, 8>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 26: launch_knn_pk_t<128, 4, 8>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 27: launch_knn_pk_t<128, 8, 1>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 25: launch_knn_pk_t<128, 6, 7>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 26: launch_knn_pk_t<128, 10, 5>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 27: launch_knn_pk_t<128, 12, 5>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
     default: launch_knn_pk_t<128, 8, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
   }
 }
