@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <algorithm>
 #include <cstdio>
+#include <utility>
 #include <vector>
 
 #include "lii_device.h"
@@ -642,10 +643,8 @@ __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const f
 // least that far - in which case the query is flagged for the completion pass (5th, 6th and 7th distances equal to 11 bits:
 // ~1e-5 of the queries).
 constexpr unsigned int kPkInf = 0xFFFFFFFFu;
-constexpr int kPkPosBits = 12, kPkLaneBits = 10;
+constexpr int kPkPosBits = 12;
 constexpr unsigned int kPkPosMask = (1u << kPkPosBits) - 1u;
-constexpr unsigned int kPkLaneMask = (1u << kPkLaneBits) - 1u;
-constexpr unsigned int kPkLaneCap = 1u << kPkLaneBits;  // candidates a lane can number
 
 struct Pk7 {
   unsigned int k0, k1, k2, k3, k4, k5, k6;
@@ -708,8 +707,8 @@ __device__ __forceinline__ F3 load_xyz(const float4* __restrict__ pts, unsigned 
 // branch would be waited for on its own), keys into L.
 template <int NB>
 __device__ __forceinline__ void pk_scan(const float4* __restrict__ pts, unsigned int split, unsigned int off_lo, unsigned int off_hi,
-                                        unsigned int first, unsigned int count, unsigned int posbase, float max_d2, float wx, float wy,
-                                        float wz, Pk7& L) {
+                                        unsigned int first, unsigned int count, unsigned int posbase, float wx, float wy, float wz,
+                                        Pk7& L) {
   const unsigned int end = first + count;
   for (unsigned int base = first; base < end; base += NB) {
     F3 P[NB];
@@ -723,22 +722,77 @@ __device__ __forceinline__ void pk_scan(const float4* __restrict__ pts, unsigned
       const unsigned int p = base + u;
       const float d = dist2_ref(wx, wy, wz, P[u].x, P[u].y, P[u].z);
       const unsigned int key = (__float_as_uint(d) & ~kPkPosMask) | (posbase + p);
-      pk_insert(L, (p < end && d <= max_d2) ? key : kPkInf);
+      pk_insert(L, p < end ? key : kPkInf);  // (the acceptance test d2 <= max_d2 waits for the re-measurement of the winners)
     }
   }
+}
+
+// Geometry of the search kernel for LPQ lanes per query (4, 2 or 1): how the 12 position bits of a key split into lane and
+// place, how many cells / winners / round-2 passes a lane takes.
+template <int LPQ>
+struct PkGeom {
+  static constexpr int kLaneShift = LPQ == 4 ? 2 : (LPQ == 2 ? 1 : 0);
+  static constexpr int kPlaceBits = kPkPosBits - kLaneShift;
+  static constexpr unsigned int kPlaceMask = (1u << kPlaceBits) - 1u;
+  static constexpr unsigned int kLaneCap = 1u << kPlaceBits;    // candidates a lane can number
+  static constexpr int NP = 4 / LPQ;                            // pairs of cells (c, 7 - c) per lane in round 1
+  static constexpr int NR = 2 * NP;                             // ... = cell ranges per lane
+  static constexpr int NW = (7 + LPQ - 1) / LPQ;                // winners a lane re-measures
+  static constexpr int MAXPASS = (19 + 2 * LPQ - 1) / (2 * LPQ);  // round 2: two outer cells per lane and pass
+};
+template <int LPQ>
+__device__ __forceinline__ unsigned int group_or(unsigned int v) {
+  if (LPQ >= 2) v |= quad_perm<0xB1>(v);
+  if (LPQ == 4) v |= quad_perm<0x4E>(v);
+  return v;
+}
+template <int LPQ>
+__device__ __forceinline__ void pk_group_merge(Pk7& L) {
+  if (LPQ >= 2) pk_merge<0xB1>(L);  // lanes 0<->1, 2<->3
+  if (LPQ == 4) pk_merge<0x4E>(L);  // lanes 0<->2, 1<->3: every lane of the group now holds the group's seven smallest keys
+}
+// the value lane J of the group holds
+template <int LPQ, int J>
+__device__ __forceinline__ float group_bcast_f(float v) {
+  if (LPQ == 4) return quad_perm_f<J * 0x55>(v);
+  if (LPQ == 2) return quad_perm_f<J == 0 ? 0xA0 : 0xF5>(v);
+  return v;
+}
+// Loops whose index must be a constant expression (register arrays must never be indexed dynamically: they would move to
+// scratch memory): f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>).
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+template <class T>
+__device__ __forceinline__ T by_value(T x) { return x; }
+// arr[BASE + sub] for sub < LPQ as a chain of selects over constant indices (entries behind the array: the last one)
+template <int LPQ, int BASE, int N, class T>
+__device__ __forceinline__ T pick_by_lane(const T (&arr)[N], int sub) {
+  T v = by_value(arr[BASE < N ? BASE : N - 1]);
+  static_for<LPQ - 1>([&](auto jc) {
+    constexpr int j = decltype(jc)::value + 1;
+    v = sub == j ? by_value(arr[BASE + j < N ? BASE + j : N - 1]) : v;
+  });
+  return v;
 }
 
 // `forced` 1: host-driven pass at the pose `ps_val` (always runs).  forced 2: always runs, pose read from `pose` (device).
 // forced < 0: device-driven loop — pose from `pose` (the control block), runs only when the control block says the next pass
 // searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).  An executed pass leaves its pose in
 // `search_pose_out` (may be null).
-// NB = candidate loads a lane keeps in flight (one batch).  diag / wlog: timing experiments (LII_KNN_DIAG).
-template <int BS, int NB, int WPE>
+// LPQ = lanes per query; NB = candidate loads a lane keeps in flight (one batch).  diag / wlog: timing experiments (LII_KNN_DIAG).
+template <int LPQ, int BS, int NB, int WPE>
 __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuffers rb, PoseArg ps_val, const PoseArg* __restrict__ pose,
                                                const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
                                                double* __restrict__ search_pose_out, int diag,
                                                unsigned long long* __restrict__ wlog) {
-  __shared__ uint2 s_rng[6 * BS];
+  using G = PkGeom<LPQ>;
+  __shared__ uint2 s_rng[2 * G::MAXPASS * BS];
   const long long t_start = wlog ? wall_clock64() : 0;
   // the pose sits in the control block: its load goes out together with the flags instead of after the branch on them
   const PoseArg ps = forced != 1 ? *pose : ps_val;
@@ -748,62 +802,70 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
   if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;
-  constexpr int QPB = BS / 4;
-  const int sub = threadIdx.x & 3;
-  const int ql = blk * QPB + (threadIdx.x >> 2);
+  constexpr int QPB = BS / LPQ;
+  const int sub = threadIdx.x & (LPQ - 1);
+  const int ql = blk * QPB + (int)(threadIdx.x / LPQ);
   // the grid is sized for an upper bound of the cloud (the voxel filter leaves the exact size on the device): wavefronts
   // beyond the cloud leave at once
-  if (blk * QPB + (int)((threadIdx.x & ~63u) >> 2) >= n_live) return;
+  if (blk * QPB + (int)((threadIdx.x & ~63u) / LPQ) >= n_live) return;
   const int qi = lo + ql;
   const bool live = ql < n_live;
   float wx = 0, wy = 0, wz = 0;
   if (live && sub == 0) body_to_world(ps, rb.body[qi], wx, wy, wz);
-  wx = quad_perm_f<0x00>(wx); wy = quad_perm_f<0x00>(wy); wz = quad_perm_f<0x00>(wz);
+  wx = group_bcast_f<LPQ, 0>(wx); wy = group_bcast_f<LPQ, 0>(wy); wz = group_bcast_f<LPQ, 0>(wz);
   const bool active = live && g.n_pts > 0;
   const float INF = __builtin_inff();
   const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
   const float4* __restrict__ pts = g.pts;
-  const unsigned int posbase = (unsigned)sub << kPkLaneBits;
-  // Round 1.  The lane's two cells: opposite corners of the 2x2x2 block (c and 7 - c differ on every axis, so a surface that runs
-  // along the axes puts one occupied cell on every lane).  Idle lanes look their cells up as well (a lookup behind a branch is
-  // waited for on its own).  Map index of position p < nAB of the lane's candidate list: p + (p < nA ? A0 : Bm).
+  const unsigned int posbase = (unsigned)sub << G::kPlaceBits;
+
+  // Round 1.  The lane's cells: pairs of opposite corners of the 2x2x2 block (c and 7 - c differ on every axis, so a surface that
+  // runs along the axes puts one occupied cell into every pair).  Idle lanes look their cells up as well (a lookup behind a
+  // branch is waited for on its own).  The lane numbers its candidates range by range: range k holds positions
+  // [end[k - 1], end[k]), map index = position + off[k].
   float g0sq, guardsq;
-  unsigned int A0, Bm, nA, nAB;
+  unsigned int end[G::NR], off[G::NR];
   {
     const QueryCell q = query_cell(g, wx, wy, wz);
     g0sq = q.g0 * q.g0;
     guardsq = q.guard * q.guard;
-    uint2 r[2];
-    int jx[2], jy[2], jz[2];
-    const bool want[2] = {true, true};
+    uint2 r[G::NR];
+    int jx[G::NR], jy[G::NR], jz[G::NR];
+    bool want[G::NR];
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-      const int c = t == 0 ? sub : 7 - sub;
+    for (int t = 0; t < G::NR; t++) {
+      const int c0 = sub + LPQ * (t >> 1), c = (t & 1) ? 7 - c0 : c0;
       jx[t] = q.cx + ((c & 1) ? q.ox : 0); jy[t] = q.cy + ((c & 2) ? q.oy : 0); jz[t] = q.cz + ((c & 4) ? q.oz : 0);
+      want[t] = true;
     }
-    lookup_cells_batched<2>(g, tab, jx, jy, jz, want, r);
-    nA = r[0].y - r[0].x;
-    nAB = nA + (r[1].y - r[1].x);
-    A0 = r[0].x;
-    Bm = r[1].x - nA;
+    lookup_cells_batched<G::NR>(g, tab, jx, jy, jz, want, r);
+    unsigned int run = 0u;
+#pragma unroll
+    for (int t = 0; t < G::NR; t++) {
+      off[t] = r[t].x - run;
+      run += r[t].y - r[t].x;
+      end[t] = run;
+    }
   }
-  // a group with a lane that cannot number its candidates is left to the completion pass (cells of more than 500 points)
-  bool ovf = nAB > kPkLaneCap;
-  ovf = ovf || quad_perm<0xB1>((unsigned)ovf) != 0u;
-  ovf = ovf || quad_perm<0x4E>((unsigned)ovf) != 0u;
+  const unsigned int n1 = end[G::NR - 1];
+  // a group with a lane that cannot number its candidates is left to the completion pass (cells of hundreds of points)
+  bool ovf = group_or<LPQ>((unsigned)(n1 > G::kLaneCap)) != 0u;
   const bool fast = active && !ovf;
 
   Pk7 L;
   L.k0 = L.k1 = L.k2 = L.k3 = L.k4 = L.k5 = L.k6 = kPkInf;
-  pk_scan<NB>(pts, nA, A0, Bm, 0u, fast ? nAB : 0u, posbase, g.max_d2, wx, wy, wz, L);
-  pk_merge<0xB1>(L);  // lanes 0<->1, 2<->3
-  pk_merge<0x4E>(L);  // lanes 0<->2, 1<->3: every lane of the group now holds the group's seven smallest keys
+#pragma unroll
+  for (int i = 0; i < G::NP; i++) {
+    const unsigned int first = i ? end[2 * i - 1] : 0u;
+    pk_scan<NB>(pts, end[2 * i], off[2 * i], off[2 * i + 1], first, fast ? end[2 * i + 1] - first : 0u, posbase, wx, wy, wz, L);
+  }
+  pk_group_merge<LPQ>(L);
 
   // Round 2 (the tree's calc_box_dist rule, ikd_Tree.cpp:1279-1289): is the 5th distance - here its upper bound, the 5th key
   // with the position bits set - within the radius round 1 covers?  If not, the outer cells of the 3x3x3 block that can hold a
-  // closer point are dealt out to the four lanes, two per lane and pass (one pass for all but ~0.2 % of the queries; three at
-  // most); their candidates continue the lane's position count, and the ranges they come from are noted in LDS for the
-  // re-measurement below: s_rng[j][lane] = (end position, map index - position) of the lane's j-th range of round 2.
+  // closer point are dealt out to the lanes of the group, two per lane and pass (with four lanes: one pass for all but ~0.2 %
+  // of the queries); their candidates continue the lane's position count, and the ranges they come from are noted in LDS for
+  // the re-measurement below: s_rng[j][lane] = (end position, map index - position) of the lane's j-th range of round 2.
   bool used2 = false;
   {
     const float ub5 = L.k4 != kPkInf ? __uint_as_float(L.k4 | kPkPosMask) : INF;
@@ -830,18 +892,20 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
       m = need2 ? m : 0u;
       used2 = m != 0u;
 #pragma unroll
-      for (int j = 0; j < 6; j++) s_rng[j * BS + threadIdx.x] = make_uint2(0u, 0u);
-      // the group's list continues on lane 0 alone (four copies would come back as duplicates), the other lanes start empty
+      for (int j = 0; j < 2 * G::MAXPASS; j++) s_rng[j * BS + threadIdx.x] = make_uint2(0u, 0u);
+      // the group's list continues on lane 0 alone (copies would come back as duplicates), the other lanes start empty
       if (sub != 0) L.k0 = L.k1 = L.k2 = L.k3 = L.k4 = L.k5 = L.k6 = kPkInf;
-      unsigned int t = m, n_pos = nAB;
+      unsigned int t = m, n_pos = n1;
 #pragma unroll
-      for (int j = 0; j < 3; j++) t = j < sub ? (t & (t - 1u)) : t;  // the lane's first survivor: number `sub` of the set bits
-      for (int pass = 0; pass < 3; pass++) {
+      for (int j = 0; j < LPQ - 1; j++) t = j < sub ? (t & (t - 1u)) : t;  // the lane's first survivor: number `sub` of the set bits
+      for (int pass = 0; pass < G::MAXPASS; pass++) {
         if (!__any(t != 0u)) break;
         const int c1 = t ? __ffs((int)t) - 1 : -1;
-        t = t & (t - 1u); t = t & (t - 1u); t = t & (t - 1u); t = t & (t - 1u);
+#pragma unroll
+        for (int j = 0; j < LPQ; j++) t = t & (t - 1u);
         const int c2 = t ? __ffs((int)t) - 1 : -1;
-        t = t & (t - 1u); t = t & (t - 1u); t = t & (t - 1u); t = t & (t - 1u);
+#pragma unroll
+        for (int j = 0; j < LPQ; j++) t = t & (t - 1u);
         uint2 r[2];
         {
           int jx[2], jy[2], jz[2];
@@ -854,68 +918,86 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
         const unsigned int nC = c1 < 0 ? 0u : r[0].y - r[0].x, nD = c2 < 0 ? 0u : r[1].y - r[1].x;
         const unsigned int eC = n_pos + nC, eD = eC + nD;
         const unsigned int Cm = r[0].x - n_pos, Dm = r[1].x - eC;
-        bool o2 = eD > kPkLaneCap;  // out of positions: the group stops here and is left to the completion pass
-        o2 = o2 || quad_perm<0xB1>((unsigned)o2) != 0u;
-        o2 = o2 || quad_perm<0x4E>((unsigned)o2) != 0u;
+        // out of positions: the group stops here and is left to the completion pass
+        const bool o2 = group_or<LPQ>((unsigned)(eD > G::kLaneCap)) != 0u;
         if (o2) { ovf = true; t = 0u; }
         const unsigned int cnt = o2 ? 0u : eD - n_pos;
         s_rng[(2 * pass) * BS + threadIdx.x] = make_uint2(n_pos + (o2 ? 0u : nC), Cm);
         s_rng[(2 * pass + 1) * BS + threadIdx.x] = make_uint2(n_pos + cnt, Dm);
-        pk_scan<NB>(pts, eC, Cm, Dm, n_pos, cnt, posbase, g.max_d2, wx, wy, wz, L);
+        pk_scan<NB>(pts, eC, Cm, Dm, n_pos, cnt, posbase, wx, wy, wz, L);
         n_pos += cnt;
       }
-      pk_merge<0xB1>(L);
-      pk_merge<0x4E>(L);
+      pk_group_merge<LPQ>(L);
     }
   }
 
   // Exact re-measurement of the seven winners.  The lane that scanned a winner knows its map index; the index travels to the
-  // other three lanes of the group (an OR over the quad: the other lanes contribute 0).  Lane `sub` then loads and measures
-  // winners `sub` and `sub + 4`, and the seven exact distances are shared by quad broadcasts.
+  // other lanes of the group (an OR over the group: the other lanes contribute 0).  Lane `sub` then loads and measures winners
+  // sub, sub + LPQ, ..., and the seven exact distances are shared by broadcasts inside the group.
   float e[7];
-  F3 Wa, Wb;  // this lane's two winners
-  float d7t;  // the truncated distance of the 7th key: no dropped candidate is nearer (inf: nothing was dropped)
+  F3 W[G::NW];  // this lane's winners
+  float d7t;    // the truncated distance of the 7th key: no dropped candidate is nearer (inf: nothing was dropped)
   bool tie = false;  // two neighbouring keys agree in their distance bits: the exact order may differ from the key order
   {
     const unsigned int K[7] = {L.k0, L.k1, L.k2, L.k3, L.k4, L.k5, L.k6};
     unsigned int widx[7];
     const bool used2w = __any(used2);  // some winner of this wavefront may sit in a round-2 range: their table comes out of LDS
-    uint2 rg[6];
+    uint2 rg[2 * G::MAXPASS];
 #pragma unroll
-    for (int j = 0; j < 6; j++) rg[j] = make_uint2(0u, 0u);
+    for (int j = 0; j < 2 * G::MAXPASS; j++) rg[j] = make_uint2(0u, 0u);
     if (used2w) {
 #pragma unroll
-      for (int j = 0; j < 6; j++) rg[j] = s_rng[j * BS + threadIdx.x];
+      for (int j = 0; j < 2 * G::MAXPASS; j++) rg[j] = s_rng[j * BS + threadIdx.x];
+    }
+    unsigned int woff[7];  // map index - position of every winner, as the lane that scanned it sees it
+#pragma unroll
+    for (int w = 0; w < 7; w++) {
+      const unsigned int p = K[w] & G::kPlaceMask;
+      unsigned int o = off[G::NR - 1];
+#pragma unroll
+      for (int k = G::NR - 2; k >= 0; k--) o = p < end[k] ? off[k] : o;
+      woff[w] = o;
+    }
+    if (used2w) {
+#pragma unroll
+      for (int w = 0; w < 7; w++) {
+        const unsigned int p = K[w] & G::kPlaceMask;
+        unsigned int o2 = rg[2 * G::MAXPASS - 1].y;
+#pragma unroll
+        for (int j = 2 * G::MAXPASS - 2; j >= 0; j--) o2 = p < rg[j].x ? rg[j].y : o2;
+        woff[w] = p < n1 ? woff[w] : o2;
+      }
     }
 #pragma unroll
     for (int w = 0; w < 7; w++) {
-      const unsigned int pos = K[w] & kPkPosMask, p = pos & kPkLaneMask;
-      const bool mine = K[w] != kPkInf && (pos >> kPkLaneBits) == (unsigned)sub;
-      unsigned int v = p + (p < nA ? A0 : Bm);
-      if (used2w) v = p < nAB ? v : p + (p < rg[0].x ? rg[0].y : (p < rg[1].x ? rg[1].y : (p < rg[2].x ? rg[2].y : (p < rg[3].x ? rg[3].y : (p < rg[4].x ? rg[4].y : rg[5].y)))));
-      v = mine ? v : 0u;
-      v |= quad_perm<0xB1>(v);
-      v |= quad_perm<0x4E>(v);
-      widx[w] = v;  // (an empty slot reads map slot 0 and is discarded)
+      const unsigned int pos = K[w] & kPkPosMask;
+      const bool mine = K[w] != kPkInf && (LPQ == 1 || (pos >> G::kPlaceBits) == (unsigned)sub);
+      widx[w] = group_or<LPQ>(mine ? (pos & G::kPlaceMask) + woff[w] : 0u);  // (an empty slot reads map slot 0 and is discarded)
     }
-    const unsigned int ia = sub == 0 ? widx[0] + 0u : (sub == 1 ? widx[1] + 0u : (sub == 2 ? widx[2] + 0u : widx[3] + 0u));
-    const unsigned int ib = sub == 0 ? widx[4] + 0u : (sub == 1 ? widx[5] + 0u : widx[6] + 0u);
-    Wa = load_xyz(pts, ia);
-    Wb = load_xyz(pts, ib);
+    float el[G::NW];
+    static_for<G::NW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      W[i] = load_xyz(pts, pick_by_lane<LPQ, LPQ * i>(widx, sub));
+    });
 #pragma unroll
     for (int w = 0; w < 6; w++) tie = tie || ((K[w] ^ K[w + 1]) <= kPkPosMask && K[w + 1] != kPkInf);
     d7t = K[6] != kPkInf ? __uint_as_float(K[6] & ~kPkPosMask) : INF;
-    const float ea = dist2_ref(wx, wy, wz, Wa.x, Wa.y, Wa.z), eb = dist2_ref(wx, wy, wz, Wb.x, Wb.y, Wb.z);
-    e[0] = quad_perm_f<0x00>(ea); e[1] = quad_perm_f<0x55>(ea); e[2] = quad_perm_f<0xAA>(ea); e[3] = quad_perm_f<0xFF>(ea);
-    e[4] = quad_perm_f<0x00>(eb); e[5] = quad_perm_f<0x55>(eb); e[6] = quad_perm_f<0xAA>(eb);
 #pragma unroll
-    for (int w = 0; w < 7; w++) e[w] = K[w] != kPkInf ? e[w] : INF;
+    for (int i = 0; i < G::NW; i++) el[i] = dist2_ref(wx, wy, wz, W[i].x, W[i].y, W[i].z);
+    e[0] = group_bcast_f<LPQ, 0 % LPQ>(el[0 / LPQ]); e[1] = group_bcast_f<LPQ, 1 % LPQ>(el[1 / LPQ]);
+    e[2] = group_bcast_f<LPQ, 2 % LPQ>(el[2 / LPQ]); e[3] = group_bcast_f<LPQ, 3 % LPQ>(el[3 / LPQ]);
+    e[4] = group_bcast_f<LPQ, 4 % LPQ>(el[4 / LPQ]); e[5] = group_bcast_f<LPQ, 5 % LPQ>(el[5 / LPQ]);
+    e[6] = group_bcast_f<LPQ, 6 % LPQ>(el[6 / LPQ]);
+#pragma unroll
+    for (int w = 0; w < 7; w++) e[w] = (K[w] != kPkInf && e[w] <= g.max_d2) ? e[w] : INF;  // acceptance: d2 <= max_d2 (quirk A5)
   }
-  // Exact ranks of this lane's two winners (a = sub, b = sub + 4) and the exact 5th distance.  The keys are in ascending order,
-  // so the exact order can differ from the key order only where the distance bits of neighbouring keys agree (a wavefront
-  // without such a pair skips the ranking), and there an equal exact distance keeps the key order (position = visiting order):
-  // for v < w, v stays ahead of w unless e[v] > e[w].  Empty slots (inf) keep their places at the end.
-  int ra = sub, rbk = sub + 4;
+  // Exact ranks of this lane's winners and the exact 5th distance.  The keys are in ascending order, so the exact order can
+  // differ from the key order only where the distance bits of neighbouring keys agree (a wavefront without such a pair skips
+  // the ranking), and there an equal exact distance keeps the key order (position = visiting order): for v < w, v stays ahead
+  // of w unless e[v] > e[w].  Empty slots (inf) keep their places at the end.
+  int rk[G::NW];
+#pragma unroll
+  for (int i = 0; i < G::NW; i++) rk[i] = sub + LPQ * i;
   float d5 = e[4];  // (inf: fewer than five candidates)
   if (__any(tie)) {
     int rank[7];
@@ -932,33 +1014,34 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
     d5 = INF;
 #pragma unroll
     for (int w = 0; w < 7; w++) d5 = rank[w] == 4 ? e[w] : d5;
-    ra = sub == 0 ? rank[0] + 0 : (sub == 1 ? rank[1] + 0 : (sub == 2 ? rank[2] + 0 : rank[3] + 0));
-    rbk = sub == 0 ? rank[4] + 0 : (sub == 1 ? rank[5] + 0 : rank[6] + 0);
+    static_for<G::NW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      rk[i] = pick_by_lane<LPQ, LPQ * i>(rank, sub);
+    });
   }
-  const float ea = sub == 0 ? e[0] + 0.f : (sub == 1 ? e[1] + 0.f : (sub == 2 ? e[2] + 0.f : e[3] + 0.f));
-  const float eb = sub == 0 ? e[4] + 0.f : (sub == 1 ? e[5] + 0.f : e[6] + 0.f);
   const int found = e[4] < INF ? 5 : (e[3] < INF ? 4 : (e[2] < INF ? 3 : (e[1] < INF ? 2 : (e[0] < INF ? 1 : 0))));
   // the five nearest are exact unless a dropped candidate could tie with or beat the 5th; a query whose 3x3x3 block cannot prove
   // its list complete (or that ran out of positions) is flagged: k_fit_reduce / k_knn_complete finishes it
   const bool amb = d7t < INF && !(d5 < d7t);
   const bool need = active && (ovf || amb || !(fminf(d5, g.max_d2) <= guardsq));
   if (live) {
-    if (ea < INF && ra < 5) rb.nbr[(size_t)ra * rb.cap + qi] = make_float4(Wa.x, Wa.y, Wa.z, ea);
-    if (sub < 3 && eb < INF && rbk < 5) rb.nbr[(size_t)rbk * rb.cap + qi] = make_float4(Wb.x, Wb.y, Wb.z, eb);
+    static_for<G::NW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const float ei = pick_by_lane<LPQ, LPQ * i>(e, sub);
+      if (sub + LPQ * i < 7 && ei < INF && rk[i] < 5) rb.nbr[(size_t)rk[i] * rb.cap + qi] = make_float4(W[i].x, W[i].y, W[i].z, ei);
+    });
     if (found < 5) {  // the missing neighbours read (0, 0, 0, inf)
-      if (sub >= found) rb.nbr[(size_t)sub * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
-      if (sub == 0) rb.nbr[(size_t)4 * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
+#pragma unroll
+      for (int r = 0; r < 5; r += LPQ)
+        if (sub + r < 5 && sub + r >= found) rb.nbr[(size_t)(sub + r) * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
     }
-    if (sub == 1) {
-      rb.nbr_count[qi] = found | (need ? kNeedy : 0);
-    } else if (sub == 2) {
-      rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-    }
+    if (sub == (LPQ > 1 ? 1 : 0)) rb.nbr_count[qi] = found | (need ? kNeedy : 0);
+    if (sub == (LPQ == 4 ? 2 : 0)) rb.world[qi] = make_float4(wx, wy, wz, 0.f);
   }
   unsigned int wmax = 0;
   if (wlog) {
-    wmax = fast ? nAB : 0u;
-    for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, off));
+    wmax = fast ? n1 : 0u;
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, o));
   }
   if (wlog && (threadIdx.x & 63) == 0) {
     const int wid = blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
@@ -1831,10 +1914,10 @@ static void wlog_dump() {
   }
   std::fprintf(stderr, "[wlog] lifetime us, rare path (%zu waves): p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f\n", life_r.size(), pct(life_r, .1), pct(life_r, .5), pct(life_r, .9), pct(life_r, .99), pct(life_r, 1.0));
 }
-template <int BS, int NB, int WPE>
+template <int LPQ, int BS, int NB, int WPE>
 static void launch_knn_pk_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                             const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
-  int nq = nblk(shard_bound(rb), BS / 4);
+  int nq = nblk(shard_bound(rb), BS / LPQ);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
   static const int diag = std::getenv("LII_KNN_DIAG") ? std::atoi(std::getenv("LII_KNN_DIAG")) : 0;  // timing experiments only
@@ -1844,7 +1927,7 @@ static void launch_knn_pk_t(const GridView& g, const RegistrationBuffers& rb, co
     g_wlog_waves = nq_pad * (BS / 64);
     wlog = g_wlog;
   }
-  hipLaunchKernelGGL((k_knn_pk<BS, NB, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out, diag, wlog);
+  hipLaunchKernelGGL((k_knn_pk<LPQ, BS, NB, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out, diag, wlog);
 }
 // variant 0: packed keys (k_knn_pk, the product path); 5: exact lists throughout (k_knn_exact, its reference form);
 // other values: diagnostic geometries of k_knn_pk
@@ -1858,14 +1941,16 @@ void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, c
       hipLaunchKernelGGL((k_knn_exact<128>), dim3(nq_pad), dim3(128), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
       break;
     }
-    case 21: launch_knn_pk_t<128, 6, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 22: launch_knn_pk_t<128, 4, 8>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 23: launch_knn_pk_t<256, 8, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 24: launch_knn_pk_t<64, 8, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 25: launch_knn_pk_t<128, 6, 7>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 26: launch_knn_pk_t<128, 10, 5>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 27: launch_knn_pk_t<128, 12, 5>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    default: launch_knn_pk_t<128, 8, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 21: launch_knn_pk_t<4, 128, 8, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 22: launch_knn_pk_t<4, 128, 4, 8>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 40: launch_knn_pk_t<2, 128, 8, 4>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 41: launch_knn_pk_t<2, 128, 12, 3>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 42: launch_knn_pk_t<2, 64, 8, 4>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 43: launch_knn_pk_t<2, 128, 6, 5>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 50: launch_knn_pk_t<1, 64, 12, 2>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 51: launch_knn_pk_t<1, 64, 8, 2>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    case 52: launch_knn_pk_t<1, 64, 16, 2>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+    default: launch_knn_pk_t<4, 128, 6, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
   }
 }
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {
