@@ -120,6 +120,9 @@ struct lii_context {
   unsigned int* d_vhist = nullptr;
   unsigned short* d_vbucket = nullptr;
   unsigned int *d_vpcl_in = nullptr, *d_vpcl_out = nullptr;  // PCL voxel index per input point / per output voxel
+  VoxelHashBuffers vh = {};      // the voxel grid by hashing (the default; LII_VOXEL_FILTER=sort: the sample sort)
+  unsigned char* d_vh_first = nullptr;
+  bool voxel_sort = false;
   bool coherent_order = false;   // LII_VOXEL_ORDER=brick: the voxel filter emits brick-major (Morton) order instead of the PCL
                                  // index order (what the LDS-tiled search needs; the default search gains 10 % from it, the
                                  // completion of the flagged searches inside the fit kernel loses more: they cluster)
@@ -770,6 +773,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   if (const char* v = std::getenv("LII_KNN_VARIANT")) h->knn_variant = std::atoi(v);  // A/B knob for profiling
   if (const char* v = std::getenv("LII_DIAG")) h->diag = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_VOXEL_ORDER")) h->coherent_order = std::string(v) == "brick";
+  if (const char* v = std::getenv("LII_VOXEL_FILTER")) h->voxel_sort = std::string(v) == "sort";
   if (const char* v = std::getenv("LII_HOST_SOLVE")) h->host_solve = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_SYNC_RESULT")) h->poll_result = std::atoi(v) == 0;
   if (const char* v = std::getenv("LII_MAP_TEST_TIGHT")) h->map_tight = std::atoi(v) != 0;
@@ -888,6 +892,16 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_vbucket, N));
   CK(dmalloc(&h->d_vpcl_in, N));
   CK(dmalloc(&h->d_vpcl_out, N));
+  {
+    const size_t slots = voxel_hash_slots((int)N);
+    CK(dmalloc(&h->vh.key, slots)); CK(dmalloc(&h->vh.first, slots)); CK(dmalloc(&h->vh.count, slots)); CK(dmalloc(&h->vh.head, slots));
+    CK(dmalloc(&h->vh.members, slots * 7));
+    CK(dmalloc(&h->vh.slot_of, N)); CK(dmalloc(&h->vh.next, N)); CK(dmalloc(&h->vh.block_firsts, N / 256 + 8));
+    CK(dmalloc(&h->d_vh_first, N));
+    h->vh.is_first = h->d_vh_first;
+    CK(hipMemset(h->vh.key, 0xFF, 4 * slots)); CK(hipMemset(h->vh.first, 0xFF, 4 * slots)); CK(hipMemset(h->vh.head, 0xFF, 4 * slots));
+    CK(hipMemset(h->vh.count, 0, 4 * slots));
+  }
   CK(dmalloc(&h->d_cal_params, 64));
   CK(dmalloc(&h->d_cal_out, 128));
   h->h_stage_elems = NM * kMatch;  // large enough for the neighbour download too
@@ -919,7 +933,7 @@ int lii_destroy(lii_handle h) {
   void* dev[] = {h->d_dropped, h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
-                 h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
+                 h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->vh.key, h->vh.first, h->vh.count, h->vh.head, h->vh.members, h->vh.slot_of, h->vh.next, h->vh.block_firsts, h->d_vh_first, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -1234,7 +1248,9 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
     h->mm_sel ^= 1;
     launch_voxel_minmax(h->d_scan, n, mm, h->d_mm + 8 * h->mm_sel, s);
   }
-  {
+  if (!h->voxel_sort) {
+    launch_voxel_hash(h->vh, h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_body, h->d_nbody, h->d_nbody + 1, h->d_vpcl_out, s);
+  } else {
     const VoxelSortPlan plan = voxel_sort_plan(n);
     launch_voxel_keys(h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_vkeys_a, h->d_vpcl_in, h->coherent_order ? 1 : 0,
                       h->d_nbody + 1, plan.samples ? h->d_vsplit + 2048 : nullptr, plan.width, s);
@@ -1248,7 +1264,7 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
   HIPCHK(h, hipGetLastError());
   h->n_body = n;  // upper bound until resolved
   h->n_body_pending = true;
-  h->body_reordered = h->coherent_order;
+  h->body_reordered = h->coherent_order || !h->voxel_sort;  // (the hashed filter emits the voxels in the order of their first points)
   h->pcl_perm_valid = false;
   if (n_down || filtered) {
     int rc = resolve_n_body(h);

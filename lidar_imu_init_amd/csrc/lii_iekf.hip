@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __
   int lo, n_live;
   shard_range(rb, lo, n_live);  // (the device-resident cloud size is loaded together with the flag below, not after the branch on it)
   if (c->stop) return;  // read by every workgroup before its ticket; the solve (which may set it) runs after all tickets
-  if (rb.n_dev || rb.shard_world > 1) n_blocks = max(1, (n_live + kBlock - 1) / kBlock);
+  (void)n_live;  // n_blocks = the workgroups of the fit launch: its points are dealt out in chunks, every workgroup may hold some
   const int t = blockIdx.x;
   const double acc = final_sum_row<kSolveThreads>(partials + (size_t)t * stride, n_blocks, s_w);
   if (threadIdx.x == 0) {
@@ -388,7 +388,8 @@ void launch_mailbox_allreduce(double* out91, const MailboxView& mb, hipStream_t 
 }
 void launch_reduce_solve(const RegistrationBuffers& rb, double* out91, unsigned int* ticket, IekfCtrl* c, IekfResult* res,
                          const MailboxView& mb, hipStream_t s) {
-  int nb = (rb.n + kBlock - 1) / kBlock;
+  const int bound = rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;  // as launch_fit_reduce
+  int nb = (bound + kBlock - 1) / kBlock;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq), dim3(kSolveThreads), 0, s, rb.partials, nb, rb.partial_stride, out91, ticket, c, res, rb,
                      mb);

@@ -1238,14 +1238,14 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
 // Plane fit + residual + Jacobian + block reduction, one lane per point.  FIT = right after a search pass (finishes
 // the flagged searches of this workgroup's points, reads the 5 neighbours, caches the plane); !FIT for the
 // non-search iterations.  `forced` as in k_knn_pruned.
-// Completion of the flagged searches among the kBlock points [first, first + kBlock) of one workgroup: one wavefront per
+// Completion of the flagged searches among the kBlock points of one workgroup (`my_point`: the calling lane's): one wavefront per
 // flagged query, four at a time (they are rare, ~0.07 % of the queries, but clustered at the map frontier).  Every lane of
 // the workgroup must call it; on return the completed lists are visible to the whole workgroup.
-__device__ __forceinline__ void complete_flagged(const GridView& g, const RegistrationBuffers& rb, int first, bool live, int* s_needy,
+__device__ __forceinline__ void complete_flagged(const GridView& g, const RegistrationBuffers& rb, int my_point, bool live, int* s_needy,
                                                  int* s_nneedy) {
   if (threadIdx.x == 0) *s_nneedy = 0;
   __syncthreads();
-  if (live && (rb.nbr_count[first + threadIdx.x] & kNeedy)) s_needy[atomicAdd(s_nneedy, 1)] = threadIdx.x;
+  if (live && (rb.nbr_count[my_point] & kNeedy)) s_needy[atomicAdd(s_nneedy, 1)] = my_point;
   __syncthreads();
 #ifdef LII_DIAG_SKIP_NEEDY  // diagnostic build only: how much of the search-pass fit kernel is the completion of flagged searches
   const int nn = 0;
@@ -1254,7 +1254,7 @@ __device__ __forceinline__ void complete_flagged(const GridView& g, const Regist
 #endif
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int e = wave; e < nn; e += kBlock / 64) {
-    const int qi = first + s_needy[e];
+    const int qi = s_needy[e];
     const float4 w4 = rb.world[qi];
     const int c0 = rb.nbr_count[qi] & 0xFF;
     const float d5 = c0 == kMatch ? rb.nbr[(size_t)4 * rb.cap + qi].w : __builtin_inff();
@@ -1274,6 +1274,16 @@ __device__ __forceinline__ void complete_flagged(const GridView& g, const Regist
   if (nn) __syncthreads();  // the completed lists are visible to their owners (workgroup-scope release/acquire)
 }
 
+// Which point a lane of the fit pass takes: workgroup b of nb takes the chunks b, b + nb, b + 2 nb, ... of 4 consecutive points
+// (4 lanes read 64 contiguous bytes).  Flagged searches cluster - a stretch of the scan that looks past the edge of the map -
+// and a workgroup completes its own, four at a time: with 256 consecutive points per workgroup one of them can sit on dozens
+// (the fit pass of a scan in sweep order took 50 us instead of 19); dealt out in chunks a cluster of 500 points is shared by 125
+// workgroups.  (Which workgroup sums which points is fixed either way: the sums stay deterministic.)
+constexpr int kFitChunkShift = 2;
+__device__ __forceinline__ int fit_point_of(int blk, int nb) {
+  return ((((int)threadIdx.x >> kFitChunkShift) * nb + blk) << kFitChunkShift) + ((int)threadIdx.x & ((1 << kFitChunkShift) - 1));
+}
+
 // The completion alone, over the whole cloud (lii_map_incremental of a sharded job: the blocks of the other ranks were searched
 // by a stand-alone k-NN pass, not by a fit pass).
 __global__ __launch_bounds__(kBlock) void k_knn_complete(GridView g, RegistrationBuffers rb) {
@@ -1281,8 +1291,8 @@ __global__ __launch_bounds__(kBlock) void k_knn_complete(GridView g, Registratio
   __shared__ int s_nneedy;
   int lo, n_live;
   shard_range(rb, lo, n_live);
-  const int first = lo + blockIdx.x * kBlock;
-  complete_flagged(g, rb, first, (int)(blockIdx.x * kBlock + threadIdx.x) < n_live, s_needy, &s_nneedy);
+  const int q = fit_point_of(blockIdx.x, (int)gridDim.x);
+  complete_flagged(g, rb, lo + q, q < n_live, s_needy, &s_nneedy);
 }
 
 __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationBuffers rb, PoseArg ps_val,
@@ -1305,9 +1315,10 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   }
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;  // uniform per block
-  const int i = lo + blk * kBlock + threadIdx.x;
-  const bool live = blk * kBlock + (int)threadIdx.x < n_live;
-  if (FIT) complete_flagged(g, rb, lo + blk * kBlock, live, s_needy, &s_nneedy);  // uniform per workgroup
+  const int q = fit_point_of(blk, nb_real);
+  const int i = lo + q;
+  const bool live = q < n_live;
+  if (FIT) complete_flagged(g, rb, i, live, s_needy, &s_nneedy);  // uniform per workgroup
   RowOut o;
 #pragma unroll
   for (int c = 0; c < 12; c++) o.h[c] = 0;
@@ -1361,11 +1372,7 @@ __global__ __launch_bounds__(256) void k_reduce91(const double* __restrict__ par
                                                    RegistrationBuffers rb) {
   __shared__ double s_w[4];
   if (forced < 0 && ctrl->stop) return;
-  if (rb.n_dev || rb.shard_world > 1) {
-    int lo, n_live;
-    shard_range(rb, lo, n_live);
-    n_blocks = max(1, (n_live + kBlock - 1) / kBlock);
-  }
+  // (n_blocks = the workgroups of the fit launch: its points are dealt out in chunks, every workgroup may hold some)
   const int t = blockIdx.x;
   const double acc = final_sum_row<256>(partials + (size_t)t * stride, n_blocks, s_w);  // same order as k_reduce_solve
   if (threadIdx.x == 0) out[t] = acc;
@@ -1751,6 +1758,165 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ p
   }
 }
 // ------------------------------------------------------------------------------------------------
+// The voxel grid without a sort (the default path; the sample sort of lii_vsort.hip stays for LII_VOXEL_FILTER=sort).
+// PCL's filter sorts the points by voxel index only to bring the points of a voxel together and to emit the voxels in index
+// order; the centroids themselves depend on the ORDER OF THE POINTS INSIDE a voxel (float sums, input order), not on the
+// order of the voxels.  So the points of a voxel are brought together by a hash table instead, and the voxels leave in the
+// order of their first points (the PCL index of every output voxel is kept: lii_scan_download / lii_neighbors_download put
+// the reference's order back on the host).  Three launches instead of six:
+//   k_vhash_insert  bounding box -> grid parameters -> PCL voxel index per point (exactly as k_voxel_keys) -> the voxel's
+//                   slot in an open-addressing table (CAS on the key), the smallest point index of the slot (atomicMin)
+//   k_vhash_link    a point that is not the first of its voxel hands its index to the voxel's slot (a few members in the
+//                   slot itself, a linked list behind them for crowded voxels); firsts are counted per workgroup
+//   k_vhash_emit    output position = number of firsts before the point (workgroup counts + a scan in the workgroup); the
+//                   first point of a voxel sorts the member indices (input order = ascending index), adds the points in
+//                   that order - the float additions of PCL's centroid - writes the centroid and clears its slot.
+// Deterministic: the slot a voxel lands in and the order in which members arrive vary from run to run, neither reaches the
+// output.
+constexpr unsigned int kVhEmpty = 0xFFFFFFFFu;
+constexpr int kVhMembers = 7;  // members (beside the first point) a slot holds itself
+struct VhashTable {
+  unsigned int* key;     // PCL voxel index (identity path: the point index), kVhEmpty = free
+  unsigned int* first;   // smallest point index of the voxel
+  unsigned int* count;   // members handed in by k_vhash_link
+  unsigned int* head;    // linked list of the members beyond kVhMembers (through `next`), kVhEmpty = none
+  unsigned int* members; // kVhMembers per slot
+  unsigned int mask;     // slots - 1
+};
+__device__ __forceinline__ unsigned int vh_hash(unsigned int k) {
+  k *= 0x9E3779B1u;
+  k ^= k >> 15;
+  k *= 0x85EBCA77u;
+  k ^= k >> 13;
+  return k;
+}
+__global__ __launch_bounds__(256) void k_vhash_insert(const float4* __restrict__ pts, int n, const unsigned int* __restrict__ mm,
+                                                      const unsigned int* __restrict__ bbox_rows, int n_rows, float leaf,
+                                                      VhashTable tb, unsigned int* __restrict__ slot_of, int* __restrict__ filtered) {
+  __shared__ unsigned int s_mm[8];
+  if (n_rows > 0) {  // the box arrives as one row per de-skew workgroup: every workgroup folds them for itself (a few KB from L2)
+    unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+    for (int r = threadIdx.x; r < n_rows; r += 256) {
+      const uint4 a = *reinterpret_cast<const uint4*>(bbox_rows + r * 8), b = *reinterpret_cast<const uint4*>(bbox_rows + r * 8 + 4);
+      lo[0] = min(lo[0], a.x); lo[1] = min(lo[1], a.y); lo[2] = min(lo[2], a.z);
+      hi[0] = max(hi[0], b.x); hi[1] = max(hi[1], b.y); hi[2] = max(hi[2], b.z);
+    }
+    block_bbox_reduce(lo, hi);
+    if (threadIdx.x < 3) { s_mm[threadIdx.x] = lo[0]; s_mm[3 + threadIdx.x] = hi[0]; }
+    __syncthreads();
+    mm = s_mm;
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const VoxelArg v = voxel_prepare(mm, leaf);
+  if (i == 0) *filtered = v.identity ? 0 : 1;
+  const float4 p = pts[i];
+  unsigned int key = kVhEmpty;  // non-finite points are dropped
+  if (v.identity) {
+    key = (unsigned)i;  // every point is its own voxel
+  } else if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+    const int i0 = (int)(floorf(p.x * v.inv_leaf) - (float)v.min_b[0]);
+    const int i1 = (int)(floorf(p.y * v.inv_leaf) - (float)v.min_b[1]);
+    const int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)v.min_b[2]);
+    key = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);  // < 2^31 (the overflow guard)
+  }
+  unsigned int slot = kVhEmpty;
+  if (key != kVhEmpty) {
+    slot = vh_hash(key) & tb.mask;
+    for (;;) {  // the table has four times as many slots as there are points: a free slot always turns up
+      const unsigned int prev = atomicCAS(tb.key + slot, kVhEmpty, key);
+      if (prev == kVhEmpty || prev == key) break;
+      slot = (slot + 1u) & tb.mask;
+    }
+    atomicMin(tb.first + slot, (unsigned)i);
+  }
+  slot_of[i] = slot;
+}
+__global__ __launch_bounds__(256) void k_vhash_link(int n, VhashTable tb, const unsigned int* __restrict__ slot_of,
+                                                    unsigned int* __restrict__ next, unsigned char* __restrict__ is_first,
+                                                    unsigned int* __restrict__ block_firsts) {
+  __shared__ unsigned int s_cnt[4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool first = false;
+  if (i < n) {
+    const unsigned int slot = slot_of[i];
+    if (slot != kVhEmpty) {
+      first = tb.first[slot] == (unsigned)i;
+      if (!first) {
+        const unsigned int k = atomicAdd(tb.count + slot, 1u);
+        if (k < (unsigned)kVhMembers) tb.members[(size_t)slot * kVhMembers + k] = (unsigned)i;
+        else next[i] = atomicExch(tb.head + slot, (unsigned)i);
+      }
+    }
+    is_first[i] = first ? 1 : 0;
+  }
+  const unsigned long long b = __ballot(first);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (unsigned)__popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) block_firsts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+// exclusive scan over the 256 lanes of a workgroup of 0 / 1 flags; *total = flags set in the workgroup
+__device__ __forceinline__ unsigned int block_rank_of_flag(bool f, unsigned int* s_w /*[4] LDS*/, unsigned int* total) {
+  const unsigned long long b = __ballot(f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_w[wave] = (unsigned)__popcll(b);
+  __syncthreads();
+  unsigned int before = 0;
+  for (int w = 0; w < wave; w++) before += s_w[w];
+  *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  return before + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+}
+__global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ pts, int n, VhashTable tb,
+                                                    const unsigned int* __restrict__ slot_of, const unsigned int* __restrict__ next,
+                                                    const unsigned char* __restrict__ is_first,
+                                                    const unsigned int* __restrict__ block_firsts, float4* __restrict__ out,
+                                                    int* __restrict__ n_out, unsigned int* __restrict__ pcl_out) {
+  __shared__ unsigned int s_w[4], s_sum[4];
+  const int tid = threadIdx.x, i = blockIdx.x * blockDim.x + tid;
+  unsigned int before = 0;  // firsts in the workgroups below this one
+  for (int q = tid; q < (int)blockIdx.x; q += 256) before += block_firsts[q];
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+  if ((tid & 63) == 0) s_sum[tid >> 6] = before;
+  __syncthreads();
+  const unsigned int base = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+  const bool first = i < n && is_first[i] != 0;
+  unsigned int total;
+  const unsigned int pos = base + block_rank_of_flag(first, s_w, &total);
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) *n_out = (int)(base + total);  // size of the down-sampled cloud
+  if (!first) return;
+  const unsigned int slot = slot_of[i];
+  const unsigned int cnt = tb.count[slot];
+  const float4 p0 = pts[i];
+  float sx = __fadd_rn(0.f, p0.x), sy = __fadd_rn(0.f, p0.y), sz = __fadd_rn(0.f, p0.z), st = __fadd_rn(0.f, p0.w);
+  if (cnt > 0u) {
+    // the members in input order: every round takes the smallest index above the last one taken - from the slot's own
+    // members (registers) and, for a crowded voxel, from the list behind them (walked again every round: slow and rare)
+    unsigned int m[kVhMembers];
+    const unsigned int own = min(cnt, (unsigned)kVhMembers);
+#pragma unroll
+    for (int k = 0; k < kVhMembers; k++) m[k] = (unsigned)k < own ? tb.members[(size_t)slot * kVhMembers + k] : kVhEmpty;
+    const unsigned int head = cnt > (unsigned)kVhMembers ? tb.head[slot] : kVhEmpty;
+    unsigned int last = (unsigned)i;
+    for (unsigned int r = 0; r < cnt; r++) {
+      unsigned int best = kVhEmpty;
+#pragma unroll
+      for (int k = 0; k < kVhMembers; k++) best = (m[k] > last && m[k] < best) ? m[k] : best;
+      for (unsigned int j = head; j != kVhEmpty; j = next[j]) best = (j > last && j < best) ? j : best;
+      const float4 p = pts[best];
+      sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+      last = best;
+    }
+  }
+  const float c = (float)(cnt + 1u);
+  // a single-point voxel reproduces the point exactly (x / 1.0f == x), which is also what the identity path needs
+  out[pos] = make_float4(sx / c, sy / c, sz / c, st / c);
+  pcl_out[pos] = tb.key[slot];
+  tb.key[slot] = kVhEmpty;  // the slot is free again for the next scan
+  tb.first[slot] = kVhEmpty;
+  tb.count[slot] = 0u;
+  tb.head[slot] = kVhEmpty;
+}
+// ------------------------------------------------------------------------------------------------
 // LI-Init residual / Jacobian evaluators (include/LI_init/LI_init.h:91-205).  Records are 22 doubles:
 // rot_end[9], ang_vel[3], linear_vel[3], ang_acc[3], linear_acc[3], timestamp.
 // Tangent convention R <- Exp(delta) R  (Appendix B of SURVEY.md):
@@ -2004,6 +2170,24 @@ void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const u
   if (n > 0)
     hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, keys, pcl_keys,
                        coherent_order, filtered_dev, samples, sample_width);
+}
+void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
+                       int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, hipStream_t s) {
+  if (n <= 0) return;
+  VhashTable tb;
+  tb.key = vh.key; tb.first = vh.first; tb.count = vh.count; tb.head = vh.head; tb.members = vh.members;
+  unsigned int slots = 1024;
+  while (slots < 4u * (unsigned)n) slots <<= 1;
+  tb.mask = slots - 1u;
+  const int nb = nblk(n, 256);
+  hipLaunchKernelGGL(k_vhash_insert, dim3(nb), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, tb, vh.slot_of, filtered);
+  hipLaunchKernelGGL(k_vhash_link, dim3(nb), dim3(256), 0, s, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts);
+  hipLaunchKernelGGL(k_vhash_emit, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, out, n_out, pcl_out);
+}
+size_t voxel_hash_slots(int max_n) {
+  size_t slots = 1024;
+  while (slots < 4u * (size_t)max_n) slots <<= 1;
+  return slots;
 }
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s) {

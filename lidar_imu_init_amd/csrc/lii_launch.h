@@ -62,6 +62,17 @@ void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned in
 void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows, int n_rows, float leaf,
                        unsigned long long* keys, unsigned int* pcl_keys, int coherent_order, int* filtered_dev,
                        unsigned long long* samples, int sample_width, hipStream_t s);
+// the voxel grid by hashing (lii_kernels.hip: k_vhash_*): the table arrays hold voxel_hash_slots(max_n) entries (`members`: 7 per
+// slot), initialised to key = first = head = 0xFFFFFFFF, count = 0 and left in that state by every filter
+struct VoxelHashBuffers {
+  unsigned int *key, *first, *count, *head, *members;
+  unsigned int *slot_of, *next;   // per input point
+  unsigned char* is_first;        // per input point
+  unsigned int* block_firsts;     // per workgroup of 256 points
+};
+size_t voxel_hash_slots(int max_n);
+void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
+                       int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, hipStream_t s);
 // calibration
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s);
