@@ -366,8 +366,9 @@ int lii_dev_alloc(lii_handle h, size_t bytes, void** dev_ptr);
 int lii_dev_free(lii_handle h, void* dev_ptr);
 int lii_dev_upload(lii_handle h, void* dev_dst, const void* host_src, size_t bytes);
 /* Accumulated device timings [ms] since lii_set_profiling(h, 1), measured with HIP events on the handle's stream:
- * [0] first pass of every update (k-NN + plane fit / residual / block reduce), [2] its final sum + solve, [3] host solve
- * (host-driven loop only), [4] wall time of the last update, [5] number of executed k-NN passes, [7] their total time. */
+ * lii_iekf_update / lii_scan_register: [5] number of executed k-NN passes, [7] their total time (events around the k-NN launches
+ * only: every event is a barrier on the stream), [4] wall time of the last update; lii_iekf_iterate: also [0] / [1] search-pass /
+ * residual-pass kernels, [2] the final sum, [6] count of [1]; [3] host solve (host-driven loop only). */
 int lii_set_profiling(lii_handle h, int32_t enabled); /* 1: start (zero the accumulators), 2: resume, 0: pause */
 int lii_last_timings(lii_handle h, double out_ms[8]);
 

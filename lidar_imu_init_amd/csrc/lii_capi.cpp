@@ -166,6 +166,9 @@ struct lii_context {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_it[32] = {};  // per-iteration brackets of the k-NN kernel in the device-driven loop
   double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double host_us[6] = {0, 0, 0, 0, 0, 0};  // LII_DIAG: per lii_scan_register - entry -> first launch, -> pre-processing enqueued, -> loop enqueued, -> result; calls; gap between calls
+  std::chrono::steady_clock::time_point host_last_return;
+  double host_loop_enq_us = 0;
 };
 
 namespace {
@@ -573,7 +576,7 @@ void fill_ctrl(lii_handle h, const lii_state* state, const lii_state* state_prop
   hc->seq = h->update_seq;
   // which k-NN launches ride along (IekfCtrl::plan_mask): the first pass always; the others as the previous update needed them
   unsigned int plan = 0xFFFFFFFFu;
-  if (h->knn_plan && !h->profiling && !h->comm && h->n_ranks == 1) plan = (h->knn_plan_force >= 0 ? (unsigned int)h->knn_plan_force : h->plan_next) | 1u;
+  if (h->knn_plan && !h->comm && h->n_ranks == 1) plan = (h->knn_plan_force >= 0 ? (unsigned int)h->knn_plan_force : h->plan_next) | 1u;
   hc->plan_mask = plan;
   h->plan_cur = plan;
 }
@@ -600,22 +603,22 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   const bool prof = h->profiling;
   const double* ne = h->comm ? h->d_out91 + 128 : h->d_out91;
   unsigned int plan = h->plan_cur;  // fill_ctrl chose it (the control block on the device carries the same mask)
+  const unsigned int plan0 = plan;
+  // (profiling = HIP events around the k-NN launches only - the dominant kernel, lii_last_timings [5] / [7]; every event is a
+  // barrier packet on the stream, so the rest of the loop is left alone: launch plan and result polling work as always)
   auto enqueue_pass = [&](int it) -> int {
-    const bool timed = prof && it == 0;  // the first pass always searches
-    if (timed) HIPCHK(h, hipEventRecord(h->ev[0], s));
-    if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it], s));
-    if (it >= 32 || ((plan >> it) & 1u)) launch_knn(h, g, rb, ps0, pose, -1);
-    if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it + 1], s));
-    if (timed) HIPCHK(h, hipEventRecord(h->ev[3], s));
+    const bool knn = it >= 32 || ((plan >> it) & 1u);
+    if (knn) {
+      if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it], s));
+      launch_knn(h, g, rb, ps0, pose, -1);
+      if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it + 1], s));
+    }
     launch_fit_reduce(g, rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
-    if (timed) HIPCHK(h, hipEventRecord(h->ev[1], s));
-    if (!h->comm) {  // single GPU or node-local mailbox: final sum (+ exchange) and solve in one launch ([2] times both)
+    if (!h->comm) {  // single GPU or node-local mailbox: final sum (+ exchange) and solve in one launch
       launch_reduce_solve(rb, h->d_out91, h->d_counter, h->d_ctrl, h->h_res, mailbox_view(h), s);
-      if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
       return LII_OK;
     }
     launch_reduce91(rb, h->d_out91, h->d_ctrl, -1, s);
-    if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
     // every rank enqueues the same number of all-reduces; a pass that is skipped on the device re-sums the
     // unchanged local buffer on all ranks alike, so the ranks stay in lock-step without a host decision
     ncclResult_t r = ncclAllReduce(h->d_out91, h->d_out91 + 128, kNormalEq, ncclDouble, ncclSum, h->comm, s);
@@ -623,6 +626,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     launch_iekf_solve(h->d_ctrl, ne, h->h_res, s);
     return LII_OK;
   };
+  const auto t_loop0 = std::chrono::steady_clock::now();
   for (int it = 0; it < opts->max_iterations; it++) {
     rc = enqueue_pass(it);
     if (rc != LII_OK) return rc;
@@ -636,7 +640,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   // scan) is continued from here with every launch: one host round trip, on the scans whose pattern changes.
   auto wait_result = [&](bool first) -> int {
     const int parked_word = first ? (h->update_seq | kLoopParked) : h->update_seq;
-    if (h->poll_result && !prof && !h->comm) {
+    if (h->poll_result && !h->comm) {
       volatile int* done = &h->h_res->done;
       unsigned int spins = 0;
       while (*done != h->update_seq && *done != parked_word) {
@@ -654,6 +658,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     }
     return LII_OK;
   };
+  if (h->diag) h->host_loop_enq_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop0).count();
   rc = wait_result(true);
   if (rc != LII_OK) return rc;
   if (h->h_res->done == (h->update_seq | kLoopParked)) {
@@ -702,20 +707,15 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     std::memcpy(report->normal_eq, hr->ne, sizeof(double) * kNormalEq);
   }
   if (prof) {
-    float a = 0, b = 0, k = 0;
-    HIPCHK(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
-    HIPCHK(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
-    HIPCHK(h, hipEventElapsedTime(&k, h->ev[0], h->ev[3]));
-    h->timings[0] += a; h->timings[2] += b;
-    // the k-NN kernel alone, over EVERY pass that actually searched (the device logs which iterations did)
+    // the k-NN kernel alone, over EVERY pass that actually searched (the device logs which iterations did); the events were
+    // recorded ahead of the stopping pass, whose result has arrived: they have completed
     for (int it = 0; it < opts->max_iterations && it < 16; it++) {
-      if (it >= hr->it || !hr->search_log[it]) continue;
+      if (it >= hr->it || !hr->search_log[it] || !((plan0 >> it) & 1u)) continue;
       float kk = 0;
-      HIPCHK(h, hipEventElapsedTime(&kk, h->ev_it[2 * it], h->ev_it[2 * it + 1]));
+      if (hipEventElapsedTime(&kk, h->ev_it[2 * it], h->ev_it[2 * it + 1]) != hipSuccess) continue;
       h->timings[7] += kk;
       h->timings[5] += 1;
     }
-    (void)k;
   }
   return LII_OK;
 }
@@ -923,6 +923,10 @@ int lii_destroy(lii_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] map updates completed by a rebuild + re-insertion: %lld\n", h->map_recoveries);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] updates continued by the host after a parked loop: %lld\n", h->plan_parked);
+  if (h->diag && h->host_us[4] > 0)
+    std::fprintf(stderr, "[libliinit_hip] host side of lii_scan_register, us per call over %.0f calls: first launch submitted %.1f, pre-processing enqueued %.1f, "
+                 "loop enqueue %.1f, call %.1f, between calls %.1f\n", h->host_us[4], h->host_us[0] / h->host_us[4], h->host_us[1] / h->host_us[4],
+                 h->host_us[2] / h->host_us[4], h->host_us[3] / h->host_us[4], h->host_us[5] / std::max(1.0, h->host_us[4] - 1));
   mailbox_close(&h->mailbox);
   if (h->d_mb_seq) (void)hipFree(h->d_mb_seq);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
@@ -1387,6 +1391,8 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   if (!h || !job || job->struct_size != sizeof(lii_scan_job) || !state || !state_prop || job->opts.max_iterations < 1)
     return fail(h, LII_ERR_INVALID, "lii_scan_register: bad arguments");
   int rc = LII_OK;
+  const auto t_entry = std::chrono::steady_clock::now();
+  if (h->diag && h->host_us[4] > 0) h->host_us[5] += std::chrono::duration<double, std::micro>(t_entry - h->host_last_return).count();
   const bool adopt = job->scan_dev != nullptr && job->n_scan_dev > 0;
   if (adopt && job->n_scan_dev > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_register: n_scan_dev > max_scan_points");
   const int n_next = adopt ? job->n_scan_dev : h->n_scan;
@@ -1413,6 +1419,7 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     rc = lii_scan_set_device(h, job->scan_dev, job->n_scan_dev);
     if (rc != LII_OK) { h->ctrl_pending = 0; h->poses_preloaded = h->ctrl_preloaded = false; return rc; }
   }
+  const auto t_first = std::chrono::steady_clock::now();
   if (job->undistort == 1) {
     rc = lii_undistort_imu(h, job->imu_poses, job->n_imu_poses, state->rot_end, state->pos_end, state->offset_R_L_I,
                            state->offset_T_L_I);
@@ -1426,8 +1433,18 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     h->ctrl_pending = 0;
   }
   if (rc == LII_OK) rc = job->leaf > 0 ? lii_downsample(h, job->leaf, nullptr, nullptr) : lii_downsample_skip(h, nullptr);
+  const auto t_pre = std::chrono::steady_clock::now();
   if (rc == LII_OK) rc = lii_iekf_update(h, state, state_prop, &job->opts, report);
   h->poses_preloaded = h->ctrl_preloaded = false;  // also on the error paths
+  if (h->diag) {
+    const auto t_end = std::chrono::steady_clock::now();
+    h->host_us[0] += std::chrono::duration<double, std::micro>(t_first - t_entry).count();
+    h->host_us[1] += std::chrono::duration<double, std::micro>(t_pre - t_entry).count();
+    h->host_us[2] += h->host_loop_enq_us;
+    h->host_us[3] += std::chrono::duration<double, std::micro>(t_end - t_entry).count();
+    h->host_us[4] += 1;
+    h->host_last_return = t_end;
+  }
   return rc;
 }
 
