@@ -184,10 +184,15 @@ def main():
     n_full = max(len(s) for s in wl["scans"])
     reg = lii.Registrar(max_scan_points=n_full + 1024, max_map_points=int(len(wl["map"]) * 1.5) + 1024,
                         filter_size_map=wl["fs_map"], map_cell_size=args.cell_size, device=local_rank)
-    if world > 1:
+    def attach(transport):
+        """(Re-)creates the job's communicator with the named transport on every rank."""
+        reg.comm_destroy()
         uid = [reg.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        reg.comm_init(world, rank, uid[0], os.environ.get("LII_BENCH_TRANSPORT", "auto"))
+        reg.comm_init(world, rank, uid[0], transport)
+
+    if world > 1:
+        attach(os.environ.get("LII_BENCH_TRANSPORT", "auto"))
     reg.map_build(wl["map"])
     reg.map_commit()
     # Every rank receives the WHOLE scan (and holds the whole map): de-skew + voxel filter run replicated, the library splits
@@ -262,46 +267,81 @@ def main():
 
     # The ROCm runtime grows internal pools (signals / staging) once, ~100 steps into a process: a single 30-50 ms
     # stall at a fixed step index.  Prime it out before the W warm-up steps so that it cannot land in the timed region.
-    if native:
-        native(0, args.prime + args.warmup, 0)
-    else:
-        for k in range(args.prime):
-            step(k)
-        for k in range(args.warmup):
-            step(k)
-    reg.synchronize()
-    reg.set_profiling(1)
-    reg.set_profiling(0)
-    iters_total[0] = search_total[0] = 0
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    last = None
     trace = os.environ.get("LII_BENCH_TRACE")
     stamps = []
-    # HIP-event brackets of the kernels are recorded on every 8th step of the timed region only: each event is a
-    # barrier packet on the stream, and ten of them per scan would cost ~5 % of the throughput being measured
-    if native:
-        totals[:] = 0
-        native(0, args.steps, args.profile_every)
-        iters_total[0], search_total[0] = int(totals[0]), int(totals[1])
-        last = last_pod
+
+    def timed_region(prime):
+        """W warm-up steps (+ the priming steps the first time), then EXACTLY K timed steps between barrier + synchronize on both
+        sides; the MAX over ranks.  Returns seconds."""
+        nonlocal last
+        if native:
+            native(0, prime + args.warmup, 0)
+        else:
+            for k in range(prime + args.warmup):
+                step(k)
+        reg.synchronize()
+        reg.set_profiling(1)
+        reg.set_profiling(0)
+        iters_total[0] = search_total[0] = 0
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        # HIP-event brackets of the k-NN launches are recorded on every 8th step of the timed region only: each event is a
+        # barrier packet on the stream
+        if native:
+            totals[:] = 0
+            native(0, args.steps, args.profile_every)
+            iters_total[0], search_total[0] = int(totals[0]), int(totals[1])
+            last = last_pod
+        else:
+            for k in range(args.steps):
+                reg.set_profiling(2 if (args.profile_every and k % args.profile_every == 0) else 0)
+                last = step(k)
+                if trace:
+                    stamps.append(time.perf_counter() - t0)
+        reg.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_device else "cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    last = None
+    transports = None
+    if world > 1:
+        # A sharded job is timed once per transport of the 91-scalar exchange, same steps, same scans: the default (the library's
+        # own choice on one node: the peer-mapped HBM mailbox - a push over xGMI inside the reduce+solve launch) gives `value`;
+        # RCCL (ncclAllReduce between a separate final-sum and solve launch) is timed beside it - on one device only the mailbox
+        # forms can run (RCCL refuses two ranks on a device).  LII_BENCH_TRANSPORT pins `value` to one of them.
+        first = os.environ.get("LII_BENCH_TRANSPORT", "auto")
+        others = [t for t in (["mailbox_host"] if one_device else ["rccl", "mailbox_host"]) if t != first]
+        transports = {}
+        dt = None
+        for n_run, t in enumerate([first] + others):
+            try:
+                if n_run > 0:
+                    attach(t)
+                d = timed_region(args.prime if n_run == 0 else 0)
+            except Exception as e:  # a transport that cannot be set up here is reported, not fatal
+                transports[t] = {"error": str(e)[:200]}
+                if n_run == 0:
+                    raise
+                continue
+            used = reg.comm_transport()
+            transports[used if n_run == 0 else t] = {"value": args.steps / d, "ms_per_step": 1e3 * d / args.steps, "transport": used,
+                                                     "rccl_ranks": reg.comm_rccl_ranks(), "avg_iterations": iters_total[0] / args.steps}
+            if n_run == 0:
+                dt, value_transport, value_rccl_ranks = d, used, reg.comm_rccl_ranks()
+        if first != "auto" or len(others):
+            attach(first)  # the rest of the run (parity calls) on the transport `value` was measured with
     else:
-        for k in range(args.steps):
-            reg.set_profiling(2 if (args.profile_every and k % args.profile_every == 0) else 0)
-            last = step(k)
-            if trace:
-                stamps.append(time.perf_counter())
-    reg.synchronize()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_device else "cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = timed_region(args.prime)
+        value_transport, value_rccl_ranks = "none", 0
     tm = reg.timings()
     # size of the down-sampled cloud (the k-NN kernel's query count) and, on one GPU, the final state of every distinct scan
     # for the parity record: one untimed call per distinct scan, on every rank (a sharded call needs all of them)
@@ -313,7 +353,7 @@ def main():
         n_ds.append(len(reg.scan_download(1)))
         gpu_results.append((st.pod.copy(), rep))
     if trace and rank == 0:
-        np.savetxt(trace, np.diff(np.r_[t0, stamps]) * 1e3, fmt="%.4f")
+        np.savetxt(trace, np.diff(np.r_[0.0, stamps]) * 1e3, fmt="%.4f")
 
     # The COMPLETE per-scan pipeline as a second, separately timed figure (never `value`): every scan handed over from HOST
     # memory (lii_scan_upload: PCIe inside the region), registered, and inserted into the map (lii_map_incremental: device-side
@@ -409,13 +449,17 @@ def main():
                        "params": f"harness/launch/{WORKLOADS[args.workload][2]} (reference-format yaml + launch)",
                        "avg_iterations": iters_total[0] / args.steps,
                        "avg_knn_passes": search_total[0] / args.steps,
-                       "host_loop": "C++ (harness/stream_driver.cpp)" if native else "Python (ctypes)", "parallelism": f"points sharded x{world}" + (f", 91-scalar exchange over {reg.comm_transport()}" if world > 1 else "")},
+                       "host_loop": "C++ (harness/stream_driver.cpp)" if native else "Python (ctypes)", "parallelism": f"points sharded x{world}" + (f", 91-scalar exchange over {value_transport}"
+                                                                    + (f" (ncclCommCount {value_rccl_ranks})" if value_rccl_ranks else "") if world > 1 else ""),
+                       "transport": value_transport, "rccl_ranks": value_rccl_ranks},
             "roofline": {"bound": "hbm", "kernel": knn_kernel_name(),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": avg_search_ms, "alg_bytes_per_launch": alg_bytes,
                          "launches": int(tm[5]),
                          "peak_measured_copy": 6290.0, "frac_of_measured_copy": achieved / 6290.0},
         }
+        if transports is not None:
+            out["transports"] = transports
         if pipeline is not None:
             out["complete_pipeline"] = pipeline
         if not args.no_cpu_baseline and args.gpus == 1:

@@ -19,9 +19,10 @@
 extern "C" {
 #endif
 
-#define LII_ABI_VERSION 4 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
+#define LII_ABI_VERSION 5 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
                              3: lii_params_*, lii_comm_set_partition (library-side split of the down-sampled cloud)
-                             4: lii_scan_upload_next / lii_scan_advance (the next scan travels while the current one registers) */
+                             4: lii_scan_upload_next / lii_scan_advance (the next scan travels while the current one registers)
+                             5: LII_COMM_MAILBOX = the peer-mapped HBM mailbox (HIP IPC), LII_COMM_MAILBOX_HOST, lii_comm_rccl_ranks */
 
 enum lii_status {
   LII_OK = 0,
@@ -310,18 +311,25 @@ int lii_li_init_set_device(lii_handle h, int32_t on_device);
  *   brick order - a compact region of the map per rank.  The sharded result equals the single-GPU result up to the
  *   re-association of the 91 sums.  lii_map_incremental of a sharded job repeats the last search for the whole cloud (no
  *   exchange) so that every rank applies the identical insert lists.  Partition 0: the caller hands every rank its own points.
- * Two transports:
- *   LII_COMM_MAILBOX  ranks of ONE node meet in a shared-memory segment that each registers with its device; the exchange
- *                     runs inside the reduce+solve kernel (no extra launch, no collective-library call; ~5 us).
- *   LII_COMM_RCCL     ncclAllReduce on the handle's stream between a separate final-sum and solve launch (any topology).
- *   LII_COMM_AUTO     mailbox when all ranks meet in the segment within LII_MAILBOX_WAIT_S (default 20 s), else RCCL.
+ * Transports:
+ *   LII_COMM_MAILBOX       ranks of ONE node; the exchange runs inside the reduce+solve kernel (no extra launch, no
+ *                          collective-library call).  Every rank keeps the slots it reads in fine-grained HBM, exported through
+ *                          a HIP IPC handle: an exchange pushes the 91 sums into the peers' memory (remote stores over xGMI)
+ *                          and polls local memory.  Works between processes on one device as well.
+ *   LII_COMM_MAILBOX_HOST  the same exchange through a POSIX shared-memory segment registered with every rank's device (host
+ *                          memory over PCIe): what LII_COMM_MAILBOX falls back to in AUTO mode when an IPC handle cannot be
+ *                          exported or opened.
+ *   LII_COMM_RCCL          ncclAllReduce on the handle's stream between a separate final-sum and solve launch (any topology).
+ *   LII_COMM_AUTO          the HBM mailbox when all ranks meet on one node within LII_MAILBOX_WAIT_S (default 20 s), else the
+ *                          host-memory mailbox, else RCCL.
  * A rank that stops calling (error on one rank only) makes the others' next update fail with LII_ERR_COMM after
  * LII_MAILBOX_TIMEOUT_S (default 30 s; RCCL: its own watchdog); the communicator must then be re-created.  lii_comm_init == lii_comm_init_ex(..., LII_COMM_AUTO). */
-enum { LII_COMM_AUTO = 0, LII_COMM_RCCL = 1, LII_COMM_MAILBOX = 2 };
+enum { LII_COMM_AUTO = 0, LII_COMM_RCCL = 1, LII_COMM_MAILBOX = 2, LII_COMM_MAILBOX_HOST = 3 };
 int lii_comm_unique_id(uint8_t id_out[128]);
 int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id[128]);
 int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id[128], int32_t transport);
 int lii_comm_transport(lii_handle h, int32_t* transport); /* the transport in use; LII_COMM_AUTO = none (single rank) */
+int lii_comm_rccl_ranks(lii_handle h, int32_t* n_ranks);  /* ncclCommCount of the attached RCCL communicator; 0: none attached */
 int lii_comm_set_partition(lii_handle h, int32_t library_partition);
 int lii_comm_destroy(lii_handle h);
 

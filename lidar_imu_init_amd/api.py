@@ -124,6 +124,7 @@ _DECLS = {
     "lii_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lii_comm_init_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     "lii_comm_transport": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lii_comm_rccl_ranks": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lii_comm_set_partition": (C.c_int, [C.c_void_p, C.c_int32]),
     "lii_comm_destroy": (C.c_int, [C.c_void_p]),
     "lii_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -497,9 +498,10 @@ class Registrar:
         return bytes(buf)
 
     def comm_init(self, n_ranks, rank, uid: bytes, transport="auto"):
-        """transport: "auto" (node-local mailbox when all ranks share the node, else RCCL), "rccl", "mailbox"."""
+        """transport: "auto" (peer-mapped HBM mailbox when all ranks share the node, else the host-memory mailbox, else RCCL),
+        "rccl", "mailbox" (HBM, over HIP IPC), "mailbox_host"."""
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
-        self._check(self.L.lii_comm_init_ex(self.h, n_ranks, rank, buf, {"auto": 0, "rccl": 1, "mailbox": 2}[transport]))
+        self._check(self.L.lii_comm_init_ex(self.h, n_ranks, rank, buf, {"auto": 0, "rccl": 1, "mailbox": 2, "mailbox_host": 3}[transport]))
 
     def comm_set_partition(self, library_partition: bool):
         """True (default): every rank hands over the whole scan, the library splits the down-sampled cloud; False: the
@@ -509,7 +511,13 @@ class Registrar:
     def comm_transport(self) -> str:
         t = C.c_int32(0)
         self._check(self.L.lii_comm_transport(self.h, C.byref(t)))
-        return {0: "none", 1: "rccl", 2: "mailbox"}[t.value]
+        return {0: "none", 1: "rccl", 2: "mailbox", 3: "mailbox_host"}[t.value]
+
+    def comm_rccl_ranks(self) -> int:
+        """ncclCommCount of the attached RCCL communicator (0: no RCCL communicator)."""
+        n = C.c_int32(0)
+        self._check(self.L.lii_comm_rccl_ranks(self.h, C.byref(n)))
+        return int(n.value)
 
     def comm_destroy(self):
         self._check(self.L.lii_comm_destroy(self.h))

@@ -509,6 +509,7 @@ unsigned long long* extent_of_scan(lii_handle h) {
 MailboxView mailbox_view(lii_handle h) {
   MailboxView v;
   v.slots = h->mailbox.dev_slots;
+  v.peers = h->mailbox.d_peers;
   v.seq = h->d_mb_seq;
   v.n_ranks = h->n_ranks;
   v.rank = h->rank;
@@ -576,7 +577,7 @@ void fill_ctrl(lii_handle h, const lii_state* state, const lii_state* state_prop
   hc->seq = h->update_seq;
   // which k-NN launches ride along (IekfCtrl::plan_mask): the first pass always; the others as the previous update needed them
   unsigned int plan = 0xFFFFFFFFu;
-  if (h->knn_plan && !h->comm && h->n_ranks == 1) plan = (h->knn_plan_force >= 0 ? (unsigned int)h->knn_plan_force : h->plan_next) | 1u;
+  if (h->knn_plan && !h->comm) plan = (h->knn_plan_force >= 0 ? (unsigned int)h->knn_plan_force : h->plan_next) | 1u;
   hc->plan_mask = plan;
   h->plan_cur = plan;
 }
@@ -1591,7 +1592,7 @@ void comm_drop(lii_handle h) {
 }
 }  // namespace
 int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128], int32_t transport) {
-  if (!h || !id_in || n_ranks < 1 || rank < 0 || rank >= n_ranks || transport < LII_COMM_AUTO || transport > LII_COMM_MAILBOX)
+  if (!h || !id_in || n_ranks < 1 || rank < 0 || rank >= n_ranks || transport < LII_COMM_AUTO || transport > LII_COMM_MAILBOX_HOST)
     return fail(h, LII_ERR_INVALID, "lii_comm_init: bad arguments");
   HIPCHK(h, hipSetDevice(h->device));
   comm_drop(h);
@@ -1607,8 +1608,15 @@ int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t 
     const char* w = std::getenv("LII_MAILBOX_WAIT_S");
     const double wait_s = w ? std::atof(w) : 20.0;
     std::string why;
-    if (mailbox_open(id_in, n_ranks, rank, wait_s, &h->mailbox, &why) == 0) return LII_OK;
-    if (transport == LII_COMM_MAILBOX) {
+    if (mailbox_open(id_in, n_ranks, rank, wait_s, transport != LII_COMM_MAILBOX_HOST, &h->mailbox, &why) == 0) {
+      if (transport == LII_COMM_MAILBOX && !h->mailbox.d_peers) {  // asked for by name: no silent change of the transport
+        mailbox_close(&h->mailbox);
+        h->n_ranks = 1; h->rank = 0;
+        return fail(h, LII_ERR_COMM, "peer-mapped HBM mailbox unavailable (a rank could not export or open an IPC handle)");
+      }
+      return LII_OK;
+    }
+    if (transport == LII_COMM_MAILBOX || transport == LII_COMM_MAILBOX_HOST) {
       h->n_ranks = 1; h->rank = 0;
       return fail(h, LII_ERR_COMM, "node-local mailbox unavailable: " + why);
     }
@@ -1632,7 +1640,18 @@ int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_
 }
 int lii_comm_transport(lii_handle h, int32_t* transport) {
   if (!h || !transport) return LII_ERR_INVALID;
-  *transport = h->comm ? LII_COMM_RCCL : (h->mailbox.dev_slots ? LII_COMM_MAILBOX : LII_COMM_AUTO);
+  *transport = h->comm ? LII_COMM_RCCL : (h->mailbox.d_peers ? LII_COMM_MAILBOX : (h->mailbox.dev_slots ? LII_COMM_MAILBOX_HOST : LII_COMM_AUTO));
+  return LII_OK;
+}
+int lii_comm_rccl_ranks(lii_handle h, int32_t* n_ranks) {
+  if (!h || !n_ranks) return LII_ERR_INVALID;
+  *n_ranks = 0;
+  if (h->comm) {
+    int n = 0;
+    const ncclResult_t r = ncclCommCount(h->comm, &n);
+    if (r != ncclSuccess) return fail(h, LII_ERR_COMM, std::string("ncclCommCount: ") + ncclGetErrorString(r));
+    *n_ranks = n;
+  }
   return LII_OK;
 }
 int lii_comm_destroy(lii_handle h) {

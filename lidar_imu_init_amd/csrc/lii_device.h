@@ -145,16 +145,22 @@ __device__ __forceinline__ double final_sum_row(const double* __restrict__ row, 
   return total;
 }
 
-// Node-local exchange of the 91 normal-equation scalars between the ranks of one job.  The slots live in
-// a POSIX shared-memory segment that every rank has registered with its own device (fine-grained host memory): rank r owns
-// two slots (parity of the exchange number) of 96 doubles + a sequence flag.  An exchange = write own slot, fence, publish the
-// flag, wait for every rank's flag, sum the slots in rank order (every rank forms the bit-identical sum).  Two parities
-// suffice: a rank can be at most one exchange ahead of the slowest reader.
+// Node-local exchange of the 91 normal-equation scalars between the ranks of one job, inside the
+// reduce+solve launch.  Rank r owns two slots per SOURCE rank (parity of the exchange number) of 96 doubles + a sequence flag.
+// Two homes for the slots:
+//   * in HBM, peer-mapped (the default on one node): every rank allocates fine-grained device memory for the slots it READS
+//     and exports it through a HIP IPC handle; an exchange PUSHES the rank's 91 sums and then the flag into every peer's
+//     memory - remote stores over xGMI, one fabric hop - and polls / sums its own memory only (`peers` != nullptr);
+//   * in a POSIX shared-memory segment that every rank has registered with its own device (host memory over PCIe: the fallback
+//     when the IPC handles cannot be opened): write own slot, publish the flag, poll and read the peers' slots.
+// Either way the slots are summed in rank order (every rank forms the bit-identical sum), and two parities suffice: a rank
+// can be at most one exchange ahead of the slowest reader.
 constexpr int kMailboxSlotDoubles = 128;               // 1 KiB: [0..90] data, [96] sequence flag (as u64)
 constexpr int kMailboxFlagAt = 96;
 constexpr int kMailboxMaxRanks = 64;                   // one polling lane per rank
 struct MailboxView {
-  double* slots;            // device address of the registered segment's slot area; nullptr = no exchange
+  double* slots;            // host-memory form: device address of the registered segment's slot area; nullptr = no exchange
+  double* const* peers;     // HBM form: peers[r] = rank r's slot area as mapped into this process (peers[rank] = the own one)
   unsigned long long* seq;  // device memory: exchanges completed so far (identical on all ranks)
   int n_ranks, rank;
   long long timeout_ticks;  // of the 100 MHz wall clock: how long to wait for a peer that may never arrive
@@ -166,19 +172,36 @@ __device__ inline bool mailbox_allreduce(const MailboxView& mb, const double* in
   const int lane = threadIdx.x & 63;
   const unsigned long long q = *mb.seq + 1ull;
   const int par = (int)(q & 1ull);
-  double* mine = mb.slots + (size_t)(mb.rank * 2 + par) * kMailboxSlotDoubles;
-  for (int i = lane; i < kNormalEq; i += 64)
-    __hip_atomic_store(mine + i, __hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-  __threadfence_system();  // the wavefront's data stores are complete before the flag leaves
-  if (lane == 0)
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine + kMailboxFlagAt), q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  double v0 = 0, v1 = 0;  // this lane's share of the 91 sums
+  if (lane < kNormalEq) v0 = __hip_atomic_load(in + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane + 64 < kNormalEq) v1 = __hip_atomic_load(in + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double* rd;   // where this rank reads the slots from: slot of source rank r at rd + (r * 2 + par) * kMailboxSlotDoubles
+  if (mb.peers) {
+    for (int r = 0; r < mb.n_ranks; r++) {  // push into every rank's memory (the own one included)
+      double* dst = mb.peers[r] + (size_t)(mb.rank * 2 + par) * kMailboxSlotDoubles;
+      if (lane < kNormalEq) __hip_atomic_store(dst + lane, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (lane + 64 < kNormalEq) __hip_atomic_store(dst + lane + 64, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();  // the wavefront's data stores are complete before the flags leave
+    if (lane < mb.n_ranks)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mb.peers[lane] + (size_t)(mb.rank * 2 + par) * kMailboxSlotDoubles + kMailboxFlagAt), q,
+                         __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    rd = mb.peers[mb.rank];
+  } else {
+    double* mine = mb.slots + (size_t)(mb.rank * 2 + par) * kMailboxSlotDoubles;
+    if (lane < kNormalEq) __hip_atomic_store(mine + lane, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane + 64 < kNormalEq) __hip_atomic_store(mine + lane + 64, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (lane == 0)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine + kMailboxFlagAt), q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    rd = mb.slots;
+  }
   const long long t0 = wall_clock64();
   bool ok = true;
   for (;;) {
     unsigned long long v = q;
     if (lane < mb.n_ranks)
-      v = __hip_atomic_load(reinterpret_cast<unsigned long long*>(mb.slots + (size_t)(lane * 2 + par) * kMailboxSlotDoubles + kMailboxFlagAt),
+      v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(rd + (size_t)(lane * 2 + par) * kMailboxSlotDoubles + kMailboxFlagAt),
                             __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (__all(v >= q)) break;
     if (wall_clock64() - t0 > mb.timeout_ticks) { ok = false; break; }
@@ -189,7 +212,7 @@ __device__ inline bool mailbox_allreduce(const MailboxView& mb, const double* in
       double acc = 0;
 #pragma unroll 8
       for (int r = 0; r < mb.n_ranks; r++)
-        acc += __hip_atomic_load(mb.slots + (size_t)(r * 2 + par) * kMailboxSlotDoubles + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        acc += __hip_atomic_load(rd + (size_t)(r * 2 + par) * kMailboxSlotDoubles + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       out[i] = acc;
     }
   }

@@ -38,14 +38,22 @@ void launch_reduce_solve(const RegistrationBuffers& rb, double* out91, unsigned 
 void launch_mailbox_allreduce(double* out91, const MailboxView& mb, hipStream_t s);
 // node-local mailbox (lii_mailbox.cpp)
 struct MailboxHost {
-  void* map = nullptr;        // the shared segment in this process
+  void* map = nullptr;        // the shared segment in this process (rendezvous; in the host-memory form also the slots)
   size_t bytes = 0;
-  double* dev_slots = nullptr;  // device address of its slot area
+  double* dev_slots = nullptr;  // host-memory form: device address of the segment's slot area
   bool registered = false;
   char name[64] = {0};        // non-empty while the segment still has a name to unlink
+  // HBM form: the own slot area (fine-grained device memory, exported through a HIP IPC handle), the peers' areas as opened
+  // here, and the device-resident table of all of them (MailboxView::peers)
+  double* own = nullptr;
+  double* peer_ptr[64] = {nullptr};
+  double** d_peers = nullptr;
+  int n_peers = 0;
 };
 size_t mailbox_segment_bytes(int n_ranks);
-int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, MailboxHost* m, std::string* why);
+// want_hbm: try the peer-mapped HBM form first (falls back to host memory inside the same rendezvous when a rank cannot
+// export / open the handles).  Returns 0 on success (m->d_peers != nullptr: HBM form; else m->dev_slots: host-memory form).
+int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bool want_hbm, MailboxHost* m, std::string* why);
 void mailbox_close(MailboxHost* m);
 void launch_loop_resume(IekfCtrl* c, hipStream_t s);
 void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s);

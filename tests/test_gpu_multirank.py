@@ -1,8 +1,10 @@
-"""Two ranks of one job on the box's single GPU: the node-local mailbox transport (lii_comm_init).
+"""Two ranks of one job on the box's single GPU: the node-local mailbox transports (lii_comm_init).
 
 RCCL refuses two ranks on one device, the mailbox does not care which device a rank drives, so the whole multi-rank
 path - rendezvous in the shared segment, the exchange inside k_reduce_solve, the device-side schedule staying in
-lock-step - runs here exactly as it does with one GPU per rank.  Checked:
+lock-step - runs here exactly as it does with one GPU per rank: in its peer-mapped HBM form (slots in fine-grained device
+memory, exported and opened through HIP IPC handles - between two processes on ONE device here, over xGMI on a multi-GPU
+node) and in its host-memory form.  Checked:
   * both ranks end every scan with the BIT-identical state, report and sums (the sum is formed in rank order on each);
   * they agree with the single-rank run within the re-association of an fp64 sum (1e-11 relative on the sums of the
     first pass, 1e-6 m / rad on the final pose as everywhere in this suite) - WITH the voxel filter on: every rank hands over
@@ -56,10 +58,11 @@ def _run_ranks(tmp_path, world, transport="auto", timeout=300, env=None):
     return [dict(np.load(o)) for o in outs]  # (read now: the archive is opened lazily)
 
 
-def test_two_ranks_meet_in_the_mailbox(tmp_path):
+@pytest.mark.parametrize("transport", ["mailbox", "mailbox_host"])
+def test_two_ranks_meet_in_the_mailbox(tmp_path, transport):
     one = _run_ranks(tmp_path, 1)[0]
-    two = _run_ranks(tmp_path, 2)
-    assert str(two[0]["transport"]) == "mailbox" and str(two[1]["transport"]) == "mailbox"
+    two = _run_ranks(tmp_path, 2, transport=transport)
+    assert str(two[0]["transport"]) == transport and str(two[1]["transport"]) == transport
     for key in ("states", "reports", "sums"):
         assert np.array_equal(two[0][key], two[1][key]), key
     assert np.array_equal(one["reports"][:, [0, 1, 3]], two[0]["reports"][:, [0, 1, 3]])  # iterations, searches, converged
@@ -82,7 +85,8 @@ def test_two_ranks_meet_in_the_mailbox(tmp_path):
 
 
 def test_three_ranks(tmp_path):
-    three = _run_ranks(tmp_path, 3)
+    three = _run_ranks(tmp_path, 3)  # "auto": the peer-mapped HBM mailbox is what three ranks on one node get
+    assert all(str(t["transport"]) == "mailbox" for t in three)
     for r in (1, 2):
         for key in ("states", "reports", "sums", "map_sizes"):
             assert np.array_equal(three[0][key], three[r][key]), key
