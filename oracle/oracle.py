@@ -561,3 +561,65 @@ class RefMath:
 
 def num_procs() -> int:
     return lib().orc_num_procs()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The UNMODIFIED reference src/IMU_Processing.hpp (ImuProcess::Process: IMU forward propagation + de-skew, both modes),
+# built by `make -C oracle ref` against oracle/ref_shim_imu + oracle/ref_shim_math (oracle/ref_imu_wrap.cpp).
+_ref_imu = None
+
+
+def ref_imu_lib():
+    """None when oracle/_ref/libref_imu.so was never built."""
+    global _ref_imu
+    if _ref_imu is None:
+        path = os.path.join(_HERE, "_ref", "libref_imu.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        D, F, I = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.ref_imu_process_lio.restype = C.c_int
+        L.ref_imu_process_lio.argtypes = [D, C.c_int, D, C.c_double, D, D, C.c_double, C.c_double, C.c_int, D, F, C.c_int, D, C.c_int, I, D]
+        L.ref_imu_process_cv.restype = C.c_int
+        L.ref_imu_process_cv.argtypes = [C.c_double, C.c_double, C.c_int, D, C.c_int, D, F, C.c_int]
+        _ref_imu = L
+    return _ref_imu
+
+
+def ref_imu_process_lio(imu, last_imu, last_lidar_end_time, acc_s_last, angvel_last, cov_gyr, cov_acc, mean_acc_norm, lidar_beg_time,
+                        state_pod, pts4, lidar_type=OUSTER):
+    """One LIO-mode ImuProcess::Process call of the reference.  imu: (n, 7) rows (t, gyr, acc); last_imu: (7,).  Returns
+    dict(state = propagated lii_state POD, points = de-skewed cloud in the reference's (time-sorted) order, poses = IMUpose table
+    (K, 22), acc_s_last, angvel_last, last_lidar_end_time)."""
+    L = ref_imu_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libref_imu.so is not built")
+    imu = np.ascontiguousarray(imu, np.float64).reshape(-1, 7)
+    st = np.ascontiguousarray(state_pod, np.float64).copy()
+    p = _f32(pts4, 4).copy()
+    poses = np.zeros((len(imu) + 4, 22))
+    n_poses = C.c_int(0)
+    carry = np.r_[_f64(acc_s_last), _f64(angvel_last)]
+    carry_out = np.zeros(7)
+    rc = L.ref_imu_process_lio(_dp(imu), len(imu), _dp(_f64(last_imu)), C.c_double(last_lidar_end_time), _dp(carry),
+                               _dp(np.r_[_f64(cov_gyr), _f64(cov_acc)]), C.c_double(mean_acc_norm), C.c_double(lidar_beg_time),
+                               int(lidar_type), _dp(st), _fp(p), len(p), _dp(poses), len(poses), C.byref(n_poses), _dp(carry_out))
+    if rc != 0:
+        raise RuntimeError(f"ref_imu_process_lio failed ({rc})")
+    return dict(state=st, points=p, poses=poses[:n_poses.value].copy(), acc_s_last=carry_out[0:3].copy(), angvel_last=carry_out[3:6].copy(),
+                last_lidar_end_time=float(carry_out[6]))
+
+
+def ref_imu_process_cv(lidar_beg_time, time_last_scan, first_frame, cov_gyr_scale, cov_acc_scale, state_pod, pts4, lidar_type=OUSTER):
+    """One LO-mode (imu_en = false) ImuProcess::Process call of the reference: constant-velocity propagation + de-skew.  Returns
+    (propagated state POD, de-skewed cloud in the reference's time-sorted order)."""
+    L = ref_imu_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libref_imu.so is not built")
+    st = np.ascontiguousarray(state_pod, np.float64).copy()
+    p = _f32(pts4, 4).copy()
+    rc = L.ref_imu_process_cv(C.c_double(lidar_beg_time), C.c_double(time_last_scan), int(bool(first_frame)),
+                              _dp(np.r_[_f64(cov_gyr_scale), _f64(cov_acc_scale)]), int(lidar_type), _dp(st), _fp(p), len(p))
+    if rc != 0:
+        raise RuntimeError(f"ref_imu_process_cv failed ({rc})")
+    return st, p
