@@ -106,7 +106,13 @@ int lii_synchronize(lii_handle h);
  * The map is a point SET kept on the device and updated in place: lii_map_download returns it in no particular order;
  * an update is enqueued, not waited for (lii_map_size / lii_map_download / lii_map_add_points' counter read the device).
  * LII_ERR_CAPACITY: n_valid + batch would exceed lii_config::max_map_points - tested BEFORE the batch is applied, counting
- * every point of it; the map is left as it was. */
+ * every point of it; the map is left as it was.  The in-place layout keeps slack behind every cell (count + max(2, count / 4)
+ * slots) and moves a cell that outgrows it to the tail of a point array of 3 * max_map_points + 65 536 slots: a SPARSE map (many
+ * one-point cells: 3 slots each) close to max_map_points can need a rebuild on almost every update, and a batch of b inserts asks
+ * for 8 b + 4 096 free tail slots after a rebuild - if even the rebuilt map cannot offer them the call fails with
+ * LII_ERR_CAPACITY ("no room left behind the cells") although n_valid + b <= max_map_points.  Size max_map_points with ~25 %
+ * headroom over the largest map expected.  An update that runs out of provisioned room while it executes loses nothing: the
+ * inserts it could not place are parked and re-inserted by a rebuild before the next search or update uses the map. */
 int lii_map_reset(lii_handle h);
 int lii_map_build(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes);
 int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes, int32_t downsample_on,
@@ -127,6 +133,16 @@ int lii_map_commit(lii_handle h);
  * lii_scan_set_device: same, from a device-resident float4 buffer (copied on the handle's stream by the kernel that also
  *                  reduces the scan's time extent; the caller's buffer is only read and free again once a later call on
  *                  the handle has returned).
+ * ORDER OF THE POINTS.  The reference sorts every scan by time before it de-skews it (std::sort by curvature,
+ *                  src/IMU_Processing.hpp:209, :287; its preprocess hands the scan over sorted as well,
+ *                  src/preprocess.cpp:296-302) and everything downstream sees that order.  The library does NOT sort: the
+ *                  de-skew itself does not need it (the time-earliest point is found by a reduction), but the voxel-grid
+ *                  centroids are float sums in input order, so results are bit-identical to the reference's only for a
+ *                  scan handed over in ascending time order (equal stamps in the reference's order) - which is what
+ *                  lii_ingest_* / lii_frame_select deliver.  An unsorted scan is registered correctly up to the rounding of
+ *                  those sums (~1e-6 m per centroid).  The voxel filter emits the down-sampled cloud in the order of the
+ *                  voxels' first points; lii_scan_download(1 / 2) and lii_neighbors_download return the reference's order
+ *                  (ascending PCL voxel index).
  * lii_undistort_imu <- back-propagation loop of ImuProcess::propagation_and_undist, src/IMU_Processing.hpp:390-414
  * lii_undistort_cv  <- CV de-skew of Forward_propagation_without_imu,            src/IMU_Processing.hpp:246-266
  * lii_downsample    <- downSizeFilterSurf.filter(*feats_down_body),              src/laserMapping.cpp:917-919

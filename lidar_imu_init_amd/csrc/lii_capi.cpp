@@ -138,6 +138,9 @@ struct lii_context {
   bool have_search = false;
   int knn_variant = 0;   // search pass: 0 = packed keys (k_knn_pk); 5 = exact lists throughout (k_knn_exact, its reference form) -
                          // LII_KNN_VARIANT selects
+  int* h_mapflag = nullptr;       // pinned: kMapCtrOverflow of the last in-place update (commit_map)
+  hipEvent_t ev_mapflag = nullptr;
+  bool map_flag_pending = false;
   bool diag = false;     // LII_DIAG=1: counters of the rare paths on stderr when the handle is destroyed
 
   // ---- pinned staging
@@ -321,7 +324,19 @@ int build_index(lii_handle h, int n, int extra_blocks = 0) {
   return rc;
 }
 
-int commit_map(lii_handle) { return LII_OK; }  // the device map is always current
+// The device map is always current - unless the last in-place update ran out of provisioned room and parked some of its inserts
+// (kMapCtrOverflow): a search must not run against that map (the parked points are missing from it, and which ones they are
+// depends on the order of the update's atomics - the replicated maps of a sharded job would drift apart).  Every update sends
+// its overflow flag to pinned memory behind its kernels (no synchronisation there); whoever searches next looks at it - by then
+// it has long arrived - and only an update that did overflow pays for settling (rebuild + re-insertion of the parked points).
+int map_counters(lii_handle h, bool already_synced);
+int commit_map(lii_handle h) {
+  if (!h->map_dirty || !h->map_flag_pending) return LII_OK;
+  HIPCHK(h, hipEventSynchronize(h->ev_mapflag));
+  h->map_flag_pending = false;
+  if (*h->h_mapflag == 0) return LII_OK;
+  return map_counters(h, false);
+}
 
 // Host copies of the device counters (one small synchronising read).  An update in flight that ran out of room (block tables,
 // slack + tail of the point array) has parked the inserts it could not place in d_dropped: the index is rebuilt with more room
@@ -330,6 +345,7 @@ int commit_map(lii_handle) { return LII_OK; }  // the device map is always curre
 int map_rebuild(lii_handle h, int extra_blocks);
 int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra);
 int map_counters(lii_handle h, bool already_synced = false) {
+  h->map_flag_pending = false;
   if (!h->map_dirty) return LII_OK;
   if (!already_synced) {
     HIPCHK(h, hipMemcpyAsync(h->h_small + 3072, h->d_mapctr, sizeof(int) * kMapCtrWords, hipMemcpyDeviceToHost, h->stream));
@@ -442,7 +458,10 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
   launch_ins_write(list_a, h->d_ins_e, n_list, nullptr, extra, h->d_ins_e2, n_extra, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, h->d_dropped,
                    h->drop_cap, s);
   HIPCHK(h, hipGetLastError());
-  // the block table may have grown: kernels launched from now on must see it (grid_view reads the host copy of the mask only)
+  // the update's overflow flag travels to the host behind its kernels (see commit_map)
+  HIPCHK(h, hipMemcpyAsync(h->h_mapflag, h->d_mapctr + kMapCtrOverflow, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipEventRecord(h->ev_mapflag, s));
+  h->map_flag_pending = true;
   return LII_OK;
 }
 
@@ -870,6 +889,9 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   std::memset(h->h_res, 0, sizeof(IekfResult));
   CK(hipEventCreateWithFlags(&h->ev_poses, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&h->ev_mapflag, hipEventDisableTiming));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_mapflag), 64, hipHostMallocDefault));
+  *h->h_mapflag = 0;
   CK(hipMemset(h->d_counter, 0, 16));
   h->partial_stride = register_blocks(int(N)) + 8;
   CK(dmalloc(&h->d_partials, size_t(h->partial_stride) * kNormalEq));
@@ -949,6 +971,8 @@ int lii_destroy(lii_handle h) {
   if (h->h_res) (void)hipHostFree(h->h_res);
   if (h->ev_poses) (void)hipEventDestroy(h->ev_poses);
   if (h->ev_stage) (void)hipEventDestroy(h->ev_stage);
+  if (h->ev_mapflag) (void)hipEventDestroy(h->ev_mapflag);
+  if (h->h_mapflag) (void)hipHostFree(h->h_mapflag);
   if (h->n_map_pinned) (void)hipHostFree(h->n_map_pinned);
   for (int i = 0; i < 4; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -1027,7 +1051,9 @@ int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int3
   const int n_old = h->n_map;
   if (n_boxes == 0 || n_old == 0) return LII_OK;
   hipStream_t s = h->stream;
-  float* d_boxes = reinterpret_cast<float*>(h->d_keys_b);  // scratch of the index build, free between calls
+  float* d_boxes = reinterpret_cast<float*>(h->d_keys_b);  // scratch of the index build (max_map_points * 8 bytes), free between calls
+  if (size_t(n_boxes) * 24 > size_t(h->cfg.max_map_points) * 8)
+    return fail(h, LII_ERR_INVALID, "lii_map_delete_boxes: more boxes than the handle's scratch holds (max_map_points / 3)");
   std::memcpy(h->h_small + 4096, boxes, sizeof(float) * 6 * size_t(n_boxes));
   HIPCHK(h, hipMemcpyAsync(d_boxes, h->h_small + 4096, sizeof(float) * 6 * size_t(n_boxes), hipMemcpyHostToDevice, s));
   // in place: every cell walks its live points, the cells that lose points squeeze them out (k_cell_apply)

@@ -72,12 +72,14 @@ __device__ bool gj12(double (&col)[H]) {
 }
 
 __device__ void d_m3_mul(const double* A, const double* B, double* C) {
+#pragma clang fp contract(off)  // this unit is built with -ffp-contract=fast; the SO(3) helpers keep the reference's rounding (so3_math.h)
   double t[9];
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) t[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
   for (int e = 0; e < 9; e++) C[e] = t[e];
 }
 __device__ void d_m3t_mul(const double* A, const double* B, double* C) {
+#pragma clang fp contract(off)  // this unit is built with -ffp-contract=fast; the SO(3) helpers keep the reference's rounding (so3_math.h)
   double t[9];
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) t[3 * r + c] = A[r] * B[c] + A[3 + r] * B[3 + c] + A[6 + r] * B[6 + c];
@@ -85,6 +87,7 @@ __device__ void d_m3t_mul(const double* A, const double* B, double* C) {
 }
 // Exp(v1,v2,v3) — so3_math.h:61-79 (identity below 1e-5)
 __device__ void d_so3_exp(double v1, double v2, double v3, double* R) {
+#pragma clang fp contract(off)  // this unit is built with -ffp-contract=fast; the SO(3) helpers keep the reference's rounding (so3_math.h)
   double n = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
   for (int e = 0; e < 9; e++) R[e] = (e % 4 == 0) ? 1.0 : 0.0;
   if (n > 0.00001) {
@@ -98,6 +101,7 @@ __device__ void d_so3_exp(double v1, double v2, double v3, double* R) {
   }
 }
 __device__ void d_so3_log(const double* R, double* out) {
+#pragma clang fp contract(off)  // this unit is built with -ffp-contract=fast; the SO(3) helpers keep the reference's rounding (so3_math.h)
   double tr = R[0] + R[4] + R[8];
   double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
   double K[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};

@@ -458,7 +458,12 @@ __global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int*
   const unsigned long long bk = d_pack_block(bx, by, bz);
   unsigned int sl = m_hash_block(bx, by, bz) & mask;
   long long id = -1;
-  for (unsigned int probes = 0; probes <= mask; probes++) {
+  // One loop, no waiting inside it: a lane that finds its block's key but not yet its id (another lane - possibly of this very
+  // wavefront - is creating the block) goes round the loop again on the SAME slot.  The lanes of a wavefront execute the loop
+  // body together, so the creator's stores are issued in the round in which it wins the slot and the waiter sees them in the
+  // next one; an inner spin loop would depend on the order in which the compiler lays out the two branches (wavefronts have
+  // no independent thread scheduling).
+  for (unsigned int probes = 0; probes <= mask;) {
     unsigned long long k = __hip_atomic_load(&blocks[sl].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k == kEmptyKey) {
       // A slot of the block table is reserved before it is claimed: the table must keep a free slot, or probes for blocks that
@@ -485,13 +490,17 @@ __global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int*
       atomicSub(&ctr[kMapCtrSlots], 1);  // somebody else took the slot
       k = prev;
     }
-    if (k == bk) {  // somebody else may be creating it right now: wait for the id
-      while (__hip_atomic_load(&blocks[sl].pad, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
-      const unsigned int got = __hip_atomic_load(&blocks[sl].id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      id = got + 1u == tables_cap ? -1 : (long long)got;  // (the shared empty table: its creator found the pool exhausted)
-      break;
+    if (k == bk) {
+      if (__hip_atomic_load(&blocks[sl].pad, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        const unsigned int got = __hip_atomic_load(&blocks[sl].id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        id = got + 1u == tables_cap ? -1 : (long long)got;  // (the shared empty table: its creator found the pool exhausted)
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);  // the id is on its way: look at this slot again
+      continue;
     }
     sl = (sl + 1) & mask;
+    probes++;
   }
   if (id < 0) {  // no table left for a new block: the point waits in the dropped list for the host's rebuild (nothing is lost)
     ins_e[i] = 0xFFFFFFFFu;

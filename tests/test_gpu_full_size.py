@@ -62,6 +62,15 @@ def test_full_size_properties(big, oracle, sensor):
     assert np.array_equal(cnt[idx], rc)
     m = rc == 5
     assert np.array_equal(nb[idx][m], pts[m])
+    # (3b) ... and with the UNMODIFIED reference ikd-Tree (oracle/_ref) on EVERY query of the OS1-128 scan against the 1 M-point map
+    if sensor == "os1_128" and oracle.ref_available():
+        rt = oracle.Tree("ref")
+        rt.build(map_pts)
+        rp, _, rcnt = rt.knn(world, threads=8)
+        rt.close()
+        assert np.array_equal(cnt, rcnt)
+        m = rcnt == 5
+        assert np.array_equal(nb[m], rp[m])
     # (4) linearity over shards: the normal equations of two halves add up to those of the whole scan
     total = np.zeros(91)
     for r in range(2):
