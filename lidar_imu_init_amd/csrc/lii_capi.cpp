@@ -122,11 +122,16 @@ struct lii_context {
   unsigned int *d_vpcl_in = nullptr, *d_vpcl_out = nullptr;  // PCL voxel index per input point / per output voxel
   VoxelHashBuffers vh = {};      // the voxel grid by hashing (the default; LII_VOXEL_FILTER=sort: the sample sort)
   unsigned char* d_vh_first = nullptr;
-  bool voxel_sort = false;
-  bool coherent_order = false;   // LII_VOXEL_ORDER=brick: the voxel filter emits brick-major (Morton) order instead of the PCL
-                                 // index order (what the LDS-tiled search needs; the default search gains 10 % from it, the
-                                 // completion of the flagged searches inside the fit kernel loses more: they cluster)
-  bool body_reordered = false;   // d_body is in brick order: the download entry points restore the PCL order (pcl_perm)
+  bool voxel_sort = false;       // LII_VOXEL_FILTER=sort
+  bool vh_pinned = false;        // LII_VOXEL_FILTER=hash: no probing
+  int vh_mode = 1;               // 1: sparse voxels (hashed filter), 0: crowded voxels (sample sort)
+  float vh_leaf = -1.f;          // the leaf size the choice was probed for
+  unsigned int vh_watch = 0;
+  bool voxel_path_hash = false;  // the path the last filter took
+  unsigned int* h_vh_crowded = nullptr;  // pinned: VoxelHashBuffers::crowded of the last hashed filter (read lazily)
+  hipEvent_t ev_vh = nullptr;
+  bool vh_flag_pending = false;
+  bool body_reordered = false;   // d_body is in the order of the voxels' first points: the download entry points restore the PCL order (pcl_perm)
   std::vector<int> pcl_perm;     // pcl_perm[r] = position in d_body of the r-th point in PCL order (valid while pcl_perm_valid)
   bool pcl_perm_valid = false;
   double* d_poses = nullptr;
@@ -482,7 +487,7 @@ int resolve_n_body(lii_handle h) {
   return LII_OK;
 }
 
-// The down-sampled cloud lives on the device in brick order (k_voxel_keys: coherent_key); the reference's filter emits it
+// The down-sampled cloud lives on the device in the order of the voxels' first points (k_vhash_emit); the reference's filter emits it
 // ascending in the PCL voxel index.  Every entry point that hands per-point data of the down-sampled cloud to the host
 // (lii_scan_download 1 / 2, lii_neighbors_download) restores that order: perm[r] = device position of the r-th point in PCL
 // order, from the PCL index kept per output voxel (distinct per voxel).  Host work, off the per-scan path.
@@ -792,13 +797,19 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   h->cell_size = std::max(h->cell_size, std::sqrt(h->cfg.max_match_dist2) / 8.0f * 1.001f);
   if (const char* v = std::getenv("LII_KNN_VARIANT")) h->knn_variant = std::atoi(v);  // A/B knob for profiling
   if (const char* v = std::getenv("LII_DIAG")) h->diag = std::atoi(v) != 0;
-  if (const char* v = std::getenv("LII_VOXEL_ORDER")) h->coherent_order = std::string(v) == "brick";
-  if (const char* v = std::getenv("LII_VOXEL_FILTER")) h->voxel_sort = std::string(v) == "sort";
+  if (const char* v = std::getenv("LII_VOXEL_FILTER")) {
+    h->voxel_sort = std::string(v) == "sort";
+    if (std::string(v) == "hash") { h->vh_pinned = true; h->vh_mode = 1; }
+  }
   if (const char* v = std::getenv("LII_HOST_SOLVE")) h->host_solve = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_SYNC_RESULT")) h->poll_result = std::atoi(v) == 0;
-  if (const char* v = std::getenv("LII_MAP_TEST_TIGHT")) h->map_tight = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_KNN_PLAN")) h->knn_plan = std::atoi(v) != 0;
-  if (const char* v = std::getenv("LII_KNN_PLAN_FORCE")) h->knn_plan_force = int(std::strtol(v, nullptr, 0) & 0x7FFFFFFF);
+  if (const char* v = std::getenv("LII_TEST")) {  // hooks of the test-suite: "map_tight" (an in-place map update without spare room),
+    const std::string t(v);                        // "plan_force=<mask>" (a launch plan that is wrong on purpose)
+    h->map_tight = t.find("map_tight") != std::string::npos;
+    const size_t q = t.find("plan_force=");
+    if (q != std::string::npos) h->knn_plan_force = int(std::strtol(t.c_str() + q + 11, nullptr, 0) & 0x7FFFFFFF);
+  }
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;
 #define CK(call)                                                                  \
@@ -921,6 +932,11 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     CK(dmalloc(&h->vh.members, slots * 7));
     CK(dmalloc(&h->vh.slot_of, N)); CK(dmalloc(&h->vh.next, N)); CK(dmalloc(&h->vh.block_firsts, N / 256 + 8));
     CK(dmalloc(&h->d_vh_first, N));
+    CK(dmalloc(&h->vh.crowded, 4));
+    CK(hipMemset(h->vh.crowded, 0, 16));
+    CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_vh_crowded), 64, hipHostMallocDefault));
+    *h->h_vh_crowded = 0;
+    CK(hipEventCreateWithFlags(&h->ev_vh, hipEventDisableTiming));
     h->vh.is_first = h->d_vh_first;
     CK(hipMemset(h->vh.key, 0xFF, 4 * slots)); CK(hipMemset(h->vh.first, 0xFF, 4 * slots)); CK(hipMemset(h->vh.head, 0xFF, 4 * slots));
     CK(hipMemset(h->vh.count, 0, 4 * slots));
@@ -960,7 +976,7 @@ int lii_destroy(lii_handle h) {
   void* dev[] = {h->d_dropped, h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
-                 h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->vh.key, h->vh.first, h->vh.count, h->vh.head, h->vh.members, h->vh.slot_of, h->vh.next, h->vh.block_firsts, h->d_vh_first, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
+                 h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->vh.key, h->vh.first, h->vh.count, h->vh.head, h->vh.members, h->vh.slot_of, h->vh.next, h->vh.block_firsts, h->vh.crowded, h->d_vh_first, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -972,6 +988,8 @@ int lii_destroy(lii_handle h) {
   if (h->ev_poses) (void)hipEventDestroy(h->ev_poses);
   if (h->ev_stage) (void)hipEventDestroy(h->ev_stage);
   if (h->ev_mapflag) (void)hipEventDestroy(h->ev_mapflag);
+  if (h->ev_vh) (void)hipEventDestroy(h->ev_vh);
+  if (h->h_vh_crowded) (void)hipHostFree(h->h_vh_crowded);
   if (h->h_mapflag) (void)hipHostFree(h->h_mapflag);
   if (h->n_map_pinned) (void)hipHostFree(h->n_map_pinned);
   for (int i = 0; i < 4; i++)
@@ -1279,23 +1297,69 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
     h->mm_sel ^= 1;
     launch_voxel_minmax(h->d_scan, n, mm, h->d_mm + 8 * h->mm_sel, s);
   }
-  if (!h->voxel_sort) {
-    launch_voxel_hash(h->vh, h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_body, h->d_nbody, h->d_nbody + 1, h->d_vpcl_out, s);
+  // Which filter: the hashed one orders the members of a voxel by repeated selection - right for the few points per voxel of a
+  // leaf matched to the sensor (the shipped configurations: leaf 0.05), quadratic for a voxel of hundreds.  The first scan of
+  // a leaf size is probed: its table is built, the longest member list (VoxelHashBuffers::crowded) read back - the one wait of
+  // this function, once per leaf size - and the scan goes on through the hashed emit or through the sample sort.  After that
+  // the counter is read behind the filter now and then (the sort reports its largest voxel the same way) and the handle
+  // changes over when the voxels fill up or thin out in the middle of a run.  LII_VOXEL_FILTER=sort | hash pins the choice.
+  if (h->vh_flag_pending && hipEventQuery(h->ev_vh) == hipSuccess) {
+    h->vh_flag_pending = false;
+    if (h->vh_mode == 0 && *h->h_vh_crowded <= 32u) h->vh_mode = 1;         // sparse again -> hash
+    else if (h->vh_mode == 1 && *h->h_vh_crowded > 64u) h->vh_mode = 0;     // crowded -> the sort
+  }
+  int hash_stages = 3;
+  if (!h->vh_pinned && !h->voxel_sort && leaf != h->vh_leaf) {
+    h->vh_leaf = leaf;
+    h->vh_flag_pending = false;
+    HIPCHK(h, hipMemsetAsync(h->vh.crowded, 0, sizeof(unsigned int), s));
+    launch_voxel_hash(h->vh, h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_body, h->d_nbody, h->d_nbody + 1, h->d_vpcl_out, 1, s);
+    HIPCHK(h, hipMemcpyAsync(h->h_vh_crowded, h->vh.crowded, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemsetAsync(h->vh.crowded, 0, sizeof(unsigned int), s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    h->vh_mode = *h->h_vh_crowded > 32u ? 0 : 1;
+    hash_stages = 2;
+    if (h->vh_mode == 0) {  // the emit would have left the table clean for the next scan; the sort does not know of it
+      const size_t slots = voxel_hash_slots(n);  // (the slots this scan could have touched)
+      HIPCHK(h, hipMemsetAsync(h->vh.key, 0xFF, 4 * slots, s));
+      HIPCHK(h, hipMemsetAsync(h->vh.first, 0xFF, 4 * slots, s));
+      HIPCHK(h, hipMemsetAsync(h->vh.head, 0xFF, 4 * slots, s));
+      HIPCHK(h, hipMemsetAsync(h->vh.count, 0, 4 * slots, s));
+    }
+  }
+  const bool use_hash = h->vh_mode == 1 && !h->voxel_sort;
+  h->voxel_path_hash = use_hash;
+  if (use_hash) {
+    launch_voxel_hash(h->vh, h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_body, h->d_nbody, h->d_nbody + 1, h->d_vpcl_out, hash_stages, s);
+    if (!h->vh_pinned && !h->vh_flag_pending && (++h->vh_watch & 15) == 0) {  // (every 16th scan: the copy costs a packet on the stream)
+      HIPCHK(h, hipMemcpyAsync(h->h_vh_crowded, h->vh.crowded, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+      HIPCHK(h, hipMemsetAsync(h->vh.crowded, 0, sizeof(unsigned int), s));
+      HIPCHK(h, hipEventRecord(h->ev_vh, s));
+      h->vh_flag_pending = true;
+    }
   } else {
     const VoxelSortPlan plan = voxel_sort_plan(n);
-    launch_voxel_keys(h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_vkeys_a, h->d_vpcl_in, h->coherent_order ? 1 : 0,
+    launch_voxel_keys(h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_vkeys_a, h->d_vpcl_in,
                       h->d_nbody + 1, plan.samples ? h->d_vsplit + 2048 : nullptr, plan.width, s);
     VoxelSortBuffers vb;
     vb.pcl_in = h->d_vpcl_in; vb.pcl_out = h->d_vpcl_out;
     vb.samples = h->d_vsplit + 2048;
     vb.keys_in = h->d_vkeys_a; vb.keys_out = h->d_vkeys_b; vb.idx_out = h->d_vidx_b;
     vb.comp = h->d_vcomp; vb.splitters = h->d_vsplit; vb.hist = h->d_vhist; vb.bucket_of = h->d_vbucket;
+    vb.max_run = h->voxel_sort ? nullptr : h->vh.crowded;
+    if (!h->voxel_sort) HIPCHK(h, hipMemsetAsync(h->vh.crowded, 0, sizeof(unsigned int), s));
     launch_voxel_sort_centroids(vb, h->d_scan, n, h->d_body, h->d_nbody, s);
+    if (!h->voxel_sort && !h->vh_flag_pending && (++h->vh_watch & 15) == 0) {  // how crowded are the voxels now?
+      HIPCHK(h, hipMemcpyAsync(h->h_vh_crowded, h->vh.crowded, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+      HIPCHK(h, hipMemsetAsync(h->vh.crowded, 0, sizeof(unsigned int), s));
+      HIPCHK(h, hipEventRecord(h->ev_vh, s));
+      h->vh_flag_pending = true;
+    }
   }
   HIPCHK(h, hipGetLastError());
   h->n_body = n;  // upper bound until resolved
   h->n_body_pending = true;
-  h->body_reordered = h->coherent_order || !h->voxel_sort;  // (the hashed filter emits the voxels in the order of their first points)
+  h->body_reordered = use_hash;  // (the hashed filter emits the voxels in the order of their first points)
   h->pcl_perm_valid = false;
   if (n_down || filtered) {
     int rc = resolve_n_body(h);

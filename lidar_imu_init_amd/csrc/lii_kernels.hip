@@ -20,10 +20,7 @@
 #include <math.h>
 #include <cstdlib>
 #include <stdint.h>
-#include <algorithm>
-#include <cstdio>
 #include <utility>
-#include <vector>
 
 #include "lii_device.h"
 
@@ -785,15 +782,14 @@ __device__ __forceinline__ T pick_by_lane(const T (&arr)[N], int sub) {
 // forced < 0: device-driven loop — pose from `pose` (the control block), runs only when the control block says the next pass
 // searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).  An executed pass leaves its pose in
 // `search_pose_out` (may be null).
-// LPQ = lanes per query; NB = candidate loads a lane keeps in flight (one batch).  diag / wlog: timing experiments (LII_KNN_DIAG).
+// LPQ = lanes per query (4: the product form; 2 and 1 compile and are exact as well - fewer instructions in total, longer chains
+// per wavefront: slower, profiles/r03_knn_ab.md); NB = candidate loads a lane keeps in flight (one batch).
 template <int LPQ, int BS, int NB, int WPE>
 __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuffers rb, PoseArg ps_val, const PoseArg* __restrict__ pose,
                                                const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
-                                               double* __restrict__ search_pose_out, int diag,
-                                               unsigned long long* __restrict__ wlog) {
+                                               double* __restrict__ search_pose_out) {
   using G = PkGeom<LPQ>;
   __shared__ uint2 s_rng[2 * G::MAXPASS * BS];
-  const long long t_start = wlog ? wall_clock64() : 0;
   // the pose sits in the control block: its load goes out together with the flags instead of after the branch on them
   const PoseArg ps = forced != 1 ? *pose : ps_val;
   int lo, n_live;
@@ -870,7 +866,7 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
   {
     const float ub5 = L.k4 != kPkInf ? __uint_as_float(L.k4 | kPkPosMask) : INF;
     const float bound = fminf(ub5, g.max_d2);
-    const bool need2 = fast && !(bound <= g0sq) && !(diag & 128);
+    const bool need2 = fast && !(bound <= g0sq);
     if (__any(need2)) {
       // per axis the squared gaps to the three cell slabs, then 27 sums against the bound (every lane of the group computes the
       // same mask; the 8 cells of round 1 are masked out)
@@ -1037,15 +1033,6 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
     }
     if (sub == (LPQ > 1 ? 1 : 0)) rb.nbr_count[qi] = found | (need ? kNeedy : 0);
     if (sub == (LPQ == 4 ? 2 : 0)) rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-  }
-  unsigned int wmax = 0;
-  if (wlog) {
-    wmax = fast ? n1 : 0u;
-    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (unsigned)__shfl_xor((int)wmax, o));
-  }
-  if (wlog && (threadIdx.x & 63) == 0) {
-    const int wid = blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
-    wlog[3 * wid] = (unsigned long long)t_start; wlog[3 * wid + 1] = (unsigned long long)wall_clock64(); wlog[3 * wid + 2] = (__any(used2) ? 1ull : 0ull) | ((unsigned long long)wmax << 8);
   }
 }
 
@@ -1247,11 +1234,7 @@ __device__ __forceinline__ void complete_flagged(const GridView& g, const Regist
   __syncthreads();
   if (live && (rb.nbr_count[my_point] & kNeedy)) s_needy[atomicAdd(s_nneedy, 1)] = my_point;
   __syncthreads();
-#ifdef LII_DIAG_SKIP_NEEDY  // diagnostic build only: how much of the search-pass fit kernel is the completion of flagged searches
-  const int nn = 0;
-#else
   const int nn = *s_nneedy;
-#endif
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int e = wave; e < nn; e += kBlock / 64) {
     const int qi = s_needy[e];
@@ -1654,8 +1637,6 @@ struct VoxelArg {
   int min_b[3];
   int mul[3];
   int identity;  // PCL's int32 index-overflow guard tripped: output = input
-  int w[3];      // coherent sort key: bits of the 8-voxel brick coordinate per axis; coherent = 0: sort by the PCL index itself
-  int coherent;
 };
 // Derives the voxel-grid parameters from the min/max reduction ON THE DEVICE (no host round trip), in every thread of the
 // key kernel (six loads + a few flops — cheaper than a launch of its own):
@@ -1684,39 +1665,14 @@ __device__ __forceinline__ VoxelArg voxel_prepare(const unsigned int* __restrict
         div_b[a] = (int)floorf(mx[a] * v.inv_leaf) - v.min_b[a] + 1;
       }
       v.mul[0] = 1; v.mul[1] = div_b[0]; v.mul[2] = div_b[0] * div_b[1];
-      int bits = 9;
-      for (int a = 0; a < 3; a++) {
-        const int nb = div_b[a] > 1 ? 32 - __clz(div_b[a] - 1) : 0;  // bits of the largest voxel coordinate
-        v.w[a] = nb > 3 ? nb - 3 : 0;
-        bits += v.w[a];
-      }
-      // dx dy dz < 2^31 bounds the sum of the rounded-up axis widths by 34 bits: always below the kVoxKeyBits of the sort key
-      v.coherent = bits < kVoxKeyBits ? 1 : 0;
     }
   }
   return v;
 }
-// Sort key of a voxel that keeps space together: Morton order over 8x8x8-voxel bricks (bits interleaved z, y, x from the top,
-// an axis joining in once its width is reached), the voxel's 9 bits inside the brick below.  Injective on the voxels of the
-// grid, so the groups - and with them the centroids, bit for bit - are those of the PCL index; only the ORDER in which the
-// down-sampled cloud comes out differs: consecutive points are neighbours in space, which is what lets the search pass stage
-// map tiles in LDS for a block of queries (k_knn_tile).  The PCL order is restored by the download entry points
-// (lii_capi.cpp: pcl_order) from the PCL index kept per output point.
-__device__ __forceinline__ unsigned long long coherent_key(const VoxelArg& v, int i0, int i1, int i2) {
-  const int h[3] = {i0 >> 3, i1 >> 3, i2 >> 3};
-  const int maxw = max(v.w[0], max(v.w[1], v.w[2]));
-  unsigned long long m = 0;
-  for (int b = maxw - 1; b >= 0; b--) {
-#pragma unroll
-    for (int a = 2; a >= 0; a--)
-      if (b < v.w[a]) m = (m << 1) | (unsigned long long)((h[a] >> b) & 1);
-  }
-  return (m << 9) | (unsigned long long)(((i2 & 7) << 6) | ((i1 & 7) << 3) | (i0 & 7));
-}
 __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ pts, int n, const unsigned int* __restrict__ mm,
                                                     const unsigned int* __restrict__ bbox_rows, int n_rows, float leaf,
                                                     unsigned long long* __restrict__ keys, unsigned int* __restrict__ pcl_keys,
-                                                    int coherent_order, int* __restrict__ filtered,
+                                                    int* __restrict__ filtered,
                                                     unsigned long long* __restrict__ samples, int sample_width) {
   __shared__ unsigned int s_mm[8];
   if (n_rows > 0) {  // the box arrives as one row per de-skew workgroup: every workgroup folds them for itself (a few KB from L2)
@@ -1745,7 +1701,7 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ p
     int i1 = (int)(floorf(p.y * v.inv_leaf) - (float)v.min_b[1]);
     int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)v.min_b[2]);
     pcl = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);
-    key = (coherent_order && v.coherent) ? coherent_key(v, i0, i1, i2) : pcl;
+    key = pcl;
   }
   keys[i] = key;
   pcl_keys[i] = pcl;
@@ -1832,9 +1788,12 @@ __global__ __launch_bounds__(256) void k_vhash_insert(const float4* __restrict__
   }
   slot_of[i] = slot;
 }
+// *crowded: the largest number of members a voxel has collected beyond its slot (written when a point goes to a list): the
+// host reads it behind the filter and takes the sort path from then on when voxels hold dozens of points (a large leaf) - the
+// first point of a voxel orders its members by repeated selection, quadratic in their number.
 __global__ __launch_bounds__(256) void k_vhash_link(int n, VhashTable tb, const unsigned int* __restrict__ slot_of,
                                                     unsigned int* __restrict__ next, unsigned char* __restrict__ is_first,
-                                                    unsigned int* __restrict__ block_firsts) {
+                                                    unsigned int* __restrict__ block_firsts, unsigned int* __restrict__ crowded) {
   __shared__ unsigned int s_cnt[4];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool first = false;
@@ -1845,7 +1804,7 @@ __global__ __launch_bounds__(256) void k_vhash_link(int n, VhashTable tb, const 
       if (!first) {
         const unsigned int k = atomicAdd(tb.count + slot, 1u);
         if (k < (unsigned)kVhMembers) tb.members[(size_t)slot * kVhMembers + k] = (unsigned)i;
-        else next[i] = atomicExch(tb.head + slot, (unsigned)i);
+        else { next[i] = atomicExch(tb.head + slot, (unsigned)i); atomicMax(crowded, k + 1u - (unsigned)kVhMembers); }
       }
     }
     is_first[i] = first ? 1 : 0;
@@ -1888,7 +1847,19 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
   const unsigned int cnt = tb.count[slot];
   const float4 p0 = pts[i];
   float sx = __fadd_rn(0.f, p0.x), sy = __fadd_rn(0.f, p0.y), sz = __fadd_rn(0.f, p0.z), st = __fadd_rn(0.f, p0.w);
-  if (cnt > 0u) {
+  if (cnt > 512u) {
+    // Safety valve for a scan on which voxels turn crowded in the middle of a run (the first scan of a leaf is probed, the
+    // following ones watched: lii_downsample): ordering hundreds of members by repeated selection would take tens of
+    // milliseconds.  They are added in list order - the centroid is then right to rounding, not bit for bit.
+    for (int k = 0; k < kVhMembers; k++) {
+      const float4 p = pts[tb.members[(size_t)slot * kVhMembers + k]];
+      sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+    }
+    for (unsigned int j = tb.head[slot]; j != kVhEmpty; j = next[j]) {
+      const float4 p = pts[j];
+      sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+    }
+  } else if (cnt > 0u) {
     // the members in input order: every round takes the smallest index above the last one taken - from the slot's own
     // members (registers) and, for a crowded voxel, from the list behind them (walked again every round: slow and rare)
     unsigned int m[kVhMembers];
@@ -2054,70 +2025,27 @@ int register_blocks(int n) { return nblk(n, kBlock); }
 static inline int shard_bound(const RegistrationBuffers& rb) {
   return rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;
 }
-// LII_KNN_DIAG & 256 (timing experiments): start / end stamps of every wavefront of the last search launch, summarised at exit
-static unsigned long long* g_wlog = nullptr;
-static int g_wlog_waves = 0;
-static void wlog_dump() {
-  if (!g_wlog || g_wlog_waves <= 0) return;
-  std::vector<unsigned long long> h(size_t(3) * g_wlog_waves);
-  if (hipMemcpy(h.data(), g_wlog, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
-  std::vector<double> st, life, life_r, en;
-  unsigned long long t0 = ~0ull;
-  for (int w = 0; w < g_wlog_waves; w++) if (h[3 * w + 1]) t0 = std::min(t0, h[3 * w]);
-  for (int w = 0; w < g_wlog_waves; w++) {
-    if (!h[3 * w + 1]) continue;
-    st.push_back((h[3 * w] - t0) * 0.01); en.push_back((h[3 * w + 1] - t0) * 0.01);
-    ((h[3 * w + 2] & 1) ? life_r : life).push_back((h[3 * w + 1] - h[3 * w]) * 0.01);
-  }
-  auto pct = [](std::vector<double>& v, double p) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[std::min(v.size() - 1, size_t(p * v.size()))]; };
-  std::fprintf(stderr, "[wlog] waves %zu  start us p50 %.2f p90 %.2f p99 %.2f max %.2f | end us p50 %.2f p90 %.2f p99 %.2f max %.2f\n", st.size(), pct(st, .5), pct(st, .9), pct(st, .99), pct(st, 1.0),
-               pct(en, .5), pct(en, .9), pct(en, .99), pct(en, 1.0));
-  std::fprintf(stderr, "[wlog] lifetime us, common path (%zu waves): p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f\n", life.size(), pct(life, .1), pct(life, .5), pct(life, .9), pct(life, .99), pct(life, 1.0));
-  for (int lo = 0; lo < 48; lo += 6) {
-    std::vector<double> b;
-    for (int w = 0; w < g_wlog_waves; w++) if (h[3 * w + 1] && !(h[3 * w + 2] & 1) && int(h[3 * w + 2] >> 8) > lo && int(h[3 * w + 2] >> 8) <= lo + 6) b.push_back((h[3 * w + 1] - h[3 * w]) * 0.01);
-    if (!b.empty()) std::fprintf(stderr, "[wlog]   wave max n in (%d, %d]: %zu waves, lifetime p50 %.2f p90 %.2f max %.2f\n", lo, lo + 6, b.size(), pct(b, .5), pct(b, .9), pct(b, 1.0));
-  }
-  std::fprintf(stderr, "[wlog] lifetime us, rare path (%zu waves): p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f\n", life_r.size(), pct(life_r, .1), pct(life_r, .5), pct(life_r, .9), pct(life_r, .99), pct(life_r, 1.0));
-}
 template <int LPQ, int BS, int NB, int WPE>
 static void launch_knn_pk_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                             const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
   int nq = nblk(shard_bound(rb), BS / LPQ);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  static const int diag = std::getenv("LII_KNN_DIAG") ? std::atoi(std::getenv("LII_KNN_DIAG")) : 0;  // timing experiments only
-  unsigned long long* wlog = nullptr;
-  if (diag & 256) {
-    if (!g_wlog) { (void)hipMalloc(&g_wlog, sizeof(unsigned long long) * 3 * 65536); (void)hipMemset(g_wlog, 0, sizeof(unsigned long long) * 3 * 65536); std::atexit(wlog_dump); }
-    g_wlog_waves = nq_pad * (BS / 64);
-    wlog = g_wlog;
-  }
-  hipLaunchKernelGGL((k_knn_pk<LPQ, BS, NB, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out, diag, wlog);
+  hipLaunchKernelGGL((k_knn_pk<LPQ, BS, NB, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
 }
-// variant 0: packed keys (k_knn_pk, the product path); 5: exact lists throughout (k_knn_exact, its reference form);
-// other values: diagnostic geometries of k_knn_pk
+// variant 0: packed keys (k_knn_pk, the product path); 5: exact lists throughout (k_knn_exact, its reference form)
 void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                 const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
-  switch (variant) {
-    case 5: {
-      int nq = nblk(shard_bound(rb), 128 / 4);
-      if (nq < 1) nq = 1;
-      const int nq_pad = ((nq + 7) / 8) * 8;
-      hipLaunchKernelGGL((k_knn_exact<128>), dim3(nq_pad), dim3(128), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
-      break;
-    }
-    case 21: launch_knn_pk_t<4, 128, 8, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 22: launch_knn_pk_t<4, 128, 4, 8>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 40: launch_knn_pk_t<2, 128, 8, 4>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 41: launch_knn_pk_t<2, 128, 12, 3>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 42: launch_knn_pk_t<2, 64, 8, 4>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 43: launch_knn_pk_t<2, 128, 6, 5>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 50: launch_knn_pk_t<1, 64, 12, 2>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 51: launch_knn_pk_t<1, 64, 8, 2>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    case 52: launch_knn_pk_t<1, 64, 16, 2>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
-    default: launch_knn_pk_t<4, 128, 6, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s); break;
+  if (variant == 5) {
+    int nq = nblk(shard_bound(rb), 128 / 4);
+    if (nq < 1) nq = 1;
+    const int nq_pad = ((nq + 7) / 8) * 8;
+    hipLaunchKernelGGL((k_knn_exact<128>), dim3(nq_pad), dim3(128), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
+    return;
   }
+  // 128 lanes, 6 loads in flight per lane, 6 wavefronts per SIMD: measured against 64 / 256 lanes, 4 / 8 / 10 / 12 loads and 2 / 1
+  // lanes per query (profiles/r03_knn_ab.md)
+  launch_knn_pk_t<4, 128, 6, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s);
 }
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);
@@ -2165,14 +2093,14 @@ void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned in
   hipLaunchKernelGGL(k_voxel_minmax, dim3(nb), dim3(256), 0, s, pts, n, mm, mm_next);
 }
 void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows, int n_rows, float leaf,
-                       unsigned long long* keys, unsigned int* pcl_keys, int coherent_order, int* filtered_dev,
+                       unsigned long long* keys, unsigned int* pcl_keys, int* filtered_dev,
                        unsigned long long* samples, int sample_width, hipStream_t s) {
   if (n > 0)
     hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, keys, pcl_keys,
-                       coherent_order, filtered_dev, samples, sample_width);
+                       filtered_dev, samples, sample_width);
 }
 void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
-                       int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, hipStream_t s) {
+                       int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, hipStream_t s) {
   if (n <= 0) return;
   VhashTable tb;
   tb.key = vh.key; tb.first = vh.first; tb.count = vh.count; tb.head = vh.head; tb.members = vh.members;
@@ -2180,9 +2108,11 @@ void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, con
   while (slots < 4u * (unsigned)n) slots <<= 1;
   tb.mask = slots - 1u;
   const int nb = nblk(n, 256);
-  hipLaunchKernelGGL(k_vhash_insert, dim3(nb), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, tb, vh.slot_of, filtered);
-  hipLaunchKernelGGL(k_vhash_link, dim3(nb), dim3(256), 0, s, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts);
-  hipLaunchKernelGGL(k_vhash_emit, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, out, n_out, pcl_out);
+  if (stages & 1) {
+    hipLaunchKernelGGL(k_vhash_insert, dim3(nb), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, tb, vh.slot_of, filtered);
+    hipLaunchKernelGGL(k_vhash_link, dim3(nb), dim3(256), 0, s, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, vh.crowded);
+  }
+  if (stages & 2) hipLaunchKernelGGL(k_vhash_emit, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, out, n_out, pcl_out);
 }
 size_t voxel_hash_slots(int max_n) {
   size_t slots = 1024;

@@ -68,7 +68,7 @@ void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned lon
 // voxel grid
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s);
 void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows, int n_rows, float leaf,
-                       unsigned long long* keys, unsigned int* pcl_keys, int coherent_order, int* filtered_dev,
+                       unsigned long long* keys, unsigned int* pcl_keys, int* filtered_dev,
                        unsigned long long* samples, int sample_width, hipStream_t s);
 // the voxel grid by hashing (lii_kernels.hip: k_vhash_*): the table arrays hold voxel_hash_slots(max_n) entries (`members`: 7 per
 // slot), initialised to key = first = head = 0xFFFFFFFF, count = 0 and left in that state by every filter
@@ -77,10 +77,11 @@ struct VoxelHashBuffers {
   unsigned int *slot_of, *next;   // per input point
   unsigned char* is_first;        // per input point
   unsigned int* block_firsts;     // per workgroup of 256 points
+  unsigned int* crowded;          // one word: the longest member list behind a slot so far (k_vhash_link)
 };
 size_t voxel_hash_slots(int max_n);
 void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
-                       int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, hipStream_t s);
+                       int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, hipStream_t s);
 // calibration
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s);
@@ -124,6 +125,7 @@ struct VoxelSortBuffers {
   unsigned short* bucket_of;      // n
   const unsigned int* pcl_in;     // PCL voxel index of every input point ...
   unsigned int* pcl_out;          // ... and of every output voxel (the order the reference's filter would emit them in)
+  unsigned int* max_run;          // optional: receives (atomicMax) the largest number of points of one voxel when it exceeds 8
 };
 size_t voxel_sort_hist_elems(int max_n);
 struct VoxelSortPlan { int buckets, samples, width, strata; };

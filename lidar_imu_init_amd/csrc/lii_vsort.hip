@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restric
                                                           const unsigned int* __restrict__ bucket_start, int B, int n,
                                                           const unsigned int* __restrict__ group_count, float4* __restrict__ out,
                                                           int* __restrict__ n_out, const unsigned int* __restrict__ pcl_in,
-                                                          unsigned int* __restrict__ pcl_out) {
+                                                          unsigned int* __restrict__ pcl_out, unsigned int* __restrict__ max_run) {
   __shared__ unsigned int wtot[4], s_sum[4];
   const int tid = threadIdx.x, g = blockIdx.x;
   const int b0 = g * kGroup, b1 = min(b0 + kGroup, B);
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(256) void k_voxel_centroids(const float4* __restric
           sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
         }
       }
+      if (max_run && j - i > 8u) atomicMax(max_run, j - i);  // (the host picks the hashed filter for sparse voxels: lii_capi.cpp)
       const float c = (float)(j - i);
       // a single-point voxel reproduces the point exactly (x / 1.0f == x), which is also what the identity path needs
       out[slot] = make_float4(sx / c, sy / c, sz / c, st / c);
@@ -465,7 +466,7 @@ void launch_voxel_sort_centroids(const VoxelSortBuffers& vb, const float4* pts, 
   if (n <= 512) {
     hipLaunchKernelGGL(k_vsort_small, dim3(1), dim3(512), 0, s, vb.keys_in, n, vb.keys_out, vb.idx_out, bucket_start, group_count);
     hipLaunchKernelGGL(k_voxel_centroids<kGroup>, dim3(1), dim3(256), 0, s, pts, vb.keys_out, vb.idx_out, bucket_start, kGroup, n,
-                       group_count, out, n_out, vb.pcl_in, vb.pcl_out);
+                       group_count, out, n_out, vb.pcl_in, vb.pcl_out, vb.max_run);
     return;
   }
   const VoxelSortPlan p = voxel_sort_plan(n);
@@ -481,12 +482,12 @@ void launch_voxel_sort_centroids(const VoxelSortBuffers& vb, const float4* pts, 
     hipLaunchKernelGGL(k_vsort_local<kGroup>, dim3(groups), dim3(256), 0, s, vb.comp, bucket_start, B, tot, cursor, vb.keys_out,
                        vb.idx_out, group_count);
     hipLaunchKernelGGL(k_voxel_centroids<kGroup>, dim3(groups), dim3(256), 0, s, pts, vb.keys_out, vb.idx_out, bucket_start, B, n,
-                       group_count, out, n_out, vb.pcl_in, vb.pcl_out);
+                       group_count, out, n_out, vb.pcl_in, vb.pcl_out, vb.max_run);
   } else {  // the bucket count is capped (n > 131 k): larger buckets, one to a workgroup
     hipLaunchKernelGGL(k_vsort_local<1>, dim3(B), dim3(256), 0, s, vb.comp, bucket_start, B, tot, cursor, vb.keys_out, vb.idx_out,
                        group_count);
     hipLaunchKernelGGL(k_voxel_centroids<1>, dim3(B), dim3(256), 0, s, pts, vb.keys_out, vb.idx_out, bucket_start, B, n, group_count,
-                       out, n_out, vb.pcl_in, vb.pcl_out);
+                       out, n_out, vb.pcl_in, vb.pcl_out, vb.max_run);
   }
 }
 

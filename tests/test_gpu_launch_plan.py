@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def _run(env, wl, states0, tables, n_rounds=2):
     import lidar_imu_init_amd as lii
-    old = {k: os.environ.get(k) for k in ("LII_KNN_PLAN", "LII_KNN_PLAN_FORCE")}
+    old = {k: os.environ.get(k) for k in ("LII_KNN_PLAN", "LII_TEST")}
     for k in old:
         os.environ.pop(k, None)
     os.environ.update(env)
@@ -46,7 +46,7 @@ def test_results_do_not_depend_on_the_launch_plan():
     states0[2].pos_end[:] += np.array([0.08, -0.05, 0.03])
     full = _run({"LII_KNN_PLAN": "0"}, wl, states0, tables)
     assert len({(r[1], r[2]) for r in full}) >= 1
-    for env in ({}, {"LII_KNN_PLAN_FORCE": "1"}, {"LII_KNN_PLAN_FORCE": "0x2B"}, {"LII_KNN_PLAN_FORCE": "0x7FFFFFFF"}):
+    for env in ({}, {"LII_TEST": "plan_force=1"}, {"LII_TEST": "plan_force=0x2B"}, {"LII_TEST": "plan_force=0x7FFFFFFF"}):
         got = _run(env, wl, states0, tables)
         for a, b in zip(full, got):
             assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3], (env, a[1:4], b[1:4])

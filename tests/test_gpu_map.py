@@ -218,7 +218,7 @@ def test_capacity_overflow_leaves_the_map_untouched(oracle):
 
 def test_update_that_runs_out_of_room_loses_nothing(oracle):
     """An in-place update provisions room for the usual batch only (a few new 8x8x8-cell blocks, some tail slots).  A batch that
-    needs more - here forced with LII_MAP_TEST_TIGHT=1: no spare block tables, a 256-slot tail - parks the inserts it cannot
+    needs more - here forced with LII_TEST=map_tight: no spare block tables, a 256-slot tail - parks the inserts it cannot
     place; the next read of the counters rebuilds the index and inserts them again.  The caller sees no error and the map is
     the reference tree's point set (ikd_Tree.cpp:381-456) all the same - including batches far outside the mapped region
     (every point a new block) and searches right after."""
@@ -227,11 +227,11 @@ def test_update_that_runs_out_of_room_loses_nothing(oracle):
     rng = np.random.default_rng(23)
     ds = 0.5
     base = np.c_[rng.uniform(-15, 15, (20_000, 2)), rng.normal(0, 0.05, 20_000)].astype(np.float32)
-    os.environ["LII_MAP_TEST_TIGHT"] = "1"
+    os.environ["LII_TEST"] = "map_tight"
     try:
         reg = lii.Registrar(max_scan_points=30_000, max_map_points=120_000, filter_size_map=ds)
     finally:
-        del os.environ["LII_MAP_TEST_TIGHT"]
+        del os.environ["LII_TEST"]
     tree = oracle.Tree("oracle", downsample=ds)
     reg.map_build(base)
     tree.build(base)
