@@ -106,6 +106,7 @@ struct lii_context {
   unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
   int extent_sel = 0, mm_sel = 0;
   bool knn_plan = true;        // LII_KNN_PLAN=0: every k-NN launch is enqueued (IekfCtrl::plan_mask)
+  int plan_passes_prev = 32;   // passes the update before the last one ran (the plan enqueues the larger of the last two)
   int knn_plan_force = -1;     // LII_KNN_PLAN_FORCE=<mask>: use this plan for every update (tests: forces the parked path)
   unsigned int plan_next = 0xFFFFFFFFu, plan_cur = 0xFFFFFFFFu;
   long long plan_parked = 0;   // updates that had to be continued by the host
@@ -601,7 +602,9 @@ void fill_ctrl(lii_handle h, const lii_state* state, const lii_state* state_prop
   hc->seq = h->update_seq;
   // which k-NN launches ride along (IekfCtrl::plan_mask): the first pass always; the others as the previous update needed them
   unsigned int plan = 0xFFFFFFFFu;
-  if (h->knn_plan && !h->comm) plan = (h->knn_plan_force >= 0 ? (unsigned int)h->knn_plan_force : h->plan_next) | 1u;
+  if (h->knn_plan && !h->comm) {
+    plan = (h->knn_plan_force >= 0 ? ((unsigned int)h->knn_plan_force | 0xFFFF0000u) : h->plan_next) | 0x00010001u;
+  }
   hc->plan_mask = plan;
   h->plan_cur = plan;
 }
@@ -632,7 +635,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   // (profiling = HIP events around the k-NN launches only - the dominant kernel, lii_last_timings [5] / [7]; every event is a
   // barrier packet on the stream, so the rest of the loop is left alone: launch plan and result polling work as always)
   auto enqueue_pass = [&](int it) -> int {
-    const bool knn = it >= 32 || ((plan >> it) & 1u);
+    const bool knn = it >= 16 || ((plan >> it) & 1u);
     if (knn) {
       if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it], s));
       launch_knn(h, g, rb, ps0, pose, -1);
@@ -653,16 +656,17 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   };
   const auto t_loop0 = std::chrono::steady_clock::now();
   for (int it = 0; it < opts->max_iterations; it++) {
+    if (it < 16 && !((plan >> (16 + it)) & 1u)) break;  // the plan ends here
     rc = enqueue_pass(it);
     if (rc != LII_OK) return rc;
   }
   // The iteration that stops the loop writes the result block (mapped host memory) and then its sequence number.  Polling
   // that word instead of synchronising the stream returns as soon as the result exists: the passes enqueued behind the
   // stopping one (they only read `stop` and return) drain while the caller already prepares the next scan.
-  // (Enqueueing only as many passes as the previous scan needed, and further ones on demand, was measured: no gain - the
-  // drained passes fit into the host's turn-around between two scans - and a scan that needs more pays a round trip.)
-  // A loop that parked itself (the next pass needs a search the plan did not hold - the pattern changed against the previous
-  // scan) is continued from here with every launch: one host round trip, on the scans whose pattern changes.
+  // The plan also ends the enqueued loop after as many passes as the last updates ran: the launches behind the stopping pass
+  // only drain (3 x 4.5 us on stream100k, about what the host needs to come back with the next scan: + 0 .. 3 % scans/s,
+  // gpurun_out/r3x4).  A loop that parked itself (the next pass is not there, or needs a search the plan did not hold - the
+  // pattern changed against the previous scans) is continued from here with every launch: one host round trip, on those scans.
   auto wait_result = [&](bool first) -> int {
     const int parked_word = first ? (h->update_seq | kLoopParked) : h->update_seq;
     if (h->poll_result && !h->comm) {
@@ -722,6 +726,9 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     unsigned int next = 0xFFFFFFFFu;
     for (int q = 0; q < 16 && q < hr->it; q++)
       if (!hr->search_log[q]) next &= ~(1u << q);
+    // ... and as many passes as the longer of the last two updates ran (a scan that needs more parks and is continued)
+    for (int q = std::max(hr->it, h->plan_passes_prev); q < 16; q++) next &= ~(1u << (16 + q));
+    h->plan_passes_prev = hr->it;
     h->plan_next = next;
   }
   if (report) {

@@ -101,10 +101,11 @@ struct IekfCtrl {
   int effect_num;    // effect_feat_num of the last iteration
   int singular;      // a matrix inversion failed
   int seq;           // number of this update (host); echoed into IekfResult::done by the iteration that ends the loop
-  unsigned int plan_mask;  // bit k: the host enqueued a k-NN launch ahead of iteration k (iterations >= 32: always).  The host
-                           // predicts the search pattern from the previous scan and leaves out the launches that would only read
-                           // the flags and return (~4.5 us each on the device); a solve that asks for a search the plan does not
-                           // hold parks the loop (stop = 2) and tells the host, which enqueues the rest with every launch.
+  unsigned int plan_mask;  // bit k (k < 16): the host enqueued a k-NN launch ahead of iteration k; bit 16 + k: it enqueued pass k
+                           // at all (iterations >= 16: always both).  The host predicts the search pattern and the number of
+                           // passes from the previous scans and leaves out the launches that would only read the flags and
+                           // return (~4.5 us each on the device); a solve whose next pass is not there, or asks for a search
+                           // the plan does not hold, parks the loop (stop = 2) and tells the host, which enqueues the rest.
   int search_log[16];  // search_log[it] = 1 when iteration `it` ran the k-NN pass (for profiling)
   double search_pose[24];  // the PoseArg of the last executed k-NN pass (written by that pass): a sharded job re-runs the search
                            // for the blocks of the other ranks at exactly this pose before map_incremental (lii_capi.cpp)

@@ -243,7 +243,10 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   if (converged || ((rematch == 0) && (it == (max_it - 2)))) { search = 1; rematch++; }
   const int do_cov = (rematch >= 2 || (it == max_it - 1));
   // the next pass searches but the host did not enqueue a k-NN launch for it: park the loop and say so (IekfCtrl::plan_mask)
-  const int parked = !do_cov && search && (it + 1 < 32) && !(((unsigned int)s_int[11] >> (it + 1)) & 1u);
+  // ... or the host did not enqueue the next pass at all (bit 16 + k: the launches of pass k are there)
+  const unsigned int pm = (unsigned int)s_int[11];
+  const bool pass_there = it + 1 >= 16 || ((pm >> (16 + it + 1)) & 1u), knn_there = it + 1 >= 16 || ((pm >> (it + 1)) & 1u);
+  const int parked = !do_cov && (!pass_there || (search && !knn_there));
   // state += solution : the two rotations on two lanes of the first wavefront, the vector blocks on 18 more; on the stopping
   // iteration the other three wavefronts start on K H = K_1[:, :12] G (needed for the covariance only) right away
   if (wave == 0) {

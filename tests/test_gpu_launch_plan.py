@@ -52,3 +52,39 @@ def test_results_do_not_depend_on_the_launch_plan():
             assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3], (env, a[1:4], b[1:4])
             assert np.array_equal(a[0], b[0]), env
             assert np.array_equal(a[4], b[4]), env
+
+
+def test_an_update_longer_than_the_plan_is_continued():
+    """The plan also ends the enqueued loop after as many passes as the last updates ran (bits 16 + k of plan_mask): an update that
+    needs more passes parks behind the last enqueued one and the host continues it - same bits as with every launch enqueued."""
+    import bench
+    import lidar_imu_init_amd as lii
+    wl = bench.build_workload("os1_128_cut3", 2)
+    states0, tables = bench.start_states(wl)
+    results = {}
+    for plan in ("0", "1"):
+        old = os.environ.get("LII_KNN_PLAN")
+        os.environ["LII_KNN_PLAN"] = plan
+        try:
+            reg = lii.Registrar(max_scan_points=140_000, max_map_points=1_100_000, filter_size_map=wl["fs_map"])
+        finally:
+            os.environ.pop("LII_KNN_PLAN", None)
+            if old is not None:
+                os.environ["LII_KNN_PLAN"] = old
+        out = []
+        try:
+            reg.map_build(wl["map"])
+            for max_it in (2, 2, 2, wl["max_it"], 1, wl["max_it"]):  # short updates teach a short plan; the long ones outrun it
+                for j, scan in enumerate(wl["scans"]):
+                    st = states0[j].copy()
+                    rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=wl["fs_surf"], max_iterations=max_it,
+                                            imu_en=True, scan_dev=reg.device_scan(scan))
+                    out.append((st.pod.copy(), rep["iterations"], rep["searches"], np.array(rep["normal_eq"])))
+        finally:
+            reg.close()
+        results[plan] = out
+    assert max(r[1] for r in results["0"]) > 2  # the long updates did run longer than the plan they met
+    for a, b in zip(results["0"], results["1"]):
+        assert a[1] == b[1] and a[2] == b[2]
+        assert np.array_equal(a[0], b[0])
+        assert np.array_equal(a[3], b[3])
