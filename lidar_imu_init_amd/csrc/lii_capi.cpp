@@ -12,6 +12,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -106,6 +107,8 @@ struct lii_context {
   unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
   int extent_sel = 0, mm_sel = 0;
   bool knn_plan = true;        // LII_KNN_PLAN=0: every k-NN launch is enqueued (IekfCtrl::plan_mask)
+  bool use_graph = false;      // LII_TEST=graph: the passes of an update are captured once per (cloud bound, plan, map view) and replayed
+  std::map<std::string, hipGraphExec_t> graphs;
   int plan_passes_prev = 32;   // passes the update before the last one ran (the plan enqueues the larger of the last two)
   int knn_plan_force = -1;     // LII_KNN_PLAN_FORCE=<mask>: use this plan for every update (tests: forces the parked path)
   unsigned int plan_next = 0xFFFFFFFFu, plan_cur = 0xFFFFFFFFu;
@@ -655,9 +658,46 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     return LII_OK;
   };
   const auto t_loop0 = std::chrono::steady_clock::now();
-  for (int it = 0; it < opts->max_iterations; it++) {
-    if (it < 16 && !((plan >> (16 + it)) & 1u)) break;  // the plan ends here
-    rc = enqueue_pass(it);
+  auto enqueue_planned = [&]() -> int {
+    for (int it = 0; it < opts->max_iterations; it++) {
+      if (it < 16 && !((plan >> (16 + it)) & 1u)) break;  // the plan ends here
+      const int r = enqueue_pass(it);
+      if (r != LII_OK) return r;
+    }
+    return LII_OK;
+  };
+  if (h->use_graph && !h->comm && !prof) {
+    // The same launches, captured once and replayed (hipGraphLaunch): every kernel argument of the loop is a device pointer or
+    // a constant of the configuration, except the bound of the cloud size (rounded up here: the kernels take the exact size
+    // from the device), the plan and the view of the map - the key of the cache.  Measured against the plain launches in
+    // profiles/r03_hipgraph_ab.md.
+    if (rb.n_dev) rb.n = std::min(rb.cap, (rb.n + 4095) & ~4095);
+    struct { const void* p[4]; unsigned int mask; int n_pts, n, plan, max_it, imu_en, variant, shard; float cs; } kv;
+    std::memset(&kv, 0, sizeof(kv));
+    kv.p[0] = g.pts; kv.p[1] = g.blocks; kv.p[2] = g.cells; kv.p[3] = rb.n_dev;
+    kv.mask = g.block_mask; kv.n_pts = g.n_pts; kv.n = rb.n; kv.plan = (int)plan; kv.max_it = opts->max_iterations;
+    kv.imu_en = opts->imu_en ? 1 : 0; kv.variant = h->knn_variant; kv.shard = rb.shard_world * 4096 + rb.shard_rank; kv.cs = g.cs;
+    const std::string key(reinterpret_cast<const char*>(&kv), sizeof(kv));
+    auto f = h->graphs.find(key);
+    if (f == h->graphs.end()) {
+      if (h->graphs.size() >= 64) {
+        for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
+        h->graphs.clear();
+      }
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      rc = enqueue_planned();
+      const hipError_t e_end = hipStreamEndCapture(s, &graph);
+      if (rc != LII_OK) return rc;
+      HIPCHK(h, e_end);
+      HIPCHK(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      HIPCHK(h, hipGraphDestroy(graph));
+      f = h->graphs.emplace(key, exec).first;
+    }
+    HIPCHK(h, hipGraphLaunch(f->second, s));
+  } else {
+    rc = enqueue_planned();
     if (rc != LII_OK) return rc;
   }
   // The iteration that stops the loop writes the result block (mapped host memory) and then its sequence number.  Polling
@@ -808,14 +848,20 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     h->voxel_sort = std::string(v) == "sort";
     if (std::string(v) == "hash") { h->vh_pinned = true; h->vh_mode = 1; }
   }
-  if (const char* v = std::getenv("LII_HOST_SOLVE")) h->host_solve = std::atoi(v) != 0;
-  if (const char* v = std::getenv("LII_SYNC_RESULT")) h->poll_result = std::atoi(v) == 0;
   if (const char* v = std::getenv("LII_KNN_PLAN")) h->knn_plan = std::atoi(v) != 0;
-  if (const char* v = std::getenv("LII_TEST")) {  // hooks of the test-suite: "map_tight" (an in-place map update without spare room),
-    const std::string t(v);                        // "plan_force=<mask>" (a launch plan that is wrong on purpose)
+  if (const char* v = std::getenv("LII_TEST")) {
+    // arrangements the test-suite and the A/B measurements ask for, comma-separated: "map_tight" (an in-place map update without
+    // spare room), "plan_force=<mask>" (a launch plan that is wrong on purpose), "host_solve" (the iteration loop driven from the
+    // host around lii_iekf_iterate with the literal two-inversion algebra), "sync_result" (every update ends with
+    // hipStreamSynchronize instead of polling the result word), "graph" (the enqueued passes of an update replayed from a
+    // captured hipGraph)
+    const std::string t(v);
     h->map_tight = t.find("map_tight") != std::string::npos;
     const size_t q = t.find("plan_force=");
     if (q != std::string::npos) h->knn_plan_force = int(std::strtol(t.c_str() + q + 11, nullptr, 0) & 0x7FFFFFFF);
+    h->host_solve = t.find("host_solve") != std::string::npos;
+    h->poll_result = t.find("sync_result") == std::string::npos;
+    h->use_graph = t.find("graph") != std::string::npos;
   }
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;
@@ -973,6 +1019,8 @@ int lii_destroy(lii_handle h) {
     std::fprintf(stderr, "[libliinit_hip] host side of lii_scan_register, us per call over %.0f calls: first launch submitted %.1f, pre-processing enqueued %.1f, "
                  "loop enqueue %.1f, call %.1f, between calls %.1f\n", h->host_us[4], h->host_us[0] / h->host_us[4], h->host_us[1] / h->host_us[4],
                  h->host_us[2] / h->host_us[4], h->host_us[3] / h->host_us[4], h->host_us[5] / std::max(1.0, h->host_us[4] - 1));
+  for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
+  h->graphs.clear();
   mailbox_close(&h->mailbox);
   if (h->d_mb_seq) (void)hipFree(h->d_mb_seq);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
@@ -1701,9 +1749,13 @@ int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t 
   if (transport != LII_COMM_RCCL) {
     if (!h->d_mb_seq) HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->d_mb_seq), sizeof(unsigned long long)));
     HIPCHK(h, hipMemset(h->d_mb_seq, 0, sizeof(unsigned long long)));
-    if (const char* t = std::getenv("LII_MAILBOX_TIMEOUT_S")) h->mailbox_timeout_ticks = (long long)(std::atof(t) * 1e8);
-    const char* w = std::getenv("LII_MAILBOX_WAIT_S");
-    const double wait_s = w ? std::atof(w) : 20.0;
+    // LII_MAILBOX_TIMEOUT_S=<exchange>[,<set-up>]: how long a reduce+solve kernel waits for a peer's sums (30 s), how long this
+    // call waits for all ranks in the node-local segment (20 s)
+    double wait_s = 20.0;
+    if (const char* t = std::getenv("LII_MAILBOX_TIMEOUT_S")) {
+      h->mailbox_timeout_ticks = (long long)(std::atof(t) * 1e8);
+      if (const char* c = std::strchr(t, ',')) wait_s = std::atof(c + 1);
+    }
     std::string why;
     if (mailbox_open(id_in, n_ranks, rank, wait_s, transport != LII_COMM_MAILBOX_HOST, &h->mailbox, &why) == 0) {
       if (transport == LII_COMM_MAILBOX && !h->mailbox.d_peers) {  // asked for by name: no silent change of the transport

@@ -119,13 +119,13 @@ def test_missing_rank_is_an_error_not_a_hang(tmp_path):
     import lidar_imu_init_amd as lii
     r = lii.Registrar(max_scan_points=1024, max_map_points=1024)
     uid = r.comm_unique_id()
-    os.environ["LII_MAILBOX_WAIT_S"] = "1.0"
+    os.environ["LII_MAILBOX_TIMEOUT_S"] = "30,1.0"
     try:
         with pytest.raises(lii.LIIError):
             r.comm_init(2, 0, uid, "mailbox")  # the peer never arrives: the rendezvous gives up
         assert r.comm_transport() == "none"
     finally:
-        del os.environ["LII_MAILBOX_WAIT_S"]
+        del os.environ["LII_MAILBOX_TIMEOUT_S"]
         r.close()
 
 
