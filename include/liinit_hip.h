@@ -253,7 +253,11 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
                       lii_iekf_report* report);
 
 /* map_incremental (src/laserMapping.cpp:516-559): decides PointToAdd / PointNoNeedDownsample from the last
- * search's neighbour lists and applies both to the map. */
+ * search's neighbour lists and applies both to the map.  n_add / n_no_downsample (the sizes of the two lists) may be NULL: then
+ * the call returns without waiting for anything - the update is enqueued for predicted list sizes (those of the previous call
+ * + 25 %) on a stream of its own, the next scan's arrival, de-skew and voxel filter overlap it, and whatever touches the map
+ * next (a search, any lii_map_* call) waits for it first; an update whose lists outgrew the prediction is repeated there with
+ * the exact sizes.  The map that results is the same either way. */
 int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, int32_t* n_no_downsample);
 
 /* ---------------------------------------------------------------- LI-Init batch calibration evaluators

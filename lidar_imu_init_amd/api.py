@@ -436,7 +436,11 @@ class Registrar:
         self._check(self.L.lii_neighbors_download(self.h, _ptr(pts), _ptr(cnt), _ptr(sel), n))
         return pts, cnt, sel
 
-    def map_incremental(self, state: State):
+    def map_incremental(self, state: State, want_counts: bool = True):
+        """want_counts=False: both size pointers NULL - the update is enqueued without a host round trip (predicted list sizes)."""
+        if not want_counts:
+            self._check(self.L.lii_map_incremental(self.h, _ptr(state.pod), None, None))
+            return None
         a, b = C.c_int32(0), C.c_int32(0)
         self._check(self.L.lii_map_incremental(self.h, _ptr(state.pod), C.byref(a), C.byref(b)))
         return a.value, b.value

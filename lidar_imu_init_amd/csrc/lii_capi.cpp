@@ -107,11 +107,13 @@ struct lii_context {
   unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
   int extent_sel = 0, mm_sel = 0;
   bool knn_plan = true;        // LII_KNN_PLAN=0: every k-NN launch is enqueued (IekfCtrl::plan_mask)
+  bool test_pred_small = false;
   bool use_graph = false;      // LII_TEST=graph: the passes of an update are captured once per (cloud bound, plan, map view) and replayed
   std::map<std::string, hipGraphExec_t> graphs;
   int plan_passes_prev = 32;   // passes the update before the last one ran (the plan enqueues the larger of the last two)
   int knn_plan_force = -1;     // LII_KNN_PLAN_FORCE=<mask>: use this plan for every update (tests: forces the parked path)
   unsigned int plan_next = 0xFFFFFFFFu, plan_cur = 0xFFFFFFFFu;
+  long long map_repeats = 0;   // map updates repeated because a list outgrew its predicted size
   long long plan_parked = 0;   // updates that had to be continued by the host
   bool staging_busy = false;  // h_ctrl / h_poses were handed to the device by lii_scan_register and no wait has covered the read yet
   size_t ctrl_pending = 0;    // bytes of h_ctrl (+ poses) the next k_time_extent launch carries to d_ctrl; 0 = nothing pending
@@ -147,7 +149,16 @@ struct lii_context {
   bool have_search = false;
   int knn_variant = 0;   // search pass: 0 = packed keys (k_knn_pk); 5 = exact lists throughout (k_knn_exact, its reference form) -
                          // LII_KNN_VARIANT selects
-  int* h_mapflag = nullptr;       // pinned: kMapCtrOverflow of the last in-place update (commit_map)
+  hipStream_t map_stream = nullptr;  // the in-place update of lii_map_incremental runs here, beside the next scan's pre-processing
+  bool map_async = false;            // ... and may still be running (map_join waits for it: ev_mapflag is its last packet)
+  int bound_add = 0, bound_nodown = 0;  // ... the sizes the update in flight was enqueued for
+  int list_hist[8][2] = {};             // ... from the sizes of the last eight calls (note_list_sizes)
+  int list_hist_n = 0;
+  int pred_add = -1, pred_nodown = -1;  // lii_map_incremental: list sizes the next update is enqueued for (< 0: none yet)
+  bool lists_predicted = false;         // the update in flight ran on predicted sizes: commit_map checks it against the exact ones
+  hipEvent_t ev_lists = nullptr;        // the two lists are complete (compute stream -> map stream)
+  int* h_mapflag = nullptr;       // pinned, behind the last in-place update: [0] kMapCtrOverflow, [16..31] the map counters, [32..36] the list
+                                  // counts of lii_map_incremental (k_compact_lists) - read by commit_map
   hipEvent_t ev_mapflag = nullptr;
   bool map_flag_pending = false;
   bool diag = false;     // LII_DIAG=1: counters of the rare paths on stderr when the handle is destroyed
@@ -339,21 +350,74 @@ int build_index(lii_handle h, int n, int extra_blocks = 0) {
 // its overflow flag to pinned memory behind its kernels (no synchronisation there); whoever searches next looks at it - by then
 // it has long arrived - and only an update that did overflow pays for settling (rebuild + re-insertion of the parked points).
 int map_counters(lii_handle h, bool already_synced);
+int map_rebuild(lii_handle h, int extra_blocks);
+int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra, bool beside = false,
+              const int* n_list_dev = nullptr, const int* n_extra_dev = nullptr);
+int map_counters(lii_handle h, bool already_synced = false);
+// lii_map_incremental leaves its in-place update running on a stream of its own: the next scan's arrival, de-skew and voxel
+// filter (which touch neither the map nor the update's scratch) overlap it.  Whatever reads or writes the map, its counters or
+// that scratch joins the update first - the search passes through commit_map, every lii_map_* entry point directly.
+// The list sizes the next lii_map_incremental is enqueued for: the largest of the last eight calls + 25 % + 1024 (consecutive
+// scans of a stream resemble each other; launching for some padding costs little, a list that outgrows its bound a repeat).
+void note_list_sizes(lii_handle h, int n_add, int n_nodown) {
+  h->list_hist[h->list_hist_n & 7][0] = n_add;
+  h->list_hist[h->list_hist_n & 7][1] = n_nodown;
+  h->list_hist_n++;
+  int ma = 0, mn = 0;
+  for (int k = 0; k < std::min(h->list_hist_n, 8); k++) { ma = std::max(ma, h->list_hist[k][0]); mn = std::max(mn, h->list_hist[k][1]); }
+  h->pred_add = ma + ma / 4 + 1024;
+  h->pred_nodown = mn + mn / 4 + 1024;
+}
+int map_join(lii_handle h) {
+  if (!h->map_async) return LII_OK;
+  h->map_async = false;
+  HIPCHK(h, hipEventSynchronize(h->ev_mapflag));
+  if (h->lists_predicted) {
+    // lii_map_incremental enqueued this update for predicted list sizes.  The exact ones came along behind it: they feed the
+    // next prediction, and an update whose lists outgrew their bounds did nothing (k_compact_lists emptied them) - it is
+    // repeated now, with the exact sizes (the lists themselves are untouched until the next lii_map_incremental).
+    h->lists_predicted = false;
+    const int ca = h->h_mapflag[32], cn = h->h_mapflag[33];
+    note_list_sizes(h, ca, cn);
+    if (h->h_mapflag[34]) {
+      h->map_repeats++;
+      if (h->diag && h->map_repeats <= 8)
+        std::fprintf(stderr, "[libliinit_hip] map update repeated: lists of %d / %d points, enqueued for %d / %d\n", ca, cn, h->bound_add, h->bound_nodown);
+      h->map_flag_pending = false;  // (of the update that did nothing)
+      return map_apply(h, h->d_list_add, ca, true, h->d_list_nodown, cn);
+    }
+  }
+  return LII_OK;
+}
 int commit_map(lii_handle h) {
+  {
+    const int rc = map_join(h);
+    if (rc != LII_OK) return rc;
+  }
   if (!h->map_dirty || !h->map_flag_pending) return LII_OK;
   HIPCHK(h, hipEventSynchronize(h->ev_mapflag));
   h->map_flag_pending = false;
-  if (*h->h_mapflag == 0) return LII_OK;
-  return map_counters(h, false);
+  if (*h->h_mapflag != 0) {  // ran out of provisioned room: rebuild + re-insertion of the parked points
+    const int rc = map_counters(h, false);
+    if (rc != LII_OK) return rc;
+  } else {  // the counters came along: the host's copies are current again without a read of their own
+    h->n_used = h->h_mapflag[16 + kMapCtrUsed];
+    h->n_map = h->h_mapflag[16 + kMapCtrValid];
+    h->n_blocks = int(std::min<size_t>(size_t(std::max(h->h_mapflag[16 + kMapCtrBlocks], 0)), h->cells_cap_blocks));
+    h->map_dirty = false;
+  }
+  return LII_OK;
 }
 
 // Host copies of the device counters (one small synchronising read).  An update in flight that ran out of room (block tables,
 // slack + tail of the point array) has parked the inserts it could not place in d_dropped: the index is rebuilt with more room
 // and those points are inserted again - nothing is lost, the caller sees no error.  Only a dropped list that itself overflowed
 // (cannot happen: it holds a whole batch) or a work-list overflow turns into LII_ERR_CAPACITY.
-int map_rebuild(lii_handle h, int extra_blocks);
-int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra);
-int map_counters(lii_handle h, bool already_synced = false) {
+int map_counters(lii_handle h, bool already_synced) {
+  {
+    const int rc = map_join(h);
+    if (rc != LII_OK) return rc;
+  }
   h->map_flag_pending = false;
   if (!h->map_dirty) return LII_OK;
   if (!already_synced) {
@@ -425,7 +489,10 @@ int map_rebuild(lii_handle h, int extra_blocks) {
 // Nothing is synchronised: the counters move on the device (map_counters reads them when somebody asks).  The capacity check is
 // made BEFORE anything is touched and is conservative: n_valid + n_list + n_extra <= max_map_points (a down-sampled batch may
 // replace points instead of adding them; the check still counts every point of it) - a refused batch leaves the map untouched.
-int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra) {
+// n_list_dev / n_extra_dev != nullptr: the lists hold *n_list_dev / *n_extra_dev points (device-resident), n_list / n_extra are
+// bounds of them (lii_map_incremental's predicted sizes); the launches are made for the bounds.
+int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra, bool beside,
+              const int* n_list_dev, const int* n_extra_dev) {
   hipStream_t s = h->stream;
   int rc = map_counters(h);
   if (rc != LII_OK) return rc;
@@ -445,6 +512,13 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
     rc = map_rebuild(h, h->map_tight ? 0 : std::max(4096, h->n_blocks / 2));
     if (rc != LII_OK) return rc;
     if ((long long)h->pts_cap_eff - h->n_used < tail_need) return fail(h, LII_ERR_CAPACITY, "local map: no room left behind the cells for an in-place update");
+    beside = false;  // (the rebuild ran on the handle's stream and has not been waited for)
+  }
+  // `beside`: the update runs on the map stream from here (see map_join), behind what the handle's stream holds now
+  if (beside) {
+    HIPCHK(h, hipEventRecord(h->ev_lists, h->stream));
+    s = h->map_stream;
+    HIPCHK(h, hipStreamWaitEvent(s, h->ev_lists, 0));
   }
   const GridView g = grid_view(h);
   h->map_dirty = true;
@@ -454,23 +528,27 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
   const float4* list_a = list;
   const unsigned int* flags_a = nullptr;
   if (downsample && n_list > 0) {
-    launch_add_keys(list, n_list, nullptr, h->ds, h->d_keys_a, h->d_idx_a, s);
+    launch_add_keys(list, n_list, n_list_dev, h->ds, h->d_keys_a, h->d_idx_a, s);
     sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, n_list, s);
     launch_add_fold(list, h->d_keys_b, h->d_idx_b, n_list, h->ds, g, h->d_tomb, h->d_ins, h->d_u32_a,
                     reinterpret_cast<unsigned int*>(h->d_mapctr + kMapCtrEvents), h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s);
     list_a = h->d_ins;
     flags_a = h->d_u32_a;
   }
-  launch_ins_cells(list_a, flags_a, n_list, nullptr, extra, n_extra, h->d_ins_e2, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp,
+  launch_ins_cells(list_a, flags_a, n_list, flags_a ? nullptr : n_list_dev, extra, n_extra, n_extra_dev, h->d_ins_e2, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp,
                    h->d_work, h->d_mapctr, h->work_cap, h->d_dropped, h->drop_cap, s);
   launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap_eff, (int)work_need, s);
-  launch_ins_write(list_a, h->d_ins_e, n_list, nullptr, extra, h->d_ins_e2, n_extra, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, h->d_dropped,
+  launch_ins_write(list_a, h->d_ins_e, n_list, flags_a ? nullptr : n_list_dev, extra, h->d_ins_e2, n_extra, n_extra_dev, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, h->d_dropped,
                    h->drop_cap, s);
   HIPCHK(h, hipGetLastError());
   // the update's overflow flag travels to the host behind its kernels (see commit_map)
   HIPCHK(h, hipMemcpyAsync(h->h_mapflag, h->d_mapctr + kMapCtrOverflow, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(h->h_mapflag + 16, h->d_mapctr, sizeof(int) * kMapCtrWords, hipMemcpyDeviceToHost, s));
+  if (n_list_dev) HIPCHK(h, hipMemcpyAsync(h->h_mapflag + 32, h->d_counts, sizeof(int) * 5, hipMemcpyDeviceToHost, s));
+  h->lists_predicted = n_list_dev != nullptr;
   HIPCHK(h, hipEventRecord(h->ev_mapflag, s));
   h->map_flag_pending = true;
+  h->map_async = beside;
   return LII_OK;
 }
 
@@ -854,7 +932,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     // spare room), "plan_force=<mask>" (a launch plan that is wrong on purpose), "host_solve" (the iteration loop driven from the
     // host around lii_iekf_iterate with the literal two-inversion algebra), "sync_result" (every update ends with
     // hipStreamSynchronize instead of polling the result word), "graph" (the enqueued passes of an update replayed from a
-    // captured hipGraph)
+    // captured hipGraph), "pred_small" (lii_map_incremental predicts list sizes that are always too small)
     const std::string t(v);
     h->map_tight = t.find("map_tight") != std::string::npos;
     const size_t q = t.find("plan_force=");
@@ -862,6 +940,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     h->host_solve = t.find("host_solve") != std::string::npos;
     h->poll_result = t.find("sync_result") == std::string::npos;
     h->use_graph = t.find("graph") != std::string::npos;
+    h->test_pred_small = t.find("pred_small") != std::string::npos;
   }
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;
@@ -883,6 +962,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     return rc;
   }
   CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&h->map_stream, hipStreamNonBlocking));
   const size_t N = size_t(cfg->max_scan_points), M = size_t(cfg->max_map_points);
   const size_t NM = std::max(N, M);
   CK(dmalloc(&h->d_map_unsorted, M));
@@ -954,8 +1034,9 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(hipEventCreateWithFlags(&h->ev_poses, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&h->ev_mapflag, hipEventDisableTiming));
-  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_mapflag), 64, hipHostMallocDefault));
-  *h->h_mapflag = 0;
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_mapflag), 256, hipHostMallocDefault));
+  std::memset(h->h_mapflag, 0, 256);
+  CK(hipEventCreateWithFlags(&h->ev_lists, hipEventDisableTiming));
   CK(hipMemset(h->d_counter, 0, 16));
   h->partial_stride = register_blocks(int(N)) + 8;
   CK(dmalloc(&h->d_partials, size_t(h->partial_stride) * kNormalEq));
@@ -1012,9 +1093,11 @@ int lii_destroy(lii_handle h) {
   if (!h) return LII_OK;
   (void)hipSetDevice(h->device);
   if (h->comm) ncclCommDestroy(h->comm);
+  if (h->map_stream) (void)hipStreamSynchronize(h->map_stream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] map updates completed by a rebuild + re-insertion: %lld\n", h->map_recoveries);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] updates continued by the host after a parked loop: %lld\n", h->plan_parked);
+  if (h->diag) std::fprintf(stderr, "[libliinit_hip] map updates repeated with exact list sizes: %lld\n", h->map_repeats);
   if (h->diag && h->host_us[4] > 0)
     std::fprintf(stderr, "[libliinit_hip] host side of lii_scan_register, us per call over %.0f calls: first launch submitted %.1f, pre-processing enqueued %.1f, "
                  "loop enqueue %.1f, call %.1f, between calls %.1f\n", h->host_us[4], h->host_us[0] / h->host_us[4], h->host_us[1] / h->host_us[4],
@@ -1046,11 +1129,13 @@ int lii_destroy(lii_handle h) {
   if (h->ev_vh) (void)hipEventDestroy(h->ev_vh);
   if (h->h_vh_crowded) (void)hipHostFree(h->h_vh_crowded);
   if (h->h_mapflag) (void)hipHostFree(h->h_mapflag);
+  if (h->ev_lists) (void)hipEventDestroy(h->ev_lists);
   if (h->n_map_pinned) (void)hipHostFree(h->n_map_pinned);
   for (int i = 0; i < 4; i++)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   for (int i = 0; i < 32; i++)
     if (h->ev_it[i]) (void)hipEventDestroy(h->ev_it[i]);
+  if (h->map_stream) (void)hipStreamDestroy(h->map_stream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return LII_OK;
@@ -1058,6 +1143,10 @@ int lii_destroy(lii_handle h) {
 
 int lii_synchronize(lii_handle h) {
   if (!h) return LII_ERR_INVALID;
+  {
+    const int rc = map_join(h);
+    if (rc != LII_OK) return rc;
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return LII_OK;
 }
@@ -1065,6 +1154,10 @@ int lii_synchronize(lii_handle h) {
 // ------------------------------------------------------------------------------------------------ map
 int lii_map_reset(lii_handle h) {
   if (!h) return LII_ERR_INVALID;
+  {
+    const int rcj = map_join(h);
+    if (rcj != LII_OK) return rcj;
+  }
   h->have_search = false;
   return build_index(h, 0);
 }
@@ -1087,6 +1180,10 @@ int upload_xyz(lii_handle h, const void* xyz, int n, int stride_bytes, float4* d
 int lii_map_build(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes) {
   if (!h || (!xyz && n > 0) || n < 0 || stride_bytes < 12 || stride_bytes % 4) return fail(h, LII_ERR_INVALID, "lii_map_build: bad arguments");
   if (n > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "lii_map_build: n > max_map_points");
+  {
+    const int rcj = map_join(h);
+    if (rcj != LII_OK) return rcj;
+  }
   h->have_search = false;
   int rc = upload_xyz(h, xyz, n, stride_bytes, h->d_map_unsorted);
   if (rc != LII_OK) return rc;
@@ -1140,7 +1237,7 @@ int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int3
   h->map_dirty = true;
   launch_box_tomb_cells(h->d_pts, h->d_cells, ne, d_boxes, n_boxes, h->d_tomb, h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s);
   launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap_eff, ne, s);
-  launch_ins_write(h->d_pts, h->d_ins_e, 0, nullptr, nullptr, nullptr, 0, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, h->d_dropped, h->drop_cap,
+  launch_ins_write(h->d_pts, h->d_ins_e, 0, nullptr, nullptr, nullptr, 0, nullptr, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, h->d_dropped, h->drop_cap,
                    s);  // (re-arms the work list)
   rc = map_counters(h);
   if (rc != LII_OK) return rc;
@@ -1177,6 +1274,10 @@ int lii_map_download(lii_handle h, float* xyz_out, int32_t capacity, int32_t* n)
 }
 int lii_map_commit(lii_handle h) {
   if (!h) return LII_ERR_INVALID;
+  {
+    const int rcj = map_join(h);
+    if (rcj != LII_OK) return rcj;
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return LII_OK;
 }
@@ -1637,6 +1738,10 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
   const int nb = h->n_body;  // upper bound while the exact count is still on the device
   if (nb <= 0) return LII_OK;
   if (nb > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "lii_map_incremental: scan larger than max_map_points");
+  {
+    const int rcj = map_join(h);
+    if (rcj != LII_OK) return rcj;
+  }
   hipStream_t s = h->stream;
   RegistrationBuffers rb = reg_buffers(h);
   if (rb.shard_world > 1) {
@@ -1652,8 +1757,22 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
     }
   }
   // decision per point on the device (world point, neighbour list of the last search) and both order-preserving compactions
+  const bool sharded = h->n_ranks > 1;
+  if (!n_add && !n_no_downsample && !sharded && h->pred_add >= 0) {
+    // Nobody asks for the list sizes: the update is enqueued for PREDICTED sizes (note_list_sizes) right
+    // behind the compaction, on the map stream - no host round trip, and the next scan's arrival / de-skew / voxel filter overlap
+    // it.  The exact sizes stay on the device (d_counts); commit_map reads them behind the update and repeats an update whose
+    // lists outgrew the prediction.  The host's copies of the map counters: see commit_map (the previous update has been joined
+    // by the search of this scan, so they are current here).
+    int ba = std::min(nb, h->pred_add), bn = std::min(nb, h->pred_nodown);
+    if (h->test_pred_small) { ba = std::min(ba, 16); bn = std::min(bn, 16); }
+    h->bound_add = ba; h->bound_nodown = bn;  // (LII_TEST=pred_small: every update outgrows its bounds)
+    launch_map_decide_compact(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, h->d_u32_a,
+                              reinterpret_cast<uint2*>(h->d_u32_b), h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, ba, bn, s);
+    return map_apply(h, h->d_list_add, ba, true, h->d_list_nodown, bn, true, h->d_counts + 3, h->d_counts + 4);
+  }
   launch_map_decide_compact(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, h->d_u32_a,
-                            reinterpret_cast<uint2*>(h->d_u32_b), h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, s);
+                            reinterpret_cast<uint2*>(h->d_u32_b), h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, nb, nb, s);
   // The sizes of the two lists, now: a converged map takes a few thousand of the ~100 k points, and everything downstream
   // (voxel keys, the batch sort, the per-voxel fold, the insert compaction) is launched for the exact count instead of the
   // scan-sized bound - one small host round trip (~15 us) against ~80 us of kernels working on padding.
@@ -1667,8 +1786,11 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
     const int rc0 = map_counters(h, true);
     if (rc0 != LII_OK) return rc0;
   }
+  note_list_sizes(h, n_lists[0], n_lists[1]);
   // Add_Points(PointToAdd, true) then Add_Points(PointNoNeedDownsample, false)  (:556-557)
-  int rc = map_apply(h, h->d_list_add, n_lists[0], true, h->d_list_nodown, n_lists[1]);
+  // (the stream has just been synchronised: the update may run beside whatever the caller enqueues next - a sharded job keeps
+  // one stream: its search of the whole cloud above reads the control block the next scan's arrival rewrites)
+  int rc = map_apply(h, h->d_list_add, n_lists[0], true, h->d_list_nodown, n_lists[1], !sharded);
   if (rc != LII_OK) return rc;
   if (n_add) *n_add = n_lists[0];
   if (n_no_downsample) *n_no_downsample = n_lists[1];

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, Pose
 // list sizes in counts[0..1].  (Replaces two library scans and two scatter kernels.)
 __global__ __launch_bounds__(256) void k_compact_lists(const float4* __restrict__ src, const unsigned int* __restrict__ cls,
                                                        const uint2* __restrict__ blk_counts, int n, float4* __restrict__ dst_add,
-                                                       float4* __restrict__ dst_nodown, int* __restrict__ counts) {
+                                                       float4* __restrict__ dst_nodown, int* __restrict__ counts, int bound_a, int bound_n) {
   __shared__ unsigned int s_a[4], s_n[4], s_wa[4], s_wn[4];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   unsigned int pa = 0, pn = 0;
@@ -191,8 +191,16 @@ __global__ __launch_bounds__(256) void k_compact_lists(const float4* __restrict_
   if (c & 1u) dst_add[base_a + (unsigned int)__popcll(ma & below)] = src[i];
   if (c & 2u) dst_nodown[base_n + (unsigned int)__popcll(mn & below)] = src[i];
   if (blockIdx.x == gridDim.x - 1 && t == 255) {
-    counts[0] = (int)(base_a + (unsigned int)__popcll(ma));
-    counts[1] = (int)(base_n + (unsigned int)__popcll(mn));
+    const int ca = (int)(base_a + (unsigned int)__popcll(ma)), cn = (int)(base_n + (unsigned int)__popcll(mn));
+    counts[0] = ca;
+    counts[1] = cn;
+    // the update behind this launch may have been enqueued for PREDICTED list sizes (lii_map_incremental): a list that outgrew
+    // its bound empties both for that update (counts[3..4] = what it works on) and raises counts[2]; the host repeats it with
+    // the exact sizes before the next search
+    const int over = (ca > bound_a || cn > bound_n) ? 1 : 0;
+    counts[2] = over;
+    counts[3] = over ? 0 : ca;
+    counts[4] = over ? 0 : cn;
   }
 }
 
@@ -438,14 +446,14 @@ __device__ __forceinline__ void drop_point(float4* __restrict__ dropped, unsigne
 // flags == nullptr: every point of the list is an insert.  n_dev != nullptr: the list holds *n_dev points (n is the launch bound).
 // A second list (list2, n2 points, all of them inserts, entries to ins_e2) rides in the same launch: lanes [n, n + n2).
 __global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int* __restrict__ flags, int n, const int* __restrict__ n_dev,
-                            const float4* __restrict__ list2, int n2, unsigned int* __restrict__ ins_e2,
+                            const float4* __restrict__ list2, int n2, const int* __restrict__ n2_dev, unsigned int* __restrict__ ins_e2,
                             BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* __restrict__ ins_e,
                             unsigned int* __restrict__ tp, unsigned int* __restrict__ work, int* __restrict__ ctr, unsigned int work_cap,
                             float4* __restrict__ dropped, unsigned int drop_cap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) {
     i -= n;
-    if (i >= n2) return;
+    if (i >= n2 || (n2_dev && i >= *n2_dev)) return;
     list = list2; flags = nullptr; ins_e = ins_e2;
   } else if (n_dev && i >= *n_dev) {
     return;
@@ -579,7 +587,7 @@ __global__ void k_cell_apply(const unsigned int* __restrict__ work, uint2* __res
 }
 
 __global__ void k_ins_write(const float4* __restrict__ list, const unsigned int* __restrict__ ins_e, int n, const int* __restrict__ n_dev,
-                            const float4* __restrict__ list2, const unsigned int* __restrict__ ins_e2, int n2,
+                            const float4* __restrict__ list2, const unsigned int* __restrict__ ins_e2, int n2, const int* __restrict__ n2_dev,
                             uint2* __restrict__ cells, const unsigned int* __restrict__ cell_cap, float4* __restrict__ pts, int* __restrict__ ctr,
                             float4* __restrict__ dropped, unsigned int drop_cap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -587,7 +595,7 @@ __global__ void k_ins_write(const float4* __restrict__ list, const unsigned int*
   bool valid = true;
   if (i >= n) {
     i -= n;
-    valid = i < n2;
+    valid = i < n2 && !(n2_dev && i >= *n2_dev);
     list = list2; ins_e = ins_e2;
   } else if (n_dev && i >= *n_dev) {
     valid = false;
@@ -673,24 +681,24 @@ __global__ void k_box_tomb_cells(const float4* __restrict__ pts, const uint2* __
 }
 
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
-void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, const float4* list2, int n2, unsigned int* ins_e2,
+void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, const float4* list2, int n2, const int* n2_dev, unsigned int* ins_e2,
                       BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp,
                       unsigned int* work, int* ctr, unsigned int work_cap, float4* dropped, unsigned int drop_cap, hipStream_t s) {
   if (n < 0) n = 0;
   if (n2 < 0) n2 = 0;
   if (n + n2 > 0)
-    hipLaunchKernelGGL(k_ins_cells, dim3(nblk(n + n2, 256)), dim3(256), 0, s, list, flags, n, n_dev, list2, n2, ins_e2, blocks, mask, inv_cs, tables_cap,
+    hipLaunchKernelGGL(k_ins_cells, dim3(nblk(n + n2, 256)), dim3(256), 0, s, list, flags, n, n_dev, list2, n2, n2_dev, ins_e2, blocks, mask, inv_cs, tables_cap,
                        ins_e, tp, work, ctr, work_cap, dropped, drop_cap);
 }
 void launch_cell_apply(const unsigned int* work, uint2* cells, unsigned int* cell_cap, float4* pts, unsigned char* tomb, unsigned int* tp, int* ctr,
                        unsigned int pts_cap, int launch_bound, hipStream_t s) {
   if (launch_bound > 0) hipLaunchKernelGGL(k_cell_apply, dim3(nblk(launch_bound, 128)), dim3(128), 0, s, work, cells, cell_cap, pts, tomb, tp, ctr, pts_cap, launch_bound);
 }
-void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, const float4* list2, const unsigned int* ins_e2, int n2,
+void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, const float4* list2, const unsigned int* ins_e2, int n2, const int* n2_dev,
                       uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, float4* dropped, unsigned int drop_cap, hipStream_t s) {
   if (n < 0) n = 0;
   if (n2 < 0) n2 = 0;
-  hipLaunchKernelGGL(k_ins_write, dim3(nblk(n + n2 > 0 ? n + n2 : 1, 256)), dim3(256), 0, s, list, ins_e, n, n_dev, list2, ins_e2, n2, cells, cell_cap, pts,
+  hipLaunchKernelGGL(k_ins_write, dim3(nblk(n + n2 > 0 ? n + n2 : 1, 256)), dim3(256), 0, s, list, ins_e, n, n_dev, list2, ins_e2, n2, n2_dev, cells, cell_cap, pts,
                      ctr, dropped, drop_cap);
 }
 void launch_cell_caps(const uint2* cells, int n_entries, unsigned int* caps, hipStream_t s) {
@@ -712,11 +720,11 @@ void launch_box_tomb_cells(const float4* pts, const uint2* cells, int n_entries,
 }
 
 void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* cls, uint2* blk_counts,
-                               float4* world, float4* dst_add, float4* dst_nodown, int* counts, hipStream_t s) {
+                               float4* world, float4* dst_add, float4* dst_nodown, int* counts, int bound_add, int bound_nodown, hipStream_t s) {
   if (rb.n <= 0) return;
   const int nb = nblk(rb.n, 256);
   hipLaunchKernelGGL(k_map_decide, dim3(nb), dim3(256), 0, s, rb, ps, fsd, have_search, cls, blk_counts, world);
-  hipLaunchKernelGGL(k_compact_lists, dim3(nb), dim3(256), 0, s, world, cls, blk_counts, rb.n, dst_add, dst_nodown, counts);
+  hipLaunchKernelGGL(k_compact_lists, dim3(nb), dim3(256), 0, s, world, cls, blk_counts, rb.n, dst_add, dst_nodown, counts, bound_add, bound_nodown);
 }
 void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_add_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, n_dev, ds, keys, idx);

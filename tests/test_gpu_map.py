@@ -2,6 +2,8 @@
 incremental k-d tree (Add_Points with per-voxel keep-closest-to-centre down-sampling, include/ikd-Tree/ikd_Tree.cpp:381-456)
 and the device index built from it must answer exactly like Nearest_Search.  Also: a multi-scan stream
 (register -> map_incremental -> next scan) stays on the oracle's trajectory."""
+import os
+
 import numpy as np
 import pytest
 
@@ -326,3 +328,49 @@ def test_long_update_sequence_keeps_the_tree_set(oracle):
         m = cnt > k
         assert np.array_equal(nb[m, k], pts[m, k])
     reg.close()
+
+
+@pytest.mark.parametrize("hook", ["", "pred_small"])
+def test_map_incremental_without_counts_gives_the_same_map(hook):
+    """lii_map_incremental with both size pointers NULL enqueues the update for PREDICTED list sizes on a stream of its own and
+    returns at once; an update whose lists outgrow the prediction is repeated with the exact sizes before the next search
+    (LII_TEST=pred_small: every one does).  Same scans, same poses -> the same map, point for point, as the waiting form."""
+    import bench
+    import lidar_imu_init_amd as lii
+    wl = bench.build_workload("os1_128_cut3", 4)
+    states0, tables = bench.start_states(wl)
+
+    def run(want_counts, env):
+        old = os.environ.get("LII_TEST")
+        if env:
+            os.environ["LII_TEST"] = env
+        try:
+            reg = lii.Registrar(max_scan_points=140_000, max_map_points=1_600_000, filter_size_map=wl["fs_map"])
+        finally:
+            os.environ.pop("LII_TEST", None)
+            if old is not None:
+                os.environ["LII_TEST"] = old
+        try:
+            reg.map_build(wl["map"])
+            out = []
+            for rnd in range(2):
+                for j, scan in enumerate(wl["scans"]):
+                    st = states0[j].copy()
+                    reg.scan_upload(scan)
+                    rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=wl["fs_surf"], max_iterations=wl["max_it"], imu_en=True)
+                    # the first call has nothing to predict from and waits either way
+                    reg.map_incremental(st, want_counts=want_counts or (rnd == 0 and j == 0))
+                    out.append((st.pod.copy(), rep["iterations"], rep["effect_num"]))
+            m = reg.map_download()
+            return out, m[np.lexsort((m[:, 2], m[:, 1], m[:, 0]))]
+        finally:
+            reg.close()
+
+    ref_out, ref_map = run(True, "")
+    got_out, got_map = run(False, hook)
+    assert len(ref_map) > len(wl["map"])  # the map did grow
+    for a, b in zip(ref_out, got_out):
+        assert a[1] == b[1] and a[2] == b[2]
+        assert np.array_equal(a[0], b[0])
+    assert ref_map.shape == got_map.shape
+    assert np.array_equal(ref_map, got_map)
