@@ -1,12 +1,12 @@
 #!/bin/bash
 # HBM traffic / L2 counters of the dominant kernel, one rocprofv3 pass per counter set (MI355X_MICROARCH.md: never mix --pmc
 # with the sys/hip/hsa trace domains; --kernel-trace is fine).  Run ON THE GPU BOX from the repo root:
-#   bash tools/collect_pmc.sh gpurun_out/pmc_r01 && python tools/summarize_pmc.py gpurun_out/pmc_r01 profiles/r01_pmc_knn.json
+#   bash tools/collect_pmc.sh gpurun_out/pmc && python tools/summarize_pmc.py gpurun_out/pmc profiles/rNN_pmc_knn.json
 set -e
 OUT=${1:-gpurun_out/pmc}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python bench.py --steps 8 --warmup 2 --prime 0 --profile-every 0 --no-cpu-baseline"
+CMD="python bench.py --steps 8 --warmup 2 --prime 0 --profile-every 0 --no-cpu-baseline --no-pipeline"
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
   i=$((i + 1))
