@@ -7,6 +7,7 @@ namespace lii {
 
 constexpr int kMatch = 5;          // NUM_MATCH_POINTS — reference include/common_lib.h:28
 constexpr int kNeedy = 0x100;      // nbr_count flag: the 3x3x3 search pass could not prove this list exact yet
+constexpr int kCovered = 0x200;    // ... but measured every point of those cells: the list is exact over them (the completion skips them)
 constexpr int kBlock = 256;        // 4 wavefronts of 64
 constexpr int kNormalEq = 91;      // 78 + 12 + 1
 constexpr int kCoarseShift = 3;    // coarse occupancy cell = 8 x 8 x 8 fine cells

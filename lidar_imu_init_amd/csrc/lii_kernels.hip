@@ -1031,7 +1031,8 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
       for (int r = 0; r < 5; r += LPQ)
         if (sub + r < 5 && sub + r >= found) rb.nbr[(size_t)(sub + r) * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
     }
-    if (sub == (LPQ > 1 ? 1 : 0)) rb.nbr_count[qi] = found | (need ? kNeedy : 0);
+    // (kCovered: flagged for its reach alone - the list is exact over the 3 x 3 x 3 cells, the completion starts from it)
+    if (sub == (LPQ > 1 ? 1 : 0)) rb.nbr_count[qi] = found | (need ? (kNeedy | ((ovf || amb) ? 0 : kCovered)) : 0);
     if (sub == (LPQ == 4 ? 2 : 0)) rb.world[qi] = make_float4(wx, wy, wz, 0.f);
   }
 }
@@ -1102,7 +1103,7 @@ __device__ __forceinline__ void wave_select5(Knn5 k, float (&od)[5], int (&oi)[5
 #pragma unroll
   for (int r = 0; r < 5; r++) {
     const float m = wave_min_f32(k.d0);
-    const unsigned long long owners = __ballot(k.d0 == m && k.i0 >= 0);
+    const unsigned long long owners = __ballot(k.d0 == m && k.i0 != -1);  // (-1: empty; <= -2: a seeded entry, see knn_fallback_wave)
     if (owners == 0ull) { od[r] = __builtin_inff(); oi[r] = -1; continue; }  // fewer than r + 1 candidates in total
     const int owner = __ffsll((long long)owners) - 1;
     od[r] = m;
@@ -1113,8 +1114,11 @@ __device__ __forceinline__ void wave_select5(Knn5 k, float (&od)[5], int (&oi)[5
     }
   }
 }
-__device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, float wy, float wz, float d5, float (&od)[5],
-                                                  int (&oi)[5]) {
+// seeded: the search pass has already measured every point of the 3 x 3 x 3 cells around the query (kCovered) - its list
+// (seed_d: the distance of entry `lane` on lanes 0..4, inf where the list ends) stands in for pass 1; a seeded entry that
+// survives comes back as index -(2 + its place in the list).
+__device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, float wy, float wz, float d5, bool seeded, float seed_d,
+                                                  float (&od)[5], int (&oi)[5]) {
   const int lane = threadIdx.x & 63;
   const float bound0 = fminf(d5, g.max_d2);
   const float cs = g.cs;
@@ -1127,7 +1131,13 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
   k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = __builtin_inff();
   k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
   // pass 1: the 3 x 3 x 3 cells around the query, one per lane
-  {
+  if (seeded) {  // (uniform)
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      od[j] = __shfl(seed_d, j);
+      oi[j] = od[j] < __builtin_inff() ? -(2 + j) : -1;
+    }
+  } else {
     const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = (lane / 9) % 3 - 1;
     const int ixx = cx + dx, iyy = cy + dy, izz = cz + dz;
     const int X = (ixx >> kCoarseShift) - X0 + 1, Y = (iyy >> kCoarseShift) - Y0 + 1, Z = (izz >> kCoarseShift) - Z0 + 1;
@@ -1140,8 +1150,8 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
         scan_range(g.pts, g.max_d2, rr.x, rr.y, wx, wy, wz, k);
       }
     }
+    wave_select5(k, od, oi);
   }
-  wave_select5(k, od, oi);
   const float bound1 = fminf(od[4], bound0);  // exact 5th distance over the inner cells (inf if they hold fewer than 5)
   // pass 2: the rest of the cube around the ball of radius sqrt(bound1) (nothing farther can enter the list), pruned with bound1
   const float r1 = fminf(r0, sqrtf(bound1) + 2.f * eps);
@@ -1155,7 +1165,7 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
   {  // the inner result re-enters as five one-element lists (lanes 0..4)
     const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
     const int ii = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
-    if (lane < 5 && ii >= 0) { k.d0 = dd; k.i0 = ii; }
+    if (lane < 5 && ii != -1) { k.d0 = dd; k.i0 = ii; }
   }
   // Four rounds of 64 cells at a time: which cells survive (inside the ball, outside the inner cube, closer than bound1) does
   // not depend on the candidates found on the way, so the four cell entries of a lane are fetched together and their
@@ -1228,6 +1238,34 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
 // Completion of the flagged searches among the kBlock points of one workgroup (`my_point`: the calling lane's): one wavefront per
 // flagged query, four at a time (they are rare, ~0.07 % of the queries, but clustered at the map frontier).  Every lane of
 // the workgroup must call it; on return the completed lists are visible to the whole workgroup.
+// One flagged search finished by a whole wavefront: the list goes to rb.nbr / rb.nbr_count.
+__device__ __forceinline__ void complete_one(const GridView& g, const RegistrationBuffers& rb, int qi) {
+  const int lane = threadIdx.x & 63;
+  const float4 w4 = rb.world[qi];
+  const int c00 = rb.nbr_count[qi];
+  const int c0 = c00 & 0xFF;
+  const bool seeded = (c00 & kCovered) != 0;  // uniform
+  // the list of the search pass: its 5th distance bounds the far search, and (kCovered) its entries are exact over the inner cells
+  const float4 sv = lane < 5 ? rb.nbr[(size_t)lane * rb.cap + qi] : make_float4(0.f, 0.f, 0.f, __builtin_inff());
+  const float d5 = c0 == kMatch ? __shfl(sv.w, 4) : __builtin_inff();
+  float od[5];
+  int oi[5];
+  knn_fallback_wave(g, w4.x, w4.y, w4.z, d5, seeded, lane < c0 ? sv.w : __builtin_inff(), od, oi);
+  const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
+  const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
+  // a seeded entry that stayed in the list: its point is in the lane that loaded it
+  const int from = idx <= -2 ? -(idx + 2) : 0;
+  const float kx = __shfl(sv.x, from), ky = __shfl(sv.y, from), kz = __shfl(sv.z, from);
+  if (lane < 5) {
+    float4 v = make_float4(0, 0, 0, 0);
+    if (idx >= 0) v = g.pts[idx];
+    else if (idx <= -2) v = make_float4(kx, ky, kz, 0.f);
+    v.w = dd;
+    rb.nbr[(size_t)lane * rb.cap + qi] = v;
+  } else if (lane == 5) {
+    rb.nbr_count[qi] = (oi[0] != -1) + (oi[1] != -1) + (oi[2] != -1) + (oi[3] != -1) + (oi[4] != -1);
+  }
+}
 __device__ __forceinline__ void complete_flagged(const GridView& g, const RegistrationBuffers& rb, int my_point, bool live, int* s_needy,
                                                  int* s_nneedy) {
   if (threadIdx.x == 0) *s_nneedy = 0;
@@ -1235,25 +1273,8 @@ __device__ __forceinline__ void complete_flagged(const GridView& g, const Regist
   if (live && (rb.nbr_count[my_point] & kNeedy)) s_needy[atomicAdd(s_nneedy, 1)] = my_point;
   __syncthreads();
   const int nn = *s_nneedy;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int e = wave; e < nn; e += kBlock / 64) {
-    const int qi = s_needy[e];
-    const float4 w4 = rb.world[qi];
-    const int c0 = rb.nbr_count[qi] & 0xFF;
-    const float d5 = c0 == kMatch ? rb.nbr[(size_t)4 * rb.cap + qi].w : __builtin_inff();
-    float od[5];
-    int oi[5];
-    knn_fallback_wave(g, w4.x, w4.y, w4.z, d5, od, oi);
-    const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
-    const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
-    if (lane < 5) {
-      float4 v = idx >= 0 ? g.pts[idx] : make_float4(0, 0, 0, 0);
-      v.w = dd;
-      rb.nbr[(size_t)lane * rb.cap + qi] = v;
-    } else if (lane == 5) {
-      rb.nbr_count[qi] = (oi[0] >= 0) + (oi[1] >= 0) + (oi[2] >= 0) + (oi[3] >= 0) + (oi[4] >= 0);
-    }
-  }
+  const int wave = threadIdx.x >> 6;
+  for (int e = wave; e < nn; e += kBlock / 64) complete_one(g, rb, s_needy[e]);
   if (nn) __syncthreads();  // the completed lists are visible to their owners (workgroup-scope release/acquire)
 }
 
