@@ -2064,9 +2064,10 @@ void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, c
     hipLaunchKernelGGL((k_knn_exact<128>), dim3(nq_pad), dim3(128), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
     return;
   }
-  // 128 lanes, 6 loads in flight per lane, 6 wavefronts per SIMD: measured against 64 / 256 lanes, 4 / 8 / 10 / 12 loads and 2 / 1
-  // lanes per query (profiles/r03_knn_ab.md)
-  launch_knn_pk_t<4, 128, 6, 6>(g, rb, ps, pose, ctrl, forced, search_pose_out, s);
+  // 128 lanes, 6 loads in flight per lane, 7 wavefronts per SIMD (69 VGPRs): measured against 64 / 256 lanes, 4 / 8 / 10 / 12
+  // loads, 6 / 8 wavefronts per SIMD (within 1 % on stream100k, 2 % behind on the larger scans) and 2 / 1 lanes per query
+  // (profiles/r03_knn_ab.md)
+  launch_knn_pk_t<4, 128, 6, 7>(g, rb, ps, pose, ctrl, forced, search_pose_out, s);
 }
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);

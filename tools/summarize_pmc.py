@@ -28,7 +28,7 @@ def main():
     fetch_kb, write_kb = res.get("FETCH_SIZE", 0.0), res.get("WRITE_SIZE", 0.0)
     hits, miss = res.get("TCC_HIT_sum", 0.0), res.get("TCC_MISS_sum", 0.0)
     j = {
-        "workload": "stream100k", "kernel": "lii::k_knn_pk<4, 128, 6, 6>",
+        "workload": "stream100k", "kernel": "lii::k_knn_pk<4, 128, 6, 7>",
         "command": "tools/collect_pmc.sh: rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python bench.py --steps 8 --warmup 2 "
                    "--prime 0 --profile-every 0 --no-cpu-baseline (one pass per counter set)",
         "counters_per_executed_launch": {k: v for k, v in res.items() if not k.endswith("_launches")},
