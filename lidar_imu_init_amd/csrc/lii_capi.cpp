@@ -516,6 +516,10 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
   }
   // `beside`: the update runs on the map stream from here (see map_join), behind what the handle's stream holds now
   if (beside) {
+    // (created on first use: a handle that never updates its map beside a scan - every rank of a sharded job - keeps one
+    // compute queue; several processes on one device oversubscribe the hardware queues otherwise, and a kernel that waits for
+    // a peer's kernel then waits for a time slice: the one-device rehearsal of a 2-rank job fell from 4 000 to 1 350 scans/s)
+    if (!h->map_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->map_stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventRecord(h->ev_lists, h->stream));
     s = h->map_stream;
     HIPCHK(h, hipStreamWaitEvent(s, h->ev_lists, 0));
@@ -962,7 +966,6 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     return rc;
   }
   CK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  CK(hipStreamCreateWithFlags(&h->map_stream, hipStreamNonBlocking));
   const size_t N = size_t(cfg->max_scan_points), M = size_t(cfg->max_map_points);
   const size_t NM = std::max(N, M);
   CK(dmalloc(&h->d_map_unsorted, M));
