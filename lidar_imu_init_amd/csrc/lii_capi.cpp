@@ -56,6 +56,10 @@ struct lii_context {
   unsigned int* d_work = nullptr;     // work list of the update in flight (cell entries)
   unsigned int work_cap = 0;
   unsigned int *d_ins_e = nullptr, *d_ins_e2 = nullptr;  // cell entry of every insert (fold output / plain list)
+  unsigned long long* d_ah_key = nullptr;   // hash-grouped fold of lii_map_incremental (lii_map.hip: AddHash): voxel keys,
+  unsigned long long* d_ah_best = nullptr;  // per-slot minima (both all ones between updates),
+  unsigned int* d_ah_slot = nullptr;        // the slot of every batch point
+  bool fold_sorted = false;                 // LII_TEST=fold_sort: lii_map_incremental folds through the batch sort as lii_map_add_points does
   int* d_mapctr = nullptr;            // kMapCtr* counters
   int n_used = 0;                     // host copy of kMapCtrUsed as of the last map_counters()
   bool map_dirty = false;             // an update has been enqueued since the last map_counters(): n_map / n_used / n_blocks are stale
@@ -157,8 +161,8 @@ struct lii_context {
   int pred_add = -1, pred_nodown = -1;  // lii_map_incremental: list sizes the next update is enqueued for (< 0: none yet)
   bool lists_predicted = false;         // the update in flight ran on predicted sizes: commit_map checks it against the exact ones
   hipEvent_t ev_lists = nullptr;        // the two lists are complete (compute stream -> map stream)
-  int* h_mapflag = nullptr;       // pinned, behind the last in-place update: [0] kMapCtrOverflow, [16..31] the map counters, [32..36] the list
-                                  // counts of lii_map_incremental (k_compact_lists) - read by commit_map
+  int* h_mapflag = nullptr;       // pinned, behind the last in-place update: [0..15] the map counters, [16..20] the list counts of
+                                  // lii_map_incremental (k_compact_lists) - read by commit_map / map_join
   hipEvent_t ev_mapflag = nullptr;
   bool map_flag_pending = false;
   bool diag = false;     // LII_DIAG=1: counters of the rare paths on stderr when the handle is destroyed
@@ -352,7 +356,7 @@ int build_index(lii_handle h, int n, int extra_blocks = 0) {
 int map_counters(lii_handle h, bool already_synced);
 int map_rebuild(lii_handle h, int extra_blocks);
 int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra, bool beside = false,
-              const int* n_list_dev = nullptr, const int* n_extra_dev = nullptr);
+              const int* n_list_dev = nullptr, const int* n_extra_dev = nullptr, bool count_events = true);
 int map_counters(lii_handle h, bool already_synced = false);
 // lii_map_incremental leaves its in-place update running on a stream of its own: the next scan's arrival, de-skew and voxel
 // filter (which touch neither the map nor the update's scratch) overlap it.  Whatever reads or writes the map, its counters or
@@ -377,14 +381,14 @@ int map_join(lii_handle h) {
     // next prediction, and an update whose lists outgrew their bounds did nothing (k_compact_lists emptied them) - it is
     // repeated now, with the exact sizes (the lists themselves are untouched until the next lii_map_incremental).
     h->lists_predicted = false;
-    const int ca = h->h_mapflag[32], cn = h->h_mapflag[33];
+    const int ca = h->h_mapflag[kMapCtrWords], cn = h->h_mapflag[kMapCtrWords + 1];
     note_list_sizes(h, ca, cn);
-    if (h->h_mapflag[34]) {
+    if (h->h_mapflag[kMapCtrWords + 2]) {
       h->map_repeats++;
       if (h->diag && h->map_repeats <= 8)
         std::fprintf(stderr, "[libliinit_hip] map update repeated: lists of %d / %d points, enqueued for %d / %d\n", ca, cn, h->bound_add, h->bound_nodown);
       h->map_flag_pending = false;  // (of the update that did nothing)
-      return map_apply(h, h->d_list_add, ca, true, h->d_list_nodown, cn);
+      return map_apply(h, h->d_list_add, ca, true, h->d_list_nodown, cn, false, nullptr, nullptr, false);
     }
   }
   return LII_OK;
@@ -397,13 +401,13 @@ int commit_map(lii_handle h) {
   if (!h->map_dirty || !h->map_flag_pending) return LII_OK;
   HIPCHK(h, hipEventSynchronize(h->ev_mapflag));
   h->map_flag_pending = false;
-  if (*h->h_mapflag != 0) {  // ran out of provisioned room: rebuild + re-insertion of the parked points
+  if (h->h_mapflag[kMapCtrOverflow] != 0) {  // ran out of provisioned room: rebuild + re-insertion of the parked points
     const int rc = map_counters(h, false);
     if (rc != LII_OK) return rc;
   } else {  // the counters came along: the host's copies are current again without a read of their own
-    h->n_used = h->h_mapflag[16 + kMapCtrUsed];
-    h->n_map = h->h_mapflag[16 + kMapCtrValid];
-    h->n_blocks = int(std::min<size_t>(size_t(std::max(h->h_mapflag[16 + kMapCtrBlocks], 0)), h->cells_cap_blocks));
+    h->n_used = h->h_mapflag[kMapCtrUsed];
+    h->n_map = h->h_mapflag[kMapCtrValid];
+    h->n_blocks = int(std::min<size_t>(size_t(std::max(h->h_mapflag[kMapCtrBlocks], 0)), h->cells_cap_blocks));
     h->map_dirty = false;
   }
   return LII_OK;
@@ -491,8 +495,10 @@ int map_rebuild(lii_handle h, int extra_blocks) {
 // replace points instead of adding them; the check still counts every point of it) - a refused batch leaves the map untouched.
 // n_list_dev / n_extra_dev != nullptr: the lists hold *n_list_dev / *n_extra_dev points (device-resident), n_list / n_extra are
 // bounds of them (lii_map_incremental's predicted sizes); the launches are made for the bounds.
+// count_events = false (lii_map_incremental): Add_Points' event counter is not needed - the down-sampled list is folded through
+// the hash table instead of the batch sort (lii_map.hip: AddHash).
 int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra, bool beside,
-              const int* n_list_dev, const int* n_extra_dev) {
+              const int* n_list_dev, const int* n_extra_dev, bool count_events) {
   hipStream_t s = h->stream;
   int rc = map_counters(h);
   if (rc != LII_OK) return rc;
@@ -516,10 +522,7 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
   }
   // `beside`: the update runs on the map stream from here (see map_join), behind what the handle's stream holds now
   if (beside) {
-    // (created on first use: a handle that never updates its map beside a scan - every rank of a sharded job - keeps one
-    // compute queue; several processes on one device oversubscribe the hardware queues otherwise, and a kernel that waits for
-    // a peer's kernel then waits for a time slice: the one-device rehearsal of a 2-rank job fell from 4 000 to 1 350 scans/s)
-    if (!h->map_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->map_stream, hipStreamNonBlocking));
+    if (!h->map_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->map_stream, hipStreamNonBlocking));  // (a handle that left a job)
     HIPCHK(h, hipEventRecord(h->ev_lists, h->stream));
     s = h->map_stream;
     HIPCHK(h, hipStreamWaitEvent(s, h->ev_lists, 0));
@@ -527,12 +530,17 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
   const GridView g = grid_view(h);
   h->map_dirty = true;
   const unsigned int tables_cap = (unsigned int)h->cells_cap_blocks;
-  HIPCHK(h, hipMemsetAsync(h->d_mapctr + kMapCtrEvents, 0, sizeof(int), s));
+  if (!(downsample && n_list > 0)) HIPCHK(h, hipMemsetAsync(h->d_mapctr + kMapCtrEvents, 0, sizeof(int), s));  // (else: k_add_keys / k_addh_insert)
   // one launch each for the cells of both insert lists and for writing both (the second list rides behind the first)
   const float4* list_a = list;
   const unsigned int* flags_a = nullptr;
-  if (downsample && n_list > 0) {
-    launch_add_keys(list, n_list, n_list_dev, h->ds, h->d_keys_a, h->d_idx_a, s);
+  if (downsample && n_list > 0 && !count_events && !h->fold_sorted && n_list <= h->cfg.max_scan_points) {
+    launch_add_fold_hashed(list, n_list, n_list_dev, h->ds, g, h->d_ah_key, h->d_ah_best, h->d_ah_slot, h->d_tomb, h->d_ins, h->d_u32_a,
+                           reinterpret_cast<unsigned int*>(h->d_mapctr + kMapCtrEvents), h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s);
+    list_a = h->d_ins;
+    flags_a = h->d_u32_a;
+  } else if (downsample && n_list > 0) {
+    launch_add_keys(list, n_list, n_list_dev, h->ds, h->d_keys_a, h->d_idx_a, h->d_mapctr + kMapCtrEvents, s);
     sort_pairs_u64(h->d_sort_temp, h->sort_temp_bytes, h->d_keys_a, h->d_keys_b, h->d_idx_a, h->d_idx_b, n_list, s);
     launch_add_fold(list, h->d_keys_b, h->d_idx_b, n_list, h->ds, g, h->d_tomb, h->d_ins, h->d_u32_a,
                     reinterpret_cast<unsigned int*>(h->d_mapctr + kMapCtrEvents), h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s);
@@ -546,9 +554,9 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
                    h->drop_cap, s);
   HIPCHK(h, hipGetLastError());
   // the update's overflow flag travels to the host behind its kernels (see commit_map)
-  HIPCHK(h, hipMemcpyAsync(h->h_mapflag, h->d_mapctr + kMapCtrOverflow, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipMemcpyAsync(h->h_mapflag + 16, h->d_mapctr, sizeof(int) * kMapCtrWords, hipMemcpyDeviceToHost, s));
-  if (n_list_dev) HIPCHK(h, hipMemcpyAsync(h->h_mapflag + 32, h->d_counts, sizeof(int) * 5, hipMemcpyDeviceToHost, s));
+  // (ONE copy: the map counters and the list counts of lii_map_incremental sit behind each other - every small copy is a blit
+  // kernel of ~5 us on this stream)
+  HIPCHK(h, hipMemcpyAsync(h->h_mapflag, h->d_mapctr, sizeof(int) * (kMapCtrWords + 8), hipMemcpyDeviceToHost, s));
   h->lists_predicted = n_list_dev != nullptr;
   HIPCHK(h, hipEventRecord(h->ev_mapflag, s));
   h->map_flag_pending = true;
@@ -701,6 +709,12 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   int rc = commit_map(h);
   if (rc != LII_OK) return rc;
   hipStream_t s = h->stream;
+  // The stream lii_map_incremental leaves its update on is created with the first update of a handle that is NOT a rank of a
+  // sharded job (those never update beside a scan).  Not in lii_create: a second compute queue per process - even one whose
+  // stream has been destroyed again: the runtime keeps the hardware queue - makes several processes on one device oversubscribe
+  // the hardware queues, and a kernel that waits for a peer's kernel (the mailbox) then waits for a time slice: the one-device
+  // rehearsal of a 2-rank job fell from 4 000 to 1 350 scans/s.
+  if (!h->map_stream && h->n_ranks <= 1) HIPCHK(h, hipStreamCreateWithFlags(&h->map_stream, hipStreamNonBlocking));
   if (!h->ctrl_preloaded) {
     if (h->staging_busy) HIPCHK(h, hipStreamSynchronize(s));  // a lii_scan_register that failed half way left the buffer in use
     fill_ctrl(h, state, state_prop, opts);
@@ -936,7 +950,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     // spare room), "plan_force=<mask>" (a launch plan that is wrong on purpose), "host_solve" (the iteration loop driven from the
     // host around lii_iekf_iterate with the literal two-inversion algebra), "sync_result" (every update ends with
     // hipStreamSynchronize instead of polling the result word), "graph" (the enqueued passes of an update replayed from a
-    // captured hipGraph), "pred_small" (lii_map_incremental predicts list sizes that are always too small)
+    // captured hipGraph), "pred_small" (lii_map_incremental predicts list sizes that are always too small), "fold_sort"
+    // (lii_map_incremental folds its list through the batch sort, as lii_map_add_points does, instead of the hash table)
     const std::string t(v);
     h->map_tight = t.find("map_tight") != std::string::npos;
     const size_t q = t.find("plan_force=");
@@ -945,6 +960,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     h->poll_result = t.find("sync_result") == std::string::npos;
     h->use_graph = t.find("graph") != std::string::npos;
     h->test_pred_small = t.find("pred_small") != std::string::npos;
+    h->fold_sorted = t.find("fold_sort") != std::string::npos;
   }
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;
@@ -976,8 +992,9 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_work, size_t(h->work_cap)));
   CK(dmalloc(&h->d_ins_e, NM));
   CK(dmalloc(&h->d_ins_e2, NM));
-  CK(dmalloc(&h->d_mapctr, kMapCtrWords));
-  CK(hipMemset(h->d_mapctr, 0, sizeof(int) * kMapCtrWords));
+  CK(dmalloc(&h->d_mapctr, kMapCtrWords + 8));  // (+ the list counts of lii_map_incremental: one copy brings both to the host)
+  CK(hipMemset(h->d_mapctr, 0, sizeof(int) * (kMapCtrWords + 8)));
+  h->d_counts = h->d_mapctr + kMapCtrWords;
   CK(dmalloc(&h->d_keys_a, M));
   CK(dmalloc(&h->d_keys_b, M));
   CK(dmalloc(&h->d_keys_c, M));
@@ -1006,10 +1023,13 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_u32_a, NM));
   CK(dmalloc(&h->d_u32_b, NM));
   CK(dmalloc(&h->d_u32_c, NM));
+  {
+    const size_t slots = add_hash_slots(int(N));
+    CK(dmalloc(&h->d_ah_key, slots)); CK(dmalloc(&h->d_ah_best, slots)); CK(dmalloc(&h->d_ah_slot, N));
+    CK(hipMemset(h->d_ah_key, 0xFF, 8 * slots)); CK(hipMemset(h->d_ah_best, 0xFF, 8 * slots));
+  }
   CK(dmalloc(&h->d_list_add, N));
   CK(dmalloc(&h->d_list_nodown, N));
-  CK(dmalloc(&h->d_counts, 8));
-  CK(hipMemset(h->d_counts, 0, 32));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->n_map_pinned), 64, hipHostMallocDefault));
   h->n_map_pinned[0] = 0;
   h->sort_temp_bytes = sort_temp_bytes(int(std::max<size_t>(NM, h->cells_cap_blocks * 512)));
@@ -1115,7 +1135,7 @@ int lii_destroy(lii_handle h) {
   if (h->h_stage_next) (void)hipHostFree(h->h_stage_next);
   if (h->d_scan_next) (void)hipFree(h->d_scan_next);
   void* dev[] = {h->d_dropped, h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
-                 h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_counts, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
+                 h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_ah_key, h->d_ah_best, h->d_ah_slot, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
                  h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->vh.key, h->vh.first, h->vh.count, h->vh.head, h->vh.members, h->vh.slot_of, h->vh.next, h->vh.block_firsts, h->vh.crowded, h->d_vh_first, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
@@ -1772,7 +1792,7 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
     h->bound_add = ba; h->bound_nodown = bn;  // (LII_TEST=pred_small: every update outgrows its bounds)
     launch_map_decide_compact(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, h->d_u32_a,
                               reinterpret_cast<uint2*>(h->d_u32_b), h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, ba, bn, s);
-    return map_apply(h, h->d_list_add, ba, true, h->d_list_nodown, bn, true, h->d_counts + 3, h->d_counts + 4);
+    return map_apply(h, h->d_list_add, ba, true, h->d_list_nodown, bn, true, h->d_counts + 3, h->d_counts + 4, false);
   }
   launch_map_decide_compact(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, h->d_u32_a,
                             reinterpret_cast<uint2*>(h->d_u32_b), h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, nb, nb, s);
@@ -1793,7 +1813,7 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
   // Add_Points(PointToAdd, true) then Add_Points(PointNoNeedDownsample, false)  (:556-557)
   // (the stream has just been synchronised: the update may run beside whatever the caller enqueues next - a sharded job keeps
   // one stream: its search of the whole cloud above reads the control block the next scan's arrival rewrites)
-  int rc = map_apply(h, h->d_list_add, n_lists[0], true, h->d_list_nodown, n_lists[1], !sharded);
+  int rc = map_apply(h, h->d_list_add, n_lists[0], true, h->d_list_nodown, n_lists[1], !sharded, nullptr, nullptr, false);
   if (rc != LII_OK) return rc;
   if (n_add) *n_add = n_lists[0];
   if (n_no_downsample) *n_no_downsample = n_lists[1];

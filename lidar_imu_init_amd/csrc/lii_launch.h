@@ -89,10 +89,14 @@ void launch_calib_eval(int stage, const double* imu, const double* lidar, int n,
 // device-side map maintenance (lii_map.hip)
 void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* cls, uint2* blk_counts,
                                float4* world, float4* dst_add, float4* dst_nodown, int* counts, int bound_add, int bound_nodown, hipStream_t s);
-void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, hipStream_t s);
+void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, int* events, hipStream_t s);
 void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
                      unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, unsigned int* tp, unsigned int* work,
                      int* ctr, unsigned int work_cap, hipStream_t s);
+size_t add_hash_slots(int max_n);
+void launch_add_fold_hashed(const float4* add_pts, int n, const int* n_dev, float ds, const GridView& g, unsigned long long* hkey,
+                            unsigned long long* hbest, unsigned int* slot_of, unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag,
+                            unsigned int* events, unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s);
 // in-place map update (lii_map.hip)
 void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, const float4* list2, int n2, const int* n2_dev, unsigned int* ins_e2,
                       BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp,

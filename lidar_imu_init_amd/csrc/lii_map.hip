@@ -208,8 +208,9 @@ __global__ __launch_bounds__(256) void k_compact_lists(const float4* __restrict_
 // ------------------------------------------------------------------------------------------------ Add_Points (down-sampling)
 // n may be an upper bound: entries i >= *n_dev get the invalid key and sort to the end.
 __global__ void k_add_keys(const float4* __restrict__ pts, int n, const int* __restrict__ n_dev, float ds,
-                           unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx) {
+                           unsigned long long* __restrict__ keys, unsigned int* __restrict__ idx, int* __restrict__ events) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *events = 0;  // the fold of this batch counts from zero (it runs behind this launch)
   if (i >= n) return;
   unsigned long long key = kInvalidKey;
   if (!n_dev || i < *n_dev) {
@@ -224,6 +225,62 @@ __global__ void k_add_keys(const float4* __restrict__ pts, int n, const int* __r
 }
 
 
+// Hash-grouped form of the same fold (lii_map_incremental; round 3).  What Add_Points leaves in a down-sample box does not depend
+// on the order of the batch except for ties: with E the existing in-box point closest to the centre (strictly closer than any
+// other, first in walk order) and P* the batch point of the voxel closest to the centre (ties: the LAST in batch order - every
+// later point replaces the running winner at equal distance, ikd_Tree.cpp:407-413), the box ends up with P* if d(P*) <= d(E) and
+// with E otherwise (and with nothing else).  Only the event counter Add_Points returns depends on the order - and
+// lii_map_incremental does not report it.  So the voxel groups need not be sorted, not even brought together: every batch point
+// finds its voxel's slot in an open-addressing table (CAS on the 63-bit voxel key) and takes part in ONE 64-bit atomicMin per
+// slot on (distance bits << 32 | ~index); the point that holds the minimum afterwards is P* and leads the voxel through
+// k_add_fold8<true>.  Two launches instead of the key kernel, the batch sort (5 - 7 launches) and the fold.
+struct AddHash {
+  unsigned long long* key;   // voxel key, kInvalidKey = free
+  unsigned long long* best;  // (float bits of d2 to the voxel centre << 32) | ~batch index; ~0 = none
+  unsigned int* slot_of;     // per batch point
+  unsigned int mask;         // slots - 1
+};
+__device__ __forceinline__ unsigned int ah_hash(unsigned long long k) {
+  k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 33; k *= 0xC4CEB9FE1A85EC53ull; k ^= k >> 33;
+  return (unsigned int)k;
+}
+__device__ __forceinline__ void add_box(const float4 p, float ds, float (&bmin)[3], float (&bmax)[3], float (&mid)[3]) {
+  const float cc[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    bmin[a] = floorf(cc[a] / ds) * ds;
+    bmax[a] = bmin[a] + ds;
+    mid[a] = (float)((double)bmin[a] + (double)(bmax[a] - bmin[a]) / 2.0);
+  }
+}
+__global__ void k_addh_insert(const float4* __restrict__ pts, int n, const int* __restrict__ n_dev, float ds, AddHash tb,
+                              unsigned int* __restrict__ ins_flag, int* __restrict__ events) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *events = 0;  // (this form does not count Add_Points' events)
+  if (i >= n) return;
+  ins_flag[i] = 0;
+  unsigned int slot = 0xFFFFFFFFu;
+  if (!n_dev || i < *n_dev) {
+    const float4 p = pts[i];
+    const int vx = (int)floorf(p.x / ds), vy = (int)floorf(p.y / ds), vz = (int)floorf(p.z / ds);  // (:390-395, float arithmetic)
+    const unsigned long long key = ((unsigned long long)(unsigned)(vz + kBias) << 42) | ((unsigned long long)(unsigned)(vy + kBias) << 21) |
+                                   (unsigned long long)(unsigned)(vx + kBias);
+    float bmin[3], bmax[3], mid[3];
+    add_box(p, ds, bmin, bmax, mid);
+    const float d = d_dist2(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
+    if (d == d) {  // (a non-finite point takes no part)
+      slot = ah_hash(key) & tb.mask;
+      while (true) {
+        const unsigned long long prev = atomicCAS(tb.key + slot, kInvalidKey, key);
+        if (prev == kInvalidKey || prev == key) break;
+        slot = (slot + 1) & tb.mask;
+      }
+      atomicMin(tb.best + slot, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(~(unsigned int)i));
+    }
+  }
+  tb.slot_of[i] = slot;
+}
+
 // Add_Points with down-sampling, one voxel group (the batch points of one down-sample box, adjacent after the sort) per EIGHT
 // lanes.  tomb[j] = 1 marks existing map point j as deleted; ins_flag[i] = 1 / ins_pts[i] = the point to insert, for the group
 // starting at sorted position i; *events accumulates the reference's tmp_counter (ikd_Tree.cpp:381-426).
@@ -234,8 +291,11 @@ __global__ void k_add_keys(const float4* __restrict__ pts, int n, const int* __r
 // of the in-place update).  Groups whose box spans more cells (a caller-chosen cell edge below ds) are walked by lane 0 alone,
 // cells in z-outer / x-inner order.  The lanes are numbered in that order too, ties of the squared distance go to the lower
 // lane / lower index: both forms visit the existing points in the same order.
+// HASHED: the groups come out of the table of k_addh_insert instead of the sorted keys - the batch point that holds its voxel's
+// minimum leads (ins_flag / ins_pts at its own batch index), the replay is the comparison of that point with the existing one.
+template <bool HASHED>
 __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ add_pts, const unsigned long long* __restrict__ keys,
-                                                   const unsigned int* __restrict__ idx, int n, float ds, GridView g,
+                                                   const unsigned int* __restrict__ idx, AddHash tb, int n, float ds, GridView g,
                                                    unsigned char* __restrict__ tomb, float4* __restrict__ ins_pts,
                                                    unsigned int* __restrict__ ins_flag, unsigned int* __restrict__ events,
                                                    unsigned int* __restrict__ tp, unsigned int* __restrict__ work, int* __restrict__ ctr,
@@ -243,21 +303,23 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
   const int c = threadIdx.x & 7;
   const bool in_range = i < n;
-  if (in_range && c == 0) ins_flag[i] = 0;
-  const unsigned long long key = in_range ? keys[i] : kInvalidKey;
-  const bool leader_pos = in_range && key != kInvalidKey && !(i > 0 && keys[i - 1] == key);  // uniform over the 8 lanes
-  if (!leader_pos) return;
-  const float4 p0 = add_pts[idx[i]];
-  float bmin[3], bmax[3], mid[3];
-  {
-    const float cc[3] = {p0.x, p0.y, p0.z};
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      bmin[a] = floorf(cc[a] / ds) * ds;
-      bmax[a] = bmin[a] + ds;
-      mid[a] = (float)((double)bmin[a] + (double)(bmax[a] - bmin[a]) / 2.0);
-    }
+  unsigned long long key = kInvalidKey;
+  unsigned int slot = 0xFFFFFFFFu;
+  bool leader_pos;  // uniform over the 8 lanes
+  if (HASHED) {
+    slot = in_range ? tb.slot_of[i] : 0xFFFFFFFFu;
+    // (a slot its leader has already cleared reads all ones: not a minimum - distances are finite)
+    const unsigned long long bs = slot != 0xFFFFFFFFu ? tb.best[slot] : ~0ull;
+    leader_pos = bs != ~0ull && (unsigned int)bs == ~(unsigned int)i;
+  } else {
+    if (in_range && c == 0) ins_flag[i] = 0;
+    key = in_range ? keys[i] : kInvalidKey;
+    leader_pos = in_range && key != kInvalidKey && !(i > 0 && keys[i - 1] == key);
   }
+  if (!leader_pos) return;
+  const float4 p0 = add_pts[HASHED ? (unsigned int)i : idx[i]];
+  float bmin[3], bmax[3], mid[3];
+  add_box(p0, ds, bmin, bmax, mid);
   int c0[3], c1[3];
 #pragma unroll
   for (int a = 0; a < 3; a++) {
@@ -271,8 +333,12 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
   // the first eight batch points of the group, one per lane (the replay below reads them by shuffle instead of walking
   // keys[t] -> idx[t] -> add_pts[...] one dependent pair of loads per point); the loads overlap the grid lookups
   const int tt = i + c;
-  const bool mv = tt < n && keys[tt] == key;
-  const float4 mp = mv ? add_pts[idx[tt]] : make_float4(0.f, 0.f, 0.f, 0.f);
+  bool mv = false;
+  float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!HASHED) {
+    mv = tt < n && keys[tt] == key;
+    if (mv) mp = add_pts[idx[tt]];
+  }
   int n0 = 0, best = -1;
   float bestd = __builtin_inff();
   uint2 r = make_uint2(0u, 0u);
@@ -326,7 +392,20 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
   // every lane): the first eight points come out of the lanes' registers by shuffle, a longer group goes on from memory.
   bool ev = false, cur_new = false;
   int cur_old = -1;
-  {
+  if (HASHED) {
+    // the leader IS the batch point that stays if a batch point does; E stays if it is strictly closer (and then every other
+    // existing in-box point goes); a lone E that stays leaves the voxel untouched
+    const float dp = d_dist2(p0.x, p0.y, p0.z, mid[0], mid[1], mid[2]);
+    const bool old_wins = (n0 > 0) && (bestd < dp);
+    ev = !old_wins || n0 > 1;
+    cur_new = !old_wins;
+    cur_old = old_wins ? best : -1;
+    if (c == 0) {
+      if (cur_new) { ins_pts[i] = make_float4(p0.x, p0.y, p0.z, 0.f); ins_flag[i] = 1; }
+      tb.key[slot] = kInvalidKey;  // the slot is free again for the next batch
+      tb.best[slot] = ~0ull;
+    }
+  } else {
     const int lead = (threadIdx.x & 63) & ~7;
     const unsigned int gm = (unsigned int)((__ballot(mv) >> lead) & 0xFFull);  // the group is contiguous: a prefix of the 8 lanes
     const int m8 = __popc(gm);
@@ -726,14 +805,34 @@ void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps,
   hipLaunchKernelGGL(k_map_decide, dim3(nb), dim3(256), 0, s, rb, ps, fsd, have_search, cls, blk_counts, world);
   hipLaunchKernelGGL(k_compact_lists, dim3(nb), dim3(256), 0, s, world, cls, blk_counts, rb.n, dst_add, dst_nodown, counts, bound_add, bound_nodown);
 }
-void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_add_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, n_dev, ds, keys, idx);
+void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, int* events, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_add_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, n_dev, ds, keys, idx, events);
 }
 void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
                      unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, unsigned int* tp, unsigned int* work,
                      int* ctr, unsigned int work_cap, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_add_fold8, dim3(nblk(n * 8, 256)), dim3(256), 0, s, add_pts, keys, idx, n, ds, g, tomb, ins_pts, ins_flag, events, tp,
-                            work, ctr, work_cap);
+  AddHash none;
+  none.key = nullptr; none.best = nullptr; none.slot_of = nullptr; none.mask = 0;
+  if (n > 0) hipLaunchKernelGGL(k_add_fold8<false>, dim3(nblk(n * 8, 256)), dim3(256), 0, s, add_pts, keys, idx, none, n, ds, g, tomb, ins_pts, ins_flag,
+                            events, tp, work, ctr, work_cap);
+}
+// The hash-grouped form: n is a launch bound when n_dev != nullptr.  key / best: add_hash_slots(max batch) words each, all ones
+// between calls (the fold leaves them so); slot_of: one word per batch point.
+size_t add_hash_slots(int max_n) {
+  size_t slots = 1024;
+  while (slots < 4u * (size_t)max_n) slots <<= 1;
+  return slots;
+}
+void launch_add_fold_hashed(const float4* add_pts, int n, const int* n_dev, float ds, const GridView& g, unsigned long long* hkey,
+                            unsigned long long* hbest, unsigned int* slot_of, unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag,
+                            unsigned int* events, unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s) {
+  if (n <= 0) return;
+  AddHash tb;
+  tb.key = hkey; tb.best = hbest; tb.slot_of = slot_of;
+  tb.mask = (unsigned int)(add_hash_slots(n) - 1);
+  hipLaunchKernelGGL(k_addh_insert, dim3(nblk(n, 256)), dim3(256), 0, s, add_pts, n, n_dev, ds, tb, ins_flag, reinterpret_cast<int*>(events));
+  hipLaunchKernelGGL(k_add_fold8<true>, dim3(nblk(n * 8, 256)), dim3(256), 0, s, add_pts, nullptr, nullptr, tb, n, ds, g, tomb, ins_pts, ins_flag,
+                     events, tp, work, ctr, work_cap);
 }
 
 }  // namespace lii

@@ -334,7 +334,9 @@ def test_long_update_sequence_keeps_the_tree_set(oracle):
 def test_map_incremental_without_counts_gives_the_same_map(hook):
     """lii_map_incremental with both size pointers NULL enqueues the update for PREDICTED list sizes on a stream of its own and
     returns at once; an update whose lists outgrow the prediction is repeated with the exact sizes before the next search
-    (LII_TEST=pred_small: every one does).  Same scans, same poses -> the same map, point for point, as the waiting form."""
+    (LII_TEST=pred_small: every one does), and folds the add list through a hash table instead of the batch sort (the box an
+    Add_Points batch leaves behind does not depend on the batch order).  Same scans, same poses -> the same map, point for point,
+    as the waiting, sorting form."""
     import bench
     import lidar_imu_init_amd as lii
     wl = bench.build_workload("os1_128_cut3", 4)
@@ -366,7 +368,9 @@ def test_map_incremental_without_counts_gives_the_same_map(hook):
         finally:
             reg.close()
 
-    ref_out, ref_map = run(True, "")
+    # the waiting form, folded through the batch sort (what lii_map_add_points does, and round 2 did here) - against the
+    # returning form, folded through the hash table, on predicted sizes
+    ref_out, ref_map = run(True, "fold_sort")
     got_out, got_map = run(False, hook)
     assert len(ref_map) > len(wl["map"])  # the map did grow
     for a, b in zip(ref_out, got_out):
