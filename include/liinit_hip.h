@@ -223,8 +223,8 @@ int lii_frame_select(lii_handle h, int32_t frame);
  *   final state lands in mapped host memory followed by a sequence word the call waits for — one host round trip per
  *   call, and the call returns as soon as the result exists: passes still queued behind the stopping one (they read a flag
  *   and return) drain in stream order while the caller goes on; every later call on the handle is ordered behind them.
- *   (LII_SYNC_RESULT=1 waits for the whole stream instead.  LII_HOST_SOLVE=1 drives the loop from the host around
- *   lii_iekf_iterate with the literal two-inversion algebra.)
+ *   (LII_TEST=sync_result waits for the whole stream instead.  LII_TEST=host_solve drives the loop from the host
+ *   around lii_iekf_iterate with the literal two-inversion algebra.)
  * lii_neighbors_download: Nearest_Points of the last search (for map_incremental, :525-549);
  *   pts = n_down x 5 x 3 floats, counts = n_down. */
 int lii_iekf_iterate(lii_handle h, const lii_state* state, int32_t search, int32_t imu_en, double out91[91]);
@@ -340,7 +340,7 @@ int lii_li_init_set_device(lii_handle h, int32_t on_device);
  *                          memory over PCIe): what LII_COMM_MAILBOX falls back to in AUTO mode when an IPC handle cannot be
  *                          exported or opened.
  *   LII_COMM_RCCL          ncclAllReduce on the handle's stream between a separate final-sum and solve launch (any topology).
- *   LII_COMM_AUTO          the HBM mailbox when all ranks meet on one node within LII_MAILBOX_WAIT_S (default 20 s), else the
+ *   LII_COMM_AUTO          the HBM mailbox when all ranks meet on one node within the set-up time (20 s; LII_MAILBOX_TIMEOUT_S=<exchange>[,<set-up>]), else the
  *                          host-memory mailbox, else RCCL.
  * A rank that stops calling (error on one rank only) makes the others' next update fail with LII_ERR_COMM after
  * LII_MAILBOX_TIMEOUT_S (default 30 s; RCCL: its own watchdog); the communicator must then be re-created.  lii_comm_init == lii_comm_init_ex(..., LII_COMM_AUTO). */
