@@ -112,6 +112,7 @@ struct lii_context {
   int extent_sel = 0, mm_sel = 0;
   bool knn_plan = true;        // LII_KNN_PLAN=0: every k-NN launch is enqueued (IekfCtrl::plan_mask)
   bool test_pred_small = false;
+  bool no_fuse = false;        // LII_TEST=no_fuse: lii_scan_register keeps the de-skew and the voxel filter's insert in separate launches
   bool use_graph = false;      // LII_TEST=graph: the passes of an update are captured once per (cloud bound, plan, map view) and replayed
   std::map<std::string, hipGraphExec_t> graphs;
   int plan_passes_prev = 32;   // passes the update before the last one ran (the plan enqueues the larger of the last two)
@@ -134,6 +135,9 @@ struct lii_context {
   unsigned char* d_vh_first = nullptr;
   bool voxel_sort = false;       // LII_VOXEL_FILTER=sort
   bool vh_pinned = false;        // LII_VOXEL_FILTER=hash: no probing
+  float fuse_leaf = 0.f;         // lii_scan_register -> lii_undistort_imu: the voxel filter that follows runs at this leaf (0: none)
+  float vh_inserted_leaf = 0.f;
+  bool vh_inserted = false;      // ... and the de-skew has filled the hashed filter's table on the way (lii_downsample goes on from there)
   int vh_mode = 1;               // 1: sparse voxels (hashed filter), 0: crowded voxels (sample sort)
   float vh_leaf = -1.f;          // the leaf size the choice was probed for
   unsigned int vh_watch = 0;
@@ -951,7 +955,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     // host around lii_iekf_iterate with the literal two-inversion algebra), "sync_result" (every update ends with
     // hipStreamSynchronize instead of polling the result word), "graph" (the enqueued passes of an update replayed from a
     // captured hipGraph), "pred_small" (lii_map_incremental predicts list sizes that are always too small), "fold_sort"
-    // (lii_map_incremental folds its list through the batch sort, as lii_map_add_points does, instead of the hash table)
+    // (lii_map_incremental folds its list through the batch sort, as lii_map_add_points does, instead of the hash table), "no_fuse"
+    // (lii_scan_register keeps the de-skew and the insert of the hashed voxel filter in separate launches)
     const std::string t(v);
     h->map_tight = t.find("map_tight") != std::string::npos;
     const size_t q = t.find("plan_force=");
@@ -961,6 +966,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     h->use_graph = t.find("graph") != std::string::npos;
     h->test_pred_small = t.find("pred_small") != std::string::npos;
     h->fold_sorted = t.find("fold_sort") != std::string::npos;
+    h->no_fuse = t.find("no_fuse") != std::string::npos;
   }
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;
@@ -1085,6 +1091,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_vpcl_out, N));
   {
     const size_t slots = voxel_hash_slots((int)N);
+    CK(dmalloc(&h->vh.key64, slots)); CK(hipMemset(h->vh.key64, 0xFF, 8 * slots));
     CK(dmalloc(&h->vh.key, slots)); CK(dmalloc(&h->vh.first, slots)); CK(dmalloc(&h->vh.count, slots)); CK(dmalloc(&h->vh.head, slots));
     CK(dmalloc(&h->vh.members, slots * 7));
     CK(dmalloc(&h->vh.slot_of, N)); CK(dmalloc(&h->vh.next, N)); CK(dmalloc(&h->vh.block_firsts, N / 256 + 8));
@@ -1137,7 +1144,7 @@ int lii_destroy(lii_handle h) {
   void* dev[] = {h->d_dropped, h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_ah_key, h->d_ah_best, h->d_ah_slot, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
-                 h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->vh.key, h->vh.first, h->vh.count, h->vh.head, h->vh.members, h->vh.slot_of, h->vh.next, h->vh.block_firsts, h->vh.crowded, h->d_vh_first, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
+                 h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->vh.key64, h->vh.key, h->vh.first, h->vh.count, h->vh.head, h->vh.members, h->vh.slot_of, h->vh.next, h->vh.block_firsts, h->vh.crowded, h->d_vh_first, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -1427,7 +1434,12 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
   std::memcpy(u.RLI, R_LI, 72);
   std::memcpy(u.TLI, T_LI, 24);
   unsigned long long* ext = extent_of_scan(h);
-  launch_undistort_imu(h->d_scan, h->n_scan, h->d_poses, n_poses, u, ext, h->d_bbox_rows, h->stream);
+  // lii_scan_register told us the hashed voxel filter follows at a leaf that has been probed: its insert rides in the de-skew
+  // (one launch less per scan; lii_downsample goes on with link + emit)
+  h->vh_inserted = h->fuse_leaf > 0.f && !h->voxel_sort && h->vh_mode == 1 && (h->vh_pinned || h->fuse_leaf == h->vh_leaf) && !h->no_fuse;
+  if (h->vh_inserted) h->vh_inserted_leaf = h->fuse_leaf;
+  if (h->vh_inserted) launch_undistort_imu_vhash(h->d_scan, h->n_scan, h->d_poses, n_poses, u, ext, h->d_bbox_rows, h->fuse_leaf, h->vh, h->stream);
+  else launch_undistort_imu(h->d_scan, h->n_scan, h->d_poses, n_poses, u, ext, h->d_bbox_rows, h->stream);
   h->bbox_rows = (h->n_scan + 255) / 256;
   HIPCHK(h, hipGetLastError());
   return LII_OK;
@@ -1488,7 +1500,13 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
     else if (h->vh_mode == 1 && *h->h_vh_crowded > 64u) h->vh_mode = 0;     // crowded -> the sort
   }
   int hash_stages = 3;
-  if (!h->vh_pinned && !h->voxel_sort && leaf != h->vh_leaf) {
+  // the de-skew of this scan has already filled the table (lii_scan_register: k_undistort_imu<true>): link + emit follow,
+  // whatever the watch above has decided for the scans to come
+  const bool inserted = h->vh_inserted;
+  h->vh_inserted = false;
+  if (inserted && leaf != h->vh_inserted_leaf) return fail(h, LII_ERR_STATE, "lii_downsample: the de-skew prepared the voxel filter for another leaf size");
+  if (inserted) hash_stages = 4;
+  if (!inserted && !h->vh_pinned && !h->voxel_sort && leaf != h->vh_leaf) {
     h->vh_leaf = leaf;
     h->vh_flag_pending = false;
     HIPCHK(h, hipMemsetAsync(h->vh.crowded, 0, sizeof(unsigned int), s));
@@ -1506,7 +1524,7 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
       HIPCHK(h, hipMemsetAsync(h->vh.count, 0, 4 * slots, s));
     }
   }
-  const bool use_hash = h->vh_mode == 1 && !h->voxel_sort;
+  const bool use_hash = inserted || (h->vh_mode == 1 && !h->voxel_sort);
   h->voxel_path_hash = use_hash;
   if (use_hash) {
     launch_voxel_hash(h->vh, h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_body, h->d_nbody, h->d_nbody + 1, h->d_vpcl_out, hash_stages, s);
@@ -1691,8 +1709,11 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   }
   const auto t_first = std::chrono::steady_clock::now();
   if (job->undistort == 1) {
+    h->fuse_leaf = job->leaf > 0 ? job->leaf : 0.f;  // (the voxel filter follows in this call: its insert may ride in the de-skew)
     rc = lii_undistort_imu(h, job->imu_poses, job->n_imu_poses, state->rot_end, state->pos_end, state->offset_R_L_I,
                            state->offset_T_L_I);
+    h->fuse_leaf = 0.f;
+    if (rc != LII_OK) h->vh_inserted = false;
   } else if (job->undistort == 2) {
     rc = lii_undistort_cv(h, state->bias_g, state->vel_end, state->rot_end);  // CV model: bias_g = omega, vel_end = v
   } else if (job->undistort != 0) {

@@ -1564,9 +1564,26 @@ __device__ __forceinline__ void deskew_bbox(float4 q, bool in_range, unsigned in
 // is: head = the LAST pose index h <= K-2 with offset_time[h] < t (strict) — points with no such head stay
 // untouched.  Quirk A3: the time-earliest point (first of the sorted cloud) is re-tested against every earlier
 // head after being compensated, so it is compensated once per qualifying head, in descending order.
+// (the table of the hashed voxel filter: described with its kernels further down)
+constexpr unsigned int kVhEmpty = 0xFFFFFFFFu;
+constexpr int kVhMembers = 7;  // members (beside the first point) a slot holds itself
+struct VhashTable {
+  unsigned long long* key64;  // the fused form (k_undistort_imu<true>): packed absolute voxel coordinates, all ones = free
+  unsigned int* key;     // PCL voxel index (identity path: the point index), kVhEmpty = free
+  unsigned int* first;   // smallest point index of the voxel
+  unsigned int* count;   // members handed in by k_vhash_link
+  unsigned int* head;    // linked list of the members beyond kVhMembers (through `next`), kVhEmpty = none
+  unsigned int* members; // kVhMembers per slot
+  unsigned int mask;     // slots - 1
+};
+__device__ __forceinline__ void vhash_insert_abs(const float4 P, int i, float leaf, const VhashTable& tb, unsigned int* __restrict__ slot_of);
+// FUSE: the de-skewed point goes straight into the table of the hashed voxel filter (vhash_insert_abs below) - the filter's own
+// insert launch is saved (lii_scan_register, IMU mode, hashed filter).
+template <bool FUSE>
 __global__ __launch_bounds__(256) void k_undistort_imu(float4* __restrict__ pts, int n, const double* __restrict__ poses, int K,
                                                        UndistArg u, const unsigned long long* __restrict__ extent,
-                                                       unsigned int* __restrict__ bbox_rows) {
+                                                       unsigned int* __restrict__ bbox_rows, float leaf, VhashTable tb,
+                                                       unsigned int* __restrict__ slot_of) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = i < n;
   float4 P = in_range ? pts[i] : make_float4(0, 0, 0, 0);
@@ -1606,6 +1623,7 @@ __global__ __launch_bounds__(256) void k_undistort_imu(float4* __restrict__ pts,
     }
   }
   deskew_bbox(P, in_range, bbox_rows);
+  if (FUSE && in_range) vhash_insert_abs(P, i, leaf, tb, slot_of);
 }
 
 struct CvArg {
@@ -1750,22 +1768,41 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ p
 //                   that order - the float additions of PCL's centroid - writes the centroid and clears its slot.
 // Deterministic: the slot a voxel lands in and the order in which members arrive vary from run to run, neither reaches the
 // output.
-constexpr unsigned int kVhEmpty = 0xFFFFFFFFu;
-constexpr int kVhMembers = 7;  // members (beside the first point) a slot holds itself
-struct VhashTable {
-  unsigned int* key;     // PCL voxel index (identity path: the point index), kVhEmpty = free
-  unsigned int* first;   // smallest point index of the voxel
-  unsigned int* count;   // members handed in by k_vhash_link
-  unsigned int* head;    // linked list of the members beyond kVhMembers (through `next`), kVhEmpty = none
-  unsigned int* members; // kVhMembers per slot
-  unsigned int mask;     // slots - 1
-};
 __device__ __forceinline__ unsigned int vh_hash(unsigned int k) {
   k *= 0x9E3779B1u;
   k ^= k >> 15;
   k *= 0x85EBCA77u;
   k ^= k >> 13;
   return k;
+}
+// The insert of the fused form.  The grid PCL lays over the cloud starts at the cloud's bounding box, which is only known when
+// every point has been de-skewed - but which points share a voxel is not: floor(x / leaf) decides it (PCL's index is
+// floor(x * inv_leaf) - min_b, the same classes).  So the table is keyed by the absolute voxel coordinates (three 21-bit fields
+// around a bias of 2^20: +- 52 km at a 5 cm leaf), and the PCL index of a voxel - the key the output is ordered by on the host -
+// is computed by k_vhash_emit<true>, which knows the box.  A point outside the 21-bit range is a voxel of its own.
+__device__ __forceinline__ void vhash_insert_abs(const float4 P, int i, float leaf, const VhashTable& tb, unsigned int* __restrict__ slot_of) {
+  unsigned int slot = kVhEmpty;
+  if (isfinite(P.x) && isfinite(P.y) && isfinite(P.z)) {  // (non-finite points are dropped, as PCL drops them)
+    const float inv_leaf = 1.0f / leaf;
+    const float fx = floorf(P.x * inv_leaf), fy = floorf(P.y * inv_leaf), fz = floorf(P.z * inv_leaf);
+    unsigned long long key;
+    if (fabsf(fx) < 1048000.f && fabsf(fy) < 1048000.f && fabsf(fz) < 1048000.f) {
+      key = ((unsigned long long)(unsigned)((int)fz + (1 << 20)) << 42) | ((unsigned long long)(unsigned)((int)fy + (1 << 20)) << 21) |
+            (unsigned long long)(unsigned)((int)fx + (1 << 20));
+    } else {
+      key = (1ull << 63) | (unsigned long long)(unsigned)i;
+    }
+    unsigned long long hk = key;
+    hk ^= hk >> 33; hk *= 0xFF51AFD7ED558CCDull; hk ^= hk >> 33;
+    slot = (unsigned int)hk & tb.mask;
+    for (;;) {  // the table has four times as many slots as there are points: a free slot always turns up
+      const unsigned long long prev = atomicCAS(tb.key64 + slot, ~0ull, key);
+      if (prev == ~0ull || prev == key) break;
+      slot = (slot + 1u) & tb.mask;
+    }
+    atomicMin(tb.first + slot, (unsigned)i);
+  }
+  slot_of[i] = slot;
 }
 __global__ __launch_bounds__(256) void k_vhash_insert(const float4* __restrict__ pts, int n, const unsigned int* __restrict__ mm,
                                                       const unsigned int* __restrict__ bbox_rows, int n_rows, float leaf,
@@ -1846,13 +1883,36 @@ __device__ __forceinline__ unsigned int block_rank_of_flag(bool f, unsigned int*
   *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
   return before + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
 }
+// ABS: the table was filled by the fused form (absolute voxel coordinates): the box arrives here (one row per de-skew
+// workgroup, folded by every workgroup for itself), the PCL index of a voxel is computed from its first point, and PCL's
+// overflow guard (the grid would have more than 2^31 voxels: "leaf size too small", the cloud passes unfiltered) is applied
+// here - every point then leaves as it is, in input order.
+template <bool ABS>
 __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ pts, int n, VhashTable tb,
                                                     const unsigned int* __restrict__ slot_of, const unsigned int* __restrict__ next,
                                                     const unsigned char* __restrict__ is_first,
                                                     const unsigned int* __restrict__ block_firsts, float4* __restrict__ out,
-                                                    int* __restrict__ n_out, unsigned int* __restrict__ pcl_out) {
+                                                    int* __restrict__ n_out, unsigned int* __restrict__ pcl_out,
+                                                    const unsigned int* __restrict__ bbox_rows, int n_rows, float leaf,
+                                                    int* __restrict__ filtered) {
   __shared__ unsigned int s_w[4], s_sum[4];
   const int tid = threadIdx.x, i = blockIdx.x * blockDim.x + tid;
+  VoxelArg v;
+  v.identity = 0;
+  if (ABS) {
+    __shared__ unsigned int s_mm[8];
+    unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+    for (int r = tid; r < n_rows; r += 256) {
+      const uint4 a = *reinterpret_cast<const uint4*>(bbox_rows + r * 8), b = *reinterpret_cast<const uint4*>(bbox_rows + r * 8 + 4);
+      lo[0] = min(lo[0], a.x); lo[1] = min(lo[1], a.y); lo[2] = min(lo[2], a.z);
+      hi[0] = max(hi[0], b.x); hi[1] = max(hi[1], b.y); hi[2] = max(hi[2], b.z);
+    }
+    block_bbox_reduce(lo, hi);
+    if (tid < 3) { s_mm[tid] = lo[0]; s_mm[3 + tid] = hi[0]; }
+    __syncthreads();
+    v = voxel_prepare(s_mm, leaf);
+    if (i == 0) *filtered = v.identity ? 0 : 1;
+  }
   unsigned int before = 0;  // firsts in the workgroups below this one
   for (int q = tid; q < (int)blockIdx.x; q += 256) before += block_firsts[q];
   for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
@@ -1862,7 +1922,15 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
   const bool first = i < n && is_first[i] != 0;
   unsigned int total;
   const unsigned int pos = base + block_rank_of_flag(first, s_w, &total);
-  if (blockIdx.x == gridDim.x - 1 && tid == 0) *n_out = (int)(base + total);  // size of the down-sampled cloud
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) *n_out = (ABS && v.identity) ? n : (int)(base + total);  // size of the down-sampled cloud
+  if (ABS && v.identity) {  // (uniform) the cloud passes unfiltered; the voxels' first points still hand their slots back
+    if (i < n) { out[i] = pts[i]; pcl_out[i] = (unsigned)i; }
+    if (first) {
+      const unsigned int sl = slot_of[i];
+      tb.key64[sl] = ~0ull; tb.first[sl] = kVhEmpty; tb.count[sl] = 0u; tb.head[sl] = kVhEmpty;
+    }
+    return;
+  }
   if (!first) return;
   const unsigned int slot = slot_of[i];
   const unsigned int cnt = tb.count[slot];
@@ -1902,8 +1970,17 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
   const float c = (float)(cnt + 1u);
   // a single-point voxel reproduces the point exactly (x / 1.0f == x), which is also what the identity path needs
   out[pos] = make_float4(sx / c, sy / c, sz / c, st / c);
-  pcl_out[pos] = tb.key[slot];
-  tb.key[slot] = kVhEmpty;  // the slot is free again for the next scan
+  if (ABS) {
+    // PCL's index of this voxel, from any of its points (the first): as k_vhash_insert computes it
+    const int i0 = (int)(floorf(p0.x * v.inv_leaf) - (float)v.min_b[0]);
+    const int i1 = (int)(floorf(p0.y * v.inv_leaf) - (float)v.min_b[1]);
+    const int i2 = (int)(floorf(p0.z * v.inv_leaf) - (float)v.min_b[2]);
+    pcl_out[pos] = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);
+    tb.key64[slot] = ~0ull;
+  } else {
+    pcl_out[pos] = tb.key[slot];
+    tb.key[slot] = kVhEmpty;  // the slot is free again for the next scan
+  }
   tb.first[slot] = kVhEmpty;
   tb.count[slot] = 0u;
   tb.head[slot] = kVhEmpty;
@@ -2099,7 +2176,9 @@ void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const 
   UndistArg u;
   static_assert(sizeof(UndistArg) == sizeof(UndistArgH), "layout");
   memcpy(&u, &uh, sizeof(u));
-  if (n > 0) hipLaunchKernelGGL(k_undistort_imu, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent, bbox_rows);
+  VhashTable none;
+  memset(&none, 0, sizeof(none));
+  if (n > 0) hipLaunchKernelGGL(k_undistort_imu<false>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent, bbox_rows, 0.f, none, nullptr);
 }
 void launch_undistort_cv(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, unsigned int* bbox_rows,
                          hipStream_t s) {
@@ -2121,10 +2200,30 @@ void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const u
     hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, keys, pcl_keys,
                        filtered_dev, samples, sample_width);
 }
+static VhashTable vhash_table(const VoxelHashBuffers& vh, int n) {
+  VhashTable tb;
+  tb.key64 = vh.key64;
+  tb.key = vh.key; tb.first = vh.first; tb.count = vh.count; tb.head = vh.head; tb.members = vh.members;
+  unsigned int slots = 1024;
+  while (slots < 4u * (unsigned)n) slots <<= 1;
+  tb.mask = slots - 1u;
+  return tb;
+}
+// The IMU-mode de-skew with the insert of the hashed voxel filter riding in it; launch_voxel_hash(..., stages = 4) goes on from
+// there (link + emit<ABS>).
+void launch_undistort_imu_vhash(float4* pts, int n, const double* poses, int K, const UndistArgH& uh, const unsigned long long* extent,
+                                unsigned int* bbox_rows, float leaf, const VoxelHashBuffers& vh, hipStream_t s) {
+  if (n <= 0) return;
+  UndistArg u;
+  memcpy(&u, &uh, sizeof(u));
+  hipLaunchKernelGGL(k_undistort_imu<true>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent, bbox_rows, leaf,
+                     vhash_table(vh, n), vh.slot_of);
+}
 void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
                        int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, hipStream_t s) {
   if (n <= 0) return;
   VhashTable tb;
+  tb.key64 = vh.key64;
   tb.key = vh.key; tb.first = vh.first; tb.count = vh.count; tb.head = vh.head; tb.members = vh.members;
   unsigned int slots = 1024;
   while (slots < 4u * (unsigned)n) slots <<= 1;
@@ -2134,7 +2233,11 @@ void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, con
     hipLaunchKernelGGL(k_vhash_insert, dim3(nb), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, tb, vh.slot_of, filtered);
     hipLaunchKernelGGL(k_vhash_link, dim3(nb), dim3(256), 0, s, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, vh.crowded);
   }
-  if (stages & 2) hipLaunchKernelGGL(k_vhash_emit, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, out, n_out, pcl_out);
+  if (stages & 2) hipLaunchKernelGGL(k_vhash_emit<false>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, out, n_out, pcl_out, nullptr, 0, leaf, filtered);
+  if (stages & 4) {  // behind launch_undistort_imu_vhash: the table is filled (absolute voxel coordinates)
+    hipLaunchKernelGGL(k_vhash_link, dim3(nb), dim3(256), 0, s, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, vh.crowded);
+    hipLaunchKernelGGL(k_vhash_emit<true>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, out, n_out, pcl_out, bbox_rows, n_rows, leaf, filtered);
+  }
 }
 size_t voxel_hash_slots(int max_n) {
   size_t slots = 1024;

@@ -73,6 +73,7 @@ void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const u
 // the voxel grid by hashing (lii_kernels.hip: k_vhash_*): the table arrays hold voxel_hash_slots(max_n) entries (`members`: 7 per
 // slot), initialised to key = first = head = 0xFFFFFFFF, count = 0 and left in that state by every filter
 struct VoxelHashBuffers {
+  unsigned long long* key64;      // the fused form's keys (absolute voxel coordinates), all ones between scans
   unsigned int *key, *first, *count, *head, *members;
   unsigned int *slot_of, *next;   // per input point
   unsigned char* is_first;        // per input point
@@ -80,6 +81,8 @@ struct VoxelHashBuffers {
   unsigned int* crowded;          // one word: the longest member list behind a slot so far (k_vhash_link)
 };
 size_t voxel_hash_slots(int max_n);
+void launch_undistort_imu_vhash(float4* pts, int n, const double* poses, int K, const UndistArgH& uh, const unsigned long long* extent,
+                                unsigned int* bbox_rows, float leaf, const VoxelHashBuffers& vh, hipStream_t s);
 void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
                        int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, hipStream_t s);
 // calibration
