@@ -266,3 +266,52 @@ def test_scan_register_equals_separate_calls(oracle):
     reg.scan_register(b, s0, cv=True, leaf=0.0, max_iterations=4, imu_en=False)
     assert np.array_equal(a.pod, b.pod)
     reg.close()
+
+
+@pytest.mark.parametrize("leaf", [0.1, 2e-4])
+def test_fused_deskew_filter_edge_cases(oracle, leaf):
+    """Inside lii_scan_register the insert of the hashed voxel filter rides in the de-skew launch (absolute voxel coordinates; the
+    emit applies PCL's index and its overflow guard once the box is known).  The down-sampled cloud must be the one the separate
+    calls produce, bit for bit and in the same order: with non-finite points in the scan (dropped), and with a leaf so small that
+    PCL refuses the grid (> 2^31 voxels: the cloud passes unfiltered, non-finite points included)."""
+    import lidar_imu_init_amd as lii
+    from harness import synth
+    from conftest import make_state
+    hall, map_pts = synth.bench_world(200_000, 0.15)
+    reg = lii.Registrar(max_scan_points=40_000, max_map_points=250_000, filter_size_map=0.15)
+    reg.map_build(map_pts)
+    R = synth.rot_zyx(0.02, 0.01, -0.4)
+    p = np.array([2.0, 1.0, 0.2])
+    scan = synth.make_scan(hall, "vlp16", R, p, noise=0.02, seed=5)
+    scan[:, 3] = np.linspace(0, 100, len(scan), dtype=np.float32)
+    scan[100, 0] = np.nan
+    scan[2000, 2] = np.inf
+    st0 = oracle.state_boxplus(make_state(oracle, R, p), np.r_[0.002, -0.001, 0.003, 0.02, -0.01, 0.01, np.zeros(18)])
+    s0 = lii.State(st0)
+    T = lii.pose6d_array(6)
+    for k in range(6):
+        T[k, 0] = 0.02 * k
+        T[k, 4:7] = [1e-3, -2e-3, 1e-3]
+        T[k, 7:10] = [1e-2, 0, 0]
+        T[k, 10:13] = s0.pos_end
+        T[k, 13:22] = s0.rot_end.reshape(-1)
+    clouds = []
+    for one_call in (False, True, False, True):  # (the first filter of a leaf size is probed; from the second on the one-call form fuses)
+        reg.scan_upload(scan)
+        st = lii.State(st0)
+        if one_call:
+            reg.scan_register(st, lii.State(st0), imu_poses=T, leaf=leaf, max_iterations=1, imu_en=True)
+        else:
+            reg.undistort_imu(T, s0.rot_end, s0.pos_end, s0.offset_R_L_I, s0.offset_T_L_I)
+            reg.downsample(leaf, want_count=False)
+            reg.iekf_update(st, lii.State(st0), max_iterations=1, imu_en=True)
+        clouds.append((reg.scan_download(1).copy(), st.pod.copy()))
+    n_finite = int(np.isfinite(scan[:, :3]).all(axis=1).sum())
+    if leaf < 1e-3:
+        assert len(clouds[0][0]) == len(scan)          # PCL's guard: unfiltered
+    else:
+        assert 0 < len(clouds[0][0]) < n_finite
+    for c, s in clouds[1:]:
+        assert np.array_equal(c, clouds[0][0], equal_nan=True)
+        assert np.array_equal(s, clouds[0][1], equal_nan=True)
+    reg.close()
