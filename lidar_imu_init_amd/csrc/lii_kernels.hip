@@ -1117,16 +1117,19 @@ __device__ __forceinline__ void wave_select5(Knn5 k, float (&od)[5], int (&oi)[5
 // seeded: the search pass has already measured every point of the 3 x 3 x 3 cells around the query (kCovered) - its list
 // (seed_d: the distance of entry `lane` on lanes 0..4, inf where the list ends) stands in for pass 1; a seeded entry that
 // survives comes back as index -(2 + its place in the list).
-__device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, float wy, float wz, float d5, bool seeded, float seed_d,
-                                                  float (&od)[5], int (&oi)[5]) {
+__device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, float wy, float wz, bool has5, float list_d, bool seeded,
+                                                  float seed_d, float (&od)[5], int (&oi)[5]) {
   const int lane = threadIdx.x & 63;
-  const float bound0 = fminf(d5, g.max_d2);
+  // (the block probes below need the query only: they are issued before the search pass's list - list_d: entry `lane`'s distance
+  // on lanes 0..4 - is looked at)
   const float cs = g.cs;
   const float eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
-  const float r0 = sqrtf(bound0) + 2.f * eps;
   const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
   const int X0 = cx >> kCoarseShift, Y0 = cy >> kCoarseShift, Z0 = cz >> kCoarseShift;
   const int my_block = lane < 27 ? find_block(g, X0 + (lane % 3) - 1, Y0 + ((lane / 3) % 3) - 1, Z0 + (lane / 9) - 1) : -1;
+  const float d5 = has5 ? __shfl(list_d, 4) : __builtin_inff();
+  const float bound0 = fminf(d5, g.max_d2);
+  const float r0 = sqrtf(bound0) + 2.f * eps;
   Knn5 k;
   k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = __builtin_inff();
   k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
@@ -1239,18 +1242,17 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
 // flagged query, four at a time (they are rare, ~0.07 % of the queries, but clustered at the map frontier).  Every lane of
 // the workgroup must call it; on return the completed lists are visible to the whole workgroup.
 // One flagged search finished by a whole wavefront: the list goes to rb.nbr / rb.nbr_count.
-__device__ __forceinline__ void complete_one(const GridView& g, const RegistrationBuffers& rb, int qi) {
+// (the owner lane has loaded the query's world point and count together with everything else it needs: the completion starts
+// with the block probes at once - one dependent round trip less than fetching them here)
+__device__ __forceinline__ void complete_one(const GridView& g, const RegistrationBuffers& rb, int qi, int c00, float wx, float wy, float wz) {
   const int lane = threadIdx.x & 63;
-  const float4 w4 = rb.world[qi];
-  const int c00 = rb.nbr_count[qi];
   const int c0 = c00 & 0xFF;
   const bool seeded = (c00 & kCovered) != 0;  // uniform
   // the list of the search pass: its 5th distance bounds the far search, and (kCovered) its entries are exact over the inner cells
   const float4 sv = lane < 5 ? rb.nbr[(size_t)lane * rb.cap + qi] : make_float4(0.f, 0.f, 0.f, __builtin_inff());
-  const float d5 = c0 == kMatch ? __shfl(sv.w, 4) : __builtin_inff();
   float od[5];
   int oi[5];
-  knn_fallback_wave(g, w4.x, w4.y, w4.z, d5, seeded, lane < c0 ? sv.w : __builtin_inff(), od, oi);
+  knn_fallback_wave(g, wx, wy, wz, c0 == kMatch, sv.w, seeded, lane < c0 ? sv.w : __builtin_inff(), od, oi);
   const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
   const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
   // a seeded entry that stayed in the list: its point is in the lane that loaded it
@@ -1266,15 +1268,25 @@ __device__ __forceinline__ void complete_one(const GridView& g, const Registrati
     rb.nbr_count[qi] = (oi[0] != -1) + (oi[1] != -1) + (oi[2] != -1) + (oi[3] != -1) + (oi[4] != -1);
   }
 }
-__device__ __forceinline__ void complete_flagged(const GridView& g, const RegistrationBuffers& rb, int my_point, bool live, int* s_needy,
-                                                 int* s_nneedy) {
-  if (threadIdx.x == 0) *s_nneedy = 0;
+struct NeedyShared {
+  int point[kBlock], count[kBlock];
+  float w[kBlock][3];
+  int n;
+};
+// `count`, `w`: nbr_count and world point of the calling lane's query (loaded by the caller, together).
+__device__ __forceinline__ void complete_flagged(const GridView& g, const RegistrationBuffers& rb, int my_point, bool live, int count, float4 w,
+                                                 NeedyShared& sh) {
+  if (threadIdx.x == 0) sh.n = 0;
   __syncthreads();
-  if (live && (rb.nbr_count[my_point] & kNeedy)) s_needy[atomicAdd(s_nneedy, 1)] = my_point;
+  if (live && (count & kNeedy)) {
+    const int at = atomicAdd(&sh.n, 1);
+    sh.point[at] = my_point; sh.count[at] = count;
+    sh.w[at][0] = w.x; sh.w[at][1] = w.y; sh.w[at][2] = w.z;
+  }
   __syncthreads();
-  const int nn = *s_nneedy;
+  const int nn = sh.n;
   const int wave = threadIdx.x >> 6;
-  for (int e = wave; e < nn; e += kBlock / 64) complete_one(g, rb, s_needy[e]);
+  for (int e = wave; e < nn; e += kBlock / 64) complete_one(g, rb, sh.point[e], sh.count[e], sh.w[e][0], sh.w[e][1], sh.w[e][2]);
   if (nn) __syncthreads();  // the completed lists are visible to their owners (workgroup-scope release/acquire)
 }
 
@@ -1291,12 +1303,14 @@ __device__ __forceinline__ int fit_point_of(int blk, int nb) {
 // The completion alone, over the whole cloud (lii_map_incremental of a sharded job: the blocks of the other ranks were searched
 // by a stand-alone k-NN pass, not by a fit pass).
 __global__ __launch_bounds__(kBlock) void k_knn_complete(GridView g, RegistrationBuffers rb) {
-  __shared__ int s_needy[kBlock];
-  __shared__ int s_nneedy;
+  __shared__ NeedyShared sh;
   int lo, n_live;
   shard_range(rb, lo, n_live);
   const int q = fit_point_of(blockIdx.x, (int)gridDim.x);
-  complete_flagged(g, rb, lo + q, q < n_live, s_needy, &s_nneedy);
+  const bool live = q < n_live;
+  const int count = live ? rb.nbr_count[lo + q] : 0;
+  const float4 w = live ? rb.world[lo + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  complete_flagged(g, rb, lo + q, live, count, w, sh);
 }
 
 __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationBuffers rb, PoseArg ps_val,
@@ -1304,8 +1318,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
                                                         const IekfCtrl* __restrict__ ctrl, int forced, int imu_en,
                                                         double plane_thr, double rinv, int nb_real) {
   __shared__ ReduceShared sh;
-  __shared__ int s_needy[kBlock];
-  __shared__ int s_nneedy;
+  __shared__ NeedyShared sh_needy;
   // (pose and point count are loaded together with the flags, not after the branch on them: see k_knn_pruned)
   const PoseArg ps = forced < 0 ? *pose : ps_val;
   int lo, n_live;
@@ -1322,7 +1335,12 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   const int q = fit_point_of(blk, nb_real);
   const int i = lo + q;
   const bool live = q < n_live;
-  if (FIT) complete_flagged(g, rb, i, live, s_needy, &s_nneedy);  // uniform per workgroup
+  float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (FIT) {  // uniform per workgroup
+    const int count0 = live ? rb.nbr_count[i] : 0;
+    if (live) w4 = rb.world[i];  // written by the search pass with the same arithmetic
+    complete_flagged(g, rb, i, live, count0, w4, sh_needy);
+  }
   RowOut o;
 #pragma unroll
   for (int c = 0; c < 12; c++) o.h[c] = 0;
@@ -1338,7 +1356,6 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
     double pa = 0, pbn = 0, pc = 0, pd = 0;
     bool candidate;
     if (FIT) {
-      float4 w4 = rb.world[i];  // written by the search pass with the same arithmetic
       wx = w4.x; wy = w4.y; wz = w4.z;
       const int found = rb.nbr_count[i];
       float4 nb[5];
