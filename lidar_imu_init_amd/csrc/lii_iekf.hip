@@ -52,12 +52,16 @@ __device__ bool gj12(double (&col)[H]) {
       if (v > best) { best = v; p = r; }
     }
     if (best == 0.0) return false;
-    double colp = col[k], mp = m[k];
+    // the row exchange: the pivot row is the same in every lane - a branch of the whole wavefront, taken only when row k is not
+    // the pivot row already (the usual case for I + P11 G), instead of eleven conditional moves per register and pivot
+    if (__builtin_amdgcn_readfirstlane(p) != k) {
+      double colp = col[k], mp = m[k];
 #pragma unroll
-    for (int r = k + 1; r < H; r++)
-      if (r == p) { colp = col[r]; mp = m[r]; col[r] = col[k]; m[r] = m[k]; }
-    col[k] = colp;
-    m[k] = mp;
+      for (int r = k + 1; r < H; r++)
+        if (r == p) { colp = col[r]; mp = m[r]; col[r] = col[k]; m[r] = m[k]; }
+      col[k] = colp;
+      m[k] = mp;
+    }
     // 1 / pivot: hardware reciprocal seed + two Newton steps (full double precision, a third of the divide's latency)
     double inv = __builtin_amdgcn_rcp(m[k]);
     inv = fma(fma(-m[k], inv, 1.0), inv, inv);
