@@ -167,21 +167,26 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   const int max_it = s_int[0], it = s_int[2], search_now = s_int[3], rematch0 = s_int[5], searches0 = s_int[7];
   // upper-triangle index t -> (i, j), packed i * 16 + j
   static const unsigned char kTri[78] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 51, 52, 53, 54, 55, 56, 57, 58, 59, 68, 69, 70, 71, 72, 73, 74, 75, 85, 86, 87, 88, 89, 90, 91, 102, 103, 104, 105, 106, 107, 119, 120, 121, 122, 123, 136, 137, 138, 139, 153, 154, 155, 170, 171, 187};
-  // ---- phase A: G on the first 78 lanes; vec = state_propagat (-) state on the second wavefront (the two rotation logs on two
-  // lanes - same instruction stream - and the vector blocks on 18 more)
-  if (tid < 78) {
-    const int i = kTri[tid] >> 4, j = kTri[tid] & 15;
-    G[i * LDH + j] = s_ne[tid];
-    G[j * LDH + i] = s_ne[tid];
-  }
-  if (wave == 1) {
-    if (lane < 2) {
-      const int o = lane * 12, so = lane * 6;  // rot_end / offset_R_L_I
-      double R[9];
-      d_m3t_mul(s_st + o, s_prop + o, R);
-      d_so3_log(R, vec + so);
-    } else if (lane >= 8 && lane < 26) {
-      const int q = lane - 8, blk = q / 3, i = q % 3;
+  // ---- phase A: A = I + P11 G on the first 144 lanes, straight from the 78 sums (G[k][j] = sum number tri(k, j)); meanwhile the
+  // last wavefront spreads G out for the later phases and takes the vector blocks of vec = state_propagat (-) state.  (The two
+  // rotation logarithms of vec - 1.2 us of serial fp64 on two lanes - run beside the elimination, on the second wavefront.)
+  if (tid < H * H) {
+    const int i = tid / H, j = tid % H;
+    double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < H; k++) {
+      const int a = k < j ? k : j, b = k < j ? j : k;
+      s += s_cov[i * N + k] * s_ne[a * H - (a * (a - 1)) / 2 + (b - a)];
+    }
+    A[i * LDH + j] = s;
+  } else if (wave == 3) {
+    for (int t = lane; t < 78; t += 64) {
+      const int i = kTri[t] >> 4, j = kTri[t] & 15;
+      G[i * LDH + j] = s_ne[t];
+      G[j * LDH + i] = s_ne[t];
+    }
+    if (lane >= 32 && lane < 50) {
+      const int q = lane - 32, blk = q / 3, i = q % 3;
       const int sto = blk == 0 ? 9 : (blk == 1 ? 21 : (blk == 2 ? 24 : (blk == 3 ? 27 : (blk == 4 ? 30 : 33))));
       const int vo = blk == 0 ? 3 : (blk == 1 ? 9 : (blk == 2 ? 12 : (blk == 3 ? 15 : (blk == 4 ? 18 : 21))));
       vec[vo + i] = s_prop[sto + i] - s_st[sto + i];
@@ -190,15 +195,6 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
   if (tid == 0) s_ok = 1;
   __syncthreads();
   LII_TS(2);
-  // ---- phase A2: A = I + P11 G
-  if (tid < H * H) {
-    const int i = tid / H, j = tid % H;
-    double s = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < H; k++) s += s_cov[i * N + k] * G[k * LDH + j];
-    A[i * LDH + j] = s;
-  }
-  __syncthreads();
   LII_TS(3);
   // ---- phase B: K_1[:, :12]^T = A^-1 P[:12, :]  (A = I + P11 G;  K_1[:, :12] = P[:, :12] (I + G P11)^-1 and G, P symmetric).
   // Gauss-Jordan on [A | P[:12, :]]: lanes 0..11 of the first wavefront hold the columns of A, lanes 12..35 the 24 columns of
@@ -217,11 +213,20 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, const double* ne, I
 #pragma unroll
       for (int r = 0; r < H; r++) K1c[(lane - H) * LDH + r] = col[r];
     }
-  } else if (wave == 1 && lane < H) {
-    double s2 = s_ne[78 + lane];
+  } else if (wave == 1) {
+    if (lane < 2) {
+      const int o = lane * 12, so = lane * 6;  // rot_end / offset_R_L_I
+      double R[9];
+      d_m3t_mul(s_st + o, s_prop + o, R);
+      d_so3_log(R, vec + so);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (one wavefront: its LDS accesses stay in order)
+    if (lane < H) {
+      double s2 = s_ne[78 + lane];
 #pragma unroll
-    for (int k = 0; k < H; k++) s2 -= G[lane * LDH + k] * vec[k];
-    s_u[lane] = s2;
+      for (int k = 0; k < H; k++) s2 -= G[lane * LDH + k] * vec[k];
+      s_u[lane] = s2;
+    }
   }
   __syncthreads();
   if (!s_ok) {  // uniform
