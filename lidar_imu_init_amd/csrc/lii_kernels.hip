@@ -1319,7 +1319,26 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
                                                         double plane_thr, double rinv, int nb_real) {
   __shared__ ReduceShared sh;
   __shared__ NeedyShared sh_needy;
-  // (pose and point count are loaded together with the flags, not after the branch on them: see k_knn_pruned)
+  // What a lane reads of its point whatever the pass turns out to be - body point, cached plane, selection flag, world point,
+  // neighbour count - is requested BEFORE the flags, the pose and the cloud size have arrived (an unsharded cloud: the point's
+  // index does not depend on them; the index is clamped, a lane beyond the cloud discards what it read): one dependent round
+  // trip instead of two at the head of every fit launch.
+  const int q_early = fit_point_of(xcd_remap(blockIdx.x, nb_real), nb_real);
+  const bool early = rb.shard_world <= 1;
+  const int ie = min(max(q_early, 0), rb.cap - 1);
+  float4 e_body = make_float4(0.f, 0.f, 0.f, 0.f), e_world = e_body;
+  double e_pl[4] = {0, 0, 0, 0};
+  int e_count = 0;
+  unsigned char e_sel = 0;
+  if (early) {
+    e_body = rb.body[ie];
+    e_world = rb.world[ie];
+    e_count = rb.nbr_count[ie];
+    e_sel = rb.selected[ie];
+    const double* pl = rb.plane + 4 * (size_t)ie;
+    e_pl[0] = pl[0]; e_pl[1] = pl[1]; e_pl[2] = pl[2]; e_pl[3] = pl[3];
+  }
+  // (pose and point count are loaded together with the flags, not after the branch on them: see k_knn_pk)
   const PoseArg ps = forced < 0 ? *pose : ps_val;
   int lo, n_live;
   shard_range(rb, lo, n_live);
@@ -1337,8 +1356,8 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   const bool live = q < n_live;
   float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (FIT) {  // uniform per workgroup
-    const int count0 = live ? rb.nbr_count[i] : 0;
-    if (live) w4 = rb.world[i];  // written by the search pass with the same arithmetic
+    const int count0 = live ? (early ? e_count : rb.nbr_count[i]) : 0;
+    if (live) w4 = early ? e_world : rb.world[i];  // written by the search pass with the same arithmetic
     complete_flagged(g, rb, i, live, count0, w4, sh_needy);
   }
   RowOut o;
@@ -1347,7 +1366,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   o.z = 0;
   o.sel = false;
   if (live) {
-    float4 pb = rb.body[i];
+    const float4 pb = early ? e_body : rb.body[i];
     double bx = pb.x, by = pb.y, bz = pb.z;
     double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
     double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
@@ -1374,9 +1393,14 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
       wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
       wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
       rb.world[i] = make_float4(wx, wy, wz, 0.f);
-      candidate = rb.selected[i] != 0;
-      const double* pl = rb.plane + 4 * (size_t)i;
-      pa = pl[0]; pbn = pl[1]; pc = pl[2]; pd = pl[3];
+      if (early) {
+        candidate = e_sel != 0;
+        pa = e_pl[0]; pbn = e_pl[1]; pc = e_pl[2]; pd = e_pl[3];
+      } else {
+        candidate = rb.selected[i] != 0;
+        const double* pl = rb.plane + 4 * (size_t)i;
+        pa = pl[0]; pbn = pl[1]; pc = pl[2]; pd = pl[3];
+      }
     }
     if (candidate) residual_row(ps, imu_en, bx, by, bz, ix, iy, iz, wx, wy, wz, pa, pbn, pc, pd, o);
     rb.selected[i] = o.sel ? 1 : 0;
