@@ -1457,13 +1457,23 @@ __global__ __launch_bounds__(256) void k_time_extent(const float4* __restrict__ 
   // it any more: its consumers belonged to the previous scan), which saves a separate initialisation launch per scan
   if (blockIdx.x == 0 && threadIdx.x == 0) { extent_next[0] = ~0ull; extent_next[1] = 0ull; }
   unsigned long long mn = ~0ull, mx = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += n_scan_blocks * blockDim.x) {
-    const float4 p = pts[i];
-    if (copy_to) copy_to[i] = p;
-    unsigned int o = f2ord(p.w);
-    unsigned long long a = ((unsigned long long)o << 32) | (unsigned)i;
-    mn = a < mn ? a : mn;
-    mx = (unsigned long long)o > mx ? (unsigned long long)o : mx;
+  // (two points per lane and trip, both loads in flight together: the launch is sized for two points per lane)
+  const int stride = n_scan_blocks * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 2 * stride) {
+    const int i1 = i + stride;
+    const float4 p0 = pts[i];
+    const float4 p1 = pts[i1 < n ? i1 : i];
+    if (copy_to) {
+      copy_to[i] = p0;
+      if (i1 < n) copy_to[i1] = p1;
+    }
+    const unsigned int o0 = f2ord(p0.w), o1 = f2ord(p1.w);
+    const unsigned long long a0 = ((unsigned long long)o0 << 32) | (unsigned)i;
+    const unsigned long long a1 = i1 < n ? (((unsigned long long)o1 << 32) | (unsigned)i1) : ~0ull;
+    mn = a0 < mn ? a0 : mn;
+    mn = a1 < mn ? a1 : mn;
+    mx = (unsigned long long)o0 > mx ? (unsigned long long)o0 : mx;
+    mx = (i1 < n && (unsigned long long)o1 > mx) ? (unsigned long long)o1 : mx;
   }
   for (int off = 32; off > 0; off >>= 1) {
     unsigned long long a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
