@@ -228,7 +228,7 @@ def main():
     reg.map_build(wl["map"])
     reg.map_commit()
     # Every rank receives the WHOLE scan (and holds the whole map): de-skew + voxel filter run replicated, the library splits
-    # the down-sampled, brick-ordered cloud into contiguous blocks (lii_comm_set_partition, default) - sharded == unsharded
+    # the down-sampled cloud (in the order of the voxels' first points) into contiguous blocks (lii_comm_set_partition, default) - sharded == unsharded
     # up to the re-association of the 91 sums (tests/test_gpu_multirank.py).
     dev_scans = [reg.device_scan(s) for s in wl["scans"]]
     host_scans = [np.ascontiguousarray(s) for s in wl["scans"]]

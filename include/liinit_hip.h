@@ -328,7 +328,7 @@ int lii_li_init_set_device(lii_handle h, int32_t on_device);
  * Partition (lii_comm_set_partition; default 1): every rank hands over the WHOLE scan and holds the whole map; the de-skew and
  *   the voxel filter run replicated (their output is bit-identical on every rank, so a voxel is never split between ranks)
  *   and rank r registers the contiguous block [n r / N, n (r + 1) / N) of the down-sampled cloud, which the filter emits in
- *   brick order - a compact region of the map per rank.  The sharded result equals the single-GPU result up to the
+ *   the order of the voxels' first points - a stretch of the sweep per rank.  The sharded result equals the single-GPU result up to the
  *   re-association of the 91 sums.  lii_map_incremental of a sharded job repeats the last search for the whole cloud (no
  *   exchange) so that every rank applies the identical insert lists.  Partition 0: the caller hands every rank its own points.
  * Transports:

@@ -39,7 +39,7 @@ struct lii_context {
   float4* d_batch = nullptr;    // a host-provided Add_Points batch (M)
   float4* d_dropped = nullptr;  // inserts an in-place update found no room for (kMapCtrDropped of them): re-inserted after a rebuild
   unsigned int drop_cap = 0;
-  bool map_tight = false;       // LII_MAP_TEST_TIGHT=1: no spare room is provisioned (tests: forces the recovery path)
+  bool map_tight = false;       // LII_TEST=map_tight: no spare room is provisioned (tests: forces the recovery path)
   long long map_recoveries = 0;
   float4 *d_ins = nullptr, *d_ins_c = nullptr;         // fold output / compacted inserts or host batches (M each)
   unsigned int *d_u32_a = nullptr, *d_u32_b = nullptr, *d_u32_c = nullptr;  // flags / ranks (max(N, M) each)
@@ -49,7 +49,7 @@ struct lii_context {
   float4* d_map = nullptr;
   float4* d_pts = nullptr;            // pts_cap slots
   unsigned int pts_cap = 0;
-  unsigned int pts_cap_eff = 0;  // = pts_cap (LII_MAP_TEST_TIGHT: a few slots behind the cells, so that updates run out of room)
+  unsigned int pts_cap_eff = 0;  // = pts_cap (LII_TEST=map_tight: a few slots behind the cells, so that updates run out of room)
   unsigned int* d_cell_cap = nullptr; // capacity end of every cell entry (same indexing as d_cells)
   unsigned int* d_tp = nullptr;       // per cell entry: on-work-list bit | pending inserts
   unsigned int *d_cs_a = nullptr, *d_cs_b = nullptr;  // per cell entry scratch (capacities / counts and their scans)
@@ -116,7 +116,7 @@ struct lii_context {
   bool use_graph = false;      // LII_TEST=graph: the passes of an update are captured once per (cloud bound, plan, map view) and replayed
   std::map<std::string, hipGraphExec_t> graphs;
   int plan_passes_prev = 32;   // passes the update before the last one ran (the plan enqueues the larger of the last two)
-  int knn_plan_force = -1;     // LII_KNN_PLAN_FORCE=<mask>: use this plan for every update (tests: forces the parked path)
+  int knn_plan_force = -1;     // LII_TEST=plan_force=<mask>: use this plan for every update (tests: forces the parked path)
   unsigned int plan_next = 0xFFFFFFFFu, plan_cur = 0xFFFFFFFFu;
   long long map_repeats = 0;   // map updates repeated because a list outgrew its predicted size
   long long plan_parked = 0;   // updates that had to be continued by the host

@@ -13,7 +13,7 @@ constexpr int kNormalEq = 91;      // 78 + 12 + 1
 constexpr int kCoarseShift = 3;    // coarse occupancy cell = 8 x 8 x 8 fine cells
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr int kCellBias = 1 << 20;
-// voxel-filter sort: 64-bit composites = (sort key << kVoxIdxBits) | point index.  The brick-order key of a grid PCL accepts
+// voxel-filter sort: 64-bit composites = (sort key << kVoxIdxBits) | point index.  An order key over the voxels of a grid PCL accepts
 // (dx dy dz < 2^31) needs at most 31 + 3 bits (every axis width rounded up to a power of two); 28 bits index 268 M points.
 constexpr int kVoxIdxBits = 28;
 constexpr int kVoxKeyBits = 36;

@@ -1237,7 +1237,7 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
 
 // Plane fit + residual + Jacobian + block reduction, one lane per point.  FIT = right after a search pass (finishes
 // the flagged searches of this workgroup's points, reads the 5 neighbours, caches the plane); !FIT for the
-// non-search iterations.  `forced` as in k_knn_pruned.
+// non-search iterations.  `forced` as in k_knn_pk.
 // Completion of the flagged searches among the kBlock points of one workgroup (`my_point`: the calling lane's): one wavefront per
 // flagged query, four at a time (they are rare, ~0.07 % of the queries, but clustered at the map frontier).  Every lane of
 // the workgroup must call it; on return the completed lists are visible to the whole workgroup.

@@ -35,7 +35,7 @@ constexpr int kMaxBuckets = 2048;
 constexpr int kPerLane = kMaxBuckets / 256;
 constexpr int kGroup = 4;          // consecutive buckets per local / centroid workgroup (1 once the buckets are large)
 constexpr int kLocalCap = 2048;    // composites a group keeps in LDS
-// Sort keys are kVoxKeyBits wide (the brick-order key of k_voxel_keys needs up to 34 bits), the point index takes the low
+// Sort keys are kVoxKeyBits wide (room for an order key of up to 34 bits: a Morton order over the voxels was measured in round 2), the point index takes the low
 // kVoxIdxBits of the 64-bit composite.  kVoxDropKey = non-finite points: sorted last, start no voxel.
 constexpr u64 kDropKey = kVoxDropKey;
 

@@ -78,7 +78,7 @@ def test_scan_register_matches_oracle_at_bench_size(world, oracle, workload, n_s
 
 def test_downsampled_cloud_is_bit_identical_at_bench_size(world, oracle):
     """The de-skewed, voxel-filtered cloud the update starts from - 100 k points through IMU back-propagation and the leaf-0.05
-    grid - equals the oracle's bit for bit, in the reference's (PCL index) order, although the device keeps it in brick order."""
+    grid - equals the oracle's bit for bit, in the reference's (PCL index) order, although the device keeps it in the order of the voxels' first points."""
     import bench
     cache, reg, tree = world
     wl = bench.build_workload("stream100k", 1, map_cache=cache)
