@@ -1452,7 +1452,10 @@ int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], c
   std::memcpy(a.vel, vel, 24);
   std::memcpy(a.endR, end_R, 72);
   unsigned long long* ext = extent_of_scan(h);
-  launch_undistort_cv(h->d_scan, h->n_scan, a, ext, h->d_bbox_rows, h->stream);
+  h->vh_inserted = h->fuse_leaf > 0.f && !h->voxel_sort && h->vh_mode == 1 && (h->vh_pinned || h->fuse_leaf == h->vh_leaf) && !h->no_fuse;
+  if (h->vh_inserted) h->vh_inserted_leaf = h->fuse_leaf;
+  if (h->vh_inserted) launch_undistort_cv_vhash(h->d_scan, h->n_scan, a, ext, h->d_bbox_rows, h->fuse_leaf, h->vh, h->stream);
+  else launch_undistort_cv(h->d_scan, h->n_scan, a, ext, h->d_bbox_rows, h->stream);
   h->bbox_rows = (h->n_scan + 255) / 256;
   HIPCHK(h, hipGetLastError());
   return LII_OK;
@@ -1715,7 +1718,10 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     h->fuse_leaf = 0.f;
     if (rc != LII_OK) h->vh_inserted = false;
   } else if (job->undistort == 2) {
+    h->fuse_leaf = job->leaf > 0 ? job->leaf : 0.f;
     rc = lii_undistort_cv(h, state->bias_g, state->vel_end, state->rot_end);  // CV model: bias_g = omega, vel_end = v
+    h->fuse_leaf = 0.f;
+    if (rc != LII_OK) h->vh_inserted = false;
   } else if (job->undistort != 0) {
     return fail(h, LII_ERR_INVALID, "lii_scan_register: undistort must be 0, 1 or 2");
   }

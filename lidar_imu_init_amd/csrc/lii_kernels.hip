@@ -1681,8 +1681,10 @@ struct CvArg {
   double omega[3], vel[3], endR[9];
 };
 // CV-mode de-skew (src/IMU_Processing.hpp:246-266).  The time-earliest point is skipped (quirk A3).
+template <bool FUSE>
 __global__ __launch_bounds__(256) void k_undistort_cv(float4* __restrict__ pts, int n, CvArg a, const unsigned long long* __restrict__ extent,
-                                                      unsigned int* __restrict__ bbox_rows) {
+                                                      unsigned int* __restrict__ bbox_rows, float leaf, VhashTable tb,
+                                                      unsigned int* __restrict__ slot_of) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = i < n;
   float4 P = in_range ? pts[i] : make_float4(0, 0, 0, 0);
@@ -1701,6 +1703,7 @@ __global__ __launch_bounds__(256) void k_undistort_cv(float4* __restrict__ pts, 
     pts[i] = P;
   }
   deskew_bbox(P, in_range, bbox_rows);
+  if (FUSE && in_range) vhash_insert_abs(P, i, leaf, tb, slot_of);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2236,7 +2239,9 @@ void launch_undistort_cv(float4* pts, int n, const CvArgH& ah, const unsigned lo
   CvArg a;
   static_assert(sizeof(CvArg) == sizeof(CvArgH), "layout");
   memcpy(&a, &ah, sizeof(a));
-  if (n > 0) hipLaunchKernelGGL(k_undistort_cv, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent, bbox_rows);
+  VhashTable none;
+  memset(&none, 0, sizeof(none));
+  if (n > 0) hipLaunchKernelGGL(k_undistort_cv<false>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent, bbox_rows, 0.f, none, nullptr);
 }
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s) {
   int nb = nblk(n, 256 * 4);
@@ -2269,6 +2274,13 @@ void launch_undistort_imu_vhash(float4* pts, int n, const double* poses, int K, 
   memcpy(&u, &uh, sizeof(u));
   hipLaunchKernelGGL(k_undistort_imu<true>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent, bbox_rows, leaf,
                      vhash_table(vh, n), vh.slot_of);
+}
+void launch_undistort_cv_vhash(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, unsigned int* bbox_rows, float leaf,
+                               const VoxelHashBuffers& vh, hipStream_t s) {
+  if (n <= 0) return;
+  CvArg a;
+  memcpy(&a, &ah, sizeof(a));
+  hipLaunchKernelGGL(k_undistort_cv<true>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent, bbox_rows, leaf, vhash_table(vh, n), vh.slot_of);
 }
 void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
                        int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, hipStream_t s) {

@@ -81,6 +81,8 @@ struct VoxelHashBuffers {
   unsigned int* crowded;          // one word: the longest member list behind a slot so far (k_vhash_link)
 };
 size_t voxel_hash_slots(int max_n);
+void launch_undistort_cv_vhash(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, unsigned int* bbox_rows, float leaf,
+                               const VoxelHashBuffers& vh, hipStream_t s);
 void launch_undistort_imu_vhash(float4* pts, int n, const double* poses, int K, const UndistArgH& uh, const unsigned long long* extent,
                                 unsigned int* bbox_rows, float leaf, const VoxelHashBuffers& vh, hipStream_t s);
 void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,

@@ -268,8 +268,9 @@ def test_scan_register_equals_separate_calls(oracle):
     reg.close()
 
 
+@pytest.mark.parametrize("cv", [False, True])
 @pytest.mark.parametrize("leaf", [0.1, 2e-4])
-def test_fused_deskew_filter_edge_cases(oracle, leaf):
+def test_fused_deskew_filter_edge_cases(oracle, leaf, cv):
     """Inside lii_scan_register the insert of the hashed voxel filter rides in the de-skew launch (absolute voxel coordinates; the
     emit applies PCL's index and its overflow guard once the box is known).  The down-sampled cloud must be the one the separate
     calls produce, bit for bit and in the same order: with non-finite points in the scan (dropped), and with a leaf so small that
@@ -288,6 +289,9 @@ def test_fused_deskew_filter_edge_cases(oracle, leaf):
     scan[2000, 2] = np.inf
     st0 = oracle.state_boxplus(make_state(oracle, R, p), np.r_[0.002, -0.001, 0.003, 0.02, -0.01, 0.01, np.zeros(18)])
     s0 = lii.State(st0)
+    if cv:  # LO mode: the constant-velocity de-skew takes omega / v from the state's bias_g / vel_end slots
+        s0.bias_g[:] = [1e-3, 0, 2e-3]
+        s0.vel_end[:] = [0.05, 0, 0]
     T = lii.pose6d_array(6)
     for k in range(6):
         T[k, 0] = 0.02 * k
@@ -298,13 +302,18 @@ def test_fused_deskew_filter_edge_cases(oracle, leaf):
     clouds = []
     for one_call in (False, True, False, True):  # (the first filter of a leaf size is probed; from the second on the one-call form fuses)
         reg.scan_upload(scan)
-        st = lii.State(st0)
-        if one_call:
-            reg.scan_register(st, lii.State(st0), imu_poses=T, leaf=leaf, max_iterations=1, imu_en=True)
+        st = s0.copy()
+        if one_call and cv:
+            reg.scan_register(st, s0, cv=True, leaf=leaf, max_iterations=1, imu_en=False)
+        elif one_call:
+            reg.scan_register(st, s0, imu_poses=T, leaf=leaf, max_iterations=1, imu_en=True)
         else:
-            reg.undistort_imu(T, s0.rot_end, s0.pos_end, s0.offset_R_L_I, s0.offset_T_L_I)
+            if cv:
+                reg.undistort_cv(s0.bias_g, s0.vel_end, s0.rot_end)
+            else:
+                reg.undistort_imu(T, s0.rot_end, s0.pos_end, s0.offset_R_L_I, s0.offset_T_L_I)
             reg.downsample(leaf, want_count=False)
-            reg.iekf_update(st, lii.State(st0), max_iterations=1, imu_en=True)
+            reg.iekf_update(st, s0, max_iterations=1, imu_en=not cv)
         clouds.append((reg.scan_download(1).copy(), st.pod.copy()))
     n_finite = int(np.isfinite(scan[:, :3]).all(axis=1).sum())
     if leaf < 1e-3:
