@@ -545,7 +545,7 @@ def knn_kernel_name():
     v = int(os.environ.get("LII_KNN_VARIANT", "0"))
     if v == 5:
         return "k_knn_exact (exact 5-NN into the block-grid local map, 4 lanes/query, exact (distance, index) lists throughout)"
-    return ("k_knn_pk (exact 5-NN into the block-grid local map, 4 lanes/query, packed 32-bit keys in round 1, winners re-measured "
+    return ("k_knn_pk (exact 5-NN into the block-grid local map, 4 lanes/query, packed 32-bit keys in both rounds, winners re-measured "
             "exactly)")
 
 
