@@ -1808,7 +1808,10 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
   }
   // decision per point on the device (world point, neighbour list of the last search) and both order-preserving compactions
   const bool sharded = h->n_ranks > 1;
-  if (!n_add && !n_no_downsample && !sharded && h->pred_add >= 0) {
+  // (near max_map_points the padded bounds could fail the capacity test a batch of the exact sizes passes: the waiting form then)
+  const bool room_for_bounds = h->pred_add >= 0 && !h->map_dirty &&
+                               (long long)h->n_map + std::min(nb, h->pred_add) + std::min(nb, h->pred_nodown) <= (long long)h->cfg.max_map_points;
+  if (!n_add && !n_no_downsample && !sharded && h->pred_add >= 0 && room_for_bounds) {
     // Nobody asks for the list sizes: the update is enqueued for PREDICTED sizes (note_list_sizes) right
     // behind the compaction, on the map stream - no host round trip, and the next scan's arrival / de-skew / voxel filter overlap
     // it.  The exact sizes stay on the device (d_counts); commit_map reads them behind the update and repeats an update whose
