@@ -23,6 +23,22 @@ constexpr unsigned long long kVoxDropKey = (1ull << kVoxKeyBits) - 1ull;
 // 8x8x8 blocks, entries of the work list of the update in flight, "a capacity was exceeded" flag, events of the last fold
 constexpr int kMapCtrUsed = 0, kMapCtrValid = 1, kMapCtrBlocks = 2, kMapCtrWork = 3, kMapCtrOverflow = 4, kMapCtrEvents = 5, kMapCtrDropped = 6, kMapCtrSlots = 7, kMapCtrWords = 16;
 
+// 3 x 3 row-major helpers (no FMA contraction in the units that use them: the reference's rounding)
+__device__ __forceinline__ void mat3_mul(const double A[9], const double B[9], double C[9]) {
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+__device__ __forceinline__ void mat3_vec(const double A[9], const double v[3], double o[3]) {
+#pragma unroll
+  for (int r = 0; r < 3; r++) o[r] = A[3 * r] * v[0] + A[3 * r + 1] * v[1] + A[3 * r + 2] * v[2];
+}
+__device__ __forceinline__ void mat3t_vec(const double A[9], const double v[3], double o[3]) {
+#pragma unroll
+  for (int r = 0; r < 3; r++) o[r] = A[r] * v[0] + A[3 + r] * v[1] + A[6 + r] * v[2];
+}
+
 // Pose the per-point kernels need: state.rot_end, pos_end, offset_R_L_I, offset_T_L_I (row-major).
 struct PoseArg {
   double R[9];

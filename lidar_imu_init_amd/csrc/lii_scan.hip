@@ -1,0 +1,719 @@
+// Scan pre-processing of libliinit_hip for gfx950: de-skew (IMU back-propagation / constant-velocity model) and the voxel-grid
+// down-sampling, i.e. everything between the arrival of a scan and its registration.  Reference code replaced:
+//   k_time_extent / k_undistort_imu / _cv ... src/IMU_Processing.hpp:390-414 and :246-266
+//   k_voxel_* / k_vhash_*                    pcl::VoxelGrid::filter call site src/laserMapping.cpp:917-919 (hashed filter; the
+//                                            sample-sort form lives in lii_vsort.hip)
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <cstring>
+#include <math.h>
+#include <stdint.h>
+
+#include "lii_device.h"
+#include "lii_launch.h"
+
+namespace lii {
+
+// ------------------------------------------------------------------------------------------------
+// undistortion
+// order-preserving float -> uint map (so that integer atomics give float min / max)
+__device__ __forceinline__ unsigned int f2ord(float f) {
+  unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// extent[0] = (ord(t_min) << 32) | index of the first point with that time ; extent[1] = ord(t_max)
+// grid-stride over a small grid, wave shuffle + LDS reduction, ONE pair of atomics per block
+// copy_to != nullptr: the scan is adopted from a caller-owned device buffer on the way (lii_scan_set_device) - one pass
+// and one launch instead of a copy followed by the reduction.
+__global__ __launch_bounds__(256) void k_time_extent(const float4* __restrict__ pts, int n, unsigned long long* __restrict__ extent,
+                                                     unsigned long long* __restrict__ extent_next, float4* __restrict__ copy_to,
+                                                     const uint4* __restrict__ ctrl_src, uint4* __restrict__ ctrl_dst, int ctrl_vec) {
+  __shared__ unsigned long long smn[4], smx[4];
+  // first kernel of a scan: one extra workgroup pulls the update's control block + IMU pose table out of the caller-side
+  // pinned buffer (ctrl_vec 16-byte words over PCIe, ~3 us beside the others' work instead of an H2D copy submission of
+  // ~10 us before the launch)
+  const int n_scan_blocks = gridDim.x - (ctrl_vec > 0 ? 1 : 0);
+  if ((int)blockIdx.x == n_scan_blocks) {
+    for (int i0 = threadIdx.x; i0 < ctrl_vec; i0 += 256 * 4) {  // four PCIe reads in flight per lane
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = i0 + 256 * u < ctrl_vec ? ctrl_src[i0 + 256 * u] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (i0 + 256 * u < ctrl_vec) ctrl_dst[i0 + 256 * u] = v[u];
+    }
+    return;
+  }
+  // the accumulators ping-pong between two buffers: this launch re-arms the one the NEXT scan will reduce into (nobody reads
+  // it any more: its consumers belonged to the previous scan), which saves a separate initialisation launch per scan
+  if (blockIdx.x == 0 && threadIdx.x == 0) { extent_next[0] = ~0ull; extent_next[1] = 0ull; }
+  unsigned long long mn = ~0ull, mx = 0;
+  // (two points per lane and trip, both loads in flight together: the launch is sized for two points per lane)
+  const int stride = n_scan_blocks * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 2 * stride) {
+    const int i1 = i + stride;
+    const float4 p0 = pts[i];
+    const float4 p1 = pts[i1 < n ? i1 : i];
+    if (copy_to) {
+      copy_to[i] = p0;
+      if (i1 < n) copy_to[i1] = p1;
+    }
+    const unsigned int o0 = f2ord(p0.w), o1 = f2ord(p1.w);
+    const unsigned long long a0 = ((unsigned long long)o0 << 32) | (unsigned)i;
+    const unsigned long long a1 = i1 < n ? (((unsigned long long)o1 << 32) | (unsigned)i1) : ~0ull;
+    mn = a0 < mn ? a0 : mn;
+    mn = a1 < mn ? a1 : mn;
+    mx = (unsigned long long)o0 > mx ? (unsigned long long)o0 : mx;
+    mx = (i1 < n && (unsigned long long)o1 > mx) ? (unsigned long long)o1 : mx;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned long long a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) { mn = smn[w] < mn ? smn[w] : mn; mx = smx[w] > mx ? smx[w] : mx; }
+    atomicMin(&extent[0], mn);
+    atomicMax(&extent[1], mx);
+  }
+}
+__device__ __forceinline__ float ord2f(unsigned int o) {
+  unsigned int u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  return __uint_as_float(u);
+}
+
+// Exp(ang_vel, dt) — include/so3_math.h:37-59 — applied to a vector: R v with Rodrigues, R built explicitly
+__device__ __forceinline__ void exp_so3(const double w[3], double dt, double R[9]) {
+  double n = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  if (n > 0.0000001) {
+    double ax = w[0] / n, ay = w[1] / n, az = w[2] / n;
+    double ang = n * dt;
+    double s = sin(ang), c1 = 1.0 - cos(ang);
+    // K = skew(axis).  The reference writes `(1.0 - cos) * K * K`, which C++ evaluates as ((1 - cos) K) K: the scalar is
+    // rounded into K before the product (so3_math.h:48-53; pinned by tests/test_oracle_math_pinned.py)
+    double K[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
+    double cK[9], KK[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) cK[e] = c1 * K[e];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) KK[3 * r + c] = cK[3 * r] * K[c] + cK[3 * r + 1] * K[3 + c] + cK[3 * r + 2] * K[6 + c];
+#pragma unroll
+    for (int e = 0; e < 9; e++) R[e] = ((e % 4 == 0) ? 1.0 : 0.0) + s * K[e] + KK[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 9; e++) R[e] = (e % 4 == 0) ? 1.0 : 0.0;
+  }
+}
+struct UndistArg {
+  double endR[9], endp[3], RLI[9], TLI[3];
+};
+
+// One back-propagation step of point p with pose-table head `h` (src/IMU_Processing.hpp:398-411)
+__device__ __forceinline__ void backprop_once(const double* __restrict__ head /*22 doubles*/, double t, const UndistArg& u,
+                                              double p[3]) {
+  double dt = t - head[0];
+  const double* acc = head + 1;
+  const double* gyr = head + 4;
+  const double* vel = head + 7;
+  const double* pos = head + 10;
+  const double* rot = head + 13;
+  double E[9], Ri[9];
+  exp_so3(gyr, dt, E);
+  mat3_mul(rot, E, Ri);
+  double Pi[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) Pi[a] = pos[a] + vel[a] * dt + 0.5 * acc[a] * dt * dt;
+  double q[3], w[3], e[3], o[3];
+  mat3_vec(u.RLI, p, q);
+#pragma unroll
+  for (int a = 0; a < 3; a++) q[a] += u.TLI[a];
+  mat3_vec(Ri, q, w);
+#pragma unroll
+  for (int a = 0; a < 3; a++) w[a] = w[a] + Pi[a] - u.endp[a];
+  mat3t_vec(u.endR, w, e);
+#pragma unroll
+  for (int a = 0; a < 3; a++) e[a] -= u.TLI[a];
+  mat3t_vec(u.RLI, e, o);
+  p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
+}
+
+// Bounding box of the points a 256-lane workgroup holds (non-finite points excluded; order-preserving uints): wave shuffle +
+// LDS reduction; afterwards lanes 0..2 hold the min / max of axis threadIdx.x in lo[0] / hi[0].  Every lane must call it.
+__device__ __forceinline__ void block_bbox_reduce(unsigned int (&lo)[3], unsigned int (&hi)[3]) {
+  __shared__ unsigned int s_lo[4][3], s_hi[4][3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    for (int off = 32; off > 0; off >>= 1) {
+      unsigned int x = __shfl_xor(lo[a], off), y = __shfl_xor(hi[a], off);
+      lo[a] = min(lo[a], x);
+      hi[a] = max(hi[a], y);
+    }
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { s_lo[wave][a] = lo[a]; s_hi[wave][a] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    lo[0] = min(min(s_lo[0][a], s_lo[1][a]), min(s_lo[2][a], s_lo[3][a]));
+    hi[0] = max(max(s_hi[0][a], s_hi[1][a]), max(s_hi[2][a], s_hi[3][a]));
+  }
+}
+__device__ __forceinline__ void bbox_point(float x, float y, float z, unsigned int (&lo)[3], unsigned int (&hi)[3]) {
+  if (isfinite(x) && isfinite(y) && isfinite(z)) {
+    const unsigned int ox = f2ord(x), oy = f2ord(y), oz = f2ord(z);
+    lo[0] = min(lo[0], ox); hi[0] = max(hi[0], ox);
+    lo[1] = min(lo[1], oy); hi[1] = max(hi[1], oy);
+    lo[2] = min(lo[2], oz); hi[2] = max(hi[2], oz);
+  }
+}
+// The de-skew kernels leave the bounding box of their output behind for the voxel filter that follows (a pass of its own
+// over the scan costs a launch): one row of 8 uints per workgroup (min xyz, -, max xyz, -), reduced by k_voxel_keys.
+// (Folding the rows with atomics instead costs the kernel ~5 us: 400 workgroups x 6 atomics on one cache line.)
+__device__ __forceinline__ void deskew_bbox(float4 q, bool in_range, unsigned int* __restrict__ rows) {
+  if (!rows) return;  // uniform
+  unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+  if (in_range) bbox_point(q.x, q.y, q.z, lo, hi);
+  block_bbox_reduce(lo, hi);
+  if (threadIdx.x < 3) {
+    rows[blockIdx.x * 8 + threadIdx.x] = lo[0];
+    rows[blockIdx.x * 8 + 4 + threadIdx.x] = hi[0];
+  }
+}
+
+// IMU-mode de-skew.  The reference walks the time-sorted cloud backwards over the pose table; per point this
+// is: head = the LAST pose index h <= K-2 with offset_time[h] < t (strict) — points with no such head stay
+// untouched.  Quirk A3: the time-earliest point (first of the sorted cloud) is re-tested against every earlier
+// head after being compensated, so it is compensated once per qualifying head, in descending order.
+// (the table of the hashed voxel filter: described with its kernels further down)
+constexpr unsigned int kVhEmpty = 0xFFFFFFFFu;
+constexpr int kVhMembers = 7;  // members (beside the first point) a slot holds itself
+struct VhashTable {
+  unsigned long long* key64;  // the fused form (k_undistort_imu<true>): packed absolute voxel coordinates, all ones = free
+  unsigned int* key;     // PCL voxel index (identity path: the point index), kVhEmpty = free
+  unsigned int* first;   // smallest point index of the voxel
+  unsigned int* count;   // members handed in by k_vhash_link
+  unsigned int* head;    // linked list of the members beyond kVhMembers (through `next`), kVhEmpty = none
+  unsigned int* members; // kVhMembers per slot
+  unsigned int mask;     // slots - 1
+};
+__device__ __forceinline__ void vhash_insert_abs(const float4 P, int i, float leaf, const VhashTable& tb, unsigned int* __restrict__ slot_of);
+// FUSE: the de-skewed point goes straight into the table of the hashed voxel filter (vhash_insert_abs below) - the filter's own
+// insert launch is saved (lii_scan_register, IMU mode, hashed filter).
+template <bool FUSE>
+__global__ __launch_bounds__(256) void k_undistort_imu(float4* __restrict__ pts, int n, const double* __restrict__ poses, int K,
+                                                       UndistArg u, const unsigned long long* __restrict__ extent,
+                                                       unsigned int* __restrict__ bbox_rows, float leaf, VhashTable tb,
+                                                       unsigned int* __restrict__ slot_of) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in_range = i < n;
+  float4 P = in_range ? pts[i] : make_float4(0, 0, 0, 0);
+  // the head search walks the table's time column backwards: staged in LDS once per workgroup (tables of up to 256 poses;
+  // longer ones are walked in global memory), a walk of up to K dependent global loads per point otherwise
+  __shared__ double s_time[256];
+  const bool staged = K <= 256;
+  if (staged) {
+    if ((int)threadIdx.x < K) s_time[threadIdx.x] = poses[22 * threadIdx.x];
+    __syncthreads();
+  }
+  if (in_range) {
+    double t = P.w / double(1000);
+    int h = -1;
+    if (staged) {
+      for (int k = K - 2; k >= 0; k--)
+        if (t > s_time[k]) { h = k; break; }
+    } else {
+      for (int k = K - 2; k >= 0; k--)
+        if (t > poses[22 * k]) { h = k; break; }
+    }
+    if (h >= 0) {
+      double p[3] = {P.x, P.y, P.z};
+      backprop_once(poses + 22 * h, t, u, p);
+      const bool is_begin = ((unsigned)(extent[0] & 0xFFFFFFFFull) == (unsigned)i);
+      if (is_begin) {
+        for (int k = h - 1; k >= 0; k--) {
+          if (t > poses[22 * k]) {
+            // the reference reads the already-overwritten float coordinates back
+            p[0] = (double)(float)p[0]; p[1] = (double)(float)p[1]; p[2] = (double)(float)p[2];
+            backprop_once(poses + 22 * k, t, u, p);
+          }
+        }
+      }
+      P = make_float4((float)p[0], (float)p[1], (float)p[2], P.w);
+      pts[i] = P;
+    }
+  }
+  deskew_bbox(P, in_range, bbox_rows);
+  if (FUSE && in_range) vhash_insert_abs(P, i, leaf, tb, slot_of);
+}
+
+struct CvArg {
+  double omega[3], vel[3], endR[9];
+};
+// CV-mode de-skew (src/IMU_Processing.hpp:246-266).  The time-earliest point is skipped (quirk A3).
+template <bool FUSE>
+__global__ __launch_bounds__(256) void k_undistort_cv(float4* __restrict__ pts, int n, CvArg a, const unsigned long long* __restrict__ extent,
+                                                      unsigned int* __restrict__ bbox_rows, float leaf, VhashTable tb,
+                                                      unsigned int* __restrict__ slot_of) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in_range = i < n;
+  float4 P = in_range ? pts[i] : make_float4(0, 0, 0, 0);
+  if (in_range && (unsigned)(extent[0] & 0xFFFFFFFFull) != (unsigned)i) {
+    double end_off = ord2f((unsigned)extent[1]) / double(1000);
+    double dt_j = end_off - P.w / double(1000);
+    double R[9];
+    exp_so3(a.omega, -dt_j, R);
+    double rv[3];
+    mat3t_vec(a.endR, a.vel, rv);
+    double p[3] = {P.x, P.y, P.z}, o[3];
+    mat3_vec(R, p, o);
+#pragma unroll
+    for (int c = 0; c < 3; c++) o[c] = o[c] + (-rv[c]) * dt_j;
+    P = make_float4((float)o[0], (float)o[1], (float)o[2], P.w);
+    pts[i] = P;
+  }
+  deskew_bbox(P, in_range, bbox_rows);
+  if (FUSE && in_range) vhash_insert_abs(P, i, leaf, tb, slot_of);
+}
+
+// ------------------------------------------------------------------------------------------------
+// voxel-grid down-sampling (PCL VoxelGrid restatement)
+// mm[0..2] = ord(min xyz), mm[3..5] = ord(max xyz)
+__global__ __launch_bounds__(256) void k_voxel_minmax(const float4* __restrict__ pts, int n, unsigned int* __restrict__ mm,
+                                                      unsigned int* __restrict__ mm_next) {
+  // grid-stride over a small grid; re-arms the ping-pong partner buffer for the next scan (see k_time_extent)
+  if (blockIdx.x == 0 && threadIdx.x < 6) mm_next[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+  unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p = pts[i];
+    bbox_point(p.x, p.y, p.z, lo, hi);
+  }
+  block_bbox_reduce(lo, hi);
+  if (threadIdx.x < 3) {  // ONE set of atomics per workgroup (<= 256 of them)
+    atomicMin(&mm[threadIdx.x], lo[0]);
+    atomicMax(&mm[3 + threadIdx.x], hi[0]);
+  }
+}
+
+struct VoxelArg {
+  float inv_leaf;
+  int min_b[3];
+  int mul[3];
+  int identity;  // PCL's int32 index-overflow guard tripped: output = input
+};
+// Derives the voxel-grid parameters from the min/max reduction ON THE DEVICE (no host round trip), in every thread of the
+// key kernel (six loads + a few flops — cheaper than a launch of its own):
+// PCL VoxelGrid::applyFilter — bounding box, (dx*dy*dz) > INT32_MAX -> "Leaf size is too small" -> identity copy.
+__device__ __forceinline__ VoxelArg voxel_prepare(const unsigned int* __restrict__ mm, float leaf) {
+  VoxelArg v;
+  v.inv_leaf = 1.0f / leaf;
+  v.identity = 0;
+  for (int a = 0; a < 3; a++) { v.min_b[a] = 0; v.mul[a] = 0; }
+  if (mm[0] != 0xFFFFFFFFu) {  // at least one finite point
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; a++) {
+      unsigned int lo = mm[a], hi = mm[3 + a];
+      unsigned int ul = (lo & 0x80000000u) ? (lo & 0x7FFFFFFFu) : ~lo, uh = (hi & 0x80000000u) ? (hi & 0x7FFFFFFFu) : ~hi;
+      mn[a] = __uint_as_float(ul);
+      mx[a] = __uint_as_float(uh);
+    }
+    long long dx = (long long)((mx[0] - mn[0]) * v.inv_leaf) + 1, dy = (long long)((mx[1] - mn[1]) * v.inv_leaf) + 1,
+              dz = (long long)((mx[2] - mn[2]) * v.inv_leaf) + 1;
+    if (dx * dy * dz > 2147483647LL) {
+      v.identity = 1;
+    } else {
+      int div_b[3];
+      for (int a = 0; a < 3; a++) {
+        v.min_b[a] = (int)floorf(mn[a] * v.inv_leaf);
+        div_b[a] = (int)floorf(mx[a] * v.inv_leaf) - v.min_b[a] + 1;
+      }
+      v.mul[0] = 1; v.mul[1] = div_b[0]; v.mul[2] = div_b[0] * div_b[1];
+    }
+  }
+  return v;
+}
+__global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ pts, int n, const unsigned int* __restrict__ mm,
+                                                    const unsigned int* __restrict__ bbox_rows, int n_rows, float leaf,
+                                                    unsigned long long* __restrict__ keys, unsigned int* __restrict__ pcl_keys,
+                                                    int* __restrict__ filtered,
+                                                    unsigned long long* __restrict__ samples, int sample_width) {
+  __shared__ unsigned int s_mm[8];
+  if (n_rows > 0) {  // the box arrives as one row per de-skew workgroup: every workgroup folds them for itself (a few KB from L2)
+    unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+    for (int r = threadIdx.x; r < n_rows; r += 256) {
+      const uint4 a = *reinterpret_cast<const uint4*>(bbox_rows + r * 8), b = *reinterpret_cast<const uint4*>(bbox_rows + r * 8 + 4);
+      lo[0] = min(lo[0], a.x); lo[1] = min(lo[1], a.y); lo[2] = min(lo[2], a.z);
+      hi[0] = max(hi[0], b.x); hi[1] = max(hi[1], b.y); hi[2] = max(hi[2], b.z);
+    }
+    block_bbox_reduce(lo, hi);
+    if (threadIdx.x < 3) { s_mm[threadIdx.x] = lo[0]; s_mm[3 + threadIdx.x] = hi[0]; }
+    __syncthreads();
+    mm = s_mm;
+  }
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const VoxelArg v = voxel_prepare(mm, leaf);
+  if (i == 0) *filtered = v.identity ? 0 : 1;
+  float4 p = pts[i];
+  unsigned long long key = kVoxDropKey;  // non-finite points sort last and are dropped
+  unsigned int pcl = 0x7FFFFFFFu;
+  if (v.identity) {
+    key = pcl = (unsigned)i;  // every point is its own voxel, in input order
+  } else if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+    int i0 = (int)(floorf(p.x * v.inv_leaf) - (float)v.min_b[0]);
+    int i1 = (int)(floorf(p.y * v.inv_leaf) - (float)v.min_b[1]);
+    int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)v.min_b[2]);
+    pcl = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);
+    key = pcl;
+  }
+  keys[i] = key;
+  pcl_keys[i] = pcl;
+  if (samples) {  // the sort's splitter samples (lii_vsort.hip): one jittered position per stratum of `sample_width` points
+    const unsigned int j = (unsigned int)i / (unsigned int)sample_width, lo = j * (unsigned int)sample_width;
+    unsigned int hsh = j * 2654435761u;
+    hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+    const unsigned int w = min((unsigned int)sample_width, (unsigned int)n - lo);
+    if (lo + hsh % w == (unsigned int)i) samples[j] = (key << kVoxIdxBits) | (unsigned long long)(unsigned int)i;
+  }
+}
+// ------------------------------------------------------------------------------------------------
+// The voxel grid without a sort (the default path; the sample sort of lii_vsort.hip stays for LII_VOXEL_FILTER=sort).
+// PCL's filter sorts the points by voxel index only to bring the points of a voxel together and to emit the voxels in index
+// order; the centroids themselves depend on the ORDER OF THE POINTS INSIDE a voxel (float sums, input order), not on the
+// order of the voxels.  So the points of a voxel are brought together by a hash table instead, and the voxels leave in the
+// order of their first points (the PCL index of every output voxel is kept: lii_scan_download / lii_neighbors_download put
+// the reference's order back on the host).  Three launches instead of six:
+//   k_vhash_insert  bounding box -> grid parameters -> PCL voxel index per point (exactly as k_voxel_keys) -> the voxel's
+//                   slot in an open-addressing table (CAS on the key), the smallest point index of the slot (atomicMin)
+//   k_vhash_link    a point that is not the first of its voxel hands its index to the voxel's slot (a few members in the
+//                   slot itself, a linked list behind them for crowded voxels); firsts are counted per workgroup
+//   k_vhash_emit    output position = number of firsts before the point (workgroup counts + a scan in the workgroup); the
+//                   first point of a voxel sorts the member indices (input order = ascending index), adds the points in
+//                   that order - the float additions of PCL's centroid - writes the centroid and clears its slot.
+// Deterministic: the slot a voxel lands in and the order in which members arrive vary from run to run, neither reaches the
+// output.
+__device__ __forceinline__ unsigned int vh_hash(unsigned int k) {
+  k *= 0x9E3779B1u;
+  k ^= k >> 15;
+  k *= 0x85EBCA77u;
+  k ^= k >> 13;
+  return k;
+}
+// The insert of the fused form.  The grid PCL lays over the cloud starts at the cloud's bounding box, which is only known when
+// every point has been de-skewed - but which points share a voxel is not: floor(x / leaf) decides it (PCL's index is
+// floor(x * inv_leaf) - min_b, the same classes).  So the table is keyed by the absolute voxel coordinates (three 21-bit fields
+// around a bias of 2^20: +- 52 km at a 5 cm leaf), and the PCL index of a voxel - the key the output is ordered by on the host -
+// is computed by k_vhash_emit<true>, which knows the box.  A point outside the 21-bit range is a voxel of its own.
+__device__ __forceinline__ void vhash_insert_abs(const float4 P, int i, float leaf, const VhashTable& tb, unsigned int* __restrict__ slot_of) {
+  unsigned int slot = kVhEmpty;
+  if (isfinite(P.x) && isfinite(P.y) && isfinite(P.z)) {  // (non-finite points are dropped, as PCL drops them)
+    const float inv_leaf = 1.0f / leaf;
+    const float fx = floorf(P.x * inv_leaf), fy = floorf(P.y * inv_leaf), fz = floorf(P.z * inv_leaf);
+    unsigned long long key;
+    if (fabsf(fx) < 1048000.f && fabsf(fy) < 1048000.f && fabsf(fz) < 1048000.f) {
+      key = ((unsigned long long)(unsigned)((int)fz + (1 << 20)) << 42) | ((unsigned long long)(unsigned)((int)fy + (1 << 20)) << 21) |
+            (unsigned long long)(unsigned)((int)fx + (1 << 20));
+    } else {
+      key = (1ull << 63) | (unsigned long long)(unsigned)i;
+    }
+    unsigned long long hk = key;
+    hk ^= hk >> 33; hk *= 0xFF51AFD7ED558CCDull; hk ^= hk >> 33;
+    slot = (unsigned int)hk & tb.mask;
+    for (;;) {  // the table has four times as many slots as there are points: a free slot always turns up
+      const unsigned long long prev = atomicCAS(tb.key64 + slot, ~0ull, key);
+      if (prev == ~0ull || prev == key) break;
+      slot = (slot + 1u) & tb.mask;
+    }
+    atomicMin(tb.first + slot, (unsigned)i);
+  }
+  slot_of[i] = slot;
+}
+__global__ __launch_bounds__(256) void k_vhash_insert(const float4* __restrict__ pts, int n, const unsigned int* __restrict__ mm,
+                                                      const unsigned int* __restrict__ bbox_rows, int n_rows, float leaf,
+                                                      VhashTable tb, unsigned int* __restrict__ slot_of, int* __restrict__ filtered) {
+  __shared__ unsigned int s_mm[8];
+  if (n_rows > 0) {  // the box arrives as one row per de-skew workgroup: every workgroup folds them for itself (a few KB from L2)
+    unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+    for (int r = threadIdx.x; r < n_rows; r += 256) {
+      const uint4 a = *reinterpret_cast<const uint4*>(bbox_rows + r * 8), b = *reinterpret_cast<const uint4*>(bbox_rows + r * 8 + 4);
+      lo[0] = min(lo[0], a.x); lo[1] = min(lo[1], a.y); lo[2] = min(lo[2], a.z);
+      hi[0] = max(hi[0], b.x); hi[1] = max(hi[1], b.y); hi[2] = max(hi[2], b.z);
+    }
+    block_bbox_reduce(lo, hi);
+    if (threadIdx.x < 3) { s_mm[threadIdx.x] = lo[0]; s_mm[3 + threadIdx.x] = hi[0]; }
+    __syncthreads();
+    mm = s_mm;
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const VoxelArg v = voxel_prepare(mm, leaf);
+  if (i == 0) *filtered = v.identity ? 0 : 1;
+  const float4 p = pts[i];
+  unsigned int key = kVhEmpty;  // non-finite points are dropped
+  if (v.identity) {
+    key = (unsigned)i;  // every point is its own voxel
+  } else if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+    const int i0 = (int)(floorf(p.x * v.inv_leaf) - (float)v.min_b[0]);
+    const int i1 = (int)(floorf(p.y * v.inv_leaf) - (float)v.min_b[1]);
+    const int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)v.min_b[2]);
+    key = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);  // < 2^31 (the overflow guard)
+  }
+  unsigned int slot = kVhEmpty;
+  if (key != kVhEmpty) {
+    slot = vh_hash(key) & tb.mask;
+    for (;;) {  // the table has four times as many slots as there are points: a free slot always turns up
+      const unsigned int prev = atomicCAS(tb.key + slot, kVhEmpty, key);
+      if (prev == kVhEmpty || prev == key) break;
+      slot = (slot + 1u) & tb.mask;
+    }
+    atomicMin(tb.first + slot, (unsigned)i);
+  }
+  slot_of[i] = slot;
+}
+// *crowded: the largest number of members a voxel has collected beyond its slot (written when a point goes to a list): the
+// host reads it behind the filter and takes the sort path from then on when voxels hold dozens of points (a large leaf) - the
+// first point of a voxel orders its members by repeated selection, quadratic in their number.
+__global__ __launch_bounds__(256) void k_vhash_link(int n, VhashTable tb, const unsigned int* __restrict__ slot_of,
+                                                    unsigned int* __restrict__ next, unsigned char* __restrict__ is_first,
+                                                    unsigned int* __restrict__ block_firsts, unsigned int* __restrict__ crowded) {
+  __shared__ unsigned int s_cnt[4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool first = false;
+  if (i < n) {
+    const unsigned int slot = slot_of[i];
+    if (slot != kVhEmpty) {
+      first = tb.first[slot] == (unsigned)i;
+      if (!first) {
+        const unsigned int k = atomicAdd(tb.count + slot, 1u);
+        if (k < (unsigned)kVhMembers) tb.members[(size_t)slot * kVhMembers + k] = (unsigned)i;
+        else { next[i] = atomicExch(tb.head + slot, (unsigned)i); atomicMax(crowded, k + 1u - (unsigned)kVhMembers); }
+      }
+    }
+    is_first[i] = first ? 1 : 0;
+  }
+  const unsigned long long b = __ballot(first);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (unsigned)__popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) block_firsts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+// exclusive scan over the 256 lanes of a workgroup of 0 / 1 flags; *total = flags set in the workgroup
+__device__ __forceinline__ unsigned int block_rank_of_flag(bool f, unsigned int* s_w /*[4] LDS*/, unsigned int* total) {
+  const unsigned long long b = __ballot(f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_w[wave] = (unsigned)__popcll(b);
+  __syncthreads();
+  unsigned int before = 0;
+  for (int w = 0; w < wave; w++) before += s_w[w];
+  *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  return before + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+}
+// ABS: the table was filled by the fused form (absolute voxel coordinates): the box arrives here (one row per de-skew
+// workgroup, folded by every workgroup for itself), the PCL index of a voxel is computed from its first point, and PCL's
+// overflow guard (the grid would have more than 2^31 voxels: "leaf size too small", the cloud passes unfiltered) is applied
+// here - every point then leaves as it is, in input order.
+template <bool ABS>
+__global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ pts, int n, VhashTable tb,
+                                                    const unsigned int* __restrict__ slot_of, const unsigned int* __restrict__ next,
+                                                    const unsigned char* __restrict__ is_first,
+                                                    const unsigned int* __restrict__ block_firsts, float4* __restrict__ out,
+                                                    int* __restrict__ n_out, unsigned int* __restrict__ pcl_out,
+                                                    const unsigned int* __restrict__ bbox_rows, int n_rows, float leaf,
+                                                    int* __restrict__ filtered) {
+  __shared__ unsigned int s_w[4], s_sum[4];
+  const int tid = threadIdx.x, i = blockIdx.x * blockDim.x + tid;
+  VoxelArg v;
+  v.identity = 0;
+  if (ABS) {
+    __shared__ unsigned int s_mm[8];
+    unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+    for (int r = tid; r < n_rows; r += 256) {
+      const uint4 a = *reinterpret_cast<const uint4*>(bbox_rows + r * 8), b = *reinterpret_cast<const uint4*>(bbox_rows + r * 8 + 4);
+      lo[0] = min(lo[0], a.x); lo[1] = min(lo[1], a.y); lo[2] = min(lo[2], a.z);
+      hi[0] = max(hi[0], b.x); hi[1] = max(hi[1], b.y); hi[2] = max(hi[2], b.z);
+    }
+    block_bbox_reduce(lo, hi);
+    if (tid < 3) { s_mm[tid] = lo[0]; s_mm[3 + tid] = hi[0]; }
+    __syncthreads();
+    v = voxel_prepare(s_mm, leaf);
+    if (i == 0) *filtered = v.identity ? 0 : 1;
+  }
+  unsigned int before = 0;  // firsts in the workgroups below this one
+  for (int q = tid; q < (int)blockIdx.x; q += 256) before += block_firsts[q];
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
+  if ((tid & 63) == 0) s_sum[tid >> 6] = before;
+  __syncthreads();
+  const unsigned int base = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+  const bool first = i < n && is_first[i] != 0;
+  unsigned int total;
+  const unsigned int pos = base + block_rank_of_flag(first, s_w, &total);
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) *n_out = (ABS && v.identity) ? n : (int)(base + total);  // size of the down-sampled cloud
+  if (ABS && v.identity) {  // (uniform) the cloud passes unfiltered; the voxels' first points still hand their slots back
+    if (i < n) { out[i] = pts[i]; pcl_out[i] = (unsigned)i; }
+    if (first) {
+      const unsigned int sl = slot_of[i];
+      tb.key64[sl] = ~0ull; tb.first[sl] = kVhEmpty; tb.count[sl] = 0u; tb.head[sl] = kVhEmpty;
+    }
+    return;
+  }
+  if (!first) return;
+  const unsigned int slot = slot_of[i];
+  const unsigned int cnt = tb.count[slot];
+  const float4 p0 = pts[i];
+  float sx = __fadd_rn(0.f, p0.x), sy = __fadd_rn(0.f, p0.y), sz = __fadd_rn(0.f, p0.z), st = __fadd_rn(0.f, p0.w);
+  if (cnt > 512u) {
+    // Safety valve for a scan on which voxels turn crowded in the middle of a run (the first scan of a leaf is probed, the
+    // following ones watched: lii_downsample): ordering hundreds of members by repeated selection would take tens of
+    // milliseconds.  They are added in list order - the centroid is then right to rounding, not bit for bit.
+    for (int k = 0; k < kVhMembers; k++) {
+      const float4 p = pts[tb.members[(size_t)slot * kVhMembers + k]];
+      sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+    }
+    for (unsigned int j = tb.head[slot]; j != kVhEmpty; j = next[j]) {
+      const float4 p = pts[j];
+      sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+    }
+  } else if (cnt > 0u) {
+    // the members in input order: every round takes the smallest index above the last one taken - from the slot's own
+    // members (registers) and, for a crowded voxel, from the list behind them (walked again every round: slow and rare)
+    unsigned int m[kVhMembers];
+    const unsigned int own = min(cnt, (unsigned)kVhMembers);
+#pragma unroll
+    for (int k = 0; k < kVhMembers; k++) m[k] = (unsigned)k < own ? tb.members[(size_t)slot * kVhMembers + k] : kVhEmpty;
+    const unsigned int head = cnt > (unsigned)kVhMembers ? tb.head[slot] : kVhEmpty;
+    unsigned int last = (unsigned)i;
+    for (unsigned int r = 0; r < cnt; r++) {
+      unsigned int best = kVhEmpty;
+#pragma unroll
+      for (int k = 0; k < kVhMembers; k++) best = (m[k] > last && m[k] < best) ? m[k] : best;
+      for (unsigned int j = head; j != kVhEmpty; j = next[j]) best = (j > last && j < best) ? j : best;
+      const float4 p = pts[best];
+      sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+      last = best;
+    }
+  }
+  const float c = (float)(cnt + 1u);
+  // a single-point voxel reproduces the point exactly (x / 1.0f == x), which is also what the identity path needs
+  out[pos] = make_float4(sx / c, sy / c, sz / c, st / c);
+  if (ABS) {
+    // PCL's index of this voxel, from any of its points (the first): as k_vhash_insert computes it
+    const int i0 = (int)(floorf(p0.x * v.inv_leaf) - (float)v.min_b[0]);
+    const int i1 = (int)(floorf(p0.y * v.inv_leaf) - (float)v.min_b[1]);
+    const int i2 = (int)(floorf(p0.z * v.inv_leaf) - (float)v.min_b[2]);
+    pcl_out[pos] = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);
+    tb.key64[slot] = ~0ull;
+  } else {
+    pcl_out[pos] = tb.key[slot];
+    tb.key[slot] = kVhEmpty;  // the slot is free again for the next scan
+  }
+  tb.first[slot] = kVhEmpty;
+  tb.count[slot] = 0u;
+  tb.head[slot] = kVhEmpty;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+static inline int nblk(int n, int b) { return (n + b - 1) / b; }
+void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, float4* copy_to,
+                        const void* ctrl_src, void* ctrl_dst, size_t ctrl_bytes, hipStream_t s) {
+  int nb = nblk(n, 256 * 2);  // every workgroup ends with a pair of atomics on one cache line: keep them few
+  if (nb > 256) nb = 256;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_time_extent, dim3(nb + (ctrl_bytes ? 1 : 0)), dim3(256), 0, s, pts, n, extent, extent_next, copy_to,
+                     static_cast<const uint4*>(ctrl_src), static_cast<uint4*>(ctrl_dst), (int)(ctrl_bytes / 16));
+}
+void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& uh,
+                          const unsigned long long* extent, unsigned int* bbox_rows, hipStream_t s) {
+  UndistArg u;
+  static_assert(sizeof(UndistArg) == sizeof(UndistArgH), "layout");
+  memcpy(&u, &uh, sizeof(u));
+  VhashTable none;
+  memset(&none, 0, sizeof(none));
+  if (n > 0) hipLaunchKernelGGL(k_undistort_imu<false>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent, bbox_rows, 0.f, none, nullptr);
+}
+void launch_undistort_cv(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, unsigned int* bbox_rows,
+                         hipStream_t s) {
+  CvArg a;
+  static_assert(sizeof(CvArg) == sizeof(CvArgH), "layout");
+  memcpy(&a, &ah, sizeof(a));
+  VhashTable none;
+  memset(&none, 0, sizeof(none));
+  if (n > 0) hipLaunchKernelGGL(k_undistort_cv<false>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent, bbox_rows, 0.f, none, nullptr);
+}
+void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s) {
+  int nb = nblk(n, 256 * 4);
+  if (nb > 256) nb = 256;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_voxel_minmax, dim3(nb), dim3(256), 0, s, pts, n, mm, mm_next);
+}
+void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows, int n_rows, float leaf,
+                       unsigned long long* keys, unsigned int* pcl_keys, int* filtered_dev,
+                       unsigned long long* samples, int sample_width, hipStream_t s) {
+  if (n > 0)
+    hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, keys, pcl_keys,
+                       filtered_dev, samples, sample_width);
+}
+static VhashTable vhash_table(const VoxelHashBuffers& vh, int n) {
+  VhashTable tb;
+  tb.key64 = vh.key64;
+  tb.key = vh.key; tb.first = vh.first; tb.count = vh.count; tb.head = vh.head; tb.members = vh.members;
+  unsigned int slots = 1024;
+  while (slots < 4u * (unsigned)n) slots <<= 1;
+  tb.mask = slots - 1u;
+  return tb;
+}
+// The IMU-mode de-skew with the insert of the hashed voxel filter riding in it; launch_voxel_hash(..., stages = 4) goes on from
+// there (link + emit<ABS>).
+void launch_undistort_imu_vhash(float4* pts, int n, const double* poses, int K, const UndistArgH& uh, const unsigned long long* extent,
+                                unsigned int* bbox_rows, float leaf, const VoxelHashBuffers& vh, hipStream_t s) {
+  if (n <= 0) return;
+  UndistArg u;
+  memcpy(&u, &uh, sizeof(u));
+  hipLaunchKernelGGL(k_undistort_imu<true>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent, bbox_rows, leaf,
+                     vhash_table(vh, n), vh.slot_of);
+}
+void launch_undistort_cv_vhash(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, unsigned int* bbox_rows, float leaf,
+                               const VoxelHashBuffers& vh, hipStream_t s) {
+  if (n <= 0) return;
+  CvArg a;
+  memcpy(&a, &ah, sizeof(a));
+  hipLaunchKernelGGL(k_undistort_cv<true>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent, bbox_rows, leaf, vhash_table(vh, n), vh.slot_of);
+}
+void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
+                       int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, hipStream_t s) {
+  if (n <= 0) return;
+  VhashTable tb;
+  tb.key64 = vh.key64;
+  tb.key = vh.key; tb.first = vh.first; tb.count = vh.count; tb.head = vh.head; tb.members = vh.members;
+  unsigned int slots = 1024;
+  while (slots < 4u * (unsigned)n) slots <<= 1;
+  tb.mask = slots - 1u;
+  const int nb = nblk(n, 256);
+  if (stages & 1) {
+    hipLaunchKernelGGL(k_vhash_insert, dim3(nb), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, tb, vh.slot_of, filtered);
+    hipLaunchKernelGGL(k_vhash_link, dim3(nb), dim3(256), 0, s, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, vh.crowded);
+  }
+  if (stages & 2) hipLaunchKernelGGL(k_vhash_emit<false>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, out, n_out, pcl_out, nullptr, 0, leaf, filtered);
+  if (stages & 4) {  // behind launch_undistort_imu_vhash: the table is filled (absolute voxel coordinates)
+    hipLaunchKernelGGL(k_vhash_link, dim3(nb), dim3(256), 0, s, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, vh.crowded);
+    hipLaunchKernelGGL(k_vhash_emit<true>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, out, n_out, pcl_out, bbox_rows, n_rows, leaf, filtered);
+  }
+}
+size_t voxel_hash_slots(int max_n) {
+  size_t slots = 1024;
+  while (slots < 4u * (size_t)max_n) slots <<= 1;
+  return slots;
+}
+float ord_to_float(unsigned int o) {
+  unsigned int u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+}  // namespace lii
