@@ -257,7 +257,7 @@ def main():
             rep = reg.iekf_update(st, states0[j], max_iterations=wl["max_it"], imu_en=True)
         else:  # the same three stages through the one-call entry point (one host round trip per scan)
             rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=0.0 if args.no_downsample else wl["fs_surf"],
-                                    max_iterations=wl["max_it"], imu_en=True, scan_dev=hand_over)
+                                    max_iterations=wl["max_it"], imu_en=True, scan_dev=hand_over, scan_sorted=True)
         iters_total[0] += rep["iterations"]
         search_total[0] += rep["searches"]
         if args.map_update:
@@ -381,7 +381,7 @@ def main():
     for j in range(len(dev_scans)):
         st = states0[j].copy()
         rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=0.0 if args.no_downsample else wl["fs_surf"],
-                                max_iterations=wl["max_it"], imu_en=True, scan_dev=dev_scans[j])
+                                max_iterations=wl["max_it"], imu_en=True, scan_dev=dev_scans[j], scan_sorted=True)
         n_ds.append(len(reg.scan_download(1)))
         gpu_results.append((st.pod.copy(), rep))
     # the GPU's neighbour lists of the first scan at its start state (one host-driven search pass, the map as timed): compared
@@ -413,7 +413,7 @@ def main():
                 j = k % len(host_scans)
                 reg.scan_upload(host_scans[j])
                 st = states0[j].copy()
-                reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=leaf, max_iterations=wl["max_it"], imu_en=True)
+                reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=leaf, max_iterations=wl["max_it"], imu_en=True, scan_sorted=True)
                 reg.map_incremental(st)
             reg.synchronize()
             return time.perf_counter() - tp0

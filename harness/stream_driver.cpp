@@ -10,6 +10,11 @@
 
 extern "C" {
 
+// The streams this loop is given are time-sorted, as the reference's preprocess hands every scan over (src/preprocess.cpp:296-302):
+// the jobs say so (lii_scan_job::scan_sorted).  lii_stream_set_sorted(0) withdraws the claim (A/B, unsorted test streams).
+static int32_t g_scan_sorted = 1;
+void lii_stream_set_sorted(int32_t sorted) { g_scan_sorted = sorted ? 1 : 0; }
+
 typedef struct lii_stream_scan {
   const void* scan_dev;      // device-resident float4 (x, y, z, t_ms), caller-owned
   int32_t n_points;
@@ -42,6 +47,7 @@ int lii_stream_run(lii_handle h, const lii_stream_scan* scans, int32_t n_scans, 
     job.opts.imu_en = imu_en;
     job.scan_dev = sc.scan_dev;
     job.n_scan_dev = sc.n_points;
+    job.scan_sorted = g_scan_sorted;
     rc = lii_scan_register(h, &job, &st, sc.state0, &rep);
     if (rc != LII_OK) return rc;
     totals[0] += rep.iterations;
@@ -89,6 +95,7 @@ int lii_stream_run_pipeline(lii_handle h, const lii_stream_scan* scans, const vo
     job.leaf = leaf;
     job.opts.max_iterations = max_iterations;
     job.opts.imu_en = imu_en;
+    job.scan_sorted = g_scan_sorted;
     rc = lii_scan_register(h, &job, &st, sc.state0, &rep);
     if (rc != LII_OK) return rc;
     totals[0] += rep.iterations;

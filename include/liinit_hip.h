@@ -19,10 +19,11 @@
 extern "C" {
 #endif
 
-#define LII_ABI_VERSION 5 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
+#define LII_ABI_VERSION 6 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
                              3: lii_params_*, lii_comm_set_partition (library-side split of the down-sampled cloud)
                              4: lii_scan_upload_next / lii_scan_advance (the next scan travels while the current one registers)
-                             5: LII_COMM_MAILBOX = the peer-mapped HBM mailbox (HIP IPC), LII_COMM_MAILBOX_HOST, lii_comm_rccl_ranks */
+                             5: LII_COMM_MAILBOX = the peer-mapped HBM mailbox (HIP IPC), LII_COMM_MAILBOX_HOST, lii_comm_rccl_ranks
+                             6: lii_scan_job::scan_sorted (struct_size 56; a job of size 48 - ABI 5 - is still accepted) */
 
 enum lii_status {
   LII_OK = 0,
@@ -248,6 +249,13 @@ typedef struct lii_scan_job {
   const void* scan_dev;            /* optional: adopt this device-resident scan first (as lii_scan_set_device would: float4
                                       x, y, z, t_ms; caller-owned, only read) - saves the separate call and a launch */
   int32_t n_scan_dev;
+  int32_t scan_sorted;             /* 1: the scan's points are in ascending time order - the order the reference's preprocess hands
+                                      every scan over in (src/preprocess.cpp:296-302) and lii_ingest_* / lii_frame_select deliver.
+                                      The time-earliest point is then the first and the sweep ends with the last: the library
+                                      skips the reduction that finds them (one launch per scan) and de-skews scan_dev in place of
+                                      copying it first.  0: nothing is assumed.  A job that claims an order the scan does not have
+                                      gets the A3 quirk / the CV sweep end applied to the wrong point - nothing else depends on it. */
+  int32_t reserved0;
 } lii_scan_job;
 int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, const lii_state* state_propagated,
                       lii_iekf_report* report);

@@ -112,6 +112,7 @@ struct lii_context {
   int extent_sel = 0, mm_sel = 0;
   bool knn_plan = true;        // LII_KNN_PLAN=0: every k-NN launch is enqueued (IekfCtrl::plan_mask)
   bool test_pred_small = false;
+  bool no_fast_prologue = false;  // LII_TEST=no_fast: a time-sorted scan takes the general path as well (k_time_extent in front of the de-skew)
   bool no_fuse = false;        // LII_TEST=no_fuse: lii_scan_register keeps the de-skew and the voxel filter's insert in separate launches
   bool use_graph = false;      // LII_TEST=graph: the passes of an update are captured once per (cloud bound, plan, map view) and replayed
   std::map<std::string, hipGraphExec_t> graphs;
@@ -132,7 +133,7 @@ struct lii_context {
   unsigned short* d_vbucket = nullptr;
   unsigned int *d_vpcl_in = nullptr, *d_vpcl_out = nullptr;  // PCL voxel index per input point / per output voxel
   VoxelHashBuffers vh = {};      // the voxel grid by hashing (the default; LII_VOXEL_FILTER=sort: the sample sort)
-  unsigned char* d_vh_first = nullptr;
+  unsigned int vh_epoch = 0;     // number of the last hashed filter run (VoxelHashBuffers::counts)
   bool voxel_sort = false;       // LII_VOXEL_FILTER=sort
   bool vh_pinned = false;        // LII_VOXEL_FILTER=hash: no probing
   float fuse_leaf = 0.f;         // lii_scan_register -> lii_undistort_imu: the voxel filter that follows runs at this leaf (0: none)
@@ -141,6 +142,7 @@ struct lii_context {
   int vh_mode = 1;               // 1: sparse voxels (hashed filter), 0: crowded voxels (sample sort)
   float vh_leaf = -1.f;          // the leaf size the choice was probed for
   unsigned int vh_watch = 0;
+  unsigned long long vh_calls = 0, vh_due = 0;  // filter runs so far; the run at which the pending `crowded` read-back is applied
   bool voxel_path_hash = false;  // the path the last filter took
   unsigned int* h_vh_crowded = nullptr;  // pinned: VoxelHashBuffers::crowded of the last hashed filter (read lazily)
   hipEvent_t ev_vh = nullptr;
@@ -956,7 +958,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     // hipStreamSynchronize instead of polling the result word), "graph" (the enqueued passes of an update replayed from a
     // captured hipGraph), "pred_small" (lii_map_incremental predicts list sizes that are always too small), "fold_sort"
     // (lii_map_incremental folds its list through the batch sort, as lii_map_add_points does, instead of the hash table), "no_fuse"
-    // (lii_scan_register keeps the de-skew and the insert of the hashed voxel filter in separate launches)
+    // (lii_scan_register keeps the de-skew and the insert of the hashed voxel filter in separate launches), "no_fast" (a
+    // time-sorted scan takes the general path of lii_scan_register too: k_time_extent in front of the de-skew)
     const std::string t(v);
     h->map_tight = t.find("map_tight") != std::string::npos;
     const size_t q = t.find("plan_force=");
@@ -967,6 +970,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     h->test_pred_small = t.find("pred_small") != std::string::npos;
     h->fold_sorted = t.find("fold_sort") != std::string::npos;
     h->no_fuse = t.find("no_fuse") != std::string::npos;
+    h->no_fast_prologue = t.find("no_fast") != std::string::npos;
   }
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;
@@ -1091,19 +1095,15 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_vpcl_out, N));
   {
     const size_t slots = voxel_hash_slots((int)N);
-    CK(dmalloc(&h->vh.key64, slots)); CK(hipMemset(h->vh.key64, 0xFF, 8 * slots));
-    CK(dmalloc(&h->vh.key, slots)); CK(dmalloc(&h->vh.first, slots)); CK(dmalloc(&h->vh.count, slots)); CK(dmalloc(&h->vh.head, slots));
-    CK(dmalloc(&h->vh.members, slots * 7));
-    CK(dmalloc(&h->vh.slot_of, N)); CK(dmalloc(&h->vh.next, N)); CK(dmalloc(&h->vh.block_firsts, N / 256 + 8));
-    CK(dmalloc(&h->d_vh_first, N));
+    CK(hipMalloc(&h->vh.slots, 64 * slots));
+    launch_voxel_hash_clear(h->vh, slots, h->stream);
+    CK(dmalloc(&h->vh.slot_of, N)); CK(dmalloc(&h->vh.next, N));
+    CK(dmalloc(&h->vh.counts, N / 256 + 8)); CK(hipMemset(h->vh.counts, 0, 8 * (N / 256 + 8)));
     CK(dmalloc(&h->vh.crowded, 4));
     CK(hipMemset(h->vh.crowded, 0, 16));
     CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_vh_crowded), 64, hipHostMallocDefault));
     *h->h_vh_crowded = 0;
     CK(hipEventCreateWithFlags(&h->ev_vh, hipEventDisableTiming));
-    h->vh.is_first = h->d_vh_first;
-    CK(hipMemset(h->vh.key, 0xFF, 4 * slots)); CK(hipMemset(h->vh.first, 0xFF, 4 * slots)); CK(hipMemset(h->vh.head, 0xFF, 4 * slots));
-    CK(hipMemset(h->vh.count, 0, 4 * slots));
   }
   CK(dmalloc(&h->d_cal_params, 64));
   CK(dmalloc(&h->d_cal_out, 128));
@@ -1144,7 +1144,7 @@ int lii_destroy(lii_handle h) {
   void* dev[] = {h->d_dropped, h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_ah_key, h->d_ah_best, h->d_ah_slot, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
-                 h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->vh.key64, h->vh.key, h->vh.first, h->vh.count, h->vh.head, h->vh.members, h->vh.slot_of, h->vh.next, h->vh.block_firsts, h->vh.crowded, h->d_vh_first, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
+                 h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->vh.slots, h->vh.slot_of, h->vh.next, h->vh.counts, h->vh.crowded, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -1435,11 +1435,13 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
   std::memcpy(u.TLI, T_LI, 24);
   unsigned long long* ext = extent_of_scan(h);
   // lii_scan_register told us the hashed voxel filter follows at a leaf that has been probed: its insert rides in the de-skew
-  // (one launch less per scan; lii_downsample goes on with link + emit)
+  // (one launch less per scan; lii_downsample goes on with the emit)
   h->vh_inserted = h->fuse_leaf > 0.f && !h->voxel_sort && h->vh_mode == 1 && (h->vh_pinned || h->fuse_leaf == h->vh_leaf) && !h->no_fuse;
   if (h->vh_inserted) h->vh_inserted_leaf = h->fuse_leaf;
-  if (h->vh_inserted) launch_undistort_imu_vhash(h->d_scan, h->n_scan, h->d_poses, n_poses, u, ext, h->d_bbox_rows, h->fuse_leaf, h->vh, h->stream);
-  else launch_undistort_imu(h->d_scan, h->n_scan, h->d_poses, n_poses, u, ext, h->d_bbox_rows, h->stream);
+  DeskewPlan dp = {};
+  dp.in = dp.out = h->d_scan; dp.n = h->n_scan; dp.sorted = 0; dp.extent = ext; dp.bbox_rows = h->d_bbox_rows;
+  dp.leaf = h->fuse_leaf; dp.vh = h->vh_inserted ? &h->vh : nullptr;
+  launch_deskew_imu(dp, nullptr, h->d_poses, n_poses, u, h->stream);
   h->bbox_rows = (h->n_scan + 255) / 256;
   HIPCHK(h, hipGetLastError());
   return LII_OK;
@@ -1454,8 +1456,10 @@ int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], c
   unsigned long long* ext = extent_of_scan(h);
   h->vh_inserted = h->fuse_leaf > 0.f && !h->voxel_sort && h->vh_mode == 1 && (h->vh_pinned || h->fuse_leaf == h->vh_leaf) && !h->no_fuse;
   if (h->vh_inserted) h->vh_inserted_leaf = h->fuse_leaf;
-  if (h->vh_inserted) launch_undistort_cv_vhash(h->d_scan, h->n_scan, a, ext, h->d_bbox_rows, h->fuse_leaf, h->vh, h->stream);
-  else launch_undistort_cv(h->d_scan, h->n_scan, a, ext, h->d_bbox_rows, h->stream);
+  DeskewPlan dp = {};
+  dp.in = dp.out = h->d_scan; dp.n = h->n_scan; dp.sorted = 0; dp.extent = ext; dp.bbox_rows = h->d_bbox_rows;
+  dp.leaf = h->fuse_leaf; dp.vh = h->vh_inserted ? &h->vh : nullptr;
+  launch_deskew_cv(dp, a, h->stream);
   h->bbox_rows = (h->n_scan + 255) / 256;
   HIPCHK(h, hipGetLastError());
   return LII_OK;
@@ -1497,14 +1501,19 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
   // this function, once per leaf size - and the scan goes on through the hashed emit or through the sample sort.  After that
   // the counter is read behind the filter now and then (the sort reports its largest voxel the same way) and the handle
   // changes over when the voxels fill up or thin out in the middle of a run.  LII_VOXEL_FILTER=sort | hash pins the choice.
-  if (h->vh_flag_pending && hipEventQuery(h->ev_vh) == hipSuccess) {
+  // (the counter is applied a fixed number of filter runs after it was requested - eight scans later the copy has long
+  // arrived, the wait is free - so that the change-over does not depend on timing: the two filters emit the cloud in different
+  // orders, and the ranks of a sharded job, which split it by index, must change over at the same scan)
+  h->vh_calls++;
+  if (h->vh_flag_pending && h->vh_calls >= h->vh_due) {
+    HIPCHK(h, hipEventSynchronize(h->ev_vh));
     h->vh_flag_pending = false;
     if (h->vh_mode == 0 && *h->h_vh_crowded <= 32u) h->vh_mode = 1;         // sparse again -> hash
     else if (h->vh_mode == 1 && *h->h_vh_crowded > 64u) h->vh_mode = 0;     // crowded -> the sort
   }
   int hash_stages = 3;
-  // the de-skew of this scan has already filled the table (lii_scan_register: k_undistort_imu<true>): link + emit follow,
-  // whatever the watch above has decided for the scans to come
+  // the de-skew of this scan has already filled the table (lii_scan_register: k_deskew_*<true>): the emit follows, whatever
+  // the watch above has decided for the scans to come
   const bool inserted = h->vh_inserted;
   h->vh_inserted = false;
   if (inserted && leaf != h->vh_inserted_leaf) return fail(h, LII_ERR_STATE, "lii_downsample: the de-skew prepared the voxel filter for another leaf size");
@@ -1513,29 +1522,26 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
     h->vh_leaf = leaf;
     h->vh_flag_pending = false;
     HIPCHK(h, hipMemsetAsync(h->vh.crowded, 0, sizeof(unsigned int), s));
-    launch_voxel_hash(h->vh, h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_body, h->d_nbody, h->d_nbody + 1, h->d_vpcl_out, 1, s);
+    launch_voxel_hash(h->vh, h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_body, h->d_nbody, h->d_nbody + 1, h->d_vpcl_out, 1, 0u, s);
     HIPCHK(h, hipMemcpyAsync(h->h_vh_crowded, h->vh.crowded, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemsetAsync(h->vh.crowded, 0, sizeof(unsigned int), s));
     HIPCHK(h, hipStreamSynchronize(s));
     h->vh_mode = *h->h_vh_crowded > 32u ? 0 : 1;
     hash_stages = 2;
-    if (h->vh_mode == 0) {  // the emit would have left the table clean for the next scan; the sort does not know of it
-      const size_t slots = voxel_hash_slots(n);  // (the slots this scan could have touched)
-      HIPCHK(h, hipMemsetAsync(h->vh.key, 0xFF, 4 * slots, s));
-      HIPCHK(h, hipMemsetAsync(h->vh.first, 0xFF, 4 * slots, s));
-      HIPCHK(h, hipMemsetAsync(h->vh.head, 0xFF, 4 * slots, s));
-      HIPCHK(h, hipMemsetAsync(h->vh.count, 0, 4 * slots, s));
-    }
+    if (h->vh_mode == 0)  // the emit would have left the table clean for the next scan; the sort does not know of it
+      launch_voxel_hash_clear(h->vh, voxel_hash_slots(n), s);  // (the slots this scan could have touched)
   }
   const bool use_hash = inserted || (h->vh_mode == 1 && !h->voxel_sort);
   h->voxel_path_hash = use_hash;
   if (use_hash) {
-    launch_voxel_hash(h->vh, h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_body, h->d_nbody, h->d_nbody + 1, h->d_vpcl_out, hash_stages, s);
+    if (++h->vh_epoch == 0u) h->vh_epoch = 1u;
+    launch_voxel_hash(h->vh, h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_body, h->d_nbody, h->d_nbody + 1, h->d_vpcl_out, hash_stages, h->vh_epoch, s);
     if (!h->vh_pinned && !h->vh_flag_pending && (++h->vh_watch & 15) == 0) {  // (every 16th scan: the copy costs a packet on the stream)
       HIPCHK(h, hipMemcpyAsync(h->h_vh_crowded, h->vh.crowded, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
       HIPCHK(h, hipMemsetAsync(h->vh.crowded, 0, sizeof(unsigned int), s));
       HIPCHK(h, hipEventRecord(h->ev_vh, s));
       h->vh_flag_pending = true;
+      h->vh_due = h->vh_calls + 8;
     }
   } else {
     const VoxelSortPlan plan = voxel_sort_plan(n);
@@ -1554,6 +1560,7 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
       HIPCHK(h, hipMemsetAsync(h->vh.crowded, 0, sizeof(unsigned int), s));
       HIPCHK(h, hipEventRecord(h->ev_vh, s));
       h->vh_flag_pending = true;
+      h->vh_due = h->vh_calls + 8;
     }
   }
   HIPCHK(h, hipGetLastError());
@@ -1679,14 +1686,60 @@ int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_prop,
 
 int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, const lii_state* state_prop,
                       lii_iekf_report* report) {
-  if (!h || !job || job->struct_size != sizeof(lii_scan_job) || !state || !state_prop || job->opts.max_iterations < 1)
+  // (struct_size 48: a job of ABI 5, without scan_sorted)
+  if (!h || !job || (job->struct_size != sizeof(lii_scan_job) && job->struct_size != 48u) || !state || !state_prop || job->opts.max_iterations < 1)
     return fail(h, LII_ERR_INVALID, "lii_scan_register: bad arguments");
+  const bool sorted = job->struct_size >= sizeof(lii_scan_job) && job->scan_sorted == 1;
   int rc = LII_OK;
   const auto t_entry = std::chrono::steady_clock::now();
   if (h->diag && h->host_us[4] > 0) h->host_us[5] += std::chrono::duration<double, std::micro>(t_entry - h->host_last_return).count();
   const bool adopt = job->scan_dev != nullptr && job->n_scan_dev > 0;
   if (adopt && job->n_scan_dev > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_register: n_scan_dev > max_scan_points");
   const int n_next = adopt ? job->n_scan_dev : h->n_scan;
+  // A scan in ascending time order: ONE launch takes it from wherever it arrived (the caller's device buffer is read in place)
+  // to the de-skewed scan with the voxel filter's table filled, and one extra workgroup of it pulls the update's control block
+  // over PCIe; the IMU pose table (<= 64 poses) travels in the kernel arguments.  Round 3 needed k_time_extent in front (copy +
+  // time extent + pull: 8.9 us per scan).
+  const bool fast = sorted && !h->host_solve && n_next > 0 && !h->no_fast_prologue &&
+                    ((job->undistort == 1 && job->imu_poses && job->n_imu_poses >= 2 && job->n_imu_poses <= 64) || job->undistort == 2);
+  if (job->undistort != 0 && job->undistort != 1 && job->undistort != 2) return fail(h, LII_ERR_INVALID, "lii_scan_register: undistort must be 0, 1 or 2");
+  const auto t_first = std::chrono::steady_clock::now();
+  if (fast) {
+    if (h->staging_busy) HIPCHK(h, hipStreamSynchronize(h->stream));  // (a call that failed half way left the buffer in use)
+    h->staging_busy = true;
+    fill_ctrl(h, state, state_prop, &job->opts);
+    h->ctrl_preloaded = true;
+    extent_discard(h);
+    h->n_scan = n_next;
+    h->n_body = 0;
+    h->n_body_pending = false;
+    h->have_search = false;
+    const float fuse_leaf = job->leaf > 0 ? job->leaf : 0.f;
+    h->vh_inserted = fuse_leaf > 0.f && !h->voxel_sort && h->vh_mode == 1 && (h->vh_pinned || fuse_leaf == h->vh_leaf) && !h->no_fuse;
+    if (h->vh_inserted) h->vh_inserted_leaf = fuse_leaf;
+    DeskewPlan dp = {};
+    dp.in = adopt ? static_cast<const float4*>(job->scan_dev) : h->d_scan;
+    dp.out = h->d_scan; dp.n = n_next; dp.sorted = 1; dp.extent = nullptr; dp.bbox_rows = h->d_bbox_rows;
+    dp.leaf = fuse_leaf; dp.vh = h->vh_inserted ? &h->vh : nullptr;
+    dp.ctrl_src = h->h_ctrl; dp.ctrl_dst = h->d_ctrl; dp.ctrl_bytes = (sizeof(IekfCtrl) + 15) / 16 * 16;
+    if (job->undistort == 1) {
+      UndistArgH u;
+      std::memcpy(u.endR, state->rot_end, 72);
+      std::memcpy(u.endp, state->pos_end, 24);
+      std::memcpy(u.RLI, state->offset_R_L_I, 72);
+      std::memcpy(u.TLI, state->offset_T_L_I, 24);
+      launch_deskew_imu(dp, reinterpret_cast<const double*>(job->imu_poses), nullptr, job->n_imu_poses, u, h->stream);
+    } else {
+      CvArgH a;  // CV model: bias_g = omega, vel_end = v
+      std::memcpy(a.omega, state->bias_g, 24);
+      std::memcpy(a.vel, state->vel_end, 24);
+      std::memcpy(a.endR, state->rot_end, 72);
+      launch_deskew_cv(dp, a, h->stream);
+    }
+    h->bbox_rows = (n_next + 255) / 256;
+    const hipError_t e_launch = hipGetLastError();
+    if (e_launch != hipSuccess) { h->vh_inserted = false; h->ctrl_preloaded = false; rc = fail(h, LII_ERR_HIP, std::string("de-skew launch: ") + hipGetErrorString(e_launch)); }
+  } else {
   if (job->undistort == 1 && !h->host_solve && job->imu_poses && job->n_imu_poses >= 2 && job->n_imu_poses <= 1024 && n_next > 0) {
     // the control block of the update AND the pose table of the de-skew (they sit behind each other) reach the device once.
     // The staging buffer is free again: the previous call returned after its stopping pass, which runs behind the kernel
@@ -1710,7 +1763,6 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     rc = lii_scan_set_device(h, job->scan_dev, job->n_scan_dev);
     if (rc != LII_OK) { h->ctrl_pending = 0; h->poses_preloaded = h->ctrl_preloaded = false; return rc; }
   }
-  const auto t_first = std::chrono::steady_clock::now();
   if (job->undistort == 1) {
     h->fuse_leaf = job->leaf > 0 ? job->leaf : 0.f;  // (the voxel filter follows in this call: its insert may ride in the de-skew)
     rc = lii_undistort_imu(h, job->imu_poses, job->n_imu_poses, state->rot_end, state->pos_end, state->offset_R_L_I,
@@ -1722,8 +1774,7 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     rc = lii_undistort_cv(h, state->bias_g, state->vel_end, state->rot_end);  // CV model: bias_g = omega, vel_end = v
     h->fuse_leaf = 0.f;
     if (rc != LII_OK) h->vh_inserted = false;
-  } else if (job->undistort != 0) {
-    return fail(h, LII_ERR_INVALID, "lii_scan_register: undistort must be 0, 1 or 2");
+  }
   }
   if (h->ctrl_preloaded && h->ctrl_pending) {  // no kernel picked the block up (cannot happen with the conditions above; a guard)
     HIPCHK(h, hipMemcpyAsync(h->d_ctrl, h->h_ctrl, h->ctrl_pending, hipMemcpyHostToDevice, h->stream));

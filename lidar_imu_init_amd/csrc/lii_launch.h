@@ -61,32 +61,40 @@ int register_blocks(int n);
 // undistortion
 void launch_time_extent(const float4* pts, int n, unsigned long long* extent, unsigned long long* extent_next, float4* copy_to,
                         const void* ctrl_src, void* ctrl_dst, size_t ctrl_bytes, hipStream_t s);
-void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& u,
-                          const unsigned long long* extent, unsigned int* bbox_rows, hipStream_t s);
-void launch_undistort_cv(float4* pts, int n, const CvArgH& a, const unsigned long long* extent, unsigned int* bbox_rows,
-                         hipStream_t s);
 // voxel grid
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s);
 void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows, int n_rows, float leaf,
                        unsigned long long* keys, unsigned int* pcl_keys, int* filtered_dev,
                        unsigned long long* samples, int sample_width, hipStream_t s);
-// the voxel grid by hashing (lii_kernels.hip: k_vhash_*): the table arrays hold voxel_hash_slots(max_n) entries (`members`: 7 per
-// slot), initialised to key = first = head = 0xFFFFFFFF, count = 0 and left in that state by every filter
+// the voxel grid by hashing (lii_scan.hip: k_vhash_*): `slots` holds voxel_hash_slots(max_n) 64-byte slots, all free between
+// scans (launch_voxel_hash_clear once; every emit leaves the slots it used free again)
 struct VoxelHashBuffers {
-  unsigned long long* key64;      // the fused form's keys (absolute voxel coordinates), all ones between scans
-  unsigned int *key, *first, *count, *head, *members;
+  void* slots;
   unsigned int *slot_of, *next;   // per input point
-  unsigned char* is_first;        // per input point
-  unsigned int* block_firsts;     // per workgroup of 256 points
-  unsigned int* crowded;          // one word: the longest member list behind a slot so far (k_vhash_link)
+  unsigned long long* counts;     // per workgroup of 256 points: (run number << 32) | voxels owned by the workgroup
+  unsigned int* crowded;          // one word: the longest member list behind a slot so far
 };
 size_t voxel_hash_slots(int max_n);
-void launch_undistort_cv_vhash(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, unsigned int* bbox_rows, float leaf,
-                               const VoxelHashBuffers& vh, hipStream_t s);
-void launch_undistort_imu_vhash(float4* pts, int n, const double* poses, int K, const UndistArgH& uh, const unsigned long long* extent,
-                                unsigned int* bbox_rows, float leaf, const VoxelHashBuffers& vh, hipStream_t s);
+void launch_voxel_hash_clear(const VoxelHashBuffers& vh, size_t slots, hipStream_t s);
 void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
-                       int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, hipStream_t s);
+                       int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, unsigned int epoch,
+                       hipStream_t s);
+// de-skew (k_deskew_imu / k_deskew_cv): where the scan comes from and goes to, what is known about it, what rides along
+struct DeskewPlan {
+  const float4* in;     // the scan as it arrived (a caller's device buffer, or == out)
+  float4* out;          // the de-skewed scan
+  int n;
+  int sorted;           // ascending time order: no time extent needed
+  const unsigned long long* extent;  // !sorted: the result of launch_time_extent
+  unsigned int* bbox_rows;           // one bounding-box row per workgroup of 256 points is left here
+  float leaf;                        // vh != nullptr: the leaf of the hashed voxel filter whose insert rides along
+  const VoxelHashBuffers* vh;
+  const void* ctrl_src;              // ctrl_bytes > 0: one extra workgroup copies this (pinned host memory) to ctrl_dst
+  void* ctrl_dst;
+  size_t ctrl_bytes;
+};
+void launch_deskew_imu(const DeskewPlan& p, const double* poses_host, const double* poses_dev, int K, const UndistArgH& u, hipStream_t s);
+void launch_deskew_cv(const DeskewPlan& p, const CvArgH& a, hipStream_t s);
 // calibration
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
                        hipStream_t s);

@@ -187,33 +187,121 @@ __device__ __forceinline__ void deskew_bbox(float4 q, bool in_range, unsigned in
   }
 }
 
+// The table of the hashed voxel filter (its kernels further down): open addressing, ONE 64-byte line per slot - the insert's
+// CAS, atomicMin, atomicAdd and member store and the emit's reads all touch that one line (round 3 kept five parallel arrays:
+// five lines per voxel).
+constexpr unsigned int kVhEmpty = 0xFFFFFFFFu;
+constexpr int kVhMembers = 10;  // the first arrivals of a voxel (its first point included) sit in the slot itself
+struct __attribute__((aligned(64))) VhSlot {
+  unsigned long long key;  // all ones = free.  Fused form: packed absolute voxel coordinates; separate form: the PCL voxel index
+  unsigned int first;      // smallest point index of the voxel (atomicMin); kVhEmpty while free
+  unsigned int count;      // points of the voxel so far (atomicAdd)
+  unsigned int head;       // arrivals beyond kVhMembers: a list through next[]; kVhEmpty = none
+  unsigned int pad;
+  unsigned int members[kVhMembers];
+};
+static_assert(sizeof(VhSlot) == 64, "one cache line per slot");
+struct VhTable {
+  VhSlot* slots;
+  unsigned int mask;        // slots - 1
+  unsigned int* slot_of;    // per input point: its voxel's slot (kVhEmpty: a non-finite point, dropped as PCL drops it)
+  unsigned int* next;       // per input point: list link of a crowded voxel
+  unsigned int* crowded;    // one word: the longest list behind a slot so far
+};
+// A point joins the voxel that owns `slot`: smallest index, arrival number, member entry.  None of it needs the voxel to be
+// complete - the emit launch, which runs when every point has arrived, picks the first point as the voxel's owner and puts the
+// members in input order (round 3 needed a launch of its own between insert and emit for this: k_vhash_link).
+__device__ __forceinline__ void vh_join(const VhTable& tb, unsigned int slot, int i) {
+  VhSlot* s = tb.slots + slot;
+  atomicMin(&s->first, (unsigned)i);
+  const unsigned int k = atomicAdd(&s->count, 1u);
+  if (k < (unsigned)kVhMembers) s->members[k] = (unsigned)i;
+  else { tb.next[i] = atomicExch(&s->head, (unsigned)i); atomicMax(tb.crowded, k + 1u - (unsigned)kVhMembers); }
+}
+__device__ __forceinline__ unsigned int vh_claim(const VhTable& tb, unsigned long long key) {
+  unsigned long long hk = key;
+  hk ^= hk >> 33; hk *= 0xFF51AFD7ED558CCDull; hk ^= hk >> 33;
+  unsigned int slot = (unsigned int)hk & tb.mask;
+  for (;;) {  // the table has four times as many slots as there are points: a free slot always turns up
+    const unsigned long long prev = atomicCAS(&tb.slots[slot].key, ~0ull, key);
+    if (prev == ~0ull || prev == key) break;
+    slot = (slot + 1u) & tb.mask;
+  }
+  return slot;
+}
+// The insert of the fused form.  The grid PCL lays over the cloud starts at the cloud's bounding box, which is only known when
+// every point has been de-skewed - but which points share a voxel is not: floor(x / leaf) decides it (PCL's index is
+// floor(x * inv_leaf) - min_b, the same classes).  So the table is keyed by the absolute voxel coordinates (three 21-bit fields
+// around a bias of 2^20: +- 52 km at a 5 cm leaf), and the PCL index of a voxel - the key the output is ordered by on the host -
+// is computed by k_vhash_emit<true>, which knows the box.  A point outside the 21-bit range is a voxel of its own.
+__device__ __forceinline__ void vhash_insert_abs(const float4 P, int i, float leaf, const VhTable& tb) {
+  unsigned int slot = kVhEmpty;
+  if (isfinite(P.x) && isfinite(P.y) && isfinite(P.z)) {  // (non-finite points are dropped, as PCL drops them)
+    const float inv_leaf = 1.0f / leaf;
+    const float fx = floorf(P.x * inv_leaf), fy = floorf(P.y * inv_leaf), fz = floorf(P.z * inv_leaf);
+    unsigned long long key;
+    if (fabsf(fx) < 1048000.f && fabsf(fy) < 1048000.f && fabsf(fz) < 1048000.f) {
+      key = ((unsigned long long)(unsigned)((int)fz + (1 << 20)) << 42) | ((unsigned long long)(unsigned)((int)fy + (1 << 20)) << 21) |
+            (unsigned long long)(unsigned)((int)fx + (1 << 20));
+    } else {
+      key = (1ull << 63) | (unsigned long long)(unsigned)i;
+    }
+    slot = vh_claim(tb, key);
+    vh_join(tb, slot, i);
+  }
+  tb.slot_of[i] = slot;
+}
+
+// What the two de-skew kernels share.  `in` is the scan as it arrived - the caller's device buffer (lii_scan_job::scan_dev:
+// the de-skew reads it in place, round 3 copied it first) or the library's own (`out`).  sorted != 0: the points come in ascending
+// time order (lii_scan_job::scan_sorted - the order the reference's preprocess hands every scan over in): the time-earliest point
+// is the first, the sweep ends with the last, and the reduction that used to find them (k_time_extent, a launch of its own)
+// is not needed; otherwise `extent` holds its result.  One EXTRA workgroup (ctrl_vec > 0) pulls the update's control block out
+// of the caller-side pinned buffer over PCIe beside the others' work - nothing in this launch waits for it.
+struct DeskewIo {
+  const float4* in;
+  float4* out;
+  int n;
+  int sorted;
+  const unsigned long long* extent;
+  unsigned int* bbox_rows;
+  float leaf;       // FUSE: the voxel filter that follows
+  VhTable tb;
+  const uint4* ctrl_src;
+  uint4* ctrl_dst;
+  int ctrl_vec;
+};
+__device__ __forceinline__ void pull_ctrl(const DeskewIo& io) {
+  for (int i0 = threadIdx.x; i0 < io.ctrl_vec; i0 += 256 * 4) {  // four PCIe reads in flight per lane
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = i0 + 256 * u < io.ctrl_vec ? io.ctrl_src[i0 + 256 * u] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (i0 + 256 * u < io.ctrl_vec) io.ctrl_dst[i0 + 256 * u] = v[u];
+  }
+}
+// The IMU pose table of a scan (K x 22 doubles) BY VALUE in the kernel arguments: the host writes the argument block straight
+// into device memory when it enqueues the launch, so the table is there when the first wavefront starts - round 3 staged it in
+// pinned memory and had the scan's first kernel pull it over PCIe, which made that kernel a launch the de-skew had to wait for.
+// KP = 0: the table is in device memory (poses_g; tables beyond the largest argument block, stand-alone lii_undistort_imu).
+template <int KP>
+struct PoseTab { double v[KP > 0 ? KP * 22 : 1]; };
+
 // IMU-mode de-skew.  The reference walks the time-sorted cloud backwards over the pose table; per point this
 // is: head = the LAST pose index h <= K-2 with offset_time[h] < t (strict) — points with no such head stay
 // untouched.  Quirk A3: the time-earliest point (first of the sorted cloud) is re-tested against every earlier
 // head after being compensated, so it is compensated once per qualifying head, in descending order.
-// (the table of the hashed voxel filter: described with its kernels further down)
-constexpr unsigned int kVhEmpty = 0xFFFFFFFFu;
-constexpr int kVhMembers = 7;  // members (beside the first point) a slot holds itself
-struct VhashTable {
-  unsigned long long* key64;  // the fused form (k_undistort_imu<true>): packed absolute voxel coordinates, all ones = free
-  unsigned int* key;     // PCL voxel index (identity path: the point index), kVhEmpty = free
-  unsigned int* first;   // smallest point index of the voxel
-  unsigned int* count;   // members handed in by k_vhash_link
-  unsigned int* head;    // linked list of the members beyond kVhMembers (through `next`), kVhEmpty = none
-  unsigned int* members; // kVhMembers per slot
-  unsigned int mask;     // slots - 1
-};
-__device__ __forceinline__ void vhash_insert_abs(const float4 P, int i, float leaf, const VhashTable& tb, unsigned int* __restrict__ slot_of);
-// FUSE: the de-skewed point goes straight into the table of the hashed voxel filter (vhash_insert_abs below) - the filter's own
-// insert launch is saved (lii_scan_register, IMU mode, hashed filter).
-template <bool FUSE>
-__global__ __launch_bounds__(256) void k_undistort_imu(float4* __restrict__ pts, int n, const double* __restrict__ poses, int K,
-                                                       UndistArg u, const unsigned long long* __restrict__ extent,
-                                                       unsigned int* __restrict__ bbox_rows, float leaf, VhashTable tb,
-                                                       unsigned int* __restrict__ slot_of) {
+// FUSE: the de-skewed point goes straight into the table of the hashed voxel filter (vhash_insert_abs) - the filter's own
+// insert launch is saved (lii_scan_register, hashed filter).
+template <bool FUSE, int KP>
+__global__ __launch_bounds__(256) void k_deskew_imu(DeskewIo io, UndistArg u, int K, const double* __restrict__ poses_g, PoseTab<KP> tab) {
+  const int n_scan_blocks = gridDim.x - (io.ctrl_vec > 0 ? 1 : 0);
+  if ((int)blockIdx.x == n_scan_blocks) { pull_ctrl(io); return; }
+  const double* __restrict__ poses = KP > 0 ? tab.v : poses_g;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in_range = i < n;
-  float4 P = in_range ? pts[i] : make_float4(0, 0, 0, 0);
+  const bool in_range = i < io.n;
+  float4 P = in_range ? io.in[i] : make_float4(0, 0, 0, 0);
   // the head search walks the table's time column backwards: staged in LDS once per workgroup (tables of up to 256 poses;
   // longer ones are walked in global memory), a walk of up to K dependent global loads per point otherwise
   __shared__ double s_time[256];
@@ -222,6 +310,7 @@ __global__ __launch_bounds__(256) void k_undistort_imu(float4* __restrict__ pts,
     if ((int)threadIdx.x < K) s_time[threadIdx.x] = poses[22 * threadIdx.x];
     __syncthreads();
   }
+  bool moved = false;
   if (in_range) {
     double t = P.w / double(1000);
     int h = -1;
@@ -235,7 +324,7 @@ __global__ __launch_bounds__(256) void k_undistort_imu(float4* __restrict__ pts,
     if (h >= 0) {
       double p[3] = {P.x, P.y, P.z};
       backprop_once(poses + 22 * h, t, u, p);
-      const bool is_begin = ((unsigned)(extent[0] & 0xFFFFFFFFull) == (unsigned)i);
+      const bool is_begin = io.sorted ? i == 0 : ((unsigned)(io.extent[0] & 0xFFFFFFFFull) == (unsigned)i);
       if (is_begin) {
         for (int k = h - 1; k >= 0; k--) {
           if (t > poses[22 * k]) {
@@ -246,11 +335,12 @@ __global__ __launch_bounds__(256) void k_undistort_imu(float4* __restrict__ pts,
         }
       }
       P = make_float4((float)p[0], (float)p[1], (float)p[2], P.w);
-      pts[i] = P;
+      moved = true;
     }
+    if (moved || io.in != io.out) io.out[i] = P;
   }
-  deskew_bbox(P, in_range, bbox_rows);
-  if (FUSE && in_range) vhash_insert_abs(P, i, leaf, tb, slot_of);
+  deskew_bbox(P, in_range, io.bbox_rows);
+  if (FUSE && in_range) vhash_insert_abs(P, i, io.leaf, io.tb);
 }
 
 struct CvArg {
@@ -258,28 +348,35 @@ struct CvArg {
 };
 // CV-mode de-skew (src/IMU_Processing.hpp:246-266).  The time-earliest point is skipped (quirk A3).
 template <bool FUSE>
-__global__ __launch_bounds__(256) void k_undistort_cv(float4* __restrict__ pts, int n, CvArg a, const unsigned long long* __restrict__ extent,
-                                                      unsigned int* __restrict__ bbox_rows, float leaf, VhashTable tb,
-                                                      unsigned int* __restrict__ slot_of) {
+__global__ __launch_bounds__(256) void k_deskew_cv(DeskewIo io, CvArg a) {
+  const int n_scan_blocks = gridDim.x - (io.ctrl_vec > 0 ? 1 : 0);
+  if ((int)blockIdx.x == n_scan_blocks) { pull_ctrl(io); return; }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in_range = i < n;
-  float4 P = in_range ? pts[i] : make_float4(0, 0, 0, 0);
-  if (in_range && (unsigned)(extent[0] & 0xFFFFFFFFull) != (unsigned)i) {
-    double end_off = ord2f((unsigned)extent[1]) / double(1000);
-    double dt_j = end_off - P.w / double(1000);
-    double R[9];
-    exp_so3(a.omega, -dt_j, R);
-    double rv[3];
-    mat3t_vec(a.endR, a.vel, rv);
-    double p[3] = {P.x, P.y, P.z}, o[3];
-    mat3_vec(R, p, o);
+  const bool in_range = i < io.n;
+  float4 P = in_range ? io.in[i] : make_float4(0, 0, 0, 0);
+  if (in_range) {
+    const bool is_begin = io.sorted ? i == 0 : ((unsigned)(io.extent[0] & 0xFFFFFFFFull) == (unsigned)i);
+    if (!is_begin) {
+      // the sweep's end: the largest time stamp (sorted: the last point's)
+      const float t_end = io.sorted ? io.in[io.n - 1].w : ord2f((unsigned)io.extent[1]);
+      double end_off = t_end / double(1000);
+      double dt_j = end_off - P.w / double(1000);
+      double R[9];
+      exp_so3(a.omega, -dt_j, R);
+      double rv[3];
+      mat3t_vec(a.endR, a.vel, rv);
+      double p[3] = {P.x, P.y, P.z}, o[3];
+      mat3_vec(R, p, o);
 #pragma unroll
-    for (int c = 0; c < 3; c++) o[c] = o[c] + (-rv[c]) * dt_j;
-    P = make_float4((float)o[0], (float)o[1], (float)o[2], P.w);
-    pts[i] = P;
+      for (int c = 0; c < 3; c++) o[c] = o[c] + (-rv[c]) * dt_j;
+      P = make_float4((float)o[0], (float)o[1], (float)o[2], P.w);
+      io.out[i] = P;
+    } else if (io.in != io.out) {
+      io.out[i] = P;
+    }
   }
-  deskew_bbox(P, in_range, bbox_rows);
-  if (FUSE && in_range) vhash_insert_abs(P, i, leaf, tb, slot_of);
+  deskew_bbox(P, in_range, io.bbox_rows);
+  if (FUSE && in_range) vhash_insert_abs(P, i, io.leaf, io.tb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -383,71 +480,52 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ p
   }
 }
 // ------------------------------------------------------------------------------------------------
-// The voxel grid without a sort (the default path; the sample sort of lii_vsort.hip stays for LII_VOXEL_FILTER=sort).
+// The voxel grid without a sort (the default path; the sample sort of lii_vsort.hip stays for crowded voxels and
+// LII_VOXEL_FILTER=sort).
 // PCL's filter sorts the points by voxel index only to bring the points of a voxel together and to emit the voxels in index
 // order; the centroids themselves depend on the ORDER OF THE POINTS INSIDE a voxel (float sums, input order), not on the
 // order of the voxels.  So the points of a voxel are brought together by a hash table instead, and the voxels leave in the
 // order of their first points (the PCL index of every output voxel is kept: lii_scan_download / lii_neighbors_download put
-// the reference's order back on the host).  Three launches instead of six:
-//   k_vhash_insert  bounding box -> grid parameters -> PCL voxel index per point (exactly as k_voxel_keys) -> the voxel's
-//                   slot in an open-addressing table (CAS on the key), the smallest point index of the slot (atomicMin)
-//   k_vhash_link    a point that is not the first of its voxel hands its index to the voxel's slot (a few members in the
-//                   slot itself, a linked list behind them for crowded voxels); firsts are counted per workgroup
-//   k_vhash_emit    output position = number of firsts before the point (workgroup counts + a scan in the workgroup); the
-//                   first point of a voxel sorts the member indices (input order = ascending index), adds the points in
-//                   that order - the float additions of PCL's centroid - writes the centroid and clears its slot.
+// the reference's order back on the host).  Two launches (round 3: three), the first of which rides in the de-skew launch
+// inside lii_scan_register:
+//   insert          the voxel's slot in an open-addressing table (CAS on the key), then vh_join: smallest point index
+//                   (atomicMin), arrival number (atomicAdd), member entry - k_vhash_insert keyed by the PCL voxel index, or
+//                   vhash_insert_abs from the de-skew kernels keyed by absolute voxel coordinates
+//   k_vhash_emit    a point is the voxel's owner when it is its first point; output position = number of owners before it -
+//                   the owners of a workgroup are counted, the count is published, and the counts of the workgroups below
+//                   are collected INSIDE the launch, after the owner has formed its centroid (by then they have long been
+//                   published: the exchange hides behind the dependent loads of the centroid; round 3 counted in a launch of
+//                   its own).  The owner puts the members in input order (ascending index) by repeated selection, adds the
+//                   points in that order - the float additions of PCL's centroid - writes the centroid and frees its slot.
 // Deterministic: the slot a voxel lands in and the order in which members arrive vary from run to run, neither reaches the
 // output.
-__device__ __forceinline__ unsigned int vh_hash(unsigned int k) {
-  k *= 0x9E3779B1u;
-  k ^= k >> 15;
-  k *= 0x85EBCA77u;
-  k ^= k >> 13;
-  return k;
+__global__ __launch_bounds__(256) void k_vh_clear(VhSlot* slots, unsigned int n_slots) {
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  VhSlot s;
+  s.key = ~0ull; s.first = kVhEmpty; s.count = 0u; s.head = kVhEmpty; s.pad = 0u;
+#pragma unroll
+  for (int k = 0; k < kVhMembers; k++) s.members[k] = kVhEmpty;
+  slots[i] = s;
 }
-// The insert of the fused form.  The grid PCL lays over the cloud starts at the cloud's bounding box, which is only known when
-// every point has been de-skewed - but which points share a voxel is not: floor(x / leaf) decides it (PCL's index is
-// floor(x * inv_leaf) - min_b, the same classes).  So the table is keyed by the absolute voxel coordinates (three 21-bit fields
-// around a bias of 2^20: +- 52 km at a 5 cm leaf), and the PCL index of a voxel - the key the output is ordered by on the host -
-// is computed by k_vhash_emit<true>, which knows the box.  A point outside the 21-bit range is a voxel of its own.
-__device__ __forceinline__ void vhash_insert_abs(const float4 P, int i, float leaf, const VhashTable& tb, unsigned int* __restrict__ slot_of) {
-  unsigned int slot = kVhEmpty;
-  if (isfinite(P.x) && isfinite(P.y) && isfinite(P.z)) {  // (non-finite points are dropped, as PCL drops them)
-    const float inv_leaf = 1.0f / leaf;
-    const float fx = floorf(P.x * inv_leaf), fy = floorf(P.y * inv_leaf), fz = floorf(P.z * inv_leaf);
-    unsigned long long key;
-    if (fabsf(fx) < 1048000.f && fabsf(fy) < 1048000.f && fabsf(fz) < 1048000.f) {
-      key = ((unsigned long long)(unsigned)((int)fz + (1 << 20)) << 42) | ((unsigned long long)(unsigned)((int)fy + (1 << 20)) << 21) |
-            (unsigned long long)(unsigned)((int)fx + (1 << 20));
-    } else {
-      key = (1ull << 63) | (unsigned long long)(unsigned)i;
-    }
-    unsigned long long hk = key;
-    hk ^= hk >> 33; hk *= 0xFF51AFD7ED558CCDull; hk ^= hk >> 33;
-    slot = (unsigned int)hk & tb.mask;
-    for (;;) {  // the table has four times as many slots as there are points: a free slot always turns up
-      const unsigned long long prev = atomicCAS(tb.key64 + slot, ~0ull, key);
-      if (prev == ~0ull || prev == key) break;
-      slot = (slot + 1u) & tb.mask;
-    }
-    atomicMin(tb.first + slot, (unsigned)i);
+// Folds the bounding-box rows the de-skew workgroups left behind (every workgroup for itself: a few KB from L2).
+__device__ __forceinline__ void fold_bbox_rows(const unsigned int* __restrict__ bbox_rows, int n_rows, unsigned int* s_mm /*[8] LDS*/) {
+  unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
+  for (int r = threadIdx.x; r < n_rows; r += 256) {
+    const uint4 a = *reinterpret_cast<const uint4*>(bbox_rows + r * 8), b = *reinterpret_cast<const uint4*>(bbox_rows + r * 8 + 4);
+    lo[0] = min(lo[0], a.x); lo[1] = min(lo[1], a.y); lo[2] = min(lo[2], a.z);
+    hi[0] = max(hi[0], b.x); hi[1] = max(hi[1], b.y); hi[2] = max(hi[2], b.z);
   }
-  slot_of[i] = slot;
+  block_bbox_reduce(lo, hi);
+  if (threadIdx.x < 3) { s_mm[threadIdx.x] = lo[0]; s_mm[3 + threadIdx.x] = hi[0]; }
+  __syncthreads();
 }
 __global__ __launch_bounds__(256) void k_vhash_insert(const float4* __restrict__ pts, int n, const unsigned int* __restrict__ mm,
                                                       const unsigned int* __restrict__ bbox_rows, int n_rows, float leaf,
-                                                      VhashTable tb, unsigned int* __restrict__ slot_of, int* __restrict__ filtered) {
+                                                      VhTable tb, int* __restrict__ filtered) {
   __shared__ unsigned int s_mm[8];
-  if (n_rows > 0) {  // the box arrives as one row per de-skew workgroup: every workgroup folds them for itself (a few KB from L2)
-    unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
-    for (int r = threadIdx.x; r < n_rows; r += 256) {
-      const uint4 a = *reinterpret_cast<const uint4*>(bbox_rows + r * 8), b = *reinterpret_cast<const uint4*>(bbox_rows + r * 8 + 4);
-      lo[0] = min(lo[0], a.x); lo[1] = min(lo[1], a.y); lo[2] = min(lo[2], a.z);
-      hi[0] = max(hi[0], b.x); hi[1] = max(hi[1], b.y); hi[2] = max(hi[2], b.z);
-    }
-    block_bbox_reduce(lo, hi);
-    if (threadIdx.x < 3) { s_mm[threadIdx.x] = lo[0]; s_mm[3 + threadIdx.x] = hi[0]; }
-    __syncthreads();
+  if (n_rows > 0) {
+    fold_bbox_rows(bbox_rows, n_rows, s_mm);
     mm = s_mm;
   }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -455,7 +533,7 @@ __global__ __launch_bounds__(256) void k_vhash_insert(const float4* __restrict__
   const VoxelArg v = voxel_prepare(mm, leaf);
   if (i == 0) *filtered = v.identity ? 0 : 1;
   const float4 p = pts[i];
-  unsigned int key = kVhEmpty;  // non-finite points are dropped
+  unsigned long long key = ~0ull;  // non-finite points are dropped
   if (v.identity) {
     key = (unsigned)i;  // every point is its own voxel
   } else if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
@@ -465,42 +543,11 @@ __global__ __launch_bounds__(256) void k_vhash_insert(const float4* __restrict__
     key = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);  // < 2^31 (the overflow guard)
   }
   unsigned int slot = kVhEmpty;
-  if (key != kVhEmpty) {
-    slot = vh_hash(key) & tb.mask;
-    for (;;) {  // the table has four times as many slots as there are points: a free slot always turns up
-      const unsigned int prev = atomicCAS(tb.key + slot, kVhEmpty, key);
-      if (prev == kVhEmpty || prev == key) break;
-      slot = (slot + 1u) & tb.mask;
-    }
-    atomicMin(tb.first + slot, (unsigned)i);
+  if (key != ~0ull) {
+    slot = vh_claim(tb, key);
+    vh_join(tb, slot, i);
   }
-  slot_of[i] = slot;
-}
-// *crowded: the largest number of members a voxel has collected beyond its slot (written when a point goes to a list): the
-// host reads it behind the filter and takes the sort path from then on when voxels hold dozens of points (a large leaf) - the
-// first point of a voxel orders its members by repeated selection, quadratic in their number.
-__global__ __launch_bounds__(256) void k_vhash_link(int n, VhashTable tb, const unsigned int* __restrict__ slot_of,
-                                                    unsigned int* __restrict__ next, unsigned char* __restrict__ is_first,
-                                                    unsigned int* __restrict__ block_firsts, unsigned int* __restrict__ crowded) {
-  __shared__ unsigned int s_cnt[4];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool first = false;
-  if (i < n) {
-    const unsigned int slot = slot_of[i];
-    if (slot != kVhEmpty) {
-      first = tb.first[slot] == (unsigned)i;
-      if (!first) {
-        const unsigned int k = atomicAdd(tb.count + slot, 1u);
-        if (k < (unsigned)kVhMembers) tb.members[(size_t)slot * kVhMembers + k] = (unsigned)i;
-        else { next[i] = atomicExch(tb.head + slot, (unsigned)i); atomicMax(crowded, k + 1u - (unsigned)kVhMembers); }
-      }
-    }
-    is_first[i] = first ? 1 : 0;
-  }
-  const unsigned long long b = __ballot(first);
-  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (unsigned)__popcll(b);
-  __syncthreads();
-  if (threadIdx.x == 0) block_firsts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  tb.slot_of[i] = slot;
 }
 // exclusive scan over the 256 lanes of a workgroup of 0 / 1 flags; *total = flags set in the workgroup
 __device__ __forceinline__ unsigned int block_rank_of_flag(bool f, unsigned int* s_w /*[4] LDS*/, unsigned int* total) {
@@ -513,107 +560,144 @@ __device__ __forceinline__ unsigned int block_rank_of_flag(bool f, unsigned int*
   *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
   return before + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
 }
+// Owners in the workgroups below this one.  Every workgroup publishes its own count as (epoch << 32 | count) - epoch: the number
+// of this filter run, so that a word left by an earlier run is never mistaken - BEFORE it waits for anything, and waits only
+// for workgroups with smaller indices: whichever workgroup is the lowest unfinished one waits for nobody, so the launch
+// always drains (workgroups are dispatched in index order; a workgroup that has not started yet holds up only those above it).
+// A count that does not arrive within seconds means the launch is broken: trap (the stream reports an error) rather than hang.
+__device__ __forceinline__ unsigned int owners_below(const unsigned long long* __restrict__ counts, unsigned int epoch, unsigned int* s_sum /*[4] LDS*/) {
+  unsigned int acc = 0;
+  for (int q = threadIdx.x; q < (int)blockIdx.x; q += 256) {
+    unsigned long long v = __hip_atomic_load(counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int spins = 0;
+    while ((unsigned int)(v >> 32) != epoch) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 24)) __builtin_trap();
+      v = __hip_atomic_load(counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    acc += (unsigned int)v;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  return s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
 // ABS: the table was filled by the fused form (absolute voxel coordinates): the box arrives here (one row per de-skew
 // workgroup, folded by every workgroup for itself), the PCL index of a voxel is computed from its first point, and PCL's
 // overflow guard (the grid would have more than 2^31 voxels: "leaf size too small", the cloud passes unfiltered) is applied
 // here - every point then leaves as it is, in input order.
+// *crowded (written by vh_join when a point goes to a list): the host reads it behind the filter and takes the sort path from
+// then on when voxels hold dozens of points (a large leaf) - the owner orders the members by repeated selection, quadratic in
+// their number.
 template <bool ABS>
-__global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ pts, int n, VhashTable tb,
-                                                    const unsigned int* __restrict__ slot_of, const unsigned int* __restrict__ next,
-                                                    const unsigned char* __restrict__ is_first,
-                                                    const unsigned int* __restrict__ block_firsts, float4* __restrict__ out,
-                                                    int* __restrict__ n_out, unsigned int* __restrict__ pcl_out,
-                                                    const unsigned int* __restrict__ bbox_rows, int n_rows, float leaf,
-                                                    int* __restrict__ filtered) {
+__global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ pts, int n, VhTable tb, unsigned long long* __restrict__ counts,
+                                                    unsigned int epoch, float4* __restrict__ out, int* __restrict__ n_out,
+                                                    unsigned int* __restrict__ pcl_out, const unsigned int* __restrict__ bbox_rows,
+                                                    int n_rows, float leaf, int* __restrict__ filtered) {
   __shared__ unsigned int s_w[4], s_sum[4];
   const int tid = threadIdx.x, i = blockIdx.x * blockDim.x + tid;
+  // everything a lane needs of its own point is requested at once: the point, its slot, and (dependent) the slot's line
+  const bool in_range = i < n;
+  const float4 p0 = in_range ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned int slot = in_range ? tb.slot_of[i] : kVhEmpty;
   VoxelArg v;
   v.identity = 0;
   if (ABS) {
     __shared__ unsigned int s_mm[8];
-    unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
-    for (int r = tid; r < n_rows; r += 256) {
-      const uint4 a = *reinterpret_cast<const uint4*>(bbox_rows + r * 8), b = *reinterpret_cast<const uint4*>(bbox_rows + r * 8 + 4);
-      lo[0] = min(lo[0], a.x); lo[1] = min(lo[1], a.y); lo[2] = min(lo[2], a.z);
-      hi[0] = max(hi[0], b.x); hi[1] = max(hi[1], b.y); hi[2] = max(hi[2], b.z);
-    }
-    block_bbox_reduce(lo, hi);
-    if (tid < 3) { s_mm[tid] = lo[0]; s_mm[3 + tid] = hi[0]; }
-    __syncthreads();
+    fold_bbox_rows(bbox_rows, n_rows, s_mm);
     v = voxel_prepare(s_mm, leaf);
     if (i == 0) *filtered = v.identity ? 0 : 1;
   }
-  unsigned int before = 0;  // firsts in the workgroups below this one
-  for (int q = tid; q < (int)blockIdx.x; q += 256) before += block_firsts[q];
-  for (int off = 32; off > 0; off >>= 1) before += __shfl_down(before, off);
-  if ((tid & 63) == 0) s_sum[tid >> 6] = before;
-  __syncthreads();
-  const unsigned int base = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-  const bool first = i < n && is_first[i] != 0;
+  VhSlot* const sl = tb.slots + (slot != kVhEmpty ? slot : 0u);
+  uint4 hd = make_uint4(0u, 0u, kVhEmpty, 0u), m0 = make_uint4(kVhEmpty, kVhEmpty, kVhEmpty, kVhEmpty), m1 = m0;
+  uint2 m2 = make_uint2(kVhEmpty, kVhEmpty);
+  unsigned long long key = 0;
+  if (slot != kVhEmpty) {  // the slot's line in four requests
+    const uint4* line = reinterpret_cast<const uint4*>(sl);
+    const uint4 a = line[0];
+    key = ((unsigned long long)a.y << 32) | a.x;
+    hd = make_uint4(a.z, a.w, 0u, 0u);  // first, count
+    const uint4 b = line[1];            // head, pad, members 0..1
+    hd.z = b.x;
+    m0 = make_uint4(b.z, b.w, 0u, 0u);
+    const uint4 c = line[2], d = line[3];  // members 2..5, 6..9
+    m0.z = c.x; m0.w = c.y; m1 = make_uint4(c.z, c.w, d.x, d.y); m2 = make_uint2(d.z, d.w);
+  }
+  const bool first = slot != kVhEmpty && hd.x == (unsigned)i;
   unsigned int total;
-  const unsigned int pos = base + block_rank_of_flag(first, s_w, &total);
-  if (blockIdx.x == gridDim.x - 1 && tid == 0) *n_out = (ABS && v.identity) ? n : (int)(base + total);  // size of the down-sampled cloud
-  if (ABS && v.identity) {  // (uniform) the cloud passes unfiltered; the voxels' first points still hand their slots back
-    if (i < n) { out[i] = pts[i]; pcl_out[i] = (unsigned)i; }
+  const unsigned int rank = block_rank_of_flag(first, s_w, &total);
+  if (tid == 0) __hip_atomic_store(counts + blockIdx.x, ((unsigned long long)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (ABS && v.identity) {  // (uniform) the cloud passes unfiltered; the voxels' owners still hand their slots back
+    if (in_range) { out[i] = p0; pcl_out[i] = (unsigned)i; }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *n_out = n;
     if (first) {
-      const unsigned int sl = slot_of[i];
-      tb.key64[sl] = ~0ull; tb.first[sl] = kVhEmpty; tb.count[sl] = 0u; tb.head[sl] = kVhEmpty;
+      uint4* line = reinterpret_cast<uint4*>(sl);
+      line[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, kVhEmpty, 0u);
+      line[1] = make_uint4(kVhEmpty, 0u, kVhEmpty, kVhEmpty);
     }
     return;
   }
-  if (!first) return;
-  const unsigned int slot = slot_of[i];
-  const unsigned int cnt = tb.count[slot];
-  const float4 p0 = pts[i];
-  float sx = __fadd_rn(0.f, p0.x), sy = __fadd_rn(0.f, p0.y), sz = __fadd_rn(0.f, p0.z), st = __fadd_rn(0.f, p0.w);
-  if (cnt > 512u) {
-    // Safety valve for a scan on which voxels turn crowded in the middle of a run (the first scan of a leaf is probed, the
-    // following ones watched: lii_downsample): ordering hundreds of members by repeated selection would take tens of
-    // milliseconds.  They are added in list order - the centroid is then right to rounding, not bit for bit.
-    for (int k = 0; k < kVhMembers; k++) {
-      const float4 p = pts[tb.members[(size_t)slot * kVhMembers + k]];
-      sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
-    }
-    for (unsigned int j = tb.head[slot]; j != kVhEmpty; j = next[j]) {
-      const float4 p = pts[j];
-      sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
-    }
-  } else if (cnt > 0u) {
-    // the members in input order: every round takes the smallest index above the last one taken - from the slot's own
-    // members (registers) and, for a crowded voxel, from the list behind them (walked again every round: slow and rare)
-    unsigned int m[kVhMembers];
-    const unsigned int own = min(cnt, (unsigned)kVhMembers);
+  float4 cen = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (first) {
+    const unsigned int cnt = hd.y;  // points of the voxel, this one included
+    float sx = __fadd_rn(0.f, p0.x), sy = __fadd_rn(0.f, p0.y), sz = __fadd_rn(0.f, p0.z), st = __fadd_rn(0.f, p0.w);
+    unsigned int m[kVhMembers] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y};
 #pragma unroll
-    for (int k = 0; k < kVhMembers; k++) m[k] = (unsigned)k < own ? tb.members[(size_t)slot * kVhMembers + k] : kVhEmpty;
-    const unsigned int head = cnt > (unsigned)kVhMembers ? tb.head[slot] : kVhEmpty;
-    unsigned int last = (unsigned)i;
-    for (unsigned int r = 0; r < cnt; r++) {
-      unsigned int best = kVhEmpty;
+    for (int k = 0; k < kVhMembers; k++)
+      if ((unsigned)k >= cnt) m[k] = kVhEmpty;  // (entries beyond the count are stale: the slot is not wiped member by member)
+    if (cnt > 512u) {
+      // Safety valve for a scan on which voxels turn crowded in the middle of a run (the first scan of a leaf is probed, the
+      // following ones watched: lii_downsample): ordering hundreds of members by repeated selection would take tens of
+      // milliseconds.  They are added in list order - the centroid is then right to rounding, not bit for bit.
 #pragma unroll
-      for (int k = 0; k < kVhMembers; k++) best = (m[k] > last && m[k] < best) ? m[k] : best;
-      for (unsigned int j = head; j != kVhEmpty; j = next[j]) best = (j > last && j < best) ? j : best;
-      const float4 p = pts[best];
-      sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
-      last = best;
+      for (int k = 0; k < kVhMembers; k++) {
+        if (m[k] == (unsigned)i || m[k] == kVhEmpty) continue;
+        const float4 p = pts[m[k]];
+        sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+      }
+      for (unsigned int j = hd.z; j != kVhEmpty; j = tb.next[j]) {
+        if (j == (unsigned)i) continue;
+        const float4 p = pts[j];
+        sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+      }
+    } else if (cnt > 1u) {
+      // the members in input order: every round takes the smallest index above the last one taken (the owner's own index is
+      // the smallest of all, so it never comes up again) - from the slot's own members (registers) and, for a crowded voxel,
+      // from the list behind them (walked again every round: slow and rare)
+      const unsigned int head = cnt > (unsigned)kVhMembers ? hd.z : kVhEmpty;
+      unsigned int last = (unsigned)i;
+      for (unsigned int r = 1; r < cnt; r++) {
+        unsigned int best = kVhEmpty;
+#pragma unroll
+        for (int k = 0; k < kVhMembers; k++) best = (m[k] > last && m[k] < best) ? m[k] : best;
+        for (unsigned int j = head; j != kVhEmpty; j = tb.next[j]) best = (j > last && j < best) ? j : best;
+        const float4 p = pts[best];
+        sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z); st = __fadd_rn(st, p.w);
+        last = best;
+      }
     }
+    const float c = (float)cnt;
+    // a single-point voxel reproduces the point exactly (x / 1.0f == x), which is also what the identity path needs
+    cen = make_float4(sx / c, sy / c, sz / c, st / c);
   }
-  const float c = (float)(cnt + 1u);
-  // a single-point voxel reproduces the point exactly (x / 1.0f == x), which is also what the identity path needs
-  out[pos] = make_float4(sx / c, sy / c, sz / c, st / c);
+  const unsigned int base = owners_below(counts, epoch, s_sum);
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) *n_out = (int)(base + total);  // size of the down-sampled cloud
+  if (!first) return;
+  const unsigned int pos = base + rank;
+  out[pos] = cen;
   if (ABS) {
     // PCL's index of this voxel, from any of its points (the first): as k_vhash_insert computes it
     const int i0 = (int)(floorf(p0.x * v.inv_leaf) - (float)v.min_b[0]);
     const int i1 = (int)(floorf(p0.y * v.inv_leaf) - (float)v.min_b[1]);
     const int i2 = (int)(floorf(p0.z * v.inv_leaf) - (float)v.min_b[2]);
     pcl_out[pos] = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);
-    tb.key64[slot] = ~0ull;
   } else {
-    pcl_out[pos] = tb.key[slot];
-    tb.key[slot] = kVhEmpty;  // the slot is free again for the next scan
+    pcl_out[pos] = (unsigned int)key;
   }
-  tb.first[slot] = kVhEmpty;
-  tb.count[slot] = 0u;
-  tb.head[slot] = kVhEmpty;
+  // the slot is free again for the next scan
+  uint4* line = reinterpret_cast<uint4*>(sl);
+  line[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, kVhEmpty, 0u);
+  line[1] = make_uint4(kVhEmpty, 0u, kVhEmpty, kVhEmpty);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -626,24 +710,6 @@ void launch_time_extent(const float4* pts, int n, unsigned long long* extent, un
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(k_time_extent, dim3(nb + (ctrl_bytes ? 1 : 0)), dim3(256), 0, s, pts, n, extent, extent_next, copy_to,
                      static_cast<const uint4*>(ctrl_src), static_cast<uint4*>(ctrl_dst), (int)(ctrl_bytes / 16));
-}
-void launch_undistort_imu(float4* pts, int n, const double* poses, int K, const UndistArgH& uh,
-                          const unsigned long long* extent, unsigned int* bbox_rows, hipStream_t s) {
-  UndistArg u;
-  static_assert(sizeof(UndistArg) == sizeof(UndistArgH), "layout");
-  memcpy(&u, &uh, sizeof(u));
-  VhashTable none;
-  memset(&none, 0, sizeof(none));
-  if (n > 0) hipLaunchKernelGGL(k_undistort_imu<false>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent, bbox_rows, 0.f, none, nullptr);
-}
-void launch_undistort_cv(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, unsigned int* bbox_rows,
-                         hipStream_t s) {
-  CvArg a;
-  static_assert(sizeof(CvArg) == sizeof(CvArgH), "layout");
-  memcpy(&a, &ah, sizeof(a));
-  VhashTable none;
-  memset(&none, 0, sizeof(none));
-  if (n > 0) hipLaunchKernelGGL(k_undistort_cv<false>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent, bbox_rows, 0.f, none, nullptr);
 }
 void launch_voxel_minmax(const float4* pts, int n, unsigned int* mm, unsigned int* mm_next, hipStream_t s) {
   int nb = nblk(n, 256 * 4);
@@ -658,51 +724,74 @@ void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const u
     hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, keys, pcl_keys,
                        filtered_dev, samples, sample_width);
 }
-static VhashTable vhash_table(const VoxelHashBuffers& vh, int n) {
-  VhashTable tb;
-  tb.key64 = vh.key64;
-  tb.key = vh.key; tb.first = vh.first; tb.count = vh.count; tb.head = vh.head; tb.members = vh.members;
-  unsigned int slots = 1024;
-  while (slots < 4u * (unsigned)n) slots <<= 1;
-  tb.mask = slots - 1u;
+static VhTable vh_table(const VoxelHashBuffers* vh, int n) {
+  VhTable tb;
+  memset(&tb, 0, sizeof(tb));
+  if (!vh) return tb;
+  tb.slots = static_cast<VhSlot*>(vh->slots);
+  tb.mask = (unsigned int)voxel_hash_slots(n) - 1u;
+  tb.slot_of = vh->slot_of; tb.next = vh->next; tb.crowded = vh->crowded;
   return tb;
 }
-// The IMU-mode de-skew with the insert of the hashed voxel filter riding in it; launch_voxel_hash(..., stages = 4) goes on from
-// there (link + emit<ABS>).
-void launch_undistort_imu_vhash(float4* pts, int n, const double* poses, int K, const UndistArgH& uh, const unsigned long long* extent,
-                                unsigned int* bbox_rows, float leaf, const VoxelHashBuffers& vh, hipStream_t s) {
-  if (n <= 0) return;
+static DeskewIo deskew_io(const DeskewPlan& p) {
+  DeskewIo io;
+  io.in = p.in; io.out = p.out; io.n = p.n; io.sorted = p.sorted; io.extent = p.extent; io.bbox_rows = p.bbox_rows;
+  io.leaf = p.leaf;
+  io.tb = vh_table(p.vh, p.n);
+  io.ctrl_src = static_cast<const uint4*>(p.ctrl_src); io.ctrl_dst = static_cast<uint4*>(p.ctrl_dst); io.ctrl_vec = (int)(p.ctrl_bytes / 16);
+  return io;
+}
+template <bool FUSE, int KP>
+static void launch_deskew_imu_t(const DeskewIo& io, const UndistArg& u, int K, const double* poses_host, const double* poses_dev, int nb, hipStream_t s) {
+  PoseTab<KP> tab;
+  if (KP > 0) memcpy(tab.v, poses_host, sizeof(double) * 22 * (size_t)K);
+  hipLaunchKernelGGL((k_deskew_imu<FUSE, KP>), dim3(nb), dim3(256), 0, s, io, u, K, poses_dev, tab);
+}
+// poses_host != nullptr and K <= 64: the table travels in the kernel arguments; otherwise it is read from poses_dev.
+// p.vh != nullptr (and p.leaf > 0): the insert of the hashed voxel filter rides along (launch_voxel_hash(..., stages = 4) goes on).
+void launch_deskew_imu(const DeskewPlan& p, const double* poses_host, const double* poses_dev, int K, const UndistArgH& uh, hipStream_t s) {
+  if (p.n <= 0) return;
   UndistArg u;
+  static_assert(sizeof(UndistArg) == sizeof(UndistArgH), "layout");
   memcpy(&u, &uh, sizeof(u));
-  hipLaunchKernelGGL(k_undistort_imu<true>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, poses, K, u, extent, bbox_rows, leaf,
-                     vhash_table(vh, n), vh.slot_of);
+  const DeskewIo io = deskew_io(p);
+  const int nb = nblk(p.n, 256) + (io.ctrl_vec > 0 ? 1 : 0);
+  const bool fuse = p.vh != nullptr;
+  const int kp = !poses_host ? 0 : (K <= 32 ? 32 : (K <= 64 ? 64 : 0));
+  if (fuse) {
+    if (kp == 32) launch_deskew_imu_t<true, 32>(io, u, K, poses_host, poses_dev, nb, s);
+    else if (kp == 64) launch_deskew_imu_t<true, 64>(io, u, K, poses_host, poses_dev, nb, s);
+    else launch_deskew_imu_t<true, 0>(io, u, K, poses_host, poses_dev, nb, s);
+  } else {
+    if (kp == 32) launch_deskew_imu_t<false, 32>(io, u, K, poses_host, poses_dev, nb, s);
+    else if (kp == 64) launch_deskew_imu_t<false, 64>(io, u, K, poses_host, poses_dev, nb, s);
+    else launch_deskew_imu_t<false, 0>(io, u, K, poses_host, poses_dev, nb, s);
+  }
 }
-void launch_undistort_cv_vhash(float4* pts, int n, const CvArgH& ah, const unsigned long long* extent, unsigned int* bbox_rows, float leaf,
-                               const VoxelHashBuffers& vh, hipStream_t s) {
-  if (n <= 0) return;
+void launch_deskew_cv(const DeskewPlan& p, const CvArgH& ah, hipStream_t s) {
+  if (p.n <= 0) return;
   CvArg a;
+  static_assert(sizeof(CvArg) == sizeof(CvArgH), "layout");
   memcpy(&a, &ah, sizeof(a));
-  hipLaunchKernelGGL(k_undistort_cv<true>, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, a, extent, bbox_rows, leaf, vhash_table(vh, n), vh.slot_of);
+  const DeskewIo io = deskew_io(p);
+  const int nb = nblk(p.n, 256) + (io.ctrl_vec > 0 ? 1 : 0);
+  if (p.vh) hipLaunchKernelGGL(k_deskew_cv<true>, dim3(nb), dim3(256), 0, s, io, a);
+  else hipLaunchKernelGGL(k_deskew_cv<false>, dim3(nb), dim3(256), 0, s, io, a);
 }
+void launch_voxel_hash_clear(const VoxelHashBuffers& vh, size_t slots, hipStream_t s) {
+  hipLaunchKernelGGL(k_vh_clear, dim3((unsigned int)((slots + 255) / 256)), dim3(256), 0, s, static_cast<VhSlot*>(vh.slots), (unsigned int)slots);
+}
+// stages: 1 = insert keyed by the PCL voxel index (stand-alone filter), 2 = its emit, 4 = the emit behind a fused de-skew
+// (the table is keyed by absolute voxel coordinates).  epoch: the number of this filter run (never 0; VoxelHashBuffers::counts).
 void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
-                       int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, hipStream_t s) {
+                       int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, unsigned int epoch,
+                       hipStream_t s) {
   if (n <= 0) return;
-  VhashTable tb;
-  tb.key64 = vh.key64;
-  tb.key = vh.key; tb.first = vh.first; tb.count = vh.count; tb.head = vh.head; tb.members = vh.members;
-  unsigned int slots = 1024;
-  while (slots < 4u * (unsigned)n) slots <<= 1;
-  tb.mask = slots - 1u;
+  const VhTable tb = vh_table(&vh, n);
   const int nb = nblk(n, 256);
-  if (stages & 1) {
-    hipLaunchKernelGGL(k_vhash_insert, dim3(nb), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, tb, vh.slot_of, filtered);
-    hipLaunchKernelGGL(k_vhash_link, dim3(nb), dim3(256), 0, s, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, vh.crowded);
-  }
-  if (stages & 2) hipLaunchKernelGGL(k_vhash_emit<false>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, out, n_out, pcl_out, nullptr, 0, leaf, filtered);
-  if (stages & 4) {  // behind launch_undistort_imu_vhash: the table is filled (absolute voxel coordinates)
-    hipLaunchKernelGGL(k_vhash_link, dim3(nb), dim3(256), 0, s, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, vh.crowded);
-    hipLaunchKernelGGL(k_vhash_emit<true>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.slot_of, vh.next, vh.is_first, vh.block_firsts, out, n_out, pcl_out, bbox_rows, n_rows, leaf, filtered);
-  }
+  if (stages & 1) hipLaunchKernelGGL(k_vhash_insert, dim3(nb), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, tb, filtered);
+  if (stages & 2) hipLaunchKernelGGL(k_vhash_emit<false>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.counts, epoch, out, n_out, pcl_out, nullptr, 0, leaf, filtered);
+  if (stages & 4) hipLaunchKernelGGL(k_vhash_emit<true>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.counts, epoch, out, n_out, pcl_out, bbox_rows, n_rows, leaf, filtered);
 }
 size_t voxel_hash_slots(int max_n) {
   size_t slots = 1024;

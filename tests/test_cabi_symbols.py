@@ -32,7 +32,7 @@ def test_python_mirror_covers_header():
     L = lii.load_library()
     import re
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "liinit_hip.h")).read()
-    assert L.lii_abi_version() == int(re.search(r"#define\s+LII_ABI_VERSION\s+(\d+)", header).group(1)) == 5
+    assert L.lii_abi_version() == int(re.search(r"#define\s+LII_ABI_VERSION\s+(\d+)", header).group(1)) == 6
 
 
 def test_struct_layouts_match_header():
@@ -71,4 +71,4 @@ def test_cxx_host_loop_links_against_the_boundary():
                                    ctypes.c_void_p, ctypes.c_void_p]
     totals = (ctypes.c_int64 * 2)()
     assert drv.lii_stream_run(None, None, 0, 0, 0, 0.0, 5, 1, 0, 0, totals, None) == -1  # LII_ERR_INVALID
-    assert ctypes.sizeof(api.lii_scan_job) == 48  # struct_size the C++ loop fills in (two 8-byte members after the options)
+    assert ctypes.sizeof(api.lii_scan_job) == 56  # struct_size the C++ loop fills in (ABI 6: scan_sorted behind n_scan_dev)

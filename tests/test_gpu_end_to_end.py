@@ -324,3 +324,65 @@ def test_fused_deskew_filter_edge_cases(oracle, leaf, cv):
         assert np.array_equal(c, clouds[0][0], equal_nan=True)
         assert np.array_equal(s, clouds[0][1], equal_nan=True)
     reg.close()
+
+
+@pytest.mark.parametrize("cv", [False, True])
+@pytest.mark.parametrize("K,tmin", [(6, 0.0), (12, 7.5), (40, 31.0), (70, 2.0)])
+def test_sorted_scan_takes_the_short_prologue_with_the_same_bits(oracle, K, tmin, cv):
+    """lii_scan_job::scan_sorted: a scan in ascending time order is de-skewed straight out of the caller's buffer by ONE launch
+    (pose table in the kernel arguments up to 64 poses, no time-extent reduction, the control block pulled by an extra workgroup).
+    De-skewed scan, down-sampled cloud and final state must be the bits of the general path - with the time-earliest point behind
+    several poses (quirk A3: compensated once per pose), with tables of every argument-block size and beyond (70 poses: the
+    general path serves the job), adopted and uploaded scans, hashed filter fused and not (first scan of a leaf: probed)."""
+    import lidar_imu_init_amd as lii
+    from harness import synth
+    from conftest import make_state
+    hall, map_pts = synth.bench_world(200_000, 0.15)
+    reg = lii.Registrar(max_scan_points=40_000, max_map_points=250_000, filter_size_map=0.15)
+    reg.map_build(map_pts)
+    R = synth.rot_zyx(0.02, 0.01, -0.4)
+    p = np.array([2.0, 1.0, 0.2])
+    scan = synth.make_scan(hall, "vlp16", R, p, noise=0.02, seed=5)
+    scan[:, 3] = np.linspace(tmin, 100, len(scan), dtype=np.float32)
+    scan[77, 1] = np.nan
+    st0 = oracle.state_boxplus(make_state(oracle, R, p), np.r_[0.002, -0.001, 0.003, 0.02, -0.01, 0.01, np.zeros(18)])
+    s0 = lii.State(st0)
+    if cv:
+        s0.bias_g[:] = [1e-3, 0, 2e-3]
+        s0.vel_end[:] = [0.05, 0, 0]
+    T = lii.pose6d_array(K)
+    rng = np.random.default_rng(K)
+    for k in range(K):
+        T[k, 0] = 0.1 * k / (K - 1)
+        T[k, 1:4] = rng.normal(0, 0.3, 3)
+        T[k, 4:7] = rng.normal(0, 0.05, 3)
+        T[k, 7:10] = rng.normal(0, 0.2, 3)
+        T[k, 10:13] = s0.pos_end + rng.normal(0, 0.01, 3)
+        T[k, 13:22] = (s0.rot_end @ synth.rot_zyx(*rng.normal(0, 0.002, 3))).reshape(-1)
+    dev = reg.device_scan(scan)
+    results = []
+    for rnd in range(2):  # (round 0 of a leaf size probes the filter; round 1 fuses its insert into the de-skew)
+        for sorted_hint in (False, True):
+            for adopt in (False, True):
+                if not adopt:
+                    reg.scan_upload(scan)
+                st = s0.copy()
+                kw = dict(cv=True) if cv else dict(imu_poses=T)
+                rep = reg.scan_register(st, s0, leaf=0.1, max_iterations=3, imu_en=not cv, scan_dev=dev if adopt else None,
+                                        scan_sorted=sorted_hint, **kw)
+                results.append((reg.scan_download(0).copy(), reg.scan_download(1).copy(), st.pod.copy(), rep["iterations"], rep["normal_eq"]))
+    ref = results[0]
+    assert len(ref[1]) > 1000 and ref[3] >= 1
+    for r in results[1:]:
+        assert np.array_equal(r[0], ref[0], equal_nan=True)
+        assert np.array_equal(r[1], ref[1], equal_nan=True)
+        assert np.array_equal(r[2], ref[2]) and r[3] == ref[3] and np.array_equal(r[4], ref[4])
+    # and the de-skewed scan is the oracle's
+    if cv:
+        want = oracle.undistort_cv(scan, s0.bias_g, s0.vel_end, s0.rot_end)
+    else:
+        want = oracle.undistort_imu(scan, T, s0.rot_end, s0.pos_end, s0.offset_R_L_I, s0.offset_T_L_I)
+    got = ref[0]
+    fin = np.isfinite(scan[:, :3]).all(axis=1)
+    assert np.abs(got[fin, :3] - want[fin, :3]).max() <= 2 * np.spacing(np.float32(np.abs(want[fin, :3]).max()))
+    reg.close()

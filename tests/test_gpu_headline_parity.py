@@ -48,7 +48,7 @@ def test_scan_register_matches_oracle_at_bench_size(world, oracle, workload, n_s
         ref = bench.oracle_scan_register(oracle, tree, scan, states0[j], tables[j], wl["fs_surf"], wl["max_it"], threads=8)
         st = states0[j].copy()
         rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=wl["fs_surf"], max_iterations=wl["max_it"], imu_en=True,
-                                scan_dev=reg.device_scan(scan))
+                                scan_dev=reg.device_scan(scan), scan_sorted=True)  # (the bench's streams are time-sorted)
         body = reg.scan_download(1)
         assert len(body) == ref["n_down"]
         par = bench.parity_against_oracle(oracle, ref, st.pod, rep, prior_cov=states0[j].cov)

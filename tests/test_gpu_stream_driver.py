@@ -55,7 +55,7 @@ def test_cxx_loop_equals_python_loop(small_world):
     for k in range(steps):
         j = k % 3
         s = states[j].copy()
-        rep = reg.scan_register(s, states[j], imu_poses=tables[j], leaf=leaf, max_iterations=max_it, imu_en=True, scan_dev=devs[j])
+        rep = reg.scan_register(s, states[j], imu_poses=tables[j], leaf=leaf, max_iterations=max_it, imu_en=True, scan_dev=devs[j], scan_sorted=True)
         it_py += rep["iterations"]
         se_py += rep["searches"]
         last_py = s.pod.copy()

@@ -20,7 +20,9 @@ def main():
     title = sys.argv[3] if len(sys.argv) > 3 else d
     rows = list(csv.DictReader(open(glob.glob(d + "/*kernel_trace.csv")[0])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "k_time_extent" in r["Kernel_Name"]]
+    starts = [i for i, r in enumerate(rows) if "k_time_extent" in r["Kernel_Name"] or "k_deskew" in r["Kernel_Name"]]
+    # (a scan that takes the general path starts with k_time_extent and has a k_deskew launch behind it: keep the first of a pair)
+    starts = [i for n, i in enumerate(starts) if n == 0 or i != starts[n - 1] + 1]
     use = list(zip(starts[-61:-1], starts[-60:]))
     dur, gap = collections.defaultdict(list), collections.defaultdict(list)
     wall, busy = [], []
