@@ -191,14 +191,14 @@ __device__ __forceinline__ void deskew_bbox(float4 q, bool in_range, unsigned in
 // CAS, atomicMin, atomicAdd and member store and the emit's reads all touch that one line (round 3 kept five parallel arrays:
 // five lines per voxel).
 constexpr unsigned int kVhEmpty = 0xFFFFFFFFu;
-constexpr int kVhMembers = 10;  // the first arrivals of a voxel (its first point included) sit in the slot itself
+constexpr int kVhMembers = 10;  // the first arrivals of a voxel (its creator included) sit in the slot itself
 struct __attribute__((aligned(64))) VhSlot {
   unsigned long long key;  // all ones = free.  Fused form: packed absolute voxel coordinates; separate form: the PCL voxel index
-  unsigned int first;      // smallest point index of the voxel (atomicMin); kVhEmpty while free
-  unsigned int count;      // points of the voxel so far (atomicAdd)
+  unsigned int first;      // smallest point index among the LATER arrivals of the voxel (atomicMin); kVhEmpty: none
+  unsigned int count;      // later arrivals so far (atomicAdd): the voxel holds count + 1 points
   unsigned int head;       // arrivals beyond kVhMembers: a list through next[]; kVhEmpty = none
   unsigned int pad;
-  unsigned int members[kVhMembers];
+  unsigned int members[kVhMembers];  // [0]: the point that created the slot; [k]: the k-th later arrival
 };
 static_assert(sizeof(VhSlot) == 64, "one cache line per slot");
 struct VhTable {
@@ -208,26 +208,34 @@ struct VhTable {
   unsigned int* next;       // per input point: list link of a crowded voxel
   unsigned int* crowded;    // one word: the longest list behind a slot so far
 };
-// A point joins the voxel that owns `slot`: smallest index, arrival number, member entry.  None of it needs the voxel to be
-// complete - the emit launch, which runs when every point has arrived, picks the first point as the voxel's owner and puts the
-// members in input order (round 3 needed a launch of its own between insert and emit for this: k_vhash_link).
-__device__ __forceinline__ void vh_join(const VhTable& tb, unsigned int slot, int i) {
-  VhSlot* s = tb.slots + slot;
-  atomicMin(&s->first, (unsigned)i);
-  const unsigned int k = atomicAdd(&s->count, 1u);
-  if (k < (unsigned)kVhMembers) s->members[k] = (unsigned)i;
-  else { tb.next[i] = atomicExch(&s->head, (unsigned)i); atomicMax(tb.crowded, k + 1u - (unsigned)kVhMembers); }
-}
-__device__ __forceinline__ unsigned int vh_claim(const VhTable& tb, unsigned long long key) {
+// A point joins its voxel: the slot is found - or created - by a CAS on the key.  The point that CREATES the slot (no key there
+// before) becomes entry 0 of the member list with a plain store and is done: one atomic for the ~95 % of the points of a leaf
+// matched to the sensor that stay alone in their voxel - the atomics of the insert, performed at the memory side, are what the
+// de-skew launch waits for (100 k of them ~ 5 us).  Only a LATER arrival pays for the bookkeeping: its arrival number (atomicAdd),
+// its member entry, and the smallest index among the later arrivals (atomicMin).  The voxel's owner - its first point in input
+// order - is min(creator, `first`), which the emit launch evaluates when every point has arrived; it also puts the members in
+// input order.  (Round 3: CAS + atomicMin per point here and a launch of its own, k_vhash_link, to collect the members.)
+__device__ __forceinline__ void vh_insert(const VhTable& tb, unsigned long long key, int i) {
   unsigned long long hk = key;
   hk ^= hk >> 33; hk *= 0xFF51AFD7ED558CCDull; hk ^= hk >> 33;
   unsigned int slot = (unsigned int)hk & tb.mask;
+  bool created;
   for (;;) {  // the table has four times as many slots as there are points: a free slot always turns up
     const unsigned long long prev = atomicCAS(&tb.slots[slot].key, ~0ull, key);
-    if (prev == ~0ull || prev == key) break;
+    created = prev == ~0ull;
+    if (created || prev == key) break;
     slot = (slot + 1u) & tb.mask;
   }
-  return slot;
+  VhSlot* s = tb.slots + slot;
+  if (created) {
+    s->members[0] = (unsigned)i;
+  } else {
+    atomicMin(&s->first, (unsigned)i);
+    const unsigned int k = atomicAdd(&s->count, 1u) + 1u;
+    if (k < (unsigned)kVhMembers) s->members[k] = (unsigned)i;
+    else { tb.next[i] = atomicExch(&s->head, (unsigned)i); atomicMax(tb.crowded, k + 1u - (unsigned)kVhMembers); }
+  }
+  tb.slot_of[i] = slot;
 }
 // The insert of the fused form.  The grid PCL lays over the cloud starts at the cloud's bounding box, which is only known when
 // every point has been de-skewed - but which points share a voxel is not: floor(x / leaf) decides it (PCL's index is
@@ -235,7 +243,6 @@ __device__ __forceinline__ unsigned int vh_claim(const VhTable& tb, unsigned lon
 // around a bias of 2^20: +- 52 km at a 5 cm leaf), and the PCL index of a voxel - the key the output is ordered by on the host -
 // is computed by k_vhash_emit<true>, which knows the box.  A point outside the 21-bit range is a voxel of its own.
 __device__ __forceinline__ void vhash_insert_abs(const float4 P, int i, float leaf, const VhTable& tb) {
-  unsigned int slot = kVhEmpty;
   if (isfinite(P.x) && isfinite(P.y) && isfinite(P.z)) {  // (non-finite points are dropped, as PCL drops them)
     const float inv_leaf = 1.0f / leaf;
     const float fx = floorf(P.x * inv_leaf), fy = floorf(P.y * inv_leaf), fz = floorf(P.z * inv_leaf);
@@ -246,10 +253,10 @@ __device__ __forceinline__ void vhash_insert_abs(const float4 P, int i, float le
     } else {
       key = (1ull << 63) | (unsigned long long)(unsigned)i;
     }
-    slot = vh_claim(tb, key);
-    vh_join(tb, slot, i);
+    vh_insert(tb, key, i);
+    return;
   }
-  tb.slot_of[i] = slot;
+  tb.slot_of[i] = kVhEmpty;
 }
 
 // What the two de-skew kernels share.  `in` is the scan as it arrived - the caller's device buffer (lii_scan_job::scan_dev:
@@ -488,9 +495,9 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ p
 // order of their first points (the PCL index of every output voxel is kept: lii_scan_download / lii_neighbors_download put
 // the reference's order back on the host).  Two launches (round 3: three), the first of which rides in the de-skew launch
 // inside lii_scan_register:
-//   insert          the voxel's slot in an open-addressing table (CAS on the key), then vh_join: smallest point index
-//                   (atomicMin), arrival number (atomicAdd), member entry - k_vhash_insert keyed by the PCL voxel index, or
-//                   vhash_insert_abs from the de-skew kernels keyed by absolute voxel coordinates
+//   insert          vh_insert: the voxel's slot in an open-addressing table (CAS on the key); the creator of a slot is done with
+//                   that, a later arrival adds its arrival number, member entry and index minimum - k_vhash_insert keyed by
+//                   the PCL voxel index, or vhash_insert_abs from the de-skew kernels keyed by absolute voxel coordinates
 //   k_vhash_emit    a point is the voxel's owner when it is its first point; output position = number of owners before it -
 //                   the owners of a workgroup are counted, the count is published, and the counts of the workgroups below
 //                   are collected INSIDE the launch, after the owner has formed its centroid (by then they have long been
@@ -542,12 +549,8 @@ __global__ __launch_bounds__(256) void k_vhash_insert(const float4* __restrict__
     const int i2 = (int)(floorf(p.z * v.inv_leaf) - (float)v.min_b[2]);
     key = (unsigned)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);  // < 2^31 (the overflow guard)
   }
-  unsigned int slot = kVhEmpty;
-  if (key != ~0ull) {
-    slot = vh_claim(tb, key);
-    vh_join(tb, slot, i);
-  }
-  tb.slot_of[i] = slot;
+  if (key != ~0ull) vh_insert(tb, key, i);
+  else tb.slot_of[i] = kVhEmpty;
 }
 // exclusive scan over the 256 lanes of a workgroup of 0 / 1 flags; *total = flags set in the workgroup
 __device__ __forceinline__ unsigned int block_rank_of_flag(bool f, unsigned int* s_w /*[4] LDS*/, unsigned int* total) {
@@ -586,7 +589,7 @@ __device__ __forceinline__ unsigned int owners_below(const unsigned long long* _
 // workgroup, folded by every workgroup for itself), the PCL index of a voxel is computed from its first point, and PCL's
 // overflow guard (the grid would have more than 2^31 voxels: "leaf size too small", the cloud passes unfiltered) is applied
 // here - every point then leaves as it is, in input order.
-// *crowded (written by vh_join when a point goes to a list): the host reads it behind the filter and takes the sort path from
+// *crowded (written by vh_insert when a point goes to a list): the host reads it behind the filter and takes the sort path from
 // then on when voxels hold dozens of points (a large leaf) - the owner orders the members by repeated selection, quadratic in
 // their number.
 template <bool ABS>
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
     const uint4 c = line[2], d = line[3];  // members 2..5, 6..9
     m0.z = c.x; m0.w = c.y; m1 = make_uint4(c.z, c.w, d.x, d.y); m2 = make_uint2(d.z, d.w);
   }
-  const bool first = slot != kVhEmpty && hd.x == (unsigned)i;
+  const bool first = slot != kVhEmpty && min(hd.x, m0.x) == (unsigned)i;  // the owner: the first point of the voxel in input order
   unsigned int total;
   const unsigned int rank = block_rank_of_flag(first, s_w, &total);
   if (tid == 0) __hip_atomic_store(counts + blockIdx.x, ((unsigned long long)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
   }
   float4 cen = make_float4(0.f, 0.f, 0.f, 0.f);
   if (first) {
-    const unsigned int cnt = hd.y;  // points of the voxel, this one included
+    const unsigned int cnt = hd.y + 1u;  // points of the voxel, this one included
     float sx = __fadd_rn(0.f, p0.x), sy = __fadd_rn(0.f, p0.y), sz = __fadd_rn(0.f, p0.z), st = __fadd_rn(0.f, p0.w);
     unsigned int m[kVhMembers] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y};
 #pragma unroll
