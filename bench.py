@@ -17,6 +17,7 @@ the ranks ("strong" scaling: the per-scan work is fixed).  The line also carries
 distinct scan of the stream against the CPU oracle (computed in the cpu_baseline leg, outside the timed region).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -315,6 +316,10 @@ def main():
         reg.set_profiling(1)
         reg.set_profiling(0)
         iters_total[0] = search_total[0] = 0
+        # (a cyclic garbage collection of the interpreter - ~1 ms over this process's objects - is kept out of the timed region: it
+        # is triggered by allocation counts, i.e. lands at a fixed point of the script, and round 4's found it inside a 20-step region)
+        gc.collect()
+        gc.disable()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -324,6 +329,7 @@ def main():
         if native:
             totals[:] = 0
             native(0, args.steps, args.profile_every)
+            t_native = time.perf_counter() - t0
             iters_total[0], search_total[0] = int(totals[0]), int(totals[1])
             last = last_pod
         else:
@@ -333,10 +339,17 @@ def main():
                 if trace:
                     stamps.append(time.perf_counter() - t0)
         reg.synchronize()
+        t_libsync = time.perf_counter() - t0
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
+        if os.environ.get("LII_BENCH_DEBUG"):
+            t_a = time.perf_counter(); torch.cuda.synchronize(); t_b = time.perf_counter()
+            print(f"[bench debug] a second device synchronize right behind: {1e3 * (t_b - t_a):.3f} ms", file=sys.stderr)
+            print(f"[bench debug] timed region: host loop {1e3 * (t_native if native else 0):.3f} ms, + library synchronize {1e3 * t_libsync:.3f}, "
+                  f"+ device synchronize (+ barrier) {1e3 * dt:.3f}", file=sys.stderr)
         if dist is not None:
             tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_device else "cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

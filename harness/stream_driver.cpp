@@ -3,7 +3,10 @@
 // (map_incremental) when asked.  bench.py times THIS loop: a ROS node calling the library is C++, and a ctypes round trip
 // per scan costs ~25 us of interpreter time that no deployment would pay.  Harness code, not product: it only calls
 // include/liinit_hip.h.   (the call sites it stands for: src/laserMapping.cpp:905-919 + :960-1120 + :1130 map_incremental)
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "liinit_hip.h"
@@ -31,7 +34,14 @@ int lii_stream_run(lii_handle h, const lii_stream_scan* scans, int32_t n_scans, 
   if (!h || !scans || n_scans < 1 || steps < 0 || !totals) return LII_ERR_INVALID;
   lii_state st;
   lii_iekf_report rep;
+  const bool trace = std::getenv("LII_STREAM_TRACE") != nullptr;  // per-step wall time on stderr (diagnostic)
+  auto t_prev = std::chrono::steady_clock::now();
   for (int32_t k = first; k < first + steps; k++) {
+    if (trace && k > first) {
+      const auto t_now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "%.1f ", std::chrono::duration<double, std::micro>(t_now - t_prev).count());
+      t_prev = t_now;
+    }
     const lii_stream_scan& sc = scans[k % n_scans];
     int rc = lii_set_profiling(h, (profile_every > 0 && k % profile_every == 0) ? 2 : 0);
     if (rc != LII_OK) return rc;
@@ -57,6 +67,7 @@ int lii_stream_run(lii_handle h, const lii_stream_scan* scans, int32_t n_scans, 
       if (rc != LII_OK) return rc;
     }
   }
+  if (trace) std::fprintf(stderr, "%.1f [us per step, %d steps]\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_prev).count(), steps);
   if (last_state && steps > 0) std::memcpy(last_state, &st, sizeof(st));
   return LII_OK;
 }

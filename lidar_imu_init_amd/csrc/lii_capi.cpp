@@ -107,6 +107,7 @@ struct lii_context {
   bool host_solve = false;      // LII_HOST_SOLVE=1: drive the loop from the host (A/B, reference arrangement)
   double* d_partials = nullptr;
   double* d_out91 = nullptr;
+  unsigned long long* d_gran = nullptr;  // k_reduce_solve: the 91 sums of a pass on their way to the solver, 2 x 91 tagged words
   unsigned long long* d_extent = nullptr;  // 2 x {min (time|index), max time}: ping-pong accumulators
   unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
   int extent_sel = 0, mm_sel = 0;
@@ -748,7 +749,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     }
     launch_fit_reduce(g, rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
     if (!h->comm) {  // single GPU or node-local mailbox: final sum (+ exchange) and solve in one launch
-      launch_reduce_solve(rb, h->d_out91, h->d_counter, h->d_ctrl, h->h_res, mailbox_view(h), s);
+      launch_reduce_solve(rb, h->d_gran, h->d_ctrl, h->h_res, mailbox_view(h), s);
       return LII_OK;
     }
     launch_reduce91(rb, h->d_out91, h->d_ctrl, -1, s);
@@ -851,10 +852,14 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   {
     static int cnt = 0;
     if (++cnt % 100 == 0) {
-      fprintf(stderr, "[solve trace, 10 ns ticks]");
-      for (int k = 1; k <= 10; k++) fprintf(stderr, " %lld", hr->ts[k] - hr->ts[k - 1]);
-      fprintf(stderr, "  | it0:");
-      for (int k = 1; k <= 10; k++) fprintf(stderr, " %lld", hr->ts0[k] - hr->ts0[k - 1]);
+      auto row = [&](const long long* t) {
+        fprintf(stderr, " loads+sums %lld | A %lld | elimination %lld | solution %lld | state %lld | cov %lld ;", t[1] - t[0], t[2] - t[1], t[4] - t[3], t[8] - t[4],
+                t[9] - t[8], t[10] - t[9]);
+      };
+      fprintf(stderr, "[solve trace, 10 ns ticks] stopping pass:");
+      row(hr->ts);
+      fprintf(stderr, "  pass 0:");
+      row(hr->ts0);
       fprintf(stderr, "\n");
     }
   }
@@ -1074,6 +1079,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   h->partial_stride = register_blocks(int(N)) + 8;
   CK(dmalloc(&h->d_partials, size_t(h->partial_stride) * kNormalEq));
   CK(dmalloc(&h->d_out91, 256));  // [0,91): local sums, [128,219): all-reduced sums (sharded scans)
+  CK(dmalloc(&h->d_gran, 256));
+  CK(hipMemset(h->d_gran, 0, 8 * 256));
   CK(dmalloc(&h->d_extent, 4));
   CK(dmalloc(&h->d_mm, 16));
   CK(dmalloc(&h->d_bbox_rows, (N / 256 + 2) * 8));
@@ -1143,7 +1150,7 @@ int lii_destroy(lii_handle h) {
   if (h->d_scan_next) (void)hipFree(h->d_scan_next);
   void* dev[] = {h->d_dropped, h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_ah_key, h->d_ah_best, h->d_ah_slot, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
-                 h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
+                 h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_gran, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
                  h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->vh.slots, h->vh.slot_of, h->vh.next, h->vh.counts, h->vh.crowded, h->d_cal_imu, h->d_cal_lidar, h->d_cal_params,
                  h->d_cal_out};
   for (void* p : dev)

@@ -184,15 +184,13 @@ struct MailboxView {
   long long timeout_ticks;  // of the 100 MHz wall clock: how long to wait for a peer that may never arrive
 };
 
-// Called by ONE wavefront (64 lanes).  `in` holds this rank's 91 partial sums, `out` receives the sum over ranks (may alias
-// `in`).  Returns false when a peer did not publish within the time limit (the communicator is unusable afterwards).
-__device__ inline bool mailbox_allreduce(const MailboxView& mb, const double* in, double* out) {
+// Called by ONE wavefront (64 lanes).  Lane l holds this rank's sums l (v0) and l + 64 (v1; lanes 0 .. 26) and receives the
+// sums over the ranks in their place.  Returns false when a peer did not publish within the time limit (the communicator is
+// unusable afterwards).
+__device__ inline bool mailbox_allreduce(const MailboxView& mb, double& v0, double& v1) {
   const int lane = threadIdx.x & 63;
   const unsigned long long q = *mb.seq + 1ull;
   const int par = (int)(q & 1ull);
-  double v0 = 0, v1 = 0;  // this lane's share of the 91 sums
-  if (lane < kNormalEq) v0 = __hip_atomic_load(in + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (lane + 64 < kNormalEq) v1 = __hip_atomic_load(in + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const double* rd;   // where this rank reads the slots from: slot of source rank r at rd + (r * 2 + par) * kMailboxSlotDoubles
   if (mb.peers) {
     for (int r = 0; r < mb.n_ranks; r++) {  // push into every rank's memory (the own one included)
@@ -231,7 +229,7 @@ __device__ inline bool mailbox_allreduce(const MailboxView& mb, const double* in
 #pragma unroll 8
       for (int r = 0; r < mb.n_ranks; r++)
         acc += __hip_atomic_load(rd + (size_t)(r * 2 + par) * kMailboxSlotDoubles + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      out[i] = acc;
+      if (i < 64) v0 = acc; else v1 = acc;
     }
   }
   __threadfence();

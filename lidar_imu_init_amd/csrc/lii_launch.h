@@ -33,8 +33,8 @@ void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipSt
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s);
 void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s);
-void launch_reduce_solve(const RegistrationBuffers& rb, double* out91, unsigned int* ticket, IekfCtrl* c, IekfResult* res,
-                         const MailboxView& mb, hipStream_t s);
+void launch_reduce_solve(const RegistrationBuffers& rb, unsigned long long* gran, IekfCtrl* c, IekfResult* res, const MailboxView& mb,
+                         hipStream_t s);
 void launch_mailbox_allreduce(double* out91, const MailboxView& mb, hipStream_t s);
 // node-local mailbox (lii_mailbox.cpp)
 struct MailboxHost {
