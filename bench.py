@@ -182,6 +182,10 @@ def main():
                     help="skip the GPU voxel-grid filter (mapping/filter_size_surf) that the step includes by default")
     ap.add_argument("--map-update", action="store_true",
                     help="also run map_incremental (device-side ikd-Tree Add_Points semantics + index rebuild) every step")
+    ap.add_argument("--long-steps", type=int, default=400, help="steps of the second timed region behind `value` (value_long; 0: none; skipped when --steps is larger)")
+    ap.add_argument("--kernel-profile-steps", type=int, default=64, help="steps of the per-launch profile pass (roofline.kernels / roofline.scan; 0: none)")
+    ap.add_argument("--no-calibration", action="store_true", help="leave the calibration record (GPU LI-Init vs oracle / reference result / ground truth) out of the line")
+    ap.add_argument("--no-calibration-stream", action="store_true", help="calibration record: the reference's committed run only, not the synthetic LO -> LI-Init stream")
     ap.add_argument("--prime", type=int, default=150, help="untimed runtime-priming steps before the warm-up")
     ap.add_argument("--scans", type=int, default=8, help="distinct resident scans cycled through")
     ap.add_argument("--cell-size", type=float, default=0.0, help="k-NN grid cell edge [m]; 0 = 2 x filter_size_map")
@@ -303,21 +307,24 @@ def main():
     trace = os.environ.get("LII_BENCH_TRACE")
     stamps = []
 
-    def timed_region(prime):
+    def timed_region(prime, n_steps=None, n_warmup=None):
         """W warm-up steps (+ the priming steps the first time), then EXACTLY K timed steps between barrier + synchronize on both
-        sides; the MAX over ranks.  Returns seconds."""
+        sides; the MAX over ranks.  Returns seconds.  (n_steps / n_warmup: another region than the command line's, `value_long`)"""
         nonlocal last
+        n_steps = args.steps if n_steps is None else n_steps
+        n_warmup = args.warmup if n_warmup is None else n_warmup
         if native:
-            native(0, prime + args.warmup, 0)
+            native(0, prime + n_warmup, 0)
         else:
-            for k in range(prime + args.warmup):
+            for k in range(prime + n_warmup):
                 step(k)
         reg.synchronize()
         reg.set_profiling(1)
         reg.set_profiling(0)
         iters_total[0] = search_total[0] = 0
         # (a cyclic garbage collection of the interpreter - ~1 ms over this process's objects - is kept out of the timed region: it
-        # is triggered by allocation counts, i.e. lands at a fixed point of the script, and round 4's found it inside a 20-step region)
+        # is triggered by allocation counts, i.e. lands at a fixed point of the script, and round 4's found it inside a 20-step region;
+        # it stays off for the rest of the run - the separately timed pipeline figures included)
         gc.collect()
         gc.disable()
         if dist is not None:
@@ -328,12 +335,12 @@ def main():
         # barrier packet on the stream
         if native:
             totals[:] = 0
-            native(0, args.steps, args.profile_every)
+            native(0, n_steps, args.profile_every)
             t_native = time.perf_counter() - t0
             iters_total[0], search_total[0] = int(totals[0]), int(totals[1])
             last = last_pod
         else:
-            for k in range(args.steps):
+            for k in range(n_steps):
                 reg.set_profiling(2 if (args.profile_every and k % args.profile_every == 0) else 0)
                 last = step(k)
                 if trace:
@@ -344,7 +351,6 @@ def main():
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
-        gc.enable()
         if os.environ.get("LII_BENCH_DEBUG"):
             t_a = time.perf_counter(); torch.cuda.synchronize(); t_b = time.perf_counter()
             print(f"[bench debug] a second device synchronize right behind: {1e3 * (t_b - t_a):.3f} ms", file=sys.stderr)
@@ -388,6 +394,29 @@ def main():
         dt = timed_region(args.prime)
         value_transport, value_rccl_ranks = "none", 0
     tm = reg.timings()
+    iters_value, searches_value = iters_total[0], search_total[0]
+    # The driver's form of this command times 20 steps (~3 ms): a second, longer region of the same steps right behind it gives the
+    # line a figure to check `value` against (never `value` itself).
+    value_long = None
+    if args.long_steps > 0 and args.long_steps > args.steps:
+        dt_long = timed_region(0, n_steps=args.long_steps, n_warmup=0)
+        value_long = {"value": args.long_steps / dt_long, "ms_per_step": 1e3 * dt_long / args.long_steps, "steps": args.long_steps,
+                      "what": "the same steps, timed the same way (barrier + synchronize on both sides), right behind the region of `value`"}
+    # Where the scan's time goes: a third pass with an event in front of EVERY launch (lii_set_profiling(h, 3); each event is a
+    # barrier packet, so this pass is slower than the timed ones and is only used for the SHARES and per-launch durations).
+    kernel_profile = None
+    if world == 1 and args.kernel_profile_steps > 0 and not (args.separate_calls or args.upload):
+        reg.set_profiling(1)
+        if native:
+            native(0, args.kernel_profile_steps, -1)
+        else:
+            for k in range(args.kernel_profile_steps):
+                reg.set_profiling(3)
+                step(k)
+        reg.synchronize()
+        kernel_profile = reg.kernel_profile()
+        reg.set_profiling(0)
+    iters_total[0], search_total[0] = iters_value, searches_value
     # size of the down-sampled cloud (the k-NN kernel's query count) and, on one GPU, the final state of every distinct scan
     # for the parity record: one untimed call per distinct scan, on every rank (a sharded call needs all of them)
     n_ds, gpu_results = [], []
@@ -518,12 +547,55 @@ def main():
                          "launches": int(tm[5]),
                          "peak_measured_copy": 6290.0, "frac_of_measured_copy": achieved / 6290.0},
         }
+        if value_long is not None:
+            out["value_long"] = value_long
+        # bytes(scan) = 32 N + S (96 N_d + 16 M) + I (32 N_d + 728), achieved = bytes(scan) x scans/s
+        I_avg, S_avg = iters_value / args.steps, searches_value / args.steps
+        n_in = float(n_full) / 1.0
+        bytes_scan = 32.0 * n_in + S_avg * (96.0 * n_d + 16.0 * M) + I_avg * (32.0 * n_d + 728.0)
+        ach_scan = bytes_scan * scans_per_s / 1e9
+        out["roofline"]["scan"] = {"alg_bytes": bytes_scan, "achieved": ach_scan, "unit": "GB/s", "frac": ach_scan / HBM_PEAK_GBS,
+                                   "frac_of_measured_copy": ach_scan / 6290.0,
+                                   "formula": "SURVEY.md 8(d): 32 N + S (96 N_d + 16 M) + I (32 N_d + 728) bytes per scan x scans/s "
+                                              f"(N {int(n_in)}, N_d {n_d:.0f}, M {M}, S {S_avg:.2f}, I {I_avg:.2f}; per GPU of a sharded job: N_d / ranks)"}
+        if kernel_profile is not None:
+            kp, kp_scans = kernel_profile
+            nb_fit = (n_d + 255) // 256
+            # algorithmic bytes of ONE launch of each kind (the corresponding term of the scan formula where it has one)
+            alg = {"deskew": 32.0 * n_in, "voxel": 16.0 * n_in + 16.0 * n_d, "knn": 96.0 * n_d + 16.0 * M, "fit_search": 128.0 * n_d + 728.0,
+                   "fit": 48.0 * n_d + 728.0, "solve": 728.0 * nb_fit + 5632.0}
+            names = {"deskew": "k_deskew_imu (adoption + IMU back-propagation + voxel-hash insert)", "voxel": "k_vhash_emit (voxel centroids)",
+                     "knn": "k_knn_pk", "fit_search": "k_fit_reduce behind a k-NN pass (completion + plane fit + row + sums)",
+                     "fit": "k_fit_reduce on cached planes", "solve": "k_reduce_solve (final sum + 24-state solve)"}
+            tot_ms = sum(v[0] for v in kp.values()) or 1.0
+            rows = []
+            for k in ("deskew", "voxel", "knn", "fit_search", "fit", "solve"):
+                ms, n_l = kp[k]
+                if n_l == 0:
+                    continue
+                avg_us = 1e3 * ms / n_l
+                rows.append({"name": names[k], "kind": k, "launches_per_scan": n_l / max(kp_scans, 1), "avg_us": avg_us,
+                             "share_of_scan": ms / tot_ms, "alg_bytes": alg[k], "achieved_GBs": alg[k] / (avg_us * 1e-6) / 1e9,
+                             "frac": alg[k] / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+            out["roofline"]["kernels"] = rows
+            out["roofline"]["kernels_note"] = (f"HIP events in front of every launch over {kp_scans} extra scans (lii_set_profiling(h, 3)): event-to-event "
+                                               "time = kernel + dispatch, in a pass that runs slower than the timed region (every event is a barrier "
+                                               f"packet: {1e3 * tot_ms / max(kp_scans, 1):.1f} us per scan here against ms_per_step); rocprofv3 durations of the same "
+                                               "kernels: profiles/r04_timeline.md")
         if transports is not None:
             out["transports"] = transports
         if pipeline is not None:
             out["complete_pipeline"] = pipeline
         if not args.no_cpu_baseline and args.gpus == 1:
             out["cpu_baseline"], out["parity"] = cpu_baseline(wl, states0, tables, args.no_downsample, gpu_results, gpu_lists)
+        if args.gpus == 1 and not args.no_calibration:
+            # the metric's second half: calibration outputs of the GPU path against the oracle, the reference's result file and
+            # ground truth (harness/calibration_bench.py)
+            try:
+                from harness import calibration_bench
+                out["calibration"] = calibration_bench.calibration_record(lii, reg, synthetic=not args.no_calibration_stream)
+            except Exception as e:  # reported, never fatal for the throughput line
+                out["calibration"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)
     reg.close()
     if dist is not None:

@@ -26,7 +26,8 @@ typedef struct lii_stream_scan {
   const lii_state* state0;   // the state IMU propagation hands to the update (state_propagat == start of the iteration)
 } lii_stream_scan;
 
-// Runs steps [first, first + steps) of the cyclic stream.  profile_every > 0: HIP-event kernel timing on every Nth step.
+// Runs steps [first, first + steps) of the cyclic stream.  profile_every > 0: HIP-event kernel timing on every Nth step;
+// profile_every < 0: every launch of every step bracketed (lii_set_profiling(h, 3): lii_last_kernel_profile).
 // Returns the first non-zero library status; totals[0] += iterations, totals[1] += k-NN passes.
 int lii_stream_run(lii_handle h, const lii_stream_scan* scans, int32_t n_scans, int32_t first, int32_t steps, float leaf,
                    int32_t max_iterations, int32_t imu_en, int32_t map_update, int32_t profile_every, int64_t totals[2],
@@ -43,7 +44,7 @@ int lii_stream_run(lii_handle h, const lii_stream_scan* scans, int32_t n_scans, 
       t_prev = t_now;
     }
     const lii_stream_scan& sc = scans[k % n_scans];
-    int rc = lii_set_profiling(h, (profile_every > 0 && k % profile_every == 0) ? 2 : 0);
+    int rc = lii_set_profiling(h, profile_every < 0 ? 3 : ((profile_every > 0 && k % profile_every == 0) ? 2 : 0));
     if (rc != LII_OK) return rc;
     std::memcpy(&st, sc.state0, sizeof(st));
     lii_scan_job job;

@@ -405,8 +405,28 @@ int lii_dev_upload(lii_handle h, void* dev_dst, const void* host_src, size_t byt
  * lii_iekf_update / lii_scan_register: [5] number of executed k-NN passes, [7] their total time (events around the k-NN launches
  * only: every event is a barrier on the stream), [4] wall time of the last update; lii_iekf_iterate: also [0] / [1] search-pass /
  * residual-pass kernels, [2] the final sum, [6] count of [1]; [3] host solve (host-driven loop only). */
-int lii_set_profiling(lii_handle h, int32_t enabled); /* 1: start (zero the accumulators), 2: resume, 0: pause */
+int lii_set_profiling(lii_handle h, int32_t enabled); /* 1: start (zero the accumulators), 2: resume, 0: pause, 3: see below */
 int lii_last_timings(lii_handle h, double out_ms[8]);
+/* lii_set_profiling(h, 3): lii_scan_register brackets EVERY launch of the scan with HIP events (a barrier packet each: the
+ * scan runs slower than unprofiled - this mode is for attributing time, not for measuring throughput) and accumulates, per
+ * kind of launch, the time from its event to the next one (kernel + dispatch) and the number of launches that executed.
+ * Accumulators start at lii_set_profiling(h, 1), like the others. */
+enum lii_kernel_kind {
+  LII_KP_DESKEW = 0,     /* adoption + de-skew (+ the voxel filter's insert, + the time-extent launch of an unsorted scan) */
+  LII_KP_VOXEL = 1,      /* the rest of the voxel filter */
+  LII_KP_KNN = 2,        /* k-NN pass */
+  LII_KP_FIT_SEARCH = 3, /* plane fit + residual + reduction behind a k-NN pass */
+  LII_KP_FIT = 4,        /* residual + reduction on cached planes */
+  LII_KP_SOLVE = 5,      /* final sum + 24-state solve */
+  LII_KP_KINDS = 8
+};
+typedef struct lii_kernel_profile {
+  uint32_t struct_size; /* sizeof(lii_kernel_profile) */
+  int32_t scans;        /* scans profiled */
+  double ms[LII_KP_KINDS];
+  int32_t launches[LII_KP_KINDS];
+} lii_kernel_profile;
+int lii_last_kernel_profile(lii_handle h, lii_kernel_profile* out);
 
 #ifdef __cplusplus
 }

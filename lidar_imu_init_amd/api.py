@@ -49,6 +49,13 @@ class lii_scan_job(C.Structure):
                 ("n_scan_dev", C.c_int32), ("scan_sorted", C.c_int32), ("reserved0", C.c_int32)]
 
 
+class lii_kernel_profile(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("scans", C.c_int32), ("ms", C.c_double * 8), ("launches", C.c_int32 * 8)]
+
+
+KERNEL_KINDS = ("deskew", "voxel", "knn", "fit_search", "fit", "solve")  # enum lii_kernel_kind
+
+
 class lii_pc2_fields(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("point_step", "x", "y", "z", "intensity", "time", "ring")]
 
@@ -138,6 +145,7 @@ _DECLS = {
     "lii_params_last_error": (C.c_char_p, []),
     "lii_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "lii_last_timings": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lii_last_kernel_profile": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_DECLS)
@@ -538,3 +546,10 @@ class Registrar:
         out = np.zeros(8)
         self._check(self.L.lii_last_timings(self.h, _ptr(out)))
         return out
+
+    def kernel_profile(self):
+        """Per-launch brackets of lii_scan_register collected under set_profiling(3): {kind: (total ms, launches)}, scans."""
+        kp = lii_kernel_profile()
+        kp.struct_size = C.sizeof(lii_kernel_profile)
+        self._check(self.L.lii_last_kernel_profile(self.h, C.byref(kp)))
+        return {k: (kp.ms[i], kp.launches[i]) for i, k in enumerate(KERNEL_KINDS)}, kp.scans

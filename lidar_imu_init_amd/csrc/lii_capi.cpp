@@ -196,6 +196,12 @@ struct lii_context {
                                   // hands over the whole scan); false: the caller hands every rank its own points
 
   // ---- profiling
+  bool kp_active = false;            // inside a lii_scan_register that is being profiled launch by launch
+  int prof_mode = 0;                 // the last lii_set_profiling value; 3: an event in front of every launch of lii_scan_register
+  std::vector<hipEvent_t> kp_ev;     // ... the events (created on demand, reused),
+  std::vector<int> kp_kind;          // ... kind * 64 + iteration of the launch behind each (kind LII_KP_KINDS: end mark)
+  int kp_n = 0;
+  lii_kernel_profile kprof{};
   bool profiling = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_it[32] = {};  // per-iteration brackets of the k-NN kernel in the device-driven loop
@@ -213,6 +219,20 @@ int fail(lii_handle h, int code, const std::string& msg) {
   if (h) h->err = msg;
   g_err = msg;
   return code;
+}
+// lii_set_profiling(h, 3): an event in front of the launch(es) that follow; `it` = the iteration of a loop launch
+int kp_mark(lii_handle h, int kind, int it = 0) {
+  if (h->prof_mode != 3) return LII_OK;
+  if (h->kp_n >= (int)h->kp_ev.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return fail(h, LII_ERR_HIP, "hipEventCreate (kernel profile)");
+    h->kp_ev.push_back(e);
+    h->kp_kind.push_back(0);
+  }
+  if (hipEventRecord(h->kp_ev[size_t(h->kp_n)], h->stream) != hipSuccess) return fail(h, LII_ERR_HIP, "hipEventRecord (kernel profile)");
+  h->kp_kind[size_t(h->kp_n)] = kind * 64 + std::min(it, 63);
+  h->kp_n++;
+  return LII_OK;
 }
 #define HIPCHK(h, call)                                                                                   \
   do {                                                                                                    \
@@ -734,7 +754,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   RegistrationBuffers rb = reg_buffers(h);
   const PoseArg* pose = reinterpret_cast<const PoseArg*>(h->d_ctrl);  // first 24 doubles of IekfCtrl::st
   const PoseArg ps0 = pose_of(*state);  // unused by the device-driven kernels (they read `pose`)
-  const bool prof = h->profiling;
+  const bool prof = h->profiling && h->prof_mode != 3;  // (mode 3 brackets every launch itself: kp_mark)
   const double* ne = h->comm ? h->d_out91 + 128 : h->d_out91;
   unsigned int plan = h->plan_cur;  // fill_ctrl chose it (the control block on the device carries the same mask)
   const unsigned int plan0 = plan;
@@ -744,10 +764,13 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     const bool knn = it >= 16 || ((plan >> it) & 1u);
     if (knn) {
       if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it], s));
+      if (h->kp_active) { const int r = kp_mark(h, LII_KP_KNN, it); if (r != LII_OK) return r; }
       launch_knn(h, g, rb, ps0, pose, -1);
       if (prof && it < 16) HIPCHK(h, hipEventRecord(h->ev_it[2 * it + 1], s));
     }
+    if (h->kp_active) { const int r = kp_mark(h, LII_KP_FIT, it); if (r != LII_OK) return r; }
     launch_fit_reduce(g, rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
+    if (h->kp_active) { const int r = kp_mark(h, LII_KP_SOLVE, it); if (r != LII_OK) return r; }
     if (!h->comm) {  // single GPU or node-local mailbox: final sum (+ exchange) and solve in one launch
       launch_reduce_solve(rb, h->d_gran, h->d_ctrl, h->h_res, mailbox_view(h), s);
       return LII_OK;
@@ -769,7 +792,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     }
     return LII_OK;
   };
-  if (h->use_graph && !h->comm && !prof) {
+  if (h->use_graph && !h->comm && !h->profiling) {
     // The same launches, captured once and replayed (hipGraphLaunch): every kernel argument of the loop is a device pointer or
     // a constant of the configuration, except the bound of the cloud size (rounded up here: the kernels take the exact size
     // from the device), the plan and the view of the map - the key of the cache.  Measured against the plain launches in
@@ -831,6 +854,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     return LII_OK;
   };
   if (h->diag) h->host_loop_enq_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop0).count();
+  if (h->kp_active) { rc = kp_mark(h, LII_KP_KINDS); if (rc != LII_OK) return rc; }  // (end mark of the planned passes)
   rc = wait_result(true);
   if (rc != LII_OK) return rc;
   if (h->h_res->done == (h->update_seq | kLoopParked)) {
@@ -842,6 +866,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
       rc = enqueue_pass(it);
       if (rc != LII_OK) return rc;
     }
+    if (h->kp_active) { rc = kp_mark(h, LII_KP_KINDS); if (rc != LII_OK) return rc; }
     rc = wait_result(false);
     if (rc != LII_OK) return rc;
   }
@@ -864,6 +889,25 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     }
   }
 #endif
+  if (h->kp_active && h->kp_n > 1 && hr->it > 0) {
+    // per-launch brackets (lii_set_profiling(h, 3)): the time from the event in front of a launch to the next event, for the
+    // launches that executed (a pass the loop did not reach, or a k-NN launch whose pass did not search, only read a flag)
+    HIPCHK(h, hipEventSynchronize(h->kp_ev[size_t(h->kp_n - 1)]));
+    for (int i = 0; i + 1 < h->kp_n; i++) {
+      int kind = h->kp_kind[size_t(i)] / 64;
+      const int it = h->kp_kind[size_t(i)] % 64;
+      if (kind >= LII_KP_KINDS) continue;
+      const bool loop_kind = kind == LII_KP_KNN || kind == LII_KP_FIT || kind == LII_KP_SOLVE;
+      if (loop_kind && (it >= hr->it || it >= 16)) continue;
+      if (kind == LII_KP_KNN && !hr->search_log[it]) continue;
+      if (kind == LII_KP_FIT && hr->search_log[it]) kind = LII_KP_FIT_SEARCH;
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, h->kp_ev[size_t(i)], h->kp_ev[size_t(i + 1)]) != hipSuccess) continue;
+      h->kprof.ms[kind] += ms;
+      h->kprof.launches[kind] += 1;
+    }
+    h->kprof.scans += 1;
+  }
   if (hr->singular == 3)
     return fail(h, LII_ERR_COMM, "mailbox exchange timed out (a rank of the job did not reach this pass); re-create the communicator");
   if (hr->singular) return fail(h, LII_ERR_INVALID, "singular covariance / normal matrix in the device solve");
@@ -1144,6 +1188,7 @@ int lii_destroy(lii_handle h) {
   mailbox_close(&h->mailbox);
   if (h->d_mb_seq) (void)hipFree(h->d_mb_seq);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+  for (hipEvent_t e : h->kp_ev) (void)hipEventDestroy(e);
   if (h->ev_next) (void)hipEventDestroy(h->ev_next);
   if (h->ev_scan_free) (void)hipEventDestroy(h->ev_scan_free);
   if (h->h_stage_next) (void)hipHostFree(h->h_stage_next);
@@ -1473,6 +1518,7 @@ int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], c
 }
 int lii_downsample_skip(lii_handle h, int32_t* n_down) {
   if (!h) return LII_ERR_INVALID;
+  if (h->kp_active) { const int r = kp_mark(h, LII_KP_VOXEL); if (r != LII_OK) return r; }
   if (h->n_scan > 0)
     HIPCHK(h, hipMemcpyAsync(h->d_body, h->d_scan, sizeof(float4) * size_t(h->n_scan), hipMemcpyDeviceToDevice, h->stream));
   h->n_body = h->n_scan;
@@ -1497,6 +1543,7 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
   // sample sort -> centroids + count (lii_vsort.hip).  The size of the result stays in HBM (d_nbody); the registration
   // kernels read it there, so the host learns it only if the caller asks (n_down / filtered != NULL, or a download).
   hipStream_t s = h->stream;
+  if (h->kp_active) { const int r = kp_mark(h, LII_KP_VOXEL); if (r != LII_OK) return r; }
   unsigned int* mm = h->d_mm + 8 * h->mm_sel;  // the box: rows a de-skew kernel left behind, or a pass of its own over the scan
   if (h->bbox_rows == 0) {
     h->mm_sel ^= 1;
@@ -1707,6 +1754,9 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   // to the de-skewed scan with the voxel filter's table filled, and one extra workgroup of it pulls the update's control block
   // over PCIe; the IMU pose table (<= 64 poses) travels in the kernel arguments.  Round 3 needed k_time_extent in front (copy +
   // time extent + pull: 8.9 us per scan).
+  h->kp_active = h->prof_mode == 3 && !h->host_solve;
+  h->kp_n = 0;
+  if (h->kp_active) { rc = kp_mark(h, LII_KP_DESKEW); if (rc != LII_OK) { h->kp_active = false; return rc; } }
   const bool fast = sorted && !h->host_solve && n_next > 0 && !h->no_fast_prologue &&
                     ((job->undistort == 1 && job->imu_poses && job->n_imu_poses >= 2 && job->n_imu_poses <= 64) || job->undistort == 2);
   if (job->undistort != 0 && job->undistort != 1 && job->undistort != 2) return fail(h, LII_ERR_INVALID, "lii_scan_register: undistort must be 0, 1 or 2");
@@ -1791,6 +1841,7 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   const auto t_pre = std::chrono::steady_clock::now();
   if (rc == LII_OK) rc = lii_iekf_update(h, state, state_prop, &job->opts, report);
   h->poses_preloaded = h->ctrl_preloaded = false;  // also on the error paths
+  h->kp_active = false;
   if (h->diag) {
     const auto t_end = std::chrono::steady_clock::now();
     h->host_us[0] += std::chrono::duration<double, std::micro>(t_first - t_entry).count();
@@ -2063,8 +2114,17 @@ int lii_dev_upload(lii_handle h, void* dev_dst, const void* host_src, size_t byt
 int lii_set_profiling(lii_handle h, int32_t enabled) {
   if (!h) return LII_ERR_INVALID;
   h->profiling = enabled != 0;
-  if (enabled == 1)
+  h->prof_mode = enabled;
+  if (enabled == 1) {
     for (double& t : h->timings) t = 0;  // 1: (re)start the accumulation; 2: resume; 0: pause (accumulators kept)
+    h->kprof = lii_kernel_profile{};
+  }
+  return LII_OK;
+}
+int lii_last_kernel_profile(lii_handle h, lii_kernel_profile* out) {
+  if (!h || !out || out->struct_size != sizeof(lii_kernel_profile)) return fail(h, LII_ERR_INVALID, "lii_last_kernel_profile: bad arguments");
+  *out = h->kprof;
+  out->struct_size = sizeof(lii_kernel_profile);
   return LII_OK;
 }
 int lii_last_timings(lii_handle h, double out_ms[8]) {

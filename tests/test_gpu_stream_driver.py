@@ -71,4 +71,22 @@ def test_cxx_loop_equals_python_loop(small_world):
     assert rc == 0
     assert (int(totals[0]), int(totals[1])) == (it_py, se_py)
     assert np.array_equal(last.pod, last_py)
+    # the same steps with an event in front of every launch (lii_set_profiling(h, 3), what bench.py's roofline.kernels is made
+    # of): the same bits, and every kind of launch of the loop accounted for - one de-skew and one voxel launch per scan, one fit
+    # and one solve per iteration, one k-NN and one search-pass fit per search
+    totals2 = np.zeros(2, np.int64)
+    last2 = lii.State()
+    reg.set_profiling(1)
+    rc = drv.lii_stream_run(reg.h, C.byref(stream), 3, 0, steps, leaf, max_it, 1, 0, -1, totals2.ctypes.data, last2.pod.ctypes.data)
+    assert rc == 0
+    reg.synchronize()
+    kp, n_scans = reg.kernel_profile()
+    reg.set_profiling(0)
+    assert np.array_equal(last2.pod, last_py) and (int(totals2[0]), int(totals2[1])) == (it_py, se_py)
+    assert n_scans == steps
+    assert kp["deskew"][1] == steps and kp["voxel"][1] == steps
+    assert kp["knn"][1] == se_py and kp["fit_search"][1] == se_py
+    assert kp["fit_search"][1] + kp["fit"][1] == it_py and kp["solve"][1] == it_py
+    for k, (ms, n) in kp.items():
+        assert n == 0 or 1e-3 < ms / n < 5.0, (k, ms, n)  # between 1 us and 5 ms per launch
     reg.close()
