@@ -265,7 +265,11 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
  * the call returns without waiting for anything - the update is enqueued for predicted list sizes (those of the previous call
  * + 25 %) on a stream of its own, the next scan's arrival, de-skew and voxel filter overlap it, and whatever touches the map
  * next (a search, any lii_map_* call) waits for it first; an update whose lists outgrew the prediction is repeated there with
- * the exact sizes.  The map that results is the same either way. */
+ * the exact sizes.  The map that results is the same either way.
+ * Deferred errors: such a repeat can itself fail (LII_ERR_CAPACITY when the exact lists no longer fit max_map_points or the work
+ * list - the padded predicted bounds passed the checks, the exact sizes are larger); the status then comes back from the call
+ * that joined the update - the next lii_scan_register / lii_iekf_update / lii_map_* / lii_synchronize - not from this one; the
+ * map is unchanged by the failed update and the handle stays usable. */
 int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, int32_t* n_no_downsample);
 
 /* ---------------------------------------------------------------- LI-Init batch calibration evaluators

@@ -100,11 +100,11 @@ struct lii_context {
   IekfResult* h_res = nullptr;  // pinned, device-mapped: written by the solve kernel of the stopping iteration
   lii_pose6d* h_poses = nullptr;  // pinned staging of the IMU pose table (lives behind h_ctrl: one upload can carry both)
   int update_seq = 0;           // IekfCtrl::seq of the last update (never 0)
-  bool poll_result = true;      // LII_SYNC_RESULT=1: end an update with hipStreamSynchronize instead of polling IekfResult::done
+  bool poll_result = true;      // LII_TEST=sync_result: end an update with hipStreamSynchronize instead of polling IekfResult::done
   bool poses_preloaded = false, ctrl_preloaded = false;  // lii_scan_register uploaded them already
   hipEvent_t ev_poses = nullptr;  // the last pose-table upload
   hipEvent_t ev_stage = nullptr;  // the last scan upload through h_stage
-  bool host_solve = false;      // LII_HOST_SOLVE=1: drive the loop from the host (A/B, reference arrangement)
+  bool host_solve = false;      // LII_TEST=host_solve: drive the loop from the host (A/B, reference arrangement)
   double* d_partials = nullptr;
   double* d_out91 = nullptr;
   unsigned long long* d_gran = nullptr;  // k_reduce_solve: the 91 sums of a pass on their way to the solver, 2 x 91 tagged words
@@ -113,6 +113,7 @@ struct lii_context {
   int extent_sel = 0, mm_sel = 0;
   bool knn_plan = true;        // LII_KNN_PLAN=0: every k-NN launch is enqueued (IekfCtrl::plan_mask)
   bool test_pred_small = false;
+  bool test_force_rebuild = false;  // LII_TEST=force_rebuild: every in-place map update rebuilds the index first (the branch a map low on room takes)
   bool no_fast_prologue = false;  // LII_TEST=no_fast: a time-sorted scan takes the general path as well (k_time_extent in front of the de-skew)
   bool no_fuse = false;        // LII_TEST=no_fuse: lii_scan_register keeps the de-skew and the voxel filter's insert in separate launches
   bool use_graph = false;      // LII_TEST=graph: the passes of an update are captured once per (cloud bound, plan, map view) and replayed
@@ -400,7 +401,9 @@ void note_list_sizes(lii_handle h, int n_add, int n_nodown) {
   h->pred_nodown = mn + mn / 4 + 1024;
 }
 int map_join(lii_handle h) {
-  if (!h->map_async) return LII_OK;
+  // (an update enqueued for predicted sizes is settled here whichever stream it ran on: when map_apply had to rebuild the index
+  // first, the update went onto the handle's own stream - map_async false - and its list sizes need the same check)
+  if (!h->map_async && !h->lists_predicted) return LII_OK;
   h->map_async = false;
   HIPCHK(h, hipEventSynchronize(h->ev_mapflag));
   if (h->lists_predicted) {
@@ -540,7 +543,7 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
   const size_t spare_blocks = h->map_tight ? 0 : std::min<size_t>(size_t(n_ins), 1024);
   const unsigned int work_need = 9u * (unsigned int)n_list + (unsigned int)n_ins + 64u;
   if (work_need > h->work_cap) return fail(h, LII_ERR_CAPACITY, "Add_Points batch larger than the work list of the in-place update");
-  if ((long long)h->pts_cap_eff - h->n_used < tail_need || size_t(h->n_blocks) + spare_blocks + 1 > h->cells_cap_blocks ||
+  if (h->test_force_rebuild || (long long)h->pts_cap_eff - h->n_used < tail_need || size_t(h->n_blocks) + spare_blocks + 1 > h->cells_cap_blocks ||
       2ull * (size_t(h->n_blocks) + spare_blocks) > size_t(h->blocks_cap)) {
     rc = map_rebuild(h, h->map_tight ? 0 : std::max(4096, h->n_blocks / 2));
     if (rc != LII_OK) return rc;
@@ -1008,7 +1011,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     // captured hipGraph), "pred_small" (lii_map_incremental predicts list sizes that are always too small), "fold_sort"
     // (lii_map_incremental folds its list through the batch sort, as lii_map_add_points does, instead of the hash table), "no_fuse"
     // (lii_scan_register keeps the de-skew and the insert of the hashed voxel filter in separate launches), "no_fast" (a
-    // time-sorted scan takes the general path of lii_scan_register too: k_time_extent in front of the de-skew)
+    // time-sorted scan takes the general path of lii_scan_register too: k_time_extent in front of the de-skew), "force_rebuild"
+    // (every in-place map update takes the branch that rebuilds the index first)
     const std::string t(v);
     h->map_tight = t.find("map_tight") != std::string::npos;
     const size_t q = t.find("plan_force=");
@@ -1020,6 +1024,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     h->fold_sorted = t.find("fold_sort") != std::string::npos;
     h->no_fuse = t.find("no_fuse") != std::string::npos;
     h->no_fast_prologue = t.find("no_fast") != std::string::npos;
+    h->test_force_rebuild = t.find("force_rebuild") != std::string::npos;
   }
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;

@@ -88,3 +88,54 @@ def test_an_update_longer_than_the_plan_is_continued():
         assert a[1] == b[1] and a[2] == b[2]
         assert np.array_equal(a[0], b[0])
         assert np.array_equal(a[3], b[3])
+
+
+def test_every_diagnostic_arrangement_gives_the_same_update():
+    """The LII_TEST arrangements each on their own: "sync_result" (stream synchronisation instead of the polled result
+    word), "no_fuse" (de-skew and voxel-filter insert in separate launches), "no_fast" (a time-sorted scan through the general
+    prologue) must reproduce the default arrangement BIT FOR BIT; "graph" (the passes replayed from a captured hipGraph: the
+    launches are made for the cloud bound rounded up to 4096 points, so the points are dealt to another number of fit workgroups
+    and the 91 sums are associated differently) and "host_solve" - the loop driven from the host with the literal two-inversion
+    algebra of src/laserMapping.cpp:1081-1114 (lii_hostmath.h) - within the bound the device algebra is held to everywhere
+    (1e-6 m / 1e-7 rad), with the same schedule and the same down-sampled cloud."""
+    import bench
+    wl = bench.build_workload("os1_128_cut3", 2)
+    states0, tables = bench.start_states(wl)
+
+    def run(env):
+        import lidar_imu_init_amd as lii
+        old = os.environ.get("LII_TEST")
+        os.environ.pop("LII_TEST", None)
+        if env:
+            os.environ["LII_TEST"] = env
+        try:
+            reg = lii.Registrar(max_scan_points=140_000, max_map_points=1_100_000, filter_size_map=wl["fs_map"])
+        finally:
+            os.environ.pop("LII_TEST", None)
+            if old is not None:
+                os.environ["LII_TEST"] = old
+        out = []
+        try:
+            reg.map_build(wl["map"])
+            for _ in range(2):
+                for j, scan in enumerate(wl["scans"]):
+                    st = states0[j].copy()
+                    rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=wl["fs_surf"], max_iterations=wl["max_it"],
+                                            imu_en=True, scan_dev=reg.device_scan(scan), scan_sorted=True)
+                    out.append((st.pod.copy(), rep["iterations"], rep["searches"], rep["effect_num"], reg.scan_download(1).copy()))
+        finally:
+            reg.close()
+        return out
+
+    ref = run("")
+    for env in ("sync_result", "no_fuse", "no_fast"):
+        for a, b in zip(ref, run(env)):
+            assert a[1:4] == b[1:4], (env, a[1:4], b[1:4])
+            assert np.array_equal(a[0], b[0]), env
+            assert np.array_equal(a[4], b[4]), env
+    for env in ("graph", "host_solve"):
+        for a, b in zip(ref, run(env)):
+            assert a[1:4] == b[1:4], (env, a[1:4], b[1:4])
+            assert np.array_equal(a[4], b[4]), env
+            assert np.abs(a[0][9:12] - b[0][9:12]).max() <= 1e-6, env      # pos_end
+            assert np.abs(a[0][0:9] - b[0][0:9]).max() <= 1e-7, env        # rot_end (element-wise: below the rotation-angle bound)

@@ -330,13 +330,15 @@ def test_long_update_sequence_keeps_the_tree_set(oracle):
     reg.close()
 
 
-@pytest.mark.parametrize("hook", ["", "pred_small"])
+@pytest.mark.parametrize("hook", ["", "pred_small", "pred_small,force_rebuild", "force_rebuild"])
 def test_map_incremental_without_counts_gives_the_same_map(hook):
     """lii_map_incremental with both size pointers NULL enqueues the update for PREDICTED list sizes on a stream of its own and
     returns at once; an update whose lists outgrow the prediction is repeated with the exact sizes before the next search
     (LII_TEST=pred_small: every one does), and folds the add list through a hash table instead of the batch sort (the box an
     Add_Points batch leaves behind does not depend on the batch order).  Same scans, same poses -> the same map, point for point,
-    as the waiting, sorting form."""
+    as the waiting, sorting form.  force_rebuild: every update takes the branch of a map low on room - the index is rebuilt first and
+    the update runs on the handle's own stream; with pred_small on top every one of those updates outgrows its bounds and has to
+    be repeated as well (that combination used to lose the scan's points silently)."""
     import bench
     import lidar_imu_init_amd as lii
     wl = bench.build_workload("os1_128_cut3", 4)
