@@ -388,11 +388,13 @@ def main():
                                                      "rccl_ranks": reg.comm_rccl_ranks(), "avg_iterations": iters_total[0] / args.steps}
             if n_run == 0:
                 dt, value_transport, value_rccl_ranks = d, used, reg.comm_rccl_ranks()
+                last_pose_value = np.array(last.pod[:12]) if last is not None else None
         if first != "auto" or len(others):
             attach(first)  # the rest of the run (parity calls) on the transport `value` was measured with
     else:
         dt = timed_region(args.prime)
         value_transport, value_rccl_ranks = "none", 0
+        last_pose_value = np.array(last.pod[:12]) if last is not None else None
     tm = reg.timings()
     iters_value, searches_value = iters_total[0], search_total[0]
     # The driver's form of this command times 20 steps (~3 ms): a second, longer region of the same steps right behind it gives the
@@ -549,6 +551,10 @@ def main():
         }
         if value_long is not None:
             out["value_long"] = value_long
+        if last_pose_value is not None:  # final pose of the last step of `value`'s region (rot_end row-major, pos_end): a sharded job must land where one rank does
+            out["last_state_pose"] = [float(v) for v in last_pose_value]
+        if world > 1:
+            out["config"]["transport_why"] = reg.comm_describe()
         # bytes(scan) = 32 N + S (96 N_d + 16 M) + I (32 N_d + 728), achieved = bytes(scan) x scans/s
         I_avg, S_avg = iters_value / args.steps, searches_value / args.steps
         n_in = float(n_full) / 1.0

@@ -361,6 +361,9 @@ int lii_comm_unique_id(uint8_t id_out[128]);
 int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id[128]);
 int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id[128], int32_t transport);
 int lii_comm_transport(lii_handle h, int32_t* transport); /* the transport in use; LII_COMM_AUTO = none (single rank) */
+/* Which transport this rank ended up with and why, as text (e.g. "mailbox in registered host memory - the HBM form was not
+ * possible: device 0 cannot access its peer 0000:c1:00.0 (hipDeviceCanAccessPeer)"); LII_DIAG=1 prints it at set-up. */
+int lii_comm_describe(lii_handle h, char* out, int32_t capacity);
 int lii_comm_rccl_ranks(lii_handle h, int32_t* n_ranks);  /* ncclCommCount of the attached RCCL communicator; 0: none attached */
 int lii_comm_set_partition(lii_handle h, int32_t library_partition);
 int lii_comm_destroy(lii_handle h);

@@ -130,6 +130,7 @@ _DECLS = {
     "lii_comm_unique_id": (C.c_int, [C.c_void_p]),
     "lii_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lii_comm_init_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    "lii_comm_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "lii_comm_transport": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lii_comm_rccl_ranks": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lii_comm_set_partition": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -526,6 +527,11 @@ class Registrar:
         t = C.c_int32(0)
         self._check(self.L.lii_comm_transport(self.h, C.byref(t)))
         return {0: "none", 1: "rccl", 2: "mailbox", 3: "mailbox_host"}[t.value]
+
+    def comm_describe(self) -> str:
+        buf = C.create_string_buffer(512)
+        self._check(self.L.lii_comm_describe(self.h, buf, 512))
+        return buf.value.decode()
 
     def comm_rccl_ranks(self) -> int:
         """ncclCommCount of the attached RCCL communicator (0: no RCCL communicator)."""

@@ -193,6 +193,7 @@ struct lii_context {
   unsigned long long* d_mb_seq = nullptr;
   long long mailbox_timeout_ticks = 3000000000ll;  // 30 s (LII_MAILBOX_TIMEOUT_S): ranks may start a scan seconds apart
   int n_ranks = 1, rank = 0;
+  std::string comm_why;           // which transport this rank ended up with and why (lii_comm_describe)
   bool library_partition = true;  // lii_comm_set_partition: the library splits the down-sampled cloud over the ranks (every rank
                                   // hands over the whole scan); false: the caller hands every rank its own points
 
@@ -2050,14 +2051,21 @@ int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t 
       if (transport == LII_COMM_MAILBOX && !h->mailbox.d_peers) {  // asked for by name: no silent change of the transport
         mailbox_close(&h->mailbox);
         h->n_ranks = 1; h->rank = 0;
-        return fail(h, LII_ERR_COMM, "peer-mapped HBM mailbox unavailable (a rank could not export or open an IPC handle)");
+        return fail(h, LII_ERR_COMM, "peer-mapped HBM mailbox unavailable: " + why);
       }
+      h->comm_why = h->mailbox.d_peers ? "mailbox in peer-mapped HBM (HIP IPC; every rank's device reaches every other's)"
+                                       : (transport == LII_COMM_MAILBOX_HOST ? std::string("mailbox in registered host memory (asked for)")
+                                                                             : "mailbox in registered host memory - the HBM form was not possible: " + why);
+      if (h->diag) std::fprintf(stderr, "[libliinit_hip] rank %d of %d: %s\n", rank, n_ranks, h->comm_why.c_str());
       return LII_OK;
     }
     if (transport == LII_COMM_MAILBOX || transport == LII_COMM_MAILBOX_HOST) {
       h->n_ranks = 1; h->rank = 0;
       return fail(h, LII_ERR_COMM, "node-local mailbox unavailable: " + why);
     }
+    h->comm_why = "RCCL - the node-local mailbox was not possible: " + why;
+  } else {
+    h->comm_why = "RCCL (asked for)";
   }
   ncclUniqueId id;
   std::memcpy(&id, id_in, 128);
@@ -2066,6 +2074,13 @@ int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t 
     h->comm = nullptr; h->n_ranks = 1; h->rank = 0;
     return fail(h, LII_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
   }
+  if (h->diag) std::fprintf(stderr, "[libliinit_hip] rank %d of %d: %s\n", rank, n_ranks, h->comm_why.c_str());
+  return LII_OK;
+}
+int lii_comm_describe(lii_handle h, char* out, int32_t capacity) {
+  if (!h || !out || capacity < 1) return LII_ERR_INVALID;
+  const std::string s = (h->comm || h->mailbox.dev_slots || h->mailbox.d_peers) ? h->comm_why : std::string("no communicator");
+  std::snprintf(out, size_t(capacity), "%s", s.c_str());
   return LII_OK;
 }
 int lii_comm_set_partition(lii_handle h, int32_t library_partition) {

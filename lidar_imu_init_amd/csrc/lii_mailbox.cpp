@@ -27,20 +27,24 @@ namespace lii {
 namespace {
 constexpr size_t kHeaderBytes = 8192;
 constexpr size_t kHandlesAt = 1024;  // n_ranks x 64 bytes: the IPC handles of the ranks' slot areas
+constexpr size_t kBusIdsAt = 5120;   // n_ranks x 32 bytes: PCI bus id of every rank's device (peer-access check)
 enum : uint32_t { kPending = 0, kReady = 1, kFailed = 2 };
+enum : uint32_t { kHbmUndecided = 0, kHbmYes = 1, kHbmNo = 2 };
 struct SegmentHeader {
   std::atomic<uint32_t> arrived;  // ranks that mapped + registered the segment
   std::atomic<uint32_t> state;    // kPending -> kReady (all arrived) | kFailed (somebody gave up / could not register)
   uint32_t n_ranks;
   std::atomic<uint32_t> exported, export_failed;  // HBM form: ranks that wrote their handle / that could not
   std::atomic<uint32_t> opened, open_failed;      // ... that opened all the others' / that could not
+  std::atomic<uint32_t> hbm_verdict;              // ONE decision for the job: kHbmYes | kHbmNo, set once by whoever decides first
 };
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
-static_assert(kHandlesAt + 64 * 64 <= kHeaderBytes, "header layout");
-// waits until `counter` reaches n (false: timed out)
-bool wait_count(std::atomic<uint32_t>& counter, uint32_t n, double wait_s) {
+static_assert(kHandlesAt + 64 * 64 <= kBusIdsAt && kBusIdsAt + 64 * 32 <= kHeaderBytes, "header layout");
+// waits until `counter` reaches n (false: timed out, or - give_up != nullptr - somebody has decided against the HBM form meanwhile)
+bool wait_count(std::atomic<uint32_t>& counter, uint32_t n, double wait_s, const std::atomic<uint32_t>* give_up = nullptr) {
   const auto t0 = std::chrono::steady_clock::now();
   while (counter.load() < n) {
+    if (give_up && give_up->load() == 2u) return false;
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_s) return false;
     std::this_thread::sleep_for(std::chrono::microseconds(100));
   }
@@ -73,7 +77,8 @@ void mailbox_close(MailboxHost* m) {
 }
 
 // Returns 0 when every rank of the job met in the segment (m is filled), 1 when they did not (different nodes, a rank that
-// could not register, timeout): the caller then uses RCCL.  `why` explains a non-zero return.
+// could not register, timeout): the caller then uses RCCL.  `why` explains a non-zero return - and, with a zero return, why the
+// HBM form was asked for but the host-memory form was taken (empty otherwise).
 int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bool want_hbm, MailboxHost* m, std::string* why) {
   *m = MailboxHost{};
   if (n_ranks > kMailboxMaxRanks) { *why = "more ranks than mailbox lanes"; return 1; }
@@ -128,6 +133,7 @@ int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bo
     return 1;
   }
   m->dev_slots = reinterpret_cast<double*>(reinterpret_cast<char*>(dev) + kHeaderBytes);
+  if (why) why->clear();
   if (!want_hbm) return 0;
   // ---- the HBM form on top: export the own slot area, open the others'.  Every step is collective: one rank that cannot
   // makes all of them stay with the host-memory form (the verdicts travel through the segment's counters).
@@ -147,32 +153,85 @@ int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bo
     }
     if (!mine_ok) { (void)hipGetLastError(); if (p) (void)hipFree(p); hdr->export_failed.fetch_add(1); }
   }
+  {  // where this rank's device sits: the peers check (and enable) access to it before they open its handle
+    int dev_now = 0;
+    char* bus = reinterpret_cast<char*>(m->map) + kBusIdsAt + 32 * (size_t)rank;
+    if (hipGetDevice(&dev_now) != hipSuccess || hipDeviceGetPCIBusId(bus, 32, dev_now) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
+  }
   std::atomic_thread_fence(std::memory_order_release);
   hdr->exported.fetch_add(1);
-  bool hbm = wait_count(hdr->exported, (uint32_t)n_ranks, wait_s) && hdr->export_failed.load() == 0;
+  // The verdict HBM / host memory is ONE word of the segment, written once: a rank that gives up - a timeout, a
+  // handle it cannot export or open - tries to set it to "no", a rank that sees every rank through tries to set it to "yes", and
+  // everybody takes what the word says afterwards.  (Counters alone let a rank that timed out in a wait leave for the host form
+  // while the others, seeing the full count a moment later, stayed with the HBM form.)
+  auto decide = [&](uint32_t want) {
+    uint32_t expect = kHbmUndecided;
+    hdr->hbm_verdict.compare_exchange_strong(expect, want);
+    return hdr->hbm_verdict.load() == kHbmYes;
+  };
+  std::string hbm_why;
+  bool hbm = wait_count(hdr->exported, (uint32_t)n_ranks, wait_s, &hdr->hbm_verdict) && hdr->export_failed.load() == 0;
+  if (!hbm) { hbm_why = hdr->export_failed.load() ? "a rank could not allocate / export its slot area" : "timed out waiting for the ranks' IPC handles"; (void)decide(kHbmNo); }
   if (hbm) {
     std::atomic_thread_fence(std::memory_order_acquire);
     m->n_peers = n_ranks;
     bool opened_all = true;
+    int my_dev = 0;
+    (void)hipGetDevice(&my_dev);
     for (int r = 0; r < n_ranks && opened_all; r++) {
       if (r == rank) { m->peer_ptr[r] = m->own; continue; }
+      // peer access from this rank's device to the device that holds rank r's slots (the same device in a one-device rehearsal)
+      const char* bus = reinterpret_cast<const char*>(m->map) + kBusIdsAt + 32 * (size_t)r;
+      int peer_dev = -1;
+      if (bus[0] && hipDeviceGetByPCIBusId(&peer_dev, bus) == hipSuccess && peer_dev != my_dev) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, my_dev, peer_dev) != hipSuccess || !can) {
+          (void)hipGetLastError();
+          hbm_why = std::string("device ") + std::to_string(my_dev) + " cannot access its peer " + bus + " (hipDeviceCanAccessPeer)";
+          opened_all = false;
+          break;
+        }
+        const hipError_t pe = hipDeviceEnablePeerAccess(peer_dev, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+          hbm_why = std::string("hipDeviceEnablePeerAccess(") + bus + "): " + hipGetErrorString(pe);
+          (void)hipGetLastError();
+          opened_all = false;
+          break;
+        }
+        (void)hipGetLastError();
+      } else {
+        (void)hipGetLastError();  // (a bus id this process cannot resolve - another visibility mask -: the open below decides)
+      }
       void* q = nullptr;
       hipIpcMemHandle_t hnd;
       std::memcpy(&hnd, &handles[r], sizeof(hnd));
-      if (hipIpcOpenMemHandle(&q, hnd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); opened_all = false; break; }
+      const hipError_t oe = hipIpcOpenMemHandle(&q, hnd, hipIpcMemLazyEnablePeerAccess);
+      if (oe != hipSuccess) {
+        hbm_why = std::string("hipIpcOpenMemHandle of rank ") + std::to_string(r) + "'s slots: " + hipGetErrorString(oe);
+        (void)hipGetLastError();
+        opened_all = false;
+        break;
+      }
       m->peer_ptr[r] = static_cast<double*>(q);
     }
     if (opened_all) {
       if (hipMalloc(reinterpret_cast<void**>(&m->d_peers), sizeof(double*) * (size_t)n_ranks) != hipSuccess ||
           hipMemcpy(m->d_peers, m->peer_ptr, sizeof(double*) * (size_t)n_ranks, hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError();
+        hbm_why = "no device memory for the table of peer pointers";
         opened_all = false;
       }
     }
-    if (!opened_all) hdr->open_failed.fetch_add(1);
+    if (!opened_all) { hdr->open_failed.fetch_add(1); (void)decide(kHbmNo); }
     hdr->opened.fetch_add(1);
-    hbm = wait_count(hdr->opened, (uint32_t)n_ranks, wait_s) && hdr->open_failed.load() == 0;
+    const bool all_through = wait_count(hdr->opened, (uint32_t)n_ranks, wait_s, &hdr->hbm_verdict) && hdr->open_failed.load() == 0;
+    if (!all_through && hbm_why.empty()) hbm_why = hdr->open_failed.load() ? "another rank could not open the IPC handles" : "timed out waiting for the ranks to open the IPC handles";
+    hbm = decide(all_through ? kHbmYes : kHbmNo);
+    if (!hbm && hbm_why.empty()) hbm_why = "another rank decided for the host-memory form";
+  } else {
+    hbm = decide(kHbmNo);  // (kHbmNo is already there)
   }
+  if (why) *why = hbm ? "" : hbm_why;
   if (!hbm) {  // stay with the host-memory form (all ranks take this branch together)
     for (int r = 0; r < m->n_peers; r++)
       if (m->peer_ptr[r] && m->peer_ptr[r] != m->own) (void)hipIpcCloseMemHandle(m->peer_ptr[r]);

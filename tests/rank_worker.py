@@ -59,7 +59,7 @@ def main():
             nd, _ = reg.downsample(leaf)
             n_down.append(nd)
             s91 = reg.iekf_iterate(st, True, True)  # at the common start state
-            rep = reg.scan_register(st, prop, imu_poses=table, leaf=leaf, max_iterations=5, imu_en=True, scan_dev=reg.device_scan(scan))
+            rep = reg.scan_register(st, prop, imu_poses=table, leaf=leaf, max_iterations=5, imu_en=True, scan_dev=reg.device_scan(scan), scan_sorted=True)
             reg.map_incremental(st)
             map_sizes.append(reg.map_size())
         states.append(st.pod.copy())

@@ -1,0 +1,71 @@
+"""bench.py as the driver launches it for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`.
+On a single-GPU box the ranks share device 0 (LII_BENCH_ONE_DEVICE=1: rendezvous over gloo, the node-local mailbox transports -
+RCCL refuses two ranks on one device); with two or more visible devices the real arrangement runs as well (one device per rank,
+rendezvous over RCCL, every transport timed).  Checked: the JSON line the driver parses is there and complete, every transport that
+can run here was timed, and the sharded job's final state is the single-rank job's within the suite's pose tolerance."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--steps", "20", "--warmup", "5", "--prime", "10", "--long-steps", "0", "--no-cpu-baseline", "--no-pipeline", "--no-calibration",
+          "--workload", "vlp16"]
+
+
+def _line(out):
+    rows = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(rows) == 1, out[-3000:]  # rank 0 prints ONE line
+    return json.loads(rows[0])
+
+
+def _single():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + COMMON, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return _line(p.stdout)
+
+
+def _sharded(n, port, one_device):
+    env = dict(os.environ)
+    if one_device:
+        env["LII_BENCH_ONE_DEVICE"] = "1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + COMMON,
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    return _line(p.stdout)
+
+
+def _check(d, one, n, expect_transports):
+    assert d["n_gpus"] == n and d["steps"] == 20 and d["value"] > 0 and d["unit"] == "scans/s"
+    assert abs(d["ms_per_step"] * d["value"] - 1e3) < 1e-6 * 1e3
+    for t in expect_transports:
+        assert t in d["transports"] and d["transports"][t].get("value", 0) > 0, d["transports"]
+    assert d["config"]["transport"] == expect_transports[0]
+    assert d["config"]["transport_why"]
+    assert np.isfinite(d["roofline"]["scan"]["frac"]) and d["roofline"]["scan"]["frac"] > 0
+    # the same stream, the same steps: the sharded job ends where the single-rank job ends (91 sums re-associated)
+    assert np.max(np.abs(np.array(d["last_state_pose"]) - np.array(one["last_state_pose"]))) <= 1e-6
+    assert d["config"]["avg_iterations"] == one["config"]["avg_iterations"]
+
+
+def test_bench_two_ranks_on_one_device():
+    one = _single()
+    d = _sharded(2, 29611, one_device=True)
+    _check(d, one, 2, ["mailbox", "mailbox_host"])
+    assert d["config"]["rccl_ranks"] == 0
+
+
+def test_bench_two_ranks_on_two_devices():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device")
+    one = _single()
+    d = _sharded(2, 29612, one_device=False)
+    _check(d, one, 2, ["mailbox", "rccl", "mailbox_host"])
+    assert d["transports"]["rccl"]["rccl_ranks"] == 2

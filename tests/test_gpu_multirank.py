@@ -32,7 +32,15 @@ def _rows(a):
     return np.unique(np.ascontiguousarray(a, np.float32), axis=0)
 
 
-def _run_ranks(tmp_path, world, transport="auto", timeout=300, env=None):
+def _n_devices():
+    import ctypes
+    import lidar_imu_init_amd as lii
+    n = ctypes.c_int(0)
+    assert lii.load_library().lii_device_count(ctypes.byref(n)) == 0
+    return n.value
+
+
+def _run_ranks(tmp_path, world, transport="auto", timeout=300, env=None, devices=None):
     import lidar_imu_init_amd as lii
     r = lii.Registrar(max_scan_points=1024, max_map_points=1024)
     uid = r.comm_unique_id().hex()
@@ -43,8 +51,8 @@ def _run_ranks(tmp_path, world, transport="auto", timeout=300, env=None):
         out = str(tmp_path / f"job{_run_ranks.calls}_w{world}_r{rank}.npz")
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "rank_worker.py"), str(rank), str(world), uid,
-                                       transport, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                                      env=dict(os.environ, **(env or {}))))
+                                       transport, out] + ([str(devices[rank])] if devices else []),
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **(env or {}))))
     logs = []
     for p in procs:
         try:
@@ -82,6 +90,35 @@ def test_two_ranks_meet_in_the_mailbox(tmp_path, transport):
     assert np.array_equal(one["n_down"], two[0]["n_down"]) and np.array_equal(two[0]["n_down"], two[1]["n_down"])
     assert np.array_equal(two[0]["map_sizes"], two[1]["map_sizes"]) and np.array_equal(_rows(two[0]["map_final"]), _rows(two[1]["map_final"]))
     assert np.all(np.abs(one["map_sizes"] - two[0]["map_sizes"]) <= 3)  # (a pose that differs by 1e-12 can flip a keep-closest tie)
+
+
+@pytest.mark.parametrize("transport", ["mailbox", "rccl", "mailbox_host"])
+def test_two_ranks_on_two_devices(tmp_path, transport):
+    """The same job with one DEVICE per rank - the arrangement the transports are made for: the HBM mailbox's remote stores cross
+    xGMI (peer access checked and enabled at set-up, lii_mailbox.cpp), RCCL runs a real two-rank all-reduce.  Needs two visible
+    devices: skipped on the single-GPU development boxes, enabled by itself on a multi-GPU node."""
+    if _n_devices() < 2:
+        pytest.skip("one visible device: the cross-device forms of the transports cannot run here")
+    one = _run_ranks(tmp_path, 1)[0]
+    two = _run_ranks(tmp_path, 2, transport=transport, devices=[0, 1])
+    assert str(two[0]["transport"]) == transport and str(two[1]["transport"]) == transport
+    for key in ("states", "reports", "sums"):
+        assert np.array_equal(two[0][key], two[1][key]), key
+    assert np.array_equal(one["reports"][:, [0, 1, 3]], two[0]["reports"][:, [0, 1, 3]])
+    ref, got = one["sums"], two[0]["sums"]
+    assert np.max(np.abs(ref[0] - got[0])) <= 1e-11 * np.max(np.abs(ref[0]))
+    assert np.max(np.abs(one["states"][:, :12] - two[0]["states"][:, :12])) <= 1e-6
+    assert np.array_equal(two[0]["map_sizes"], two[1]["map_sizes"]) and np.array_equal(_rows(two[0]["map_final"]), _rows(two[1]["map_final"]))
+
+
+def test_four_ranks_on_four_devices(tmp_path):
+    if _n_devices() < 4:
+        pytest.skip("fewer than four visible devices")
+    four = _run_ranks(tmp_path, 4, devices=[0, 1, 2, 3])
+    assert all(str(t["transport"]) == "mailbox" for t in four)
+    for r in (1, 2, 3):
+        for key in ("states", "reports", "sums", "map_sizes"):
+            assert np.array_equal(four[0][key], four[r][key]), key
 
 
 def test_three_ranks(tmp_path):
