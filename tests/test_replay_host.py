@@ -158,59 +158,35 @@ def _status_type():
     return ReplayStatus
 
 
-@pytest.mark.gpu
-def test_replay_host_runs_lo_li_init_lio_like_the_python_harness(tmp_path):
-    import lidar_imu_init_amd as lii
-    from lidar_imu_init_amd import calib_state_array
-    from lidar_imu_init_amd.api import data_sufficiency, lii_pc2_fields
-    from harness import synth, wire, result_file
-    from harness.lo_harness import cv_propagate
-    from harness.lio_harness import LioOdometry
-    d = _drv()
-    (tmp_path / "config").mkdir()
-    (tmp_path / "launch").mkdir()
-    (tmp_path / "config" / "replay_test.yaml").write_text(YAML)
-    (tmp_path / "launch" / "replay_test.launch").write_text(LAUNCH)
-    result_path = str(tmp_path / "Initialization_result.txt")
-
-    # ---- the stream: 10 Hz Ouster-layout messages of ~16 k points, 200 Hz IMU with a known extrinsic / offset / biases
-    hall = synth.Hall(size=(24.0, 18.0, 6.0), n_boxes=8, seed=7)
-    traj = synth.Trajectory()
-    msg_period, n_msgs = 0.1, 230
-    R_LI = synth.rot_zyx(np.deg2rad(2.0), np.deg2rad(-1.0), np.deg2rad(-45.0))
-    T_LI = np.array([0.05, -0.03, 0.10])
-    b_g, b_a, t_off = np.array([-0.001, 0.0015, 0.0005]), np.array([0.004, 0.005, -0.006]), 0.02
-    t_imu, gyro, accel = synth.simulate_imu(traj, -0.5, n_msgs * msg_period + 0.5, 200.0, R_LI, T_LI, b_g, b_a, t_off)
-    f = wire.pc2_fields(wire.OUSTER)
-    msgs = []
-    for k in range(n_msgs):
-        stamp = k * msg_period
-        scan = synth.make_distorted_scan(hall, "mid16k", traj, stamp, msg_period, noise=0.01, seed=3000 + k, blind=0.0)
-        raw = wire.pack_pcl2(wire.OUSTER, scan[:, :3], np.zeros(len(scan), np.int32), scan[:, 3].astype(np.float64), stamp)
-        msgs.append((stamp, np.frombuffer(raw, np.uint8).copy(), len(scan)))
-
-    # ---- the C++ host
-    cfg = ReplayConfig(C.sizeof(ReplayConfig), 0, 40_000, 600_000, str(tmp_path / "launch" / "replay_test.launch").encode(), None,
-                       result_path.encode(), 0, 0)
-    rp = C.c_void_p()
+def _bind(d):
     d.lii_replay_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
-    assert d.lii_replay_create(C.byref(cfg), C.byref(rp)) == 0
     d.lii_replay_imu.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     d.lii_replay_pcl2.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int32, C.c_void_p]
+    d.lii_replay_livox.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int32, C.c_void_p]
     d.lii_replay_spin.argtypes = [C.c_void_p]
     d.lii_replay_last_error.restype = C.c_char_p
     d.lii_replay_last_error.argtypes = [C.c_void_p]
     d.lii_replay_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     d.lii_replay_get_status.argtypes = [C.c_void_p, C.c_void_p]
     d.lii_replay_destroy.argtypes = [C.c_void_p]
-    fields = lii_pc2_fields(*f)
+
+
+def _cxx_host(d, launch, result_path, msgs, imu, fields, livox, msg_period, max_scan, max_map):
+    """Plays the stream into harness/li_init_replay.cpp the way a bag plays it: the IMU samples up to the end of a message's sweep, then
+    the message, then one turn of the loop.  Returns (log rows, status)."""
+    _bind(d)
+    t_imu, gyro, accel = imu
+    cfg = ReplayConfig(C.sizeof(ReplayConfig), 0, max_scan, max_map, launch.encode(), None, result_path.encode() if result_path else None, 0, 0)
+    rp = C.c_void_p()
+    assert d.lii_replay_create(C.byref(cfg), C.byref(rp)) == 0
     k_imu = 0
-    for stamp, raw, n in msgs:  # messages in time order, as a bag plays them: the IMU samples up to the message's stamp, then the message
+    for stamp, raw, n in msgs:
         while k_imu < len(t_imu) and t_imu[k_imu] <= stamp + msg_period:
             g, a = np.ascontiguousarray(gyro[k_imu]), np.ascontiguousarray(accel[k_imu])
             assert d.lii_replay_imu(rp, float(t_imu[k_imu]), _dp(g), _dp(a)) == 0
             k_imu += 1
-        assert d.lii_replay_pcl2(rp, stamp, raw.ctypes.data_as(C.c_void_p), n, C.byref(fields)) == 0
+        push = d.lii_replay_livox if livox else d.lii_replay_pcl2
+        assert push(rp, stamp, raw.ctypes.data_as(C.c_void_p), n, C.byref(fields)) == 0
         rc = d.lii_replay_spin(rp)
         assert rc >= 0, d.lii_replay_last_error(rp)
     n_rows = C.c_int32(0)
@@ -222,99 +198,99 @@ def test_replay_host_runs_lo_li_init_lio_like_the_python_harness(tmp_path):
     status.struct_size = C.sizeof(ST)
     assert d.lii_replay_get_status(rp, C.byref(status)) == 0
     d.lii_replay_destroy(rp)
-    assert status.data_accum_start and status.data_accum_finished and status.imu_en and status.refine_done
-    assert status.cut_frame_num == 2
-    n_lo = int((log[:, 1] == 0).sum())
-    n_lio = int((log[:, 1] == 1).sum())
-    assert n_lo > 150 and n_lio > 30, (n_lo, n_lio)
+    return log, status
 
-    # ---- the same sequence of library calls from Python, numpy propagation (harness/lo_harness.py, lio_harness.py)
-    reg = lii.Registrar(max_scan_points=40_000, max_map_points=600_000, filter_size_map=0.15)
+
+def _python_host(msgs, imu, ingest, msg_period, p):
+    """The same sequence of library calls from Python with the numpy propagation of harness/lo_harness.py / lio_harness.py.
+    p: the parameters the launch file gives the C++ host.  Returns (rows, LI-Init result or None)."""
+    import lidar_imu_init_amd as lii
+    from lidar_imu_init_amd import calib_state_array
+    from lidar_imu_init_amd.api import data_sufficiency
+    from harness.lo_harness import cv_propagate
+    from harness.lio_harness import LioOdometry
+    t_imu, gyro, accel = imu
+    reg = lii.Registrar(max_scan_points=p["max_scan"], max_map_points=p["max_map"], filter_size_map=p["fs_map"])
     st = lii.State()
     rows = []
-    imu_buf, imu_all, lidar_states, omg = [], [], [], []
-    k_imu, scan_count = 0, 0
-    time_lag, imu_en, accum_start, accum_done, move_start = 0.0, False, False, False, 0.0
-    first_frame, t_last_beg, map_built, cut = True, 0.0, False, 2
-    lio, hand_over_frame, init_res = None, False, None
-    last_ts_imu = -1.0
-    queue = []  # (t_beg, t_end, frame index of the message being worked on) - the device holds one message's frames
+    S = dict(imu_buf=[], imu_all=[], lidar_states=[], omg=[], time_lag=0.0, imu_en=False, accum_start=False, accum_done=False, move_start=0.0,
+             first_frame=True, t_last_beg=0.0, map_built=False, cut=p["cut"], lio=None, hand_over_frame=False, init_res=None, last_ts_imu=-1.0)
 
     def process(frame, t_beg, t_end, meas):
-        nonlocal first_frame, t_last_beg, map_built, accum_start, accum_done, move_start, imu_en, time_lag, lio, hand_over_frame, init_res, cut, imu_buf, last_ts_imu
-        select = True
-        kw = {}
-        if imu_en:
+        select, kw = True, {}
+        if S["imu_en"]:
             if not meas:
                 return
-            if hand_over_frame:  # the first LIO frame only re-arms the IMU processor; the previous scan is registered once more
-                lio.last_imu, lio.last_lidar_end_time = meas[-1], 0.0
-                hand_over_frame, select = False, False
+            if S["hand_over_frame"]:  # the first LIO frame only re-arms the IMU processor; the previous scan is registered once more
+                S["lio"].last_imu, S["lio"].last_lidar_end_time = meas[-1], 0.0
+                S["hand_over_frame"], select = False, False
             else:
-                table = lio.propagate(meas, t_beg, t_end)
-                kw = dict(imu_poses=table)
+                kw = dict(imu_poses=S["lio"].propagate(meas, t_beg, t_end))
         else:
-            dt = 0.1 if first_frame else t_beg - t_last_beg
-            first_frame, t_last_beg = False, t_beg
-            cv_propagate(st, dt, 50.0, 2.0)
+            dt = 0.1 if S["first_frame"] else t_beg - S["t_last_beg"]
+            S["first_frame"], S["t_last_beg"] = False, t_beg
+            cv_propagate(st, dt, p["gyr_cov"], p["acc_cov"])
             kw = dict(cv=True)
         prop = st.copy()
         if select:
             reg.frame_select(frame)
-        if not map_built:
+        if not S["map_built"]:
             reg.undistort_cv(st.bias_g, st.vel_end, st.rot_end)
-            reg.downsample(0.1, want_count=False)
+            reg.downsample(p["leaf"], want_count=False)
             body = reg.scan_download(1)[:, :3].astype(np.float64)
             reg.map_build((body @ st.rot_end.T + st.pos_end).astype(np.float32))
-            map_built = True
+            S["map_built"] = True
             return
-        rep = reg.scan_register(st, prop, leaf=0.1, max_iterations=5, imu_en=imu_en, scan_sorted=True, **kw)
+        rep = reg.scan_register(st, prop, leaf=p["leaf"], max_iterations=5, imu_en=S["imu_en"], scan_sorted=True, **kw)
         reg.map_incremental(st, want_counts=False)
-        if not imu_en and not accum_start and np.linalg.norm(st.pos_end) > 0.05:
-            accum_start, move_start = True, t_end
-        rows.append(np.r_[t_end, float(imu_en), rep["iterations"], rep["effect_num"], st.pod[:36]])
-        if not imu_en and not accum_done and accum_start:
-            lidar_states.append((st.rot_end.copy(), st.bias_g.copy(), st.vel_end.copy(), t_end))
-            omg.append(st.bias_g.copy())
-            if (len(rows) % 10) * cut == 0 and data_sufficiency(np.array(omg), 80.0)[2]:  # an appraisal every second (LI_init.cpp:513)
-                accum_done = True
-                ia = calib_state_array(len(imu_all))
-                for i, (t, g, a) in enumerate(imu_all):
-                    ia[i, 9:12], ia[i, 18:21], ia[i, 21] = g, a / 9.81 * 9.81, t
-                la = calib_state_array(len(lidar_states))
-                for i, (R, w, v, t) in enumerate(lidar_states):
+        if not S["imu_en"] and not S["accum_start"] and np.linalg.norm(st.pos_end) > 0.05:
+            S["accum_start"], S["move_start"] = True, t_end
+        rows.append(np.r_[t_end, float(S["imu_en"]), rep["iterations"], rep["effect_num"], st.pod[:36]])
+        if not S["imu_en"] and not S["accum_done"] and S["accum_start"]:
+            S["lidar_states"].append((st.rot_end.copy(), st.bias_g.copy(), st.vel_end.copy(), t_end))
+            S["omg"].append(st.bias_g.copy())
+            # an appraisal every second (include/LI_init/LI_init.cpp:513)
+            if (len(rows) % p["orig_freq"]) * S["cut"] == 0 and data_sufficiency(np.array(S["omg"]), p["accum_len"])[2]:
+                S["accum_done"] = True
+                ia = calib_state_array(len(S["imu_all"]))
+                for i, (t, g, a) in enumerate(S["imu_all"]):
+                    ia[i, 9:12], ia[i, 18:21], ia[i, 21] = g, a / p["mean_acc_norm"] * 9.81, t
+                la = calib_state_array(len(S["lidar_states"]))
+                for i, (R, w, v, t) in enumerate(S["lidar_states"]):
                     la[i, 0:9], la[i, 9:12], la[i, 12:15], la[i, 21] = R.reshape(-1), w, v, t
                 oi, ol = calib_state_array(len(la)), calib_state_array(len(la))
                 n = C.c_int32(0)
                 L = lii.load_library()
-                assert L.lii_li_init_interpolate(ia.ctypes.data_as(C.c_void_p), len(ia), la.ctypes.data_as(C.c_void_p), len(la), C.c_double(move_start),
+                assert L.lii_li_init_interpolate(ia.ctypes.data_as(C.c_void_p), len(ia), la.ctypes.data_as(C.c_void_p), len(la), C.c_double(S["move_start"]),
                                                  oi.ctypes.data_as(C.c_void_p), ol.ctypes.data_as(C.c_void_p), C.byref(n)) == 0
-                res, lag1, total = reg.li_init_run(oi[:n.value], ol[:n.value], 10, cut)
-                init_res = (res, lag1, total)
-                imu_en = True
+                res, lag1, total = reg.li_init_run(oi[:n.value], ol[:n.value], p["orig_freq"], S["cut"])
+                S["init_res"] = (res, lag1, total)
+                S["imu_en"] = True
                 Rli, Tli = np.array(res.R_LI[:]).reshape(3, 3), np.array(res.T_LI[:])
                 st.offset_R_L_I[:], st.offset_T_L_I[:] = Rli, Tli
                 st.pos_end[:] = -(st.rot_end @ (Rli.T @ Tli)) + st.pos_end
                 st.rot_end[:] = st.rot_end @ Rli.T
                 st.gravity[:], st.bias_g[:], st.bias_a[:] = res.grav_L0[:], res.gyro_bias[:], res.acc_bias[:]
-                cut = 2
-                time_lag = total
-                imu_buf = [(t - time_lag, g, a) for (t, g, a) in imu_buf]
-                if imu_buf:
-                    last_ts_imu = imu_buf[-1][0]
-                lio = LioOdometry(reg, st, filter_size_surf=0.1, max_iteration=5, cov_gyr=0.1, cov_acc=0.1, cov_bias_gyr=1e-4, cov_bias_acc=1e-4,
-                                  cov_R_LI=5e-5, cov_T_LI=1e-4, imu_mean_acc_norm=9.81)
-                lio.first = False
-                hand_over_frame = True
+                if not p["avia"]:
+                    S["cut"] = 2
+                S["time_lag"] = total
+                S["imu_buf"] = [(t - total, g, a) for (t, g, a) in S["imu_buf"]]
+                if S["imu_buf"]:
+                    S["last_ts_imu"] = S["imu_buf"][-1][0]
+                S["lio"] = LioOdometry(reg, st, filter_size_surf=p["leaf"], max_iteration=5, cov_gyr=0.1, cov_acc=0.1, cov_bias_gyr=1e-4, cov_bias_acc=1e-4,
+                                       cov_R_LI=p["cov_R_LI"], cov_T_LI=p["cov_T_LI"], imu_mean_acc_norm=p["mean_acc_norm"])
+                S["lio"].first = False
+                S["hand_over_frame"] = True
 
+    k_imu, scan_count, queue = 0, 0, []
     frames, frame_next = [], 0  # the sub-frames of the message at the head of the queue stay on the device until they are used up
     for stamp, raw, n in msgs:
         while k_imu < len(t_imu) and t_imu[k_imu] <= stamp + msg_period:
-            t = float(t_imu[k_imu]) - time_lag
-            imu_buf.append((t, gyro[k_imu].copy(), accel[k_imu].copy()))
-            last_ts_imu = t
-            if not imu_en and not accum_done:
-                imu_all.append((t, gyro[k_imu].copy(), accel[k_imu].copy()))
+            t = float(t_imu[k_imu]) - S["time_lag"]
+            S["imu_buf"].append((t, gyro[k_imu].copy(), accel[k_imu].copy()))
+            S["last_ts_imu"] = t
+            if not S["imu_en"] and not S["accum_done"]:
+                S["imu_all"].append((t, gyro[k_imu].copy(), accel[k_imu].copy()))
             k_imu += 1
         scan_count += 1
         queue.append((stamp, raw, n, scan_count))
@@ -323,34 +299,71 @@ def test_replay_host_runs_lo_li_init_lio_like_the_python_harness(tmp_path):
                 if not queue:
                     break
                 s_, raw_, n_, sc_ = queue.pop(0)
-                fr = reg.ingest_pcl2(raw_, n_, f, wire.OUSTER, 32, 1, 0.5, s_, cut, scan_count=sc_)
+                fr = ingest(reg, raw_, n_, s_, S["cut"], sc_)
                 frames = [(t_beg, t_beg + reg.frame_tail_ms[j] / 1000.0) for j, (t_beg, off, cnt) in enumerate(fr)]
                 frame_next = 0
                 continue
             t_beg, t_end = frames[frame_next]
-            if not imu_buf or last_ts_imu < t_end:
+            if not S["imu_buf"] or S["last_ts_imu"] < t_end:
                 break
             meas = []
-            while imu_buf and imu_buf[0][0] <= t_end:   # (== sync_packages' loop for strictly increasing stamps)
-                meas.append(imu_buf.pop(0))
+            while S["imu_buf"] and S["imu_buf"][0][0] <= t_end:   # (== sync_packages' loop for strictly increasing stamps)
+                meas.append(S["imu_buf"].pop(0))
             process(frame_next, t_beg, t_end, meas)
             frame_next += 1
     reg.close()
-    rows = np.array(rows)
+    return np.array(rows), S["init_res"]
 
-    # ---- the two hosts agree
+
+def _compare_hosts(rows, log, pos_tol=5e-3, rot_tol=2e-3):
+    """The two hosts make the same library calls with the same arguments up to the rounding of the host-side propagation (numpy's
+    BLAS products against plain loops): the first scans agree to 1e-9.  Later a 1e-16 difference of a propagated state flips a
+    point across the plane / residual threshold of some pass, and the constant-velocity model - whose velocity states are only held
+    by consecutive poses - amplifies that from scan to scan; what remains comparable is the odometry at the level of the method."""
     assert len(rows) == len(log)
-    assert np.array_equal(rows[:, 1], log[:, 1])                       # the switch to LIO happens at the same scan
+    assert np.array_equal(rows[:, 1], log[:, 1])                       # the switch to LIO (if any) happens at the same scan
     assert np.allclose(rows[:, 0], log[:, 0], rtol=0, atol=1e-9)       # scan end times
-    # The two hosts make the same library calls with the same arguments up to the rounding of the host-side propagation (numpy's
-    # BLAS products against plain loops): the first scans agree to 1e-9.  Later a 1e-16 difference of a propagated state flips a
-    # point across the plane / residual threshold of some pass, and the constant-velocity model - whose velocity states are only
-    # held by consecutive poses - amplifies that from scan to scan; what remains comparable is the odometry at the level of the
-    # method and the calibration both hosts arrive at.
     dd = np.abs(rows[:, 4:] - log[:, 4:])
     assert dd[:10].max() <= 1e-9, dd.max(axis=1)[:12]
-    print(f"hosts: pose difference over the run: rot {dd[:, 0:9].max():.2e}, pos {dd[:, 9:12].max():.2e} m; LIO phase rot {dd[n_lo:, 0:9].max():.2e} pos {dd[n_lo:, 9:12].max():.2e}")
-    assert dd[:, 9:12].max() < 5e-3 and dd[:, 0:9].max() < 2e-3  # (measured 5e-4 m / 2.4e-4)
+    print(f"hosts: pose difference over the run: rot {dd[:, 0:9].max():.2e}, pos {dd[:, 9:12].max():.2e} m")
+    assert dd[:, 9:12].max() < pos_tol and dd[:, 0:9].max() < rot_tol  # (measured 5e-4 m / 2.4e-4 on the 16 k-point stream)
+
+
+@pytest.mark.gpu
+def test_replay_host_runs_lo_li_init_lio_like_the_python_harness(tmp_path):
+    from lidar_imu_init_amd.api import lii_pc2_fields
+    from harness import synth, wire, result_file
+    d = _drv()
+    (tmp_path / "config").mkdir()
+    (tmp_path / "launch").mkdir()
+    (tmp_path / "config" / "replay_test.yaml").write_text(YAML)
+    (tmp_path / "launch" / "replay_test.launch").write_text(LAUNCH)
+    result_path = str(tmp_path / "Initialization_result.txt")
+    # ---- the stream: 10 Hz Ouster-layout messages of ~16 k points, 200 Hz IMU with a known extrinsic / offset / biases
+    hall = synth.Hall(size=(24.0, 18.0, 6.0), n_boxes=8, seed=7)
+    traj = synth.Trajectory()
+    msg_period, n_msgs = 0.1, 230
+    R_LI = synth.rot_zyx(np.deg2rad(2.0), np.deg2rad(-1.0), np.deg2rad(-45.0))
+    T_LI = np.array([0.05, -0.03, 0.10])
+    b_g, b_a, t_off = np.array([-0.001, 0.0015, 0.0005]), np.array([0.004, 0.005, -0.006]), 0.02
+    imu = synth.simulate_imu(traj, -0.5, n_msgs * msg_period + 0.5, 200.0, R_LI, T_LI, b_g, b_a, t_off)
+    f = wire.pc2_fields(wire.OUSTER)
+    msgs = []
+    for k in range(n_msgs):
+        stamp = k * msg_period
+        scan = synth.make_distorted_scan(hall, "mid16k", traj, stamp, msg_period, noise=0.01, seed=3000 + k, blind=0.0)
+        raw = wire.pack_pcl2(wire.OUSTER, scan[:, :3], np.zeros(len(scan), np.int32), scan[:, 3].astype(np.float64), stamp)
+        msgs.append((stamp, np.frombuffer(raw, np.uint8).copy(), len(scan)))
+    log, status = _cxx_host(d, str(tmp_path / "launch" / "replay_test.launch"), result_path, msgs, imu, lii_pc2_fields(*f), False, msg_period, 40_000, 600_000)
+    assert status.data_accum_start and status.data_accum_finished and status.imu_en and status.refine_done
+    assert status.cut_frame_num == 2
+    n_lo, n_lio = int((log[:, 1] == 0).sum()), int((log[:, 1] == 1).sum())
+    assert n_lo > 150 and n_lio > 30, (n_lo, n_lio)
+    p = dict(max_scan=40_000, max_map=600_000, fs_map=0.15, leaf=0.1, gyr_cov=50.0, acc_cov=2.0, accum_len=80.0, orig_freq=10, cut=2, mean_acc_norm=9.81,
+             cov_R_LI=5e-5, cov_T_LI=1e-4, avia=False)
+    rows, init_res = _python_host(msgs, imu, lambda reg, raw, n, s, cut, sc: reg.ingest_pcl2(raw, n, f, wire.OUSTER, 32, 1, 0.5, s, cut, scan_count=sc),
+                                  msg_period, p)
+    _compare_hosts(rows, log)
     res, lag1, total = init_res
     R_py, R_cc = np.array(res.R_LI[:]).reshape(3, 3), np.array(status.init.R_LI[:]).reshape(3, 3)
     ang_hosts = np.rad2deg(np.arccos(np.clip((np.trace(R_py.T @ R_cc) - 1) / 2, -1, 1)))
@@ -381,3 +394,37 @@ def test_replay_host_runs_lo_li_init_lio_like_the_python_harness(tmp_path):
                              np.array(status.init.acc_bias[:]), np.array(status.init.grav_L0[:]))
     first_block = open(result_path).read().split("Refinement result:")[0]
     assert first_block == open(py_path).read()
+
+
+@pytest.mark.gpu
+def test_replay_host_takes_livox_messages_with_the_avia_launch_file():
+    """BASELINE.json configs[0] through the C++ host: Livox-Avia CustomMsg messages with the parameters of harness/launch/avia.launch
+    (config/avia.yaml: 5 sub-frames per message, point_filter_num 2, blind 2 m, leaf 0.05) - callbacks, device ingest + cut, LO,
+    movement detection and accumulation - against the same library calls made from Python."""
+    from lidar_imu_init_amd.api import lii_livox_fields
+    from harness import synth, wire
+    d = _drv()
+    hall = synth.Hall(size=(24.0, 18.0, 6.0), n_boxes=8, seed=7)
+    traj = synth.Trajectory()
+    msg_period, n_msgs = 0.1, 70
+    imu = synth.simulate_imu(traj, -0.5, n_msgs * msg_period + 0.5, 200.0, synth.rot_zyx(0.01, -0.02, 0.3), np.array([0.02, 0.0, 0.05]),
+                             np.zeros(3), np.zeros(3), 0.0)
+    msgs = []
+    for m in range(n_msgs):
+        raw, n = wire.avia_message(hall, traj, m * msg_period, msg_period, 24000, seed=100 + m)
+        msgs.append((m * msg_period, np.frombuffer(raw, np.uint8).copy(), n))
+    fl = wire.livox_fields()
+    log, status = _cxx_host(d, os.path.join(ROOT, "harness", "launch", "avia.launch"), None, msgs, imu, lii_livox_fields(*fl), True, msg_period, 30_000, 600_000)
+    assert status.data_accum_start and not status.data_accum_finished and not status.imu_en   # data_accum_length 400: ~20 s of motion
+    assert status.cut_frame_num == 5 and len(log) > 250    # the first 5 messages are not cut (src/preprocess.cpp:63-64), the others into 5
+    p = dict(max_scan=30_000, max_map=600_000, fs_map=0.15, leaf=0.05, gyr_cov=50.0, acc_cov=2.0, accum_len=400.0, orig_freq=10, cut=5, mean_acc_norm=9.805,
+             cov_R_LI=5e-5, cov_T_LI=1e-5, avia=True)
+    rows, init_res = _python_host(msgs, imu, lambda reg, raw, n, s, cut, sc: reg.ingest_livox(raw, n, fl, 6, 2, 2.0, s, cut, scan_count=sc), msg_period, p)
+    assert init_res is None
+    _compare_hosts(rows, log, pos_tol=0.03, rot_tol=0.01)  # (2.4 k-point sub-frames: measured 8 mm)
+    ts = log[:, 0]
+    pos_err = np.linalg.norm(log[:, 13:16] - traj.p(ts), axis=1)
+    # (how well a 2.4 k-point, 70-degree odometry tracks is the method's business - tests/test_oracle_end_to_end.py runs this stream to the
+    # calibration; here: it ends near the truth and never loses the trajectory)
+    print(f"avia LO through the C++ host: final position error {pos_err[-1] * 100:.1f} cm, worst {pos_err.max() * 100:.1f} cm")
+    assert pos_err[-1] < 0.15 and pos_err.max() < 1.0
