@@ -1,0 +1,118 @@
+// libliinit_hip — the communicator of a sharded job: node-local mailbox (lii_mailbox.cpp; the exchange itself runs inside
+// k_reduce_solve, lii_iekf.hip) or RCCL.  SURVEY.md section 8(e).
+#include "lii_context.h"
+
+using namespace lii_impl;
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------ multi-GPU
+int lii_comm_unique_id(uint8_t id_out[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  if (!id_out) return LII_ERR_INVALID;
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return fail(nullptr, LII_ERR_COMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+  std::memcpy(id_out, &id, 128);
+  return LII_OK;
+}
+}  // extern "C"
+namespace lii_impl {
+void comm_drop(lii_handle h) {
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->net.comm) { ncclCommDestroy(h->net.comm); h->net.comm = nullptr; }
+  mailbox_close(&h->net.mailbox);
+  h->net.n_ranks = 1;
+  h->net.rank = 0;
+}
+}  // namespace lii_impl
+extern "C" {
+int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128], int32_t transport) {
+  if (!h || !id_in || n_ranks < 1 || rank < 0 || rank >= n_ranks || transport < LII_COMM_AUTO || transport > LII_COMM_MAILBOX_HOST)
+    return fail(h, LII_ERR_INVALID, "lii_comm_init: bad arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  comm_drop(h);
+  h->net.n_ranks = n_ranks;
+  h->net.rank = rank;
+  // a single rank needs no exchange; asked for by name, the RCCL transport is still set up (a one-rank communicator), so that
+  // the three-launch form of the loop - final sum, ncclAllReduce, solve - can be exercised on one device
+  if (n_ranks == 1 && transport != LII_COMM_RCCL) return LII_OK;
+  if (transport != LII_COMM_RCCL) {
+    if (!h->net.d_mb_seq) HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->net.d_mb_seq), sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->net.d_mb_seq, 0, sizeof(unsigned long long)));
+    // LII_MAILBOX_TIMEOUT_S=<exchange>[,<set-up>]: how long a reduce+solve kernel waits for a peer's sums (30 s), how long this
+    // call waits for all ranks in the node-local segment (20 s)
+    double wait_s = 20.0;
+    if (const char* t = std::getenv("LII_MAILBOX_TIMEOUT_S")) {
+      h->net.mailbox_timeout_ticks = (long long)(std::atof(t) * 1e8);
+      if (const char* c = std::strchr(t, ',')) wait_s = std::atof(c + 1);
+    }
+    std::string why;
+    if (mailbox_open(id_in, n_ranks, rank, wait_s, transport != LII_COMM_MAILBOX_HOST, &h->net.mailbox, &why) == 0) {
+      if (transport == LII_COMM_MAILBOX && !h->net.mailbox.d_peers) {  // asked for by name: no silent change of the transport
+        mailbox_close(&h->net.mailbox);
+        h->net.n_ranks = 1; h->net.rank = 0;
+        return fail(h, LII_ERR_COMM, "peer-mapped HBM mailbox unavailable: " + why);
+      }
+      h->net.comm_why = h->net.mailbox.d_peers ? "mailbox in peer-mapped HBM (HIP IPC; every rank's device reaches every other's)"
+                                       : (transport == LII_COMM_MAILBOX_HOST ? std::string("mailbox in registered host memory (asked for)")
+                                                                             : "mailbox in registered host memory - the HBM form was not possible: " + why);
+      if (h->diag) std::fprintf(stderr, "[libliinit_hip] rank %d of %d: %s\n", rank, n_ranks, h->net.comm_why.c_str());
+      return LII_OK;
+    }
+    if (transport == LII_COMM_MAILBOX || transport == LII_COMM_MAILBOX_HOST) {
+      h->net.n_ranks = 1; h->net.rank = 0;
+      return fail(h, LII_ERR_COMM, "node-local mailbox unavailable: " + why);
+    }
+    h->net.comm_why = "RCCL - the node-local mailbox was not possible: " + why;
+  } else {
+    h->net.comm_why = "RCCL (asked for)";
+  }
+  ncclUniqueId id;
+  std::memcpy(&id, id_in, 128);
+  ncclResult_t r = ncclCommInitRank(&h->net.comm, n_ranks, id, rank);
+  if (r != ncclSuccess) {
+    h->net.comm = nullptr; h->net.n_ranks = 1; h->net.rank = 0;
+    return fail(h, LII_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  }
+  if (h->diag) std::fprintf(stderr, "[libliinit_hip] rank %d of %d: %s\n", rank, n_ranks, h->net.comm_why.c_str());
+  return LII_OK;
+}
+int lii_comm_describe(lii_handle h, char* out, int32_t capacity) {
+  if (!h || !out || capacity < 1) return LII_ERR_INVALID;
+  const std::string s = (h->net.comm || h->net.mailbox.dev_slots || h->net.mailbox.d_peers) ? h->net.comm_why : std::string("no communicator");
+  std::snprintf(out, size_t(capacity), "%s", s.c_str());
+  return LII_OK;
+}
+int lii_comm_set_partition(lii_handle h, int32_t library_partition) {
+  if (!h) return LII_ERR_INVALID;
+  h->net.library_partition = library_partition != 0;
+  return LII_OK;
+}
+int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128]) {
+  return lii_comm_init_ex(h, n_ranks, rank, id_in, LII_COMM_AUTO);
+}
+int lii_comm_transport(lii_handle h, int32_t* transport) {
+  if (!h || !transport) return LII_ERR_INVALID;
+  *transport = h->net.comm ? LII_COMM_RCCL : (h->net.mailbox.d_peers ? LII_COMM_MAILBOX : (h->net.mailbox.dev_slots ? LII_COMM_MAILBOX_HOST : LII_COMM_AUTO));
+  return LII_OK;
+}
+int lii_comm_rccl_ranks(lii_handle h, int32_t* n_ranks) {
+  if (!h || !n_ranks) return LII_ERR_INVALID;
+  *n_ranks = 0;
+  if (h->net.comm) {
+    int n = 0;
+    const ncclResult_t r = ncclCommCount(h->net.comm, &n);
+    if (r != ncclSuccess) return fail(h, LII_ERR_COMM, std::string("ncclCommCount: ") + ncclGetErrorString(r));
+    *n_ranks = n;
+  }
+  return LII_OK;
+}
+int lii_comm_destroy(lii_handle h) {
+  if (!h) return LII_ERR_INVALID;
+  (void)hipSetDevice(h->device);
+  comm_drop(h);
+  return LII_OK;
+}
+
+}  // extern "C"

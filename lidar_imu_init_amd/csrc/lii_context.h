@@ -1,0 +1,263 @@
+// The handle of libliinit_hip and the host-side internals its translation units share (not part of the C-ABI):
+//   lii_capi.cpp           life cycle, scan in / de-skew / voxel grid, downloads, profiling
+//   lii_capi_map.cpp       the device-resident local map: (re)build, in-place updates, lii_map_*, lii_map_incremental
+//   lii_capi_register.cpp  the registration loop: lii_iekf_*, lii_scan_register, neighbour download
+//   lii_capi_comm.cpp      the communicator of a sharded job (node-local mailbox / RCCL)
+//   lii_capi_calib.cpp     the LI_init evaluators' entry points
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/liinit_hip.h"
+#include "lii_launch.h"
+
+using lii::BlockEntry; using lii::IekfCtrl; using lii::IekfResult; using lii::PoseArg; using lii::VoxelHashBuffers; using lii::MailboxHost;
+constexpr size_t kCtrlBytes = (sizeof(lii::IekfCtrl) + 255) / 256 * 256;
+
+struct lii_context {
+  lii_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // ---- local map (device resident).  d_pts is the live point array: cell by cell with slack behind every cell (in-place
+  // updates, lii_map.hip); d_map_unsorted / d_map are staging for (re)builds (input, then cell-sorted and compact).
+  float ds = 0.2f;              // ikd-Tree downsample box (set_downsample_param)
+  unsigned char* d_tomb = nullptr;
+  float4* d_batch = nullptr;    // a host-provided Add_Points batch (M)
+  float4* d_dropped = nullptr;  // inserts an in-place update found no room for (kMapCtrDropped of them): re-inserted after a rebuild
+  unsigned int drop_cap = 0;
+  bool map_tight = false;       // LII_TEST=map_tight: no spare room is provisioned (tests: forces the recovery path)
+  long long map_recoveries = 0;
+  float4 *d_ins = nullptr, *d_ins_c = nullptr;         // fold output / compacted inserts or host batches (M each)
+  unsigned int *d_u32_a = nullptr, *d_u32_b = nullptr, *d_u32_c = nullptr;  // flags / ranks (max(N, M) each)
+  float4 *d_list_add = nullptr, *d_list_nodown = nullptr;  // map_incremental lists (N each)
+  int* d_counts = nullptr;      // [0] add list, [1] no-downsample list, [2] alive, [3] inserted, [4] total, [5] events
+  float4* d_map_unsorted = nullptr;
+  float4* d_map = nullptr;
+  float4* d_pts = nullptr;            // pts_cap slots
+  unsigned int pts_cap = 0;
+  unsigned int pts_cap_eff = 0;  // = pts_cap (LII_TEST=map_tight: a few slots behind the cells, so that updates run out of room)
+  unsigned int* d_cell_cap = nullptr; // capacity end of every cell entry (same indexing as d_cells)
+  unsigned int* d_tp = nullptr;       // per cell entry: on-work-list bit | pending inserts
+  unsigned int *d_cs_a = nullptr, *d_cs_b = nullptr;  // per cell entry scratch (capacities / counts and their scans)
+  unsigned int* d_work = nullptr;     // work list of the update in flight (cell entries)
+  unsigned int work_cap = 0;
+  unsigned int *d_ins_e = nullptr, *d_ins_e2 = nullptr;  // cell entry of every insert (fold output / plain list)
+  unsigned long long* d_ah_key = nullptr;   // hash-grouped fold of lii_map_incremental (lii_map.hip: AddHash): voxel keys,
+  unsigned long long* d_ah_best = nullptr;  // per-slot minima (both all ones between updates),
+  unsigned int* d_ah_slot = nullptr;        // the slot of every batch point
+  bool fold_sorted = false;                 // LII_TEST=fold_sort: lii_map_incremental folds through the batch sort as lii_map_add_points does
+  int* d_mapctr = nullptr;            // kMapCtr* counters
+  int n_used = 0;                     // host copy of kMapCtrUsed as of the last map_counters()
+  bool map_dirty = false;             // an update has been enqueued since the last map_counters(): n_map / n_used / n_blocks are stale
+  unsigned long long *d_keys_a = nullptr, *d_keys_b = nullptr, *d_keys_c = nullptr;
+  unsigned int *d_idx_a = nullptr, *d_idx_b = nullptr;
+  BlockEntry* d_blocks = nullptr;   // capacity-managed (grows on demand)
+  unsigned int blocks_cap = 0;      // allocated entries
+  unsigned int block_mask = 0;      // entries in use - 1
+  uint2* d_cells = nullptr;         // capacity-managed: 512 entries per occupied block
+  size_t cells_cap_blocks = 0;
+  int n_blocks = 0;
+  unsigned int* d_counter = nullptr;
+  int partial_stride = 0;
+  int n_map = 0;
+  int* n_map_pinned = nullptr;  // small pinned scratch for H2D of counters
+  float cell_size = 0.3f;
+  void* d_sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+
+  // ---- scan
+  float4* d_scan = nullptr;   // raw / undistorted (x,y,z,t_ms)
+  // lii_scan_upload_next / lii_scan_advance: the next scan travels on a copy stream into a second buffer
+  float4* d_scan_next = nullptr;
+  float4* h_stage_next = nullptr;   // pinned staging for sources that are not (pinned, stride 16)
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_next = nullptr;      // the transfer of the next scan
+  hipEvent_t ev_scan_free = nullptr; // the compute stream has finished with the buffer the next transfer writes to
+  int n_scan_next = -1;              // >= 0: a scan is waiting in d_scan_next
+  float4* d_body = nullptr;   // down-sampled body points
+  float4* d_world = nullptr;
+  float4* d_nbr = nullptr;    // 5 x cap
+  int* d_nbr_count = nullptr;
+  double* d_plane = nullptr;
+  unsigned char* d_selected = nullptr;
+  IekfCtrl* d_ctrl = nullptr;   // device-resident loop state of lii_iekf_update
+  PoseArg* d_pose = nullptr;    // pose slot of the host-driven lii_iekf_iterate
+  IekfCtrl* h_ctrl = nullptr;   // pinned upload image
+  IekfResult* h_res = nullptr;  // pinned, device-mapped: written by the solve kernel of the stopping iteration
+  lii_pose6d* h_poses = nullptr;  // pinned staging of the IMU pose table (lives behind h_ctrl: one upload can carry both)
+  int update_seq = 0;           // IekfCtrl::seq of the last update (never 0)
+  bool poll_result = true;      // LII_TEST=sync_result: end an update with hipStreamSynchronize instead of polling IekfResult::done
+  bool poses_preloaded = false, ctrl_preloaded = false;  // lii_scan_register uploaded them already
+  hipEvent_t ev_poses = nullptr;  // the last pose-table upload
+  hipEvent_t ev_stage = nullptr;  // the last scan upload through h_stage
+  bool host_solve = false;      // LII_TEST=host_solve: drive the loop from the host (A/B, reference arrangement)
+  double* d_partials = nullptr;
+  double* d_out91 = nullptr;
+  unsigned long long* d_gran = nullptr;  // k_reduce_solve: the 91 sums of a pass on their way to the solver, 2 x 91 tagged words
+  unsigned long long* d_extent = nullptr;  // 2 x {min (time|index), max time}: ping-pong accumulators
+  unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
+  int extent_sel = 0, mm_sel = 0;
+  bool knn_plan = true;        // LII_KNN_PLAN=0: every k-NN launch is enqueued (IekfCtrl::plan_mask)
+  bool test_pred_small = false;
+  bool test_force_rebuild = false;  // LII_TEST=force_rebuild: every in-place map update rebuilds the index first (the branch a map low on room takes)
+  bool no_fast_prologue = false;  // LII_TEST=no_fast: a time-sorted scan takes the general path as well (k_time_extent in front of the de-skew)
+  bool no_fuse = false;        // LII_TEST=no_fuse: lii_scan_register keeps the de-skew and the voxel filter's insert in separate launches
+  bool use_graph = false;      // LII_TEST=graph: the passes of an update are captured once per (cloud bound, plan, map view) and replayed
+  std::map<std::string, hipGraphExec_t> graphs;
+  int plan_passes_prev = 32;   // passes the update before the last one ran (the plan enqueues the larger of the last two)
+  int knn_plan_force = -1;     // LII_TEST=plan_force=<mask>: use this plan for every update (tests: forces the parked path)
+  unsigned int plan_next = 0xFFFFFFFFu, plan_cur = 0xFFFFFFFFu;
+  long long map_repeats = 0;   // map updates repeated because a list outgrew its predicted size
+  long long plan_parked = 0;   // updates that had to be continued by the host
+  bool staging_busy = false;  // h_ctrl / h_poses were handed to the device by lii_scan_register and no wait has covered the read yet
+  size_t ctrl_pending = 0;    // bytes of h_ctrl (+ poses) the next k_time_extent launch carries to d_ctrl; 0 = nothing pending
+  bool extent_valid = false;  // d_extent[extent_sel] holds the time extent of d_scan (lii_scan_set_device computed it on the way)
+  unsigned int* d_bbox_rows = nullptr;  // one row per de-skew workgroup: bounding box of its output points
+  int bbox_rows = 0;                    // rows valid for the current d_scan (0: the voxel filter makes its own pass)
+  unsigned long long *d_vkeys_a = nullptr, *d_vkeys_b = nullptr;  // sort keys of the voxel filter (kVoxKeyBits wide)
+  unsigned int* d_vidx_b = nullptr;
+  unsigned long long *d_vcomp = nullptr, *d_vsplit = nullptr;  // sample sort of the voxel filter (lii_vsort.hip)
+  unsigned int* d_vhist = nullptr;
+  unsigned short* d_vbucket = nullptr;
+  unsigned int *d_vpcl_in = nullptr, *d_vpcl_out = nullptr;  // PCL voxel index per input point / per output voxel
+  VoxelHashBuffers vh = {};      // the voxel grid by hashing (the default; LII_VOXEL_FILTER=sort: the sample sort)
+  unsigned int vh_epoch = 0;     // number of the last hashed filter run (VoxelHashBuffers::counts)
+  bool voxel_sort = false;       // LII_VOXEL_FILTER=sort
+  bool vh_pinned = false;        // LII_VOXEL_FILTER=hash: no probing
+  float fuse_leaf = 0.f;         // lii_scan_register -> lii_undistort_imu: the voxel filter that follows runs at this leaf (0: none)
+  float vh_inserted_leaf = 0.f;
+  bool vh_inserted = false;      // ... and the de-skew has filled the hashed filter's table on the way (lii_downsample goes on from there)
+  int vh_mode = 1;               // 1: sparse voxels (hashed filter), 0: crowded voxels (sample sort)
+  float vh_leaf = -1.f;          // the leaf size the choice was probed for
+  unsigned int vh_watch = 0;
+  unsigned long long vh_calls = 0, vh_due = 0;  // filter runs so far; the run at which the pending `crowded` read-back is applied
+  bool voxel_path_hash = false;  // the path the last filter took
+  unsigned int* h_vh_crowded = nullptr;  // pinned: VoxelHashBuffers::crowded of the last hashed filter (read lazily)
+  hipEvent_t ev_vh = nullptr;
+  bool vh_flag_pending = false;
+  bool body_reordered = false;   // d_body is in the order of the voxels' first points: the download entry points restore the PCL order (pcl_perm)
+  std::vector<int> pcl_perm;     // pcl_perm[r] = position in d_body of the r-th point in PCL order (valid while pcl_perm_valid)
+  bool pcl_perm_valid = false;
+  double* d_poses = nullptr;
+  int n_scan = 0, n_body = 0;   // n_body is an upper bound while n_body_pending (the exact count lives in d_nbody)
+  bool n_body_pending = false;
+  int last_filtered = 1;
+  int* d_nbody = nullptr;       // [0] size of the down-sampled cloud, [1] `filtered` flag of the last voxel filter
+  bool body_is_scan = false;
+  bool have_search = false;
+  int knn_variant = 0;   // search pass: 0 = packed keys (k_knn_pk); 5 = exact lists throughout (k_knn_exact, its reference form) -
+                         // LII_KNN_VARIANT selects
+  hipStream_t map_stream = nullptr;  // the in-place update of lii_map_incremental runs here, beside the next scan's pre-processing
+  bool map_async = false;            // ... and may still be running (map_join waits for it: ev_mapflag is its last packet)
+  int bound_add = 0, bound_nodown = 0;  // ... the sizes the update in flight was enqueued for
+  int list_hist[8][2] = {};             // ... from the sizes of the last eight calls (note_list_sizes)
+  int list_hist_n = 0;
+  int pred_add = -1, pred_nodown = -1;  // lii_map_incremental: list sizes the next update is enqueued for (< 0: none yet)
+  bool lists_predicted = false;         // the update in flight ran on predicted sizes: commit_map checks it against the exact ones
+  hipEvent_t ev_lists = nullptr;        // the two lists are complete (compute stream -> map stream)
+  int* h_mapflag = nullptr;       // pinned, behind the last in-place update: [0..15] the map counters, [16..20] the list counts of
+                                  // lii_map_incremental (k_compact_lists) - read by commit_map / map_join
+  hipEvent_t ev_mapflag = nullptr;
+  bool map_flag_pending = false;
+  bool diag = false;     // LII_DIAG=1: counters of the rare paths on stderr when the handle is destroyed
+
+  // ---- pinned staging
+  float4* h_stage = nullptr;     // max(max_scan, max_map) float4
+  size_t h_stage_elems = 0;
+  double* h_small = nullptr;     // 4096 doubles
+
+  // ---- calibration
+  struct CalibState {  // lii_capi_calib.cpp: the LI_init evaluators' buffers
+    double *d_cal_imu = nullptr, *d_cal_lidar = nullptr, *d_cal_params = nullptr, *d_cal_out = nullptr;
+    int n_cal = 0;
+
+    bool li_init_device = false;  // lii_li_init_set_device: zero-phase filter + cross-correlation of lii_li_init_run on the device
+  } cal;
+  void* ingest = nullptr;  // lii_ingest.hip state (frames of the last driver message)
+
+  // ---- comm
+  struct CommState {  // lii_capi_comm.cpp: the communicator of a sharded job
+    ncclComm_t comm = nullptr;   // RCCL transport (ranks on several nodes, or forced)
+    MailboxHost mailbox;         // node-local transport: the exchange happens inside k_reduce_solve
+    unsigned long long* d_mb_seq = nullptr;
+    long long mailbox_timeout_ticks = 3000000000ll;  // 30 s (LII_MAILBOX_TIMEOUT_S): ranks may start a scan seconds apart
+    int n_ranks = 1, rank = 0;
+    std::string comm_why;           // which transport this rank ended up with and why (lii_comm_describe)
+    bool library_partition = true;  // lii_comm_set_partition: the library splits the down-sampled cloud over the ranks (every rank
+                                    // hands over the whole scan); false: the caller hands every rank its own points
+  } net;
+
+  // ---- profiling
+  struct ProfState {  // lii_set_profiling / lii_last_timings / lii_last_kernel_profile, LII_DIAG
+    bool kp_active = false;            // inside a lii_scan_register that is being profiled launch by launch
+    int prof_mode = 0;                 // the last lii_set_profiling value; 3: an event in front of every launch of lii_scan_register
+    std::vector<hipEvent_t> kp_ev;     // ... the events (created on demand, reused),
+    std::vector<int> kp_kind;          // ... kind * 64 + iteration of the launch behind each (kind LII_KP_KINDS: end mark)
+    int kp_n = 0;
+    lii_kernel_profile kprof{};
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_it[32] = {};  // per-iteration brackets of the k-NN kernel in the device-driven loop
+    double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double host_us[6] = {0, 0, 0, 0, 0, 0};  // LII_DIAG: per lii_scan_register - entry -> first launch, -> pre-processing enqueued, -> loop enqueued, -> result; calls; gap between calls
+    std::chrono::steady_clock::time_point host_last_return;
+    double host_loop_enq_us = 0;
+  } prof;
+};
+
+
+namespace lii_impl {
+using namespace lii;
+
+int fail(lii_handle h, int code, const std::string& msg);
+#define HIPCHK(h, call)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = (call);                                                                               \
+    if (e_ != hipSuccess)                                                                                 \
+      return lii_impl::fail(h, LII_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+template <class T>
+hipError_t dmalloc(T** p, size_t n) {
+  return hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
+}
+inline unsigned int next_pow2(unsigned int v) {
+  unsigned int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+// lii_capi.cpp
+int kp_mark(lii_handle h, int kind, int it = 0);
+GridView grid_view(const lii_context* c);
+RegistrationBuffers reg_buffers(const lii_context* c);
+PoseArg pose_of(const lii_state& s);
+int resolve_n_body(lii_handle h);
+int pcl_order(lii_handle h, const int** perm);
+void extent_discard(lii_handle h);
+unsigned long long* extent_of_scan(lii_handle h);
+MailboxView mailbox_view(lii_handle h);
+// lii_capi_map.cpp
+int build_index(lii_handle h, int n, int extra_blocks = 0);
+void note_list_sizes(lii_handle h, int n_add, int n_nodown);
+int map_join(lii_handle h);
+int commit_map(lii_handle h);
+int map_counters(lii_handle h, bool already_synced = false);
+int map_gather(lii_handle h, int* n_out);
+int map_rebuild(lii_handle h, int extra_blocks);
+int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra, bool beside = false,
+              const int* n_list_dev = nullptr, const int* n_extra_dev = nullptr, bool count_events = true);
+// lii_capi_comm.cpp
+void comm_drop(lii_handle h);
+}  // namespace lii_impl
