@@ -322,56 +322,50 @@ __device__ __forceinline__ void qr_solve_5x3(double (&a)[5][3], double (&x)[3]) 
 
 // ------------------------------------------------------------------------------------------------
 // per-block reduction of the 12-column Jacobian rows into 78 + 12 sums (+ count)
-constexpr int kCols = 13;         // 12 Jacobian columns + z
-constexpr int kColStride = 65;    // 64 lanes + 1 pad: column c of lane p at (c * 65 + p) — conflict-free b64 reads
+// Round 4: the sums of a wavefront are ONE small matrix product - S = V^T V with V the 64 x 13 matrix of its rows (12 Jacobian
+// columns + z) - and run on the matrix cores: v_mfma_f64_16x16x4_f64 takes A (16 x 4) and B (4 x 16) with lane l supplying
+// A[l % 16][l / 16] and B[l / 16][l % 16], i.e. for S = V^T V over four points the SAME value in both operands - component l % 16
+// of point 4 kb + l / 16 - so one LDS read per lane and instruction, sixteen instructions per wavefront (round 3: 64 steps of two
+// multiply-adds per lane on the vector ALU, 256 LDS reads per lane: ~1.3 us of every fit launch).  The only contraction of the path;
+// fp64 in, fp64 accumulate, fixed order (deterministic).  R^-1 scales the sums, not the factors.
+constexpr int kRowStride = 17;    // doubles per point in LDS (16 components + 1 pad: conflict-free writes, near conflict-free reads)
 constexpr int kFitWaves = kBlock / 64;
 struct ReduceShared {
-  double col[kFitWaves][kCols * kColStride];
-  double part[kFitWaves][90];
+  double row[kFitWaves][64 * kRowStride];
+  double part[kFitWaves][96];
   int cnt[kFitWaves];
 };
-
-// pair t (0..89) -> (a, b): t < 78 upper triangle of 12x12 row-major (a <= b), else (t - 78, 12)
-__device__ __forceinline__ void pair_of(int t, int& a, int& b) {
-  if (t >= 78) { a = t - 78; b = 12; return; }
-  int rem = t, row = 0;
-#pragma unroll
-  for (int r = 0; r < 12; r++) {
-    int len = 12 - r;
-    if (rem >= len && row == r) { rem -= len; row = r + 1; }
-  }
-  a = row;
-  b = row + rem;
-}
+typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // partial_out[t * stride] (t < 91) receives this block's sums
 __device__ __forceinline__ void block_reduce_rows(ReduceShared& sh, const double (&h)[12], double z, bool sel, double rinv,
                                                   double* __restrict__ partial_out, int stride) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* col = sh.col[wave];
+  double* row = sh.row[wave];
 #pragma unroll
-  for (int c = 0; c < 12; c++) col[c * kColStride + lane] = sel ? h[c] : 0.0;
-  col[12 * kColStride + lane] = sel ? z : 0.0;
+  for (int c = 0; c < 12; c++) row[lane * kRowStride + c] = sel ? h[c] : 0.0;
+  row[lane * kRowStride + 12] = sel ? z : 0.0;
+  row[lane * kRowStride + 13] = 0.0; row[lane * kRowStride + 14] = 0.0; row[lane * kRowStride + 15] = 0.0;
   unsigned long long m = __ballot(sel);
   if (lane == 0) sh.cnt[wave] = __popcll(m);
-  __syncthreads();
-  // each lane owns pairs lane and lane + 64 (90 pairs per wave)
-  int a0, b0, a1, b1;
-  pair_of(lane, a0, b0);
-  const bool two = (lane + 64) < 90;
-  pair_of(two ? lane + 64 : 0, a1, b1);
-  double s0 = 0, s1 = 0;
-  const double* ca0 = col + a0 * kColStride;
-  const double* cb0 = col + b0 * kColStride;
-  const double* ca1 = col + a1 * kColStride;
-  const double* cb1 = col + b1 * kColStride;
-#pragma unroll 8
-  for (int p = 0; p < 64; p++) {
-    s0 += (ca0[p] * rinv) * cb0[p];
-    s1 += (ca1[p] * rinv) * cb1[p];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // (the wavefront reads back only what it wrote itself)
+  const int c = lane & 15, q = lane >> 4;
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kb = 0; kb < 16; kb++) {
+    const double v = row[(4 * kb + q) * kRowStride + c];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
   }
-  sh.part[wave][lane] = s0;
-  if (two) sh.part[wave][lane + 64] = s1;
+  // acc[r] = S[q + 4 r][c] (the f64 form's own C / D map: row = (lane >> 4) + 4 reg, col = lane & 15 - not the f32 forms'): the upper
+  // triangle of the 12 x 12 block (78), the z column (12)
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = q + 4 * r, j = c;
+    if (i < 12 && j <= 12 && i <= j) {
+      const int t = j == 12 ? 78 + i : i * 12 - (i * (i - 1)) / 2 + (j - i);
+      sh.part[wave][t] = acc[r] * rinv;
+    }
+  }
   __syncthreads();
   // (kBlock = 64: one wavefront, lanes 0..63 write pairs t and t + 64)
   for (int t = threadIdx.x; t < 91; t += kBlock) {
