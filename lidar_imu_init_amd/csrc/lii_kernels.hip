@@ -861,23 +861,30 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
     const float bound = fminf(ub5, g.max_d2);
     const bool need2 = fast && !(bound <= g0sq);
     if (__any(need2)) {
-      // per axis the squared gaps to the three cell slabs, then 27 sums against the bound (every lane of the group computes the
-      // same mask; the 8 cells of round 1 are masked out)
+      // Which of the 19 outer cells of the 3 x 3 x 3 block can still hold a closer point: per axis the squared gap to the slab on the
+      // NEAR side (round 1 looked there) and on the FAR side - the own slab's is 0 - and one sum per outer cell against the bound
+      // (every lane of the group computes the same mask).  Cells are numbered in these terms, s in {0 own, 1 near, 2 far} per
+      // axis, id = sx + 3 sy + 9 sz: the outer cells are the ids with a 2 in them whatever the query's octant, so the mask is
+      // nineteen add / compare / select triples without a branch (round 3 numbered the cells by their offsets and tested
+      // every one of the 27 for membership of round 1 first: the compiler made a chain of 27 predicated blocks of it).
       const QueryCell q = query_cell(g, wx, wy, wz);
-      float gx[3], gy[3], gz[3];
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const float ax = axis_gap(wx, q.cx + j - 1, g.cs, q.eps), ay = axis_gap(wy, q.cy + j - 1, g.cs, q.eps),
-                    az = axis_gap(wz, q.cz + j - 1, g.cs, q.eps);
-        gx[j] = ax * ax; gy[j] = ay * ay; gz[j] = az * az;
+      float GX[3], GY[3], GZ[3];
+      {
+        const float nx = axis_gap(wx, q.cx + q.ox, g.cs, q.eps), fx = axis_gap(wx, q.cx - q.ox, g.cs, q.eps);
+        const float ny = axis_gap(wy, q.cy + q.oy, g.cs, q.eps), fy = axis_gap(wy, q.cy - q.oy, g.cs, q.eps);
+        const float nz = axis_gap(wz, q.cz + q.oz, g.cs, q.eps), fz = axis_gap(wz, q.cz - q.oz, g.cs, q.eps);
+        GX[0] = 0.f; GX[1] = nx * nx; GX[2] = fx * fx;
+        GY[0] = 0.f; GY[1] = ny * ny; GY[2] = fy * fy;
+        GZ[0] = 0.f; GZ[1] = nz * nz; GZ[2] = fz * fz;
       }
       unsigned int m = 0u;
-#pragma unroll
-      for (int c = 0; c < 27; c++) {
-        const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
-        const bool in_r1 = (dx == 0 || dx == q.ox) && (dy == 0 || dy == q.oy) && (dz == 0 || dz == q.oz);
-        if (!in_r1 && !(gx[dx + 1] + gy[dy + 1] + gz[dz + 1] > bound)) m |= 1u << c;
-      }
+      static_for<27>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, sx = c % 3, sy = (c / 3) % 3, sz = c / 9;
+        if constexpr (sx == 2 || sy == 2 || sz == 2) {
+          const float d = GX[sx] + GY[sy] + GZ[sz];
+          m |= d > bound ? 0u : (1u << c);
+        }
+      });
       m = need2 ? m : 0u;
       used2 = m != 0u;
 #pragma unroll
@@ -899,9 +906,11 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
         {
           int jx[2], jy[2], jz[2];
           const bool want[2] = {true, true};
-          const int ca = c1 < 0 ? 13 : c1, cb = c2 < 0 ? 13 : c2;  // (13 = the query's own cell: looked up for nothing, not branched around)
-          jx[0] = q.cx + ca % 3 - 1; jy[0] = q.cy + (ca / 3) % 3 - 1; jz[0] = q.cz + ca / 9 - 1;
-          jx[1] = q.cx + cb % 3 - 1; jy[1] = q.cy + (cb / 3) % 3 - 1; jz[1] = q.cz + cb / 9 - 1;
+          const int ca = c1 < 0 ? 0 : c1, cb = c2 < 0 ? 0 : c2;  // (0 = the query's own cell: looked up for nothing, not branched around)
+          // id -> cell: s = 0 own, 1 one step towards the near side, 2 one step away from it
+          auto step = [](int sdig, int o) { return o * ((sdig & 1) - (sdig >> 1)); };
+          jx[0] = q.cx + step(ca % 3, q.ox); jy[0] = q.cy + step((ca / 3) % 3, q.oy); jz[0] = q.cz + step(ca / 9, q.oz);
+          jx[1] = q.cx + step(cb % 3, q.ox); jy[1] = q.cy + step((cb / 3) % 3, q.oy); jz[1] = q.cz + step(cb / 9, q.oz);
           lookup_cells_batched<2>(g, tab, jx, jy, jz, want, r);
         }
         const unsigned int nC = c1 < 0 ? 0u : r[0].y - r[0].x, nD = c2 < 0 ? 0u : r[1].y - r[1].x;
