@@ -518,7 +518,7 @@ def main():
         # HBM traffic of the dominant kernel per launch: PMC counters cannot be read inside this process - the figure comes from
         # the committed rocprofv3 --pmc passes of the same command (tools/collect_pmc.sh) and is labelled as such
         traffic, traffic_source = None, None
-        for prof_name in ("r03_pmc_knn.json", "r02_pmc_knn.json"):
+        for prof_name in ("r04_pmc_knn.json", "r03_pmc_knn.json", "r02_pmc_knn.json"):
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
                 if prof.get("workload") == args.workload:
