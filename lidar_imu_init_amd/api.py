@@ -518,10 +518,13 @@ class Registrar:
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._check(self.L.lii_comm_init_ex(self.h, n_ranks, rank, buf, {"auto": 0, "rccl": 1, "mailbox": 2, "mailbox_host": 3}[transport]))
 
-    def comm_set_partition(self, library_partition: bool):
-        """True (default): every rank hands over the whole scan, the library splits the down-sampled cloud; False: the
-        caller hands every rank its own points."""
-        self._check(self.L.lii_comm_set_partition(self.h, int(library_partition)))
+    def comm_set_partition(self, library_partition):
+        """True / 1 / "index" (default): every rank hands over the whole scan, the library splits the down-sampled cloud into
+        contiguous blocks; 2 / "voxel": ... by voxel - a rank filters and registers the voxels whose key hashes to it (where the
+        filter is fused into the de-skew: lii_scan_register; by index elsewhere); False / 0 / "caller": the caller hands every
+        rank its own points."""
+        mode = {"caller": 0, "index": 1, "voxel": 2}.get(library_partition, library_partition)
+        self._check(self.L.lii_comm_set_partition(self.h, int(mode)))
 
     def comm_transport(self) -> str:
         t = C.c_int32(0)

@@ -57,7 +57,7 @@ RegistrationBuffers reg_buffers(const lii_context* c) {
   rb.n_dev = c->n_body_pending ? c->d_nbody : nullptr;
   rb.cap = c->cfg.max_scan_points;
   rb.shard_rank = c->net.rank;
-  rb.shard_world = (c->net.n_ranks > 1 && c->net.library_partition) ? c->net.n_ranks : 1;
+  rb.shard_world = (c->net.n_ranks > 1 && c->net.library_partition && !c->body_partitioned) ? c->net.n_ranks : 1;
   return rb;
 }
 PoseArg pose_of(const lii_state& s) {
@@ -67,6 +67,14 @@ PoseArg pose_of(const lii_state& s) {
   std::memcpy(p.RLI, s.offset_R_L_I, 72);
   std::memcpy(p.TLI, s.offset_T_L_I, 24);
   return p;
+}
+// The insert of the hashed voxel filter rides in the de-skew kernel when the hashed filter is the one in use for this leaf.  A job
+// that shares the filter by voxel (lii_comm_set_partition(h, 2)) always uses it - every rank must take the same path, and the
+// watch that changes over to the sort sees a different share of the voxels on every rank - unless the sort has been pinned.
+bool fuse_filter(lii_handle h, float leaf) {
+  if (!(leaf > 0.f) || h->voxel_sort || h->no_fuse) return false;
+  if (h->vh.part_world > 1) return true;
+  return h->vh_mode == 1 && (h->vh_pinned || leaf == h->vh_leaf);
 }
 // Fetches the exact size of the down-sampled cloud from the device (one small synchronising copy).
 int resolve_n_body(lii_handle h) {
@@ -123,6 +131,16 @@ unsigned long long* extent_of_scan(lii_handle h) {
   h->extent_sel ^= 1;  // consumed: the partner (re-armed by whoever filled `ext`) serves the next scan
   h->extent_valid = false;
   return ext;
+}
+lii::GatherView gather_view(lii_handle h) {
+  lii::GatherView g;
+  g.peers = h->net.mailbox.d_gather_peers;
+  g.block_bytes = h->net.mailbox.gather_block;
+  g.cap_points = h->net.mailbox.gather_cap;
+  g.n_ranks = h->net.n_ranks;
+  g.rank = h->net.rank;
+  g.timeout_ticks = h->net.mailbox_timeout_ticks;
+  return g;
 }
 MailboxView mailbox_view(lii_handle h) {
   MailboxView v;
@@ -381,6 +399,7 @@ int lii_destroy(lii_handle h) {
   h->graphs.clear();
   mailbox_close(&h->net.mailbox);
   if (h->net.d_mb_seq) (void)hipFree(h->net.d_mb_seq);
+  if (h->net.d_gather_ticket) (void)hipFree(h->net.d_gather_ticket);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
   for (hipEvent_t e : h->prof.kp_ev) (void)hipEventDestroy(e);
   if (h->ev_next) (void)hipEventDestroy(h->ev_next);
@@ -551,7 +570,7 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
   unsigned long long* ext = extent_of_scan(h);
   // lii_scan_register told us the hashed voxel filter follows at a leaf that has been probed: its insert rides in the de-skew
   // (one launch less per scan; lii_downsample goes on with the emit)
-  h->vh_inserted = h->fuse_leaf > 0.f && !h->voxel_sort && h->vh_mode == 1 && (h->vh_pinned || h->fuse_leaf == h->vh_leaf) && !h->no_fuse;
+  h->vh_inserted = fuse_filter(h, h->fuse_leaf);
   if (h->vh_inserted) h->vh_inserted_leaf = h->fuse_leaf;
   DeskewPlan dp = {};
   dp.in = dp.out = h->d_scan; dp.n = h->n_scan; dp.sorted = 0; dp.extent = ext; dp.bbox_rows = h->d_bbox_rows;
@@ -569,7 +588,7 @@ int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], c
   std::memcpy(a.vel, vel, 24);
   std::memcpy(a.endR, end_R, 72);
   unsigned long long* ext = extent_of_scan(h);
-  h->vh_inserted = h->fuse_leaf > 0.f && !h->voxel_sort && h->vh_mode == 1 && (h->vh_pinned || h->fuse_leaf == h->vh_leaf) && !h->no_fuse;
+  h->vh_inserted = fuse_filter(h, h->fuse_leaf);
   if (h->vh_inserted) h->vh_inserted_leaf = h->fuse_leaf;
   DeskewPlan dp = {};
   dp.in = dp.out = h->d_scan; dp.n = h->n_scan; dp.sorted = 0; dp.extent = ext; dp.bbox_rows = h->d_bbox_rows;
@@ -588,6 +607,7 @@ int lii_downsample_skip(lii_handle h, int32_t* n_down) {
   h->n_body_pending = false;
   h->have_search = false;
   h->body_reordered = false;
+  h->body_partitioned = false;
   if (n_down) *n_down = h->n_body;
   return LII_OK;
 }
@@ -650,10 +670,11 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
   }
   const bool use_hash = inserted || (h->vh_mode == 1 && !h->voxel_sort);
   h->voxel_path_hash = use_hash;
+  const bool by_voxel = inserted && h->vh.part_world > 1;  // this rank emits ITS voxels only
   if (use_hash) {
     if (++h->vh_epoch == 0u) h->vh_epoch = 1u;
     launch_voxel_hash(h->vh, h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_body, h->d_nbody, h->d_nbody + 1, h->d_vpcl_out, hash_stages, h->vh_epoch, s);
-    if (!h->vh_pinned && !h->vh_flag_pending && (++h->vh_watch & 15) == 0) {  // (every 16th scan: the copy costs a packet on the stream)
+    if (!h->vh_pinned && !by_voxel && !h->vh_flag_pending && (++h->vh_watch & 15) == 0) {  // (every 16th scan: the copy costs a packet on the stream)
       HIPCHK(h, hipMemcpyAsync(h->h_vh_crowded, h->vh.crowded, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
       HIPCHK(h, hipMemsetAsync(h->vh.crowded, 0, sizeof(unsigned int), s));
       HIPCHK(h, hipEventRecord(h->ev_vh, s));
@@ -681,8 +702,9 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
     }
   }
   HIPCHK(h, hipGetLastError());
-  h->n_body = n;  // upper bound until resolved
+  h->n_body = by_voxel ? voxel_partition_bound(n, h->vh.part_world) : n;  // upper bound until resolved
   h->n_body_pending = true;
+  h->body_partitioned = by_voxel;
   h->body_reordered = use_hash;  // (the hashed filter emits the voxels in the order of their first points)
   h->pcl_perm_valid = false;
   if (n_down || filtered) {

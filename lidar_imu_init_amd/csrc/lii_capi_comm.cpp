@@ -18,18 +18,25 @@ int lii_comm_unique_id(uint8_t id_out[128]) {
 }
 }  // extern "C"
 namespace lii_impl {
+void partition_refresh(lii_handle h) {
+  // (by voxel, a rank never sees the other ranks' points: the map update needs the list exchange, which the peer-mapped mailbox
+  // carries - a job on another transport stays with the split by index; lii_comm_describe says which)
+  const bool by_voxel = h->net.n_ranks > 1 && h->net.library_partition && h->net.voxel_partition && h->net.mailbox.d_gather_peers;
+  h->vh.part_world = by_voxel ? h->net.n_ranks : 0;
+  h->vh.part_rank = by_voxel ? h->net.rank : 0;
+  h->vh.part_overflow = h->h_res ? &h->h_res->part_overflow : nullptr;
+}
 void comm_drop(lii_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->net.comm) { ncclCommDestroy(h->net.comm); h->net.comm = nullptr; }
   mailbox_close(&h->net.mailbox);
   h->net.n_ranks = 1;
   h->net.rank = 0;
+  partition_refresh(h);
 }
 }  // namespace lii_impl
-extern "C" {
-int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128], int32_t transport) {
-  if (!h || !id_in || n_ranks < 1 || rank < 0 || rank >= n_ranks || transport < LII_COMM_AUTO || transport > LII_COMM_MAILBOX_HOST)
-    return fail(h, LII_ERR_INVALID, "lii_comm_init: bad arguments");
+namespace {
+int comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128], int32_t transport) {
   HIPCHK(h, hipSetDevice(h->device));
   comm_drop(h);
   h->net.n_ranks = n_ranks;
@@ -40,6 +47,9 @@ int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t 
   if (transport != LII_COMM_RCCL) {
     if (!h->net.d_mb_seq) HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->net.d_mb_seq), sizeof(unsigned long long)));
     HIPCHK(h, hipMemset(h->net.d_mb_seq, 0, sizeof(unsigned long long)));
+    if (!h->net.d_gather_ticket) HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->net.d_gather_ticket), sizeof(unsigned int)));
+    HIPCHK(h, hipMemset(h->net.d_gather_ticket, 0, sizeof(unsigned int)));
+    h->net.gather_seq = 0;
     // LII_MAILBOX_TIMEOUT_S=<exchange>[,<set-up>]: how long a reduce+solve kernel waits for a peer's sums (30 s), how long this
     // call waits for all ranks in the node-local segment (20 s)
     double wait_s = 20.0;
@@ -48,7 +58,7 @@ int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t 
       if (const char* c = std::strchr(t, ',')) wait_s = std::atof(c + 1);
     }
     std::string why;
-    if (mailbox_open(id_in, n_ranks, rank, wait_s, transport != LII_COMM_MAILBOX_HOST, &h->net.mailbox, &why) == 0) {
+    if (mailbox_open(id_in, n_ranks, rank, wait_s, transport != LII_COMM_MAILBOX_HOST, h->cfg.max_scan_points, &h->net.mailbox, &why) == 0) {
       if (transport == LII_COMM_MAILBOX && !h->net.mailbox.d_peers) {  // asked for by name: no silent change of the transport
         mailbox_close(&h->net.mailbox);
         h->net.n_ranks = 1; h->net.rank = 0;
@@ -78,15 +88,32 @@ int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t 
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] rank %d of %d: %s\n", rank, n_ranks, h->net.comm_why.c_str());
   return LII_OK;
 }
+}  // namespace
+extern "C" {
+int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128], int32_t transport) {
+  if (!h || !id_in || n_ranks < 1 || rank < 0 || rank >= n_ranks || transport < LII_COMM_AUTO || transport > LII_COMM_MAILBOX_HOST)
+    return fail(h, LII_ERR_INVALID, "lii_comm_init: bad arguments");
+  const int rc = comm_init(h, n_ranks, rank, id_in, transport);
+  partition_refresh(h);  // (n_ranks / rank as the set-up left them: 1 / 0 after a failure)
+  return rc;
+}
 int lii_comm_describe(lii_handle h, char* out, int32_t capacity) {
   if (!h || !out || capacity < 1) return LII_ERR_INVALID;
-  const std::string s = (h->net.comm || h->net.mailbox.dev_slots || h->net.mailbox.d_peers) ? h->net.comm_why : std::string("no communicator");
+  std::string s = (h->net.comm || h->net.mailbox.dev_slots || h->net.mailbox.d_peers) ? h->net.comm_why : std::string("no communicator");
+  if (h->net.n_ranks > 1) {
+    s += !h->net.library_partition ? "; the caller splits the cloud"
+         : (h->vh.part_world > 1 ? "; cloud split by voxel (fused filter) / by index, map lists exchanged"
+                                 : (h->net.mailbox.d_gather_peers ? "; cloud split by index, map lists exchanged" : "; cloud split by index, map update repeats the search"));
+    if (h->net.voxel_partition && h->vh.part_world <= 1) s += " (the split by voxel needs the peer-mapped mailbox)";
+  }
   std::snprintf(out, size_t(capacity), "%s", s.c_str());
   return LII_OK;
 }
 int lii_comm_set_partition(lii_handle h, int32_t library_partition) {
-  if (!h) return LII_ERR_INVALID;
+  if (!h || library_partition < 0 || library_partition > 2) return fail(h, LII_ERR_INVALID, "lii_comm_set_partition: 0 (caller), 1 (by index) or 2 (by voxel)");
   h->net.library_partition = library_partition != 0;
+  h->net.voxel_partition = library_partition == 2;
+  partition_refresh(h);
   return LII_OK;
 }
 int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128]) {

@@ -456,11 +456,13 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
   }
   hipStream_t s = h->stream;
   RegistrationBuffers rb = reg_buffers(h);
-  if (rb.shard_world > 1) {
-    // A sharded job: this rank holds neighbour lists for its own block only, but every rank must take the SAME decisions for
-    // the whole cloud or the replicated maps drift apart.  No exchange: the search is repeated here for the whole cloud at the
-    // pose of the last executed search pass (IekfCtrl::search_pose, identical on every rank) - one more k-NN pass, a few
-    // percent of what the map update itself costs - and the lists come out bit-identical on every rank.
+  const lii::GatherView gv = gather_view(h);
+  const bool exchange = h->net.n_ranks > 1 && h->net.library_partition && gv.peers != nullptr;
+  if (rb.shard_world > 1 && !exchange) {
+    // A job split by index on a transport without the list exchange (host-memory mailbox, RCCL): this rank holds neighbour lists
+    // for its own block only, but every rank must take the SAME decisions for the whole cloud or the replicated maps drift apart.
+    // The search is repeated here for the whole cloud at the pose of the last executed search pass (IekfCtrl::search_pose,
+    // identical on every rank) - one more k-NN pass - and the lists come out bit-identical on every rank.
     rb.shard_world = 1;
     if (h->have_search) {
       const GridView g = grid_view(h);
@@ -488,15 +490,23 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
   }
   launch_map_decide_compact(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, h->d_u32_a,
                             reinterpret_cast<uint2*>(h->d_u32_b), h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, nb, nb, s);
+  if (exchange) {
+    // This rank has decided for ITS points (its block of the cloud, or its voxels): the lists of all ranks, in rank order, are the
+    // batch every replica of the map receives (lii_exchange.hip: remote stores into the peers' gather areas; in place here).
+    launch_lists_exchange(gv, h->d_list_add, h->d_list_nodown, h->d_counts, 5, h->net.d_gather_ticket, ++h->net.gather_seq, h->d_list_add,
+                          h->d_list_nodown, s);
+  }
   // The sizes of the two lists, now: a converged map takes a few thousand of the ~100 k points, and everything downstream
   // (voxel keys, the batch sort, the per-voxel fold, the insert compaction) is launched for the exact count instead of the
   // scan-sized bound - one small host round trip (~15 us) against ~80 us of kernels working on padding.
   // (the same round trip brings the map's counters up to date: the previous update ran without a synchronisation)
-  HIPCHK(h, hipMemcpyAsync(h->h_small + 3090, h->d_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(h->h_small + 3090, h->d_counts, 6 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(h->h_small + 3072, h->d_mapctr, sizeof(int) * kMapCtrWords, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
-  int n_lists[2];
+  int n_lists[6];
   std::memcpy(n_lists, h->h_small + 3090, sizeof(n_lists));
+  if (exchange && n_lists[5])
+    return fail(h, LII_ERR_COMM, "list exchange timed out (a rank of the job did not reach this map update); re-create the communicator");
   {
     const int rc0 = map_counters(h, true);
     if (rc0 != LII_OK) return rc0;

@@ -260,6 +260,10 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     }
     h->prof.kprof.scans += 1;
   }
+  if (hr->part_overflow) {
+    h->h_res->part_overflow = 0;
+    return fail(h, LII_ERR_CAPACITY, "voxel-partitioned job: this rank's share of the down-sampled cloud exceeds its bound (mean share + 25 % + 2048 points); use lii_comm_set_partition(h, 1)");
+  }
   if (hr->singular == 3)
     return fail(h, LII_ERR_COMM, "mailbox exchange timed out (a rank of the job did not reach this pass); re-create the communicator");
   if (hr->singular) return fail(h, LII_ERR_INVALID, "singular covariance / normal matrix in the device solve");
@@ -422,7 +426,7 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     h->n_body_pending = false;
     h->have_search = false;
     const float fuse_leaf = job->leaf > 0 ? job->leaf : 0.f;
-    h->vh_inserted = fuse_leaf > 0.f && !h->voxel_sort && h->vh_mode == 1 && (h->vh_pinned || fuse_leaf == h->vh_leaf) && !h->no_fuse;
+    h->vh_inserted = fuse_filter(h, fuse_leaf);
     if (h->vh_inserted) h->vh_inserted_leaf = fuse_leaf;
     DeskewPlan dp = {};
     dp.in = adopt ? static_cast<const float4*>(job->scan_dev) : h->d_scan;

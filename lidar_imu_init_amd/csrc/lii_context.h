@@ -148,6 +148,7 @@ struct lii_context {
   unsigned int* h_vh_crowded = nullptr;  // pinned: VoxelHashBuffers::crowded of the last hashed filter (read lazily)
   hipEvent_t ev_vh = nullptr;
   bool vh_flag_pending = false;
+  bool body_partitioned = false; // the down-sampled cloud on this rank holds ITS voxels only (a voxel-partitioned job, fused filter): no split by index
   bool body_reordered = false;   // d_body is in the order of the voxels' first points: the download entry points restore the PCL order (pcl_perm)
   std::vector<int> pcl_perm;     // pcl_perm[r] = position in d_body of the r-th point in PCL order (valid while pcl_perm_valid)
   bool pcl_perm_valid = false;
@@ -193,11 +194,15 @@ struct lii_context {
     ncclComm_t comm = nullptr;   // RCCL transport (ranks on several nodes, or forced)
     MailboxHost mailbox;         // node-local transport: the exchange happens inside k_reduce_solve
     unsigned long long* d_mb_seq = nullptr;
+    unsigned int* d_gather_ticket = nullptr;  // the list exchange of lii_map_incremental (lii_exchange.hip): its ticket word,
+    unsigned long long gather_seq = 0;        // ... and the exchanges enqueued so far (the ranks call in lock-step: the same on all)
     long long mailbox_timeout_ticks = 3000000000ll;  // 30 s (LII_MAILBOX_TIMEOUT_S): ranks may start a scan seconds apart
     int n_ranks = 1, rank = 0;
     std::string comm_why;           // which transport this rank ended up with and why (lii_comm_describe)
     bool library_partition = true;  // lii_comm_set_partition: the library splits the down-sampled cloud over the ranks (every rank
                                     // hands over the whole scan); false: the caller hands every rank its own points
+    bool voxel_partition = false;   // lii_comm_set_partition(h, 2): ... by VOXEL where the filter is fused into the de-skew (this rank
+                                    // filters and registers the voxels whose key hashes to it), by index otherwise
   } net;
 
   // ---- profiling
@@ -244,10 +249,12 @@ GridView grid_view(const lii_context* c);
 RegistrationBuffers reg_buffers(const lii_context* c);
 PoseArg pose_of(const lii_state& s);
 int resolve_n_body(lii_handle h);
+bool fuse_filter(lii_handle h, float leaf);  // does the de-skew of this scan fill the hashed voxel filter's table on the way?
 int pcl_order(lii_handle h, const int** perm);
 void extent_discard(lii_handle h);
 unsigned long long* extent_of_scan(lii_handle h);
 MailboxView mailbox_view(lii_handle h);
+lii::GatherView gather_view(lii_handle h);  // .peers == nullptr: this job has no list exchange (single rank, host-memory mailbox, RCCL)
 // lii_capi_map.cpp
 int build_index(lii_handle h, int n, int extra_blocks = 0);
 void note_list_sizes(lii_handle h, int n_add, int n_nodown);
@@ -260,4 +267,5 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
               const int* n_list_dev = nullptr, const int* n_extra_dev = nullptr, bool count_events = true);
 // lii_capi_comm.cpp
 void comm_drop(lii_handle h);
+void partition_refresh(lii_handle h);  // (lii_capi_comm.cpp) the voxel filter's view of the job after the communicator or its partition changed
 }  // namespace lii_impl

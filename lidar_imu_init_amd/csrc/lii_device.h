@@ -184,6 +184,21 @@ struct MailboxView {
   long long timeout_ticks;  // of the 100 MHz wall clock: how long to wait for a peer that may never arrive
 };
 
+// The second exchange of a sharded job, once per map update (lii_map_incremental; kernels in lii_exchange.hip): every rank decides
+// for ITS points of the down-sampled cloud which ones enter the map, and the two lists - PointToAdd, PointNoNeedDownsample: a few
+// thousand float4 - are pushed into every rank's gather area (peer-mapped fine-grained HBM behind the mailbox slots, remote stores
+// over xGMI) and put together in rank order there, so that all replicas of the map receive the identical batch.  One block per
+// (parity, source rank): a 64-byte header {u64 sequence flag, i32 n_add, i32 n_nodown} and the payload (the add list, then the
+// no-down-sample list).  Two parities for the same reason as the slots.
+constexpr int kGatherHeaderBytes = 64;
+struct GatherView {
+  unsigned char* const* peers;  // peers[r] = rank r's gather area as mapped into this process (peers[rank]: the own one); nullptr = no exchange
+  size_t block_bytes;           // header + payload capacity
+  int cap_points;               // payload capacity in float4 (the handle's max_scan_points: a rank's lists never hold more)
+  int n_ranks, rank;
+  long long timeout_ticks;
+};
+
 // Called by ONE wavefront (64 lanes).  Lane l holds this rank's sums l (v0) and l + 64 (v1; lanes 0 .. 26) and receives the
 // sums over the ranks in their place.  Returns false when a peer did not publish within the time limit (the communicator is
 // unusable afterwards).
@@ -247,7 +262,7 @@ struct IekfResult {
   int done;  // == IekfCtrl::seq once everything above has landed (written last, after a system-scope fence): the host polls it
              // (== seq | kLoopParked: the loop is parked ahead of iteration `parked_it`, see IekfCtrl::plan_mask)
   int parked_it;
-  int pad[1];
+  int part_overflow;  // set by the voxel filter of a voxel-partitioned job (k_vhash_emit): this rank's share outgrew its bound
   int search_log[16];
   long long ts[16];  // LII_SOLVE_TRACE builds: wall_clock64 stamps of the solve phases (stopping iteration)
   long long ts0[16]; // ... of iteration 0

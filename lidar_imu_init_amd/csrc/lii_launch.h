@@ -49,11 +49,21 @@ struct MailboxHost {
   double* peer_ptr[64] = {nullptr};
   double** d_peers = nullptr;
   int n_peers = 0;
+  // ... and behind the slots of every area the gather area of the list exchange (GatherView; gather_points > 0 at set-up)
+  unsigned char** d_gather_peers = nullptr;
+  size_t gather_block = 0;
+  int gather_cap = 0;
 };
 size_t mailbox_segment_bytes(int n_ranks);
 // want_hbm: try the peer-mapped HBM form first (falls back to host memory inside the same rendezvous when a rank cannot
 // export / open the handles).  Returns 0 on success (m->d_peers != nullptr: HBM form; else m->dev_slots: host-memory form).
-int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bool want_hbm, MailboxHost* m, std::string* why);
+// gather_points: capacity (float4) of one rank's lists in the exchange of lii_map_incremental (HBM form only; 0: no gather areas).
+int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bool want_hbm, int gather_points, MailboxHost* m, std::string* why);
+// the list exchange (lii_exchange.hip): push this rank's lists (sizes in counts[0..1], device) into every rank's gather area, wait for
+// all ranks' lists of exchange number `seq` (1, 2, ... - the same on every rank) and leave them concatenated in rank order in
+// dst_add / dst_nodown (may be the sources), the totals in counts[0..1]; counts[err_at] = 1 when a rank did not deliver in time.
+void launch_lists_exchange(const GatherView& gv, const float4* src_add, const float4* src_nodown, int* counts, int err_at, unsigned int* ticket,
+                           unsigned long long seq, float4* dst_add, float4* dst_nodown, hipStream_t s);
 void mailbox_close(MailboxHost* m);
 void launch_loop_resume(IekfCtrl* c, hipStream_t s);
 void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s);
@@ -73,8 +83,13 @@ struct VoxelHashBuffers {
   unsigned int *slot_of, *next;   // per input point
   unsigned long long* counts;     // per workgroup of 256 points: (run number << 32) | voxels owned by the workgroup
   unsigned int* crowded;          // one word: the longest member list behind a slot so far
+  // part_world > 1: a job that shares the FUSED filter (insert inside the de-skew) by voxel - rank part_rank inserts the voxels
+  // whose key hashes to it and emits at most voxel_partition_bound(n, part_world) of them (else *part_overflow = 1, mapped host memory)
+  int part_world, part_rank;
+  int* part_overflow;
 };
 size_t voxel_hash_slots(int max_n);
+int voxel_partition_bound(int n, int world);
 void launch_voxel_hash_clear(const VoxelHashBuffers& vh, size_t slots, hipStream_t s);
 void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
                        int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, unsigned int epoch,

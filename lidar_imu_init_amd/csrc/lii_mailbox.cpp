@@ -69,6 +69,7 @@ void mailbox_close(MailboxHost* m) {
   for (int r = 0; r < m->n_peers; r++)
     if (m->peer_ptr[r] && m->peer_ptr[r] != m->own) (void)hipIpcCloseMemHandle(m->peer_ptr[r]);
   if (m->d_peers) (void)hipFree(m->d_peers);
+  if (m->d_gather_peers) (void)hipFree(m->d_gather_peers);
   if (m->own) (void)hipFree(m->own);
   if (m->registered) (void)hipHostUnregister(m->map);
   if (m->map) munmap(m->map, m->bytes);
@@ -79,7 +80,7 @@ void mailbox_close(MailboxHost* m) {
 // Returns 0 when every rank of the job met in the segment (m is filled), 1 when they did not (different nodes, a rank that
 // could not register, timeout): the caller then uses RCCL.  `why` explains a non-zero return - and, with a zero return, why the
 // HBM form was asked for but the host-memory form was taken (empty otherwise).
-int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bool want_hbm, MailboxHost* m, std::string* why) {
+int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bool want_hbm, int gather_points, MailboxHost* m, std::string* why) {
   *m = MailboxHost{};
   if (n_ranks > kMailboxMaxRanks) { *why = "more ranks than mailbox lanes"; return 1; }
   std::snprintf(m->name, sizeof(m->name), "/lii_mbx_%016llx_%d", fnv1a(id, 128), n_ranks);
@@ -137,7 +138,10 @@ int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bo
   if (!want_hbm) return 0;
   // ---- the HBM form on top: export the own slot area, open the others'.  Every step is collective: one rank that cannot
   // makes all of them stay with the host-memory form (the verdicts travel through the segment's counters).
-  const size_t slot_bytes = (size_t)n_ranks * 2 * kMailboxSlotDoubles * sizeof(double);
+  // one allocation, one handle per rank: the slots, then (gather_points > 0) the gather areas of the list exchange
+  const size_t slot_region = ((size_t)n_ranks * 2 * kMailboxSlotDoubles * sizeof(double) + 4095) & ~(size_t)4095;
+  const size_t gather_block = gather_points > 0 ? (size_t)kGatherHeaderBytes + sizeof(float4) * (size_t)gather_points : 0;
+  const size_t slot_bytes = slot_region + 2 * (size_t)n_ranks * gather_block;
   auto* handles = reinterpret_cast<hipIpcMemHandle_t*>(reinterpret_cast<char*>(m->map) + kHandlesAt);
   bool mine_ok = false;
   {
@@ -222,6 +226,18 @@ int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bo
         opened_all = false;
       }
     }
+    if (opened_all && gather_block) {
+      unsigned char* g[64];
+      for (int r = 0; r < n_ranks; r++) g[r] = reinterpret_cast<unsigned char*>(m->peer_ptr[r]) + slot_region;
+      if (hipMalloc(reinterpret_cast<void**>(&m->d_gather_peers), sizeof(unsigned char*) * (size_t)n_ranks) != hipSuccess ||
+          hipMemcpy(m->d_gather_peers, g, sizeof(unsigned char*) * (size_t)n_ranks, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        hbm_why = "no device memory for the table of gather areas";
+        opened_all = false;
+      }
+      m->gather_block = gather_block;
+      m->gather_cap = gather_points;
+    }
     if (!opened_all) { hdr->open_failed.fetch_add(1); (void)decide(kHbmNo); }
     hdr->opened.fetch_add(1);
     const bool all_through = wait_count(hdr->opened, (uint32_t)n_ranks, wait_s, &hdr->hbm_verdict) && hdr->open_failed.load() == 0;
@@ -238,6 +254,8 @@ int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bo
     for (int r = 0; r < 64; r++) m->peer_ptr[r] = nullptr;
     m->n_peers = 0;
     if (m->d_peers) { (void)hipFree(m->d_peers); m->d_peers = nullptr; }
+    if (m->d_gather_peers) { (void)hipFree(m->d_gather_peers); m->d_gather_peers = nullptr; }
+    m->gather_block = 0; m->gather_cap = 0;
     if (m->own) { (void)hipFree(m->own); m->own = nullptr; }
   }
   return 0;

@@ -124,7 +124,9 @@ __global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, Pose
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = rb.n_dev ? *rb.n_dev : rb.n;
   unsigned int fa = 0, fn = 0;
-  if (i < rb.n && i < n) {  // rb.n is the launch bound
+  int lo = 0, n_live = n;  // a rank of a job split by index decides for its block (the lists are exchanged afterwards)
+  if (rb.shard_world > 1) shard_range(rb, lo, n_live);
+  if (i < rb.n && i >= lo && i < lo + n_live && i < n) {  // rb.n is the launch bound
     float4 pb = rb.body[i];
     double bx = pb.x, by = pb.y, bz = pb.z;
     double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];

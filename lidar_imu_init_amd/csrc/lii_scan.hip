@@ -207,7 +207,22 @@ struct VhTable {
   unsigned int* slot_of;    // per input point: its voxel's slot (kVhEmpty: a non-finite point, dropped as PCL drops it)
   unsigned int* next;       // per input point: list link of a crowded voxel
   unsigned int* crowded;    // one word: the longest list behind a slot so far
+  // A job whose ranks share the filter by VOXEL (lii_comm_set_partition(h, 2), fused form only): part_world > 1, and a voxel whose
+  // key does not hash to part_rank is none of this rank's business - its points are not inserted (voxel_rank below).
+  unsigned int part_world, part_rank;
+  int part_bound;           // ... and the down-sampled cloud of this rank may hold this many points (the launches behind are sized for it)
+  int* part_overflow;       // ... or this word (mapped host memory) is set: the update reports LII_ERR_CAPACITY
 };
+__device__ __forceinline__ unsigned long long vh_mix(unsigned long long hk) {
+  hk ^= hk >> 33; hk *= 0xFF51AFD7ED558CCDull; hk ^= hk >> 33;
+  return hk;
+}
+// Which rank of a voxel-partitioned job owns a voxel: the upper half of the key's hash scaled to [0, world) - the lower half picks
+// the slot.  A hash, not a range of keys: whatever the scene, every rank gets 1 / world of the voxels (+- a percent), and the
+// launches behind the filter take as long as their largest share.
+__device__ __forceinline__ unsigned int voxel_rank(unsigned long long key, unsigned int world) {
+  return (unsigned int)(((vh_mix(key) >> 32) * (unsigned long long)world) >> 32);
+}
 // A point joins its voxel: the slot is found - or created - by a CAS on the key.  The point that CREATES the slot (no key there
 // before) becomes entry 0 of the member list with a plain store and is done: one atomic for the ~95 % of the points of a leaf
 // matched to the sensor that stay alone in their voxel - the atomics of the insert, performed at the memory side, are what the
@@ -216,9 +231,7 @@ struct VhTable {
 // order - is min(creator, `first`), which the emit launch evaluates when every point has arrived; it also puts the members in
 // input order.  (Round 3: CAS + atomicMin per point here and a launch of its own, k_vhash_link, to collect the members.)
 __device__ __forceinline__ void vh_insert(const VhTable& tb, unsigned long long key, int i) {
-  unsigned long long hk = key;
-  hk ^= hk >> 33; hk *= 0xFF51AFD7ED558CCDull; hk ^= hk >> 33;
-  unsigned int slot = (unsigned int)hk & tb.mask;
+  unsigned int slot = (unsigned int)vh_mix(key) & tb.mask;
   bool created;
   for (;;) {  // the table has four times as many slots as there are points: a free slot always turns up
     const unsigned long long prev = atomicCAS(&tb.slots[slot].key, ~0ull, key);
@@ -233,7 +246,12 @@ __device__ __forceinline__ void vh_insert(const VhTable& tb, unsigned long long 
     atomicMin(&s->first, (unsigned)i);
     const unsigned int k = atomicAdd(&s->count, 1u) + 1u;
     if (k < (unsigned)kVhMembers) s->members[k] = (unsigned)i;
-    else { tb.next[i] = atomicExch(&s->head, (unsigned)i); atomicMax(tb.crowded, k + 1u - (unsigned)kVhMembers); }
+    else {
+      tb.next[i] = atomicExch(&s->head, (unsigned)i);
+      // (the watch that changes the handle over to the sort must see the same number on every rank: a rank that holds a share of
+      // the voxels does not feed it)
+      if (tb.part_world <= 1u) atomicMax(tb.crowded, k + 1u - (unsigned)kVhMembers);
+    }
   }
   tb.slot_of[i] = slot;
 }
@@ -252,6 +270,10 @@ __device__ __forceinline__ void vhash_insert_abs(const float4 P, int i, float le
             (unsigned long long)(unsigned)((int)fx + (1 << 20));
     } else {
       key = (1ull << 63) | (unsigned long long)(unsigned)i;
+    }
+    if (tb.part_world > 1u && voxel_rank(key, tb.part_world) != tb.part_rank) {  // another rank's voxel
+      tb.slot_of[i] = kVhEmpty;
+      return;
     }
     vh_insert(tb, key, i);
     return;
@@ -626,11 +648,14 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
     const uint4 c = line[2], d = line[3];  // members 2..5, 6..9
     m0.z = c.x; m0.w = c.y; m1 = make_uint4(c.z, c.w, d.x, d.y); m2 = make_uint2(d.z, d.w);
   }
-  const bool first = slot != kVhEmpty && min(hd.x, m0.x) == (unsigned)i;  // the owner: the first point of the voxel in input order
+  // (a voxel-partitioned job whose cloud passes unfiltered - PCL's overflow guard - still shares it by voxel: every point of a
+  // voxel of this rank leaves on its own)
+  const bool ident_part = ABS && v.identity && tb.part_world > 1u;
+  const bool first = slot != kVhEmpty && (ident_part || min(hd.x, m0.x) == (unsigned)i);  // the owner: the first point of the voxel in input order
   unsigned int total;
   const unsigned int rank = block_rank_of_flag(first, s_w, &total);
   if (tid == 0) __hip_atomic_store(counts + blockIdx.x, ((unsigned long long)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (ABS && v.identity) {  // (uniform) the cloud passes unfiltered; the voxels' owners still hand their slots back
+  if (ABS && v.identity && !ident_part) {  // (uniform) the cloud passes unfiltered; the voxels' owners still hand their slots back
     if (in_range) { out[i] = p0; pcl_out[i] = (unsigned)i; }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) *n_out = n;
     if (first) {
@@ -642,7 +667,7 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
   }
   float4 cen = make_float4(0.f, 0.f, 0.f, 0.f);
   if (first) {
-    const unsigned int cnt = hd.y + 1u;  // points of the voxel, this one included
+    const unsigned int cnt = ident_part ? 1u : hd.y + 1u;  // points of the voxel, this one included
     float sx = __fadd_rn(0.f, p0.x), sy = __fadd_rn(0.f, p0.y), sz = __fadd_rn(0.f, p0.z), st = __fadd_rn(0.f, p0.w);
     unsigned int m[kVhMembers] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y};
 #pragma unroll
@@ -684,11 +709,20 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
     cen = make_float4(sx / c, sy / c, sz / c, st / c);
   }
   const unsigned int base = owners_below(counts, epoch, s_sum);
-  if (blockIdx.x == gridDim.x - 1 && tid == 0) *n_out = (int)(base + total);  // size of the down-sampled cloud
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {  // size of the down-sampled cloud
+    int n_down = (int)(base + total);
+    if (ABS && tb.part_world > 1u && n_down > tb.part_bound) {  // this rank's share outgrew what the launches behind are sized for
+      n_down = tb.part_bound;
+      __hip_atomic_store(tb.part_overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    *n_out = n_down;
+  }
   if (!first) return;
   const unsigned int pos = base + rank;
   out[pos] = cen;
-  if (ABS) {
+  if (ident_part) {
+    pcl_out[pos] = (unsigned)i;
+  } else if (ABS) {
     // PCL's index of this voxel, from any of its points (the first): as k_vhash_insert computes it
     const int i0 = (int)(floorf(p0.x * v.inv_leaf) - (float)v.min_b[0]);
     const int i1 = (int)(floorf(p0.y * v.inv_leaf) - (float)v.min_b[1]);
@@ -727,20 +761,30 @@ void launch_voxel_keys(const float4* pts, int n, const unsigned int* mm, const u
     hipLaunchKernelGGL(k_voxel_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, keys, pcl_keys,
                        filtered_dev, samples, sample_width);
 }
-static VhTable vh_table(const VoxelHashBuffers* vh, int n) {
+// fused: the table is keyed by absolute voxel coordinates (the only form a job can share by voxel)
+static VhTable vh_table(const VoxelHashBuffers* vh, int n, bool fused) {
   VhTable tb;
   memset(&tb, 0, sizeof(tb));
   if (!vh) return tb;
   tb.slots = static_cast<VhSlot*>(vh->slots);
   tb.mask = (unsigned int)voxel_hash_slots(n) - 1u;
   tb.slot_of = vh->slot_of; tb.next = vh->next; tb.crowded = vh->crowded;
+  if (fused && vh->part_world > 1) {
+    tb.part_world = (unsigned int)vh->part_world; tb.part_rank = (unsigned int)vh->part_rank;
+    tb.part_bound = voxel_partition_bound(n, vh->part_world); tb.part_overflow = vh->part_overflow;
+  }
   return tb;
+}
+int voxel_partition_bound(int n, int world) {
+  if (world <= 1) return n;
+  const long long b = (long long)n / world + (long long)n / (4 * world) + 2048;  // the mean share + 25 % + 2048: tens of standard deviations of a hashed split
+  return (int)(b < n ? b : n);
 }
 static DeskewIo deskew_io(const DeskewPlan& p) {
   DeskewIo io;
   io.in = p.in; io.out = p.out; io.n = p.n; io.sorted = p.sorted; io.extent = p.extent; io.bbox_rows = p.bbox_rows;
   io.leaf = p.leaf;
-  io.tb = vh_table(p.vh, p.n);
+  io.tb = vh_table(p.vh, p.n, true);
   io.ctrl_src = static_cast<const uint4*>(p.ctrl_src); io.ctrl_dst = static_cast<uint4*>(p.ctrl_dst); io.ctrl_vec = (int)(p.ctrl_bytes / 16);
   return io;
 }
@@ -790,7 +834,7 @@ void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, con
                        int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, unsigned int epoch,
                        hipStream_t s) {
   if (n <= 0) return;
-  const VhTable tb = vh_table(&vh, n);
+  const VhTable tb = vh_table(&vh, n, (stages & 4) != 0);
   const int nb = nblk(n, 256);
   if (stages & 1) hipLaunchKernelGGL(k_vhash_insert, dim3(nb), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, tb, filtered);
   if (stages & 2) hipLaunchKernelGGL(k_vhash_emit<false>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.counts, epoch, out, n_out, pcl_out, nullptr, 0, leaf, filtered);

@@ -2,7 +2,8 @@
 
 argv: rank world uid_hex transport out.npz [device]
 Every rank builds the same map and receives the WHOLE scan (LII_WORKER_PARTITION=library, the default: the library splits the
-down-sampled cloud) or its contiguous block of it (=caller: the round-1 arrangement, no voxel filter), attaches the communicator
+down-sampled cloud by index; =voxel: by voxel, lii_comm_set_partition(h, 2)) or its contiguous block of it (=caller: the round-1
+arrangement, no voxel filter), attaches the communicator
 and runs (a) one host-driven pass at the common start state (lii_iekf_iterate: only the summation order differs between
 worlds), (b) the whole per-scan call - de-skew, voxel filter ON, device-driven iterated update - through lii_scan_register,
 (c) map_incremental.  The final state, the report, the 91 sums and the map size after every scan are saved.
@@ -21,7 +22,8 @@ def main():
     uid, transport, out = bytes.fromhex(sys.argv[3]), sys.argv[4], sys.argv[5]
     device = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     n_scans = int(os.environ.get("LII_WORKER_SCANS", "3"))
-    caller_partition = os.environ.get("LII_WORKER_PARTITION", "library") == "caller"
+    partition = os.environ.get("LII_WORKER_PARTITION", "library")
+    caller_partition = partition == "caller"
     leaf = float(os.environ.get("LII_WORKER_LEAF", "0.1"))
     import bench
     import lidar_imu_init_amd as lii
@@ -34,8 +36,8 @@ def main():
     reg.map_build(map_pts)
     if world > 1 or transport == "rccl":
         reg.comm_init(world, rank, uid, transport)
-        reg.comm_set_partition(not caller_partition)
-    states, reports, sums, map_sizes, n_down = [], [], [], [], []
+        reg.comm_set_partition({"caller": 0, "library": 1, "voxel": 2}[partition])
+    states, reports, sums, sums_b, map_sizes, n_down, n_local = [], [], [], [], [], [], []
     for k in range(n_scans):
         R = synth.rot_zyx(0.03, -0.02, 0.4 + 0.05 * k)
         p = np.array([0.8 + 0.1 * k, -0.6, 0.1])
@@ -60,13 +62,17 @@ def main():
             n_down.append(nd)
             s91 = reg.iekf_iterate(st, True, True)  # at the common start state
             rep = reg.scan_register(st, prop, imu_poses=table, leaf=leaf, max_iterations=5, imu_en=True, scan_dev=reg.device_scan(scan), scan_sorted=True)
+            n_local.append(len(reg.scan_download(1)))  # what THIS rank holds of the cloud: its voxels (a split by voxel), or all of it
+            # one more host-driven pass, now on the cloud lii_scan_register left behind (a split by voxel exists only there), at the
+            # common start state: again only the summation order differs between worlds
+            sums_b.append(np.asarray(reg.iekf_iterate(prop, True, True)).copy())
             reg.map_incremental(st)
             map_sizes.append(reg.map_size())
         states.append(st.pod.copy())
         reports.append([rep["iterations"], rep["searches"], rep["effect_num"], int(rep["converged"])])
         sums.append(np.asarray(s91).copy())
-    np.savez(out, states=np.array(states), reports=np.array(reports), sums=np.array(sums), map_sizes=np.array(map_sizes),
-             n_down=np.array(n_down), map_final=reg.map_download() if not caller_partition else np.zeros((0, 3), np.float32),
+    np.savez(out, states=np.array(states), reports=np.array(reports), sums=np.array(sums), sums_b=np.array(sums_b), map_sizes=np.array(map_sizes),
+             n_down=np.array(n_down), n_local=np.array(n_local), describe=reg.comm_describe() if world > 1 else "", map_final=reg.map_download() if not caller_partition else np.zeros((0, 3), np.float32),
              transport=reg.comm_transport())
     reg.close()
 

@@ -130,6 +130,42 @@ def test_three_ranks(tmp_path):
         assert np.array_equal(_rows(three[0]["map_final"]), _rows(three[r]["map_final"]))
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_split_the_cloud_by_voxel(tmp_path, world):
+    """lii_comm_set_partition(h, 2) ("a voxel-key partition"): inside lii_scan_register every rank de-skews the
+    scan, but inserts, filters, searches and fits only the voxels whose key hashes to it, and lii_map_incremental decides for those
+    and EXCHANGES the two insert lists (lii_exchange.hip) instead of repeating the search for the whole cloud."""
+    env = {"LII_WORKER_PARTITION": "voxel"}
+    one = _run_ranks(tmp_path, 1, env=env)[0]
+    many = _run_ranks(tmp_path, world, env=env)
+    assert all(str(t["transport"]) == "mailbox" and "split by voxel" in str(t["describe"]) for t in many), [str(t["describe"]) for t in many]
+    for r in range(1, world):
+        for key in ("states", "reports", "sums", "sums_b", "map_sizes"):
+            assert np.array_equal(many[0][key], many[r][key]), key
+        assert np.array_equal(_rows(many[0]["map_final"]), _rows(many[r]["map_final"]))
+    # the shares: disjoint and complete (they add up to the single-rank cloud), and even (a hash of the voxel key deals them out)
+    shares = np.array([t["n_local"] for t in many])
+    assert np.array_equal(shares.sum(axis=0), one["n_local"]), (shares, one["n_local"])
+    assert np.all(np.abs(shares - one["n_local"] / world) <= 0.1 * one["n_local"] / world), shares
+    # the same 91 sums as the single-rank job up to the order of the additions - on the partitioned cloud (sums_b) as on the one
+    # split by index (sums: the stand-alone filter in front of lii_iekf_iterate is not fused, hence not split by voxel)
+    for key in ("sums", "sums_b"):
+        ref, got = one[key], many[0][key]
+        assert np.max(np.abs(ref[0] - got[0])) <= 1e-11 * np.max(np.abs(ref[0])), key
+        assert np.max(np.abs(ref - got)) <= 1e-6 * np.max(np.abs(ref)), key
+    assert np.array_equal(one["reports"][:, [0, 1, 3]], many[0]["reports"][:, [0, 1, 3]])
+    assert np.all(np.abs(one["reports"][:, 2] - many[0]["reports"][:, 2]) <= 2)
+    assert np.max(np.abs(one["states"][:, :12] - many[0]["states"][:, :12])) <= 1e-6
+    # the exchanged lists hold the single-rank job's points in another order: the same map as a set (up to keep-closest ties / ulp flips)
+    assert np.all(np.abs(one["map_sizes"] - many[0]["map_sizes"]) <= 3)
+    # (the final poses of the two jobs differ by ~1e-9 - a threshold flip in a later pass - so a few hundred of the inserted world
+    # points differ by a float ulp: every point of one map has its partner in the other within 1e-5 m, but for a handful)
+    from scipy.spatial import cKDTree
+    a, b = _rows(one["map_final"]), _rows(many[0]["map_final"])
+    d_ab, d_ba = cKDTree(b).query(a)[0], cKDTree(a).query(b)[0]
+    assert np.sum(d_ab > 1e-5) <= 5 and np.sum(d_ba > 1e-5) <= 5, (len(a), len(b), np.sum(d_ab > 1e-5), np.sum(d_ba > 1e-5))
+
+
 def test_caller_partitioned_ranks(tmp_path):
     """lii_comm_set_partition(0): every rank hands over its own block of an unfiltered scan (the round-1 arrangement)."""
     env = {"LII_WORKER_PARTITION": "caller"}
