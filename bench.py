@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--kernel-profile-steps", type=int, default=64, help="steps of the per-launch profile pass (roofline.kernels / roofline.scan; 0: none)")
     ap.add_argument("--no-calibration", action="store_true", help="leave the calibration record (GPU LI-Init vs oracle / reference result / ground truth) out of the line")
     ap.add_argument("--no-calibration-stream", action="store_true", help="calibration record: the reference's committed run only, not the synthetic LO -> LI-Init stream")
+    ap.add_argument("--partition", default=os.environ.get("LII_BENCH_PARTITION", "index"), choices=["index", "voxel"],
+                    help="--gpus N > 1: how the library splits the down-sampled cloud over the ranks (lii_comm_set_partition): contiguous blocks, or "
+                         "by voxel inside the fused filter; `value` is measured with this one, the other is timed beside it (`partitions`)")
     ap.add_argument("--prime", type=int, default=150, help="untimed runtime-priming steps before the warm-up")
     ap.add_argument("--scans", type=int, default=8, help="distinct resident scans cycled through")
     ap.add_argument("--cell-size", type=float, default=0.0, help="k-NN grid cell edge [m]; 0 = 2 x filter_size_map")
@@ -223,11 +226,15 @@ def main():
                         filter_size_map=wl["fs_map"], map_cell_size=args.cell_size, device=local_rank)
     def attach(transport):
         """(Re-)creates the job's communicator with the named transport on every rank."""
+        if os.environ.get("LII_BENCH_DEBUG"):
+            print(f"[bench rank {rank}] attach {transport} / {partition_now[0]}", file=sys.stderr, flush=True)
         reg.comm_destroy()
         uid = [reg.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         reg.comm_init(world, rank, uid[0], transport)
+        reg.comm_set_partition(partition_now[0])
 
+    partition_now = [args.partition]
     if world > 1:
         attach(os.environ.get("LII_BENCH_TRANSPORT", "auto"))
     reg.map_build(wl["map"])
@@ -385,12 +392,26 @@ def main():
                 continue
             used = reg.comm_transport()
             transports[used if n_run == 0 else t] = {"value": args.steps / d, "ms_per_step": 1e3 * d / args.steps, "transport": used,
-                                                     "rccl_ranks": reg.comm_rccl_ranks(), "avg_iterations": iters_total[0] / args.steps}
+                                                     "rccl_ranks": reg.comm_rccl_ranks(), "avg_iterations": iters_total[0] / args.steps,
+                                                     "describe": reg.comm_describe()}
             if n_run == 0:
                 dt, value_transport, value_rccl_ranks = d, used, reg.comm_rccl_ranks()
                 last_pose_value = np.array(last.pod[:12]) if last is not None else None
-        if first != "auto" or len(others):
-            attach(first)  # the rest of the run (parity calls) on the transport `value` was measured with
+        # ... and once more on the first transport with the OTHER split of the cloud
+        partitions = {args.partition: {"value": args.steps / dt, "ms_per_step": 1e3 * dt / args.steps, "describe": transports[value_transport].get("describe")}}
+        other = "voxel" if args.partition == "index" else "index"
+        try:
+            if os.environ.get("LII_BENCH_ONE_PARTITION") == "1":
+                raise RuntimeError("not timed (LII_BENCH_ONE_PARTITION=1)")
+            partition_now[0] = other
+            attach(first)
+            d = timed_region(0)
+            partitions[other] = {"value": args.steps / d, "ms_per_step": 1e3 * d / args.steps, "describe": reg.comm_describe(),
+                                 "avg_iterations": iters_total[0] / args.steps}
+        except Exception as e:
+            partitions[other] = {"error": str(e)[:200]}
+        partition_now[0] = args.partition
+        attach(first)  # the rest of the run (parity calls) on the transport and split `value` was measured with
     else:
         dt = timed_region(args.prime)
         value_transport, value_rccl_ranks = "none", 0
@@ -590,6 +611,8 @@ def main():
                                                "kernels: profiles/r04_timeline.md")
         if transports is not None:
             out["transports"] = transports
+            out["partitions"] = partitions
+            out["config"]["partition"] = args.partition
         if pipeline is not None:
             out["complete_pipeline"] = pipeline
         if not args.no_cpu_baseline and args.gpus == 1:

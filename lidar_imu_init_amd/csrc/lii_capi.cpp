@@ -219,7 +219,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     // (lii_map_incremental folds its list through the batch sort, as lii_map_add_points does, instead of the hash table), "no_fuse"
     // (lii_scan_register keeps the de-skew and the insert of the hashed voxel filter in separate launches), "no_fast" (a
     // time-sorted scan takes the general path of lii_scan_register too: k_time_extent in front of the de-skew), "force_rebuild"
-    // (every in-place map update takes the branch that rebuilds the index first)
+    // (every in-place map update takes the branch that rebuilds the index first), "no_gather" (a sharded job sets up no gather areas:
+    // its map update repeats the search instead of exchanging the lists)
     const std::string t(v);
     h->map_tight = t.find("map_tight") != std::string::npos;
     const size_t q = t.find("plan_force=");
@@ -232,6 +233,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     h->no_fuse = t.find("no_fuse") != std::string::npos;
     h->no_fast_prologue = t.find("no_fast") != std::string::npos;
     h->test_force_rebuild = t.find("force_rebuild") != std::string::npos;
+    h->no_gather = t.find("no_gather") != std::string::npos;
   }
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;

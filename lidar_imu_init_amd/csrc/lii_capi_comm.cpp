@@ -58,7 +58,7 @@ int comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[1
       if (const char* c = std::strchr(t, ',')) wait_s = std::atof(c + 1);
     }
     std::string why;
-    if (mailbox_open(id_in, n_ranks, rank, wait_s, transport != LII_COMM_MAILBOX_HOST, h->cfg.max_scan_points, &h->net.mailbox, &why) == 0) {
+    if (mailbox_open(id_in, n_ranks, rank, wait_s, transport != LII_COMM_MAILBOX_HOST, h->no_gather ? 0 : h->cfg.max_scan_points, &h->net.mailbox, &why) == 0) {
       if (transport == LII_COMM_MAILBOX && !h->net.mailbox.d_peers) {  // asked for by name: no silent change of the transport
         mailbox_close(&h->net.mailbox);
         h->net.n_ranks = 1; h->net.rank = 0;

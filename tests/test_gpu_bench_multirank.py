@@ -30,12 +30,12 @@ def _single():
     return _line(p.stdout)
 
 
-def _sharded(n, port, one_device):
+def _sharded(n, port, one_device, partition="index"):
     env = dict(os.environ)
     if one_device:
         env["LII_BENCH_ONE_DEVICE"] = "1"
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + COMMON,
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--partition", partition] + COMMON,
                        cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     return _line(p.stdout)
@@ -52,13 +52,19 @@ def _check(d, one, n, expect_transports):
     # the same stream, the same steps: the sharded job ends where the single-rank job ends (91 sums re-associated)
     assert np.max(np.abs(np.array(d["last_state_pose"]) - np.array(one["last_state_pose"]))) <= 1e-6
     assert d["config"]["avg_iterations"] == one["config"]["avg_iterations"]
+    # both splits of the cloud were timed on the first transport (`value` with config.partition), and the split by voxel was really one
+    for part in ("index", "voxel"):
+        assert d["partitions"][part].get("value", 0) > 0, d["partitions"]
+    assert "split by voxel" in d["partitions"]["voxel"]["describe"] and "split by index" in d["partitions"]["index"]["describe"]
+    assert d["partitions"][d["config"]["partition"]]["value"] == d["value"]
 
 
-def test_bench_two_ranks_on_one_device():
+@pytest.mark.parametrize("partition", ["index", "voxel"])
+def test_bench_two_ranks_on_one_device(partition):
     one = _single()
-    d = _sharded(2, 29611, one_device=True)
+    d = _sharded(2, 29611 + (partition == "voxel"), one_device=True, partition=partition)
     _check(d, one, 2, ["mailbox", "mailbox_host"])
-    assert d["config"]["rccl_ranks"] == 0
+    assert d["config"]["rccl_ranks"] == 0 and d["config"]["partition"] == partition
 
 
 def test_bench_two_ranks_on_two_devices():
@@ -66,6 +72,6 @@ def test_bench_two_ranks_on_two_devices():
     if torch.cuda.device_count() < 2:
         pytest.skip("one visible device")
     one = _single()
-    d = _sharded(2, 29612, one_device=False)
+    d = _sharded(2, 29613, one_device=False)
     _check(d, one, 2, ["mailbox", "rccl", "mailbox_host"])
     assert d["transports"]["rccl"]["rccl_ranks"] == 2
