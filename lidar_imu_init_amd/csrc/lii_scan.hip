@@ -193,12 +193,18 @@ __device__ __forceinline__ void deskew_bbox(float4 q, bool in_range, unsigned in
 constexpr unsigned int kVhEmpty = 0xFFFFFFFFu;
 constexpr int kVhMembers = 10;  // the first arrivals of a voxel (its creator included) sit in the slot itself
 struct __attribute__((aligned(64))) VhSlot {
+  // The first 16 bytes decide who OWNS the voxel (min(first, creator)); the emit launch reads them with one 16-byte load and the
+  // owner hands the slot back with one 16-byte store, so that a lane which looks at the slot while its owner is already freeing
+  // it sees either the state before or the state after - never `first` of one and `creator` of the other (round 4 kept the creator
+  // in the second 16 bytes: a lane that saw the first half old and the second half freed took itself for the owner of a
+  // two-point voxel without members.  Rare - the two loads of a lane are cycles apart - until four processes time-shared one device).
   unsigned long long key;  // all ones = free.  Fused form: packed absolute voxel coordinates; separate form: the PCL voxel index
   unsigned int first;      // smallest point index among the LATER arrivals of the voxel (atomicMin); kVhEmpty: none
+  unsigned int creator;    // the point that created the slot (member 0); kVhEmpty in a free slot
   unsigned int count;      // later arrivals so far (atomicAdd): the voxel holds count + 1 points
   unsigned int head;       // arrivals beyond kVhMembers: a list through next[]; kVhEmpty = none
+  unsigned int members[kVhMembers - 1];  // [k - 1]: the k-th later arrival
   unsigned int pad;
-  unsigned int members[kVhMembers];  // [0]: the point that created the slot; [k]: the k-th later arrival
 };
 static_assert(sizeof(VhSlot) == 64, "one cache line per slot");
 struct VhTable {
@@ -241,11 +247,11 @@ __device__ __forceinline__ void vh_insert(const VhTable& tb, unsigned long long 
   }
   VhSlot* s = tb.slots + slot;
   if (created) {
-    s->members[0] = (unsigned)i;
+    s->creator = (unsigned)i;
   } else {
     atomicMin(&s->first, (unsigned)i);
     const unsigned int k = atomicAdd(&s->count, 1u) + 1u;
-    if (k < (unsigned)kVhMembers) s->members[k] = (unsigned)i;
+    if (k < (unsigned)kVhMembers) s->members[k - 1u] = (unsigned)i;
     else {
       tb.next[i] = atomicExch(&s->head, (unsigned)i);
       // (the watch that changes the handle over to the sort must see the same number on every rank: a rank that holds a share of
@@ -532,9 +538,9 @@ __global__ __launch_bounds__(256) void k_vh_clear(VhSlot* slots, unsigned int n_
   const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_slots) return;
   VhSlot s;
-  s.key = ~0ull; s.first = kVhEmpty; s.count = 0u; s.head = kVhEmpty; s.pad = 0u;
+  s.key = ~0ull; s.first = kVhEmpty; s.creator = kVhEmpty; s.count = 0u; s.head = kVhEmpty; s.pad = 0u;
 #pragma unroll
-  for (int k = 0; k < kVhMembers; k++) s.members[k] = kVhEmpty;
+  for (int k = 0; k < kVhMembers - 1; k++) s.members[k] = kVhEmpty;
   slots[i] = s;
 }
 // Folds the bounding-box rows the de-skew workgroups left behind (every workgroup for itself: a few KB from L2).
@@ -639,14 +645,15 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
   unsigned long long key = 0;
   if (slot != kVhEmpty) {  // the slot's line in four requests
     const uint4* line = reinterpret_cast<const uint4*>(sl);
-    const uint4 a = line[0];
+    const uint4 a = line[0];  // key, first, creator: ONE request decides the ownership (see VhSlot)
     key = ((unsigned long long)a.y << 32) | a.x;
-    hd = make_uint4(a.z, a.w, 0u, 0u);  // first, count
-    const uint4 b = line[1];            // head, pad, members 0..1
-    hd.z = b.x;
-    m0 = make_uint4(b.z, b.w, 0u, 0u);
-    const uint4 c = line[2], d = line[3];  // members 2..5, 6..9
-    m0.z = c.x; m0.w = c.y; m1 = make_uint4(c.z, c.w, d.x, d.y); m2 = make_uint2(d.z, d.w);
+    hd.x = a.z;
+    m0.x = a.w;
+    const uint4 b = line[1];  // count, head, members 1..2
+    hd.y = b.x; hd.z = b.y;
+    m0.y = b.z; m0.z = b.w;
+    const uint4 c = line[2], d = line[3];  // members 3..6, 7..9 (+ padding)
+    m0.w = c.x; m1 = make_uint4(c.y, c.z, c.w, d.x); m2 = make_uint2(d.y, d.z);
   }
   // (a voxel-partitioned job whose cloud passes unfiltered - PCL's overflow guard - still shares it by voxel: every point of a
   // voxel of this rank leaves on its own)
@@ -660,8 +667,8 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
     if (blockIdx.x == gridDim.x - 1 && tid == 0) *n_out = n;
     if (first) {
       uint4* line = reinterpret_cast<uint4*>(sl);
-      line[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, kVhEmpty, 0u);
-      line[1] = make_uint4(kVhEmpty, 0u, kVhEmpty, kVhEmpty);
+      line[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, kVhEmpty, kVhEmpty);
+      line[1] = make_uint4(0u, kVhEmpty, kVhEmpty, kVhEmpty);
     }
     return;
   }
@@ -733,8 +740,8 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
   }
   // the slot is free again for the next scan
   uint4* line = reinterpret_cast<uint4*>(sl);
-  line[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, kVhEmpty, 0u);
-  line[1] = make_uint4(kVhEmpty, 0u, kVhEmpty, kVhEmpty);
+  line[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, kVhEmpty, kVhEmpty);
+  line[1] = make_uint4(0u, kVhEmpty, kVhEmpty, kVhEmpty);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -804,13 +811,15 @@ void launch_deskew_imu(const DeskewPlan& p, const double* poses_host, const doub
   const DeskewIo io = deskew_io(p);
   const int nb = nblk(p.n, 256) + (io.ctrl_vec > 0 ? 1 : 0);
   const bool fuse = p.vh != nullptr;
-  const int kp = !poses_host ? 0 : (K <= 32 ? 32 : (K <= 64 ? 64 : 0));
+  const int kp = !poses_host ? 0 : (K <= 16 ? 16 : (K <= 32 ? 32 : (K <= 64 ? 64 : 0)));
   if (fuse) {
-    if (kp == 32) launch_deskew_imu_t<true, 32>(io, u, K, poses_host, poses_dev, nb, s);
+    if (kp == 16) launch_deskew_imu_t<true, 16>(io, u, K, poses_host, poses_dev, nb, s);
+    else if (kp == 32) launch_deskew_imu_t<true, 32>(io, u, K, poses_host, poses_dev, nb, s);
     else if (kp == 64) launch_deskew_imu_t<true, 64>(io, u, K, poses_host, poses_dev, nb, s);
     else launch_deskew_imu_t<true, 0>(io, u, K, poses_host, poses_dev, nb, s);
   } else {
-    if (kp == 32) launch_deskew_imu_t<false, 32>(io, u, K, poses_host, poses_dev, nb, s);
+    if (kp == 16) launch_deskew_imu_t<false, 16>(io, u, K, poses_host, poses_dev, nb, s);
+    else if (kp == 32) launch_deskew_imu_t<false, 32>(io, u, K, poses_host, poses_dev, nb, s);
     else if (kp == 64) launch_deskew_imu_t<false, 64>(io, u, K, poses_host, poses_dev, nb, s);
     else launch_deskew_imu_t<false, 0>(io, u, K, poses_host, poses_dev, nb, s);
   }

@@ -67,6 +67,14 @@ def test_bench_two_ranks_on_one_device(partition):
     assert d["config"]["rccl_ranks"] == 0 and d["config"]["partition"] == partition
 
 
+def test_bench_four_ranks_on_one_device():
+    """Four processes time-sharing one device: wavefronts are preempted in the middle of kernels, which stretches every window between
+    two dependent loads - the arrangement that exposed a torn read of a voxel-filter slot in round 4 (VhSlot, lii_scan.hip)."""
+    one = _single()
+    d = _sharded(4, 29615, one_device=True, partition="voxel")
+    _check(d, one, 4, ["mailbox", "mailbox_host"])
+
+
 def test_bench_two_ranks_on_two_devices():
     import torch
     if torch.cuda.device_count() < 2:

@@ -2,7 +2,7 @@
 # Full GPU suite + default bench + driver-form bench.  Usage: gpurun -- 'bash tools/gpu_suite.sh <label>'
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$1; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/pytest.txt; cat $O/pytest.txt
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_full.txt 2>&1; grep -a -E "passed|failed|error|FAILED|ERROR|^E " $O/pytest_full.txt | tail -25 > $O/pytest.txt; cat $O/pytest.txt
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.err
 python - <<PY
 import json
