@@ -23,7 +23,8 @@ extern "C" {
                              3: lii_params_*, lii_comm_set_partition (library-side split of the down-sampled cloud)
                              4: lii_scan_upload_next / lii_scan_advance (the next scan travels while the current one registers)
                              5: LII_COMM_MAILBOX = the peer-mapped HBM mailbox (HIP IPC), LII_COMM_MAILBOX_HOST, lii_comm_rccl_ranks
-                             6: lii_scan_job::scan_sorted (struct_size 56; a job of size 48 - ABI 5 - is still accepted) */
+                             6: lii_scan_job::scan_sorted (struct_size 56; a job of size 48 - ABI 5 - is still accepted), lii_last_kernel_profile,
+                                lii_comm_describe, lii_comm_set_partition(h, 2) (split by voxel) */
 
 enum lii_status {
   LII_OK = 0,
@@ -337,12 +338,22 @@ int lii_li_init_set_device(lii_handle h, int32_t on_device);
  * torch.distributed broadcast), every rank calls lii_comm_init with the SAME state / options per scan; afterwards
  * lii_iekf_iterate / lii_iekf_update / lii_scan_register sum the 91 normal-equation scalars (fp64, in rank order, so every
  * rank forms the bit-identical sum and takes the same decisions) over the ranks.
- * Partition (lii_comm_set_partition; default 1): every rank hands over the WHOLE scan and holds the whole map; the de-skew and
- *   the voxel filter run replicated (their output is bit-identical on every rank, so a voxel is never split between ranks)
- *   and rank r registers the contiguous block [n r / N, n (r + 1) / N) of the down-sampled cloud, which the filter emits in
- *   the order of the voxels' first points - a stretch of the sweep per rank.  The sharded result equals the single-GPU result up to the
- *   re-association of the 91 sums.  lii_map_incremental of a sharded job repeats the last search for the whole cloud (no
- *   exchange) so that every rank applies the identical insert lists.  Partition 0: the caller hands every rank its own points.
+ * Partition (lii_comm_set_partition; default 1): every rank hands over the WHOLE scan and holds the whole map.
+ *   1 - by index: the de-skew and the voxel filter run replicated (their output is bit-identical on every rank, so a voxel is never
+ *       split between ranks) and rank r registers the contiguous block [n r / N, n (r + 1) / N) of the down-sampled cloud, which the
+ *       filter emits in the order of the voxels' first points - a stretch of the sweep per rank.
+ *   2 - by voxel (SURVEY.md section 8e "a voxel-key partition"): where the voxel filter's insert is fused into the de-skew
+ *       (lii_scan_register with leaf > 0; the hashed filter is then used for every scan) every rank de-skews the scan but inserts,
+ *       filters, searches and fits only the voxels whose key hashes to it (~ 1 / N of them, +- a percent, whatever the scene);
+ *       lii_downsample's / lii_scan_download's view of the down-sampled cloud is then this rank's share.  Elsewhere (stand-alone
+ *       lii_downsample, leaf 0) the split is by index.  A share that outgrows n / N + 25 % + 2048 points fails the update with
+ *       LII_ERR_CAPACITY.  Needs the peer-mapped mailbox (other transports stay with 1; lii_comm_describe tells).
+ *   0 - the caller hands every rank its own points.
+ *   Either way the sharded result equals the single-GPU result up to the re-association of the 91 sums.
+ *   lii_map_incremental of a sharded job: every rank decides for ITS points, and the two insert lists (PointToAdd /
+ *   PointNoNeedDownsample, src/laserMapping.cpp:516-559) are exchanged - pushed into every rank's gather area behind the mailbox
+ *   slots and put together in rank order - so that every replica of the map applies the identical batch.  On a transport without
+ *   gather areas (host-memory mailbox, RCCL) a job split by index repeats the last search for the whole cloud instead (no exchange).
  * Transports:
  *   LII_COMM_MAILBOX       ranks of ONE node; the exchange runs inside the reduce+solve kernel (no extra launch, no
  *                          collective-library call).  Every rank keeps the slots it reads in fine-grained HBM, exported through
@@ -365,7 +376,7 @@ int lii_comm_transport(lii_handle h, int32_t* transport); /* the transport in us
  * possible: device 0 cannot access its peer 0000:c1:00.0 (hipDeviceCanAccessPeer)"); LII_DIAG=1 prints it at set-up. */
 int lii_comm_describe(lii_handle h, char* out, int32_t capacity);
 int lii_comm_rccl_ranks(lii_handle h, int32_t* n_ranks);  /* ncclCommCount of the attached RCCL communicator; 0: none attached */
-int lii_comm_set_partition(lii_handle h, int32_t library_partition);
+int lii_comm_set_partition(lii_handle h, int32_t library_partition);  /* 0 caller | 1 by index (default) | 2 by voxel */
 int lii_comm_destroy(lii_handle h);
 
 /* ---------------------------------------------------------------- parameter surface (config/<sensor>.yaml + launch/<sensor>.launch)
