@@ -186,7 +186,7 @@ def main():
     ap.add_argument("--kernel-profile-steps", type=int, default=64, help="steps of the per-launch profile pass (roofline.kernels / roofline.scan; 0: none)")
     ap.add_argument("--no-calibration", action="store_true", help="leave the calibration record (GPU LI-Init vs oracle / reference result / ground truth) out of the line")
     ap.add_argument("--no-calibration-stream", action="store_true", help="calibration record: the reference's committed run only, not the synthetic LO -> LI-Init stream")
-    ap.add_argument("--partition", default=os.environ.get("LII_BENCH_PARTITION", "index"), choices=["index", "voxel"],
+    ap.add_argument("--partition", default=os.environ.get("LII_BENCH_PARTITION", "voxel"), choices=["index", "voxel"],
                     help="--gpus N > 1: how the library splits the down-sampled cloud over the ranks (lii_comm_set_partition): contiguous blocks, or "
                          "by voxel inside the fused filter; `value` is measured with this one, the other is timed beside it (`partitions`)")
     ap.add_argument("--prime", type=int, default=150, help="untimed runtime-priming steps before the warm-up")
@@ -239,9 +239,10 @@ def main():
         attach(os.environ.get("LII_BENCH_TRANSPORT", "auto"))
     reg.map_build(wl["map"])
     reg.map_commit()
-    # Every rank receives the WHOLE scan (and holds the whole map): de-skew + voxel filter run replicated, the library splits
-    # the down-sampled cloud (in the order of the voxels' first points) into contiguous blocks (lii_comm_set_partition, default) - sharded == unsharded
-    # up to the re-association of the 91 sums (tests/test_gpu_multirank.py).
+    # Every rank receives the WHOLE scan (and holds the whole map) and the library splits the work (lii_comm_set_partition): by voxel
+    # (--partition voxel, the default here: every rank de-skews the scan but inserts, filters, searches and fits only the voxels whose
+    # key hashes to it) or by index (de-skew + voxel filter replicated, contiguous blocks of the down-sampled cloud) - sharded ==
+    # unsharded up to the re-association of the 91 sums either way (tests/test_gpu_multirank.py).
     dev_scans = [reg.device_scan(s) for s in wl["scans"]]
     host_scans = [np.ascontiguousarray(s) for s in wl["scans"]]
     states0, tables = start_states(wl)

@@ -58,6 +58,7 @@ RegistrationBuffers reg_buffers(const lii_context* c) {
   rb.cap = c->cfg.max_scan_points;
   rb.shard_rank = c->net.rank;
   rb.shard_world = (c->net.n_ranks > 1 && c->net.library_partition && !c->body_partitioned) ? c->net.n_ranks : 1;
+  if (c->solo_share < -1 && c->net.n_ranks <= 1) { rb.shard_world = -c->solo_share; rb.shard_rank = 0; }
   return rb;
 }
 PoseArg pose_of(const lii_state& s) {
@@ -220,7 +221,9 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     // (lii_scan_register keeps the de-skew and the insert of the hashed voxel filter in separate launches), "no_fast" (a
     // time-sorted scan takes the general path of lii_scan_register too: k_time_extent in front of the de-skew), "force_rebuild"
     // (every in-place map update takes the branch that rebuilds the index first), "no_gather" (a sharded job sets up no gather areas:
-    // its map update repeats the search instead of exchanging the lists)
+    // its map update repeats the search instead of exchanging the lists), "solo_share=<N>" / "solo_share=-<N>" (kernel-timing
+    // rehearsal: ONE process works on rank 0's share of an N-rank job split by voxel / by index, nothing is exchanged - the
+    // durations of a rank's launches without N devices; the result is that of a part of the cloud)
     const std::string t(v);
     h->map_tight = t.find("map_tight") != std::string::npos;
     const size_t q = t.find("plan_force=");
@@ -234,6 +237,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     h->no_fast_prologue = t.find("no_fast") != std::string::npos;
     h->test_force_rebuild = t.find("force_rebuild") != std::string::npos;
     h->no_gather = t.find("no_gather") != std::string::npos;
+    const size_t qs = t.find("solo_share=");
+    if (qs != std::string::npos) h->solo_share = int(std::strtol(t.c_str() + qs + 11, nullptr, 0));
   }
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;
@@ -327,6 +332,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   h->h_poses = reinterpret_cast<lii_pose6d*>(reinterpret_cast<char*>(h->h_ctrl) + kCtrlBytes);
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_res), sizeof(IekfResult), hipHostMallocMapped));
   std::memset(h->h_res, 0, sizeof(IekfResult));
+  partition_refresh(h);
   CK(hipEventCreateWithFlags(&h->ev_poses, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&h->ev_mapflag, hipEventDisableTiming));

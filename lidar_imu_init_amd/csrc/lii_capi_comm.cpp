@@ -25,6 +25,7 @@ void partition_refresh(lii_handle h) {
   h->vh.part_world = by_voxel ? h->net.n_ranks : 0;
   h->vh.part_rank = by_voxel ? h->net.rank : 0;
   h->vh.part_overflow = h->h_res ? &h->h_res->part_overflow : nullptr;
+  if (h->solo_share > 1 && h->net.n_ranks <= 1) { h->vh.part_world = h->solo_share; h->vh.part_rank = 0; }  // (LII_TEST=solo_share)
 }
 void comm_drop(lii_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);

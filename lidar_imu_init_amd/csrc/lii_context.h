@@ -113,6 +113,7 @@ struct lii_context {
   bool knn_plan = true;        // LII_KNN_PLAN=0: every k-NN launch is enqueued (IekfCtrl::plan_mask)
   bool test_pred_small = false;
   bool test_force_rebuild = false;  // LII_TEST=force_rebuild: every in-place map update rebuilds the index first (the branch a map low on room takes)
+  int solo_share = 0;             // LII_TEST=solo_share=<N>: kernel-timing rehearsal of one rank's share (N > 1: by voxel, N < -1: by index)
   bool no_gather = false;         // LII_TEST=no_gather: no gather areas behind the mailbox slots (the map update of a sharded job repeats the search)
   bool no_fast_prologue = false;  // LII_TEST=no_fast: a time-sorted scan takes the general path as well (k_time_extent in front of the de-skew)
   bool no_fuse = false;        // LII_TEST=no_fuse: lii_scan_register keeps the de-skew and the voxel filter's insert in separate launches
