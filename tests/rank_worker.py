@@ -62,7 +62,10 @@ def main():
             n_down.append(nd)
             s91 = reg.iekf_iterate(st, True, True)  # at the common start state
             rep = reg.scan_register(st, prop, imu_poses=table, leaf=leaf, max_iterations=5, imu_en=True, scan_dev=reg.device_scan(scan), scan_sorted=True)
-            n_local.append(len(reg.scan_download(1)))  # what THIS rank holds of the cloud: its voxels (a split by voxel), or all of it
+            body_local = reg.scan_download(1)
+            if k == 0:
+                body0 = body_local.copy()
+            n_local.append(len(body_local))  # what THIS rank holds of the cloud: its voxels (a split by voxel), or all of it
             # one more host-driven pass, now on the cloud lii_scan_register left behind (a split by voxel exists only there), at the
             # common start state: again only the summation order differs between worlds
             sums_b.append(np.asarray(reg.iekf_iterate(prop, True, True)).copy())
@@ -72,7 +75,7 @@ def main():
         reports.append([rep["iterations"], rep["searches"], rep["effect_num"], int(rep["converged"])])
         sums.append(np.asarray(s91).copy())
     np.savez(out, states=np.array(states), reports=np.array(reports), sums=np.array(sums), sums_b=np.array(sums_b), map_sizes=np.array(map_sizes),
-             n_down=np.array(n_down), n_local=np.array(n_local), describe=reg.comm_describe() if world > 1 else "", map_final=reg.map_download() if not caller_partition else np.zeros((0, 3), np.float32),
+             n_down=np.array(n_down), n_local=np.array(n_local), body0=body0 if not caller_partition and n_scans > 0 else np.zeros((0, 4), np.float32), describe=reg.comm_describe() if world > 1 else "", map_final=reg.map_download() if not caller_partition else np.zeros((0, 3), np.float32),
              transport=reg.comm_transport())
     reg.close()
 

@@ -147,6 +147,14 @@ def test_ranks_split_the_cloud_by_voxel(tmp_path, world):
     shares = np.array([t["n_local"] for t in many])
     assert np.array_equal(shares.sum(axis=0), one["n_local"]), (shares, one["n_local"])
     assert np.all(np.abs(shares - one["n_local"] / world) <= 0.1 * one["n_local"] / world), shares
+    # ... and they are the ones the published hash deals out (lidar_imu_init_amd/sharding.py restates it on the host): the centroid
+    # of a voxel lies inside the voxel, so the single-rank cloud tells every voxel's key
+    from lidar_imu_init_amd import sharding
+    owner = sharding.voxel_rank(sharding.voxel_keys(one["body0"][:, :3], float(os.environ.get("LII_WORKER_LEAF", "0.1"))), world)
+    predicted = np.bincount(owner, minlength=world)
+    assert np.all(np.abs(predicted - shares[:, 0]) <= 2), (predicted, shares[:, 0])  # (a centroid within an ulp of a voxel face)
+    for r in range(world):
+        assert len(many[r]["body0"]) == shares[r, 0]
     # the same 91 sums as the single-rank job up to the order of the additions - on the partitioned cloud (sums_b) as on the one
     # split by index (sums: the stand-alone filter in front of lii_iekf_iterate is not fused, hence not split by voxel)
     for key in ("sums", "sums_b"):
