@@ -174,6 +174,33 @@ def test_ranks_split_the_cloud_by_voxel(tmp_path, world):
     assert np.sum(d_ab > 1e-5) <= 5 and np.sum(d_ba > 1e-5) <= 5, (len(a), len(b), np.sum(d_ab > 1e-5), np.sum(d_ba > 1e-5))
 
 
+def test_list_exchange_equals_the_repeated_search(tmp_path):
+    """A job split by index keeps its replicas identical in two ways: the insert lists of lii_map_incremental are exchanged (gather
+    areas behind the mailbox slots), or - no gather areas: LII_TEST=no_gather here, the host-memory mailbox and RCCL in the field -
+    every rank repeats the search for the whole cloud.  Same decisions, same lists, same order: bit-identical states, sums and map contents."""
+    a = _run_ranks(tmp_path, 2, transport="mailbox")
+    b = _run_ranks(tmp_path, 2, transport="mailbox", env={"LII_TEST": "no_gather"})
+    assert "map lists exchanged" in str(a[0]["describe"]) and "repeats the search" in str(b[0]["describe"])
+    for key in ("states", "reports", "sums", "sums_b", "map_sizes", "n_local"):
+        assert np.array_equal(a[0][key], b[0][key]) and np.array_equal(a[1][key], b[1][key]), key
+    assert np.array_equal(_rows(a[0]["map_final"]), _rows(b[0]["map_final"]))
+
+
+def test_one_process_rehearses_a_share(tmp_path):
+    """LII_TEST=solo_share=<N> (tools/gpu_share.sh: the durations of ONE rank's launches without N devices): rank 0's share of an
+    N-rank job split by voxel (N > 1) or by index (N < -1) in a single process, nothing exchanged."""
+    from lidar_imu_init_amd import sharding
+    one = _run_ranks(tmp_path, 1)[0]
+    by_voxel = _run_ranks(tmp_path, 1, env={"LII_TEST": "solo_share=4"})[0]
+    by_index = _run_ranks(tmp_path, 1, env={"LII_TEST": "solo_share=-4"})[0]
+    owner = sharding.voxel_rank(sharding.voxel_keys(one["body0"][:, :3], 0.1), 4)
+    assert abs(int(by_voxel["n_local"][0]) - int(np.sum(owner == 0))) <= 2
+    assert np.array_equal(by_index["n_local"], one["n_local"])  # (the whole cloud is there; a quarter of it is registered)
+    for part in (by_voxel, by_index):  # a quarter of the effective points, a pose from a quarter of the rows: close to the full job's
+        assert np.all(np.abs(part["reports"][:, 2] - one["reports"][:, 2] / 4) <= 0.1 * one["reports"][:, 2] / 4)
+        assert np.max(np.abs(part["states"][:, :12] - one["states"][:, :12])) <= 5e-3
+
+
 def test_caller_partitioned_ranks(tmp_path):
     """lii_comm_set_partition(0): every rank hands over its own block of an unfiltered scan (the round-1 arrangement)."""
     env = {"LII_WORKER_PARTITION": "caller"}
