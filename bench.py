@@ -182,6 +182,9 @@ def main():
                     help="skip the GPU voxel-grid filter (mapping/filter_size_surf) that the step includes by default")
     ap.add_argument("--map-update", action="store_true",
                     help="also run map_incremental (device-side ikd-Tree Add_Points semantics + index rebuild) every step")
+    ap.add_argument("--map-update-separate", action="store_true",
+                    help="--map-update / the complete pipeline: lii_map_incremental as a call of its own behind lii_scan_register (round 3's form) "
+                         "instead of lii_scan_job::map_update (its launches enqueued behind the update's passes)")
     ap.add_argument("--long-steps", type=int, default=400, help="steps of the second timed region behind `value` (value_long; 0: none; skipped when --steps is larger)")
     ap.add_argument("--kernel-profile-steps", type=int, default=64, help="steps of the per-launch profile pass (roofline.kernels / roofline.scan; 0: none)")
     ap.add_argument("--no-calibration", action="store_true", help="leave the calibration record (GPU LI-Init vs oracle / reference result / ground truth) out of the line")
@@ -270,10 +273,11 @@ def main():
             rep = reg.iekf_update(st, states0[j], max_iterations=wl["max_it"], imu_en=True)
         else:  # the same three stages through the one-call entry point (one host round trip per scan)
             rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=0.0 if args.no_downsample else wl["fs_surf"],
-                                    max_iterations=wl["max_it"], imu_en=True, scan_dev=hand_over, scan_sorted=True)
+                                    max_iterations=wl["max_it"], imu_en=True, scan_dev=hand_over, scan_sorted=True,
+                                    map_update=args.map_update and not args.map_update_separate)
         iters_total[0] += rep["iterations"]
         search_total[0] += rep["searches"]
-        if args.map_update:
+        if args.map_update and (args.map_update_separate or args.separate_calls):
             reg.map_incremental(st)
         return st
 
@@ -291,6 +295,7 @@ def main():
         if not os.path.exists(drv_path):
             raise SystemExit(f"{drv_path} missing - run `python -c 'import __graft_entry__ as g; g.build()'` (or --python-loop)")
         drv = C.CDLL(drv_path)
+        drv.lii_stream_set_map_in_job(0 if args.map_update_separate else 1)
         drv.lii_stream_run.restype = C.c_int
         drv.lii_stream_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]

@@ -17,6 +17,10 @@ extern "C" {
 // the jobs say so (lii_scan_job::scan_sorted).  lii_stream_set_sorted(0) withdraws the claim (A/B, unsorted test streams).
 static int32_t g_scan_sorted = 1;
 void lii_stream_set_sorted(int32_t sorted) { g_scan_sorted = sorted ? 1 : 0; }
+// The map update of a step rides in the registration job (lii_scan_job::map_update: its launches are enqueued behind the update's
+// passes); lii_stream_set_map_in_job(0): lii_map_incremental as a call of its own behind lii_scan_register, the form of round 3 (A/B).
+static int32_t g_map_in_job = 1;
+void lii_stream_set_map_in_job(int32_t in_job) { g_map_in_job = in_job ? 1 : 0; }
 
 typedef struct lii_stream_scan {
   const void* scan_dev;      // device-resident float4 (x, y, z, t_ms), caller-owned
@@ -59,11 +63,12 @@ int lii_stream_run(lii_handle h, const lii_stream_scan* scans, int32_t n_scans, 
     job.scan_dev = sc.scan_dev;
     job.n_scan_dev = sc.n_points;
     job.scan_sorted = g_scan_sorted;
+    job.map_update = (map_update && g_map_in_job) ? 1 : 0;
     rc = lii_scan_register(h, &job, &st, sc.state0, &rep);
     if (rc != LII_OK) return rc;
     totals[0] += rep.iterations;
     totals[1] += rep.searches;
-    if (map_update) {
+    if (map_update && !g_map_in_job) {
       rc = lii_map_incremental(h, &st, nullptr, nullptr);
       if (rc != LII_OK) return rc;
     }
@@ -108,11 +113,12 @@ int lii_stream_run_pipeline(lii_handle h, const lii_stream_scan* scans, const vo
     job.opts.max_iterations = max_iterations;
     job.opts.imu_en = imu_en;
     job.scan_sorted = g_scan_sorted;
+    job.map_update = g_map_in_job;
     rc = lii_scan_register(h, &job, &st, sc.state0, &rep);
     if (rc != LII_OK) return rc;
     totals[0] += rep.iterations;
     totals[1] += rep.searches;
-    rc = lii_map_incremental(h, &st, nullptr, nullptr);
+    if (!g_map_in_job) rc = lii_map_incremental(h, &st, nullptr, nullptr);
     if (rc != LII_OK) return rc;
     if (overlap && k + 1 < steps) {
       rc = lii_scan_advance(h);

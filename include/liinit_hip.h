@@ -24,7 +24,7 @@ extern "C" {
                              4: lii_scan_upload_next / lii_scan_advance (the next scan travels while the current one registers)
                              5: LII_COMM_MAILBOX = the peer-mapped HBM mailbox (HIP IPC), LII_COMM_MAILBOX_HOST, lii_comm_rccl_ranks
                              6: lii_scan_job::scan_sorted (struct_size 56; a job of size 48 - ABI 5 - is still accepted), lii_last_kernel_profile,
-                                lii_comm_describe, lii_comm_set_partition(h, 2) (split by voxel) */
+                                lii_comm_describe, lii_comm_set_partition(h, 2) (split by voxel), lii_scan_job::map_update (the reserved field) */
 
 enum lii_status {
   LII_OK = 0,
@@ -256,7 +256,10 @@ typedef struct lii_scan_job {
                                       skips the reduction that finds them (one launch per scan) and de-skews scan_dev in place of
                                       copying it first.  0: nothing is assumed.  A job that claims an order the scan does not have
                                       gets the A3 quirk / the CV sweep end applied to the wrong point - nothing else depends on it. */
-  int32_t reserved0;
+  int32_t map_update;              /* 1: lii_map_incremental(h, state, NULL, NULL) with the update's final state follows the update inside
+                                      this call (src/laserMapping.cpp:1146 behind :1134) - its launches are enqueued behind the update's passes
+                                      while the device still works on them, instead of after the result has come back.  The caller does NOT
+                                      call lii_map_incremental for this scan.  0 (the value of the formerly reserved field): nothing follows. */
 } lii_scan_job;
 int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, const lii_state* state_propagated,
                       lii_iekf_report* report);

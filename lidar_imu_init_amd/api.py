@@ -46,7 +46,7 @@ class lii_iekf_report(C.Structure):
 class lii_scan_job(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("undistort", C.c_int32), ("imu_poses", C.c_void_p),
                 ("n_imu_poses", C.c_int32), ("leaf", C.c_float), ("opts", lii_iekf_opts), ("scan_dev", C.c_void_p),
-                ("n_scan_dev", C.c_int32), ("scan_sorted", C.c_int32), ("reserved0", C.c_int32)]
+                ("n_scan_dev", C.c_int32), ("scan_sorted", C.c_int32), ("map_update", C.c_int32)]
 
 
 class lii_kernel_profile(C.Structure):
@@ -418,13 +418,15 @@ class Registrar:
                     converged=bool(rep.converged), normal_eq=np.array(rep.normal_eq[:]))
 
     def scan_register(self, state: State, state_prop: State, *, imu_poses=None, cv=False, leaf=0.0, max_iterations=4,
-                      imu_en=False, scan_dev=None, scan_sorted=False):
+                      imu_en=False, scan_dev=None, scan_sorted=False, map_update=False):
         """Undistortion + voxel grid + iterated update in one library call (one host synchronisation).  scan_dev: a
         device_scan() handle to adopt first (what scan_set_device would do, without the separate call).  scan_sorted: the
-        points are in ascending time order (lii_scan_job::scan_sorted)."""
+        points are in ascending time order (lii_scan_job::scan_sorted).  map_update: map_incremental with the final state
+        follows inside the call (lii_scan_job::map_update) - do not call map_incremental() for this scan."""
         job = lii_scan_job()
         job.struct_size = C.sizeof(lii_scan_job)
         job.scan_sorted = 1 if scan_sorted else 0
+        job.map_update = 1 if map_update else 0
         if scan_dev is not None:
             job.scan_dev, job.n_scan_dev = scan_dev[0], scan_dev[1]
         poses = None

@@ -300,6 +300,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_ins_c, M));
   CK(dmalloc(&h->d_u32_a, NM));
   CK(dmalloc(&h->d_u32_b, NM));
+  CK(hipMemset(h->d_u32_b, 0, sizeof(unsigned int) * NM));  // (k_map_decide's block words: run number 0 is never used)
   CK(dmalloc(&h->d_u32_c, NM));
   {
     const size_t slots = add_hash_slots(int(N));
@@ -336,7 +337,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(hipEventCreateWithFlags(&h->ev_poses, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&h->ev_mapflag, hipEventDisableTiming));
-  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_mapflag), 256, hipHostMallocDefault));
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_mapflag), 256, hipHostMallocMapped));  // (written by k_map_publish)
   std::memset(h->h_mapflag, 0, 256);
   CK(hipEventCreateWithFlags(&h->ev_lists, hipEventDisableTiming));
   CK(hipMemset(h->d_counter, 0, 16));
@@ -403,6 +404,9 @@ int lii_destroy(lii_handle h) {
     std::fprintf(stderr, "[libliinit_hip] host side of lii_scan_register, us per call over %.0f calls: first launch submitted %.1f, pre-processing enqueued %.1f, "
                  "loop enqueue %.1f, call %.1f, between calls %.1f\n", h->prof.host_us[4], h->prof.host_us[0] / h->prof.host_us[4], h->prof.host_us[1] / h->prof.host_us[4],
                  h->prof.host_us[2] / h->prof.host_us[4], h->prof.host_us[3] / h->prof.host_us[4], h->prof.host_us[5] / std::max(1.0, h->prof.host_us[4] - 1));
+  if (h->diag && h->prof.host_us[4] > 0 && (h->prof.host_map_us[0] > 0 || h->prof.host_map_us[1] > 0))
+    std::fprintf(stderr, "[libliinit_hip] map update, host us per scan: waited for the update in flight %.1f, enqueued behind the passes %.1f\n",
+                 h->prof.host_map_us[0] / h->prof.host_us[4], h->prof.host_map_us[1] / h->prof.host_us[4]);
   for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.second);
   h->graphs.clear();
   mailbox_close(&h->net.mailbox);

@@ -113,15 +113,32 @@ void note_list_sizes(lii_handle h, int n_add, int n_nodown) {
   h->pred_add = ma + ma / 4 + 1024;
   h->pred_nodown = mn + mn / 4 + 1024;
 }
+// Waits until the last in-place update has published its counters (k_map_publish): the word behind them is polled - the update's
+// last packet is microseconds away when somebody asks - with a look at the event now and then (a stream in error must not hang us).
+static int wait_mapflag(lii_handle h) {
+  volatile int* seqw = &h->h_mapflag[kMapFlagSeqAt];
+  unsigned int spins = 0;
+  while (*seqw != h->map_seq) {
+    if ((++spins & 0x3FFF) == 0) {
+      const hipError_t q = hipEventQuery(h->ev_mapflag);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) return fail(h, LII_ERR_HIP, std::string("map update: ") + hipGetErrorString(q));
+    }
+    __builtin_ia32_pause();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  if (*seqw != h->map_seq) HIPCHK(h, hipEventSynchronize(h->ev_mapflag));
+  return LII_OK;
+}
 int map_join(lii_handle h) {
   // (an update enqueued for predicted sizes is settled here whichever stream it ran on: when map_apply had to rebuild the index
   // first, the update went onto the handle's own stream - map_async false - and its list sizes need the same check)
   if (!h->map_async && !h->lists_predicted) return LII_OK;
   h->map_async = false;
-  HIPCHK(h, hipEventSynchronize(h->ev_mapflag));
+  { const int rcw = wait_mapflag(h); if (rcw != LII_OK) return rcw; }
   if (h->lists_predicted) {
     // lii_map_incremental enqueued this update for predicted list sizes.  The exact ones came along behind it: they feed the
-    // next prediction, and an update whose lists outgrew their bounds did nothing (k_compact_lists emptied them) - it is
+    // next prediction, and an update whose lists outgrew their bounds did nothing (k_map_decide emptied them) - it is
     // repeated now, with the exact sizes (the lists themselves are untouched until the next lii_map_incremental).
     h->lists_predicted = false;
     const int ca = h->h_mapflag[kMapCtrWords], cn = h->h_mapflag[kMapCtrWords + 1];
@@ -142,7 +159,7 @@ int commit_map(lii_handle h) {
     if (rc != LII_OK) return rc;
   }
   if (!h->map_dirty || !h->map_flag_pending) return LII_OK;
-  HIPCHK(h, hipEventSynchronize(h->ev_mapflag));
+  { const int rcw = wait_mapflag(h); if (rcw != LII_OK) return rcw; }
   h->map_flag_pending = false;
   if (h->h_mapflag[kMapCtrOverflow] != 0) {  // ran out of provisioned room: rebuild + re-insertion of the parked points
     const int rc = map_counters(h, false);
@@ -293,18 +310,42 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
   launch_ins_cells(list_a, flags_a, n_list, flags_a ? nullptr : n_list_dev, extra, n_extra, n_extra_dev, h->d_ins_e2, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp,
                    h->d_work, h->d_mapctr, h->work_cap, h->d_dropped, h->drop_cap, s);
   launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap_eff, (int)work_need, s);
+  h->map_seq = h->map_seq == 0x7FFFFFFF ? 1 : h->map_seq + 1;
   launch_ins_write(list_a, h->d_ins_e, n_list, flags_a ? nullptr : n_list_dev, extra, h->d_ins_e2, n_extra, n_extra_dev, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, h->d_dropped,
-                   h->drop_cap, s);
+                   h->drop_cap, s, h->h_mapflag, kMapCtrWords + 8, kMapFlagSeqAt, h->map_seq);
   HIPCHK(h, hipGetLastError());
-  // the update's overflow flag travels to the host behind its kernels (see commit_map)
-  // (ONE copy: the map counters and the list counts of lii_map_incremental sit behind each other - every small copy is a blit
-  // kernel of ~5 us on this stream)
-  HIPCHK(h, hipMemcpyAsync(h->h_mapflag, h->d_mapctr, sizeof(int) * (kMapCtrWords + 8), hipMemcpyDeviceToHost, s));
+  // (the update's counters, its overflow flag and the list sizes of lii_map_incremental travel to the host with the last workgroup
+  // of k_ins_write: see wait_mapflag / commit_map; the event behind it is for a stream in error only)
   h->lists_predicted = n_list_dev != nullptr;
   HIPCHK(h, hipEventRecord(h->ev_mapflag, s));
   h->map_flag_pending = true;
   h->map_async = beside;
   return LII_OK;
+}
+
+// lii_scan_job::map_update: map_incremental enqueued BEHIND the passes of the iterated update that is still running (called by
+// update_on_device between its last launch and its wait for the result): the host's ~ 45 us of launches for the map update pass
+// while the device registers the scan, instead of after the result has come back with the device idle.  The decision kernel
+// takes the update's final state from the control block and does nothing unless the update has ended regularly (k_map_decide).
+// Only the form that waits for nothing can be enqueued ahead: predicted list sizes, a map with room for them, one rank.
+int map_update_early(lii_handle h) {
+  const int nb = h->n_body;
+  if (nb <= 0 || nb > h->cfg.max_map_points || h->net.n_ranks > 1 || h->pred_add < 0 || h->map_dirty || h->map_async || h->lists_predicted) return 0;
+  if ((long long)h->n_map + std::min(nb, h->pred_add) + std::min(nb, h->pred_nodown) > (long long)h->cfg.max_map_points) return 0;
+  RegistrationBuffers rb = reg_buffers(h);
+  int ba = std::min(nb, h->pred_add), bn = std::min(nb, h->pred_nodown);
+  if (h->test_pred_small) { ba = std::min(ba, 16); bn = std::min(bn, 16); }
+  h->bound_add = ba; h->bound_nodown = bn;
+  PoseArg unused;
+  std::memset(&unused, 0, sizeof(unused));
+  if (++h->decide_epoch == 0u) h->decide_epoch = 1u;
+  launch_map_decide_compact(rb, unused, double(h->cfg.map_downsample_size), 1, reinterpret_cast<unsigned long long*>(h->d_u32_b), h->decide_epoch, h->d_world,
+                            h->d_list_add, h->d_list_nodown, h->d_counts, ba, bn, h->stream, h->d_ctrl, h->update_seq);
+  // (on the handle's own stream: the update sits right behind the passes anyway, and handing it to the map stream costs more - an
+  // event between two hardware queues - than the next scan's de-skew and voxel filter beside it bring back: 5 007 against 4 826
+  // scans/s with an update every scan, gpurun_out/r4y)
+  const int rc = map_apply(h, h->d_list_add, ba, true, h->d_list_nodown, bn, false, h->d_counts + 3, h->d_counts + 4, false);
+  return rc == LII_OK ? 1 : rc;
 }
 
 }  // namespace lii_impl
@@ -484,12 +525,14 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
     int ba = std::min(nb, h->pred_add), bn = std::min(nb, h->pred_nodown);
     if (h->test_pred_small) { ba = std::min(ba, 16); bn = std::min(bn, 16); }
     h->bound_add = ba; h->bound_nodown = bn;  // (LII_TEST=pred_small: every update outgrows its bounds)
-    launch_map_decide_compact(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, h->d_u32_a,
-                              reinterpret_cast<uint2*>(h->d_u32_b), h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, ba, bn, s);
+    if (++h->decide_epoch == 0u) h->decide_epoch = 1u;
+    launch_map_decide_compact(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0,
+                              reinterpret_cast<unsigned long long*>(h->d_u32_b), h->decide_epoch, h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, ba, bn, s);
     return map_apply(h, h->d_list_add, ba, true, h->d_list_nodown, bn, true, h->d_counts + 3, h->d_counts + 4, false);
   }
-  launch_map_decide_compact(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, h->d_u32_a,
-                            reinterpret_cast<uint2*>(h->d_u32_b), h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, nb, nb, s);
+  if (++h->decide_epoch == 0u) h->decide_epoch = 1u;
+  launch_map_decide_compact(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, reinterpret_cast<unsigned long long*>(h->d_u32_b),
+                            h->decide_epoch, h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, nb, nb, s);
   if (exchange) {
     // This rank has decided for ITS points (its block of the cloud, or its voxels): the lists of all ranks, in rank order, are the
     // batch every replica of the map receives (lii_exchange.hip: remote stores into the peers' gather areas; in place here).

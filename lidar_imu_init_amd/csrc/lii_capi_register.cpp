@@ -85,8 +85,10 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
                      lii_iekf_report* report) {
   static_assert(sizeof(lii_state) == sizeof(double) * kStateDoubles, "lii_state layout");
   if (h->n_body <= 0) return fail(h, LII_ERR_STATE, "no down-sampled scan (call lii_downsample / lii_downsample_skip)");
+  const auto t_map0 = std::chrono::steady_clock::now();
   int rc = commit_map(h);
   if (rc != LII_OK) return rc;
+  if (h->diag) h->prof.host_map_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_map0).count();
   hipStream_t s = h->stream;
   // The stream lii_map_incremental leaves its update on is created with the first update of a handle that is NOT a rank of a
   // sharded job (those never update beside a scan).  Not in lii_create: a second compute queue per process - even one whose
@@ -207,11 +209,21 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   };
   if (h->diag) h->prof.host_loop_enq_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_loop0).count();
   if (h->prof.kp_active) { rc = kp_mark(h, LII_KP_KINDS); if (rc != LII_OK) return rc; }  // (end mark of the planned passes)
+  h->map_enqueued_early = false;
+  if (h->map_after_update && !h->net.comm && !h->prof.profiling) {
+    // lii_scan_job::map_update: the map update goes out now, behind the passes, while the device still works on them
+    const auto t_me0 = std::chrono::steady_clock::now();
+    rc = map_update_early(h);
+    if (rc < 0) return rc;
+    h->map_enqueued_early = rc == 1;
+    if (h->diag) h->prof.host_map_us[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_me0).count();
+  }
   rc = wait_result(true);
   if (rc != LII_OK) return rc;
   if (h->h_res->done == (h->update_seq | kLoopParked)) {
     const int from = h->h_res->parked_it;
     h->plan_parked++;
+    h->map_enqueued_early = false;  // (that launch saw a parked loop and did nothing: the caller makes the map update when the loop has ended)
     plan = 0xFFFFFFFFu;
     launch_loop_resume(h->d_ctrl, s);
     for (int it = from; it < opts->max_iterations; it++) {
@@ -493,7 +505,14 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   }
   if (rc == LII_OK) rc = job->leaf > 0 ? lii_downsample(h, job->leaf, nullptr, nullptr) : lii_downsample_skip(h, nullptr);
   const auto t_pre = std::chrono::steady_clock::now();
+  const bool map_update = job->struct_size >= sizeof(lii_scan_job) && job->map_update == 1;
+  h->map_after_update = map_update && !h->host_solve;
+  h->map_enqueued_early = false;
   if (rc == LII_OK) rc = lii_iekf_update(h, state, state_prop, &job->opts, report);
+  h->map_after_update = false;
+  // map_incremental behind the update: already enqueued behind its passes (update_on_device), or made now
+  if (rc == LII_OK && map_update && !h->map_enqueued_early) rc = lii_map_incremental(h, state, nullptr, nullptr);
+  h->map_enqueued_early = false;
   h->poses_preloaded = h->ctrl_preloaded = false;  // also on the error paths
   h->prof.kp_active = false;
   if (h->diag) {

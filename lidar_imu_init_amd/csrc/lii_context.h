@@ -169,11 +169,15 @@ struct lii_context {
   int list_hist[8][2] = {};             // ... from the sizes of the last eight calls (note_list_sizes)
   int list_hist_n = 0;
   int pred_add = -1, pred_nodown = -1;  // lii_map_incremental: list sizes the next update is enqueued for (< 0: none yet)
+  bool map_after_update = false;        // lii_scan_job::map_update: the iterated update in progress enqueues the map update behind its passes
+  bool map_enqueued_early = false;      // ... and did (update_on_device -> map_update_early)
   bool lists_predicted = false;         // the update in flight ran on predicted sizes: commit_map checks it against the exact ones
   hipEvent_t ev_lists = nullptr;        // the two lists are complete (compute stream -> map stream)
   int* h_mapflag = nullptr;       // pinned, behind the last in-place update: [0..15] the map counters, [16..20] the list counts of
-                                  // lii_map_incremental (k_compact_lists) - read by commit_map / map_join
+                                  // lii_map_incremental (k_map_decide) - read by commit_map / map_join
   hipEvent_t ev_mapflag = nullptr;
+  unsigned int decide_epoch = 0;     // runs of k_map_decide so far (its in-launch exchange of block counts tells its words from older ones by it)
+  int map_seq = 0;                   // number of the last in-place update: k_map_publish leaves it in h_mapflag[kMapFlagSeqAt] behind the counters
   bool map_flag_pending = false;
   bool diag = false;     // LII_DIAG=1: counters of the rare paths on stderr when the handle is destroyed
 
@@ -219,6 +223,7 @@ struct lii_context {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_it[32] = {};  // per-iteration brackets of the k-NN kernel in the device-driven loop
     double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double host_map_us[2] = {0, 0};  // LII_DIAG: per update - waiting for the map update in flight (commit_map), enqueueing the map update behind the passes
     double host_us[6] = {0, 0, 0, 0, 0, 0};  // LII_DIAG: per lii_scan_register - entry -> first launch, -> pre-processing enqueued, -> loop enqueued, -> result; calls; gap between calls
     std::chrono::steady_clock::time_point host_last_return;
     double host_loop_enq_us = 0;
@@ -261,6 +266,8 @@ lii::GatherView gather_view(lii_handle h);  // .peers == nullptr: this job has n
 int build_index(lii_handle h, int n, int extra_blocks = 0);
 void note_list_sizes(lii_handle h, int n_add, int n_nodown);
 int map_join(lii_handle h);
+constexpr int kMapFlagSeqAt = 40;  // (h_mapflag: 64 ints; [0, kMapCtrWords + 8): the counters and list sizes)
+int map_update_early(lii_handle h);  // 1: enqueued behind the passes of the update in progress, 0: not possible this time, < 0: error
 int commit_map(lii_handle h);
 int map_counters(lii_handle h, bool already_synced = false);
 int map_gather(lii_handle h, int* n_out);

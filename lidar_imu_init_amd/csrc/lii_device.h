@@ -21,7 +21,7 @@ constexpr unsigned long long kVoxDropKey = (1ull << kVoxKeyBits) - 1ull;
 
 // device-resident counters of the in-place map (lii_map.hip): slots used at the tail of the point array, live points, occupied
 // 8x8x8 blocks, entries of the work list of the update in flight, "a capacity was exceeded" flag, events of the last fold
-constexpr int kMapCtrUsed = 0, kMapCtrValid = 1, kMapCtrBlocks = 2, kMapCtrWork = 3, kMapCtrOverflow = 4, kMapCtrEvents = 5, kMapCtrDropped = 6, kMapCtrSlots = 7, kMapCtrWords = 16;
+constexpr int kMapCtrUsed = 0, kMapCtrValid = 1, kMapCtrBlocks = 2, kMapCtrWork = 3, kMapCtrOverflow = 4, kMapCtrEvents = 5, kMapCtrDropped = 6, kMapCtrSlots = 7, kMapCtrTicket = 15 /* k_ins_write: workgroups that are done */, kMapCtrWords = 16;
 
 // 3 x 3 row-major helpers (no FMA contraction in the units that use them: the reference's rounding)
 __device__ __forceinline__ void mat3_mul(const double A[9], const double B[9], double C[9]) {

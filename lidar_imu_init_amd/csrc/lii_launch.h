@@ -115,8 +115,10 @@ void launch_calib_eval(int stage, const double* imu, const double* lidar, int n,
                        hipStream_t s);
 
 // device-side map maintenance (lii_map.hip)
-void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* cls, uint2* blk_counts,
-                               float4* world, float4* dst_add, float4* dst_nodown, int* counts, int bound_add, int bound_nodown, hipStream_t s);
+void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned long long* blk_counts, unsigned int epoch,
+                               float4* world, float4* dst_add, float4* dst_nodown, int* counts, int bound_add, int bound_nodown, hipStream_t s,
+                               const IekfCtrl* guard = nullptr, int seq = 0);  // blk_counts: one word per 256 points; epoch: the number of this run (never 0); guard: see k_map_decide
+void launch_map_publish(const int* ctr, int n_words, int* host, int seq_at, int seq, hipStream_t s);
 void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, int* events, hipStream_t s);
 void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
                      unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, unsigned int* tp, unsigned int* work,
@@ -132,7 +134,8 @@ void launch_ins_cells(const float4* list, const unsigned int* flags, int n, cons
 void launch_cell_apply(const unsigned int* work, uint2* cells, unsigned int* cell_cap, float4* pts, unsigned char* tomb, unsigned int* tp, int* ctr,
                        unsigned int pts_cap, int launch_bound, hipStream_t s);
 void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, const float4* list2, const unsigned int* ins_e2, int n2, const int* n2_dev,
-                      uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, float4* dropped, unsigned int drop_cap, hipStream_t s);
+                      uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, float4* dropped, unsigned int drop_cap, hipStream_t s,
+                      int* host = nullptr, int n_words = 0, int seq_at = 0, int seq = 0)  /* host != nullptr: the last workgroup publishes the counters there */;
 void launch_cell_caps(const uint2* cells, int n_entries, unsigned int* caps, hipStream_t s);
 void launch_spread(const float4* src, uint2* cells, unsigned int* cell_cap, const unsigned int* caps, const unsigned int* capsum, int n_entries,
                    float4* dst, int* ctr, int n_valid, int n_blocks, hipStream_t s);

@@ -1,6 +1,6 @@
 // Device-side maintenance of the local map with the reference's incremental k-d tree SET semantics, IN PLACE (DESIGN.md
 // section 2): the point array keeps slack behind every cell, an update touches the cells of its batch only.
-//   k_map_decide + k_compact_lists  map_incremental's per-point decision and its two lists     src/laserMapping.cpp:516-553
+//   k_map_decide                    map_incremental's per-point decision and its two lists         src/laserMapping.cpp:516-553
 //   k_add_keys / k_add_fold8        KD_TREE::Add_Points(points, downsample_on = true)  include/ikd-Tree/ikd_Tree.cpp:381-426:
 //                         per down-sample voxel "keep the point closest to the voxel centre": the points of one batch that
 //                         fall into the same voxel interact sequentially, different voxels are independent - eight lanes
@@ -119,13 +119,27 @@ __device__ __forceinline__ bool d_same_point(float ax, float ay, float az, float
 // ------------------------------------------------------------------------------------------------ map_incremental
 // cls[i]: 0 = not added, 1 = PointToAdd (with down-sampling), 2 = PointNoNeedDownsample.  world[i] = the world point.
 // cls[i] = fa | fn << 1; blk_counts[block] = (#fa, #fn) of the block's 256 points, for the single-pass compaction below.
-__global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, PoseArg ps, double fsd, int have_search, unsigned int* __restrict__ cls,
-                                                    uint2* __restrict__ blk_counts, float4* __restrict__ world_out) {
+// guard != nullptr: the launch was enqueued BEHIND the passes of iterated update number `seq`, before the host knew how that
+// update ends (lii_scan_job::map_update): the pose is the update's final state (the control block's first 24 doubles), and the
+// launch does nothing - empty lists - unless that update has ended regularly (a loop that parked itself is continued by the host,
+// which then makes the map update again).
+// The two order-preserving compactions happen in the same launch (round 4; a launch of its own before): a workgroup counts its
+// two kinds of points, publishes the counts as ONE word (run number << 32 | adds << 16 | no-down-samples) before it waits for
+// anything, adds up the words of the workgroups below it - the exchange of k_vhash_emit, lii_scan.hip: whichever workgroup is the
+// lowest unfinished one waits for nobody - ranks its own points with wavefront ballots and writes both lists; the last workgroup
+// leaves the list sizes in counts[0..1].
+__global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, PoseArg ps_val, double fsd, int have_search,
+                                                    unsigned long long* __restrict__ blk_counts, unsigned int epoch, float4* __restrict__ world_out,
+                                                    float4* __restrict__ dst_add, float4* __restrict__ dst_nodown, int* __restrict__ counts, int bound_a,
+                                                    int bound_n, const IekfCtrl* __restrict__ guard, int seq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = rb.n_dev ? *rb.n_dev : rb.n;
+  const PoseArg ps = guard ? *reinterpret_cast<const PoseArg*>(guard->st) : ps_val;
+  const bool go = !guard || (guard->stop == 1 && guard->singular == 0 && guard->seq == seq);  // uniform
+  const int n = go ? (rb.n_dev ? *rb.n_dev : rb.n) : 0;
   unsigned int fa = 0, fn = 0;
   int lo = 0, n_live = n;  // a rank of a job split by index decides for its block (the lists are exchanged afterwards)
   if (rb.shard_world > 1) shard_range(rb, lo, n_live);
+  float4 wp = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < rb.n && i >= lo && i < lo + n_live && i < n) {  // rb.n is the launch bound
     float4 pb = rb.body[i];
     double bx = pb.x, by = pb.y, bz = pb.z;
@@ -135,7 +149,8 @@ __global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, Pose
     const float wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
     const float wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
     const float wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
-    world_out[i] = make_float4(wx, wy, wz, 0.f);
+    wp = make_float4(wx, wy, wz, 0.f);
+    world_out[i] = wp;
     const int cnt = have_search ? rb.nbr_count[i] : 0;
     if (cnt > 0) {
       // mid_point = floor(p / filter_size_map) * filter_size_map + 0.5 * filter_size_map, double math stored to float (:529-534)
@@ -161,39 +176,35 @@ __global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, Pose
       fa = 1;  // no neighbour list: always added (:551-553)
     }
   }
-  if (i < rb.n) cls[i] = fa | (fn << 1);
-  __shared__ unsigned int s_a[4], s_n[4];
-  const int w = threadIdx.x >> 6;
-  const unsigned int ca = (unsigned int)__popcll(__ballot(fa != 0)), cn = (unsigned int)__popcll(__ballot(fn != 0));
-  if ((threadIdx.x & 63) == 0) { s_a[w] = ca; s_n[w] = cn; }
+  __shared__ unsigned int s_a[4], s_n[4], s_sum[8];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned long long ma = __ballot(fa != 0), mn = __ballot(fn != 0);
+  if (lane == 0) { s_a[w] = (unsigned int)__popcll(ma); s_n[w] = (unsigned int)__popcll(mn); }
   __syncthreads();
-  if (threadIdx.x == 0) blk_counts[blockIdx.x] = make_uint2(s_a[0] + s_a[1] + s_a[2] + s_a[3], s_n[0] + s_n[1] + s_n[2] + s_n[3]);
-}
-
-// Both order-preserving compactions of map_incremental in ONE launch: a block adds up the counts of the blocks before it (a few
-// hundred values at most), ranks its own 256 points with wavefront ballots, and writes the two lists; the last block leaves the
-// list sizes in counts[0..1].  (Replaces two library scans and two scatter kernels.)
-__global__ __launch_bounds__(256) void k_compact_lists(const float4* __restrict__ src, const unsigned int* __restrict__ cls,
-                                                       const uint2* __restrict__ blk_counts, int n, float4* __restrict__ dst_add,
-                                                       float4* __restrict__ dst_nodown, int* __restrict__ counts, int bound_a, int bound_n) {
-  __shared__ unsigned int s_a[4], s_n[4], s_wa[4], s_wn[4];
-  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const unsigned int tot_a = s_a[0] + s_a[1] + s_a[2] + s_a[3], tot_n = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+  if (threadIdx.x == 0)
+    __hip_atomic_store(blk_counts + blockIdx.x, ((unsigned long long)epoch << 32) | ((unsigned long long)tot_a << 16) | tot_n, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  // adds / no-down-samples in the workgroups below this one (their words carry this run's number, or have not arrived yet)
   unsigned int pa = 0, pn = 0;
-  for (int j = t; j < (int)blockIdx.x; j += 256) { const uint2 c = blk_counts[j]; pa += c.x; pn += c.y; }
+  for (int q = threadIdx.x; q < (int)blockIdx.x; q += 256) {
+    unsigned long long v = __hip_atomic_load(blk_counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int spins = 0;
+    while ((unsigned int)(v >> 32) != epoch) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 24)) __builtin_trap();  // a count that never arrives: the launch is broken
+      v = __hip_atomic_load(blk_counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    pa += (unsigned int)(v >> 16) & 0xFFFFu;
+    pn += (unsigned int)v & 0xFFFFu;
+  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { pa += __shfl_xor(pa, off); pn += __shfl_xor(pn, off); }
-  const int i = blockIdx.x * 256 + t;
-  const unsigned int c = i < n ? cls[i] : 0u;
-  const unsigned long long ma = __ballot(c & 1u), mn = __ballot(c & 2u);
-  if (lane == 0) { s_a[w] = pa; s_n[w] = pn; s_wa[w] = (unsigned int)__popcll(ma); s_wn[w] = (unsigned int)__popcll(mn); }
+  for (int off = 32; off > 0; off >>= 1) { pa += __shfl_down(pa, off); pn += __shfl_down(pn, off); }
+  if (lane == 0) { s_sum[w] = pa; s_sum[4 + w] = pn; }
   __syncthreads();
-  unsigned int base_a = s_a[0] + s_a[1] + s_a[2] + s_a[3], base_n = s_n[0] + s_n[1] + s_n[2] + s_n[3];
-  for (int k = 0; k < w; k++) { base_a += s_wa[k]; base_n += s_wn[k]; }
-  const unsigned long long below = (1ull << lane) - 1ull;
-  if (c & 1u) dst_add[base_a + (unsigned int)__popcll(ma & below)] = src[i];
-  if (c & 2u) dst_nodown[base_n + (unsigned int)__popcll(mn & below)] = src[i];
-  if (blockIdx.x == gridDim.x - 1 && t == 255) {
-    const int ca = (int)(base_a + (unsigned int)__popcll(ma)), cn = (int)(base_n + (unsigned int)__popcll(mn));
+  unsigned int base_a = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3], base_n = s_sum[4] + s_sum[5] + s_sum[6] + s_sum[7];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    const int ca = (int)(base_a + tot_a), cn = (int)(base_n + tot_n);
     counts[0] = ca;
     counts[1] = cn;
     // the update behind this launch may have been enqueued for PREDICTED list sizes (lii_map_incremental): a list that outgrew
@@ -204,6 +215,10 @@ __global__ __launch_bounds__(256) void k_compact_lists(const float4* __restrict_
     counts[3] = over ? 0 : ca;
     counts[4] = over ? 0 : cn;
   }
+  for (int k = 0; k < w; k++) { base_a += s_a[k]; base_n += s_n[k]; }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (fa) dst_add[base_a + (unsigned int)__popcll(ma & below)] = wp;
+  if (fn) dst_nodown[base_n + (unsigned int)__popcll(mn & below)] = wp;
 }
 
 
@@ -670,9 +685,10 @@ __global__ void k_cell_apply(const unsigned int* __restrict__ work, uint2* __res
 __global__ void k_ins_write(const float4* __restrict__ list, const unsigned int* __restrict__ ins_e, int n, const int* __restrict__ n_dev,
                             const float4* __restrict__ list2, const unsigned int* __restrict__ ins_e2, int n2, const int* __restrict__ n2_dev,
                             uint2* __restrict__ cells, const unsigned int* __restrict__ cell_cap, float4* __restrict__ pts, int* __restrict__ ctr,
-                            float4* __restrict__ dropped, unsigned int drop_cap) {
+                            float4* __restrict__ dropped, unsigned int drop_cap, int* __restrict__ host, int n_words, int seq_at, int seq) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) ctr[kMapCtrWork] = 0;  // the work list has been consumed (k_cell_apply ran before this launch)
+  // (the counters this launch writes are read again by its LAST workgroup, on whichever XCD that runs: atomic stores, not plain ones)
+  if (i == 0) __hip_atomic_store(&ctr[kMapCtrWork], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the work list has been consumed (k_cell_apply ran before this launch)
   bool valid = true;
   if (i >= n) {
     i -= n;
@@ -692,12 +708,30 @@ __global__ void k_ins_write(const float4* __restrict__ list, const unsigned int*
         added = 1;
       } else {
         atomicSub(reinterpret_cast<unsigned int*>(&cells[e]) + 1, 1u);
-        ctr[kMapCtrOverflow] = 1;
+        __hip_atomic_store(&ctr[kMapCtrOverflow], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         drop_point(dropped, drop_cap, ctr, p);
       }
     }
   }
   wave_atomic_add_all(&ctr[kMapCtrValid], added);  // every lane of the wavefront arrives here
+  if (!host) return;  // (uniform)
+  // The update ends here: the workgroup that finishes last (a ticket) hands the map's counters - and the list sizes behind them - to
+  // the host's pinned, mapped buffer and puts the number of the update behind them; the host polls that word (an event behind a
+  // copy woke it ~ 15 us late, and the copy was a launch of its own: the next scan's search is waiting for exactly this).
+  wait_published_atomics();
+  __syncthreads();
+  __shared__ int s_last;
+  if (threadIdx.x == 0) s_last = atomicAdd(reinterpret_cast<unsigned int*>(&ctr[kMapCtrTicket]), 1u) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  if ((int)threadIdx.x < n_words) {
+    int v = __hip_atomic_load(&ctr[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == kMapCtrTicket) { v = 0; __hip_atomic_store(&ctr[kMapCtrTicket], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __hip_atomic_store(host + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host + seq_at, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- (re)build: slack layout from the compact, cell-sorted array
@@ -776,11 +810,12 @@ void launch_cell_apply(const unsigned int* work, uint2* cells, unsigned int* cel
   if (launch_bound > 0) hipLaunchKernelGGL(k_cell_apply, dim3(nblk(launch_bound, 128)), dim3(128), 0, s, work, cells, cell_cap, pts, tomb, tp, ctr, pts_cap, launch_bound);
 }
 void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, const float4* list2, const unsigned int* ins_e2, int n2, const int* n2_dev,
-                      uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, float4* dropped, unsigned int drop_cap, hipStream_t s) {
+                      uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, float4* dropped, unsigned int drop_cap, hipStream_t s,
+                      int* host, int n_words, int seq_at, int seq) {
   if (n < 0) n = 0;
   if (n2 < 0) n2 = 0;
   hipLaunchKernelGGL(k_ins_write, dim3(nblk(n + n2 > 0 ? n + n2 : 1, 256)), dim3(256), 0, s, list, ins_e, n, n_dev, list2, ins_e2, n2, n2_dev, cells, cell_cap, pts,
-                     ctr, dropped, drop_cap);
+                     ctr, dropped, drop_cap, host, n_words, seq_at, seq);
 }
 void launch_cell_caps(const uint2* cells, int n_entries, unsigned int* caps, hipStream_t s) {
   if (n_entries > 0) hipLaunchKernelGGL(k_cell_caps, dim3(nblk(n_entries, 256)), dim3(256), 0, s, cells, n_entries, caps);
@@ -800,12 +835,24 @@ void launch_box_tomb_cells(const float4* pts, const uint2* cells, int n_entries,
   if (n_entries > 0) hipLaunchKernelGGL(k_box_tomb_cells, dim3(nblk(n_entries, 256)), dim3(256), 0, s, pts, cells, n_entries, boxes, n_boxes, tomb, tp, work, ctr, work_cap);
 }
 
-void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned int* cls, uint2* blk_counts,
-                               float4* world, float4* dst_add, float4* dst_nodown, int* counts, int bound_add, int bound_nodown, hipStream_t s) {
+// The last launch of an in-place update: the map's counters (and the list sizes behind them) go to the caller's pinned, mapped buffer
+// with plain system-scope stores, the number of the update behind them - the host polls that word instead of waiting for an event
+// behind a copy (an event wait wakes the host ~ 15 us after the fact; the search of the next scan is waiting for exactly this).
+__global__ __launch_bounds__(64) void k_map_publish(const int* __restrict__ ctr, int n_words, int* __restrict__ host, int seq_at, int seq) {
+  const int l = threadIdx.x;
+  if (l < n_words) __hip_atomic_store(host + l, ctr[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  if (l == 0) __hip_atomic_store(host + seq_at, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_map_publish(const int* ctr, int n_words, int* host, int seq_at, int seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_map_publish, dim3(1), dim3(64), 0, s, ctr, n_words, host, seq_at, seq);
+}
+void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned long long* blk_counts, unsigned int epoch,
+                               float4* world, float4* dst_add, float4* dst_nodown, int* counts, int bound_add, int bound_nodown, hipStream_t s,
+                               const IekfCtrl* guard, int seq) {
   if (rb.n <= 0) return;
-  const int nb = nblk(rb.n, 256);
-  hipLaunchKernelGGL(k_map_decide, dim3(nb), dim3(256), 0, s, rb, ps, fsd, have_search, cls, blk_counts, world);
-  hipLaunchKernelGGL(k_compact_lists, dim3(nb), dim3(256), 0, s, world, cls, blk_counts, rb.n, dst_add, dst_nodown, counts, bound_add, bound_nodown);
+  hipLaunchKernelGGL(k_map_decide, dim3(nblk(rb.n, 256)), dim3(256), 0, s, rb, ps, fsd, have_search, blk_counts, epoch, world, dst_add, dst_nodown, counts,
+                     bound_add, bound_nodown, guard, seq);
 }
 void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, int* events, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_add_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, n_dev, ds, keys, idx, events);

@@ -330,7 +330,8 @@ def test_long_update_sequence_keeps_the_tree_set(oracle):
     reg.close()
 
 
-@pytest.mark.parametrize("hook", ["", "pred_small", "pred_small,force_rebuild", "force_rebuild"])
+@pytest.mark.parametrize("hook", ["", "pred_small", "pred_small,force_rebuild", "force_rebuild", "job", "job,pred_small", "job,force_rebuild",
+                                  "job,plan_force=0x10001"])
 def test_map_incremental_without_counts_gives_the_same_map(hook):
     """lii_map_incremental with both size pointers NULL enqueues the update for PREDICTED list sizes on a stream of its own and
     returns at once; an update whose lists outgrow the prediction is repeated with the exact sizes before the next search
@@ -338,13 +339,19 @@ def test_map_incremental_without_counts_gives_the_same_map(hook):
     Add_Points batch leaves behind does not depend on the batch order).  Same scans, same poses -> the same map, point for point,
     as the waiting, sorting form.  force_rebuild: every update takes the branch of a map low on room - the index is rebuilt first and
     the update runs on the handle's own stream; with pred_small on top every one of those updates outgrows its bounds and has to
-    be repeated as well (that combination used to lose the scan's points silently)."""
+    be repeated as well (that combination used to lose the scan's points silently).
+    job: the map update rides in the registration job (lii_scan_job::map_update) - enqueued behind the update's passes before the
+    host knows how the update ends; with plan_force=0x10001 (a launch plan that holds the first pass only) every update parks, the
+    early launch sees that and does nothing, and the update is made when the loop has ended."""
     import bench
     import lidar_imu_init_amd as lii
     wl = bench.build_workload("os1_128_cut3", 4)
     states0, tables = bench.start_states(wl)
 
-    def run(want_counts, env):
+    in_job = hook.startswith("job")
+    hook = hook[4:] if in_job else hook
+
+    def run(want_counts, env, in_job=False):
         old = os.environ.get("LII_TEST")
         if env:
             os.environ["LII_TEST"] = env
@@ -361,9 +368,11 @@ def test_map_incremental_without_counts_gives_the_same_map(hook):
                 for j, scan in enumerate(wl["scans"]):
                     st = states0[j].copy()
                     reg.scan_upload(scan)
-                    rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=wl["fs_surf"], max_iterations=wl["max_it"], imu_en=True)
+                    rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=wl["fs_surf"], max_iterations=wl["max_it"], imu_en=True,
+                                            map_update=in_job)
                     # the first call has nothing to predict from and waits either way
-                    reg.map_incremental(st, want_counts=want_counts or (rnd == 0 and j == 0))
+                    if not in_job:
+                        reg.map_incremental(st, want_counts=want_counts or (rnd == 0 and j == 0))
                     out.append((st.pod.copy(), rep["iterations"], rep["effect_num"]))
             m = reg.map_download()
             return out, m[np.lexsort((m[:, 2], m[:, 1], m[:, 0]))]
@@ -373,7 +382,7 @@ def test_map_incremental_without_counts_gives_the_same_map(hook):
     # the waiting form, folded through the batch sort (what lii_map_add_points does, and round 2 did here) - against the
     # returning form, folded through the hash table, on predicted sizes
     ref_out, ref_map = run(True, "fold_sort")
-    got_out, got_map = run(False, hook)
+    got_out, got_map = run(False, hook, in_job)
     assert len(ref_map) > len(wl["map"])  # the map did grow
     for a, b in zip(ref_out, got_out):
         assert a[1] == b[1] and a[2] == b[2]
