@@ -25,6 +25,7 @@ def main():
     partition = os.environ.get("LII_WORKER_PARTITION", "library")
     caller_partition = partition == "caller"
     leaf = float(os.environ.get("LII_WORKER_LEAF", "0.1"))
+    map_in_job = os.environ.get("LII_WORKER_MAP_IN_JOB") == "1"  # lii_scan_job::map_update instead of a call of lii_map_incremental
     import bench
     import lidar_imu_init_amd as lii
     from harness import synth
@@ -61,15 +62,18 @@ def main():
             nd, _ = reg.downsample(leaf)
             n_down.append(nd)
             s91 = reg.iekf_iterate(st, True, True)  # at the common start state
-            rep = reg.scan_register(st, prop, imu_poses=table, leaf=leaf, max_iterations=5, imu_en=True, scan_dev=reg.device_scan(scan), scan_sorted=True)
+            rep = reg.scan_register(st, prop, imu_poses=table, leaf=leaf, max_iterations=5, imu_en=True, scan_dev=reg.device_scan(scan), scan_sorted=True,
+                                    map_update=map_in_job)
             body_local = reg.scan_download(1)
             if k == 0:
                 body0 = body_local.copy()
             n_local.append(len(body_local))  # what THIS rank holds of the cloud: its voxels (a split by voxel), or all of it
             # one more host-driven pass, now on the cloud lii_scan_register left behind (a split by voxel exists only there), at the
             # common start state: again only the summation order differs between worlds
-            sums_b.append(np.asarray(reg.iekf_iterate(prop, True, True)).copy())
-            reg.map_incremental(st)
+            if not map_in_job and os.environ.get("LII_WORKER_NO_SUMS_B") != "1":  # (in the job: the pass would search the map the job has already updated)
+                sums_b.append(np.asarray(reg.iekf_iterate(prop, True, True)).copy())
+            if not map_in_job:
+                reg.map_incremental(st)
             map_sizes.append(reg.map_size())
         states.append(st.pod.copy())
         reports.append([rep["iterations"], rep["searches"], rep["effect_num"], int(rep["converged"])])

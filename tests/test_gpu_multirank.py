@@ -174,6 +174,22 @@ def test_ranks_split_the_cloud_by_voxel(tmp_path, world):
     assert np.sum(d_ab > 1e-5) <= 5 and np.sum(d_ba > 1e-5) <= 5, (len(a), len(b), np.sum(d_ab > 1e-5), np.sum(d_ba > 1e-5))
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_map_update_inside_the_job(tmp_path, world):
+    """lii_scan_job::map_update = 1 instead of a call of lii_map_incremental: one rank enqueues the update behind the passes of the
+    registration (map_update_early), a sharded job - its lists have to be exchanged first - makes it when the update has ended; the
+    maps and the states are those of the explicit call either way."""
+    env = {"LII_WORKER_PARTITION": "voxel"}
+    a = _run_ranks(tmp_path, world, env=dict(env, LII_WORKER_NO_SUMS_B="1"))  # (no extra search pass between the update and its map update)
+    b = _run_ranks(tmp_path, world, env=dict(env, LII_WORKER_MAP_IN_JOB="1"))
+    for r in range(world):
+        for key in ("states", "reports", "map_sizes", "n_local"):
+            assert np.array_equal(a[r][key], b[r][key]), key
+        assert np.array_equal(_rows(a[r]["map_final"]), _rows(b[r]["map_final"]))
+    for r in range(1, world):
+        assert np.array_equal(b[0]["states"], b[r]["states"]) and np.array_equal(_rows(b[0]["map_final"]), _rows(b[r]["map_final"]))
+
+
 def test_list_exchange_equals_the_repeated_search(tmp_path):
     """A job split by index keeps its replicas identical in two ways: the insert lists of lii_map_incremental are exchanged (gather
     areas behind the mailbox slots), or - no gather areas: LII_TEST=no_gather here, the host-memory mailbox and RCCL in the field -
