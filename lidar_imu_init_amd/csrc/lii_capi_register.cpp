@@ -186,7 +186,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   // The plan also ends the enqueued loop after as many passes as the last updates ran: the launches behind the stopping pass
   // only drain (3 x 4.5 us on stream100k, about what the host needs to come back with the next scan: + 0 .. 3 % scans/s,
   // gpurun_out/r3x4).  A loop that parked itself (the next pass is not there, or needs a search the plan did not hold - the
-  // pattern changed against the previous scans) is continued from here with every launch: one host round trip, on those scans.
+  // pattern changed against the previous scans) is continued from here (below): one host round trip, on those scans.
   auto wait_result = [&](bool first) -> int {
     const int parked_word = first ? (h->update_seq | kLoopParked) : h->update_seq;
     if (h->poll_result && !h->net.comm) {
@@ -220,18 +220,30 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   }
   rc = wait_result(true);
   if (rc != LII_OK) return rc;
-  if (h->h_res->done == (h->update_seq | kLoopParked)) {
+  // A parked loop is continued with what it is known to need: the pass it parked in front of - behind a k-NN launch if that pass
+  // searches - and as many passes behind it as the longer of the last two updates ran; should that not be enough (the next search
+  // comes at another pass as well, or the update runs longer) it parks again and is continued again.  (Round 3 enqueued every
+  // remaining pass with every k-NN launch: up to nine launches that only read a flag, ~ 20 us on a scan that parks.)
+  for (int round = 0; h->h_res->done == (h->update_seq | kLoopParked); round++) {
+    if (round > 2 * opts->max_iterations) return fail(h, LII_ERR_HIP, "device loop parked again and again");
     const int from = h->h_res->parked_it;
+    const bool search = h->h_res->parked_search != 0;
     h->plan_parked++;
     h->map_enqueued_early = false;  // (that launch saw a parked loop and did nothing: the caller makes the map update when the loop has ended)
-    plan = 0xFFFFFFFFu;
-    launch_loop_resume(h->d_ctrl, s);
-    for (int it = from; it < opts->max_iterations; it++) {
+    const int last = std::min(opts->max_iterations, std::max(h->plan_passes_prev, from + 1));  // (exclusive; from < max_iterations: the last pass never parks)
+    unsigned int rplan = 0u;
+    for (int q = from; q < last && q < 16; q++) rplan |= 1u << (16 + q);
+    if (search && from < 16) rplan |= 1u << from;
+    plan = rplan;
+    h->h_res->done = 0;  // (the parked word of this round must not be taken for the next one's)
+    std::atomic_thread_fence(std::memory_order_release);
+    launch_loop_resume(h->d_ctrl, rplan, s);
+    for (int it = from; it < last; it++) {
       rc = enqueue_pass(it);
       if (rc != LII_OK) return rc;
     }
     if (h->prof.kp_active) { rc = kp_mark(h, LII_KP_KINDS); if (rc != LII_OK) return rc; }
-    rc = wait_result(false);
+    rc = wait_result(true);
     if (rc != LII_OK) return rc;
   }
   h->staging_busy = false;  // the wait above covers everything enqueued before the stopping pass

@@ -314,6 +314,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
       if (parked) {
         c->stop = 2;
         res->parked_it = it + 1;
+        res->parked_search = search;
       }
       if (do_cov) {
         c->stop = 1;
@@ -479,12 +480,12 @@ void launch_reduce_solve(const RegistrationBuffers& rb, unsigned long long* gran
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq + 1), dim3(kSolveThreads), 0, s, rb.partials, nb, rb.partial_stride, gran, c, res, mb);
 }
-// A parked loop goes on: every launch is enqueued from here on.
-__global__ void k_loop_resume(IekfCtrl* c) {
+// A parked loop goes on with the launches the host has put behind this one (plan_mask, as IekfCtrl::plan_mask).
+__global__ void k_loop_resume(IekfCtrl* c, unsigned int plan_mask) {
   c->stop = 0;
-  c->plan_mask = 0xFFFFFFFFu;
+  c->plan_mask = plan_mask;
 }
-void launch_loop_resume(IekfCtrl* c, hipStream_t s) { hipLaunchKernelGGL(k_loop_resume, dim3(1), dim3(1), 0, s, c); }
+void launch_loop_resume(IekfCtrl* c, unsigned int plan_mask, hipStream_t s) { hipLaunchKernelGGL(k_loop_resume, dim3(1), dim3(1), 0, s, c, plan_mask); }
 void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s) {
   hipLaunchKernelGGL(k_iekf_solve, dim3(1), dim3(kSolveThreads), 0, s, c, ne, res);
 }

@@ -65,7 +65,7 @@ int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bo
 void launch_lists_exchange(const GatherView& gv, const float4* src_add, const float4* src_nodown, int* counts, int err_at, unsigned int* ticket,
                            unsigned long long seq, float4* dst_add, float4* dst_nodown, hipStream_t s);
 void mailbox_close(MailboxHost* m);
-void launch_loop_resume(IekfCtrl* c, hipStream_t s);
+void launch_loop_resume(IekfCtrl* c, unsigned int plan_mask, hipStream_t s);
 void launch_iekf_solve(IekfCtrl* c, const double* ne, IekfResult* res, hipStream_t s);
 int register_blocks(int n);
 // undistortion
