@@ -1116,6 +1116,24 @@ __device__ __forceinline__ void wave_select5(Knn5 k, float (&od)[5], int (&oi)[5
     }
   }
 }
+// The candidates of NB cell ranges against a lane's list (the far pass of knn_fallback_wave): four loads in flight per range.
+template <int NB>
+__device__ __forceinline__ void far_candidates(const GridView& g, const uint2 (&rr)[NB], float wx, float wy, float wz, float bound1, Knn5& k) {
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    // candidates must beat the inner 5th distance as well as the lane's own list
+    for (unsigned int j = rr[b].x; j < rr[b].y; j += 4) {
+      const unsigned int last = rr[b].y - 1;
+      const float4 p0 = g.pts[j], p1 = g.pts[min(j + 1, last)], p2 = g.pts[min(j + 2, last)], p3 = g.pts[min(j + 3, last)];
+      const float d0 = dist2_ref(wx, wy, wz, p0.x, p0.y, p0.z), d1 = dist2_ref(wx, wy, wz, p1.x, p1.y, p1.z);
+      const float d2 = dist2_ref(wx, wy, wz, p2.x, p2.y, p2.z), d3 = dist2_ref(wx, wy, wz, p3.x, p3.y, p3.z);
+      if (d0 <= g.max_d2 && d0 < fminf(k.d4, bound1)) knn_insert(k, d0, (int)j);
+      if (j + 1 <= last && d1 <= g.max_d2 && d1 < fminf(k.d4, bound1)) knn_insert(k, d1, (int)(j + 1));
+      if (j + 2 <= last && d2 <= g.max_d2 && d2 < fminf(k.d4, bound1)) knn_insert(k, d2, (int)(j + 2));
+      if (j + 3 <= last && d3 <= g.max_d2 && d3 < fminf(k.d4, bound1)) knn_insert(k, d3, (int)(j + 3));
+    }
+  }
+}
 // seeded: the search pass has already measured every point of the 3 x 3 x 3 cells around the query (kCovered) - its list
 // (seed_d: the distance of entry `lane` on lanes 0..4, inf where the list ends) stands in for pass 1; a seeded entry that
 // survives comes back as index -(2 + its place in the list).
@@ -1175,8 +1193,9 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
   // Four rounds of 64 cells at a time: which cells survive (inside the ball, outside the inner cube, closer than bound1) does
   // not depend on the candidates found on the way, so the four cell entries of a lane are fetched together and their
   // candidates four per trip - the loop is a chain of dependent loads, not of arithmetic.
-  constexpr int NB = 4;
   const int nxy = nx * ny;
+  if (total <= 256) {
+  constexpr int NB = 4;
   for (int c0 = 0; c0 < total; c0 += 64 * NB) {  // uniform trip count: the shuffle below needs every lane
     uint2 rr[NB];
 #pragma unroll
@@ -1201,20 +1220,51 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
         rr[b] = g.cells[(size_t)id * kBlockCells + local];
       }
     }
+    far_candidates<NB>(g, rr, wx, wy, wz, bound1, k);
+  }
+  } else {
+  // Which cells survive (inside the ball, outside the inner cube, closer than bound1) does not depend on the candidates found on
+  // the way.  A lane takes one (x, y) COLUMN of the cube at a time and walks it in z, NB cells per trip: one integer division per
+  // column (the flat cell index of round 3 cost two per cell - a query that looks past the edge of the map walks the whole ball of
+  // sqrt(max_d2) = 2.2 m, 11 x 11 x 11 cells at the default cell edge: ~ 2 500 instructions of index arithmetic per lane, 15 us
+  // per search pass on the one scan of the bench stream that has such queries).  The NB cell entries of a trip are requested back
+  // to back from a valid address whether the cell is wanted or not (entry 0 for the others; the answer is dropped afterwards): a
+  // load behind a branch is waited for on its own.
+  constexpr int NB = 12;
+  for (int col0 = 0; col0 < nxy; col0 += 64) {  // uniform trip counts: the shuffles below need every lane
+    const int col = col0 + lane;
+    const bool in_col = col < nxy;
+    const int q1 = (in_col ? col : 0) / nx;
+    const int ixx = ix0 + ((in_col ? col : 0) - q1 * nx), iyy = iy0 + q1;
+    const int X = (ixx >> kCoarseShift) - X0 + 1, Y = (iyy >> kCoarseShift) - Y0 + 1;
+    const bool xy_blocks = in_col && (unsigned)X <= 2u && (unsigned)Y <= 2u;  // else farther than 8 cells >= sqrt(max_d2)
+    const bool xy_inner = abs(ixx - cx) <= 1 && abs(iyy - cy) <= 1;
+    const float gx = axis_gap(wx, ixx, cs, eps), gy = axis_gap(wy, iyy, cs, eps);
+    const float gxy = gx * gx + gy * gy;
+    for (int z0 = 0; z0 < nz; z0 += NB) {
+      bool act[NB];
+      size_t ci[NB];
 #pragma unroll
-    for (int b = 0; b < NB; b++) {
-      // candidates must beat the inner 5th distance as well as the lane's own list
-      for (unsigned int j = rr[b].x; j < rr[b].y; j += 4) {
-        const unsigned int last = rr[b].y - 1;
-        const float4 p0 = g.pts[j], p1 = g.pts[min(j + 1, last)], p2 = g.pts[min(j + 2, last)], p3 = g.pts[min(j + 3, last)];
-        const float d0 = dist2_ref(wx, wy, wz, p0.x, p0.y, p0.z), d1 = dist2_ref(wx, wy, wz, p1.x, p1.y, p1.z);
-        const float d2 = dist2_ref(wx, wy, wz, p2.x, p2.y, p2.z), d3 = dist2_ref(wx, wy, wz, p3.x, p3.y, p3.z);
-        if (d0 <= g.max_d2 && d0 < fminf(k.d4, bound1)) knn_insert(k, d0, (int)j);
-        if (j + 1 <= last && d1 <= g.max_d2 && d1 < fminf(k.d4, bound1)) knn_insert(k, d1, (int)(j + 1));
-        if (j + 2 <= last && d2 <= g.max_d2 && d2 < fminf(k.d4, bound1)) knn_insert(k, d2, (int)(j + 2));
-        if (j + 3 <= last && d3 <= g.max_d2 && d3 < fminf(k.d4, bound1)) knn_insert(k, d3, (int)(j + 3));
+      for (int b = 0; b < NB; b++) {
+        const int izz = iz0 + z0 + b;
+        const int Z = (izz >> kCoarseShift) - Z0 + 1;
+        const bool in_blocks = xy_blocks && z0 + b < nz && (unsigned)Z <= 2u;
+        const int id = __shfl(my_block, in_blocks ? Z * 9 + Y * 3 + X : 0);
+        const bool inner = xy_inner && abs(izz - cz) <= 1;  // done in pass 1
+        const float gz = axis_gap(wz, izz, cs, eps);
+        const bool a = in_blocks && !inner && id >= 0 && !(gxy + gz * gz > bound1);
+        const unsigned local = (((unsigned)izz & 7u) << 6) | (((unsigned)iyy & 7u) << 3) | ((unsigned)ixx & 7u);
+        act[b] = a;
+        ci[b] = a ? (size_t)id * kBlockCells + local : (size_t)0;
       }
+      uint2 rr[NB];
+#pragma unroll
+      for (int b = 0; b < NB; b++) rr[b] = g.cells[ci[b]];
+#pragma unroll
+      for (int b = 0; b < NB; b++) rr[b] = act[b] ? rr[b] : make_uint2(0u, 0u);
+      far_candidates<NB>(g, rr, wx, wy, wz, bound1, k);
     }
+  }
   }
   wave_select5(k, od, oi);
 }
