@@ -213,9 +213,9 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   if (h->map_after_update && !h->net.comm && !h->prof.profiling) {
     // lii_scan_job::map_update: the map update goes out now, behind the passes, while the device still works on them
     const auto t_me0 = std::chrono::steady_clock::now();
-    rc = map_update_early(h);
-    if (rc < 0) return rc;
-    h->map_enqueued_early = rc == 1;
+    // (a batch that cannot be enqueued now - no room for the predicted sizes - is not this update's failure: the map update is made
+    // when the update has ended, by the call that reports such things)
+    h->map_enqueued_early = map_update_early(h) == 1;
     if (h->diag) h->prof.host_map_us[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_me0).count();
   }
   rc = wait_result(true);
