@@ -350,13 +350,15 @@ int lii_li_init_set_device(lii_handle h, int32_t on_device);
  *       filters, searches and fits only the voxels whose key hashes to it (~ 1 / N of them, +- a percent, whatever the scene);
  *       lii_downsample's / lii_scan_download's view of the down-sampled cloud is then this rank's share.  Elsewhere (stand-alone
  *       lii_downsample, leaf 0) the split is by index.  A share that outgrows n / N + 25 % + 2048 points fails the update with
- *       LII_ERR_CAPACITY.  Needs the peer-mapped mailbox (other transports stay with 1; lii_comm_describe tells).
+ *       LII_ERR_CAPACITY.  Needs a transport that carries the list exchange below - the peer-mapped mailbox or RCCL - (the host-memory
+ *       mailbox stays with 1; lii_comm_describe tells).
  *   0 - the caller hands every rank its own points.
  *   Either way the sharded result equals the single-GPU result up to the re-association of the 91 sums.
  *   lii_map_incremental of a sharded job: every rank decides for ITS points, and the two insert lists (PointToAdd /
  *   PointNoNeedDownsample, src/laserMapping.cpp:516-559) are exchanged - pushed into every rank's gather area behind the mailbox
- *   slots and put together in rank order - so that every replica of the map applies the identical batch.  On a transport without
- *   gather areas (host-memory mailbox, RCCL) a job split by index repeats the last search for the whole cloud instead (no exchange).
+ *   slots, or gathered with two ncclAllGather calls on the RCCL transport - and put together in rank order, so that every replica of
+ *   the map applies the identical batch.  On the host-memory mailbox a job split by index repeats the last search for the whole
+ *   cloud instead (no exchange).
  * Transports:
  *   LII_COMM_MAILBOX       ranks of ONE node; the exchange runs inside the reduce+solve kernel (no extra launch, no
  *                          collective-library call).  Every rank keeps the slots it reads in fine-grained HBM, exported through

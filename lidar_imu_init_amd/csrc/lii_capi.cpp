@@ -412,6 +412,7 @@ int lii_destroy(lii_handle h) {
   mailbox_close(&h->net.mailbox);
   if (h->net.d_mb_seq) (void)hipFree(h->net.d_mb_seq);
   if (h->net.d_gather_ticket) (void)hipFree(h->net.d_gather_ticket);
+  if (h->net.d_gx) (void)hipFree(h->net.d_gx);
   if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
   for (hipEvent_t e : h->prof.kp_ev) (void)hipEventDestroy(e);
   if (h->ev_next) (void)hipEventDestroy(h->ev_next);

@@ -19,13 +19,66 @@ int lii_comm_unique_id(uint8_t id_out[128]) {
 }  // extern "C"
 namespace lii_impl {
 void partition_refresh(lii_handle h) {
-  // (by voxel, a rank never sees the other ranks' points: the map update needs the list exchange, which the peer-mapped mailbox
-  // carries - a job on another transport stays with the split by index; lii_comm_describe says which)
-  const bool by_voxel = h->net.n_ranks > 1 && h->net.library_partition && h->net.voxel_partition && h->net.mailbox.d_gather_peers;
+  // (by voxel, a rank never sees the other ranks' points: the map update needs the list exchange, which the peer-mapped mailbox and
+  // RCCL carry - a job on the host-memory mailbox stays with the split by index; lii_comm_describe says which)
+  const bool by_voxel = h->net.n_ranks > 1 && h->net.library_partition && h->net.voxel_partition && (h->net.mailbox.d_gather_peers || h->net.comm);
   h->vh.part_world = by_voxel ? h->net.n_ranks : 0;
   h->vh.part_rank = by_voxel ? h->net.rank : 0;
   h->vh.part_overflow = h->h_res ? &h->h_res->part_overflow : nullptr;
   if (h->solo_share > 1 && h->net.n_ranks <= 1) { h->vh.part_world = h->solo_share; h->vh.part_rank = 0; }  // (LII_TEST=solo_share)
+}
+// The list exchange of a sharded job's map update over RCCL (lii_exchange.hip describes the mailbox form): pack this rank's two lists
+// into one block, all-gather the 64-byte headers, learn the longest block of the job from them (one synchronising copy - the map
+// update that follows reads the list sizes back anyway), all-gather the blocks trimmed to that length into a local area laid out like
+// a gather area, and let k_lists_collect put the lists together in rank order, in place.
+int lists_exchange_rccl(lii_handle h, hipStream_t s) {
+  const int N = h->net.n_ranks;
+  const size_t block = size_t(kGatherHeaderBytes) + sizeof(float4) * size_t(h->cfg.max_scan_points);
+  if (!h->net.d_gx || h->net.gx_block != block || h->net.gx_ranks != N) {
+    if (h->net.d_gx) HIPCHK(h, hipFree(h->net.d_gx));
+    h->net.d_gx = nullptr;
+    const size_t bytes = block * (size_t(N) + 1) + size_t(N) * kGatherHeaderBytes + sizeof(void*) * (size_t(N) + 1);
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->net.d_gx), bytes));
+    HIPCHK(h, hipMemset(h->net.d_gx, 0, bytes));
+    h->net.gx_block = block; h->net.gx_ranks = N;
+    std::vector<unsigned char*> tab(size_t(N) + 1);
+    tab[0] = h->net.d_gx;                                        // the send block (a view of one rank)
+    for (int r = 0; r < N; r++) tab[size_t(r) + 1] = h->net.d_gx + block;  // the gathered blocks (every entry: this rank's local area)
+    HIPCHK(h, hipMemcpy(h->net.d_gx + block * (size_t(N) + 1) + size_t(N) * kGatherHeaderBytes, tab.data(), sizeof(void*) * tab.size(), hipMemcpyHostToDevice));
+    if (!h->net.d_gather_ticket) {
+      HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->net.d_gather_ticket), sizeof(unsigned int)));
+      HIPCHK(h, hipMemset(h->net.d_gather_ticket, 0, sizeof(unsigned int)));
+    }
+  }
+  unsigned char* send = h->net.d_gx;
+  unsigned char* recv = h->net.d_gx + block;
+  unsigned char* hdrs = h->net.d_gx + block * (size_t(N) + 1);
+  unsigned char** tabs = reinterpret_cast<unsigned char**>(hdrs + size_t(N) * kGatherHeaderBytes);
+  const unsigned long long seq = 2ull * ++h->net.gather_seq;  // (even: both views keep to parity 0)
+  lii::GatherView one;
+  one.peers = tabs; one.block_bytes = block; one.cap_points = h->cfg.max_scan_points; one.n_ranks = 1; one.rank = 0;
+  one.timeout_ticks = h->net.mailbox_timeout_ticks;
+  launch_lists_push(one, h->d_list_add, h->d_list_nodown, h->d_counts, h->net.d_gather_ticket, seq, s);
+  ncclResult_t r = ncclAllGather(send, hdrs, kGatherHeaderBytes, ncclChar, h->net.comm, s);
+  if (r != ncclSuccess) return fail(h, LII_ERR_COMM, std::string("ncclAllGather (list headers): ") + ncclGetErrorString(r));
+  unsigned char* host_hdrs = reinterpret_cast<unsigned char*>(h->h_small + 3200);
+  HIPCHK(h, hipMemcpyAsync(host_hdrs, hdrs, size_t(N) * kGatherHeaderBytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  long long longest = 0;
+  for (int q = 0; q < N; q++) {
+    unsigned long long c = 0;
+    std::memcpy(&c, host_hdrs + size_t(q) * kGatherHeaderBytes + 8, 8);
+    longest = std::max(longest, (long long)(unsigned int)c + (long long)(unsigned int)(c >> 32));
+  }
+  if (longest > h->cfg.max_scan_points) return fail(h, LII_ERR_COMM, "list exchange: a rank announced more points than a scan holds");
+  const size_t trimmed = size_t(kGatherHeaderBytes) + sizeof(float4) * size_t(longest);
+  r = ncclAllGather(send, recv, trimmed, ncclChar, h->net.comm, s);
+  if (r != ncclSuccess) return fail(h, LII_ERR_COMM, std::string("ncclAllGather (lists): ") + ncclGetErrorString(r));
+  lii::GatherView all;
+  all.peers = tabs + 1; all.block_bytes = trimmed; all.cap_points = h->cfg.max_scan_points; all.n_ranks = N; all.rank = h->net.rank;
+  all.timeout_ticks = h->net.mailbox_timeout_ticks;
+  launch_lists_collect(all, seq, h->d_list_add, h->d_list_nodown, h->d_counts, 5, s);
+  return LII_OK;
 }
 void comm_drop(lii_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -104,8 +157,8 @@ int lii_comm_describe(lii_handle h, char* out, int32_t capacity) {
   if (h->net.n_ranks > 1) {
     s += !h->net.library_partition ? "; the caller splits the cloud"
          : (h->vh.part_world > 1 ? "; cloud split by voxel (fused filter) / by index, map lists exchanged"
-                                 : (h->net.mailbox.d_gather_peers ? "; cloud split by index, map lists exchanged" : "; cloud split by index, map update repeats the search"));
-    if (h->net.voxel_partition && h->vh.part_world <= 1) s += " (the split by voxel needs the peer-mapped mailbox)";
+                                 : ((h->net.mailbox.d_gather_peers || h->net.comm) ? "; cloud split by index, map lists exchanged" : "; cloud split by index, map update repeats the search"));
+    if (h->net.voxel_partition && h->vh.part_world <= 1) s += " (the split by voxel needs the peer-mapped mailbox or RCCL)";
   }
   std::snprintf(out, size_t(capacity), "%s", s.c_str());
   return LII_OK;

@@ -498,7 +498,10 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
   hipStream_t s = h->stream;
   RegistrationBuffers rb = reg_buffers(h);
   const lii::GatherView gv = gather_view(h);
-  const bool exchange = h->net.n_ranks > 1 && h->net.library_partition && gv.peers != nullptr;
+  // (the lists travel through the peers' gather areas - the node-local mailbox - or through ncclAllGather; a one-rank RCCL job
+  // exchanges with itself: the only form of that path a single-device box can execute)
+  const bool exchange_rccl = h->net.comm != nullptr && h->net.library_partition;
+  const bool exchange = (h->net.n_ranks > 1 && h->net.library_partition && gv.peers != nullptr) || exchange_rccl;
   if (rb.shard_world > 1 && !exchange) {
     // A job split by index on a transport without the list exchange (host-memory mailbox, RCCL): this rank holds neighbour lists
     // for its own block only, but every rank must take the SAME decisions for the whole cloud or the replicated maps drift apart.
@@ -512,7 +515,7 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
     }
   }
   // decision per point on the device (world point, neighbour list of the last search) and both order-preserving compactions
-  const bool sharded = h->net.n_ranks > 1;
+  const bool sharded = h->net.n_ranks > 1 || exchange_rccl;
   // (near max_map_points the padded bounds could fail the capacity test a batch of the exact sizes passes: the waiting form then)
   const bool room_for_bounds = h->pred_add >= 0 && !h->map_dirty &&
                                (long long)h->n_map + std::min(nb, h->pred_add) + std::min(nb, h->pred_nodown) <= (long long)h->cfg.max_map_points;
@@ -536,8 +539,13 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
   if (exchange) {
     // This rank has decided for ITS points (its block of the cloud, or its voxels): the lists of all ranks, in rank order, are the
     // batch every replica of the map receives (lii_exchange.hip: remote stores into the peers' gather areas; in place here).
-    launch_lists_exchange(gv, h->d_list_add, h->d_list_nodown, h->d_counts, 5, h->net.d_gather_ticket, ++h->net.gather_seq, h->d_list_add,
-                          h->d_list_nodown, s);
+    if (exchange_rccl) {
+      const int rcx = lists_exchange_rccl(h, s);
+      if (rcx != LII_OK) return rcx;
+    } else {
+      launch_lists_exchange(gv, h->d_list_add, h->d_list_nodown, h->d_counts, 5, h->net.d_gather_ticket, ++h->net.gather_seq, h->d_list_add,
+                            h->d_list_nodown, s);
+    }
   }
   // The sizes of the two lists, now: a converged map takes a few thousand of the ~100 k points, and everything downstream
   // (voxel keys, the batch sort, the per-voxel fold, the insert compaction) is launched for the exact count instead of the

@@ -201,6 +201,8 @@ struct lii_context {
     MailboxHost mailbox;         // node-local transport: the exchange happens inside k_reduce_solve
     unsigned long long* d_mb_seq = nullptr;
     unsigned int* d_gather_ticket = nullptr;  // the list exchange of lii_map_incremental (lii_exchange.hip): its ticket word,
+    unsigned char* d_gx = nullptr;            // RCCL form of the list exchange: send block | N gathered blocks | N headers | pointer tables
+    size_t gx_block = 0; int gx_ranks = 0;    // ... laid out for this block size (64 + 16 max_scan_points) and this many ranks
     unsigned long long gather_seq = 0;        // ... and the exchanges enqueued so far (the ranks call in lock-step: the same on all)
     long long mailbox_timeout_ticks = 3000000000ll;  // 30 s (LII_MAILBOX_TIMEOUT_S): ranks may start a scan seconds apart
     int n_ranks = 1, rank = 0;
@@ -276,5 +278,6 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
               const int* n_list_dev = nullptr, const int* n_extra_dev = nullptr, bool count_events = true);
 // lii_capi_comm.cpp
 void comm_drop(lii_handle h);
-void partition_refresh(lii_handle h);  // (lii_capi_comm.cpp) the voxel filter's view of the job after the communicator or its partition changed
+void partition_refresh(lii_handle h);
+int lists_exchange_rccl(lii_handle h, hipStream_t s);  // (lii_capi_comm.cpp) the list exchange of lii_map_incremental over ncclAllGather; synchronises the stream once  // (lii_capi_comm.cpp) the voxel filter's view of the job after the communicator or its partition changed
 }  // namespace lii_impl

@@ -10,6 +10,9 @@
 //                    EVERY rank's area; the workgroup that finishes last (a ticket) writes the headers and then the flags
 //   k_lists_collect  waits for the flags of all source ranks in the OWN area, adds up the sizes in rank order and copies the
 //                    payloads behind each other; a source that does not deliver in time raises counts[err_at]
+// A job on the RCCL transport runs the same two kernels around two ncclAllGather calls (lii_capi_comm.cpp: lists_exchange_rccl): the
+// push packs this rank's block into a send buffer (a view of one rank), the blocks - trimmed to the longest list of the job, which
+// a first all-gather of the 64-byte headers tells - are gathered into a local area laid out like a gather area, the collect reads that.
 #include <hip/hip_runtime.h>
 
 #include "lii_device.h"
@@ -112,12 +115,19 @@ __global__ __launch_bounds__(256) void k_lists_collect(GatherView gv, unsigned l
 
 }  // namespace
 
+// (a few thousand points per list: a handful of workgroups moves them; every one of the push's ends in a device-scope ticket)
+constexpr int kListBlocks = 16;
+void launch_lists_push(const GatherView& gv, const float4* src_add, const float4* src_nodown, const int* counts, unsigned int* ticket,
+                       unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_lists_push, dim3(kListBlocks), dim3(256), 0, s, gv, src_add, src_nodown, counts, ticket, seq);
+}
+void launch_lists_collect(const GatherView& gv, unsigned long long seq, float4* dst_add, float4* dst_nodown, int* counts, int err_at, hipStream_t s) {
+  hipLaunchKernelGGL(k_lists_collect, dim3(kListBlocks), dim3(256), 0, s, gv, seq, dst_add, dst_nodown, counts, err_at);
+}
 void launch_lists_exchange(const GatherView& gv, const float4* src_add, const float4* src_nodown, int* counts, int err_at, unsigned int* ticket,
                            unsigned long long seq, float4* dst_add, float4* dst_nodown, hipStream_t s) {
-  // (a few thousand points per list: a handful of workgroups moves them; every one of them ends in a device-scope ticket)
-  const int nb = 16;
-  hipLaunchKernelGGL(k_lists_push, dim3(nb), dim3(256), 0, s, gv, src_add, src_nodown, counts, ticket, seq);
-  hipLaunchKernelGGL(k_lists_collect, dim3(nb), dim3(256), 0, s, gv, seq, dst_add, dst_nodown, counts, err_at);
+  launch_lists_push(gv, src_add, src_nodown, counts, ticket, seq, s);
+  launch_lists_collect(gv, seq, dst_add, dst_nodown, counts, err_at, s);
 }
 
 }  // namespace lii

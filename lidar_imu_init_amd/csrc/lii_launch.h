@@ -62,6 +62,9 @@ int mailbox_open(const uint8_t id[128], int n_ranks, int rank, double wait_s, bo
 // the list exchange (lii_exchange.hip): push this rank's lists (sizes in counts[0..1], device) into every rank's gather area, wait for
 // all ranks' lists of exchange number `seq` (1, 2, ... - the same on every rank) and leave them concatenated in rank order in
 // dst_add / dst_nodown (may be the sources), the totals in counts[0..1]; counts[err_at] = 1 when a rank did not deliver in time.
+void launch_lists_push(const GatherView& gv, const float4* src_add, const float4* src_nodown, const int* counts, unsigned int* ticket,
+                       unsigned long long seq, hipStream_t s);
+void launch_lists_collect(const GatherView& gv, unsigned long long seq, float4* dst_add, float4* dst_nodown, int* counts, int err_at, hipStream_t s);
 void launch_lists_exchange(const GatherView& gv, const float4* src_add, const float4* src_nodown, int* counts, int err_at, unsigned int* ticket,
                            unsigned long long seq, float4* dst_add, float4* dst_nodown, hipStream_t s);
 void mailbox_close(MailboxHost* m);

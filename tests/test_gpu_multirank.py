@@ -111,6 +111,25 @@ def test_two_ranks_on_two_devices(tmp_path, transport):
     assert np.array_equal(two[0]["map_sizes"], two[1]["map_sizes"]) and np.array_equal(_rows(two[0]["map_final"]), _rows(two[1]["map_final"]))
 
 
+@pytest.mark.parametrize("transport", ["mailbox", "rccl"])
+def test_two_ranks_split_by_voxel_on_two_devices(tmp_path, transport):
+    """The split by voxel with one device per rank: the list exchange of the map update crosses xGMI (remote stores into the peer's
+    gather area) or runs as two real ncclAllGather calls.  Skipped on the single-GPU development boxes."""
+    if _n_devices() < 2:
+        pytest.skip("one visible device: the cross-device forms of the transports cannot run here")
+    env = {"LII_WORKER_PARTITION": "voxel"}
+    one = _run_ranks(tmp_path, 1, env=env)[0]
+    two = _run_ranks(tmp_path, 2, transport=transport, devices=[0, 1], env=env)
+    assert all(str(t["transport"]) == transport and "split by voxel" in str(t["describe"]) for t in two), [str(t["describe"]) for t in two]
+    for key in ("states", "reports", "sums", "sums_b", "map_sizes"):
+        assert np.array_equal(two[0][key], two[1][key]), key
+    assert np.array_equal(_rows(two[0]["map_final"]), _rows(two[1]["map_final"]))
+    assert np.array_equal(two[0]["n_local"] + two[1]["n_local"], one["n_local"])
+    assert np.max(np.abs(one["sums_b"][0] - two[0]["sums_b"][0])) <= 1e-11 * np.max(np.abs(one["sums_b"][0]))
+    assert np.max(np.abs(one["states"][:, :12] - two[0]["states"][:, :12])) <= 1e-6
+    assert np.all(np.abs(one["map_sizes"] - two[0]["map_sizes"]) <= 3)
+
+
 def test_four_ranks_on_four_devices(tmp_path):
     if _n_devices() < 4:
         pytest.skip("fewer than four visible devices")
@@ -232,6 +251,7 @@ def test_rccl_transport_on_a_one_rank_communicator(tmp_path):
     """ncclCommInitRank(1 rank) + ncclAllReduce inside the loop: the three-launch form of the update must give the fused
     loop's result bit for bit (the all-reduce over one rank is the identity).  RCCL with N > 1 needs N devices and has not
     been executed anywhere yet (this box has one GPU) - stated in DESIGN.md section 6."""
+    # (the map update of the RCCL job exchanges its insert lists - with itself here: pack, two ncclAllGather, collect - lii_capi_comm.cpp)
     fused = _run_ranks(tmp_path, 1)[0]
     rccl = _run_ranks(tmp_path, 1, transport="rccl")[0]
     assert str(rccl["transport"]) == "rccl" and str(fused["transport"]) == "none"
