@@ -326,6 +326,12 @@ def main():
         nonlocal last
         n_steps = args.steps if n_steps is None else n_steps
         n_warmup = args.warmup if n_warmup is None else n_warmup
+        # (a cyclic garbage collection of the interpreter - ~1 ms over this process's objects - is kept out of the timed region: it
+        # is triggered by allocation counts, i.e. lands at a fixed point of the script, and round 4's found it inside a 20-step region;
+        # it stays off for the rest of the run - the separately timed pipeline figures included.  Collected BEFORE the warm-up steps:
+        # between them and the timed ones the device must not sit idle for a millisecond - it would start the region from a lower clock)
+        gc.collect()
+        gc.disable()
         if native:
             native(0, prime + n_warmup, 0)
         else:
@@ -335,11 +341,6 @@ def main():
         reg.set_profiling(1)
         reg.set_profiling(0)
         iters_total[0] = search_total[0] = 0
-        # (a cyclic garbage collection of the interpreter - ~1 ms over this process's objects - is kept out of the timed region: it
-        # is triggered by allocation counts, i.e. lands at a fixed point of the script, and round 4's found it inside a 20-step region;
-        # it stays off for the rest of the run - the separately timed pipeline figures included)
-        gc.collect()
-        gc.disable()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
