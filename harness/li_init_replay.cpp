@@ -601,11 +601,11 @@ static int process(lii_replay* r) {
     return LII_OK;
   }
   // ---- ICP + iterated Kalman filter update (:957-1134) and map_incremental (:1146)
+  // (map_incremental rides in the job - lii_scan_job::map_update: its launches are enqueued behind the update's passes)
   lii_iekf_report rep{};
+  job.map_update = 1;
   int rc = lii_scan_register(r->h, &job, &st, &r->state_propagat, &rep);
-  if (rc != LII_OK) return fail(r, rc, std::string("lii_scan_register: ") + lii_last_error(r->h));
-  rc = lii_map_incremental(r->h, &st, nullptr, nullptr);
-  if (rc != LII_OK) return fail(r, rc, std::string("lii_map_incremental: ") + lii_last_error(r->h));
+  if (rc != LII_OK) return fail(r, rc, std::string("lii_scan_register (+ map_incremental): ") + lii_last_error(r->h));
   // ---- "Device starts to move, data accumulation begins" (:1151-1155)
   const double pn = std::sqrt(st.pos_end[0] * st.pos_end[0] + st.pos_end[1] * st.pos_end[1] + st.pos_end[2] * st.pos_end[2]);
   if (!r->imu_en && !r->data_accum_start && pn > 0.05) {
