@@ -383,6 +383,15 @@ int lii_comm_describe(lii_handle h, char* out, int32_t capacity);
 int lii_comm_rccl_ranks(lii_handle h, int32_t* n_ranks);  /* ncclCommCount of the attached RCCL communicator; 0: none attached */
 int lii_comm_set_partition(lii_handle h, int32_t library_partition);  /* 0 caller | 1 by index (default) | 2 by voxel */
 int lii_comm_destroy(lii_handle h);
+/* Self-test of the list exchange of a sharded job's map update (lii_map_incremental; lii_exchange.hip) with n_ranks > 1 on ONE device:
+ * the handle (not a rank of a job) plays rank 0 .. n_ranks - 1 in turn.  form 0: the gather areas of the mailbox transport; form 1:
+ * the trimmed all-gather layout of the RCCL transport (the functions lists_exchange_rccl is made of, device copies standing in for the
+ * two ncclAllGather calls - a communicator holds one rank per device, the layout can still be exercised).  Rank r's lists: n_add[r] /
+ * n_nodown[r] points (x, y, z, w) behind each other in add_xyzw / nodown_xyzw.  Every played rank must end with the identical pair
+ * of joined lists (else LII_ERR_COMM); they are returned (capacity: points per output).  Reference: the two Add_Points calls every
+ * replica of the map must receive identically, src/laserMapping.cpp:556-557. */
+int lii_selftest_list_exchange(lii_handle h, int32_t n_ranks, int32_t form, const float* add_xyzw, const int32_t* n_add, const float* nodown_xyzw,
+                               const int32_t* n_nodown, float* out_add, int32_t* out_n_add, float* out_nodown, int32_t* out_n_nodown, int32_t capacity);
 
 /* ---------------------------------------------------------------- parameter surface (config/<sensor>.yaml + launch/<sensor>.launch)
  * The nh.param<> block of main() (src/laserMapping.cpp:767-799) as a POD: same names (`section/key` -> field), same defaults.

@@ -135,6 +135,8 @@ _DECLS = {
     "lii_comm_rccl_ranks": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lii_comm_set_partition": (C.c_int, [C.c_void_p, C.c_int32]),
     "lii_comm_destroy": (C.c_int, [C.c_void_p]),
+    "lii_selftest_list_exchange": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32), C.c_int32]),
     "lii_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "lii_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lii_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -543,6 +545,23 @@ class Registrar:
         n = C.c_int32(0)
         self._check(self.L.lii_comm_rccl_ranks(self.h, C.byref(n)))
         return int(n.value)
+
+    def selftest_list_exchange(self, add_lists, nodown_lists, form):
+        """The list exchange of a sharded job's map update played by ONE handle for len(add_lists) ranks (form "gather": the mailbox
+        transport's gather areas, "allgather": the trimmed all-gather layout of the RCCL transport); rank r's lists are (n, 4) float32.
+        Returns the joined (add, nodown) lists every played rank ended with."""
+        n = len(add_lists)
+        assert n == len(nodown_lists) and n >= 1
+        na = np.array([len(a) for a in add_lists], np.int32)
+        nn = np.array([len(a) for a in nodown_lists], np.int32)
+        cat = lambda ls: np.ascontiguousarray(np.concatenate([np.asarray(a, np.float32).reshape(-1, 4) for a in ls] + [np.zeros((1, 4), np.float32)]))
+        a, d = cat(add_lists), cat(nodown_lists)
+        cap = int(max(na.sum(), nn.sum(), 1))
+        oa, od = np.zeros((cap, 4), np.float32), np.zeros((cap, 4), np.float32)
+        ona, onn = C.c_int32(0), C.c_int32(0)
+        self._check(self.L.lii_selftest_list_exchange(self.h, n, {"gather": 0, "allgather": 1}[form], _ptr(a), _ptr(na), _ptr(d), _ptr(nn),
+                                                      _ptr(oa), C.byref(ona), _ptr(od), C.byref(onn), cap))
+        return oa[:ona.value].copy(), od[:onn.value].copy()
 
     def comm_destroy(self):
         self._check(self.L.lii_comm_destroy(self.h))

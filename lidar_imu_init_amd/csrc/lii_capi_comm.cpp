@@ -31,8 +31,16 @@ void partition_refresh(lii_handle h) {
 // into one block, all-gather the 64-byte headers, learn the longest block of the job from them (one synchronising copy - the map
 // update that follows reads the list sizes back anyway), all-gather the blocks trimmed to that length into a local area laid out like
 // a gather area, and let k_lists_collect put the lists together in rank order, in place.
-int lists_exchange_rccl(lii_handle h, hipStream_t s) {
-  const int N = h->net.n_ranks;
+// Three steps, the collective a parameter of the last: lii_selftest_list_exchange plays the ranks of a job one after the other on ONE
+// device with copies standing in for ncclAllGather - the trimmed layout with N > 1 is then exercised where RCCL cannot be (a
+// communicator holds one rank per device).
+namespace {
+struct GxLayout {
+  unsigned char *send, *recv, *hdrs;
+  unsigned char** tabs;
+  size_t block;
+};
+int gx_prepare(lii_handle h, int N, GxLayout* L) {
   const size_t block = size_t(kGatherHeaderBytes) + sizeof(float4) * size_t(h->cfg.max_scan_points);
   if (!h->net.d_gx || h->net.gx_block != block || h->net.gx_ranks != N) {
     if (h->net.d_gx) HIPCHK(h, hipFree(h->net.d_gx));
@@ -50,19 +58,27 @@ int lists_exchange_rccl(lii_handle h, hipStream_t s) {
       HIPCHK(h, hipMemset(h->net.d_gather_ticket, 0, sizeof(unsigned int)));
     }
   }
-  unsigned char* send = h->net.d_gx;
-  unsigned char* recv = h->net.d_gx + block;
-  unsigned char* hdrs = h->net.d_gx + block * (size_t(N) + 1);
-  unsigned char** tabs = reinterpret_cast<unsigned char**>(hdrs + size_t(N) * kGatherHeaderBytes);
-  const unsigned long long seq = 2ull * ++h->net.gather_seq;  // (even: both views keep to parity 0)
+  L->block = block;
+  L->send = h->net.d_gx;
+  L->recv = h->net.d_gx + block;
+  L->hdrs = h->net.d_gx + block * (size_t(N) + 1);
+  L->tabs = reinterpret_cast<unsigned char**>(L->hdrs + size_t(N) * kGatherHeaderBytes);
+  return LII_OK;
+}
+// this rank's lists (h->d_list_add / d_list_nodown, sizes in h->d_counts[0..1]) -> the send block
+void gx_push(lii_handle h, const GxLayout& L, unsigned long long seq, hipStream_t s) {
   lii::GatherView one;
-  one.peers = tabs; one.block_bytes = block; one.cap_points = h->cfg.max_scan_points; one.n_ranks = 1; one.rank = 0;
+  one.peers = L.tabs; one.block_bytes = L.block; one.cap_points = h->cfg.max_scan_points; one.n_ranks = 1; one.rank = 0;
   one.timeout_ticks = h->net.mailbox_timeout_ticks;
   launch_lists_push(one, h->d_list_add, h->d_list_nodown, h->d_counts, h->net.d_gather_ticket, seq, s);
-  ncclResult_t r = ncclAllGather(send, hdrs, kGatherHeaderBytes, ncclChar, h->net.comm, s);
-  if (r != ncclSuccess) return fail(h, LII_ERR_COMM, std::string("ncclAllGather (list headers): ") + ncclGetErrorString(r));
+}
+// gather(send, recv, bytes): every rank's first `bytes` bytes of `send`, in rank order, into `recv` (0: fine; else an error text)
+template <class Gather>
+int gx_gather_collect(lii_handle h, const GxLayout& L, int N, int rank, unsigned long long seq, hipStream_t s, Gather&& gather) {
+  std::string e = gather(L.send, L.hdrs, size_t(kGatherHeaderBytes));
+  if (!e.empty()) return fail(h, LII_ERR_COMM, "list headers: " + e);
   unsigned char* host_hdrs = reinterpret_cast<unsigned char*>(h->h_small + 3200);
-  HIPCHK(h, hipMemcpyAsync(host_hdrs, hdrs, size_t(N) * kGatherHeaderBytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(host_hdrs, L.hdrs, size_t(N) * kGatherHeaderBytes, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   long long longest = 0;
   for (int q = 0; q < N; q++) {
@@ -72,13 +88,26 @@ int lists_exchange_rccl(lii_handle h, hipStream_t s) {
   }
   if (longest > h->cfg.max_scan_points) return fail(h, LII_ERR_COMM, "list exchange: a rank announced more points than a scan holds");
   const size_t trimmed = size_t(kGatherHeaderBytes) + sizeof(float4) * size_t(longest);
-  r = ncclAllGather(send, recv, trimmed, ncclChar, h->net.comm, s);
-  if (r != ncclSuccess) return fail(h, LII_ERR_COMM, std::string("ncclAllGather (lists): ") + ncclGetErrorString(r));
+  e = gather(L.send, L.recv, trimmed);
+  if (!e.empty()) return fail(h, LII_ERR_COMM, "lists: " + e);
   lii::GatherView all;
-  all.peers = tabs + 1; all.block_bytes = trimmed; all.cap_points = h->cfg.max_scan_points; all.n_ranks = N; all.rank = h->net.rank;
+  all.peers = L.tabs + 1; all.block_bytes = trimmed; all.cap_points = h->cfg.max_scan_points; all.n_ranks = N; all.rank = rank;
   all.timeout_ticks = h->net.mailbox_timeout_ticks;
   launch_lists_collect(all, seq, h->d_list_add, h->d_list_nodown, h->d_counts, 5, s);
   return LII_OK;
+}
+}  // namespace
+int lists_exchange_rccl(lii_handle h, hipStream_t s) {
+  const int N = h->net.n_ranks;
+  GxLayout L;
+  int rc = gx_prepare(h, N, &L);
+  if (rc != LII_OK) return rc;
+  const unsigned long long seq = 2ull * ++h->net.gather_seq;  // (even: both views keep to parity 0)
+  gx_push(h, L, seq, s);
+  return gx_gather_collect(h, L, N, h->net.rank, seq, s, [&](const unsigned char* send, unsigned char* recv, size_t bytes) -> std::string {
+    const ncclResult_t r = ncclAllGather(send, recv, bytes, ncclChar, h->net.comm, s);
+    return r == ncclSuccess ? std::string() : std::string("ncclAllGather: ") + ncclGetErrorString(r);
+  });
 }
 void comm_drop(lii_handle h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -86,6 +115,13 @@ void comm_drop(lii_handle h) {
   mailbox_close(&h->net.mailbox);
   h->net.n_ranks = 1;
   h->net.rank = 0;
+  // The list exchange numbers its rounds, and the ranks of a job must count alike: whatever transport comes next starts from 0 on
+  // EVERY rank - a handle that is re-attached beside a fresh one would otherwise carry its old count into the headers, and
+  // k_lists_collect's `v >= seq` on the fresh rank's side would never see it arrive.  The RCCL form's local areas
+  // hold headers of the old numbering: dropped with it (lists_exchange_rccl lays them out again, zeroed).
+  h->net.gather_seq = 0;
+  if (h->net.d_gx) { (void)hipFree(h->net.d_gx); h->net.d_gx = nullptr; h->net.gx_block = 0; h->net.gx_ranks = 0; }
+  if (h->net.d_gather_ticket) (void)hipMemset(h->net.d_gather_ticket, 0, sizeof(unsigned int));
   partition_refresh(h);
 }
 }  // namespace lii_impl
@@ -193,6 +229,121 @@ int lii_comm_destroy(lii_handle h) {
   if (!h) return LII_ERR_INVALID;
   (void)hipSetDevice(h->device);
   comm_drop(h);
+  return LII_OK;
+}
+
+// Self-test of the list exchange's two layouts with SEVERAL ranks on one device (liinit_hip.h).  The handle plays rank 0 .. n_ranks - 1
+// in turn: form 0 - the gather areas of the mailbox transport (every rank's push stores into every rank's area, every rank collects from
+// its own); form 1 - the trimmed all-gather layout of the RCCL transport, through the very functions lists_exchange_rccl is made of,
+// device copies standing in for the two ncclAllGather calls.  Every rank must end with the identical pair of lists; rank 0's is returned.
+int lii_selftest_list_exchange(lii_handle h, int32_t n_ranks, int32_t form, const float* add_xyzw, const int32_t* n_add, const float* nodown_xyzw,
+                               const int32_t* n_nodown, float* out_add, int32_t* out_n_add, float* out_nodown, int32_t* out_n_nodown, int32_t capacity) {
+  if (!h || n_ranks < 1 || n_ranks > kMailboxMaxRanks || (form != 0 && form != 1) || !n_add || !n_nodown || !out_add || !out_n_add || !out_nodown || !out_n_nodown)
+    return fail(h, LII_ERR_INVALID, "lii_selftest_list_exchange: bad arguments");
+  if (h->net.n_ranks > 1 || h->net.comm) return fail(h, LII_ERR_STATE, "lii_selftest_list_exchange: the handle is a rank of a job");
+  const int N = n_ranks, cap = h->cfg.max_scan_points;
+  std::vector<size_t> at_a(size_t(N) + 1, 0), at_n(size_t(N) + 1, 0);
+  for (int r = 0; r < N; r++) {
+    if (n_add[r] < 0 || n_nodown[r] < 0 || n_add[r] + n_nodown[r] > cap) return fail(h, LII_ERR_CAPACITY, "lii_selftest_list_exchange: a rank's lists exceed max_scan_points");
+    at_a[size_t(r) + 1] = at_a[size_t(r)] + size_t(n_add[r]);
+    at_n[size_t(r) + 1] = at_n[size_t(r)] + size_t(n_nodown[r]);
+  }
+  if (at_a[size_t(N)] > size_t(cap) || at_n[size_t(N)] > size_t(cap) || at_a[size_t(N)] > size_t(capacity) || at_n[size_t(N)] > size_t(capacity))
+    return fail(h, LII_ERR_CAPACITY, "lii_selftest_list_exchange: the joined lists exceed max_scan_points or the output capacity");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = map_join(h);
+  if (rc != LII_OK) return rc;
+  hipStream_t s = h->stream;
+  HIPCHK(h, hipStreamSynchronize(s));
+  const size_t block = size_t(kGatherHeaderBytes) + sizeof(float4) * size_t(cap);
+  std::vector<unsigned char*> bufs;  // temporaries of this call
+  auto cleanup = [&]() { for (unsigned char* b : bufs) (void)hipFree(b); };
+  auto upload_rank = [&](int r) -> int {  // rank r's lists and sizes into the handle's list buffers
+    const int c[6] = {n_add[r], n_nodown[r], 0, 0, 0, 0};
+    if (n_add[r]) HIPCHK(h, hipMemcpyAsync(h->d_list_add, add_xyzw + 4 * at_a[size_t(r)], sizeof(float4) * size_t(n_add[r]), hipMemcpyHostToDevice, s));
+    if (n_nodown[r]) HIPCHK(h, hipMemcpyAsync(h->d_list_nodown, nodown_xyzw + 4 * at_n[size_t(r)], sizeof(float4) * size_t(n_nodown[r]), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_counts, c, sizeof(c), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return LII_OK;
+  };
+  std::vector<float> got_a, got_n, ref_a, ref_n;
+  int ref_na = -1, ref_nn = -1;
+  auto download_and_compare = [&](int q) -> int {
+    int c[6];
+    HIPCHK(h, hipMemcpyAsync(c, h->d_counts, sizeof(c), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (c[5]) return fail(h, LII_ERR_COMM, "lii_selftest_list_exchange: the collect timed out");
+    if (c[0] < 0 || c[1] < 0 || c[0] > cap || c[1] > cap) return fail(h, LII_ERR_HIP, "lii_selftest_list_exchange: sizes out of range");
+    got_a.assign(4 * size_t(c[0]), 0.f); got_n.assign(4 * size_t(c[1]), 0.f);
+    if (c[0]) HIPCHK(h, hipMemcpy(got_a.data(), h->d_list_add, sizeof(float4) * size_t(c[0]), hipMemcpyDeviceToHost));
+    if (c[1]) HIPCHK(h, hipMemcpy(got_n.data(), h->d_list_nodown, sizeof(float4) * size_t(c[1]), hipMemcpyDeviceToHost));
+    if (q == 0) { ref_a = got_a; ref_n = got_n; ref_na = c[0]; ref_nn = c[1]; return LII_OK; }
+    if (c[0] != ref_na || c[1] != ref_nn || std::memcmp(got_a.data(), ref_a.data(), sizeof(float) * got_a.size()) != 0 ||
+        std::memcmp(got_n.data(), ref_n.data(), sizeof(float) * got_n.size()) != 0)
+      return fail(h, LII_ERR_COMM, "lii_selftest_list_exchange: rank " + std::to_string(q) + " put together other lists than rank 0");
+    return LII_OK;
+  };
+  if (!h->net.d_gather_ticket) {
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->net.d_gather_ticket), sizeof(unsigned int)));
+    HIPCHK(h, hipMemset(h->net.d_gather_ticket, 0, sizeof(unsigned int)));
+  }
+  const unsigned long long seq = form == 0 ? ++h->net.gather_seq : 2ull * ++h->net.gather_seq;
+  if (form == 0) {
+    // N gather areas (two parities x N source blocks each) and the table of them, as mailbox_open lays them out
+    const size_t area = 2 * size_t(N) * block;
+    unsigned char* base = nullptr;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&base), area * size_t(N) + sizeof(void*) * size_t(N)));
+    bufs.push_back(base);
+    if (hipMemset(base, 0, area * size_t(N)) != hipSuccess) { cleanup(); return fail(h, LII_ERR_HIP, "hipMemset"); }
+    std::vector<unsigned char*> tab(static_cast<size_t>(N));
+    for (int r = 0; r < N; r++) tab[size_t(r)] = base + area * size_t(r);
+    unsigned char** d_tab = reinterpret_cast<unsigned char**>(base + area * size_t(N));
+    if (hipMemcpy(d_tab, tab.data(), sizeof(void*) * size_t(N), hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(h, LII_ERR_HIP, "hipMemcpy"); }
+    lii::GatherView gv;
+    gv.peers = d_tab; gv.block_bytes = block; gv.cap_points = cap; gv.n_ranks = N; gv.timeout_ticks = 200000000ll;  // 2 s
+    for (int r = 0; r < N && rc == LII_OK; r++) {
+      rc = upload_rank(r);
+      gv.rank = r;
+      if (rc == LII_OK) launch_lists_push(gv, h->d_list_add, h->d_list_nodown, h->d_counts, h->net.d_gather_ticket, seq, s);
+      if (rc == LII_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(h, LII_ERR_HIP, "lists push");
+    }
+    for (int q = 0; q < N && rc == LII_OK; q++) {
+      gv.rank = q;
+      launch_lists_collect(gv, seq, h->d_list_add, h->d_list_nodown, h->d_counts, 5, s);
+      rc = download_and_compare(q);
+    }
+  } else {
+    GxLayout L;
+    rc = gx_prepare(h, N, &L);
+    unsigned char* sends = nullptr;  // every rank's send block, kept while the others are played
+    if (rc == LII_OK) {
+      if (hipMalloc(reinterpret_cast<void**>(&sends), block * size_t(N)) != hipSuccess) rc = fail(h, LII_ERR_HIP, "hipMalloc");
+      else bufs.push_back(sends);
+    }
+    for (int r = 0; r < N && rc == LII_OK; r++) {
+      rc = upload_rank(r);
+      if (rc != LII_OK) break;
+      gx_push(h, L, seq, s);
+      if (hipMemcpyAsync(sends + block * size_t(r), L.send, block, hipMemcpyDeviceToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        rc = fail(h, LII_ERR_HIP, "lists push (send block)");
+    }
+    for (int q = 0; q < N && rc == LII_OK; q++) {
+      // rank q's view: its own send block in place, the all-gathers deliver the first `bytes` bytes of every rank's block in rank order
+      if (hipMemcpyAsync(L.send, sends + block * size_t(q), block, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = fail(h, LII_ERR_HIP, "hipMemcpyAsync"); break; }
+      if (hipMemsetAsync(L.recv, 0xEE, block * size_t(N), s) != hipSuccess) { rc = fail(h, LII_ERR_HIP, "hipMemsetAsync"); break; }  // (nothing stale may pass for data)
+      rc = gx_gather_collect(h, L, N, q, seq, s, [&](const unsigned char*, unsigned char* recv, size_t bytes) -> std::string {
+        for (int r = 0; r < N; r++)
+          if (hipMemcpyAsync(recv + bytes * size_t(r), sends + block * size_t(r), bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return "copy standing in for the all-gather failed";
+        return std::string();
+      });
+      if (rc == LII_OK) rc = download_and_compare(q);
+    }
+  }
+  cleanup();
+  if (rc != LII_OK) return rc;
+  *out_n_add = ref_na; *out_n_nodown = ref_nn;
+  if (ref_na) std::memcpy(out_add, ref_a.data(), sizeof(float) * ref_a.size());
+  if (ref_nn) std::memcpy(out_nodown, ref_n.data(), sizeof(float) * ref_n.size());
   return LII_OK;
 }
 

@@ -73,8 +73,10 @@ void fill_ctrl(lii_handle h, const lii_state* state, const lii_state* state_prop
   h->update_seq = h->update_seq == 0x7FFFFFFF ? 1 : h->update_seq + 1;
   hc->seq = h->update_seq;
   // which k-NN launches ride along (IekfCtrl::plan_mask): the first pass always; the others as the previous update needed them
+  // (the mask holds 16 passes: a longer loop is enqueued whole - the device takes every pass from 16 on for enqueued, which a
+  // plan that ends earlier would not honour - ADVICE r4)
   unsigned int plan = 0xFFFFFFFFu;
-  if (h->knn_plan && !h->net.comm) {
+  if (h->knn_plan && !h->net.comm && opts->max_iterations <= 16) {
     plan = (h->knn_plan_force >= 0 ? ((unsigned int)h->knn_plan_force | 0xFFFF0000u) : h->plan_next) | 0x00010001u;
   }
   hc->plan_mask = plan;
@@ -216,6 +218,10 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     // (a batch that cannot be enqueued now - no room for the predicted sizes - is not this update's failure: the map update is made
     // when the update has ended, by the call that reports such things)
     h->map_enqueued_early = map_update_early(h) == 1;
+    // (map_apply rebuilds the index when the map is short of room - build_index may free and reallocate the block table, the cell
+    // tables and their side arrays and change the mask: a loop that parks is continued below with launches that must see the map
+    // as it is NOW, not the view taken before the passes went out - ADVICE r4)
+    g = grid_view(h);
     if (h->diag) h->prof.host_map_us[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_me0).count();
   }
   rc = wait_result(true);
@@ -230,6 +236,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     const bool search = h->h_res->parked_search != 0;
     h->plan_parked++;
     h->map_enqueued_early = false;  // (that launch saw a parked loop and did nothing: the caller makes the map update when the loop has ended)
+    g = grid_view(h);  // (see above: never a view older than the last thing that may have rebuilt the index)
     const int last = std::min(opts->max_iterations, std::max(h->plan_passes_prev, from + 1));  // (exclusive; from < max_iterations: the last pass never parks)
     unsigned int rplan = 0u;
     for (int q = from; q < last && q < 16; q++) rplan |= 1u << (16 + q);

@@ -221,6 +221,41 @@ def test_list_exchange_equals_the_repeated_search(tmp_path):
     assert np.array_equal(_rows(a[0]["map_final"]), _rows(b[0]["map_final"]))
 
 
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_list_exchange_layouts_with_several_ranks_on_one_device(world):
+    """k_lists_push / k_lists_collect over the TRIMMED all-gather layout lists_exchange_rccl builds (block_bytes =
+    header + the longest block of the job, every peers[] entry the same local area) had only ever run with one rank - a communicator
+    holds one rank per device.  lii_selftest_list_exchange plays the ranks one after the other through the functions
+    lists_exchange_rccl is made of, device copies standing in for the two ncclAllGather calls, and through the gather areas of the
+    mailbox transport: both forms must hand every rank the lists of all ranks, concatenated in rank order, bit for bit."""
+    import lidar_imu_init_amd as lii
+    rng = np.random.default_rng(40 + world)
+    reg = lii.Registrar(max_scan_points=6000, max_map_points=1000)
+    try:
+        for trial in range(3):
+            # ragged on purpose: an empty rank, a rank with one list only, the longest block in the middle
+            sizes_a = rng.integers(0, 900, world)
+            sizes_n = rng.integers(0, 300, world)
+            if trial == 0:
+                sizes_a[0] = 0; sizes_n[0] = 0
+            if trial == 1:
+                sizes_a[-1] = 0
+                sizes_n[world // 2] = 0
+                sizes_a[world // 2] = 1100
+            adds = [rng.normal(size=(int(k), 4)).astype(np.float32) for k in sizes_a]
+            nods = [rng.normal(size=(int(k), 4)).astype(np.float32) for k in sizes_n]
+            want_a, want_n = np.concatenate(adds), np.concatenate(nods)
+            for form in ("gather", "allgather"):
+                got_a, got_n = reg.selftest_list_exchange(adds, nods, form)
+                assert got_a.shape == want_a.shape and got_n.shape == want_n.shape, (form, trial)
+                assert got_a.tobytes() == want_a.tobytes() and got_n.tobytes() == want_n.tobytes(), (form, trial)
+        # capacity: a rank's lists together may fill the scan, the joined lists may not exceed it
+        with pytest.raises(lii.LIIError):
+            reg.selftest_list_exchange([np.zeros((4000, 4), np.float32)] * 2, [np.zeros((0, 4), np.float32)] * 2, "allgather")
+    finally:
+        reg.close()
+
+
 def test_one_process_rehearses_a_share(tmp_path):
     """LII_TEST=solo_share=<N> (tools/gpu_share.sh: the durations of ONE rank's launches without N devices): rank 0's share of an
     N-rank job split by voxel (N > 1) or by index (N < -1) in a single process, nothing exchanged."""

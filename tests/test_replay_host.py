@@ -428,3 +428,73 @@ def test_replay_host_takes_livox_messages_with_the_avia_launch_file():
     # calibration; here: it ends near the truth and never loses the trajectory)
     print(f"avia LO through the C++ host: final position error {pos_err[-1] * 100:.1f} cm, worst {pos_err.max() * 100:.1f} cm")
     assert pos_err[-1] < 0.15 and pos_err.max() < 1.0
+
+
+@pytest.mark.gpu
+def test_replay_host_lo_phase_follows_the_cpu_oracle(oracle, tmp_path):
+    """the GPU LO sequence through the C++ host held to the CPU ORACLE end to end, not to another host making the
+    same library calls.  The first 26 messages of the Ouster-layout stream (19 whole sweeps - process_cut_frame_pcl2 does not cut
+    the first 19 messages, src/preprocess.cpp:314-315 - then 7 x 2 sub-frames: 32 registered scans) go through
+    harness/li_init_replay.cpp - callbacks, device ingest + cut, constant-velocity propagation, CV de-skew, voxel grid, iterated
+    update, map_incremental, all on the GPU behind the C-ABI - and through the oracle's restatement of the same chain on the host:
+    oracle.ingest_pcl2 (held to the unmodified preprocess.cpp) -> cv_propagate -> oracle.undistort_cv -> oracle.voxel_grid ->
+    Tree.iekf_update -> Tree.map_incremental (the restated ikd-Tree, held to the unmodified one).  Every scan starts from the
+    previous scan's result and registers against the map the previous scans left: differences compound, and the bound is the
+    per-scan bound of this suite, 1e-6 m / 1e-7 rad, over the whole stretch."""
+    import lidar_imu_init_amd as lii
+    from lidar_imu_init_amd.api import lii_pc2_fields
+    from harness import synth, wire
+    from harness.lo_harness import cv_propagate
+    d = _drv()
+    (tmp_path / "config").mkdir()
+    (tmp_path / "launch").mkdir()
+    (tmp_path / "config" / "replay_test.yaml").write_text(YAML)
+    (tmp_path / "launch" / "replay_test.launch").write_text(LAUNCH)
+    hall = synth.Hall(size=(24.0, 18.0, 6.0), n_boxes=8, seed=7)
+    traj = synth.Trajectory()
+    msg_period, n_msgs, cut = 0.1, 26, 2
+    imu = synth.simulate_imu(traj, -0.5, n_msgs * msg_period + 0.5, 200.0, synth.rot_zyx(0.03, -0.02, -0.8), np.array([0.05, -0.03, 0.10]),
+                             np.zeros(3), np.zeros(3), 0.0)
+    f = wire.pc2_fields(wire.OUSTER)
+    msgs = []
+    for k in range(n_msgs):
+        stamp = k * msg_period
+        scan = synth.make_distorted_scan(hall, "mid16k", traj, stamp, msg_period, noise=0.01, seed=3000 + k, blind=0.0)
+        raw = wire.pack_pcl2(wire.OUSTER, scan[:, :3], np.zeros(len(scan), np.int32), scan[:, 3].astype(np.float64), stamp)
+        msgs.append((stamp, np.frombuffer(raw, np.uint8).copy(), len(scan)))
+    log, status = _cxx_host(d, str(tmp_path / "launch" / "replay_test.launch"), None, msgs, imu, lii_pc2_fields(*f), False, msg_period, 40_000, 600_000)
+    assert not status.imu_en and len(log) == 32 and np.all(log[:, 1] == 0)
+
+    # ---- the same stream through the oracle (yaml above: leaf 0.1, map box 0.15, gyr_cov 50, acc_cov 2, blind 0.5, 32 lines)
+    tree = oracle.Tree("oracle")
+    tree.set_downsample(0.15)
+    st = lii.State()
+    rows, first, t_last = [], True, None
+    for m, (stamp, raw, n) in enumerate(msgs):
+        for tb_ms, pts in oracle.ingest_pcl2(raw, n, f, wire.OUSTER, 32, 1, 0.5, stamp, cut, m + 1):
+            t_beg = tb_ms / 1000.0
+            t_end = t_beg + float(pts[-1, 3]) / 1000.0
+            cv_propagate(st, 0.1 if t_last is None else t_beg - t_last, 50.0, 2.0)
+            t_last = t_beg
+            body, _ = oracle.voxel_grid(oracle.undistort_cv(pts, st.bias_g, st.vel_end, st.rot_end), 0.1)
+            if first:
+                tree.build((body[:, :3].astype(np.float64) @ st.rot_end.T + st.pos_end).astype(np.float32))
+                first = False
+                continue
+            r = tree.iekf_update(body, st.pod, st.pod, max_iterations=5, imu_en=False, threads=8)
+            st.pod[:] = r["state"]
+            tree.map_incremental(body, st.pod, 0.15)
+            rows.append(np.r_[t_end, 0.0, r["iters"], int(r["logs"][-1, 1]), st.pod[:36]])
+    rows = np.array(rows)
+    tree.close()
+    n = min(len(rows), len(log))
+    assert n >= 20 and len(rows) == len(log), (len(rows), len(log))
+    assert np.allclose(rows[:, 0], log[:, 0], rtol=0, atol=1e-9)   # the sub-frames end at the same instants: same cut, same time stamps
+    dpos = np.linalg.norm(rows[:n, 13:16] - log[:n, 13:16], axis=1)
+    drot = np.array([np.linalg.norm(oracle.log_so3(rows[i, 4:13].reshape(3, 3).T @ log[i, 4:13].reshape(3, 3))) for i in range(n)])
+    dvel = np.abs(rows[:n, 28:34] - log[:n, 28:34]).max(axis=1)   # vel_end, bias_g (= the CV model's angular velocity)
+    print(f"C++ host on the GPU vs the CPU oracle over {n} LO scans: |dp| max {dpos.max():.2e} m (scan 20: {dpos[19]:.2e}), "
+          f"|dtheta| max {drot.max():.2e} rad, velocity states {dvel.max():.2e}; iterations equal on {int((rows[:n, 2] == log[:n, 2]).sum())} of {n}")
+    assert np.array_equal(rows[:n, 2], log[:n, 2])                 # the same number of passes on every scan
+    assert np.abs(rows[:n, 3] - log[:n, 3]).max() <= 2             # effect_feat_num (1-ulp threshold flips)
+    assert dpos.max() <= 1e-6 and drot.max() <= 1e-7, (dpos, drot)
