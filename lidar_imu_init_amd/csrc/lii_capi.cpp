@@ -223,7 +223,9 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     // (every in-place map update takes the branch that rebuilds the index first), "no_gather" (a sharded job sets up no gather areas:
     // its map update repeats the search instead of exchanging the lists), "solo_share=<N>" / "solo_share=-<N>" (kernel-timing
     // rehearsal: ONE process works on rank 0's share of an N-rank job split by voxel / by index, nothing is exchanged - the
-    // durations of a rank's launches without N devices; the result is that of a part of the cloud)
+    // durations of a rank's launches without N devices; the result is that of a part of the cloud), "emit_late" (every seventh
+    // workgroup of the voxel filter's emit and of the map update's decision launch publishes its count only when it is done: the
+    // workgroups above it take the path of a launch whose workgroups are not all resident and count its block themselves)
     const std::string t(v);
     h->map_tight = t.find("map_tight") != std::string::npos;
     const size_t q = t.find("plan_force=");
@@ -237,6 +239,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     h->no_fast_prologue = t.find("no_fast") != std::string::npos;
     h->test_force_rebuild = t.find("force_rebuild") != std::string::npos;
     h->no_gather = t.find("no_gather") != std::string::npos;
+    h->test_emit_late = t.find("emit_late") != std::string::npos;
     const size_t qs = t.find("solo_share=");
     if (qs != std::string::npos) h->solo_share = int(std::strtol(t.c_str() + qs + 11, nullptr, 0));
   }
@@ -686,7 +689,7 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
   const bool by_voxel = inserted && h->vh.part_world > 1;  // this rank emits ITS voxels only
   if (use_hash) {
     if (++h->vh_epoch == 0u) h->vh_epoch = 1u;
-    launch_voxel_hash(h->vh, h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_body, h->d_nbody, h->d_nbody + 1, h->d_vpcl_out, hash_stages, h->vh_epoch, s);
+    launch_voxel_hash(h->vh, h->d_scan, n, mm, h->d_bbox_rows, h->bbox_rows, leaf, h->d_body, h->d_nbody, h->d_nbody + 1, h->d_vpcl_out, hash_stages, h->vh_epoch, s, h->test_emit_late ? 1 : 0);
     if (!h->vh_pinned && !by_voxel && !h->vh_flag_pending && (++h->vh_watch & 15) == 0) {  // (every 16th scan: the copy costs a packet on the stream)
       HIPCHK(h, hipMemcpyAsync(h->h_vh_crowded, h->vh.crowded, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
       HIPCHK(h, hipMemsetAsync(h->vh.crowded, 0, sizeof(unsigned int), s));

@@ -340,7 +340,7 @@ int map_update_early(lii_handle h) {
   std::memset(&unused, 0, sizeof(unused));
   if (++h->decide_epoch == 0u) h->decide_epoch = 1u;
   launch_map_decide_compact(rb, unused, double(h->cfg.map_downsample_size), 1, reinterpret_cast<unsigned long long*>(h->d_u32_b), h->decide_epoch, h->d_world,
-                            h->d_list_add, h->d_list_nodown, h->d_counts, ba, bn, h->stream, h->d_ctrl, h->update_seq);
+                            h->d_list_add, h->d_list_nodown, h->d_counts, ba, bn, h->stream, h->d_ctrl, h->update_seq, h->test_emit_late ? 1 : 0);
   // (on the handle's own stream: the update sits right behind the passes anyway, and handing it to the map stream costs more - an
   // event between two hardware queues - than the next scan's de-skew and voxel filter beside it bring back: 5 007 against 4 826
   // scans/s with an update every scan, gpurun_out/r4y)
@@ -530,12 +530,12 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
     h->bound_add = ba; h->bound_nodown = bn;  // (LII_TEST=pred_small: every update outgrows its bounds)
     if (++h->decide_epoch == 0u) h->decide_epoch = 1u;
     launch_map_decide_compact(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0,
-                              reinterpret_cast<unsigned long long*>(h->d_u32_b), h->decide_epoch, h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, ba, bn, s);
+                              reinterpret_cast<unsigned long long*>(h->d_u32_b), h->decide_epoch, h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, ba, bn, s, nullptr, 0, h->test_emit_late ? 1 : 0);
     return map_apply(h, h->d_list_add, ba, true, h->d_list_nodown, bn, true, h->d_counts + 3, h->d_counts + 4, false);
   }
   if (++h->decide_epoch == 0u) h->decide_epoch = 1u;
   launch_map_decide_compact(rb, pose_of(*state), double(h->cfg.map_downsample_size), h->have_search ? 1 : 0, reinterpret_cast<unsigned long long*>(h->d_u32_b),
-                            h->decide_epoch, h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, nb, nb, s);
+                            h->decide_epoch, h->d_world, h->d_list_add, h->d_list_nodown, h->d_counts, nb, nb, s, nullptr, 0, h->test_emit_late ? 1 : 0);
   if (exchange) {
     // This rank has decided for ITS points (its block of the cloud, or its voxels): the lists of all ranks, in rank order, are the
     // batch every replica of the map receives (lii_exchange.hip: remote stores into the peers' gather areas; in place here).

@@ -117,6 +117,7 @@ struct lii_context {
   bool no_gather = false;         // LII_TEST=no_gather: no gather areas behind the mailbox slots (the map update of a sharded job repeats the search)
   bool no_fast_prologue = false;  // LII_TEST=no_fast: a time-sorted scan takes the general path as well (k_time_extent in front of the de-skew)
   bool no_fuse = false;        // LII_TEST=no_fuse: lii_scan_register keeps the de-skew and the voxel filter's insert in separate launches
+  bool test_emit_late = false; // LII_TEST=emit_late: every seventh workgroup of k_vhash_emit / k_map_decide publishes its count late: the others count its block themselves (prefix_below)
   bool use_graph = false;      // LII_TEST=graph: the passes of an update are captured once per (cloud bound, plan, map view) and replayed
   std::map<std::string, hipGraphExec_t> graphs;
   int plan_passes_prev = 32;   // passes the update before the last one ran (the plan enqueues the larger of the last two)

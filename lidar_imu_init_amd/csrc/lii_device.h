@@ -163,6 +163,74 @@ __device__ __forceinline__ double final_sum_row(const double* __restrict__ row, 
   return total;
 }
 
+// Prefix of per-workgroup counts INSIDE one launch, placement-independent (MI355X guide, Contract [G]: "HIP promises nothing about
+// dispatch order ... deadlock or stale data if an order or a co-location is assumed; placement-independent protocols only").
+// Every workgroup publishes its word - (epoch << 32 | a << 16 | b), a, b <= 256: counts over its 256 points; epoch: the number of
+// this run, so that a word left by an earlier run is never mistaken - BEFORE it looks at anybody else's, then adds up the words of
+// the workgroups below it.  A word that has not arrived after a bounded wait is NOT waited for any longer: its workgroup may not
+// have been dispatched yet - the hardware queues of several processes share the compute units, an XCD can fall behind the others -
+// and may be unable to start before THIS workgroup has left.  The waiting workgroup then counts that block itself (`recount(q)`:
+// all 256 lanes, uniform; what the block's own workgroup will find), publishes the word on its behalf - the value is the same
+// whoever writes it - and goes on: no workgroup ever depends on one that is not running.  Rounds 3 - 4 spun until the word came and
+// trapped after ~1 s ("workgroups are dispatched in index order: the lowest unfinished one waits for nobody" - true of ONE XCD's
+// queue, not across the eight: eight processes on one device locked each other out XCD by XCD).
+// The fast path - every word there at the first or second look - is the old one: no ticket, no extra round trip.
+// Returns (sum of a, sum of b) over the blocks below `my_block` in every lane.  `late_test`: tests only - treat every word that is
+// not there at the first look as overdue.
+constexpr unsigned int kPrefixSpinLimit = 256;  // looks at one word before giving up on it (~1 us each: far beyond a healthy launch's skew)
+template <class Recount>
+__device__ __forceinline__ uint2 prefix_below(unsigned long long* __restrict__ words, unsigned int epoch, int my_block, unsigned int* s_sum /*[12] LDS*/,
+                                              bool late_test, Recount&& recount) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned int pa = 0, pb = 0;
+  bool late = false;
+  for (int q = threadIdx.x; q < my_block; q += 256) {
+    unsigned long long v = __hip_atomic_load(words + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned int spins = 0;
+    while ((unsigned int)(v >> 32) != epoch) {
+      if (late_test || ++spins > kPrefixSpinLimit) { late = true; break; }
+      __builtin_amdgcn_s_sleep(2);
+      v = __hip_atomic_load(words + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (late) break;
+    pa += ((unsigned int)v >> 16) & 0xFFFFu;
+    pb += (unsigned int)v & 0xFFFFu;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { pa += __shfl_down(pa, off); pb += __shfl_down(pb, off); }
+  const bool wave_late = __any(late);
+  if (lane == 0) { s_sum[w] = pa; s_sum[4 + w] = pb; s_sum[8 + w] = wave_late ? 1u : 0u; }
+  __syncthreads();
+  if (!(s_sum[8] | s_sum[9] | s_sum[10] | s_sum[11]))  // (uniform) the usual case
+    return make_uint2(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3], s_sum[4] + s_sum[5] + s_sum[6] + s_sum[7]);
+  // Some word is overdue: the blocks below one after the other, the whole workgroup together (uniform control flow: lane 0 looks,
+  // everybody takes what it saw).  A word that is there is taken; a block whose word is not is counted here and now.  The recount
+  // is only valid while the block's own workgroup has not begun to change what it is counted from, which it does AFTER its word is
+  // out: the word is looked at again behind the recount, and if it has arrived in the meantime it wins.
+  __shared__ unsigned long long s_word;
+  unsigned int sa = 0, sb = 0;
+  for (int q = 0; q < my_block; q++) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_word = __hip_atomic_load(words + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    unsigned long long v = s_word;
+    if ((unsigned int)(v >> 32) != epoch) {  // uniform
+      const unsigned int mine = recount(q);  // (a << 16 | b; contains barriers)
+      __syncthreads();
+      if (threadIdx.x == 0) s_word = __hip_atomic_load(words + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      v = s_word;
+      if ((unsigned int)(v >> 32) != epoch) {
+        v = ((unsigned long long)epoch << 32) | mine;
+        if (threadIdx.x == 0) __hip_atomic_store(words + q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    sa += ((unsigned int)v >> 16) & 0xFFFFu;
+    sb += (unsigned int)v & 0xFFFFu;
+  }
+  return make_uint2(sa, sb);
+}
+
 // Node-local exchange of the 91 normal-equation scalars between the ranks of one job, inside the
 // reduce+solve launch.  Rank r owns two slots per SOURCE rank (parity of the exchange number) of 96 doubles + a sequence flag.
 // Two homes for the slots:

@@ -96,7 +96,7 @@ int voxel_partition_bound(int n, int world);
 void launch_voxel_hash_clear(const VoxelHashBuffers& vh, size_t slots, hipStream_t s);
 void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
                        int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, unsigned int epoch,
-                       hipStream_t s);
+                       hipStream_t s, int test_late = 0 /* LII_TEST=emit_late: see k_vhash_emit */);
 // de-skew (k_deskew_imu / k_deskew_cv): where the scan comes from and goes to, what is known about it, what rides along
 struct DeskewPlan {
   const float4* in;     // the scan as it arrived (a caller's device buffer, or == out)
@@ -120,7 +120,7 @@ void launch_calib_eval(int stage, const double* imu, const double* lidar, int n,
 // device-side map maintenance (lii_map.hip)
 void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned long long* blk_counts, unsigned int epoch,
                                float4* world, float4* dst_add, float4* dst_nodown, int* counts, int bound_add, int bound_nodown, hipStream_t s,
-                               const IekfCtrl* guard = nullptr, int seq = 0);  // blk_counts: one word per 256 points; epoch: the number of this run (never 0); guard: see k_map_decide
+                               const IekfCtrl* guard = nullptr, int seq = 0, int test_late = 0);  // blk_counts: one word per 256 points; epoch: the number of this run (never 0); guard: see k_map_decide
 void launch_map_publish(const int* ctr, int n_words, int* host, int seq_at, int seq, hipStream_t s);
 void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, int* events, hipStream_t s);
 void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,

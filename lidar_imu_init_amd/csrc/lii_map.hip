@@ -125,21 +125,19 @@ __device__ __forceinline__ bool d_same_point(float ax, float ay, float az, float
 // which then makes the map update again).
 // The two order-preserving compactions happen in the same launch (round 4; a launch of its own before): a workgroup counts its
 // two kinds of points, publishes the counts as ONE word (run number << 32 | adds << 16 | no-down-samples) before it waits for
-// anything, adds up the words of the workgroups below it - the exchange of k_vhash_emit, lii_scan.hip: whichever workgroup is the
-// lowest unfinished one waits for nobody - ranks its own points with wavefront ballots and writes both lists; the last workgroup
-// leaves the list sizes in counts[0..1].
-__global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, PoseArg ps_val, double fsd, int have_search,
-                                                    unsigned long long* __restrict__ blk_counts, unsigned int epoch, float4* __restrict__ world_out,
-                                                    float4* __restrict__ dst_add, float4* __restrict__ dst_nodown, int* __restrict__ counts, int bound_a,
-                                                    int bound_n, const IekfCtrl* __restrict__ guard, int seq) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const PoseArg ps = guard ? *reinterpret_cast<const PoseArg*>(guard->st) : ps_val;
-  const bool go = !guard || (guard->stop == 1 && guard->singular == 0 && guard->seq == seq);  // uniform
-  const int n = go ? (rb.n_dev ? *rb.n_dev : rb.n) : 0;
-  unsigned int fa = 0, fn = 0;
-  int lo = 0, n_live = n;  // a rank of a job split by index decides for its block (the lists are exchanged afterwards)
-  if (rb.shard_world > 1) shard_range(rb, lo, n_live);
-  float4 wp = make_float4(0.f, 0.f, 0.f, 0.f);
+// anything, adds up the words of the workgroups below it - prefix_below, lii_device.h: a word that is overdue is not waited for, its
+// block is decided again by the workgroup that needs it - ranks its own points with wavefront ballots and writes both lists; the
+// last workgroup leaves the list sizes in counts[0..1].
+// The decision for point i (src/laserMapping.cpp:516-553): fa = PointToAdd, fn = PointNoNeedDownsample, wp = its world point.
+struct MapDecision {
+  unsigned int fa, fn;
+  float4 wp;
+};
+__device__ __forceinline__ MapDecision map_decide_point(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, int i, int n, int lo,
+                                                        int n_live) {
+  MapDecision d;
+  d.fa = 0; d.fn = 0;
+  d.wp = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < rb.n && i >= lo && i < lo + n_live && i < n) {  // rb.n is the launch bound
     float4 pb = rb.body[i];
     double bx = pb.x, by = pb.y, bz = pb.z;
@@ -149,8 +147,7 @@ __global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, Pose
     const float wx = (float)(ps.R[0] * ix + ps.R[1] * iy + ps.R[2] * iz + ps.p[0]);
     const float wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
     const float wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
-    wp = make_float4(wx, wy, wz, 0.f);
-    world_out[i] = wp;
+    d.wp = make_float4(wx, wy, wz, 0.f);
     const int cnt = have_search ? rb.nbr_count[i] : 0;
     if (cnt > 0) {
       // mid_point = floor(p / filter_size_map) * filter_size_map + 0.5 * filter_size_map, double math stored to float (:529-534)
@@ -160,7 +157,7 @@ __global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, Pose
       const float dist = d_dist2(wx, wy, wz, mx, my, mz);
       const float4 n0 = rb.nbr[i];
       if ((double)fabsf(n0.x - mx) > 0.5 * fsd && (double)fabsf(n0.y - my) > 0.5 * fsd && (double)fabsf(n0.z - mz) > 0.5 * fsd) {
-        fn = 1;  // PointNoNeedDownsample (:536-541)
+        d.fn = 1;  // PointNoNeedDownsample (:536-541)
       } else {
         bool need_add = true;
         if (cnt >= kMatch) {
@@ -170,39 +167,56 @@ __global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, Pose
             if (need_add && d_dist2(q.x, q.y, q.z, mx, my, mz) < dist) need_add = false;
           }
         }
-        fa = need_add ? 1u : 0u;
+        d.fa = need_add ? 1u : 0u;
       }
     } else {
-      fa = 1;  // no neighbour list: always added (:551-553)
+      d.fa = 1;  // no neighbour list: always added (:551-553)
     }
   }
-  __shared__ unsigned int s_a[4], s_n[4], s_sum[8];
+  return d;
+}
+// (adds << 16 | no-down-samples) over the 256 points of a workgroup; every lane must call it
+__device__ __forceinline__ unsigned int map_decide_count(unsigned int fa, unsigned int fn, unsigned int* s_a /*[4]*/, unsigned int* s_n /*[4]*/,
+                                                         unsigned long long* ma_out, unsigned long long* mn_out) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned long long ma = __ballot(fa != 0), mn = __ballot(fn != 0);
   if (lane == 0) { s_a[w] = (unsigned int)__popcll(ma); s_n[w] = (unsigned int)__popcll(mn); }
   __syncthreads();
-  const unsigned int tot_a = s_a[0] + s_a[1] + s_a[2] + s_a[3], tot_n = s_n[0] + s_n[1] + s_n[2] + s_n[3];
-  if (threadIdx.x == 0)
-    __hip_atomic_store(blk_counts + blockIdx.x, ((unsigned long long)epoch << 32) | ((unsigned long long)tot_a << 16) | tot_n, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  // adds / no-down-samples in the workgroups below this one (their words carry this run's number, or have not arrived yet)
-  unsigned int pa = 0, pn = 0;
-  for (int q = threadIdx.x; q < (int)blockIdx.x; q += 256) {
-    unsigned long long v = __hip_atomic_load(blk_counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned int spins = 0;
-    while ((unsigned int)(v >> 32) != epoch) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 24)) __builtin_trap();  // a count that never arrives: the launch is broken
-      v = __hip_atomic_load(blk_counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    pa += (unsigned int)(v >> 16) & 0xFFFFu;
-    pn += (unsigned int)v & 0xFFFFu;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { pa += __shfl_down(pa, off); pn += __shfl_down(pn, off); }
-  if (lane == 0) { s_sum[w] = pa; s_sum[4 + w] = pn; }
-  __syncthreads();
-  unsigned int base_a = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3], base_n = s_sum[4] + s_sum[5] + s_sum[6] + s_sum[7];
+  *ma_out = ma; *mn_out = mn;
+  return ((s_a[0] + s_a[1] + s_a[2] + s_a[3]) << 16) | (s_n[0] + s_n[1] + s_n[2] + s_n[3]);
+}
+__global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, PoseArg ps_val, double fsd, int have_search,
+                                                    unsigned long long* __restrict__ blk_counts, unsigned int epoch, float4* __restrict__ world_out,
+                                                    float4* __restrict__ dst_add, float4* __restrict__ dst_nodown, int* __restrict__ counts, int bound_a,
+                                                    int bound_n, const IekfCtrl* __restrict__ guard, int seq, int test_late) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const PoseArg ps = guard ? *reinterpret_cast<const PoseArg*>(guard->st) : ps_val;
+  const bool go = !guard || (guard->stop == 1 && guard->singular == 0 && guard->seq == seq);  // uniform
+  const int n = go ? (rb.n_dev ? *rb.n_dev : rb.n) : 0;
+  int lo = 0, n_live = n;  // a rank of a job split by index decides for its block (the lists are exchanged afterwards)
+  if (rb.shard_world > 1) shard_range(rb, lo, n_live);
+  const MapDecision d = map_decide_point(rb, ps, fsd, have_search, i, n, lo, n_live);
+  const unsigned int fa = d.fa, fn = d.fn;
+  const float4 wp = d.wp;
+  if (i < rb.n && i >= lo && i < lo + n_live && i < n) world_out[i] = wp;
+  __shared__ unsigned int s_a[4], s_n[4], s_sum[12], s_ra[4], s_rn[4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long ma, mn;
+  const unsigned int word = map_decide_count(fa, fn, s_a, s_n, &ma, &mn);
+  const unsigned int tot_a = word >> 16, tot_n = word & 0xFFFFu;
+  // the workgroup's word goes out before it looks at anybody else's; a block whose word is overdue is decided here again
+  // (prefix_below, lii_device.h: placement-independent - nothing the decision reads changes during this launch)
+  const bool hold = test_late != 0 && (blockIdx.x % 7u) == 3u;  // LII_TEST=emit_late, as k_vhash_emit
+  if (threadIdx.x == 0 && !hold)
+    __hip_atomic_store(blk_counts + blockIdx.x, ((unsigned long long)epoch << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint2 below = prefix_below(blk_counts, epoch, (int)blockIdx.x, s_sum, test_late != 0, [&](int q) -> unsigned int {
+    const MapDecision dq = map_decide_point(rb, ps, fsd, have_search, q * 256 + (int)threadIdx.x, n, lo, n_live);
+    unsigned long long xa, xn;
+    return map_decide_count(dq.fa, dq.fn, s_ra, s_rn, &xa, &xn);
+  });
+  if (threadIdx.x == 0 && hold)
+    __hip_atomic_store(blk_counts + blockIdx.x, ((unsigned long long)epoch << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned int base_a = below.x, base_n = below.y;
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     const int ca = (int)(base_a + tot_a), cn = (int)(base_n + tot_n);
     counts[0] = ca;
@@ -216,9 +230,9 @@ __global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, Pose
     counts[4] = over ? 0 : cn;
   }
   for (int k = 0; k < w; k++) { base_a += s_a[k]; base_n += s_n[k]; }
-  const unsigned long long below = (1ull << lane) - 1ull;
-  if (fa) dst_add[base_a + (unsigned int)__popcll(ma & below)] = wp;
-  if (fn) dst_nodown[base_n + (unsigned int)__popcll(mn & below)] = wp;
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  if (fa) dst_add[base_a + (unsigned int)__popcll(ma & lanes_below)] = wp;
+  if (fn) dst_nodown[base_n + (unsigned int)__popcll(mn & lanes_below)] = wp;
 }
 
 
@@ -849,10 +863,10 @@ void launch_map_publish(const int* ctr, int n_words, int* host, int seq_at, int 
 }
 void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned long long* blk_counts, unsigned int epoch,
                                float4* world, float4* dst_add, float4* dst_nodown, int* counts, int bound_add, int bound_nodown, hipStream_t s,
-                               const IekfCtrl* guard, int seq) {
+                               const IekfCtrl* guard, int seq, int test_late) {
   if (rb.n <= 0) return;
   hipLaunchKernelGGL(k_map_decide, dim3(nblk(rb.n, 256)), dim3(256), 0, s, rb, ps, fsd, have_search, blk_counts, epoch, world, dst_add, dst_nodown, counts,
-                     bound_add, bound_nodown, guard, seq);
+                     bound_add, bound_nodown, guard, seq, test_late);
 }
 void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, int* events, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_add_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, n_dev, ds, keys, idx, events);

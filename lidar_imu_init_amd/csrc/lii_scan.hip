@@ -591,28 +591,6 @@ __device__ __forceinline__ unsigned int block_rank_of_flag(bool f, unsigned int*
   *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
   return before + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
 }
-// Owners in the workgroups below this one.  Every workgroup publishes its own count as (epoch << 32 | count) - epoch: the number
-// of this filter run, so that a word left by an earlier run is never mistaken - BEFORE it waits for anything, and waits only
-// for workgroups with smaller indices: whichever workgroup is the lowest unfinished one waits for nobody, so the launch
-// always drains (workgroups are dispatched in index order; a workgroup that has not started yet holds up only those above it).
-// A count that does not arrive within seconds means the launch is broken: trap (the stream reports an error) rather than hang.
-__device__ __forceinline__ unsigned int owners_below(const unsigned long long* __restrict__ counts, unsigned int epoch, unsigned int* s_sum /*[4] LDS*/) {
-  unsigned int acc = 0;
-  for (int q = threadIdx.x; q < (int)blockIdx.x; q += 256) {
-    unsigned long long v = __hip_atomic_load(counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned int spins = 0;
-    while ((unsigned int)(v >> 32) != epoch) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 24)) __builtin_trap();
-      v = __hip_atomic_load(counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    acc += (unsigned int)v;
-  }
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  return s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-}
 // ABS: the table was filled by the fused form (absolute voxel coordinates): the box arrives here (one row per de-skew
 // workgroup, folded by every workgroup for itself), the PCL index of a voxel is computed from its first point, and PCL's
 // overflow guard (the grid would have more than 2^31 voxels: "leaf size too small", the cloud passes unfiltered) is applied
@@ -624,8 +602,8 @@ template <bool ABS>
 __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ pts, int n, VhTable tb, unsigned long long* __restrict__ counts,
                                                     unsigned int epoch, float4* __restrict__ out, int* __restrict__ n_out,
                                                     unsigned int* __restrict__ pcl_out, const unsigned int* __restrict__ bbox_rows,
-                                                    int n_rows, float leaf, int* __restrict__ filtered) {
-  __shared__ unsigned int s_w[4], s_sum[4];
+                                                    int n_rows, float leaf, int* __restrict__ filtered, int test_late) {
+  __shared__ unsigned int s_w[4], s_sum[12];
   const int tid = threadIdx.x, i = blockIdx.x * blockDim.x + tid;
   // everything a lane needs of its own point is requested at once: the point, its slot, and (dependent) the slot's line
   const bool in_range = i < n;
@@ -661,7 +639,11 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
   const bool first = slot != kVhEmpty && (ident_part || min(hd.x, m0.x) == (unsigned)i);  // the owner: the first point of the voxel in input order
   unsigned int total;
   const unsigned int rank = block_rank_of_flag(first, s_w, &total);
-  if (tid == 0) __hip_atomic_store(counts + blockIdx.x, ((unsigned long long)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // The workgroup's count goes out BEFORE it looks at anybody else's (prefix_below, lii_device.h: the exchange of the counts inside
+  // the launch, placement-independent).  LII_TEST=emit_late: every seventh workgroup holds its word back until it is done, so that
+  // the workgroups above it have to count its block themselves - the path a launch takes whose workgroups are not all resident.
+  const bool hold = test_late != 0 && (blockIdx.x % 7u) == 3u && !(ABS && v.identity && !ident_part);
+  if (tid == 0 && !hold) __hip_atomic_store(counts + blockIdx.x, ((unsigned long long)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (ABS && v.identity && !ident_part) {  // (uniform) the cloud passes unfiltered; the voxels' owners still hand their slots back
     if (in_range) { out[i] = p0; pcl_out[i] = (unsigned)i; }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) *n_out = n;
@@ -715,7 +697,24 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
     // a single-point voxel reproduces the point exactly (x / 1.0f == x), which is also what the identity path needs
     cen = make_float4(sx / c, sy / c, sz / c, st / c);
   }
-  const unsigned int base = owners_below(counts, epoch, s_sum);
+  // owners in the workgroups below this one; a block whose word is overdue is counted here: which of its points own their voxel
+  // (one 16-byte request per point decides it, as above; a slot its owner - a point of another block - has freed already reads
+  // empty: not this point's voxel any more, and it never was its owner)
+  const unsigned int base = prefix_below(counts, epoch, (int)blockIdx.x, s_sum, test_late != 0, [&](int q) -> unsigned int {
+    const int j = q * 256 + tid;
+    bool f = false;
+    if (j < n) {
+      const unsigned int sq = tb.slot_of[j];
+      if (sq != kVhEmpty) {
+        const uint4 a = *reinterpret_cast<const uint4*>(tb.slots + sq);
+        f = ident_part || min(a.z, a.w) == (unsigned)j;
+      }
+    }
+    unsigned int tot;
+    (void)block_rank_of_flag(f, s_w, &tot);
+    return tot;
+  }).y;
+  if (tid == 0 && hold) __hip_atomic_store(counts + blockIdx.x, ((unsigned long long)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (blockIdx.x == gridDim.x - 1 && tid == 0) {  // size of the down-sampled cloud
     int n_down = (int)(base + total);
     if (ABS && tb.part_world > 1u && n_down > tb.part_bound) {  // this rank's share outgrew what the launches behind are sized for
@@ -841,13 +840,13 @@ void launch_voxel_hash_clear(const VoxelHashBuffers& vh, size_t slots, hipStream
 // (the table is keyed by absolute voxel coordinates).  epoch: the number of this filter run (never 0; VoxelHashBuffers::counts).
 void launch_voxel_hash(const VoxelHashBuffers& vh, const float4* pts, int n, const unsigned int* mm, const unsigned int* bbox_rows,
                        int n_rows, float leaf, float4* out, int* n_out, int* filtered, unsigned int* pcl_out, int stages, unsigned int epoch,
-                       hipStream_t s) {
+                       hipStream_t s, int test_late) {
   if (n <= 0) return;
   const VhTable tb = vh_table(&vh, n, (stages & 4) != 0);
   const int nb = nblk(n, 256);
   if (stages & 1) hipLaunchKernelGGL(k_vhash_insert, dim3(nb), dim3(256), 0, s, pts, n, mm, bbox_rows, n_rows, leaf, tb, filtered);
-  if (stages & 2) hipLaunchKernelGGL(k_vhash_emit<false>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.counts, epoch, out, n_out, pcl_out, nullptr, 0, leaf, filtered);
-  if (stages & 4) hipLaunchKernelGGL(k_vhash_emit<true>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.counts, epoch, out, n_out, pcl_out, bbox_rows, n_rows, leaf, filtered);
+  if (stages & 2) hipLaunchKernelGGL(k_vhash_emit<false>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.counts, epoch, out, n_out, pcl_out, nullptr, 0, leaf, filtered, test_late);
+  if (stages & 4) hipLaunchKernelGGL(k_vhash_emit<true>, dim3(nb), dim3(256), 0, s, pts, n, tb, vh.counts, epoch, out, n_out, pcl_out, bbox_rows, n_rows, leaf, filtered, test_late);
 }
 size_t voxel_hash_slots(int max_n) {
   size_t slots = 1024;

@@ -331,7 +331,7 @@ def test_long_update_sequence_keeps_the_tree_set(oracle):
 
 
 @pytest.mark.parametrize("hook", ["", "pred_small", "pred_small,force_rebuild", "force_rebuild", "job", "job,pred_small", "job,force_rebuild",
-                                  "job,plan_force=0x10001", "job,force_rebuild,plan_force=0x10001"])
+                                  "job,plan_force=0x10001", "job,force_rebuild,plan_force=0x10001", "emit_late", "job,emit_late"])
 def test_map_incremental_without_counts_gives_the_same_map(hook):
     """lii_map_incremental with both size pointers NULL enqueues the update for PREDICTED list sizes on a stream of its own and
     returns at once; an update whose lists outgrow the prediction is repeated with the exact sizes before the next search
@@ -344,7 +344,8 @@ def test_map_incremental_without_counts_gives_the_same_map(hook):
     host knows how the update ends; with plan_force=0x10001 (a launch plan that holds the first pass only) every update parks, the
     early launch sees that and does nothing, and the update is made when the loop has ended; with force_rebuild on top the index is
     rebuilt by the early enqueue of EVERY scan and the parked loop is continued behind it - its launches must see the rebuilt index,
-    not the view taken before the passes went out."""
+    not the view taken before the passes went out.  emit_late: every seventh workgroup of k_map_decide (and of the voxel
+    filter's emit) publishes its counts only when it is done - the workgroups above it decide its block again (prefix_below)."""
     import bench
     import lidar_imu_init_amd as lii
     wl = bench.build_workload("os1_128_cut3", 4)
