@@ -16,7 +16,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "lib", "libliinit_hip.so")
+# (LII_LIB: another build of the same library - A/B measurements of tools/ab.sh; the default is the in-tree build)
+_LIB = os.environ.get("LII_LIB") or os.path.join(_HERE, "lib", "libliinit_hip.so")
 
 STATE_DOUBLES = 36 + 576
 
@@ -115,6 +116,7 @@ _DECLS = {
                                   C.POINTER(lii_iekf_report)]),
     "lii_scan_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(lii_iekf_report)]),
     "lii_neighbors_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "lii_last_knn_lanes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "lii_map_incremental": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lii_calib_set_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "lii_calib_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
@@ -168,6 +170,8 @@ def load_library():
                                "(there is no Python/CPU fallback)")
         L = C.CDLL(_LIB)
         for name, (res, args) in _DECLS.items():
+            if os.environ.get("LII_LIB") and not hasattr(L, name):
+                continue  # (an older build under A/B measurement: what it lacks cannot be called)
             fn = getattr(L, name)  # AttributeError here = the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
@@ -443,6 +447,13 @@ class Registrar:
         self._check(self.L.lii_scan_register(self.h, C.byref(job), _ptr(state.pod), _ptr(state_prop.pod), C.byref(rep)))
         return dict(iterations=rep.iterations, searches=rep.searches, effect_num=rep.effect_num,
                     converged=bool(rep.converged), normal_eq=np.array(rep.normal_eq[:]))
+
+    def last_knn_lanes(self) -> int:
+        if not hasattr(self.L, "lii_last_knn_lanes"):
+            return 4  # (an older build under A/B measurement)
+        v = C.c_int32(0)
+        self._check(self.L.lii_last_knn_lanes(self.h, C.byref(v)))
+        return v.value
 
     def neighbors(self, n):
         pts = np.zeros((n, 5, 3), np.float32)

@@ -39,11 +39,11 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane is
   return u.d;
 }
 // Pivoting (round 4): THRESHOLD pivoting.  Row k stays the pivot row whenever |a_kk| >= 1/4 of the largest magnitude below it in
-// its column - the usual case by far for I + P11 G - and only otherwise the largest entry is searched and the rows exchanged
-// (partial pivoting's choice).  Stable like partial pivoting (element growth per step bounded by 1 + 1/tau = 5 instead of 2),
-// and the test is a four-level maximum over the lane's own registers instead of the eleven dependent compare / select pairs of
-// the sequential search (measured at 1.9 us of the 4.1 us elimination in round 3).
-__device__ bool gj12(double (&col)[H]) {
+// its column and only otherwise the largest entry is searched and the rows exchanged (partial pivoting's choice).  Stable like
+// partial pivoting (element growth per step bounded by 1 + 1/tau = 5 instead of 2).
+// Round 5: this routine - twelve unrolled steps with the exchange code behind every one of them, ~30 KB of straight-line code that
+// a launch executes once, every line of it an instruction-cache miss - is now the FALLBACK of gj12_loop below.
+__device__ __forceinline__ bool gj12_pivoting(double (&col)[H]) {
 #pragma unroll
   for (int k = 0; k < H; k++) {
     // every lane: largest magnitude of its own column below the diagonal (a tree over registers; lane k's is the one that counts)
@@ -90,6 +90,68 @@ __device__ bool gj12(double (&col)[H]) {
     col[k] = rowk;
   }
   return true;
+}
+
+// The same elimination as a LOOP of twelve identical steps (round 5).  What made the unrolled form necessary were the register
+// indices: step k reads row k as the pivot row.  Here the rows ROTATE instead: position 0 always holds the pivot row, the update of
+// row p lands in position p - 1 (the fused multiply-add writes its result one register pair down: the rotation costs no move) and
+// the finished pivot row enters at position 11 - after twelve steps every row is back where it started.  Only the lane that
+// holds the pivot column changes from step to step, and v_readlane takes the lane from a scalar register.  The body is ~60
+// instructions (~0.5 KB): fetched once, it runs out of the instruction cache, where the unrolled form paid a memory round trip for
+// every eight instructions (phase stamps: 3.0 us for ~700 instructions - ten cycles per instruction on a wavefront that can
+// issue one every four or five).
+// Pivoting: none inside the loop - a data-dependent row exchange is what cannot be expressed with static register indices - but
+// the elimination WATCHES ITS OWN GROWTH: every lane keeps the largest magnitude its column takes on the way (twelve maxima per
+// step, off the critical chain readlane -> reciprocal -> multiply-add), and the result stands only if the columns of A never
+// outgrew kGrowthMax x max(1, max |A|) - the quantity the backward error of an elimination is proportional to (Wilkinson) - and
+// every pivot was a number.  Otherwise the saved input goes through gj12_pivoting.  I + P11 G with P11, G positive semi-definite
+// has its spectrum in [1, inf): measured on LIO sequences (hall, corridor: tools/exp/gj_growth.py) the pivot-free growth stays
+// below 10 where the 1/4-threshold test of round 4 would have exchanged rows on nine scans of ten.
+constexpr double kGrowthMax = 256.0;  // eight bits of the 53: <= 3e-14 x cond(A) on the gain, far inside the 1e-4 the covariance is held to
+// max(|a|, |b|) as ONE instruction (the source modifiers are free; written as fmax(fabs(a), fabs(b)) the compiler first
+// canonicalises every loop-carried operand with a v_max of its own: 23 instructions for twelve values instead of 11)
+__device__ __forceinline__ double absmax2(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double col_absmax(const double (&col)[H]) {
+  const double t0 = absmax2(col[0], col[1]), t1 = absmax2(col[2], col[3]), t2 = absmax2(col[4], col[5]), t3 = absmax2(col[6], col[7]),
+               t4 = absmax2(col[8], col[9]), t5 = absmax2(col[10], col[11]);
+  return absmax2(absmax2(absmax2(t0, t1), absmax2(t2, t3)), absmax2(t4, t5));
+}
+// Every lane watches ITS column against ITS column's own scale, max(1, largest magnitude at the start): stricter than the growth
+// factor of the whole matrix (a column's scale is at most the matrix's) and needs no reduction over the lanes - the verdict is one
+// ballot at the end.  (The columns of the right-hand side are watched as well: they only ride along, but a column that outgrows
+// its start by 2^8 says the multipliers were large.)
+__device__ __forceinline__ bool gj12_loop(double (&col)[H]) {
+  double g = col_absmax(col);
+  const double bound = kGrowthMax * fmax(g, 1.0);
+#pragma nounroll
+  for (int k = 0; k < H; k++) {
+    double m[H];
+#pragma unroll
+    for (int r = 0; r < H; r++) m[r] = readlane_f64(col[r], k);  // the pivot column (lane k), pivot row first
+    // 1 / pivot: hardware reciprocal seed + two Newton steps (full double precision, a third of the divide's latency)
+    double inv = __builtin_amdgcn_rcp(m[0]);
+    inv = fma(fma(-m[0], inv, 1.0), inv, inv);
+    inv = fma(fma(-m[0], inv, 1.0), inv, inv);
+    const double rowk = col[0] * inv;
+#pragma unroll
+    for (int r = 1; r < H; r++) col[r - 1] = fma(-m[r], rowk, col[r]);
+    col[H - 1] = rowk;
+    g = absmax2(g, col_absmax(col));
+  }
+  return __all(g <= bound);  // (false for a pivot that was zero or not a number: the maxima carry it; idle lanes hold zeros)
+}
+__device__ __forceinline__ bool gj12(double (&col)[H]) {
+  double keep[H];
+#pragma unroll
+  for (int r = 0; r < H; r++) keep[r] = col[r];
+  if (__builtin_expect(gj12_loop(col), 1)) return true;  // (wave-uniform)
+#pragma unroll
+  for (int r = 0; r < H; r++) col[r] = keep[r];
+  return gj12_pivoting(col);
 }
 
 __device__ void d_m3_mul(const double* A, const double* B, double* C) {
@@ -157,7 +219,7 @@ __device__ __forceinline__ void publish_done(IekfResult* res, int seq) {
 // ne_src: where the 91 sums come from - a functor called by every lane AFTER the other loads have been issued; it leaves the sums
 // in s_ne[0 .. 90] (LDS; the barrier below makes them visible) and returns false when they could not be had (uniform).
 template <class NeSrc>
-__device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, NeSrc ne_src) {
+__device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, int n_cloud, NeSrc ne_src) {
 #ifdef LII_SOLVE_TRACE
   __shared__ long long s_ts[16];
 #endif
@@ -323,6 +385,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
         res->effect_num = (int)s_ne[90];
         res->converged = converged;
         res->singular = 0;
+        res->n_cloud = n_cloud;
       }
     }
   } else if (do_cov) {
@@ -381,25 +444,34 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
 // (MI355X guide, "data-tagged granules": one producer -> consumer hand-off ~1 us).  Round 3: atomic store of the sum, wait
 // for its acknowledgement, returning ticket atomic, and the LAST arriver - not known in advance, so nothing could be
 // fetched ahead - loaded everything it needed behind the ticket: three more dependent round trips per pass.
-// The solver executes ~30 KB of straight-line code exactly once, on one workgroup, behind kernels that have swept the L2: every
-// instruction line is a cold miss served by HBM, one after the other.  The workgroup therefore reads its own code as DATA first -
-// `lines` x 64 bytes ahead of this point, all requests in flight together while it waits for the sums anyway - so that the
-// instruction fetches that follow hit in the XCD's L2.  The value is folded into a word nobody reads (the loads must not be
-// dropped; the wait for them lands where the caller consumes the return value).  Reads at most 24 KB ahead: stays inside this
-// kernel and the one defined behind it.
+// The solver's code is executed exactly once per launch, on one workgroup, behind kernels that have swept the L2: every instruction
+// line is a cold miss served by HBM, one after the other (round 4: ~30 KB of straight-line code; round 5: the elimination is a loop
+// and its pivoting form sits in a cold branch, ~10 KB are hot).  The workgroup therefore reads its own code as DATA first - 64-byte
+// lines ahead of this point, all requests in flight together while it waits for the sums anyway - so that the instruction fetches
+// that follow hit in the XCD's L2.  The value is folded into a word nobody reads (the loads must not be dropped; the wait for them
+// lands where the caller consumes the return value).
+// How far it may read is bounded by the address of solve_code_end(), a function defined behind the last kernel of this unit: a read
+// never leaves the code between this point and that symbol, whatever the toolchain does with the order of the functions - a marker
+// that ends up in FRONT of this point turns the prefetch off (round 4 read 24 KB ahead on the strength of the
+// definition order alone).
+__device__ __attribute__((noinline, used)) void solve_code_end();
 __device__ __forceinline__ int warm_code() {
   const char* pc = reinterpret_cast<const char*>(__builtin_amdgcn_s_getpc() & ~63ull);
+  const char* end = reinterpret_cast<const char*>(&solve_code_end);
   int acc = 0;
   if (threadIdx.x < 192) {
 #pragma unroll
-    for (int u = 0; u < 2; u++) acc ^= *reinterpret_cast<const volatile int*>(pc + (size_t)(threadIdx.x + 192 * u) * 64);
+    for (int u = 0; u < 2; u++) {
+      const char* a = pc + (size_t)(threadIdx.x + 192 * u) * 64;
+      if (a + 64 <= end) acc ^= *reinterpret_cast<const volatile int*>(a);
+    }
   }
   return acc;
 }
 __device__ __forceinline__ unsigned int pass_tag(int seq, int it) { return ((unsigned int)seq << 6) ^ (unsigned int)(it + 1); }
 __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __restrict__ partials, int n_blocks, int stride,
                                                                  unsigned long long* __restrict__ gran, IekfCtrl* c, IekfResult* res,
-                                                                 MailboxView mb) {
+                                                                 MailboxView mb, RegistrationBuffers rb) {
   __shared__ double s_w[kSolveThreads / 64];
   const int stop = c->stop, seq = c->seq, it = c->it;  // (one request: the three words share a line)
   const int t = blockIdx.x;
@@ -419,7 +491,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __
   if (stop) return;  // (the solver; it may set the flag itself, after every workgroup above has read it and published)
   const unsigned int tag = pass_tag(seq, it);
   const int warm = warm_code();
-  iekf_solve_body(c, res, [&](double* s_ne) {
+  int lo_unused, n_cloud;
+  shard_range(rb, lo_unused, n_cloud);  // (the size of the cloud: the host picks the next scan's search geometry by it)
+  iekf_solve_body(c, res, n_cloud, [&](double* s_ne) {
     __shared__ int s_mb_ok;
     if (threadIdx.x < 64) {  // one wavefront collects the sums (lane l: sums l and l + 64) and runs the exchange between the ranks
       const int l = threadIdx.x;
@@ -454,12 +528,15 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __
 
 // (defined BEHIND k_reduce_solve on purpose: that kernel reads its own code ahead, see warm_code)
 __global__ __launch_bounds__(kSolveThreads) void k_iekf_solve(IekfCtrl* c, const double* __restrict__ ne, IekfResult* res) {
-  iekf_solve_body(c, res, [&](double* s_ne) {
+  iekf_solve_body(c, res, -1, [&](double* s_ne) {
     const int tid = threadIdx.x;
     if (tid >= 64 && tid < 64 + 91) s_ne[tid - 64] = ne[tid - 64];
     return true;
   });
 }
+
+// (the end of the code warm_code may read: see there)
+__device__ __attribute__((noinline, used)) void solve_code_end() { asm volatile("s_nop 0"); }
 
 // The same exchange for the host-driven single pass (lii_iekf_iterate): in place on the 91 sums; a timeout poisons them.
 __global__ __launch_bounds__(64) void k_mailbox_allreduce(double* out, MailboxView mb) {
@@ -478,7 +555,7 @@ void launch_reduce_solve(const RegistrationBuffers& rb, unsigned long long* gran
   const int bound = rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;  // as launch_fit_reduce
   int nb = (bound + kBlock - 1) / kBlock;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq + 1), dim3(kSolveThreads), 0, s, rb.partials, nb, rb.partial_stride, gran, c, res, mb);
+  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq + 1), dim3(kSolveThreads), 0, s, rb.partials, nb, rb.partial_stride, gran, c, res, mb, rb);
 }
 // A parked loop goes on with the launches the host has put behind this one (plan_mask, as IekfCtrl::plan_mask).
 __global__ void k_loop_resume(IekfCtrl* c, unsigned int plan_mask) {

@@ -444,11 +444,14 @@ __device__ __forceinline__ bool fit_plane(const float4 (&nb)[5], double plane_th
 __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]);
 
 // ------------------------------------------------------------------------------------------------
+#ifdef LII_KNN_EXACT  // (helpers of k_knn_exact only)
 template <bool DEDUP>
 __device__ __forceinline__ void knn_merge_one(Knn5& k, float e, int j) {
   if (DEDUP && (j == k.i0 || j == k.i1 || j == k.i2 || j == k.i3 || j == k.i4)) return;
   if (e < k.d4) knn_insert(k, e, j);
 }
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // The search pass: LPQ (4 by default, 8 optional) lanes per query with box-distance pruning in two rounds.
 // Round 1: the 2x2x2 block of cells nearest to the query (own cell + the neighbour on the nearer side of every axis) —
@@ -456,6 +459,7 @@ __device__ __forceinline__ void knn_merge_one(Knn5& k, float e, int j) {
 // If the merged 5th distance is within g0 the search is complete (the usual case for a converged map).
 // Round 2: the other 19 cells of the 3x3x3 block, each tested against the current 5th distance first (the tree's
 // calc_box_dist rule), so most of them cost neither a table lookup nor a candidate.
+#ifdef LII_KNN_EXACT  // (helpers of k_knn_exact only)
 __device__ __forceinline__ uint2 lookup_cell(const GridView& g, const uint4* __restrict__ tab, int ix, int iy, int iz) {
   const int bb = kCellBias >> kCoarseShift;
   const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
@@ -472,6 +476,7 @@ __device__ __forceinline__ uint2 lookup_cell(const GridView& g, const uint4* __r
   const unsigned local = (((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u);
   return g.cells[(size_t)e.z * kBlockCells + local];
 }
+#endif
 
 // NC cell lookups with their loads issued as two batches (first probes of all block-table slots, then all cell entries)
 // instead of NC dependent probe -> entry chains; a probe that hits a foreign key walks on alone (load factor <= 1/8: rare).
@@ -517,6 +522,7 @@ __device__ __forceinline__ void lookup_cells_batched(const GridView& g, const ui
 // distance first (the tree's calc_box_dist rule, ikd_Tree.cpp:1279-1289).
 // A query whose 3x3x3 block cannot prove its list complete is flagged (kNeedy) and finished by k_fit_reduce / k_knn_complete.
 
+#ifdef LII_KNN_EXACT  // (helpers of k_knn_exact only)
 template <bool DEDUP>
 __device__ __forceinline__ void knn_group_merge4(Knn5& k) {
 #pragma unroll
@@ -538,6 +544,7 @@ __device__ __forceinline__ void knn_group_bcast(Knn5& k, int leader) {
   k.i0 = __shfl(k.i0, leader); k.i1 = __shfl(k.i1, leader); k.i2 = __shfl(k.i2, leader); k.i3 = __shfl(k.i3, leader);
   k.i4 = __shfl(k.i4, leader);
 }
+#endif
 
 // element t of a PoseArg seen as 24 doubles, without dynamic indexing (which would push the struct into scratch memory)
 __device__ __forceinline__ double pose_element(const PoseArg& ps, int t) {
@@ -579,6 +586,7 @@ __device__ __forceinline__ QueryCell query_cell(const GridView& g, float wx, flo
   return q;
 }
 
+#ifdef LII_KNN_EXACT  // (helpers of k_knn_exact only)
 // Round 2 on exact (distance, index) lists: every lane of the group enters with the group's round-1 list; the lanes of a
 // query that needs it (`more`) visit the 19 outer cells that can still hold a closer point, the lists are merged with
 // duplicate suppression.  Must be called by every lane of the wavefront.
@@ -621,6 +629,7 @@ __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const f
     rb.world[qi] = make_float4(wx, wy, wz, 0.f);
   }
 }
+#endif
 
 // ---- packed keys ---------------------------------------------------------------------------------
 // k_knn_pk ranks its candidates as 32-bit keys: the float bits of d2 with the low kPkPosBits mantissa bits replaced by the
@@ -1039,6 +1048,7 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
   }
 }
 
+#ifdef LII_KNN_EXACT
 // The search pass on exact (distance, index) lists throughout (round 2's form in round 1 too).  Kept as the reference form of
 // k_knn_pk: same cells, same candidates; LII_KNN_VARIANT=5 selects it.
 template <int BS>
@@ -1087,6 +1097,7 @@ __global__ __launch_bounds__(BS) void k_knn_exact(GridView g, RegistrationBuffer
   const bool need = active && !(fminf(k.d4, g.max_d2) <= q.guard * q.guard);
   if (live) knn_store(rb, g.pts, qi, sub, k, need, wx, wy, wz);
 }
+#endif  // LII_KNN_EXACT
 
 
 // Second stage of the search for a flagged query, run by ONE WAVEFRONT (four flagged queries of a workgroup proceed
@@ -1621,9 +1632,20 @@ static void launch_knn_pk_t(const GridView& g, const RegistrationBuffers& rb, co
   const int nq_pad = ((nq + 7) / 8) * 8;
   hipLaunchKernelGGL((k_knn_pk<LPQ, BS, NB, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
 }
-// variant 0: packed keys (k_knn_pk, the product path); 5: exact lists throughout (k_knn_exact, its reference form)
+// Lanes per query of the search pass for a cloud of (at most) `n_queries` points.  Four lanes per query issue ~20 % more
+// instructions in total than two (the per-query work - pose transform, cell arithmetic, merges, re-measurement - is replicated on
+// every lane of a group), but give twice the wavefronts to hide the dependent chain point -> block probe -> cell entry ->
+// candidates behind: at 95 k queries two lanes leave 2.9 wavefronts per SIMD and lose to latency (profiles/r03_knn_ab.md), at
+// >= kKnnTwoLaneQueries the chip is full either way and the instruction total decides (profiles/r05_knn_lpq.md).
+// variant (LII_KNN_VARIANT): 0 = by size; 4 / 2 / 1 = that many lanes whatever the size; 5 = k_knn_exact (test builds only).
+constexpr int kKnnTwoLaneQueries = 250000;
+int knn_lanes_for(int variant, int n_queries) {
+  if (variant == 1 || variant == 2 || variant == 4) return variant;
+  return n_queries >= kKnnTwoLaneQueries ? 2 : 4;
+}
 void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
-                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
+                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s, int n_queries_hint) {
+#ifdef LII_KNN_EXACT
   if (variant == 5) {
     int nq = nblk(shard_bound(rb), 128 / 4);
     if (nq < 1) nq = 1;
@@ -1631,10 +1653,14 @@ void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, c
     hipLaunchKernelGGL((k_knn_exact<128>), dim3(nq_pad), dim3(128), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
     return;
   }
+#endif
   // 128 lanes, 6 loads in flight per lane, 7 wavefronts per SIMD (69 VGPRs): measured against 64 / 256 lanes, 4 / 8 / 10 / 12
-  // loads, 6 / 8 wavefronts per SIMD (within 1 % on stream100k, 2 % behind on the larger scans) and 2 / 1 lanes per query
-  // (profiles/r03_knn_ab.md)
-  launch_knn_pk_t<4, 128, 6, 7>(g, rb, ps, pose, ctrl, forced, search_pose_out, s);
+  // loads, 6 / 8 wavefronts per SIMD (within 1 % on stream100k, 2 % behind on the larger scans; profiles/r03_knn_ab.md)
+  const int bound = shard_bound(rb);
+  const int lanes = knn_lanes_for(variant, n_queries_hint > 0 && n_queries_hint < bound ? n_queries_hint : bound);
+  if (lanes == 2) launch_knn_pk_t<2, 128, 6, 7>(g, rb, ps, pose, ctrl, forced, search_pose_out, s);
+  else if (lanes == 1) launch_knn_pk_t<1, 128, 6, 4>(g, rb, ps, pose, ctrl, forced, search_pose_out, s);
+  else launch_knn_pk_t<4, 128, 6, 7>(g, rb, ps, pose, ctrl, forced, search_pose_out, s);
 }
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);
