@@ -9,12 +9,12 @@ using namespace lii_impl;
 namespace {
 
 
-void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose, int forced) {
+void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose, int forced) {
   // (the bound of the launch is exact unless the voxel filter left the size on the device: then the last cloud's size stands in)
   const int hint = rb.n_dev ? h->knn_cloud_hint : 0;
   const int bound = rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;
   h->knn_lanes_last = lii::knn_lanes_for(h->knn_variant, hint > 0 && hint < bound ? hint : bound);
-  lii::launch_knn(h->knn_variant, g, rb, ps, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->stream, hint);
+  lii::launch_knn(h->knn_variant, g, rb, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->stream, hint);
 }
 
 
@@ -27,10 +27,15 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
   RegistrationBuffers rb = reg_buffers(h);
   const bool prof = h->prof.profiling;
   if (prof) HIPCHK(h, hipEventRecord(h->prof.ev[0], h->stream));
-  const PoseArg ps = pose_of(*st);
-  if (search) launch_knn(h, g, rb, ps, h->d_pose, 1);
+  // the pose of a host-driven pass travels to the handle's pose slot first: the kernels read it from device memory on every path
+  {
+    PoseArg* stage = reinterpret_cast<PoseArg*>(h->h_small + 20000);  // (pinned, a stretch nothing else uses; this call ends with a synchronisation)
+    *stage = pose_of(*st);
+    HIPCHK(h, hipMemcpyAsync(h->d_pose, stage, sizeof(PoseArg), hipMemcpyHostToDevice, h->stream));
+  }
+  if (search) launch_knn(h, g, rb, h->d_pose, 1);
   if (prof) HIPCHK(h, hipEventRecord(h->prof.ev[3], h->stream));
-  launch_fit_reduce(g, rb, ps, h->d_pose, h->d_ctrl, search ? 1 : 0, imu_en ? 1 : 0, h->cfg.plane_threshold,
+  launch_fit_reduce(g, rb, h->d_pose, h->d_ctrl, search ? 1 : 0, imu_en ? 1 : 0, h->cfg.plane_threshold,
                     h->cfg.laser_point_cov_inv, h->stream);
   if (prof) HIPCHK(h, hipEventRecord(h->prof.ev[1], h->stream));
   launch_reduce91(rb, h->d_out91, h->d_ctrl, 1, h->stream);
@@ -113,7 +118,6 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   GridView g = grid_view(h);
   RegistrationBuffers rb = reg_buffers(h);
   const PoseArg* pose = reinterpret_cast<const PoseArg*>(h->d_ctrl);  // first 24 doubles of IekfCtrl::st
-  const PoseArg ps0 = pose_of(*state);  // unused by the device-driven kernels (they read `pose`)
   const bool prof = h->prof.profiling && h->prof.prof_mode != 3;  // (mode 3 brackets every launch itself: kp_mark)
   const double* ne = h->net.comm ? h->d_out91 + 128 : h->d_out91;
   unsigned int plan = h->plan_cur;  // fill_ctrl chose it (the control block on the device carries the same mask)
@@ -125,11 +129,11 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     if (knn) {
       if (prof && it < 16) HIPCHK(h, hipEventRecord(h->prof.ev_it[2 * it], s));
       if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_KNN, it); if (r != LII_OK) return r; }
-      launch_knn(h, g, rb, ps0, pose, -1);
+      launch_knn(h, g, rb, pose, -1);
       if (prof && it < 16) HIPCHK(h, hipEventRecord(h->prof.ev_it[2 * it + 1], s));
     }
     if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_FIT, it); if (r != LII_OK) return r; }
-    launch_fit_reduce(g, rb, ps0, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
+    launch_fit_reduce(g, rb, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
     if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_SOLVE, it); if (r != LII_OK) return r; }
     if (!h->net.comm) {  // single GPU or node-local mailbox: final sum (+ exchange) and solve in one launch
       launch_reduce_solve(rb, h->d_gran, h->d_ctrl, h->h_res, mailbox_view(h), s);

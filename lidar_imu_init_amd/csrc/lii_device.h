@@ -47,6 +47,53 @@ struct PoseArg {
   double TLI[3];
 };
 
+// The pose a per-point kernel works with lives in DEVICE MEMORY on every path (the control block of the device-driven loop, or the
+// handle's pose slot, which a host-driven pass uploads first) and is read in one batch of loads: one round
+// trip.  Rounds 1 - 4 also carried a pose by value in the kernel arguments and chose with `cond ? *pose : by_value`: the compiler
+// selected the 24 doubles ONE BY ONE - 24 conditional scalar loads, sixteen of them behind a wait for the one before (three of those
+// cache misses: the block was written by the previous launch, on another XCD), at the head of every search and fit launch - and the
+// second copy of the pose took the scalar registers the first requests of the kernel needed to go out together.
+// The pose as VECTOR loads (twelve 16-byte requests per lane, every lane the same address - the offset is an opaque zero in a vector
+// register, or the compiler would turn them back into scalar loads): they go out in one batch together with the point's own data,
+// behind no wait, and the 48 registers they land in are vector registers - 48 scalar registers on top of a kernel's arguments do not
+// fit the scalar file (k_fit_reduce spilled 62 of them into vector-register lanes and fetched them back with v_readlane), and the
+// compiler staggers scalar loads it has no registers for into dependent batches.
+__device__ __forceinline__ PoseArg load_pose(const PoseArg* __restrict__ pose) {
+  unsigned int zero = 0u;
+  asm volatile("" : "+v"(zero));
+  const double2* __restrict__ src = reinterpret_cast<const double2*>(reinterpret_cast<const char*>(pose) + zero);
+  double2 v[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) v[k] = src[k];
+  PoseArg m;
+#pragma unroll
+  for (int k = 0; k < 24; k++) {
+    const double x = (k & 1) ? v[k >> 1].y : v[k >> 1].x;
+    if (k < 9) m.R[k] = x;
+    else if (k < 12) m.p[k - 9] = x;
+    else if (k < 21) m.RLI[k - 12] = x;
+    else m.TLI[k - 21] = x;
+  }
+  return m;
+}
+// The loop flags a per-point kernel starts with - IekfCtrl::search_next and ::stop, neighbours in the block - requested the same way
+// (a scalar load is sunk to its first use by the compiler, behind the wait for everything else); (search_next, stop).
+__device__ __forceinline__ int2 request_loop_flags(const int* __restrict__ search_next_and_stop) {
+  unsigned int zero = 0u;
+  asm volatile("" : "+v"(zero));
+  return *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(search_next_and_stop) + zero);
+}
+// (to be called BEHIND the kernel's other first requests: the value is needed in a scalar register, which is a wait)
+__device__ __forceinline__ int2 take_loop_flags(int2 v) {
+  return make_int2(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y));
+}
+// (a kernel that still takes a pose by value beside the pointer - k_map_decide: the caller's final state, or the control block's)
+__device__ __forceinline__ PoseArg load_pose(bool from_memory, const PoseArg* __restrict__ pose, const PoseArg& by_value) {
+  PoseArg ps = by_value;
+  if (from_memory) ps = load_pose(pose);  // (uniform)
+  return ps;
+}
+
 // One occupied 8x8x8 block of grid cells: open-addressing table entry  block key -> dense block id.
 struct __attribute__((aligned(16))) BlockEntry {
   unsigned long long key;  // packed (Bz, By, Bx) = cell coordinate >> 3; kEmptyKey = free slot
@@ -88,6 +135,25 @@ struct RegistrationBuffers {
 
 // The block of the down-sampled cloud this rank registers: first index and size.  Every rank holds the WHOLE cloud (the
 // de-skew and the voxel filter run replicated, so the cloud is bit-identical everywhere) and the split needs no exchange.
+// The device-resident size of the cloud, requested without a branch (a valid address either way: `fallback` is any int the kernel may
+// read; the value is only used when rb.n_dev is set) and as a vector load, like the pose and the loop flags (load_pose): it goes out
+// with the kernel's other first requests; take_scalar() - behind them - moves it to a scalar register.
+__device__ __forceinline__ int request_cloud_size(const RegistrationBuffers& rb, const int* fallback) {
+  unsigned int zero = 0u;
+  asm volatile("" : "+v"(zero));
+  const int* p = rb.n_dev ? rb.n_dev : fallback;
+  return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(p) + zero);
+}
+__device__ __forceinline__ int take_scalar(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void shard_range_n(const RegistrationBuffers& rb, int n_mem /* load_cloud_size */, int& lo, int& n_live) {
+  const int n_all = rb.n_dev ? n_mem : rb.n;
+  lo = 0;
+  n_live = n_all;
+  if (rb.shard_world > 1) {
+    lo = (int)(((long long)n_all * rb.shard_rank) / rb.shard_world);
+    n_live = (int)(((long long)n_all * (rb.shard_rank + 1)) / rb.shard_world) - lo;
+  }
+}
 __device__ __forceinline__ void shard_range(const RegistrationBuffers& rb, int& lo, int& n_live) {
   const int n_all = rb.n_dev ? *rb.n_dev : rb.n;
   lo = 0;

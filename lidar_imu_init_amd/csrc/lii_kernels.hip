@@ -780,36 +780,47 @@ __device__ __forceinline__ T pick_by_lane(const T (&arr)[N], int sub) {
   return v;
 }
 
-// `forced` 1: host-driven pass at the pose `ps_val` (always runs).  forced 2: always runs, pose read from `pose` (device).
+// `forced` > 0: always runs (a host-driven pass: the host has put the pose into `pose`, device memory).
 // forced < 0: device-driven loop — pose from `pose` (the control block), runs only when the control block says the next pass
 // searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).  An executed pass leaves its pose in
 // `search_pose_out` (may be null).
 // LPQ = lanes per query (4: the product form; 2 and 1 compile and are exact as well - fewer instructions in total, longer chains
 // per wavefront: slower, profiles/r03_knn_ab.md); NB = candidate loads a lane keeps in flight (one batch).
 template <int LPQ, int BS, int NB, int WPE>
-__global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuffers rb, PoseArg ps_val, const PoseArg* __restrict__ pose,
+__global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuffers rb, const PoseArg* __restrict__ pose,
                                                const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
                                                double* __restrict__ search_pose_out) {
   using G = PkGeom<LPQ>;
   __shared__ uint2 s_rng[2 * G::MAXPASS * BS];
-  // the pose sits in the control block: its load goes out together with the flags instead of after the branch on them
-  const PoseArg ps = forced != 1 ? *pose : ps_val;
-  int lo, n_live;
-  shard_range(rb, lo, n_live);
-  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
-  if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
-  const int blk = xcd_remap(blockIdx.x, nb_real);
-  if (blk >= nb_real) return;
+  // Everything the head of the kernel needs from memory is requested AT ONCE, before anything is waited for: the loop flags, the
+  // size of the cloud, the pose (one batch of wide scalar loads: load_pose) and - an unsharded cloud: its index does not depend on
+  // any of them - the query point itself (index clamped; a lane beyond the cloud discards it).  Round 4 had the flags behind the
+  // size behind the pose (24 dependent scalar loads) and the point behind all of them: ~3 us of start-up in which every wavefront
+  // walked the same chain.
   constexpr int QPB = BS / LPQ;
+  const int blk = xcd_remap(blockIdx.x, nb_real);
   const int sub = threadIdx.x & (LPQ - 1);
   const int ql = blk * QPB + (int)(threadIdx.x / LPQ);
+  const bool early = rb.shard_world <= 1;
+  const int2 c_flags_raw = request_loop_flags(&ctrl->search_next);
+  const int n_mem_raw = request_cloud_size(rb, &ctrl->max_it);
+  float4 pb_early = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (early) pb_early = rb.body[min(max(ql, 0), rb.cap - 1)];
+  const PoseArg ps = load_pose(pose);
+  const int2 c_flags = take_loop_flags(c_flags_raw);
+  const int c_search = c_flags.x, c_stop = c_flags.y, n_mem = take_scalar(n_mem_raw);
+  int lo, n_live;
+  shard_range_n(rb, n_mem, lo, n_live);
+  if (forced < 0 && (c_stop || !c_search)) return;
+  if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
+  if (blk >= nb_real) return;
   // the grid is sized for an upper bound of the cloud (the voxel filter leaves the exact size on the device): wavefronts
   // beyond the cloud leave at once
   if (blk * QPB + (int)((threadIdx.x & ~63u) / LPQ) >= n_live) return;
   const int qi = lo + ql;
   const bool live = ql < n_live;
   float wx = 0, wy = 0, wz = 0;
-  if (live && sub == 0) body_to_world(ps, rb.body[qi], wx, wy, wz);
+  if (live && sub == 0) body_to_world(ps, early ? pb_early : rb.body[qi], wx, wy, wz);
   wx = group_bcast_f<LPQ, 0>(wx); wy = group_bcast_f<LPQ, 0>(wy); wz = group_bcast_f<LPQ, 0>(wz);
   const bool active = live && g.n_pts > 0;
   const float INF = __builtin_inff();
@@ -1052,10 +1063,10 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
 // The search pass on exact (distance, index) lists throughout (round 2's form in round 1 too).  Kept as the reference form of
 // k_knn_pk: same cells, same candidates; LII_KNN_VARIANT=5 selects it.
 template <int BS>
-__global__ __launch_bounds__(BS) void k_knn_exact(GridView g, RegistrationBuffers rb, PoseArg ps_val, const PoseArg* __restrict__ pose,
+__global__ __launch_bounds__(BS) void k_knn_exact(GridView g, RegistrationBuffers rb, const PoseArg* __restrict__ pose,
                                                   const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
                                                   double* __restrict__ search_pose_out) {
-  const PoseArg ps = forced != 1 ? *pose : ps_val;
+  const PoseArg ps = load_pose(pose);
   int lo, n_live;
   shard_range(rb, lo, n_live);
   if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
@@ -1376,7 +1387,7 @@ __global__ __launch_bounds__(kBlock) void k_knn_complete(GridView g, Registratio
   complete_flagged(g, rb, lo + q, live, count, w, sh);
 }
 
-__global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationBuffers rb, PoseArg ps_val,
+__global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationBuffers rb,
                                                         const PoseArg* __restrict__ pose,
                                                         const IekfCtrl* __restrict__ ctrl, int forced, int imu_en,
                                                         double plane_thr, double rinv, int nb_real) {
@@ -1386,6 +1397,11 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   // neighbour count - is requested BEFORE the flags, the pose and the cloud size have arrived (an unsharded cloud: the point's
   // index does not depend on them; the index is clamped, a lane beyond the cloud discards what it read): one dependent round
   // trip instead of two at the head of every fit launch.
+  // (the flags, the size of the cloud and the pose - scalar requests - go out first, the point's data right behind them; all of it is
+  // waited for once: k_knn_pk)
+  const int2 c_flags_raw = request_loop_flags(&ctrl->search_next);
+  const int n_mem_raw = request_cloud_size(rb, &ctrl->max_it);
+  const PoseArg ps = load_pose(pose);
   const int q_early = fit_point_of(xcd_remap(blockIdx.x, nb_real), nb_real);
   const bool early = rb.shard_world <= 1;
   const int ie = min(max(q_early, 0), rb.cap - 1);
@@ -1396,21 +1412,21 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   if (early) {
     e_body = rb.body[ie];
     e_world = rb.world[ie];
-    e_count = rb.nbr_count[ie];
-    e_sel = rb.selected[ie];
     const double* pl = rb.plane + 4 * (size_t)ie;
     e_pl[0] = pl[0]; e_pl[1] = pl[1]; e_pl[2] = pl[2]; e_pl[3] = pl[3];
+    e_count = rb.nbr_count[ie];
+    e_sel = rb.selected[ie];  // (the LAST request: the compiler tests the flag right here, and the wait for it must not stand in front of the others)
   }
-  // (pose and point count are loaded together with the flags, not after the branch on them: see k_knn_pk)
-  const PoseArg ps = forced < 0 ? *pose : ps_val;
+  const int2 c_flags = take_loop_flags(c_flags_raw);
+  const int c_search = c_flags.x, c_stop = c_flags.y, n_mem = take_scalar(n_mem_raw);
   int lo, n_live;
-  shard_range(rb, lo, n_live);
+  shard_range_n(rb, n_mem, lo, n_live);
   bool FIT;
   if (forced >= 0) {
     FIT = forced != 0;
   } else {
-    if (ctrl->stop) return;
-    FIT = ctrl->search_next != 0;
+    if (c_stop) return;
+    FIT = c_search != 0;
   }
   const int blk = xcd_remap(blockIdx.x, nb_real);
   if (blk >= nb_real) return;  // uniform per block
@@ -1625,12 +1641,12 @@ static inline int shard_bound(const RegistrationBuffers& rb) {
   return rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;
 }
 template <int LPQ, int BS, int NB, int WPE>
-static void launch_knn_pk_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+static void launch_knn_pk_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                             const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
   int nq = nblk(shard_bound(rb), BS / LPQ);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_knn_pk<LPQ, BS, NB, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
+  hipLaunchKernelGGL((k_knn_pk<LPQ, BS, NB, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out);
 }
 // Lanes per query of the search pass for a cloud of (at most) `n_queries` points.  Four lanes per query issue ~20 % more
 // instructions in total than two (the per-query work - pose transform, cell arithmetic, merges, re-measurement - is replicated on
@@ -1643,14 +1659,14 @@ int knn_lanes_for(int variant, int n_queries) {
   if (variant == 1 || variant == 2 || variant == 4) return variant;
   return n_queries >= kKnnTwoLaneQueries ? 2 : 4;
 }
-void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                 const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s, int n_queries_hint) {
 #ifdef LII_KNN_EXACT
   if (variant == 5) {
     int nq = nblk(shard_bound(rb), 128 / 4);
     if (nq < 1) nq = 1;
     const int nq_pad = ((nq + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_knn_exact<128>), dim3(nq_pad), dim3(128), 0, s, g, rb, ps, pose, ctrl, forced, nq, search_pose_out);
+    hipLaunchKernelGGL((k_knn_exact<128>), dim3(nq_pad), dim3(128), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out);
     return;
   }
 #endif
@@ -1658,21 +1674,21 @@ void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, c
   // loads, 6 / 8 wavefronts per SIMD (within 1 % on stream100k, 2 % behind on the larger scans; profiles/r03_knn_ab.md)
   const int bound = shard_bound(rb);
   const int lanes = knn_lanes_for(variant, n_queries_hint > 0 && n_queries_hint < bound ? n_queries_hint : bound);
-  if (lanes == 2) launch_knn_pk_t<2, 128, 6, 7>(g, rb, ps, pose, ctrl, forced, search_pose_out, s);
-  else if (lanes == 1) launch_knn_pk_t<1, 128, 6, 4>(g, rb, ps, pose, ctrl, forced, search_pose_out, s);
-  else launch_knn_pk_t<4, 128, 6, 7>(g, rb, ps, pose, ctrl, forced, search_pose_out, s);
+  if (lanes == 2) launch_knn_pk_t<2, 128, 6, 7>(g, rb, pose, ctrl, forced, search_pose_out, s);
+  else if (lanes == 1) launch_knn_pk_t<1, 128, 6, 4>(g, rb, pose, ctrl, forced, search_pose_out, s);
+  else launch_knn_pk_t<4, 128, 6, 7>(g, rb, pose, ctrl, forced, search_pose_out, s);
 }
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(k_knn_complete, dim3(nb), dim3(kBlock), 0, s, g, rb);
 }
-void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg& ps, const PoseArg* pose,
+void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);
   if (nb < 1) nb = 1;
   const int nb_pad = ((nb + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_fit_reduce, dim3(nb_pad), dim3(kBlock), 0, s, g, rb, ps, pose, ctrl, forced, imu_en, plane_thr, rinv, nb);
+  hipLaunchKernelGGL(k_fit_reduce, dim3(nb_pad), dim3(kBlock), 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb);
 }
 void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);

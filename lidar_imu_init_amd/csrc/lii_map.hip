@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, Pose
                                                     float4* __restrict__ dst_add, float4* __restrict__ dst_nodown, int* __restrict__ counts, int bound_a,
                                                     int bound_n, const IekfCtrl* __restrict__ guard, int seq, int test_late) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const PoseArg ps = guard ? *reinterpret_cast<const PoseArg*>(guard->st) : ps_val;
+  const PoseArg ps = load_pose(guard != nullptr, reinterpret_cast<const PoseArg*>(guard), ps_val);  // (IekfCtrl::st leads the block)
   const bool go = !guard || (guard->stop == 1 && guard->singular == 0 && guard->seq == seq);  // uniform
   const int n = go ? (rb.n_dev ? *rb.n_dev : rb.n) : 0;
   int lo = 0, n_live = n;  // a rank of a job split by index decides for its block (the lists are exchanged afterwards)
