@@ -53,40 +53,63 @@ struct PoseArg {
 // selected the 24 doubles ONE BY ONE - 24 conditional scalar loads, sixteen of them behind a wait for the one before (three of those
 // cache misses: the block was written by the previous launch, on another XCD), at the head of every search and fit launch - and the
 // second copy of the pose took the scalar registers the first requests of the kernel needed to go out together.
-// The pose as VECTOR loads (twelve 16-byte requests per lane, every lane the same address - the offset is an opaque zero in a vector
-// register, or the compiler would turn them back into scalar loads): they go out in one batch together with the point's own data,
-// behind no wait, and the 48 registers they land in are vector registers - 48 scalar registers on top of a kernel's arguments do not
-// fit the scalar file (k_fit_reduce spilled 62 of them into vector-register lanes and fetched them back with v_readlane), and the
-// compiler staggers scalar loads it has no registers for into dependent batches.
-__device__ __forceinline__ PoseArg load_pose(const PoseArg* __restrict__ pose) {
-  unsigned int zero = 0u;
-  asm volatile("" : "+v"(zero));
-  const double2* __restrict__ src = reinterpret_cast<const double2*>(reinterpret_cast<const char*>(pose) + zero);
-  double2 v[12];
+// What the head of a search or fit launch needs from memory besides its point: the pose (24 doubles = three 64-byte lines), the loop
+// flags (IekfCtrl::search_next, ::stop: neighbours in the block) and the device-resident size of the cloud.  Five SCALAR loads,
+// issued back to back and waited for once - written out as instructions, because the compiler cannot be made to: it sinks scalar
+// loads to their first use (behind the waits for everything else), splits a batch it has no registers for into dependent ones, and
+// turned round 4's `cond ? *pose : by_value` into 24 conditional loads with a wait between them.  (Round 5 first read the pose with
+// vector loads - one batch as well, and 0.7 us off every fit launch of the 100 k-point stream - but thirteen more vector-memory
+// instructions per wavefront cost the 500 k-point scan 6 us per search launch: profiles/r05_head_loads.md.)
+// The caller issues its own vector loads (the point's data) BEFORE this call: the "memory" clobber keeps them in front, and they are
+// in flight while the wavefront waits for the scalars.  `n_ptr` must be a valid address (a kernel whose cloud size is not on the
+// device passes any int it may read and ignores the value).
+typedef unsigned int lii_u16v __attribute__((ext_vector_type(16)));
+typedef unsigned int lii_u2v __attribute__((ext_vector_type(2)));
+struct HeadScalars {
+  PoseArg ps;
+  int search_next, stop, n_mem;
+};
+__device__ __forceinline__ HeadScalars load_head_scalars(const PoseArg* __restrict__ pose, const int* __restrict__ search_next_and_stop,
+                                                         const int* __restrict__ n_ptr) {
+  lii_u16v l0, l1, l2;
+  lii_u2v fl;
+  unsigned int nm;
+  asm volatile(
+      "s_load_dwordx16 %0, %5, 0x0\n\t"
+      "s_load_dwordx16 %1, %5, 0x40\n\t"
+      "s_load_dwordx16 %2, %5, 0x80\n\t"
+      "s_load_dwordx2 %3, %6, 0x0\n\t"
+      "s_load_dword %4, %7, 0x0\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(l0), "=&s"(l1), "=&s"(l2), "=&s"(fl), "=&s"(nm)
+      : "s"(pose), "s"(search_next_and_stop), "s"(n_ptr)
+      : "memory");
+  auto dbl = [](unsigned int lo, unsigned int hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
+  HeadScalars h;
+  PoseArg& m = h.ps;
+  m.R[0] = dbl(l0[0], l0[1]); m.R[1] = dbl(l0[2], l0[3]); m.R[2] = dbl(l0[4], l0[5]); m.R[3] = dbl(l0[6], l0[7]);
+  m.R[4] = dbl(l0[8], l0[9]); m.R[5] = dbl(l0[10], l0[11]); m.R[6] = dbl(l0[12], l0[13]); m.R[7] = dbl(l0[14], l0[15]);
+  m.R[8] = dbl(l1[0], l1[1]);
+  m.p[0] = dbl(l1[2], l1[3]); m.p[1] = dbl(l1[4], l1[5]); m.p[2] = dbl(l1[6], l1[7]);
+  m.RLI[0] = dbl(l1[8], l1[9]); m.RLI[1] = dbl(l1[10], l1[11]); m.RLI[2] = dbl(l1[12], l1[13]); m.RLI[3] = dbl(l1[14], l1[15]);
+  m.RLI[4] = dbl(l2[0], l2[1]); m.RLI[5] = dbl(l2[2], l2[3]); m.RLI[6] = dbl(l2[4], l2[5]); m.RLI[7] = dbl(l2[6], l2[7]);
+  m.RLI[8] = dbl(l2[8], l2[9]);
+  m.TLI[0] = dbl(l2[10], l2[11]); m.TLI[1] = dbl(l2[12], l2[13]); m.TLI[2] = dbl(l2[14], l2[15]);
+  h.search_next = (int)fl[0]; h.stop = (int)fl[1]; h.n_mem = (int)nm;
+  return h;
+}
+// The same pose in VECTOR registers (24 moves): a kernel that keeps the pose for its whole life has no scalar registers for it -
+// k_fit_reduce spilled 62 of them into vector-register lanes and fetched them back one v_readlane at a time.
+__device__ __forceinline__ PoseArg pose_to_vgprs(const PoseArg& s) {
+  PoseArg v;
+  auto mv = [](double x) { double r; asm volatile("v_mov_b64 %0, %1" : "=v"(r) : "s"(x)); return r; };
 #pragma unroll
-  for (int k = 0; k < 12; k++) v[k] = src[k];
-  PoseArg m;
+  for (int k = 0; k < 9; k++) { v.R[k] = mv(s.R[k]); v.RLI[k] = mv(s.RLI[k]); }
 #pragma unroll
-  for (int k = 0; k < 24; k++) {
-    const double x = (k & 1) ? v[k >> 1].y : v[k >> 1].x;
-    if (k < 9) m.R[k] = x;
-    else if (k < 12) m.p[k - 9] = x;
-    else if (k < 21) m.RLI[k - 12] = x;
-    else m.TLI[k - 21] = x;
-  }
-  return m;
+  for (int k = 0; k < 3; k++) { v.p[k] = mv(s.p[k]); v.TLI[k] = mv(s.TLI[k]); }
+  return v;
 }
-// The loop flags a per-point kernel starts with - IekfCtrl::search_next and ::stop, neighbours in the block - requested the same way
-// (a scalar load is sunk to its first use by the compiler, behind the wait for everything else); (search_next, stop).
-__device__ __forceinline__ int2 request_loop_flags(const int* __restrict__ search_next_and_stop) {
-  unsigned int zero = 0u;
-  asm volatile("" : "+v"(zero));
-  return *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(search_next_and_stop) + zero);
-}
-// (to be called BEHIND the kernel's other first requests: the value is needed in a scalar register, which is a wait)
-__device__ __forceinline__ int2 take_loop_flags(int2 v) {
-  return make_int2(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y));
-}
+__device__ __forceinline__ PoseArg load_pose(const PoseArg* __restrict__ pose) { return *pose; }  // (no hurry: k_map_decide, k_knn_exact)
 // (a kernel that still takes a pose by value beside the pointer - k_map_decide: the caller's final state, or the control block's)
 __device__ __forceinline__ PoseArg load_pose(bool from_memory, const PoseArg* __restrict__ pose, const PoseArg& by_value) {
   PoseArg ps = by_value;
@@ -135,17 +158,7 @@ struct RegistrationBuffers {
 
 // The block of the down-sampled cloud this rank registers: first index and size.  Every rank holds the WHOLE cloud (the
 // de-skew and the voxel filter run replicated, so the cloud is bit-identical everywhere) and the split needs no exchange.
-// The device-resident size of the cloud, requested without a branch (a valid address either way: `fallback` is any int the kernel may
-// read; the value is only used when rb.n_dev is set) and as a vector load, like the pose and the loop flags (load_pose): it goes out
-// with the kernel's other first requests; take_scalar() - behind them - moves it to a scalar register.
-__device__ __forceinline__ int request_cloud_size(const RegistrationBuffers& rb, const int* fallback) {
-  unsigned int zero = 0u;
-  asm volatile("" : "+v"(zero));
-  const int* p = rb.n_dev ? rb.n_dev : fallback;
-  return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(p) + zero);
-}
-__device__ __forceinline__ int take_scalar(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ void shard_range_n(const RegistrationBuffers& rb, int n_mem /* load_cloud_size */, int& lo, int& n_live) {
+__device__ __forceinline__ void shard_range_n(const RegistrationBuffers& rb, int n_mem /* the cloud's size as loaded from rb.n_dev */, int& lo, int& n_live) {
   const int n_all = rb.n_dev ? n_mem : rb.n;
   lo = 0;
   n_live = n_all;

@@ -103,30 +103,29 @@ __device__ __forceinline__ bool gj12_pivoting(double (&col)[H]) {
 // Pivoting: none inside the loop - a data-dependent row exchange is what cannot be expressed with static register indices - but
 // the elimination WATCHES ITS OWN GROWTH: every lane keeps the largest magnitude its column takes on the way (twelve maxima per
 // step, off the critical chain readlane -> reciprocal -> multiply-add), and the result stands only if the columns of A never
-// outgrew kGrowthMax x max(1, max |A|) - the quantity the backward error of an elimination is proportional to (Wilkinson) - and
+// outgrew 2^8 x max(1, max |A|) - the quantity the backward error of an elimination is proportional to (Wilkinson) - and
 // every pivot was a number.  Otherwise the saved input goes through gj12_pivoting.  I + P11 G with P11, G positive semi-definite
 // has its spectrum in [1, inf): measured on LIO sequences (hall, corridor: tools/exp/gj_growth.py) the pivot-free growth stays
 // below 10 where the 1/4-threshold test of round 4 would have exchanged rows on nine scans of ten.
-constexpr double kGrowthMax = 256.0;  // eight bits of the 53: <= 3e-14 x cond(A) on the gain, far inside the 1e-4 the covariance is held to
-// max(|a|, |b|) as ONE instruction (the source modifiers are free; written as fmax(fabs(a), fabs(b)) the compiler first
-// canonicalises every loop-carried operand with a v_max of its own: 23 instructions for twelve values instead of 11)
-__device__ __forceinline__ double absmax2(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ double col_absmax(const double (&col)[H]) {
-  const double t0 = absmax2(col[0], col[1]), t1 = absmax2(col[2], col[3]), t2 = absmax2(col[4], col[5]), t3 = absmax2(col[6], col[7]),
-               t4 = absmax2(col[8], col[9]), t5 = absmax2(col[10], col[11]);
-  return absmax2(absmax2(absmax2(t0, t1), absmax2(t2, t3)), absmax2(t4, t5));
+// (kGrowthMax = 2^8: eight bits of the 53 - <= 3e-14 x cond(A) on the gain, far inside the 1e-4 the covariance is held to)
+// The watch works on the HIGH WORDS of the doubles - sign off, the exponent and the top 20 mantissa bits order like the magnitudes:
+// twelve v_and_b32 and six v_max3_u32 per step, 72 cycles of a lone wavefront where twelve v_max_f64 take 120 (tools/ubench/
+// solve_ubench.hip: a double-precision max or multiply-add occupies the pipe for 7 - 10 cycles, a 32-bit operation for 4) - and
+// "x 2^8" is an addition to the exponent field.  Not-a-number and infinity sort above every finite bound.
+__device__ __forceinline__ unsigned int col_absmax_hi(const double (&col)[H]) {
+  unsigned int t[H];
+#pragma unroll
+  for (int r = 0; r < H; r++) t[r] = (unsigned int)__double2hiint(col[r]) & 0x7FFFFFFFu;
+  const unsigned int a = max(max(t[0], t[1]), t[2]), b = max(max(t[3], t[4]), t[5]), c = max(max(t[6], t[7]), t[8]), d = max(max(t[9], t[10]), t[11]);
+  return max(max(a, b), max(c, d));
 }
 // Every lane watches ITS column against ITS column's own scale, max(1, largest magnitude at the start): stricter than the growth
 // factor of the whole matrix (a column's scale is at most the matrix's) and needs no reduction over the lanes - the verdict is one
 // ballot at the end.  (The columns of the right-hand side are watched as well: they only ride along, but a column that outgrows
 // its start by 2^8 says the multipliers were large.)
 __device__ __forceinline__ bool gj12_loop(double (&col)[H]) {
-  double g = col_absmax(col);
-  const double bound = kGrowthMax * fmax(g, 1.0);
+  unsigned int g = col_absmax_hi(col);
+  const unsigned int bound = max(g, 0x3FF00000u /* 1.0 */) + (8u << 20);  // kGrowthMax = 2^8
 #pragma nounroll
   for (int k = 0; k < H; k++) {
     double m[H];
@@ -140,7 +139,7 @@ __device__ __forceinline__ bool gj12_loop(double (&col)[H]) {
 #pragma unroll
     for (int r = 1; r < H; r++) col[r - 1] = fma(-m[r], rowk, col[r]);
     col[H - 1] = rowk;
-    g = absmax2(g, col_absmax(col));
+    g = max(g, col_absmax_hi(col));
   }
   return __all(g <= bound);  // (false for a pivot that was zero or not a number: the maxima carry it; idle lanes hold zeros)
 }

@@ -802,13 +802,11 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
   const int sub = threadIdx.x & (LPQ - 1);
   const int ql = blk * QPB + (int)(threadIdx.x / LPQ);
   const bool early = rb.shard_world <= 1;
-  const int2 c_flags_raw = request_loop_flags(&ctrl->search_next);
-  const int n_mem_raw = request_cloud_size(rb, &ctrl->max_it);
   float4 pb_early = make_float4(0.f, 0.f, 0.f, 0.f);
   if (early) pb_early = rb.body[min(max(ql, 0), rb.cap - 1)];
-  const PoseArg ps = load_pose(pose);
-  const int2 c_flags = take_loop_flags(c_flags_raw);
-  const int c_search = c_flags.x, c_stop = c_flags.y, n_mem = take_scalar(n_mem_raw);
+  const HeadScalars hs = load_head_scalars(pose, &ctrl->search_next, rb.n_dev ? rb.n_dev : &ctrl->max_it);
+  const PoseArg& ps = hs.ps;
+  const int c_search = hs.search_next, c_stop = hs.stop, n_mem = hs.n_mem;
   int lo, n_live;
   shard_range_n(rb, n_mem, lo, n_live);
   if (forced < 0 && (c_stop || !c_search)) return;
@@ -1054,6 +1052,295 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
         if (sub + r < 5 && sub + r >= found) rb.nbr[(size_t)(sub + r) * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
     }
     // (kCovered: flagged for its reach alone - the list is exact over the 3 x 3 x 3 cells, the completion starts from it)
+    if (sub == (LPQ > 1 ? 1 : 0)) rb.nbr_count[qi] = found | (need ? (kNeedy | ((ovf || amb) ? 0 : kCovered)) : 0);
+    if (sub == (LPQ == 4 ? 2 : 0)) rb.world[qi] = make_float4(wx, wy, wz, 0.f);
+  }
+}
+
+// ---- the search pass with the GROUP scanning every cell together ("chunked", round 5) ------------------------------------------
+// k_knn_pk gives every lane of a query its own cells: a candidate load of a wavefront then touches up to 64 different cache lines -
+// measured 40 per instruction (TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD), 6.6 M (100 k-point scan) and 21 M (500 k) line lookups
+// per launch: at one lookup per cycle and compute unit 10.7 and 34.3 us of the vector-memory front end, in launches of 17 - 21 and
+// 52 - 64 us (profiles/r05_knn_l1.md).  Here the LPQ lanes of a query read LPQ CONSECUTIVE points of one cell - 64 contiguous bytes
+// with four lanes, one or two lines - and neighbouring queries that scan the same cell read the same lines.
+// The cells' ranges are cut into chunks of LPQ points; the group keeps a table of its chunks in LDS - word = first map index << 3 |
+// points in the chunk (1 .. LPQ; 0: padding behind the last chunk, so that a batch of NB loads needs no bounds test) - in the order
+// the cells were looked up: round 1's eight cells, then the outer cells round 2 adds.  A candidate is numbered (chunk << log2 LPQ) |
+// lane: the position in its key.  Whatever needs a candidate's map index afterwards - the winners' re-measurement - reads it from
+// the table; the per-lane range arithmetic of k_knn_pk (which range does position p belong to?) is gone.
+template <int LPQ>
+struct CkGeom {
+  static constexpr int kLaneShift = LPQ == 4 ? 2 : (LPQ == 2 ? 1 : 0);
+  static constexpr int kChunkBits = 6;
+  static constexpr int MAXCH = 1 << kChunkBits;                 // chunks a group can number: 64 x LPQ candidates
+  static constexpr int kPosBits = kChunkBits + kLaneShift;      // 8 of the 23 mantissa bits with four lanes (k_knn_pk: 12)
+  static constexpr unsigned int kPosMask = (1u << kPosBits) - 1u;
+  static constexpr int NR = 8 / LPQ;                            // cells per lane in round 1
+  static constexpr int NW = (7 + LPQ - 1) / LPQ;                // winners a lane re-measures
+  static constexpr int MAXPASS = (19 + 2 * LPQ - 1) / (2 * LPQ);  // round 2: two outer cells per lane and pass
+};
+// sum of `v` over the lanes of the group below this one (exclusive prefix) and over all of them
+template <int LPQ>
+__device__ __forceinline__ void group_prefix(unsigned int v, int sub, unsigned int& before, unsigned int& total) {
+  if (LPQ == 4) {
+    const unsigned int v0 = quad_perm<0x00>(v), v1 = quad_perm<0x55>(v), v2 = quad_perm<0xAA>(v), v3 = quad_perm<0xFF>(v);
+    before = sub == 0 ? 0u : (sub == 1 ? v0 : (sub == 2 ? v0 + v1 : v0 + v1 + v2));
+    total = v0 + v1 + v2 + v3;
+  } else if (LPQ == 2) {
+    const unsigned int v0 = quad_perm<0xA0>(v), v1 = quad_perm<0xF5>(v);
+    before = sub == 0 ? 0u : v0;
+    total = v0 + v1;
+  } else {
+    before = 0u;
+    total = v;
+  }
+}
+// The lane's NC cell ranges become chunks at tab[at ...] (the group's table; `at` = where this lane's chunks start); the caller
+// has checked that they fit.
+template <int LPQ, int NC>
+__device__ __forceinline__ void ck_write_chunks(unsigned int* __restrict__ tab, unsigned int at, const uint2 (&r)[NC]) {
+#pragma unroll
+  for (int t = 0; t < NC; t++) {
+    for (unsigned int j = r[t].x; j < r[t].y; j += LPQ) tab[at++] = (j << 3) | min((unsigned)LPQ, r[t].y - j);
+  }
+}
+// chunks [first, end) of the group's table (end is followed by >= NB - 1 padding words), NB loads in flight per lane
+template <int LPQ, int NB>
+__device__ __forceinline__ void ck_scan(const float4* __restrict__ pts, const unsigned int* __restrict__ tab, unsigned int first, unsigned int end,
+                                        int sub, float wx, float wy, float wz, Pk7& L) {
+  using G = CkGeom<LPQ>;
+  for (unsigned int base = first; base < end; base += NB) {
+    unsigned int w[NB];
+#pragma unroll
+    for (int u = 0; u < NB; u++) w[u] = tab[base + u];
+    F3 P[NB];
+#pragma unroll
+    for (int u = 0; u < NB; u++) P[u] = load_xyz(pts, (w[u] >> 3) + min((unsigned)sub, (w[u] & 7u) - 1u));  // (padding: count 0 -> slot `sub` of the array, discarded)
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+      const float d = dist2_ref(wx, wy, wz, P[u].x, P[u].y, P[u].z);
+      const unsigned int key = (__float_as_uint(d) & ~G::kPosMask) | (((base + u) << G::kLaneShift) | (unsigned)sub);
+      pk_insert(L, (unsigned)sub < (w[u] & 7u) ? key : kPkInf);  // (the acceptance test d2 <= max_d2 waits for the re-measurement of the winners)
+    }
+  }
+}
+template <int LPQ, int BS, int NB, int WPE>
+__global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuffers rb, const PoseArg* __restrict__ pose,
+                                               const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
+                                               double* __restrict__ search_pose_out) {
+  using G = CkGeom<LPQ>;
+  constexpr int QPB = BS / LPQ;
+  __shared__ unsigned int s_tab[QPB * (G::MAXCH + NB)];
+  // (the head: as k_knn_pk - everything it needs from memory is requested at once)
+  const int blk = xcd_remap(blockIdx.x, nb_real);
+  const int sub = threadIdx.x & (LPQ - 1);
+  const int ql = blk * QPB + (int)(threadIdx.x / LPQ);
+  const bool early = rb.shard_world <= 1;
+  float4 pb_early = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (early) pb_early = rb.body[min(max(ql, 0), rb.cap - 1)];
+  const HeadScalars hs = load_head_scalars(pose, &ctrl->search_next, rb.n_dev ? rb.n_dev : &ctrl->max_it);
+  const PoseArg& ps = hs.ps;
+  const int c_search = hs.search_next, c_stop = hs.stop, n_mem = hs.n_mem;
+  int lo, n_live;
+  shard_range_n(rb, n_mem, lo, n_live);
+  if (forced < 0 && (c_stop || !c_search)) return;
+  if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
+  if (blk >= nb_real) return;
+  if (blk * QPB + (int)((threadIdx.x & ~63u) / LPQ) >= n_live) return;
+  const int qi = lo + ql;
+  const bool live = ql < n_live;
+  float wx = 0, wy = 0, wz = 0;
+  if (live && sub == 0) body_to_world(ps, early ? pb_early : rb.body[qi], wx, wy, wz);
+  wx = group_bcast_f<LPQ, 0>(wx); wy = group_bcast_f<LPQ, 0>(wy); wz = group_bcast_f<LPQ, 0>(wz);
+  const bool active = live && g.n_pts > 0;
+  const float INF = __builtin_inff();
+  const uint4* __restrict__ tab_blocks = reinterpret_cast<const uint4*>(g.blocks);
+  const float4* __restrict__ pts = g.pts;
+  unsigned int* const tab = s_tab + (threadIdx.x / LPQ) * (G::MAXCH + NB);
+
+  // Round 1: the 2x2x2 block of cells nearest to the query, NR cells per lane (looked up as a batch), their chunks into the table
+  const QueryCell q = query_cell(g, wx, wy, wz);
+  const float g0sq = q.g0 * q.g0, guardsq = q.guard * q.guard;
+  unsigned int n_chunks;  // chunks in the group's table (group-uniform)
+  bool ovf;
+  {
+    uint2 r[G::NR];
+    int jx[G::NR], jy[G::NR], jz[G::NR];
+    bool want[G::NR];
+#pragma unroll
+    for (int t = 0; t < G::NR; t++) {
+      const int c = sub * G::NR + t;
+      jx[t] = q.cx + ((c & 1) ? q.ox : 0); jy[t] = q.cy + ((c & 2) ? q.oy : 0); jz[t] = q.cz + ((c & 4) ? q.oz : 0);
+      want[t] = true;
+    }
+    lookup_cells_batched<G::NR>(g, tab_blocks, jx, jy, jz, want, r);
+    unsigned int mine = 0u;
+#pragma unroll
+    for (int t = 0; t < G::NR; t++) {
+      if (!active) r[t] = make_uint2(0u, 0u);
+      mine += (r[t].y - r[t].x + (unsigned)LPQ - 1u) / (unsigned)LPQ;
+    }
+    unsigned int before;
+    group_prefix<LPQ>(mine, sub, before, n_chunks);
+    // a group whose cells hold more than MAXCH x LPQ points is left to the completion pass (cells of hundreds of points)
+    ovf = n_chunks > (unsigned)G::MAXCH;
+    if (ovf) n_chunks = 0u;
+    else ck_write_chunks<LPQ, G::NR>(tab, before, r);
+    if (sub == 0) {
+#pragma unroll
+      for (int u = 0; u < NB - 1; u++) tab[n_chunks + u] = 0u;  // padding: a batch of loads runs past the last chunk
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const bool fast = active && !ovf;
+  Pk7 L;
+  L.k0 = L.k1 = L.k2 = L.k3 = L.k4 = L.k5 = L.k6 = kPkInf;
+  ck_scan<LPQ, NB>(pts, tab, 0u, n_chunks, sub, wx, wy, wz, L);
+  pk_group_merge<LPQ>(L);
+
+  // Round 2 (the tree's calc_box_dist rule, ikd_Tree.cpp:1279-1289), as in k_knn_pk: the outer cells of the 3x3x3 block that can
+  // still hold a closer point, two per lane and pass; their chunks continue the table.
+  {
+    const float ub5 = L.k4 != kPkInf ? __uint_as_float(L.k4 | G::kPosMask) : INF;
+    const float bound = fminf(ub5, g.max_d2);
+    const bool need2 = fast && !(bound <= g0sq);
+    if (__any(need2)) {
+      float GX[3], GY[3], GZ[3];
+      {
+        const float nx = axis_gap(wx, q.cx + q.ox, g.cs, q.eps), fx = axis_gap(wx, q.cx - q.ox, g.cs, q.eps);
+        const float ny = axis_gap(wy, q.cy + q.oy, g.cs, q.eps), fy = axis_gap(wy, q.cy - q.oy, g.cs, q.eps);
+        const float nz = axis_gap(wz, q.cz + q.oz, g.cs, q.eps), fz = axis_gap(wz, q.cz - q.oz, g.cs, q.eps);
+        GX[0] = 0.f; GX[1] = nx * nx; GX[2] = fx * fx;
+        GY[0] = 0.f; GY[1] = ny * ny; GY[2] = fy * fy;
+        GZ[0] = 0.f; GZ[1] = nz * nz; GZ[2] = fz * fz;
+      }
+      unsigned int m = 0u;
+      static_for<27>([&](auto cc) {
+        constexpr int c = decltype(cc)::value, sx = c % 3, sy = (c / 3) % 3, sz = c / 9;
+        if constexpr (sx == 2 || sy == 2 || sz == 2) {
+          const float d = GX[sx] + GY[sy] + GZ[sz];
+          m |= d > bound ? 0u : (1u << c);
+        }
+      });
+      m = need2 ? m : 0u;
+      // the group's list continues on lane 0 alone (copies would come back as duplicates), the other lanes start empty
+      if (sub != 0) L.k0 = L.k1 = L.k2 = L.k3 = L.k4 = L.k5 = L.k6 = kPkInf;
+      unsigned int t = m;
+#pragma unroll
+      for (int j = 0; j < LPQ - 1; j++) t = j < sub ? (t & (t - 1u)) : t;  // the lane's first survivor: number `sub` of the set bits
+      for (int pass = 0; pass < G::MAXPASS; pass++) {
+        if (!__any(t != 0u)) break;
+        const int c1 = t ? __ffs((int)t) - 1 : -1;
+#pragma unroll
+        for (int j = 0; j < LPQ; j++) t = t & (t - 1u);
+        const int c2 = t ? __ffs((int)t) - 1 : -1;
+#pragma unroll
+        for (int j = 0; j < LPQ; j++) t = t & (t - 1u);
+        uint2 r[2];
+        {
+          int jx[2], jy[2], jz[2];
+          const bool want[2] = {true, true};
+          const int ca = c1 < 0 ? 0 : c1, cb = c2 < 0 ? 0 : c2;  // (0 = the query's own cell: looked up for nothing, not branched around)
+          auto step = [](int sdig, int o) { return o * ((sdig & 1) - (sdig >> 1)); };
+          jx[0] = q.cx + step(ca % 3, q.ox); jy[0] = q.cy + step((ca / 3) % 3, q.oy); jz[0] = q.cz + step(ca / 9, q.oz);
+          jx[1] = q.cx + step(cb % 3, q.ox); jy[1] = q.cy + step((cb / 3) % 3, q.oy); jz[1] = q.cz + step(cb / 9, q.oz);
+          lookup_cells_batched<2>(g, tab_blocks, jx, jy, jz, want, r);
+        }
+        if (c1 < 0) r[0] = make_uint2(0u, 0u);
+        if (c2 < 0) r[1] = make_uint2(0u, 0u);
+        const unsigned int mine = (r[0].y - r[0].x + (unsigned)LPQ - 1u) / (unsigned)LPQ + (r[1].y - r[1].x + (unsigned)LPQ - 1u) / (unsigned)LPQ;
+        unsigned int before, add;
+        group_prefix<LPQ>(mine, sub, before, add);
+        const unsigned int from = n_chunks;
+        if (from + add > (unsigned)G::MAXCH) {  // out of table: the group stops here and is left to the completion pass
+          ovf = true;
+          t = 0u;
+          add = 0u;
+        } else {
+          ck_write_chunks<LPQ, 2>(tab, from + before, r);
+        }
+        n_chunks = from + add;
+        if (sub == 0) {
+#pragma unroll
+          for (int u = 0; u < NB - 1; u++) tab[n_chunks + u] = 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ck_scan<LPQ, NB>(pts, tab, from, n_chunks, sub, wx, wy, wz, L);
+      }
+      pk_group_merge<LPQ>(L);
+    }
+  }
+
+  // Exact re-measurement of the seven winners: a key's position names its chunk and lane, the table gives the map index - lane `sub`
+  // loads and measures winners sub, sub + LPQ, ..., and the seven exact distances are shared by broadcasts inside the group.
+  float e[7];
+  F3 W[G::NW];
+  float d7t;
+  bool tie = false;
+  {
+    const unsigned int K[7] = {L.k0, L.k1, L.k2, L.k3, L.k4, L.k5, L.k6};
+    float el[G::NW];
+    static_for<G::NW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const unsigned int key = pick_by_lane<LPQ, LPQ * i>(K, sub);
+      const unsigned int pos = key == kPkInf ? 0u : (key & G::kPosMask);  // (an empty slot reads chunk 0 - or padding - and is discarded)
+      W[i] = load_xyz(pts, (tab[pos >> G::kLaneShift] >> 3) + (pos & (unsigned)(LPQ - 1)));
+    });
+#pragma unroll
+    for (int w = 0; w < 6; w++) tie = tie || ((K[w] ^ K[w + 1]) <= G::kPosMask && K[w + 1] != kPkInf);
+    d7t = K[6] != kPkInf ? __uint_as_float(K[6] & ~G::kPosMask) : INF;
+#pragma unroll
+    for (int i = 0; i < G::NW; i++) el[i] = dist2_ref(wx, wy, wz, W[i].x, W[i].y, W[i].z);
+    e[0] = group_bcast_f<LPQ, 0 % LPQ>(el[0 / LPQ]); e[1] = group_bcast_f<LPQ, 1 % LPQ>(el[1 / LPQ]);
+    e[2] = group_bcast_f<LPQ, 2 % LPQ>(el[2 / LPQ]); e[3] = group_bcast_f<LPQ, 3 % LPQ>(el[3 / LPQ]);
+    e[4] = group_bcast_f<LPQ, 4 % LPQ>(el[4 / LPQ]); e[5] = group_bcast_f<LPQ, 5 % LPQ>(el[5 / LPQ]);
+    e[6] = group_bcast_f<LPQ, 6 % LPQ>(el[6 / LPQ]);
+#pragma unroll
+    for (int w = 0; w < 7; w++) e[w] = (K[w] != kPkInf && e[w] <= g.max_d2) ? e[w] : INF;  // acceptance: d2 <= max_d2 (quirk A5)
+  }
+  // exact ranks (only where two neighbouring keys agree in their distance bits), as in k_knn_pk
+  int rk[G::NW];
+#pragma unroll
+  for (int i = 0; i < G::NW; i++) rk[i] = sub + LPQ * i;
+  float d5 = e[4];
+  if (__any(tie)) {
+    int rank[7];
+#pragma unroll
+    for (int w = 0; w < 7; w++) rank[w] = 0;
+#pragma unroll
+    for (int v = 0; v < 7; v++)
+#pragma unroll
+      for (int w = v + 1; w < 7; w++) {
+        const bool swapped = e[v] > e[w];
+        rank[w] += swapped ? 0 : 1;
+        rank[v] += swapped ? 1 : 0;
+      }
+    d5 = INF;
+#pragma unroll
+    for (int w = 0; w < 7; w++) d5 = rank[w] == 4 ? e[w] : d5;
+    static_for<G::NW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      rk[i] = pick_by_lane<LPQ, LPQ * i>(rank, sub);
+    });
+  }
+  const int found = e[4] < INF ? 5 : (e[3] < INF ? 4 : (e[2] < INF ? 3 : (e[1] < INF ? 2 : (e[0] < INF ? 1 : 0))));
+  const bool amb = d7t < INF && !(d5 < d7t);
+  const bool need = active && (ovf || amb || !(fminf(d5, g.max_d2) <= guardsq));
+  if (live) {
+    static_for<G::NW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const float ei = pick_by_lane<LPQ, LPQ * i>(e, sub);
+      if (sub + LPQ * i < 7 && ei < INF && rk[i] < 5) rb.nbr[(size_t)rk[i] * rb.cap + qi] = make_float4(W[i].x, W[i].y, W[i].z, ei);
+    });
+    if (found < 5) {  // the missing neighbours read (0, 0, 0, inf)
+#pragma unroll
+      for (int r = 0; r < 5; r += LPQ)
+        if (sub + r < 5 && sub + r >= found) rb.nbr[(size_t)(sub + r) * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
+    }
     if (sub == (LPQ > 1 ? 1 : 0)) rb.nbr_count[qi] = found | (need ? (kNeedy | ((ovf || amb) ? 0 : kCovered)) : 0);
     if (sub == (LPQ == 4 ? 2 : 0)) rb.world[qi] = make_float4(wx, wy, wz, 0.f);
   }
@@ -1399,26 +1686,25 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   // trip instead of two at the head of every fit launch.
   // (the flags, the size of the cloud and the pose - scalar requests - go out first, the point's data right behind them; all of it is
   // waited for once: k_knn_pk)
-  const int2 c_flags_raw = request_loop_flags(&ctrl->search_next);
-  const int n_mem_raw = request_cloud_size(rb, &ctrl->max_it);
-  const PoseArg ps = load_pose(pose);
   const int q_early = fit_point_of(xcd_remap(blockIdx.x, nb_real), nb_real);
   const bool early = rb.shard_world <= 1;
   const int ie = min(max(q_early, 0), rb.cap - 1);
   float4 e_body = make_float4(0.f, 0.f, 0.f, 0.f), e_world = e_body;
   double e_pl[4] = {0, 0, 0, 0};
   int e_count = 0;
-  unsigned char e_sel = 0;
+  unsigned int e_sel = 0;
   if (early) {
     e_body = rb.body[ie];
     e_world = rb.world[ie];
     const double* pl = rb.plane + 4 * (size_t)ie;
     e_pl[0] = pl[0]; e_pl[1] = pl[1]; e_pl[2] = pl[2]; e_pl[3] = pl[3];
     e_count = rb.nbr_count[ie];
-    e_sel = rb.selected[ie];  // (the LAST request: the compiler tests the flag right here, and the wait for it must not stand in front of the others)
+    e_sel = rb.selected[ie];
   }
-  const int2 c_flags = take_loop_flags(c_flags_raw);
-  const int c_search = c_flags.x, c_stop = c_flags.y, n_mem = take_scalar(n_mem_raw);
+  const HeadScalars hs = load_head_scalars(pose, &ctrl->search_next, rb.n_dev ? rb.n_dev : &ctrl->max_it);
+  asm volatile("" : "+v"(e_sel));  // (the selection flag is not looked at before this point: the compiler tests it where it is loaded, and the wait for it would stand in front of the scalar requests)
+  const PoseArg ps = pose_to_vgprs(hs.ps);
+  const int c_search = hs.search_next, c_stop = hs.stop, n_mem = hs.n_mem;
   int lo, n_live;
   shard_range_n(rb, n_mem, lo, n_live);
   bool FIT;
@@ -1674,6 +1960,13 @@ void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, c
   // loads, 6 / 8 wavefronts per SIMD (within 1 % on stream100k, 2 % behind on the larger scans; profiles/r03_knn_ab.md)
   const int bound = shard_bound(rb);
   const int lanes = knn_lanes_for(variant, n_queries_hint > 0 && n_queries_hint < bound ? n_queries_hint : bound);
+  if (variant == 3) {  // (A/B: the group scanning every cell together)
+    int nq = nblk(bound, 128 / 4);
+    if (nq < 1) nq = 1;
+    const int nq_pad = ((nq + 7) / 8) * 8;
+    hipLaunchKernelGGL((k_knn_ck<4, 128, 6, 7>), dim3(nq_pad), dim3(128), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out);
+    return;
+  }
   if (lanes == 2) launch_knn_pk_t<2, 128, 6, 7>(g, rb, pose, ctrl, forced, search_pose_out, s);
   else if (lanes == 1) launch_knn_pk_t<1, 128, 6, 4>(g, rb, pose, ctrl, forced, search_pose_out, s);
   else launch_knn_pk_t<4, 128, 6, 7>(g, rb, pose, ctrl, forced, search_pose_out, s);

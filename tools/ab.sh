@@ -7,8 +7,10 @@ COMMON="--no-cpu-baseline --no-pipeline --no-calibration --kernel-profile-steps 
 for v in $VARS; do
   if [ "$v" = "tree" ]; then unset LII_LIB; LDP=""; else export LII_LIB=$PWD/build_ab/$v/libliinit_hip.so; LDP=$PWD/build_ab/$v; fi
   for w in $WLS; do
-    L=${v}_${w}
-    env "$@" LD_LIBRARY_PATH=$LDP:$LD_LIBRARY_PATH timeout 200 python bench.py --workload $w --steps 300 --warmup 30 $COMMON > $O/$L.json 2> $O/$L.err
+    L=${AB_TAG}${v}_${w}
+    if [ -z "$AB_PROFILE_ONLY" ]; then
+      env "$@" LD_LIBRARY_PATH=$LDP:$LD_LIBRARY_PATH timeout 200 python bench.py --workload $w --steps 300 --warmup 30 $COMMON > $O/$L.json 2> $O/$L.err
+    fi
     env "$@" LD_LIBRARY_PATH=$LDP:$LD_LIBRARY_PATH timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/prof_$L -o t -- python bench.py --workload $w --steps 80 --warmup 10 --prime 10 $COMMON > $O/prof_$L.log 2>&1
     python tools/timeline.py $O/prof_$L $O/${L}_timeline.md "$L" > /dev/null 2>&1
     rm -rf $O/prof_$L

@@ -18,7 +18,7 @@ per = collections.defaultdict(list)
 total = None
 try:
     for line in open(tl):
-        m = re.match(r"Scan period ([\d.]+), of which kernels ([\d.]+)", line)
+        m = re.match(r"Scan period ([\d.]+), of which kernels (\d+\.\d+)", line)
         if m:
             total = float(m.group(2))
         m = re.match(r"\| (\d+) \| `([^`]+)` \| ([\d.]+) \|", line)
