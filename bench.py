@@ -571,7 +571,7 @@ def main():
                        "host_loop": "C++ (harness/stream_driver.cpp)" if native else "Python (ctypes)", "parallelism": f"points sharded x{world}" + (f", 91-scalar exchange over {value_transport}"
                                                                     + (f" (ncclCommCount {value_rccl_ranks})" if value_rccl_ranks else "") if world > 1 else ""),
                        "transport": value_transport, "rccl_ranks": value_rccl_ranks},
-            "roofline": {"bound": "hbm", "kernel": knn_kernel_name(reg),
+            "roofline": {"bound": "hbm", "kernel": knn_kernel_name(),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": avg_search_ms, "alg_bytes_per_launch": alg_bytes,
                          "launches": int(tm[5]),
@@ -662,10 +662,9 @@ def cpu_sweep_worker(args):
     print(json.dumps(out), flush=True)
 
 
-def knn_kernel_name(reg=None):
-    lanes = reg.last_knn_lanes() if reg is not None else 4  # (chosen by the library from the size of the cloud: lii_last_knn_lanes)
-    return (f"k_knn_pk (exact 5-NN into the block-grid local map, {lanes} lanes/query, packed 32-bit keys in both rounds, winners re-measured "
-            "exactly)")
+def knn_kernel_name():
+    return ("k_knn_ck (exact 5-NN into the block-grid local map, 4 lanes/query scanning every cell together, packed 32-bit keys in both "
+            "rounds, winners re-measured exactly)")
 
 
 def cpu_baseline(wl, states0, tables, no_downsample, gpu_results, gpu_lists=None, budget_s=14.0):

@@ -233,10 +233,6 @@ int lii_iekf_iterate(lii_handle h, const lii_state* state, int32_t search, int32
 int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_propagated, const lii_iekf_opts* opts,
                     lii_iekf_report* report);
 int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* selected, int32_t capacity);
-/* Lanes per query of the last k-NN launch (diagnostics): the search pass (KD_TREE::Nearest_Search for every point of the scan,
- * include/ikd-Tree/ikd_Tree.cpp:349-379) runs with 4 lanes per query on clouds below ~250 k points and with 2 above (fewer
- * instructions in total once the chip is full either way); LII_KNN_VARIANT=4|2|1 pins it.  0: no search launched yet. */
-int lii_last_knn_lanes(lii_handle h, int32_t* lanes);
 
 /* The per-scan sequence of main() (src/laserMapping.cpp:909-1134) in ONE call, enqueued back to back on the handle's
  * stream with a single host round trip at the end: p_imu->Process' undistortion (:909; the scan is the one handed over by

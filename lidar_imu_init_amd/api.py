@@ -116,7 +116,6 @@ _DECLS = {
                                   C.POINTER(lii_iekf_report)]),
     "lii_scan_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(lii_iekf_report)]),
     "lii_neighbors_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
-    "lii_last_knn_lanes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "lii_map_incremental": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lii_calib_set_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "lii_calib_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
@@ -447,13 +446,6 @@ class Registrar:
         self._check(self.L.lii_scan_register(self.h, C.byref(job), _ptr(state.pod), _ptr(state_prop.pod), C.byref(rep)))
         return dict(iterations=rep.iterations, searches=rep.searches, effect_num=rep.effect_num,
                     converged=bool(rep.converged), normal_eq=np.array(rep.normal_eq[:]))
-
-    def last_knn_lanes(self) -> int:
-        if not hasattr(self.L, "lii_last_knn_lanes"):
-            return 4  # (an older build under A/B measurement)
-        v = C.c_int32(0)
-        self._check(self.L.lii_last_knn_lanes(self.h, C.byref(v)))
-        return v.value
 
     def neighbors(self, n):
         pts = np.zeros((n, 5, 3), np.float32)

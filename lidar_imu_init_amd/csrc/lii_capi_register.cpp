@@ -10,11 +10,7 @@ namespace {
 
 
 void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose, int forced) {
-  // (the bound of the launch is exact unless the voxel filter left the size on the device: then the last cloud's size stands in)
-  const int hint = rb.n_dev ? h->knn_cloud_hint : 0;
-  const int bound = rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;
-  h->knn_lanes_last = lii::knn_lanes_for(h->knn_variant, hint > 0 && hint < bound ? hint : bound);
-  lii::launch_knn(h->knn_variant, g, rb, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->stream, hint);
+  lii::launch_knn(h->knn_variant, g, rb, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->stream);
 }
 
 
@@ -167,7 +163,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     kv.p[0] = g.pts; kv.p[1] = g.blocks; kv.p[2] = g.cells; kv.p[3] = rb.n_dev;
     kv.mask = g.block_mask; kv.n_pts = g.n_pts; kv.n = rb.n; kv.plan = (int)plan; kv.max_it = opts->max_iterations;
     kv.imu_en = opts->imu_en ? 1 : 0;
-    kv.variant = h->knn_variant * 8 + lii::knn_lanes_for(h->knn_variant, rb.n_dev && h->knn_cloud_hint > 0 && h->knn_cloud_hint < rb.n ? h->knn_cloud_hint : rb.n); kv.shard = rb.shard_world * 4096 + rb.shard_rank; kv.cs = g.cs;
+    kv.variant = h->knn_variant; kv.shard = rb.shard_world * 4096 + rb.shard_rank; kv.cs = g.cs;
     const std::string key(reinterpret_cast<const char*>(&kv), sizeof(kv));
     auto f = h->graphs.find(key);
     if (f == h->graphs.end()) {
@@ -309,7 +305,6 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   if (hr->singular) return fail(h, LII_ERR_INVALID, "singular covariance / normal matrix in the device solve");
   if (hr->it < 0) return fail(h, LII_ERR_HIP, "device loop ended without a result");
   std::memcpy(state, hr->st, sizeof(lii_state));
-  h->knn_cloud_hint = hr->n_cloud > 0 ? hr->n_cloud + hr->n_cloud / 16 : 0;  // (+ 6 %: scan-to-scan variation must not flip the geometry back and forth at the threshold)
   {  // the next update's plan: this one's pattern; passes it did not reach keep their launch
     unsigned int next = 0xFFFFFFFFu;
     for (int q = 0; q < 16 && q < hr->it; q++)
@@ -554,12 +549,6 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     h->prof.host_last_return = t_end;
   }
   return rc;
-}
-
-int lii_last_knn_lanes(lii_handle h, int32_t* lanes) {
-  if (!h || !lanes) return LII_ERR_INVALID;
-  *lanes = h->knn_lanes_last;
-  return LII_OK;
 }
 
 int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* selected, int32_t capacity) {

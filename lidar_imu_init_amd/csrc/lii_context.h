@@ -162,11 +162,8 @@ struct lii_context {
   int* d_nbody = nullptr;       // [0] size of the down-sampled cloud, [1] `filtered` flag of the last voxel filter
   bool body_is_scan = false;
   bool have_search = false;
-  int knn_variant = 0;   // search pass (k_knn_pk): 0 = lanes per query by the size of the cloud; 4 / 2 / 1 = that many whatever the size;
-                         // 5 = exact lists throughout (k_knn_exact: builds with -DLII_KNN_EXACT only) - LII_KNN_VARIANT
-  int knn_cloud_hint = 0;   // size of the last registered cloud (IekfResult::n_cloud): the launch bound of the next scan's search may be the raw
-                         // scan's size while the down-sampled size is still on the device; 0: unknown
-  int knn_lanes_last = 0;   // lanes per query of the last search launch (lii_last_knn_lanes)
+  int knn_variant = 0;   // search pass: 0 = k_knn_ck (the product form); 5 = exact lists throughout (k_knn_exact: builds with -DLII_KNN_EXACT
+                         // only) - LII_KNN_VARIANT
   hipStream_t map_stream = nullptr;  // the in-place update of lii_map_incremental runs here, beside the next scan's pre-processing
   bool map_async = false;            // ... and may still be running (map_join waits for it: ev_mapflag is its last packet)
   int bound_add = 0, bound_nodown = 0;  // ... the sizes the update in flight was enqueued for

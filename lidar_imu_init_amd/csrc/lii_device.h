@@ -412,7 +412,7 @@ struct IekfResult {
   int part_overflow;  // set by the voxel filter of a voxel-partitioned job (k_vhash_emit): this rank's share outgrew its bound
   int search_log[16];
   int parked_search;  // ... and that iteration searches (1) or not (0): the host puts a k-NN launch in front of it only then
-  int n_cloud;        // size of the cloud the update registered (this rank's share), as the device knows it; -1: not reported
+  int pad2;
   long long ts[16];  // LII_SOLVE_TRACE builds: wall_clock64 stamps of the solve phases (stopping iteration)
   long long ts0[16]; // ... of iteration 0
 };

@@ -218,7 +218,7 @@ __device__ __forceinline__ void publish_done(IekfResult* res, int seq) {
 // ne_src: where the 91 sums come from - a functor called by every lane AFTER the other loads have been issued; it leaves the sums
 // in s_ne[0 .. 90] (LDS; the barrier below makes them visible) and returns false when they could not be had (uniform).
 template <class NeSrc>
-__device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, int n_cloud, NeSrc ne_src) {
+__device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, NeSrc ne_src) {
 #ifdef LII_SOLVE_TRACE
   __shared__ long long s_ts[16];
 #endif
@@ -384,7 +384,6 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, in
         res->effect_num = (int)s_ne[90];
         res->converged = converged;
         res->singular = 0;
-        res->n_cloud = n_cloud;
       }
     }
   } else if (do_cov) {
@@ -470,7 +469,7 @@ __device__ __forceinline__ int warm_code() {
 __device__ __forceinline__ unsigned int pass_tag(int seq, int it) { return ((unsigned int)seq << 6) ^ (unsigned int)(it + 1); }
 __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __restrict__ partials, int n_blocks, int stride,
                                                                  unsigned long long* __restrict__ gran, IekfCtrl* c, IekfResult* res,
-                                                                 MailboxView mb, RegistrationBuffers rb) {
+                                                                 MailboxView mb) {
   __shared__ double s_w[kSolveThreads / 64];
   const int stop = c->stop, seq = c->seq, it = c->it;  // (one request: the three words share a line)
   const int t = blockIdx.x;
@@ -490,9 +489,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __
   if (stop) return;  // (the solver; it may set the flag itself, after every workgroup above has read it and published)
   const unsigned int tag = pass_tag(seq, it);
   const int warm = warm_code();
-  int lo_unused, n_cloud;
-  shard_range(rb, lo_unused, n_cloud);  // (the size of the cloud: the host picks the next scan's search geometry by it)
-  iekf_solve_body(c, res, n_cloud, [&](double* s_ne) {
+  iekf_solve_body(c, res, [&](double* s_ne) {
     __shared__ int s_mb_ok;
     if (threadIdx.x < 64) {  // one wavefront collects the sums (lane l: sums l and l + 64) and runs the exchange between the ranks
       const int l = threadIdx.x;
@@ -527,7 +524,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __
 
 // (defined BEHIND k_reduce_solve on purpose: that kernel reads its own code ahead, see warm_code)
 __global__ __launch_bounds__(kSolveThreads) void k_iekf_solve(IekfCtrl* c, const double* __restrict__ ne, IekfResult* res) {
-  iekf_solve_body(c, res, -1, [&](double* s_ne) {
+  iekf_solve_body(c, res, [&](double* s_ne) {
     const int tid = threadIdx.x;
     if (tid >= 64 && tid < 64 + 91) s_ne[tid - 64] = ne[tid - 64];
     return true;
@@ -554,7 +551,7 @@ void launch_reduce_solve(const RegistrationBuffers& rb, unsigned long long* gran
   const int bound = rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;  // as launch_fit_reduce
   int nb = (bound + kBlock - 1) / kBlock;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq + 1), dim3(kSolveThreads), 0, s, rb.partials, nb, rb.partial_stride, gran, c, res, mb, rb);
+  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq + 1), dim3(kSolveThreads), 0, s, rb.partials, nb, rb.partial_stride, gran, c, res, mb);
 }
 // A parked loop goes on with the launches the host has put behind this one (plan_mask, as IekfCtrl::plan_mask).
 __global__ void k_loop_resume(IekfCtrl* c, unsigned int plan_mask) {

@@ -5,7 +5,7 @@
 //   k_map_keys / k_map_gather / k_block_flags / k_cells_fill
 //                      device mirror of the ikd-Tree point set as a cell-sorted array + block-hierarchical grid
 //                      (include/ikd-Tree/ikd_Tree.cpp:336-347 Build)
-//   k_knn_pk / _exact  KD_TREE::Nearest_Search (ikd_Tree.cpp:349-379, Search :825-968) for every point of the
+//   k_knn_ck / _exact  KD_TREE::Nearest_Search (ikd_Tree.cpp:349-379, Search :825-968) for every point of the
 //                      scan, after pointBodyToWorld (src/laserMapping.cpp:209-220, call :973-985)
 //   k_fit_reduce       completes the few searches the 3x3x3 pass could not prove exact, then esti_plane +
 //                      residual/selection (src/laserMapping.cpp:987-1011), Jacobian rows (:1035-1071) and the
@@ -632,18 +632,16 @@ __device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const f
 #endif
 
 // ---- packed keys ---------------------------------------------------------------------------------
-// k_knn_pk ranks its candidates as 32-bit keys: the float bits of d2 with the low kPkPosBits mantissa bits replaced by the
-// candidate's position in the group's candidate list (2 bits: the lane that scanned it, 10 bits: its place in that lane's
-// cells).  d2 >= 0, so the keys order like the distances (to 11 mantissa bits) and are unique; a sorted list of the SEVEN
-// smallest keys is maintained with one v_min_u32 and six v_med3_u32 per candidate - no compares, no selects, no index
-// registers.  The four lists of a group are joined by two bitonic merges over DPP quad permutes.  At the end the seven winners
+// The search pass ranks its candidates as 32-bit keys: the float bits of d2 with the low position bits (CkGeom::kPosBits: 8 with
+// four lanes per query) replaced by the candidate's position in the group's candidate list - its chunk in the group's table and the
+// lane that measured it.  d2 >= 0, so the keys order like the distances (to 15 mantissa bits) and are unique; a sorted list of the
+// SEVEN smallest keys is maintained with one v_min_u32 and six v_med3_u32 per candidate - no compares, no selects, no index
+// registers.  The lists of a group's lanes are joined by bitonic merges over DPP quad permutes.  At the end the seven winners
 // are re-measured exactly and ranked exactly (distance, then position - the visiting order): the five nearest are the exact
 // answer unless the exact 5th distance reaches the truncated distance of the 7th key - every candidate that was dropped is at
-// least that far - in which case the query is flagged for the completion pass (5th, 6th and 7th distances equal to 11 bits:
-// ~1e-5 of the queries).
+// least that far - in which case the query is flagged for the completion pass (5th, 6th and 7th distances equal in their kept bits:
+// never observed on the bench streams).
 constexpr unsigned int kPkInf = 0xFFFFFFFFu;
-constexpr int kPkPosBits = 12;
-constexpr unsigned int kPkPosMask = (1u << kPkPosBits) - 1u;
 
 struct Pk7 {
   unsigned int k0, k1, k2, k3, k4, k5, k6;
@@ -701,50 +699,6 @@ __device__ __forceinline__ F3 load_xyz(const float4* __restrict__ pts, unsigned 
   return r;
 }
 
-// Scans positions [first, first + count) of the lane's candidate list - two cell ranges: map index = p + (p < split ? off_lo :
-// off_hi) - in batches of NB loads (positions behind the end re-read the last candidate and are discarded: a load behind a
-// branch would be waited for on its own), keys into L.
-template <int NB>
-__device__ __forceinline__ void pk_scan(const float4* __restrict__ pts, unsigned int split, unsigned int off_lo, unsigned int off_hi,
-                                        unsigned int first, unsigned int count, unsigned int posbase, float wx, float wy, float wz,
-                                        Pk7& L) {
-  const unsigned int end = first + count;
-  for (unsigned int base = first; base < end; base += NB) {
-    F3 P[NB];
-#pragma unroll
-    for (int u = 0; u < NB; u++) {
-      const unsigned int p = min(base + u, end - 1u);
-      P[u] = load_xyz(pts, p + (p < split ? off_lo : off_hi));
-    }
-#pragma unroll
-    for (int u = 0; u < NB; u++) {
-      const unsigned int p = base + u;
-      const float d = dist2_ref(wx, wy, wz, P[u].x, P[u].y, P[u].z);
-      const unsigned int key = (__float_as_uint(d) & ~kPkPosMask) | (posbase + p);
-      pk_insert(L, p < end ? key : kPkInf);  // (the acceptance test d2 <= max_d2 waits for the re-measurement of the winners)
-    }
-  }
-}
-
-// Geometry of the search kernel for LPQ lanes per query (4, 2 or 1): how the 12 position bits of a key split into lane and
-// place, how many cells / winners / round-2 passes a lane takes.
-template <int LPQ>
-struct PkGeom {
-  static constexpr int kLaneShift = LPQ == 4 ? 2 : (LPQ == 2 ? 1 : 0);
-  static constexpr int kPlaceBits = kPkPosBits - kLaneShift;
-  static constexpr unsigned int kPlaceMask = (1u << kPlaceBits) - 1u;
-  static constexpr unsigned int kLaneCap = 1u << kPlaceBits;    // candidates a lane can number
-  static constexpr int NP = 4 / LPQ;                            // pairs of cells (c, 7 - c) per lane in round 1
-  static constexpr int NR = 2 * NP;                             // ... = cell ranges per lane
-  static constexpr int NW = (7 + LPQ - 1) / LPQ;                // winners a lane re-measures
-  static constexpr int MAXPASS = (19 + 2 * LPQ - 1) / (2 * LPQ);  // round 2: two outer cells per lane and pass
-};
-template <int LPQ>
-__device__ __forceinline__ unsigned int group_or(unsigned int v) {
-  if (LPQ >= 2) v |= quad_perm<0xB1>(v);
-  if (LPQ == 4) v |= quad_perm<0x4E>(v);
-  return v;
-}
 template <int LPQ>
 __device__ __forceinline__ void pk_group_merge(Pk7& L) {
   if (LPQ >= 2) pk_merge<0xB1>(L);  // lanes 0<->1, 2<->3
@@ -780,285 +734,8 @@ __device__ __forceinline__ T pick_by_lane(const T (&arr)[N], int sub) {
   return v;
 }
 
-// `forced` > 0: always runs (a host-driven pass: the host has put the pose into `pose`, device memory).
-// forced < 0: device-driven loop — pose from `pose` (the control block), runs only when the control block says the next pass
-// searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).  An executed pass leaves its pose in
-// `search_pose_out` (may be null).
-// LPQ = lanes per query (4: the product form; 2 and 1 compile and are exact as well - fewer instructions in total, longer chains
-// per wavefront: slower, profiles/r03_knn_ab.md); NB = candidate loads a lane keeps in flight (one batch).
-template <int LPQ, int BS, int NB, int WPE>
-__global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuffers rb, const PoseArg* __restrict__ pose,
-                                               const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
-                                               double* __restrict__ search_pose_out) {
-  using G = PkGeom<LPQ>;
-  __shared__ uint2 s_rng[2 * G::MAXPASS * BS];
-  // Everything the head of the kernel needs from memory is requested AT ONCE, before anything is waited for: the loop flags, the
-  // size of the cloud, the pose (one batch of wide scalar loads: load_pose) and - an unsharded cloud: its index does not depend on
-  // any of them - the query point itself (index clamped; a lane beyond the cloud discards it).  Round 4 had the flags behind the
-  // size behind the pose (24 dependent scalar loads) and the point behind all of them: ~3 us of start-up in which every wavefront
-  // walked the same chain.
-  constexpr int QPB = BS / LPQ;
-  const int blk = xcd_remap(blockIdx.x, nb_real);
-  const int sub = threadIdx.x & (LPQ - 1);
-  const int ql = blk * QPB + (int)(threadIdx.x / LPQ);
-  const bool early = rb.shard_world <= 1;
-  float4 pb_early = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (early) pb_early = rb.body[min(max(ql, 0), rb.cap - 1)];
-  const HeadScalars hs = load_head_scalars(pose, &ctrl->search_next, rb.n_dev ? rb.n_dev : &ctrl->max_it);
-  const PoseArg& ps = hs.ps;
-  const int c_search = hs.search_next, c_stop = hs.stop, n_mem = hs.n_mem;
-  int lo, n_live;
-  shard_range_n(rb, n_mem, lo, n_live);
-  if (forced < 0 && (c_stop || !c_search)) return;
-  if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
-  if (blk >= nb_real) return;
-  // the grid is sized for an upper bound of the cloud (the voxel filter leaves the exact size on the device): wavefronts
-  // beyond the cloud leave at once
-  if (blk * QPB + (int)((threadIdx.x & ~63u) / LPQ) >= n_live) return;
-  const int qi = lo + ql;
-  const bool live = ql < n_live;
-  float wx = 0, wy = 0, wz = 0;
-  if (live && sub == 0) body_to_world(ps, early ? pb_early : rb.body[qi], wx, wy, wz);
-  wx = group_bcast_f<LPQ, 0>(wx); wy = group_bcast_f<LPQ, 0>(wy); wz = group_bcast_f<LPQ, 0>(wz);
-  const bool active = live && g.n_pts > 0;
-  const float INF = __builtin_inff();
-  const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
-  const float4* __restrict__ pts = g.pts;
-  const unsigned int posbase = (unsigned)sub << G::kPlaceBits;
-
-  // Round 1.  The lane's cells: pairs of opposite corners of the 2x2x2 block (c and 7 - c differ on every axis, so a surface that
-  // runs along the axes puts one occupied cell into every pair).  Idle lanes look their cells up as well (a lookup behind a
-  // branch is waited for on its own).  The lane numbers its candidates range by range: range k holds positions
-  // [end[k - 1], end[k]), map index = position + off[k].
-  float g0sq, guardsq;
-  unsigned int end[G::NR], off[G::NR];
-  {
-    const QueryCell q = query_cell(g, wx, wy, wz);
-    g0sq = q.g0 * q.g0;
-    guardsq = q.guard * q.guard;
-    uint2 r[G::NR];
-    int jx[G::NR], jy[G::NR], jz[G::NR];
-    bool want[G::NR];
-#pragma unroll
-    for (int t = 0; t < G::NR; t++) {
-      const int c0 = sub + LPQ * (t >> 1), c = (t & 1) ? 7 - c0 : c0;
-      jx[t] = q.cx + ((c & 1) ? q.ox : 0); jy[t] = q.cy + ((c & 2) ? q.oy : 0); jz[t] = q.cz + ((c & 4) ? q.oz : 0);
-      want[t] = true;
-    }
-    lookup_cells_batched<G::NR>(g, tab, jx, jy, jz, want, r);
-    unsigned int run = 0u;
-#pragma unroll
-    for (int t = 0; t < G::NR; t++) {
-      off[t] = r[t].x - run;
-      run += r[t].y - r[t].x;
-      end[t] = run;
-    }
-  }
-  const unsigned int n1 = end[G::NR - 1];
-  // a group with a lane that cannot number its candidates is left to the completion pass (cells of hundreds of points)
-  bool ovf = group_or<LPQ>((unsigned)(n1 > G::kLaneCap)) != 0u;
-  const bool fast = active && !ovf;
-
-  Pk7 L;
-  L.k0 = L.k1 = L.k2 = L.k3 = L.k4 = L.k5 = L.k6 = kPkInf;
-#pragma unroll
-  for (int i = 0; i < G::NP; i++) {
-    const unsigned int first = i ? end[2 * i - 1] : 0u;
-    pk_scan<NB>(pts, end[2 * i], off[2 * i], off[2 * i + 1], first, fast ? end[2 * i + 1] - first : 0u, posbase, wx, wy, wz, L);
-  }
-  pk_group_merge<LPQ>(L);
-
-  // Round 2 (the tree's calc_box_dist rule, ikd_Tree.cpp:1279-1289): is the 5th distance - here its upper bound, the 5th key
-  // with the position bits set - within the radius round 1 covers?  If not, the outer cells of the 3x3x3 block that can hold a
-  // closer point are dealt out to the lanes of the group, two per lane and pass (with four lanes: one pass for all but ~0.2 %
-  // of the queries); their candidates continue the lane's position count, and the ranges they come from are noted in LDS for
-  // the re-measurement below: s_rng[j][lane] = (end position, map index - position) of the lane's j-th range of round 2.
-  bool used2 = false;
-  {
-    const float ub5 = L.k4 != kPkInf ? __uint_as_float(L.k4 | kPkPosMask) : INF;
-    const float bound = fminf(ub5, g.max_d2);
-    const bool need2 = fast && !(bound <= g0sq);
-    if (__any(need2)) {
-      // Which of the 19 outer cells of the 3 x 3 x 3 block can still hold a closer point: per axis the squared gap to the slab on the
-      // NEAR side (round 1 looked there) and on the FAR side - the own slab's is 0 - and one sum per outer cell against the bound
-      // (every lane of the group computes the same mask).  Cells are numbered in these terms, s in {0 own, 1 near, 2 far} per
-      // axis, id = sx + 3 sy + 9 sz: the outer cells are the ids with a 2 in them whatever the query's octant, so the mask is
-      // nineteen add / compare / select triples without a branch (round 3 numbered the cells by their offsets and tested
-      // every one of the 27 for membership of round 1 first: the compiler made a chain of 27 predicated blocks of it).
-      const QueryCell q = query_cell(g, wx, wy, wz);
-      float GX[3], GY[3], GZ[3];
-      {
-        const float nx = axis_gap(wx, q.cx + q.ox, g.cs, q.eps), fx = axis_gap(wx, q.cx - q.ox, g.cs, q.eps);
-        const float ny = axis_gap(wy, q.cy + q.oy, g.cs, q.eps), fy = axis_gap(wy, q.cy - q.oy, g.cs, q.eps);
-        const float nz = axis_gap(wz, q.cz + q.oz, g.cs, q.eps), fz = axis_gap(wz, q.cz - q.oz, g.cs, q.eps);
-        GX[0] = 0.f; GX[1] = nx * nx; GX[2] = fx * fx;
-        GY[0] = 0.f; GY[1] = ny * ny; GY[2] = fy * fy;
-        GZ[0] = 0.f; GZ[1] = nz * nz; GZ[2] = fz * fz;
-      }
-      unsigned int m = 0u;
-      static_for<27>([&](auto cc) {
-        constexpr int c = decltype(cc)::value, sx = c % 3, sy = (c / 3) % 3, sz = c / 9;
-        if constexpr (sx == 2 || sy == 2 || sz == 2) {
-          const float d = GX[sx] + GY[sy] + GZ[sz];
-          m |= d > bound ? 0u : (1u << c);
-        }
-      });
-      m = need2 ? m : 0u;
-      used2 = m != 0u;
-#pragma unroll
-      for (int j = 0; j < 2 * G::MAXPASS; j++) s_rng[j * BS + threadIdx.x] = make_uint2(0u, 0u);
-      // the group's list continues on lane 0 alone (copies would come back as duplicates), the other lanes start empty
-      if (sub != 0) L.k0 = L.k1 = L.k2 = L.k3 = L.k4 = L.k5 = L.k6 = kPkInf;
-      unsigned int t = m, n_pos = n1;
-#pragma unroll
-      for (int j = 0; j < LPQ - 1; j++) t = j < sub ? (t & (t - 1u)) : t;  // the lane's first survivor: number `sub` of the set bits
-      for (int pass = 0; pass < G::MAXPASS; pass++) {
-        if (!__any(t != 0u)) break;
-        const int c1 = t ? __ffs((int)t) - 1 : -1;
-#pragma unroll
-        for (int j = 0; j < LPQ; j++) t = t & (t - 1u);
-        const int c2 = t ? __ffs((int)t) - 1 : -1;
-#pragma unroll
-        for (int j = 0; j < LPQ; j++) t = t & (t - 1u);
-        uint2 r[2];
-        {
-          int jx[2], jy[2], jz[2];
-          const bool want[2] = {true, true};
-          const int ca = c1 < 0 ? 0 : c1, cb = c2 < 0 ? 0 : c2;  // (0 = the query's own cell: looked up for nothing, not branched around)
-          // id -> cell: s = 0 own, 1 one step towards the near side, 2 one step away from it
-          auto step = [](int sdig, int o) { return o * ((sdig & 1) - (sdig >> 1)); };
-          jx[0] = q.cx + step(ca % 3, q.ox); jy[0] = q.cy + step((ca / 3) % 3, q.oy); jz[0] = q.cz + step(ca / 9, q.oz);
-          jx[1] = q.cx + step(cb % 3, q.ox); jy[1] = q.cy + step((cb / 3) % 3, q.oy); jz[1] = q.cz + step(cb / 9, q.oz);
-          lookup_cells_batched<2>(g, tab, jx, jy, jz, want, r);
-        }
-        const unsigned int nC = c1 < 0 ? 0u : r[0].y - r[0].x, nD = c2 < 0 ? 0u : r[1].y - r[1].x;
-        const unsigned int eC = n_pos + nC, eD = eC + nD;
-        const unsigned int Cm = r[0].x - n_pos, Dm = r[1].x - eC;
-        // out of positions: the group stops here and is left to the completion pass
-        const bool o2 = group_or<LPQ>((unsigned)(eD > G::kLaneCap)) != 0u;
-        if (o2) { ovf = true; t = 0u; }
-        const unsigned int cnt = o2 ? 0u : eD - n_pos;
-        s_rng[(2 * pass) * BS + threadIdx.x] = make_uint2(n_pos + (o2 ? 0u : nC), Cm);
-        s_rng[(2 * pass + 1) * BS + threadIdx.x] = make_uint2(n_pos + cnt, Dm);
-        pk_scan<NB>(pts, eC, Cm, Dm, n_pos, cnt, posbase, wx, wy, wz, L);
-        n_pos += cnt;
-      }
-      pk_group_merge<LPQ>(L);
-    }
-  }
-
-  // Exact re-measurement of the seven winners.  The lane that scanned a winner knows its map index; the index travels to the
-  // other lanes of the group (an OR over the group: the other lanes contribute 0).  Lane `sub` then loads and measures winners
-  // sub, sub + LPQ, ..., and the seven exact distances are shared by broadcasts inside the group.
-  float e[7];
-  F3 W[G::NW];  // this lane's winners
-  float d7t;    // the truncated distance of the 7th key: no dropped candidate is nearer (inf: nothing was dropped)
-  bool tie = false;  // two neighbouring keys agree in their distance bits: the exact order may differ from the key order
-  {
-    const unsigned int K[7] = {L.k0, L.k1, L.k2, L.k3, L.k4, L.k5, L.k6};
-    unsigned int widx[7];
-    const bool used2w = __any(used2);  // some winner of this wavefront may sit in a round-2 range: their table comes out of LDS
-    uint2 rg[2 * G::MAXPASS];
-#pragma unroll
-    for (int j = 0; j < 2 * G::MAXPASS; j++) rg[j] = make_uint2(0u, 0u);
-    if (used2w) {
-#pragma unroll
-      for (int j = 0; j < 2 * G::MAXPASS; j++) rg[j] = s_rng[j * BS + threadIdx.x];
-    }
-    unsigned int woff[7];  // map index - position of every winner, as the lane that scanned it sees it
-#pragma unroll
-    for (int w = 0; w < 7; w++) {
-      const unsigned int p = K[w] & G::kPlaceMask;
-      unsigned int o = off[G::NR - 1];
-#pragma unroll
-      for (int k = G::NR - 2; k >= 0; k--) o = p < end[k] ? off[k] : o;
-      woff[w] = o;
-    }
-    if (used2w) {
-#pragma unroll
-      for (int w = 0; w < 7; w++) {
-        const unsigned int p = K[w] & G::kPlaceMask;
-        unsigned int o2 = rg[2 * G::MAXPASS - 1].y;
-#pragma unroll
-        for (int j = 2 * G::MAXPASS - 2; j >= 0; j--) o2 = p < rg[j].x ? rg[j].y : o2;
-        woff[w] = p < n1 ? woff[w] : o2;
-      }
-    }
-#pragma unroll
-    for (int w = 0; w < 7; w++) {
-      const unsigned int pos = K[w] & kPkPosMask;
-      const bool mine = K[w] != kPkInf && (LPQ == 1 || (pos >> G::kPlaceBits) == (unsigned)sub);
-      widx[w] = group_or<LPQ>(mine ? (pos & G::kPlaceMask) + woff[w] : 0u);  // (an empty slot reads map slot 0 and is discarded)
-    }
-    float el[G::NW];
-    static_for<G::NW>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      W[i] = load_xyz(pts, pick_by_lane<LPQ, LPQ * i>(widx, sub));
-    });
-#pragma unroll
-    for (int w = 0; w < 6; w++) tie = tie || ((K[w] ^ K[w + 1]) <= kPkPosMask && K[w + 1] != kPkInf);
-    d7t = K[6] != kPkInf ? __uint_as_float(K[6] & ~kPkPosMask) : INF;
-#pragma unroll
-    for (int i = 0; i < G::NW; i++) el[i] = dist2_ref(wx, wy, wz, W[i].x, W[i].y, W[i].z);
-    e[0] = group_bcast_f<LPQ, 0 % LPQ>(el[0 / LPQ]); e[1] = group_bcast_f<LPQ, 1 % LPQ>(el[1 / LPQ]);
-    e[2] = group_bcast_f<LPQ, 2 % LPQ>(el[2 / LPQ]); e[3] = group_bcast_f<LPQ, 3 % LPQ>(el[3 / LPQ]);
-    e[4] = group_bcast_f<LPQ, 4 % LPQ>(el[4 / LPQ]); e[5] = group_bcast_f<LPQ, 5 % LPQ>(el[5 / LPQ]);
-    e[6] = group_bcast_f<LPQ, 6 % LPQ>(el[6 / LPQ]);
-#pragma unroll
-    for (int w = 0; w < 7; w++) e[w] = (K[w] != kPkInf && e[w] <= g.max_d2) ? e[w] : INF;  // acceptance: d2 <= max_d2 (quirk A5)
-  }
-  // Exact ranks of this lane's winners and the exact 5th distance.  The keys are in ascending order, so the exact order can
-  // differ from the key order only where the distance bits of neighbouring keys agree (a wavefront without such a pair skips
-  // the ranking), and there an equal exact distance keeps the key order (position = visiting order): for v < w, v stays ahead
-  // of w unless e[v] > e[w].  Empty slots (inf) keep their places at the end.
-  int rk[G::NW];
-#pragma unroll
-  for (int i = 0; i < G::NW; i++) rk[i] = sub + LPQ * i;
-  float d5 = e[4];  // (inf: fewer than five candidates)
-  if (__any(tie)) {
-    int rank[7];
-#pragma unroll
-    for (int w = 0; w < 7; w++) rank[w] = 0;
-#pragma unroll
-    for (int v = 0; v < 7; v++)
-#pragma unroll
-      for (int w = v + 1; w < 7; w++) {
-        const bool swapped = e[v] > e[w];
-        rank[w] += swapped ? 0 : 1;
-        rank[v] += swapped ? 1 : 0;
-      }
-    d5 = INF;
-#pragma unroll
-    for (int w = 0; w < 7; w++) d5 = rank[w] == 4 ? e[w] : d5;
-    static_for<G::NW>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      rk[i] = pick_by_lane<LPQ, LPQ * i>(rank, sub);
-    });
-  }
-  const int found = e[4] < INF ? 5 : (e[3] < INF ? 4 : (e[2] < INF ? 3 : (e[1] < INF ? 2 : (e[0] < INF ? 1 : 0))));
-  // the five nearest are exact unless a dropped candidate could tie with or beat the 5th; a query whose 3x3x3 block cannot prove
-  // its list complete (or that ran out of positions) is flagged: k_fit_reduce / k_knn_complete finishes it
-  const bool amb = d7t < INF && !(d5 < d7t);
-  const bool need = active && (ovf || amb || !(fminf(d5, g.max_d2) <= guardsq));
-  if (live) {
-    static_for<G::NW>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const float ei = pick_by_lane<LPQ, LPQ * i>(e, sub);
-      if (sub + LPQ * i < 7 && ei < INF && rk[i] < 5) rb.nbr[(size_t)rk[i] * rb.cap + qi] = make_float4(W[i].x, W[i].y, W[i].z, ei);
-    });
-    if (found < 5) {  // the missing neighbours read (0, 0, 0, inf)
-#pragma unroll
-      for (int r = 0; r < 5; r += LPQ)
-        if (sub + r < 5 && sub + r >= found) rb.nbr[(size_t)(sub + r) * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
-    }
-    // (kCovered: flagged for its reach alone - the list is exact over the 3 x 3 x 3 cells, the completion starts from it)
-    if (sub == (LPQ > 1 ? 1 : 0)) rb.nbr_count[qi] = found | (need ? (kNeedy | ((ovf || amb) ? 0 : kCovered)) : 0);
-    if (sub == (LPQ == 4 ? 2 : 0)) rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-  }
-}
-
 // ---- the search pass with the GROUP scanning every cell together ("chunked", round 5) ------------------------------------------
-// k_knn_pk gives every lane of a query its own cells: a candidate load of a wavefront then touches up to 64 different cache lines -
+// Rounds 3 - 4 (k_knn_pk) gave every lane of a query its own cells: a candidate load of a wavefront then touches up to 64 different cache lines -
 // measured 40 per instruction (TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD), 6.6 M (100 k-point scan) and 21 M (500 k) line lookups
 // per launch: at one lookup per cycle and compute unit 10.7 and 34.3 us of the vector-memory front end, in launches of 17 - 21 and
 // 52 - 64 us (profiles/r05_knn_l1.md).  Here the LPQ lanes of a query read LPQ CONSECUTIVE points of one cell - 64 contiguous bytes
@@ -1067,13 +744,13 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_pk(GridView g, RegistrationBuff
 // points in the chunk (1 .. LPQ; 0: padding behind the last chunk, so that a batch of NB loads needs no bounds test) - in the order
 // the cells were looked up: round 1's eight cells, then the outer cells round 2 adds.  A candidate is numbered (chunk << log2 LPQ) |
 // lane: the position in its key.  Whatever needs a candidate's map index afterwards - the winners' re-measurement - reads it from
-// the table; the per-lane range arithmetic of k_knn_pk (which range does position p belong to?) is gone.
+// the table; the per-lane range arithmetic of rounds 3 - 4 (which range does position p belong to?) is gone.
 template <int LPQ>
 struct CkGeom {
   static constexpr int kLaneShift = LPQ == 4 ? 2 : (LPQ == 2 ? 1 : 0);
   static constexpr int kChunkBits = 6;
   static constexpr int MAXCH = 1 << kChunkBits;                 // chunks a group can number: 64 x LPQ candidates
-  static constexpr int kPosBits = kChunkBits + kLaneShift;      // 8 of the 23 mantissa bits with four lanes (k_knn_pk: 12)
+  static constexpr int kPosBits = kChunkBits + kLaneShift;      // 8 of the 23 mantissa bits with four lanes (rounds 3 - 4: 12)
   static constexpr unsigned int kPosMask = (1u << kPosBits) - 1u;
   static constexpr int NR = 8 / LPQ;                            // cells per lane in round 1
   static constexpr int NW = (7 + LPQ - 1) / LPQ;                // winners a lane re-measures
@@ -1124,6 +801,12 @@ __device__ __forceinline__ void ck_scan(const float4* __restrict__ pts, const un
     }
   }
 }
+// `forced` > 0: always runs (a host-driven pass: the host has put the pose into `pose`, device memory).
+// forced < 0: device-driven loop — pose from `pose` (the control block), runs only when the control block says the next pass
+// searches and the loop has not stopped (src/laserMapping.cpp:978, :1102-1106).  An executed pass leaves its pose in
+// `search_pose_out` (may be null).
+// LPQ = lanes per query (4; 2 lanes issue fewer instructions in total but lose to latency and to the vector-memory front end at every
+// size measured: profiles/r05_knn_lpq.md); NB = candidate loads a lane keeps in flight (one batch).
 template <int LPQ, int BS, int NB, int WPE>
 __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuffers rb, const PoseArg* __restrict__ pose,
                                                const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
@@ -1131,7 +814,10 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuff
   using G = CkGeom<LPQ>;
   constexpr int QPB = BS / LPQ;
   __shared__ unsigned int s_tab[QPB * (G::MAXCH + NB)];
-  // (the head: as k_knn_pk - everything it needs from memory is requested at once)
+  // Everything the head of the kernel needs from memory is requested AT ONCE, before anything is waited for: the query point itself
+  // (an unsharded cloud: its index depends on nothing that has to be loaded; index clamped, a lane beyond the cloud discards it) and -
+  // load_head_scalars - the pose, the loop flags and the size of the cloud.  Round 4 had the flags behind the size behind the pose
+  // (24 dependent scalar loads) and the point behind all of them.
   const int blk = xcd_remap(blockIdx.x, nb_real);
   const int sub = threadIdx.x & (LPQ - 1);
   const int ql = blk * QPB + (int)(threadIdx.x / LPQ);
@@ -1200,7 +886,8 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuff
   ck_scan<LPQ, NB>(pts, tab, 0u, n_chunks, sub, wx, wy, wz, L);
   pk_group_merge<LPQ>(L);
 
-  // Round 2 (the tree's calc_box_dist rule, ikd_Tree.cpp:1279-1289), as in k_knn_pk: the outer cells of the 3x3x3 block that can
+  // Round 2 (the tree's calc_box_dist rule, ikd_Tree.cpp:1279-1289): is the 5th distance - here its upper bound, the 5th key with the
+  // position bits set - within the radius round 1 covers?  If not, the outer cells of the 3x3x3 block that can
   // still hold a closer point, two per lane and pass; their chunks continue the table.
   {
     const float ub5 = L.k4 != kPkInf ? __uint_as_float(L.k4 | G::kPosMask) : INF;
@@ -1302,7 +989,9 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuff
 #pragma unroll
     for (int w = 0; w < 7; w++) e[w] = (K[w] != kPkInf && e[w] <= g.max_d2) ? e[w] : INF;  // acceptance: d2 <= max_d2 (quirk A5)
   }
-  // exact ranks (only where two neighbouring keys agree in their distance bits), as in k_knn_pk
+  // Exact ranks of this lane's winners and the exact 5th distance.  The keys are in ascending order, so the exact order can differ
+  // from the key order only where the distance bits of neighbouring keys agree (a wavefront without such a pair skips the ranking),
+  // and there an equal exact distance keeps the key order (position = visiting order).
   int rk[G::NW];
 #pragma unroll
   for (int i = 0; i < G::NW; i++) rk[i] = sub + LPQ * i;
@@ -1348,7 +1037,7 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuff
 
 #ifdef LII_KNN_EXACT
 // The search pass on exact (distance, index) lists throughout (round 2's form in round 1 too).  Kept as the reference form of
-// k_knn_pk: same cells, same candidates; LII_KNN_VARIANT=5 selects it.
+// k_knn_ck: same cells, same candidates; LII_KNN_VARIANT=5 selects it (test builds).
 template <int BS>
 __global__ __launch_bounds__(BS) void k_knn_exact(GridView g, RegistrationBuffers rb, const PoseArg* __restrict__ pose,
                                                   const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
@@ -1598,7 +1287,7 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
 
 // Plane fit + residual + Jacobian + block reduction, one lane per point.  FIT = right after a search pass (finishes
 // the flagged searches of this workgroup's points, reads the 5 neighbours, caches the plane); !FIT for the
-// non-search iterations.  `forced` as in k_knn_pk.
+// non-search iterations.  `forced` as in k_knn_ck.
 // Completion of the flagged searches among the kBlock points of one workgroup (`my_point`: the calling lane's): one wavefront per
 // flagged query, four at a time (they are rare, ~0.07 % of the queries, but clustered at the map frontier).  Every lane of
 // the workgroup must call it; on return the completed lists are visible to the whole workgroup.
@@ -1685,7 +1374,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   // index does not depend on them; the index is clamped, a lane beyond the cloud discards what it read): one dependent round
   // trip instead of two at the head of every fit launch.
   // (the flags, the size of the cloud and the pose - scalar requests - go out first, the point's data right behind them; all of it is
-  // waited for once: k_knn_pk)
+  // waited for once: k_knn_ck)
   const int q_early = fit_point_of(xcd_remap(blockIdx.x, nb_real), nb_real);
   const bool early = rb.shard_world <= 1;
   const int ie = min(max(q_early, 0), rb.cap - 1);
@@ -1926,50 +1615,23 @@ int register_blocks(int n) { return nblk(n, kBlock); }
 static inline int shard_bound(const RegistrationBuffers& rb) {
   return rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;
 }
-template <int LPQ, int BS, int NB, int WPE>
-static void launch_knn_pk_t(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
-                            const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
-  int nq = nblk(shard_bound(rb), BS / LPQ);
+// variant (LII_KNN_VARIANT): 0 = k_knn_ck, four lanes per query (the product form); 5 = k_knn_exact (builds with -DLII_KNN_EXACT).
+// 128 lanes per workgroup, 6 loads in flight per lane, 7 wavefronts per SIMD (69 VGPRs): measured on the per-lane form of rounds 3 - 4
+// against 64 / 256 lanes, 4 .. 12 loads, 6 / 8 wavefronts per SIMD (within 1 - 2 %: profiles/r03_knn_ab.md), and 2 / 1 lanes per query
+// (slower at every cloud size: profiles/r05_knn_lpq.md).
+void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
+                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
+  int nq = nblk(shard_bound(rb), 128 / 4);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_knn_pk<LPQ, BS, NB, WPE>), dim3(nq_pad), dim3(BS), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out);
-}
-// Lanes per query of the search pass for a cloud of (at most) `n_queries` points.  Four lanes per query issue ~20 % more
-// instructions in total than two (the per-query work - pose transform, cell arithmetic, merges, re-measurement - is replicated on
-// every lane of a group), but give twice the wavefronts to hide the dependent chain point -> block probe -> cell entry ->
-// candidates behind: at 95 k queries two lanes leave 2.9 wavefronts per SIMD and lose to latency (profiles/r03_knn_ab.md), at
-// >= kKnnTwoLaneQueries the chip is full either way and the instruction total decides (profiles/r05_knn_lpq.md).
-// variant (LII_KNN_VARIANT): 0 = by size; 4 / 2 / 1 = that many lanes whatever the size; 5 = k_knn_exact (test builds only).
-constexpr int kKnnTwoLaneQueries = 250000;
-int knn_lanes_for(int variant, int n_queries) {
-  if (variant == 1 || variant == 2 || variant == 4) return variant;
-  return n_queries >= kKnnTwoLaneQueries ? 2 : 4;
-}
-void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
-                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s, int n_queries_hint) {
 #ifdef LII_KNN_EXACT
   if (variant == 5) {
-    int nq = nblk(shard_bound(rb), 128 / 4);
-    if (nq < 1) nq = 1;
-    const int nq_pad = ((nq + 7) / 8) * 8;
     hipLaunchKernelGGL((k_knn_exact<128>), dim3(nq_pad), dim3(128), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out);
     return;
   }
 #endif
-  // 128 lanes, 6 loads in flight per lane, 7 wavefronts per SIMD (69 VGPRs): measured against 64 / 256 lanes, 4 / 8 / 10 / 12
-  // loads, 6 / 8 wavefronts per SIMD (within 1 % on stream100k, 2 % behind on the larger scans; profiles/r03_knn_ab.md)
-  const int bound = shard_bound(rb);
-  const int lanes = knn_lanes_for(variant, n_queries_hint > 0 && n_queries_hint < bound ? n_queries_hint : bound);
-  if (variant == 3) {  // (A/B: the group scanning every cell together)
-    int nq = nblk(bound, 128 / 4);
-    if (nq < 1) nq = 1;
-    const int nq_pad = ((nq + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_knn_ck<4, 128, 6, 7>), dim3(nq_pad), dim3(128), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out);
-    return;
-  }
-  if (lanes == 2) launch_knn_pk_t<2, 128, 6, 7>(g, rb, pose, ctrl, forced, search_pose_out, s);
-  else if (lanes == 1) launch_knn_pk_t<1, 128, 6, 4>(g, rb, pose, ctrl, forced, search_pose_out, s);
-  else launch_knn_pk_t<4, 128, 6, 7>(g, rb, pose, ctrl, forced, search_pose_out, s);
+  (void)variant;
+  hipLaunchKernelGGL((k_knn_ck<4, 128, 6, 7>), dim3(nq_pad), dim3(128), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out);
 }
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);

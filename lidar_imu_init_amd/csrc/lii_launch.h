@@ -27,12 +27,9 @@ void launch_table_clear(BlockEntry* blocks, unsigned int cap, hipStream_t s);
 void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks, int n, BlockEntry* blocks,
                        unsigned int block_mask, uint2* cells, hipStream_t s);
 // registration
-// n_queries_hint > 0: the size of the cloud as far as the host knows it (the launch bound may be the raw scan's size while the
-// down-sampled cloud's exact size is still on the device): picks the lanes per query (knn_lanes_for)
 // (`pose`: device memory on every path - a host-driven pass uploads it first)
 void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
-                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s, int n_queries_hint = 0);
-int knn_lanes_for(int variant, int n_queries);
+                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s);
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s);
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s);
