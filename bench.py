@@ -599,7 +599,7 @@ def main():
             alg = {"deskew": 32.0 * n_in, "voxel": 16.0 * n_in + 16.0 * n_d, "knn": 96.0 * n_d + 16.0 * M, "fit_search": 128.0 * n_d + 728.0,
                    "fit": 48.0 * n_d + 728.0, "solve": 728.0 * nb_fit + 5632.0}
             names = {"deskew": "k_deskew_imu (adoption + IMU back-propagation + voxel-hash insert)", "voxel": "k_vhash_emit (voxel centroids)",
-                     "knn": "k_knn_pk", "fit_search": "k_fit_reduce behind a k-NN pass (completion + plane fit + row + sums)",
+                     "knn": "k_knn_ck", "fit_search": "k_fit_reduce behind a k-NN pass (completion + plane fit + row + sums)",
                      "fit": "k_fit_reduce on cached planes", "solve": "k_reduce_solve (final sum + 24-state solve)"}
             tot_ms = sum(v[0] for v in kp.values()) or 1.0
             rows = []

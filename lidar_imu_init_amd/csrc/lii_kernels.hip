@@ -1363,6 +1363,11 @@ __global__ __launch_bounds__(kBlock) void k_knn_complete(GridView g, Registratio
   complete_flagged(g, rb, lo + q, live, count, w, sh);
 }
 
+// POSE_V: the pose lives in vector registers (204 VGPRs: two wavefronts per SIMD - no matter while the launch has no more than two per
+// SIMD to offer, i.e. up to ~130 k points) instead of scalar ones (160 VGPRs: three per SIMD, but 56 of the pose's scalar registers
+// are spilled into vector-register lanes and fetched back one v_readlane at a time).  Measured: 100 k-point scan 5.9 against 6.5 us
+// per cached-plane launch, 500 k-point scan 18.4 against 17.6 (profiles/r05_head_loads.md): launch_fit_reduce picks by size.
+template <bool POSE_V>
 __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationBuffers rb,
                                                         const PoseArg* __restrict__ pose,
                                                         const IekfCtrl* __restrict__ ctrl, int forced, int imu_en,
@@ -1392,7 +1397,8 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   }
   const HeadScalars hs = load_head_scalars(pose, &ctrl->search_next, rb.n_dev ? rb.n_dev : &ctrl->max_it);
   asm volatile("" : "+v"(e_sel));  // (the selection flag is not looked at before this point: the compiler tests it where it is loaded, and the wait for it would stand in front of the scalar requests)
-  const PoseArg ps = pose_to_vgprs(hs.ps);
+  PoseArg ps = hs.ps;
+  if (POSE_V) ps = pose_to_vgprs(hs.ps);
   const int c_search = hs.search_next, c_stop = hs.stop, n_mem = hs.n_mem;
   int lo, n_live;
   shard_range_n(rb, n_mem, lo, n_live);
@@ -1643,7 +1649,9 @@ void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const P
   int nb = nblk(shard_bound(rb), kBlock);
   if (nb < 1) nb = 1;
   const int nb_pad = ((nb + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_fit_reduce, dim3(nb_pad), dim3(kBlock), 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb);
+  // (four wavefronts per workgroup on 1024 SIMDs: up to 512 workgroups are two wavefronts per SIMD at most)
+  if (nb <= 512) hipLaunchKernelGGL(k_fit_reduce<true>, dim3(nb_pad), dim3(kBlock), 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb);
+  else hipLaunchKernelGGL(k_fit_reduce<false>, dim3(nb_pad), dim3(kBlock), 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb);
 }
 void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);

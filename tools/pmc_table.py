@@ -9,7 +9,7 @@ import sys
 
 d, w = sys.argv[1], sys.argv[2]
 out = {}
-for kern in ("k_knn_pk", "k_fit_reduce"):
+for kern in ("k_knn_ck", "k_fit_reduce"):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for f in glob.glob(f"{d}/{w}_p*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
