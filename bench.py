@@ -732,7 +732,7 @@ def cpu_baseline(wl, states0, tables, no_downsample, gpu_results, gpu_lists=None
                 nb, cnt = gpu_lists
                 same = (cnt == ref_cnt) & ((ref_cnt < 5) | np.all(nb.reshape(len(q), -1) == ref_pts.reshape(len(q), -1), axis=1))
                 knn_parity = {"identical": int(same.sum()), "of": int(len(q)),
-                              "what": "5-NN lists of every down-sampled point of the first scan at its start state: GPU (k_knn_pk + "
+                              "what": "5-NN lists of every down-sampled point of the first scan at its start state: GPU (k_knn_ck + "
                                       "completion) vs the UNMODIFIED reference ikd-Tree (oracle/_ref) on the same 1 M-point map"}
             t0 = time.perf_counter(); tree.knn(q, threads=3); t_port = time.perf_counter() - t0
             extra = (f"; k-NN stage alone on {len(q)} queries, 3 threads: unmodified reference ikd-Tree {t_ref * 1e3:.0f} ms, "

@@ -462,7 +462,7 @@ static int sync(lii_replay* r, bool* ready) {
     lii_ingest_opts io = r->ing;
     io.struct_size = sizeof(io);
     io.stamp_s = m.stamp;
-    io.cut_frame_num = r->cut_frame_num;
+    io.cut_frame_num = r->prm.cut_frame ? r->cut_frame_num : 0;  // (cut_frame: false -> Preprocess::process, laserMapping.cpp:337-342, :374-379)
     io.scan_count = m.scan_count;
     r->frames.assign(64, lii_frame_info{});
     int32_t nf = 0;
@@ -518,7 +518,7 @@ static int process(lii_replay* r) {
   job.leaf = r->leaf;
   job.opts = r->opts;
   job.opts.imu_en = r->imu_en ? 1 : 0;
-  job.scan_sorted = 1;  // lii_ingest_* hands the frames over in ascending time order, as process_cut_frame_* does
+  job.scan_sorted = r->prm.cut_frame ? 1 : 0;  // lii_ingest_* hands cut frames over in ascending time order, as process_cut_frame_* does; a whole message keeps the driver's order
   bool select = true;
   // ---- p_imu->Process(Measures, state, feats_undistort), src/IMU_Processing.hpp:419-462
   if (r->imu_en) {

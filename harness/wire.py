@@ -28,6 +28,8 @@ DTYPES = {
     ROBOSENSE: np.dtype({"names": ["x", "y", "z", "intensity", "ring", "timestamp"],
                          "formats": ["<f4", "<f4", "<f4", "u1", "<u2", "<f8"], "offsets": [0, 4, 8, 12, 14, 16], "itemsize": 24}),
 }
+# Intel RealSense L515 through realsense-ros: pcl::PointXYZRGB (x y z f32, packed rgb at 16); the reference reads x, y, z only
+DTYPES[L515] = np.dtype({"names": ["x", "y", "z", "rgb"], "formats": ["<f4", "<f4", "<f4", "<u4"], "offsets": [0, 4, 8, 16], "itemsize": 32})
 LIVOX_DTYPE = np.dtype({"names": ["offset_time", "x", "y", "z", "reflectivity", "tag", "line"],
                         "formats": ["<u4", "<f4", "<f4", "<f4", "u1", "u1", "u1"], "offsets": [0, 4, 8, 12, 16, 17, 18],
                         "itemsize": 20})
@@ -35,6 +37,8 @@ LIVOX_DTYPE = np.dtype({"names": ["offset_time", "x", "y", "z", "reflectivity", 
 
 def pc2_fields(lidar_type):
     d = DTYPES[lidar_type]
+    if lidar_type == L515:  # no intensity / time / ring in the record: offsets of fields the handler never reads
+        return (d.itemsize, 0, 4, 8, 0, 0, 0)
     tname = {VELO: "time", OUSTER: "t", PANDAR: "timestamp", ROBOSENSE: "timestamp"}[lidar_type]
     off = {n: d.fields[n][1] for n in d.names}
     return (d.itemsize, off["x"], off["y"], off["z"], off["intensity"], off[tname], off["ring"])
@@ -71,6 +75,9 @@ def pack_pcl2(lidar_type, xyz, ring, t_ms, stamp_s, with_time=True, seed=3):
     a = np.zeros(n, DTYPES[lidar_type])
     rng = np.random.default_rng(seed)
     a["x"], a["y"], a["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    if lidar_type == L515:
+        a["rgb"] = rng.integers(0, 1 << 24, n)
+        return a.tobytes()
     a["ring"] = ring
     if lidar_type == ROBOSENSE:
         a["intensity"] = rng.integers(0, 255, n)

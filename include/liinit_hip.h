@@ -173,6 +173,13 @@ int lii_scan_download(lii_handle h, int32_t which, float* out_float4, int32_t ca
 /* ---------------------------------------------------------------- ingest: driver message -> device-resident scan frames
  * lii_ingest_pcl2  <- Preprocess::process_cut_frame_pcl2  (src/preprocess.cpp:115-335; callers laserMapping.cpp:363-372)
  * lii_ingest_livox <- Preprocess::process_cut_frame_livox (src/preprocess.cpp:50-113;  callers laserMapping.cpp:326-336)
+ * ... and, with lii_ingest_opts::cut_frame_num = 0, the callbacks' branch for `initialization/cut_frame: false`
+ *                     (laserMapping.cpp:337-342, :374-379): Preprocess::process - oust_handler / velodyne_handler / l515_handler
+ *                     (PointCloud2; any other lidar_type is "Error LiDAR Type" there, LII_ERR_INVALID here) and avia_handler
+ *                     (CustomMsg) with feature extraction disabled, src/preprocess.cpp:337-713: the handler's filters (they are not
+ *                     the cutting functions' in every detail: velodyne_handler has no ring test), no time sort, no cut - ONE frame
+ *                     holding pl_surf in input order, its first point included, begin_time_s = header.stamp; hand such a frame to
+ *                     lii_scan_register with scan_sorted = 0.  An empty cloud yields no frame (the node skips it, laserMapping.cpp:909-914).
  * `data` is sensor_msgs/PointCloud2::data (or the CustomPoint array) as received; the field offsets are what
  * pcl::fromROSMsg derives from msg->fields for the point structs of src/preprocess.h:35-116 (types per lidar_type:
  * VELO time f32 [s] / ring u16; OUSTER t u32 [ns] / ring u8; PANDAR timestamp f64 / ring u16; ROBOSENSE timestamp f64 /
@@ -199,7 +206,7 @@ typedef struct lii_ingest_opts {
   int32_t point_filter_num; /* point_filter_num */
   double blind;             /* preprocess/blind [m] */
   double stamp_s;           /* msg->header.stamp.toSec() */
-  int32_t cut_frame_num;    /* required_frame_num (initialization/cut_frame_num), <= 64 */
+  int32_t cut_frame_num;    /* required_frame_num (initialization/cut_frame_num), <= 64; 0: do not cut (initialization/cut_frame: false) */
   int32_t scan_count;       /* the caller's scan_count: the first 20 (PointCloud2) / 5 (Livox) messages are not cut */
 } lii_ingest_opts;
 typedef struct lii_frame_info {

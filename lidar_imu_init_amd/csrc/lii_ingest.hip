@@ -2,6 +2,9 @@
 // sub-frame cutting, straight into device-resident scan frames (gfx950).  Replaces
 //   Preprocess::process_cut_frame_livox   reference src/preprocess.cpp:50-113
 //   Preprocess::process_cut_frame_pcl2    reference src/preprocess.cpp:115-335
+//   Preprocess::process (oust_handler / velodyne_handler / l515_handler / avia_handler, feature extraction disabled)
+//                                         reference src/preprocess.cpp:337-713 - lii_ingest_opts::cut_frame_num == 0: the callbacks'
+//                                         branch for initialization/cut_frame: false (no time sort, no cut, input order)
 // for the point layouts of src/preprocess.h:35-116.  HBM-bound byte work: one pass over the raw records, one scan, one
 // stable radix sort of the kept points by time, one pass that writes the frames.  One host synchronisation per message
 // (the frame table lands in mapped host memory).
@@ -70,6 +73,7 @@ struct Pc2Arg {
   lii_pc2_fields f;
   int lidar_type, n_scans, pfn;
   double blind2, stamp_s;
+  int whole;  // Preprocess::process instead of process_cut_frame_pcl2 (the handlers differ in which filters they apply)
 };
 
 // given_offset_time (src/preprocess.cpp:132-139, :246-253): the LAST point carries a positive time
@@ -99,17 +103,23 @@ __global__ void k_pc2_decode(const uint8_t* __restrict__ raw, int n, Pc2Arg a, f
     const double ts0 = rd<double>(raw + a.f.time);
     t = (float)((rd<double>(p + a.f.time) - ts0) * 1000);
     ring = rd<uint16_t>(p + a.f.ring);
+  } else if (a.lidar_type == LII_LIDAR_L515) {  // l515_handler (:444-470): x, y, z only; curvature 0
+    t = 0.f;
+    ring = 0;
   } else {
     t = (float)((rd<double>(p + a.f.time) - a.stamp_s + 0.1) * 1000.0);
     ring = rd<uint16_t>(p + a.f.ring);
   }
   const float d = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));  // float arithmetic, then widened
-  const bool ok = !((double)d < a.blind2 || isnan(x) || isnan(y) || isnan(z));
+  // (l515_handler tests the range alone: a NaN range is not below the blind radius, such a point passes)
+  const bool ok = a.lidar_type == LII_LIDAR_L515 ? !((double)d < a.blind2) : !((double)d < a.blind2 || isnan(x) || isnan(y) || isnan(z));
   pts[i] = make_float4(x, y, z, t);
   ring_out[i] = (uint8_t)min(ring, 255);
   yaw[i] = atan2((double)y, (double)x) * 57.2957;
   pass0[i] = ok ? 1u : 0u;
-  keep[i] = (ok && (i % a.pfn == 0) && ring < a.n_scans) ? 1u : 0u;
+  // (velodyne_handler's feature-less branch, :661-700, has no `ring < N_SCANS` test; oust_handler's, :545-563, has)
+  const bool ring_ok = (a.whole && a.lidar_type != LII_LIDAR_OUSTER) || ring < a.n_scans;
+  keep[i] = (ok && (i % a.pfn == 0) && ring_ok) ? 1u : 0u;
 }
 
 // Time synthesis from the azimuth when the driver gives none (:163-185, :272-294): a sequential recurrence per ring —
@@ -258,6 +268,29 @@ __global__ void k_cut_apply(const float4* __restrict__ pts, const unsigned int* 
   frames[s - 1] = p;
 }
 
+// Preprocess::process: the kept points in input order are THE cloud - one frame, stamped with the message's own time (the caller
+// pushes header.stamp, laserMapping.cpp:340,377), the first kept point included, curvatures as decoded.
+__global__ void k_whole_apply(const float4* __restrict__ pts, const unsigned int* __restrict__ idx, const unsigned int* __restrict__ rank, int n,
+                              double stamp_ms, float4* __restrict__ frames, IngestTable* __restrict__ dev, IngestTable* __restrict__ host) {
+  const unsigned int kept = n > 0 ? rank[n - 1] : 0u;
+  const unsigned int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < kept) frames[r] = pts[idx[r]];
+  if (r == 0) {
+    IngestTable t;
+    t.n_kept = (int)kept;
+    t.n_frames = kept > 0u ? 1 : 0;  // (an empty cloud is skipped by the node: laserMapping.cpp:909-914)
+    t.n_emitted = (int)kept;
+    t.pad = 0;
+    t.first[0] = 1;
+    t.last[0] = (int)kept;
+    t.begin_ms[0] = stamp_ms;
+    t.delta[0] = 0.0;
+    t.tail_ms[0] = kept > 0u ? (double)pts[idx[kept - 1u]].w : 0.0;  // points.back().curvature (sync_packages, laserMapping.cpp:452-456)
+    *dev = t;
+    *host = t;
+  }
+}
+
 template <class T>
 hipError_t dm(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (n ? n : 1)); }
 
@@ -326,13 +359,17 @@ int ingest_finish(lii_handle h, IngestCtx* c, int n, const lii_ingest_opts* o, i
   const int nb = (n + 255) / 256;
   inclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_flag, c->d_rank, n, s);
   hipLaunchKernelGGL(k_ingest_compact, dim3(nb), dim3(256), 0, s, c->d_pts, c->d_flag, c->d_rank, n, c->d_key_a, c->d_idx_a);
-  sort_pairs_u32(c->d_temp, c->temp_bytes, c->d_key_a, c->d_key_b, c->d_idx_a, c->d_idx_b, n, s);
-  int required = o->cut_frame_num;
-  if (o->scan_count < uncut_below) required = 1;
   IngestTable* d_table = reinterpret_cast<IngestTable*>(c->d_aux);  // d_aux is free again after the Livox scan
-  hipLaunchKernelGGL(k_cut_plan, dim3(1), dim3(64), 0, s, c->d_pts, c->d_idx_b, c->d_rank, n, o->stamp_s * 1000, required, d_table,
-                     c->h_table);
-  hipLaunchKernelGGL(k_cut_apply, dim3(nb), dim3(256), 0, s, c->d_pts, c->d_idx_b, d_table, n, c->d_frames);
+  if (o->cut_frame_num == 0) {  // Preprocess::process: no sort, no cut
+    hipLaunchKernelGGL(k_whole_apply, dim3(nb), dim3(256), 0, s, c->d_pts, c->d_idx_a, c->d_rank, n, o->stamp_s * 1000, c->d_frames, d_table, c->h_table);
+  } else {
+    sort_pairs_u32(c->d_temp, c->temp_bytes, c->d_key_a, c->d_key_b, c->d_idx_a, c->d_idx_b, n, s);
+    int required = o->cut_frame_num;
+    if (o->scan_count < uncut_below) required = 1;
+    hipLaunchKernelGGL(k_cut_plan, dim3(1), dim3(64), 0, s, c->d_pts, c->d_idx_b, c->d_rank, n, o->stamp_s * 1000, required, d_table,
+                       c->h_table);
+    hipLaunchKernelGGL(k_cut_apply, dim3(nb), dim3(256), 0, s, c->d_pts, c->d_idx_b, d_table, n, c->d_frames);
+  }
   ICHK(h, hipGetLastError());
   ICHK(h, hipStreamSynchronize(s));
   c->table = *c->h_table;
@@ -361,10 +398,13 @@ extern "C" {
 int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_pc2_fields* f, const lii_ingest_opts* o,
                     lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
   if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || !frames || !n_frames || n_points < 0 || (!data && n_points > 0) ||
-      f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 1 || o->cut_frame_num > kMaxFrames)
+      f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 0 || o->cut_frame_num > kMaxFrames)
     return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: bad arguments");
-  if (o->lidar_type != LII_LIDAR_VELO && o->lidar_type != LII_LIDAR_OUSTER && o->lidar_type != LII_LIDAR_PANDAR &&
-      o->lidar_type != LII_LIDAR_ROBOSENSE)
+  if (o->cut_frame_num == 0) {  // Preprocess::process knows Ouster, Velodyne and L515 (src/preprocess.cpp:337-354)
+    if (o->lidar_type != LII_LIDAR_VELO && o->lidar_type != LII_LIDAR_OUSTER && o->lidar_type != LII_LIDAR_L515)
+      return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: Error LiDAR Type (src/preprocess.cpp:350-352: the non-cutting Preprocess::process handles Ouster, Velodyne and L515)");
+  } else if (o->lidar_type != LII_LIDAR_VELO && o->lidar_type != LII_LIDAR_OUSTER && o->lidar_type != LII_LIDAR_PANDAR &&
+             o->lidar_type != LII_LIDAR_ROBOSENSE)
     return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: Wrong LiDAR Type (src/preprocess.cpp:290-292)");
   *n_frames = 0;
   IngestCtx* c = ctx_of(h);
@@ -382,6 +422,7 @@ int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_
   a.pfn = o->point_filter_num;
   a.blind2 = o->blind * o->blind;
   a.stamp_s = o->stamp_s;
+  a.whole = o->cut_frame_num == 0 ? 1 : 0;
   const int nb = (n_points + 255) / 256;
   hipLaunchKernelGGL(k_pc2_decode, dim3(nb), dim3(256), 0, s, c->d_raw, n_points, a, c->d_pts, c->d_yaw, c->d_ring, c->d_aux, c->d_flag);
   if (o->lidar_type == LII_LIDAR_VELO || o->lidar_type == LII_LIDAR_ROBOSENSE) {
@@ -395,7 +436,7 @@ int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_
 int lii_ingest_livox(lii_handle h, const void* points, int32_t n_points, const lii_livox_fields* f, const lii_ingest_opts* o,
                      lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
   if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || !frames || !n_frames || n_points < 0 || (!points && n_points > 0) ||
-      f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 1 || o->cut_frame_num > kMaxFrames)
+      f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 0 || o->cut_frame_num > kMaxFrames)
     return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_livox: bad arguments");
   *n_frames = 0;
   IngestCtx* c = ctx_of(h);

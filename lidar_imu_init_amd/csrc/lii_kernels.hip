@@ -1132,11 +1132,85 @@ __device__ __forceinline__ void far_candidates(const GridView& g, const uint2 (&
     }
   }
 }
+// The far pass gathers its candidates through a LIST (round 5).  Round 4 had every lane scan the cells of its own columns one
+// after the other - one dependent round trip per non-empty cell and four candidates: a query that looks past the edge of the map
+// (a 2.2 m ball: 11 x 11 x 11 cells, a hundred of them occupied, most lanes holding none and a few holding several) cost its
+// workgroup 18 us of candidate loads.  Now the lanes only LIST what they find - every surviving cell range cut into chunks of up to
+// four points, word = first map index << 3 | points, appended to a per-wavefront list in LDS behind a prefix sum over the lanes - and
+// the wavefront scans the list together, two chunks (eight loads in flight) per lane and round: a hundred occupied cells are 225
+// chunks, two rounds.
+constexpr int kFarCap = 2048;  // chunks the list holds (it lives in the LDS the launch's final reduction uses later: ReduceShared::row)
+__device__ __forceinline__ unsigned int wave_excl_prefix_u32(unsigned int v, unsigned int* total) {
+  const int lane = threadIdx.x & 63;
+  unsigned int x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned int y = (unsigned int)__shfl_up((int)x, off);
+    x += lane >= off ? y : 0u;
+  }
+  *total = (unsigned int)__shfl((int)x, 63);
+  return x - v;
+}
+// the chunks of NB cell ranges to list[at ...]
+template <int NB>
+__device__ __forceinline__ void far_list_write(unsigned int* __restrict__ list, unsigned int at, const uint2 (&rr)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+    for (unsigned int j = rr[b].x; j < rr[b].y; j += 4u) list[at++] = (j << 3) | min(4u, rr[b].y - j);
+}
+// every candidate of list[0 .. n) against the lanes' lists (uniform call)
+__device__ __forceinline__ void far_list_scan(const GridView& g, const unsigned int* __restrict__ list, unsigned int n, float wx, float wy, float wz,
+                                              float bound1, Knn5& k) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (unsigned int i0 = 0; i0 < n; i0 += 128u) {
+    unsigned int w[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) w[c] = i0 + 64u * c + lane < n ? list[i0 + 64u * c + lane] : 0u;
+    float4 P[8];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) P[4 * c + u] = g.pts[(w[c] >> 3) + min((unsigned)u, (w[c] & 7u) - 1u)];  // (an empty word reads slots 0 .. 3 and discards them)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float d = dist2_ref(wx, wy, wz, P[4 * c + u].x, P[4 * c + u].y, P[4 * c + u].z);
+        if ((unsigned)u < (w[c] & 7u) && d <= g.max_d2 && d < fminf(k.d4, bound1)) knn_insert(k, d, (int)((w[c] >> 3) + (unsigned)u));
+      }
+  }
+  __builtin_amdgcn_wave_barrier();  // (the list is rewritten behind this call)
+}
+// One trip of the far pass: the lanes' NB surviving cell ranges join the list (scanned first if it is full; a trip that would
+// overflow the list on its own - cells of hundreds of points - is scanned lane by lane as in round 4).
+template <int NB>
+__device__ __forceinline__ void far_list_trip(const GridView& g, unsigned int* __restrict__ list, unsigned int& n_list, const uint2 (&rr)[NB], float wx, float wy,
+                                              float wz, float bound1, Knn5& k) {
+  unsigned int mine = 0u;
+#pragma unroll
+  for (int b = 0; b < NB; b++) mine += (rr[b].y - rr[b].x + 3u) >> 2;
+  unsigned int total;
+  const unsigned int before = wave_excl_prefix_u32(mine, &total);
+  if (total == 0u) return;  // (uniform)
+  if (total > (unsigned)kFarCap) {
+    far_candidates<NB>(g, rr, wx, wy, wz, bound1, k);
+    return;
+  }
+  if (n_list + total > (unsigned)kFarCap) {
+    far_list_scan(g, list, n_list, wx, wy, wz, bound1, k);
+    n_list = 0u;
+  }
+  far_list_write<NB>(list, n_list + before, rr);
+  n_list += total;
+}
 // seeded: the search pass has already measured every point of the 3 x 3 x 3 cells around the query (kCovered) - its list
 // (seed_d: the distance of entry `lane` on lanes 0..4, inf where the list ends) stands in for pass 1; a seeded entry that
 // survives comes back as index -(2 + its place in the list).
 __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, float wy, float wz, bool has5, float list_d, bool seeded,
-                                                  float seed_d, float (&od)[5], int (&oi)[5]) {
+                                                  float seed_d, float (&od)[5], int (&oi)[5], unsigned int* __restrict__ far_list /* [kFarCap] LDS, this wavefront's */) {
   const int lane = threadIdx.x & 63;
   // (the block probes below need the query only: they are issued before the search pass's list - list_d: entry `lane`'s distance
   // on lanes 0..4 - is looked at)
@@ -1192,6 +1266,7 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
   // not depend on the candidates found on the way, so the four cell entries of a lane are fetched together and their
   // candidates four per trip - the loop is a chain of dependent loads, not of arithmetic.
   const int nxy = nx * ny;
+  unsigned int n_far = 0u;  // chunks on the list (uniform)
   if (total <= 256) {
   constexpr int NB = 4;
   for (int c0 = 0; c0 < total; c0 += 64 * NB) {  // uniform trip count: the shuffle below needs every lane
@@ -1218,7 +1293,7 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
         rr[b] = g.cells[(size_t)id * kBlockCells + local];
       }
     }
-    far_candidates<NB>(g, rr, wx, wy, wz, bound1, k);
+    far_list_trip<NB>(g, far_list, n_far, rr, wx, wy, wz, bound1, k);
   }
   } else {
   // Which cells survive (inside the ball, outside the inner cube, closer than bound1) does not depend on the candidates found on
@@ -1260,10 +1335,11 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
       for (int b = 0; b < NB; b++) rr[b] = g.cells[ci[b]];
 #pragma unroll
       for (int b = 0; b < NB; b++) rr[b] = act[b] ? rr[b] : make_uint2(0u, 0u);
-      far_candidates<NB>(g, rr, wx, wy, wz, bound1, k);
+      far_list_trip<NB>(g, far_list, n_far, rr, wx, wy, wz, bound1, k);
     }
   }
   }
+  far_list_scan(g, far_list, n_far, wx, wy, wz, bound1, k);
   wave_select5(k, od, oi);
 }
 
@@ -1294,7 +1370,8 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
 // One flagged search finished by a whole wavefront: the list goes to rb.nbr / rb.nbr_count.
 // (the owner lane has loaded the query's world point and count together with everything else it needs: the completion starts
 // with the block probes at once - one dependent round trip less than fetching them here)
-__device__ __forceinline__ void complete_one(const GridView& g, const RegistrationBuffers& rb, int qi, int c00, float wx, float wy, float wz) {
+__device__ __forceinline__ void complete_one(const GridView& g, const RegistrationBuffers& rb, int qi, int c00, float wx, float wy, float wz,
+                                             unsigned int* __restrict__ far_list) {
   const int lane = threadIdx.x & 63;
   const int c0 = c00 & 0xFF;
   const bool seeded = (c00 & kCovered) != 0;  // uniform
@@ -1302,7 +1379,7 @@ __device__ __forceinline__ void complete_one(const GridView& g, const Registrati
   const float4 sv = lane < 5 ? rb.nbr[(size_t)lane * rb.cap + qi] : make_float4(0.f, 0.f, 0.f, __builtin_inff());
   float od[5];
   int oi[5];
-  knn_fallback_wave(g, wx, wy, wz, c0 == kMatch, sv.w, seeded, lane < c0 ? sv.w : __builtin_inff(), od, oi);
+  knn_fallback_wave(g, wx, wy, wz, c0 == kMatch, sv.w, seeded, lane < c0 ? sv.w : __builtin_inff(), od, oi, far_list);
   const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
   const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
   // a seeded entry that stayed in the list: its point is in the lane that loaded it
@@ -1324,8 +1401,9 @@ struct NeedyShared {
   int n;
 };
 // `count`, `w`: nbr_count and world point of the calling lane's query (loaded by the caller, together).
+// far_lists: kBlock / 64 lists of kFarCap words (LDS), one per wavefront
 __device__ __forceinline__ void complete_flagged(const GridView& g, const RegistrationBuffers& rb, int my_point, bool live, int count, float4 w,
-                                                 NeedyShared& sh) {
+                                                 NeedyShared& sh, unsigned int* __restrict__ far_lists) {
   if (threadIdx.x == 0) sh.n = 0;
   __syncthreads();
   if (live && (count & kNeedy)) {
@@ -1336,7 +1414,7 @@ __device__ __forceinline__ void complete_flagged(const GridView& g, const Regist
   __syncthreads();
   const int nn = sh.n;
   const int wave = threadIdx.x >> 6;
-  for (int e = wave; e < nn; e += kBlock / 64) complete_one(g, rb, sh.point[e], sh.count[e], sh.w[e][0], sh.w[e][1], sh.w[e][2]);
+  for (int e = wave; e < nn; e += kBlock / 64) complete_one(g, rb, sh.point[e], sh.count[e], sh.w[e][0], sh.w[e][1], sh.w[e][2], far_lists + wave * kFarCap);
   if (nn) __syncthreads();  // the completed lists are visible to their owners (workgroup-scope release/acquire)
 }
 
@@ -1354,13 +1432,14 @@ __device__ __forceinline__ int fit_point_of(int blk, int nb) {
 // by a stand-alone k-NN pass, not by a fit pass).
 __global__ __launch_bounds__(kBlock) void k_knn_complete(GridView g, RegistrationBuffers rb) {
   __shared__ NeedyShared sh;
+  __shared__ unsigned int s_far[(kBlock / 64) * kFarCap];
   int lo, n_live;
   shard_range(rb, lo, n_live);
   const int q = fit_point_of(blockIdx.x, (int)gridDim.x);
   const bool live = q < n_live;
   const int count = live ? rb.nbr_count[lo + q] : 0;
   const float4 w = live ? rb.world[lo + q] : make_float4(0.f, 0.f, 0.f, 0.f);
-  complete_flagged(g, rb, lo + q, live, count, w, sh);
+  complete_flagged(g, rb, lo + q, live, count, w, sh, s_far);
 }
 
 // POSE_V: the pose lives in vector registers (204 VGPRs: two wavefronts per SIMD - no matter while the launch has no more than two per
@@ -1418,7 +1497,9 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
   if (FIT) {  // uniform per workgroup
     const int count0 = live ? (early ? e_count : rb.nbr_count[i]) : 0;
     if (live) w4 = early ? e_world : rb.world[i];  // written by the search pass with the same arithmetic
-    complete_flagged(g, rb, i, live, count0, w4, sh_needy);
+    // (the far lists live where the launch's final reduction stages its rows later: one wavefront's row area holds kFarCap words)
+    static_assert(sizeof(sh.row[0]) >= sizeof(unsigned int) * kFarCap, "far list");
+    complete_flagged(g, rb, i, live, count0, w4, sh_needy, reinterpret_cast<unsigned int*>(&sh.row[0][0]));
   }
   RowOut o;
 #pragma unroll

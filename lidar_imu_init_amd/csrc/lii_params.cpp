@@ -336,7 +336,7 @@ int lii_params_apply(const lii_params* p, int32_t device, int32_t max_scan_point
     ingest->n_scans = p->scan_line;
     ingest->point_filter_num = p->point_filter_num;
     ingest->blind = p->blind;
-    ingest->cut_frame_num = p->cut_frame ? p->cut_frame_num : 1;
+    ingest->cut_frame_num = p->cut_frame ? p->cut_frame_num : 0;  // (0: the callbacks' non-cutting branch, Preprocess::process - laserMapping.cpp:337-342, :374-379)
     ingest->scan_count = 0;  // per message: the caller's running count
     ingest->stamp_s = 0.0;   // per message
   }

@@ -4,6 +4,9 @@
 // cutting — a CPU restatement of
 //   Preprocess::process_cut_frame_livox   reference src/preprocess.cpp:50-113
 //   Preprocess::process_cut_frame_pcl2    reference src/preprocess.cpp:115-335
+//   Preprocess::process (PointCloud2: oust_handler / velodyne_handler / l515_handler; CustomMsg: avia_handler), feature extraction
+//       disabled                            reference src/preprocess.cpp:337-713 - the callbacks' branch for initialization/cut_frame:
+//       false (src/laserMapping.cpp:337-342, :374-379): selected here by IngestOpts::cut_frame_num == 0
 // for the point layouts the reference registers (src/preprocess.h:35-116):
 //   velodyne_ros::Point  x y z f32, intensity f32, time f32 [s], ring u16
 //   ouster_ros::Point    x y z f32, intensity f32, t u32 [ns], ring u8
@@ -92,8 +95,71 @@ inline void cut_frames(std::vector<P4>& pl_surf, const IngestOpts& o, int uncut_
   }
 }
 
+// Preprocess::process(PointCloud2) with feature_enabled == false — src/preprocess.cpp:337-354 -> oust_handler :472-565 (the else
+// branch :544-564), velodyne_handler :567-702 (:660-701), l515_handler :444-470.  No time sort, no cut, no point dropped at index
+// 0: the cloud as the handler leaves it in pl_surf, input order; the caller stamps it with header.stamp (laserMapping.cpp:340,377).
+// Any other lidar_type prints "Error LiDAR Type" and hands back whatever pl_surf held before: -1 here.
+inline int ingest_pcl2_whole(const uint8_t* data, int plsize, const Pc2Fields& f, const IngestOpts& o, std::vector<Frame>& out) {
+  constexpr int MAX_LINE_NUM = 128;
+  if (o.lidar_type != VELO && o.lidar_type != OUSTER && o.lidar_type != L515) return -1;
+  Frame fr;
+  fr.begin_time_ms = o.stamp_s * 1000;
+  bool given_offset_time = true;
+  bool is_first[MAX_LINE_NUM];
+  double yaw_fp[MAX_LINE_NUM] = {0};
+  const double omega_l = 3.61;
+  float time_last[MAX_LINE_NUM] = {0.0f};
+  if (o.lidar_type == VELO && plsize > 0) {
+    given_offset_time = (double)rd<float>(data + (size_t)(plsize - 1) * f.point_step + f.time) > 0;  // (:586-592)
+    if (!given_offset_time) std::memset(is_first, true, sizeof(is_first));
+  }
+  for (int i = 0; i < plsize; i++) {
+    const uint8_t* p = data + (size_t)i * f.point_step;
+    P4 a;
+    a.x = rd<float>(p + f.x);
+    a.y = rd<float>(p + f.y);
+    a.z = rd<float>(p + f.z);
+    if (o.lidar_type == L515) {  // (:455-469): decimation first, no NaN test (a NaN range is not < blind^2), no ring, time 0
+      if (i % o.point_filter_num != 0) continue;
+      const double range = a.x * a.x + a.y * a.y + a.z * a.z;
+      if (range < o.blind * o.blind) continue;
+      a.t = 0.0f;
+      fr.pts.push_back(a);
+    } else if (o.lidar_type == OUSTER) {  // (:545-563)
+      if (i % o.point_filter_num != 0) continue;
+      a.t = (float)(rd<uint32_t>(p + f.time) / 1e6);
+      const double dist = a.x * a.x + a.y * a.y + a.z * a.z;
+      if (dist < o.blind * o.blind || std::isnan(a.x) || std::isnan(a.y) || std::isnan(a.z)) continue;
+      if (rd<uint8_t>(p + f.ring) < o.n_scans) fr.pts.push_back(a);
+    } else {  // VELO (:661-700): no ring filter in this branch; the decimation comes last
+      a.t = (float)(rd<float>(p + f.time) * 1000.0);
+      const double dist = a.x * a.x + a.y * a.y + a.z * a.z;
+      if (dist < o.blind * o.blind || std::isnan(a.x) || std::isnan(a.y) || std::isnan(a.z)) continue;
+      if (!given_offset_time) {
+        const int layer = rd<uint16_t>(p + f.ring);
+        if (layer < 0 || layer >= MAX_LINE_NUM) continue;  // the reference indexes out of bounds here; such points are dropped
+        const double yaw_angle = std::atan2(a.y, a.x) * 57.2957;
+        if (is_first[layer]) {
+          yaw_fp[layer] = yaw_angle;
+          is_first[layer] = false;
+          time_last[layer] = 0.0f;
+          continue;
+        }
+        if (yaw_angle <= yaw_fp[layer]) a.t = (float)((yaw_fp[layer] - yaw_angle) / omega_l);
+        else a.t = (float)((yaw_fp[layer] - yaw_angle + 360.0) / omega_l);
+        if (a.t < time_last[layer]) a.t = (float)(a.t + 360.0 / omega_l);
+        time_last[layer] = a.t;
+      }
+      if (i % o.point_filter_num == 0) fr.pts.push_back(a);
+    }
+  }
+  out.push_back(std::move(fr));
+  return 0;
+}
+
 // process_cut_frame_pcl2 — src/preprocess.cpp:115-335
 inline int ingest_pcl2(const uint8_t* data, int plsize, const Pc2Fields& f, const IngestOpts& o, std::vector<Frame>& out) {
+  if (o.cut_frame_num == 0) return ingest_pcl2_whole(data, plsize, f, o, out);
   std::vector<P4> pl_surf;
   pl_surf.reserve(plsize);
   constexpr int MAX_LINE_NUM = 128;
@@ -170,7 +236,9 @@ inline int ingest_pcl2(const uint8_t* data, int plsize, const Pc2Fields& f, cons
   return 0;
 }
 
-// process_cut_frame_livox — src/preprocess.cpp:50-113
+// process_cut_frame_livox — src/preprocess.cpp:50-113; cut_frame_num == 0: Preprocess::process(CustomMsg) = avia_handler with
+// feature_enabled == false (:355-443, the else branch :419-442) - the same per-point loop, then neither the time sort nor the cut:
+// pl_surf in input order, its first point included.
 inline int ingest_livox(const uint8_t* data, int plsize, const LivoxFields& f, const IngestOpts& o, std::vector<Frame>& out) {
   std::vector<P4> pl_surf;
   pl_surf.reserve(plsize);
@@ -194,6 +262,13 @@ inline int ingest_livox(const uint8_t* data, int plsize, const LivoxFields& f, c
         }
       }
     }
+  }
+  if (o.cut_frame_num == 0) {
+    Frame fr;
+    fr.begin_time_ms = o.stamp_s * 1000;
+    fr.pts = pl_surf;
+    out.push_back(std::move(fr));
+    return 0;
   }
   cut_frames(pl_surf, o, 5, out);
   return 0;

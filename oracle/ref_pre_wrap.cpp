@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  extern "C" wrapper around the UNMODIFIED reference Preprocess class
 // (/root/reference/src/preprocess.{h,cpp}, compiled where it lies against oracle/ref_shim_pre): builds the message
-// structs from raw bytes + field offsets and calls Preprocess::process_cut_frame_pcl2 / process_cut_frame_livox.
+// structs from raw bytes + field offsets and calls Preprocess::process_cut_frame_pcl2 / process_cut_frame_livox - or, with
+// cut_frame_num == 0, Preprocess::process (the callbacks' branch for initialization/cut_frame: false).
 // Used by tests/golden/make_ingest_fixture.py to pin oracle/orc_ingest.hpp against the reference's own code.
 #include "preprocess.h"
 
@@ -51,7 +52,15 @@ int ref_ingest_pcl2(const unsigned char* data, int n, const int* fields7, int li
   pre.N_SCANS = n_scans;
   deque<PointCloudXYZI::Ptr> pcl_out;
   deque<double> time_lidar;
-  pre.process_cut_frame_pcl2(msg, pcl_out, time_lidar, cut_frame_num, scan_count);
+  if (cut_frame_num == 0) {  // src/laserMapping.cpp:337-342: p_pre->process(msg, ptr); time_buffer.push_back(msg->header.stamp.toSec())
+    if (lidar_type != VELO && lidar_type != OUSTER && lidar_type != L515) return -1;  // "Error LiDAR Type": pl_surf is whatever it was
+    PointCloudXYZI::Ptr ptr(new PointCloudXYZI());
+    pre.process(msg, ptr);
+    pcl_out.push_back(ptr);
+    time_lidar.push_back(stamp_s * 1000);
+  } else {
+    pre.process_cut_frame_pcl2(msg, pcl_out, time_lidar, cut_frame_num, scan_count);
+  }
   return flatten(pcl_out, time_lidar, out4, cap_pts, begin_ms, offsets, counts, cap_frames);
 }
 
@@ -78,7 +87,14 @@ int ref_ingest_livox(const unsigned char* data, int n, const int* fields8, int n
   pre.N_SCANS = n_scans;
   deque<PointCloudXYZI::Ptr> pcl_out;
   deque<double> time_lidar;
-  pre.process_cut_frame_livox(msg, pcl_out, time_lidar, cut_frame_num, scan_count);
+  if (cut_frame_num == 0) {  // src/laserMapping.cpp:374-379
+    PointCloudXYZI::Ptr ptr(new PointCloudXYZI());
+    pre.process(msg, ptr);
+    pcl_out.push_back(ptr);
+    time_lidar.push_back(stamp_s * 1000);
+  } else {
+    pre.process_cut_frame_livox(msg, pcl_out, time_lidar, cut_frame_num, scan_count);
+  }
   return flatten(pcl_out, time_lidar, out4, cap_pts, begin_ms, offsets, counts, cap_frames);
 }
 

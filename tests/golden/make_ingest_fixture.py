@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes tests/golden/ingest/reference_frames.npz: small driver messages (raw bytes) together with what the REFERENCE's own
-Preprocess::process_cut_frame_pcl2 / process_cut_frame_livox return for them.  The reference code is the unmodified
+Preprocess::process_cut_frame_pcl2 / process_cut_frame_livox / process (cut_frame_num 0) return for them.  The reference code is the unmodified
 /root/reference/src/preprocess.cpp compiled by `make -C oracle ref` into oracle/_ref/libref_preprocess.so; this script
 only runs where that library exists (this container).  Times are made distinct so that the reference's unstable std::sort
 has a unique answer."""
@@ -23,12 +23,14 @@ def main():
     rng = np.random.default_rng(9)
     t_j = t_ms + rng.permutation(len(t_ms)) * 1e-3
     out = {}
+    # (cut 0: Preprocess::process - the non-cutting handlers of initialization/cut_frame: false, src/preprocess.cpp:337-713)
     cases = [(wire.VELO, 3, 100, 1, True), (wire.OUSTER, 4, 100, 2, True), (wire.PANDAR, 2, 100, 1, True),
-             (wire.ROBOSENSE, 3, 5, 1, True), (wire.VELO, 2, 100, 1, False)]
+             (wire.ROBOSENSE, 3, 5, 1, True), (wire.VELO, 2, 100, 1, False),
+             (wire.OUSTER, 0, 100, 2, True), (wire.VELO, 0, 100, 1, True), (wire.VELO, 0, 100, 2, False), (wire.L515, 0, 100, 3, True)]
     for k, (lt, cut, sc, pfn, with_time) in enumerate(cases):
         stamp, blind, n_scans = 321.25, 1.2, 14
         raw = wire.pack_pcl2(lt, xyz, ring, t_j, stamp, with_time=with_time)
-        if not with_time:
+        if not with_time and cut > 0:
             # the azimuth-derived times of different rings tie; keep one ring so that the reference's order is unique
             n_scans = 1
         fr = O.ref_ingest_pcl2(raw, len(xyz), wire.pc2_fields(lt), lt, n_scans, pfn, blind, stamp, cut, sc)
@@ -40,7 +42,7 @@ def main():
         out[c + "/counts"] = np.array([len(p) for _, p in fr])
         out[c + "/points"] = np.concatenate([p for _, p in fr])
     raw, n = wire.avia_sweep(hall, synth.rot_zyx(0, 0, 0.3), np.array([0.5, 0.5, 0.0]), n_points=3000)
-    for k, (cut, sc, pfn) in enumerate([(5, 100, 2), (3, 2, 1)]):
+    for k, (cut, sc, pfn) in enumerate([(5, 100, 2), (3, 2, 1), (0, 100, 2)]):
         fr = O.ref_ingest_livox(raw, n, wire.livox_fields(), 6, pfn, 1.0, 12.5, cut, sc)
         c = f"livox{k}"
         out[c + "/meta"] = np.array([1, wire.AVIA, n, 6, pfn, cut, sc])

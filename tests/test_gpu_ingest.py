@@ -147,3 +147,51 @@ def test_ingest_feeds_registration(reg, oracle):
         assert rep["effect_num"] > 2000
         assert np.linalg.norm(s.pos_end - p) < 0.01
     r2.close()
+
+
+@pytest.mark.parametrize("sensor,lidar_type,pfn,with_time", [("os1_128", wire.OUSTER, 1, True), ("os1_128", wire.OUSTER, 3, True), ("vlp16", wire.VELO, 1, True),
+                                                             ("vlp16", wire.VELO, 2, True), ("vlp16", wire.VELO, 1, False), ("mid16k", wire.L515, 2, True)])
+def test_whole_message_bit_exact(reg, oracle, sensor, lidar_type, pfn, with_time):
+    """cut_frame_num = 0: the callbacks' branch for initialization/cut_frame: false - Preprocess::process (oust_handler / velodyne_handler /
+    l515_handler, feature extraction disabled, src/preprocess.cpp:337-713) on the device: the handler's own filters, no time sort, no
+    cut, ONE frame in input order stamped with the message's time.  Against the oracle's restatement - which tests/test_oracle_ingest.py
+    holds bit for bit to the reference's unmodified Preprocess::process - and, where it travelled with the repository, against that
+    library itself."""
+    hall = synth.Hall()
+    xyz, ring, t_ms = wire.raw_sweep(hall, sensor, synth.rot_zyx(0.02, 0.01, 0.7), np.array([1.0, -1.0, 0.2]))
+    n, stamp = len(xyz), 1_650_000_321.5
+    raw = wire.pack_pcl2(lidar_type, xyz, ring, t_ms, stamp, with_time=with_time)
+    f = wire.pc2_fields(lidar_type)
+    n_scans = synth.SENSORS[sensor][0] - 2
+    info = reg.ingest_pcl2(raw, n, f, lidar_type, n_scans, pfn, 1.0, stamp, 0, 100)
+    orc = oracle.ingest_pcl2(raw, n, f, lidar_type, n_scans, pfn, 1.0, stamp, 0, 100)
+    assert len(info) == 1 and info[0][1] == 0 and info[0][2] == len(orc[0][1])
+    got = gpu_frames(reg, info)
+    assert_same(got, orc, exact_time=with_time)  # (synthesised times: atan2 of the device library vs glibc, <= 1 ulp of float32)
+    assert reg.frame_tail_ms[0] == float(got[0][1][-1, 3])  # points.back().curvature: what sync_packages ends the scan with
+    if with_time and oracle.ref_preprocess_lib() is not None:
+        ref = oracle.ref_ingest_pcl2(raw, n, f, lidar_type, n_scans, pfn, 1.0, stamp, 0, 100)
+        assert_same(got, ref)
+
+
+def test_whole_message_livox_and_errors(reg, oracle):
+    import lidar_imu_init_amd as lii
+    hall = synth.Hall()
+    raw, n = wire.avia_sweep(hall, synth.rot_zyx(0, 0, 0.3), np.array([0.5, 0.5, 0.0]), n_points=24000)
+    for pfn in (1, 2, 3):
+        info = reg.ingest_livox(raw, n, wire.livox_fields(), 6, pfn, 1.0, 12.5, 0, 100)
+        orc = oracle.ingest_livox(raw, n, wire.livox_fields(), 6, pfn, 1.0, 12.5, 0, 100)
+        assert len(info) == 1
+        assert_same(gpu_frames(reg, info), orc)
+    # Preprocess::process does not know Pandar / RoboSense clouds ("Error LiDAR Type"): refused, not decoded as something else
+    xyz = np.ones((8, 3), np.float32) * 3
+    rawp = wire.pack_pcl2(wire.PANDAR, xyz, np.zeros(8, np.int32), np.arange(8.0), 5.0)
+    with pytest.raises(lii.LIIError):
+        reg.ingest_pcl2(rawp, 8, wire.pc2_fields(wire.PANDAR), wire.PANDAR, 16, 1, 0.5, 5.0, 0, 100)
+    # everything inside the blind zone: no frame (the node skips an empty cloud)
+    rawo = wire.pack_pcl2(wire.OUSTER, xyz, np.zeros(8, np.int32), np.arange(8.0), 5.0)
+    assert reg.ingest_pcl2(rawo, 8, wire.pc2_fields(wire.OUSTER), wire.OUSTER, 16, 1, 10.0, 5.0, 0, 100) == []
+    # and the frame registers like any other scan handed over unsorted
+    info = reg.ingest_livox(raw, n, wire.livox_fields(), 6, 2, 1.0, 12.5, 0, 100)
+    reg.frame_select(0)
+    assert len(reg.scan_download(0)) == info[0][2]

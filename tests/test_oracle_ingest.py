@@ -217,6 +217,77 @@ def test_livox_against_reference_code(oracle):
         assert_frames_equal(got, ref)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# The callbacks' other branch (initialization/cut_frame: false, src/laserMapping.cpp:337-342, :374-379): Preprocess::process -
+# oust_handler / velodyne_handler / l515_handler / avia_handler with feature extraction disabled (src/preprocess.cpp:337-713) -
+# selected by cut_frame_num = 0.  No sort, so no ties: every bit must agree with the reference's own code.
+WHOLE_CASES = [(wire.OUSTER, 1, True), (wire.OUSTER, 3, True), (wire.VELO, 1, True), (wire.VELO, 2, True), (wire.VELO, 1, False), (wire.VELO, 3, False),
+               (wire.L515, 1, True), (wire.L515, 4, True)]
+
+
+def np_whole_pcl2(lidar_type, raw, n, n_scans, pfn, blind, with_time):
+    """The handlers' rules as array operations (independent of the loop restatement), for messages that carry per-point time."""
+    a = np.frombuffer(raw, wire.DTYPES[lidar_type], count=n)
+    x, y, z = a["x"], a["y"], a["z"]
+    d = ((x * x + y * y) + z * z).astype(np.float64)
+    dec = np.arange(n) % pfn == 0
+    if lidar_type == wire.L515:
+        keep = dec & ~(d < blind * blind)  # (a NaN range is not below the blind radius: such points pass, as in the reference)
+        t = np.zeros(n, np.float32)
+    else:
+        ok = ~((d < blind * blind) | np.isnan(x) | np.isnan(y) | np.isnan(z))
+        if lidar_type == wire.OUSTER:
+            keep = dec & ok & (a["ring"].astype(np.int64) < n_scans)
+            t = (a["t"].astype(np.float64) / 1e6).astype(np.float32)
+        else:
+            keep = dec & ok  # velodyne_handler's feature-less branch has no ring test
+            t = (a["time"].astype(np.float64) * 1000.0).astype(np.float32)
+    return np.stack([x, y, z, t], 1)[keep]
+
+
+@pytest.mark.parametrize("lidar_type,pfn,with_time", WHOLE_CASES)
+def test_whole_message_handlers(oracle, sweep, lidar_type, pfn, with_time):
+    xyz, ring, t_ms = sweep
+    n, stamp = len(xyz), 4321.5
+    raw = wire.pack_pcl2(lidar_type, xyz, ring, t_ms, stamp, with_time=with_time)
+    f = wire.pc2_fields(lidar_type)
+    got = oracle.ingest_pcl2(raw, n, f, lidar_type, 12, pfn, 1.5, stamp, 0, 100)
+    assert len(got) == 1 and got[0][0] == stamp * 1000
+    if with_time:
+        want = np_whole_pcl2(lidar_type, raw, n, 12, pfn, 1.5, with_time)
+        assert got[0][1].shape == want.shape and np.array_equal(got[0][1].view(np.uint32), want.view(np.uint32))
+        if lidar_type == wire.OUSTER:
+            assert len(want) < n * 0.6 / pfn + 1  # rings 12 .. 15 and the missing returns are gone
+    else:  # time from the azimuth: every ring's first surviving point only seeds the recurrence
+        assert np.all(got[0][1][:, 3] >= 0) and got[0][1][:, 3].max() < 2 * 360.0 / 3.61 + 1.0  # (up to two revolutions at 3.61 deg/ms)
+    if oracle.ref_preprocess_lib() is not None:  # the reference's own Preprocess::process
+        ref = oracle.ref_ingest_pcl2(raw, n, f, lidar_type, 12, pfn, 1.5, stamp, 0, 100)
+        assert_frames_equal(got, ref)
+
+
+def test_whole_message_livox_and_edge_cases(oracle):
+    hall = synth.Hall()
+    raw, n = wire.avia_sweep(hall, synth.rot_zyx(0, 0, 0.3), np.array([0.5, 0.5, 0.0]), n_points=6000)
+    for pfn in (1, 2, 3):
+        got = oracle.ingest_livox(raw, n, wire.livox_fields(), 6, pfn, 1.0, 12.5, 0, 100)
+        cut1 = oracle.ingest_livox(raw, n, wire.livox_fields(), 6, pfn, 1.0, 12.5, 1, 100)
+        assert len(got) == 1 and got[0][0] == 12500.0
+        # the cutting form emits the same points but the time-earliest one, sorted by time; this one keeps the input order
+        assert len(got[0][1]) == len(cut1[0][1]) + 1
+        assert np.array_equal(np.sort(got[0][1][:, 3])[1:], cut1[0][1][:, 3])
+        if oracle.ref_preprocess_lib() is not None:
+            assert_frames_equal(got, oracle.ref_ingest_livox(raw, n, wire.livox_fields(), 6, pfn, 1.0, 12.5, 0, 100))
+    # a lidar_type Preprocess::process does not know ("Error LiDAR Type", the cloud of the previous message is handed back): refused
+    xyz = np.ones((4, 3), np.float32) * 3
+    rawp = wire.pack_pcl2(wire.PANDAR, xyz, np.zeros(4, np.int32), np.arange(4.0), 5.0)
+    with pytest.raises(RuntimeError):
+        oracle.ingest_pcl2(rawp, 4, wire.pc2_fields(wire.PANDAR), wire.PANDAR, 16, 1, 0.5, 5.0, 0, 100)
+    # an empty message / everything inside the blind zone: one empty cloud (the node skips it: laserMapping.cpp:909-914)
+    rawo = wire.pack_pcl2(wire.OUSTER, xyz, np.zeros(4, np.int32), np.arange(4.0), 5.0)
+    got = oracle.ingest_pcl2(rawo, 4, wire.pc2_fields(wire.OUSTER), wire.OUSTER, 16, 1, 10.0, 5.0, 0, 100)
+    assert len(got) == 1 and len(got[0][1]) == 0
+
+
 def test_ingest_golden_fixture(oracle):
     """Outputs of the reference's own Preprocess (generated by tests/golden/make_ingest_fixture.py) replayed through the
     restatement — runs everywhere, with or without oracle/_ref."""
@@ -224,7 +295,7 @@ def test_ingest_golden_fixture(oracle):
     path = os.path.join(os.path.dirname(__file__), "golden", "ingest", "reference_frames.npz")
     z = np.load(path)
     cases = sorted({k.split("/")[0] for k in z.files})
-    assert len(cases) >= 6
+    assert len(cases) >= 11
     for c in cases:
         meta = z[c + "/meta"]  # kind, lidar_type, n, n_scans, pfn, cut, scan_count
         kind, lidar_type, n, n_scans, pfn, cut, sc = [int(v) for v in meta]

@@ -106,7 +106,7 @@ def test_overrides_and_errors(tmp_path):
     p.set("max_iteration", 7).set("/initialization/cut_frame_num", 3).set("initialization/cut_frame", False)
     p.set("initialization/Trans_LI_cov", [1e-3, 2e-3, 3e-3]).set("a/name/nobody/reads", 1)
     assert p.max_iteration == 7 and p.cut_frame_num == 3 and p.cut_frame == 0 and p.Trans_LI_cov == [1e-3, 2e-3, 3e-3]
-    assert p.apply()[1].cut_frame_num == 1  # cut_frame false: process_cut_frame is bypassed (laserMapping.cpp:326,363)
+    assert p.apply()[1].cut_frame_num == 0  # cut_frame false: Preprocess::process instead of process_cut_frame_* (laserMapping.cpp:326-342, :363-379)
     with pytest.raises(api.LIIError):
         p.set("mapping/filter_size_surf", "wide")
     with pytest.raises(api.LIIError):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-executed-launch means of every counter tools/pmc_probe.sh collected for the search kernel (k_knn_pk) and the fit launch.
+"""Per-executed-launch means of every counter tools/pmc_probe.sh collected for the search kernel (k_knn_ck) and the fit launch.
 usage: pmc_table.py <dir> <workload>"""
 import collections
 import csv

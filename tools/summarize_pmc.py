@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-launch PMC figures of the search kernel (k_knn_pk) from the passes written by tools/collect_pmc.sh -> profiles/rNN_pmc_knn.json.
+"""Per-launch PMC figures of the search kernel (k_knn_ck) from the passes written by tools/collect_pmc.sh -> profiles/rNN_pmc_knn.json.
 Only launches that executed count (the device-driven loop enqueues the kernel for every iteration; the ones that return at
 once move no data): a launch is 'executed' when its WRITE_SIZE / wave count is non-trivial.
 usage: summarize_pmc.py <dir of collect_pmc.sh> <out.json> [algorithmic bytes per launch]"""
@@ -16,7 +16,7 @@ def main():
     per = collections.defaultdict(lambda: collections.defaultdict(list))  # counter -> dispatch id -> values
     for f in glob.glob(d + "/p*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "k_knn_pk" not in r["Kernel_Name"]:
+            if "k_knn_ck" not in r["Kernel_Name"]:
                 continue
             per[r["Counter_Name"]][(f, r["Dispatch_Id"])].append(float(r["Counter_Value"]))
     res = {}
@@ -28,7 +28,7 @@ def main():
     fetch_kb, write_kb = res.get("FETCH_SIZE", 0.0), res.get("WRITE_SIZE", 0.0)
     hits, miss = res.get("TCC_HIT_sum", 0.0), res.get("TCC_MISS_sum", 0.0)
     j = {
-        "workload": "stream100k", "kernel": "lii::k_knn_pk<4, 128, 6, 7>",
+        "workload": "stream100k", "kernel": "lii::k_knn_ck<4, 128, 6, 7>",
         "command": "tools/collect_pmc.sh: rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python bench.py --steps 8 --warmup 2 "
                    "--prime 0 --profile-every 0 --no-cpu-baseline (one pass per counter set)",
         "counters_per_executed_launch": {k: v for k, v in res.items() if not k.endswith("_launches")},
