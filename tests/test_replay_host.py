@@ -511,3 +511,38 @@ def test_replay_host_lo_phase_follows_the_cpu_oracle(oracle, tmp_path):
     assert dpos[:10].max() <= 1e-12 and drot[:10].max() <= 1e-12, (dpos[:10], drot[:10])
     assert dpos[:20].max() <= 1e-5 and drot[:20].max() <= 5e-6, (dpos[:20], drot[:20])
     assert dpos.max() <= 2e-3 and drot.max() <= 1e-3, (dpos, drot)
+
+
+@pytest.mark.gpu
+def test_replay_host_without_frame_cutting(tmp_path):
+    """initialization/cut_frame: false - the callbacks take Preprocess::process (src/laserMapping.cpp:337-342): the C++ host ingests every
+    message with cut_frame_num = 0 (one frame per message, the driver's point order, not time-sorted) and registers it with scan_sorted = 0;
+    the odometry must follow the trajectory exactly as it does on cut frames."""
+    from lidar_imu_init_amd.api import lii_pc2_fields
+    from harness import synth, wire
+    d = _drv()
+    (tmp_path / "config").mkdir()
+    (tmp_path / "launch").mkdir()
+    (tmp_path / "config" / "replay_test.yaml").write_text(YAML.replace("cut_frame: true", "cut_frame: false"))
+    (tmp_path / "launch" / "replay_test.launch").write_text(LAUNCH)
+    hall = synth.Hall(size=(24.0, 18.0, 6.0), n_boxes=8, seed=7)
+    traj = synth.Trajectory()
+    msg_period, n_msgs = 0.1, 30
+    imu = synth.simulate_imu(traj, -0.5, n_msgs * msg_period + 0.5, 200.0, synth.rot_zyx(0.03, -0.02, -0.8), np.array([0.05, -0.03, 0.10]),
+                             np.zeros(3), np.zeros(3), 0.0)
+    f = wire.pc2_fields(wire.OUSTER)
+    rng = np.random.default_rng(3)
+    msgs = []
+    for k in range(n_msgs):
+        stamp = k * msg_period
+        scan = synth.make_distorted_scan(hall, "mid16k", traj, stamp, msg_period, noise=0.01, seed=3000 + k, blind=0.0)
+        scan = scan[rng.permutation(len(scan))]  # a driver order that is NOT the time order
+        raw = wire.pack_pcl2(wire.OUSTER, scan[:, :3], np.zeros(len(scan), np.int32), scan[:, 3].astype(np.float64), stamp)
+        msgs.append((stamp, np.frombuffer(raw, np.uint8).copy(), len(scan)))
+    log, status = _cxx_host(d, str(tmp_path / "launch" / "replay_test.launch"), None, msgs, imu, lii_pc2_fields(*f), False, msg_period, 40_000, 600_000)
+    assert not status.imu_en and len(log) >= n_msgs - 3 and np.all(log[:, 1] == 0)
+    pos_err = np.linalg.norm(log[:, 13:16] - traj.p(log[:, 0]), axis=1)
+    print(f"LO on whole (uncut, unsorted) messages: {len(log)} scans, position error median {np.median(pos_err) * 100:.1f} cm, worst {pos_err.max() * 100:.1f} cm")
+    # (whole 0.1 s sweeps under the constant-velocity de-skew: the method tracks less tightly than on half-sweep sub-frames - measured 4.9 cm
+    # median, 19 cm worst on this stream; the 2-sub-frame run above: 2 cm / 6 cm)
+    assert np.median(pos_err) < 0.08 and pos_err.max() < 0.30
