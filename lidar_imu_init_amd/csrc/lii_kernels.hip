@@ -1137,8 +1137,8 @@ __device__ __forceinline__ void far_candidates(const GridView& g, const uint2 (&
 // (a 2.2 m ball: 11 x 11 x 11 cells, a hundred of them occupied, most lanes holding none and a few holding several) cost its
 // workgroup 18 us of candidate loads.  Now the lanes only LIST what they find - every surviving cell range cut into chunks of up to
 // four points, word = first map index << 3 | points, appended to a per-wavefront list in LDS behind a prefix sum over the lanes - and
-// the wavefront scans the list together, two chunks (eight loads in flight) per lane and round: a hundred occupied cells are 225
-// chunks, two rounds.
+// the wavefront scans the list together, one chunk (four loads in flight) per lane and round: a hundred occupied cells are 225
+// chunks, four rounds.
 constexpr int kFarCap = 2048;  // chunks the list holds (it lives in the LDS the launch's final reduction uses later: ReduceShared::row)
 __device__ __forceinline__ unsigned int wave_excl_prefix_u32(unsigned int v, unsigned int* total) {
   const int lane = threadIdx.x & 63;
@@ -1165,22 +1165,18 @@ __device__ __forceinline__ void far_list_scan(const GridView& g, const unsigned 
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (unsigned int i0 = 0; i0 < n; i0 += 128u) {
-    unsigned int w[2];
+  // (one chunk - four loads in flight - per lane and round: the launch this runs in, k_fit_reduce, must keep its three wavefronts per
+  // SIMD; two chunks per lane cost 24 more vector registers and the 500 k-point scan 2 us per fit launch)
+  for (unsigned int i0 = 0; i0 < n; i0 += 64u) {
+    const unsigned int w = i0 + lane < n ? list[i0 + lane] : 0u;
+    F3 P[4];
 #pragma unroll
-    for (int c = 0; c < 2; c++) w[c] = i0 + 64u * c + lane < n ? list[i0 + 64u * c + lane] : 0u;
-    float4 P[8];
+    for (int u = 0; u < 4; u++) P[u] = load_xyz(g.pts, (w >> 3) + min((unsigned)u, (w & 7u) - 1u));  // (an empty word reads slots 0 .. 3 and discards them)
 #pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-      for (int u = 0; u < 4; u++) P[4 * c + u] = g.pts[(w[c] >> 3) + min((unsigned)u, (w[c] & 7u) - 1u)];  // (an empty word reads slots 0 .. 3 and discards them)
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const float d = dist2_ref(wx, wy, wz, P[4 * c + u].x, P[4 * c + u].y, P[4 * c + u].z);
-        if ((unsigned)u < (w[c] & 7u) && d <= g.max_d2 && d < fminf(k.d4, bound1)) knn_insert(k, d, (int)((w[c] >> 3) + (unsigned)u));
-      }
+    for (int u = 0; u < 4; u++) {
+      const float d = dist2_ref(wx, wy, wz, P[u].x, P[u].y, P[u].z);
+      if ((unsigned)u < (w & 7u) && d <= g.max_d2 && d < fminf(k.d4, bound1)) knn_insert(k, d, (int)((w >> 3) + (unsigned)u));
+    }
   }
   __builtin_amdgcn_wave_barrier();  // (the list is rewritten behind this call)
 }
@@ -1303,7 +1299,7 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
   // per search pass on the one scan of the bench stream that has such queries).  The NB cell entries of a trip are requested back
   // to back from a valid address whether the cell is wanted or not (entry 0 for the others; the answer is dropped afterwards): a
   // load behind a branch is waited for on its own.
-  constexpr int NB = 12;
+  constexpr int NB = 8;  // (cells of a column per trip: 12 would take the 11-cell ball in one, at 12 more vector registers than k_fit_reduce can spare)
   for (int col0 = 0; col0 < nxy; col0 += 64) {  // uniform trip counts: the shuffles below need every lane
     const int col = col0 + lane;
     const bool in_col = col < nxy;
@@ -1706,9 +1702,18 @@ static inline int shard_bound(const RegistrationBuffers& rb) {
 // 128 lanes per workgroup, 6 loads in flight per lane, 7 wavefronts per SIMD (69 VGPRs): measured on the per-lane form of rounds 3 - 4
 // against 64 / 256 lanes, 4 .. 12 loads, 6 / 8 wavefronts per SIMD (within 1 - 2 %: profiles/r03_knn_ab.md), and 2 / 1 lanes per query
 // (slower at every cloud size: profiles/r05_knn_lpq.md).
+#ifndef LII_KNN_BS  // (experiment builds: tools/ab_build.sh ... -DLII_KNN_BS=256 -DLII_KNN_NB=4 -DLII_KNN_WPE=8)
+#define LII_KNN_BS 128
+#endif
+#ifndef LII_KNN_NB
+#define LII_KNN_NB 6
+#endif
+#ifndef LII_KNN_WPE
+#define LII_KNN_WPE 7
+#endif
 void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                 const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
-  int nq = nblk(shard_bound(rb), 128 / 4);
+  int nq = nblk(shard_bound(rb), LII_KNN_BS / 4);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
 #ifdef LII_KNN_EXACT
@@ -1718,7 +1723,7 @@ void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, c
   }
 #endif
   (void)variant;
-  hipLaunchKernelGGL((k_knn_ck<4, 128, 6, 7>), dim3(nq_pad), dim3(128), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out);
+  hipLaunchKernelGGL((k_knn_ck<4, LII_KNN_BS, LII_KNN_NB, LII_KNN_WPE>), dim3(nq_pad), dim3(LII_KNN_BS), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out);
 }
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);
