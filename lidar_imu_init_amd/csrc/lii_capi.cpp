@@ -56,6 +56,8 @@ RegistrationBuffers reg_buffers(const lii_context* c) {
   rb.n = c->n_body;
   rb.n_dev = c->n_body_pending ? c->d_nbody : nullptr;
   rb.cap = c->cfg.max_scan_points;
+  rb.flag_count = c->d_flags;
+  rb.flag_list = c->d_flags + 2;
   rb.shard_rank = c->net.rank;
   rb.shard_world = (c->net.n_ranks > 1 && c->net.library_partition && !c->body_partitioned) ? c->net.n_ranks : 1;
   if (c->solo_share < -1 && c->net.n_ranks <= 1) { rb.shard_world = -c->solo_share; rb.shard_rank = 0; }
@@ -344,7 +346,9 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   std::memset(h->h_mapflag, 0, 256);
   CK(hipEventCreateWithFlags(&h->ev_lists, hipEventDisableTiming));
   CK(hipMemset(h->d_counter, 0, 16));
-  h->partial_stride = register_blocks(int(N)) + 8;
+  h->partial_stride = register_blocks(int(N)) + lii::kCompletionBlocks + 8;  // (+ the columns of the fit launches' completion workgroups)
+  CK(dmalloc(&h->d_flags, 2 + 2 * lii::kFlagCap));
+  CK(hipMemset(h->d_flags, 0, sizeof(int) * (2 + 2 * lii::kFlagCap)));
   CK(dmalloc(&h->d_partials, size_t(h->partial_stride) * kNormalEq));
   CK(dmalloc(&h->d_out91, 256));  // [0,91): local sums, [128,219): all-reduced sums (sharded scans)
   CK(dmalloc(&h->d_gran, 256));
@@ -426,7 +430,7 @@ int lii_destroy(lii_handle h) {
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_ah_key, h->d_ah_best, h->d_ah_slot, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_gran, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
                  h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->vh.slots, h->vh.slot_of, h->vh.next, h->vh.counts, h->vh.crowded, h->cal.d_cal_imu, h->cal.d_cal_lidar, h->cal.d_cal_params,
-                 h->cal.d_cal_out};
+                 h->cal.d_cal_out, h->d_flags};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (h->ingest) ingest_destroy(h->ingest);

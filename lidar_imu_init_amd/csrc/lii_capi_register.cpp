@@ -9,8 +9,16 @@ using namespace lii_impl;
 namespace {
 
 
-void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose, int forced) {
-  lii::launch_knn(h->knn_variant, g, rb, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->stream);
+// (every enqueued search launch has a number, which the fit launch behind it shares: the list of unfinished queries the one leaves
+// and the other consumes - RegistrationBuffers::flag_*; 0 = no list: the exact-list kernel of test builds, and launches captured
+// into a hipGraph, whose arguments are frozen)
+int next_knn_epoch(lii_handle h, bool listed) {
+  if (!listed || h->knn_variant == 5) return 0;
+  h->knn_epoch = h->knn_epoch >= 0x3FFFFFFE ? 1 : h->knn_epoch + 1;  // (consecutive numbers alternate between the two slots, across the wrap as well)
+  return h->knn_epoch;
+}
+void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose, int forced, int epoch) {
+  lii::launch_knn(h->knn_variant, g, rb, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->stream, epoch);
 }
 
 
@@ -29,10 +37,11 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
     *stage = pose_of(*st);
     HIPCHK(h, hipMemcpyAsync(h->d_pose, stage, sizeof(PoseArg), hipMemcpyHostToDevice, h->stream));
   }
-  if (search) launch_knn(h, g, rb, h->d_pose, 1);
+  const int epoch = search ? next_knn_epoch(h, true) : 0;
+  if (search) launch_knn(h, g, rb, h->d_pose, 1, epoch);
   if (prof) HIPCHK(h, hipEventRecord(h->prof.ev[3], h->stream));
   launch_fit_reduce(g, rb, h->d_pose, h->d_ctrl, search ? 1 : 0, imu_en ? 1 : 0, h->cfg.plane_threshold,
-                    h->cfg.laser_point_cov_inv, h->stream);
+                    h->cfg.laser_point_cov_inv, h->stream, epoch);
   if (prof) HIPCHK(h, hipEventRecord(h->prof.ev[1], h->stream));
   launch_reduce91(rb, h->d_out91, h->d_ctrl, 1, h->stream);
   if (prof) HIPCHK(h, hipEventRecord(h->prof.ev[2], h->stream));
@@ -120,16 +129,19 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   const unsigned int plan0 = plan;
   // (profiling = HIP events around the k-NN launches only - the dominant kernel, lii_last_timings [5] / [7]; every event is a
   // barrier packet on the stream, so the rest of the loop is left alone: launch plan and result polling work as always)
+  const bool graph_mode = h->use_graph && !h->net.comm && !h->prof.profiling;
   auto enqueue_pass = [&](int it) -> int {
     const bool knn = it >= 16 || ((plan >> it) & 1u);
+    // (a fit launch that is not behind a search launch never runs as a search pass - the plan parks the loop instead - and needs no number)
+    const int epoch = knn ? next_knn_epoch(h, !graph_mode) : 0;
     if (knn) {
       if (prof && it < 16) HIPCHK(h, hipEventRecord(h->prof.ev_it[2 * it], s));
       if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_KNN, it); if (r != LII_OK) return r; }
-      launch_knn(h, g, rb, pose, -1);
+      launch_knn(h, g, rb, pose, -1, epoch);
       if (prof && it < 16) HIPCHK(h, hipEventRecord(h->prof.ev_it[2 * it + 1], s));
     }
     if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_FIT, it); if (r != LII_OK) return r; }
-    launch_fit_reduce(g, rb, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s);
+    launch_fit_reduce(g, rb, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s, epoch);
     if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_SOLVE, it); if (r != LII_OK) return r; }
     if (!h->net.comm) {  // single GPU or node-local mailbox: final sum (+ exchange) and solve in one launch
       launch_reduce_solve(rb, h->d_gran, h->d_ctrl, h->h_res, mailbox_view(h), s);
@@ -152,7 +164,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     }
     return LII_OK;
   };
-  if (h->use_graph && !h->net.comm && !h->prof.profiling) {
+  if (graph_mode) {
     // The same launches, captured once and replayed (hipGraphLaunch): every kernel argument of the loop is a device pointer or
     // a constant of the configuration, except the bound of the cloud size (rounded up here: the kernels take the exact size
     // from the device), the plan and the view of the map - the key of the cache.  Measured against the plain launches in

@@ -67,22 +67,24 @@ typedef unsigned int lii_u16v __attribute__((ext_vector_type(16)));
 typedef unsigned int lii_u2v __attribute__((ext_vector_type(2)));
 struct HeadScalars {
   PoseArg ps;
-  int search_next, stop, n_mem;
+  int search_next, stop, n_mem, extra;
 };
+// extra_ptr: one more int the kernel wants with the batch (a valid address; k_fit_reduce: the number of listed queries)
 __device__ __forceinline__ HeadScalars load_head_scalars(const PoseArg* __restrict__ pose, const int* __restrict__ search_next_and_stop,
-                                                         const int* __restrict__ n_ptr) {
+                                                         const int* __restrict__ n_ptr, const int* __restrict__ extra_ptr) {
   lii_u16v l0, l1, l2;
   lii_u2v fl;
-  unsigned int nm;
+  unsigned int nm, ex;
   asm volatile(
-      "s_load_dwordx16 %0, %5, 0x0\n\t"
-      "s_load_dwordx16 %1, %5, 0x40\n\t"
-      "s_load_dwordx16 %2, %5, 0x80\n\t"
-      "s_load_dwordx2 %3, %6, 0x0\n\t"
-      "s_load_dword %4, %7, 0x0\n\t"
+      "s_load_dwordx16 %0, %6, 0x0\n\t"
+      "s_load_dwordx16 %1, %6, 0x40\n\t"
+      "s_load_dwordx16 %2, %6, 0x80\n\t"
+      "s_load_dwordx2 %3, %7, 0x0\n\t"
+      "s_load_dword %4, %8, 0x0\n\t"
+      "s_load_dword %5, %9, 0x0\n\t"
       "s_waitcnt lgkmcnt(0)"
-      : "=&s"(l0), "=&s"(l1), "=&s"(l2), "=&s"(fl), "=&s"(nm)
-      : "s"(pose), "s"(search_next_and_stop), "s"(n_ptr)
+      : "=&s"(l0), "=&s"(l1), "=&s"(l2), "=&s"(fl), "=&s"(nm), "=&s"(ex)
+      : "s"(pose), "s"(search_next_and_stop), "s"(n_ptr), "s"(extra_ptr)
       : "memory");
   auto dbl = [](unsigned int lo, unsigned int hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
   HeadScalars h;
@@ -95,7 +97,7 @@ __device__ __forceinline__ HeadScalars load_head_scalars(const PoseArg* __restri
   m.RLI[4] = dbl(l2[0], l2[1]); m.RLI[5] = dbl(l2[2], l2[3]); m.RLI[6] = dbl(l2[4], l2[5]); m.RLI[7] = dbl(l2[6], l2[7]);
   m.RLI[8] = dbl(l2[8], l2[9]);
   m.TLI[0] = dbl(l2[10], l2[11]); m.TLI[1] = dbl(l2[12], l2[13]); m.TLI[2] = dbl(l2[14], l2[15]);
-  h.search_next = (int)fl[0]; h.stop = (int)fl[1]; h.n_mem = (int)nm;
+  h.search_next = (int)fl[0]; h.stop = (int)fl[1]; h.n_mem = (int)nm; h.extra = (int)ex;
   return h;
 }
 // The same pose in VECTOR registers (24 moves): a kernel that keeps the pose for its whole life has no scalar registers for it -
@@ -154,7 +156,13 @@ struct RegistrationBuffers {
   const int* n_dev;   // device-resident point count (set by the sync-free voxel filter), or nullptr
   int shard_rank;     // points of one scan sharded across ranks: this rank registers the contiguous
   int shard_world;    // block [n * rank / world, n * (rank + 1) / world) of the down-sampled cloud; world <= 1: all of it
+  // The queries a search pass could not finish (kNeedy), listed by that pass for the completion workgroups of the fit launch behind
+  // it (k_fit_reduce): flag_count[e & 1] entries in flag_list[(e & 1) * kFlagCap ...], e = the search launch's number (`epoch`).
+  int* flag_count;
+  int* flag_list;
 };
+constexpr int kFlagCap = 256;          // listed queries a fit launch hands to its completion workgroups (more: every workgroup finishes its own, as in round 4)
+constexpr int kCompletionBlocks = 32;  // ... of which there are this many, behind the workgroups of the cloud; each writes one more column of partial sums
 
 // The block of the down-sampled cloud this rank registers: first index and size.  Every rank holds the WHOLE cloud (the
 // de-skew and the voxel filter run replicated, so the cloud is bit-identical everywhere) and the split needs no exchange.

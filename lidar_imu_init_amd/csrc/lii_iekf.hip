@@ -551,6 +551,7 @@ void launch_reduce_solve(const RegistrationBuffers& rb, unsigned long long* gran
   const int bound = rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;  // as launch_fit_reduce
   int nb = (bound + kBlock - 1) / kBlock;
   if (nb < 1) nb = 1;
+  nb += kCompletionBlocks;  // (the columns of the fit launch's completion workgroups)
   hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq + 1), dim3(kSolveThreads), 0, s, rb.partials, nb, rb.partial_stride, gran, c, res, mb);
 }
 // A parked loop goes on with the launches the host has put behind this one (plan_mask, as IekfCtrl::plan_mask).

@@ -810,7 +810,7 @@ __device__ __forceinline__ void ck_scan(const float4* __restrict__ pts, const un
 template <int LPQ, int BS, int NB, int WPE>
 __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuffers rb, const PoseArg* __restrict__ pose,
                                                const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
-                                               double* __restrict__ search_pose_out) {
+                                               double* __restrict__ search_pose_out, int epoch) {
   using G = CkGeom<LPQ>;
   constexpr int QPB = BS / LPQ;
   __shared__ unsigned int s_tab[QPB * (G::MAXCH + NB)];
@@ -824,11 +824,14 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuff
   const bool early = rb.shard_world <= 1;
   float4 pb_early = make_float4(0.f, 0.f, 0.f, 0.f);
   if (early) pb_early = rb.body[min(max(ql, 0), rb.cap - 1)];
-  const HeadScalars hs = load_head_scalars(pose, &ctrl->search_next, rb.n_dev ? rb.n_dev : &ctrl->max_it);
+  const HeadScalars hs = load_head_scalars(pose, &ctrl->search_next, rb.n_dev ? rb.n_dev : &ctrl->max_it, &ctrl->max_it);
   const PoseArg& ps = hs.ps;
   const int c_search = hs.search_next, c_stop = hs.stop, n_mem = hs.n_mem;
   int lo, n_live;
   shard_range_n(rb, n_mem, lo, n_live);
+  // (the list of unfinished queries: launch number e appends to slot e & 1; EVERY enqueued launch - whether its pass is due or not -
+  // empties the other slot for launch e + 1: its readers, the fit launch behind launch e - 1, are done)
+  if (epoch > 0 && blockIdx.x == 0 && threadIdx.x == 0) rb.flag_count[(epoch + 1) & 1] = 0;
   if (forced < 0 && (c_stop || !c_search)) return;
   if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
   if (blk >= nb_real) return;
@@ -1030,7 +1033,13 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuff
       for (int r = 0; r < 5; r += LPQ)
         if (sub + r < 5 && sub + r >= found) rb.nbr[(size_t)(sub + r) * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
     }
-    if (sub == (LPQ > 1 ? 1 : 0)) rb.nbr_count[qi] = found | (need ? (kNeedy | ((ovf || amb) ? 0 : kCovered)) : 0);
+    if (sub == (LPQ > 1 ? 1 : 0)) {
+      rb.nbr_count[qi] = found | (need ? (kNeedy | ((ovf || amb) ? 0 : kCovered)) : 0);
+      if (need && epoch > 0) {  // listed for the completion workgroups of the fit launch behind this one (~80 of 95 k queries)
+        const int at = atomicAdd(&rb.flag_count[epoch & 1], 1);
+        if (at < kFlagCap) rb.flag_list[(epoch & 1) * kFlagCap + at] = qi;
+      }
+    }
     if (sub == (LPQ == 4 ? 2 : 0)) rb.world[qi] = make_float4(wx, wy, wz, 0.f);
   }
 }
@@ -1041,7 +1050,7 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuff
 template <int BS>
 __global__ __launch_bounds__(BS) void k_knn_exact(GridView g, RegistrationBuffers rb, const PoseArg* __restrict__ pose,
                                                   const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
-                                                  double* __restrict__ search_pose_out) {
+                                                  double* __restrict__ search_pose_out) {  // (lists no unfinished queries: its fit launches run with epoch 0)
   const PoseArg ps = load_pose(pose);
   int lo, n_live;
   shard_range(rb, lo, n_live);
@@ -1443,20 +1452,31 @@ __global__ __launch_bounds__(kBlock) void k_knn_complete(GridView g, Registratio
 // are spilled into vector-register lanes and fetched back one v_readlane at a time).  Measured: 100 k-point scan 5.9 against 6.5 us
 // per cached-plane launch, 500 k-point scan 18.4 against 17.6 (profiles/r05_head_loads.md): launch_fit_reduce picks by size.
 template <bool POSE_V>
-__global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationBuffers rb,
+__global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView g, RegistrationBuffers rb,
                                                         const PoseArg* __restrict__ pose,
                                                         const IekfCtrl* __restrict__ ctrl, int forced, int imu_en,
-                                                        double plane_thr, double rinv, int nb_real) {
+                                                        double plane_thr, double rinv, int nb_real, int epoch) {
   __shared__ ReduceShared sh;
   __shared__ NeedyShared sh_needy;
+  // The last kCompletionBlocks workgroups of the launch are COMPLETION workgroups (round 5): behind a search pass they finish the
+  // queries that pass listed as unfinished - and fit, gate and sum them like any other point, into a column of partial sums of their
+  // own - while the workgroups of the cloud leave those points out.  Round 4 had every workgroup finish its own flagged queries in
+  // front of its fit: four or five dependent round trips that ONE workgroup in five went through and the whole launch waited for
+  // (13.5 us per search-pass fit launch against 5.8 on cached planes).  Which workgroup takes which query, and in which order it adds
+  // them up, depends on the queries' indices alone: the sums stay deterministic.
+  // (they come FIRST in the grid - a launch with more workgroups than the chip holds at once must not start them last - and their
+  // number is a multiple of eight: the workgroups of the cloud keep their XCDs)
+  static_assert(kCompletionBlocks % 8 == 0, "XCD mapping of the cloud's workgroups");
+  const bool completion_wg = (int)blockIdx.x < kCompletionBlocks;
+  const int cloud_block = (int)blockIdx.x - kCompletionBlocks;
   // What a lane reads of its point whatever the pass turns out to be - body point, cached plane, selection flag, world point,
   // neighbour count - is requested BEFORE the flags, the pose and the cloud size have arrived (an unsharded cloud: the point's
   // index does not depend on them; the index is clamped, a lane beyond the cloud discards what it read): one dependent round
   // trip instead of two at the head of every fit launch.
   // (the flags, the size of the cloud and the pose - scalar requests - go out first, the point's data right behind them; all of it is
   // waited for once: k_knn_ck)
-  const int q_early = fit_point_of(xcd_remap(blockIdx.x, nb_real), nb_real);
-  const bool early = rb.shard_world <= 1;
+  const int q_early = fit_point_of(xcd_remap(completion_wg ? 0 : cloud_block, nb_real), nb_real);
+  const bool early = rb.shard_world <= 1 && !completion_wg;
   const int ie = min(max(q_early, 0), rb.cap - 1);
   float4 e_body = make_float4(0.f, 0.f, 0.f, 0.f), e_world = e_body;
   double e_pl[4] = {0, 0, 0, 0};
@@ -1470,7 +1490,7 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
     e_count = rb.nbr_count[ie];
     e_sel = rb.selected[ie];
   }
-  const HeadScalars hs = load_head_scalars(pose, &ctrl->search_next, rb.n_dev ? rb.n_dev : &ctrl->max_it);
+  const HeadScalars hs = load_head_scalars(pose, &ctrl->search_next, rb.n_dev ? rb.n_dev : &ctrl->max_it, epoch > 0 ? rb.flag_count + (epoch & 1) : &ctrl->max_it);
   asm volatile("" : "+v"(e_sel));  // (the selection flag is not looked at before this point: the compiler tests it where it is loaded, and the wait for it would stand in front of the scalar requests)
   PoseArg ps = hs.ps;
   if (POSE_V) ps = pose_to_vgprs(hs.ps);
@@ -1484,25 +1504,79 @@ __global__ __launch_bounds__(kBlock) void k_fit_reduce(GridView g, RegistrationB
     if (c_stop) return;
     FIT = c_search != 0;
   }
-  const int blk = xcd_remap(blockIdx.x, nb_real);
-  if (blk >= nb_real) return;  // uniform per block
-  const int q = fit_point_of(blk, nb_real);
-  const int i = lo + q;
-  const bool live = q < n_live;
+  // the unfinished queries of the search pass go to the completion workgroups when the pass could list them all
+  const int n_flagged = epoch > 0 ? hs.extra : kFlagCap + 1;
+  const bool defer = FIT && n_flagged <= kFlagCap;  // (uniform over the launch)
+  int blk, i;
+  bool live;
   float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (FIT) {  // uniform per workgroup
-    const int count0 = live ? (early ? e_count : rb.nbr_count[i]) : 0;
-    if (live) w4 = early ? e_world : rb.world[i];  // written by the search pass with the same arithmetic
-    // (the far lists live where the launch's final reduction stages its rows later: one wavefront's row area holds kFarCap words)
-    static_assert(sizeof(sh.row[0]) >= sizeof(unsigned int) * kFarCap, "far list");
-    complete_flagged(g, rb, i, live, count0, w4, sh_needy, reinterpret_cast<unsigned int*>(&sh.row[0][0]));
+  bool skip_row = false;  // a flagged point in a workgroup of the cloud: the completion workgroups own it
+  if (!completion_wg) {
+    blk = xcd_remap(cloud_block, nb_real);
+    if (blk >= nb_real) return;  // uniform per block
+    const int q = fit_point_of(blk, nb_real);
+    i = lo + q;
+    live = q < n_live;
+    if (FIT) {  // uniform per workgroup
+      const int count0 = live ? (early ? e_count : rb.nbr_count[i]) : 0;
+      if (live) w4 = early ? e_world : rb.world[i];  // written by the search pass with the same arithmetic
+      if (defer) {
+        skip_row = live && (count0 & kNeedy) != 0;
+      } else {
+        // (the far lists live where the launch's final reduction stages its rows later: one wavefront's row area holds kFarCap words)
+        static_assert(sizeof(sh.row[0]) >= sizeof(unsigned int) * kFarCap, "far list");
+        complete_flagged(g, rb, i, live, count0, w4, sh_needy, reinterpret_cast<unsigned int*>(&sh.row[0][0]));
+      }
+    }
+  } else {
+    // Completion workgroup j: the listed queries with (index / 4) % kCompletionBlocks == j (clusters of flagged queries - a stretch of
+    // the sweep that looks past the edge of the map - are dealt out over the workgroups), in ascending order of their index: lane L
+    // takes the L-th.  Not behind a search pass, or with the queries left to their own workgroups: nothing to do but the zero column.
+    blk = nb_real + (int)blockIdx.x;
+    i = 0;
+    live = false;
+    if (defer) {
+      const int j = (int)blockIdx.x;
+      int* s_raw = sh_needy.point;   // (NeedyShared's arrays hold kBlock >= kFlagCap entries)
+      int* s_sorted = sh_needy.count;
+      static_assert(kFlagCap <= kBlock, "one lane per listed query");
+      if (threadIdx.x == 0) sh_needy.n = 0;
+      __syncthreads();
+      const int* list = rb.flag_list + (epoch & 1) * kFlagCap;
+      if ((int)threadIdx.x < n_flagged) {
+        const int qx = list[threadIdx.x];
+        if (((qx >> 2) % kCompletionBlocks) == j) s_raw[atomicAdd(&sh_needy.n, 1)] = qx;
+      }
+      __syncthreads();
+      const int m = sh_needy.n;
+      if ((int)threadIdx.x < m) {
+        const int x = s_raw[threadIdx.x];
+        int rank = 0;
+        for (int u = 0; u < m; u++) rank += s_raw[u] < x ? 1 : 0;
+        s_sorted[rank] = x;
+      }
+      __syncthreads();
+      const int wave = threadIdx.x >> 6;
+      for (int e = wave; e < m; e += kBlock / 64) {  // one wavefront per query
+        const int qx = s_sorted[e];
+        const int c00 = rb.nbr_count[qx];
+        const float4 wq = rb.world[qx];
+        complete_one(g, rb, qx, c00, wq.x, wq.y, wq.z, reinterpret_cast<unsigned int*>(&sh.row[0][0]) + wave * kFarCap);
+      }
+      __syncthreads();  // the completed lists are visible to the lanes that fit them (workgroup-scope release / acquire)
+      if ((int)threadIdx.x < m) {
+        i = s_sorted[threadIdx.x];
+        live = true;
+        w4 = rb.world[i];
+      }
+    }
   }
   RowOut o;
 #pragma unroll
   for (int c = 0; c < 12; c++) o.h[c] = 0;
   o.z = 0;
   o.sel = false;
-  if (live) {
+  if (live && !skip_row) {
     const float4 pb = early ? e_body : rb.body[i];
     double bx = pb.x, by = pb.y, bz = pb.z;
     double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
@@ -1711,8 +1785,10 @@ static inline int shard_bound(const RegistrationBuffers& rb) {
 #ifndef LII_KNN_WPE
 #define LII_KNN_WPE 7
 #endif
+// epoch: the number of this search launch (> 0; the fit launch behind it gets the same) - or 0: no list of unfinished queries, every
+// workgroup of the fit launch finishes its own (hipGraph replays, whose arguments are frozen; k_knn_exact)
 void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
-                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s) {
+                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s, int epoch) {
   int nq = nblk(shard_bound(rb), LII_KNN_BS / 4);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
@@ -1723,7 +1799,7 @@ void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, c
   }
 #endif
   (void)variant;
-  hipLaunchKernelGGL((k_knn_ck<4, LII_KNN_BS, LII_KNN_NB, LII_KNN_WPE>), dim3(nq_pad), dim3(LII_KNN_BS), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out);
+  hipLaunchKernelGGL((k_knn_ck<4, LII_KNN_BS, LII_KNN_NB, LII_KNN_WPE>), dim3(nq_pad), dim3(LII_KNN_BS), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out, epoch);
 }
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);
@@ -1731,17 +1807,19 @@ void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipSt
   hipLaunchKernelGGL(k_knn_complete, dim3(nb), dim3(kBlock), 0, s, g, rb);
 }
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
-                       const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s) {
+                       const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s, int epoch) {
   int nb = nblk(shard_bound(rb), kBlock);
   if (nb < 1) nb = 1;
   const int nb_pad = ((nb + 7) / 8) * 8;
   // (four wavefronts per workgroup on 1024 SIMDs: up to 512 workgroups are two wavefronts per SIMD at most)
-  if (nb <= 512) hipLaunchKernelGGL(k_fit_reduce<true>, dim3(nb_pad), dim3(kBlock), 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb);
-  else hipLaunchKernelGGL(k_fit_reduce<false>, dim3(nb_pad), dim3(kBlock), 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb);
+  // (+ the completion workgroups behind the workgroups of the cloud)
+  if (nb <= 512) hipLaunchKernelGGL(k_fit_reduce<true>, dim3(nb_pad + kCompletionBlocks), dim3(kBlock), 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb, epoch);
+  else hipLaunchKernelGGL(k_fit_reduce<false>, dim3(nb_pad + kCompletionBlocks), dim3(kBlock), 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb, epoch);
 }
 void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);
   if (nb < 1) nb = 1;
+  nb += kCompletionBlocks;  // (the columns of the fit launch's completion workgroups)
   hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(256), 0, s, rb.partials, nb, rb.partial_stride, out91, ctrl, forced, rb);
 }
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,
