@@ -57,7 +57,7 @@ RegistrationBuffers reg_buffers(const lii_context* c) {
   rb.n_dev = c->n_body_pending ? c->d_nbody : nullptr;
   rb.cap = c->cfg.max_scan_points;
   rb.flag_count = c->d_flags;
-  rb.flag_list = c->d_flags + 2;
+  rb.flag_list = reinterpret_cast<float4*>(c->d_flags + 4);
   rb.shard_rank = c->net.rank;
   rb.shard_world = (c->net.n_ranks > 1 && c->net.library_partition && !c->body_partitioned) ? c->net.n_ranks : 1;
   if (c->solo_share < -1 && c->net.n_ranks <= 1) { rb.shard_world = -c->solo_share; rb.shard_rank = 0; }
@@ -347,8 +347,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(hipEventCreateWithFlags(&h->ev_lists, hipEventDisableTiming));
   CK(hipMemset(h->d_counter, 0, 16));
   h->partial_stride = register_blocks(int(N)) + lii::kCompletionBlocks + 8;  // (+ the columns of the fit launches' completion workgroups)
-  CK(dmalloc(&h->d_flags, 2 + 2 * lii::kFlagCap));
-  CK(hipMemset(h->d_flags, 0, sizeof(int) * (2 + 2 * lii::kFlagCap)));
+  CK(dmalloc(&h->d_flags, 4 + 16 * lii::kFlagCap));  // 2 counters (+ 2 pad), 2 x kFlagCap entries of two float4
+  CK(hipMemset(h->d_flags, 0, sizeof(int) * (4 + 16 * lii::kFlagCap)));
   CK(dmalloc(&h->d_partials, size_t(h->partial_stride) * kNormalEq));
   CK(dmalloc(&h->d_out91, 256));  // [0,91): local sums, [128,219): all-reduced sums (sharded scans)
   CK(dmalloc(&h->d_gran, 256));

@@ -164,7 +164,7 @@ struct lii_context {
   bool have_search = false;
   int knn_variant = 0;   // search pass: 0 = k_knn_ck (the product form); 5 = exact lists throughout (k_knn_exact: builds with -DLII_KNN_EXACT
                          // only) - LII_KNN_VARIANT
-  int* d_flags = nullptr;       // the lists of unfinished queries (RegistrationBuffers::flag_count / flag_list): 2 counters + 2 x kFlagCap entries
+  int* d_flags = nullptr;       // the lists of unfinished queries (RegistrationBuffers::flag_count / flag_list): 2 counters + 2 x kFlagCap entries of two float4
   int knn_epoch = 0;            // number of the last enqueued search launch (never 0 again once used)
   hipStream_t map_stream = nullptr;  // the in-place update of lii_map_incremental runs here, beside the next scan's pre-processing
   bool map_async = false;            // ... and may still be running (map_join waits for it: ev_mapflag is its last packet)

@@ -158,8 +158,9 @@ struct RegistrationBuffers {
   int shard_world;    // block [n * rank / world, n * (rank + 1) / world) of the down-sampled cloud; world <= 1: all of it
   // The queries a search pass could not finish (kNeedy), listed by that pass for the completion workgroups of the fit launch behind
   // it (k_fit_reduce): flag_count[e & 1] entries in flag_list[(e & 1) * kFlagCap ...], e = the search launch's number (`epoch`).
+  // An entry is everything the completion needs to start with: (world point, query index) and (neighbour count with its flags, -, -, -).
   int* flag_count;
-  int* flag_list;
+  float4* flag_list;  // 2 x kFlagCap entries of two float4
 };
 constexpr int kFlagCap = 256;          // listed queries a fit launch hands to its completion workgroups (more: every workgroup finishes its own, as in round 4)
 constexpr int kCompletionBlocks = 32;  // ... of which there are this many, behind the workgroups of the cloud; each writes one more column of partial sums

@@ -1034,10 +1034,15 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuff
         if (sub + r < 5 && sub + r >= found) rb.nbr[(size_t)(sub + r) * rb.cap + qi] = make_float4(0.f, 0.f, 0.f, INF);
     }
     if (sub == (LPQ > 1 ? 1 : 0)) {
-      rb.nbr_count[qi] = found | (need ? (kNeedy | ((ovf || amb) ? 0 : kCovered)) : 0);
+      const int cflags = found | (need ? (kNeedy | ((ovf || amb) ? 0 : kCovered)) : 0);
+      rb.nbr_count[qi] = cflags;
       if (need && epoch > 0) {  // listed for the completion workgroups of the fit launch behind this one (~80 of 95 k queries)
         const int at = atomicAdd(&rb.flag_count[epoch & 1], 1);
-        if (at < kFlagCap) rb.flag_list[(epoch & 1) * kFlagCap + at] = qi;
+        if (at < kFlagCap) {
+          float4* e = rb.flag_list + 2 * ((epoch & 1) * kFlagCap + at);
+          e[0] = make_float4(wx, wy, wz, __int_as_float(qi));
+          e[1] = make_float4(__int_as_float(cflags), 0.f, 0.f, 0.f);
+        }
       }
     }
     if (sub == (LPQ == 4 ? 2 : 0)) rb.world[qi] = make_float4(wx, wy, wz, 0.f);
@@ -1403,6 +1408,7 @@ __device__ __forceinline__ void complete_one(const GridView& g, const Registrati
 struct NeedyShared {
   int point[kBlock], count[kBlock];
   float w[kBlock][3];
+  int aux[kBlock], key[kBlock];  // (completion workgroups: the listed queries in ascending order; as listed)
   int n;
 };
 // `count`, `w`: nbr_count and world point of the calling lane's query (loaded by the caller, together).
@@ -1537,37 +1543,42 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
     live = false;
     if (defer) {
       const int j = (int)blockIdx.x;
-      int* s_raw = sh_needy.point;   // (NeedyShared's arrays hold kBlock >= kFlagCap entries)
-      int* s_sorted = sh_needy.count;
       static_assert(kFlagCap <= kBlock, "one lane per listed query");
       if (threadIdx.x == 0) sh_needy.n = 0;
       __syncthreads();
-      const int* list = rb.flag_list + (epoch & 1) * kFlagCap;
+      // the entries of this workgroup: their positions in the list first (sh_needy.point), then - ranked by query index - the queries
+      // (aux), their neighbour counts with the flags (count) and world points (w): everything complete_one starts from, in LDS
+      const float4* list = rb.flag_list + 2 * (epoch & 1) * kFlagCap;
       if ((int)threadIdx.x < n_flagged) {
-        const int qx = list[threadIdx.x];
-        if (((qx >> 2) % kCompletionBlocks) == j) s_raw[atomicAdd(&sh_needy.n, 1)] = qx;
+        const int qx = __float_as_int(list[2 * threadIdx.x].w);
+        if (((qx >> 2) % kCompletionBlocks) == j) {
+          const int at = atomicAdd(&sh_needy.n, 1);
+          sh_needy.point[at] = (int)threadIdx.x;
+          sh_needy.key[at] = qx;
+        }
       }
       __syncthreads();
       const int m = sh_needy.n;
       if ((int)threadIdx.x < m) {
-        const int x = s_raw[threadIdx.x];
+        const int at = sh_needy.point[threadIdx.x];
+        const float4 e0 = list[2 * at], e1 = list[2 * at + 1];
+        const int x = __float_as_int(e0.w);
         int rank = 0;
-        for (int u = 0; u < m; u++) rank += s_raw[u] < x ? 1 : 0;
-        s_sorted[rank] = x;
+        for (int u = 0; u < m; u++) rank += sh_needy.key[u] < x ? 1 : 0;
+        sh_needy.aux[rank] = x;
+        sh_needy.count[rank] = __float_as_int(e1.x);
+        sh_needy.w[rank][0] = e0.x; sh_needy.w[rank][1] = e0.y; sh_needy.w[rank][2] = e0.z;
       }
       __syncthreads();
       const int wave = threadIdx.x >> 6;
-      for (int e = wave; e < m; e += kBlock / 64) {  // one wavefront per query
-        const int qx = s_sorted[e];
-        const int c00 = rb.nbr_count[qx];
-        const float4 wq = rb.world[qx];
-        complete_one(g, rb, qx, c00, wq.x, wq.y, wq.z, reinterpret_cast<unsigned int*>(&sh.row[0][0]) + wave * kFarCap);
-      }
+      for (int e = wave; e < m; e += kBlock / 64)  // one wavefront per query
+        complete_one(g, rb, sh_needy.aux[e], sh_needy.count[e], sh_needy.w[e][0], sh_needy.w[e][1], sh_needy.w[e][2],
+                     reinterpret_cast<unsigned int*>(&sh.row[0][0]) + wave * kFarCap);
       __syncthreads();  // the completed lists are visible to the lanes that fit them (workgroup-scope release / acquire)
       if ((int)threadIdx.x < m) {
-        i = s_sorted[threadIdx.x];
+        i = sh_needy.aux[threadIdx.x];
         live = true;
-        w4 = rb.world[i];
+        w4 = make_float4(sh_needy.w[threadIdx.x][0], sh_needy.w[threadIdx.x][1], sh_needy.w[threadIdx.x][2], 0.f);
       }
     }
   }
