@@ -1107,10 +1107,21 @@ __global__ __launch_bounds__(BS) void k_knn_exact(GridView g, RegistrationBuffer
 // nothing.  Two passes: the 3x3x3 cells around the query first; their exact top-5 gives the bound that prunes the (up to
 // ~1300) outer cells.  The per-lane sorted lists are merged by five rounds of "wave-wide minimum of the list heads, owner
 // pops" — ~25 instructions per round instead of a 6-step butterfly of 5-element insertions.  The result is wave-uniform.
-__device__ __forceinline__ float wave_min_f32(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-  return v;
+// (reductions over the wavefront on DPP row operations: ~60 cycles where six rounds of __shfl_xor - LDS permutes - take ~700; the
+// completion of ONE query runs ten of them, on the critical path of the fit launch)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned int dpp_u32(unsigned int old, unsigned int v) {
+  return (unsigned int)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ float wave_min_f32(float v) {  // v >= 0 or +inf: the bit patterns order like the values
+  unsigned int x = __float_as_uint(v);
+  x = min(x, dpp_u32<0xB1, 0xF>(x, x));    // quad_perm [1, 0, 3, 2]
+  x = min(x, dpp_u32<0x4E, 0xF>(x, x));    // quad_perm [2, 3, 0, 1]
+  x = min(x, dpp_u32<0x141, 0xF>(x, x));   // row_half_mirror
+  x = min(x, dpp_u32<0x140, 0xF>(x, x));   // row_mirror: every lane of a row of 16 holds the row's minimum
+  x = min(x, dpp_u32<0x142, 0xA>(x, x));   // row_bcast15 into rows 1 and 3
+  x = min(x, dpp_u32<0x143, 0xC>(x, x));   // row_bcast31 into rows 2 and 3: lane 63 holds the minimum of all
+  return __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)x, 63));
 }
 // pops the 5 smallest (d, idx) over the lists of all lanes into uniform arrays; lists must be sorted ascending (Knn5 is)
 __device__ __forceinline__ void wave_select5(Knn5 k, float (&od)[5], int (&oi)[5]) {
@@ -1121,7 +1132,7 @@ __device__ __forceinline__ void wave_select5(Knn5 k, float (&od)[5], int (&oi)[5
     if (owners == 0ull) { od[r] = __builtin_inff(); oi[r] = -1; continue; }  // fewer than r + 1 candidates in total
     const int owner = __ffsll((long long)owners) - 1;
     od[r] = m;
-    oi[r] = __shfl(k.i0, owner);
+    oi[r] = __builtin_amdgcn_readlane(k.i0, owner);  // (owner is uniform)
     if ((int)(threadIdx.x & 63) == owner) {
       k.d0 = k.d1; k.d1 = k.d2; k.d2 = k.d3; k.d3 = k.d4; k.d4 = __builtin_inff();
       k.i0 = k.i1; k.i1 = k.i2; k.i2 = k.i3; k.i3 = k.i4; k.i4 = -1;
@@ -1155,14 +1166,16 @@ __device__ __forceinline__ void far_candidates(const GridView& g, const uint2 (&
 // chunks, four rounds.
 constexpr int kFarCap = 2048;  // chunks the list holds (it lives in the LDS the launch's final reduction uses later: ReduceShared::row)
 __device__ __forceinline__ unsigned int wave_excl_prefix_u32(unsigned int v, unsigned int* total) {
-  const int lane = threadIdx.x & 63;
+  // inclusive scan inside the rows of 16 (row_shr 1, 2, 4, 8: lanes shifted in from outside a row read 0), then the totals of the rows
+  // in front (row_bcast15, row_bcast31)
   unsigned int x = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const unsigned int y = (unsigned int)__shfl_up((int)x, off);
-    x += lane >= off ? y : 0u;
-  }
-  *total = (unsigned int)__shfl((int)x, 63);
+  x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+  x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+  x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+  x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+  x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+  x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+  *total = (unsigned int)__builtin_amdgcn_readlane((int)x, 63);
   return x - v;
 }
 // the chunks of NB cell ranges to list[at ...]
@@ -1202,9 +1215,9 @@ __device__ __forceinline__ void far_list_trip(const GridView& g, unsigned int* _
   unsigned int mine = 0u;
 #pragma unroll
   for (int b = 0; b < NB; b++) mine += (rr[b].y - rr[b].x + 3u) >> 2;
+  if (!__any(mine != 0u)) return;  // (uniform) nothing in this trip: most trips of a ball that reaches past the map
   unsigned int total;
   const unsigned int before = wave_excl_prefix_u32(mine, &total);
-  if (total == 0u) return;  // (uniform)
   if (total > (unsigned)kFarCap) {
     far_candidates<NB>(g, rr, wx, wy, wz, bound1, k);
     return;
