@@ -546,7 +546,7 @@ def main():
         # HBM traffic of the dominant kernel per launch: PMC counters cannot be read inside this process - the figure comes from
         # the committed rocprofv3 --pmc passes of the same command (tools/collect_pmc.sh) and is labelled as such
         traffic, traffic_source = None, None
-        for prof_name in ("r04_pmc_knn.json", "r03_pmc_knn.json", "r02_pmc_knn.json"):
+        for prof_name in ("r05_pmc_knn.json", "r04_pmc_knn.json"):  # (r04: the per-lane search kernel of round 4 - only until round 5's passes are committed)
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
                 if prof.get("workload") == args.workload:
@@ -615,7 +615,7 @@ def main():
             out["roofline"]["kernels_note"] = (f"HIP events in front of every launch over {kp_scans} extra scans (lii_set_profiling(h, 3)): event-to-event "
                                                "time = kernel + dispatch, in a pass that runs slower than the timed region (every event is a barrier "
                                                f"packet: {1e3 * tot_ms / max(kp_scans, 1):.1f} us per scan here against ms_per_step); rocprofv3 durations of the same "
-                                               "kernels: profiles/r04_timeline.md")
+                                               "kernels: profiles/r05_timeline.md")
         if transports is not None:
             out["transports"] = transports
             out["partitions"] = partitions
