@@ -351,6 +351,10 @@ def main():
             totals[:] = 0
             native(0, n_steps, args.profile_every)
             t_native = time.perf_counter() - t0
+            if hasattr(drv, "lii_stream_last_slowest"):
+                sl = np.zeros(3)
+                drv.lii_stream_last_slowest(C.c_void_p(sl.ctypes.data))
+                slowest_step.update(ms=sl[0] / 1e3, index=int(sl[1]), second_ms=sl[2] / 1e3)
             iters_total[0], search_total[0] = int(totals[0]), int(totals[1])
             last = last_pod
         else:
@@ -377,6 +381,7 @@ def main():
         return dt
 
     last = None
+    slowest_step = {}  # of the most recent timed region (host clock per step, C++ host loop only)
     transports = None
     if world > 1:
         # A sharded job is timed once per transport of the 91-scalar exchange, same steps, same scans: the default (the library's
@@ -425,6 +430,7 @@ def main():
         last_pose_value = np.array(last.pod[:12]) if last is not None else None
     tm = reg.timings()
     iters_value, searches_value = iters_total[0], search_total[0]
+    slowest_value = dict(slowest_step)
     # The driver's form of this command times 20 steps (~3 ms): a second, longer region of the same steps right behind it gives the
     # line a figure to check `value` against (never `value` itself).
     value_long = None
@@ -579,6 +585,9 @@ def main():
         }
         if value_long is not None:
             out["value_long"] = value_long
+        if slowest_value:  # a one-off stall of the runtime inside the region shows here (and in value vs value_long), not in the kernels
+            out["slowest_step"] = dict(slowest_value, what="longest and second-longest step of `value`'s region on the host clock (call to return; "
+                                       "steps with event brackets - every --profile-every-th - are the usual holders)")
         if last_pose_value is not None:  # final pose of the last step of `value`'s region (rot_end row-major, pos_end): a sharded job must land where one rank does
             out["last_state_pose"] = [float(v) for v in last_pose_value]
         if world > 1:

@@ -33,6 +33,11 @@ typedef struct lii_stream_scan {
 // Runs steps [first, first + steps) of the cyclic stream.  profile_every > 0: HIP-event kernel timing on every Nth step;
 // profile_every < 0: every launch of every step bracketed (lii_set_profiling(h, 3): lii_last_kernel_profile).
 // Returns the first non-zero library status; totals[0] += iterations, totals[1] += k-NN passes.
+// The slowest step of the last lii_stream_run (host clock, call to return) and where it sat: a one-off stall of the runtime (a pool
+// that grows, a page that is read in) shows here instead of hiding in the mean.  out: {slowest [us], its step index, second slowest [us]}
+static double g_slowest[3];
+void lii_stream_last_slowest(double out[3]) { std::memcpy(out, g_slowest, sizeof(g_slowest)); }
+
 int lii_stream_run(lii_handle h, const lii_stream_scan* scans, int32_t n_scans, int32_t first, int32_t steps, float leaf,
                    int32_t max_iterations, int32_t imu_en, int32_t map_update, int32_t profile_every, int64_t totals[2],
                    lii_state* last_state) {
@@ -41,7 +46,16 @@ int lii_stream_run(lii_handle h, const lii_stream_scan* scans, int32_t n_scans, 
   lii_iekf_report rep;
   const bool trace = std::getenv("LII_STREAM_TRACE") != nullptr;  // per-step wall time on stderr (diagnostic)
   auto t_prev = std::chrono::steady_clock::now();
+  auto t_step = t_prev;
+  g_slowest[0] = g_slowest[1] = g_slowest[2] = 0.0;
   for (int32_t k = first; k < first + steps; k++) {
+    if (k > first) {
+      const auto t_now = std::chrono::steady_clock::now();
+      const double us = std::chrono::duration<double, std::micro>(t_now - t_step).count();
+      t_step = t_now;
+      if (us > g_slowest[0]) { g_slowest[2] = g_slowest[0]; g_slowest[0] = us; g_slowest[1] = k - 1 - first; }
+      else if (us > g_slowest[2]) g_slowest[2] = us;
+    }
     if (trace && k > first) {
       const auto t_now = std::chrono::steady_clock::now();
       std::fprintf(stderr, "%.1f ", std::chrono::duration<double, std::micro>(t_now - t_prev).count());

@@ -19,12 +19,14 @@
 extern "C" {
 #endif
 
-#define LII_ABI_VERSION 6 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
+#define LII_ABI_VERSION 7 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
                              3: lii_params_*, lii_comm_set_partition (library-side split of the down-sampled cloud)
                              4: lii_scan_upload_next / lii_scan_advance (the next scan travels while the current one registers)
                              5: LII_COMM_MAILBOX = the peer-mapped HBM mailbox (HIP IPC), LII_COMM_MAILBOX_HOST, lii_comm_rccl_ranks
                              6: lii_scan_job::scan_sorted (struct_size 56; a job of size 48 - ABI 5 - is still accepted), lii_last_kernel_profile,
-                                lii_comm_describe, lii_comm_set_partition(h, 2) (split by voxel), lii_scan_job::map_update (the reserved field) */
+                                lii_comm_describe, lii_comm_set_partition(h, 2) (split by voxel), lii_scan_job::map_update (the reserved field)
+                             7: lii_ingest_opts::cut_frame_num = 0 (the whole message as one frame: Preprocess::process), lii_last_solve_info,
+                                lii_selftest_list_exchange */
 
 enum lii_status {
   LII_OK = 0,
@@ -240,6 +242,11 @@ int lii_iekf_iterate(lii_handle h, const lii_state* state, int32_t search, int32
 int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_propagated, const lii_iekf_opts* opts,
                     lii_iekf_report* report);
 int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* selected, int32_t capacity);
+/* How the last device-resident update solved its passes: *pivoted_passes = the passes (of the first 16) whose 12 x 12 elimination left the
+ * pivot-free form for the routine with row exchanges (its element growth exceeded 2^8, or a pivot was zero).  The reference inverts
+ * with Eigen's partial-pivoting LU every time (src/laserMapping.cpp:1081-1085); the result is held to the same tolerance either way -
+ * the count exists so that tests can tell which routine they exercised. */
+int lii_last_solve_info(lii_handle h, int32_t* pivoted_passes);
 
 /* The per-scan sequence of main() (src/laserMapping.cpp:909-1134) in ONE call, enqueued back to back on the handle's
  * stream with a single host round trip at the end: p_imu->Process' undistortion (:909; the scan is the one handed over by

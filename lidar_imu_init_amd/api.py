@@ -116,6 +116,7 @@ _DECLS = {
                                   C.POINTER(lii_iekf_report)]),
     "lii_scan_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(lii_iekf_report)]),
     "lii_neighbors_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "lii_last_solve_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "lii_map_incremental": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lii_calib_set_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "lii_calib_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
@@ -547,6 +548,12 @@ class Registrar:
         """ncclCommCount of the attached RCCL communicator (0: no RCCL communicator)."""
         n = C.c_int32(0)
         self._check(self.L.lii_comm_rccl_ranks(self.h, C.byref(n)))
+        return int(n.value)
+
+    def last_solve_info(self):
+        """Passes of the last device-resident update whose 12 x 12 elimination needed the routine with row exchanges."""
+        n = C.c_int32(0)
+        self._check(self.L.lii_last_solve_info(self.h, C.byref(n)))
         return int(n.value)
 
     def selftest_list_exchange(self, add_lists, nodown_lists, form):

@@ -299,8 +299,8 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
       if (kind >= LII_KP_KINDS) continue;
       const bool loop_kind = kind == LII_KP_KNN || kind == LII_KP_FIT || kind == LII_KP_SOLVE;
       if (loop_kind && (it >= hr->it || it >= 16)) continue;
-      if (kind == LII_KP_KNN && !hr->search_log[it]) continue;
-      if (kind == LII_KP_FIT && hr->search_log[it]) kind = LII_KP_FIT_SEARCH;
+      if (kind == LII_KP_KNN && !(hr->search_log[it] & 1)) continue;
+      if (kind == LII_KP_FIT && (hr->search_log[it] & 1)) kind = LII_KP_FIT_SEARCH;
       float ms = 0;
       if (hipEventElapsedTime(&ms, h->prof.kp_ev[size_t(i)], h->prof.kp_ev[size_t(i + 1)]) != hipSuccess) continue;
       h->prof.kprof.ms[kind] += ms;
@@ -317,10 +317,12 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   if (hr->singular) return fail(h, LII_ERR_INVALID, "singular covariance / normal matrix in the device solve");
   if (hr->it < 0) return fail(h, LII_ERR_HIP, "device loop ended without a result");
   std::memcpy(state, hr->st, sizeof(lii_state));
+  h->last_pivoted_passes = 0;
+  for (int q = 0; q < 16 && q < hr->it; q++) h->last_pivoted_passes += (hr->search_log[q] >> 1) & 1;
   {  // the next update's plan: this one's pattern; passes it did not reach keep their launch
     unsigned int next = 0xFFFFFFFFu;
     for (int q = 0; q < 16 && q < hr->it; q++)
-      if (!hr->search_log[q]) next &= ~(1u << q);
+      if (!(hr->search_log[q] & 1)) next &= ~(1u << q);
     // ... and as many passes as the longer of the last two updates ran (a scan that needs more parks and is continued)
     for (int q = std::max(hr->it, h->plan_passes_prev); q < 16; q++) next &= ~(1u << (16 + q));
     h->plan_passes_prev = hr->it;
@@ -337,7 +339,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     // the k-NN kernel alone, over EVERY pass that actually searched (the device logs which iterations did); the events were
     // recorded ahead of the stopping pass, whose result has arrived: they have completed
     for (int it = 0; it < opts->max_iterations && it < 16; it++) {
-      if (it >= hr->it || !hr->search_log[it] || !((plan0 >> it) & 1u)) continue;
+      if (it >= hr->it || !(hr->search_log[it] & 1) || !((plan0 >> it) & 1u)) continue;
       float kk = 0;
       if (hipEventElapsedTime(&kk, h->prof.ev_it[2 * it], h->prof.ev_it[2 * it + 1]) != hipSuccess) continue;
       h->prof.timings[7] += kk;
@@ -353,6 +355,12 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
 extern "C" {
 
 // ------------------------------------------------------------------------------------------------ registration
+int lii_last_solve_info(lii_handle h, int32_t* pivoted_passes) {
+  if (!h || !pivoted_passes) return LII_ERR_INVALID;
+  *pivoted_passes = h->last_pivoted_passes;
+  return LII_OK;
+}
+
 int lii_iekf_iterate(lii_handle h, const lii_state* state, int32_t search, int32_t imu_en, double out91[91]) {
   if (!h || !state || !out91) return fail(h, LII_ERR_INVALID, "lii_iekf_iterate: bad arguments");
   return iterate(h, state, search != 0, imu_en != 0, out91);

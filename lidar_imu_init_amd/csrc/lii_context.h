@@ -166,6 +166,7 @@ struct lii_context {
                          // only) - LII_KNN_VARIANT
   int* d_flags = nullptr;       // the lists of unfinished queries (RegistrationBuffers::flag_count / flag_list): 2 counters + 2 x kFlagCap entries of two float4
   int knn_epoch = 0;            // number of the last enqueued search launch (never 0 again once used)
+  int last_pivoted_passes = 0;  // lii_last_solve_info: passes of the last device update whose elimination needed the pivoting routine
   hipStream_t map_stream = nullptr;  // the in-place update of lii_map_incremental runs here, beside the next scan's pre-processing
   bool map_async = false;            // ... and may still be running (map_join waits for it: ev_mapflag is its last packet)
   int bound_add = 0, bound_nodown = 0;  // ... the sizes the update in flight was enqueued for

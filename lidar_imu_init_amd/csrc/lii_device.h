@@ -211,7 +211,8 @@ struct IekfCtrl {
                            // passes from the previous scans and leaves out the launches that would only read the flags and
                            // return (~4.5 us each on the device); a solve whose next pass is not there, or asks for a search
                            // the plan does not hold, parks the loop (stop = 2) and tells the host, which enqueues the rest.
-  int search_log[16];  // search_log[it] = 1 when iteration `it` ran the k-NN pass (for profiling)
+  int search_log[16];  // search_log[it]: bit 0 = iteration `it` ran the k-NN pass (for profiling and the next launch plan), bit 1 = its
+                       // elimination left the pivot-free loop for the pivoting routine (lii_last_solve_info)
   double search_pose[24];  // the PoseArg of the last executed k-NN pass (written by that pass): a sharded job re-runs the search
                            // for the blocks of the other ranks at exactly this pose before map_incremental (lii_capi.cpp)
 };

@@ -108,24 +108,38 @@ __device__ __forceinline__ bool gj12_pivoting(double (&col)[H]) {
 // has its spectrum in [1, inf): measured on LIO sequences (hall, corridor: tools/exp/gj_growth.py) the pivot-free growth stays
 // below 10 where the 1/4-threshold test of round 4 would have exchanged rows on nine scans of ten.
 // (kGrowthMax = 2^8: eight bits of the 53 - <= 3e-14 x cond(A) on the gain, far inside the 1e-4 the covariance is held to)
-// The watch works on the HIGH WORDS of the doubles - sign off, the exponent and the top 20 mantissa bits order like the magnitudes:
-// twelve v_and_b32 and six v_max3_u32 per step, 72 cycles of a lone wavefront where twelve v_max_f64 take 120 (tools/ubench/
-// solve_ubench.hip: a double-precision max or multiply-add occupies the pipe for 7 - 10 cycles, a 32-bit operation for 4) - and
-// "x 2^8" is an addition to the exponent field.  Not-a-number and infinity sort above every finite bound.
-__device__ __forceinline__ unsigned int col_absmax_hi(const double (&col)[H]) {
-  unsigned int t[H];
+// The watch works on the HIGH WORDS of the doubles read as SINGLE-precision numbers (sign | the exponent field's upper eight bits | its
+// lower three and twenty mantissa bits): their magnitudes order like the doubles' - the word is a monotone function of |x| - so |.| is the operand modifier of v_max3_f32 and a step's twelve magnitudes cost six instructions (round 5, first form: twelve
+// v_and_b32 + six v_max3_u32; twelve v_max_f64 before that: tools/ubench/solve_ubench.hip - a double-precision max or multiply-add
+// occupies the pipe for 7 - 10 cycles, a 32-bit operation for 4), and "x 2^8" is an addition to the double's exponent field.  A word
+// whose upper exponent bits are all ones - a double beyond 2^1016, infinity, not-a-number - reads as a single-precision NaN, which the
+// maximum SKIPS: such a value cannot pass the elimination unnoticed all the same, a pivot that was zero or not a number turns its
+// whole row - every lane's last entry - into not-a-number for good, and gj12_loop looks at that entry once at the end.
+__device__ __forceinline__ float max3_abs(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float max3_pos(float a, float b, float c) {  // (operands >= 0)
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// max(g, the largest magnitude of the column) on the high words: six instructions
+__device__ __forceinline__ float col_absmax_hi(const double (&col)[H], float g) {
+  float t[H];
 #pragma unroll
-  for (int r = 0; r < H; r++) t[r] = (unsigned int)__double2hiint(col[r]) & 0x7FFFFFFFu;
-  const unsigned int a = max(max(t[0], t[1]), t[2]), b = max(max(t[3], t[4]), t[5]), c = max(max(t[6], t[7]), t[8]), d = max(max(t[9], t[10]), t[11]);
-  return max(max(a, b), max(c, d));
+  for (int r = 0; r < H; r++) t[r] = __int_as_float(__double2hiint(col[r]));
+  const float a = max3_abs(t[0], t[1], t[2]), b = max3_abs(t[3], t[4], t[5]), c = max3_abs(t[6], t[7], t[8]), d = max3_abs(t[9], t[10], t[11]);
+  return max3_pos(max3_pos(a, b, c), d, g);
 }
 // Every lane watches ITS column against ITS column's own scale, max(1, largest magnitude at the start): stricter than the growth
 // factor of the whole matrix (a column's scale is at most the matrix's) and needs no reduction over the lanes - the verdict is one
 // ballot at the end.  (The columns of the right-hand side are watched as well: they only ride along, but a column that outgrows
 // its start by 2^8 says the multipliers were large.)
 __device__ __forceinline__ bool gj12_loop(double (&col)[H]) {
-  unsigned int g = col_absmax_hi(col);
-  const unsigned int bound = max(g, 0x3FF00000u /* 1.0 */) + (8u << 20);  // kGrowthMax = 2^8
+  float g = col_absmax_hi(col, 0.f);
+  const unsigned int bound = max(__float_as_uint(g), 0x3FF00000u /* 1.0 */) + (8u << 20);  // kGrowthMax = 2^8
 #pragma nounroll
   for (int k = 0; k < H; k++) {
     double m[H];
@@ -139,17 +153,21 @@ __device__ __forceinline__ bool gj12_loop(double (&col)[H]) {
 #pragma unroll
     for (int r = 1; r < H; r++) col[r - 1] = fma(-m[r], rowk, col[r]);
     col[H - 1] = rowk;
-    g = max(g, col_absmax_hi(col));
+    g = col_absmax_hi(col, g);
   }
-  return __all(g <= bound);  // (false for a pivot that was zero or not a number: the maxima carry it; idle lanes hold zeros)
+  // (g >= 0: its bits order like its value.  The last pivot row: not-a-number if any pivot was zero or not a number; idle lanes hold zeros)
+  return __all(__float_as_uint(g) <= bound && col[H - 1] == col[H - 1]);
 }
-__device__ __forceinline__ bool gj12(double (&col)[H]) {
+// pivoted: the elimination went through gj12_pivoting (wave-uniform)
+__device__ __forceinline__ bool gj12(double (&col)[H], bool& pivoted) {
+  pivoted = false;
   double keep[H];
 #pragma unroll
   for (int r = 0; r < H; r++) keep[r] = col[r];
   if (__builtin_expect(gj12_loop(col), 1)) return true;  // (wave-uniform)
 #pragma unroll
   for (int r = 0; r < H; r++) col[r] = keep[r];
+  pivoted = true;
   return gj12_pivoting(col);
 }
 
@@ -292,8 +310,9 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
     double col[H];
 #pragma unroll
     for (int r = 0; r < H; r++) col[r] = lane < H ? A[r * LDH + lane] : (lane < H + N ? s_cov[r * N + (lane - H)] : 0.0);
-    const bool ok = gj12(col);
-    if (!ok && lane == 0) s_ok = 0;
+    bool pivoted;
+    const bool ok = gj12(col, pivoted);
+    if (lane == 0) s_ok = ok ? (pivoted ? 2 : 1) : 0;
     if (lane >= H && lane < H + N) {
 #pragma unroll
       for (int r = 0; r < H; r++) K1c[(lane - H) * LDH + r] = col[r];
@@ -371,7 +390,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
       c->effect_num = (int)s_ne[90];
       c->it = it + 1;
       c->searches = searches0 + (search_now ? 1 : 0);
-      if (it < 16) c->search_log[it] = search_now;
+      if (it < 16) c->search_log[it] = search_now | (s_ok == 2 ? 2 : 0);
       if (parked) {
         c->stop = 2;
         res->parked_it = it + 1;
@@ -419,7 +438,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
     if (tid < 91) res->ne[tid] = s_ne[tid];
     if (tid >= 96 && tid < 112) {
       const int q = tid - 96;
-      res->search_log[q] = (q < it) ? c->search_log[q] : (q == it ? search_now : 0);
+      res->search_log[q] = (q < it) ? c->search_log[q] : (q == it ? (search_now | (s_ok == 2 ? 2 : 0)) : 0);
     }
     publish_done(res, s_int[10]);
   } else if (parked) {  // uniform

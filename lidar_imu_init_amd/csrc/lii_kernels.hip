@@ -1413,8 +1413,10 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
 // One flagged search finished by a whole wavefront: the list goes to rb.nbr / rb.nbr_count.
 // (the owner lane has loaded the query's world point and count together with everything else it needs: the completion starts
 // with the block probes at once - one dependent round trip less than fetching them here)
+// lds_nb / lds_found (or null): the finished list and its count also go to the workgroup's LDS, for the lane that fits this query.
 __device__ __forceinline__ void complete_one(const GridView& g, const RegistrationBuffers& rb, int qi, int c00, float wx, float wy, float wz,
-                                             unsigned int* __restrict__ far_list) {
+                                             unsigned int* __restrict__ far_list, float4* __restrict__ lds_nb = nullptr,
+                                             int* __restrict__ lds_found = nullptr) {
   const int lane = threadIdx.x & 63;
   const int c0 = c00 & 0xFF;
   const bool seeded = (c00 & kCovered) != 0;  // uniform
@@ -1434,14 +1436,20 @@ __device__ __forceinline__ void complete_one(const GridView& g, const Registrati
     else if (idx <= -2) v = make_float4(kx, ky, kz, 0.f);
     v.w = dd;
     rb.nbr[(size_t)lane * rb.cap + qi] = v;
+    if (lds_nb) lds_nb[lane] = v;
   } else if (lane == 5) {
-    rb.nbr_count[qi] = (oi[0] != -1) + (oi[1] != -1) + (oi[2] != -1) + (oi[3] != -1) + (oi[4] != -1);
+    const int found = (oi[0] != -1) + (oi[1] != -1) + (oi[2] != -1) + (oi[3] != -1) + (oi[4] != -1);
+    rb.nbr_count[qi] = found;
+    if (lds_found) *lds_found = found;
   }
 }
+constexpr int kHandOver = 64;  // queries of a completion workgroup whose finished lists reach the fitting lane through LDS (usually all: 2 ... 8 per workgroup)
 struct NeedyShared {
   int point[kBlock], count[kBlock];
   float w[kBlock][3];
   int aux[kBlock], key[kBlock];  // (completion workgroups: the listed queries in ascending order; as listed)
+  float4 nb[kHandOver][5], body[kHandOver];
+  int found[kHandOver];
   int n;
 };
 // `count`, `w`: nbr_count and world point of the calling lane's query (loaded by the caller, together).
@@ -1529,6 +1537,15 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
     e_count = rb.nbr_count[ie];
     e_sel = rb.selected[ie];
   }
+  // (a completion workgroup: entry `lane` of the search pass's list - its length arrives with the scalars below, what lies behind the
+  // end is read and dropped)
+  const float4* flag_list = rb.flag_list + 2 * (epoch & 1) * kFlagCap;
+  // (unconditional - the other workgroups read the list's first line and drop it: behind a branch the compiler joins the two paths
+  // with a register copy, and the wait for the entry would stand in front of the scalar requests)
+  static_assert(kFlagCap <= kBlock, "one lane per listed query");
+  const float4* my_entry = flag_list + (completion_wg ? 2 * threadIdx.x : 0u);
+  const float4 l0 = my_entry[0];
+  const int l1x = __float_as_int(my_entry[1].x);
   const HeadScalars hs = load_head_scalars(pose, &ctrl->search_next, rb.n_dev ? rb.n_dev : &ctrl->max_it, epoch > 0 ? rb.flag_count + (epoch & 1) : &ctrl->max_it);
   asm volatile("" : "+v"(e_sel));  // (the selection flag is not looked at before this point: the compiler tests it where it is loaded, and the wait for it would stand in front of the scalar requests)
   PoseArg ps = hs.ps;
@@ -1550,6 +1567,7 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
   bool live;
   float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
   bool skip_row = false;  // a flagged point in a workgroup of the cloud: the completion workgroups own it
+  bool handed = false;    // a completion workgroup's lane whose query came through LDS (list, count, body point)
   if (!completion_wg) {
     blk = xcd_remap(cloud_block, nb_real);
     if (blk >= nb_real) return;  // uniform per block
@@ -1576,41 +1594,40 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
     live = false;
     if (defer) {
       const int j = (int)blockIdx.x;
-      static_assert(kFlagCap <= kBlock, "one lane per listed query");
       if (threadIdx.x == 0) sh_needy.n = 0;
       __syncthreads();
-      // the entries of this workgroup: their positions in the list first (sh_needy.point), then - ranked by query index - the queries
-      // (aux), their neighbour counts with the flags (count) and world points (w): everything complete_one starts from, in LDS
-      const float4* list = rb.flag_list + 2 * (epoch & 1) * kFlagCap;
-      if ((int)threadIdx.x < n_flagged) {
-        const int qx = __float_as_int(list[2 * threadIdx.x].w);
-        if (((qx >> 2) % kCompletionBlocks) == j) {
-          const int at = atomicAdd(&sh_needy.n, 1);
-          sh_needy.point[at] = (int)threadIdx.x;
-          sh_needy.key[at] = qx;
-        }
+      // The entries of this workgroup, ranked by query index: query (aux), neighbour count with the flags (count), world point (w) and
+      // body point - everything complete_one and the fit start from - go to LDS from the lane that read the entry at the head of the
+      // launch: one dependent round trip (list + scalars) in front of the block probes, where the first form of this had three (the
+      // list's length, the queries' indices, the entries).
+      const int qx = __float_as_int(l0.w);
+      const bool mine = (int)threadIdx.x < n_flagged && ((qx >> 2) % kCompletionBlocks) == j;
+      float4 my_body = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mine) {
+        my_body = rb.body[qx];
+        sh_needy.key[atomicAdd(&sh_needy.n, 1)] = qx;
       }
       __syncthreads();
       const int m = sh_needy.n;
-      if ((int)threadIdx.x < m) {
-        const int at = sh_needy.point[threadIdx.x];
-        const float4 e0 = list[2 * at], e1 = list[2 * at + 1];
-        const int x = __float_as_int(e0.w);
+      if (mine) {
         int rank = 0;
-        for (int u = 0; u < m; u++) rank += sh_needy.key[u] < x ? 1 : 0;
-        sh_needy.aux[rank] = x;
-        sh_needy.count[rank] = __float_as_int(e1.x);
-        sh_needy.w[rank][0] = e0.x; sh_needy.w[rank][1] = e0.y; sh_needy.w[rank][2] = e0.z;
+        for (int u = 0; u < m; u++) rank += sh_needy.key[u] < qx ? 1 : 0;
+        sh_needy.aux[rank] = qx;
+        sh_needy.count[rank] = l1x;
+        sh_needy.w[rank][0] = l0.x; sh_needy.w[rank][1] = l0.y; sh_needy.w[rank][2] = l0.z;
+        if (rank < kHandOver) sh_needy.body[rank] = my_body;
       }
       __syncthreads();
       const int wave = threadIdx.x >> 6;
       for (int e = wave; e < m; e += kBlock / 64)  // one wavefront per query
         complete_one(g, rb, sh_needy.aux[e], sh_needy.count[e], sh_needy.w[e][0], sh_needy.w[e][1], sh_needy.w[e][2],
-                     reinterpret_cast<unsigned int*>(&sh.row[0][0]) + wave * kFarCap);
+                     reinterpret_cast<unsigned int*>(&sh.row[0][0]) + wave * kFarCap, e < kHandOver ? &sh_needy.nb[e][0] : nullptr,
+                     e < kHandOver ? &sh_needy.found[e] : nullptr);
       __syncthreads();  // the completed lists are visible to the lanes that fit them (workgroup-scope release / acquire)
       if ((int)threadIdx.x < m) {
         i = sh_needy.aux[threadIdx.x];
         live = true;
+        handed = (int)threadIdx.x < kHandOver;
         w4 = make_float4(sh_needy.w[threadIdx.x][0], sh_needy.w[threadIdx.x][1], sh_needy.w[threadIdx.x][2], 0.f);
       }
     }
@@ -1621,7 +1638,11 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
   o.z = 0;
   o.sel = false;
   if (live && !skip_row) {
-    const float4 pb = early ? e_body : rb.body[i];
+    float4 pb = e_body;
+    if (!early) {  // (by value on every path: a choice between the three ADDRESSES sends e_body to scratch and waits for it at the head)
+      if (handed) pb = sh_needy.body[threadIdx.x & (kHandOver - 1)];
+      else pb = rb.body[i];
+    }
     double bx = pb.x, by = pb.y, bz = pb.z;
     double ix = ps.RLI[0] * bx + ps.RLI[1] * by + ps.RLI[2] * bz + ps.TLI[0];
     double iy = ps.RLI[3] * bx + ps.RLI[4] * by + ps.RLI[5] * bz + ps.TLI[1];
@@ -1631,10 +1652,17 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
     bool candidate;
     if (FIT) {
       wx = w4.x; wy = w4.y; wz = w4.z;
-      const int found = rb.nbr_count[i];
+      int found;
       float4 nb[5];
+      if (handed) {
+        found = sh_needy.found[threadIdx.x & (kHandOver - 1)];
 #pragma unroll
-      for (int j = 0; j < 5; j++) nb[j] = rb.nbr[(size_t)j * rb.cap + i];
+        for (int j = 0; j < 5; j++) nb[j] = sh_needy.nb[threadIdx.x & (kHandOver - 1)][j];
+      } else {
+        found = rb.nbr_count[i];
+#pragma unroll
+        for (int j = 0; j < 5; j++) nb[j] = rb.nbr[(size_t)j * rb.cap + i];
+      }
       if (found == kMatch && canon_ties(nb)) {
 #pragma unroll
         for (int j = 0; j < 5; j++) rb.nbr[(size_t)j * rb.cap + i] = nb[j];

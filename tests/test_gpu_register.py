@@ -141,6 +141,53 @@ def test_update_with_lio_regime_covariance(reg, oracle, small_world):
         assert np.max(np.abs(d[12:])) < 1e-5, d[12:]          # velocity, biases, gravity (prior std 1 .. 3e-3)
         assert np.max(np.abs(v.cov - s.cov)) <= 1e-6 * np.max(np.abs(v.cov))
 
+def test_elimination_with_row_exchanges_when_the_pivot_vanishes(reg, oracle, small_world):
+    """The device solve eliminates [I + P11 G | P[:12, :]] without row exchanges while the elimination's element growth stays below
+    2^8, and repeats it with threshold pivoting otherwise (lii_iekf.hip: gj12_loop / gj12_pivoting).  A prior whose pose block is
+    eps I + s v v^T with v chosen against the scene's G makes the first pivot 1 + (P11 G)_00 vanish (1e-7): the pivot-free form
+    would divide by it.  The update must report the routine with exchanges (lii_last_solve_info) and land where the oracle's
+    two-inversion algebra (Eigen's partial-pivoting LU, src/laserMapping.cpp:1081-1085) lands; an ordinary prior reports none."""
+    import lidar_imu_init_amd as lii
+    hall, map_pts = small_world
+    scan, R, p = _scan(small_world, "vlp16", seed=11)
+    st_true = make_state(oracle, R, p)
+    st0 = oracle.state_boxplus(st_true, np.r_[0.002, -0.001, 0.002, 0.01, -0.01, 0.005, np.zeros(18)])
+    reg.map_build(map_pts)
+    reg.scan_upload(scan)
+    reg.downsample_skip()
+    out = reg.iekf_iterate(lii.State(st0), True, True)
+    G = np.zeros((12, 12))
+    G[np.triu_indices(12)] = out[:78]
+    G = G + np.triu(G, 1).T
+    u = G[:, 0]
+    j = 1 + int(np.argmax(np.abs(u[1:])))
+    v = np.zeros(12)
+    v[0], v[j] = 1.0, -2.0 * u[0] / u[j]                      # v . u = -u0 < 0
+    eps, delta = 1e-10, 1e-7
+    s_ = (1.0 - delta + eps * u[0]) / u[0]                     # 1 + eps u0 + s (v0)(v . u) = delta
+    P11 = eps * np.eye(12) + s_ * np.outer(v, v)
+    assert abs(1.0 + (P11 @ G)[0, 0]) < 1e-5 and np.max(np.abs((np.eye(12) + P11 @ G)[1:, 0])) > 1e-2
+    prop = lii.State(st0)
+    prop.cov[:] = 0
+    prop.cov[:12, :12] = P11
+    prop.cov[12:, 12:] = 1e-4 * np.eye(12)
+    tree = oracle.Tree("oracle")
+    tree.build(map_pts)
+    ref = tree.iekf_update(scan, prop.pod, prop.pod, max_iterations=4, imu_en=True, threads=4)
+    s = prop.copy()
+    rep = reg.iekf_update(s, prop, max_iterations=4, imu_en=True)
+    assert reg.last_solve_info() >= 1
+    assert rep["iterations"] == ref["iters"]
+    d = oracle.state_boxminus(s.pod, ref["state"])
+    assert np.max(np.abs(d[:12])) < 1e-7, d[:12]
+    assert np.max(np.abs(d[12:])) < 1e-6, d[12:]
+    v_ = oracle.StateView(ref["state"])
+    assert np.max(np.abs(v_.cov - s.cov)) <= 1e-6 * np.max(np.abs(v_.cov))
+    # an ordinary prior: no pass needs the exchanges
+    s2 = lii.State(st0)
+    reg.iekf_update(s2, lii.State(st0), max_iterations=4, imu_en=True)
+    assert reg.last_solve_info() == 0
+
 
 def test_sparse_and_empty_neighbourhoods(reg, oracle):
     """Frontier behaviour: queries with fewer than 5 neighbours within sqrt(5) m, phase-2 ring search."""

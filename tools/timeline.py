@@ -23,7 +23,10 @@ def main():
     starts = [i for i, r in enumerate(rows) if "k_time_extent" in r["Kernel_Name"] or "k_deskew" in r["Kernel_Name"]]
     # (a scan that takes the general path starts with k_time_extent and has a k_deskew launch behind it: keep the first of a pair)
     starts = [i for n, i in enumerate(starts) if n == 0 or i != starts[n - 1] + 1]
-    use = list(zip(starts[-61:-1], starts[-60:]))
+    # (scans with a runtime copy kernel between their launches are not steps of the stream: the bench registers its eight scans once more
+    # behind the timed steps and downloads their results for the parity record)
+    pairs = [(a, b) for a, b in zip(starts[:-1], starts[1:]) if not any("__amd_rocclr" in rows[j]["Kernel_Name"] for j in range(a, b))]
+    use = pairs[-60:]
     dur, gap = collections.defaultdict(list), collections.defaultdict(list)
     wall, busy = [], []
     for a, b in use:
@@ -46,19 +49,30 @@ def main():
             if len(dur[key]) < len(use) // 2:
                 continue  # a position that only exists in scans with an unusual number of launches
             f.write(f"| {key[0]} | `{key[1]}` | {statistics.mean(dur[key]) / 1e3:.1f} | {statistics.mean(gap[key]) / 1e3:.1f} |\n")
-        # One scan in eight of the bench stream looks past the edge of the map: the slowest eighth of the scans against the others
+        # One scan in eight of the bench stream looks past the edge of the map: the slowest eighth of the scans against the others,
+        # launch by launch where their launch sequences agree (a parked loop adds a k_loop_resume and shifts the positions)
         order = sorted(range(len(busy)), key=lambda i: busy[i])
         n_slow = max(len(busy) // 8, 1)
-        slow, rest = set(order[-n_slow:]), set(order[:-n_slow])
+        slow, rest = order[-n_slow:], order[:-n_slow]
         f.write(f"\nSlowest eighth of the scans ({n_slow}) against the others: kernels {statistics.mean(busy[i] for i in slow) / 1e3:.1f} "
-                f"against {statistics.mean(busy[i] for i in rest) / 1e3:.1f} us per scan; per launch (slow - others, us): ")
-        parts = []
-        for key in sorted(dur):
-            if len(dur[key]) != len(use):
-                continue
-            d_s = statistics.mean(dur[key][i] for i in slow) - statistics.mean(dur[key][i] for i in rest)
-            parts.append(f"{key[0]} {key[1].split('::')[-1].split('<')[0]} {d_s / 1e3:+.1f}")
-        f.write(", ".join(parts) + ".\n")
+                f"against {statistics.mean(busy[i] for i in rest) / 1e3:.1f} us per scan.\n\n")
+        seqs = [[(short(rows[j]["Kernel_Name"]), int(rows[j]["End_Timestamp"]) - int(rows[j]["Start_Timestamp"])) for j in range(a, b)] for a, b in use]
+        sig = lambda i: tuple(n for n, _ in seqs[i])
+        common = collections.Counter(sig(i) for i in rest).most_common(1)[0][0]
+        rest_c = [i for i in rest if sig(i) == common]
+        slow_c = [i for i in slow if sig(i) == common]
+        f.write(f"{len(slow_c)} of the slow and {len(rest_c)} of the other scans run the usual launch sequence; per launch, slow / others / difference:\n\n")
+        f.write("| # | kernel | slow | others | + |\n|---|---|---|---|---|\n")
+        if slow_c and rest_c:
+            for pos, name in enumerate(common):
+                a_ = statistics.mean(seqs[i][pos][1] for i in slow_c) / 1e3
+                b_ = statistics.mean(seqs[i][pos][1] for i in rest_c) / 1e3
+                f.write(f"| {pos} | `{name}` | {a_:.1f} | {b_:.1f} | {a_ - b_:+.1f} |\n")
+        odd = [i for i in slow if sig(i) != common]
+        if odd:
+            i = odd[-1]
+            f.write(f"\n{len(odd)} slow scans run another sequence; the slowest of them ({busy[i] / 1e3:.1f} us): "
+                    + ", ".join(f"{n.split('::')[-1].split('<')[0]} {t / 1e3:.1f}" for n, t in seqs[i]) + ".\n")
     print(open(out).read())
 
 
