@@ -206,7 +206,6 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   h->cell_size = cfg->map_cell_size > 0 ? cfg->map_cell_size : 3.0f * h->cfg.map_downsample_size;
   // the 3x3x3 neighbourhood of 8x8x8-cell blocks must cover the acceptance radius sqrt(max_match_dist2)
   h->cell_size = std::max(h->cell_size, std::sqrt(h->cfg.max_match_dist2) / 8.0f * 1.001f);
-  if (const char* v = std::getenv("LII_KNN_VARIANT")) h->knn_variant = std::atoi(v);  // A/B knob for profiling
   if (const char* v = std::getenv("LII_DIAG")) h->diag = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_VOXEL_FILTER")) {
     h->voxel_sort = std::string(v) == "sort";

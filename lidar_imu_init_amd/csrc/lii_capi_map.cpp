@@ -510,7 +510,7 @@ int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, in
     rb.shard_world = 1;
     if (h->have_search) {
       const GridView g = grid_view(h);
-      lii::launch_knn(h->knn_variant, g, rb, reinterpret_cast<const PoseArg*>(h->d_ctrl->search_pose), h->d_ctrl, 2, nullptr, s, 0);  // (k_knn_complete behind it works from the flags in nbr_count, not from a list)
+      lii::launch_knn(g, rb, reinterpret_cast<const PoseArg*>(h->d_ctrl->search_pose), h->d_ctrl, 2, nullptr, s, 0);  // (k_knn_complete behind it works from the flags in nbr_count, not from a list)
       launch_knn_complete(g, rb, s);
     }
   }

@@ -10,15 +10,14 @@ namespace {
 
 
 // (every enqueued search launch has a number, which the fit launch behind it shares: the list of unfinished queries the one leaves
-// and the other consumes - RegistrationBuffers::flag_*; 0 = no list: the exact-list kernel of test builds, and launches captured
-// into a hipGraph, whose arguments are frozen)
+// and the other consumes - RegistrationBuffers::flag_*; 0 = no list: launches captured into a hipGraph, whose arguments are frozen)
 int next_knn_epoch(lii_handle h, bool listed) {
-  if (!listed || h->knn_variant == 5) return 0;
+  if (!listed) return 0;
   h->knn_epoch = h->knn_epoch >= 0x3FFFFFFE ? 1 : h->knn_epoch + 1;  // (consecutive numbers alternate between the two slots, across the wrap as well)
   return h->knn_epoch;
 }
 void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose, int forced, int epoch) {
-  lii::launch_knn(h->knn_variant, g, rb, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->stream, epoch);
+  lii::launch_knn(g, rb, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->stream, epoch);
 }
 
 
@@ -170,12 +169,12 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     // from the device), the plan and the view of the map - the key of the cache.  Measured against the plain launches in
     // profiles/r03_hipgraph_ab.md.
     if (rb.n_dev) rb.n = std::min(rb.cap, (rb.n + 4095) & ~4095);
-    struct { const void* p[4]; unsigned int mask; int n_pts, n, plan, max_it, imu_en, variant, shard; float cs; } kv;
+    struct { const void* p[4]; unsigned int mask; int n_pts, n, plan, max_it, imu_en, shard; float cs; } kv;
     std::memset(&kv, 0, sizeof(kv));
     kv.p[0] = g.pts; kv.p[1] = g.blocks; kv.p[2] = g.cells; kv.p[3] = rb.n_dev;
     kv.mask = g.block_mask; kv.n_pts = g.n_pts; kv.n = rb.n; kv.plan = (int)plan; kv.max_it = opts->max_iterations;
     kv.imu_en = opts->imu_en ? 1 : 0;
-    kv.variant = h->knn_variant; kv.shard = rb.shard_world * 4096 + rb.shard_rank; kv.cs = g.cs;
+    kv.shard = rb.shard_world * 4096 + rb.shard_rank; kv.cs = g.cs;
     const std::string key(reinterpret_cast<const char*>(&kv), sizeof(kv));
     auto f = h->graphs.find(key);
     if (f == h->graphs.end()) {

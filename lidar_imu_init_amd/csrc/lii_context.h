@@ -162,8 +162,6 @@ struct lii_context {
   int* d_nbody = nullptr;       // [0] size of the down-sampled cloud, [1] `filtered` flag of the last voxel filter
   bool body_is_scan = false;
   bool have_search = false;
-  int knn_variant = 0;   // search pass: 0 = k_knn_ck (the product form); 5 = exact lists throughout (k_knn_exact: builds with -DLII_KNN_EXACT
-                         // only) - LII_KNN_VARIANT
   int* d_flags = nullptr;       // the lists of unfinished queries (RegistrationBuffers::flag_count / flag_list): 2 counters + 2 x kFlagCap entries of two float4
   int knn_epoch = 0;            // number of the last enqueued search launch (never 0 again once used)
   int last_pivoted_passes = 0;  // lii_last_solve_info: passes of the last device update whose elimination needed the pivoting routine

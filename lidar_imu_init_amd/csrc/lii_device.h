@@ -111,7 +111,7 @@ __device__ __forceinline__ PoseArg pose_to_vgprs(const PoseArg& s) {
   for (int k = 0; k < 3; k++) { v.p[k] = mv(s.p[k]); v.TLI[k] = mv(s.TLI[k]); }
   return v;
 }
-__device__ __forceinline__ PoseArg load_pose(const PoseArg* __restrict__ pose) { return *pose; }  // (no hurry: k_map_decide, k_knn_exact)
+__device__ __forceinline__ PoseArg load_pose(const PoseArg* __restrict__ pose) { return *pose; }  // (no hurry: k_map_decide)
 // (a kernel that still takes a pose by value beside the pointer - k_map_decide: the caller's final state, or the control block's)
 __device__ __forceinline__ PoseArg load_pose(bool from_memory, const PoseArg* __restrict__ pose, const PoseArg& by_value) {
   PoseArg ps = by_value;
@@ -163,7 +163,10 @@ struct RegistrationBuffers {
   float4* flag_list;  // 2 x kFlagCap entries of two float4
 };
 constexpr int kFlagCap = 256;          // listed queries a fit launch hands to its completion workgroups (more: every workgroup finishes its own, as in round 4)
-constexpr int kCompletionBlocks = 32;  // ... of which there are this many, behind the workgroups of the cloud; each writes one more column of partial sums
+#ifndef LII_COMPLETION_BLOCKS
+#define LII_COMPLETION_BLOCKS 32
+#endif
+constexpr int kCompletionBlocks = LII_COMPLETION_BLOCKS;  // ... of which there are this many, behind the workgroups of the cloud; each writes one more column of partial sums
 
 // The block of the down-sampled cloud this rank registers: first index and size.  Every rank holds the WHOLE cloud (the
 // de-skew and the voxel filter run replicated, so the cloud is bit-identical everywhere) and the split needs no exchange.

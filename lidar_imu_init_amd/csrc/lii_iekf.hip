@@ -105,7 +105,7 @@ __device__ __forceinline__ bool gj12_pivoting(double (&col)[H]) {
 // step, off the critical chain readlane -> reciprocal -> multiply-add), and the result stands only if the columns of A never
 // outgrew 2^8 x max(1, max |A|) - the quantity the backward error of an elimination is proportional to (Wilkinson) - and
 // every pivot was a number.  Otherwise the saved input goes through gj12_pivoting.  I + P11 G with P11, G positive semi-definite
-// has its spectrum in [1, inf): measured on LIO sequences (hall, corridor: tools/exp/gj_growth.py) the pivot-free growth stays
+// has its spectrum in [1, inf): measured on LIO sequences (hall, corridor: tools/gj_growth.py) the pivot-free growth stays
 // below 10 where the 1/4-threshold test of round 4 would have exchanged rows on nine scans of ten.
 // (kGrowthMax = 2^8: eight bits of the 53 - <= 3e-14 x cond(A) on the gain, far inside the 1e-4 the covariance is held to)
 // The watch works on the HIGH WORDS of the doubles read as SINGLE-precision numbers (sign | the exponent field's upper eight bits | its

@@ -444,13 +444,6 @@ __device__ __forceinline__ bool fit_plane(const float4 (&nb)[5], double plane_th
 __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]);
 
 // ------------------------------------------------------------------------------------------------
-#ifdef LII_KNN_EXACT  // (helpers of k_knn_exact only)
-template <bool DEDUP>
-__device__ __forceinline__ void knn_merge_one(Knn5& k, float e, int j) {
-  if (DEDUP && (j == k.i0 || j == k.i1 || j == k.i2 || j == k.i3 || j == k.i4)) return;
-  if (e < k.d4) knn_insert(k, e, j);
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // The search pass: LPQ (4 by default, 8 optional) lanes per query with box-distance pruning in two rounds.
@@ -459,24 +452,6 @@ __device__ __forceinline__ void knn_merge_one(Knn5& k, float e, int j) {
 // If the merged 5th distance is within g0 the search is complete (the usual case for a converged map).
 // Round 2: the other 19 cells of the 3x3x3 block, each tested against the current 5th distance first (the tree's
 // calc_box_dist rule), so most of them cost neither a table lookup nor a candidate.
-#ifdef LII_KNN_EXACT  // (helpers of k_knn_exact only)
-__device__ __forceinline__ uint2 lookup_cell(const GridView& g, const uint4* __restrict__ tab, int ix, int iy, int iz) {
-  const int bb = kCellBias >> kCoarseShift;
-  const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
-  const unsigned long long bk = pack_block(bx, by, bz);
-  unsigned int sl = hash_block(bx, by, bz) & g.block_mask;
-  uint4 e = tab[sl];
-  unsigned long long ek = ((unsigned long long)e.y << 32) | e.x;
-  while (ek != bk && ek != kEmptyKey) {
-    sl = (sl + 1) & g.block_mask;
-    e = tab[sl];
-    ek = ((unsigned long long)e.y << 32) | e.x;
-  }
-  if (ek != bk) return make_uint2(0u, 0u);
-  const unsigned local = (((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u);
-  return g.cells[(size_t)e.z * kBlockCells + local];
-}
-#endif
 
 // NC cell lookups with their loads issued as two batches (first probes of all block-table slots, then all cell entries)
 // instead of NC dependent probe -> entry chains; a probe that hits a foreign key walks on alone (load factor <= 1/8: rare).
@@ -522,29 +497,6 @@ __device__ __forceinline__ void lookup_cells_batched(const GridView& g, const ui
 // distance first (the tree's calc_box_dist rule, ikd_Tree.cpp:1279-1289).
 // A query whose 3x3x3 block cannot prove its list complete is flagged (kNeedy) and finished by k_fit_reduce / k_knn_complete.
 
-#ifdef LII_KNN_EXACT  // (helpers of k_knn_exact only)
-template <bool DEDUP>
-__device__ __forceinline__ void knn_group_merge4(Knn5& k) {
-#pragma unroll
-  for (int off = 1; off < 4; off <<= 1) {
-    float e0 = __shfl_xor(k.d0, off), e1 = __shfl_xor(k.d1, off), e2 = __shfl_xor(k.d2, off), e3 = __shfl_xor(k.d3, off),
-          e4 = __shfl_xor(k.d4, off);
-    int j0 = __shfl_xor(k.i0, off), j1 = __shfl_xor(k.i1, off), j2 = __shfl_xor(k.i2, off), j3 = __shfl_xor(k.i3, off),
-        j4 = __shfl_xor(k.i4, off);
-    if (j0 >= 0) knn_merge_one<DEDUP>(k, e0, j0);
-    if (j1 >= 0) knn_merge_one<DEDUP>(k, e1, j1);
-    if (j2 >= 0) knn_merge_one<DEDUP>(k, e2, j2);
-    if (j3 >= 0) knn_merge_one<DEDUP>(k, e3, j3);
-    if (j4 >= 0) knn_merge_one<DEDUP>(k, e4, j4);
-  }
-}
-__device__ __forceinline__ void knn_group_bcast(Knn5& k, int leader) {
-  k.d0 = __shfl(k.d0, leader); k.d1 = __shfl(k.d1, leader); k.d2 = __shfl(k.d2, leader); k.d3 = __shfl(k.d3, leader);
-  k.d4 = __shfl(k.d4, leader);
-  k.i0 = __shfl(k.i0, leader); k.i1 = __shfl(k.i1, leader); k.i2 = __shfl(k.i2, leader); k.i3 = __shfl(k.i3, leader);
-  k.i4 = __shfl(k.i4, leader);
-}
-#endif
 
 // element t of a PoseArg seen as 24 doubles, without dynamic indexing (which would push the struct into scratch memory)
 __device__ __forceinline__ double pose_element(const PoseArg& ps, int t) {
@@ -586,50 +538,6 @@ __device__ __forceinline__ QueryCell query_cell(const GridView& g, float wx, flo
   return q;
 }
 
-#ifdef LII_KNN_EXACT  // (helpers of k_knn_exact only)
-// Round 2 on exact (distance, index) lists: every lane of the group enters with the group's round-1 list; the lanes of a
-// query that needs it (`more`) visit the 19 outer cells that can still hold a closer point, the lists are merged with
-// duplicate suppression.  Must be called by every lane of the wavefront.
-__device__ __forceinline__ void knn_round2(const GridView& g, const uint4* __restrict__ tab, const QueryCell& q, bool more, float wx,
-                                           float wy, float wz, int sub, int leader, Knn5& k) {
-  const float bound = fminf(__shfl(k.d4, leader), g.max_d2);
-  if (more) {
-    for (int c = sub; c < 27; c += 4) {
-      const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
-      const bool in_r1 = (dx == 0 || dx == q.ox) && (dy == 0 || dy == q.oy) && (dz == 0 || dz == q.oz);
-      if (in_r1) continue;
-      const float gx = axis_gap(wx, q.cx + dx, g.cs, q.eps), gy = axis_gap(wy, q.cy + dy, g.cs, q.eps),
-                  gz = axis_gap(wz, q.cz + dz, g.cs, q.eps);
-      if (gx * gx + gy * gy + gz * gz > bound) continue;
-      const uint2 r = lookup_cell(g, tab, q.cx + dx, q.cy + dy, q.cz + dz);
-      scan_range(g.pts, g.max_d2, r.x, r.y, wx, wy, wz, k);
-    }
-  }
-  knn_group_merge4<true>(k);
-}
-
-// The group's lanes store the five neighbours (coordinates from the map, w = d2), the count (+ kNeedy) and the world point.
-__device__ __forceinline__ void knn_store(const RegistrationBuffers& rb, const float4* __restrict__ pts, int qi, int sub, const Knn5& k,
-                                          bool need, float wx, float wy, float wz) {
-  const int found = (k.i0 >= 0) + (k.i1 >= 0) + (k.i2 >= 0) + (k.i3 >= 0) + (k.i4 >= 0);
-  {
-    const int idx = sub == 0 ? k.i0 : (sub == 1 ? k.i1 : (sub == 2 ? k.i2 : k.i3));
-    const float dd = sub == 0 ? k.d0 : (sub == 1 ? k.d1 : (sub == 2 ? k.d2 : k.d3));
-    float4 v = idx >= 0 ? pts[idx] : make_float4(0, 0, 0, 0);
-    v.w = dd;
-    rb.nbr[(size_t)sub * rb.cap + qi] = v;
-  }
-  if (sub == 0) {
-    float4 v = k.i4 >= 0 ? pts[k.i4] : make_float4(0, 0, 0, 0);
-    v.w = k.d4;
-    rb.nbr[(size_t)4 * rb.cap + qi] = v;
-  } else if (sub == 1) {
-    rb.nbr_count[qi] = found | (need ? kNeedy : 0);
-  } else if (sub == 2) {
-    rb.world[qi] = make_float4(wx, wy, wz, 0.f);
-  }
-}
-#endif
 
 // ---- packed keys ---------------------------------------------------------------------------------
 // The search pass ranks its candidates as 32-bit keys: the float bits of d2 with the low position bits (CkGeom::kPosBits: 8 with
@@ -1049,56 +957,6 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuff
   }
 }
 
-#ifdef LII_KNN_EXACT
-// The search pass on exact (distance, index) lists throughout (round 2's form in round 1 too).  Kept as the reference form of
-// k_knn_ck: same cells, same candidates; LII_KNN_VARIANT=5 selects it (test builds).
-template <int BS>
-__global__ __launch_bounds__(BS) void k_knn_exact(GridView g, RegistrationBuffers rb, const PoseArg* __restrict__ pose,
-                                                  const IekfCtrl* __restrict__ ctrl, int forced, int nb_real,
-                                                  double* __restrict__ search_pose_out) {  // (lists no unfinished queries: its fit launches run with epoch 0)
-  const PoseArg ps = load_pose(pose);
-  int lo, n_live;
-  shard_range(rb, lo, n_live);
-  if (forced < 0 && (ctrl->stop || !ctrl->search_next)) return;
-  if (search_pose_out && blockIdx.x == 0 && threadIdx.x < 24) search_pose_out[threadIdx.x] = pose_element(ps, threadIdx.x);
-  const int blk = xcd_remap(blockIdx.x, nb_real);
-  if (blk >= nb_real) return;
-  constexpr int QPB = BS / 4;
-  const int sub = threadIdx.x & 3;
-  const int ql = blk * QPB + (threadIdx.x >> 2);
-  const int qi = lo + ql;
-  const bool live = ql < n_live;
-  const int leader = (threadIdx.x & 63) & ~3;
-  float wx = 0, wy = 0, wz = 0;
-  if (live && sub == 0) body_to_world(ps, rb.body[qi], wx, wy, wz);
-  wx = __shfl(wx, leader); wy = __shfl(wy, leader); wz = __shfl(wz, leader);
-  const bool active = live && g.n_pts > 0;
-  const uint4* __restrict__ tab = reinterpret_cast<const uint4*>(g.blocks);
-  const QueryCell q = query_cell(g, wx, wy, wz);
-  Knn5 k;
-  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = __builtin_inff();
-  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
-  if (active) {
-    uint2 r[2];
-    int jx[2], jy[2], jz[2];
-    const bool want[2] = {true, true};
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-      const int c = t == 0 ? sub : 7 - sub;
-      jx[t] = q.cx + ((c & 1) ? q.ox : 0); jy[t] = q.cy + ((c & 2) ? q.oy : 0); jz[t] = q.cz + ((c & 4) ? q.oz : 0);
-    }
-    lookup_cells_batched<2>(g, tab, jx, jy, jz, want, r);
-    scan_range(g.pts, g.max_d2, r[0].x, r[0].y, wx, wy, wz, k);
-    scan_range(g.pts, g.max_d2, r[1].x, r[1].y, wx, wy, wz, k);
-  }
-  knn_group_merge4<false>(k);
-  const bool more = active && !(fminf(k.d4, g.max_d2) <= q.g0 * q.g0);
-  if (__any(more)) knn_round2(g, tab, q, more, wx, wy, wz, sub, leader, k);
-  knn_group_bcast(k, leader);
-  const bool need = active && !(fminf(k.d4, g.max_d2) <= q.guard * q.guard);
-  if (live) knn_store(rb, g.pts, qi, sub, k, need, wx, wy, wz);
-}
-#endif  // LII_KNN_EXACT
 
 
 // Second stage of the search for a flagged query, run by ONE WAVEFRONT (four flagged queries of a workgroup proceed
@@ -1844,7 +1702,7 @@ int register_blocks(int n) { return nblk(n, kBlock); }
 static inline int shard_bound(const RegistrationBuffers& rb) {
   return rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;
 }
-// variant (LII_KNN_VARIANT): 0 = k_knn_ck, four lanes per query (the product form); 5 = k_knn_exact (builds with -DLII_KNN_EXACT).
+// The search launch: k_knn_ck, four lanes per query.
 // 128 lanes per workgroup, 6 loads in flight per lane, 7 wavefronts per SIMD (69 VGPRs): measured on the per-lane form of rounds 3 - 4
 // against 64 / 256 lanes, 4 .. 12 loads, 6 / 8 wavefronts per SIMD (within 1 - 2 %: profiles/r03_knn_ab.md), and 2 / 1 lanes per query
 // (slower at every cloud size: profiles/r05_knn_lpq.md).
@@ -1858,19 +1716,12 @@ static inline int shard_bound(const RegistrationBuffers& rb) {
 #define LII_KNN_WPE 7
 #endif
 // epoch: the number of this search launch (> 0; the fit launch behind it gets the same) - or 0: no list of unfinished queries, every
-// workgroup of the fit launch finishes its own (hipGraph replays, whose arguments are frozen; k_knn_exact)
-void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
+// workgroup of the fit launch finishes its own (hipGraph replays, whose arguments are frozen)
+void launch_knn(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                 const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s, int epoch) {
   int nq = nblk(shard_bound(rb), LII_KNN_BS / 4);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
-#ifdef LII_KNN_EXACT
-  if (variant == 5) {
-    hipLaunchKernelGGL((k_knn_exact<128>), dim3(nq_pad), dim3(128), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out);
-    return;
-  }
-#endif
-  (void)variant;
   hipLaunchKernelGGL((k_knn_ck<4, LII_KNN_BS, LII_KNN_NB, LII_KNN_WPE>), dim3(nq_pad), dim3(LII_KNN_BS), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out, epoch);
 }
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {

@@ -29,7 +29,7 @@ void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks
 // registration
 // (`pose`: device memory on every path - a host-driven pass uploads it first)
 // epoch: the number of this search launch (> 0, RegistrationBuffers::flag_*) and of the fit launch behind it; 0: no list of unfinished queries
-void launch_knn(int variant, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
+void launch_knn(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                 const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s, int epoch);
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s);
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,

@@ -15,9 +15,14 @@ try:
 except Exception as e:  # noqa
     val = f"bench failed: {e}"
 per = collections.defaultdict(list)
+slow = collections.defaultdict(list)
 total = None
 try:
     for line in open(tl):
+        m = re.match(r"\| (\d+) \| `([^`]+)` \| ([\d.]+) \| ([\d.]+) \| ([+-][\d.]+) \|", line)  # the slow-scan table: slow / others / +
+        if m:
+            slow[re.sub(r"lii::|<.*", "", m.group(2))].append(float(m.group(5)))
+            continue
         m = re.match(r"Scan period ([\d.]+), of which kernels (\d+\.\d+)", line)
         if m:
             total = float(m.group(2))
@@ -28,4 +33,5 @@ try:
     kinds = "; ".join(f"{k} {'/'.join(f'{x:.1f}' for x in v)}" for k, v in per.items())
 except Exception as e:  # noqa
     kinds = f"timeline failed: {e}"
-print(f"{label}: {val}; kernels {total} us/scan: {kinds}")
+edge = "; ".join(f"{k} {'/'.join(f'{x:+.1f}' for x in v)}" for k, v in slow.items() if max(abs(x) for x in v) >= 0.5)
+print(f"{label}: {val}; kernels {total} us/scan: {kinds}" + (f"\n    slowest eighth of the scans, + per launch: {edge}" if edge else ""))
