@@ -187,6 +187,7 @@ def main():
                          "instead of lii_scan_job::map_update (its launches enqueued behind the update's passes)")
     ap.add_argument("--long-steps", type=int, default=400, help="steps of the second timed region behind `value` (value_long; 0: none; skipped when --steps is larger)")
     ap.add_argument("--kernel-profile-steps", type=int, default=64, help="steps of the per-launch profile pass (roofline.kernels / roofline.scan; 0: none)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC profile instead of two rocprofv3 --pmc passes of this command made now (child processes, ~15 s each)")
     ap.add_argument("--no-calibration", action="store_true", help="leave the calibration record (GPU LI-Init vs oracle / reference result / ground truth) out of the line")
     ap.add_argument("--no-calibration-stream", action="store_true", help="calibration record: the reference's committed run only, not the synthetic LO -> LI-Init stream")
     ap.add_argument("--partition", default=os.environ.get("LII_BENCH_PARTITION", "voxel"), choices=["index", "voxel"],
@@ -549,14 +550,21 @@ def main():
         # the map once (16 B per map point)
         alg_bytes = 96.0 * n_d + 16.0 * M
         achieved = alg_bytes / (avg_search_ms * 1e-3) / 1e9 if avg_search_ms > 0 else 0.0
-        # HBM traffic of the dominant kernel per launch: PMC counters cannot be read inside this process - the figure comes from
-        # the committed rocprofv3 --pmc passes of the same command (tools/collect_pmc.sh) and is labelled as such
+        # HBM traffic of the dominant kernel per launch: PMC counters cannot be read inside this process - a single-rank line measures
+        # them NOW with two rocprofv3 passes around a short run of this command in a child process (measure_traffic_live); otherwise, or
+        # when that fails, the figure comes from the committed passes (tools/collect_pmc.sh) and is labelled as such
         traffic, traffic_source = None, None
+        live_note = None
+        if world == 1 and not args.no_live_traffic and not (args.separate_calls or args.upload or args.python_loop):
+            traffic, traffic_source = measure_traffic_live(args)
+            if traffic is None:
+                live_note, traffic_source = traffic_source, None
         for prof_name in ("r05_pmc_knn.json", "r04_pmc_knn.json"):  # (r04: the per-lane search kernel of round 4 - only until round 5's passes are committed)
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
-                if prof.get("workload") == args.workload:
-                    traffic, traffic_source = prof["hbm_bytes_per_launch"], "profiles/" + prof_name + " (rocprofv3 --pmc passes of this command; not measured in this run)"
+                if traffic is None and prof.get("workload") == args.workload:
+                    traffic, traffic_source = prof["hbm_bytes_per_launch"], ("profiles/" + prof_name + " (rocprofv3 --pmc passes of this command; not measured in this run"
+                                                                             + (": " + live_note if live_note else "") + ")")
                     break
             except Exception:
                 pass
@@ -674,6 +682,55 @@ def cpu_sweep_worker(args):
 def knn_kernel_name():
     return ("k_knn_ck (exact 5-NN into the block-grid local map, 4 lanes/query scanning every cell together, packed 32-bit keys in both "
             "rounds, winners re-measured exactly)")
+
+
+def measure_traffic_live(args):
+    """HBM bytes per executed launch of the dominant kernel, MEASURED NOW: two `rocprofv3 --pmc <counter> --kernel-trace` passes (FETCH_SIZE,
+    WRITE_SIZE - one counter set per pass, no sys / hip / hsa trace domain beside them: MI355X_MICROARCH.md) around a short run of THIS
+    command in a child process; per dispatch of k_knn_ck the counter summed over its rows, executed launches = those above a fifth of the
+    largest (the device-driven loop enqueues launches that find their pass not due and move nothing); FETCH_SIZE / WRITE_SIZE are in KB and
+    gfx950 reports half of the fetched bytes, so the read side is doubled (the guide's correction; tools/summarize_pmc.py does the same on
+    the committed passes).  Returns (bytes per launch, description) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if os.environ.get("LII_BENCH_CHILD") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "this process already runs under a profiler"
+    tmp = tempfile.mkdtemp(prefix="lii_pmc_", dir="/tmp")
+    res = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, ctr), "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "8", "--warmup", "2", "--prime", "0",
+                   "--profile-every", "0", "--no-cpu-baseline", "--no-pipeline", "--no-calibration", "--kernel-profile-steps", "0",
+                   "--long-steps", "0", "--no-live-traffic"] + (["--no-downsample"] if args.no_downsample else [])
+            subprocess.run(cmd, env={**os.environ, "TMPDIR": "/tmp", "LII_BENCH_CHILD": "1"}, cwd="/tmp", timeout=150,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            per = {}
+            for f in glob.glob(os.path.join(tmp, ctr, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k_knn_ck" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        per[(f, r["Dispatch_Id"])] = per.get((f, r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+            vals = sorted(per.values())
+            big = [v for v in vals if v > 0.2 * vals[-1]] if vals else []
+            if not big:
+                return None, f"no {ctr} rows for the search kernel"
+            res[ctr] = (sum(big) / len(big), len(big))
+    except Exception as e:  # a profiler that cannot run here must not cost the line
+        return None, f"{type(e).__name__}: {str(e)[:120]}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch_kb, write_kb = res["FETCH_SIZE"][0], res["WRITE_SIZE"][0]
+    return (2.0 * fetch_kb + write_kb) * 1024.0, (
+        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (one pass each, --kernel-trace beside it) around "
+        f"`bench.py --workload {args.workload} --steps 8` in a child process, mean over {res['FETCH_SIZE'][1]} executed launches; "
+        f"(2 x FETCH_SIZE {fetch_kb:.0f} KB + WRITE_SIZE {write_kb:.0f} KB) x 1024 - gfx950 reports half of the fetched bytes (MI355X_MICROARCH.md)")
+
 
 
 def cpu_baseline(wl, states0, tables, no_downsample, gpu_results, gpu_lists=None, budget_s=14.0):

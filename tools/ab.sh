@@ -3,7 +3,7 @@
 # short profiled run and the scans/s of an unprofiled one.  usage: bash tools/ab.sh <outdir> "<variants>" "<workloads>" [env assignments for every run]
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$1; VARS=$2; WLS=$3; shift; shift; shift; mkdir -p $O
-COMMON="--no-cpu-baseline --no-pipeline --no-calibration --kernel-profile-steps 0 --long-steps 0"
+COMMON="--no-cpu-baseline --no-pipeline --no-calibration --no-live-traffic --kernel-profile-steps 0 --long-steps 0"
 for v in $VARS; do
   if [ "$v" = "tree" ]; then unset LII_LIB; LDP=""; else export LII_LIB=$PWD/build_ab/$v/libliinit_hip.so; LDP=$PWD/build_ab/$v; fi
   for w in $WLS; do

@@ -3,7 +3,8 @@
 S=gpurun_out/$1; R=$2; P=profiles
 cp $S/bench_default.json $P/${R}_bench_default.json
 cp $S/bench_driver_form.json $P/${R}_bench_driver_form.json
-cp $S/${R}_bench_kernel_stats.csv $S/${R}_bench_kernel_summary.md $S/${R}_timeline.md $S/${R}_mapupdate_kernel_summary.md $S/${R}_pmc_knn.json $P/
+cp $S/${R}_bench_kernel_stats.csv $S/${R}_bench_kernel_summary.md $S/${R}_timeline.md $S/${R}_mapupdate_kernel_summary.md $S/${R}_mapupd_timeline.md $S/${R}_pmc_knn.json $P/
+[ -f $S/perscan.txt ] && cp $S/perscan.txt $P/${R}_perscan.txt
 python3 - "$S" "$P/${R}_bench_other_workloads.json" <<'PY'
 import json, sys
 s, out = sys.argv[1], sys.argv[2]
@@ -16,5 +17,5 @@ for name, f in (("vlp16", "bench_vlp16"), ("os1_128", "bench_os1_128"), ("os1_12
         res[name] = {"error": str(e)}
 json.dump(res, open(out, "w"), indent=1)
 PY
-for f in rehearsal_x2 rehearsal_x4 rehearsal_cut3_x2; do tail -1 $S/$f.json > $P/${R}_rehearsal_one_device_${f#rehearsal_}.json; done
+for f in rehearsal_x2 rehearsal_x4 rehearsal_x8 rehearsal_cut3_x2; do [ -f $S/$f.json ] && tail -1 $S/$f.json > $P/${R}_rehearsal_one_device_${f#rehearsal_}.json; done
 ls -la $P | grep $R

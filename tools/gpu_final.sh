@@ -8,7 +8,7 @@ O=gpurun_out/$1; R=${2:-r05}; SKIP=" $3 "; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q --timeout 300 > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|^FAILED|^ERROR" $O/pytest.log | tail -6
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench default rc=$?"; cut -c1-400 $O/bench_default.json
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_form.json 2> $O/bench_driver_form.err; echo "bench driver-form rc=$?"; cut -c1-220 $O/bench_driver_form.json
-CMDP="--steps 100 --warmup 10 --prime 20 --no-cpu-baseline --no-pipeline --no-calibration --kernel-profile-steps 0 --long-steps 0"
+CMDP="--steps 100 --warmup 10 --prime 20 --no-cpu-baseline --no-pipeline --no-calibration --no-live-traffic --kernel-profile-steps 0 --long-steps 0"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o $R -- python bench.py $CMDP > $O/prof.log 2>&1; echo "prof rc=$?"
 python tools/summarize_profile.py $O/prof $O/${R}_bench_kernel_summary.md "Round 5 - python bench.py $CMDP (stream100k, voxel grid on, one lii_scan_register call per scan from the C++ host loop)" > /dev/null 2>&1
 python tools/timeline.py $O/prof $O/${R}_timeline.md "Round 5 - per-scan kernel timeline of the default bench step (stream100k)" > /dev/null 2>&1
@@ -24,8 +24,14 @@ if [[ "$SKIP" != *" others "* ]]; then
 import json; d=json.loads(open('$O/bench_$w.json').readline()); print(round(d['value']), d['ms_per_step'], d['roofline']['avg_launch_ms'], d.get('parity',{}))" 2>&1 | cut -c1-700
   done
 fi
+if [[ "$SKIP" != *" others "* ]]; then
+  X="--no-cpu-baseline --no-pipeline --no-calibration --no-live-traffic --steps 200"
+  LII_KNN_PLAN=0 timeout 200 python bench.py $X > $O/bench_noplan.json 2> $O/bench_noplan.err; echo "LII_KNN_PLAN=0 rc=$?"; cut -c1-100 $O/bench_noplan.json
+  timeout 200 python bench.py $X --upload > $O/bench_upload.json 2> $O/bench_upload.err; echo "--upload rc=$?"; cut -c1-100 $O/bench_upload.json
+  timeout 200 python bench.py $X --no-downsample > $O/bench_nodown.json 2> $O/bench_nodown.err; echo "--no-downsample rc=$?"; cut -c1-100 $O/bench_nodown.json
+fi
 if [[ "$SKIP" != *" map "* ]]; then
-  timeout 300 python bench.py --map-update --no-cpu-baseline --no-pipeline --no-calibration --steps 200 > $O/bench_mapupdate.json 2> $O/bench_mapupdate.err; echo "map-update rc=$?"; cut -c1-130 $O/bench_mapupdate.json
+  timeout 300 python bench.py --map-update --no-cpu-baseline --no-pipeline --no-calibration --no-live-traffic --steps 200 > $O/bench_mapupdate.json 2> $O/bench_mapupdate.err; echo "map-update rc=$?"; cut -c1-130 $O/bench_mapupdate.json
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_map -o $R -- python bench.py $CMDP --map-update > $O/prof_map.log 2>&1; echo "prof map rc=$?"
   python tools/summarize_profile.py $O/prof_map $O/${R}_mapupdate_kernel_summary.md "Round 5 - python bench.py $CMDP --map-update (stream100k; the map update rides in the registration job)" > /dev/null 2>&1
   python tools/timeline.py $O/prof_map $O/${R}_mapupd_timeline.md "Round 5 - per-scan kernel timeline with the map update in the job (stream100k)" > /dev/null 2>&1

@@ -2,7 +2,7 @@
 # Where does a one-off stall sit in the default bench region?  Per-step host times of the C++ loop (LII_STREAM_TRACE) of three fresh processes.
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$1; mkdir -p $O
-F="--no-cpu-baseline --no-pipeline --no-calibration --kernel-profile-steps 0 --long-steps 0"
+F="--no-cpu-baseline --no-pipeline --no-calibration --no-live-traffic --kernel-profile-steps 0 --long-steps 0"
 for r in 1 2 3; do
   LII_STREAM_TRACE=1 timeout 300 python bench.py $F > $O/run$r.json 2> $O/run$r.err
   python - $O/run$r.err $O/run$r.json <<'PY'
