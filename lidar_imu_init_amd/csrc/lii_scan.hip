@@ -714,7 +714,14 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
     (void)block_rank_of_flag(f, s_w, &tot);
     return tot;
   }).y;
-  if (tid == 0 && hold) __hip_atomic_store(counts + blockIdx.x, ((unsigned long long)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (hold) {  // (uniform; tests only) the word must be out before ANY lane of this workgroup frees a slot: a helper that recounts this
+               // block from freed slots trusts its own count only while the word is missing (prefix_below)
+    if (tid == 0) {
+      __hip_atomic_store(counts + blockIdx.x, ((unsigned long long)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
+    __syncthreads();
+  }
   if (blockIdx.x == gridDim.x - 1 && tid == 0) {  // size of the down-sampled cloud
     int n_down = (int)(base + total);
     if (ABS && tb.part_world > 1u && n_down > tb.part_bound) {  // this rank's share outgrew what the launches behind are sized for

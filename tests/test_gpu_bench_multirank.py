@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--steps", "20", "--warmup", "5", "--prime", "10", "--long-steps", "0", "--no-cpu-baseline", "--no-pipeline", "--no-calibration",
-          "--workload", "vlp16"]
+          "--no-live-traffic", "--workload", "vlp16"]
 
 
 def _line(out):
@@ -83,3 +83,19 @@ def test_bench_two_ranks_on_two_devices():
     d = _sharded(2, 29613, one_device=False)
     _check(d, one, 2, ["mailbox", "rccl", "mailbox_host"])
     assert d["transports"]["rccl"]["rccl_ranks"] == 2
+
+
+def test_single_rank_line_measures_its_hbm_traffic_in_the_run():
+    """roofline.traffic of a single-rank line: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) around a short child run of the same
+    command, per executed launch of the search kernel - or, where no profiler can run, the committed passes, saying so and why."""
+    flags = [f for f in COMMON if f != "--no-live-traffic"][:-2] + ["--workload", "stream100k", "--kernel-profile-steps", "0"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + flags, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = _line(p.stdout)["roofline"]
+    assert r["traffic"] is not None and r["traffic_source"]
+    if r["traffic_source"].startswith("measured in this run"):
+        # the search reads every query and the map once and writes five neighbours per query: the counters must land near the
+        # algorithmic bytes (22.6 MB measured against 25.1 MB: the L2 keeps part of the map across the two passes of a scan)
+        assert 0.5 * r["alg_bytes_per_launch"] < r["traffic"] < 1.5 * r["alg_bytes_per_launch"], r
+    else:
+        assert "not measured in this run" in r["traffic_source"], r
