@@ -1,4 +1,4 @@
-"""GPU parity of one registration pass (k_knn_pk + k_fit_reduce + k_reduce91) and of the full iterated update
+"""GPU parity of one registration pass (k_knn_ck + k_fit_reduce + k_reduce91) and of the full iterated update
 against the oracle, through the C-ABI.  Tolerances (stated per SURVEY.md Appendix B):
   * neighbour lists: BIT-EXACT (same 5 points, same float32 squared distances, same order);
   * selected set: identical except at 1-ulp threshold flips (Jaccard >= 0.999);
