@@ -1356,7 +1356,10 @@ __global__ __launch_bounds__(kBlock) void k_knn_complete(GridView g, Registratio
 // SIMD to offer, i.e. up to ~130 k points) instead of scalar ones (160 VGPRs: three per SIMD, but 56 of the pose's scalar registers
 // are spilled into vector-register lanes and fetched back one v_readlane at a time).  Measured: 100 k-point scan 5.9 against 6.5 us
 // per cached-plane launch, 500 k-point scan 18.4 against 17.6 (profiles/r05_head_loads.md): launch_fit_reduce picks by size.
-template <bool POSE_V>
+// PRE: the launch stands behind a search launch (the host knows when it enqueues it): a lane requests its five neighbours at the head,
+// together with everything else, instead of its cached plane and selection flag - the fit of a search pass is then one round trip
+// (head) instead of two (head, lists) in front of the QR.  Should the device not search after all, the plane is fetched late.
+template <bool POSE_V, bool PRE>
 __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView g, RegistrationBuffers rb,
                                                         const PoseArg* __restrict__ pose,
                                                         const IekfCtrl* __restrict__ ctrl, int forced, int imu_en,
@@ -1387,13 +1390,21 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
   double e_pl[4] = {0, 0, 0, 0};
   int e_count = 0;
   unsigned int e_sel = 0;
+  float4 e_nb[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) e_nb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (early) {
     e_body = rb.body[ie];
     e_world = rb.world[ie];
-    const double* pl = rb.plane + 4 * (size_t)ie;
-    e_pl[0] = pl[0]; e_pl[1] = pl[1]; e_pl[2] = pl[2]; e_pl[3] = pl[3];
     e_count = rb.nbr_count[ie];
-    e_sel = rb.selected[ie];
+    if (PRE) {
+#pragma unroll
+      for (int j = 0; j < 5; j++) e_nb[j] = rb.nbr[(size_t)j * rb.cap + ie];
+    } else {
+      const double* pl = rb.plane + 4 * (size_t)ie;
+      e_pl[0] = pl[0]; e_pl[1] = pl[1]; e_pl[2] = pl[2]; e_pl[3] = pl[3];
+      e_sel = rb.selected[ie];
+    }
   }
   // (a completion workgroup: entry `lane` of the search pass's list - its length arrives with the scalars below, what lies behind the
   // end is read and dropped)
@@ -1516,6 +1527,10 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
         found = sh_needy.found[threadIdx.x & (kHandOver - 1)];
 #pragma unroll
         for (int j = 0; j < 5; j++) nb[j] = sh_needy.nb[threadIdx.x & (kHandOver - 1)][j];
+      } else if (PRE && early && !(e_count & kNeedy)) {  // (an unflagged query: nobody has touched its list since the search pass wrote it)
+        found = e_count;
+#pragma unroll
+        for (int j = 0; j < 5; j++) nb[j] = e_nb[j];
       } else {
         found = rb.nbr_count[i];
 #pragma unroll
@@ -1534,7 +1549,7 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
       wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
       wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
       rb.world[i] = make_float4(wx, wy, wz, 0.f);
-      if (early) {
+      if (early && !PRE) {
         candidate = e_sel != 0;
         pa = e_pl[0]; pbn = e_pl[1]; pc = e_pl[2]; pd = e_pl[3];
       } else {
@@ -1736,8 +1751,15 @@ void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const P
   const int nb_pad = ((nb + 7) / 8) * 8;
   // (four wavefronts per workgroup on 1024 SIMDs: up to 512 workgroups are two wavefronts per SIMD at most)
   // (+ the completion workgroups behind the workgroups of the cloud)
-  if (nb <= 512) hipLaunchKernelGGL(k_fit_reduce<true>, dim3(nb_pad + kCompletionBlocks), dim3(kBlock), 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb, epoch);
-  else hipLaunchKernelGGL(k_fit_reduce<false>, dim3(nb_pad + kCompletionBlocks), dim3(kBlock), 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb, epoch);
+  const dim3 grid(nb_pad + kCompletionBlocks), block(kBlock);
+  const bool pre = epoch > 0;  // behind a search launch that lists its unfinished queries: the lanes request their neighbour lists at the head
+  if (nb <= 512) {
+    if (pre) hipLaunchKernelGGL((k_fit_reduce<true, true>), grid, block, 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb, epoch);
+    else hipLaunchKernelGGL((k_fit_reduce<true, false>), grid, block, 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb, epoch);
+  } else {
+    if (pre) hipLaunchKernelGGL((k_fit_reduce<false, true>), grid, block, 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb, epoch);
+    else hipLaunchKernelGGL((k_fit_reduce<false, false>), grid, block, 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb, epoch);
+  }
 }
 void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s) {
   int nb = nblk(shard_bound(rb), kBlock);
