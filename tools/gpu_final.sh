@@ -2,10 +2,12 @@
 # Round-end measurement pass (run on the GPU box from the repo root): the -m gpu suite, the default bench line, the driver's form, kernel
 # trace + stats + timeline of the same command, the PMC passes of the dominant kernel, the other workloads WITH the CPU baseline (every
 # record carries `parity`), the map-update form, the one-device multi-rank rehearsals.  Everything lands under gpurun_out/$1; the
-# summaries to keep are copied to profiles/ by hand.  usage: bash tools/gpu_final.sh <outdir> <rNN> [skip-list: words of pmc others map rehearsal]
+# summaries to keep are copied to profiles/ by hand.  usage: bash tools/gpu_final.sh <outdir> <rNN> [skip-list: words of tests pmc others map rehearsal]
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$1; R=${2:-r05}; SKIP=" $3 "; mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -q --timeout 300 > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|^FAILED|^ERROR" $O/pytest.log | tail -6
+if [[ "$SKIP" != *" tests "* ]]; then
+  timeout 900 python -m pytest tests -m gpu -q --timeout 300 > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|^FAILED|^ERROR" $O/pytest.log | tail -6
+fi
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench default rc=$?"; cut -c1-400 $O/bench_default.json
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_form.json 2> $O/bench_driver_form.err; echo "bench driver-form rc=$?"; cut -c1-220 $O/bench_driver_form.json
 CMDP="--steps 100 --warmup 10 --prime 20 --no-cpu-baseline --no-pipeline --no-calibration --no-live-traffic --kernel-profile-steps 0 --long-steps 0"
@@ -44,5 +46,5 @@ if [[ "$SKIP" != *" rehearsal "* ]]; then
   LII_BENCH_ONE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --workload os1_128_cut3 --steps 200 --no-cpu-baseline --no-calibration > $O/rehearsal_cut3_x2.json 2> $O/rehearsal_cut3_x2.err; echo "rehearsal cut3 x2 rc=$?"; tail -1 $O/rehearsal_cut3_x2.json | cut -c1-300
 fi
 timeout 200 python tools/perscan.py > $O/perscan.txt 2>&1; tail -8 $O/perscan.txt | cut -c1-60
-timeout 600 python bench.py > $O/bench_default_2.json 2> $O/bench_default_2.err; echo "bench default (second run) rc=$?"; python -c "
+[[ "$SKIP" == *" second "* ]] || timeout 600 python bench.py > $O/bench_default_2.json 2> $O/bench_default_2.err; echo "bench default (second run) rc=$?"; python -c "
 import json; d=json.loads(open('$O/bench_default_2.json').readline()); print(round(d['value']), d.get('slowest_step'), round(d['complete_pipeline']['value']))"
