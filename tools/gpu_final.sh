@@ -46,5 +46,6 @@ if [[ "$SKIP" != *" rehearsal "* ]]; then
   LII_BENCH_ONE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --workload os1_128_cut3 --steps 200 --no-cpu-baseline --no-calibration > $O/rehearsal_cut3_x2.json 2> $O/rehearsal_cut3_x2.err; echo "rehearsal cut3 x2 rc=$?"; tail -1 $O/rehearsal_cut3_x2.json | cut -c1-300
 fi
 timeout 200 python tools/perscan.py > $O/perscan.txt 2>&1; tail -8 $O/perscan.txt | cut -c1-60
-[[ "$SKIP" == *" second "* ]] || timeout 600 python bench.py > $O/bench_default_2.json 2> $O/bench_default_2.err; echo "bench default (second run) rc=$?"; python -c "
+[[ "$SKIP" == *" second "* ]] && exit 0
+timeout 600 python bench.py > $O/bench_default_2.json 2> $O/bench_default_2.err; echo "bench default (second run) rc=$?"; python -c "
 import json; d=json.loads(open('$O/bench_default_2.json').readline()); print(round(d['value']), d.get('slowest_step'), round(d['complete_pipeline']['value']))"
