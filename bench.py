@@ -239,8 +239,13 @@ def main():
         reg.comm_set_partition(partition_now[0])
 
     partition_now = [args.partition]
+    # Which transport of the 91-scalar exchange `value` is measured on: ranks on distinct devices -> RCCL (north_star / SURVEY 8(e):
+    # "one RCCL all-reduce", so the headline line says config.transport "rccl" and config.rccl_ranks == world); the library's own
+    # node-local choice (the peer-mapped HBM mailbox) and the host mailbox are timed beside it under `transports`.  Ranks
+    # rehearsing on ONE device cannot use RCCL (it refuses two ranks on a device): the library's choice there.
+    default_transport = os.environ.get("LII_BENCH_TRANSPORT", "auto" if one_device else "rccl")
     if world > 1:
-        attach(os.environ.get("LII_BENCH_TRANSPORT", "auto"))
+        attach(default_transport)
     reg.map_build(wl["map"])
     reg.map_commit()
     # Every rank receives the WHOLE scan (and holds the whole map) and the library splits the work (lii_comm_set_partition): by voxel
@@ -385,12 +390,12 @@ def main():
     slowest_step = {}  # of the most recent timed region (host clock per step, C++ host loop only)
     transports = None
     if world > 1:
-        # A sharded job is timed once per transport of the 91-scalar exchange, same steps, same scans: the default (the library's
-        # own choice on one node: the peer-mapped HBM mailbox - a push over xGMI inside the reduce+solve launch) gives `value`;
-        # RCCL (ncclAllReduce between a separate final-sum and solve launch) is timed beside it - on one device only the mailbox
-        # forms can run (RCCL refuses two ranks on a device).  LII_BENCH_TRANSPORT pins `value` to one of them.
-        first = os.environ.get("LII_BENCH_TRANSPORT", "auto")
-        others = [t for t in (["mailbox_host"] if one_device else ["rccl", "mailbox_host"]) if t != first]
+        # A sharded job is timed once per transport of the 91-scalar exchange, same steps, same scans: `default_transport` gives
+        # `value` (RCCL on distinct devices: ncclAllReduce between a separate final-sum and solve launch); the library's own
+        # node-local choice ("auto": the peer-mapped HBM mailbox - a push over xGMI inside the reduce+solve launch) and the host
+        # mailbox are timed beside it - on one device only the mailbox forms can run.  LII_BENCH_TRANSPORT pins `value` to one of them.
+        first = default_transport
+        others = [t for t in (["mailbox_host"] if one_device else ["rccl", "auto", "mailbox_host"]) if t != first]
         transports = {}
         dt = None
         for n_run, t in enumerate([first] + others):
