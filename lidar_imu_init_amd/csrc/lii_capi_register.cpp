@@ -595,7 +595,7 @@ int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* s
     HIPCHK(h, hipMemcpyAsync(h->h_stage, h->d_nbr_count, sizeof(int) * size_t(n), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     const int* src = reinterpret_cast<const int*>(h->h_stage);
-    for (int i = 0; i < n; i++) counts[i] = src[perm ? perm[i] : i];
+    for (int i = 0; i < n; i++) counts[i] = src[perm ? perm[i] : i] & kCountMask;  // (without the completion flags)
   }
   if (selected) {
     HIPCHK(h, hipMemcpyAsync(h->h_stage, h->d_selected, size_t(n), hipMemcpyDeviceToHost, s));

@@ -7,6 +7,10 @@ namespace lii {
 
 constexpr int kMatch = 5;          // NUM_MATCH_POINTS — reference include/common_lib.h:28
 constexpr int kNeedy = 0x100;      // nbr_count flag: the 3x3x3 search pass could not prove this list exact yet
+constexpr int kDone = 0x400;       // ... finished by a COMPLETION workgroup of the fit launch behind the search pass: the workgroups of the cloud leave the
+                                   // point out whether they read its count before (kNeedy) or after (kDone) the completion stored it (ownership must
+                                   // not depend on when a workgroup of the same launch looks).  Readers of the count mask with kCountMask.
+constexpr int kCountMask = 0xFF;
 constexpr int kCovered = 0x200;    // ... but measured every point of those cells: the list is exact over them (the completion skips them)
 constexpr int kBlock = 256;        // 4 wavefronts of 64
 constexpr int kNormalEq = 91;      // 78 + 12 + 1

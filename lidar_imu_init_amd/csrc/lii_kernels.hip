@@ -1274,7 +1274,7 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
 // lds_nb / lds_found (or null): the finished list and its count also go to the workgroup's LDS, for the lane that fits this query.
 __device__ __forceinline__ void complete_one(const GridView& g, const RegistrationBuffers& rb, int qi, int c00, float wx, float wy, float wz,
                                              unsigned int* __restrict__ far_list, float4* __restrict__ lds_nb = nullptr,
-                                             int* __restrict__ lds_found = nullptr) {
+                                             int* __restrict__ lds_found = nullptr, int mark = 0) {
   const int lane = threadIdx.x & 63;
   const int c0 = c00 & 0xFF;
   const bool seeded = (c00 & kCovered) != 0;  // uniform
@@ -1297,7 +1297,7 @@ __device__ __forceinline__ void complete_one(const GridView& g, const Registrati
     if (lds_nb) lds_nb[lane] = v;
   } else if (lane == 5) {
     const int found = (oi[0] != -1) + (oi[1] != -1) + (oi[2] != -1) + (oi[3] != -1) + (oi[4] != -1);
-    rb.nbr_count[qi] = found;
+    rb.nbr_count[qi] = found | mark;  // (mark: kDone from a completion workgroup - see lii_device.h)
     if (lds_found) *lds_found = found;
   }
 }
@@ -1447,7 +1447,9 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
       const int count0 = live ? (early ? e_count : rb.nbr_count[i]) : 0;
       if (live) w4 = early ? e_world : rb.world[i];  // written by the search pass with the same arithmetic
       if (defer) {
-        skip_row = live && (count0 & kNeedy) != 0;
+        // (kNeedy: not completed yet; kDone: a completion workgroup of THIS launch has stored the finished list already - the
+        // point is theirs either way, and its list may be half rewritten: never read here)
+        skip_row = live && (count0 & (kNeedy | kDone)) != 0;
       } else {
         // (the far lists live where the launch's final reduction stages its rows later: one wavefront's row area holds kFarCap words)
         static_assert(sizeof(sh.row[0]) >= sizeof(unsigned int) * kFarCap, "far list");
@@ -1491,7 +1493,7 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
       for (int e = wave; e < m; e += kBlock / 64)  // one wavefront per query
         complete_one(g, rb, sh_needy.aux[e], sh_needy.count[e], sh_needy.w[e][0], sh_needy.w[e][1], sh_needy.w[e][2],
                      reinterpret_cast<unsigned int*>(&sh.row[0][0]) + wave * kFarCap, e < kHandOver ? &sh_needy.nb[e][0] : nullptr,
-                     e < kHandOver ? &sh_needy.found[e] : nullptr);
+                     e < kHandOver ? &sh_needy.found[e] : nullptr, kDone);
       __syncthreads();  // the completed lists are visible to the lanes that fit them (workgroup-scope release / acquire)
       if ((int)threadIdx.x < m) {
         i = sh_needy.aux[threadIdx.x];
@@ -1527,12 +1529,12 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
         found = sh_needy.found[threadIdx.x & (kHandOver - 1)];
 #pragma unroll
         for (int j = 0; j < 5; j++) nb[j] = sh_needy.nb[threadIdx.x & (kHandOver - 1)][j];
-      } else if (PRE && early && !(e_count & kNeedy)) {  // (an unflagged query: nobody has touched its list since the search pass wrote it)
+      } else if (PRE && early && !(e_count & (kNeedy | kDone))) {  // (an unflagged query: nobody has touched its list since the search pass wrote it)
         found = e_count;
 #pragma unroll
         for (int j = 0; j < 5; j++) nb[j] = e_nb[j];
       } else {
-        found = rb.nbr_count[i];
+        found = rb.nbr_count[i] & kCountMask;
 #pragma unroll
         for (int j = 0; j < 5; j++) nb[j] = rb.nbr[(size_t)j * rb.cap + i];
       }

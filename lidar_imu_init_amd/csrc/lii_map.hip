@@ -148,7 +148,7 @@ __device__ __forceinline__ MapDecision map_decide_point(const RegistrationBuffer
     const float wy = (float)(ps.R[3] * ix + ps.R[4] * iy + ps.R[5] * iz + ps.p[1]);
     const float wz = (float)(ps.R[6] * ix + ps.R[7] * iy + ps.R[8] * iz + ps.p[2]);
     d.wp = make_float4(wx, wy, wz, 0.f);
-    const int cnt = have_search ? rb.nbr_count[i] : 0;
+    const int cnt = have_search ? (rb.nbr_count[i] & kCountMask) : 0;
     if (cnt > 0) {
       // mid_point = floor(p / filter_size_map) * filter_size_map + 0.5 * filter_size_map, double math stored to float (:529-534)
       const float mx = (float)(floor(wx / fsd) * fsd + 0.5 * fsd);

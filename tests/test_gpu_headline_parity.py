@@ -119,3 +119,30 @@ def test_downsampled_cloud_is_bit_identical_at_bench_size(world, oracle):
         assert np.array_equal(got, ref)
     else:
         assert np.max(np.abs(got - ref)) <= 4e-6
+
+
+@pytest.mark.parametrize("workload", ["stream100k", "dense500k"])
+def test_registration_is_bit_identical_run_to_run(world, oracle, workload):
+    """behind a search pass the completion workgroups of k_fit_reduce rewrite the flagged queries' lists and counts
+    WHILE the workgroups of the cloud of the same launch decide from those counts whether a point is theirs.  Ownership now rests on
+    flags that say "not mine" before (kNeedy) and after (kDone) the completion: the normal equations - and with them every bit of
+    the result - must not depend on which workgroup ran first.  dense500k is the launch with ~1 300 workgroups (more than the chip
+    holds at once) the finding was about; five runs from the same state must agree to the last bit, the neighbour lists included."""
+    import bench
+    cache, reg, tree = world
+    wl = bench.build_workload(workload, 1, map_cache=cache)
+    states0, tables = bench.start_states(wl)
+    dev = reg.device_scan(wl["scans"][0])
+    first = None
+    for run in range(5):
+        st = states0[0].copy()
+        rep = reg.scan_register(st, states0[0], imu_poses=tables[0], leaf=wl["fs_surf"], max_iterations=wl["max_it"], imu_en=True,
+                                scan_dev=dev, scan_sorted=True)
+        nb, cnt, sel = reg.neighbors(len(reg.scan_download(1)))
+        got = (np.array(st.pod).tobytes(), rep["iterations"], rep["searches"], rep["effect_num"], nb.tobytes(), cnt.tobytes(), sel.tobytes())
+        if first is None:
+            first = got
+            assert cnt.max() <= 5  # the completion flags never leave the library
+        else:
+            for a, b, what in zip(first, got, ("state", "iterations", "searches", "effect_num", "neighbours", "counts", "selected")):
+                assert a == b, f"run {run}: {what} differs from run 0"
