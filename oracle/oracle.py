@@ -623,3 +623,72 @@ def ref_imu_process_cv(lidar_beg_time, time_last_scan, first_frame, cov_gyr_scal
     if rc != 0:
         raise RuntimeError(f"ref_imu_process_cv failed ({rc})")
     return st, p
+
+
+# ------------------------------------------------------------------------------------------------
+_ref_iekf = None
+
+
+def ref_iekf_lib():
+    """The reference's OWN TEXT of the per-scan update (src/laserMapping.cpp:936-1134 + map_incremental :516-559, cut out at build
+    time by oracle/ref_slice_iekf.py) with the unmodified esti_plane / StatesGroup / ikd-Tree, built by `make -C oracle ref` into
+    oracle/_ref/libref_iekf.so (None when it was never built).  ONE map and ONE set of the reference's file-scope variables per process."""
+    global _ref_iekf
+    if _ref_iekf is None:
+        path = os.path.join(_HERE, "_ref", "libref_iekf.so")
+        if not os.path.exists(path):
+            return None
+        L = C.CDLL(path)
+        F, D, I, U = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_ubyte)
+        L.ref_iekf_map_build.argtypes = [F, C.c_int, C.c_double]
+        L.ref_iekf_update.argtypes = [F, C.c_int, D, C.c_int, C.c_int, I, I, I, U, F, F, I]
+        L.ref_iekf_map_incremental.argtypes = [I]
+        L.ref_iekf_tree_flatten.argtypes = [F, C.c_int, C.c_int]
+        L.ref_esti_plane.argtypes = [F, C.c_double, D]
+        _ref_iekf = L
+    return _ref_iekf
+
+
+class RefIekf:
+    """numpy front-end of ref_iekf_lib(): map_build(xyz, filter_size_map); update(body, state) -> dict shaped like Tree.iekf_update's
+    (state, iters, rematch, effect_num, nearest, nearest_n, selected, normvec); map_incremental() -> (add_point_size, tree size);
+    flatten()."""
+
+    def __init__(self):
+        self.L = ref_iekf_lib()
+        assert self.L is not None, "oracle/_ref/libref_iekf.so not built (make -C oracle ref, needs /root/reference)"
+
+    def map_build(self, xyz, filter_size_map):
+        xyz = _f32(xyz, 3)
+        return self.L.ref_iekf_map_build(_fp(xyz), len(xyz), float(filter_size_map))
+
+    def update(self, body, state, max_iterations=4, imu_en=False):
+        body = _f32(np.asarray(body)[:, :3], 3)
+        n = len(body)
+        st = _f64(state).copy()
+        it, rm, eff = C.c_int(0), C.c_int(0), C.c_int(0)
+        sel = np.zeros(n, np.uint8)
+        normvec = np.zeros((n, 4), np.float32)
+        near = np.zeros((n, 5, 3), np.float32)
+        nn = np.zeros(n, np.int32)
+        rc = self.L.ref_iekf_update(_fp(body), n, _dp(st), max_iterations, int(imu_en), C.byref(it), C.byref(rm), C.byref(eff),
+                                    sel.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(normvec), _fp(near), _ip(nn))
+        assert rc == 0, "more than 100 000 points: the reference's arrays end there (quirk A1)"
+        return dict(state=st, iters=it.value, rematch=rm.value, effect_num=eff.value, selected=sel, normvec=normvec, nearest=near,
+                    nearest_n=nn)
+
+    def esti_plane(self, pts5x3, threshold=0.1):
+        pts = _f32(np.asarray(pts5x3).reshape(5, 3), 3)
+        out = np.zeros(4)
+        ok = self.L.ref_esti_plane(_fp(pts), float(threshold), _dp(out))
+        return bool(ok), out
+
+    def map_incremental(self):
+        ts = C.c_int(0)
+        added = self.L.ref_iekf_map_incremental(C.byref(ts))
+        return added, ts.value
+
+    def flatten(self, settle_ms=200, cap=4_000_000):
+        out = np.zeros((cap, 3), np.float32)
+        n = self.L.ref_iekf_tree_flatten(_fp(out), cap, settle_ms)
+        return out[:n].copy()

@@ -14,10 +14,14 @@
 //   * K(24 x m) is never materialised by default: K z = K1[:, :12](H^T R^-1 z) and
 //     K H = K1[:, :12](H^T R^-1 H) exactly; `literal_gain` forms K as the reference
 //     does, for the equivalence test.
-// Parity status: UNPINNED by the reference (no point clouds or tests are committed); validated by closed-form
-// synthetic ground truth (tests/test_oracle_core.py::test_iekf_recovers_known_pose_and_literal_gain) and by an independent numpy
-// iteration with the literal 24 x m gain (tests/test_oracle_iekf_independent.py); its so3 / StatesGroup algebra (orc_math.hpp) is
-// pinned bit for bit to the reference's headers (tests/test_oracle_math_pinned.py).
+// Parity status: PINNED TO THE REFERENCE'S OWN TEXT around the linear algebra (round 6): `make -C oracle ref` cuts
+// src/laserMapping.cpp:936-1134 and :516-559 out of the reference at build time and compiles them, with the unmodified
+// include/common_lib.h, so3_math.h and ikd-Tree, into oracle/_ref/libref_iekf.so; tests/test_oracle_iekf_pinned.py holds this file -
+// in `literal_gain` mode - BIT FOR BIT to it over consecutive LO and LIO scans with map_incremental between them (state, covariance,
+// schedule, selected set, normvec, the tree), and measures the default sums form against it (<= 1e-12 LO, <= 1e-10 LIO).  Still
+// unpinned (no Eigen on disk): the insides of Eigen's inverse(), ColPivHouseholderQR and matrix products, which that library takes
+// from this oracle.  Independent checks: closed-form synthetic ground truth (tests/test_oracle_core.py) and an independent numpy
+// iteration with the literal gain (tests/test_oracle_iekf_independent.py).
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -124,11 +128,14 @@ inline void jacobian_row(const State& st, const float* pb, const float* nv4, int
   M3 cm = skew(p_this);
   V3 nvec(nv4[0], nv4[1], nv4[2]);
   M3 Rt = transpose(st.rot_end);
-  V3 A = cm * (Rt * nvec);
+  // (Eigen evaluates a chain of products left to right, every inner product into a temporary: (cm * Rt) * nvec, :1059 - the
+  // association is part of the rounding, and in LIO mode the normal matrix amplifies a last-bit difference of a row to ~1e-8 in
+  // the extrinsic states: tests/test_oracle_iekf_pinned.py holds this function to the reference's text)
+  V3 A = (cm * Rt) * nvec;
   h[0] = A.x; h[1] = A.y; h[2] = A.z;
   h[3] = nv4[0]; h[4] = nv4[1]; h[5] = nv4[2];
   if (imu_en) {
-    V3 H_R_LI = skew(pL) * (transpose(st.offset_R_L_I) * (Rt * nvec));
+    V3 H_R_LI = ((skew(pL) * transpose(st.offset_R_L_I)) * Rt) * nvec;  // :1055-1056, left to right
     V3 H_T_LI = Rt * nvec;
     h[6] = H_R_LI.x; h[7] = H_R_LI.y; h[8] = H_R_LI.z;
     h[9] = H_T_LI.x; h[10] = H_T_LI.y; h[11] = H_T_LI.z;

@@ -11,6 +11,9 @@ struct PointCloud {
   std::vector<T> points;
   std::uint32_t width = 0, height = 0;
   bool is_dense = true;
+  PointCloud() {}
+  PointCloud(std::uint32_t w, std::uint32_t h) : points(std::size_t(w) * h), width(w), height(h) {}  // (src/laserMapping.cpp:117-119)
+  bool empty() const { return points.empty(); }
   std::size_t size() const { return points.size(); }
   void clear() { points.clear(); width = height = 0; }
   void reserve(std::size_t n) { points.reserve(n); }
