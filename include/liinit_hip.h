@@ -397,7 +397,10 @@ int lii_comm_describe(lii_handle h, char* out, int32_t capacity);
 int lii_comm_rccl_ranks(lii_handle h, int32_t* n_ranks);  /* ncclCommCount of the attached RCCL communicator; 0: none attached */
 int lii_comm_set_partition(lii_handle h, int32_t library_partition);  /* 0 caller | 1 by index (default) | 2 by voxel */
 int lii_comm_destroy(lii_handle h);
-/* Self-test of the list exchange of a sharded job's map update (lii_map_incremental; lii_exchange.hip) with n_ranks > 1 on ONE device:
+/* TEST ENTRY POINT - not part of the per-scan path.  It plays its ranks in the handle's own list buffers: LII_ERR_STATE while a map update
+ * of the handle is pending (its lists would be overwritten; call lii_map_commit first); leaves the exchange's sequence number and scratch
+ * as it found them.
+ * Self-test of the list exchange of a sharded job's map update (lii_map_incremental; lii_exchange.hip) with n_ranks > 1 on ONE device:
  * the handle (not a rank of a job) plays rank 0 .. n_ranks - 1 in turn.  form 0: the gather areas of the mailbox transport; form 1:
  * the trimmed all-gather layout of the RCCL transport (the functions lists_exchange_rccl is made of, device copies standing in for the
  * two ncclAllGather calls - a communicator holds one rank per device, the layout can still be exercised).  Rank r's lists: n_add[r] /

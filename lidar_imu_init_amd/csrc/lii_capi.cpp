@@ -49,6 +49,9 @@ GridView grid_view(const lii_context* c) {
   g.cs = c->cell_size;
   g.inv_cs = 1.0f / c->cell_size;
   g.max_d2 = c->cfg.max_match_dist2;
+  g.win = (c->win_valid && !c->map_dirty) ? c->d_win : nullptr;
+  g.wx0 = c->win_org[0]; g.wy0 = c->win_org[1]; g.wz0 = c->win_org[2];
+  g.wnx = c->win_dim[0]; g.wny = c->win_dim[1]; g.wnz = c->win_dim[2];
   return g;
 }
 RegistrationBuffers reg_buffers(const lii_context* c) {
@@ -161,6 +164,8 @@ MailboxView mailbox_view(lii_handle h) {
   v.n_ranks = h->net.n_ranks;
   v.rank = h->net.rank;
   v.timeout_ticks = h->net.mailbox_timeout_ticks;
+  v.handoff_ticks = h->test_sum_lost ? 20000000ll : 200000000ll;  // 0.2 s under test, 2 s otherwise
+  v.test_drop_sum = h->test_sum_lost ? 1 : 0;
   return v;
 }
 
@@ -220,6 +225,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     if (std::string(v) == "hash") { h->vh_pinned = true; h->vh_mode = 1; }
   }
   if (const char* v = std::getenv("LII_KNN_PLAN")) h->knn_plan = std::atoi(v) != 0;
+  if (const char* v = std::getenv("LII_WINDOW")) h->use_window = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_TEST")) {
     // arrangements the test-suite and the A/B measurements ask for, comma-separated: "map_tight" (an in-place map update without
     // spare room), "plan_force=<mask>" (a launch plan that is wrong on purpose), "host_solve" (the iteration loop driven from the
@@ -249,6 +255,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     h->test_force_rebuild = t.find("force_rebuild") != std::string::npos;
     h->no_gather = t.find("no_gather") != std::string::npos;
     h->test_emit_late = t.find("emit_late") != std::string::npos;
+    h->test_sum_lost = t.find("sum_lost") != std::string::npos;
     const size_t qs = t.find("solo_share=");
     if (qs != std::string::npos) h->solo_share = int(std::strtol(t.c_str() + qs + 11, nullptr, 0));
   }
@@ -411,6 +418,14 @@ int lii_destroy(lii_handle h) {
   if (h->net.comm) ncclCommDestroy(h->net.comm);
   if (h->map_stream) (void)hipStreamSynchronize(h->map_stream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+#ifdef LII_GAP_TRACE
+  if (h->d_gran) {
+    unsigned long long g[4] = {0, 0, 0, 0};
+    if (hipMemcpy(g, h->d_gran + 200, sizeof(g), hipMemcpyDeviceToHost) == hipSuccess && g[2] > 0)
+      std::fprintf(stderr, "[libliinit_hip gap trace] device idle between the stopping solve of a scan and the first kernel of the next: %.2f us mean over %llu "
+                   "back-to-back scans (%llu gaps of 50 us or more left out)\n", 0.01 * double(g[1]) / double(g[2]), g[2], g[3]);
+  }
+#endif
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] map updates completed by a rebuild + re-insertion: %lld\n", h->map_recoveries);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] updates continued by the host after a parked loop: %lld\n", h->plan_parked);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] map updates repeated with exact list sizes: %lld\n", h->map_repeats);
@@ -433,7 +448,7 @@ int lii_destroy(lii_handle h) {
   if (h->ev_scan_free) (void)hipEventDestroy(h->ev_scan_free);
   if (h->h_stage_next) (void)hipHostFree(h->h_stage_next);
   if (h->d_scan_next) (void)hipFree(h->d_scan_next);
-  void* dev[] = {h->d_dropped, h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells,
+  void* dev[] = {h->d_dropped, h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells, h->d_win,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_ah_key, h->d_ah_best, h->d_ah_slot, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_gran, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
                  h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->vh.slots, h->vh.slot_of, h->vh.next, h->vh.counts, h->vh.crowded, h->cal.d_cal_imu, h->cal.d_cal_lidar, h->cal.d_cal_params,

@@ -241,6 +241,19 @@ int lii_selftest_list_exchange(lii_handle h, int32_t n_ranks, int32_t form, cons
   if (!h || n_ranks < 1 || n_ranks > kMailboxMaxRanks || (form != 0 && form != 1) || !n_add || !n_nodown || !out_add || !out_n_add || !out_nodown || !out_n_nodown)
     return fail(h, LII_ERR_INVALID, "lii_selftest_list_exchange: bad arguments");
   if (h->net.n_ranks > 1 || h->net.comm) return fail(h, LII_ERR_STATE, "lii_selftest_list_exchange: the handle is a rank of a job");
+  // TEST ENTRY POINT: it plays its ranks in the handle's own list buffers (d_list_add / d_list_nodown / d_counts).  A map update whose
+  // lists have not been consumed yet would be clobbered without a trace - refused; the sequence number and the all-gather
+  // scratch it uses are put back / released on every way out.
+  if (h->map_async || h->map_dirty || h->lists_predicted || h->map_enqueued_early)
+    return fail(h, LII_ERR_STATE, "lii_selftest_list_exchange: a map update is pending on this handle (call lii_map_commit first)");
+  const unsigned long long gather_seq_at_entry = h->net.gather_seq;
+  struct Restore {
+    lii_handle h; unsigned long long seq;
+    ~Restore() {
+      h->net.gather_seq = seq;
+      if (h->net.d_gx) { (void)hipFree(h->net.d_gx); h->net.d_gx = nullptr; h->net.gx_block = 0; h->net.gx_ranks = 0; }
+    }
+  } restore{h, gather_seq_at_entry};
   const int N = n_ranks, cap = h->cfg.max_scan_points;
   std::vector<size_t> at_a(size_t(N) + 1, 0), at_n(size_t(N) + 1, 0);
   for (int r = 0; r < N; r++) {

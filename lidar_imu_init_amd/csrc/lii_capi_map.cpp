@@ -81,6 +81,39 @@ int build_index(lii_handle h, int n, int extra_blocks) {
     launch_spread(h->d_map, h->d_cells, h->d_cell_cap, caps, capsum, ne, h->d_pts, h->d_mapctr, n, int(n_blocks), s);
   }
   HIPCHK(h, hipGetLastError());
+  h->win_valid = false;
+  if (h->use_window && n > 0) {
+    // the dense cell window: the box of the occupied blocks, one block of margin on every side (queries at the map's edge look one
+    // cell out), if it fits 64 MiB of entries
+    unsigned int* box = reinterpret_cast<unsigned int*>(h->d_cs_a);  // (free again)
+    const unsigned int init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    std::memcpy(h->h_small + 2100, init, sizeof(init));
+    HIPCHK(h, hipMemcpyAsync(box, h->h_small + 2100, sizeof(init), hipMemcpyHostToDevice, s));
+    launch_win_bbox(h->d_blocks, bcap, box, s);
+    HIPCHK(h, hipMemcpyAsync(h->h_small + 2100, box, sizeof(init), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    unsigned int bxx[6];
+    std::memcpy(bxx, h->h_small + 2100, sizeof(bxx));
+    const int bb = kCellBias >> kCoarseShift;
+    size_t entries_w = 1;
+    for (int a = 0; a < 3; a++) {
+      h->win_org[a] = (int(bxx[a]) - bb - 1) * 8;
+      h->win_dim[a] = (int(bxx[3 + a]) - int(bxx[a]) + 3) * 8;
+      entries_w *= size_t(h->win_dim[a]);
+    }
+    if (bxx[0] <= bxx[3] && entries_w * sizeof(uint2) <= (64u << 20)) {
+      if (entries_w > h->win_cap) {
+        if (h->d_win) HIPCHK(h, hipFree(h->d_win));
+        h->d_win = nullptr;
+        HIPCHK(h, dmalloc(&h->d_win, entries_w));
+        h->win_cap = entries_w;
+      }
+      HIPCHK(h, hipMemsetAsync(h->d_win, 0, sizeof(uint2) * entries_w, s));
+      launch_win_fill(h->d_blocks, bcap, h->d_cells, h->d_win, h->win_org, h->win_dim, s);
+      HIPCHK(h, hipGetLastError());
+      h->win_valid = true;
+    }
+  }
   int rc = LII_OK;
   {  // the slots in use (sum of the capacities) - and a first capacity check
     HIPCHK(h, hipMemcpyAsync(h->h_small + 3072, h->d_mapctr, sizeof(int) * kMapCtrWords, hipMemcpyDeviceToHost, s));
@@ -309,6 +342,7 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
   }
   launch_ins_cells(list_a, flags_a, n_list, flags_a ? nullptr : n_list_dev, extra, n_extra, n_extra_dev, h->d_ins_e2, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp,
                    h->d_work, h->d_mapctr, h->work_cap, h->d_dropped, h->drop_cap, s);
+  h->win_valid = false;  // (cell entries change: the dense window is a copy of them as build_index left them)
   launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap_eff, (int)work_need, s);
   h->map_seq = h->map_seq == 0x7FFFFFFF ? 1 : h->map_seq + 1;
   launch_ins_write(list_a, h->d_ins_e, n_list, flags_a ? nullptr : n_list_dev, extra, h->d_ins_e2, n_extra, n_extra_dev, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, h->d_dropped,
@@ -437,6 +471,7 @@ int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int3
   }
   h->map_dirty = true;
   launch_box_tomb_cells(h->d_pts, h->d_cells, ne, d_boxes, n_boxes, h->d_tomb, h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s);
+  h->win_valid = false;
   launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap_eff, ne, s);
   launch_ins_write(h->d_pts, h->d_ins_e, 0, nullptr, nullptr, nullptr, 0, nullptr, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, h->d_dropped, h->drop_cap,
                    s);  // (re-arms the work list)

@@ -313,6 +313,8 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   }
   if (hr->singular == 3)
     return fail(h, LII_ERR_COMM, "mailbox exchange timed out (a rank of the job did not reach this pass); re-create the communicator");
+  if (hr->singular == 4)
+    return fail(h, LII_ERR_COMM, "the sums of a pass did not reach the solver within 2 s (a summing workgroup of the launch was not scheduled: is the device shared?)");
   if (hr->singular) return fail(h, LII_ERR_INVALID, "singular covariance / normal matrix in the device solve");
   if (hr->it < 0) return fail(h, LII_ERR_HIP, "device loop ended without a result");
   std::memcpy(state, hr->st, sizeof(lii_state));
@@ -488,6 +490,9 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     dp.out = h->d_scan; dp.n = n_next; dp.sorted = 1; dp.extent = nullptr; dp.bbox_rows = h->d_bbox_rows;
     dp.leaf = fuse_leaf; dp.vh = h->vh_inserted ? &h->vh : nullptr;
     dp.ctrl_src = h->h_ctrl; dp.ctrl_dst = h->d_ctrl; dp.ctrl_bytes = (sizeof(IekfCtrl) + 15) / 16 * 16;
+#ifdef LII_GAP_TRACE
+    dp.gap = h->d_gran;
+#endif
     if (job->undistort == 1) {
       UndistArgH u;
       std::memcpy(u.endR, state->rot_end, 72);

@@ -38,6 +38,12 @@ struct lii_context {
   float4* d_batch = nullptr;    // a host-provided Add_Points batch (M)
   float4* d_dropped = nullptr;  // inserts an in-place update found no room for (kMapCtrDropped of them): re-inserted after a rebuild
   unsigned int drop_cap = 0;
+  // dense cell window over the map's box (GridView::win; LII_WINDOW=0 turns it off): filled by build_index, dropped by whatever changes a cell entry
+  bool use_window = true;
+  uint2* d_win = nullptr;
+  size_t win_cap = 0;            // entries allocated
+  int win_org[3] = {0, 0, 0}, win_dim[3] = {0, 0, 0};
+  bool win_valid = false;
   bool map_tight = false;       // LII_TEST=map_tight: no spare room is provisioned (tests: forces the recovery path)
   long long map_recoveries = 0;
   float4 *d_ins = nullptr, *d_ins_c = nullptr;         // fold output / compacted inserts or host batches (M each)
@@ -117,6 +123,7 @@ struct lii_context {
   bool no_gather = false;         // LII_TEST=no_gather: no gather areas behind the mailbox slots (the map update of a sharded job repeats the search)
   bool no_fast_prologue = false;  // LII_TEST=no_fast: a time-sorted scan takes the general path as well (k_time_extent in front of the de-skew)
   bool no_fuse = false;        // LII_TEST=no_fuse: lii_scan_register keeps the de-skew and the voxel filter's insert in separate launches
+  bool test_sum_lost = false;  // LII_TEST=sum_lost: one summing workgroup of k_reduce_solve never publishes - the solver's wait must end in LII_ERR_COMM
   bool test_emit_late = false; // LII_TEST=emit_late: every seventh workgroup of k_vhash_emit / k_map_decide publishes its count late: the others count its block themselves (prefix_below)
   bool use_graph = false;      // LII_TEST=graph: the passes of an update are captured once per (cloud bound, plan, map view) and replayed
   std::map<std::string, hipGraphExec_t> graphs;

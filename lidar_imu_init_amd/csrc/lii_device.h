@@ -144,6 +144,12 @@ struct GridView {
   float cs;
   float inv_cs;
   float max_d2;
+  // Dense CELL WINDOW (round 6): the cell entries of the map's bounding box, direct-indexed by cell coordinate -
+  // win[((cz - wz0) * wny + (cy - wy0)) * wnx + (cx - wx0)] = the (first, end) entry the block table + cell table would give - so
+  // that a lookup inside the box is ONE load instead of the dependent pair block probe -> cell entry.  nullptr: no window (the box
+  // exceeds the budget, or the map has changed since the window was filled); a cell outside the box goes through the hash.
+  const uint2* win;
+  int wx0, wy0, wz0, wnx, wny, wnz;
 };
 
 struct RegistrationBuffers {
@@ -346,6 +352,8 @@ struct MailboxView {
   unsigned long long* seq;  // device memory: exchanges completed so far (identical on all ranks)
   int n_ranks, rank;
   long long timeout_ticks;  // of the 100 MHz wall clock: how long to wait for a peer that may never arrive
+  long long handoff_ticks;  // ... and for the sums of the launch's own summing workgroups (k_reduce_solve; 2 s)
+  int test_drop_sum;        // LII_TEST=sum_lost: summing workgroup 5 of every launch keeps its sum to itself (tests: the solver's bounded wait)
 };
 
 // The second exchange of a sharded job, once per map update (lii_map_incremental; kernels in lii_exchange.hip): every rank decides

@@ -156,7 +156,13 @@ __device__ __forceinline__ bool gj12_loop(double (&col)[H]) {
     g = col_absmax_hi(col, g);
   }
   // (g >= 0: its bits order like its value.  The last pivot row: not-a-number if any pivot was zero or not a number; idle lanes hold zeros)
-  return __all(__float_as_uint(g) <= bound && col[H - 1] == col[H - 1]);
+  // The growth watch reads the doubles' high words as floats, and v_max3_f32 skips an operand that reads as a float NaN - which is what
+  // the high word of a double beyond 2^1016, of an infinity or of a NaN looks like.  One INTEGER look at the end closes that hole
+  // (ADVICE r5): a double is finite iff its exponent field is not all ones, and an overflow never turns back into a finite number.
+  unsigned int top = 0u;
+#pragma unroll
+  for (int r = 0; r < H; r++) top = max(top, (unsigned int)__double2hiint(col[r]) & 0x7FFFFFFFu);
+  return __all(__float_as_uint(g) <= bound && top < 0x7FF00000u);
 }
 // pivoted: the elimination went through gj12_pivoting (wave-uniform)
 __device__ __forceinline__ bool gj12(double (&col)[H], bool& pivoted) {
@@ -234,7 +240,9 @@ __device__ __forceinline__ void publish_done(IekfResult* res, int seq) {
 }
 
 // ne_src: where the 91 sums come from - a functor called by every lane AFTER the other loads have been issued; it leaves the sums
-// in s_ne[0 .. 90] (LDS; the barrier below makes them visible) and returns false when they could not be had (uniform).
+// in s_ne[0 .. 90] (LDS; the barrier below makes them visible) and returns 0, or - when they could not be had (uniform) - the code the
+// host finds in IekfResult::singular: 3 = the exchange between the ranks timed out, 4 = the sums of this launch's own summing
+// workgroups did not arrive in time.  Both end the update with LII_ERR_COMM; neither traps.
 template <class NeSrc>
 __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, NeSrc ne_src) {
 #ifdef LII_SOLVE_TRACE
@@ -258,9 +266,9 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
     const double* cov = c->st + 36;
     for (int e = tid; e < N * N; e += kSolveThreads) s_cov[e] = cov[e];
   }
-  if (!ne_src(s_ne)) {  // (uniform) the exchange between the ranks timed out
+  if (const int why = ne_src(s_ne)) {  // (uniform) the sums could not be had
     __syncthreads();
-    if (threadIdx.x == 0) { c->stop = 1; c->singular = 3; res->singular = 3; res->it = 0; }
+    if (threadIdx.x == 0) { c->stop = 1; c->singular = why; res->singular = why; res->it = 0; }
     publish_done(res, s_int[10]);
     return;
   }
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __
     // requested together with the flags, not behind the branch on them: one round trip at the head of the launch instead of two)
     const double acc = final_sum_row<kSolveThreads>(partials + (size_t)t * stride, n_blocks, s_w);
     if (stop) return;  // the loop has ended: nothing is published
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !(mb.test_drop_sum && t == 5)) {
       const unsigned int tag = pass_tag(seq, it);
       const unsigned long long b = (unsigned long long)__double_as_longlong(acc);
       __hip_atomic_store(gran + 2 * t, ((unsigned long long)tag << 32) | (b & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -516,6 +524,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __
       const int a = 2 * l, b = two ? 2 * (l + 64) : 2 * l;
       unsigned long long g0, g1, g2, g3;
       unsigned int spins = 0;
+      bool arrived = true;
+      const long long t0 = wall_clock64();
       for (;;) {
         g0 = __hip_atomic_load(gran + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         g1 = __hip_atomic_load(gran + a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -524,21 +534,29 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __
         const bool ok = (unsigned int)(g0 >> 32) == tag && (unsigned int)(g1 >> 32) == tag && (unsigned int)(g2 >> 32) == tag &&
                         (unsigned int)(g3 >> 32) == tag;
         if (__all(ok)) break;
-        if (++spins > (1u << 24)) __builtin_trap();  // a summing workgroup that never publishes: the launch is broken
+        // A summing workgroup that has not published yet may simply not be running: the 92 workgroups of this launch share the
+        // device with whatever else is queued on it.  The wait is bounded by TIME (2 s of the 100 MHz clock, looked at every 1024
+        // polls), and running out ends the update with an error the caller can handle (LII_ERR_COMM) - rounds 4 - 5 trapped here
+        // after 2^24 polls, which took the process down with the launch.
+        if ((++spins & 1023u) == 0u && wall_clock64() - t0 > mb.handoff_ticks) { arrived = false; break; }
         __builtin_amdgcn_s_sleep(1);
       }
       double v0 = __longlong_as_double((long long)((g1 << 32) | (g0 & 0xFFFFFFFFull)));
       double v1 = two ? __longlong_as_double((long long)((g3 << 32) | (g2 & 0xFFFFFFFFull))) : 0.0;
       bool ok = true;
-      if (mb.slots || mb.peers) ok = mailbox_allreduce(mb, v0, v1);  // several ranks: the sums meet the others' in the node-local mailbox
+      if (arrived && (mb.slots || mb.peers)) ok = mailbox_allreduce(mb, v0, v1);  // several ranks: the sums meet the others' in the node-local mailbox
       s_ne[l] = v0;
       if (two) s_ne[l + 64] = v1;
-      if (l == 0) s_mb_ok = ok ? 1 : 0;
+      if (l == 0) s_mb_ok = !arrived ? 4 : (ok ? 0 : 3);
     }
     if (warm == 0x5EED5EED) s_ne[95] = 0.0;  // (s_ne[91 .. 95] is padding)
     __syncthreads();
-    return s_mb_ok != 0;
+    return s_mb_ok;
   });
+#ifdef LII_GAP_TRACE
+  __syncthreads();
+  if (threadIdx.x == 0 && c->stop == 1) gran[200] = wall_clock64();  // (measurement builds: see gap_trace, lii_scan.hip)
+#endif
 }
 
 // (defined BEHIND k_reduce_solve on purpose: that kernel reads its own code ahead, see warm_code)
@@ -546,7 +564,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_iekf_solve(IekfCtrl* c, const
   iekf_solve_body(c, res, [&](double* s_ne) {
     const int tid = threadIdx.x;
     if (tid >= 64 && tid < 64 + 91) s_ne[tid - 64] = ne[tid - 64];
-    return true;
+    return 0;
   });
 }
 

@@ -400,6 +400,15 @@ int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_
   if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || !frames || !n_frames || n_points < 0 || (!data && n_points > 0) ||
       f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 0 || o->cut_frame_num > kMaxFrames)
     return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: bad arguments");
+  // An L515 message is ONE frame whatever cut_frame says: the reference's callback sends only Velodyne, Ouster, Pandar and RoboSense
+  // through process_cut_frame_pcl2 and everything else - L515 - through Preprocess::process (src/laserMapping.cpp:363-377).  ADVICE r5:
+  // with `cut_frame: true` in the yaml this call used to fail with "Wrong LiDAR Type" where the reference processes the message.
+  lii_ingest_opts whole_opts;
+  if (o->lidar_type == LII_LIDAR_L515 && o->cut_frame_num != 0) {
+    whole_opts = *o;
+    whole_opts.cut_frame_num = 0;
+    o = &whole_opts;
+  }
   if (o->cut_frame_num == 0) {  // Preprocess::process knows Ouster, Velodyne and L515 (src/preprocess.cpp:337-354)
     if (o->lidar_type != LII_LIDAR_VELO && o->lidar_type != LII_LIDAR_OUSTER && o->lidar_type != LII_LIDAR_L515)
       return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: Error LiDAR Type (src/preprocess.cpp:350-352: the non-cutting Preprocess::process handles Ouster, Velodyne and L515)");

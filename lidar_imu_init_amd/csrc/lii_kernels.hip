@@ -460,6 +460,35 @@ __device__ __forceinline__ void lookup_cells_batched(const GridView& g, const ui
                                                      const int (&iy)[NC], const int (&iz)[NC], const bool (&want)[NC],
                                                      uint2 (&out)[NC]) {
   const int bb = kCellBias >> kCoarseShift;
+  if (g.win) {  // (uniform) the dense window: one load per cell; the rare cell outside the box takes the tables' way alone
+    unsigned int wi[NC];
+    bool in[NC];
+#pragma unroll
+    for (int t = 0; t < NC; t++) {
+      const unsigned int ux = (unsigned)(ix[t] - g.wx0), uy = (unsigned)(iy[t] - g.wy0), uz = (unsigned)(iz[t] - g.wz0);
+      in[t] = ux < (unsigned)g.wnx && uy < (unsigned)g.wny && uz < (unsigned)g.wnz;
+      wi[t] = in[t] ? (uz * (unsigned)g.wny + uy) * (unsigned)g.wnx + ux : 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < NC; t++) out[t] = (want[t] && in[t]) ? g.win[wi[t]] : make_uint2(0u, 0u);
+#pragma unroll
+    for (int t = 0; t < NC; t++) {
+      if (want[t] && !in[t]) {
+        const int bx = (ix[t] >> kCoarseShift) + bb, by = (iy[t] >> kCoarseShift) + bb, bz = (iz[t] >> kCoarseShift) + bb;
+        const unsigned long long key = pack_block(bx, by, bz);
+        unsigned int slot = hash_block(bx, by, bz) & g.block_mask;
+        uint4 en = tab[slot];
+        unsigned long long ek = ((unsigned long long)en.y << 32) | en.x;
+        while (ek != key && ek != kEmptyKey) {
+          slot = (slot + 1) & g.block_mask;
+          en = tab[slot];
+          ek = ((unsigned long long)en.y << 32) | en.x;
+        }
+        if (ek == key) out[t] = g.cells[en.z * (unsigned)kBlockCells + ((((unsigned)iz[t] & 7u) << 6) | (((unsigned)iy[t] & 7u) << 3) | ((unsigned)ix[t] & 7u))];
+      }
+    }
+    return;
+  }
   unsigned long long bk[NC];
   unsigned int sl[NC];
   uint4 e[NC];
@@ -1706,6 +1735,34 @@ void launch_map_gather(const float4* src, const unsigned int* idx, int n, float4
 }
 void launch_block_flags(const unsigned long long* keys, int n, unsigned int* flags, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_block_flags, dim3(nblk(n, 256)), dim3(256), 0, s, keys, n, flags);
+}
+// ---- dense cell window (GridView::win) ---------------------------------------------------------------------------------------------
+// box[0..2] = min, box[3..5] = max of the BIASED block coordinates over the occupied slots of the block table
+__global__ void k_win_bbox(const BlockEntry* __restrict__ blocks, unsigned int cap, unsigned int* __restrict__ box) {
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  const unsigned long long k = blocks[i].key;
+  if (k == kEmptyKey) return;
+  const unsigned int bx = (unsigned)(k & 0x3FFFF), by = (unsigned)((k >> 18) & 0x3FFFF), bz = (unsigned)((k >> 36) & 0x3FFFF);
+  atomicMin(&box[0], bx); atomicMin(&box[1], by); atomicMin(&box[2], bz);
+  atomicMax(&box[3], bx); atomicMax(&box[4], by); atomicMax(&box[5], bz);
+}
+// one workgroup of 512 lanes per slot of the block table: the 512 cell entries of an occupied block go to their places in the window
+__global__ __launch_bounds__(512) void k_win_fill(const BlockEntry* __restrict__ blocks, const uint2* __restrict__ cells, uint2* __restrict__ win,
+                                                  int wx0, int wy0, int wz0, int wnx, int wny, int wnz) {
+  const BlockEntry e = blocks[blockIdx.x];
+  if (e.key == kEmptyKey) return;
+  const int bb = kCellBias >> kCoarseShift;
+  const int bx = (int)(e.key & 0x3FFFF) - bb, by = (int)((e.key >> 18) & 0x3FFFF) - bb, bz = (int)((e.key >> 36) & 0x3FFFF) - bb;
+  const int l = threadIdx.x;
+  const unsigned int ux = (unsigned)(bx * 8 + (l & 7) - wx0), uy = (unsigned)(by * 8 + ((l >> 3) & 7) - wy0), uz = (unsigned)(bz * 8 + (l >> 6) - wz0);
+  if (ux < (unsigned)wnx && uy < (unsigned)wny && uz < (unsigned)wnz) win[((size_t)uz * wny + uy) * wnx + ux] = cells[(size_t)e.id * kBlockCells + l];
+}
+void launch_win_bbox(const BlockEntry* blocks, unsigned int cap, unsigned int* box, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_bbox, dim3((cap + 255) / 256), dim3(256), 0, s, blocks, cap, box);
+}
+void launch_win_fill(const BlockEntry* blocks, unsigned int cap, const uint2* cells, uint2* win, const int org[3], const int dim[3], hipStream_t s) {
+  hipLaunchKernelGGL(k_win_fill, dim3(cap), dim3(512), 0, s, blocks, cells, win, org[0], org[1], org[2], dim[0], dim[1], dim[2]);
 }
 void launch_table_clear(BlockEntry* blocks, unsigned int cap, hipStream_t s) {
   hipLaunchKernelGGL(k_table_clear, dim3(nblk((int)cap, 256)), dim3(256), 0, s, blocks, cap);

@@ -24,6 +24,8 @@ void launch_map_keys(const float4* pts, int n, float inv_cs, unsigned long long*
 void launch_map_gather(const float4* src, const unsigned int* idx, int n, float4* dst, hipStream_t s);
 void launch_block_flags(const unsigned long long* keys, int n, unsigned int* flags, hipStream_t s);
 void launch_table_clear(BlockEntry* blocks, unsigned int cap, hipStream_t s);
+void launch_win_bbox(const BlockEntry* blocks, unsigned int cap, unsigned int* box, hipStream_t s);
+void launch_win_fill(const BlockEntry* blocks, unsigned int cap, const uint2* cells, uint2* win, const int org[3], const int dim[3], hipStream_t s);
 void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks, int n, BlockEntry* blocks,
                        unsigned int block_mask, uint2* cells, hipStream_t s);
 // registration
@@ -112,6 +114,9 @@ struct DeskewPlan {
   const void* ctrl_src;              // ctrl_bytes > 0: one extra workgroup copies this (pinned host memory) to ctrl_dst
   void* ctrl_dst;
   size_t ctrl_bytes;
+#ifdef LII_GAP_TRACE
+  unsigned long long* gap;  // measurement builds only (tools/ab_build.sh ... -DLII_GAP_TRACE): words 200 .. 202 of the granule buffer
+#endif
 };
 void launch_deskew_imu(const DeskewPlan& p, const double* poses_host, const double* poses_dev, int K, const UndistArgH& u, hipStream_t s);
 void launch_deskew_cv(const DeskewPlan& p, const CvArgH& a, hipStream_t s);

@@ -305,7 +305,27 @@ struct DeskewIo {
   const uint4* ctrl_src;
   uint4* ctrl_dst;
   int ctrl_vec;
+#ifdef LII_GAP_TRACE
+  unsigned long long* gap;
+#endif
 };
+// Measurement builds (-DLII_GAP_TRACE): how long the device sat idle between the end of the pass that stopped the previous scan's
+// loop (k_reduce_solve leaves a wall_clock64 stamp, 100 MHz) and the first instruction of this scan's first kernel - the host's
+// share of the scan period, measured where it is paid.  Sum and count are read back by lii_destroy.
+__device__ __forceinline__ void gap_trace(const DeskewIo& io) {
+#ifdef LII_GAP_TRACE
+  if (blockIdx.x == 0 && threadIdx.x == 0 && io.gap) {
+    const unsigned long long now = wall_clock64(), prev = io.gap[200];
+    // (gaps of 50 us and more - the host did something else between two scans: the bench's bookkeeping between its regions, a
+    // first-time allocation - are counted apart: the mean is over the back-to-back scans)
+    if (prev != 0ull && now > prev) {
+      if (now - prev < 5000ull) { io.gap[201] += now - prev; io.gap[202] += 1ull; }
+      else io.gap[203] += 1ull;
+    }
+    io.gap[200] = 0ull;
+  }
+#endif
+}
 __device__ __forceinline__ void pull_ctrl(const DeskewIo& io) {
   for (int i0 = threadIdx.x; i0 < io.ctrl_vec; i0 += 256 * 4) {  // four PCIe reads in flight per lane
     uint4 v[4];
@@ -332,6 +352,7 @@ struct PoseTab { double v[KP > 0 ? KP * 22 : 1]; };
 template <bool FUSE, int KP>
 __global__ __launch_bounds__(256) void k_deskew_imu(DeskewIo io, UndistArg u, int K, const double* __restrict__ poses_g, PoseTab<KP> tab) {
   const int n_scan_blocks = gridDim.x - (io.ctrl_vec > 0 ? 1 : 0);
+  gap_trace(io);
   if ((int)blockIdx.x == n_scan_blocks) { pull_ctrl(io); return; }
   const double* __restrict__ poses = KP > 0 ? tab.v : poses_g;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -700,7 +721,17 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
   // owners in the workgroups below this one; a block whose word is overdue is counted here: which of its points own their voxel
   // (one 16-byte request per point decides it, as above; a slot its owner - a point of another block - has freed already reads
   // empty: not this point's voxel any more, and it never was its owner)
-  const unsigned int base = prefix_below(counts, epoch, (int)blockIdx.x, s_sum, test_late != 0, [&](int q) -> unsigned int {
+#ifdef LII_ABL_EMIT_NOPREFIX
+  // ABLATION (timing only, tools/ab_build.sh ... -DLII_ABL_EMIT_NOPREFIX): no exchange of counts inside the launch - every workgroup
+  // writes its owners to its own stretch of 256 slots and the cloud is taken to have n entries (the holes keep whatever they held).
+  // Prices what an UNCOMPACTED down-sampled cloud would save in this kernel; the results of such a build are wrong.
+  const unsigned int base_abl = blockIdx.x * 256u;
+#endif
+  const unsigned int base =
+#ifdef LII_ABL_EMIT_NOPREFIX
+      true ? base_abl :
+#endif
+      prefix_below(counts, epoch, (int)blockIdx.x, s_sum, test_late != 0, [&](int q) -> unsigned int {
     const int j = q * 256 + tid;
     bool f = false;
     if (j < n) {
@@ -724,6 +755,9 @@ __global__ __launch_bounds__(256) void k_vhash_emit(const float4* __restrict__ p
   }
   if (blockIdx.x == gridDim.x - 1 && tid == 0) {  // size of the down-sampled cloud
     int n_down = (int)(base + total);
+#ifdef LII_ABL_EMIT_NOPREFIX
+    n_down = n;
+#endif
     if (ABS && tb.part_world > 1u && n_down > tb.part_bound) {  // this rank's share outgrew what the launches behind are sized for
       n_down = tb.part_bound;
       __hip_atomic_store(tb.part_overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -799,6 +833,9 @@ static DeskewIo deskew_io(const DeskewPlan& p) {
   io.leaf = p.leaf;
   io.tb = vh_table(p.vh, p.n, true);
   io.ctrl_src = static_cast<const uint4*>(p.ctrl_src); io.ctrl_dst = static_cast<uint4*>(p.ctrl_dst); io.ctrl_vec = (int)(p.ctrl_bytes / 16);
+#ifdef LII_GAP_TRACE
+  io.gap = p.gap;
+#endif
   return io;
 }
 template <bool FUSE, int KP>

@@ -172,6 +172,12 @@ def test_whole_message_bit_exact(reg, oracle, sensor, lidar_type, pfn, with_time
     if with_time and oracle.ref_preprocess_lib() is not None:
         ref = oracle.ref_ingest_pcl2(raw, n, f, lidar_type, n_scans, pfn, 1.0, stamp, 0, 100)
         assert_same(got, ref)
+    if lidar_type == wire.L515:
+        # with `cut_frame: true` the reference's callback still sends an L515 message through Preprocess::process (src/laserMapping.cpp:363-377:
+        # only Velodyne / Ouster / Pandar / RoboSense are cut): the same single frame, not "Wrong LiDAR Type" 
+        info3 = reg.ingest_pcl2(raw, n, f, lidar_type, n_scans, pfn, 1.0, stamp, 3, 100)
+        assert len(info3) == 1 and info3[0][2] == info[0][2]
+        assert_same(gpu_frames(reg, info3), orc, exact_time=with_time)
 
 
 def test_whole_message_livox_and_errors(reg, oracle):
