@@ -20,6 +20,19 @@ thread_local std::string g_err;
 #endif
 static constexpr unsigned kProfEventFlags = LII_PROF_EVENT_FLAGS;
 
+// The k-NN launches of the last profiled update: their events are read here, not behind the update (see update_on_device).
+void harvest_knn_events(lii_handle h) {
+  const unsigned int due = h->prof.ev_it_due;
+  h->prof.ev_it_due = 0u;
+  for (int it = 0; it < 16; it++) {
+    if (!((due >> it) & 1u)) continue;
+    float kk = 0;
+    if (hipEventElapsedTime(&kk, h->prof.ev_it[2 * it], h->prof.ev_it[2 * it + 1]) != hipSuccess) continue;
+    h->prof.timings[7] += kk;
+    h->prof.timings[5] += 1;
+  }
+}
+
 int fail(lii_handle h, int code, const std::string& msg) {
   if (h) h->err = msg;
   g_err = msg;
@@ -220,6 +233,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   // the 3x3x3 neighbourhood of 8x8x8-cell blocks must cover the acceptance radius sqrt(max_match_dist2)
   h->cell_size = std::max(h->cell_size, std::sqrt(h->cfg.max_match_dist2) / 8.0f * 1.001f);
   if (const char* v = std::getenv("LII_DIAG")) h->diag = std::atoi(v) != 0;
+  if (const char* v = std::getenv("LII_PROF_BRACKET")) h->prof.bracket_events = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_VOXEL_FILTER")) {
     h->voxel_sort = std::string(v) == "sort";
     if (std::string(v) == "hash") { h->vh_pinned = true; h->vh_mode = 1; }
@@ -483,6 +497,24 @@ int lii_synchronize(lii_handle h) {
   {
     const int rc = map_join(h);
     if (rc != LII_OK) return rc;
+  }
+  // What is left on the stream when a caller of the per-scan loop synchronises are the launches behind the stopping pass (they read a
+  // flag and return): microseconds.  hipStreamSynchronize spins briefly and then sleeps on an interrupt - ~60 us until the caller
+  // runs again (bench.py's debug stamps, round 6) - so the stream is polled first, for up to ~0.2 ms, and the blocking wait only
+  // takes over for work that really lasts.
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int polls = 1;; polls++) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) {
+        if (h->diag) std::fprintf(stderr, "[libliinit_hip] lii_synchronize: stream empty after %d polls, %.1f us\n", polls,
+                                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        return LII_OK;
+      }
+      if (q != hipErrorNotReady) return fail(h, LII_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+      __builtin_ia32_pause();
+    }
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return LII_OK;
@@ -799,6 +831,7 @@ int lii_set_profiling(lii_handle h, int32_t enabled) {
   h->prof.profiling = enabled != 0;
   h->prof.prof_mode = enabled;
   if (enabled == 1) {
+    h->prof.ev_it_due = 0u;  // (a new accumulation: what has not been read belongs to the old one)
     for (double& t : h->prof.timings) t = 0;  // 1: (re)start the accumulation; 2: resume; 0: pause (accumulators kept)
     h->prof.kprof = lii_kernel_profile{};
   }
@@ -812,6 +845,7 @@ int lii_last_kernel_profile(lii_handle h, lii_kernel_profile* out) {
 }
 int lii_last_timings(lii_handle h, double out_ms[8]) {
   if (!h || !out_ms) return LII_ERR_INVALID;
+  harvest_knn_events(h);
   std::memcpy(out_ms, h->prof.timings, sizeof(h->prof.timings));
   return LII_OK;
 }

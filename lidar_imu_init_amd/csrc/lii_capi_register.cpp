@@ -16,8 +16,9 @@ int next_knn_epoch(lii_handle h, bool listed) {
   h->knn_epoch = h->knn_epoch >= 0x3FFFFFFE ? 1 : h->knn_epoch + 1;  // (consecutive numbers alternate between the two slots, across the wrap as well)
   return h->knn_epoch;
 }
-void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose, int forced, int epoch) {
-  lii::launch_knn(g, rb, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->stream, epoch);
+void launch_knn(lii_handle h, const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose, int forced, int epoch,
+                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+  lii::launch_knn(g, rb, pose, h->d_ctrl, forced, h->d_ctrl->search_pose, h->stream, epoch, ev_start, ev_stop);
 }
 
 
@@ -123,6 +124,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   RegistrationBuffers rb = reg_buffers(h);
   const PoseArg* pose = reinterpret_cast<const PoseArg*>(h->d_ctrl);  // first 24 doubles of IekfCtrl::st
   const bool prof = h->prof.profiling && h->prof.prof_mode != 3;  // (mode 3 brackets every launch itself: kp_mark)
+  if (prof) harvest_knn_events(h);  // (the events are about to be used again)
   const double* ne = h->net.comm ? h->d_out91 + 128 : h->d_out91;
   unsigned int plan = h->plan_cur;  // fill_ctrl chose it (the control block on the device carries the same mask)
   const unsigned int plan0 = plan;
@@ -134,10 +136,15 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     // (a fit launch that is not behind a search launch never runs as a search pass - the plan parks the loop instead - and needs no number)
     const int epoch = knn ? next_knn_epoch(h, !graph_mode) : 0;
     if (knn) {
-      if (prof && it < 16) HIPCHK(h, hipEventRecord(h->prof.ev_it[2 * it], s));
+      // (the k-NN launches of a profiled update carry their two events IN the dispatch: the kernel's own start and end stamps.  Rounds
+      // 1 - 5 recorded an event in front of and behind the launch - two barrier packets each, + 22 us on a profiled scan, and the
+      // bracket held the dispatch as well as the kernel; LII_PROF_BRACKET=1 keeps that form for comparison)
+      const bool in_dispatch = prof && it < 16 && !h->prof.bracket_events;
+      if (prof && it < 16 && !in_dispatch) HIPCHK(h, hipEventRecord(h->prof.ev_it[2 * it], s));
       if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_KNN, it); if (r != LII_OK) return r; }
-      launch_knn(h, g, rb, pose, -1, epoch);
-      if (prof && it < 16) HIPCHK(h, hipEventRecord(h->prof.ev_it[2 * it + 1], s));
+      if (in_dispatch) launch_knn(h, g, rb, pose, -1, epoch, h->prof.ev_it[2 * it], h->prof.ev_it[2 * it + 1]);
+      else launch_knn(h, g, rb, pose, -1, epoch);
+      if (prof && it < 16 && !in_dispatch) HIPCHK(h, hipEventRecord(h->prof.ev_it[2 * it + 1], s));
     }
     if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_FIT, it); if (r != LII_OK) return r; }
     launch_fit_reduce(g, rb, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s, epoch);
@@ -337,15 +344,16 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     std::memcpy(report->normal_eq, hr->ne, sizeof(double) * kNormalEq);
   }
   if (prof) {
-    // the k-NN kernel alone, over EVERY pass that actually searched (the device logs which iterations did); the events were
-    // recorded ahead of the stopping pass, whose result has arrived: they have completed
+    // the k-NN kernel alone, over EVERY pass that actually searched (the device logs which iterations did).  The events are READ
+    // LATER (harvest_knn_events: in front of the next profiled update, or when the timings are asked for): asking the runtime for
+    // an event's time right behind the launch it belongs to makes it wait for its completion handler - ~10 us per pair on the
+    // host's path to the next scan (round 6: a profiled step cost + 22 us against its neighbours).
+    unsigned int due = 0u;
     for (int it = 0; it < opts->max_iterations && it < 16; it++) {
       if (it >= hr->it || !(hr->search_log[it] & 1) || !((plan0 >> it) & 1u)) continue;
-      float kk = 0;
-      if (hipEventElapsedTime(&kk, h->prof.ev_it[2 * it], h->prof.ev_it[2 * it + 1]) != hipSuccess) continue;
-      h->prof.timings[7] += kk;
-      h->prof.timings[5] += 1;
+      due |= 1u << it;
     }
+    h->prof.ev_it_due = due;
   }
   return LII_OK;
 }

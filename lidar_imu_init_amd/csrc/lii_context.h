@@ -232,7 +232,9 @@ struct lii_context {
     lii_kernel_profile kprof{};
     bool profiling = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_it[32] = {};  // per-iteration brackets of the k-NN kernel in the device-driven loop
+    bool bracket_events = false;       // LII_PROF_BRACKET=1: events recorded around the k-NN launches instead of inside their dispatch
+    hipEvent_t ev_it[32] = {};
+    unsigned int ev_it_due = 0u;       // iterations whose pair of ev_it holds a k-NN launch that has not been read yet (harvest_knn_events)  // per-iteration brackets of the k-NN kernel in the device-driven loop
     double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double host_map_us[2] = {0, 0};  // LII_DIAG: per update - waiting for the map update in flight (commit_map), enqueueing the map update behind the passes
     double host_us[6] = {0, 0, 0, 0, 0, 0};  // LII_DIAG: per lii_scan_register - entry -> first launch, -> pre-processing enqueued, -> loop enqueued, -> result; calls; gap between calls
@@ -263,6 +265,7 @@ inline unsigned int next_pow2(unsigned int v) {
 }
 // lii_capi.cpp
 int kp_mark(lii_handle h, int kind, int it = 0);
+void harvest_knn_events(lii_handle h);
 GridView grid_view(const lii_context* c);
 RegistrationBuffers reg_buffers(const lii_context* c);
 PoseArg pose_of(const lii_state& s);

@@ -14,6 +14,7 @@
 //   (de-skew and voxel grid: lii_scan.hip)
 //   k_calib_eval       include/LI_init/LI_init.h:91-205 residuals + analytic Jacobians
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <string.h>
 #include <cstring>
 #include <math.h>
@@ -1792,10 +1793,15 @@ static inline int shard_bound(const RegistrationBuffers& rb) {
 // epoch: the number of this search launch (> 0; the fit launch behind it gets the same) - or 0: no list of unfinished queries, every
 // workgroup of the fit launch finishes its own (hipGraph replays, whose arguments are frozen)
 void launch_knn(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
-                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s, int epoch) {
+                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s, int epoch, hipEvent_t ev_start, hipEvent_t ev_stop) {
   int nq = nblk(shard_bound(rb), LII_KNN_BS / 4);
   if (nq < 1) nq = 1;
   const int nq_pad = ((nq + 7) / 8) * 8;
+  if (ev_start && ev_stop) {  // (measurement: the dispatch's own time stamps, no barrier packets around it)
+    hipExtLaunchKernelGGL((k_knn_ck<4, LII_KNN_BS, LII_KNN_NB, LII_KNN_WPE>), dim3(nq_pad), dim3(LII_KNN_BS), 0, s, ev_start, ev_stop, 0u, g, rb, pose, ctrl, forced, nq,
+                          search_pose_out, epoch);
+    return;
+  }
   hipLaunchKernelGGL((k_knn_ck<4, LII_KNN_BS, LII_KNN_NB, LII_KNN_WPE>), dim3(nq_pad), dim3(LII_KNN_BS), 0, s, g, rb, pose, ctrl, forced, nq, search_pose_out, epoch);
 }
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s) {

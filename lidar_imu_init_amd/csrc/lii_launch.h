@@ -31,8 +31,11 @@ void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks
 // registration
 // (`pose`: device memory on every path - a host-driven pass uploads it first)
 // epoch: the number of this search launch (> 0, RegistrationBuffers::flag_*) and of the fit launch behind it; 0: no list of unfinished queries
+// ev_start / ev_stop (both or none): the launch's own dispatch carries the two events (hipExtLaunchKernelGGL: the time stamps of the
+// dispatch packet's completion signal) - the kernel's duration without a barrier packet in front of and behind it on the stream
 void launch_knn(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
-                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s, int epoch);
+                const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s, int epoch,
+                hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s);
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s, int epoch);
