@@ -42,7 +42,15 @@ WORKLOADS = {
 }
 
 
-def build_workload(name, n_scans, seed=20220613, map_cache=None):
+# --edge: the map lacks a patch of the floor that every pose of the stream looks at - the part of the hall a live sensor has not mapped
+# yet.  Every scan then has queries whose 2.2 m ball (max_match_dist2 = 5) reaches past what the map holds: the completion path of
+# k_fit_reduce on EVERY scan, where the plain stream has it on one scan of eight (profiles/r06_edge.md).
+EDGE_PATCH = ((9.0, 11.4), (-1.2, 1.2), (-10.0, -1.0))  # x, y, z ranges [m] of the floor patch taken out of the map (--edge-wide: six times the area)
+EDGE_PATCH_WIDE = ((8.0, 14.0), (-3.0, 3.0), (-10.0, -1.0))
+
+
+def build_workload(name, n_scans, seed=20220613, map_cache=None, edge=False):
+    # (edge: False, True = EDGE_PATCH, "wide" = EDGE_PATCH_WIDE)
     """Synthetic stream: `n_scans` sweeps from poses on a small loop, time-sorted (and, for cut_frame_num > 1, cut into
     sub-frames the way process_cut_frame_pcl2 does: equal point counts, time re-based to the sub-frame start)."""
     from harness import params, synth
@@ -55,6 +63,11 @@ def build_workload(name, n_scans, seed=20220613, map_cache=None):
         hall, map_pts = synth.bench_world(n_map, fs_map, seed=seed)
         if map_cache is not None:
             map_cache[(n_map, fs_map)] = (hall, map_pts)
+    if edge:
+        (x0, x1), (y0, y1), (z0, z1) = EDGE_PATCH_WIDE if edge == "wide" else EDGE_PATCH
+        m = map_pts
+        inside = (m[:, 0] > x0) & (m[:, 0] < x1) & (m[:, 1] > y0) & (m[:, 1] < y1) & (m[:, 2] > z0) & (m[:, 2] < z1)
+        map_pts = np.ascontiguousarray(m[~inside])
     rng = np.random.default_rng(seed)
     scans, poses = [], []
     k = 0
@@ -73,7 +86,7 @@ def build_workload(name, n_scans, seed=20220613, map_cache=None):
                 poses.append((R, p))
         k += 1
     return dict(name=name, map=map_pts, hall=hall, scans=scans, poses=poses, fs_map=fs_map, fs_surf=fs_surf, max_it=max_it, rng=rng,
-                sweep_s=0.1 / cut, params=prm)
+                sweep_s=0.1 / cut, params=prm, edge=edge)
 
 
 def start_states(wl):
@@ -196,6 +209,8 @@ def main():
     ap.add_argument("--prime", type=int, default=150, help="untimed runtime-priming steps before the warm-up")
     ap.add_argument("--scans", type=int, default=8, help="distinct resident scans cycled through")
     ap.add_argument("--cell-size", type=float, default=0.0, help="k-NN grid cell edge [m]; 0 = 2 x filter_size_map")
+    ap.add_argument("--edge", action="store_true", help="every scan looks past the edge of the map (a floor patch in view of every pose is missing from it)")
+    ap.add_argument("--edge-wide", action="store_true", help="--edge with a patch of six times the area: more unfinished queries per search pass than the completion workgroups take (256)")
     ap.add_argument("--cpu-sweep-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_sweep_worker:  # (cpu_baseline's thread sweep, in a process of its own: see there)
@@ -224,7 +239,9 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    wl = build_workload(args.workload, args.scans)
+    if args.edge_wide:
+        args.edge = "wide"
+    wl = build_workload(args.workload, args.scans, edge=args.edge)
     n_full = max(len(s) for s in wl["scans"])
     reg = lii.Registrar(max_scan_points=n_full + 1024, max_map_points=int(len(wl["map"]) * 1.5) + 1024,
                         filter_size_map=wl["fs_map"], map_cell_size=args.cell_size, device=local_rank)
@@ -465,13 +482,15 @@ def main():
     iters_total[0], search_total[0] = iters_value, searches_value
     # size of the down-sampled cloud (the k-NN kernel's query count) and, on one GPU, the final state of every distinct scan
     # for the parity record: one untimed call per distinct scan, on every rank (a sharded call needs all of them)
-    n_ds, gpu_results = [], []
+    n_ds, gpu_results, n_short = [], [], []
     for j in range(len(dev_scans)):
         st = states0[j].copy()
         rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=0.0 if args.no_downsample else wl["fs_surf"],
                                 max_iterations=wl["max_it"], imu_en=True, scan_dev=dev_scans[j], scan_sorted=True)
         n_ds.append(len(reg.scan_download(1)))
         gpu_results.append((st.pod.copy(), rep))
+        if args.edge and world == 1:
+            n_short.append((int((reg.neighbors(n_ds[-1])[1] < 5).sum()), reg.last_unfinished_queries()))
     # the GPU's neighbour lists of the first scan at its start state (one host-driven search pass, the map as timed): compared
     # with the unmodified reference ikd-Tree in the cpu_baseline leg
     gpu_lists = None
@@ -600,6 +619,12 @@ def main():
                          "launches": int(tm[5]),
                          "peak_measured_copy": 6290.0, "frac_of_measured_copy": achieved / 6290.0},
         }
+        if args.edge:
+            out["config"]["workload"] = out["config"]["workload"].replace(args.workload + ":", args.workload + "_edge:", 1)
+            out["edge"] = {"patch_missing_from_the_map_m": EDGE_PATCH_WIDE if args.edge == "wide" else EDGE_PATCH,
+                           "queries_with_fewer_than_5_neighbours_per_scan": [a for a, _ in n_short],
+                           "queries_left_unfinished_by_the_search_passes_per_scan": [list(b) for _, b in n_short],
+                           "what": "every scan of the stream looks past the edge of the map (never `value` of the headline line)"}
         if value_long is not None:
             out["value_long"] = value_long
         if slowest_value:  # a one-off stall of the runtime inside the region shows here (and in value vs value_long), not in the kernels
@@ -668,7 +693,7 @@ def cpu_sweep_worker(args):
     """The oracle's step on 3 / 8 / 32 / 64 OpenMP threads, ~3 s each; prints one JSON object {threads: scans/s}.  Started by
     cpu_baseline with OMP_PROC_BIND=close OMP_PLACES=cores; touches no GPU."""
     from oracle import oracle as O
-    wl = build_workload(args.workload, 2)
+    wl = build_workload(args.workload, 2, edge=args.edge)
     states0, tables = start_states(wl)
     tree = O.Tree("oracle")
     tree.build(wl["map"])
@@ -717,7 +742,7 @@ def measure_traffic_live(args):
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, ctr), "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "8", "--warmup", "2", "--prime", "0",
                    "--profile-every", "0", "--no-cpu-baseline", "--no-pipeline", "--no-calibration", "--kernel-profile-steps", "0",
-                   "--long-steps", "0", "--no-live-traffic"] + (["--no-downsample"] if args.no_downsample else [])
+                   "--long-steps", "0", "--no-live-traffic"] + (["--no-downsample"] if args.no_downsample else []) + (["--edge-wide"] if args.edge == "wide" else (["--edge"] if args.edge else []))
             subprocess.run(cmd, env={**os.environ, "TMPDIR": "/tmp", "LII_BENCH_CHILD": "1"}, cwd="/tmp", timeout=150,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             per = {}
@@ -782,7 +807,7 @@ def cpu_baseline(wl, states0, tables, no_downsample, gpu_results, gpu_lists=None
         import subprocess
         env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
         outp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-sweep-worker", "--workload", wl["name"]] +
-                              (["--no-downsample"] if no_downsample else []), env=env, capture_output=True, timeout=120, text=True)
+                              (["--no-downsample"] if no_downsample else []) + (["--edge-wide"] if wl.get("edge") == "wide" else (["--edge"] if wl.get("edge") else [])), env=env, capture_output=True, timeout=120, text=True)
         sweep = json.loads(outp.stdout.strip().splitlines()[-1])
     except Exception as e:
         sweep = {"error": str(e)[:200]}

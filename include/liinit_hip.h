@@ -19,14 +19,15 @@
 extern "C" {
 #endif
 
-#define LII_ABI_VERSION 7 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
+#define LII_ABI_VERSION 8 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
                              3: lii_params_*, lii_comm_set_partition (library-side split of the down-sampled cloud)
                              4: lii_scan_upload_next / lii_scan_advance (the next scan travels while the current one registers)
                              5: LII_COMM_MAILBOX = the peer-mapped HBM mailbox (HIP IPC), LII_COMM_MAILBOX_HOST, lii_comm_rccl_ranks
                              6: lii_scan_job::scan_sorted (struct_size 56; a job of size 48 - ABI 5 - is still accepted), lii_last_kernel_profile,
                                 lii_comm_describe, lii_comm_set_partition(h, 2) (split by voxel), lii_scan_job::map_update (the reserved field)
                              7: lii_ingest_opts::cut_frame_num = 0 (the whole message as one frame: Preprocess::process), lii_last_solve_info,
-                                lii_selftest_list_exchange */
+                                lii_selftest_list_exchange
+                             8: lii_last_unfinished_queries */
 
 enum lii_status {
   LII_OK = 0,
@@ -247,6 +248,12 @@ int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* s
  * with Eigen's partial-pivoting LU every time (src/laserMapping.cpp:1081-1085); the result is held to the same tolerance either way -
  * the count exists so that tests can tell which routine they exercised. */
 int lii_last_solve_info(lii_handle h, int32_t* pivoted_passes);
+/* How many queries the last two search passes could not finish inside their own launch - their 5th neighbour lies beyond what the
+ * 3 x 3 x 3 cells around the query can prove: the reference's tree walks on into farther boxes for them (include/ikd-Tree/
+ * ikd_Tree.cpp:827-842) - and left to the fit launch behind them (ABI 8).  out[0]: the most recent search launch, out[1]: the one before.
+ * Up to 256 per launch are finished by completion workgroups of their own; beyond that every workgroup finishes its own points'.
+ * A diagnostic (one small device read); synchronises the handle's stream. */
+int lii_last_unfinished_queries(lii_handle h, int32_t out[2]);
 
 /* The per-scan sequence of main() (src/laserMapping.cpp:909-1134) in ONE call, enqueued back to back on the handle's
  * stream with a single host round trip at the end: p_imu->Process' undistortion (:909; the scan is the one handed over by

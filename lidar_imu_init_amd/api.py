@@ -117,6 +117,7 @@ _DECLS = {
     "lii_scan_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(lii_iekf_report)]),
     "lii_neighbors_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "lii_last_solve_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "lii_last_unfinished_queries": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "lii_map_incremental": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lii_calib_set_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "lii_calib_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
@@ -555,6 +556,12 @@ class Registrar:
         n = C.c_int32(0)
         self._check(self.L.lii_last_solve_info(self.h, C.byref(n)))
         return int(n.value)
+
+    def last_unfinished_queries(self):
+        """(most recent search launch, the one before): queries the search pass left to the fit launch behind it."""
+        out = (C.c_int32 * 2)()
+        self._check(self.L.lii_last_unfinished_queries(self.h, out))
+        return int(out[0]), int(out[1])
 
     def selftest_list_exchange(self, add_lists, nodown_lists, form):
         """The list exchange of a sharded job's map update played by ONE handle for len(add_lists) ranks (form "gather": the mailbox

@@ -432,6 +432,26 @@ int lii_destroy(lii_handle h) {
   if (h->net.comm) ncclCommDestroy(h->net.comm);
   if (h->map_stream) (void)hipStreamSynchronize(h->map_stream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+#ifdef LII_FALLBACK_TRACE
+  {
+    unsigned long long t[32] = {};
+    lii::fb_trace_read(t);
+    for (int kind = 0; kind < 2; kind++) {
+      const unsigned long long* q = t + 8 * kind;
+      if (q[0] == 0) continue;
+      const double n = double(q[0]);
+      std::fprintf(stderr, "[libliinit_hip completion trace] %s: %llu queries, us per query: head -> inner list %.2f, cell entries -> list %.2f, candidates %.2f, selection %.2f, "
+                   "winners stored %.2f; chunks listed %.1f, cells of the cube %.0f\n", kind == 0 ? "balls of more than 256 cells" : "balls of up to 256 cells", q[0],
+                   0.01 * q[1] / n, 0.01 * q[2] / n, 0.01 * q[3] / n, 0.01 * q[4] / n, 0.01 * q[5] / n, double(q[6]) / n, double(q[7]) / n);
+    }
+    if (t[0] > 0)
+      std::fprintf(stderr, "[libliinit_hip completion trace] of 'cell entries -> list' (window rows only), us per query: until the block probes are in %.2f, waiting for the row loads %.2f, "
+                   "list trips %.2f\n", 0.01 * t[24] / double(t[0]), 0.01 * t[25] / double(t[0]), 0.01 * t[26] / double(t[0]));
+    if (t[16] > 0)
+      std::fprintf(stderr, "[libliinit_hip completion trace] completion workgroups with work: %llu (%.2f queries each), us: head %.2f, completions %.2f, fit + sums %.2f\n", t[16],
+                   double(t[20]) / double(t[16]), 0.01 * t[17] / double(t[16]), 0.01 * t[18] / double(t[16]), 0.01 * t[19] / double(t[16]));
+  }
+#endif
 #ifdef LII_GAP_TRACE
   if (h->d_gran) {
     unsigned long long g[4] = {0, 0, 0, 0};

@@ -370,6 +370,17 @@ int lii_last_solve_info(lii_handle h, int32_t* pivoted_passes) {
   return LII_OK;
 }
 
+int lii_last_unfinished_queries(lii_handle h, int32_t out[2]) {
+  if (!h || !out) return LII_ERR_INVALID;
+  int c[2] = {0, 0};
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(c, h->d_flags, sizeof(c), hipMemcpyDeviceToHost));  // RegistrationBuffers::flag_count, one word per slot
+  const int last = h->knn_epoch & 1;  // (consecutive launch numbers alternate between the two slots)
+  out[0] = c[last];
+  out[1] = c[last ^ 1];
+  return LII_OK;
+}
+
 int lii_iekf_iterate(lii_handle h, const lii_state* state, int32_t search, int32_t imu_en, double out91[91]) {
   if (!h || !state || !out91) return fail(h, LII_ERR_INVALID, "lii_iekf_iterate: bad arguments");
   return iterate(h, state, search != 0, imu_en != 0, out91);

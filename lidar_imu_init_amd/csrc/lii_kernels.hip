@@ -472,22 +472,9 @@ __device__ __forceinline__ void lookup_cells_batched(const GridView& g, const ui
     }
 #pragma unroll
     for (int t = 0; t < NC; t++) out[t] = (want[t] && in[t]) ? g.win[wi[t]] : make_uint2(0u, 0u);
-#pragma unroll
-    for (int t = 0; t < NC; t++) {
-      if (want[t] && !in[t]) {
-        const int bx = (ix[t] >> kCoarseShift) + bb, by = (iy[t] >> kCoarseShift) + bb, bz = (iz[t] >> kCoarseShift) + bb;
-        const unsigned long long key = pack_block(bx, by, bz);
-        unsigned int slot = hash_block(bx, by, bz) & g.block_mask;
-        uint4 en = tab[slot];
-        unsigned long long ek = ((unsigned long long)en.y << 32) | en.x;
-        while (ek != key && ek != kEmptyKey) {
-          slot = (slot + 1) & g.block_mask;
-          en = tab[slot];
-          ek = ((unsigned long long)en.y << 32) | en.x;
-        }
-        if (ek == key) out[t] = g.cells[en.z * (unsigned)kBlockCells + ((((unsigned)iz[t] & 7u) << 6) | (((unsigned)iy[t] & 7u) << 3) | ((unsigned)ix[t] & 7u))];
-      }
-    }
+    // (a cell outside the box is EMPTY: the window covers every block the map has - and a block of margin - and is only handed to a
+    // launch while the map is as the window found it.  The first form walked the block table for such a cell: the queries of a scan
+    // that looks past the map's edge paid a dependent probe each for a block that cannot exist.)
     return;
   }
   unsigned long long bk[NC];
@@ -997,6 +984,17 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuff
 // pops" — ~25 instructions per round instead of a 6-step butterfly of 5-element insertions.  The result is wave-uniform.
 // (reductions over the wavefront on DPP row operations: ~60 cycles where six rounds of __shfl_xor - LDS permutes - take ~700; the
 // completion of ONE query runs ten of them, on the critical path of the fit launch)
+// Measurement builds (-DLII_FALLBACK_TRACE, tools/ab_build.sh): where a completion's time goes - 100 MHz stamps around the phases of
+// complete_one / knn_fallback_wave, summed per kind of query (0: a ball of more than 256 cells - the queries that look past the
+// map's edge; 1: the others) and read back by lii_destroy.  [kind * 8 + 0] queries, [+1] head -> inner list, [+2] cell entries -> list,
+// [+3] candidates, [+4] selection, [+5] winners stored; [16 ..] per completion workgroup with work: count, head, completions, fit + sums.
+#ifdef LII_FALLBACK_TRACE
+__device__ unsigned long long g_fb_trace[32];
+#define LII_FB_TS(v) const long long v = wall_clock64()
+__device__ __forceinline__ void fb_add(int at, long long v) { if ((threadIdx.x & 63) == 0) atomicAdd(&g_fb_trace[at], (unsigned long long)v); }
+#else
+#define LII_FB_TS(v)
+#endif
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned int dpp_u32(unsigned int old, unsigned int v) {
   return (unsigned int)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
@@ -1052,7 +1050,8 @@ __device__ __forceinline__ void far_candidates(const GridView& g, const uint2 (&
 // four points, word = first map index << 3 | points, appended to a per-wavefront list in LDS behind a prefix sum over the lanes - and
 // the wavefront scans the list together, one chunk (four loads in flight) per lane and round: a hundred occupied cells are 225
 // chunks, four rounds.
-constexpr int kFarCap = 2048;  // chunks the list holds (it lives in the LDS the launch's final reduction uses later: ReduceShared::row)
+constexpr int kFarCap = 2048;  // words of the list (it lives in the LDS the launch's final reduction uses later: ReduceShared::row)
+constexpr int kFarUse = kFarCap - 1;  // chunks it holds: the last word takes the writes of far_list_write that have nothing to say
 __device__ __forceinline__ unsigned int wave_excl_prefix_u32(unsigned int v, unsigned int* total) {
   // inclusive scan inside the rows of 16 (row_shr 1, 2, 4, 8: lanes shifted in from outside a row read 0), then the totals of the rows
   // in front (row_bcast15, row_bcast31)
@@ -1067,11 +1066,30 @@ __device__ __forceinline__ unsigned int wave_excl_prefix_u32(unsigned int v, uns
   return x - v;
 }
 // the chunks of NB cell ranges to list[at ...]
+// (round 6: the first two chunks of a cell - eight points, most cells hold no more - are written without a loop, the rest behind ONE
+// wave-wide test.  The first form ran a loop per cell range: NB loops of divergent trip counts per lane and trip, ~800 instructions
+// of a wavefront that runs alone on its SIMD - half of the 5.4 us "cell entries -> list" of a query at the map's edge.)
 template <int NB>
 __device__ __forceinline__ void far_list_write(unsigned int* __restrict__ list, unsigned int at, const uint2 (&rr)[NB]) {
+  const unsigned int at0 = at;
+  bool more = false;
 #pragma unroll
-  for (int b = 0; b < NB; b++)
-    for (unsigned int j = rr[b].x; j < rr[b].y; j += 4u) list[at++] = (j << 3) | min(4u, rr[b].y - j);
+  for (int b = 0; b < NB; b++) {  // (no branch: a chunk that does not exist goes to the list's last word, which is never used - kFarUse)
+    const unsigned int n = rr[b].y - rr[b].x;
+    list[n > 0u ? at : (unsigned)kFarUse] = (rr[b].x << 3) | min(4u, n);
+    list[n > 4u ? at + 1u : (unsigned)kFarUse] = ((rr[b].x + 4u) << 3) | min(4u, n - 4u);
+    more = more || n > 8u;
+    at += (n + 3u) >> 2;
+  }
+  if (__any(more)) {  // (uniform) cells of more than eight points: their other chunks
+    at = at0;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      unsigned int a2 = at + 2u;
+      for (unsigned int j = rr[b].x + 8u; j < rr[b].y; j += 4u) list[a2++] = (j << 3) | min(4u, rr[b].y - j);
+      at += (rr[b].y - rr[b].x + 3u) >> 2;
+    }
+  }
 }
 // every candidate of list[0 .. n) against the lanes' lists (uniform call)
 __device__ __forceinline__ void far_list_scan(const GridView& g, const unsigned int* __restrict__ list, unsigned int n, float wx, float wy, float wz,
@@ -1106,11 +1124,11 @@ __device__ __forceinline__ void far_list_trip(const GridView& g, unsigned int* _
   if (!__any(mine != 0u)) return;  // (uniform) nothing in this trip: most trips of a ball that reaches past the map
   unsigned int total;
   const unsigned int before = wave_excl_prefix_u32(mine, &total);
-  if (total > (unsigned)kFarCap) {
+  if (total > (unsigned)kFarUse) {
     far_candidates<NB>(g, rr, wx, wy, wz, bound1, k);
     return;
   }
-  if (n_list + total > (unsigned)kFarCap) {
+  if (n_list + total > (unsigned)kFarUse) {
     far_list_scan(g, list, n_list, wx, wy, wz, bound1, k);
     n_list = 0u;
   }
@@ -1121,7 +1139,11 @@ __device__ __forceinline__ void far_list_trip(const GridView& g, unsigned int* _
 // (seed_d: the distance of entry `lane` on lanes 0..4, inf where the list ends) stands in for pass 1; a seeded entry that
 // survives comes back as index -(2 + its place in the list).
 __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, float wy, float wz, bool has5, float list_d, bool seeded,
-                                                  float seed_d, float (&od)[5], int (&oi)[5], unsigned int* __restrict__ far_list /* [kFarCap] LDS, this wavefront's */) {
+                                                  float seed_d, float (&od)[5], int (&oi)[5], unsigned int* __restrict__ far_list /* [kFarCap] LDS, this wavefront's */
+#ifdef LII_FALLBACK_TRACE
+                                                  , long long fb_t0, int* fb_kind
+#endif
+                                                  ) {
   const int lane = threadIdx.x & 63;
   // (the block probes below need the query only: they are issued before the search pass's list - list_d: entry `lane`'s distance
   // on lanes 0..4 - is looked at)
@@ -1129,7 +1151,14 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
   const float eps = 1e-6f * (fabsf(wx) + fabsf(wy) + fabsf(wz) + 8.f);
   const int cx = cell_of(wx, g.inv_cs), cy = cell_of(wy, g.inv_cs), cz = cell_of(wz, g.inv_cs);
   const int X0 = cx >> kCoarseShift, Y0 = cy >> kCoarseShift, Z0 = cz >> kCoarseShift;
+  // (with the dense window - GridView::win - the far pass reads whole ROWS of cell entries, see below; the 27 block probes stay: which
+  // blocks exist around the query clips the cube far tighter than the window's box - a query on the floor of a hall has no block
+  // above it, the box reaches to the ceiling: 588 against 1204 cells per edge query on the bench stream)
+  const bool windowed = g.win != nullptr;  // uniform
   const int my_block = lane < 27 ? find_block(g, X0 + (lane % 3) - 1, Y0 + ((lane / 3) % 3) - 1, Z0 + (lane / 9) - 1) : -1;
+  auto win_entry = [&](int ixx, int iyy, int izz) -> size_t {  // index of a cell INSIDE the window
+    return ((size_t)(izz - g.wz0) * (size_t)g.wny + (size_t)(iyy - g.wy0)) * (size_t)g.wnx + (size_t)(ixx - g.wx0);
+  };
   const float d5 = has5 ? __shfl(list_d, 4) : __builtin_inff();
   const float bound0 = fminf(d5, g.max_d2);
   const float r0 = sqrtf(bound0) + 2.f * eps;
@@ -1158,6 +1187,7 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
     }
     wave_select5(k, od, oi);
   }
+  LII_FB_TS(fb_t1);
   const float bound1 = fminf(od[4], bound0);  // exact 5th distance over the inner cells (inf if they hold fewer than 5)
   // pass 2: the rest of the cube around the ball of radius sqrt(bound1) (nothing farther can enter the list), pruned with bound1
   const float r1 = fminf(r0, sqrtf(bound1) + 2.f * eps);
@@ -1186,6 +1216,10 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
   }
   const int nx = max(ix1 - ix0 + 1, 0), ny = max(iy1 - iy0 + 1, 0), nz = max(iz1 - iz0 + 1, 0);
   const int total = nx * ny * nz;
+#ifdef LII_FALLBACK_TRACE
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the block probes are in)
+  long long fb_t1a = wall_clock64(), fb_ld = 0, fb_tr = 0;
+#endif
   k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = __builtin_inff();
   k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
   {  // the inner result re-enters as five one-element lists (lanes 0..4)
@@ -1198,7 +1232,76 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
   // candidates four per trip - the loop is a chain of dependent loads, not of arithmetic.
   const int nxy = nx * ny;
   unsigned int n_far = 0u;  // chunks on the list (uniform)
-  if (total <= 256) {
+  // the clipped cube lies inside the window?  (it does whenever the window is the map's: the cube is clipped to blocks that exist, the
+  // window covers them all and a block of margin - checked all the same, the row loads below rely on it)
+  const bool rows_ok = windowed && total > 0 && ix0 - 1 >= g.wx0 && ix1 + 1 < g.wx0 + g.wnx && iy0 >= g.wy0 && iy1 < g.wy0 + g.wny && iz0 >= g.wz0 &&
+                       iz1 < g.wz0 + g.wnz;
+  if (rows_ok) {
+    // ROW TRIPS (round 6).  In the window the cells of a row (x running) lie next to each other: a lane takes one (y, z) row of the
+    // cube and reads it with 16-byte loads, two cell entries each - the 11 x 11 x 5 cube of a query at the map's edge is 55 rows, ONE
+    // trip of seven loads per lane, where the column walk over the hashed tables took three trips of eight (phase stamps,
+    // profiles/r06_edge.md: 6.6 of the 11.9 us of such a completion).  Cells of blocks that do not exist read as empty entries.
+    constexpr int NV = 7;  // 14 cells of a row per trip (a ball of sqrt(max_d2) spans 11 - 12 at the default cell edge)
+    const int nrows = ny * nz;
+    for (int r0 = 0; r0 < nrows; r0 += 64) {                 // uniform trip counts
+      const int r = r0 + lane;
+      const bool in_row = r < nrows;
+      const int rz = (in_row ? r : 0) / ny, ry = (in_row ? r : 0) - rz * ny;
+      const int iyy = iy0 + ry, izz = iz0 + rz;
+      const float gy = axis_gap(wy, iyy, cs, eps), gz = axis_gap(wz, izz, cs, eps);
+      const float gyz = gy * gy + gz * gz;
+      const bool row_ok = in_row && !(gyz > bound1);
+      const bool yz_inner = abs(iyy - cy) <= 1 && abs(izz - cz) <= 1;
+      const int xs0 = ix0 - ((ix0 - g.wx0) & 1);              // the entry pairs are 16-byte aligned: rows are a multiple of eight cells long
+      for (int xs = xs0; xs <= ix1; xs += 2 * NV) {          // uniform
+        // (what depends on x alone is the same for every row: lane i works it out for cell xs + i, everyone reads it back - v_readlane -
+        // and a cell costs an addition and a comparison instead of the ten instructions of its gap.  The completion's wavefront shares
+        // its SIMD with a wavefront of the plane fit: instructions, not loads, are what it waits for - phase stamps, profiles/r06_edge.md)
+        float gx2[2 * NV];
+        {
+          const float gxl = axis_gap(wx, xs + (lane < 2 * NV ? lane : 0), cs, eps);
+          const float gx2l = gxl * gxl;
+#pragma unroll
+          for (int c = 0; c < 2 * NV; c++) gx2[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gx2l), c));
+        }
+        // which cells of the row can hold a candidate is decided FIRST: a pair of entries is only fetched when one of its cells can
+        // (the corners of the cube lie outside the ball - half of its cells; a launch with a thousand unfinished queries is short of
+        // memory requests, not of instructions)
+        bool act[2 * NV];
+#pragma unroll
+        for (int c = 0; c < 2 * NV; c++) {
+          const int ixx = xs + c;
+          const bool x_in = ixx >= ix0 && ixx <= ix1, x_inner = abs(ixx - cx) <= 1;  // (uniform)
+          act[c] = row_ok && x_in && !(yz_inner && x_inner) && !(gyz + gx2[c] > bound1);  // (the inner cube: done in pass 1)
+        }
+        const size_t base = win_entry(xs, iyy, izz);
+        uint4 v[NV];
+#pragma unroll
+        for (int t = 0; t < NV; t++)  // (requested from entry 0 when not wanted, and dropped afterwards: no load behind a branch)
+          v[t] = *reinterpret_cast<const uint4*>(g.win + ((act[2 * t] || act[2 * t + 1]) ? base + 2 * (size_t)t : (size_t)0));
+#ifdef LII_FALLBACK_TRACE
+        const long long fb_a = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the row loads have arrived)
+        const long long fb_b = wall_clock64();
+        fb_ld += fb_b - fb_a;
+#endif
+        uint2 rr[2 * NV];
+#pragma unroll
+        for (int t = 0; t < NV; t++) {
+          rr[2 * t] = act[2 * t] ? make_uint2(v[t].x, v[t].y) : make_uint2(0u, 0u);
+          rr[2 * t + 1] = act[2 * t + 1] ? make_uint2(v[t].z, v[t].w) : make_uint2(0u, 0u);
+        }
+#ifdef LII_FALLBACK_TRACE
+        const long long fb_c = wall_clock64();
+#endif
+        far_list_trip<2 * NV>(g, far_list, n_far, rr, wx, wy, wz, bound1, k);
+#ifdef LII_FALLBACK_TRACE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        fb_tr += wall_clock64() - fb_c;
+#endif
+      }
+    }
+  } else if (total <= 256) {
   constexpr int NB = 4;
   for (int c0 = 0; c0 < total; c0 += 64 * NB) {  // uniform trip count: the shuffle below needs every lane
     uint2 rr[NB];
@@ -1270,8 +1373,20 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
     }
   }
   }
+  LII_FB_TS(fb_t2);
   far_list_scan(g, far_list, n_far, wx, wy, wz, bound1, k);
+  LII_FB_TS(fb_t3);
   wave_select5(k, od, oi);
+#ifdef LII_FALLBACK_TRACE
+  {
+    const long long fb_t4 = wall_clock64();
+    const int kind = total > 256 ? 0 : 8;
+    fb_add(kind + 0, 1); fb_add(kind + 1, fb_t1 - fb_t0); fb_add(kind + 2, fb_t2 - fb_t1); fb_add(kind + 3, fb_t3 - fb_t2); fb_add(kind + 4, fb_t4 - fb_t3);
+    fb_add(kind + 6, (long long)n_far); fb_add(kind + 7, (long long)total);
+    if (kind == 0) { fb_add(24, fb_t1a - fb_t1); fb_add(25, fb_ld); fb_add(26, fb_tr); }
+    *fb_kind = kind;
+  }
+#endif
 }
 
 // Equal squared distances inside the kept list are ordered by x, ascending — what the reference's heap comparator
@@ -1305,6 +1420,7 @@ __device__ __forceinline__ bool canon_ties(float4 (&nb)[5]) {
 __device__ __forceinline__ void complete_one(const GridView& g, const RegistrationBuffers& rb, int qi, int c00, float wx, float wy, float wz,
                                              unsigned int* __restrict__ far_list, float4* __restrict__ lds_nb = nullptr,
                                              int* __restrict__ lds_found = nullptr, int mark = 0) {
+  LII_FB_TS(fb_t0);
   const int lane = threadIdx.x & 63;
   const int c0 = c00 & 0xFF;
   const bool seeded = (c00 & kCovered) != 0;  // uniform
@@ -1312,7 +1428,13 @@ __device__ __forceinline__ void complete_one(const GridView& g, const Registrati
   const float4 sv = lane < 5 ? rb.nbr[(size_t)lane * rb.cap + qi] : make_float4(0.f, 0.f, 0.f, __builtin_inff());
   float od[5];
   int oi[5];
+#ifdef LII_FALLBACK_TRACE
+  int fb_kind = 0;
+  knn_fallback_wave(g, wx, wy, wz, c0 == kMatch, sv.w, seeded, lane < c0 ? sv.w : __builtin_inff(), od, oi, far_list, fb_t0, &fb_kind);
+#else
   knn_fallback_wave(g, wx, wy, wz, c0 == kMatch, sv.w, seeded, lane < c0 ? sv.w : __builtin_inff(), od, oi, far_list);
+#endif
+  LII_FB_TS(fb_t5);
   const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
   const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
   // a seeded entry that stayed in the list: its point is in the lane that loaded it
@@ -1330,6 +1452,9 @@ __device__ __forceinline__ void complete_one(const GridView& g, const Registrati
     rb.nbr_count[qi] = found | mark;  // (mark: kDone from a completion workgroup - see lii_device.h)
     if (lds_found) *lds_found = found;
   }
+#ifdef LII_FALLBACK_TRACE
+  fb_add(fb_kind + 5, wall_clock64() - fb_t5);
+#endif
 }
 constexpr int kHandOver = 64;  // queries of a completion workgroup whose finished lists reach the fitting lane through LDS (usually all: 2 ... 8 per workgroup)
 struct NeedyShared {
@@ -1396,6 +1521,7 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
                                                         double plane_thr, double rinv, int nb_real, int epoch) {
   __shared__ ReduceShared sh;
   __shared__ NeedyShared sh_needy;
+  LII_FB_TS(fb_ta);
   // The last kCompletionBlocks workgroups of the launch are COMPLETION workgroups (round 5): behind a search pass they finish the
   // queries that pass listed as unfinished - and fit, gate and sum them like any other point, into a column of partial sums of their
   // own - while the workgroups of the cloud leave those points out.  Round 4 had every workgroup finish its own flagged queries in
@@ -1495,24 +1621,31 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
     live = false;
     if (defer) {
       const int j = (int)blockIdx.x;
+      LII_FB_TS(fb_tb);
       if (threadIdx.x == 0) sh_needy.n = 0;
       __syncthreads();
       // The entries of this workgroup, ranked by query index: query (aux), neighbour count with the flags (count), world point (w) and
       // body point - everything complete_one and the fit start from - go to LDS from the lane that read the entry at the head of the
       // launch: one dependent round trip (list + scalars) in front of the block probes, where the first form of this had three (the
       // list's length, the queries' indices, the entries).
+      // Round 6: the listed queries are dealt out by their RANK in ascending order of the query index - rank r goes to workgroup
+      // r % kCompletionBlocks, place r / kCompletionBlocks there - so that no workgroup holds more than ceil(n / 32) of them: 73 queries
+      // are at most three per workgroup, one per wavefront, ONE round of completions.  (Round 5 dealt by (index / 4) % 32: clusters of
+      // flagged queries left workgroups with six or eight - two rounds of ~12 us - beside idle ones; the order of the sums still
+      // depends on the indices alone.)
       const int qx = __float_as_int(l0.w);
-      const bool mine = (int)threadIdx.x < n_flagged && ((qx >> 2) % kCompletionBlocks) == j;
-      float4 my_body = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (mine) {
-        my_body = rb.body[qx];
-        sh_needy.key[atomicAdd(&sh_needy.n, 1)] = qx;
-      }
+      const bool listed = (int)threadIdx.x < n_flagged;
+      if (listed) sh_needy.key[threadIdx.x] = qx;
       __syncthreads();
-      const int m = sh_needy.n;
+      int rank_all = 0;
+      for (int u = 0; u < n_flagged; u++) rank_all += sh_needy.key[u] < qx ? 1 : 0;  // (uniform trip count, broadcast reads)
+      const bool mine = listed && (rank_all % kCompletionBlocks) == j;
+      const int m = n_flagged > j ? (n_flagged - j + kCompletionBlocks - 1) / kCompletionBlocks : 0;
+      float4 my_body = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mine) my_body = rb.body[qx];
+      if (threadIdx.x == 0) sh_needy.n = m;
       if (mine) {
-        int rank = 0;
-        for (int u = 0; u < m; u++) rank += sh_needy.key[u] < qx ? 1 : 0;
+        const int rank = rank_all / kCompletionBlocks;
         sh_needy.aux[rank] = qx;
         sh_needy.count[rank] = l1x;
         sh_needy.w[rank][0] = l0.x; sh_needy.w[rank][1] = l0.y; sh_needy.w[rank][2] = l0.z;
@@ -1525,6 +1658,14 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
                      reinterpret_cast<unsigned int*>(&sh.row[0][0]) + wave * kFarCap, e < kHandOver ? &sh_needy.nb[e][0] : nullptr,
                      e < kHandOver ? &sh_needy.found[e] : nullptr, kDone);
       __syncthreads();  // the completed lists are visible to the lanes that fit them (workgroup-scope release / acquire)
+#ifdef LII_FALLBACK_TRACE
+      if (threadIdx.x == 0 && m > 0) {
+        const long long fb_tc = wall_clock64();
+        atomicAdd(&g_fb_trace[16], 1ull); atomicAdd(&g_fb_trace[17], (unsigned long long)(fb_tb - fb_ta)); atomicAdd(&g_fb_trace[18], (unsigned long long)(fb_tc - fb_tb));
+        atomicAdd(&g_fb_trace[20], (unsigned long long)m);
+        sh_needy.key[kBlock - 1] = (int)(fb_tc & 0x7FFFFFFF);  // (low bits: the end stamp below subtracts them)
+      }
+#endif
       if ((int)threadIdx.x < m) {
         i = sh_needy.aux[threadIdx.x];
         live = true;
@@ -1594,6 +1735,10 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
     rb.selected[i] = o.sel ? 1 : 0;
   }
   block_reduce_rows(sh, o.h, o.z, o.sel, rinv, rb.partials + blk, rb.partial_stride);
+#ifdef LII_FALLBACK_TRACE
+  if (completion_wg && defer && threadIdx.x == 0 && sh_needy.n > 0)
+    atomicAdd(&g_fb_trace[19], (unsigned long long)(((int)(wall_clock64() & 0x7FFFFFFF) - sh_needy.key[kBlock - 1]) & 0x7FFFFFFF));
+#endif
 }
 
 // Deterministic final reduction of the transposed partials: out[t] = sum_b partials[t * stride + b].
@@ -1773,6 +1918,9 @@ void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks
   if (n > 0) hipLaunchKernelGGL(k_cells_fill, dim3(nblk(n, 256)), dim3(256), 0, s, keys, ranks, n, blocks, block_mask, cells);
 }
 int register_blocks(int n) { return nblk(n, kBlock); }
+#ifdef LII_FALLBACK_TRACE
+void fb_trace_read(unsigned long long out[32]) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fb_trace), sizeof(unsigned long long) * 32); }
+#endif
 // upper bound of the points one rank registers (the exact split is taken on the device from the exact cloud size)
 static inline int shard_bound(const RegistrationBuffers& rb) {
   return rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;

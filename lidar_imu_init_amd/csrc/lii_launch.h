@@ -36,6 +36,9 @@ void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks
 void launch_knn(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                 const IekfCtrl* ctrl, int forced, double* search_pose_out, hipStream_t s, int epoch,
                 hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+#ifdef LII_FALLBACK_TRACE
+void fb_trace_read(unsigned long long out[32]);  // (measurement builds: the completion's phase sums, lii_kernels.hip)
+#endif
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s);
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s, int epoch);
