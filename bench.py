@@ -69,7 +69,7 @@ def build_workload(name, n_scans, seed=20220613, map_cache=None, edge=False):
         inside = (m[:, 0] > x0) & (m[:, 0] < x1) & (m[:, 1] > y0) & (m[:, 1] < y1) & (m[:, 2] > z0) & (m[:, 2] < z1)
         map_pts = np.ascontiguousarray(m[~inside])
     rng = np.random.default_rng(seed)
-    scans, poses = [], []
+    scans, poses, sweeps = [], [], []
     k = 0
     while len(scans) < n_scans:
         yaw = 0.15 * k
@@ -77,6 +77,7 @@ def build_workload(name, n_scans, seed=20220613, map_cache=None, edge=False):
         p = np.array([3.0 * np.cos(0.2 * k), 2.0 * np.sin(0.2 * k), 0.2 + 0.05 * np.sin(k)])
         sweep = synth.make_scan(hall, sensor, R, p, noise=0.02, seed=seed + k)
         sweep = sweep[np.argsort(sweep[:, 3], kind="stable")]  # time order, as the ingest delivers it
+        sweeps.append(sweep)  # (the whole driver message: complete_pipeline.from_wire packs it as PointCloud2 bytes)
         for c in range(cut):
             lo, hi = (len(sweep) * c) // cut, (len(sweep) * (c + 1)) // cut
             sub = sweep[lo:hi].copy()
@@ -86,7 +87,7 @@ def build_workload(name, n_scans, seed=20220613, map_cache=None, edge=False):
                 poses.append((R, p))
         k += 1
     return dict(name=name, map=map_pts, hall=hall, scans=scans, poses=poses, fs_map=fs_map, fs_surf=fs_surf, max_it=max_it, rng=rng,
-                sweep_s=0.1 / cut, params=prm, edge=edge)
+                sweep_s=0.1 / cut, params=prm, edge=edge, sweeps=sweeps, cut=cut)
 
 
 def start_states(wl):
@@ -562,6 +563,11 @@ def main():
                         "pageable_source": {"value": n_pipe / tp_pageable, "ms_per_scan": 1e3 * tp_pageable / n_pipe},
                         "serial_upload": {"value": n_pipe / tp_serial, "ms_per_scan": 1e3 * tp_serial / n_pipe},
                         "map_points_after": reg.map_size()}
+            if hasattr(drv, "lii_stream_run_wire") and not args.no_downsample:
+                try:
+                    pipeline["from_wire"] = from_wire_record(args, wl, reg, drv, stream, len(dev_scans), n_pipe)
+                except Exception as e:  # reported, never fatal for the line
+                    pipeline["from_wire"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         else:
             tp = python_pipeline()
             pipeline = {"value": n_pipe / tp, "unit": "scans/s", "ms_per_scan": 1e3 * tp / n_pipe, "steps": n_pipe,
@@ -623,7 +629,7 @@ def main():
             out["config"]["workload"] = out["config"]["workload"].replace(args.workload + ":", args.workload + "_edge:", 1)
             out["edge"] = {"patch_missing_from_the_map_m": EDGE_PATCH_WIDE if args.edge == "wide" else EDGE_PATCH,
                            "queries_with_fewer_than_5_neighbours_per_scan": [a for a, _ in n_short],
-                           "queries_left_unfinished_by_the_search_passes_per_scan": [list(b) for _, b in n_short],
+                           "queries_left_unfinished_by_the_last_search_pass_per_scan": [b for _, b in n_short],
                            "what": "every scan of the stream looks past the edge of the map (never `value` of the headline line)"}
         if value_long is not None:
             out["value_long"] = value_long
@@ -687,6 +693,60 @@ def main():
     reg.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def from_wire_record(args, wl, reg, drv, stream, n_stream, n_pipe):
+    """complete_pipeline.from_wire: driver messages in, poses out.  Every sweep of the workload packed as sensor_msgs/PointCloud2 bytes
+    in the Ouster driver's layout (harness/wire.py: 48-byte records, time as uint32 nanoseconds) -> lii_ingest_pcl2 (H2D of the raw
+    bytes, decode, blind / ring filters, time sort, cut into `cut_frame_num` sub-frames: src/preprocess.cpp:115-335) -> per sub-frame
+    lii_frame_select + lii_scan_register with the map update in the job (src/laserMapping.cpp:326-379, 909-1134, 516-559), C++ host
+    loop (harness/stream_driver.cpp: lii_stream_run_wire).  Never `value`."""
+    import ctypes as C
+    from harness import wire
+    from lidar_imu_init_amd.api import lii_ingest_opts, lii_pc2_fields
+    cut = int(wl["cut"])
+    prm = wl["params"]
+    msgs = []
+    for k, sw in enumerate(wl["sweeps"]):
+        raw = wire.pack_pcl2(wire.OUSTER, sw[:, :3], (np.arange(len(sw)) % 128).astype(np.int32), sw[:, 3].astype(np.float64), 0.1 * k)
+        msgs.append(np.frombuffer(raw, np.uint8).copy())
+    n_msgs = max(1, n_stream // cut)  # whole messages whose sub-frames the stream's states cover
+    msgs = msgs[:n_msgs]
+    ptrs = (C.c_void_p * n_msgs)(*[m.ctypes.data for m in msgs])
+    npts = np.array([len(sw) for sw in wl["sweeps"][:n_msgs]], np.int32)
+    fields = lii_pc2_fields(*wire.pc2_fields(wire.OUSTER))
+    opts = lii_ingest_opts()
+    opts.struct_size = C.sizeof(lii_ingest_opts)
+    opts.lidar_type, opts.n_scans, opts.point_filter_num = wire.OUSTER, 128, 1
+    opts.blind, opts.stamp_s, opts.cut_frame_num, opts.scan_count = 0.01, 0.0, cut, 1000  # (past the first 20 messages, which the reference does not cut)
+    drv.lii_stream_run_wire.restype = C.c_int
+    drv.lii_stream_run_wire.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+
+    def run(steps, map_update):
+        tot = np.zeros(2, np.int64)
+        ing = np.zeros(2)
+        reg.synchronize()
+        t0 = time.perf_counter()
+        rc = drv.lii_stream_run_wire(reg.h, C.byref(stream), n_stream, ptrs, npts.ctypes.data, n_msgs, steps, C.byref(fields), C.byref(opts),
+                                     float(wl["fs_surf"]), int(wl["max_it"]), 1, int(map_update), tot.ctypes.data, ing.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"lii_stream_run_wire: status {rc}: {reg.L.lii_last_error(reg.h).decode()}")
+        return time.perf_counter() - t0, ing, tot
+
+    n_m = max(4, n_pipe // cut)
+    run(min(n_m, 2 * n_msgs), True)  # (untimed: first-time allocations of the ingest)
+    dt, ing, tot = run(n_m, True)
+    frames = int(ing[1])
+    return {"value": frames / dt, "unit": "scans/s", "ms_per_scan": 1e3 * dt / max(frames, 1), "messages": n_m, "sub_frames": frames,
+            "cut_frame_num": cut, "points_per_message": int(npts[0]), "bytes_per_message": int(len(msgs[0])),
+            "ingest_us_per_message": float(ing[0]) / n_m,
+            "ingest_share_of_the_loop": float(ing[0]) * 1e-6 / dt,
+            "avg_iterations": float(tot[0]) / max(frames, 1),
+            "what": "PointCloud2 bytes (Ouster layout, pageable host memory) -> lii_ingest_pcl2 -> lii_frame_select -> lii_scan_register with "
+                    "map_update = 1 per sub-frame, C++ host loop; ingest_us_per_message = host time inside lii_ingest_pcl2 (H2D of the raw bytes, "
+                    "its kernels and its one synchronisation)",
+            "map_points_after": reg.map_size()}
 
 
 def cpu_sweep_worker(args):

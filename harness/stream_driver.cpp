@@ -142,4 +142,56 @@ int lii_stream_run_pipeline(lii_handle h, const lii_stream_scan* scans, const vo
   return lii_synchronize(h);
 }
 
+// FROM THE WIRE (round 6): a driver message in, poses out.  Per message the PointCloud2 bytes go through the device ingest
+// (lii_ingest_pcl2 = process_cut_frame_pcl2: H2D of the raw bytes, decode, filters, time sort, cut into sub-frames), every sub-frame
+// becomes the current scan (lii_frame_select) and is registered with the map update in the job - the reference's callback
+// (src/laserMapping.cpp:326-379 -> src/preprocess.cpp:115-335) and main loop (:909-1134, map_incremental :516-559) in one host loop.
+// scans[j]: state and pose table of sub-frame j of the cyclic stream (message m holds sub-frames m * cut ... m * cut + cut - 1).
+// ingest_us[0] += host time inside lii_ingest_pcl2 (its one synchronisation included), [1] += sub-frames registered.
+int lii_stream_run_wire(lii_handle h, const lii_stream_scan* scans, int32_t n_scans, const void* const* msgs, const int32_t* msg_points,
+                        int32_t n_msgs, int32_t steps, const lii_pc2_fields* fields, const lii_ingest_opts* opts0, float leaf,
+                        int32_t max_iterations, int32_t imu_en, int32_t map_update, int64_t totals[2], double ingest_us[2]) {
+  if (!h || !scans || !msgs || !msg_points || !fields || !opts0 || n_scans < 1 || n_msgs < 1 || steps < 0 || !totals || !ingest_us) return LII_ERR_INVALID;
+  lii_state st;
+  lii_iekf_report rep;
+  int rc = lii_set_profiling(h, 0);
+  if (rc != LII_OK) return rc;
+  const int cut = opts0->cut_frame_num > 0 ? opts0->cut_frame_num : 1;
+  for (int32_t m = 0; m < steps; m++) {
+    const int32_t jm = m % n_msgs;
+    lii_ingest_opts o = *opts0;
+    o.stamp_s = opts0->stamp_s + 0.1 * m;
+    o.scan_count = opts0->scan_count + m;
+    lii_frame_info frames[64];
+    int32_t nf = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = lii_ingest_pcl2(h, msgs[jm], msg_points[jm], fields, &o, frames, 64, &nf);
+    ingest_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (rc != LII_OK) return rc;
+    for (int32_t f = 0; f < nf; f++) {
+      rc = lii_frame_select(h, f);
+      if (rc != LII_OK) return rc;
+      const lii_stream_scan& sc = scans[(jm * cut + (f < cut ? f : cut - 1)) % n_scans];
+      std::memcpy(&st, sc.state0, sizeof(st));
+      lii_scan_job job;
+      std::memset(&job, 0, sizeof(job));
+      job.struct_size = sizeof(job);
+      job.undistort = 1;
+      job.imu_poses = sc.poses;
+      job.n_imu_poses = sc.n_poses;
+      job.leaf = leaf;
+      job.opts.max_iterations = max_iterations;
+      job.opts.imu_en = imu_en;
+      job.scan_sorted = 1;  // (the ingest delivers every frame in ascending time order, as the reference's preprocess does)
+      job.map_update = map_update ? 1 : 0;
+      rc = lii_scan_register(h, &job, &st, sc.state0, &rep);
+      if (rc != LII_OK) return rc;
+      totals[0] += rep.iterations;
+      totals[1] += rep.searches;
+      ingest_us[1] += 1.0;
+    }
+  }
+  return lii_synchronize(h);
+}
+
 }  // extern "C"

@@ -248,12 +248,11 @@ int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* s
  * with Eigen's partial-pivoting LU every time (src/laserMapping.cpp:1081-1085); the result is held to the same tolerance either way -
  * the count exists so that tests can tell which routine they exercised. */
 int lii_last_solve_info(lii_handle h, int32_t* pivoted_passes);
-/* How many queries the last two search passes could not finish inside their own launch - their 5th neighbour lies beyond what the
+/* How many queries the most recent search pass could not finish inside its own launch - their 5th neighbour lies beyond what the
  * 3 x 3 x 3 cells around the query can prove: the reference's tree walks on into farther boxes for them (include/ikd-Tree/
- * ikd_Tree.cpp:827-842) - and left to the fit launch behind them (ABI 8).  out[0]: the most recent search launch, out[1]: the one before.
- * Up to 256 per launch are finished by completion workgroups of their own; beyond that every workgroup finishes its own points'.
- * A diagnostic (one small device read); synchronises the handle's stream. */
-int lii_last_unfinished_queries(lii_handle h, int32_t out[2]);
+ * ikd_Tree.cpp:827-842) - and left to the fit launch behind it (ABI 8).  Up to 256 per launch are finished by completion workgroups of
+ * their own; beyond that every workgroup finishes its own points'.  A diagnostic (one small device read); synchronises the handle's stream. */
+int lii_last_unfinished_queries(lii_handle h, int32_t* n_last);
 
 /* The per-scan sequence of main() (src/laserMapping.cpp:909-1134) in ONE call, enqueued back to back on the handle's
  * stream with a single host round trip at the end: p_imu->Process' undistortion (:909; the scan is the one handed over by

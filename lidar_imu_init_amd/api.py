@@ -558,10 +558,10 @@ class Registrar:
         return int(n.value)
 
     def last_unfinished_queries(self):
-        """(most recent search launch, the one before): queries the search pass left to the fit launch behind it."""
-        out = (C.c_int32 * 2)()
-        self._check(self.L.lii_last_unfinished_queries(self.h, out))
-        return int(out[0]), int(out[1])
+        """Queries the most recent search pass left to the fit launch behind it."""
+        n = C.c_int32(0)
+        self._check(self.L.lii_last_unfinished_queries(self.h, C.byref(n)))
+        return int(n.value)
 
     def selftest_list_exchange(self, add_lists, nodown_lists, form):
         """The list exchange of a sharded job's map update played by ONE handle for len(add_lists) ranks (form "gather": the mailbox

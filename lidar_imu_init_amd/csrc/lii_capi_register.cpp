@@ -370,14 +370,12 @@ int lii_last_solve_info(lii_handle h, int32_t* pivoted_passes) {
   return LII_OK;
 }
 
-int lii_last_unfinished_queries(lii_handle h, int32_t out[2]) {
-  if (!h || !out) return LII_ERR_INVALID;
+int lii_last_unfinished_queries(lii_handle h, int32_t* n_last) {
+  if (!h || !n_last) return LII_ERR_INVALID;
   int c[2] = {0, 0};
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(c, h->d_flags, sizeof(c), hipMemcpyDeviceToHost));  // RegistrationBuffers::flag_count, one word per slot
-  const int last = h->knn_epoch & 1;  // (consecutive launch numbers alternate between the two slots)
-  out[0] = c[last];
-  out[1] = c[last ^ 1];
+  *n_last = c[h->knn_epoch & 1];  // (consecutive launch numbers alternate between the two slots; a launch clears the other one)
   return LII_OK;
 }
 
