@@ -147,6 +147,14 @@ int pcl_order(lii_handle h, const int** perm) {
 void extent_discard(lii_handle h) {
   if (h->extent_valid) h->extent_sel ^= 1;
   h->extent_valid = false;
+  h->scan_pending = nullptr;  // (whatever replaces the scan replaces a selected frame that nobody has read as well)
+  h->scan_pending_n = 0;
+}
+int scan_materialize(lii_handle h) {
+  if (!h->scan_pending) return LII_OK;
+  const float4* src = h->scan_pending;
+  const int n = h->scan_pending_n;
+  return lii_scan_set_device(h, src, n);  // (clears the pending frame through extent_discard, then copies from `src`)
 }
 unsigned long long* extent_of_scan(lii_handle h) {
   unsigned long long* ext = h->d_extent + 2 * h->extent_sel;
@@ -185,6 +193,24 @@ MailboxView mailbox_view(lii_handle h) {
 }  // namespace lii_impl
 
 int lii_internal_fail(lii_context* h, int code, const std::string& msg) { return fail(h, code, msg); }
+int lii_internal_scan_materialize(lii_context* h) { return scan_materialize(h); }
+// lii_frame_select's hand-over (lii_ingest.hip): the frame becomes the current scan WITHOUT being copied - round 6: the copy + time
+// extent launch of lii_scan_set_device was 5 - 8 us per sub-frame in front of a registration that reads the frame in place anyway
+// and, told that it is time-sorted, needs no extent.
+int lii_internal_scan_defer(lii_handle h, const void* dev_float4, int32_t n) {
+  if (!h || (!dev_float4 && n > 0) || n < 0) return fail(h, LII_ERR_INVALID, "lii_frame_select: bad frame");
+  if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_frame_select: frame larger than max_scan_points");
+  extent_discard(h);
+  h->bbox_rows = 0;
+  h->scan_pending = n > 0 ? static_cast<const float4*>(dev_float4) : nullptr;
+  h->scan_pending_n = n > 0 ? n : 0;
+  h->n_scan = n;
+  h->n_body = 0;
+  h->n_body_pending = false;
+  h->have_search = false;
+  return LII_OK;
+}
+
 int lii_internal_li_init_on_device(lii_context* h) { return h && h->cal.li_init_device ? 1 : 0; }
 hipStream_t lii_internal_stream(lii_context* h) { return h->stream; }
 void** lii_internal_ingest_slot(lii_context* h) { return &h->ingest; }
@@ -646,6 +672,7 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
                       const double R_LI[9], const double T_LI[3]) {
   if (!h || !poses || n_poses < 1 || n_poses > 1024 || !end_R || !end_p || !R_LI || !T_LI)
     return fail(h, LII_ERR_INVALID, "lii_undistort_imu: bad arguments");
+  { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }
   static_assert(sizeof(lii_pose6d) == 22 * sizeof(double), "lii_pose6d layout");
   if (h->n_scan <= 0 || n_poses < 2) return LII_OK;  // nothing to compensate (IMUpose needs a head and a tail)
   if (!h->poses_preloaded) {
@@ -676,6 +703,7 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
 }
 int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], const double end_R[9]) {
   if (!h || !omega || !vel || !end_R) return fail(h, LII_ERR_INVALID, "lii_undistort_cv: bad arguments");
+  { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }
   if (h->n_scan <= 0) return LII_OK;
   CvArgH a;
   std::memcpy(a.omega, omega, 24);
@@ -694,6 +722,7 @@ int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], c
 }
 int lii_downsample_skip(lii_handle h, int32_t* n_down) {
   if (!h) return LII_ERR_INVALID;
+  { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }
   if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_VOXEL); if (r != LII_OK) return r; }
   if (h->n_scan > 0)
     HIPCHK(h, hipMemcpyAsync(h->d_body, h->d_scan, sizeof(float4) * size_t(h->n_scan), hipMemcpyDeviceToDevice, h->stream));
@@ -707,6 +736,7 @@ int lii_downsample_skip(lii_handle h, int32_t* n_down) {
 }
 int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered) {
   if (!h || !(leaf > 0)) return fail(h, LII_ERR_INVALID, "lii_downsample: bad arguments");
+  { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }
   h->have_search = false;
   h->n_body_pending = false;
   const int n = h->n_scan;
@@ -811,6 +841,7 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
 }
 int lii_scan_download(lii_handle h, int32_t which, float* out_float4, int32_t capacity, int32_t* n) {
   if (!h || !n) return LII_ERR_INVALID;
+  if (which == 0) { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }
   const float4* src = which == 0 ? h->d_scan : (which == 1 ? h->d_body : h->d_world);
   if (which != 0) { int rc0 = resolve_n_body(h); if (rc0 != LII_OK) return rc0; }
   int cnt = which == 0 ? h->n_scan : h->n_body;

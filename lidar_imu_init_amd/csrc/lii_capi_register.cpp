@@ -475,9 +475,13 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   int rc = LII_OK;
   const auto t_entry = std::chrono::steady_clock::now();
   if (h->diag && h->prof.host_us[4] > 0) h->prof.host_us[5] += std::chrono::duration<double, std::micro>(t_entry - h->prof.host_last_return).count();
-  const bool adopt = job->scan_dev != nullptr && job->n_scan_dev > 0;
-  if (adopt && job->n_scan_dev > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_register: n_scan_dev > max_scan_points");
-  const int n_next = adopt ? job->n_scan_dev : h->n_scan;
+  // the scan to adopt: the caller's device buffer (lii_scan_job::scan_dev), or the frame lii_frame_select left where the ingest put it
+  const bool from_job = job->scan_dev != nullptr && job->n_scan_dev > 0;
+  const void* const src_dev = from_job ? job->scan_dev : static_cast<const void*>(h->scan_pending);
+  const int src_n = from_job ? job->n_scan_dev : h->scan_pending_n;
+  const bool adopt = src_dev != nullptr && src_n > 0;
+  if (adopt && src_n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_register: n_scan_dev > max_scan_points");
+  const int n_next = adopt ? src_n : h->n_scan;
   // A scan in ascending time order: ONE launch takes it from wherever it arrived (the caller's device buffer is read in place)
   // to the de-skewed scan with the voxel filter's table filled, and one extra workgroup of it pulls the update's control block
   // over PCIe; the IMU pose table (<= 64 poses) travels in the kernel arguments.  Round 3 needed k_time_extent in front (copy +
@@ -503,7 +507,7 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     h->vh_inserted = fuse_filter(h, fuse_leaf);
     if (h->vh_inserted) h->vh_inserted_leaf = fuse_leaf;
     DeskewPlan dp = {};
-    dp.in = adopt ? static_cast<const float4*>(job->scan_dev) : h->d_scan;
+    dp.in = adopt ? static_cast<const float4*>(src_dev) : h->d_scan;
     dp.out = h->d_scan; dp.n = n_next; dp.sorted = 1; dp.extent = nullptr; dp.bbox_rows = h->d_bbox_rows;
     dp.leaf = fuse_leaf; dp.vh = h->vh_inserted ? &h->vh : nullptr;
     dp.ctrl_src = h->h_ctrl; dp.ctrl_dst = h->d_ctrl; dp.ctrl_bytes = (sizeof(IekfCtrl) + 15) / 16 * 16;
@@ -548,7 +552,7 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     h->poses_preloaded = h->ctrl_preloaded = true;
   }
   if (adopt) {
-    rc = lii_scan_set_device(h, job->scan_dev, job->n_scan_dev);
+    rc = lii_scan_set_device(h, src_dev, src_n);
     if (rc != LII_OK) { h->ctrl_pending = 0; h->poses_preloaded = h->ctrl_preloaded = false; return rc; }
   }
   if (job->undistort == 1) {

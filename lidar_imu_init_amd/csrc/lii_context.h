@@ -86,6 +86,10 @@ struct lii_context {
 
   // ---- scan
   float4* d_scan = nullptr;   // raw / undistorted (x,y,z,t_ms)
+  // lii_frame_select: the frame stays where the ingest left it until something reads the scan - lii_scan_register takes it from
+  // there like a caller's device buffer (lii_scan_job::scan_dev), every other reader copies it into d_scan first (scan_materialize)
+  const float4* scan_pending = nullptr;
+  int scan_pending_n = 0;
   // lii_scan_upload_next / lii_scan_advance: the next scan travels on a copy stream into a second buffer
   float4* d_scan_next = nullptr;
   float4* h_stage_next = nullptr;   // pinned staging for sources that are not (pinned, stride 16)
@@ -273,6 +277,7 @@ int resolve_n_body(lii_handle h);
 bool fuse_filter(lii_handle h, float leaf);  // does the de-skew of this scan fill the hashed voxel filter's table on the way?
 int pcl_order(lii_handle h, const int** perm);
 void extent_discard(lii_handle h);
+int scan_materialize(lii_handle h);  // a frame selected by lii_frame_select and not read yet -> d_scan (lii_scan_set_device)
 unsigned long long* extent_of_scan(lii_handle h);
 MailboxView mailbox_view(lii_handle h);
 lii::GatherView gather_view(lii_handle h);  // .peers == nullptr: this job has no list exchange (single rank, host-memory mailbox, RCCL)

@@ -400,6 +400,7 @@ int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_
   if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || !frames || !n_frames || n_points < 0 || (!data && n_points > 0) ||
       f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 0 || o->cut_frame_num > kMaxFrames)
     return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: bad arguments");
+  { const int rcm = lii_internal_scan_materialize(h); if (rcm != LII_OK) return rcm; }  // (a selected frame of the last message nobody has read: the frames are about to be overwritten)
   // An L515 message is ONE frame whatever cut_frame says: the reference's callback sends only Velodyne, Ouster, Pandar and RoboSense
   // through process_cut_frame_pcl2 and everything else - L515 - through Preprocess::process (src/laserMapping.cpp:363-377).  ADVICE r5:
   // with `cut_frame: true` in the yaml this call used to fail with "Wrong LiDAR Type" where the reference processes the message.
@@ -447,6 +448,7 @@ int lii_ingest_livox(lii_handle h, const void* points, int32_t n_points, const l
   if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || !frames || !n_frames || n_points < 0 || (!points && n_points > 0) ||
       f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 0 || o->cut_frame_num > kMaxFrames)
     return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_livox: bad arguments");
+  { const int rcm = lii_internal_scan_materialize(h); if (rcm != LII_OK) return rcm; }
   *n_frames = 0;
   IngestCtx* c = ctx_of(h);
   c->have = false;
@@ -473,7 +475,7 @@ int lii_frame_select(lii_handle h, int32_t frame) {
   IngestCtx* c = ctx_of(h);
   if (!c->have || frame < 0 || frame >= c->table.n_frames) return lii_internal_fail(h, LII_ERR_STATE, "lii_frame_select: no such frame");
   const int first = c->table.first[frame], cnt = c->table.last[frame] - first + 1;
-  return lii_scan_set_device(h, c->d_frames + (first - 1), cnt);
+  return lii_internal_scan_defer(h, c->d_frames + (first - 1), cnt);  // (read in place by lii_scan_register, copied by any other reader)
 }
 
 }  // extern "C"

@@ -10,6 +10,8 @@
 struct lii_context;
 // internal hooks of the handle for the translation units that live beside lii_capi.cpp (not exported in the C-ABI header)
 int lii_internal_fail(lii_context* h, int code, const std::string& msg);
+int lii_internal_scan_defer(lii_context* h, const void* dev_float4, int32_t n);  // (lii_capi.cpp) lii_frame_select's hand-over
+int lii_internal_scan_materialize(lii_context* h);  // (lii_capi.cpp) a selected frame nobody has read yet -> the handle's own scan buffer
 hipStream_t lii_internal_stream(lii_context* h);
 void** lii_internal_ingest_slot(lii_context* h);
 
