@@ -262,8 +262,16 @@ def main():
     # node-local choice (the peer-mapped HBM mailbox) and the host mailbox are timed beside it under `transports`.  Ranks
     # rehearsing on ONE device cannot use RCCL (it refuses two ranks on a device): the library's choice there.
     default_transport = os.environ.get("LII_BENCH_TRANSPORT", "auto" if one_device else "rccl")
+    attach_errors = {}
     if world > 1:
-        attach(default_transport)
+        try:
+            attach(default_transport)
+        except Exception as e:  # (the same on every rank: the set-up is collective) - the library's own choice carries the line instead
+            attach_errors[default_transport] = {"error": str(e)[:200]}
+            if default_transport == "auto":
+                raise
+            default_transport = "auto"
+            attach(default_transport)
     reg.map_build(wl["map"])
     reg.map_commit()
     # Every rank receives the WHOLE scan (and holds the whole map) and the library splits the work (lii_comm_set_partition): by voxel
@@ -418,25 +426,27 @@ def main():
         # mailbox are timed beside it - on one device only the mailbox forms can run.  LII_BENCH_TRANSPORT pins `value` to one of them.
         first = default_transport
         others = [t for t in (["mailbox_host"] if one_device else ["rccl", "auto", "mailbox_host"]) if t != first]
-        transports = {}
+        transports = dict(attach_errors)
         dt = None
+        primed = False
         for n_run, t in enumerate([first] + others):
             try:
                 if n_run > 0:
                     attach(t)
-                d = timed_region(args.prime if n_run == 0 else 0)
-            except Exception as e:  # a transport that cannot be set up here is reported, not fatal
+                d = timed_region(0 if primed else args.prime)
+                primed = True
+            except Exception as e:  # a transport that cannot be set up or run here is reported; the next one carries `value`
                 transports[t] = {"error": str(e)[:200]}
-                if n_run == 0:
-                    raise
                 continue
             used = reg.comm_transport()
-            transports[used if n_run == 0 else t] = {"value": args.steps / d, "ms_per_step": 1e3 * d / args.steps, "transport": used,
+            transports[used if dt is None else t] = {"value": args.steps / d, "ms_per_step": 1e3 * d / args.steps, "transport": used,
                                                      "rccl_ranks": reg.comm_rccl_ranks(), "avg_iterations": iters_total[0] / args.steps,
                                                      "describe": reg.comm_describe()}
-            if n_run == 0:
-                dt, value_transport, value_rccl_ranks = d, used, reg.comm_rccl_ranks()
+            if dt is None:  # the first transport that ran carries `value` (RCCL on distinct devices unless it failed: see transports)
+                dt, value_transport, value_rccl_ranks, first = d, used, reg.comm_rccl_ranks(), t
                 last_pose_value = np.array(last.pod[:12]) if last is not None else None
+        if dt is None:
+            raise SystemExit(f"no transport of the 91-scalar exchange ran: {transports}")
         # ... and once more on the first transport with the OTHER split of the cloud
         partitions = {args.partition: {"value": args.steps / dt, "ms_per_step": 1e3 * dt / args.steps, "describe": transports[value_transport].get("describe")}}
         other = "voxel" if args.partition == "index" else "index"

@@ -22,6 +22,11 @@ void lii_stream_set_sorted(int32_t sorted) { g_scan_sorted = sorted ? 1 : 0; }
 static int32_t g_map_in_job = 1;
 void lii_stream_set_map_in_job(int32_t in_job) { g_map_in_job = in_job ? 1 : 0; }
 
+// The scans of these streams are resident in device memory: every job announces its successor (lii_scan_job::next_scan_dev) and the
+// library pre-arms that scan's first launch.  lii_stream_set_announce(0): no announcement, the form of ABI <= 7 (A/B).
+static int32_t g_announce_next = 1;
+void lii_stream_set_announce(int32_t on) { g_announce_next = on ? 1 : 0; }
+
 typedef struct lii_stream_scan {
   const void* scan_dev;      // device-resident float4 (x, y, z, t_ms), caller-owned
   int32_t n_points;
@@ -78,6 +83,11 @@ int lii_stream_run(lii_handle h, const lii_stream_scan* scans, int32_t n_scans, 
     job.n_scan_dev = sc.n_points;
     job.scan_sorted = g_scan_sorted;
     job.map_update = (map_update && g_map_in_job) ? 1 : 0;
+    if (g_announce_next && k + 1 < first + steps) {  // the next scan of the stream is in device memory already: its prologue is pre-armed
+      const lii_stream_scan& nx = scans[(k + 1) % n_scans];
+      job.next_scan_dev = nx.scan_dev;
+      job.next_n_scan = nx.n_points;
+    }
     rc = lii_scan_register(h, &job, &st, sc.state0, &rep);
     if (rc != LII_OK) return rc;
     totals[0] += rep.iterations;

@@ -27,7 +27,7 @@ extern "C" {
                                 lii_comm_describe, lii_comm_set_partition(h, 2) (split by voxel), lii_scan_job::map_update (the reserved field)
                              7: lii_ingest_opts::cut_frame_num = 0 (the whole message as one frame: Preprocess::process), lii_last_solve_info,
                                 lii_selftest_list_exchange
-                             8: lii_last_unfinished_queries */
+                             8: lii_last_unfinished_queries, lii_scan_job::next_scan_dev / next_n_scan (struct_size 72: the pre-armed prologue) */
 
 enum lii_status {
   LII_OK = 0,
@@ -280,6 +280,18 @@ typedef struct lii_scan_job {
                                       this call (src/laserMapping.cpp:1146 behind :1134) - its launches are enqueued behind the update's passes
                                       while the device still works on them, instead of after the result has come back.  The caller does NOT
                                       call lii_map_incremental for this scan.  0 (the value of the formerly reserved field): nothing follows. */
+  /* ABI 8 (struct_size 72; jobs of size 56 and 48 are still accepted): THE NEXT SCAN, if the caller already holds it in device memory.
+   * The library then enqueues the next call's first launch - IMU de-skew + the voxel filter's insert over next_scan_dev - behind this
+   * call's passes, where it waits ON THE DEVICE for what only the next call can know (the propagated state and the IMU pose table:
+   * they depend on this call's result; src/laserMapping.cpp:905-915 - p_imu->Process runs on the state the update left).  The next
+   * lii_scan_register hands them over with a store to mapped memory instead of a launch: the round trip result -> host -> first
+   * kernel of the next scan loses the launch path (~5 us of ~10 per scan on an MI355X).  Only used when the next call asks for the
+   * same thing (scan_dev == next_scan_dev, n_scan_dev == next_n_scan, undistort 1, scan_sorted 1, the same leaf, up to 64 poses);
+   * anything else - another scan, any other entry point of the handle - ends the waiting launch first (it has touched nothing), and
+   * a launch nobody comes for ends itself after 2 s (LII_PREARM_TIMEOUT_MS).  NULL / 0: no announcement (the forms of ABI <= 7). */
+  const void* next_scan_dev;
+  int32_t next_n_scan;
+  int32_t reserved1;
 } lii_scan_job;
 int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, const lii_state* state_propagated,
                       lii_iekf_report* report);

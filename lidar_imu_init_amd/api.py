@@ -47,7 +47,8 @@ class lii_iekf_report(C.Structure):
 class lii_scan_job(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("undistort", C.c_int32), ("imu_poses", C.c_void_p),
                 ("n_imu_poses", C.c_int32), ("leaf", C.c_float), ("opts", lii_iekf_opts), ("scan_dev", C.c_void_p),
-                ("n_scan_dev", C.c_int32), ("scan_sorted", C.c_int32), ("map_update", C.c_int32)]
+                ("n_scan_dev", C.c_int32), ("scan_sorted", C.c_int32), ("map_update", C.c_int32),
+                ("next_scan_dev", C.c_void_p), ("next_n_scan", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class lii_kernel_profile(C.Structure):
@@ -425,7 +426,7 @@ class Registrar:
                     converged=bool(rep.converged), normal_eq=np.array(rep.normal_eq[:]))
 
     def scan_register(self, state: State, state_prop: State, *, imu_poses=None, cv=False, leaf=0.0, max_iterations=4,
-                      imu_en=False, scan_dev=None, scan_sorted=False, map_update=False):
+                      imu_en=False, scan_dev=None, scan_sorted=False, map_update=False, next_scan=None):
         """Undistortion + voxel grid + iterated update in one library call (one host synchronisation).  scan_dev: a
         device_scan() handle to adopt first (what scan_set_device would do, without the separate call).  scan_sorted: the
         points are in ascending time order (lii_scan_job::scan_sorted).  map_update: map_incremental with the final state
@@ -436,6 +437,8 @@ class Registrar:
         job.map_update = 1 if map_update else 0
         if scan_dev is not None:
             job.scan_dev, job.n_scan_dev = scan_dev[0], scan_dev[1]
+        if next_scan is not None:  # a device_scan() handle: the scan the NEXT call will bring (lii_scan_job::next_scan_dev - its prologue is pre-armed)
+            job.next_scan_dev, job.next_n_scan = next_scan[0], next_scan[1]
         poses = None
         if imu_poses is not None:
             poses = np.ascontiguousarray(imu_poses, np.float64).reshape(-1, 22)

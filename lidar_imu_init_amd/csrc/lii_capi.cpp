@@ -150,6 +150,17 @@ void extent_discard(lii_handle h) {
   h->scan_pending = nullptr;  // (whatever replaces the scan replaces a selected frame that nobody has read as well)
   h->scan_pending_n = 0;
 }
+// The state word of the gate record is moved on by exactly one side (compare-and-swap on both): true = this call moved it.
+bool gate_move(lii::GateState* st, unsigned long long seq, unsigned long long to) {
+  unsigned long long expect = (seq << 2) | lii::kGateArmed;
+  return __atomic_compare_exchange_n(&st->word, &expect, (seq << 2) | to, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+}
+void prearm_cancel(lii_handle h) {
+  if (!h || !h->pre.armed) return;
+  h->pre.armed = false;
+  if (gate_move(h->pre.state, h->pre.seq, lii::kGateCancel)) h->pre.n_cancelled++;
+  else h->pre.n_expired++;  // (the launch had given up already)
+}
 int scan_materialize(lii_handle h) {
   if (!h->scan_pending) return LII_OK;
   const float4* src = h->scan_pending;
@@ -194,6 +205,7 @@ MailboxView mailbox_view(lii_handle h) {
 
 int lii_internal_fail(lii_context* h, int code, const std::string& msg) { return fail(h, code, msg); }
 int lii_internal_scan_materialize(lii_context* h) { return scan_materialize(h); }
+void lii_internal_prearm_cancel(lii_context* h) { prearm_cancel(h); }
 // lii_frame_select's hand-over (lii_ingest.hip): the frame becomes the current scan WITHOUT being copied - round 6: the copy + time
 // extent launch of lii_scan_set_device was 5 - 8 us per sub-frame in front of a registration that reads the frame in place anyway
 // and, told that it is time-sorted, needs no extent.
@@ -390,6 +402,19 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_pose, 1));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_ctrl), kCtrlBytes + sizeof(lii_pose6d) * 1024 + 1024, hipHostMallocDefault));
   h->h_poses = reinterpret_cast<lii_pose6d*>(reinterpret_cast<char*>(h->h_ctrl) + kCtrlBytes);
+  CK(hipHostMalloc(reinterpret_cast<void**>(&h->pre.state), 64, hipHostMallocMapped));
+  std::memset(h->pre.state, 0, 64);
+  CK(dmalloc(&h->pre.d_ring, size_t(lii::kGateRing) * lii::kGateLines * 8));
+  CK(hipMemset(h->pre.d_ring, 0, sizeof(double) * size_t(lii::kGateRing) * lii::kGateLines * 8));
+  CK(dmalloc(&h->pre.d_flag, 8));
+  CK(hipMemset(h->pre.d_flag, 0, 64));
+  {  // the host writes the record straight into device memory: only where the whole of it is visible to the host (large BAR)
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, h->device) != hipSuccess) large_bar = 0;
+    h->pre.enabled = large_bar != 0;
+  }
+  if (const char* v = std::getenv("LII_PREARM")) h->pre.enabled = h->pre.enabled && std::atoi(v) != 0;
+  if (const char* v = std::getenv("LII_PREARM_TIMEOUT_MS")) h->pre.timeout_ticks = std::max(1ll, (long long)(std::atof(v) * 1e5));
   CK(hipHostMalloc(reinterpret_cast<void**>(&h->h_res), sizeof(IekfResult), hipHostMallocMapped));
   std::memset(h->h_res, 0, sizeof(IekfResult));
   partition_refresh(h);
@@ -453,6 +478,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
 }
 
 int lii_destroy(lii_handle h) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_OK;
   (void)hipSetDevice(h->device);
   if (h->net.comm) ncclCommDestroy(h->net.comm);
@@ -486,6 +512,7 @@ int lii_destroy(lii_handle h) {
                    "back-to-back scans (%llu gaps of 50 us or more left out)\n", 0.01 * double(g[1]) / double(g[2]), g[2], g[3]);
   }
 #endif
+  if (h->diag) std::fprintf(stderr, "[libliinit_hip] pre-armed prologues: %lld used, %lld cancelled, %lld expired\n", h->pre.n_used, h->pre.n_cancelled, h->pre.n_expired);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] map updates completed by a rebuild + re-insertion: %lld\n", h->map_recoveries);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] updates continued by the host after a parked loop: %lld\n", h->plan_parked);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] map updates repeated with exact list sizes: %lld\n", h->map_repeats);
@@ -520,6 +547,9 @@ int lii_destroy(lii_handle h) {
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
   if (h->h_res) (void)hipHostFree(h->h_res);
+  if (h->pre.state) (void)hipHostFree(h->pre.state);
+  if (h->pre.d_ring) (void)hipFree(h->pre.d_ring);
+  if (h->pre.d_flag) (void)hipFree(h->pre.d_flag);
   if (h->ev_poses) (void)hipEventDestroy(h->ev_poses);
   if (h->ev_stage) (void)hipEventDestroy(h->ev_stage);
   if (h->ev_mapflag) (void)hipEventDestroy(h->ev_mapflag);
@@ -539,6 +569,7 @@ int lii_destroy(lii_handle h) {
 }
 
 int lii_synchronize(lii_handle h) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_ERR_INVALID;
   {
     const int rc = map_join(h);
@@ -568,6 +599,7 @@ int lii_synchronize(lii_handle h) {
 
 // ------------------------------------------------------------------------------------------------ scan
 int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_bytes, int32_t time_offset_bytes) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || (!points && n > 0) || n < 0 || stride_bytes < 16 || time_offset_bytes < 12 || time_offset_bytes + 4 > stride_bytes)
     return fail(h, LII_ERR_INVALID, "lii_scan_upload: bad arguments");
   if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_upload: n > max_scan_points");
@@ -594,6 +626,7 @@ int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_
   return LII_OK;
 }
 int lii_scan_upload_next(lii_handle h, const void* points, int32_t n, int32_t stride_bytes, int32_t time_offset_bytes) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || (!points && n > 0) || n < 0 || stride_bytes < 16 || time_offset_bytes < 12 || time_offset_bytes + 4 > stride_bytes)
     return fail(h, LII_ERR_INVALID, "lii_scan_upload_next: bad arguments");
   if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_upload_next: n > max_scan_points");
@@ -638,6 +671,7 @@ int lii_scan_upload_next(lii_handle h, const void* points, int32_t n, int32_t st
   return LII_OK;
 }
 int lii_scan_advance(lii_handle h) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_ERR_INVALID;
   if (h->n_scan_next < 0) return fail(h, LII_ERR_STATE, "lii_scan_advance: no scan under way (call lii_scan_upload_next)");
   HIPCHK(h, hipEventSynchronize(h->ev_next));  // long done when the transfer overlapped a registration; frees the caller's buffer
@@ -652,6 +686,7 @@ int lii_scan_advance(lii_handle h) {
   return LII_OK;
 }
 int lii_scan_set_device(lii_handle h, const void* dev_float4, int32_t n) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || (!dev_float4 && n > 0) || n < 0) return fail(h, LII_ERR_INVALID, "lii_scan_set_device: bad arguments");
   if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_set_device: n > max_scan_points");
   extent_discard(h);
@@ -670,6 +705,7 @@ int lii_scan_set_device(lii_handle h, const void* dev_float4, int32_t n) {
 }
 int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, const double end_R[9], const double end_p[3],
                       const double R_LI[9], const double T_LI[3]) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !poses || n_poses < 1 || n_poses > 1024 || !end_R || !end_p || !R_LI || !T_LI)
     return fail(h, LII_ERR_INVALID, "lii_undistort_imu: bad arguments");
   { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }
@@ -702,6 +738,7 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
   return LII_OK;
 }
 int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], const double end_R[9]) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !omega || !vel || !end_R) return fail(h, LII_ERR_INVALID, "lii_undistort_cv: bad arguments");
   { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }
   if (h->n_scan <= 0) return LII_OK;
@@ -721,6 +758,7 @@ int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], c
   return LII_OK;
 }
 int lii_downsample_skip(lii_handle h, int32_t* n_down) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_ERR_INVALID;
   { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }
   if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_VOXEL); if (r != LII_OK) return r; }
@@ -735,6 +773,7 @@ int lii_downsample_skip(lii_handle h, int32_t* n_down) {
   return LII_OK;
 }
 int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !(leaf > 0)) return fail(h, LII_ERR_INVALID, "lii_downsample: bad arguments");
   { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }
   h->have_search = false;
@@ -840,6 +879,7 @@ int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered)
   return LII_OK;
 }
 int lii_scan_download(lii_handle h, int32_t which, float* out_float4, int32_t capacity, int32_t* n) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !n) return LII_ERR_INVALID;
   if (which == 0) { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }
   const float4* src = which == 0 ? h->d_scan : (which == 1 ? h->d_body : h->d_world);
@@ -862,17 +902,20 @@ int lii_scan_download(lii_handle h, int32_t which, float* out_float4, int32_t ca
 
 // ------------------------------------------------------------------------------------------------ utilities
 int lii_dev_alloc(lii_handle h, size_t bytes, void** dev_ptr) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !dev_ptr) return LII_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMalloc(dev_ptr, bytes));
   return LII_OK;
 }
 int lii_dev_free(lii_handle h, void* dev_ptr) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_ERR_INVALID;
   HIPCHK(h, hipFree(dev_ptr));
   return LII_OK;
 }
 int lii_dev_upload(lii_handle h, void* dev_dst, const void* host_src, size_t bytes) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !dev_dst || !host_src) return LII_ERR_INVALID;
   HIPCHK(h, hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
   return LII_OK;

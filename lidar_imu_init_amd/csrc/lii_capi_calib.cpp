@@ -8,6 +8,7 @@ extern "C" {
 
 // ------------------------------------------------------------------------------------------------ calibration
 int lii_calib_set_buffers(lii_handle h, const lii_calib_state* imu, const lii_calib_state* lidar, int32_t n) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !imu || !lidar || n <= 0) return fail(h, LII_ERR_INVALID, "lii_calib_set_buffers: bad arguments");
   static_assert(sizeof(lii_calib_state) == 22 * sizeof(double), "lii_calib_state layout");
   if (n > h->cal.n_cal || !h->cal.d_cal_imu) {
@@ -25,6 +26,7 @@ int lii_calib_set_buffers(lii_handle h, const lii_calib_state* imu, const lii_ca
 }
 
 int lii_calib_eval(lii_handle h, int32_t stage, const double* params, double* JtJ, double* Jtr, double* cost) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !params || stage < 1 || stage > 3) return fail(h, LII_ERR_INVALID, "lii_calib_eval: bad arguments");
   if (h->cal.n_cal <= 0) return fail(h, LII_ERR_STATE, "lii_calib_eval: no buffers uploaded");
   const int np = stage == 1 ? 9 : (stage == 2 ? 13 : 24);

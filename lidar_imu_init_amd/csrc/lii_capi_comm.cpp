@@ -181,6 +181,7 @@ int comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[1
 }  // namespace
 extern "C" {
 int lii_comm_init_ex(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128], int32_t transport) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !id_in || n_ranks < 1 || rank < 0 || rank >= n_ranks || transport < LII_COMM_AUTO || transport > LII_COMM_MAILBOX_HOST)
     return fail(h, LII_ERR_INVALID, "lii_comm_init: bad arguments");
   const int rc = comm_init(h, n_ranks, rank, id_in, transport);
@@ -200,6 +201,7 @@ int lii_comm_describe(lii_handle h, char* out, int32_t capacity) {
   return LII_OK;
 }
 int lii_comm_set_partition(lii_handle h, int32_t library_partition) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || library_partition < 0 || library_partition > 2) return fail(h, LII_ERR_INVALID, "lii_comm_set_partition: 0 (caller), 1 (by index) or 2 (by voxel)");
   h->net.library_partition = library_partition != 0;
   h->net.voxel_partition = library_partition == 2;
@@ -207,6 +209,7 @@ int lii_comm_set_partition(lii_handle h, int32_t library_partition) {
   return LII_OK;
 }
 int lii_comm_init(lii_handle h, int32_t n_ranks, int32_t rank, const uint8_t id_in[128]) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   return lii_comm_init_ex(h, n_ranks, rank, id_in, LII_COMM_AUTO);
 }
 int lii_comm_transport(lii_handle h, int32_t* transport) {
@@ -226,6 +229,7 @@ int lii_comm_rccl_ranks(lii_handle h, int32_t* n_ranks) {
   return LII_OK;
 }
 int lii_comm_destroy(lii_handle h) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_ERR_INVALID;
   (void)hipSetDevice(h->device);
   comm_drop(h);
@@ -238,6 +242,7 @@ int lii_comm_destroy(lii_handle h) {
 // device copies standing in for the two ncclAllGather calls.  Every rank must end with the identical pair of lists; rank 0's is returned.
 int lii_selftest_list_exchange(lii_handle h, int32_t n_ranks, int32_t form, const float* add_xyzw, const int32_t* n_add, const float* nodown_xyzw,
                                const int32_t* n_nodown, float* out_add, int32_t* out_n_add, float* out_nodown, int32_t* out_n_nodown, int32_t capacity) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || n_ranks < 1 || n_ranks > kMailboxMaxRanks || (form != 0 && form != 1) || !n_add || !n_nodown || !out_add || !out_n_add || !out_nodown || !out_n_nodown)
     return fail(h, LII_ERR_INVALID, "lii_selftest_list_exchange: bad arguments");
   if (h->net.n_ranks > 1 || h->net.comm) return fail(h, LII_ERR_STATE, "lii_selftest_list_exchange: the handle is a rank of a job");

@@ -388,6 +388,7 @@ extern "C" {
 
 // ------------------------------------------------------------------------------------------------ map
 int lii_map_reset(lii_handle h) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_ERR_INVALID;
   {
     const int rcj = map_join(h);
@@ -413,6 +414,7 @@ int upload_xyz(lii_handle h, const void* xyz, int n, int stride_bytes, float4* d
 }
 }  // namespace
 int lii_map_build(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || (!xyz && n > 0) || n < 0 || stride_bytes < 12 || stride_bytes % 4) return fail(h, LII_ERR_INVALID, "lii_map_build: bad arguments");
   if (n > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "lii_map_build: n > max_map_points");
   {
@@ -428,6 +430,7 @@ int lii_map_build(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes
   return LII_OK;
 }
 int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_bytes, int32_t downsample_on, int32_t* n_added) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || (!xyz && n > 0) || n < 0 || stride_bytes < 12 || stride_bytes % 4) return fail(h, LII_ERR_INVALID, "lii_map_add_points: bad arguments");
   if (n > h->cfg.max_map_points) return fail(h, LII_ERR_CAPACITY, "lii_map_add_points: batch larger than max_map_points");
   if (n_added) *n_added = 0;
@@ -449,6 +452,7 @@ int lii_map_add_points(lii_handle h, const void* xyz, int32_t n, int32_t stride_
   return LII_OK;
 }
 int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int32_t* n_deleted) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || (!boxes && n_boxes > 0) || n_boxes < 0 || n_boxes > 4096) return fail(h, LII_ERR_INVALID, "lii_map_delete_boxes: bad arguments (<= 4096 boxes)");
   if (n_deleted) *n_deleted = 0;
   int rc = map_counters(h);
@@ -482,12 +486,14 @@ int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int3
   return LII_OK;
 }
 int lii_map_size(lii_handle h, int32_t* n_valid) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !n_valid) return LII_ERR_INVALID;
   int rc = map_counters(h);  // (a pending in-place update: one small synchronising read)
   *n_valid = h->n_map;
   return rc;
 }
 int lii_map_download(lii_handle h, float* xyz_out, int32_t capacity, int32_t* n) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !n) return LII_ERR_INVALID;
   int rc = map_counters(h);
   if (rc != LII_OK) return rc;
@@ -509,6 +515,7 @@ int lii_map_download(lii_handle h, float* xyz_out, int32_t capacity, int32_t* n)
   return LII_OK;
 }
 int lii_map_commit(lii_handle h) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_ERR_INVALID;
   {
     const int rcj = map_join(h);
@@ -520,6 +527,7 @@ int lii_map_commit(lii_handle h) {
 
 
 int lii_map_incremental(lii_handle h, const lii_state* state, int32_t* n_add, int32_t* n_no_downsample) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !state) return fail(h, LII_ERR_INVALID, "lii_map_incremental: bad arguments");
   if (n_add) *n_add = 0;
   if (n_no_downsample) *n_no_downsample = 0;

@@ -247,6 +247,29 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     g = grid_view(h);
     if (h->diag) h->prof.host_map_us[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_me0).count();
   }
+  // THE NEXT SCAN'S PROLOGUE, pre-armed (lii_launch.h: DeskewGate): the job announced the scan the next call will bring - its de-skew +
+  // filter-insert launch goes out now, behind this update's passes (and its map update), and waits on the device for the record
+  // the next lii_scan_register writes.
+  if (h->pre.want_dev && !h->net.comm && h->net.n_ranks <= 1 && !h->prof.profiling && !graph_mode && !h->map_async) {
+    lii::GateState* gst = h->pre.state;
+    h->pre.seq = (h->pre.seq + 1) & 0x3FFFFFFFFFFFFFFFull;
+    __atomic_store_n(&gst->word, (h->pre.seq << 2) | lii::kGateArmed, __ATOMIC_RELEASE);
+    h->pre.scan_dev = h->pre.want_dev; h->pre.n = h->pre.want_n; h->pre.leaf = h->pre.want_leaf;
+    h->pre.fuse = fuse_filter(h, h->pre.leaf);
+    DeskewPlan dp = {};
+    dp.in = static_cast<const float4*>(h->pre.scan_dev);
+    dp.out = h->d_scan; dp.n = h->pre.n; dp.sorted = 1; dp.extent = nullptr; dp.bbox_rows = h->d_bbox_rows;
+    dp.leaf = h->pre.leaf; dp.vh = h->pre.fuse ? &h->vh : nullptr;
+    dp.ctrl_src = h->h_ctrl; dp.ctrl_dst = h->d_ctrl; dp.ctrl_bytes = (sizeof(IekfCtrl) + 15) / 16 * 16;
+#ifdef LII_GAP_TRACE
+    dp.gap = h->d_gran;
+#endif
+    lii::DeskewGate gate = {gst, h->pre.d_ring + size_t(h->pre.seq % lii::kGateRing) * lii::kGateLines * 8, h->pre.d_flag, h->pre.seq, h->pre.timeout_ticks};
+    launch_deskew_imu_gated(dp, gate, s);
+    h->pre.armed = hipGetLastError() == hipSuccess;
+    if (!h->pre.armed) __atomic_store_n(&gst->word, (h->pre.seq << 2) | lii::kGateCancel, __ATOMIC_RELEASE);
+  }
+  h->pre.want_dev = nullptr;
   rc = wait_result(true);
   if (rc != LII_OK) return rc;
   // A parked loop is continued with what it is known to need: the pass it parked in front of - behind a k-NN launch if that pass
@@ -258,6 +281,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     const int from = h->h_res->parked_it;
     const bool search = h->h_res->parked_search != 0;
     h->plan_parked++;
+    prearm_cancel(h);  // (the launches that continue the loop would queue up behind a launch that waits for this call to return)
     h->map_enqueued_early = false;  // (that launch saw a parked loop and did nothing: the caller makes the map update when the loop has ended)
     g = grid_view(h);  // (see above: never a view older than the last thing that may have rebuilt the index)
     const int last = std::min(opts->max_iterations, std::max(h->plan_passes_prev, from + 1));  // (exclusive; from < max_iterations: the last pass never parks)
@@ -371,6 +395,7 @@ int lii_last_solve_info(lii_handle h, int32_t* pivoted_passes) {
 }
 
 int lii_last_unfinished_queries(lii_handle h, int32_t* n_last) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !n_last) return LII_ERR_INVALID;
   int c[2] = {0, 0};
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -380,12 +405,14 @@ int lii_last_unfinished_queries(lii_handle h, int32_t* n_last) {
 }
 
 int lii_iekf_iterate(lii_handle h, const lii_state* state, int32_t search, int32_t imu_en, double out91[91]) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !state || !out91) return fail(h, LII_ERR_INVALID, "lii_iekf_iterate: bad arguments");
   return iterate(h, state, search != 0, imu_en != 0, out91);
 }
 
 int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_prop, const lii_iekf_opts* opts,
                     lii_iekf_report* report) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !state || !state_prop || !opts || opts->max_iterations < 1) return fail(h, LII_ERR_INVALID, "lii_iekf_update: bad arguments");
   const int max_it = opts->max_iterations;
   auto t_begin = std::chrono::steady_clock::now();
@@ -469,9 +496,10 @@ int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_prop,
 int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, const lii_state* state_prop,
                       lii_iekf_report* report) {
   // (struct_size 48: a job of ABI 5, without scan_sorted)
-  if (!h || !job || (job->struct_size != sizeof(lii_scan_job) && job->struct_size != 48u) || !state || !state_prop || job->opts.max_iterations < 1)
+  // (struct_size 72: ABI 8; 56: ABI 6 - 7, without next_scan_dev; 48: ABI 5, without scan_sorted)
+  if (!h || !job || (job->struct_size != sizeof(lii_scan_job) && job->struct_size != 56u && job->struct_size != 48u) || !state || !state_prop || job->opts.max_iterations < 1)
     return fail(h, LII_ERR_INVALID, "lii_scan_register: bad arguments");
-  const bool sorted = job->struct_size >= sizeof(lii_scan_job) && job->scan_sorted == 1;
+  const bool sorted = job->struct_size >= 56u && job->scan_sorted == 1;
   int rc = LII_OK;
   const auto t_entry = std::chrono::steady_clock::now();
   if (h->diag && h->prof.host_us[4] > 0) h->prof.host_us[5] += std::chrono::duration<double, std::micro>(t_entry - h->prof.host_last_return).count();
@@ -482,6 +510,19 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   const bool adopt = src_dev != nullptr && src_n > 0;
   if (adopt && src_n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_register: n_scan_dev > max_scan_points");
   const int n_next = adopt ? src_n : h->n_scan;
+  // A gated de-skew launch waits on the stream (the previous call enqueued it for the scan its job announced): it is used when THIS
+  // call asks for exactly that, and told to end otherwise - before anything here could wait for the stream.
+  const float leaf_now = job->leaf > 0 ? job->leaf : 0.f;
+  bool use_pre = h->pre.armed && from_job && sorted && job->undistort == 1 && job->imu_poses && job->n_imu_poses >= 2 && job->n_imu_poses <= lii::kGateMaxPoses &&
+                 src_dev == h->pre.scan_dev && src_n == h->pre.n && leaf_now == h->pre.leaf && !h->host_solve && !h->no_fast_prologue &&
+                 h->prof.prof_mode != 3 && !h->staging_busy && fuse_filter(h, leaf_now) == h->pre.fuse;
+  if (!use_pre) prearm_cancel(h);
+  // ... and what this job announces for the next call (update_on_device arms it behind the passes)
+  h->pre.want_dev = nullptr;
+  if (job->struct_size >= sizeof(lii_scan_job) && job->next_scan_dev && job->next_n_scan > 0 && job->next_n_scan <= h->cfg.max_scan_points && h->pre.enabled &&
+      sorted && job->undistort == 1) {
+    h->pre.want_dev = job->next_scan_dev; h->pre.want_n = job->next_n_scan; h->pre.want_leaf = leaf_now;
+  }
   // A scan in ascending time order: ONE launch takes it from wherever it arrived (the caller's device buffer is read in place)
   // to the de-skewed scan with the voxel filter's table filled, and one extra workgroup of it pulls the update's control block
   // over PCIe; the IMU pose table (<= 64 poses) travels in the kernel arguments.  Round 3 needed k_time_extent in front (copy +
@@ -506,6 +547,38 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
     const float fuse_leaf = job->leaf > 0 ? job->leaf : 0.f;
     h->vh_inserted = fuse_filter(h, fuse_leaf);
     if (h->vh_inserted) h->vh_inserted_leaf = fuse_leaf;
+    if (use_pre) {
+      // GO - unless the launch gave up in this very moment (then the scan is launched below like any other) - and the record: straight
+      // into device memory (large BAR), payload, then the tags, line 0's last, a store fence between the three
+      h->pre.armed = false;
+      if (gate_move(h->pre.state, h->pre.seq, lii::kGateGo)) {
+        h->pre.n_used++;
+        const int K = job->n_imu_poses;
+        const int n_pay = 25 + 22 * K, n_lines = (n_pay + 6) / 7;
+        double pay[7 * lii::kGateLines];
+        pay[0] = double(K);
+        std::memcpy(pay + 1, state->rot_end, 72);
+        std::memcpy(pay + 10, state->pos_end, 24);
+        std::memcpy(pay + 13, state->offset_R_L_I, 72);
+        std::memcpy(pay + 22, state->offset_T_L_I, 24);
+        std::memcpy(pay + 25, job->imu_poses, sizeof(lii_pose6d) * size_t(K));
+        for (int e = n_pay; e < 7 * n_lines; e++) pay[e] = 0.0;
+        volatile double* rec = h->pre.d_ring + size_t(h->pre.seq % lii::kGateRing) * lii::kGateLines * 8;
+        double tag;
+        const unsigned long long tagw = (h->pre.seq << 2) | lii::kGateGo;
+        std::memcpy(&tag, &tagw, 8);
+        for (int l = 0; l < n_lines; l++)
+          for (int c = 0; c < 7; c++) rec[8 * l + c] = pay[7 * l + c];
+        __builtin_ia32_sfence();
+        for (int l = 1; l < n_lines; l++) rec[8 * l + 7] = tag;
+        __builtin_ia32_sfence();
+        rec[7] = tag;
+        __builtin_ia32_sfence();
+      } else {
+        use_pre = false;
+        h->pre.n_expired++;
+      }
+    }
     DeskewPlan dp = {};
     dp.in = adopt ? static_cast<const float4*>(src_dev) : h->d_scan;
     dp.out = h->d_scan; dp.n = n_next; dp.sorted = 1; dp.extent = nullptr; dp.bbox_rows = h->d_bbox_rows;
@@ -514,7 +587,9 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
 #ifdef LII_GAP_TRACE
     dp.gap = h->d_gran;
 #endif
-    if (job->undistort == 1) {
+    if (use_pre) {
+      // (the launch is on the stream already and has its go)
+    } else if (job->undistort == 1) {
       UndistArgH u;
       std::memcpy(u.endR, state->rot_end, 72);
       std::memcpy(u.endp, state->pos_end, 24);
@@ -574,7 +649,7 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   }
   if (rc == LII_OK) rc = job->leaf > 0 ? lii_downsample(h, job->leaf, nullptr, nullptr) : lii_downsample_skip(h, nullptr);
   const auto t_pre = std::chrono::steady_clock::now();
-  const bool map_update = job->struct_size >= sizeof(lii_scan_job) && job->map_update == 1;
+  const bool map_update = job->struct_size >= 56u && job->map_update == 1;
   h->map_after_update = map_update && !h->host_solve;
   h->map_enqueued_early = false;
   if (rc == LII_OK) rc = lii_iekf_update(h, state, state_prop, &job->opts, report);
@@ -597,6 +672,7 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
 }
 
 int lii_neighbors_download(lii_handle h, float* pts, int32_t* counts, uint8_t* selected, int32_t capacity) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_ERR_INVALID;
   { int rc0 = resolve_n_body(h); if (rc0 != LII_OK) return rc0; }
   const int n = h->n_body;

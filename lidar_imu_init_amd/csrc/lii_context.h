@@ -194,6 +194,25 @@ struct lii_context {
   bool map_flag_pending = false;
   bool diag = false;     // LII_DIAG=1: counters of the rare paths on stderr when the handle is destroyed
 
+  // ---- the pre-armed prologue (lii_launch.h: DeskewGate; lii_scan_job::next_scan_dev)
+  struct Prearm {
+    lii::GateState* state = nullptr;         // pinned, device-mapped: the state word
+    double* d_ring = nullptr;                // device memory the HOST writes (large BAR): kGateRing records of kGateLines x 8 doubles
+    unsigned long long* d_flag = nullptr;
+    unsigned long long seq = 0;
+    bool enabled = true;                     // LII_PREARM=0: a job's next_scan_dev is ignored
+    bool armed = false;                      // a gated de-skew launch sits on the stream, waiting for its record
+    const void* scan_dev = nullptr;          // ... enqueued for this scan,
+    int n = 0;
+    float leaf = 0.f;                        // ... this leaf,
+    bool fuse = false;                       // ... with the hashed filter's insert riding along or not
+    const void* want_dev = nullptr;          // lii_scan_register -> update_on_device: the job in progress names this next scan
+    int want_n = 0;
+    float want_leaf = 0.f;
+    long long timeout_ticks = 200000000ll;   // 2 s of the 100 MHz clock (LII_PREARM_TIMEOUT_MS)
+    long long n_used = 0, n_cancelled = 0, n_expired = 0;  // LII_DIAG
+  } pre;
+
   // ---- pinned staging
   float4* h_stage = nullptr;     // max(max_scan, max_map) float4
   size_t h_stage_elems = 0;
@@ -277,7 +296,9 @@ int resolve_n_body(lii_handle h);
 bool fuse_filter(lii_handle h, float leaf);  // does the de-skew of this scan fill the hashed voxel filter's table on the way?
 int pcl_order(lii_handle h, const int** perm);
 void extent_discard(lii_handle h);
-int scan_materialize(lii_handle h);  // a frame selected by lii_frame_select and not read yet -> d_scan (lii_scan_set_device)
+int scan_materialize(lii_handle h);
+bool gate_move(lii::GateState* st, unsigned long long seq, unsigned long long to);  // the state word: armed -> `to`, if still armed
+void prearm_cancel(lii_handle h);  // a gated de-skew launch that waits on the stream is told to end (every entry point that uses the stream calls this first)  // a frame selected by lii_frame_select and not read yet -> d_scan (lii_scan_set_device)
 unsigned long long* extent_of_scan(lii_handle h);
 MailboxView mailbox_view(lii_handle h);
 lii::GatherView gather_view(lii_handle h);  // .peers == nullptr: this job has no list exchange (single rank, host-memory mailbox, RCCL)

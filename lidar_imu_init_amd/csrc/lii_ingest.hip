@@ -397,6 +397,7 @@ extern "C" {
 
 int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_pc2_fields* f, const lii_ingest_opts* o,
                     lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || !frames || !n_frames || n_points < 0 || (!data && n_points > 0) ||
       f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 0 || o->cut_frame_num > kMaxFrames)
     return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: bad arguments");
@@ -445,6 +446,7 @@ int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_
 
 int lii_ingest_livox(lii_handle h, const void* points, int32_t n_points, const lii_livox_fields* f, const lii_ingest_opts* o,
                      lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || !frames || !n_frames || n_points < 0 || (!points && n_points > 0) ||
       f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 0 || o->cut_frame_num > kMaxFrames)
     return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_livox: bad arguments");
@@ -471,6 +473,7 @@ int lii_ingest_livox(lii_handle h, const void* points, int32_t n_points, const l
 }
 
 int lii_frame_select(lii_handle h, int32_t frame) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_ERR_INVALID;
   IngestCtx* c = ctx_of(h);
   if (!c->have || frame < 0 || frame >= c->table.n_frames) return lii_internal_fail(h, LII_ERR_STATE, "lii_frame_select: no such frame");

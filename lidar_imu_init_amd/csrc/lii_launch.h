@@ -11,7 +11,8 @@ struct lii_context;
 // internal hooks of the handle for the translation units that live beside lii_capi.cpp (not exported in the C-ABI header)
 int lii_internal_fail(lii_context* h, int code, const std::string& msg);
 int lii_internal_scan_defer(lii_context* h, const void* dev_float4, int32_t n);  // (lii_capi.cpp) lii_frame_select's hand-over
-int lii_internal_scan_materialize(lii_context* h);  // (lii_capi.cpp) a selected frame nobody has read yet -> the handle's own scan buffer
+int lii_internal_scan_materialize(lii_context* h);
+void lii_internal_prearm_cancel(lii_context* h);  // (lii_capi.cpp) see lii_impl::prearm_cancel  // (lii_capi.cpp) a selected frame nobody has read yet -> the handle's own scan buffer
 hipStream_t lii_internal_stream(lii_context* h);
 void** lii_internal_ingest_slot(lii_context* h);
 
@@ -127,6 +128,34 @@ struct DeskewPlan {
 #endif
 };
 void launch_deskew_imu(const DeskewPlan& p, const double* poses_host, const double* poses_dev, int K, const UndistArgH& u, hipStream_t s);
+// THE PRE-ARMED PROLOGUE (round 6).  The de-skew launch of the NEXT scan is enqueued while the current scan's passes still run, and waits
+// on the device for a record the host writes once it knows what that launch needs - the propagated state and the IMU pose table, which
+// depend on the current scan's result.  What the host then pays between two scans is a few stores, not a launch: the dependent chain
+// result -> host -> first kernel of the next scan loses the runtime's launch path and the command processor's fetch + dispatch
+// (profiles/r06_chain.md).
+// The record: {K, UndistArgH, K x 22 doubles} in DEVICE memory, which the host writes directly (large BAR: posted writes, no round
+// trip; a first form kept it in mapped host memory and had one workgroup fetch and re-publish it - three PCIe round trips and two
+// cache-wide fences on the critical path, 10 us slower than the launch it replaced).  It is laid out in 64-byte lines of seven
+// payload doubles and a TAG (seq << 2 | kGateGo); the host writes the payload, then the tags, line 0's tag last, a store fence between
+// the three - so a workgroup that sees line 0's tag finds every line complete, and a line it finds with another tag is a stale cached
+// copy (the record lives in a ring of kGateRing slots), fetched again past the caches.
+// The state word (GateState::word, mapped HOST memory) is seq << 2 | state; the host arms it before it enqueues the launch, and exactly
+// one side moves it on, by compare-and-swap: the host to GO (then it writes the record) or CANCEL (this scan is not the one that was
+// announced, or another entry point needs the stream), the launch itself to EXPIRED when nobody came for `timeout_ticks` (100 MHz) -
+// it then ends having touched nothing, so a forgotten launch can delay the stream by that long, never hang it.
+constexpr unsigned long long kGateArmed = 0ull, kGateGo = 1ull, kGateCancel = 2ull, kGateExpired = 3ull;
+constexpr int kGateMaxPoses = 29;                                   // pose tables the pre-armed form takes (longer ones: the plain launch)
+constexpr int kGateLines = (25 + 22 * kGateMaxPoses + 6) / 7;       // 64-byte lines of a record (95)
+constexpr int kGateRing = 64;                                       // record slots (seq % kGateRing)
+struct GateState { unsigned long long word; };                      // pinned, device-mapped host memory: seq << 2 | kGate*
+struct DeskewGate {
+  GateState* host;                  // the state word (polled by the gate workgroup alone; one compare-and-swap over PCIe if it gives up)
+  const double* rec;                // this launch's record slot in device memory (kGateLines x 8 doubles)
+  unsigned long long* dev_flag;     // seq << 2 | kGateCancel when the launch is to end without running (published by the gate workgroup)
+  unsigned long long seq;
+  long long timeout_ticks;
+};
+void launch_deskew_imu_gated(const DeskewPlan& p, const DeskewGate& gate, hipStream_t s);
 void launch_deskew_cv(const DeskewPlan& p, const CvArgH& a, hipStream_t s);
 // calibration
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,

@@ -130,6 +130,7 @@ using namespace lii;
 extern "C" {
 
 int lii_zero_phase_filter(lii_handle h, const lii_calib_state* in, int32_t n_seq, int32_t n, lii_calib_state* out) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !in || !out || n_seq < 1 || n < 62) return lii_internal_fail(h, LII_ERR_INVALID, "lii_zero_phase_filter: bad arguments (n >= 62: the 60-sample reflection)");
   hipStream_t s = lii_internal_stream(h);
   const size_t rec = size_t(n_seq) * size_t(n) * 22;
@@ -148,6 +149,7 @@ int lii_zero_phase_filter(lii_handle h, const lii_calib_state* in, int32_t n_seq
 }
 
 int lii_xcorr_lag(lii_handle h, const lii_calib_state* imu, const lii_calib_state* lidar, int32_t n, int32_t* lag_imu_wrt_lidar) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !imu || !lidar || !lag_imu_wrt_lidar || n < 1) return lii_internal_fail(h, LII_ERR_INVALID, "lii_xcorr_lag: bad arguments");
   hipStream_t s = lii_internal_stream(h);
   const size_t rec = size_t(n) * 22;

@@ -176,16 +176,17 @@ __device__ __forceinline__ void bbox_point(float x, float y, float z, unsigned i
 // The de-skew kernels leave the bounding box of their output behind for the voxel filter that follows (a pass of its own
 // over the scan costs a launch): one row of 8 uints per workgroup (min xyz, -, max xyz, -), reduced by k_voxel_keys.
 // (Folding the rows with atomics instead costs the kernel ~5 us: 400 workgroups x 6 atomics on one cache line.)
-__device__ __forceinline__ void deskew_bbox(float4 q, bool in_range, unsigned int* __restrict__ rows) {
+__device__ __forceinline__ void deskew_bbox(float4 q, bool in_range, unsigned int* __restrict__ rows, int row) {
   if (!rows) return;  // uniform
   unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0, 0, 0};
   if (in_range) bbox_point(q.x, q.y, q.z, lo, hi);
   block_bbox_reduce(lo, hi);
   if (threadIdx.x < 3) {
-    rows[blockIdx.x * 8 + threadIdx.x] = lo[0];
-    rows[blockIdx.x * 8 + 4 + threadIdx.x] = hi[0];
+    rows[row * 8 + threadIdx.x] = lo[0];
+    rows[row * 8 + 4 + threadIdx.x] = hi[0];
   }
 }
+__device__ __forceinline__ void deskew_bbox(float4 q, bool in_range, unsigned int* __restrict__ rows) { deskew_bbox(q, in_range, rows, (int)blockIdx.x); }
 
 // The table of the hashed voxel filter (its kernels further down): open addressing, ONE 64-byte line per slot - the insert's
 // CAS, atomicMin, atomicAdd and member store and the emit's reads all touch that one line (round 3 kept five parallel arrays:
@@ -349,6 +350,9 @@ struct PoseTab { double v[KP > 0 ? KP * 22 : 1]; };
 // head after being compensated, so it is compensated once per qualifying head, in descending order.
 // FUSE: the de-skewed point goes straight into the table of the hashed voxel filter (vhash_insert_abs) - the filter's own
 // insert launch is saved (lii_scan_register, hashed filter).
+template <bool FUSE>
+__device__ __forceinline__ void deskew_imu_point(const DeskewIo& io, const UndistArg& u, int K, const double* __restrict__ poses, int row, int i, bool in_range,
+                                                 float4 P);
 template <bool FUSE, int KP>
 __global__ __launch_bounds__(256) void k_deskew_imu(DeskewIo io, UndistArg u, int K, const double* __restrict__ poses_g, PoseTab<KP> tab) {
   const int n_scan_blocks = gridDim.x - (io.ctrl_vec > 0 ? 1 : 0);
@@ -358,6 +362,11 @@ __global__ __launch_bounds__(256) void k_deskew_imu(DeskewIo io, UndistArg u, in
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = i < io.n;
   float4 P = in_range ? io.in[i] : make_float4(0, 0, 0, 0);
+  deskew_imu_point<FUSE>(io, u, K, poses, (int)blockIdx.x, i, in_range, P);
+}
+template <bool FUSE>
+__device__ __forceinline__ void deskew_imu_point(const DeskewIo& io, const UndistArg& u, int K, const double* __restrict__ poses, int row, int i, bool in_range,
+                                                 float4 P) {
   // the head search walks the table's time column backwards: staged in LDS once per workgroup (tables of up to 256 poses;
   // longer ones are walked in global memory), a walk of up to K dependent global loads per point otherwise
   __shared__ double s_time[256];
@@ -395,8 +404,86 @@ __global__ __launch_bounds__(256) void k_deskew_imu(DeskewIo io, UndistArg u, in
     }
     if (moved || io.in != io.out) io.out[i] = P;
   }
-  deskew_bbox(P, in_range, io.bbox_rows);
+  deskew_bbox(P, in_range, io.bbox_rows, row);
   if (FUSE && in_range) vhash_insert_abs(P, i, io.leaf, io.tb);
+}
+
+// The pre-armed form (lii_launch.h: DeskewGate).  Every workgroup requests its point, then one lane polls the tag of the record's first
+// line past the caches (the host writes it last); the record goes to LDS - through the caches, every line checked against its tag -
+// and the de-skew runs from there.  Workgroup 0 is the GATE - first in the grid, so that it runs whatever the launch's size: it
+// watches the host's state word for CANCEL, bounds the wait (EXPIRED, by compare-and-swap), tells the others through dev_flag when
+// the launch is to end without running, and pulls the update's control block once the record is there (what the extra workgroup
+// of k_deskew_imu does).  A launch that does not run has written nothing.
+__device__ __forceinline__ unsigned long long gate_load_u64(const void* p) {  // past the caches
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+template <bool FUSE>
+__global__ __launch_bounds__(256) void k_deskew_imu_gated(DeskewIo io, DeskewGate gate) {
+  __shared__ unsigned long long s_verdict;
+  __shared__ int s_bad;
+  __shared__ double s_rec[7 * kGateLines];
+  const unsigned long long armed = (gate.seq << 2) | kGateArmed, go = (gate.seq << 2) | kGateGo, cancel = (gate.seq << 2) | kGateCancel;
+  const bool gate_wg = blockIdx.x == 0;
+  const int row = (int)blockIdx.x - 1;
+  const int i = row * (int)blockDim.x + threadIdx.x;
+  const bool in_range = !gate_wg && i < io.n;
+  float4 P = in_range ? io.in[i] : make_float4(0, 0, 0, 0);  // (requested before the wait: the scan itself has been there all along)
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    unsigned long long verdict = go;
+    unsigned int spins = 0;
+    for (;;) {
+      if (gate_load_u64(gate.rec + 7) == go) break;  // line 0's tag: the record is complete
+      ++spins;
+      if (gate_wg) {
+        const unsigned long long w = gate_load_u64(&gate.host->word);
+        if (w == cancel) { verdict = cancel; break; }
+        if (w == armed && (spins & 31u) == 0u && wall_clock64() - t0 > gate.timeout_ticks) {
+          // nobody came: EXPIRED - unless the host moves the word in this very moment, then its verdict stands (GO: the record follows)
+          unsigned long long expect = armed;
+          if (__hip_atomic_compare_exchange_strong(&gate.host->word, &expect, (gate.seq << 2) | kGateExpired, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE,
+                                                   __HIP_MEMORY_SCOPE_SYSTEM) || expect == cancel) { verdict = cancel; break; }
+        }
+      } else if ((spins & 3u) == 0u) {
+        if (gate_load_u64(gate.dev_flag) == cancel) { verdict = cancel; break; }
+        // (the gate workgroup bounds the wait; this bound - four times as long - only ends a launch whose gate never ran)
+        if ((spins & 255u) == 0u && wall_clock64() - t0 > 4 * gate.timeout_ticks) { verdict = cancel; break; }
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (gate_wg && verdict == cancel) __hip_atomic_store(gate.dev_flag, cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    s_verdict = verdict;
+    s_bad = 0;
+  }
+  __syncthreads();
+  if (s_verdict != go) return;
+  if (gate_wg) {
+#ifdef LII_GAP_TRACE
+    gap_trace(io);
+#endif
+    if (io.ctrl_vec > 0) pull_ctrl(io);
+    return;
+  }
+  // the record -> LDS.  K sits in line 0 (whose tag has been seen: read past the caches once more, it is this record's)
+  const int K = (int)__longlong_as_double((long long)gate_load_u64(gate.rec));
+  const int n_lines = (25 + 22 * (K < 2 ? 2 : (K > kGateMaxPoses ? kGateMaxPoses : K)) + 6) / 7;
+  for (int e = threadIdx.x; e < 8 * n_lines; e += 256) {
+    const double v = gate.rec[e];
+    if ((e & 7) == 7) { if ((unsigned long long)__double_as_longlong(v) != go) s_bad = 1; }
+    else s_rec[(e >> 3) * 7 + (e & 7)] = v;
+  }
+  __syncthreads();
+  if (s_bad) {  // (uniform; rare) a line came out of a cache as an older record left it: everything again, past the caches
+    for (int e = threadIdx.x; e < 8 * n_lines; e += 256)
+      if ((e & 7) != 7) s_rec[(e >> 3) * 7 + (e & 7)] = __longlong_as_double((long long)gate_load_u64(gate.rec + e));
+    __syncthreads();
+  }
+  UndistArg u;
+#pragma unroll
+  for (int e = 0; e < 9; e++) { u.endR[e] = s_rec[1 + e]; u.RLI[e] = s_rec[13 + e]; }
+#pragma unroll
+  for (int e = 0; e < 3; e++) { u.endp[e] = s_rec[10 + e]; u.TLI[e] = s_rec[22 + e]; }
+  deskew_imu_point<FUSE>(io, u, K, s_rec + 25, row, i, i < io.n, P);
 }
 
 struct CvArg {
@@ -866,6 +953,13 @@ void launch_deskew_imu(const DeskewPlan& p, const double* poses_host, const doub
     else if (kp == 64) launch_deskew_imu_t<false, 64>(io, u, K, poses_host, poses_dev, nb, s);
     else launch_deskew_imu_t<false, 0>(io, u, K, poses_host, poses_dev, nb, s);
   }
+}
+void launch_deskew_imu_gated(const DeskewPlan& p, const DeskewGate& gate, hipStream_t s) {
+  if (p.n <= 0) return;
+  const DeskewIo io = deskew_io(p);
+  const int nb = nblk(p.n, 256) + 1;  // (+ the gate workgroup, which also pulls the control block)
+  if (p.vh) hipLaunchKernelGGL(k_deskew_imu_gated<true>, dim3(nb), dim3(256), 0, s, io, gate);
+  else hipLaunchKernelGGL(k_deskew_imu_gated<false>, dim3(nb), dim3(256), 0, s, io, gate);
 }
 void launch_deskew_cv(const DeskewPlan& p, const CvArgH& ah, hipStream_t s) {
   if (p.n <= 0) return;
