@@ -626,7 +626,9 @@ int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_
   return LII_OK;
 }
 int lii_scan_upload_next(lii_handle h, const void* points, int32_t n, int32_t stride_bytes, int32_t time_offset_bytes) {
-  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
+  // (a pre-armed launch that waits for the scan in the OTHER buffer - the one lii_scan_advance made current - stays: this call only
+  // puts an event and a wait between the two streams; one that waits for the buffer this call overwrites is told to end)
+  if (h && h->pre.armed && !(h->pre.late && h->pre.scan_dev == h->d_scan)) lii_internal_prearm_cancel(h);
   if (!h || (!points && n > 0) || n < 0 || stride_bytes < 16 || time_offset_bytes < 12 || time_offset_bytes + 4 > stride_bytes)
     return fail(h, LII_ERR_INVALID, "lii_scan_upload_next: bad arguments");
   if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_upload_next: n > max_scan_points");
@@ -671,7 +673,8 @@ int lii_scan_upload_next(lii_handle h, const void* points, int32_t n, int32_t st
   return LII_OK;
 }
 int lii_scan_advance(lii_handle h) {
-  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
+  // (a pre-armed launch that waits for exactly the scan this call makes current stays)
+  if (h && h->pre.armed && !(h->pre.late && h->pre.scan_dev == h->d_scan_next && h->pre.n == h->n_scan_next)) lii_internal_prearm_cancel(h);
   if (!h) return LII_ERR_INVALID;
   if (h->n_scan_next < 0) return fail(h, LII_ERR_STATE, "lii_scan_advance: no scan under way (call lii_scan_upload_next)");
   HIPCHK(h, hipEventSynchronize(h->ev_next));  // long done when the transfer overlapped a registration; frees the caller's buffer

@@ -254,17 +254,18 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     lii::GateState* gst = h->pre.state;
     h->pre.seq = (h->pre.seq + 1) & 0x3FFFFFFFFFFFFFFFull;
     __atomic_store_n(&gst->word, (h->pre.seq << 2) | lii::kGateArmed, __ATOMIC_RELEASE);
-    h->pre.scan_dev = h->pre.want_dev; h->pre.n = h->pre.want_n; h->pre.leaf = h->pre.want_leaf;
+    h->pre.scan_dev = h->pre.want_dev; h->pre.n = h->pre.want_n; h->pre.leaf = h->pre.want_leaf; h->pre.late = h->pre.want_late;
     h->pre.fuse = fuse_filter(h, h->pre.leaf);
     DeskewPlan dp = {};
     dp.in = static_cast<const float4*>(h->pre.scan_dev);
-    dp.out = h->d_scan; dp.n = h->pre.n; dp.sorted = 1; dp.extent = nullptr; dp.bbox_rows = h->d_bbox_rows;
+    dp.out = h->pre.late ? const_cast<float4*>(dp.in) : h->d_scan;  // (late: the buffer becomes the handle's scan buffer with lii_scan_advance)
+    dp.n = h->pre.n; dp.sorted = 1; dp.extent = nullptr; dp.bbox_rows = h->d_bbox_rows;
     dp.leaf = h->pre.leaf; dp.vh = h->pre.fuse ? &h->vh : nullptr;
     dp.ctrl_src = h->h_ctrl; dp.ctrl_dst = h->d_ctrl; dp.ctrl_bytes = (sizeof(IekfCtrl) + 15) / 16 * 16;
 #ifdef LII_GAP_TRACE
     dp.gap = h->d_gran;
 #endif
-    lii::DeskewGate gate = {gst, h->pre.d_ring + size_t(h->pre.seq % lii::kGateRing) * lii::kGateLines * 8, h->pre.d_flag, h->pre.seq, h->pre.timeout_ticks};
+    lii::DeskewGate gate = {gst, h->pre.d_ring + size_t(h->pre.seq % lii::kGateRing) * lii::kGateLines * 8, h->pre.d_flag, h->pre.seq, h->pre.timeout_ticks, h->pre.late ? 1 : 0};
     launch_deskew_imu_gated(dp, gate, s);
     h->pre.armed = hipGetLastError() == hipSuccess;
     if (!h->pre.armed) __atomic_store_n(&gst->word, (h->pre.seq << 2) | lii::kGateCancel, __ATOMIC_RELEASE);
@@ -513,15 +514,22 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   // A gated de-skew launch waits on the stream (the previous call enqueued it for the scan its job announced): it is used when THIS
   // call asks for exactly that, and told to end otherwise - before anything here could wait for the stream.
   const float leaf_now = job->leaf > 0 ? job->leaf : 0.f;
-  bool use_pre = h->pre.armed && from_job && sorted && job->undistort == 1 && job->imu_poses && job->n_imu_poses >= 2 && job->n_imu_poses <= lii::kGateMaxPoses &&
-                 src_dev == h->pre.scan_dev && src_n == h->pre.n && leaf_now == h->pre.leaf && !h->host_solve && !h->no_fast_prologue &&
+  // (the announced scan: the job's own device buffer, or - announced while lii_scan_upload_next was bringing it - the handle's current
+  // scan after lii_scan_advance, de-skewed in place)
+  const void* const cur_dev = from_job ? job->scan_dev : (adopt ? nullptr : static_cast<const void*>(h->d_scan));
+  const int cur_n = from_job ? job->n_scan_dev : h->n_scan;
+  bool use_pre = h->pre.armed && sorted && job->undistort == 1 && job->imu_poses && job->n_imu_poses >= 2 && job->n_imu_poses <= lii::kGateMaxPoses &&
+                 cur_dev != nullptr && cur_dev == h->pre.scan_dev && cur_n == h->pre.n && h->pre.late == !from_job && leaf_now == h->pre.leaf && !h->host_solve && !h->no_fast_prologue &&
                  h->prof.prof_mode != 3 && !h->staging_busy && fuse_filter(h, leaf_now) == h->pre.fuse;
   if (!use_pre) prearm_cancel(h);
   // ... and what this job announces for the next call (update_on_device arms it behind the passes)
   h->pre.want_dev = nullptr;
   if (job->struct_size >= sizeof(lii_scan_job) && job->next_scan_dev && job->next_n_scan > 0 && job->next_n_scan <= h->cfg.max_scan_points && h->pre.enabled &&
       sorted && job->undistort == 1) {
-    h->pre.want_dev = job->next_scan_dev; h->pre.want_n = job->next_n_scan; h->pre.want_leaf = leaf_now;
+    h->pre.want_dev = job->next_scan_dev; h->pre.want_n = job->next_n_scan; h->pre.want_leaf = leaf_now; h->pre.want_late = false;
+  } else if (h->n_scan_next > 0 && h->d_scan_next && h->pre.enabled && sorted && job->undistort == 1 && !from_job) {
+    // a scan is on its way through lii_scan_upload_next: it is the next call's (after lii_scan_advance), de-skewed where it lands
+    h->pre.want_dev = h->d_scan_next; h->pre.want_n = h->n_scan_next; h->pre.want_leaf = leaf_now; h->pre.want_late = true;
   }
   // A scan in ascending time order: ONE launch takes it from wherever it arrived (the caller's device buffer is read in place)
   // to the de-skewed scan with the voxel filter's table filled, and one extra workgroup of it pulls the update's control block

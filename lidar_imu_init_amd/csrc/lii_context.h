@@ -206,6 +206,8 @@ struct lii_context {
     int n = 0;
     float leaf = 0.f;                        // ... this leaf,
     bool fuse = false;                       // ... with the hashed filter's insert riding along or not
+    bool late = false;                       // ... which was still being uploaded then (lii_scan_upload_next): read in place, behind the wait
+    bool want_late = false;
     const void* want_dev = nullptr;          // lii_scan_register -> update_on_device: the job in progress names this next scan
     int want_n = 0;
     float want_leaf = 0.f;

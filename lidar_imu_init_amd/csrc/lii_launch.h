@@ -154,6 +154,7 @@ struct DeskewGate {
   unsigned long long* dev_flag;     // seq << 2 | kGateCancel when the launch is to end without running (published by the gate workgroup)
   unsigned long long seq;
   long long timeout_ticks;
+  int late_load;                    // 1: the scan itself may still be on its way when the launch starts (lii_scan_upload_next): no point is read before the record is there
 };
 void launch_deskew_imu_gated(const DeskewPlan& p, const DeskewGate& gate, hipStream_t s);
 void launch_deskew_cv(const DeskewPlan& p, const CvArgH& a, hipStream_t s);

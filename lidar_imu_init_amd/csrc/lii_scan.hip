@@ -427,7 +427,9 @@ __global__ __launch_bounds__(256) void k_deskew_imu_gated(DeskewIo io, DeskewGat
   const int row = (int)blockIdx.x - 1;
   const int i = row * (int)blockDim.x + threadIdx.x;
   const bool in_range = !gate_wg && i < io.n;
-  float4 P = in_range ? io.in[i] : make_float4(0, 0, 0, 0);  // (requested before the wait: the scan itself has been there all along)
+  // (requested before the wait where the scan has been in device memory all along; a scan announced while its transfer was under way -
+  // late_load - is read behind the wait: the host only writes the record once the transfer is complete)
+  float4 P = (in_range && !gate.late_load) ? io.in[i] : make_float4(0, 0, 0, 0);
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();
     unsigned long long verdict = go;
@@ -464,6 +466,7 @@ __global__ __launch_bounds__(256) void k_deskew_imu_gated(DeskewIo io, DeskewGat
     if (io.ctrl_vec > 0) pull_ctrl(io);
     return;
   }
+  if (in_range && gate.late_load) P = io.in[i];
   // the record -> LDS.  K sits in line 0 (whose tag has been seen: read past the caches once more, it is this record's)
   const int K = (int)__longlong_as_double((long long)gate_load_u64(gate.rec));
   const int n_lines = (25 + 22 * (K < 2 ? 2 : (K > kGateMaxPoses ? kGateMaxPoses : K)) + 6) / 7;

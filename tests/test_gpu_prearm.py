@@ -100,3 +100,45 @@ print("OK")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
     assert "1 expired" in r.stderr, r.stderr[-800:]  # (LII_DIAG: "pre-armed prologues: 0 used, 0 cancelled, 1 expired")
+
+
+@pytest.mark.gpu
+def test_a_scan_announced_while_it_is_uploaded_gives_the_same_bits():
+    """The complete pipeline (lii_scan_upload_next / lii_scan_register with the map update in the job / lii_scan_advance): the scan on
+    its way is announced by the library itself and de-skewed where it lands.  The same loop with LII_PREARM=0 and 1, in two processes:
+    every state bit for bit, and the pre-armed form did run."""
+    code = r'''
+import sys, hashlib, numpy as np
+sys.path.insert(0, %r)
+import bench, lidar_imu_init_amd as lii
+wl = bench.build_workload("vlp16", 4)
+states0, tables = bench.start_states(wl)
+n_full = max(len(s) for s in wl["scans"])
+reg = lii.Registrar(max_scan_points=n_full + 1024, max_map_points=int(len(wl["map"]) * 1.5) + 1024, filter_size_map=wl["fs_map"])
+reg.map_build(wl["map"]); reg.map_commit()
+hs = [np.ascontiguousarray(s) for s in wl["scans"]]
+order = [0, 1, 2, 3, 1, 0, 3, 2, 2, 1]
+reg.scan_upload_next(hs[order[0]]); reg.scan_advance()
+m = hashlib.sha256()
+for k, j in enumerate(order):
+    if k + 1 < len(order):
+        reg.scan_upload_next(hs[order[k + 1]])
+    st = states0[j].copy()
+    rep = reg.scan_register(st, states0[j], imu_poses=tables[j], leaf=wl["fs_surf"], max_iterations=wl["max_it"], imu_en=True, scan_sorted=True, map_update=True)
+    m.update(st.pod.tobytes()); m.update(np.int64([rep["iterations"], rep["effect_num"]]).tobytes())
+    if k + 1 < len(order):
+        reg.scan_advance()
+reg.synchronize()
+print("HASH", m.hexdigest(), reg.map_size())
+reg.close()
+''' % ROOT
+    out = {}
+    for v in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LII_PREARM=v, LII_DIAG="1"), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "HASH" in r.stdout, (v, r.stdout[-500:], r.stderr[-1500:])
+        out[v] = (r.stdout.split("HASH")[1].split()[:2], r.stderr)
+    assert out["0"][0] == out["1"][0], (out["0"][0], out["1"][0])
+    import re
+    used = int(re.search(r"pre-armed prologues: (\d+) used", out["1"][1]).group(1))
+    assert used >= 8, out["1"][1][-600:]
+    assert "pre-armed prologues: 0 used" in out["0"][1]
