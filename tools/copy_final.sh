@@ -5,6 +5,19 @@ cp $S/bench_default.json $P/${R}_bench_default.json
 cp $S/bench_driver_form.json $P/${R}_bench_driver_form.json
 cp $S/${R}_bench_kernel_stats.csv $S/${R}_bench_kernel_summary.md $S/${R}_timeline.md $S/${R}_mapupdate_kernel_summary.md $S/${R}_mapupd_timeline.md $S/${R}_pmc_knn.json $P/
 [ -f $S/perscan.txt ] && cp $S/perscan.txt $P/${R}_perscan.txt
+for w in os1_128_cut3 stream100k; do [ -f $S/ingest_timeline_$w.md ] && cp $S/ingest_timeline_$w.md $P/${R}_ingest_timeline_$w.md; done
+python3 - "$S" "$P/${R}_bench_edge.json" <<'PY'
+import json, sys
+s, out = sys.argv[1], sys.argv[2]
+res = {}
+for name, f in (("--edge", "bench_edge"), ("--edge-wide", "bench_edge-wide"), ("LII_PREARM=0", "bench_noprearm")):
+    try:
+        res[name] = json.loads(open(f"{s}/{f}.json").readline())
+    except Exception as e:
+        res[name] = {"error": str(e)}
+json.dump(res, open(out, "w"), indent=1)
+PY
+grep -h -a "solve trace\|gap trace\|completion trace" $S/trace_*.err 2>/dev/null | sort | uniq -c | sort -rn | head -40 > $P/${R}_traces.txt
 python3 - "$S" "$P/${R}_bench_other_workloads.json" <<'PY'
 import json, sys
 s, out = sys.argv[1], sys.argv[2]
