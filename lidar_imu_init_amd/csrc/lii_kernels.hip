@@ -1,15 +1,17 @@
-// HIP kernels of the LI-Init hot path for gfx950 (CDNA4, wave64).  Hand-written; no MFMA (the path is
-// gather + per-point small algebra + a low-rank reduction — DESIGN.md §3).
+// HIP kernels of the LI-Init hot path for gfx950 (CDNA4, wave64).  Hand-written.  The path is gather + per-point small algebra + a
+// low-rank reduction; its one contraction - the 13 x 13 Gram matrix of a wavefront's rows - runs on the fp64 matrix
+// cores (block_reduce_rows: v_mfma_f64_16x16x4_f64).
 //
 // Kernels and the reference code they replace (paths relative to the reference root):
-//   k_map_keys / k_map_gather / k_block_flags / k_cells_fill
-//                      device mirror of the ikd-Tree point set as a cell-sorted array + block-hierarchical grid
-//                      (include/ikd-Tree/ikd_Tree.cpp:336-347 Build)
-//   k_knn_ck / _exact  KD_TREE::Nearest_Search (ikd_Tree.cpp:349-379, Search :825-968) for every point of the
-//                      scan, after pointBodyToWorld (src/laserMapping.cpp:209-220, call :973-985)
-//   k_fit_reduce       completes the few searches the 3x3x3 pass could not prove exact, then esti_plane +
-//                      residual/selection (src/laserMapping.cpp:987-1011), Jacobian rows (:1035-1071) and the
-//                      H^T R^-1 H / H^T R^-1 z sums (:1073-1080)
+//   k_map_keys / k_map_gather / k_block_flags / k_cells_fill / k_win_bbox / k_win_fill
+//                      device mirror of the ikd-Tree point set as a cell-sorted array + block-hierarchical grid, and the dense cell
+//                      window over the map's box (include/ikd-Tree/ikd_Tree.cpp:336-347 Build)
+//   k_knn_ck           KD_TREE::Nearest_Search (ikd_Tree.cpp:349-379, Search :825-968) for every point of the scan, after
+//                      pointBodyToWorld (src/laserMapping.cpp:209-220, call :973-985): four lanes per query, chunked scan, packed keys
+//   k_fit_reduce       its completion workgroups finish the searches the 3 x 3 x 3 pass could not prove exact (knn_fallback_wave:
+//                      ikd_Tree.cpp:827-842), then esti_plane + residual / selection (src/laserMapping.cpp:987-1011), Jacobian rows
+//                      (:1035-1071) and the H^T R^-1 H / H^T R^-1 z sums (:1073-1080)
+//   k_knn_complete     the completion alone (lii_map_incremental of a sharded job)
 //   k_reduce91         deterministic final sum of the per-block partials (lii_iekf.hip fuses it with the solve)
 //   (de-skew and voxel grid: lii_scan.hip)
 //   k_calib_eval       include/LI_init/LI_init.h:91-205 residuals + analytic Jacobians
