@@ -233,10 +233,18 @@ constexpr int kSolveThreads = 256;
 // The iteration that ends the loop tells the host so through the mapped result block: every lane's stores to `res` have been
 // acknowledged (system-scope fence by every lane, then the barrier) before the flag goes out, so a host that sees
 // done == seq sees the result.
+// Round 6: the result block lives in HOST memory, which the device does not cache - its stores travel straight out, and "acknowledged"
+// is what s_waitcnt vmcnt(0) waits for.  A system-scope release fence does more: it writes back every dirty line of the XCD's L2 -
+// whatever the launches before left there - which nobody on the host will read (1 - 2 us of the stopping pass; the device-side stores
+// of this kernel become visible to the next launch at the kernel boundary as always).  So: every lane waits for its own stores, the
+// barrier collects them, one relaxed store raises the flag behind them (posted writes of one device to host memory stay in order).
+// (every store into the result block: system scope, i.e. written through to the host as it is issued)
+template <class T>
+__device__ __forceinline__ void res_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void publish_done(IekfResult* res, int seq) {
-  __threadfence_system();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(&res->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) __hip_atomic_store(&res->done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ne_src: where the 91 sums come from - a functor called by every lane AFTER the other loads have been issued; it leaves the sums
@@ -268,7 +276,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
   }
   if (const int why = ne_src(s_ne)) {  // (uniform) the sums could not be had
     __syncthreads();
-    if (threadIdx.x == 0) { c->stop = 1; c->singular = why; res->singular = why; res->it = 0; }
+    if (threadIdx.x == 0) { c->stop = 1; c->singular = why; res_store(&res->singular, why); res_store(&res->it, 0); }
     publish_done(res, s_int[10]);
     return;
   }
@@ -342,7 +350,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
   }
   __syncthreads();
   if (!s_ok) {  // uniform
-    if (tid == 0) { c->stop = 1; c->singular = 1; res->singular = 1; }
+    if (tid == 0) { c->stop = 1; c->singular = 1; res_store(&res->singular, 1); }
     publish_done(res, s_int[10]);
     return;
   }
@@ -379,7 +387,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
       d_m3_mul(s_st + o, E, Rn);
       for (int e = 0; e < 9; e++) c->st[o + e] = Rn[e];
       if (do_cov)
-        for (int e = 0; e < 9; e++) res->st[o + e] = Rn[e];
+        for (int e = 0; e < 9; e++) res_store(&res->st[o + e], Rn[e]);
     } else if (lane >= 8 && lane < 26) {
       const int q = lane - 8;  // 0..17 : six 3-vectors
       const int blk = q / 3, i = q % 3;
@@ -387,7 +395,7 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
       const int soo = blk == 0 ? 3 : (blk == 1 ? 9 : (blk == 2 ? 12 : (blk == 3 ? 15 : (blk == 4 ? 18 : 21))));
       const double v = s_st[sto + i] + sol[soo + i];
       c->st[sto + i] = v;
-      if (do_cov) res->st[sto + i] = v;
+      if (do_cov) res_store(&res->st[sto + i], v);
     } else if (lane >= 32 && lane < 32 + N) {
       c->solution[lane - 32] = sol[lane - 32];
     }
@@ -401,37 +409,44 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
       if (it < 16) c->search_log[it] = search_now | (s_ok == 2 ? 2 : 0);
       if (parked) {
         c->stop = 2;
-        res->parked_it = it + 1;
-        res->parked_search = search;
+        res_store(&res->parked_it, it + 1);
+        res_store(&res->parked_search, search);
       }
       if (do_cov) {
         c->stop = 1;
-        res->it = it + 1;
-        res->searches = searches0 + (search_now ? 1 : 0);
-        res->effect_num = (int)s_ne[90];
-        res->converged = converged;
-        res->singular = 0;
+        res_store(&res->it, it + 1);
+        res_store(&res->searches, searches0 + (search_now ? 1 : 0));
+        res_store(&res->effect_num, (int)s_ne[90]);
+        res_store(&res->converged, converged);
+        res_store(&res->singular, 0);
       }
     }
   } else if (do_cov) {
-    for (int e = tid - 64; e < N * H; e += kSolveThreads - 64) {
-      const int r = e / H, cc = e % H;
+    // Round 6: every one of the three wavefronts takes EIGHT ROWS of K H and then the same eight rows of
+    // state.cov = (I - K H) cov = cov - (K H) cov[0:12, :]   (:1111-1114, all operands already in LDS) - a row of the product needs its
+    // own row of K H and nothing else, so no workgroup barrier stands between the two and both run in the shadow of the state update on
+    // the first wavefront (round 5: K H here, then barrier - product over 256 lanes - barrier behind the state update: 1.4 us of the
+    // stopping pass; the sums of every entry are formed in the same order as before).
+    const int r0 = 8 * (wave - 1);
+    for (int e = lane; e < 8 * H; e += 64) {
+      const int r = r0 + e / H, cc = e % H;
       double s2 = 0;
 #pragma unroll
       for (int k = 0; k < H; k++) s2 += K1c[r * LDH + k] * G[k * LDH + cc];
-      s_KH[e] = s2;
+      s_KH[r * H + cc] = s2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = lane; e < 8 * N; e += 64) {
+      const int r = r0 + e / N, cc = e % N;
+      double s2 = s_cov[r * N + cc];
+      for (int k = 0; k < H; k++) s2 -= s_KH[r * H + k] * s_cov[k * N + cc];
+      s_x[r * N + cc] = s2;
     }
   }
   LII_TS(9);
   if (do_cov) {  // uniform
-    __syncthreads();
-    // state.cov = (I - K H) cov = cov - (K H) cov[0:12, :]   (:1111-1114), all operands already in LDS
-    for (int e = tid; e < N * N; e += kSolveThreads) {
-      const int r = e / N, cc = e % N;
-      double s2 = s_cov[e];
-      for (int k = 0; k < H; k++) s2 -= s_KH[r * H + k] * s_cov[k * N + cc];
-      s_x[e] = s2;
-    }
     __syncthreads();
     // the posterior leaves as its symmetric part: the gain above relies on P = P^T, and whatever asymmetry rounding puts into
     // (I - K H) P must not feed back into the next scan's gain (it compounds otherwise: the pose block of P grew to 0.4 within
@@ -441,12 +456,12 @@ __device__ __forceinline__ void iekf_solve_body(IekfCtrl* c, IekfResult* res, Ne
       const int r = e / N, cc = e % N;
       const double v = 0.5 * (s_x[e] + s_x[cc * N + r]);
       covw[e] = v;
-      res->st[36 + e] = v;
+      res_store(&res->st[36 + e], v);
     }
-    if (tid < 91) res->ne[tid] = s_ne[tid];
+    if (tid < 91) res_store(&res->ne[tid], s_ne[tid]);
     if (tid >= 96 && tid < 112) {
       const int q = tid - 96;
-      res->search_log[q] = (q < it) ? c->search_log[q] : (q == it ? (search_now | (s_ok == 2 ? 2 : 0)) : 0);
+      res_store(&res->search_log[q], (q < it) ? c->search_log[q] : (q == it ? (search_now | (s_ok == 2 ? 2 : 0)) : 0));
     }
     publish_done(res, s_int[10]);
   } else if (parked) {  // uniform
