@@ -743,9 +743,11 @@ __global__ void k_ins_write(const float4* __restrict__ list, const unsigned int*
     if (threadIdx.x == kMapCtrTicket) { v = 0; __hip_atomic_store(&ctr[kMapCtrTicket], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __hip_atomic_store(host + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __threadfence_system();
+  // (the words above are system-scope stores into host memory: every lane waits for its own, the barrier collects them, a relaxed store
+  // raises the number behind them - no system-scope release fence, which would write the whole L2 back first: lii_iekf.hip, publish_done)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(host + seq_at, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) __hip_atomic_store(host + seq_at, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- (re)build: slack layout from the compact, cell-sorted array
@@ -855,8 +857,8 @@ void launch_box_tomb_cells(const float4* pts, const uint2* cells, int n_entries,
 __global__ __launch_bounds__(64) void k_map_publish(const int* __restrict__ ctr, int n_words, int* __restrict__ host, int seq_at, int seq) {
   const int l = threadIdx.x;
   if (l < n_words) __hip_atomic_store(host + l, ctr[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __threadfence_system();
-  if (l == 0) __hip_atomic_store(host + seq_at, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (one wavefront: its system-scope stores are out before the number goes: see k_ins_write)
+  if (l == 0) __hip_atomic_store(host + seq_at, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 void launch_map_publish(const int* ctr, int n_words, int* host, int seq_at, int seq, hipStream_t s) {
   hipLaunchKernelGGL(k_map_publish, dim3(1), dim3(64), 0, s, ctr, n_words, host, seq_at, seq);
