@@ -213,6 +213,7 @@ int lii_internal_scan_defer(lii_handle h, const void* dev_float4, int32_t n) {
   if (!h || (!dev_float4 && n > 0) || n < 0) return fail(h, LII_ERR_INVALID, "lii_frame_select: bad frame");
   if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_frame_select: frame larger than max_scan_points");
   extent_discard(h);
+  h->scan_buf_idle = false;
   h->bbox_rows = 0;
   h->scan_pending = n > 0 ? static_cast<const float4*>(dev_float4) : nullptr;
   h->scan_pending_n = n > 0 ? n : 0;
@@ -599,6 +600,7 @@ int lii_synchronize(lii_handle h) {
 
 // ------------------------------------------------------------------------------------------------ scan
 int lii_scan_upload(lii_handle h, const void* points, int32_t n, int32_t stride_bytes, int32_t time_offset_bytes) {
+  if (h) h->scan_buf_idle = false;  // (work on the current scan buffer goes out)
   lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || (!points && n > 0) || n < 0 || stride_bytes < 16 || time_offset_bytes < 12 || time_offset_bytes + 4 > stride_bytes)
     return fail(h, LII_ERR_INVALID, "lii_scan_upload: bad arguments");
@@ -665,8 +667,12 @@ int lii_scan_upload_next(lii_handle h, const void* points, int32_t n, int32_t st
   }
   // the buffer being written was the current scan of an earlier call: whatever the compute stream still has to do with it
   // (kernels enqueued up to now) comes first
-  HIPCHK(h, hipEventRecord(h->ev_scan_free, h->stream));
-  HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_scan_free, 0));
+  // (... unless it is known to have nothing left to do with it: the last update's result came back behind every launch that read the
+  // buffer, and nothing has touched a scan buffer since - the per-scan loop's case, two runtime calls less between two registrations)
+  if (!h->scan_buf_idle) {
+    HIPCHK(h, hipEventRecord(h->ev_scan_free, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_scan_free, 0));
+  }
   if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scan_next, src, sizeof(float4) * size_t(n), hipMemcpyHostToDevice, h->copy_stream));
   HIPCHK(h, hipEventRecord(h->ev_next, h->copy_stream));
   h->n_scan_next = n;
@@ -689,6 +695,7 @@ int lii_scan_advance(lii_handle h) {
   return LII_OK;
 }
 int lii_scan_set_device(lii_handle h, const void* dev_float4, int32_t n) {
+  if (h) h->scan_buf_idle = false;  // (work on the current scan buffer goes out)
   lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || (!dev_float4 && n > 0) || n < 0) return fail(h, LII_ERR_INVALID, "lii_scan_set_device: bad arguments");
   if (n > h->cfg.max_scan_points) return fail(h, LII_ERR_CAPACITY, "lii_scan_set_device: n > max_scan_points");
@@ -708,6 +715,7 @@ int lii_scan_set_device(lii_handle h, const void* dev_float4, int32_t n) {
 }
 int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, const double end_R[9], const double end_p[3],
                       const double R_LI[9], const double T_LI[3]) {
+  if (h) h->scan_buf_idle = false;  // (work on the current scan buffer goes out)
   lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !poses || n_poses < 1 || n_poses > 1024 || !end_R || !end_p || !R_LI || !T_LI)
     return fail(h, LII_ERR_INVALID, "lii_undistort_imu: bad arguments");
@@ -741,6 +749,7 @@ int lii_undistort_imu(lii_handle h, const lii_pose6d* poses, int32_t n_poses, co
   return LII_OK;
 }
 int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], const double end_R[9]) {
+  if (h) h->scan_buf_idle = false;  // (work on the current scan buffer goes out)
   lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !omega || !vel || !end_R) return fail(h, LII_ERR_INVALID, "lii_undistort_cv: bad arguments");
   { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }
@@ -761,6 +770,7 @@ int lii_undistort_cv(lii_handle h, const double omega[3], const double vel[3], c
   return LII_OK;
 }
 int lii_downsample_skip(lii_handle h, int32_t* n_down) {
+  if (h) h->scan_buf_idle = false;  // (work on the current scan buffer goes out)
   lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_ERR_INVALID;
   { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }
@@ -776,6 +786,7 @@ int lii_downsample_skip(lii_handle h, int32_t* n_down) {
   return LII_OK;
 }
 int lii_downsample(lii_handle h, float leaf, int32_t* n_down, int32_t* filtered) {
+  if (h) h->scan_buf_idle = false;  // (work on the current scan buffer goes out)
   lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !(leaf > 0)) return fail(h, LII_ERR_INVALID, "lii_downsample: bad arguments");
   { const int rcm = scan_materialize(h); if (rcm != LII_OK) return rcm; }

@@ -302,6 +302,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     if (rc != LII_OK) return rc;
   }
   h->staging_busy = false;  // the wait above covers everything enqueued before the stopping pass
+  h->scan_buf_idle = true;  // ... every launch that read or wrote the current scan buffer among it (what was enqueued behind - drained passes, the map update, a pre-armed launch on the OTHER buffer - does not touch it)
   const IekfResult* hr = h->h_res;
   h->have_search = true;
 #ifdef LII_SOLVE_TRACE
@@ -501,6 +502,7 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   if (!h || !job || (job->struct_size != sizeof(lii_scan_job) && job->struct_size != 56u && job->struct_size != 48u) || !state || !state_prop || job->opts.max_iterations < 1)
     return fail(h, LII_ERR_INVALID, "lii_scan_register: bad arguments");
   const bool sorted = job->struct_size >= 56u && job->scan_sorted == 1;
+  h->scan_buf_idle = false;
   int rc = LII_OK;
   const auto t_entry = std::chrono::steady_clock::now();
   if (h->diag && h->prof.host_us[4] > 0) h->prof.host_us[5] += std::chrono::duration<double, std::micro>(t_entry - h->prof.host_last_return).count();

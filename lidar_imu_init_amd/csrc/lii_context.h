@@ -97,6 +97,9 @@ struct lii_context {
   hipEvent_t ev_next = nullptr;      // the transfer of the next scan
   hipEvent_t ev_scan_free = nullptr; // the compute stream has finished with the buffer the next transfer writes to
   int n_scan_next = -1;              // >= 0: a scan is waiting in d_scan_next
+  bool scan_buf_idle = false;        // everything ever enqueued on the CURRENT scan buffer is known to have completed (an update's result came back behind it,
+                                     // nothing touched the buffer since): lii_scan_upload_next may write the other buffer - the one that was current before the
+                                     // last lii_scan_advance - without an event between the two streams
   float4* d_body = nullptr;   // down-sampled body points
   float4* d_world = nullptr;
   float4* d_nbr = nullptr;    // 5 x cap
