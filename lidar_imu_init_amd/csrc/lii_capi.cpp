@@ -279,6 +279,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   }
   if (const char* v = std::getenv("LII_KNN_PLAN")) h->knn_plan = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_WINDOW")) h->use_window = std::atoi(v) != 0;
+  if (const char* v = std::getenv("LII_WINDOW_KEEP")) h->win_keep = std::atoi(v) != 0;
   if (const char* v = std::getenv("LII_TEST")) {
     // arrangements the test-suite and the A/B measurements ask for, comma-separated: "map_tight" (an in-place map update without
     // spare room), "plan_force=<mask>" (a launch plan that is wrong on purpose), "host_solve" (the iteration loop driven from the
@@ -359,6 +360,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(dmalloc(&h->d_tp, h->cells_cap_blocks * 512));
   CK(dmalloc(&h->d_cs_a, h->cells_cap_blocks * 512));
   CK(dmalloc(&h->d_cs_b, h->cells_cap_blocks * 512));
+  CK(dmalloc(&h->d_block_key, h->cells_cap_blocks));
   CK(hipMemset(h->d_cells, 0, sizeof(uint2) * h->cells_cap_blocks * 512));
   CK(hipMemset(h->d_cell_cap, 0, sizeof(unsigned int) * h->cells_cap_blocks * 512));
   CK(hipMemset(h->d_tp, 0, sizeof(unsigned int) * h->cells_cap_blocks * 512));
@@ -514,6 +516,7 @@ int lii_destroy(lii_handle h) {
   }
 #endif
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] pre-armed prologues: %lld used, %lld cancelled, %lld expired\n", h->pre.n_used, h->pre.n_cancelled, h->pre.n_expired);
+  if (h->diag) std::fprintf(stderr, "[libliinit_hip] dense cell window: kept current through %lld in-place updates, dropped %lld times\n", h->win_kept, h->win_dropped);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] map updates completed by a rebuild + re-insertion: %lld\n", h->map_recoveries);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] updates continued by the host after a parked loop: %lld\n", h->plan_parked);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] map updates repeated with exact list sizes: %lld\n", h->map_repeats);
@@ -536,7 +539,7 @@ int lii_destroy(lii_handle h) {
   if (h->ev_scan_free) (void)hipEventDestroy(h->ev_scan_free);
   if (h->h_stage_next) (void)hipHostFree(h->h_stage_next);
   if (h->d_scan_next) (void)hipFree(h->d_scan_next);
-  void* dev[] = {h->d_dropped, h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells, h->d_win,
+  void* dev[] = {h->d_dropped, h->d_pts, h->d_cell_cap, h->d_tp, h->d_cs_a, h->d_cs_b, h->d_work, h->d_ins_e, h->d_ins_e2, h->d_mapctr, h->d_map_unsorted, h->d_map, h->d_keys_a, h->d_keys_b, h->d_keys_c, h->d_idx_a, h->d_idx_b, h->d_blocks, h->d_cells, h->d_win, h->d_block_key,
                  h->d_counter, h->d_tomb, h->d_batch, h->d_ins, h->d_ins_c, h->d_u32_a, h->d_u32_b, h->d_u32_c, h->d_list_add, h->d_list_nodown, h->d_ah_key, h->d_ah_best, h->d_ah_slot, h->d_sort_temp, h->d_scan, h->d_body, h->d_world, h->d_nbr, h->d_nbr_count, h->d_plane,
                  h->d_selected, h->d_nbody, h->d_ctrl, h->d_pose, h->d_partials, h->d_out91, h->d_gran, h->d_extent, h->d_mm, h->d_bbox_rows, h->d_vkeys_a, h->d_vkeys_b,
                  h->d_vidx_b, h->d_vcomp, h->d_vsplit, h->d_vhist, h->d_vbucket, h->d_vpcl_in, h->d_vpcl_out, h->vh.slots, h->vh.slot_of, h->vh.next, h->vh.counts, h->vh.crowded, h->cal.d_cal_imu, h->cal.d_cal_lidar, h->cal.d_cal_params,
@@ -645,9 +648,18 @@ int lii_scan_upload_next(lii_handle h, const void* points, int32_t n, int32_t st
   const void* src = points;
   bool direct = false;
   if (n > 0 && stride_bytes == 16 && time_offset_bytes == 12) {
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, points) == hipSuccess) direct = attr.type == hipMemoryTypeHost;
-    else (void)hipGetLastError();  // pageable memory: not an error
+    // (asked once per source buffer: a loop that cycles through a few pinned buffers pays the runtime's look-up - microseconds - once each;
+    // a buffer wrongly remembered as pinned is still copied correctly, the runtime stages it)
+    bool known = false;
+    for (int q = 0; q < 8; q++)
+      if (h->pin_cache_ptr[q] == points) { direct = h->pin_cache_direct[q]; known = true; break; }
+    if (!known) {
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, points) == hipSuccess) direct = attr.type == hipMemoryTypeHost;
+      else (void)hipGetLastError();  // pageable memory: not an error
+      h->pin_cache_ptr[h->pin_cache_at] = points; h->pin_cache_direct[h->pin_cache_at] = direct;
+      h->pin_cache_at = (h->pin_cache_at + 1) & 7;
+    }
   }
   if (n > 0 && !direct) {
     if (!h->h_stage_next)

@@ -35,9 +35,9 @@ int build_index(lii_handle h, int n, int extra_blocks) {
   const size_t want_blocks = size_t(n_blocks) + size_t(std::max(extra_blocks, 0));
   if (want_blocks + 1 > h->cells_cap_blocks || !h->d_cell_cap) {
     for (void* q : {static_cast<void*>(h->d_cells), static_cast<void*>(h->d_cell_cap), static_cast<void*>(h->d_tp), static_cast<void*>(h->d_cs_a),
-                    static_cast<void*>(h->d_cs_b)})
+                    static_cast<void*>(h->d_cs_b), static_cast<void*>(h->d_block_key)})
       if (q) HIPCHK(h, hipFree(q));
-    h->d_cells = nullptr; h->d_cell_cap = nullptr; h->d_tp = nullptr; h->d_cs_a = nullptr; h->d_cs_b = nullptr;
+    h->d_cells = nullptr; h->d_cell_cap = nullptr; h->d_tp = nullptr; h->d_cs_a = nullptr; h->d_cs_b = nullptr; h->d_block_key = nullptr;
     // (+ 1: the last table of the pool is the shared all-empty one, k_ins_cells)
     const size_t want = h->map_tight ? want_blocks + 1 : std::max<size_t>(std::max<size_t>(want_blocks * 2, h->cells_cap_blocks), 4096);
     HIPCHK(h, dmalloc(&h->d_cells, want * 512));
@@ -45,6 +45,7 @@ int build_index(lii_handle h, int n, int extra_blocks) {
     HIPCHK(h, dmalloc(&h->d_tp, want * 512));
     HIPCHK(h, dmalloc(&h->d_cs_a, want * 512));
     HIPCHK(h, dmalloc(&h->d_cs_b, want * 512));
+    HIPCHK(h, dmalloc(&h->d_block_key, want));
     h->cells_cap_blocks = want;
     if (want * 512 * sizeof(unsigned int) + 4096 > h->sort_temp_bytes) {  // the scans over the cell entries need their temporary storage
       if (h->d_sort_temp) HIPCHK(h, hipFree(h->d_sort_temp));
@@ -72,7 +73,7 @@ int build_index(lii_handle h, int n, int extra_blocks) {
   HIPCHK(h, hipMemsetAsync(h->d_mapctr, 0, sizeof(int) * kMapCtrWords, s));
   launch_table_clear(h->d_blocks, bcap, s);
   if (n > 0) {
-    launch_cells_fill(h->d_keys_b, ranks, n, h->d_blocks, h->block_mask, h->d_cells, s);
+    launch_cells_fill(h->d_keys_b, ranks, n, h->d_blocks, h->block_mask, h->d_cells, h->d_block_key, s);
     const int ne = int(n_blocks) * 512;
     unsigned int* caps = h->d_cs_a;
     unsigned int* capsum = h->d_cs_b;
@@ -198,6 +199,7 @@ int commit_map(lii_handle h) {
     const int rc = map_counters(h, false);
     if (rc != LII_OK) return rc;
   } else {  // the counters came along: the host's copies are current again without a read of their own
+    if (h->h_mapflag[kMapCtrWinStale] && h->win_valid) { h->win_valid = false; h->win_dropped++; }  // (the update touched a cell outside the window's box)
     h->n_used = h->h_mapflag[kMapCtrUsed];
     h->n_map = h->h_mapflag[kMapCtrValid];
     h->n_blocks = int(std::min<size_t>(size_t(std::max(h->h_mapflag[kMapCtrBlocks], 0)), h->cells_cap_blocks));
@@ -223,6 +225,7 @@ int map_counters(lii_handle h, bool already_synced) {
   }
   int c[kMapCtrWords];
   std::memcpy(c, h->h_small + 3072, sizeof(c));
+  if (c[kMapCtrWinStale] && h->win_valid) { h->win_valid = false; h->win_dropped++; }
   h->n_used = c[kMapCtrUsed];
   h->n_map = c[kMapCtrValid];
   h->n_blocks = int(std::min<size_t>(size_t(std::max(c[kMapCtrBlocks], 0)), h->cells_cap_blocks));  // (the counter runs past the pool when it is exhausted)
@@ -290,6 +293,15 @@ int map_rebuild(lii_handle h, int extra_blocks) {
 // bounds of them (lii_map_incremental's predicted sizes); the launches are made for the bounds.
 // count_events = false (lii_map_incremental): Add_Points' event counter is not needed - the down-sampled list is folded through
 // the hash table instead of the batch sort (lii_map.hip: AddHash).
+lii::WinKeep win_keep_view(lii_handle h) {
+  lii::WinKeep wk = {};
+  if (h->win_valid && h->win_keep && h->d_win && h->d_block_key) {
+    wk.win = h->d_win; wk.key_of_id = h->d_block_key;
+    wk.x0 = h->win_org[0]; wk.y0 = h->win_org[1]; wk.z0 = h->win_org[2];
+    wk.nx = h->win_dim[0]; wk.ny = h->win_dim[1]; wk.nz = h->win_dim[2];
+  }
+  return wk;
+}
 int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra, bool beside,
               const int* n_list_dev, const int* n_extra_dev, bool count_events) {
   hipStream_t s = h->stream;
@@ -341,12 +353,15 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
     flags_a = h->d_u32_a;
   }
   launch_ins_cells(list_a, flags_a, n_list, flags_a ? nullptr : n_list_dev, extra, n_extra, n_extra_dev, h->d_ins_e2, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp,
-                   h->d_work, h->d_mapctr, h->work_cap, h->d_dropped, h->drop_cap, s);
-  h->win_valid = false;  // (cell entries change: the dense window is a copy of them as build_index left them)
-  launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap_eff, (int)work_need, s);
+                   h->d_work, h->d_mapctr, h->work_cap, h->d_dropped, h->drop_cap, h->d_block_key, s);
+  // (cell entries change: the dense window is kept current by the two launches that change them - WinKeep - or dropped)
+  const lii::WinKeep wk = win_keep_view(h);
+  if (wk.win) h->win_kept++;
+  else if (h->win_valid) { h->win_valid = false; h->win_dropped++; }
+  launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap_eff, (int)work_need, wk, s);
   h->map_seq = h->map_seq == 0x7FFFFFFF ? 1 : h->map_seq + 1;
   launch_ins_write(list_a, h->d_ins_e, n_list, flags_a ? nullptr : n_list_dev, extra, h->d_ins_e2, n_extra, n_extra_dev, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, h->d_dropped,
-                   h->drop_cap, s, h->h_mapflag, kMapCtrWords + 8, kMapFlagSeqAt, h->map_seq);
+                   h->drop_cap, s, h->h_mapflag, kMapCtrWords + 8, kMapFlagSeqAt, h->map_seq, wk);
   HIPCHK(h, hipGetLastError());
   // (the update's counters, its overflow flag and the list sizes of lii_map_incremental travel to the host with the last workgroup
   // of k_ins_write: see wait_mapflag / commit_map; the event behind it is for a stream in error only)
@@ -475,10 +490,11 @@ int lii_map_delete_boxes(lii_handle h, const float* boxes, int32_t n_boxes, int3
   }
   h->map_dirty = true;
   launch_box_tomb_cells(h->d_pts, h->d_cells, ne, d_boxes, n_boxes, h->d_tomb, h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s);
-  h->win_valid = false;
-  launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap_eff, ne, s);
+  const lii::WinKeep wk = win_keep_view(h);
+  if (!wk.win) h->win_valid = false;
+  launch_cell_apply(h->d_work, h->d_cells, h->d_cell_cap, h->d_pts, h->d_tomb, h->d_tp, h->d_mapctr, h->pts_cap_eff, ne, wk, s);
   launch_ins_write(h->d_pts, h->d_ins_e, 0, nullptr, nullptr, nullptr, 0, nullptr, h->d_cells, h->d_cell_cap, h->d_pts, h->d_mapctr, h->d_dropped, h->drop_cap,
-                   s);  // (re-arms the work list)
+                   s, nullptr, 0, 0, 0, wk);  // (re-arms the work list)
   rc = map_counters(h);
   if (rc != LII_OK) return rc;
   if (n_deleted) *n_deleted = n_old - h->n_map;

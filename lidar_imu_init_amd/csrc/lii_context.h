@@ -44,6 +44,9 @@ struct lii_context {
   size_t win_cap = 0;            // entries allocated
   int win_org[3] = {0, 0, 0}, win_dim[3] = {0, 0, 0};
   bool win_valid = false;
+  long long win_kept = 0, win_dropped = 0;  // LII_DIAG: in-place updates the window was kept current through / times it had to be dropped
+  bool win_keep = true;          // LII_WINDOW_KEEP=0: the first in-place update drops the window (round 6's first form) instead of keeping it current
+  unsigned long long* d_block_key = nullptr;  // packed block coordinates by block id (WinKeep::key_of_id), cells_cap_blocks entries
   bool map_tight = false;       // LII_TEST=map_tight: no spare room is provisioned (tests: forces the recovery path)
   long long map_recoveries = 0;
   float4 *d_ins = nullptr, *d_ins_c = nullptr;         // fold output / compacted inserts or host batches (M each)
@@ -97,6 +100,9 @@ struct lii_context {
   hipEvent_t ev_next = nullptr;      // the transfer of the next scan
   hipEvent_t ev_scan_free = nullptr; // the compute stream has finished with the buffer the next transfer writes to
   int n_scan_next = -1;              // >= 0: a scan is waiting in d_scan_next
+  const void* pin_cache_ptr[8] = {};  // lii_scan_upload_next: the last source buffers and whether the copy engine can read them directly
+  bool pin_cache_direct[8] = {};
+  int pin_cache_at = 0;
   bool scan_buf_idle = false;        // everything ever enqueued on the CURRENT scan buffer is known to have completed (an update's result came back behind it,
                                      // nothing touched the buffer since): lii_scan_upload_next may write the other buffer - the one that was current before the
                                      // last lii_scan_advance - without an event between the two streams
@@ -315,6 +321,7 @@ constexpr int kMapFlagSeqAt = 40;  // (h_mapflag: 64 ints; [0, kMapCtrWords + 8)
 int map_update_early(lii_handle h);  // 1: enqueued behind the passes of the update in progress, 0: not possible this time, < 0: error
 int commit_map(lii_handle h);
 int map_counters(lii_handle h, bool already_synced = false);
+lii::WinKeep win_keep_view(lii_handle h);  // the window as the update's launches keep it current (win == nullptr: nothing to keep)
 int map_gather(lii_handle h, int* n_out);
 int map_rebuild(lii_handle h, int extra_blocks);
 int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra, bool beside = false,

@@ -25,7 +25,7 @@ constexpr unsigned long long kVoxDropKey = (1ull << kVoxKeyBits) - 1ull;
 
 // device-resident counters of the in-place map (lii_map.hip): slots used at the tail of the point array, live points, occupied
 // 8x8x8 blocks, entries of the work list of the update in flight, "a capacity was exceeded" flag, events of the last fold
-constexpr int kMapCtrUsed = 0, kMapCtrValid = 1, kMapCtrBlocks = 2, kMapCtrWork = 3, kMapCtrOverflow = 4, kMapCtrEvents = 5, kMapCtrDropped = 6, kMapCtrSlots = 7, kMapCtrTicket = 15 /* k_ins_write: workgroups that are done */, kMapCtrWords = 16;
+constexpr int kMapCtrUsed = 0, kMapCtrValid = 1, kMapCtrBlocks = 2, kMapCtrWork = 3, kMapCtrOverflow = 4, kMapCtrEvents = 5, kMapCtrDropped = 6, kMapCtrSlots = 7, kMapCtrWinStale = 8 /* an in-place update touched a cell outside the dense window: the window no longer mirrors the cell tables */, kMapCtrTicket = 15 /* k_ins_write: workgroups that are done */, kMapCtrWords = 16;
 
 // 3 x 3 row-major helpers (no FMA contraction in the units that use them: the reference's rounding)
 __device__ __forceinline__ void mat3_mul(const double A[9], const double B[9], double C[9]) {
@@ -151,6 +151,25 @@ struct GridView {
   const uint2* win;
   int wx0, wy0, wz0, wnx, wny, wnz;
 };
+
+// The dense cell window kept current through an in-place map update (round 6): whatever rewrites a cell entry (k_cell_apply) or counts an
+// insert into it (k_ins_write) does the same to the window's copy.  key_of_id[id] = packed biased block coordinates of block `id` (filled by
+// k_cells_fill and by the lane of k_ins_cells that creates a block); a cell outside the box raises ctr[kMapCtrWinStale] and the host drops
+// the window with the update's counters.  win == nullptr: no window to keep.
+struct WinKeep {
+  uint2* win;
+  const unsigned long long* key_of_id;
+  int x0, y0, z0, nx, ny, nz;
+};
+__device__ __forceinline__ long long win_index_of_entry(const WinKeep& w, unsigned int e) {  // -1: outside the window
+  const unsigned long long k = w.key_of_id[e >> 9];
+  const int bb = kCellBias >> kCoarseShift;
+  const int bx = (int)(k & 0x3FFFF) - bb, by = (int)((k >> 18) & 0x3FFFF) - bb, bz = (int)((k >> 36) & 0x3FFFF) - bb;
+  const unsigned int l = e & 511u;
+  const unsigned int ux = (unsigned)(bx * 8 + (int)(l & 7u) - w.x0), uy = (unsigned)(by * 8 + (int)((l >> 3) & 7u) - w.y0), uz = (unsigned)(bz * 8 + (int)(l >> 6) - w.z0);
+  if (ux < (unsigned)w.nx && uy < (unsigned)w.ny && uz < (unsigned)w.nz) return ((long long)uz * w.ny + uy) * w.nx + ux;
+  return -1;
+}
 
 struct RegistrationBuffers {
   const float4* body;   // down-sampled LiDAR-frame points (x,y,z,t)

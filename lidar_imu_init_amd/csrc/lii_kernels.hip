@@ -102,7 +102,7 @@ __global__ void k_table_clear(BlockEntry* blocks, unsigned int cap) {
 
 // cells must be zero-filled for the n_blocks * 512 entries in use
 __global__ void k_cells_fill(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ ranks, int n,
-                             BlockEntry* blocks, unsigned int block_mask, uint2* __restrict__ cells) {
+                             BlockEntry* blocks, unsigned int block_mask, uint2* __restrict__ cells, unsigned long long* __restrict__ key_of_id) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned long long key = keys[i];
@@ -116,6 +116,7 @@ __global__ void k_cells_fill(const unsigned long long* __restrict__ keys, const 
   if (is_end) cell[1] = (unsigned)(i + 1);
   if (is_start && ((i == 0) || ((keys[i - 1] >> 9) != (key >> 9)))) {
     const unsigned long long bk = key >> 9;
+    if (key_of_id) key_of_id[id] = bk;  // (WinKeep: the block's coordinates by its id)
     unsigned int slot = hash_block((int)(bk & 0x3FFFF), (int)((bk >> 18) & 0x3FFFF), (int)((bk >> 36) & 0x3FFFF)) & block_mask;
     while (true) {
       unsigned long long prev = atomicCAS(&blocks[slot].key, kEmptyKey, bk);
@@ -1916,8 +1917,8 @@ void launch_table_clear(BlockEntry* blocks, unsigned int cap, hipStream_t s) {
   hipLaunchKernelGGL(k_table_clear, dim3(nblk((int)cap, 256)), dim3(256), 0, s, blocks, cap);
 }
 void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks, int n, BlockEntry* blocks,
-                       unsigned int block_mask, uint2* cells, hipStream_t s) {
-  if (n > 0) hipLaunchKernelGGL(k_cells_fill, dim3(nblk(n, 256)), dim3(256), 0, s, keys, ranks, n, blocks, block_mask, cells);
+                       unsigned int block_mask, uint2* cells, unsigned long long* key_of_id, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(k_cells_fill, dim3(nblk(n, 256)), dim3(256), 0, s, keys, ranks, n, blocks, block_mask, cells, key_of_id);
 }
 int register_blocks(int n) { return nblk(n, kBlock); }
 #ifdef LII_FALLBACK_TRACE

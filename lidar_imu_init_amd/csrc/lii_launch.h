@@ -30,7 +30,7 @@ void launch_table_clear(BlockEntry* blocks, unsigned int cap, hipStream_t s);
 void launch_win_bbox(const BlockEntry* blocks, unsigned int cap, unsigned int* box, hipStream_t s);
 void launch_win_fill(const BlockEntry* blocks, unsigned int cap, const uint2* cells, uint2* win, const int org[3], const int dim[3], hipStream_t s);
 void launch_cells_fill(const unsigned long long* keys, const unsigned int* ranks, int n, BlockEntry* blocks,
-                       unsigned int block_mask, uint2* cells, hipStream_t s);
+                       unsigned int block_mask, uint2* cells, unsigned long long* key_of_id, hipStream_t s);
 // registration
 // (`pose`: device memory on every path - a host-driven pass uploads it first)
 // epoch: the number of this search launch (> 0, RegistrationBuffers::flag_*) and of the fit launch behind it; 0: no list of unfinished queries
@@ -178,12 +178,12 @@ void launch_add_fold_hashed(const float4* add_pts, int n, const int* n_dev, floa
 // in-place map update (lii_map.hip)
 void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, const float4* list2, int n2, const int* n2_dev, unsigned int* ins_e2,
                       BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp,
-                      unsigned int* work, int* ctr, unsigned int work_cap, float4* dropped, unsigned int drop_cap, hipStream_t s);
+                      unsigned int* work, int* ctr, unsigned int work_cap, float4* dropped, unsigned int drop_cap, unsigned long long* key_of_id, hipStream_t s);
 void launch_cell_apply(const unsigned int* work, uint2* cells, unsigned int* cell_cap, float4* pts, unsigned char* tomb, unsigned int* tp, int* ctr,
-                       unsigned int pts_cap, int launch_bound, hipStream_t s);
+                       unsigned int pts_cap, int launch_bound, const WinKeep& wk, hipStream_t s);
 void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, const float4* list2, const unsigned int* ins_e2, int n2, const int* n2_dev,
                       uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, float4* dropped, unsigned int drop_cap, hipStream_t s,
-                      int* host = nullptr, int n_words = 0, int seq_at = 0, int seq = 0)  /* host != nullptr: the last workgroup publishes the counters there */;
+                      int* host, int n_words, int seq_at, int seq, const WinKeep& wk)  /* host != nullptr: the last workgroup publishes the counters there */;
 void launch_cell_caps(const uint2* cells, int n_entries, unsigned int* caps, hipStream_t s);
 void launch_spread(const float4* src, uint2* cells, unsigned int* cell_cap, const unsigned int* caps, const unsigned int* capsum, int n_entries,
                    float4* dst, int* ctr, int n_valid, int n_blocks, hipStream_t s);

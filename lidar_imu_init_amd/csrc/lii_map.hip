@@ -559,7 +559,7 @@ __global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int*
                             const float4* __restrict__ list2, int n2, const int* __restrict__ n2_dev, unsigned int* __restrict__ ins_e2,
                             BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* __restrict__ ins_e,
                             unsigned int* __restrict__ tp, unsigned int* __restrict__ work, int* __restrict__ ctr, unsigned int work_cap,
-                            float4* __restrict__ dropped, unsigned int drop_cap) {
+                            float4* __restrict__ dropped, unsigned int drop_cap, unsigned long long* __restrict__ key_of_id) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) {
     i -= n;
@@ -600,6 +600,7 @@ __global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int*
         // one does (leaving `pad` at 0 would have them wait forever; the host rebuilds with more room).
         const bool got_table = (unsigned int)nid + 1u < tables_cap;
         if (!got_table) ctr[kMapCtrOverflow] = 1;
+        if (got_table && key_of_id) key_of_id[nid] = bk;  // (WinKeep; read by the launches behind this one)
         __hip_atomic_store(&blocks[sl].id, got_table ? (unsigned int)nid : tables_cap - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&blocks[sl].pad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         id = got_table ? nid : -1;
@@ -634,7 +635,7 @@ __global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int*
 
 __global__ void k_cell_apply(const unsigned int* __restrict__ work, uint2* __restrict__ cells, unsigned int* __restrict__ cell_cap,
                              float4* __restrict__ pts, unsigned char* __restrict__ tomb, unsigned int* __restrict__ tp, int* __restrict__ ctr,
-                             unsigned int pts_cap, int launch_bound) {
+                             unsigned int pts_cap, int launch_bound, WinKeep wk) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   const int n_work = ctr[kMapCtrWork];
   const bool valid = w < n_work && w < launch_bound;
@@ -691,6 +692,11 @@ __global__ void k_cell_apply(const unsigned int* __restrict__ work, uint2* __res
     }
   }
   cells[e] = make_uint2(first, first + alive);
+  if (wk.win) {  // (uniform) the window's copy of the entry
+    const long long wi = win_index_of_entry(wk, e);
+    if (wi >= 0) wk.win[wi] = make_uint2(first, first + alive);
+    else __hip_atomic_store(&ctr[kMapCtrWinStale], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   gone = (int)deleted;
   }
   wave_atomic_add_all(&ctr[kMapCtrValid], -gone);
@@ -699,7 +705,7 @@ __global__ void k_cell_apply(const unsigned int* __restrict__ work, uint2* __res
 __global__ void k_ins_write(const float4* __restrict__ list, const unsigned int* __restrict__ ins_e, int n, const int* __restrict__ n_dev,
                             const float4* __restrict__ list2, const unsigned int* __restrict__ ins_e2, int n2, const int* __restrict__ n2_dev,
                             uint2* __restrict__ cells, const unsigned int* __restrict__ cell_cap, float4* __restrict__ pts, int* __restrict__ ctr,
-                            float4* __restrict__ dropped, unsigned int drop_cap, int* __restrict__ host, int n_words, int seq_at, int seq) {
+                            float4* __restrict__ dropped, unsigned int drop_cap, int* __restrict__ host, int n_words, int seq_at, int seq, WinKeep wk) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   // (the counters this launch writes are read again by its LAST workgroup, on whichever XCD that runs: atomic stores, not plain ones)
   if (i == 0) __hip_atomic_store(&ctr[kMapCtrWork], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the work list has been consumed (k_cell_apply ran before this launch)
@@ -720,6 +726,10 @@ __global__ void k_ins_write(const float4* __restrict__ list, const unsigned int*
       if (slot < cell_cap[e]) {
         pts[slot] = make_float4(p.x, p.y, p.z, 0.f);
         added = 1;
+        if (wk.win) {  // (uniform) the window counts the insert as the cell table did (k_cell_apply left the two entries equal)
+          const long long wi = win_index_of_entry(wk, e);
+          if (wi >= 0) atomicAdd(reinterpret_cast<unsigned int*>(&wk.win[wi]) + 1, 1u);
+        }
       } else {
         atomicSub(reinterpret_cast<unsigned int*>(&cells[e]) + 1, 1u);
         __hip_atomic_store(&ctr[kMapCtrOverflow], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -814,24 +824,24 @@ __global__ void k_box_tomb_cells(const float4* __restrict__ pts, const uint2* __
 static inline int nblk(int n, int b) { return (n + b - 1) / b; }
 void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, const float4* list2, int n2, const int* n2_dev, unsigned int* ins_e2,
                       BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp,
-                      unsigned int* work, int* ctr, unsigned int work_cap, float4* dropped, unsigned int drop_cap, hipStream_t s) {
+                      unsigned int* work, int* ctr, unsigned int work_cap, float4* dropped, unsigned int drop_cap, unsigned long long* key_of_id, hipStream_t s) {
   if (n < 0) n = 0;
   if (n2 < 0) n2 = 0;
   if (n + n2 > 0)
     hipLaunchKernelGGL(k_ins_cells, dim3(nblk(n + n2, 256)), dim3(256), 0, s, list, flags, n, n_dev, list2, n2, n2_dev, ins_e2, blocks, mask, inv_cs, tables_cap,
-                       ins_e, tp, work, ctr, work_cap, dropped, drop_cap);
+                       ins_e, tp, work, ctr, work_cap, dropped, drop_cap, key_of_id);
 }
 void launch_cell_apply(const unsigned int* work, uint2* cells, unsigned int* cell_cap, float4* pts, unsigned char* tomb, unsigned int* tp, int* ctr,
-                       unsigned int pts_cap, int launch_bound, hipStream_t s) {
-  if (launch_bound > 0) hipLaunchKernelGGL(k_cell_apply, dim3(nblk(launch_bound, 128)), dim3(128), 0, s, work, cells, cell_cap, pts, tomb, tp, ctr, pts_cap, launch_bound);
+                       unsigned int pts_cap, int launch_bound, const WinKeep& wk, hipStream_t s) {
+  if (launch_bound > 0) hipLaunchKernelGGL(k_cell_apply, dim3(nblk(launch_bound, 128)), dim3(128), 0, s, work, cells, cell_cap, pts, tomb, tp, ctr, pts_cap, launch_bound, wk);
 }
 void launch_ins_write(const float4* list, const unsigned int* ins_e, int n, const int* n_dev, const float4* list2, const unsigned int* ins_e2, int n2, const int* n2_dev,
                       uint2* cells, const unsigned int* cell_cap, float4* pts, int* ctr, float4* dropped, unsigned int drop_cap, hipStream_t s,
-                      int* host, int n_words, int seq_at, int seq) {
+                      int* host, int n_words, int seq_at, int seq, const WinKeep& wk) {
   if (n < 0) n = 0;
   if (n2 < 0) n2 = 0;
   hipLaunchKernelGGL(k_ins_write, dim3(nblk(n + n2 > 0 ? n + n2 : 1, 256)), dim3(256), 0, s, list, ins_e, n, n_dev, list2, ins_e2, n2, n2_dev, cells, cell_cap, pts,
-                     ctr, dropped, drop_cap, host, n_words, seq_at, seq);
+                     ctr, dropped, drop_cap, host, n_words, seq_at, seq, wk);
 }
 void launch_cell_caps(const uint2* cells, int n_entries, unsigned int* caps, hipStream_t s) {
   if (n_entries > 0) hipLaunchKernelGGL(k_cell_caps, dim3(nblk(n_entries, 256)), dim3(256), 0, s, cells, n_entries, caps);
