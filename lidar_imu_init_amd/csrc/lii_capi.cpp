@@ -428,7 +428,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   std::memset(h->h_mapflag, 0, 256);
   CK(hipEventCreateWithFlags(&h->ev_lists, hipEventDisableTiming));
   CK(hipMemset(h->d_counter, 0, 16));
-  h->partial_stride = register_blocks(int(N)) + lii::kCompletionBlocks + 8;  // (+ the columns of the fit launches' completion workgroups)
+  h->partial_stride = register_blocks(int(N)) + std::max(lii::kCompletionBlocks, lii::kCompletionBlocksPre) + 8;  // (+ the columns of the fit launches' completion workgroups)
   CK(dmalloc(&h->d_flags, 4 + 16 * lii::kFlagCap));  // 2 counters (+ 2 pad), 2 x kFlagCap entries of two float4
   CK(hipMemset(h->d_flags, 0, sizeof(int) * (4 + 16 * lii::kFlagCap)));
   CK(dmalloc(&h->d_partials, size_t(h->partial_stride) * kNormalEq));

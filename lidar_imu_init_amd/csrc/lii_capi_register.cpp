@@ -43,7 +43,7 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
   launch_fit_reduce(g, rb, h->d_pose, h->d_ctrl, search ? 1 : 0, imu_en ? 1 : 0, h->cfg.plane_threshold,
                     h->cfg.laser_point_cov_inv, h->stream, epoch);
   if (prof) HIPCHK(h, hipEventRecord(h->prof.ev[1], h->stream));
-  launch_reduce91(rb, h->d_out91, h->d_ctrl, 1, h->stream);
+  launch_reduce91(rb, h->d_out91, h->d_ctrl, 1, h->stream, epoch);
   if (prof) HIPCHK(h, hipEventRecord(h->prof.ev[2], h->stream));
   if (search) h->have_search = true;
   if (h->net.comm) {
@@ -150,10 +150,10 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     launch_fit_reduce(g, rb, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s, epoch);
     if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_SOLVE, it); if (r != LII_OK) return r; }
     if (!h->net.comm) {  // single GPU or node-local mailbox: final sum (+ exchange) and solve in one launch
-      launch_reduce_solve(rb, h->d_gran, h->d_ctrl, h->h_res, mailbox_view(h), s);
+      launch_reduce_solve(rb, h->d_gran, h->d_ctrl, h->h_res, mailbox_view(h), s, epoch);
       return LII_OK;
     }
-    launch_reduce91(rb, h->d_out91, h->d_ctrl, -1, s);
+    launch_reduce91(rb, h->d_out91, h->d_ctrl, -1, s, epoch);
     // every rank enqueues the same number of all-reduces; a pass that is skipped on the device re-sums the
     // unchanged local buffer on all ranks alike, so the ranks stay in lock-step without a host decision
     ncclResult_t r = ncclAllReduce(h->d_out91, h->d_out91 + 128, kNormalEq, ncclDouble, ncclSum, h->net.comm, s);

@@ -195,6 +195,13 @@ constexpr int kFlagCap = 256;          // listed queries a fit launch hands to i
 #ifndef LII_COMPLETION_BLOCKS
 #define LII_COMPLETION_BLOCKS 32
 #endif
+#ifndef LII_COMPLETION_BLOCKS_PRE
+#define LII_COMPLETION_BLOCKS_PRE 96
+#endif
+// (a fit launch BEHIND A SEARCH LAUNCH that lists its unfinished queries - epoch > 0 - gets kCompletionBlocksPre of them: up to that many listed
+// queries are one per workgroup, finished by its four wavefronts together; the launches on cached planes keep kCompletionBlocks, which only write a zero column)
+constexpr int kCompletionBlocksPre = LII_COMPLETION_BLOCKS_PRE;
+__host__ __device__ inline int completion_blocks(int epoch) { return epoch > 0 ? kCompletionBlocksPre : LII_COMPLETION_BLOCKS; }
 constexpr int kCompletionBlocks = LII_COMPLETION_BLOCKS;  // ... of which there are this many, behind the workgroups of the cloud; each writes one more column of partial sums
 
 // The block of the down-sampled cloud this rank registers: first index and size.  Every rank holds the WHOLE cloud (the

@@ -599,11 +599,11 @@ void launch_mailbox_allreduce(double* out91, const MailboxView& mb, hipStream_t 
   hipLaunchKernelGGL(k_mailbox_allreduce, dim3(1), dim3(64), 0, s, out91, mb);
 }
 void launch_reduce_solve(const RegistrationBuffers& rb, unsigned long long* gran, IekfCtrl* c, IekfResult* res, const MailboxView& mb,
-                         hipStream_t s) {
+                         hipStream_t s, int epoch) {
   const int bound = rb.shard_world > 1 ? (rb.n + rb.shard_world - 1) / rb.shard_world + 1 : rb.n;  // as launch_fit_reduce
   int nb = (bound + kBlock - 1) / kBlock;
   if (nb < 1) nb = 1;
-  nb += kCompletionBlocks;  // (the columns of the fit launch's completion workgroups)
+  nb += completion_blocks(epoch);  // (the columns of the fit launch's completion workgroups: as many as THAT launch had)
   hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq + 1), dim3(kSolveThreads), 0, s, rb.partials, nb, rb.partial_stride, gran, c, res, mb);
 }
 // A parked loop goes on with the launches the host has put behind this one (plan_mask, as IekfCtrl::plan_mask).

@@ -1141,12 +1141,16 @@ __device__ __forceinline__ void far_list_trip(const GridView& g, unsigned int* _
 // seeded: the search pass has already measured every point of the 3 x 3 x 3 cells around the query (kCovered) - its list
 // (seed_d: the distance of entry `lane` on lanes 0..4, inf where the list ends) stands in for pass 1; a seeded entry that
 // survives comes back as index -(2 + its place in the list).
+template <int nparts = 1>
 __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, float wy, float wz, bool has5, float list_d, bool seeded,
                                                   float seed_d, float (&od)[5], int (&oi)[5], unsigned int* __restrict__ far_list /* [kFarCap] LDS, this wavefront's */
 #ifdef LII_FALLBACK_TRACE
                                                   , long long fb_t0, int* fb_kind
 #endif
-                                                  ) {
+                                                  , int part = 0) {
+  // part / nparts (uniform): FOUR wavefronts finish one query together (complete_one_coop) - every one of them runs this routine, the head
+  // and the inner pass alike (so they agree on the bound), and takes every fourth pair of cell entries of the far pass' rows; part 0 also
+  // carries the inner result.  The four results are joined by the caller.
   const int lane = threadIdx.x & 63;
   // (the block probes below need the query only: they are issued before the search pass's list - list_d: entry `lane`'s distance
   // on lanes 0..4 - is looked at)
@@ -1228,7 +1232,7 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
   {  // the inner result re-enters as five one-element lists (lanes 0..4)
     const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
     const int ii = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
-    if (lane < 5 && ii != -1) { k.d0 = dd; k.i0 = ii; }
+    if (part == 0 && lane < 5 && ii != -1) { k.d0 = dd; k.i0 = ii; }
   }
   // Four rounds of 64 cells at a time: which cells survive (inside the ball, outside the inner cube, closer than bound1) does
   // not depend on the candidates found on the way, so the four cell entries of a lane are fetched together and their
@@ -1239,7 +1243,49 @@ __device__ __forceinline__ void knn_fallback_wave(const GridView& g, float wx, f
   // window covers them all and a block of margin - checked all the same, the row loads below rely on it)
   const bool rows_ok = windowed && total > 0 && ix0 - 1 >= g.wx0 && ix1 + 1 < g.wx0 + g.wnx && iy0 >= g.wy0 && iy1 < g.wy0 + g.wny && iz0 >= g.wz0 &&
                        iz1 < g.wz0 + g.wnz;
-  if (rows_ok) {
+  if (rows_ok && nparts == 4) {
+    // ROW TRIPS, a quarter of every row: the pairs of entries t = part, part + 4 of the seven a row trip reads (see below) - a lane's
+    // instruction count, which is what this pass costs (profiles/r06_edge.md), falls to a third, and every wavefront scans a list of its own.
+    constexpr int NV = 7, NVP = 2;
+    const int nrows = ny * nz;
+    for (int r0 = 0; r0 < nrows; r0 += 64) {                 // uniform trip counts
+      const int r = r0 + lane;
+      const bool in_row = r < nrows;
+      const int rz = (in_row ? r : 0) / ny, ry = (in_row ? r : 0) - rz * ny;
+      const int iyy = iy0 + ry, izz = iz0 + rz;
+      const float gy = axis_gap(wy, iyy, cs, eps), gz = axis_gap(wz, izz, cs, eps);
+      const float gyz = gy * gy + gz * gz;
+      const bool row_ok = in_row && !(gyz > bound1);
+      const bool yz_inner = abs(iyy - cy) <= 1 && abs(izz - cz) <= 1;
+      const int xs0 = ix0 - ((ix0 - g.wx0) & 1);
+      for (int xs = xs0; xs <= ix1; xs += 2 * NV) {          // uniform
+        const size_t base = win_entry(xs, iyy, izz);
+        bool act[2 * NVP];
+        uint4 v[NVP];
+#pragma unroll
+        for (int tt = 0; tt < NVP; tt++) {
+          const int t = tt * 4 + part;                       // (uniform)
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) {
+            const int ixx = xs + 2 * t + hh;
+            const bool x_in = t < NV && ixx >= ix0 && ixx <= ix1, x_inner = abs(ixx - cx) <= 1;
+            const float gx = axis_gap(wx, ixx, cs, eps);
+            act[2 * tt + hh] = row_ok && x_in && !(yz_inner && x_inner) && !(gyz + gx * gx > bound1);  // (the same sum as the whole-row form)
+          }
+          v[tt] = *reinterpret_cast<const uint4*>(g.win + ((act[2 * tt] || act[2 * tt + 1]) ? base + 2 * (size_t)t : (size_t)0));
+        }
+        uint2 rr[2 * NVP];
+#pragma unroll
+        for (int tt = 0; tt < NVP; tt++) {
+          rr[2 * tt] = act[2 * tt] ? make_uint2(v[tt].x, v[tt].y) : make_uint2(0u, 0u);
+          rr[2 * tt + 1] = act[2 * tt + 1] ? make_uint2(v[tt].z, v[tt].w) : make_uint2(0u, 0u);
+        }
+        far_list_trip<2 * NVP>(g, far_list, n_far, rr, wx, wy, wz, bound1, k);
+      }
+    }
+  } else if (nparts > 1 && part != 0) {
+    // (no window: the far pass over the hashed tables is not split - part 0 walks it alone, the others have nothing to add)
+  } else if (rows_ok) {
     // ROW TRIPS (round 6).  In the window the cells of a row (x running) lie next to each other: a lane takes one (y, z) row of the
     // cube and reads it with 16-byte loads, two cell entries each - the 11 x 11 x 5 cube of a query at the map's edge is 55 rows, ONE
     // trip of seven loads per lane, where the column walk over the hashed tables took three trips of eight (phase stamps,
@@ -1459,6 +1505,54 @@ __device__ __forceinline__ void complete_one(const GridView& g, const Registrati
   fb_add(fb_kind + 5, wall_clock64() - fb_t5);
 #endif
 }
+// ONE query finished by the four wavefronts of a workgroup together (round 6; a completion workgroup that holds a single query - up to
+// kCompletionBlocksPre listed queries are dealt one per workgroup).  Every wavefront runs knn_fallback_wave on its quarter of the far pass;
+// the four results (five candidates each, part 0's with the inner list) meet in LDS and the first wavefront selects the five nearest and
+// stores the list as complete_one does.  Every lane of the workgroup must call it.
+struct CoopMerge { float d[20]; int i[20]; };
+__device__ __forceinline__ void complete_one_coop(const GridView& g, const RegistrationBuffers& rb, int qi, int c00, float wx, float wy, float wz,
+                                                  unsigned int* __restrict__ far_lists, CoopMerge& mg, float4* __restrict__ lds_nb,
+                                                  int* __restrict__ lds_found, int mark) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = c00 & 0xFF;
+  const bool seeded = (c00 & kCovered) != 0;  // uniform
+  const float4 sv = lane < 5 ? rb.nbr[(size_t)lane * rb.cap + qi] : make_float4(0.f, 0.f, 0.f, __builtin_inff());
+  float od[5];
+  int oi[5];
+#ifdef LII_FALLBACK_TRACE
+  int fb_kind = 0;
+  knn_fallback_wave<4>(g, wx, wy, wz, c0 == kMatch, sv.w, seeded, lane < c0 ? sv.w : __builtin_inff(), od, oi, far_lists + wave * kFarCap, wall_clock64(), &fb_kind, wave);
+#else
+  knn_fallback_wave<4>(g, wx, wy, wz, c0 == kMatch, sv.w, seeded, lane < c0 ? sv.w : __builtin_inff(), od, oi, far_lists + wave * kFarCap, wave);
+#endif
+  if (lane < 5) {
+    mg.d[wave * 5 + lane] = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
+    mg.i[wave * 5 + lane] = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  Knn5 k;
+  k.d0 = k.d1 = k.d2 = k.d3 = k.d4 = __builtin_inff();
+  k.i0 = k.i1 = k.i2 = k.i3 = k.i4 = -1;
+  if (lane < 20) { k.d0 = mg.d[lane]; k.i0 = mg.i[lane]; }  // twenty one-element lists: part 0's entries in the lowest lanes (they win ties, as in one wavefront)
+  wave_select5(k, od, oi);
+  const int idx = lane == 0 ? oi[0] : (lane == 1 ? oi[1] : (lane == 2 ? oi[2] : (lane == 3 ? oi[3] : oi[4])));
+  const float dd = lane == 0 ? od[0] : (lane == 1 ? od[1] : (lane == 2 ? od[2] : (lane == 3 ? od[3] : od[4])));
+  const int from = idx <= -2 ? -(idx + 2) : 0;  // a seeded entry that stayed in the list: its point is in the lane that loaded it
+  const float kx = __shfl(sv.x, from), ky = __shfl(sv.y, from), kz = __shfl(sv.z, from);
+  if (lane < 5) {
+    float4 v = make_float4(0, 0, 0, 0);
+    if (idx >= 0) v = g.pts[idx];
+    else if (idx <= -2) v = make_float4(kx, ky, kz, 0.f);
+    v.w = dd;
+    rb.nbr[(size_t)lane * rb.cap + qi] = v;
+    if (lds_nb) lds_nb[lane] = v;
+  } else if (lane == 5) {
+    const int found = (oi[0] != -1) + (oi[1] != -1) + (oi[2] != -1) + (oi[3] != -1) + (oi[4] != -1);
+    rb.nbr_count[qi] = found | mark;
+    if (lds_found) *lds_found = found;
+  }
+}
 constexpr int kHandOver = 64;  // queries of a completion workgroup whose finished lists reach the fitting lane through LDS (usually all: 2 ... 8 per workgroup)
 struct NeedyShared {
   int point[kBlock], count[kBlock];
@@ -1467,6 +1561,7 @@ struct NeedyShared {
   float4 nb[kHandOver][5], body[kHandOver];
   int found[kHandOver];
   int n;
+  CoopMerge merge;
 };
 // `count`, `w`: nbr_count and world point of the calling lane's query (loaded by the caller, together).
 // far_lists: kBlock / 64 lists of kFarCap words (LDS), one per wavefront
@@ -1533,9 +1628,10 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
   // them up, depends on the queries' indices alone: the sums stay deterministic.
   // (they come FIRST in the grid - a launch with more workgroups than the chip holds at once must not start them last - and their
   // number is a multiple of eight: the workgroups of the cloud keep their XCDs)
-  static_assert(kCompletionBlocks % 8 == 0, "XCD mapping of the cloud's workgroups");
-  const bool completion_wg = (int)blockIdx.x < kCompletionBlocks;
-  const int cloud_block = (int)blockIdx.x - kCompletionBlocks;
+  static_assert(kCompletionBlocks % 8 == 0 && kCompletionBlocksPre % 8 == 0, "XCD mapping of the cloud's workgroups");
+  const int n_comp = completion_blocks(epoch);  // (uniform: as the host sized the grid)
+  const bool completion_wg = (int)blockIdx.x < n_comp;
+  const int cloud_block = (int)blockIdx.x - n_comp;
   // What a lane reads of its point whatever the pass turns out to be - body point, cached plane, selection flag, world point,
   // neighbour count - is requested BEFORE the flags, the pose and the cloud size have arrived (an unsharded cloud: the point's
   // index does not depend on them; the index is clamped, a lane beyond the cloud discards what it read): one dependent round
@@ -1642,13 +1738,13 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
       __syncthreads();
       int rank_all = 0;
       for (int u = 0; u < n_flagged; u++) rank_all += sh_needy.key[u] < qx ? 1 : 0;  // (uniform trip count, broadcast reads)
-      const bool mine = listed && (rank_all % kCompletionBlocks) == j;
-      const int m = n_flagged > j ? (n_flagged - j + kCompletionBlocks - 1) / kCompletionBlocks : 0;
+      const bool mine = listed && (rank_all % n_comp) == j;
+      const int m = n_flagged > j ? (n_flagged - j + n_comp - 1) / n_comp : 0;
       float4 my_body = make_float4(0.f, 0.f, 0.f, 0.f);
       if (mine) my_body = rb.body[qx];
       if (threadIdx.x == 0) sh_needy.n = m;
       if (mine) {
-        const int rank = rank_all / kCompletionBlocks;
+        const int rank = rank_all / n_comp;
         sh_needy.aux[rank] = qx;
         sh_needy.count[rank] = l1x;
         sh_needy.w[rank][0] = l0.x; sh_needy.w[rank][1] = l0.y; sh_needy.w[rank][2] = l0.z;
@@ -1656,10 +1752,17 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
       }
       __syncthreads();
       const int wave = threadIdx.x >> 6;
-      for (int e = wave; e < m; e += kBlock / 64)  // one wavefront per query
-        complete_one(g, rb, sh_needy.aux[e], sh_needy.count[e], sh_needy.w[e][0], sh_needy.w[e][1], sh_needy.w[e][2],
-                     reinterpret_cast<unsigned int*>(&sh.row[0][0]) + wave * kFarCap, e < kHandOver ? &sh_needy.nb[e][0] : nullptr,
-                     e < kHandOver ? &sh_needy.found[e] : nullptr, kDone);
+      // (the four-wavefront form only in the launch that has the registers and runs behind a search: the other three instances of this
+      // kernel keep their code and their register count - the 3-wavefronts-per-SIMD ones would spill 20 - 40 registers)
+      if (POSE_V && PRE && m == 1) {  // (uniform) the workgroup's one query: its four wavefronts together
+        complete_one_coop(g, rb, sh_needy.aux[0], sh_needy.count[0], sh_needy.w[0][0], sh_needy.w[0][1], sh_needy.w[0][2],
+                          reinterpret_cast<unsigned int*>(&sh.row[0][0]), sh_needy.merge, &sh_needy.nb[0][0], &sh_needy.found[0], kDone);
+      } else {
+        for (int e = wave; e < m; e += kBlock / 64)  // one wavefront per query
+          complete_one(g, rb, sh_needy.aux[e], sh_needy.count[e], sh_needy.w[e][0], sh_needy.w[e][1], sh_needy.w[e][2],
+                       reinterpret_cast<unsigned int*>(&sh.row[0][0]) + wave * kFarCap, e < kHandOver ? &sh_needy.nb[e][0] : nullptr,
+                       e < kHandOver ? &sh_needy.found[e] : nullptr, kDone);
+      }
       __syncthreads();  // the completed lists are visible to the lanes that fit them (workgroup-scope release / acquire)
 #ifdef LII_FALLBACK_TRACE
       if (threadIdx.x == 0 && m > 0) {
@@ -1967,7 +2070,7 @@ void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const P
   const int nb_pad = ((nb + 7) / 8) * 8;
   // (four wavefronts per workgroup on 1024 SIMDs: up to 512 workgroups are two wavefronts per SIMD at most)
   // (+ the completion workgroups behind the workgroups of the cloud)
-  const dim3 grid(nb_pad + kCompletionBlocks), block(kBlock);
+  const dim3 grid(nb_pad + completion_blocks(epoch)), block(kBlock);
   const bool pre = epoch > 0;  // behind a search launch that lists its unfinished queries: the lanes request their neighbour lists at the head
   if (nb <= 512) {
     if (pre) hipLaunchKernelGGL((k_fit_reduce<true, true>), grid, block, 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb, epoch);
@@ -1977,10 +2080,10 @@ void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const P
     else hipLaunchKernelGGL((k_fit_reduce<false, false>), grid, block, 0, s, g, rb, pose, ctrl, forced, imu_en, plane_thr, rinv, nb, epoch);
   }
 }
-void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s) {
+void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s, int epoch) {
   int nb = nblk(shard_bound(rb), kBlock);
   if (nb < 1) nb = 1;
-  nb += kCompletionBlocks;  // (the columns of the fit launch's completion workgroups)
+  nb += completion_blocks(epoch);  // (the columns of the fit launch's completion workgroups: as many as THAT launch had)
   hipLaunchKernelGGL(k_reduce91, dim3(kNormalEq), dim3(256), 0, s, rb.partials, nb, rb.partial_stride, out91, ctrl, forced, rb);
 }
 void launch_calib_eval(int stage, const double* imu, const double* lidar, int n, const double* params, double* out,

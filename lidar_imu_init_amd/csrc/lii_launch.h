@@ -45,9 +45,9 @@ void fb_trace_read(unsigned long long out[32]);  // (measurement builds: the com
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s);
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s, int epoch);
-void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s);
+void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s, int epoch);  // epoch: of the fit launch whose columns it sums
 void launch_reduce_solve(const RegistrationBuffers& rb, unsigned long long* gran, IekfCtrl* c, IekfResult* res, const MailboxView& mb,
-                         hipStream_t s);
+                         hipStream_t s, int epoch);
 void launch_mailbox_allreduce(double* out91, const MailboxView& mb, hipStream_t s);
 // node-local mailbox (lii_mailbox.cpp)
 struct MailboxHost {
