@@ -252,7 +252,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   // the next lii_scan_register writes.
   if (h->pre.want_dev && !h->net.comm && h->net.n_ranks <= 1 && !h->prof.profiling && !graph_mode && !h->map_async) {
     lii::GateState* gst = h->pre.state;
-    h->pre.seq = (h->pre.seq + 1) & 0x3FFFFFFFFFFFFFFFull;
+    h->pre.seq = (h->pre.seq + 1) & 0x003FFFFFFFFFFFFFull;  // (seq << 2 stays below the tag's top byte)
     __atomic_store_n(&gst->word, (h->pre.seq << 2) | lii::kGateArmed, __ATOMIC_RELEASE);
     h->pre.scan_dev = h->pre.want_dev; h->pre.n = h->pre.want_n; h->pre.leaf = h->pre.want_leaf; h->pre.late = h->pre.want_late;
     h->pre.fuse = fuse_filter(h, h->pre.leaf);
@@ -582,7 +582,12 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
         __builtin_ia32_sfence();
         for (int l = 1; l < n_lines; l++) rec[8 * l + 7] = tag;
         __builtin_ia32_sfence();
-        rec[7] = tag;
+        {  // (line 0's tag carries K in its top byte: lii_scan.hip, k_deskew_imu_gated)
+          const unsigned long long tag0 = tagw | ((unsigned long long)K << 56);
+          double t0d;
+          std::memcpy(&t0d, &tag0, 8);
+          rec[7] = t0d;
+        }
         __builtin_ia32_sfence();
       } else {
         use_pre = false;

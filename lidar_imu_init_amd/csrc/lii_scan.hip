@@ -420,7 +420,7 @@ __device__ __forceinline__ unsigned long long gate_load_u64(const void* p) {  //
 template <bool FUSE>
 __global__ __launch_bounds__(256) void k_deskew_imu_gated(DeskewIo io, DeskewGate gate) {
   __shared__ unsigned long long s_verdict;
-  __shared__ int s_bad;
+  __shared__ int s_bad, s_k;
   __shared__ double s_rec[7 * kGateLines];
   const unsigned long long armed = (gate.seq << 2) | kGateArmed, go = (gate.seq << 2) | kGateGo, cancel = (gate.seq << 2) | kGateCancel;
   const bool gate_wg = blockIdx.x == 0;
@@ -435,7 +435,10 @@ __global__ __launch_bounds__(256) void k_deskew_imu_gated(DeskewIo io, DeskewGat
     unsigned long long verdict = go;
     unsigned int spins = 0;
     for (;;) {
-      if (gate_load_u64(gate.rec + 7) == go) break;  // line 0's tag: the record is complete
+      // line 0's tag: the record is complete.  (That one tag also carries K in its top byte - the host writes it last, so the workgroup
+      // knows how many lines to fetch without another load past the caches.)
+      const unsigned long long t0w = gate_load_u64(gate.rec + 7);
+      if ((t0w & 0x00FFFFFFFFFFFFFFull) == go) { s_k = (int)(t0w >> 56); break; }
       ++spins;
       if (gate_wg) {
         const unsigned long long w = gate_load_u64(&gate.host->word);
@@ -467,12 +470,12 @@ __global__ __launch_bounds__(256) void k_deskew_imu_gated(DeskewIo io, DeskewGat
     return;
   }
   if (in_range && gate.late_load) P = io.in[i];
-  // the record -> LDS.  K sits in line 0 (whose tag has been seen: read past the caches once more, it is this record's)
-  const int K = (int)__longlong_as_double((long long)gate_load_u64(gate.rec));
+  // the record -> LDS
+  const int K = s_k;
   const int n_lines = (25 + 22 * (K < 2 ? 2 : (K > kGateMaxPoses ? kGateMaxPoses : K)) + 6) / 7;
   for (int e = threadIdx.x; e < 8 * n_lines; e += 256) {
     const double v = gate.rec[e];
-    if ((e & 7) == 7) { if ((unsigned long long)__double_as_longlong(v) != go) s_bad = 1; }
+    if ((e & 7) == 7) { if (((unsigned long long)__double_as_longlong(v) & 0x00FFFFFFFFFFFFFFull) != go) s_bad = 1; }
     else s_rec[(e >> 3) * 7 + (e & 7)] = v;
   }
   __syncthreads();
