@@ -1,4 +1,5 @@
-"""Point sharding of one scan across ranks: every rank voxel-filters the WHOLE scan (replicated), the
+"""(test support, not product: the library splits a scan itself - lii_comm_set_partition - and this restates that split on the host for tests/test_sharding_gloo.py)
+Point sharding of one scan across ranks: every rank voxel-filters the WHOLE scan (replicated), the
 down-sampled cloud is split into contiguous blocks (or, lii_comm_set_partition(h, 2), every rank filters the voxels whose key
 hashes to it: voxel_keys / voxel_rank below), the local map is replicated, every rank evaluates its block, and ONE sum
 (fp64) of the 91 normal-equation scalars per IEKF iteration joins them.  On GPUs both the split (shard_range in

@@ -542,6 +542,7 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   if (h->prof.kp_active) { rc = kp_mark(h, LII_KP_DESKEW); if (rc != LII_OK) { h->prof.kp_active = false; return rc; } }
   const bool fast = sorted && !h->host_solve && n_next > 0 && !h->no_fast_prologue &&
                     ((job->undistort == 1 && job->imu_poses && job->n_imu_poses >= 2 && job->n_imu_poses <= 64) || job->undistort == 2);
+  if (use_pre && !fast) { prearm_cancel(h); use_pre = false; }  // (cannot happen with the conditions above; a waiting launch must never be left behind a call that will not feed it)
   if (job->undistort != 0 && job->undistort != 1 && job->undistort != 2) return fail(h, LII_ERR_INVALID, "lii_scan_register: undistort must be 0, 1 or 2");
   const auto t_first = std::chrono::steady_clock::now();
   if (fast) {

@@ -23,7 +23,7 @@ def big():
 @pytest.mark.parametrize("sensor", ["os1_128", "dense500k"])
 def test_full_size_properties(big, oracle, sensor):
     import lidar_imu_init_amd as lii
-    from lidar_imu_init_amd import sharding
+    from harness import sharding
     from harness import synth
     hall, map_pts, reg = big
     R = synth.rot_zyx(0.01, -0.02, 0.8)

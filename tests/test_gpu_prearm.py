@@ -142,3 +142,33 @@ reg.close()
     used = int(re.search(r"pre-armed prologues: (\d+) used", out["1"][1]).group(1))
     assert used >= 8, out["1"][1][-600:]
     assert "pre-armed prologues: 0 used" in out["0"][1]
+
+
+@pytest.mark.gpu
+def test_a_job_of_abi_6_is_served_as_before():
+    """A caller built against ABI 6 - 7 fills in the first 56 bytes of lii_scan_job and says so (struct_size 56): no announcement, same bits."""
+    import ctypes as C
+    import lidar_imu_init_amd as lii
+    from lidar_imu_init_amd.api import lii_iekf_opts, lii_iekf_report, lii_scan_job
+    wl, states0, tables = _stream(2)
+    n_full = max(len(s) for s in wl["scans"])
+    reg = lii.Registrar(max_scan_points=n_full + 1024, max_map_points=int(len(wl["map"]) * 1.5) + 1024, filter_size_map=wl["fs_map"])
+    reg.map_build(wl["map"])
+    reg.map_commit()
+    dev = [reg.device_scan(s) for s in wl["scans"]]
+    ref = _run(reg, wl, states0, tables, dev, [0, 1], lambda k: None)
+    for j in (0, 1):
+        job = lii_scan_job()
+        job.struct_size = 56
+        poses = np.ascontiguousarray(tables[j], np.float64).reshape(-1, 22)
+        job.undistort, job.imu_poses, job.n_imu_poses = 1, poses.ctypes.data, len(poses)
+        job.leaf = float(wl["fs_surf"])
+        job.opts = lii_iekf_opts(int(wl["max_it"]), 1)
+        job.scan_dev, job.n_scan_dev, job.scan_sorted = dev[j][0], dev[j][1], 1
+        job.next_scan_dev, job.next_n_scan = dev[1 - j][0], dev[1 - j][1]  # (bytes behind the 56 the caller vouches for: must be ignored)
+        st = states0[j].copy()
+        rep = lii_iekf_report()
+        rc = reg.L.lii_scan_register(reg.h, C.byref(job), st.pod.ctypes.data_as(C.c_void_p), states0[j].pod.ctypes.data_as(C.c_void_p), C.byref(rep))
+        assert rc == 0
+        assert np.array_equal(st.pod, ref[j][0]) and rep.iterations == ref[j][1]["iterations"]
+    reg.close()

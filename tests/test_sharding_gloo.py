@@ -26,7 +26,7 @@ def _worker(rank, world, port, q, by_voxel=False):
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     from conftest import make_state
-    from lidar_imu_init_amd import sharding
+    from harness import sharding
     from harness import synth
     from oracle import oracle as O
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -83,7 +83,7 @@ def test_sharded_normal_equations_match_unsharded(world, by_voxel):
 
 
 def test_shard_bounds_properties():
-    from lidar_imu_init_amd import sharding
+    from harness import sharding
     for n in (0, 1, 7, 100_000, 131_072):
         for w in (1, 2, 3, 4, 8):
             b = [sharding.shard_bounds(n, w, r) for r in range(w)]
