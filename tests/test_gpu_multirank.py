@@ -168,7 +168,7 @@ def test_ranks_split_the_cloud_by_voxel(tmp_path, world):
     assert np.all(np.abs(shares - one["n_local"] / world) <= 0.1 * one["n_local"] / world), shares
     # ... and they are the ones the published hash deals out (lidar_imu_init_amd/sharding.py restates it on the host): the centroid
     # of a voxel lies inside the voxel, so the single-rank cloud tells every voxel's key
-    from lidar_imu_init_amd import sharding
+    from harness import sharding
     owner = sharding.voxel_rank(sharding.voxel_keys(one["body0"][:, :3], float(os.environ.get("LII_WORKER_LEAF", "0.1"))), world)
     predicted = np.bincount(owner, minlength=world)
     assert np.all(np.abs(predicted - shares[:, 0]) <= 2), (predicted, shares[:, 0])  # (a centroid within an ulp of a voxel face)
@@ -259,7 +259,7 @@ def test_list_exchange_layouts_with_several_ranks_on_one_device(world):
 def test_one_process_rehearses_a_share(tmp_path):
     """LII_TEST=solo_share=<N> (tools/gpu_share.sh: the durations of ONE rank's launches without N devices): rank 0's share of an
     N-rank job split by voxel (N > 1) or by index (N < -1) in a single process, nothing exchanged."""
-    from lidar_imu_init_amd import sharding
+    from harness import sharding
     one = _run_ranks(tmp_path, 1)[0]
     by_voxel = _run_ranks(tmp_path, 1, env={"LII_TEST": "solo_share=4"})[0]
     by_index = _run_ranks(tmp_path, 1, env={"LII_TEST": "solo_share=-4"})[0]
