@@ -250,7 +250,7 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   // THE NEXT SCAN'S PROLOGUE, pre-armed (lii_launch.h: DeskewGate): the job announced the scan the next call will bring - its de-skew +
   // filter-insert launch goes out now, behind this update's passes (and its map update), and waits on the device for the record
   // the next lii_scan_register writes.
-  if (h->pre.want_dev && !h->net.comm && h->net.n_ranks <= 1 && h->prof.prof_mode != 3 && !graph_mode && !h->map_async) {  // (mode 3 puts an event in front of every launch: not in front of one that waits)
+  if (h->pre.want_dev && !h->net.comm && h->net.n_ranks <= 1 && h->prof.prof_mode != 3 && !graph_mode && !h->map_async && h->poll_result) {  // (poll_result: a caller that ends its updates with a stream synchronise - LII_TEST=sync_result - would wait for the waiting launch)  // (mode 3 puts an event in front of every launch: not in front of one that waits)
     lii::GateState* gst = h->pre.state;
     h->pre.seq = (h->pre.seq + 1) & 0x003FFFFFFFFFFFFFull;  // (seq << 2 stays below the tag's top byte)
     __atomic_store_n(&gst->word, (h->pre.seq << 2) | lii::kGateArmed, __ATOMIC_RELEASE);
