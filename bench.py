@@ -735,30 +735,52 @@ def from_wire_record(args, wl, reg, drv, stream, n_stream, n_pipe):
     drv.lii_stream_run_wire.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
 
-    def run(steps, map_update):
+    import torch
+    pinned_msgs = [torch.from_numpy(m).pin_memory() for m in msgs]
+    ptrs_pinned = (C.c_void_p * n_msgs)(*[t.data_ptr() for t in pinned_msgs])
+    drv.lii_stream_set_wire_overlap.argtypes = [C.c_int32]
+    drv.lii_stream_set_wire_overlap.restype = None
+
+    def run(steps, map_update, overlap=0, src=ptrs):
         tot = np.zeros(2, np.int64)
         ing = np.zeros(2)
+        drv.lii_stream_set_wire_overlap(int(overlap))
         reg.synchronize()
         t0 = time.perf_counter()
-        rc = drv.lii_stream_run_wire(reg.h, C.byref(stream), n_stream, ptrs, npts.ctypes.data, n_msgs, steps, C.byref(fields), C.byref(opts),
+        rc = drv.lii_stream_run_wire(reg.h, C.byref(stream), n_stream, src, npts.ctypes.data, n_msgs, steps, C.byref(fields), C.byref(opts),
                                      float(wl["fs_surf"]), int(wl["max_it"]), 1, int(map_update), tot.ctypes.data, ing.ctypes.data)
+        dt = time.perf_counter() - t0
+        drv.lii_stream_set_wire_overlap(0)
         if rc != 0:
             raise RuntimeError(f"lii_stream_run_wire: status {rc}: {reg.L.lii_last_error(reg.h).decode()}")
-        return time.perf_counter() - t0, ing, tot
+        return dt, ing, tot
+
+    def record(dt, ing, tot, n_m):
+        frames = int(ing[1])
+        return {"value": frames / dt, "unit": "scans/s", "ms_per_scan": 1e3 * dt / max(frames, 1), "messages": n_m, "sub_frames": frames,
+                "ingest_us_per_message": float(ing[0]) / n_m, "ingest_share_of_the_loop": float(ing[0]) * 1e-6 / dt,
+                "avg_iterations": float(tot[0]) / max(frames, 1)}
 
     n_m = max(4, n_pipe // cut)
     run(min(n_m, 2 * n_msgs), True)  # (untimed: first-time allocations of the ingest)
-    dt, ing, tot = run(n_m, True)
-    frames = int(ing[1])
-    return {"value": frames / dt, "unit": "scans/s", "ms_per_scan": 1e3 * dt / max(frames, 1), "messages": n_m, "sub_frames": frames,
-            "cut_frame_num": cut, "points_per_message": int(npts[0]), "bytes_per_message": int(len(msgs[0])),
-            "ingest_us_per_message": float(ing[0]) / n_m,
-            "ingest_share_of_the_loop": float(ing[0]) * 1e-6 / dt,
-            "avg_iterations": float(tot[0]) / max(frames, 1),
-            "what": "PointCloud2 bytes (Ouster layout, pageable host memory) -> lii_ingest_pcl2 -> lii_frame_select -> lii_scan_register with "
-                    "map_update = 1 per sub-frame, C++ host loop; ingest_us_per_message = host time inside lii_ingest_pcl2 (H2D of the raw bytes, "
-                    "its kernels and its one synchronisation)",
-            "map_points_after": reg.map_size()}
+    run(min(n_m, 2 * n_msgs), True, 1, ptrs_pinned)  # (... and of the overlapped form's ring)
+    serial = record(*run(n_m, True), n_m)
+    over_pageable = record(*run(n_m, True, 1, ptrs), n_m)
+    over = record(*run(n_m, True, 1, ptrs_pinned), n_m)
+    over_early = record(*run(n_m, True, 3, ptrs_pinned), n_m)
+    out = dict(over)
+    out.update({"cut_frame_num": cut, "points_per_message": int(npts[0]), "bytes_per_message": int(len(msgs[0])),
+                "what": "PointCloud2 bytes (Ouster layout, page-locked host memory) -> lii_ingest_pcl2_begin ... lii_ingest_end (ABI 9: message "
+                        "m + 1 is decoded and the bytes of m + 2 travel on streams of their own while message m is registered) -> lii_frame_select "
+                        "-> lii_scan_register with map_update = 1 per sub-frame, C++ host loop; ingest_us_per_message = host time inside "
+                        "lii_ingest_end + lii_ingest_pcl2_begin (one call per message each)",
+                "pageable_source": over_pageable,
+                "begun_before_the_registrations": over_early,
+                "serial_ingest": dict(serial, what="one lii_ingest_pcl2 call per message on the handle's own stream (pageable source): H2D of "
+                                                   "the raw bytes, its launches and its one synchronisation before the first sub-frame is registered "
+                                                   "(the form of the record until ABI 8)"),
+                "map_points_after": reg.map_size()})
+    return out
 
 
 def cpu_sweep_worker(args):

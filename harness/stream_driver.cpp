@@ -21,6 +21,9 @@ void lii_stream_set_sorted(int32_t sorted) { g_scan_sorted = sorted ? 1 : 0; }
 // passes); lii_stream_set_map_in_job(0): lii_map_incremental as a call of its own behind lii_scan_register, the form of round 3 (A/B).
 static int32_t g_map_in_job = 1;
 void lii_stream_set_map_in_job(int32_t in_job) { g_map_in_job = in_job ? 1 : 0; }
+// lii_stream_run_wire: 1 = the overlapped ingest (lii_ingest_pcl2_begin / lii_ingest_end), 0 = one lii_ingest_pcl2 call per message
+static int32_t g_wire_overlap = 0;
+void lii_stream_set_wire_overlap(int32_t overlap) { g_wire_overlap = overlap; }  // (2: one message under way instead of two; 3: begun before the registrations)
 
 // The scans of these streams are resident in device memory: every job announces its successor (lii_scan_job::next_scan_dev) and the
 // library pre-arms that scan's first launch.  lii_stream_set_announce(0): no announcement, the form of ABI <= 7 (A/B).
@@ -167,6 +170,20 @@ int lii_stream_run_wire(lii_handle h, const lii_stream_scan* scans, int32_t n_sc
   int rc = lii_set_profiling(h, 0);
   if (rc != LII_OK) return rc;
   const int cut = opts0->cut_frame_num > 0 ? opts0->cut_frame_num : 1;
+  // g_wire_overlap (lii_stream_set_wire_overlap): the messages queue on the device (lii_ingest_pcl2_begin / lii_ingest_end, ABI 9) -
+  // message m + 1 is decoded, and the bytes of m + 2 travel, while the sub-frames of message m are registered
+  auto begin = [&](int32_t m) {
+    lii_ingest_opts o = *opts0;
+    o.stamp_s = opts0->stamp_s + 0.1 * m;
+    o.scan_count = opts0->scan_count + m;
+    return lii_ingest_pcl2_begin(h, msgs[m % n_msgs], msg_points[m % n_msgs], fields, &o);
+  };
+  if (g_wire_overlap) {
+    for (int32_t m = 0; m < (g_wire_overlap == 2 ? 1 : 2) && m < steps; m++) {
+      rc = begin(m);
+      if (rc != LII_OK) return rc;
+    }
+  }
   for (int32_t m = 0; m < steps; m++) {
     const int32_t jm = m % n_msgs;
     lii_ingest_opts o = *opts0;
@@ -175,7 +192,12 @@ int lii_stream_run_wire(lii_handle h, const lii_stream_scan* scans, int32_t n_sc
     lii_frame_info frames[64];
     int32_t nf = 0;
     const auto t0 = std::chrono::steady_clock::now();
-    rc = lii_ingest_pcl2(h, msgs[jm], msg_points[jm], fields, &o, frames, 64, &nf);
+    if (g_wire_overlap) {
+      rc = lii_ingest_end(h, frames, 64, &nf);
+      if (rc == LII_OK && g_wire_overlap == 3 && m + 2 < steps) rc = begin(m + 2);  // (3: the next message begun BEFORE the registrations, A/B)
+    } else {
+      rc = lii_ingest_pcl2(h, msgs[jm], msg_points[jm], fields, &o, frames, 64, &nf);
+    }
     ingest_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     if (rc != LII_OK) return rc;
     for (int32_t f = 0; f < nf; f++) {
@@ -199,6 +221,15 @@ int lii_stream_run_wire(lii_handle h, const lii_stream_scan* scans, int32_t n_sc
       totals[0] += rep.iterations;
       totals[1] += rep.searches;
       ingest_us[1] += 1.0;
+    }
+    // the message after next is put under way HERE: its copy and launches are enqueued while the device still runs the map update of
+    // the registration that has just returned (begun before the registrations, the host's ~ 50 us of enqueueing sat in front of them)
+    if (g_wire_overlap == 1 || g_wire_overlap == 2) {
+      const int32_t ahead = g_wire_overlap == 2 ? 1 : 2;
+      const auto t1 = std::chrono::steady_clock::now();
+      if (m + ahead < steps) rc = begin(m + ahead);
+      ingest_us[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+      if (rc != LII_OK) return rc;
     }
   }
   return lii_synchronize(h);

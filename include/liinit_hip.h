@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define LII_ABI_VERSION 8 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
+#define LII_ABI_VERSION 9 /* 2: lii_scan_job::scan_dev / n_scan_dev, lii_comm_init_ex, lii_comm_transport
                              3: lii_params_*, lii_comm_set_partition (library-side split of the down-sampled cloud)
                              4: lii_scan_upload_next / lii_scan_advance (the next scan travels while the current one registers)
                              5: LII_COMM_MAILBOX = the peer-mapped HBM mailbox (HIP IPC), LII_COMM_MAILBOX_HOST, lii_comm_rccl_ranks
@@ -27,7 +27,9 @@ extern "C" {
                                 lii_comm_describe, lii_comm_set_partition(h, 2) (split by voxel), lii_scan_job::map_update (the reserved field)
                              7: lii_ingest_opts::cut_frame_num = 0 (the whole message as one frame: Preprocess::process), lii_last_solve_info,
                                 lii_selftest_list_exchange
-                             8: lii_last_unfinished_queries, lii_scan_job::next_scan_dev / next_n_scan (struct_size 72: the pre-armed prologue) */
+                             8: lii_last_unfinished_queries, lii_scan_job::next_scan_dev / next_n_scan (struct_size 72: the pre-armed prologue)
+                             9: lii_ingest_pcl2_begin / lii_ingest_livox_begin / lii_ingest_end (driver messages queue on the device: message k + 1 is
+                                transferred and decoded while the sub-frames of message k are registered) */
 
 enum lii_status {
   LII_OK = 0,
@@ -222,6 +224,17 @@ int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_
 int lii_ingest_livox(lii_handle h, const void* points, int32_t n_points, const lii_livox_fields* fields,
                      const lii_ingest_opts* opts, lii_frame_info* frames, int32_t max_frames, int32_t* n_frames);
 int lii_frame_select(lii_handle h, int32_t frame);
+/* The overlapped forms (ABI 9) - the reference's message queue (lidar_buffer / time_buffer filled by the callbacks, src/laserMapping.cpp:326-379,
+ * drained by sync_packages, :432-480) kept ON THE DEVICE: lii_ingest_*_begin puts a message under way (H2D of the raw bytes on a copy stream,
+ * decode ... cut on a stream of its own) and returns without waiting; lii_ingest_end waits for the OLDEST message under way (long
+ * done when it overlapped a registration), makes its frames the ones lii_frame_select serves and returns its frame table exactly as the
+ * one-call form does.  Up to two messages may be under way (LII_ERR_STATE for a third); the frames of the message before stay selectable until
+ * lii_ingest_end.  Call order of a single-threaded host: lii_ingest_end(m) -> register the sub-frames of m -> lii_ingest_*_begin(m + 2): the
+ * begin's launches are then enqueued while the device still runs the map update of m's last sub-frame.  `data` must stay valid until the matching lii_ingest_end; from page-locked memory the transfer is asynchronous, from pageable
+ * memory the call returns once the runtime has staged the bytes (the launches still overlap).  Results are the one-call forms' bits. */
+int lii_ingest_pcl2_begin(lii_handle h, const void* data, int32_t n_points, const lii_pc2_fields* fields, const lii_ingest_opts* opts);
+int lii_ingest_livox_begin(lii_handle h, const void* points, int32_t n_points, const lii_livox_fields* fields, const lii_ingest_opts* opts);
+int lii_ingest_end(lii_handle h, lii_frame_info* frames, int32_t max_frames, int32_t* n_frames);
 
 /* ---------------------------------------------------------------- scan-to-map registration
  * lii_iekf_iterate: ONE pass of the per-point loop + Jacobian + normal-equation reduction at a fixed state —

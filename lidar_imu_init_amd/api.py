@@ -112,6 +112,9 @@ _DECLS = {
     "lii_ingest_livox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(lii_livox_fields), C.POINTER(lii_ingest_opts),
                                    C.POINTER(lii_frame_info), C.c_int32, C.POINTER(C.c_int32)]),
     "lii_frame_select": (C.c_int, [C.c_void_p, C.c_int32]),
+    "lii_ingest_pcl2_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(lii_pc2_fields), C.POINTER(lii_ingest_opts)]),
+    "lii_ingest_livox_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(lii_livox_fields), C.POINTER(lii_ingest_opts)]),
+    "lii_ingest_end": (C.c_int, [C.c_void_p, C.POINTER(lii_frame_info), C.c_int32, C.POINTER(C.c_int32)]),
     "lii_iekf_iterate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "lii_iekf_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(lii_iekf_opts),
                                   C.POINTER(lii_iekf_report)]),
@@ -410,6 +413,33 @@ class Registrar:
 
     def frame_select(self, k: int):
         self._check(self.L.lii_frame_select(self.h, k))
+
+    def ingest_pcl2_begin(self, data, n_points, fields, lidar_type, n_scans, point_filter_num, blind, stamp_s, cut_frame_num=1,
+                          scan_count=1000):
+        """The overlapped form (ABI 9): the message is put under way and the call returns; `data` (a buffer object) is kept alive here
+        until the matching ingest_end."""
+        raw = np.frombuffer(data, np.uint8)
+        opts = lii_ingest_opts(C.sizeof(lii_ingest_opts), lidar_type, n_scans, point_filter_num, blind, stamp_s, cut_frame_num, scan_count)
+        f = lii_pc2_fields(*fields)
+        self._check(self.L.lii_ingest_pcl2_begin(self.h, _ptr(raw) if len(raw) else None, n_points, C.byref(f), C.byref(opts)))
+        self._ingest_keep = getattr(self, "_ingest_keep", []) + [raw]
+
+    def ingest_livox_begin(self, data, n_points, fields, n_scans, point_filter_num, blind, stamp_s, cut_frame_num=1, scan_count=1000):
+        raw = np.frombuffer(data, np.uint8)
+        opts = lii_ingest_opts(C.sizeof(lii_ingest_opts), 1, n_scans, point_filter_num, blind, stamp_s, cut_frame_num, scan_count)
+        f = lii_livox_fields(*fields)
+        self._check(self.L.lii_ingest_livox_begin(self.h, _ptr(raw) if len(raw) else None, n_points, C.byref(f), C.byref(opts)))
+        self._ingest_keep = getattr(self, "_ingest_keep", []) + [raw]
+
+    def ingest_end(self):
+        """Waits for the oldest message under way; its frames become the ones frame_select serves.  Returns what ingest_pcl2 returns."""
+        frames = (lii_frame_info * 64)()
+        nf = C.c_int32(0)
+        self._check(self.L.lii_ingest_end(self.h, frames, 64, C.byref(nf)))
+        if getattr(self, "_ingest_keep", None):
+            self._ingest_keep.pop(0)
+        self.frame_tail_ms = [frames[k].last_offset_ms for k in range(nf.value)]
+        return [(frames[k].begin_time_s, frames[k].offset, frames[k].count) for k in range(nf.value)]
 
     # ------------------------------------------------------------------ registration
     def iekf_iterate(self, state: State, search: bool, imu_en: bool):

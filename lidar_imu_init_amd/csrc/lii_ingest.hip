@@ -7,7 +7,10 @@
 //                                         branch for initialization/cut_frame: false (no time sort, no cut, input order)
 // for the point layouts of src/preprocess.h:35-116.  HBM-bound byte work: one pass over the raw records, one scan, one
 // stable radix sort of the kept points by time, one pass that writes the frames.  One host synchronisation per message
-// (the frame table lands in mapped host memory).
+// (the frame table lands in mapped host memory).  Overlapped forms (ABI 9: lii_ingest_*_begin / lii_ingest_end): a ring of three message
+// contexts, the raw bytes on a copy stream, the launches on a stream of their own - message k + 1 (and the bytes of k + 2) travel and are
+// decoded while the handle's stream registers the sub-frames of message k (the reference queues driver messages the same way:
+// lidar_buffer / time_buffer, src/laserMapping.cpp:326-379, consumed by sync_packages :432-480).
 //
 // The order of points with equal time stamps is the input order (stable sort); the reference's std::sort leaves it
 // implementation-defined (oracle/orc_ingest.hpp).
@@ -16,6 +19,7 @@
 #include <cstring>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 
 #include "../../include/liinit_hip.h"
@@ -56,6 +60,7 @@ struct IngestCtx {
   IngestTable* h_table = nullptr;  // pinned + mapped
   IngestTable table;               // host copy of the last message
   bool have = false;
+  int n_under_way = 0;              // points of the message an overlapped call put under way in this context
 };
 
 template <class T>
@@ -294,14 +299,41 @@ __global__ void k_whole_apply(const float4* __restrict__ pts, const unsigned int
 template <class T>
 hipError_t dm(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (n ? n : 1)); }
 
-void ingest_free(IngestCtx* c) {
-  if (!c) return;
+void ingest_release(IngestCtx* c) {
   void* ptrs[] = {c->d_raw, c->d_pts, c->d_yaw, c->d_ring, c->d_flag, c->d_rank, c->d_aux, c->d_aux_rank, c->d_key_a, c->d_key_b,
                   c->d_idx_a, c->d_idx_b, c->d_frames, c->d_temp};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_table) (void)hipHostFree(c->h_table);
-  delete c;
+}
+
+// The handle's ingest state: a ring of three message contexts.  `front` holds the message whose frames lii_frame_select serves (the
+// one-call forms lii_ingest_pcl2 / _livox work in it, on the handle's stream).  The overlapped forms (lii_ingest_*_begin / lii_ingest_end,
+// ABI 9) put up to two more messages under way in the other contexts: raw bytes on a copy stream, decode ... cut on a
+// kernel stream behind them, while the handle's stream registers the sub-frames of `front`.
+struct IngestRing {
+  static constexpr int kSlots = 3;
+  IngestCtx slot[kSlots];
+  int front = 0;
+  int pending[kSlots] = {0, 0, 0};  // FIFO of contexts under way, oldest first
+  int n_pending = 0;
+  hipStream_t s_copy = nullptr, s_kern = nullptr;
+  hipEvent_t ev_copied[kSlots] = {nullptr, nullptr, nullptr}, ev_done[kSlots] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_read = nullptr;  // the handle's stream has copied a selected frame out of a context that is about to be reused
+  int guard_slot = -1;
+};
+
+void ingest_free(IngestRing* r) {
+  if (!r) return;
+  if (r->s_copy) { (void)hipStreamSynchronize(r->s_copy); (void)hipStreamDestroy(r->s_copy); }
+  if (r->s_kern) { (void)hipStreamSynchronize(r->s_kern); (void)hipStreamDestroy(r->s_kern); }
+  for (int k = 0; k < IngestRing::kSlots; k++) {
+    if (r->ev_copied[k]) (void)hipEventDestroy(r->ev_copied[k]);
+    if (r->ev_done[k]) (void)hipEventDestroy(r->ev_done[k]);
+    ingest_release(&r->slot[k]);
+  }
+  if (r->ev_read) (void)hipEventDestroy(r->ev_read);
+  delete r;
 }
 
 #define ICHK(h, expr)                                                                                         \
@@ -346,16 +378,37 @@ int ingest_reserve(lii_handle h, IngestCtx* c, int n, size_t raw_bytes) {
   return LII_OK;
 }
 
-IngestCtx* ctx_of(lii_handle h) {
+IngestRing* ring_of(lii_handle h) {
   void** slot = lii_internal_ingest_slot(h);
-  if (!*slot) *slot = new IngestCtx();
-  return static_cast<IngestCtx*>(*slot);
+  if (!*slot) *slot = new IngestRing();
+  return static_cast<IngestRing*>(*slot);
 }
 
-// shared tail: scan of the keep flags, compaction, stable sort by time, plan, apply, one synchronisation, frame table out
-int ingest_finish(lii_handle h, IngestCtx* c, int n, const lii_ingest_opts* o, int uncut_below, lii_frame_info* frames,
-                  int32_t max_frames, int32_t* n_frames) {
-  hipStream_t s = lii_internal_stream(h);
+// The overlapped forms' streams, at the DEFAULT priority: a low-priority stream was measured first (a registration launch ahead of a
+// message that is not due yet, the idea went) and made the whole loop 2.4 x SLOWER than the serial form - 1 904 against 4 454 scans/s
+// at the default priority, 2 541 serial (profiles/r06_ingest_overlap.md): queues of unequal priority are time-sliced on this device.
+// LII_INGEST_PRIO=low brings that form back for measurements.
+int ring_streams(lii_handle h, IngestRing* r) {
+  if (r->s_kern) return LII_OK;
+  const char* ep = getenv("LII_INGEST_PRIO");
+  if (ep && ep[0] == 'l') {
+    int least = 0, greatest = 0;
+    ICHK(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    ICHK(h, hipStreamCreateWithPriority(&r->s_kern, hipStreamNonBlocking, least));
+  } else {
+    ICHK(h, hipStreamCreateWithFlags(&r->s_kern, hipStreamNonBlocking));
+  }
+  ICHK(h, hipStreamCreateWithFlags(&r->s_copy, hipStreamNonBlocking));
+  for (int k = 0; k < IngestRing::kSlots; k++) {
+    ICHK(h, hipEventCreateWithFlags(&r->ev_copied[k], hipEventDisableTiming));
+    ICHK(h, hipEventCreateWithFlags(&r->ev_done[k], hipEventDisableTiming));
+  }
+  ICHK(h, hipEventCreateWithFlags(&r->ev_read, hipEventDisableTiming));
+  return LII_OK;
+}
+
+// shared tail, enqueued on `s`: scan of the keep flags, compaction, stable sort by time, plan, apply (the frame table lands in mapped host memory)
+int ingest_tail(lii_handle h, IngestCtx* c, int n, const lii_ingest_opts* o, int uncut_below, hipStream_t s) {
   const int nb = (n + 255) / 256;
   inclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_flag, c->d_rank, n, s);
   hipLaunchKernelGGL(k_ingest_compact, dim3(nb), dim3(256), 0, s, c->d_pts, c->d_flag, c->d_rank, n, c->d_key_a, c->d_idx_a);
@@ -371,7 +424,10 @@ int ingest_finish(lii_handle h, IngestCtx* c, int n, const lii_ingest_opts* o, i
     hipLaunchKernelGGL(k_cut_apply, dim3(nb), dim3(256), 0, s, c->d_pts, c->d_idx_b, d_table, n, c->d_frames);
   }
   ICHK(h, hipGetLastError());
-  ICHK(h, hipStreamSynchronize(s));
+  return LII_OK;
+}
+// ... and, once whatever stream ran it is known to be through: the frame table out
+int ingest_collect(lii_handle h, IngestCtx* c, lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
   c->table = *c->h_table;
   c->have = true;
   *n_frames = c->table.n_frames;
@@ -385,31 +441,19 @@ int ingest_finish(lii_handle h, IngestCtx* c, int n, const lii_ingest_opts* o, i
   return LII_OK;
 }
 
-}  // namespace
-
-void ingest_destroy(void* slot) { ingest_free(static_cast<IngestCtx*>(slot)); }
-
-}  // namespace lii
-
-using namespace lii;
-
-extern "C" {
-
-int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_pc2_fields* f, const lii_ingest_opts* o,
-                    lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
-  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
-  if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || !frames || !n_frames || n_points < 0 || (!data && n_points > 0) ||
+// argument checks of the PointCloud2 forms; *o may be redirected to `whole_opts`
+int pcl2_check(lii_handle h, const void* data, int32_t n_points, const lii_pc2_fields* f, const lii_ingest_opts** po, lii_ingest_opts* whole_opts) {
+  const lii_ingest_opts* o = *po;
+  if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || n_points < 0 || (!data && n_points > 0) ||
       f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 0 || o->cut_frame_num > kMaxFrames)
     return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: bad arguments");
-  { const int rcm = lii_internal_scan_materialize(h); if (rcm != LII_OK) return rcm; }  // (a selected frame of the last message nobody has read: the frames are about to be overwritten)
   // An L515 message is ONE frame whatever cut_frame says: the reference's callback sends only Velodyne, Ouster, Pandar and RoboSense
   // through process_cut_frame_pcl2 and everything else - L515 - through Preprocess::process (src/laserMapping.cpp:363-377).  ADVICE r5:
   // with `cut_frame: true` in the yaml this call used to fail with "Wrong LiDAR Type" where the reference processes the message.
-  lii_ingest_opts whole_opts;
   if (o->lidar_type == LII_LIDAR_L515 && o->cut_frame_num != 0) {
-    whole_opts = *o;
-    whole_opts.cut_frame_num = 0;
-    o = &whole_opts;
+    *whole_opts = *o;
+    whole_opts->cut_frame_num = 0;
+    o = *po = whole_opts;
   }
   if (o->cut_frame_num == 0) {  // Preprocess::process knows Ouster, Velodyne and L515 (src/preprocess.cpp:337-354)
     if (o->lidar_type != LII_LIDAR_VELO && o->lidar_type != LII_LIDAR_OUSTER && o->lidar_type != LII_LIDAR_L515)
@@ -417,15 +461,26 @@ int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_
   } else if (o->lidar_type != LII_LIDAR_VELO && o->lidar_type != LII_LIDAR_OUSTER && o->lidar_type != LII_LIDAR_PANDAR &&
              o->lidar_type != LII_LIDAR_ROBOSENSE)
     return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: Wrong LiDAR Type (src/preprocess.cpp:290-292)");
-  *n_frames = 0;
-  IngestCtx* c = ctx_of(h);
-  c->have = false;
-  if (n_points == 0) return LII_OK;
+  return LII_OK;
+}
+int livox_check(lii_handle h, const void* points, int32_t n_points, const lii_livox_fields* f, const lii_ingest_opts* o) {
+  if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || n_points < 0 || (!points && n_points > 0) ||
+      f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 0 || o->cut_frame_num > kMaxFrames)
+    return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_livox: bad arguments");
+  return LII_OK;
+}
+
+// H2D of the raw bytes on `s_copy`, the message's launches on `s_kern` behind it (one stream for the one-call forms)
+int pcl2_enqueue(lii_handle h, IngestCtx* c, const void* data, int32_t n_points, const lii_pc2_fields* f, const lii_ingest_opts* o,
+                 hipStream_t s_copy, hipStream_t s, hipEvent_t ev_copied) {
   const size_t bytes = (size_t)n_points * f->point_step;
   int rc = ingest_reserve(h, c, n_points, bytes);
   if (rc != LII_OK) return rc;
-  hipStream_t s = lii_internal_stream(h);
-  ICHK(h, hipMemcpyAsync(c->d_raw, data, bytes, hipMemcpyHostToDevice, s));
+  ICHK(h, hipMemcpyAsync(c->d_raw, data, bytes, hipMemcpyHostToDevice, s_copy));
+  if (s_copy != s) {
+    ICHK(h, hipEventRecord(ev_copied, s_copy));
+    ICHK(h, hipStreamWaitEvent(s, ev_copied, 0));
+  }
   Pc2Arg a;
   a.f = *f;
   a.lidar_type = o->lidar_type;
@@ -441,25 +496,18 @@ int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_
                        c->d_flag);
     hipLaunchKernelGGL(k_pc2_drop_wide_rings, dim3(nb), dim3(256), 0, s, c->d_raw, n_points, a, c->d_ring, c->d_flag);
   }
-  return ingest_finish(h, c, n_points, o, 20, frames, max_frames, n_frames);
+  return ingest_tail(h, c, n_points, o, 20, s);
 }
-
-int lii_ingest_livox(lii_handle h, const void* points, int32_t n_points, const lii_livox_fields* f, const lii_ingest_opts* o,
-                     lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
-  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
-  if (!h || !f || !o || o->struct_size != sizeof(lii_ingest_opts) || !frames || !n_frames || n_points < 0 || (!points && n_points > 0) ||
-      f->point_step <= 0 || o->point_filter_num < 1 || o->cut_frame_num < 0 || o->cut_frame_num > kMaxFrames)
-    return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_livox: bad arguments");
-  { const int rcm = lii_internal_scan_materialize(h); if (rcm != LII_OK) return rcm; }
-  *n_frames = 0;
-  IngestCtx* c = ctx_of(h);
-  c->have = false;
-  if (n_points == 0) return LII_OK;
+int livox_enqueue(lii_handle h, IngestCtx* c, const void* points, int32_t n_points, const lii_livox_fields* f, const lii_ingest_opts* o,
+                  hipStream_t s_copy, hipStream_t s, hipEvent_t ev_copied) {
   const size_t bytes = (size_t)n_points * f->point_step;
   int rc = ingest_reserve(h, c, n_points, bytes);
   if (rc != LII_OK) return rc;
-  hipStream_t s = lii_internal_stream(h);
-  ICHK(h, hipMemcpyAsync(c->d_raw, points, bytes, hipMemcpyHostToDevice, s));
+  ICHK(h, hipMemcpyAsync(c->d_raw, points, bytes, hipMemcpyHostToDevice, s_copy));
+  if (s_copy != s) {
+    ICHK(h, hipEventRecord(ev_copied, s_copy));
+    ICHK(h, hipStreamWaitEvent(s, ev_copied, 0));
+  }
   LivoxArg a;
   a.f = *f;
   a.n_scans = o->n_scans;
@@ -469,13 +517,154 @@ int lii_ingest_livox(lii_handle h, const void* points, int32_t n_points, const l
   hipLaunchKernelGGL(k_livox_valid, dim3(nb), dim3(256), 0, s, c->d_raw, n_points, a, c->d_aux);
   inclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_aux, c->d_aux_rank, n_points, s);
   hipLaunchKernelGGL(k_livox_decode, dim3(nb), dim3(256), 0, s, c->d_raw, n_points, a, c->d_aux, c->d_aux_rank, c->d_pts, c->d_flag);
-  return ingest_finish(h, c, n_points, o, 5, frames, max_frames, n_frames);
+  return ingest_tail(h, c, n_points, o, 5, s);
+}
+
+// A context for the next overlapped message: not `front`, not under way.  What the handle's stream may still be doing with it - the copy
+// of a selected frame that nobody had read when its message left `front` - comes first.
+int ring_take(lii_handle h, IngestRing* r, int* out) {
+  int rc = ring_streams(h, r);
+  if (rc != LII_OK) return rc;
+  if (r->n_pending >= IngestRing::kSlots - 1)
+    return lii_internal_fail(h, LII_ERR_STATE, "lii_ingest_*_begin: two messages are under way already (call lii_ingest_end)");
+  int k = -1;
+  for (int q = 0; q < IngestRing::kSlots && k < 0; q++) {
+    bool used = q == r->front;
+    for (int p = 0; p < r->n_pending; p++) used = used || r->pending[p] == q;
+    if (!used) k = q;
+  }
+  if (r->guard_slot == k) {
+    ICHK(h, hipStreamWaitEvent(r->s_copy, r->ev_read, 0));
+    r->guard_slot = -1;
+  }
+  *out = k;
+  return LII_OK;
+}
+void ring_push(IngestRing* r, int k) { r->pending[r->n_pending++] = k; }
+
+}  // namespace
+
+void ingest_destroy(void* slot) { ingest_free(static_cast<IngestRing*>(slot)); }
+
+}  // namespace lii
+
+using namespace lii;
+
+extern "C" {
+
+int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_pc2_fields* f, const lii_ingest_opts* o,
+                    lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
+  if (!frames || !n_frames) return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: bad arguments");
+  lii_ingest_opts whole_opts;
+  int rc = pcl2_check(h, data, n_points, f, &o, &whole_opts);
+  if (rc != LII_OK) return rc;
+  { const int rcm = lii_internal_scan_materialize(h); if (rcm != LII_OK) return rcm; }  // (a selected frame of the last message nobody has read: the frames are about to be overwritten)
+  *n_frames = 0;
+  IngestRing* r = ring_of(h);
+  IngestCtx* c = &r->slot[r->front];
+  c->have = false;
+  if (n_points == 0) return LII_OK;
+  hipStream_t s = lii_internal_stream(h);
+  rc = pcl2_enqueue(h, c, data, n_points, f, o, s, s, nullptr);
+  if (rc != LII_OK) return rc;
+  ICHK(h, hipStreamSynchronize(s));
+  return ingest_collect(h, c, frames, max_frames, n_frames);
+}
+
+int lii_ingest_livox(lii_handle h, const void* points, int32_t n_points, const lii_livox_fields* f, const lii_ingest_opts* o,
+                     lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
+  lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
+  if (!frames || !n_frames) return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_livox: bad arguments");
+  int rc = livox_check(h, points, n_points, f, o);
+  if (rc != LII_OK) return rc;
+  { const int rcm = lii_internal_scan_materialize(h); if (rcm != LII_OK) return rcm; }
+  *n_frames = 0;
+  IngestRing* r = ring_of(h);
+  IngestCtx* c = &r->slot[r->front];
+  c->have = false;
+  if (n_points == 0) return LII_OK;
+  hipStream_t s = lii_internal_stream(h);
+  rc = livox_enqueue(h, c, points, n_points, f, o, s, s, nullptr);
+  if (rc != LII_OK) return rc;
+  ICHK(h, hipStreamSynchronize(s));
+  return ingest_collect(h, c, frames, max_frames, n_frames);
+}
+
+// The overlapped forms (ABI 9).  Neither uses the handle's stream: a registration under way - or a pre-armed launch - is not disturbed.
+int lii_ingest_pcl2_begin(lii_handle h, const void* data, int32_t n_points, const lii_pc2_fields* f, const lii_ingest_opts* o) {
+  lii_ingest_opts whole_opts;
+  int rc = pcl2_check(h, data, n_points, f, &o, &whole_opts);
+  if (rc != LII_OK) return rc;
+  IngestRing* r = ring_of(h);
+  int k = -1;
+  rc = ring_take(h, r, &k);
+  if (rc != LII_OK) return rc;
+  IngestCtx* c = &r->slot[k];
+  c->have = false;
+  c->n_under_way = n_points;
+  if (n_points > 0) {
+    rc = pcl2_enqueue(h, c, data, n_points, f, o, r->s_copy, r->s_kern, r->ev_copied[k]);
+    if (rc != LII_OK) return rc;
+    ICHK(h, hipEventRecord(r->ev_done[k], r->s_kern));
+  }
+  ring_push(r, k);
+  return LII_OK;
+}
+int lii_ingest_livox_begin(lii_handle h, const void* points, int32_t n_points, const lii_livox_fields* f, const lii_ingest_opts* o) {
+  int rc = livox_check(h, points, n_points, f, o);
+  if (rc != LII_OK) return rc;
+  IngestRing* r = ring_of(h);
+  int k = -1;
+  rc = ring_take(h, r, &k);
+  if (rc != LII_OK) return rc;
+  IngestCtx* c = &r->slot[k];
+  c->have = false;
+  c->n_under_way = n_points;
+  if (n_points > 0) {
+    rc = livox_enqueue(h, c, points, n_points, f, o, r->s_copy, r->s_kern, r->ev_copied[k]);
+    if (rc != LII_OK) return rc;
+    ICHK(h, hipEventRecord(r->ev_done[k], r->s_kern));
+  }
+  ring_push(r, k);
+  return LII_OK;
+}
+int lii_ingest_end(lii_handle h, lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
+  if (!h || !frames || !n_frames) return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_end: bad arguments");
+  IngestRing* r = ring_of(h);
+  if (r->n_pending < 1) return lii_internal_fail(h, LII_ERR_STATE, "lii_ingest_end: no message under way (call lii_ingest_pcl2_begin / lii_ingest_livox_begin)");
+  // A selected frame of the outgoing message that nobody has read is copied into the handle's own scan buffer first - by the handle's
+  // stream, which the next message that takes this context waits for.
+  if (lii_internal_scan_is_deferred(h)) {
+    lii_internal_prearm_cancel(h);
+    const int rcm = lii_internal_scan_materialize(h);
+    if (rcm != LII_OK) return rcm;
+    ICHK(h, hipEventRecord(r->ev_read, lii_internal_stream(h)));
+    r->guard_slot = r->front;
+  }
+  const int k = r->pending[0];
+  IngestCtx* c = &r->slot[k];
+  *n_frames = 0;
+  if (c->n_under_way > 0) {
+    // long done when the message overlapped a registration: asked first (a blocking wait's wake-up is tens of microseconds)
+    hipError_t e = hipEventQuery(r->ev_done[k]);
+    for (int spin = 0; e == hipErrorNotReady && spin < 2000; spin++) e = hipEventQuery(r->ev_done[k]);
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); e = hipEventSynchronize(r->ev_done[k]); }
+    ICHK(h, e);
+  }
+  for (int p = 1; p < r->n_pending; p++) r->pending[p - 1] = r->pending[p];
+  r->n_pending--;
+  r->slot[r->front].have = false;
+  r->front = k;
+  if (c->n_under_way <= 0) return LII_OK;  // (an empty message: no frame, as in the one-call forms)
+  return ingest_collect(h, c, frames, max_frames, n_frames);
 }
 
 int lii_frame_select(lii_handle h, int32_t frame) {
   lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_ERR_INVALID;
-  IngestCtx* c = ctx_of(h);
+  IngestRing* r = ring_of(h);
+  IngestCtx* c = &r->slot[r->front];
   if (!c->have || frame < 0 || frame >= c->table.n_frames) return lii_internal_fail(h, LII_ERR_STATE, "lii_frame_select: no such frame");
   const int first = c->table.first[frame], cnt = c->table.last[frame] - first + 1;
   return lii_internal_scan_defer(h, c->d_frames + (first - 1), cnt);  // (read in place by lii_scan_register, copied by any other reader)

@@ -32,7 +32,7 @@ def test_python_mirror_covers_header():
     L = lii.load_library()
     import re
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "liinit_hip.h")).read()
-    assert L.lii_abi_version() == int(re.search(r"#define\s+LII_ABI_VERSION\s+(\d+)", header).group(1)) == 8
+    assert L.lii_abi_version() == int(re.search(r"#define\s+LII_ABI_VERSION\s+(\d+)", header).group(1)) == 9
 
 
 def test_struct_layouts_match_header():
