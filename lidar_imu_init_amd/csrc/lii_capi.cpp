@@ -314,6 +314,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     const size_t qs = t.find("solo_share=");
     if (qs != std::string::npos) h->solo_share = int(std::strtol(t.c_str() + qs + 11, nullptr, 0));
   }
+  if (const char* mf = std::getenv("LII_MAP_FUSE")) h->map_fuse = mf[0] != '0';
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;
 #define CK(call)                                                                  \

@@ -182,6 +182,7 @@ int map_join(lii_handle h) {
       if (h->diag && h->map_repeats <= 8)
         std::fprintf(stderr, "[libliinit_hip] map update repeated: lists of %d / %d points, enqueued for %d / %d\n", ca, cn, h->bound_add, h->bound_nodown);
       h->map_flag_pending = false;  // (of the update that did nothing)
+      if (h->map_fuse) h->ah_filled = true;  // (k_map_decide filled the fold's table up to the bound and no fold consumed it: map_apply clears it first)
       return map_apply(h, h->d_list_add, ca, true, h->d_list_nodown, cn, false, nullptr, nullptr, false);
     }
   }
@@ -303,7 +304,7 @@ lii::WinKeep win_keep_view(lii_handle h) {
   return wk;
 }
 int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra, bool beside,
-              const int* n_list_dev, const int* n_extra_dev, bool count_events) {
+              const int* n_list_dev, const int* n_extra_dev, bool count_events, bool prefilled) {
   hipStream_t s = h->stream;
   int rc = map_counters(h);
   if (rc != LII_OK) return rc;
@@ -339,9 +340,29 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
   // one launch each for the cells of both insert lists and for writing both (the second list rides behind the first)
   const float4* list_a = list;
   const unsigned int* flags_a = nullptr;
-  if (downsample && n_list > 0 && !count_events && !h->fold_sorted && n_list <= h->cfg.max_scan_points) {
+  bool cells_done = false;
+  const bool hashed = downsample && n_list > 0 && !count_events && !h->fold_sorted && n_list <= h->cfg.max_scan_points;
+  // The table of the hash-grouped fold is all ones between updates.  k_map_decide may have filled it for THIS list and bound (`prefilled`:
+  // map_update_early); a fill that no fold consumed - the list outgrew its bound, or the update before this one never got as far as its
+  // fold - is cleared before anything else uses the table.
+  if (h->ah_filled && !(hashed && prefilled)) {
+    const size_t slots = lii::add_hash_slots(h->cfg.max_scan_points);
+    HIPCHK(h, hipMemsetAsync(h->d_ah_key, 0xFF, 8 * slots, s));
+    HIPCHK(h, hipMemsetAsync(h->d_ah_best, 0xFF, 8 * slots, s));
+    h->ah_cleared++;
+    prefilled = false;
+  }
+  h->ah_filled = false;
+  if (hashed) {
+    // round 6: the cells of the inserts are found / created inside the fold launch, the second list's in workgroups behind the fold's
+    // (LII_MAP_FUSE=0: launch_ins_cells behind the fold, the form of rounds 2 - 5)
+    lii::FoldCellsH fcells;
+    fcells.blocks = h->d_blocks; fcells.mask = h->block_mask; fcells.tables_cap = tables_cap; fcells.ins_e = h->d_ins_e; fcells.dropped = h->d_dropped;
+    fcells.drop_cap = h->drop_cap; fcells.key_of_id = h->d_block_key; fcells.list2 = extra; fcells.n2 = n_extra; fcells.n2_dev = n_extra_dev; fcells.ins_e2 = h->d_ins_e2;
+    cells_done = h->map_fuse;
     launch_add_fold_hashed(list, n_list, n_list_dev, h->ds, g, h->d_ah_key, h->d_ah_best, h->d_ah_slot, h->d_tomb, h->d_ins, h->d_u32_a,
-                           reinterpret_cast<unsigned int*>(h->d_mapctr + kMapCtrEvents), h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s);
+                           reinterpret_cast<unsigned int*>(h->d_mapctr + kMapCtrEvents), h->d_tp, h->d_work, h->d_mapctr, h->work_cap, s,
+                           prefilled, cells_done ? &fcells : nullptr);
     list_a = h->d_ins;
     flags_a = h->d_u32_a;
   } else if (downsample && n_list > 0) {
@@ -352,8 +373,9 @@ int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, con
     list_a = h->d_ins;
     flags_a = h->d_u32_a;
   }
-  launch_ins_cells(list_a, flags_a, n_list, flags_a ? nullptr : n_list_dev, extra, n_extra, n_extra_dev, h->d_ins_e2, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp,
-                   h->d_work, h->d_mapctr, h->work_cap, h->d_dropped, h->drop_cap, h->d_block_key, s);
+  if (!cells_done)
+    launch_ins_cells(list_a, flags_a, n_list, flags_a ? nullptr : n_list_dev, extra, n_extra, n_extra_dev, h->d_ins_e2, h->d_blocks, h->block_mask, g.inv_cs, tables_cap, h->d_ins_e, h->d_tp,
+                     h->d_work, h->d_mapctr, h->work_cap, h->d_dropped, h->drop_cap, h->d_block_key, s);
   // (cell entries change: the dense window is kept current by the two launches that change them - WinKeep - or dropped)
   const lii::WinKeep wk = win_keep_view(h);
   if (wk.win) h->win_kept++;
@@ -388,12 +410,16 @@ int map_update_early(lii_handle h) {
   PoseArg unused;
   std::memset(&unused, 0, sizeof(unused));
   if (++h->decide_epoch == 0u) h->decide_epoch = 1u;
+  // round 6: the hash insert of the fold rides in the decision launch when the fold that follows will take the hash-grouped form
+  const bool fill = h->map_fuse && ba > 0 && !h->fold_sorted && ba <= h->cfg.max_scan_points && !h->ah_filled;
   launch_map_decide_compact(rb, unused, double(h->cfg.map_downsample_size), 1, reinterpret_cast<unsigned long long*>(h->d_u32_b), h->decide_epoch, h->d_world,
-                            h->d_list_add, h->d_list_nodown, h->d_counts, ba, bn, h->stream, h->d_ctrl, h->update_seq, h->test_emit_late ? 1 : 0);
+                            h->d_list_add, h->d_list_nodown, h->d_counts, ba, bn, h->stream, h->d_ctrl, h->update_seq, h->test_emit_late ? 1 : 0,
+                            fill ? h->d_ah_key : nullptr, h->d_ah_best, h->d_ah_slot, h->ds, h->d_u32_a, h->d_mapctr + kMapCtrEvents);
+  if (fill) h->ah_filled = true;
   // (on the handle's own stream: the update sits right behind the passes anyway, and handing it to the map stream costs more - an
   // event between two hardware queues - than the next scan's de-skew and voxel filter beside it bring back: 5 007 against 4 826
   // scans/s with an update every scan, gpurun_out/r4y)
-  const int rc = map_apply(h, h->d_list_add, ba, true, h->d_list_nodown, bn, false, h->d_counts + 3, h->d_counts + 4, false);
+  const int rc = map_apply(h, h->d_list_add, ba, true, h->d_list_nodown, bn, false, h->d_counts + 3, h->d_counts + 4, false, fill);
   return rc == LII_OK ? 1 : rc;
 }
 

@@ -67,6 +67,9 @@ struct lii_context {
   unsigned long long* d_ah_key = nullptr;   // hash-grouped fold of lii_map_incremental (lii_map.hip: AddHash): voxel keys,
   unsigned long long* d_ah_best = nullptr;  // per-slot minima (both all ones between updates),
   unsigned int* d_ah_slot = nullptr;        // the slot of every batch point
+  bool map_fuse = true;                     // round 6 (LII_MAP_FUSE=0 turns both off): the fold's hash insert rides in k_map_decide, the inserts' cells in the fold launch
+  bool ah_filled = false;                   // k_map_decide has filled the fold's table and no fold has consumed it yet
+  long long ah_cleared = 0;                 // ... times such a fill had to be cleared (a list that outgrew its bound)
   bool fold_sorted = false;                 // LII_TEST=fold_sort: lii_map_incremental folds through the batch sort as lii_map_add_points does
   int* d_mapctr = nullptr;            // kMapCtr* counters
   int n_used = 0;                     // host copy of kMapCtrUsed as of the last map_counters()
@@ -325,7 +328,7 @@ lii::WinKeep win_keep_view(lii_handle h);  // the window as the update's launche
 int map_gather(lii_handle h, int* n_out);
 int map_rebuild(lii_handle h, int extra_blocks);
 int map_apply(lii_handle h, const float4* list, int n_list, bool downsample, const float4* extra, int n_extra, bool beside = false,
-              const int* n_list_dev = nullptr, const int* n_extra_dev = nullptr, bool count_events = true);
+              const int* n_list_dev = nullptr, const int* n_extra_dev = nullptr, bool count_events = true, bool prefilled = false);
 // lii_capi_comm.cpp
 void comm_drop(lii_handle h);
 void partition_refresh(lii_handle h);

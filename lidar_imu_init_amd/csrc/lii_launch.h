@@ -166,16 +166,25 @@ void launch_calib_eval(int stage, const double* imu, const double* lidar, int n,
 // device-side map maintenance (lii_map.hip)
 void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned long long* blk_counts, unsigned int epoch,
                                float4* world, float4* dst_add, float4* dst_nodown, int* counts, int bound_add, int bound_nodown, hipStream_t s,
-                               const IekfCtrl* guard = nullptr, int seq = 0, int test_late = 0);  // blk_counts: one word per 256 points; epoch: the number of this run (never 0); guard: see k_map_decide
+                               const IekfCtrl* guard = nullptr, int seq = 0, int test_late = 0,
+                               // (hkey != nullptr: the hash insert of the fold that follows rides in this launch - table sized by bound_add)
+                               unsigned long long* hkey = nullptr, unsigned long long* hbest = nullptr, unsigned int* slot_of = nullptr, float ds = 0.f,
+                               unsigned int* ins_flag = nullptr, int* events = nullptr);  // blk_counts: one word per 256 points; epoch: the number of this run (never 0); guard: see k_map_decide
 void launch_map_publish(const int* ctr, int n_words, int* host, int seq_at, int seq, hipStream_t s);
 void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, int* events, hipStream_t s);
 void launch_add_fold(const float4* add_pts, const unsigned long long* keys, const unsigned int* idx, int n, float ds, const GridView& g,
                      unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag, unsigned int* events, unsigned int* tp, unsigned int* work,
                      int* ctr, unsigned int work_cap, hipStream_t s);
 size_t add_hash_slots(int max_n);
+// the cells of the inserts found / created inside the fold launch (k_add_fold8<true, true>) instead of by launch_ins_cells behind it
+struct FoldCellsH {
+  BlockEntry* blocks; unsigned int mask; unsigned int tables_cap; unsigned int* ins_e; float4* dropped; unsigned int drop_cap; unsigned long long* key_of_id;
+  const float4* list2; int n2; const int* n2_dev; unsigned int* ins_e2;
+};
 void launch_add_fold_hashed(const float4* add_pts, int n, const int* n_dev, float ds, const GridView& g, unsigned long long* hkey,
                             unsigned long long* hbest, unsigned int* slot_of, unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag,
-                            unsigned int* events, unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s);
+                            unsigned int* events, unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s,
+                            bool inserted = false, const FoldCellsH* cells = nullptr);
 // in-place map update (lii_map.hip)
 void launch_ins_cells(const float4* list, const unsigned int* flags, int n, const int* n_dev, const float4* list2, int n2, const int* n2_dev, unsigned int* ins_e2,
                       BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* ins_e, unsigned int* tp,

@@ -35,6 +35,11 @@ __device__ __forceinline__ unsigned int d_hash_block(int bx, int by, int bz) {
 __device__ __forceinline__ unsigned long long d_pack_block(int bx, int by, int bz) {
   return ((unsigned long long)(unsigned)bz << 36) | ((unsigned long long)(unsigned)by << 18) | (unsigned long long)(unsigned)bx;
 }
+// FRESH: blocks may be CREATED beside this lookup, in the same launch (k_add_fold8<true, true>: the inserts' cells ride in the fold).  A block
+// whose key is there and whose id is not yet (pad == 0; k_ins_cells' creator stores key -> id -> pad, the pad with release order) is a block
+// of this very launch: it holds no point yet - empty, like a block that is not in the table.  id and pad are ONE aligned 8-byte word: a copy
+// of the entry that shows pad = 1 shows the id that was stored before it, however old the copy of the key beside it is.
+template <bool FRESH = false>
 __device__ __forceinline__ uint2 d_cell_range(const GridView& g, int ix, int iy, int iz) {
   const int bb = kBias >> kCoarseShift;
   const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
@@ -43,6 +48,7 @@ __device__ __forceinline__ uint2 d_cell_range(const GridView& g, int ix, int iy,
   while (true) {
     BlockEntry e = g.blocks[sl];
     if (e.key == bk) {
+      if (FRESH && e.pad == 0u) return make_uint2(0u, 0u);
       const unsigned local = (((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u);
       return g.cells[(size_t)e.id * kCells + local];
     }
@@ -51,6 +57,7 @@ __device__ __forceinline__ uint2 d_cell_range(const GridView& g, int ix, int iy,
   }
 }
 // the same lookup, also returning the cell's entry index (block id * 512 + local cell; -1: the block is not in the table)
+template <bool FRESH = false>
 __device__ __forceinline__ uint2 d_cell_range_e(const GridView& g, int ix, int iy, int iz, long long& entry) {
   const int bb = kBias >> kCoarseShift;
   const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
@@ -59,6 +66,7 @@ __device__ __forceinline__ uint2 d_cell_range_e(const GridView& g, int ix, int i
   while (true) {
     BlockEntry e = g.blocks[sl];
     if (e.key == bk) {
+      if (FRESH && e.pad == 0u) { entry = -1; return make_uint2(0u, 0u); }
       const unsigned local = (((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u);
       entry = (long long)e.id * kCells + local;
       return g.cells[(size_t)entry];
@@ -175,6 +183,43 @@ __device__ __forceinline__ MapDecision map_decide_point(const RegistrationBuffer
   }
   return d;
 }
+struct AddHash {
+  unsigned long long* key;   // voxel key, kInvalidKey = free
+  unsigned long long* best;  // (float bits of d2 to the voxel centre << 32) | ~batch index; ~0 = none
+  unsigned int* slot_of;     // per batch point
+  unsigned int mask;         // slots - 1
+};
+__device__ __forceinline__ unsigned int ah_hash(unsigned long long k) {
+  k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 33; k *= 0xC4CEB9FE1A85EC53ull; k ^= k >> 33;
+  return (unsigned int)k;
+}
+__device__ __forceinline__ void add_box(const float4 p, float ds, float (&bmin)[3], float (&bmax)[3], float (&mid)[3]) {
+  const float cc[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    bmin[a] = floorf(cc[a] / ds) * ds;
+    bmax[a] = bmin[a] + ds;
+    mid[a] = (float)((double)bmin[a] + (double)(bmax[a] - bmin[a]) / 2.0);
+  }
+}
+// one batch point into the table: its voxel's slot (found or created) and its bid for the voxel's minimum; 0xFFFFFFFF: a non-finite point
+__device__ __forceinline__ unsigned int addh_insert_one(const float4 p, unsigned int index, float ds, const AddHash& tb) {
+  const int vx = (int)floorf(p.x / ds), vy = (int)floorf(p.y / ds), vz = (int)floorf(p.z / ds);  // (:390-395, float arithmetic)
+  const unsigned long long key = ((unsigned long long)(unsigned)(vz + kBias) << 42) | ((unsigned long long)(unsigned)(vy + kBias) << 21) |
+                                 (unsigned long long)(unsigned)(vx + kBias);
+  float bmin[3], bmax[3], mid[3];
+  add_box(p, ds, bmin, bmax, mid);
+  const float d = d_dist2(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
+  if (!(d == d)) return 0xFFFFFFFFu;  // (a non-finite point takes no part)
+  unsigned int slot = ah_hash(key) & tb.mask;
+  while (true) {
+    const unsigned long long prev = atomicCAS(tb.key + slot, kInvalidKey, key);
+    if (prev == kInvalidKey || prev == key) break;
+    slot = (slot + 1) & tb.mask;
+  }
+  atomicMin(tb.best + slot, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(~index));
+  return slot;
+}
 // (adds << 16 | no-down-samples) over the 256 points of a workgroup; every lane must call it
 __device__ __forceinline__ unsigned int map_decide_count(unsigned int fa, unsigned int fn, unsigned int* s_a /*[4]*/, unsigned int* s_n /*[4]*/,
                                                          unsigned long long* ma_out, unsigned long long* mn_out) {
@@ -188,7 +233,8 @@ __device__ __forceinline__ unsigned int map_decide_count(unsigned int fa, unsign
 __global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, PoseArg ps_val, double fsd, int have_search,
                                                     unsigned long long* __restrict__ blk_counts, unsigned int epoch, float4* __restrict__ world_out,
                                                     float4* __restrict__ dst_add, float4* __restrict__ dst_nodown, int* __restrict__ counts, int bound_a,
-                                                    int bound_n, const IekfCtrl* __restrict__ guard, int seq, int test_late) {
+                                                    int bound_n, const IekfCtrl* __restrict__ guard, int seq, int test_late, AddHash tb, float ds,
+                                                    unsigned int* __restrict__ ins_flag, int* __restrict__ events) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const PoseArg ps = load_pose(guard != nullptr, reinterpret_cast<const PoseArg*>(guard), ps_val);  // (IekfCtrl::st leads the block)
   const bool go = !guard || (guard->stop == 1 && guard->singular == 0 && guard->seq == seq);  // uniform
@@ -231,8 +277,17 @@ __global__ __launch_bounds__(256) void k_map_decide(RegistrationBuffers rb, Pose
   }
   for (int k = 0; k < w; k++) { base_a += s_a[k]; base_n += s_n[k]; }
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
-  if (fa) dst_add[base_a + (unsigned int)__popcll(ma & lanes_below)] = wp;
+  const unsigned int at_a = base_a + (unsigned int)__popcll(ma & lanes_below);
+  if (fa) dst_add[at_a] = wp;
   if (fn) dst_nodown[base_n + (unsigned int)__popcll(mn & lanes_below)] = wp;
+  // lii_scan_job::map_update (round 6): the fold's hash insert rides here - every point of the add list knows its place in the list, which
+  // is all k_addh_insert took from a launch of its own.  Only places below the bound the fold is enqueued for are inserted (its table is
+  // sized by the bound); a list that outgrows the bound leaves a table the repeated update clears first (map_join).
+  if (tb.key) {  // (uniform)
+    if (i == 0) *events = 0;
+    if (i < bound_a) ins_flag[i] = 0u;
+    if (fa && at_a < (unsigned int)bound_a) tb.slot_of[at_a] = addh_insert_one(wp, at_a, ds, tb);
+  }
 }
 
 
@@ -265,25 +320,6 @@ __global__ void k_add_keys(const float4* __restrict__ pts, int n, const int* __r
 // finds its voxel's slot in an open-addressing table (CAS on the 63-bit voxel key) and takes part in ONE 64-bit atomicMin per
 // slot on (distance bits << 32 | ~index); the point that holds the minimum afterwards is P* and leads the voxel through
 // k_add_fold8<true>.  Two launches instead of the key kernel, the batch sort (5 - 7 launches) and the fold.
-struct AddHash {
-  unsigned long long* key;   // voxel key, kInvalidKey = free
-  unsigned long long* best;  // (float bits of d2 to the voxel centre << 32) | ~batch index; ~0 = none
-  unsigned int* slot_of;     // per batch point
-  unsigned int mask;         // slots - 1
-};
-__device__ __forceinline__ unsigned int ah_hash(unsigned long long k) {
-  k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 33; k *= 0xC4CEB9FE1A85EC53ull; k ^= k >> 33;
-  return (unsigned int)k;
-}
-__device__ __forceinline__ void add_box(const float4 p, float ds, float (&bmin)[3], float (&bmax)[3], float (&mid)[3]) {
-  const float cc[3] = {p.x, p.y, p.z};
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    bmin[a] = floorf(cc[a] / ds) * ds;
-    bmax[a] = bmin[a] + ds;
-    mid[a] = (float)((double)bmin[a] + (double)(bmax[a] - bmin[a]) / 2.0);
-  }
-}
 __global__ void k_addh_insert(const float4* __restrict__ pts, int n, const int* __restrict__ n_dev, float ds, AddHash tb,
                               unsigned int* __restrict__ ins_flag, int* __restrict__ events) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,25 +327,101 @@ __global__ void k_addh_insert(const float4* __restrict__ pts, int n, const int* 
   if (i >= n) return;
   ins_flag[i] = 0;
   unsigned int slot = 0xFFFFFFFFu;
-  if (!n_dev || i < *n_dev) {
-    const float4 p = pts[i];
-    const int vx = (int)floorf(p.x / ds), vy = (int)floorf(p.y / ds), vz = (int)floorf(p.z / ds);  // (:390-395, float arithmetic)
-    const unsigned long long key = ((unsigned long long)(unsigned)(vz + kBias) << 42) | ((unsigned long long)(unsigned)(vy + kBias) << 21) |
-                                   (unsigned long long)(unsigned)(vx + kBias);
-    float bmin[3], bmax[3], mid[3];
-    add_box(p, ds, bmin, bmax, mid);
-    const float d = d_dist2(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
-    if (d == d) {  // (a non-finite point takes no part)
-      slot = ah_hash(key) & tb.mask;
-      while (true) {
-        const unsigned long long prev = atomicCAS(tb.key + slot, kInvalidKey, key);
-        if (prev == kInvalidKey || prev == key) break;
-        slot = (slot + 1) & tb.mask;
-      }
-      atomicMin(tb.best + slot, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(~(unsigned int)i));
-    }
-  }
+  if (!n_dev || i < *n_dev) slot = addh_insert_one(pts[i], (unsigned int)i, ds, tb);
   tb.slot_of[i] = slot;
+}
+
+namespace {
+__device__ __forceinline__ unsigned int m_hash_block(int bx, int by, int bz) { return d_hash_block(bx, by, bz); }
+}  // namespace
+
+// An insert that found no room (block tables full, no slack left and no tail to move the cell to) is kept for the host: the
+// next read of the counters rebuilds the index with more room and inserts these points again.
+__device__ __forceinline__ void drop_point(float4* __restrict__ dropped, unsigned int drop_cap, int* __restrict__ ctr, const float4 p) {
+  const unsigned int at = (unsigned int)atomicAdd(&ctr[kMapCtrDropped], 1);
+  if (at < drop_cap) dropped[at] = make_float4(p.x, p.y, p.z, 0.f);
+}
+
+// One insert finds its cell entry - creating the 8x8x8 block when the map has never seen it -, bumps the cell's pending count and puts the
+// cell on the work list; *ins_e_out = the entry (0xFFFFFFFF: parked for the host's rebuild).
+struct InsCells {
+  BlockEntry* blocks;
+  unsigned int mask;
+  float inv_cs;
+  unsigned int tables_cap;
+  unsigned int* tp;
+  unsigned int* work;
+  int* ctr;
+  unsigned int work_cap;
+  float4* dropped;
+  unsigned int drop_cap;
+  unsigned long long* key_of_id;
+};
+__device__ __forceinline__ void ins_cell_one(const float4 p, unsigned int* __restrict__ ins_e_out, const InsCells& a) {
+  BlockEntry* blocks = a.blocks;
+  const unsigned int mask = a.mask, tables_cap = a.tables_cap;
+  int* ctr = a.ctr;
+  const int ix = (int)floorf(p.x * a.inv_cs), iy = (int)floorf(p.y * a.inv_cs), iz = (int)floorf(p.z * a.inv_cs);
+  const int bb = kBias >> kCoarseShift;
+  const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
+  const unsigned long long bk = d_pack_block(bx, by, bz);
+  unsigned int sl = m_hash_block(bx, by, bz) & mask;
+  long long id = -1;
+  // One loop, no waiting inside it: a lane that finds its block's key but not yet its id (another lane - possibly of this very
+  // wavefront - is creating the block) goes round the loop again on the SAME slot.  The lanes of a wavefront execute the loop
+  // body together, so the creator's stores are issued in the round in which it wins the slot and the waiter sees them in the
+  // next one; an inner spin loop would depend on the order in which the compiler lays out the two branches (wavefronts have
+  // no independent thread scheduling).
+  for (unsigned int probes = 0; probes <= mask;) {
+    unsigned long long k = __hip_atomic_load(&blocks[sl].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == kEmptyKey) {
+      // A slot of the block table is reserved before it is claimed: the table must keep a free slot, or probes for blocks that
+      // are not there (every search does them) would never end.
+      const int s_used = atomicAdd(&ctr[kMapCtrSlots], 1);
+      if ((unsigned int)s_used >= mask) {
+        atomicSub(&ctr[kMapCtrSlots], 1);
+        ctr[kMapCtrOverflow] = 1;
+        break;  // (id < 0: the point is parked for the host's rebuild)
+      }
+      const unsigned long long prev = atomicCAS(&blocks[sl].key, kEmptyKey, bk);
+      if (prev == kEmptyKey) {  // this lane creates the block: a cell table from the (zeroed) pool
+        const int nid = atomicAdd(&ctr[kMapCtrBlocks], 1);
+        // The LAST table of the pool is never handed out: it stays all-empty, and a block that finds the pool exhausted points
+        // at it - searches see an empty block, lanes waiting for this block's id are released and park their points like this
+        // one does (leaving `pad` at 0 would have them wait forever; the host rebuilds with more room).
+        const bool got_table = (unsigned int)nid + 1u < tables_cap;
+        if (!got_table) ctr[kMapCtrOverflow] = 1;
+        if (got_table && a.key_of_id) a.key_of_id[nid] = bk;  // (WinKeep; read by the launches behind this one)
+        __hip_atomic_store(&blocks[sl].id, got_table ? (unsigned int)nid : tables_cap - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&blocks[sl].pad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        id = got_table ? nid : -1;
+        break;
+      }
+      atomicSub(&ctr[kMapCtrSlots], 1);  // somebody else took the slot
+      k = prev;
+    }
+    if (k == bk) {
+      if (__hip_atomic_load(&blocks[sl].pad, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        const unsigned int got = __hip_atomic_load(&blocks[sl].id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        id = got + 1u == tables_cap ? -1 : (long long)got;  // (the shared empty table: its creator found the pool exhausted)
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);  // the id is on its way: look at this slot again
+      continue;
+    }
+    sl = (sl + 1) & mask;
+    probes++;
+  }
+  if (id < 0) {  // no table left for a new block: the point waits in the dropped list for the host's rebuild (nothing is lost)
+    *ins_e_out = 0xFFFFFFFFu;
+    ctr[kMapCtrOverflow] = 1;
+    drop_point(a.dropped, a.drop_cap, ctr, p);
+    return;
+  }
+  const unsigned int e = (unsigned int)id * kCells + ((((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u));
+  *ins_e_out = e;
+  touch_cell(a.tp, a.work, ctr, a.work_cap, e);
+  atomicAdd(&a.tp[e], 1u);
 }
 
 // Add_Points with down-sampling, one voxel group (the batch points of one down-sample box, adjacent after the sort) per EIGHT
@@ -324,16 +436,36 @@ __global__ void k_addh_insert(const float4* __restrict__ pts, int n, const int* 
 // lane / lower index: both forms visit the existing points in the same order.
 // HASHED: the groups come out of the table of k_addh_insert instead of the sorted keys - the batch point that holds its voxel's
 // minimum leads (ins_flag / ins_pts at its own batch index), the replay is the comparison of that point with the existing one.
-template <bool HASHED>
+// CELLS (round 6; HASHED only): what k_ins_cells did in a launch of its own behind the fold rides here - a leader whose batch point stays
+// finds / creates that point's cell at once (fc.ins_e[i]; every other position of the list gets 0xFFFFFFFF), and the workgroups behind the
+// fold's own (blockIdx >= fc.fold_blocks) do the same for the second insert list, which does not pass through the fold.  Cell lookups of
+// such a launch run beside block creations: d_cell_range<FRESH>.
+struct FoldCells {
+  InsCells a;
+  unsigned int* ins_e;     // per position of the folded list
+  const int* n_dev;        // the folded list holds *n_dev points (n is the launch bound); may be nullptr
+  const float4* list2;     // the second list: n2 points (or *n2_dev), all of them inserts, entries to ins_e2
+  int n2;
+  const int* n2_dev;
+  unsigned int* ins_e2;
+  unsigned int fold_blocks;
+};
+template <bool HASHED, bool CELLS>
 __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ add_pts, const unsigned long long* __restrict__ keys,
                                                    const unsigned int* __restrict__ idx, AddHash tb, int n, float ds, GridView g,
                                                    unsigned char* __restrict__ tomb, float4* __restrict__ ins_pts,
                                                    unsigned int* __restrict__ ins_flag, unsigned int* __restrict__ events,
                                                    unsigned int* __restrict__ tp, unsigned int* __restrict__ work, int* __restrict__ ctr,
-                                                   unsigned int work_cap) {
+                                                   unsigned int work_cap, FoldCells fc) {
+  if (CELLS && blockIdx.x >= fc.fold_blocks) {  // (uniform per workgroup) the second insert list
+    const int j = (int)((blockIdx.x - fc.fold_blocks) * blockDim.x + threadIdx.x);
+    if (j < fc.n2 && !(fc.n2_dev && j >= *fc.n2_dev)) ins_cell_one(fc.list2[j], &fc.ins_e2[j], fc.a);
+    return;
+  }
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
   const int c = threadIdx.x & 7;
-  const bool in_range = i < n;
+  const bool in_bound = i < n;  // (n is a launch bound when the list's size is on the device: fc.n_dev)
+  const bool in_range = in_bound && !(HASHED && fc.n_dev && i >= *fc.n_dev);
   unsigned long long key = kInvalidKey;
   unsigned int slot = 0xFFFFFFFFu;
   bool leader_pos;  // uniform over the 8 lanes
@@ -347,7 +479,10 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
     key = in_range ? keys[i] : kInvalidKey;
     leader_pos = in_range && key != kInvalidKey && !(i > 0 && keys[i - 1] == key);
   }
-  if (!leader_pos) return;
+  if (!leader_pos) {
+    if (CELLS && in_bound && c == 0) fc.ins_e[i] = 0xFFFFFFFFu;  // (k_ins_write looks at every position below the bound)
+    return;
+  }
   const float4 p0 = add_pts[HASHED ? (unsigned int)i : idx[i]];
   float bmin[3], bmax[3], mid[3];
   add_box(p0, ds, bmin, bmax, mid);
@@ -376,7 +511,7 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
   long long my_entry = -1;
   if (g.n_pts > 0) {
     if (mine) {
-      r = d_cell_range_e(g, c0[0] + dx, c0[1] + dy, c0[2] + dz, my_entry);
+      r = d_cell_range_e<CELLS>(g, c0[0] + dx, c0[1] + dy, c0[2] + dz, my_entry);
       for (unsigned int j0 = r.x; j0 < r.y; j0 += 4u) {  // four candidates per trip, loaded together; visited in index order
         float4 q4[4];
 #pragma unroll
@@ -395,7 +530,7 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
       for (int cz = c0[2]; cz <= c1[2]; cz++)
         for (int cy = c0[1]; cy <= c1[1]; cy++)
           for (int cx = c0[0]; cx <= c1[0]; cx++) {
-            const uint2 rr = d_cell_range(g, cx, cy, cz);
+            const uint2 rr = d_cell_range<CELLS>(g, cx, cy, cz);
             for (unsigned int j = rr.x; j < rr.y; j++) {
               const float4 q = g.pts[j];
               if (bmin[0] <= q.x && bmax[0] > q.x && bmin[1] <= q.y && bmax[1] > q.y && bmin[2] <= q.z && bmax[2] > q.z) {
@@ -482,7 +617,7 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
       }
     }
   }
-  if (!ev) return;
+  if (ev) {
   // delete every existing in-box point except a surviving one
   // (the lane whose cell holds a tombstoned point also puts that cell on the work list of the in-place update)
   if (n0 == 1) {
@@ -495,7 +630,7 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
       tomb[best] = 1;
       const float4 q = g.pts[best];
       long long e;
-      (void)d_cell_range_e(g, (int)floorf(q.x * g.inv_cs), (int)floorf(q.y * g.inv_cs), (int)floorf(q.z * g.inv_cs), e);
+      (void)d_cell_range_e<CELLS>(g, (int)floorf(q.x * g.inv_cs), (int)floorf(q.y * g.inv_cs), (int)floorf(q.z * g.inv_cs), e);
       if (e >= 0) touch_cell(tp, work, ctr, work_cap, (unsigned int)e);
     }
   } else if (n0 > 1) {
@@ -511,7 +646,7 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
         for (int cy = c0[1]; cy <= c1[1]; cy++)
           for (int cx = c0[0]; cx <= c1[0]; cx++) {
             long long e;
-            const uint2 rr2 = d_cell_range_e(g, cx, cy, cz, e);
+            const uint2 rr2 = d_cell_range_e<CELLS>(g, cx, cy, cz, e);
             bool any = false;
             for (unsigned int j = rr2.x; j < rr2.y; j++) {
               const float4 q = g.pts[j];
@@ -522,6 +657,27 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
             }
             if (any && e >= 0) touch_cell(tp, work, ctr, work_cap, (unsigned int)e);
           }
+    }
+  }
+  }
+  // (behind the tombstones: the leader's atomics are not in the way of the other seven lanes' marks)
+  if (CELLS) {
+    // The cell of the batch point that stays is one of the (up to) eight cells the group's lanes have just looked up: its entry comes out
+    // of that lane's register - no probe of the block table, the chain k_ins_cells spent its launch on.  Only a point whose block does
+    // not exist yet (or is being created beside this lookup), or a box wider than 2 x 2 x 2 cells, goes through the find-or-create loop.
+    const int ix = (int)floorf(p0.x * g.inv_cs) - c0[0], iy = (int)floorf(p0.y * g.inv_cs) - c0[1], iz = (int)floorf(p0.z * g.inv_cs) - c0[2];
+    const bool among = !wide && (unsigned)ix < 2u && (unsigned)iy < 2u && (unsigned)iz < 2u;
+    const int e_lane = __shfl((int)my_entry, (among ? (ix | (iy << 1) | (iz << 2)) : 0), 8);  // (all eight lanes of a leader's group are here)
+    if (c == 0) {
+      if (!cur_new) {
+        fc.ins_e[i] = 0xFFFFFFFFu;
+      } else if (among && e_lane >= 0) {
+        fc.ins_e[i] = (unsigned int)e_lane;
+        touch_cell(tp, work, ctr, work_cap, (unsigned int)e_lane);
+        atomicAdd(&tp[e_lane], 1u);
+      } else {
+        ins_cell_one(make_float4(p0.x, p0.y, p0.z, 0.f), &fc.ins_e[i], fc.a);
+      }
     }
   }
 }
@@ -541,25 +697,13 @@ __global__ __launch_bounds__(256) void k_add_fold8(const float4* __restrict__ ad
 // in the array) depends on the order the atomics resolve: the map is the same SET on every run and every rank, its array
 // order is not.  A rebuild (gather -> sort -> index -> spread, lii_capi.cpp) restores the cell-sorted order when the tail
 // fills up or the block table gets crowded.
-namespace {
-__device__ __forceinline__ unsigned int m_hash_block(int bx, int by, int bz) { return d_hash_block(bx, by, bz); }
-}  // namespace
 
-
-// An insert that found no room (block tables full, no slack left and no tail to move the cell to) is kept for the host: the
-// next read of the counters rebuilds the index with more room and inserts these points again.
-__device__ __forceinline__ void drop_point(float4* __restrict__ dropped, unsigned int drop_cap, int* __restrict__ ctr, const float4 p) {
-  const unsigned int at = (unsigned int)atomicAdd(&ctr[kMapCtrDropped], 1);
-  if (at < drop_cap) dropped[at] = make_float4(p.x, p.y, p.z, 0.f);
-}
 
 // flags == nullptr: every point of the list is an insert.  n_dev != nullptr: the list holds *n_dev points (n is the launch bound).
 // A second list (list2, n2 points, all of them inserts, entries to ins_e2) rides in the same launch: lanes [n, n + n2).
 __global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int* __restrict__ flags, int n, const int* __restrict__ n_dev,
                             const float4* __restrict__ list2, int n2, const int* __restrict__ n2_dev, unsigned int* __restrict__ ins_e2,
-                            BlockEntry* blocks, unsigned int mask, float inv_cs, unsigned int tables_cap, unsigned int* __restrict__ ins_e,
-                            unsigned int* __restrict__ tp, unsigned int* __restrict__ work, int* __restrict__ ctr, unsigned int work_cap,
-                            float4* __restrict__ dropped, unsigned int drop_cap, unsigned long long* __restrict__ key_of_id) {
+                            unsigned int* __restrict__ ins_e, InsCells a) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) {
     i -= n;
@@ -569,68 +713,7 @@ __global__ void k_ins_cells(const float4* __restrict__ list, const unsigned int*
     return;
   }
   if (flags && !flags[i]) { ins_e[i] = 0xFFFFFFFFu; return; }
-  const float4 p = list[i];
-  const int ix = (int)floorf(p.x * inv_cs), iy = (int)floorf(p.y * inv_cs), iz = (int)floorf(p.z * inv_cs);
-  const int bb = kBias >> kCoarseShift;
-  const int bx = (ix >> kCoarseShift) + bb, by = (iy >> kCoarseShift) + bb, bz = (iz >> kCoarseShift) + bb;
-  const unsigned long long bk = d_pack_block(bx, by, bz);
-  unsigned int sl = m_hash_block(bx, by, bz) & mask;
-  long long id = -1;
-  // One loop, no waiting inside it: a lane that finds its block's key but not yet its id (another lane - possibly of this very
-  // wavefront - is creating the block) goes round the loop again on the SAME slot.  The lanes of a wavefront execute the loop
-  // body together, so the creator's stores are issued in the round in which it wins the slot and the waiter sees them in the
-  // next one; an inner spin loop would depend on the order in which the compiler lays out the two branches (wavefronts have
-  // no independent thread scheduling).
-  for (unsigned int probes = 0; probes <= mask;) {
-    unsigned long long k = __hip_atomic_load(&blocks[sl].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == kEmptyKey) {
-      // A slot of the block table is reserved before it is claimed: the table must keep a free slot, or probes for blocks that
-      // are not there (every search does them) would never end.
-      const int s_used = atomicAdd(&ctr[kMapCtrSlots], 1);
-      if ((unsigned int)s_used >= mask) {
-        atomicSub(&ctr[kMapCtrSlots], 1);
-        ctr[kMapCtrOverflow] = 1;
-        break;  // (id < 0: the point is parked for the host's rebuild)
-      }
-      const unsigned long long prev = atomicCAS(&blocks[sl].key, kEmptyKey, bk);
-      if (prev == kEmptyKey) {  // this lane creates the block: a cell table from the (zeroed) pool
-        const int nid = atomicAdd(&ctr[kMapCtrBlocks], 1);
-        // The LAST table of the pool is never handed out: it stays all-empty, and a block that finds the pool exhausted points
-        // at it - searches see an empty block, lanes waiting for this block's id are released and park their points like this
-        // one does (leaving `pad` at 0 would have them wait forever; the host rebuilds with more room).
-        const bool got_table = (unsigned int)nid + 1u < tables_cap;
-        if (!got_table) ctr[kMapCtrOverflow] = 1;
-        if (got_table && key_of_id) key_of_id[nid] = bk;  // (WinKeep; read by the launches behind this one)
-        __hip_atomic_store(&blocks[sl].id, got_table ? (unsigned int)nid : tables_cap - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&blocks[sl].pad, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        id = got_table ? nid : -1;
-        break;
-      }
-      atomicSub(&ctr[kMapCtrSlots], 1);  // somebody else took the slot
-      k = prev;
-    }
-    if (k == bk) {
-      if (__hip_atomic_load(&blocks[sl].pad, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-        const unsigned int got = __hip_atomic_load(&blocks[sl].id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        id = got + 1u == tables_cap ? -1 : (long long)got;  // (the shared empty table: its creator found the pool exhausted)
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);  // the id is on its way: look at this slot again
-      continue;
-    }
-    sl = (sl + 1) & mask;
-    probes++;
-  }
-  if (id < 0) {  // no table left for a new block: the point waits in the dropped list for the host's rebuild (nothing is lost)
-    ins_e[i] = 0xFFFFFFFFu;
-    ctr[kMapCtrOverflow] = 1;
-    drop_point(dropped, drop_cap, ctr, p);
-    return;
-  }
-  const unsigned int e = (unsigned int)id * kCells + ((((unsigned)iz & 7u) << 6) | (((unsigned)iy & 7u) << 3) | ((unsigned)ix & 7u));
-  ins_e[i] = e;
-  touch_cell(tp, work, ctr, work_cap, e);
-  atomicAdd(&tp[e], 1u);
+  ins_cell_one(list[i], &ins_e[i], a);
 }
 
 __global__ void k_cell_apply(const unsigned int* __restrict__ work, uint2* __restrict__ cells, unsigned int* __restrict__ cell_cap,
@@ -827,9 +910,11 @@ void launch_ins_cells(const float4* list, const unsigned int* flags, int n, cons
                       unsigned int* work, int* ctr, unsigned int work_cap, float4* dropped, unsigned int drop_cap, unsigned long long* key_of_id, hipStream_t s) {
   if (n < 0) n = 0;
   if (n2 < 0) n2 = 0;
+  InsCells a;
+  a.blocks = blocks; a.mask = mask; a.inv_cs = inv_cs; a.tables_cap = tables_cap; a.tp = tp; a.work = work; a.ctr = ctr; a.work_cap = work_cap;
+  a.dropped = dropped; a.drop_cap = drop_cap; a.key_of_id = key_of_id;
   if (n + n2 > 0)
-    hipLaunchKernelGGL(k_ins_cells, dim3(nblk(n + n2, 256)), dim3(256), 0, s, list, flags, n, n_dev, list2, n2, n2_dev, ins_e2, blocks, mask, inv_cs, tables_cap,
-                       ins_e, tp, work, ctr, work_cap, dropped, drop_cap, key_of_id);
+    hipLaunchKernelGGL(k_ins_cells, dim3(nblk(n + n2, 256)), dim3(256), 0, s, list, flags, n, n_dev, list2, n2, n2_dev, ins_e2, ins_e, a);
 }
 void launch_cell_apply(const unsigned int* work, uint2* cells, unsigned int* cell_cap, float4* pts, unsigned char* tomb, unsigned int* tp, int* ctr,
                        unsigned int pts_cap, int launch_bound, const WinKeep& wk, hipStream_t s) {
@@ -873,12 +958,21 @@ __global__ __launch_bounds__(64) void k_map_publish(const int* __restrict__ ctr,
 void launch_map_publish(const int* ctr, int n_words, int* host, int seq_at, int seq, hipStream_t s) {
   hipLaunchKernelGGL(k_map_publish, dim3(1), dim3(64), 0, s, ctr, n_words, host, seq_at, seq);
 }
+size_t add_hash_slots(int max_n) {
+  size_t slots = 1024;
+  while (slots < 4u * (size_t)max_n) slots <<= 1;
+  return slots;
+}
 void launch_map_decide_compact(const RegistrationBuffers& rb, const PoseArg& ps, double fsd, int have_search, unsigned long long* blk_counts, unsigned int epoch,
                                float4* world, float4* dst_add, float4* dst_nodown, int* counts, int bound_add, int bound_nodown, hipStream_t s,
-                               const IekfCtrl* guard, int seq, int test_late) {
+                               const IekfCtrl* guard, int seq, int test_late, unsigned long long* hkey, unsigned long long* hbest, unsigned int* slot_of,
+                               float ds, unsigned int* ins_flag, int* events) {
   if (rb.n <= 0) return;
+  AddHash tb;  // hkey != nullptr: the hash insert of the fold behind this launch rides in it (table sized by bound_add, as launch_add_fold_hashed sizes it)
+  tb.key = hkey; tb.best = hbest; tb.slot_of = slot_of;
+  tb.mask = hkey ? (unsigned int)(add_hash_slots(bound_add) - 1) : 0u;
   hipLaunchKernelGGL(k_map_decide, dim3(nblk(rb.n, 256)), dim3(256), 0, s, rb, ps, fsd, have_search, blk_counts, epoch, world, dst_add, dst_nodown, counts,
-                     bound_add, bound_nodown, guard, seq, test_late);
+                     bound_add, bound_nodown, guard, seq, test_late, tb, ds, ins_flag, events);
 }
 void launch_add_keys(const float4* pts, int n, const int* n_dev, float ds, unsigned long long* keys, unsigned int* idx, int* events, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(k_add_keys, dim3(nblk(n, 256)), dim3(256), 0, s, pts, n, n_dev, ds, keys, idx, events);
@@ -888,26 +982,40 @@ void launch_add_fold(const float4* add_pts, const unsigned long long* keys, cons
                      int* ctr, unsigned int work_cap, hipStream_t s) {
   AddHash none;
   none.key = nullptr; none.best = nullptr; none.slot_of = nullptr; none.mask = 0;
-  if (n > 0) hipLaunchKernelGGL(k_add_fold8<false>, dim3(nblk(n * 8, 256)), dim3(256), 0, s, add_pts, keys, idx, none, n, ds, g, tomb, ins_pts, ins_flag,
-                            events, tp, work, ctr, work_cap);
+  FoldCells fc;
+  std::memset(&fc, 0, sizeof(fc));
+  if (n > 0) hipLaunchKernelGGL((k_add_fold8<false, false>), dim3(nblk(n * 8, 256)), dim3(256), 0, s, add_pts, keys, idx, none, n, ds, g, tomb, ins_pts, ins_flag,
+                            events, tp, work, ctr, work_cap, fc);
 }
 // The hash-grouped form: n is a launch bound when n_dev != nullptr.  key / best: add_hash_slots(max batch) words each, all ones
 // between calls (the fold leaves them so); slot_of: one word per batch point.
-size_t add_hash_slots(int max_n) {
-  size_t slots = 1024;
-  while (slots < 4u * (size_t)max_n) slots <<= 1;
-  return slots;
-}
 void launch_add_fold_hashed(const float4* add_pts, int n, const int* n_dev, float ds, const GridView& g, unsigned long long* hkey,
                             unsigned long long* hbest, unsigned int* slot_of, unsigned char* tomb, float4* ins_pts, unsigned int* ins_flag,
-                            unsigned int* events, unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s) {
+                            unsigned int* events, unsigned int* tp, unsigned int* work, int* ctr, unsigned int work_cap, hipStream_t s,
+                            bool inserted, const FoldCellsH* cells) {
   if (n <= 0) return;
   AddHash tb;
   tb.key = hkey; tb.best = hbest; tb.slot_of = slot_of;
   tb.mask = (unsigned int)(add_hash_slots(n) - 1);
-  hipLaunchKernelGGL(k_addh_insert, dim3(nblk(n, 256)), dim3(256), 0, s, add_pts, n, n_dev, ds, tb, ins_flag, reinterpret_cast<int*>(events));
-  hipLaunchKernelGGL(k_add_fold8<true>, dim3(nblk(n * 8, 256)), dim3(256), 0, s, add_pts, nullptr, nullptr, tb, n, ds, g, tomb, ins_pts, ins_flag,
-                     events, tp, work, ctr, work_cap);
+  // inserted: k_map_decide has filled the table for exactly this list and bound (launch_map_decide_compact with hkey)
+  if (!inserted) hipLaunchKernelGGL(k_addh_insert, dim3(nblk(n, 256)), dim3(256), 0, s, add_pts, n, n_dev, ds, tb, ins_flag, reinterpret_cast<int*>(events));
+  FoldCells fc;
+  std::memset(&fc, 0, sizeof(fc));
+  fc.n_dev = n_dev;
+  if (!cells) {
+    hipLaunchKernelGGL((k_add_fold8<true, false>), dim3(nblk(n * 8, 256)), dim3(256), 0, s, add_pts, nullptr, nullptr, tb, n, ds, g, tomb, ins_pts, ins_flag,
+                       events, tp, work, ctr, work_cap, fc);
+    return;
+  }
+  // cells: the inserts' cells ride in the fold (and the second list's in workgroups behind it)
+  fc.a.blocks = cells->blocks; fc.a.mask = cells->mask; fc.a.inv_cs = g.inv_cs; fc.a.tables_cap = cells->tables_cap;
+  fc.a.tp = tp; fc.a.work = work; fc.a.ctr = ctr; fc.a.work_cap = work_cap;
+  fc.a.dropped = cells->dropped; fc.a.drop_cap = cells->drop_cap; fc.a.key_of_id = cells->key_of_id;
+  fc.ins_e = cells->ins_e;
+  fc.list2 = cells->list2; fc.n2 = cells->n2 > 0 ? cells->n2 : 0; fc.n2_dev = cells->n2_dev; fc.ins_e2 = cells->ins_e2;
+  fc.fold_blocks = (unsigned int)nblk(n * 8, 256);
+  hipLaunchKernelGGL((k_add_fold8<true, true>), dim3(fc.fold_blocks + (unsigned int)nblk(fc.n2, 256)), dim3(256), 0, s, add_pts, nullptr, nullptr, tb, n, ds, g,
+                     tomb, ins_pts, ins_flag, events, tp, work, ctr, work_cap, fc);
 }
 
 }  // namespace lii
