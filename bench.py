@@ -731,6 +731,8 @@ def from_wire_record(args, wl, reg, drv, stream, n_stream, n_pipe):
     opts.struct_size = C.sizeof(lii_ingest_opts)
     opts.lidar_type, opts.n_scans, opts.point_filter_num = wire.OUSTER, 128, 1
     opts.blind, opts.stamp_s, opts.cut_frame_num, opts.scan_count = 0.01, 0.0, cut, 1000  # (past the first 20 messages, which the reference does not cut)
+    if os.environ.get("LII_WIRE_WHOLE") == "1" and cut == 1:  # (measurement: Preprocess::process - no time sort, 5 launches instead of 16)
+        opts.cut_frame_num = 0
     drv.lii_stream_run_wire.restype = C.c_int
     drv.lii_stream_run_wire.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
@@ -768,14 +770,17 @@ def from_wire_record(args, wl, reg, drv, stream, n_stream, n_pipe):
     over_pageable = record(*run(n_m, True, 1, ptrs), n_m)
     over = record(*run(n_m, True, 1, ptrs_pinned), n_m)
     over_early = record(*run(n_m, True, 3, ptrs_pinned), n_m)
+    over_behind = record(*run(n_m, True, 4, ptrs_pinned), n_m)
     out = dict(over)
     out.update({"cut_frame_num": cut, "points_per_message": int(npts[0]), "bytes_per_message": int(len(msgs[0])),
                 "what": "PointCloud2 bytes (Ouster layout, page-locked host memory) -> lii_ingest_pcl2_begin ... lii_ingest_end (ABI 9: message "
                         "m + 1 is decoded and the bytes of m + 2 travel on streams of their own while message m is registered) -> lii_frame_select "
-                        "-> lii_scan_register with map_update = 1 per sub-frame, C++ host loop; ingest_us_per_message = host time inside "
-                        "lii_ingest_end + lii_ingest_pcl2_begin (one call per message each)",
+                        "-> lii_scan_register with map_update = 1 per sub-frame, C++ host loop; the next message is begun from the registration's "
+                        "while_waiting hook (lii_scan_job::while_waiting: inside the call, when its launches are out); ingest_us_per_message = host "
+                        "time inside lii_ingest_end (the begin's time lies inside lii_scan_register)",
                 "pageable_source": over_pageable,
                 "begun_before_the_registrations": over_early,
+                "begun_behind_the_registrations": over_behind,
                 "serial_ingest": dict(serial, what="one lii_ingest_pcl2 call per message on the handle's own stream (pageable source): H2D of "
                                                    "the raw bytes, its launches and its one synchronisation before the first sub-frame is registered "
                                                    "(the form of the record until ABI 8)"),

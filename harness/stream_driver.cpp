@@ -23,7 +23,7 @@ static int32_t g_map_in_job = 1;
 void lii_stream_set_map_in_job(int32_t in_job) { g_map_in_job = in_job ? 1 : 0; }
 // lii_stream_run_wire: 1 = the overlapped ingest (lii_ingest_pcl2_begin / lii_ingest_end), 0 = one lii_ingest_pcl2 call per message
 static int32_t g_wire_overlap = 0;
-void lii_stream_set_wire_overlap(int32_t overlap) { g_wire_overlap = overlap; }  // (2: one message under way instead of two; 3: begun before the registrations)
+void lii_stream_set_wire_overlap(int32_t overlap) { g_wire_overlap = overlap; }  // (1: begun from the registration's while_waiting hook; 4: behind the registrations; 3: before them; 2: one message under way, behind)
 
 // The scans of these streams are resident in device memory: every job announces its successor (lii_scan_job::next_scan_dev) and the
 // library pre-arms that scan's first launch.  lii_stream_set_announce(0): no announcement, the form of ABI <= 7 (A/B).
@@ -178,6 +178,10 @@ int lii_stream_run_wire(lii_handle h, const lii_stream_scan* scans, int32_t n_sc
     o.scan_count = opts0->scan_count + m;
     return lii_ingest_pcl2_begin(h, msgs[m % n_msgs], msg_points[m % n_msgs], fields, &o);
   };
+  // (how the next message is put under way: 1 = from the registration's while_waiting hook, inside the call, when its launches are out and
+  // the thread would only wait; 4 = behind the registrations; 3 = before them; 2 = one message under way instead of two, behind)
+  struct Hook { decltype(begin)* fn; int32_t m; int rc; bool due; } hook = {&begin, 0, LII_OK, false};
+  auto hook_fn = [](void* a) { Hook* k = static_cast<Hook*>(a); if (k->due) { k->rc = (*k->fn)(k->m); k->due = false; } };
   if (g_wire_overlap) {
     for (int32_t m = 0; m < (g_wire_overlap == 2 ? 1 : 2) && m < steps; m++) {
       rc = begin(m);
@@ -216,15 +220,29 @@ int lii_stream_run_wire(lii_handle h, const lii_stream_scan* scans, int32_t n_sc
       job.opts.imu_en = imu_en;
       job.scan_sorted = 1;  // (the ingest delivers every frame in ascending time order, as the reference's preprocess does)
       job.map_update = map_update ? 1 : 0;
+      if (g_wire_overlap == 1 && f == nf - 1 && m + 2 < steps) {  // (with the message's last sub-frame: the context of message m - 1 is free since lii_ingest_end)
+        hook.m = m + 2; hook.due = true; hook.rc = LII_OK;
+        job.while_waiting = hook_fn; job.while_waiting_arg = &hook;
+      }
       rc = lii_scan_register(h, &job, &st, sc.state0, &rep);
       if (rc != LII_OK) return rc;
+      if (hook.rc != LII_OK) return hook.rc;
       totals[0] += rep.iterations;
       totals[1] += rep.searches;
       ingest_us[1] += 1.0;
     }
+    if (g_wire_overlap == 1 && hook.due) {  // (a message without frames, or a registration that never reached its wait: begun here)
+      hook.due = false;
+      rc = begin(hook.m);
+      if (rc != LII_OK) return rc;
+    }
+    if (g_wire_overlap == 1 && nf == 0 && m + 2 < steps) {
+      rc = begin(m + 2);
+      if (rc != LII_OK) return rc;
+    }
     // the message after next is put under way HERE: its copy and launches are enqueued while the device still runs the map update of
     // the registration that has just returned (begun before the registrations, the host's ~ 50 us of enqueueing sat in front of them)
-    if (g_wire_overlap == 1 || g_wire_overlap == 2) {
+    if (g_wire_overlap == 4 || g_wire_overlap == 2) {
       const int32_t ahead = g_wire_overlap == 2 ? 1 : 2;
       const auto t1 = std::chrono::steady_clock::now();
       if (m + ahead < steps) rc = begin(m + ahead);

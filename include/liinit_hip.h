@@ -29,7 +29,7 @@ extern "C" {
                                 lii_selftest_list_exchange
                              8: lii_last_unfinished_queries, lii_scan_job::next_scan_dev / next_n_scan (struct_size 72: the pre-armed prologue)
                              9: lii_ingest_pcl2_begin / lii_ingest_livox_begin / lii_ingest_end (driver messages queue on the device: message k + 1 is
-                                transferred and decoded while the sub-frames of message k are registered) */
+                                transferred and decoded while the sub-frames of message k are registered), lii_scan_job::while_waiting (struct_size 88) */
 
 enum lii_status {
   LII_OK = 0,
@@ -305,6 +305,16 @@ typedef struct lii_scan_job {
   const void* next_scan_dev;
   int32_t next_n_scan;
   int32_t reserved1;
+  /* ABI 9 (struct_size 88; jobs of size 72, 56 and 48 are still accepted): THE HOST'S TIME INSIDE THE CALL.  Once every launch of the job is
+   * enqueued the calling thread has nothing to do but wait for the result (~ 130 us per scan): while_waiting(while_waiting_arg) is called
+   * exactly then, once, before the wait - the place for what the reference does between two scans (ros::spinOnce, src/laserMapping.cpp:893:
+   * the callbacks that queue the next driver message - here lii_ingest_pcl2_begin / lii_ingest_livox_begin, whose ~ 50 us of enqueueing
+   * then cost the loop nothing).  The hook may call the overlapped ingest's begin functions of this handle and anything that does not take the
+   * handle; it must NOT call entry points that use the handle's stream (they would wait for, or disturb, the update under way).  A hook that
+   * runs longer than the device delays the result by the difference.  Called once by every call that gets as far as its update, not by a
+   * call that fails before.  NULL: nothing is called. */
+  void (*while_waiting)(void* arg);
+  void* while_waiting_arg;
 } lii_scan_job;
 int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, const lii_state* state_propagated,
                       lii_iekf_report* report);

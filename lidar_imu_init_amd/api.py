@@ -48,7 +48,11 @@ class lii_scan_job(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("undistort", C.c_int32), ("imu_poses", C.c_void_p),
                 ("n_imu_poses", C.c_int32), ("leaf", C.c_float), ("opts", lii_iekf_opts), ("scan_dev", C.c_void_p),
                 ("n_scan_dev", C.c_int32), ("scan_sorted", C.c_int32), ("map_update", C.c_int32),
-                ("next_scan_dev", C.c_void_p), ("next_n_scan", C.c_int32), ("reserved1", C.c_int32)]
+                ("next_scan_dev", C.c_void_p), ("next_n_scan", C.c_int32), ("reserved1", C.c_int32),
+                ("while_waiting", C.c_void_p), ("while_waiting_arg", C.c_void_p)]
+
+
+WAIT_HOOK = C.CFUNCTYPE(None, C.c_void_p)  # lii_scan_job::while_waiting
 
 
 class lii_kernel_profile(C.Structure):
@@ -456,7 +460,7 @@ class Registrar:
                     converged=bool(rep.converged), normal_eq=np.array(rep.normal_eq[:]))
 
     def scan_register(self, state: State, state_prop: State, *, imu_poses=None, cv=False, leaf=0.0, max_iterations=4,
-                      imu_en=False, scan_dev=None, scan_sorted=False, map_update=False, next_scan=None):
+                      imu_en=False, scan_dev=None, scan_sorted=False, map_update=False, next_scan=None, while_waiting=None):
         """Undistortion + voxel grid + iterated update in one library call (one host synchronisation).  scan_dev: a
         device_scan() handle to adopt first (what scan_set_device would do, without the separate call).  scan_sorted: the
         points are in ascending time order (lii_scan_job::scan_sorted).  map_update: map_incremental with the final state
@@ -469,6 +473,10 @@ class Registrar:
             job.scan_dev, job.n_scan_dev = scan_dev[0], scan_dev[1]
         if next_scan is not None:  # a device_scan() handle: the scan the NEXT call will bring (lii_scan_job::next_scan_dev - its prologue is pre-armed)
             job.next_scan_dev, job.next_n_scan = next_scan[0], next_scan[1]
+        hook = None
+        if while_waiting is not None:  # a Python callable: runs once inside the call, when every launch is enqueued (lii_scan_job::while_waiting)
+            hook = WAIT_HOOK(lambda _arg: while_waiting())
+            job.while_waiting = C.cast(hook, C.c_void_p)
         poses = None
         if imu_poses is not None:
             poses = np.ascontiguousarray(imu_poses, np.float64).reshape(-1, 22)

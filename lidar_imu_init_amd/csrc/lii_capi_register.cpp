@@ -271,6 +271,12 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     if (!h->pre.armed) __atomic_store_n(&gst->word, (h->pre.seq << 2) | lii::kGateCancel, __ATOMIC_RELEASE);
   }
   h->pre.want_dev = nullptr;
+  // lii_scan_job::while_waiting (ABI 9): everything is enqueued, the thread would only wait now - the caller's hook runs first
+  if (h->wait_hook) {
+    void (*hook)(void*) = h->wait_hook;
+    h->wait_hook = nullptr;
+    hook(h->wait_hook_arg);
+  }
   rc = wait_result(true);
   if (rc != LII_OK) return rc;
   // A parked loop is continued with what it is known to need: the pass it parked in front of - behind a k-NN launch if that pass
@@ -498,8 +504,9 @@ int lii_iekf_update(lii_handle h, lii_state* state, const lii_state* state_prop,
 int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, const lii_state* state_prop,
                       lii_iekf_report* report) {
   // (struct_size 48: a job of ABI 5, without scan_sorted)
-  // (struct_size 72: ABI 8; 56: ABI 6 - 7, without next_scan_dev; 48: ABI 5, without scan_sorted)
-  if (!h || !job || (job->struct_size != sizeof(lii_scan_job) && job->struct_size != 56u && job->struct_size != 48u) || !state || !state_prop || job->opts.max_iterations < 1)
+  // (struct_size 88: ABI 9; 72: ABI 8, without while_waiting; 56: ABI 6 - 7, without next_scan_dev; 48: ABI 5, without scan_sorted)
+  static_assert(sizeof(lii_scan_job) == 88, "lii_scan_job: the sizes of the earlier ABIs are accepted by number");
+  if (!h || !job || (job->struct_size != sizeof(lii_scan_job) && job->struct_size != 72u && job->struct_size != 56u && job->struct_size != 48u) || !state || !state_prop || job->opts.max_iterations < 1)
     return fail(h, LII_ERR_INVALID, "lii_scan_register: bad arguments");
   const bool sorted = job->struct_size >= 56u && job->scan_sorted == 1;
   h->scan_buf_idle = false;
@@ -526,7 +533,7 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   if (!use_pre) prearm_cancel(h);
   // ... and what this job announces for the next call (update_on_device arms it behind the passes)
   h->pre.want_dev = nullptr;
-  if (job->struct_size >= sizeof(lii_scan_job) && job->next_scan_dev && job->next_n_scan > 0 && job->next_n_scan <= h->cfg.max_scan_points && h->pre.enabled &&
+  if (job->struct_size >= 72u && job->next_scan_dev && job->next_n_scan > 0 && job->next_n_scan <= h->cfg.max_scan_points && h->pre.enabled &&
       sorted && job->undistort == 1) {
     h->pre.want_dev = job->next_scan_dev; h->pre.want_n = job->next_n_scan; h->pre.want_leaf = leaf_now; h->pre.want_late = false;
   } else if (h->n_scan_next > 0 && h->d_scan_next && h->pre.enabled && sorted && job->undistort == 1 && !from_job) {
@@ -668,7 +675,16 @@ int lii_scan_register(lii_handle h, const lii_scan_job* job, lii_state* state, c
   const bool map_update = job->struct_size >= 56u && job->map_update == 1;
   h->map_after_update = map_update && !h->host_solve;
   h->map_enqueued_early = false;
+  // lii_scan_job::while_waiting (ABI 9): update_on_device calls it when its launches are out, before it waits for the result; an
+  // arrangement without that wait (LII_TEST=host_solve) calls it behind the update - once per call that got this far, never otherwise
+  h->wait_hook = (rc == LII_OK && job->struct_size >= 88u) ? job->while_waiting : nullptr;
+  h->wait_hook_arg = job->struct_size >= 88u ? job->while_waiting_arg : nullptr;
   if (rc == LII_OK) rc = lii_iekf_update(h, state, state_prop, &job->opts, report);
+  if (h->wait_hook) {
+    void (*hook)(void*) = h->wait_hook;
+    h->wait_hook = nullptr;
+    hook(h->wait_hook_arg);
+  }
   h->map_after_update = false;
   // map_incremental behind the update: already enqueued behind its passes (update_on_device), or made now
   if (rc == LII_OK && map_update && !h->map_enqueued_early) rc = lii_map_incremental(h, state, nullptr, nullptr);

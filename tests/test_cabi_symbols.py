@@ -71,13 +71,15 @@ def test_cxx_host_loop_links_against_the_boundary():
                                    ctypes.c_void_p, ctypes.c_void_p]
     totals = (ctypes.c_int64 * 2)()
     assert drv.lii_stream_run(None, None, 0, 0, 0, 0.0, 5, 1, 0, 0, totals, None) == -1  # LII_ERR_INVALID
-    assert ctypes.sizeof(api.lii_scan_job) == 72  # struct_size the C++ loop fills in (ABI 8; 56: ABI 6 - 7, scan_sorted behind n_scan_dev)
+    assert ctypes.sizeof(api.lii_scan_job) == 88  # struct_size the C++ loop fills in (ABI 9; 72: ABI 8; 56: ABI 6 - 7, scan_sorted behind n_scan_dev)
     # ... and map_update in the formerly reserved word behind it (a job that leaves it 0 behaves as before)
     assert api.lii_scan_job.scan_sorted.offset == 44 and api.lii_scan_job.map_update.offset == 48
     import re
     hdr = open(os.path.join(ROOT, "include", "liinit_hip.h")).read()
     body = hdr[hdr.index("typedef struct lii_scan_job {"):hdr.index("} lii_scan_job;")]
     fields = re.findall(r"^\s*(?:const\s+)?[A-Za-z_0-9]+\*?\s+\*?([a-z_0-9]+);", body, re.M)
-    assert fields[-5:] == ["scan_sorted", "map_update", "next_scan_dev", "next_n_scan", "reserved1"], fields
+    assert fields[-6:] == ["scan_sorted", "map_update", "next_scan_dev", "next_n_scan", "reserved1", "while_waiting_arg"], fields
+    # ABI 9: the hook of the host's time inside the call sits behind the job of ABI 8
+    assert api.lii_scan_job.while_waiting.offset == 72 and api.lii_scan_job.while_waiting_arg.offset == 80
     # ABI 8: the announcement of the next scan sits BEHIND the job of ABI 6 - 7 (a caller that fills in 56 bytes and says so is served as before)
     assert api.lii_scan_job.next_scan_dev.offset == 56 and api.lii_scan_job.next_n_scan.offset == 64

@@ -167,3 +167,54 @@ def test_overlapped_ingest_under_a_registration(oracle):
             assert np.array_equal(sa, sb)
     finally:
         r.close()
+
+
+def test_the_next_message_is_begun_from_inside_the_registration(oracle):
+    """lii_scan_job::while_waiting (ABI 9): the hook runs once inside lii_scan_register, when the job's launches are out - the place to put
+    the next driver message under way.  Frames and registered states are the bits of the serial order."""
+    import lidar_imu_init_amd as lii
+    from conftest import make_state
+    hall, map_pts = synth.bench_world(150_000, 0.15)
+    r = lii.Registrar(max_scan_points=40_000, max_map_points=200_000, filter_size_map=0.15)
+    try:
+        r.map_build(map_pts)
+        msgs, truth = [], []
+        for k in range(5):
+            R, p = synth.rot_zyx(0.0, 0.01, 0.3 + 0.02 * k), np.array([1.0 + 0.05 * k, 2.0, 0.3])
+            xyz, ring, t_ms = wire.raw_sweep(hall, "vlp16", R, p, nan_fraction=0.0)
+            msgs.append((wire.pack_pcl2(wire.VELO, xyz, ring, t_ms, 10.0 + 0.1 * k), len(xyz), wire.pc2_fields(wire.VELO), wire.VELO,
+                         16, 1, 0.5, 10.0 + 0.1 * k, 2, 100))
+            truth.append(make_state(oracle, R, p))
+        calls = []
+
+        def run(hooked):
+            out = []
+            if hooked:
+                r.ingest_pcl2_begin(*msgs[0])
+                r.ingest_pcl2_begin(*msgs[1])
+            for k in range(len(msgs)):
+                info = r.ingest_end() if hooked else r.ingest_pcl2(*msgs[k])
+                for f in range(len(info)):
+                    r.frame_select(f)
+                    s0 = lii.State(oracle.state_boxplus(truth[k], np.r_[0.002, -0.002, 0.003, 0.02, -0.02, 0.01, np.zeros(18)]))
+                    s = s0.copy()
+                    hook = None
+                    if hooked and f == len(info) - 1 and k + 2 < len(msgs):
+                        def hook(k=k):
+                            calls.append(k)
+                            r.ingest_pcl2_begin(*msgs[k + 2])
+                    rep = r.scan_register(s, s0, leaf=0.1, max_iterations=5, imu_en=False, scan_sorted=True, map_update=True, while_waiting=hook)
+                    out.append((info[f], np.array(s.pod).copy(), rep["iterations"], rep["effect_num"]))
+            return out
+
+        a = run(False)
+        n_a = r.map_size()
+        r.map_build(map_pts)
+        b = run(True)
+        assert calls == [0, 1, 2]  # once per registration that carried a hook
+        assert len(a) == len(b) == 10 and r.map_size() == n_a
+        for (ia, sa, ita, ea), (ib, sb, itb, eb) in zip(a, b):
+            assert ia == ib and ita == itb and ea == eb and ea > 2000
+            assert np.array_equal(sa, sb)
+    finally:
+        r.close()

@@ -9,9 +9,9 @@ run() {  # label, env...
 import json
 d=json.loads(open('$O/wire_$l.json').readline()); p=d['complete_pipeline']; w=p.get('from_wire',{})
 g=lambda r: (round(r['value']), round(r['ingest_us_per_message'])) if isinstance(r,dict) and 'value' in r else r
-print('$l', 'value', round(d['value']), 'pipeline', round(p['value']), 'wire: overlapped', g(w), 'pageable', g(w.get('pageable_source')), 'begun early', g(w.get('begun_before_the_registrations')), 'serial', g(w.get('serial_ingest')))
+print('$l', 'value', round(d['value']), 'pipeline', round(p['value']), 'wire: overlapped', g(w), 'pageable', g(w.get('pageable_source')), 'begun early', g(w.get('begun_before_the_registrations')), 'behind', g(w.get('begun_behind_the_registrations')), 'serial', g(w.get('serial_ingest')))
 PY
 }
 run default A=1
-run low LII_INGEST_PRIO=low
+run default2 A=1
 W=os1_128_cut3 run cut3 A=1
