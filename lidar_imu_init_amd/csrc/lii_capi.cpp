@@ -206,6 +206,7 @@ MailboxView mailbox_view(lii_handle h) {
 int lii_internal_fail(lii_context* h, int code, const std::string& msg) { return fail(h, code, msg); }
 int lii_internal_scan_materialize(lii_context* h) { return scan_materialize(h); }
 int lii_internal_scan_is_deferred(lii_context* h) { return h && h->scan_pending ? 1 : 0; }
+int lii_internal_in_wait_hook(lii_context* h) { return h && h->in_wait_hook ? 1 : 0; }
 void lii_internal_prearm_cancel(lii_context* h) { prearm_cancel(h); }
 // lii_frame_select's hand-over (lii_ingest.hip): the frame becomes the current scan WITHOUT being copied - round 6: the copy + time
 // extent launch of lii_scan_set_device was 5 - 8 us per sub-frame in front of a registration that reads the frame in place anyway

@@ -275,7 +275,9 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
   if (h->wait_hook) {
     void (*hook)(void*) = h->wait_hook;
     h->wait_hook = nullptr;
+    h->in_wait_hook = true;
     hook(h->wait_hook_arg);
+    h->in_wait_hook = false;
   }
   rc = wait_result(true);
   if (rc != LII_OK) return rc;

@@ -69,6 +69,7 @@ struct lii_context {
   unsigned int* d_ah_slot = nullptr;        // the slot of every batch point
   void (*wait_hook)(void*) = nullptr;       // lii_scan_job::while_waiting of the call under way (update_on_device calls it once, before its wait)
   void* wait_hook_arg = nullptr;
+  bool in_wait_hook = false;               // ... while it runs: entry points that change which frames are current refuse (lii_ingest_end, lii_frame_select)
   bool map_fuse = true;                     // round 6 (LII_MAP_FUSE=0 turns both off): the fold's hash insert rides in k_map_decide, the inserts' cells in the fold launch
   bool ah_filled = false;                   // k_map_decide has filled the fold's table and no fold has consumed it yet
   long long ah_cleared = 0;                 // ... times such a fill had to be cleared (a list that outgrew its bound)

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string>
 
@@ -37,7 +38,7 @@ struct IngestTable {  // written by k_cut_plan into mapped host memory
   int n_frames;
   int n_kept;        // pl_surf.size()
   int n_emitted;     // points inside frames
-  int pad;
+  int unsorted;      // 1: the kept points did NOT arrive in ascending time order (k_cut_apply)
   int first[kMaxFrames];   // sorted index of the first point of frame c
   int last[kMaxFrames];    // sorted index of the boundary point of frame c
   double begin_ms[kMaxFrames];
@@ -60,6 +61,10 @@ struct IngestCtx {
   IngestTable* h_table = nullptr;  // pinned + mapped
   IngestTable table;               // host copy of the last message
   bool have = false;
+  bool cut_msg = false;            // the message in this context went through the time sort + cut (cut_frame_num != 0)
+  bool sort_skipped = false;       // the message in this context was enqueued without its time sort (IngestRing::predict_sorted)
+  int n_tail = 0, required_tail = 0;  // what ingest_redo_sorted needs of the message: its raw point count, the cut it asked for
+  double stamp_ms_tail = 0;
   int n_under_way = 0;              // points of the message an overlapped call put under way in this context
 };
 
@@ -237,7 +242,7 @@ __global__ void k_cut_plan(const float4* __restrict__ pts, const unsigned int* _
   t.n_kept = (int)size;
   t.n_frames = 0;
   t.n_emitted = 0;
-  t.pad = 0;
+  t.unsorted = 0;
   double lfe = stamp_ms;
   unsigned int cut_num = 0;
   int start = 1;
@@ -262,9 +267,18 @@ __global__ void k_cut_plan(const float4* __restrict__ pts, const unsigned int* _
   *host = t;
 }
 // frame point (sorted position s in [1, n_emitted]) -> frames[s - 1] with curvature += stamp_ms - last_frame_end_time
+// ... and the launch looks at the kept points' time keys in INPUT order (key_in; position s against s - 1): a message that arrives in
+// ascending time order - drivers that publish in firing order do - needs no sort at all, and the next message of the stream is then
+// enqueued without one (IngestRing::predict_sorted).  `unsorted` (device table and its host mirror) is raised by any lane that sees a
+// descent; a message that was enqueued without the sort and raises it is done again with the sort (ingest_redo_sorted).
 __global__ void k_cut_apply(const float4* __restrict__ pts, const unsigned int* __restrict__ sorted_idx,
-                            const IngestTable* __restrict__ tab, int n, float4* __restrict__ frames) {
+                            IngestTable* __restrict__ tab, int n, float4* __restrict__ frames, const unsigned int* __restrict__ key_in,
+                            IngestTable* __restrict__ host_tab) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  if (s < tab->n_kept && s < n && key_in[s] < key_in[s - 1]) {
+    tab->unsorted = 1;
+    host_tab->unsorted = 1;
+  }
   if (s > tab->n_emitted || s >= n + 1) return;
   int c = 0;
   while (c + 1 < tab->n_frames && s > tab->last[c]) c++;
@@ -285,7 +299,7 @@ __global__ void k_whole_apply(const float4* __restrict__ pts, const unsigned int
     t.n_kept = (int)kept;
     t.n_frames = kept > 0u ? 1 : 0;  // (an empty cloud is skipped by the node: laserMapping.cpp:909-914)
     t.n_emitted = (int)kept;
-    t.pad = 0;
+    t.unsorted = 0;
     t.first[0] = 1;
     t.last[0] = (int)kept;
     t.begin_ms[0] = stamp_ms;
@@ -321,10 +335,19 @@ struct IngestRing {
   hipEvent_t ev_copied[kSlots] = {nullptr, nullptr, nullptr}, ev_done[kSlots] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_read = nullptr;  // the handle's stream has copied a selected frame out of a context that is about to be reused
   int guard_slot = -1;
+  // The launch plan of the time sort (its eleven launches are two thirds of a message's kernel time): the last cut message's kept points
+  // arrived in ascending time order -> the next one is enqueued WITHOUT the sort, the device checks the order, a message that fails the
+  // check is done again with the sort before its frames are handed out.  LII_INGEST_SORT=always: never predicted.
+  bool predict_sorted = false;
+  bool never_predict = false;
+  long long n_unsorted_skipped = 0, n_redone = 0;
 };
 
 void ingest_free(IngestRing* r) {
   if (!r) return;
+  if (getenv("LII_DIAG") && (r->n_unsorted_skipped || r->n_redone))
+    fprintf(stderr, "[libliinit_hip] ingest: messages cut without their time sort (they arrived in time order): %lld, done again with it: %lld\n",
+            r->n_unsorted_skipped, r->n_redone);
   if (r->s_copy) { (void)hipStreamSynchronize(r->s_copy); (void)hipStreamDestroy(r->s_copy); }
   if (r->s_kern) { (void)hipStreamSynchronize(r->s_kern); (void)hipStreamDestroy(r->s_kern); }
   for (int k = 0; k < IngestRing::kSlots; k++) {
@@ -380,7 +403,12 @@ int ingest_reserve(lii_handle h, IngestCtx* c, int n, size_t raw_bytes) {
 
 IngestRing* ring_of(lii_handle h) {
   void** slot = lii_internal_ingest_slot(h);
-  if (!*slot) *slot = new IngestRing();
+  if (!*slot) {
+    IngestRing* r = new IngestRing();
+    const char* e = getenv("LII_INGEST_SORT");
+    r->never_predict = e && e[0] == 'a';
+    *slot = r;
+  }
   return static_cast<IngestRing*>(*slot);
 }
 
@@ -413,21 +441,50 @@ int ingest_tail(lii_handle h, IngestCtx* c, int n, const lii_ingest_opts* o, int
   inclusive_scan_u32(c->d_temp, c->temp_bytes, c->d_flag, c->d_rank, n, s);
   hipLaunchKernelGGL(k_ingest_compact, dim3(nb), dim3(256), 0, s, c->d_pts, c->d_flag, c->d_rank, n, c->d_key_a, c->d_idx_a);
   IngestTable* d_table = reinterpret_cast<IngestTable*>(c->d_aux);  // d_aux is free again after the Livox scan
+  c->sort_skipped = false;
+  c->cut_msg = o->cut_frame_num != 0;
   if (o->cut_frame_num == 0) {  // Preprocess::process: no sort, no cut
     hipLaunchKernelGGL(k_whole_apply, dim3(nb), dim3(256), 0, s, c->d_pts, c->d_idx_a, c->d_rank, n, o->stamp_s * 1000, c->d_frames, d_table, c->h_table);
   } else {
-    sort_pairs_u32(c->d_temp, c->temp_bytes, c->d_key_a, c->d_key_b, c->d_idx_a, c->d_idx_b, n, s);
+    IngestRing* r = ring_of(h);
+    c->sort_skipped = r->predict_sorted && !r->never_predict;
+    if (!c->sort_skipped) sort_pairs_u32(c->d_temp, c->temp_bytes, c->d_key_a, c->d_key_b, c->d_idx_a, c->d_idx_b, n, s);
+    const unsigned int* order = c->sort_skipped ? c->d_idx_a : c->d_idx_b;  // (a stable sort of keys in ascending order is the identity)
     int required = o->cut_frame_num;
     if (o->scan_count < uncut_below) required = 1;
-    hipLaunchKernelGGL(k_cut_plan, dim3(1), dim3(64), 0, s, c->d_pts, c->d_idx_b, c->d_rank, n, o->stamp_s * 1000, required, d_table,
-                       c->h_table);
-    hipLaunchKernelGGL(k_cut_apply, dim3(nb), dim3(256), 0, s, c->d_pts, c->d_idx_b, d_table, n, c->d_frames);
+    c->n_tail = n; c->required_tail = required; c->stamp_ms_tail = o->stamp_s * 1000;
+    hipLaunchKernelGGL(k_cut_plan, dim3(1), dim3(64), 0, s, c->d_pts, order, c->d_rank, n, c->stamp_ms_tail, required, d_table, c->h_table);
+    hipLaunchKernelGGL(k_cut_apply, dim3(nb), dim3(256), 0, s, c->d_pts, order, d_table, n, c->d_frames, c->d_key_a, c->h_table);
   }
   ICHK(h, hipGetLastError());
   return LII_OK;
 }
+// A message that was enqueued without its time sort and turned out not to be in time order: sort, plan and apply again (on `s`, waited for).
+int ingest_redo_sorted(lii_handle h, IngestCtx* c, hipStream_t s) {
+  const int n = c->n_tail, nb = (n + 255) / 256;
+  IngestTable* d_table = reinterpret_cast<IngestTable*>(c->d_aux);
+  sort_pairs_u32(c->d_temp, c->temp_bytes, c->d_key_a, c->d_key_b, c->d_idx_a, c->d_idx_b, n, s);
+  hipLaunchKernelGGL(k_cut_plan, dim3(1), dim3(64), 0, s, c->d_pts, c->d_idx_b, c->d_rank, n, c->stamp_ms_tail, c->required_tail, d_table, c->h_table);
+  hipLaunchKernelGGL(k_cut_apply, dim3(nb), dim3(256), 0, s, c->d_pts, c->d_idx_b, d_table, n, c->d_frames, c->d_key_a, c->h_table);
+  ICHK(h, hipGetLastError());
+  ICHK(h, hipStreamSynchronize(s));
+  c->sort_skipped = false;
+  return LII_OK;
+}
 // ... and, once whatever stream ran it is known to be through: the frame table out
-int ingest_collect(lii_handle h, IngestCtx* c, lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
+int ingest_collect(lii_handle h, IngestCtx* c, lii_frame_info* frames, int32_t max_frames, int32_t* n_frames, hipStream_t s) {
+  if (c->cut_msg) {
+    IngestRing* r = ring_of(h);
+    const bool unsorted = c->h_table->unsorted != 0;
+    if (unsorted && c->sort_skipped) {  // the prediction was wrong for this message: its frames are cut again, behind the sort
+      r->n_redone++;
+      const int rc = ingest_redo_sorted(h, c, s);
+      if (rc != LII_OK) return rc;
+    } else if (c->sort_skipped) {
+      r->n_unsorted_skipped++;
+    }
+    r->predict_sorted = !unsorted;
+  }
   c->table = *c->h_table;
   c->have = true;
   *n_frames = c->table.n_frames;
@@ -554,6 +611,7 @@ extern "C" {
 
 int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_pc2_fields* f, const lii_ingest_opts* o,
                     lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
+  if (lii_internal_in_wait_hook(h)) return lii_internal_fail(h, LII_ERR_STATE, "lii_ingest_pcl2: not from lii_scan_job::while_waiting (lii_ingest_pcl2_begin is)");
   lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!frames || !n_frames) return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_pcl2: bad arguments");
   lii_ingest_opts whole_opts;
@@ -569,11 +627,12 @@ int lii_ingest_pcl2(lii_handle h, const void* data, int32_t n_points, const lii_
   rc = pcl2_enqueue(h, c, data, n_points, f, o, s, s, nullptr);
   if (rc != LII_OK) return rc;
   ICHK(h, hipStreamSynchronize(s));
-  return ingest_collect(h, c, frames, max_frames, n_frames);
+  return ingest_collect(h, c, frames, max_frames, n_frames, s);
 }
 
 int lii_ingest_livox(lii_handle h, const void* points, int32_t n_points, const lii_livox_fields* f, const lii_ingest_opts* o,
                      lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
+  if (lii_internal_in_wait_hook(h)) return lii_internal_fail(h, LII_ERR_STATE, "lii_ingest_livox: not from lii_scan_job::while_waiting (lii_ingest_livox_begin is)");
   lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!frames || !n_frames) return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_livox: bad arguments");
   int rc = livox_check(h, points, n_points, f, o);
@@ -588,7 +647,7 @@ int lii_ingest_livox(lii_handle h, const void* points, int32_t n_points, const l
   rc = livox_enqueue(h, c, points, n_points, f, o, s, s, nullptr);
   if (rc != LII_OK) return rc;
   ICHK(h, hipStreamSynchronize(s));
-  return ingest_collect(h, c, frames, max_frames, n_frames);
+  return ingest_collect(h, c, frames, max_frames, n_frames, s);
 }
 
 // The overlapped forms (ABI 9).  Neither uses the handle's stream: a registration under way - or a pre-armed launch - is not disturbed.
@@ -631,6 +690,8 @@ int lii_ingest_livox_begin(lii_handle h, const void* points, int32_t n_points, c
 }
 int lii_ingest_end(lii_handle h, lii_frame_info* frames, int32_t max_frames, int32_t* n_frames) {
   if (!h || !frames || !n_frames) return lii_internal_fail(h, LII_ERR_INVALID, "lii_ingest_end: bad arguments");
+  // (inside lii_scan_job::while_waiting the registration under way may still be reading the frames this call would retire)
+  if (lii_internal_in_wait_hook(h)) return lii_internal_fail(h, LII_ERR_STATE, "lii_ingest_end: not from lii_scan_job::while_waiting (only the begin functions are)");
   IngestRing* r = ring_of(h);
   if (r->n_pending < 1) return lii_internal_fail(h, LII_ERR_STATE, "lii_ingest_end: no message under way (call lii_ingest_pcl2_begin / lii_ingest_livox_begin)");
   // A selected frame of the outgoing message that nobody has read is copied into the handle's own scan buffer first - by the handle's
@@ -657,10 +718,11 @@ int lii_ingest_end(lii_handle h, lii_frame_info* frames, int32_t max_frames, int
   r->slot[r->front].have = false;
   r->front = k;
   if (c->n_under_way <= 0) return LII_OK;  // (an empty message: no frame, as in the one-call forms)
-  return ingest_collect(h, c, frames, max_frames, n_frames);
+  return ingest_collect(h, c, frames, max_frames, n_frames, r->s_kern);
 }
 
 int lii_frame_select(lii_handle h, int32_t frame) {
+  if (lii_internal_in_wait_hook(h)) return lii_internal_fail(h, LII_ERR_STATE, "lii_frame_select: not from lii_scan_job::while_waiting");
   lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h) return LII_ERR_INVALID;
   IngestRing* r = ring_of(h);

@@ -12,6 +12,7 @@ struct lii_context;
 int lii_internal_fail(lii_context* h, int code, const std::string& msg);
 int lii_internal_scan_defer(lii_context* h, const void* dev_float4, int32_t n);  // (lii_capi.cpp) lii_frame_select's hand-over
 int lii_internal_scan_materialize(lii_context* h);
+int lii_internal_in_wait_hook(lii_context* h);       // (lii_capi.cpp) 1: inside lii_scan_job::while_waiting of a registration under way
 int lii_internal_scan_is_deferred(lii_context* h);  // (lii_capi.cpp) 1: a selected frame that nobody has read yet
 void lii_internal_prearm_cancel(lii_context* h);  // (lii_capi.cpp) see lii_impl::prearm_cancel  // (lii_capi.cpp) a selected frame nobody has read yet -> the handle's own scan buffer
 hipStream_t lii_internal_stream(lii_context* h);

@@ -185,7 +185,7 @@ def test_the_next_message_is_begun_from_inside_the_registration(oracle):
             msgs.append((wire.pack_pcl2(wire.VELO, xyz, ring, t_ms, 10.0 + 0.1 * k), len(xyz), wire.pc2_fields(wire.VELO), wire.VELO,
                          16, 1, 0.5, 10.0 + 0.1 * k, 2, 100))
             truth.append(make_state(oracle, R, p))
-        calls = []
+        calls, refused = [], []
 
         def run(hooked):
             out = []
@@ -202,6 +202,13 @@ def test_the_next_message_is_begun_from_inside_the_registration(oracle):
                     if hooked and f == len(info) - 1 and k + 2 < len(msgs):
                         def hook(k=k):
                             calls.append(k)
+                            if k == 0:  # what would retire or replace the frames the registration under way reads is refused inside the hook
+                                for bad in (r.ingest_end, lambda: r.frame_select(0), lambda: r.ingest_pcl2(*msgs[0])):
+                                    try:
+                                        bad()
+                                        refused.append(False)
+                                    except lii.LIIError as e:
+                                        refused.append(e.code == -5)
                             r.ingest_pcl2_begin(*msgs[k + 2])
                     rep = r.scan_register(s, s0, leaf=0.1, max_iterations=5, imu_en=False, scan_sorted=True, map_update=True, while_waiting=hook)
                     out.append((info[f], np.array(s.pod).copy(), rep["iterations"], rep["effect_num"]))
@@ -212,9 +219,60 @@ def test_the_next_message_is_begun_from_inside_the_registration(oracle):
         r.map_build(map_pts)
         b = run(True)
         assert calls == [0, 1, 2]  # once per registration that carried a hook
+        assert refused == [True, True, True]
         assert len(a) == len(b) == 10 and r.map_size() == n_a
         for (ia, sa, ita, ea), (ib, sb, itb, eb) in zip(a, b):
             assert ia == ib and ita == itb and ea == eb and ea > 2000
             assert np.array_equal(sa, sb)
     finally:
         r.close()
+
+
+def test_the_time_sort_is_left_out_for_streams_in_time_order(oracle, monkeypatch):
+    """The launch plan of the ingest's time sort: after a message whose kept points arrived in ascending time order the next one is enqueued
+    without the sort (the device checks the order; a message that fails the check is cut again behind the sort).  Frames are the oracle's
+    bits whatever the sequence of ordered and unordered messages, through the one-call and the overlapped forms."""
+    import lidar_imu_init_amd as lii
+    hall = synth.Hall()
+    xyz, ring, t_ms = wire.raw_sweep(hall, "os1_128", synth.rot_zyx(0.01, 0.02, 0.4), np.array([0.5, -1.0, 0.2]))
+    order = np.argsort(t_ms, kind="stable")
+    rng = np.random.default_rng(3)
+    shuffled = rng.permutation(len(xyz))
+    f = wire.pc2_fields(wire.OUSTER)
+    n_scans = synth.SENSORS["os1_128"][0] - 2
+
+    def msg(perm, k, cut):
+        stamp = 500.0 + 0.1 * k
+        raw = wire.pack_pcl2(wire.OUSTER, xyz[perm], ring[perm], t_ms[perm], stamp)
+        return (raw, len(xyz), f, wire.OUSTER, n_scans, 1, 1.0, stamp, cut, 100 + k)
+
+    seq = [msg(order, 0, 3), msg(order, 1, 3), msg(order, 2, 1), msg(shuffled, 3, 3), msg(shuffled, 4, 2), msg(order, 5, 3), msg(order, 6, 4),
+           msg(shuffled, 7, 3), msg(order, 8, 3)]
+    want = [oracle.ingest_pcl2(*m) for m in seq]
+
+    def check(got, orc):
+        assert len(got) == len(orc)
+        for (tb_g, _, pg), (tb_o, po) in zip(got, orc):
+            assert tb_g == tb_o / 1000.0 and pg.shape == po.shape
+            assert np.array_equal(pg.view(np.uint32), po.view(np.uint32))
+
+    r = lii.Registrar(max_scan_points=140_000, max_map_points=1000, filter_size_map=0.2)
+    try:
+        for m, w in zip(seq, want):  # one-call form
+            check(frames_of(r, r.ingest_pcl2(*m)), w)
+        r.ingest_pcl2_begin(*seq[0])  # overlapped: the prediction made for a message is one or two messages old
+        r.ingest_pcl2_begin(*seq[1])
+        for k in range(len(seq)):
+            info = r.ingest_end()
+            if k + 2 < len(seq):
+                r.ingest_pcl2_begin(*seq[k + 2])
+            check(frames_of(r, info), want[k])
+    finally:
+        r.close()
+    monkeypatch.setenv("LII_INGEST_SORT", "always")  # (read when a handle's ingest state is created)
+    r2 = lii.Registrar(max_scan_points=140_000, max_map_points=1000, filter_size_map=0.2)
+    try:
+        for m, w in zip(seq[:4], want[:4]):
+            check(frames_of(r2, r2.ingest_pcl2(*m)), w)
+    finally:
+        r2.close()
