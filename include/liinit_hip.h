@@ -264,7 +264,10 @@ int lii_last_solve_info(lii_handle h, int32_t* pivoted_passes);
 /* How many queries the most recent search pass could not finish inside its own launch - their 5th neighbour lies beyond what the
  * 3 x 3 x 3 cells around the query can prove: the reference's tree walks on into farther boxes for them (include/ikd-Tree/
  * ikd_Tree.cpp:827-842) - and left to the fit launch behind it (ABI 8).  Up to 256 per launch are finished by completion workgroups of
- * their own; beyond that every workgroup finishes its own points'.  A diagnostic (one small device read); synchronises the handle's stream. */
+ * their own; beyond that a launch of its own finishes the listed ones (up to 4096, one wavefront each) when the scan before was in that
+ * regime too, and every workgroup finishes its own points' otherwise.  ABI 9: behind lii_iekf_update / lii_scan_register on one rank the value
+ * is the LARGEST count among the update's search passes and comes with the result (no device read); otherwise the most recent search
+ * launch's (one small device read, synchronises the handle's stream). */
 int lii_last_unfinished_queries(lii_handle h, int32_t* n_last);
 
 /* The per-scan sequence of main() (src/laserMapping.cpp:909-1134) in ONE call, enqueued back to back on the handle's

@@ -316,6 +316,7 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
     if (qs != std::string::npos) h->solo_share = int(std::strtol(t.c_str() + qs + 11, nullptr, 0));
   }
   if (const char* mf = std::getenv("LII_MAP_FUSE")) h->map_fuse = mf[0] != '0';
+  if (const char* wc = std::getenv("LII_WIDE_COMPLETION")) h->wide_enabled = wc[0] != '0';
   h->ds = h->cfg.map_downsample_size;
   h->device = cfg->device;
 #define CK(call)                                                                  \
@@ -432,8 +433,8 @@ int lii_create(const lii_config* cfg, lii_handle* out) {
   CK(hipEventCreateWithFlags(&h->ev_lists, hipEventDisableTiming));
   CK(hipMemset(h->d_counter, 0, 16));
   h->partial_stride = register_blocks(int(N)) + std::max(lii::kCompletionBlocks, lii::kCompletionBlocksPre) + 8;  // (+ the columns of the fit launches' completion workgroups)
-  CK(dmalloc(&h->d_flags, 4 + 16 * lii::kFlagCap));  // 2 counters (+ 2 pad), 2 x kFlagCap entries of two float4
-  CK(hipMemset(h->d_flags, 0, sizeof(int) * (4 + 16 * lii::kFlagCap)));
+  CK(dmalloc(&h->d_flags, 4 + 16 * lii::kListCap));  // 2 counters (+ 2 pad), 2 x kListCap entries of two float4
+  CK(hipMemset(h->d_flags, 0, sizeof(int) * (4 + 16 * lii::kListCap)));
   CK(dmalloc(&h->d_partials, size_t(h->partial_stride) * kNormalEq));
   CK(dmalloc(&h->d_out91, 256));  // [0,91): local sums, [128,219): all-reduced sums (sharded scans)
   CK(dmalloc(&h->d_gran, 256));
@@ -523,6 +524,7 @@ int lii_destroy(lii_handle h) {
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] map updates completed by a rebuild + re-insertion: %lld\n", h->map_recoveries);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] updates continued by the host after a parked loop: %lld\n", h->plan_parked);
   if (h->diag) std::fprintf(stderr, "[libliinit_hip] map updates repeated with exact list sizes: %lld\n", h->map_repeats);
+  if (h->diag) std::fprintf(stderr, "[libliinit_hip] scans whose search passes left more than %d unfinished queries: %lld (the completion launch was switched on / off %lld times); fold tables cleared: %lld\n", lii::kFlagCap, h->wide_scans, h->wide_switches, h->ah_cleared);
   if (h->diag && h->prof.host_us[4] > 0)
     std::fprintf(stderr, "[libliinit_hip] host side of lii_scan_register, us per call over %.0f calls: first launch submitted %.1f, pre-processing enqueued %.1f, "
                  "loop enqueue %.1f, call %.1f, between calls %.1f\n", h->prof.host_us[4], h->prof.host_us[0] / h->prof.host_us[4], h->prof.host_us[1] / h->prof.host_us[4],

@@ -37,6 +37,7 @@ int iterate(lii_handle h, const lii_state* st, bool search, bool imu_en, double*
     *stage = pose_of(*st);
     HIPCHK(h, hipMemcpyAsync(h->d_pose, stage, sizeof(PoseArg), hipMemcpyHostToDevice, h->stream));
   }
+  if (search) h->unfinished_known = false;  // (a search pass of this host-driven call: lii_last_unfinished_queries reads the device again)
   const int epoch = search ? next_knn_epoch(h, true) : 0;
   if (search) launch_knn(h, g, rb, h->d_pose, 1, epoch);
   if (prof) HIPCHK(h, hipEventRecord(h->prof.ev[3], h->stream));
@@ -147,6 +148,9 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
       if (prof && it < 16 && !in_dispatch) HIPCHK(h, hipEventRecord(h->prof.ev_it[2 * it + 1], s));
     }
     if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_FIT, it); if (r != LII_OK) return r; }
+    // the scan before left more unfinished queries per search pass than the fit launch's completion workgroups take: this one's
+    // are finished by a launch of their own, one wavefront per listed query (k_complete_listed; nothing to do -> it returns at once)
+    if (knn && h->wide_listed && !graph_mode && !h->net.comm && h->net.n_ranks <= 1) launch_complete_listed(g, rb, h->d_ctrl, -1, s, epoch);
     launch_fit_reduce(g, rb, pose, h->d_ctrl, -1, opts->imu_en ? 1 : 0, h->cfg.plane_threshold, h->cfg.laser_point_cov_inv, s, epoch);
     if (h->prof.kp_active) { const int r = kp_mark(h, LII_KP_SOLVE, it); if (r != LII_OK) return r; }
     if (!h->net.comm) {  // single GPU or node-local mailbox: final sum (+ exchange) and solve in one launch
@@ -309,6 +313,15 @@ int update_on_device(lii_handle h, lii_state* state, const lii_state* state_prop
     rc = wait_result(true);
     if (rc != LII_OK) return rc;
   }
+  h->unfinished_known = !h->net.comm;
+  if (!h->net.comm && h->wide_enabled) {  // (the launch plan of the completions, see enqueue_pass)
+    // (two scans in a row decide: a stream on which one scan in eight crosses the capacity - bench --edge - would pay for a launch that
+    // finds nothing behind every such scan and never have it where it is needed)
+    const bool wide = h->h_res->unfinished > lii::kFlagCap;
+    if (wide == h->wide_prev && wide != h->wide_listed) { h->wide_listed = wide; h->wide_switches++; }
+    h->wide_prev = wide;
+    if (wide) h->wide_scans++;
+  }
   h->staging_busy = false;  // the wait above covers everything enqueued before the stopping pass
   h->scan_buf_idle = true;  // ... every launch that read or wrote the current scan buffer among it (what was enqueued behind - drained passes, the map update, a pre-armed launch on the OTHER buffer - does not touch it)
   const IekfResult* hr = h->h_res;
@@ -407,6 +420,7 @@ int lii_last_solve_info(lii_handle h, int32_t* pivoted_passes) {
 int lii_last_unfinished_queries(lii_handle h, int32_t* n_last) {
   lii_internal_prearm_cancel(h);  // (a pre-armed de-skew launch waiting on the stream is told to end: this entry point uses the stream)
   if (!h || !n_last) return LII_ERR_INVALID;
+  if (h->unfinished_known) { *n_last = h->h_res->unfinished; return LII_OK; }  // (came with the last update's result: the largest count among its search passes)
   int c[2] = {0, 0};
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(c, h->d_flags, sizeof(c), hipMemcpyDeviceToHost));  // RegistrationBuffers::flag_count, one word per slot

@@ -67,6 +67,11 @@ struct lii_context {
   unsigned long long* d_ah_key = nullptr;   // hash-grouped fold of lii_map_incremental (lii_map.hip: AddHash): voxel keys,
   unsigned long long* d_ah_best = nullptr;  // per-slot minima (both all ones between updates),
   unsigned int* d_ah_slot = nullptr;        // the slot of every batch point
+  bool wide_listed = false;                 // the last scan's search passes listed more than kFlagCap unfinished queries: the next one's search launches are followed by k_complete_listed
+  bool wide_prev = false;                   // ... the scan before it did (two in a row switch wide_listed)
+  bool unfinished_known = false;            // IekfResult::unfinished belongs to the last search the handle ran (lii_last_unfinished_queries)
+  bool wide_enabled = true;                 // LII_WIDE_COMPLETION=0: never (every workgroup of the fit launch finishes its own, rounds 4 - 6)
+  long long wide_scans = 0, wide_switches = 0;
   void (*wait_hook)(void*) = nullptr;       // lii_scan_job::while_waiting of the call under way (update_on_device calls it once, before its wait)
   void* wait_hook_arg = nullptr;
   bool in_wait_hook = false;               // ... while it runs: entry points that change which frames are current refuse (lii_ingest_end, lii_frame_select)
@@ -131,7 +136,7 @@ struct lii_context {
   bool host_solve = false;      // LII_TEST=host_solve: drive the loop from the host (A/B, reference arrangement)
   double* d_partials = nullptr;
   double* d_out91 = nullptr;
-  unsigned long long* d_gran = nullptr;  // k_reduce_solve: the 91 sums of a pass on their way to the solver, 2 x 91 tagged words
+  unsigned long long* d_gran = nullptr;  // k_reduce_solve: the 91 sums of a pass on their way to the solver, 2 x 91 tagged words; [200 ..]: the gap trace's stamps; [240]: the scan's largest count of unfinished queries so far
   unsigned long long* d_extent = nullptr;  // 2 x {min (time|index), max time}: ping-pong accumulators
   unsigned int* d_mm = nullptr;           // 2 x {min xyz, max xyz} (order-preserving uints)
   int extent_sel = 0, mm_sel = 0;

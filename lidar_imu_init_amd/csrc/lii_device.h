@@ -186,12 +186,15 @@ struct RegistrationBuffers {
   int shard_rank;     // points of one scan sharded across ranks: this rank registers the contiguous
   int shard_world;    // block [n * rank / world, n * (rank + 1) / world) of the down-sampled cloud; world <= 1: all of it
   // The queries a search pass could not finish (kNeedy), listed by that pass for the completion workgroups of the fit launch behind
-  // it (k_fit_reduce): flag_count[e & 1] entries in flag_list[(e & 1) * kFlagCap ...], e = the search launch's number (`epoch`).
+  // it (k_fit_reduce): flag_count[e & 1] entries in flag_list[(e & 1) * kListCap ...], e = the search launch's number (`epoch`); the first
+  // kListCap are stored.
   // An entry is everything the completion needs to start with: (world point, query index) and (neighbour count with its flags, -, -, -).
   int* flag_count;
-  float4* flag_list;  // 2 x kFlagCap entries of two float4
+  float4* flag_list;  // 2 x kListCap entries of two float4
 };
-constexpr int kFlagCap = 256;          // listed queries a fit launch hands to its completion workgroups (more: every workgroup finishes its own, as in round 4)
+constexpr int kFlagCap = 256;          // listed queries a fit launch hands to its completion workgroups (more: every workgroup finishes its own, as in round 4 ...
+constexpr int kListCap = 4096;         // ... unless a launch of its own in front of the fit launch has finished the listed ones, one wavefront per query:
+                                       // k_complete_listed, enqueued when the scan before listed more than kFlagCap - the launch plan's way)
 #ifndef LII_COMPLETION_BLOCKS
 #define LII_COMPLETION_BLOCKS 32
 #endif
@@ -463,7 +466,7 @@ struct IekfResult {
   int part_overflow;  // set by the voxel filter of a voxel-partitioned job (k_vhash_emit): this rank's share outgrew its bound
   int search_log[16];
   int parked_search;  // ... and that iteration searches (1) or not (0): the host puts a k-NN launch in front of it only then
-  int pad2;
+  int unfinished;     // queries the scan's search passes left unfinished (max over its two most recent search launches; k_reduce_solve)
   long long ts[16];  // LII_SOLVE_TRACE builds: wall_clock64 stamps of the solve phases (stopping iteration)
   long long ts0[16]; // ... of iteration 0
 };

@@ -511,7 +511,7 @@ __device__ __forceinline__ int warm_code() {
 __device__ __forceinline__ unsigned int pass_tag(int seq, int it) { return ((unsigned int)seq << 6) ^ (unsigned int)(it + 1); }
 __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __restrict__ partials, int n_blocks, int stride,
                                                                  unsigned long long* __restrict__ gran, IekfCtrl* c, IekfResult* res,
-                                                                 MailboxView mb) {
+                                                                 MailboxView mb, const int* __restrict__ flag_count) {
   __shared__ double s_w[kSolveThreads / 64];
   const int stop = c->stop, seq = c->seq, it = c->it;  // (one request: the three words share a line)
   const int t = blockIdx.x;
@@ -529,6 +529,18 @@ __global__ __launch_bounds__(kSolveThreads) void k_reduce_solve(const double* __
     return;
   }
   if (stop) return;  // (the solver; it may set the flag itself, after every workgroup above has read it and published)
+  // How many queries the scan's search passes left unfinished (the two most recent search launches' counts) rides to the host beside the
+  // result: the next scan's launch plan puts k_complete_listed behind its search launches when it was more than the fit launch's
+  // completion workgroups take.  (a lane that has nothing to do with the sums; its store is waited for in publish_done like every other)
+  // (every enqueued search launch empties the OTHER slot: behind pass `it` the two slots hold this pass's count and 0, or - a pass
+  // without a search launch - what an earlier pass left; the maximum over the scan's passes is kept in gran[240])
+  if (threadIdx.x == kSolveThreads - 1 && flag_count) {
+    const int now = max(flag_count[0], flag_count[1]);
+    const int before = it == 0 ? 0 : (int)gran[240];
+    const int um = max(now, before);
+    gran[240] = (unsigned long long)um;
+    res_store(&res->unfinished, um);
+  }
   const unsigned int tag = pass_tag(seq, it);
   const int warm = warm_code();
   iekf_solve_body(c, res, [&](double* s_ne) {
@@ -604,7 +616,7 @@ void launch_reduce_solve(const RegistrationBuffers& rb, unsigned long long* gran
   int nb = (bound + kBlock - 1) / kBlock;
   if (nb < 1) nb = 1;
   nb += completion_blocks(epoch);  // (the columns of the fit launch's completion workgroups: as many as THAT launch had)
-  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq + 1), dim3(kSolveThreads), 0, s, rb.partials, nb, rb.partial_stride, gran, c, res, mb);
+  hipLaunchKernelGGL(k_reduce_solve, dim3(kNormalEq + 1), dim3(kSolveThreads), 0, s, rb.partials, nb, rb.partial_stride, gran, c, res, mb, rb.flag_count);
 }
 // A parked loop goes on with the launches the host has put behind this one (plan_mask, as IekfCtrl::plan_mask).
 __global__ void k_loop_resume(IekfCtrl* c, unsigned int plan_mask) {

@@ -966,8 +966,8 @@ __global__ __launch_bounds__(BS, WPE) void k_knn_ck(GridView g, RegistrationBuff
       rb.nbr_count[qi] = cflags;
       if (need && epoch > 0) {  // listed for the completion workgroups of the fit launch behind this one (~80 of 95 k queries)
         const int at = atomicAdd(&rb.flag_count[epoch & 1], 1);
-        if (at < kFlagCap) {
-          float4* e = rb.flag_list + 2 * ((epoch & 1) * kFlagCap + at);
+        if (at < kListCap) {
+          float4* e = rb.flag_list + 2 * ((epoch & 1) * kListCap + at);
           e[0] = make_float4(wx, wy, wz, __int_as_float(qi));
           e[1] = make_float4(__int_as_float(cflags), 0.f, 0.f, 0.f);
         }
@@ -1605,6 +1605,30 @@ __global__ __launch_bounds__(kBlock) void k_knn_complete(GridView g, Registratio
   complete_flagged(g, rb, lo + q, live, count, w, sh, s_far);
 }
 
+// A search pass that left MORE unfinished queries than the completion workgroups of the fit launch take (kFlagCap; a sensor that looks into
+// unmapped space: hundreds to thousands per pass) - round 6: the listed queries (up to kListCap, in the order the search pass listed them)
+// are finished HERE, one wavefront each, in a launch of its own between the search and the fit launch.  The fit launch then finds no
+// flagged point among its own (beyond kListCap: the few that are left) and runs as on any other scan - every point is fitted and summed
+// by its own lane, in the cloud's order: the same bits as with every workgroup finishing its own (31 - 33 us per fit launch there).
+// The host enqueues this launch only behind the search launches of a scan whose predecessor listed more than kFlagCap (IekfResult::unfinished);
+// it returns at once when the pass did not search or listed no more than kFlagCap (those are the completion workgroups').
+__global__ __launch_bounds__(kBlock) void k_complete_listed(GridView g, RegistrationBuffers rb, const IekfCtrl* __restrict__ ctrl, int forced, int epoch) {
+  __shared__ unsigned int s_far[(kBlock / 64) * kFarCap];
+  const int wave = threadIdx.x >> 6;
+  const int e = (int)blockIdx.x * (kBlock / 64) + wave;
+  const float4* ent = rb.flag_list + 2 * ((epoch & 1) * kListCap + e);
+  const float4 l0 = ent[0];  // (requested beside the flags; dropped when the entry is not there)
+  const int cflags = __float_as_int(ent[1].x);
+  const int n_listed = rb.flag_count[epoch & 1];
+  if (forced >= 0) {
+    if (!forced) return;
+  } else {
+    if (ctrl->stop || !ctrl->search_next) return;  // (as k_fit_reduce decides whether it stands behind an executed search pass)
+  }
+  if (n_listed <= kFlagCap || e >= min(n_listed, kListCap)) return;  // (uniform per wavefront)
+  complete_one(g, rb, __float_as_int(l0.w), cflags, l0.x, l0.y, l0.z, s_far + wave * kFarCap);
+}
+
 // POSE_V: the pose lives in vector registers (204 VGPRs: two wavefronts per SIMD - no matter while the launch has no more than two per
 // SIMD to offer, i.e. up to ~130 k points) instead of scalar ones (160 VGPRs: three per SIMD, but 56 of the pose's scalar registers
 // are spilled into vector-register lanes and fetched back one v_readlane at a time).  Measured: 100 k-point scan 5.9 against 6.5 us
@@ -1663,7 +1687,7 @@ __global__ __launch_bounds__(kBlock, POSE_V ? 2 : 3) void k_fit_reduce(GridView 
   }
   // (a completion workgroup: entry `lane` of the search pass's list - its length arrives with the scalars below, what lies behind the
   // end is read and dropped)
-  const float4* flag_list = rb.flag_list + 2 * (epoch & 1) * kFlagCap;
+  const float4* flag_list = rb.flag_list + 2 * (epoch & 1) * kListCap;
   // (unconditional - the other workgroups read the list's first line and drop it: behind a branch the compiler joins the two paths
   // with a register copy, and the wait for the entry would stand in front of the scalar requests)
   static_assert(kFlagCap <= kBlock, "one lane per listed query");
@@ -2062,6 +2086,10 @@ void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipSt
   int nb = nblk(shard_bound(rb), kBlock);
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(k_knn_complete, dim3(nb), dim3(kBlock), 0, s, g, rb);
+}
+void launch_complete_listed(const GridView& g, const RegistrationBuffers& rb, const IekfCtrl* ctrl, int forced, hipStream_t s, int epoch) {
+  if (epoch <= 0) return;
+  hipLaunchKernelGGL(k_complete_listed, dim3(kListCap / (kBlock / 64)), dim3(kBlock), 0, s, g, rb, ctrl, forced, epoch);
 }
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s, int epoch) {

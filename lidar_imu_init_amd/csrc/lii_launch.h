@@ -45,6 +45,7 @@ void launch_knn(const GridView& g, const RegistrationBuffers& rb, const PoseArg*
 void fb_trace_read(unsigned long long out[32]);  // (measurement builds: the completion's phase sums, lii_kernels.hip)
 #endif
 void launch_knn_complete(const GridView& g, const RegistrationBuffers& rb, hipStream_t s);
+void launch_complete_listed(const GridView& g, const RegistrationBuffers& rb, const IekfCtrl* ctrl, int forced, hipStream_t s, int epoch);  // (k_complete_listed: behind search launch `epoch`)
 void launch_fit_reduce(const GridView& g, const RegistrationBuffers& rb, const PoseArg* pose,
                        const IekfCtrl* ctrl, int forced, int imu_en, double plane_thr, double rinv, hipStream_t s, int epoch);
 void launch_reduce91(const RegistrationBuffers& rb, double* out91, const IekfCtrl* ctrl, int forced, hipStream_t s, int epoch);  // epoch: of the fit launch whose columns it sums
