@@ -333,8 +333,8 @@ struct IngestRing {
   int n_pending = 0;
   hipStream_t s_copy = nullptr, s_kern = nullptr;
   hipEvent_t ev_copied[kSlots] = {nullptr, nullptr, nullptr}, ev_done[kSlots] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_read = nullptr;  // the handle's stream has copied a selected frame out of a context that is about to be reused
-  int guard_slot = -1;
+  hipEvent_t ev_read = nullptr;  // recorded on the handle's stream when a message leaves `front`: whatever that stream still has to do with its frames lies in front of it
+  bool guard[kSlots] = {false, false, false};  // ... and the contexts whose next message waits for it
   // The launch plan of the time sort (its eleven launches are two thirds of a message's kernel time): the last cut message's kept points
   // arrived in ascending time order -> the next one is enqueued WITHOUT the sort, the device checks the order, a message that fails the
   // check is done again with the sort before its frames are handed out.  LII_INGEST_SORT=always: never predicted.
@@ -577,8 +577,8 @@ int livox_enqueue(lii_handle h, IngestCtx* c, const void* points, int32_t n_poin
   return ingest_tail(h, c, n_points, o, 5, s);
 }
 
-// A context for the next overlapped message: not `front`, not under way.  What the handle's stream may still be doing with it - the copy
-// of a selected frame that nobody had read when its message left `front` - comes first.
+// A context for the next overlapped message: not `front`, not under way.  What the handle's stream may still be doing with the frames of
+// the message that lay in it comes first (IngestRing::ev_read).
 int ring_take(lii_handle h, IngestRing* r, int* out) {
   int rc = ring_streams(h, r);
   if (rc != LII_OK) return rc;
@@ -590,9 +590,9 @@ int ring_take(lii_handle h, IngestRing* r, int* out) {
     for (int p = 0; p < r->n_pending; p++) used = used || r->pending[p] == q;
     if (!used) k = q;
   }
-  if (r->guard_slot == k) {
+  if (r->guard[k]) {  // (the event's latest record lies behind every earlier one on the same stream)
     ICHK(h, hipStreamWaitEvent(r->s_copy, r->ev_read, 0));
-    r->guard_slot = -1;
+    r->guard[k] = false;
   }
   *out = k;
   return LII_OK;
@@ -700,9 +700,11 @@ int lii_ingest_end(lii_handle h, lii_frame_info* frames, int32_t max_frames, int
     lii_internal_prearm_cancel(h);
     const int rcm = lii_internal_scan_materialize(h);
     if (rcm != LII_OK) return rcm;
-    ICHK(h, hipEventRecord(r->ev_read, lii_internal_stream(h)));
-    r->guard_slot = r->front;
   }
+  // ... and whatever else that stream has been given to do with the outgoing frames (an asynchronous reader that copied a selected frame
+  // on demand) is in front of this event, which the next message to take the context waits for - long complete in the per-scan loop
+  ICHK(h, hipEventRecord(r->ev_read, lii_internal_stream(h)));  // (a message is under way: the ring's streams and events exist)
+  r->guard[r->front] = true;
   const int k = r->pending[0];
   IngestCtx* c = &r->slot[k];
   *n_frames = 0;
