@@ -12,6 +12,8 @@
 //                      ikd_Tree.cpp:827-842), then esti_plane + residual / selection (src/laserMapping.cpp:987-1011), Jacobian rows
 //                      (:1035-1071) and the H^T R^-1 H / H^T R^-1 z sums (:1073-1080)
 //   k_knn_complete     the completion alone (lii_map_incremental of a sharded job)
+//   k_complete_listed  the completion of a search pass that listed more unfinished queries than the fit launch's completion workgroups
+//                      take (a sensor looking into unmapped space): one wavefront per listed query, in a launch of its own
 //   k_reduce91         deterministic final sum of the per-block partials (lii_iekf.hip fuses it with the solve)
 //   (de-skew and voxel grid: lii_scan.hip)
 //   k_calib_eval       include/LI_init/LI_init.h:91-205 residuals + analytic Jacobians

@@ -6,6 +6,8 @@
 //                         fall into the same voxel interact sequentially, different voxels are independent - eight lanes
 //                         fold one voxel group in the batch order (stable sort by voxel), querying the current map grid with
 //                         the reference's exact float box predicate (Search_by_range / Delete_by_range, :616-629, :970-985).
+//                         Round 6, lii_map_incremental on one rank: the hash insert of the hash-grouped fold rides in k_map_decide, the
+//                         inserts' cells (k_ins_cells) in the fold launch - k_add_fold8<true, true> - : four launches per update.
 //   k_ins_cells -> k_cell_apply -> k_ins_write   apply the tombstones and the inserts cell by cell: find / create the cell of
 //                         every insert, squeeze the touched cells (moving one to the tail of the array when its slack is used
 //                         up), claim a slot per insert.  Inserts that find no room wait in a list for the host's rebuild.
