@@ -276,3 +276,20 @@ def test_the_time_sort_is_left_out_for_streams_in_time_order(oracle, monkeypatch
             check(frames_of(r2, r2.ingest_pcl2(*m)), w)
     finally:
         r2.close()
+
+
+def test_a_handle_is_destroyed_with_messages_under_way():
+    """lii_destroy waits for the ingest's streams and frees the ring: no crash, no hang, and the next handle starts clean."""
+    import lidar_imu_init_amd as lii
+    msgs = messages()
+    r = lii.Registrar(max_scan_points=140_000, max_map_points=1000, filter_size_map=0.2)
+    r.ingest_pcl2_begin(*msgs[0])
+    r.ingest_pcl2_begin(*msgs[1])
+    r.close()
+    r = lii.Registrar(max_scan_points=140_000, max_map_points=1000, filter_size_map=0.2)
+    try:
+        want = frames_of(r, r.ingest_pcl2(*msgs[0]))
+        r.ingest_pcl2_begin(*msgs[0])
+        same(frames_of(r, r.ingest_end()), want)
+    finally:
+        r.close()
