@@ -764,6 +764,8 @@ def from_wire_record(args, wl, reg, drv, stream, n_stream, n_pipe):
                 "avg_iterations": float(tot[0]) / max(frames, 1)}
 
     n_m = max(4, n_pipe // cut)
+    if os.environ.get("LII_BENCH_WIRE_STEPS"):  # (soak: this many messages per form)
+        n_m = max(4, int(os.environ["LII_BENCH_WIRE_STEPS"]))
     run(min(n_m, 2 * n_msgs), True)  # (untimed: first-time allocations of the ingest)
     run(min(n_m, 2 * n_msgs), True, 1, ptrs_pinned)  # (... and of the overlapped form's ring)
     over_pageable = record(*run(n_m, True, 1, ptrs), n_m)
