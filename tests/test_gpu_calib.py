@@ -140,7 +140,11 @@ def test_conditioning_chain_on_the_device(reg):
     b = LI.CalibSeq(64)
     assert reg.xcorr_lag(a.to_records(), b.to_records()) == LI.xcorr_temporal_init(a, b, 50.0)[1]
     # the whole initialization with the device chain: bit-identical to the host chain
+    reg.li_init_set_device(False)
     res_h, lag_h, tot_h = reg.li_init_run(imu.to_records(), lid.to_records(), 10, 5)
+    t0 = time.perf_counter()
+    reg.li_init_run(imu.to_records(), lid.to_records(), 10, 5)
+    t_host = time.perf_counter() - t0
     reg.li_init_set_device(True)
     try:
         t0 = time.perf_counter()
@@ -153,4 +157,4 @@ def test_conditioning_chain_on_the_device(reg):
         assert np.array_equal(np.array(getattr(res_d, f)[:]), np.array(getattr(res_h, f)[:])), f
     assert res_d.time_lag_2 == res_h.time_lag_2
     print(f"device zero-phase filter of 2 x {batch.shape[1]} states: {t_dev * 1e3:.2f} ms; cross-correlation ({len(fi2)} samples): "
-          f"{t_x * 1e3:.2f} ms; lii_li_init_run with the device chain: {t_run * 1e3:.1f} ms")
+          f"{t_x * 1e3:.2f} ms; lii_li_init_run with the device chain: {t_run * 1e3:.1f} ms, with the host chain: {t_host * 1e3:.1f} ms")
